@@ -1,0 +1,352 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the reference itself (build container only).
+
+TEST INFRASTRUCTURE.  Imports the reference (``/root/reference``, a fairseq fork) with the inert
+third-party stand-ins of ``ref_stubs.py``, builds small reference models with seeded
+weights and dumps inputs, weights and outputs as ``tests/golden/*.npz``.  The reference never travels
+to the GPU box; these small ``.npz`` files (data only) do.
+
+Run (from a cwd OUTSIDE the repo so that no by-product can land in either tree):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference:/root/repo/oracle \
+        python /root/repo/oracle/gen_golden.py /root/repo/tests/golden
+
+Reference entry points exercised (file:line under /root/reference/fairseq):
+  models/speech_to_text/s2t_transformer.py:1714  S2TTransformerEncoder.forward
+  models/transformer.py:1249                     TransformerDecoder.extract_features_scriptable
+  criterions/label_smoothed_cross_entropy_with_ctc.py:74  joint CE + CTC loss
+  models/speech_to_text/s2t_ctc.py:236           CTCDecoder.generate (greedy)
+  modules/speech_to_text/subsampling.py:145      Conv1dSubsampling.forward
+  modules/positional_encoding.py:151             RelPositionalEncoding.forward
+  modules/sinusoidal_positional_embedding.py:60  SinusoidalPositionalEmbedding.forward
+"""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+
+import ref_stubs
+
+ref_stubs.install()
+
+import torch  # noqa: E402
+
+import fairseq  # noqa: E402,F401
+from fairseq.data import Dictionary  # noqa: E402
+from fairseq.models import ARCH_CONFIG_REGISTRY, ARCH_MODEL_REGISTRY  # noqa: E402
+
+torch.set_num_threads(8)
+torch.backends.mkldnn.enabled = True
+
+
+def make_dict(v):
+    d = Dictionary()  # <s>=0 (CTC blank) <pad>=1 </s>=2 <unk>=3
+    for i in range(v - 4):
+        d.add_symbol("w%d" % i)
+    assert len(d) == v
+    return d
+
+
+class FakeTask:
+    def __init__(self, d):
+        self.source_dictionary = d
+        self.target_dictionary = d
+        self.src_dict = d
+        self.tgt_dict = d
+
+    def get_source_dictionary(self, i):
+        return self.source_dictionary
+
+
+def base_args(arch, **kw):
+    a = Namespace(
+        arch=arch,
+        input_feat_per_channel=80,
+        input_channels=1,
+        max_source_positions=6000,
+        max_target_positions=1024,
+        ctc_weight=0.3,
+        layer_padding_mask=False,
+        fp16=False,
+        dropout=0.0,
+        attention_dropout=0.0,
+        activation_dropout=0.0,
+        share_decoder_input_output_embed=True,
+        share_ctc_and_embed=True,
+        encoder_embed_norm=True,
+        encoder_no_scale_embedding=True,
+        subsampling_type="conv1d",
+        subsampling_layers=2,
+        subsampling_kernel=5,
+        subsampling_stride=2,
+        subsampling_norm="none",
+        subsampling_activation="glu",
+        activation_fn="relu",
+    )
+    for k, v in kw.items():
+        setattr(a, k, v)
+    ARCH_CONFIG_REGISTRY[arch](a)
+    return a
+
+
+def make_batch(B, T, V, seed, umin=3, umax=9):
+    """collater-shaped batch: speech_to_text_dataset.py:411-485 (sorted desc, zero-padded,
+    prev_output_tokens = eos moved to the front)."""
+    g = torch.Generator().manual_seed(seed)
+    lens = [T] + [int(torch.randint(int(0.6 * T), T + 1, (1,), generator=g)) for _ in range(B - 1)]
+    lens = sorted(lens, reverse=True)
+    src = torch.randn(B, T, 80, generator=g)
+    for b, l in enumerate(lens):
+        src[b, l:] = 0
+    ulens = [int(torch.randint(umin, umax + 1, (1,), generator=g)) for _ in range(B)]
+    U = max(ulens) + 1
+    target = torch.full((B, U), 1, dtype=torch.long)
+    prev = torch.full((B, U), 1, dtype=torch.long)
+    for b, u in enumerate(ulens):
+        toks = torch.randint(4, V, (u,), generator=g)
+        target[b, :u] = toks
+        target[b, u] = 2
+        prev[b, 0] = 2
+        prev[b, 1 : u + 1] = toks
+    ntokens = int(sum(ulens) + B)
+    return src, torch.tensor(lens), prev, target, ntokens
+
+
+def seed_weights(model, seed):
+    """Re-draw every parameter from a seeded N(0, s) so that no weight is left at a trivial init
+    (LayerNorm gain 1 / bias 0 would hide a swapped gain/bias)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / fan_in**0.5))
+            elif name.endswith("weight"):  # norm gains
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        for name, b in model.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            if name.endswith("running_var"):
+                b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g))
+
+
+def sd_np(model):
+    out = {}
+    for k, v in model.state_dict().items():
+        out["w::" + k] = v.detach().cpu().numpy().copy()  # copy: BN buffers are updated in place later
+    return out
+
+
+def build(arch, V, **kw):
+    d = make_dict(V)
+    task = FakeTask(d)
+    args = base_args(arch, **kw)
+    model = ARCH_MODEL_REGISTRY[arch].build_model(args, task)
+    return model, args, task
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def criterion_for(task, args):
+    from fairseq.criterions.ctc import CtcCriterionConfig
+    from fairseq.criterions.label_smoothed_cross_entropy_with_ctc import (
+        LabelSmoothedCrossEntropyCriterionWithCTC,
+    )
+
+    cfg = CtcCriterionConfig()
+    cfg.sentence_avg = False
+    cfg.zero_infinity = True
+    cfg.post_process = "none"
+    crit = LabelSmoothedCrossEntropyCriterionWithCTC(
+        task, label_smoothing=0.1, sentence_avg=False, cfg=cfg, ctc_weight=args.ctc_weight
+    )
+    return crit
+
+
+def encdec_case(name, outdir, arch, V, B, T, seed, train_bn=False, **kw):
+    torch.manual_seed(seed)
+    model, args, task = build(arch, V, **kw)
+    seed_weights(model, seed + 100)
+    src, lens, prev, target, ntokens = make_batch(B, T, V, seed + 200)
+    out = {}
+    out.update(sd_np(model))
+    out["in::src_tokens"] = np_(src)
+    out["in::src_lengths"] = np_(lens)
+    out["in::prev_output_tokens"] = np_(prev)
+    out["in::target"] = np_(target)
+    out["in::ntokens"] = np.int64(ntokens)
+
+    # ---- eval forward
+    model.eval()
+    with torch.no_grad():
+        enc = model.encoder(src, lens)
+        logits, extra = model.decoder(prev_output_tokens=prev, encoder_out=enc)
+    out["out::encoder_out"] = np_(enc["encoder_out"][0])  # (T', B, d)
+    out["out::ctc_logit"] = np_(enc["ctc_logit"][0])  # (T', B, V)
+    out["out::encoder_padding_mask"] = np_(enc["encoder_padding_mask"][0])
+    out["out::decoder_logits"] = np_(logits)  # (B, U, V)
+
+    # ---- loss + grads (training mode, dropout 0; BatchNorm uses batch statistics when present)
+    model.train()
+    crit = criterion_for(task, args)
+    crit.train()
+    sample = {
+        "id": torch.arange(B),
+        "net_input": {"src_tokens": src, "src_lengths": lens, "prev_output_tokens": prev},
+        "target": target,
+        "ntokens": ntokens,
+    }
+    model.zero_grad()
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    out["out::loss"] = np.float64(loss.item())
+    out["out::trans_loss"] = np.float64(log["trans_loss"])
+    out["out::nll_loss"] = np.float64(log["nll_loss"])
+    out["out::ctc_loss"] = np.float64(log["ctc_loss"])
+    out["out::n_correct"] = np.int64(log["n_correct"])
+    out["out::total"] = np.int64(log["total"])
+    out["out::sample_size"] = np.int64(sample_size)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out["grad::" + k] = np_(p.grad)
+    if train_bn:
+        for k, b in model.named_buffers():
+            if "running_" in k or "num_batches" in k:
+                out["bn_after::" + k] = np_(b)
+    # hyper-parameters the restatement needs
+    for k in (
+        "encoder_embed_dim encoder_ffn_embed_dim encoder_layers encoder_attention_heads decoder_layers "
+        "decoder_embed_dim decoder_ffn_embed_dim decoder_attention_heads subsampling_filter cnn_module_kernel "
+        "ctc_weight"
+    ).split():
+        out["cfg::" + k] = np.float64(getattr(args, k))
+    for k in "encoder_attention_type encoder_activation_fn activation_fn".split():
+        out["cfg::" + k] = np.array(getattr(args, k))
+    for k in "macaron_style use_cnn_module layer_padding_mask encoder_normalize_before".split():
+        out["cfg::" + k] = np.bool_(bool(getattr(args, k)))
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    print(name, "loss", loss.item(), {k: v for k, v in log.items() if "loss" in k})
+
+
+def ctc_greedy_case(name, outdir, V, B, T, seed, **kw):
+    from fairseq.models.speech_to_text.s2t_ctc import CTCDecoder
+
+    torch.manual_seed(seed)
+    model, args, task = build("s2t_ctc_s", V, **kw)
+    seed_weights(model, seed + 100)
+    # make the greedy output non-trivial: scale the CTC projection so that the arg-max changes over time
+    with torch.no_grad():
+        model.encoder.ctc.ctc_projection.weight.mul_(4.0)
+    src, lens, prev, target, ntokens = make_batch(B, T, V, seed + 200)
+    model.eval()
+    dargs = Namespace(beam=1, ctc_self_ensemble=False, ctc_inter_logit=0, cal_flops=False, print_alignment=False)
+    dec = CTCDecoder([model], dargs, task.target_dictionary, blank_idx=0)
+    sample = {"net_input": {"src_tokens": src, "src_lengths": lens, "prev_output_tokens": prev}, "target": target}
+    with torch.no_grad():
+        hyps = dec.generate([model], sample)
+        enc = model.encoder(src, lens)
+    out = {}
+    out.update(sd_np(model))
+    out["in::src_tokens"] = np_(src)
+    out["in::src_lengths"] = np_(lens)
+    out["out::ctc_logit"] = np_(enc["ctc_logit"][0])
+    out["out::encoder_padding_mask"] = np_(enc["encoder_padding_mask"][0])
+    toks = [np_(h[0]["tokens"]).astype(np.int64) for h in hyps]
+    out["out::hyp_lengths"] = np.array([len(t) for t in toks], dtype=np.int64)
+    out["out::hyp_tokens"] = np.concatenate(toks) if sum(len(t) for t in toks) else np.zeros(0, np.int64)
+    out["out::hyp_scores"] = np.array([float(h[0]["score"]) for h in hyps])
+    for k in "encoder_embed_dim encoder_ffn_embed_dim encoder_layers encoder_attention_heads subsampling_filter".split():
+        out["cfg::" + k] = np.float64(getattr(args, k))
+    for k in "encoder_attention_type encoder_activation_fn activation_fn".split():
+        out["cfg::" + k] = np.array(getattr(args, k))
+    for k in "macaron_style use_cnn_module layer_padding_mask encoder_normalize_before".split():
+        out["cfg::" + k] = np.bool_(bool(getattr(args, k)))
+    out["cfg::cnn_module_kernel"] = np.float64(getattr(args, "cnn_module_kernel", 0))
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    print(name, "hyp lens", [len(t) for t in toks])
+
+
+def module_cases(outdir):
+    from fairseq.modules import LayerNorm
+    from fairseq.modules.positional_encoding import RelPositionalEncoding
+    from fairseq.modules.sinusoidal_positional_embedding import SinusoidalPositionalEmbedding
+    from fairseq.modules.speech_to_text.subsampling import Conv1dSubsampling
+    from fairseq.data.data_utils import lengths_to_padding_mask
+
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    # Conv1dSubsampling(2, 80, [48, 32], 5, 2, "none", "glu")
+    sub = Conv1dSubsampling(2, 80, [48, 32], 5, stride=2, norm="none", act="glu")
+    x = torch.randn(37, 3, 80, generator=g)
+    lens = torch.tensor([37, 30, 22])
+    with torch.no_grad():
+        y, yl = sub(x, lens)
+    for k, v in sub.state_dict().items():
+        out["sub::w::" + k] = np_(v)
+    out["sub::x"] = np_(x)
+    out["sub::lens"] = np_(lens)
+    out["sub::y"] = np_(y)
+    out["sub::ylens"] = np_(yl)
+    # rel-pos table
+    rp = RelPositionalEncoding(6000, 32)
+    out["relpos::T7"] = np_(rp(torch.zeros(7, 1, 32)))
+    out["relpos::T12"] = np_(rp(torch.zeros(12, 1, 32)))
+    # sinusoidal table driven by the bool padding mask (s2t_transformer.py:1785)
+    sp = SinusoidalPositionalEmbedding(32, 1, init_size=64)
+    mask = lengths_to_padding_mask(torch.tensor([9, 6, 4]))
+    out["sinpos::mask"] = np_(mask)
+    out["sinpos::out"] = np_(sp(mask))
+    toks = torch.tensor([[2, 5, 6, 7, 1], [2, 9, 1, 1, 1]])
+    out["sinpos::tokens"] = np_(toks)
+    out["sinpos::tokens_out"] = np_(sp(toks))
+    # LayerNorm
+    ln = LayerNorm(32)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(32, generator=g))
+        ln.bias.copy_(0.1 * torch.randn(32, generator=g))
+    xx = torch.randn(5, 32, generator=g)
+    out["ln::x"] = np_(xx)
+    out["ln::w"] = np_(ln.weight)
+    out["ln::b"] = np_(ln.bias)
+    out["ln::y"] = np_(ln(xx))
+    np.savez_compressed(os.path.join(outdir, "modules.npz"), **out)
+    print("modules ok")
+
+
+def main():
+    outdir = sys.argv[1]
+    os.makedirs(outdir, exist_ok=True)
+    small = dict(
+        encoder_embed_dim=32,
+        encoder_ffn_embed_dim=64,
+        encoder_attention_heads=2,
+        decoder_attention_heads=2,
+        encoder_layers=2,
+        decoder_layers=2,
+        subsampling_filter=48,
+    )
+    conf = dict(
+        macaron_style=True,
+        use_cnn_module=True,
+        cnn_module_kernel=15,
+        encoder_attention_type="rel_pos",
+        encoder_activation_fn="swish",
+        layer_padding_mask=True,
+    )
+    module_cases(outdir)
+    encdec_case("transformer_small", outdir, "s2t_transformer_s", V=40, B=3, T=50, seed=1, **small)
+    encdec_case("conformer_small", outdir, "s2t_transformer_s", V=40, B=3, T=50, seed=2, train_bn=True, **small, **conf)
+    # ragged: one full row + short rows; T not a multiple of 4; B=4
+    encdec_case("conformer_ragged", outdir, "s2t_transformer_s", V=37, B=4, T=67, seed=3, train_bn=True, **small, **conf)
+    small_ctc = {k: v for k, v in small.items() if not k.startswith("decoder")}
+    ctc_greedy_case("ctc_greedy_transformer", outdir, V=40, B=4, T=64, seed=4, **small_ctc)
+    ctc_greedy_case("ctc_greedy_conformer", outdir, V=40, B=4, T=64, seed=5, **small_ctc, **conf)
+
+
+if __name__ == "__main__":
+    main()

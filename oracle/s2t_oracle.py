@@ -1,0 +1,473 @@
+"""CPU oracle for the S2T hot path — TEST INFRASTRUCTURE, NOT A PRODUCT PATH.
+
+A plain fp32 PyTorch-CPU restatement, written from the maths, of the reference's algorithm for the
+path named in BASELINE.json.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module, and only as the checker.  The shipped
+package ``s2t_amd`` never imports it and has no CPU fallback.
+
+Pinning: every function here is checked against golden vectors dumped from the reference itself
+(``oracle/gen_golden.py`` -> ``tests/golden/*.npz``) by ``tests/test_oracle_golden.py``.
+
+All tensors are batch-major ``(B, T, C)`` inside the oracle; the reference is time-major between
+modules (``(T, B, C)``), so boundary outputs are transposed back where the reference returns them.
+Weights are addressed by the reference's own ``state_dict`` keys.
+
+Reference file:line citations are relative to ``/root/reference/fairseq``.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+NEG_INF = float("-inf")
+
+
+# ----------------------------------------------------------------------------------------------
+# small pieces
+# ----------------------------------------------------------------------------------------------
+def lengths_to_padding_mask(lens: torch.Tensor, max_len: Optional[int] = None) -> torch.Tensor:
+    """data/data_utils.py:518-522 — True where t >= len."""
+    max_len = int(lens.max()) if max_len is None else max_len
+    return torch.arange(max_len)[None, :] >= lens[:, None]
+
+
+def subsampled_lengths(lens: torch.Tensor, n_layers: int = 2) -> torch.Tensor:
+    """modules/speech_to_text/subsampling.py:153-154 — l -> floor((l-1)/2)+1 per strided conv."""
+    for _ in range(n_layers):
+        lens = torch.div(lens - 1, 2, rounding_mode="floor") + 1
+    return lens
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    """modules/layer_norm.py:30-35 -> torch.nn.LayerNorm(eps=1e-5): biased variance over the last dim."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def activation(name: str, x):
+    """modules/activations.py — relu / swish (x * sigmoid(x)) / gelu."""
+    if name == "relu":
+        return torch.clamp_min(x, 0.0)
+    if name == "swish":
+        return x * torch.sigmoid(x)
+    if name == "gelu":
+        return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    raise ValueError(name)
+
+
+def glu_channels(x):
+    """GLU over the channel (last) dim: first half * sigmoid(second half)."""
+    a, g = x.chunk(2, dim=-1)
+    return a * torch.sigmoid(g)
+
+
+def linear(x, w, b=None):
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+# ----------------------------------------------------------------------------------------------
+# positional encodings
+# ----------------------------------------------------------------------------------------------
+def sinusoidal_table(n_pos: int, dim: int, padding_idx: int = 1) -> torch.Tensor:
+    """modules/sinusoidal_positional_embedding.py:36-58 — [sin | cos] halves (not interleaved),
+    log-timescale step log(1e4)/(dim/2-1), row ``padding_idx`` zeroed."""
+    half = dim // 2
+    step = math.log(10000.0) / (half - 1)
+    inv = torch.exp(torch.arange(half, dtype=torch.float32) * -step)
+    ang = torch.arange(n_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    if dim % 2 == 1:
+        tab = torch.cat([tab, torch.zeros(n_pos, 1)], dim=1)
+    tab[padding_idx] = 0.0
+    return tab
+
+
+def sinusoidal_positions(tokens_or_mask: torch.Tensor, dim: int, padding_idx: int = 1) -> torch.Tensor:
+    """modules/sinusoidal_positional_embedding.py:60-105 + utils.py:240-250 (make_positions).
+
+    ``tokens_or_mask`` is (B, T) — token ids for the decoder, or the *bool padding mask* for the S2T
+    encoder (s2t_transformer.py:1785), in which case True(=1) equals ``padding_idx`` and marks padding.
+    Non-pad positions count 1,2,... and are offset by ``padding_idx`` (first real frame -> row 2)."""
+    x = tokens_or_mask.long()
+    nonpad = (x != padding_idx).long()
+    pos = torch.cumsum(nonpad, dim=1) * nonpad + padding_idx
+    tab = sinusoidal_table(padding_idx + 1 + x.size(1), dim, padding_idx)
+    return tab[pos]  # (B, T, dim)
+
+
+def rel_pos_table(T: int, dim: int) -> torch.Tensor:
+    """modules/positional_encoding.py:121-166 — (2T-1, dim); row n encodes relative offset T-1-n,
+    interleaved sin (even cols) / cos (odd cols)."""
+    rel = torch.arange(T - 1, -T, -1, dtype=torch.float32)[:, None]
+    inv = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    tab = torch.zeros(2 * T - 1, dim)
+    tab[:, 0::2] = torch.sin(rel * inv)
+    tab[:, 1::2] = torch.cos(rel * inv)
+    return tab
+
+
+# ----------------------------------------------------------------------------------------------
+# subsampler
+# ----------------------------------------------------------------------------------------------
+def conv1d_subsample(x, lens, W: Dict[str, torch.Tensor], prefix: str, n_layers: int = 2):
+    """modules/speech_to_text/subsampling.py:106-159 — n x [Conv1d(k, stride 2, pad k//2) -> GLU(ch)].
+
+    x (B, T, C) -> (B, T', C_out).  Padded input frames are whatever the caller put there (zeros from
+    the collater); no masking happens between the convolutions."""
+    y = x.transpose(1, 2)  # (B, C, T)
+    for i in range(n_layers):
+        w = W[f"{prefix}layers.{i}.0.weight"]
+        b = W[f"{prefix}layers.{i}.0.bias"]
+        k = w.size(2)
+        y = F.conv1d(y, w, b, stride=2, padding=(k - 1) // 2)
+        a, g = y.chunk(2, dim=1)
+        y = a * torch.sigmoid(g)
+    return y.transpose(1, 2), subsampled_lengths(lens, n_layers)
+
+
+# ----------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------
+def _split_heads(x, h):
+    B, T, d = x.shape
+    return x.view(B, T, h, d // h).transpose(1, 2)  # (B, h, T, dk)
+
+
+def mha(q_in, kv_in, W, prefix, h, key_padding_mask=None, causal=False):
+    """modules/multihead_attention.py:161-431 — q scaled by dk^-0.5 (:265), scores + causal mask,
+    key-pad -> -inf (:383-395), fp32 softmax (:403), @V, out_proj."""
+    d = q_in.size(-1)
+    dk = d // h
+    q = linear(q_in, W[prefix + "q_proj.weight"], W[prefix + "q_proj.bias"]) * dk**-0.5
+    k = linear(kv_in, W[prefix + "k_proj.weight"], W[prefix + "k_proj.bias"])
+    v = linear(kv_in, W[prefix + "v_proj.weight"], W[prefix + "v_proj.bias"])
+    q, k, v = _split_heads(q, h), _split_heads(k, h), _split_heads(v, h)
+    s = q @ k.transpose(-1, -2)  # (B,h,Tq,Tk)
+    if causal:
+        Tq, Tk = s.shape[-2:]
+        s = s + torch.triu(torch.full((Tq, Tk), NEG_INF), diagonal=1)
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], NEG_INF)
+    p = torch.softmax(s.float(), dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(q_in.size(0), q_in.size(1), d)
+    return linear(o, W[prefix + "out_proj.weight"], W[prefix + "out_proj.bias"])
+
+
+def rel_pos_mha(x, pos_tab, W, prefix, h, key_padding_mask=None):
+    """modules/espnet_multihead_attention.py:313-356 (+ :88-155, :292-311).
+
+    scores[i,j] = ((q_i+u)·k_j + (q_i+v)·p[T-1-i+j]) / sqrt(dk) where p = linear_pos(pos_tab) and
+    row n of pos_tab encodes offset T-1-n, so the pair (i,j) sees the encoding of offset i-j — this is
+    what the reference's pad-reshape-slice ``rel_shift`` selects.  Key-pad -> -inf, clamp to +-1e8
+    (:127-128; -inf becomes -1e8), fp32 softmax, @V, linear_out."""
+    B, T, d = x.shape
+    dk = d // h
+    q = _split_heads(linear(x, W[prefix + "linear_q.weight"], W[prefix + "linear_q.bias"]), h)
+    k = _split_heads(linear(x, W[prefix + "linear_k.weight"], W[prefix + "linear_k.bias"]), h)
+    v = _split_heads(linear(x, W[prefix + "linear_v.weight"], W[prefix + "linear_v.bias"]), h)
+    p = linear(pos_tab, W[prefix + "linear_pos.weight"]).view(2 * T - 1, h, dk).transpose(0, 1)  # (h,2T-1,dk)
+    u = W[prefix + "pos_bias_u"][None, :, None, :]
+    vb = W[prefix + "pos_bias_v"][None, :, None, :]
+    ac = (q + u) @ k.transpose(-1, -2)  # (B,h,T,T)
+    bd_full = (q + vb) @ p.transpose(-1, -2)[None]  # (B,h,T,2T-1)
+    idx = (T - 1) - torch.arange(T)[:, None] + torch.arange(T)[None, :]  # (T,T) in [0, 2T-2]
+    bd = torch.gather(bd_full, 3, idx[None, None].expand(B, h, T, T))
+    s = (ac + bd) / math.sqrt(dk)
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], NEG_INF)
+    s = s.clamp(min=-1e8, max=1e8)
+    pr = torch.softmax(s.float(), dim=-1)
+    o = (pr @ v).transpose(1, 2).reshape(B, T, d)
+    return linear(o, W[prefix + "linear_out.weight"], W[prefix + "linear_out.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# Conformer convolution module
+# ----------------------------------------------------------------------------------------------
+def conv_module(x, pad_mask, W, prefix, act: str, training: bool, bn_eps=1e-5):
+    """modules/convolution.py:76-120 — mask-zero; pointwise d->2d (no bias); GLU; depthwise K (pad K//2,
+    no bias); BatchNorm1d over (B,T) *including padded frames*; activation; pointwise d->d; mask-zero.
+
+    Returns (y, (batch_mean, batch_var_biased, n)) so tests can check the running-stat update."""
+    if pad_mask is not None:
+        x = x.masked_fill(pad_mask[:, :, None], 0.0)
+    y = linear(x, W[prefix + "pointwise_conv1.weight"][:, :, 0])
+    y = glu_channels(y)
+    wd = W[prefix + "depthwise_conv.weight"]  # (d,1,K)
+    K = wd.size(2)
+    y = F.conv1d(y.transpose(1, 2), wd, None, padding=(K - 1) // 2, groups=wd.size(0)).transpose(1, 2)
+    stats = None
+    if training:
+        mean = y.mean(dim=(0, 1))
+        var = ((y - mean) ** 2).mean(dim=(0, 1))
+        stats = (mean, var, y.size(0) * y.size(1))
+    else:
+        mean = W[prefix + "norm.running_mean"]
+        var = W[prefix + "norm.running_var"]
+    y = (y - mean) / torch.sqrt(var + bn_eps) * W[prefix + "norm.weight"] + W[prefix + "norm.bias"]
+    y = activation(act, y)
+    y = linear(y, W[prefix + "pointwise_conv2.weight"][:, :, 0])
+    if pad_mask is not None:
+        y = y.masked_fill(pad_mask[:, :, None], 0.0)
+    return y, stats
+
+
+def ffn(x, W, prefix, act, n1="w_1", n2="w_2"):
+    """modules/s2t_transformer_layer.py:55-66 — Linear -> act -> Linear."""
+    hdn = activation(act, linear(x, W[f"{prefix}{n1}.weight"], W[f"{prefix}{n1}.bias"]))
+    return linear(hdn, W[f"{prefix}{n2}.weight"], W[f"{prefix}{n2}.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder
+# ----------------------------------------------------------------------------------------------
+def encoder_layer(x, pad_mask, pos_tab, W, prefix, cfg, training, bn_stats=None):
+    """modules/s2t_transformer_layer.py:229-322, pre-LN (encoder_normalize_before=True)."""
+    h = cfg["encoder_attention_heads"]
+    act = cfg["encoder_activation_fn"]
+    if cfg["macaron_style"]:
+        y = layer_norm(x, W[prefix + "macaron_norm.weight"], W[prefix + "macaron_norm.bias"])
+        x = x + 0.5 * ffn(y, W, prefix + "macaron_ffn.", act)
+        scale = 0.5
+    else:
+        scale = 1.0
+    y = layer_norm(x, W[prefix + "self_attn_layer_norm.weight"], W[prefix + "self_attn_layer_norm.bias"])
+    if cfg["encoder_attention_type"] == "rel_pos":
+        y = rel_pos_mha(y, pos_tab, W, prefix + "self_attn.", h, pad_mask)
+    else:
+        y = mha(y, y, W, prefix + "self_attn.", h, pad_mask)
+    x = x + y
+    if cfg["use_cnn_module"]:
+        y = layer_norm(x, W[prefix + "conv_norm.weight"], W[prefix + "conv_norm.bias"])
+        # conv-module activation is --activation-fn (s2t_transformer_layer.py:125), not the FFN's
+        y, st = conv_module(y, pad_mask, W, prefix + "conv_module.", cfg["activation_fn"], training)
+        if bn_stats is not None:
+            bn_stats[prefix + "conv_module.norm"] = st
+        x = x + y
+    y = layer_norm(x, W[prefix + "ffn_norm.weight"], W[prefix + "ffn_norm.bias"])
+    x = x + scale * ffn(y, W, prefix + "ffn.", act)
+    if cfg["use_cnn_module"]:
+        x = layer_norm(x, W[prefix + "final_norm.weight"], W[prefix + "final_norm.bias"])
+    return x
+
+
+def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None):
+    """models/speech_to_text/s2t_transformer.py:1714-2154 (no mixup / inter-CTC / PAE branches).
+
+    Returns the reference's dict (time-major tensors in lists)."""
+    d = cfg["encoder_embed_dim"]
+    x, lens = conv1d_subsample(src_tokens, src_lengths, W, prefix + "subsample.")
+    T = x.size(1)
+    pad_mask = lengths_to_padding_mask(lens, T)
+    x = x * (~pad_mask)[:, :, None].to(x.dtype)  # :1765
+    if cfg.get("encoder_embed_norm", True):
+        x = layer_norm(x, W[prefix + "embed_ln.weight"], W[prefix + "embed_ln.bias"])  # :1769
+    if not cfg.get("encoder_no_scale_embedding", True):
+        x = x * math.sqrt(d)
+    pos_tab = None
+    if cfg["encoder_attention_type"] == "rel_pos":
+        pos_tab = rel_pos_table(T, d)  # not added to x (:1777-1778)
+    else:
+        x = x + sinusoidal_positions(pad_mask, d, padding_idx=1)  # :1785-1787
+    any_valid = not bool(pad_mask.all())
+    for i in range(cfg["encoder_layers"]):
+        if cfg.get("layer_padding_mask", False) and any_valid:
+            x = x.masked_fill(pad_mask[:, :, None], 0.0)  # :1828-1836
+        x = encoder_layer(x, pad_mask, pos_tab, W, f"{prefix}layers.{i}.", cfg, training, bn_stats)
+    x = layer_norm(x, W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"])
+    out = {
+        "encoder_out": [x.transpose(0, 1)],
+        "encoder_padding_mask": [pad_mask],
+        "ctc_logit": [],
+    }
+    if prefix + "ctc.ctc_projection.weight" in W:
+        logit = linear(x, W[prefix + "ctc.ctc_projection.weight"], W[prefix + "ctc.ctc_projection.bias"])
+        out["ctc_logit"] = [logit.transpose(0, 1)]  # (T', B, V)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# decoder
+# ----------------------------------------------------------------------------------------------
+def decoder_forward(prev_output_tokens, enc_out, W, cfg, prefix="decoder.", pad_idx=1):
+    """models/transformer.py:1249-1448 + modules/transformer_layer.py:395-543 (pre-LN, teacher forced)."""
+    d = cfg["decoder_embed_dim"]
+    h = cfg["decoder_attention_heads"]
+    emb = W[prefix + "embed_tokens.weight"]
+    x = math.sqrt(d) * emb[prev_output_tokens]  # :1314
+    x = x + sinusoidal_positions(prev_output_tokens, d, padding_idx=pad_idx)  # :1304,1323
+    self_pad = prev_output_tokens.eq(pad_idx)
+    self_pad = self_pad if bool(self_pad.any()) else None  # :1340-1342
+    mem = enc_out["encoder_out"][0].transpose(0, 1)  # (B, T', d)
+    mem_pad = enc_out["encoder_padding_mask"][0]
+    for i in range(cfg["decoder_layers"]):
+        p = f"{prefix}layers.{i}."
+        y = layer_norm(x, W[p + "self_attn_layer_norm.weight"], W[p + "self_attn_layer_norm.bias"])
+        x = x + mha(y, y, W, p + "self_attn.", h, self_pad, causal=True)
+        y = layer_norm(x, W[p + "encoder_attn_layer_norm.weight"], W[p + "encoder_attn_layer_norm.bias"])
+        x = x + mha(y, mem, W, p + "encoder_attn.", h, mem_pad)
+        y = layer_norm(x, W[p + "final_layer_norm.weight"], W[p + "final_layer_norm.bias"])
+        x = x + ffn(y, W, p, cfg.get("activation_fn", "relu"), n1="fc1", n2="fc2")
+    x = layer_norm(x, W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"])
+    wout = W.get(prefix + "output_projection.weight", emb)
+    return x @ wout.t()  # (B, U, V)
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+def label_smoothed_nll(logits, target, eps, pad_idx=1):
+    """criterions/label_smoothed_cross_entropy.py:42-60, summed over non-pad tokens (fp32 log-softmax)."""
+    lp = torch.log_softmax(logits.float(), dim=-1)
+    nll = -lp.gather(-1, target[..., None]).squeeze(-1)
+    smooth = -lp.sum(-1)
+    keep = target.ne(pad_idx)
+    nll = (nll * keep).sum()
+    smooth = (smooth * keep).sum()
+    eps_i = eps / (lp.size(-1) - 1)
+    return (1.0 - eps - eps_i) * nll + eps_i * smooth, nll
+
+
+def ce_accuracy(logits, target, pad_idx=1):
+    """criterions/label_smoothed_cross_entropy.py compute_accuracy: argmax == target over non-pad."""
+    keep = target.ne(pad_idx)
+    n_correct = (logits.argmax(-1).eq(target) & keep).sum()
+    return int(n_correct), int(keep.sum())
+
+
+def ctc_nll(log_probs, targets: List[torch.Tensor], input_lengths, blank=0, zero_infinity=True):
+    """CTC negative log-likelihood per utterance, log-space alpha recursion (Graves 2006), matching
+    torch.nn.CTCLoss(blank, reduction="none", zero_infinity) as used at criterions/ctc.py:243-245.
+
+    log_probs (T, B, V) fp32 log-softmax; targets: list of B 1-D label tensors (no blanks)."""
+    T, B, V = log_probs.shape
+    out = []
+    for b in range(B):
+        y = targets[b]
+        S = int(y.numel())
+        Tb = int(input_lengths[b])
+        L = 2 * S + 1
+        ext = torch.full((L,), blank, dtype=torch.long)
+        ext[1::2] = y
+        lp = log_probs[:Tb, b, :][:, ext]  # (Tb, L)
+        # transition s-2 -> s allowed when ext[s] != blank and ext[s] != ext[s-2]
+        skip = torch.zeros(L, dtype=torch.bool)
+        if L > 2:
+            skip[2:] = (ext[2:] != blank) & (ext[2:] != ext[:-2])
+        # "log zero" is a large finite negative so that autograd through the recursion stays NaN-free
+        LOG0 = -1e30
+        alpha = torch.full((L,), LOG0)
+        alpha = torch.cat([lp[0, :min(2, L)], alpha[min(2, L):]])
+        for t in range(1, Tb):
+            a1 = torch.cat([torch.full((1,), LOG0), alpha[:-1]])
+            a2 = torch.cat([torch.full((2,), LOG0), alpha[:-2]])[:L]
+            a2 = torch.where(skip, a2, torch.full_like(a2, LOG0))
+            alpha = torch.logsumexp(torch.stack([alpha, a1, a2]), 0) + lp[t]
+        if L > 1:
+            ll = torch.logsumexp(torch.stack([alpha[-1], alpha[-2]]), 0)
+        else:
+            ll = alpha[-1]
+        nll = -ll
+        if float(nll.detach()) > 1e29:  # no feasible alignment (T too short): inf -> 0 with zero gradient
+            nll = nll * 0.0 if zero_infinity else nll + float("inf")
+        out.append(nll)
+    return torch.stack(out)
+
+
+def ctc_targets(target, pad_idx=1, eos_idx=2):
+    """criterions/ctc.py:516-540 — strip pad and eos; per-utterance label lists."""
+    return [row[(row != pad_idx) & (row != eos_idx)] for row in target]
+
+
+def joint_loss(W, cfg, src_tokens, src_lengths, prev_output_tokens, target, eps=0.1, training=True,
+               use_torch_ctc=False, bn_stats=None):
+    """criterions/label_smoothed_cross_entropy_with_ctc.py:74-165: CE(label-smoothed) + ctc_weight * CTC."""
+    enc = encoder_forward(src_tokens, src_lengths, W, cfg, training=training, bn_stats=bn_stats)
+    logits = decoder_forward(prev_output_tokens, enc, W, cfg)
+    ce, nll = label_smoothed_nll(logits, target, eps)
+    lens = (~enc["encoder_padding_mask"][0]).long().sum(-1)
+    lp = torch.log_softmax(enc["ctc_logit"][0].float(), dim=-1)
+    tg = ctc_targets(target)
+    if use_torch_ctc:
+        flat = torch.cat(tg)
+        tl = torch.tensor([len(t) for t in tg])
+        ctc = F.ctc_loss(lp, flat, lens, tl, blank=0, reduction="none", zero_infinity=True).sum()
+    else:
+        ctc = ctc_nll(lp, tg, lens).sum()
+    loss = ce + cfg["ctc_weight"] * ctc
+    n_correct, total = ce_accuracy(logits, target)
+    return loss, {"trans_loss": ce, "nll_loss": nll, "ctc_loss": ctc, "n_correct": n_correct, "total": total,
+                  "logits": logits, "enc": enc}
+
+
+# ----------------------------------------------------------------------------------------------
+# CTC greedy decode
+# ----------------------------------------------------------------------------------------------
+def ctc_greedy(ctc_logit_tbv, pad_mask, blank=0):
+    """models/speech_to_text/s2t_ctc.py:312-347 — fp32 log-softmax, arg-max (ties -> lowest index),
+    padded frames -> blank, collapse repeats, drop blanks.  score = -sum of top-1 log-probs over frames
+    whose *unmasked* arg-max is not blank (:327-328 use the index before padding is applied)."""
+    lp = torch.log_softmax(ctc_logit_tbv.transpose(0, 1).float(), dim=-1)  # (B,T,V)
+    top_p, top_i = lp.max(-1)
+    # torch.max returns the first maximal index on CPU, same as topk(1)
+    real_i = top_i.masked_fill(pad_mask, blank)
+    real_p = top_p.masked_fill(top_i == blank, float(blank))
+    scores = -real_p.sum(-1)
+    hyps = []
+    for b in range(real_i.size(0)):
+        seq = real_i[b]
+        keep = torch.ones_like(seq, dtype=torch.bool)
+        keep[1:] = seq[1:] != seq[:-1]
+        h = seq[keep]
+        hyps.append(h[h != blank])
+    return hyps, scores
+
+
+# ----------------------------------------------------------------------------------------------
+# utterance CMVN (dataloader stage, a2)
+# ----------------------------------------------------------------------------------------------
+def utterance_cmvn(x, norm_means=True, norm_vars=True):
+    """data/audio/feature_transforms/utterance_cmvn.py:31-45 — per-utterance over time:
+    x - mean; / sqrt(max(E[x^2]-mean^2, 1e-10)) (variance computed from the *un-centred* moments)."""
+    mean = x.mean(0)
+    sq = (x**2).sum(0)
+    y = x - mean if norm_means else x
+    if norm_vars:
+        var = sq / x.size(0) - mean**2
+        y = y / torch.sqrt(torch.clamp_min(var, 1e-10))
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# helpers for tests / bench
+# ----------------------------------------------------------------------------------------------
+def cfg_from_golden(z) -> dict:
+    cfg = {}
+    for k in z.files:
+        if k.startswith("cfg::"):
+            v = z[k]
+            name = k[5:]
+            if v.dtype.kind in "US":
+                cfg[name] = str(v)
+            elif v.dtype == bool:
+                cfg[name] = bool(v)
+            else:
+                f = float(v)
+                cfg[name] = int(f) if f == int(f) and name != "ctc_weight" else f
+    cfg.setdefault("encoder_embed_norm", True)
+    cfg.setdefault("encoder_no_scale_embedding", True)
+    return cfg
+
+
+def weights_from_golden(z, requires_grad=False) -> Dict[str, torch.Tensor]:
+    W = {}
+    for k in z.files:
+        if k.startswith("w::"):
+            t = torch.from_numpy(z[k])
+            if requires_grad and t.is_floating_point():
+                t = t.clone().requires_grad_(True)
+            W[k[3:]] = t
+    return W

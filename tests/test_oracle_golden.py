@@ -1,0 +1,151 @@
+"""Pin the CPU oracle (oracle/s2t_oracle.py) against vectors dumped from the reference itself
+(oracle/gen_golden.py).  CPU-only; this is what makes the oracle trustworthy as the HIP checker."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2t_oracle as O
+
+CASES = ["transformer_small", "conformer_small", "conformer_ragged"]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_modules(golden_dir):
+    z = _load(golden_dir, "modules")
+    W = {k[len("sub::w::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sub::w::")}
+    x = torch.from_numpy(z["sub::x"]).transpose(0, 1)  # (T,B,C) -> (B,T,C)
+    y, yl = O.conv1d_subsample(x, torch.from_numpy(z["sub::lens"]), W, "")
+    _close(y.transpose(0, 1), z["sub::y"])
+    assert yl.tolist() == z["sub::ylens"].tolist()
+    for T in (7, 12):
+        _close(O.rel_pos_table(T, 32)[:, None, :], z[f"relpos::T{T}"], atol=1e-6)
+    _close(O.sinusoidal_positions(torch.from_numpy(z["sinpos::mask"]), 32), z["sinpos::out"], atol=1e-6)
+    _close(O.sinusoidal_positions(torch.from_numpy(z["sinpos::tokens"]), 32), z["sinpos::tokens_out"], atol=1e-6)
+    _close(O.layer_norm(torch.from_numpy(z["ln::x"]), torch.from_numpy(z["ln::w"]), torch.from_numpy(z["ln::b"])),
+           z["ln::y"], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_eval_forward(golden_dir, name):
+    z = _load(golden_dir, name)
+    cfg, W = O.cfg_from_golden(z), O.weights_from_golden(z)
+    src, lens = torch.from_numpy(z["in::src_tokens"]), torch.from_numpy(z["in::src_lengths"])
+    with torch.no_grad():
+        enc = O.encoder_forward(src, lens, W, cfg, training=False)
+        logits = O.decoder_forward(torch.from_numpy(z["in::prev_output_tokens"]), enc, W, cfg)
+    assert (enc["encoder_padding_mask"][0].numpy() == z["out::encoder_padding_mask"]).all()
+    _close(enc["encoder_out"][0], z["out::encoder_out"], rtol=1e-4, atol=2e-5)
+    _close(enc["ctc_logit"][0], z["out::ctc_logit"], rtol=1e-4, atol=2e-5)
+    _close(logits, z["out::decoder_logits"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("torch_ctc", [False, True])
+def test_loss_and_grads(golden_dir, name, torch_ctc):
+    z = _load(golden_dir, name)
+    cfg, W = O.cfg_from_golden(z), O.weights_from_golden(z, requires_grad=True)
+    bn = {}
+    loss, log = O.joint_loss(
+        W, cfg,
+        torch.from_numpy(z["in::src_tokens"]), torch.from_numpy(z["in::src_lengths"]),
+        torch.from_numpy(z["in::prev_output_tokens"]), torch.from_numpy(z["in::target"]),
+        eps=0.1, training=True, use_torch_ctc=torch_ctc, bn_stats=bn,
+    )
+    assert abs(float(loss.detach()) - float(z["out::loss"])) <= 1e-4 * abs(float(z["out::loss"]))
+    assert abs(float(log["trans_loss"]) - float(z["out::trans_loss"])) <= 1e-4 * abs(float(z["out::trans_loss"]))
+    assert abs(float(log["nll_loss"]) - float(z["out::nll_loss"])) <= 1e-4 * abs(float(z["out::nll_loss"]))
+    assert abs(float(log["ctc_loss"]) - float(z["out::ctc_loss"])) <= 1e-4 * abs(float(z["out::ctc_loss"]))
+    assert log["n_correct"] == int(z["out::n_correct"]) and log["total"] == int(z["out::total"])
+    loss.backward()
+    tied = ["decoder.embed_tokens.weight", "decoder.output_projection.weight", "encoder.ctc.ctc_projection.weight"]
+    n = 0
+    for k in z.files:
+        if not k.startswith("grad::"):
+            continue
+        key = k[6:]
+        if key in tied:
+            g = sum(W[t].grad for t in tied if t in W and W[t].grad is not None)
+        else:
+            g = W[key].grad
+        ref = z[k]
+        # k_proj.bias has a mathematically zero gradient (softmax is invariant to a per-row shift):
+        # both sides hold rounding noise there, hence the absolute floor
+        scale = max(np.abs(ref).max(), 1e-3)
+        err = np.abs(g.numpy() - ref).max() / scale
+        assert err < 2e-3, (key, err)
+        n += 1
+    assert n > 20
+    # BatchNorm running-stat update (momentum 0.1, unbiased variance), convolution.py:60 -> nn.BatchNorm1d
+    for k in z.files:
+        if k.startswith("bn_after::") and k.endswith("running_mean"):
+            mod = k[len("bn_after::"):-len(".running_mean")]
+            mean, var, cnt = bn[mod]
+            rm0 = z["w::" + mod + ".running_mean"]
+            rv0 = z["w::" + mod + ".running_var"]
+            _close(0.9 * rm0 + 0.1 * mean.detach().numpy(), z[k], rtol=1e-4, atol=1e-6)
+            _close(0.9 * rv0 + 0.1 * var.detach().numpy() * cnt / (cnt - 1), z["bn_after::" + mod + ".running_var"],
+                   rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["ctc_greedy_transformer", "ctc_greedy_conformer"])
+def test_ctc_greedy(golden_dir, name):
+    z = _load(golden_dir, name)
+    cfg, W = O.cfg_from_golden(z), O.weights_from_golden(z)
+    with torch.no_grad():
+        enc = O.encoder_forward(torch.from_numpy(z["in::src_tokens"]), torch.from_numpy(z["in::src_lengths"]), W, cfg)
+    _close(enc["ctc_logit"][0], z["out::ctc_logit"], rtol=1e-4, atol=5e-5)
+    hyps, scores = O.ctc_greedy(enc["ctc_logit"][0], enc["encoder_padding_mask"][0])
+    assert [len(h) for h in hyps] == z["out::hyp_lengths"].tolist()
+    assert torch.cat(hyps).tolist() == z["out::hyp_tokens"].tolist()  # bit-exact token ids
+    _close(scores, z["out::hyp_scores"], rtol=1e-4, atol=1e-4)
+    # and the oracle's decode applied to the reference's own logits gives the same ids
+    hyps2, _ = O.ctc_greedy(torch.from_numpy(z["out::ctc_logit"]), torch.from_numpy(z["out::encoder_padding_mask"]))
+    assert torch.cat(hyps2).tolist() == z["out::hyp_tokens"].tolist()
+
+
+def test_ctc_nll_matches_aten_and_edge_cases():
+    g = torch.Generator().manual_seed(0)
+    T, B, V = 12, 4, 7
+    lp = torch.log_softmax(torch.randn(T, B, V, generator=g), -1)
+    tg = [torch.tensor([1, 1, 2]), torch.tensor([3]), torch.tensor([], dtype=torch.long), torch.tensor([4, 5, 6, 4, 5, 6, 1])]
+    il = torch.tensor([12, 9, 5, 6])  # last: T < needed (7 labels need >= 7 frames) -> inf -> 0
+    mine = O.ctc_nll(lp, tg, il)
+    ref = torch.nn.functional.ctc_loss(lp, torch.cat(tg), il, torch.tensor([len(t) for t in tg]), blank=0,
+                                       reduction="none", zero_infinity=True)
+    np.testing.assert_allclose(mine.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert float(mine[3]) == 0.0
+
+
+def test_label_smoothing_properties():
+    """The four properties the reference's own tests/test_label_smoothing.py:62-117 asserts."""
+    g = torch.Generator().manual_seed(1)
+    logits = torch.randn(2, 5, 11, generator=g)
+    tgt = torch.randint(2, 11, (2, 5), generator=g)
+    tgt[1, 3:] = 1
+    loss, nll = O.label_smoothed_nll(logits, tgt, 0.1)
+    ce = torch.nn.functional.cross_entropy(logits.view(-1, 11), tgt.view(-1), ignore_index=1, reduction="sum")
+    assert abs(float(nll) - float(ce)) < 1e-5  # nll part == plain CE
+    loss0, nll0 = O.label_smoothed_nll(logits, tgt, 0.0)
+    assert abs(float(loss0) - float(ce)) < 1e-5  # eps = 0 == CE
+    logits2 = logits.clone()
+    logits2[1, 3:] = torch.randn(2, 11, generator=g)  # padding invariance
+    loss2, _ = O.label_smoothed_nll(logits2, tgt, 0.1)
+    assert abs(float(loss2) - float(loss)) < 1e-5
+    per = sum(O.label_smoothed_nll(logits[b:b + 1, u:u + 1], tgt[b:b + 1, u:u + 1], 0.1)[0] for b in range(2) for u in range(5))
+    assert abs(float(per) - float(loss)) < 1e-4  # reduce == sum of unreduced
+
+
+def test_utterance_cmvn():
+    x = torch.randn(50, 80, generator=torch.Generator().manual_seed(2)) * 3 + 1
+    y = O.utterance_cmvn(x)
+    assert y.mean(0).abs().max() < 1e-5 and (y.std(0, unbiased=False) - 1).abs().max() < 1e-4
