@@ -1,0 +1,95 @@
+// Shared device/host helpers for libs2t_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/s2t_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits in HBM
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define S2T_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T>
+__device__ __forceinline__ float ld_as_f32(const T* p);
+template <>
+__device__ __forceinline__ float ld_as_f32<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld_as_f32<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+template <typename T>
+__device__ __forceinline__ void st_from_f32(T* p, float v);
+template <>
+__device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void st_from_f32<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 4 consecutive elements
+template <typename T>
+__device__ __forceinline__ void ld4_as_f32(const T* p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void ld4_as_f32<float>(const float* p, float (&v)[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void ld4_as_f32<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ void st4_from_f32(T* p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void st4_from_f32<float>(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void st4_from_f32<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  uint2 t;
+  t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float act_apply(int act, float x) {
+  if (act == S2T_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (act == S2T_ACT_SWISH) return x * sigmoidf_(x);
+  return x;
+}
+// derivative of the activation w.r.t. its pre-activation input z
+__device__ __forceinline__ float act_grad(int act, float z) {
+  if (act == S2T_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == S2T_ACT_SWISH) {
+    float s = sigmoidf_(z);
+    return s * (1.f + z * (1.f - s));
+  }
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int s2t_hip_status(hipError_t e) { return e == hipSuccess ? S2T_OK : (int)e; }
+#define S2T_LAUNCH_CHECK() s2t_hip_status(hipGetLastError())

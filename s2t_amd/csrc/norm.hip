@@ -1,0 +1,195 @@
+// LayerNorm forward / backward (reference: modules/layer_norm.py:30-35 -> torch.nn.LayerNorm, eps 1e-5).
+// HBM-bound: one wavefront per row, 4 elements (8 B bf16 / 16 B f32) per lane per step, fp32 statistics by
+// wave shuffles.  Optional fused row mask (rows t >= len[b] are written as zero) covers the reference's
+// per-layer `masked_fill(pad, 0)` (s2t_transformer.py:1828-1836) when it directly follows a LayerNorm.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_VEC = 8;  // supports cols <= 64*4*8 = 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int64_t rows, int cols, float eps,
+                                                     const int32_t* __restrict__ row_lens, int row_T) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * cols;
+  float v[LN_MAX_VEC][4];
+  const int nvec = (cols + 255) / 256;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    if (i < nvec) {
+      const int c = i * 256 + lane * 4;
+      if (c < cols) ld4_as_f32<T>(xr + c, v[i]);
+      else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    if (i < nvec) {
+      const int c = i * 256 + lane * 4;
+      if (c < cols) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = v[i][r] - mean;
+          q += d * d;
+        }
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+  bool masked = false;
+  if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
+  T* yr = y + row * cols;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    if (i < nvec) {
+      const int c = i * 256 + lane * 4;
+      if (c < cols) {
+        float g[4], b[4], o[4];
+        ld4_as_f32<float>(gamma + c, g);
+        ld4_as_f32<float>(beta + c, b);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = masked ? 0.f : (v[i][r] - mean) * rstd * g[r] + b[r];
+        st4_from_f32<T>(yr + c, o);
+      }
+    }
+  }
+  if (lane == 0 && mean_out) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+// dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)); dgamma += sum_rows dy*xhat; dbeta += sum_rows dy
+// A fixed grid of workgroups strides over the rows so that the per-column partial sums stay in registers and
+// each workgroup issues ONE set of atomics (avoids a chip-wide pile-up on the same 2*cols addresses).
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const T* __restrict__ dy, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int64_t rows, int cols, const int32_t* __restrict__ row_lens,
+                                                     int row_T) {
+  __shared__ float red[2][4][LN_MAX_VEC * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nvec = (cols + 255) / 256;
+  float ag[LN_MAX_VEC][4], ab[LN_MAX_VEC][4];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ag[i][r] = ab[i][r] = 0.f;
+
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
+    bool masked = false;
+    if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
+    const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAX_VEC][4], dg[LN_MAX_VEC][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+      if (i < nvec) {
+        const int c = i * 256 + lane * 4;
+        if (c < cols) {
+          float xv[4], dv[4], g[4];
+          ld4_as_f32<T>(x + row * cols + c, xv);
+          ld4_as_f32<T>(dy + row * cols + c, dv);
+          ld4_as_f32<float>(gamma + c, g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = masked ? 0.f : dv[r];
+            xh[i][r] = (xv[r] - mu) * rs;
+            dg[i][r] = d * g[r];
+            s1 += dg[i][r];
+            s2 += dg[i][r] * xh[i][r];
+            ag[i][r] += d * xh[i][r];
+            ab[i][r] += d;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xh[i][r] = dg[i][r] = 0.f;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / cols;
+    s2 = wave_sum(s2) / cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+      if (i < nvec) {
+        const int c = i * 256 + lane * 4;
+        if (c < cols) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = rs * (dg[i][r] - s1 - xh[i][r] * s2);
+          st4_from_f32<T>(dx + row * cols + c, o);
+        }
+      }
+    }
+  }
+  // block reduce over the 4 waves, then one atomic per column per workgroup
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    if (i < nvec) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[0][w][i * 256 + lane * 4 + r] = ag[i][r];
+        red[1][w][i * 256 + lane * 4 + r] = ab[i][r];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(dgamma + c, g);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
+}  // namespace
+
+extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
+                                 float* mean, float* rstd, int64_t rows, int cols, float eps,
+                                 const int32_t* row_lens, int row_T, void* stream) {
+  if (!x || !gamma || !beta || !y || rows < 0 || cols <= 0) return S2T_ERR_ARG;
+  if (cols % 4 || cols > LN_MAX_VEC * 256) return S2T_ERR_UNSUPPORTED;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd,
+                       rows, cols, eps, row_lens, row_T);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean,
+                       rstd, rows, cols, eps, row_lens, row_T);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* dy, const float* mean,
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
+                                 const int32_t* row_lens, int row_T, void* stream) {
+  if (!x || !gamma || !dy || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || cols <= 0) return S2T_ERR_ARG;
+  if (cols % 4 || cols > LN_MAX_VEC * 256) return S2T_ERR_UNSUPPORTED;
+  if (rows == 0) return S2T_OK;
+  int64_t nb = (rows + 3) / 4;
+  if (nb > 512) nb = 512;
+  dim3 grid((unsigned)nb), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, s, (const float*)x, gamma, (const float*)dy, mean, rstd,
+                       (float*)dx, dgamma, dbeta, rows, cols, row_lens, row_T);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean,
+                       rstd, (bf16_t*)dx, dgamma, dbeta, rows, cols, row_lens, row_T);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}

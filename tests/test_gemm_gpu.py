@@ -1,0 +1,152 @@
+"""GPU parity of the MFMA GEMM (s2t_gemm) against a float64 CPU matmul (the oracle of a GEMM).
+
+Covers all four operand layouts, both dtypes, ragged M/N/K (not multiples of the tile or of the
+16-byte chunk), two-level batching, and every epilogue stage."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from s2t_amd import ops  # noqa: E402
+
+
+def _mk(shape, dtype, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def _pad_ld(n, dtype):
+    epb = 4 if dtype == torch.float32 else 8
+    return (n + epb - 1) // epb * epb
+
+
+def _tol(dtype, K):
+    # bf16 inputs are exact in the reference product (cast first); only the fp32 accumulation order
+    # differs; outputs rounded to bf16 add 2^-8 relative
+    return (2e-5, 2e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 130, 100), (16, 10, 8), (300, 250, 64), (64, 1000, 256), (250, 64, 250)])
+def test_layouts(dtype, akm, bkm, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    dev = "cuda"
+    # storage with padded leading dims (row starts stay 16-byte aligned)
+    if akm:
+        lda = _pad_ld(M, dtype); A_st = torch.zeros(K, lda, dtype=dtype); A_log = _mk((M, K), dtype, g); A_st[:, :M] = A_log.t()
+    else:
+        lda = _pad_ld(K, dtype); A_st = torch.zeros(M, lda, dtype=dtype); A_log = _mk((M, K), dtype, g); A_st[:, :K] = A_log
+    if bkm:
+        ldb = _pad_ld(N, dtype); B_st = torch.zeros(K, ldb, dtype=dtype); B_log = _mk((K, N), dtype, g); B_st[:, :N] = B_log
+    else:
+        ldb = _pad_ld(K, dtype); B_st = torch.zeros(N, ldb, dtype=dtype); B_log = _mk((K, N), dtype, g); B_st[:, :K] = B_log.t()
+    # poison the padding so that a kernel reading it shows up
+    if akm: A_st[:, M:] = float("nan")
+    else: A_st[:, K:] = float("nan")
+    if bkm: B_st[:, N:] = float("nan")
+    else: B_st[:, K:] = float("nan")
+    ref = A_log.double() @ B_log.double()
+    ldc = N + 3
+    out = torch.full((M, ldc), 7.0, dtype=dtype, device=dev)
+    ops.gemm(A_st.to(dev), B_st.to(dev), out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_kmajor=akm, b_kmajor=bkm)
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    rtol, atol = _tol(dtype, K)
+    scale = ref.abs().max().item()
+    np.testing.assert_allclose(got[:, :N].numpy(), ref.numpy(), rtol=rtol, atol=atol * scale)
+    assert (got[:, N:] == 7.0).all(), "wrote outside the N columns"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_epilogue_bias_act_residual_mask(dtype):
+    g = torch.Generator().manual_seed(5)
+    dev = "cuda"
+    B_, T, K, N = 3, 50, 72, 136
+    M = B_ * T
+    A = _mk((M, K), dtype, g); W = _mk((N, K), dtype, g, 0.2); bias = _mk((N,), torch.float32, g)
+    R = _mk((M, N), dtype, g)
+    lens = torch.tensor([50, 31, 7], dtype=torch.int32)
+    for act in ("relu", "swish", None):
+        out = torch.empty(M, N, dtype=dtype, device=dev)
+        pre = torch.empty(M, N, dtype=dtype, device=dev)
+        ops.gemm(A.to(dev), W.to(dev), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias.to(dev), act=act, alpha=0.5,
+                 residual=R.to(dev), ldr=N, preact=pre if act else None, ldp=N, row_lens=lens.to(dev), row_T=T)
+        z = A.double() @ W.double().t() + bias.double()
+        a = {"relu": torch.relu, "swish": lambda v: v * torch.sigmoid(v), None: lambda v: v}[act](z)
+        ref = R.double() + 0.5 * a
+        mask = (torch.arange(T)[None, :] >= lens[:, None]).reshape(-1)
+        ref[mask] = 0
+        rtol, atol = _tol(dtype, K)
+        np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=rtol, atol=atol * 4)
+        if act:
+            np.testing.assert_allclose(pre.cpu().double().numpy(), z.numpy(), rtol=rtol, atol=atol * 4)
+    # dact: out = (A @ W^T) * act'(Z)
+    Z = _mk((M, N), dtype, g)
+    for act in ("relu", "swish"):
+        out = torch.empty(M, N, dtype=dtype, device=dev)
+        ops.gemm(A.to(dev), W.to(dev), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dact_z=Z.to(dev), ldz=N, dact=act)
+        zd = Z.double()
+        if act == "relu":
+            d = (zd > 0).double()
+        else:
+            s = torch.sigmoid(zd); d = s * (1 + zd * (1 - s))
+        ref = (A.double() @ W.double().t()) * d
+        rtol, atol = _tol(dtype, K)
+        np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=rtol, atol=atol * 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_glu_epilogue_and_conv_rows(dtype):
+    """Conv1d(k=5, stride 2, pad 2) + GLU as an overlapping-row GEMM over a zero-padded (B, T+4, C) buffer —
+    the formulation the subsampler uses (reference: modules/speech_to_text/subsampling.py:145-159)."""
+    g = torch.Generator().manual_seed(9)
+    dev = "cuda"
+    Bz, T, Cin, Cout = 3, 37, 16, 80  # Cout must be even; out channels = 40
+    x = _mk((Bz, T, Cin), dtype, g)
+    w = _mk((Cout, Cin, 5), dtype, g, 0.2)
+    b = _mk((Cout,), torch.float32, g)
+    Tout = (T - 1) // 2 + 1
+    Tp = 2 * Tout + 4
+    xp = torch.zeros(Bz, Tp, Cin, dtype=dtype)
+    xp[:, 2:2 + T] = x
+    wk = w.permute(0, 2, 1).contiguous().view(Cout, 5 * Cin)  # [Cout][k*Cin + c]
+    out = torch.empty(Bz, Tout, Cout // 2, dtype=dtype, device=dev)
+    pre = torch.empty(Bz, Tout, Cout, dtype=dtype, device=dev)
+    lens = torch.tensor([Tout, Tout - 3, 5], dtype=torch.int32)
+    ops.gemm(xp.to(dev), wk.to(dev), out, M=Tout, N=Cout, K=5 * Cin, lda=2 * Cin, ldb=5 * Cin, ldc=Cout // 2,
+             batch=Bz, a_s=(Tp * Cin, 0), c_s=(Tout * (Cout // 2), 0), bias=b.to(dev), act="glu",
+             preact=pre, ldp=Cout, p_s=(Tout * Cout, 0), row_lens=lens.to(dev), row_T=Tout)
+    y = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), b.double(), stride=2, padding=2)  # (B, Cout, Tout)
+    a, gt = y.chunk(2, dim=1)
+    ref = (a * torch.sigmoid(gt)).transpose(1, 2).clone()
+    for i, l in enumerate(lens.tolist()):
+        ref[i, l:] = 0
+    rtol, atol = _tol(dtype, 5 * Cin)
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=rtol, atol=atol * 4)
+    np.testing.assert_allclose(pre.cpu().double().numpy(), y.transpose(1, 2).numpy(), rtol=rtol, atol=atol * 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_two_level_and_splitk(dtype):
+    g = torch.Generator().manual_seed(11)
+    dev = "cuda"
+    Bz, H, T, dk = 3, 2, 50, 16
+    d = H * dk
+    q = _mk((Bz, T, d), dtype, g); k = _mk((Bz, T, d), dtype, g)
+    ldS = _pad_ld(T, dtype)
+    S = torch.zeros(Bz, H, T, ldS, dtype=dtype, device=dev)
+    # S[b,h] = q[b,:,h] @ k[b,:,h]^T  (z = b*H + h)
+    ops.gemm(q.to(dev), k.to(dev), S, M=T, N=T, K=dk, lda=d, ldb=d, ldc=ldS, batch=Bz * H, zdiv=H,
+             a_s=(T * d, dk), b_s=(T * d, dk), c_s=(H * T * ldS, T * ldS), alpha=0.25)
+    qh = q.double().view(Bz, T, H, dk).transpose(1, 2); kh = k.double().view(Bz, T, H, dk).transpose(1, 2)
+    ref = 0.25 * qh @ kh.transpose(-1, -2)
+    rtol, atol = _tol(dtype, dk)
+    np.testing.assert_allclose(S.cpu().double()[..., :T].numpy(), ref.numpy(), rtol=rtol, atol=atol * 4)
+    # split-K wgrad: dW[N,K] += dY^T[N,M] X[M,K] accumulated into fp32
+    M, N, K = 1000, 72, 40
+    dY = _mk((M, N), dtype, g); X = _mk((M, K), dtype, g)
+    dW = torch.ones(N, K, dtype=torch.float32, device=dev)
+    ops.gemm(dY.to(dev), X.to(dev), dW, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, a_kmajor=True, b_kmajor=True, split_k=4)
+    ref = 1.0 + dY.double().t() @ X.double()
+    np.testing.assert_allclose(dW.cpu().double().numpy(), ref.numpy(), rtol=1e-3, atol=1e-3 * ref.abs().max().item())
