@@ -46,9 +46,10 @@ int s2t_device_cu_count(void);
  * Epilogue, in order (v = fp32 accumulator):
  *   v += bias[n]; [GLU: out column c pairs accumulator columns c (value) and c + N/2 (gate),
  *   v = value*sigmoid(gate), C has N/2 columns]; [preact: store v before the activation];
- *   v = act(v); [dact_z: v *= act'(dact_z[m,n])]; v *= alpha; [residual: v += residual[m,n]];
- *   [row_lens: rows with (global_row % row_T) >= row_lens[global_row / row_T] are stored as 0];
- *   store (c_dtype).   global_row = z*M + m.
+ *   v = act(v); [dact_z: v *= act'(dact_z[m,n])]; v *= alpha;
+ *   [row_lens: v = 0 on rows with (global_row % row_T) >= row_lens[global_row / row_T]  (padded frames;
+ *    the reference masks the branch output, not the residual: modules/convolution.py:109-116)];
+ *   [residual: v += residual[m,n]]; store (c_dtype).   global_row = z*M + m.
  * split_k > 1 (wgrad): K is split over blockIdx.y and alpha*acc is atomically added to an fp32 C
  *   (no other epilogue stage allowed).
  * Alignment: A, B base pointers and strides must keep 16-byte alignment of every row start.
@@ -75,6 +76,116 @@ typedef struct s2t_gemm_args {
 } s2t_gemm_args;
 
 int s2t_gemm(const s2t_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (modules/layer_norm.py:30-35 -> torch.nn.LayerNorm, eps 1e-5).  x,y,dy,dx: [rows][cols] in
+ * `dtype`; gamma/beta and the saved statistics are fp32.  row_lens/row_T (optional): rows of padded
+ * frames are written as 0 in forward and carry no gradient in backward (the reference's per-layer
+ * masked_fill, s2t_transformer.py:1828-1836, and the conv-module input mask, convolution.py:86-88).
+ * dgamma/dbeta are ACCUMULATED (fp32).
+ * ------------------------------------------------------------------------------------------------ */
+int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, int64_t rows, int cols, float eps, const int32_t* row_lens, int row_T, void* stream);
+int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* dy, const float* mean,
+                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
+                      const int32_t* row_lens, int row_T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention probabilities from raw scores (fp32 in, `p_dtype` out), one row per (z, query):
+ *   s[j] = (S[j] + (BD ? BD[Tq-1-i+j] : 0)) * scale ; key j >= key_lens[z / H] or (causal && j > i) -> -inf ;
+ *   clamp != 0: s = clamp(s, -1e8, 1e8) (ESPnet flavour; -inf becomes -1e8) ; P = softmax_fp32(s).
+ * Replaces modules/multihead_attention.py:367-403 and modules/espnet_multihead_attention.py:108-129,292-311,343-350
+ * (rel_shift is an index computation here, not a pad/reshape/slice).  Backward:
+ *   dS = P * (dP - sum_j P*dP) * scale ; dBD (optional) [row][n] = dS[n-(Tq-1-i)] inside the band, 0 outside.
+ * ------------------------------------------------------------------------------------------------ */
+int s2t_attn_softmax_fwd(int p_dtype, const float* S, int64_t ldS, const float* BD, int64_t ldBD, void* P, int64_t ldP,
+                         int Z, int H, int Tq, int Tk, float scale, const int32_t* key_lens, int causal, int clamp,
+                         void* stream);
+int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP, int64_t ldDP, void* dS, int64_t ldDS,
+                         void* dBD, int64_t ldDBD, int Z, int Tq, int Tk, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / gather pieces of S2TTransformerEncoder.forward and TransformerDecoder
+ *   s2t_add_positions : x = scale*x + (t < lens[b] ? tab[t+pos_offset] : 0)       s2t_transformer.py:1773-1787
+ *   s2t_mask_rows     : zero padded frames in place                                s2t_transformer.py:1765,1828-1836
+ *   s2t_embedding_fwd : out = scale*E[tok] + tab[pos]  ;  _bwd: dE[tok] += scale*dOut (pad row skipped)
+ *                                                                                  models/transformer.py:1304-1323
+ *   s2t_glu_bwd       : backward of GLU over channels (Z = [value | gate])         subsampling.py:131-144, convolution.py:92
+ *   s2t_colsum_accum  : db[n] += sum_m dY[m,n] (bias gradients)
+ * ------------------------------------------------------------------------------------------------ */
+int s2t_add_positions(int dtype, void* x, const float* tab, const int32_t* lens, int64_t rows, int T, int d,
+                      float scale, int pos_offset, void* stream);
+int s2t_mask_rows(int dtype, void* x, const int32_t* lens, int64_t rows, int T, int d, void* stream);
+int s2t_embedding_fwd(int dtype, const int64_t* tokens, const int32_t* pos, const void* E, const float* tab, void* out,
+                      int64_t n, int d, float scale, void* stream);
+int s2t_embedding_bwd(int dtype, const int64_t* tokens, const void* dout, float* dE, int64_t n, int d, float scale,
+                      int64_t pad_idx, void* stream);
+int s2t_glu_bwd(int dtype, const void* Z, const void* dY, void* dZ, int64_t rows, int n, const int32_t* lens, int T,
+                void* stream);
+int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db, int64_t rows, int n, void* stream);
+int s2t_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int s2t_axpy(int dtype, const void* a, const void* b, void* y, float alpha, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer / gradient bookkeeping on FLAT fp32 buffers (one launch for the whole model)
+ *   s2t_adam_step   : fairseq Adam (optim/adam.py:146-226) reading {lr, step_size, grad_scale} from the
+ *                     device array `hyper` (so a captured hipGraph replays with fresh values); g is multiplied
+ *                     by grad_scale first; refreshes the bf16 weight shadow when given.
+ *   s2t_sumsq_accum : *out += sum g^2 (gradient norm, utils.py:328-369)
+ *   s2t_clip_coef   : hyper[2] = mult*min(1, max_norm/(sqrt(sumsq)*mult+1e-6)), hyper[3] = grad norm
+ *                     (trainer.py:729-741: multiply_grads(world/sample_size) then clip_grad_norm)
+ * ------------------------------------------------------------------------------------------------ */
+int s2t_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, int64_t n, float beta1, float beta2,
+                  float eps, float weight_decay, const float* hyper, void* stream);
+int s2t_clip_coef(const float* sumsq, float max_norm, float mult, float* hyper, void* stream);
+int s2t_sumsq_accum(const float* g, int64_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conformer convolution module core (modules/convolution.py:94-104), channels-last (B,T,C):
+ *   s2t_dwconv_fwd : y[b,t,c] = sum_k x[b,t+k-(K-1)/2,c] * w[c, flip ? K-1-k : k]   (zero outside [0,T)).
+ *        scale/shift != NULL : y = act(y*scale[c] + shift[c]), frames t >= lens[b] -> 0   (eval: BN folded)
+ *        stats != NULL       : stats[c] += sum y, stats[C+c] += sum y^2 over all (b,t)     (train: BN batch stats)
+ *        flip = 1 gives the input gradient of the same convolution.
+ *   s2t_dwconv_bwd_weight : dw[c,k] += sum_{b,t} dD[b,t,c] * G[b,t+k-(K-1)/2,c]
+ *   s2t_bn_finalize : stats -> scale = gamma*rstd, shift = beta - mean*scale (+ running-stat update, momentum,
+ *                     unbiased variance) ; training = 0 uses the running statistics.
+ *   s2t_bn_act_fwd  : out = act(D*scale + shift), padded frames -> 0
+ *   s2t_bn_act_bwd  : dD from dOut (two passes); sums[0:C] = sum du (= dbeta), sums[C:2C] = sum du*xhat (= dgamma)
+ * ------------------------------------------------------------------------------------------------ */
+int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, int flip,
+                   const float* scale, const float* shift, int act, const int32_t* lens, float* stats, void* stream);
+int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, int B, int T, int C, int K, void* stream);
+int s2t_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                    float* mean, float* rstd, int C, void* stream);
+int s2t_bn_act_fwd(int dtype, const void* D, void* out, const float* scale, const float* shift, int act, int64_t rows,
+                   int C, const int32_t* lens, int T, void* stream);
+int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const float* scale, const float* shift,
+                   const float* mean, const float* rstd, float* sums, float count, int act, int64_t rows, int C,
+                   const int32_t* lens, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vocabulary-wide kernels.  logits are row matrices [rows][ld] (batch-major: row = b*T + t).
+ *   s2t_argmax_lse     : per row first arg-max, its log-prob, logsumexp        s2t_ctc.py:312-324, utils.py:470-481
+ *   s2t_ctc_collapse   : pad->blank, unique_consecutive, drop blank, score      s2t_ctc.py:326-347
+ *   s2t_ls_cross_entropy : label-smoothed CE summed over non-pad rows + unit gradient
+ *                          sums[0..3] += loss, nll, n_correct, n_total          label_smoothed_cross_entropy.py:42-60
+ *   s2t_ctc_loss_fwd/_bwd : CTC alpha/beta (log space) and d nll / d logits     criterions/ctc.py:243-245,435-474
+ *                          (torch.nn.CTCLoss(blank, reduction="none", zero_infinity=True)); Lmax = 2*max(S)+1 (odd)
+ * ------------------------------------------------------------------------------------------------ */
+int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int V, int32_t* idx, float* top_lp,
+                   float* lse, void* stream);
+int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens, int B, int T, int blank,
+                     int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
+int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V, const int64_t* target,
+                         int64_t pad_idx, float eps, void* dlogits, int64_t ldd, float* sums, void* stream);
+int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
+                     const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens, int blank,
+                     float* alpha, float* beta, int Lmax, float* nll, void* stream);
+int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
+                     const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens, int blank,
+                     const float* alpha, const float* beta, int Lmax, const float* nll, float gscale, void* grad,
+                     int64_t ldg, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,15 +1,18 @@
-"""ctypes binding of libs2t_hip.so (the drop-in boundary, include/s2t_hip.h).
+"""ctypes binding of libs2t_hip.so (the drop-in boundary declared in include/s2t_hip.h).
 
+The prototypes are parsed from the header itself, so the binding cannot drift from the C-ABI.
 Loading is lazy and LOUD: a missing library raises ``RuntimeError`` — the product path never
 falls back to a CPU implementation.
 """
 import ctypes as C
 import os
+import re
 
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libs2t_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "s2t_hip.h")
 
 S2T_F32, S2T_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GLU = 0, 1, 2, 3
@@ -19,6 +22,8 @@ _lib = None
 
 
 class GemmArgs(C.Structure):
+    """Mirror of ``struct s2t_gemm_args`` (include/s2t_hip.h)."""
+
     _fields_ = [
         ("dtype", C.c_int32), ("c_dtype", C.c_int32),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
@@ -39,6 +44,29 @@ class GemmArgs(C.Structure):
     ]
 
 
+_CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float}
+
+
+def header_prototypes(path=HEADER_PATH):
+    """Parse ``int s2t_*(...);`` declarations of the header -> {name: [ctypes argtypes]}."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(s2t_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(C.POINTER(GemmArgs) if "s2t_gemm_args" in a else C.c_void_p)
+                else:
+                    ty = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPE[ty])
+        protos[name] = argtypes
+    return protos
+
+
 def lib():
     """Return the loaded library; raise loudly when it has not been built."""
     global _lib
@@ -48,24 +76,13 @@ def lib():
                 "s2t_amd: %s is missing — run `python -m s2t_amd.build` (or __graft_entry__.build()); "
                 "there is no CPU fallback for the HIP hot path" % LIB_PATH
             )
-        _lib = C.CDLL(LIB_PATH)
-        _declare(_lib)
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in header_prototypes().items():
+            fn = getattr(l, name)  # AttributeError here = header declares a symbol the library lacks
+            fn.restype = C.c_int
+            fn.argtypes = argtypes
+        _lib = l
     return _lib
-
-
-def _declare(l):
-    l.s2t_version.restype = C.c_int
-    l.s2t_device_cu_count.restype = C.c_int
-    l.s2t_gemm.restype = C.c_int
-    l.s2t_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
-    for name, argtypes in _PROTOS.items():
-        fn = getattr(l, name)
-        fn.restype = C.c_int
-        fn.argtypes = argtypes
-
-
-# name -> argtypes for the flat-argument entry points (filled in by ops modules' declarations below)
-_PROTOS = {}
 
 
 def dtype_id(t: torch.dtype) -> int:

@@ -1,0 +1,388 @@
+// Conformer convolution-module core: depthwise Conv1d over time + BatchNorm1d + activation
+// (reference: modules/convolution.py:94-104; BatchNorm statistics are taken over ALL (B,T) positions,
+// padded frames included, exactly as nn.BatchNorm1d on the (B,C,T) tensor does).
+//
+// Layout is channels-last (B, T, C): a lane owns 4 consecutive channels (8/16-byte accesses), a 256-thread
+// workgroup covers 256 channels x 32 time steps; the input window (32 + K - 1 rows) and the K x 256 weights
+// are staged in LDS, each thread then produces 8 consecutive time steps for its 4 channels.
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 32;      // time steps per workgroup tile
+constexpr int CCH = 256;    // channels per workgroup
+
+// stage rows [t0 - pad, t0 + TT + K - 1 - pad) of utterance b into LDS (fp32), zero outside [0,T)
+template <typename T>
+__device__ __forceinline__ void stage_rows(float* lds, const T* __restrict__ x, int64_t base_row, int T_, int C, int c0,
+                                           int t_first, int nrows) {
+  for (int idx = threadIdx.x; idx < nrows * 64; idx += 256) {
+    const int r = idx >> 6, cq = idx & 63;
+    const int t = t_first + r;
+    const int c = c0 + cq * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t >= 0 && t < T_ && c < C) ld4_as_f32<T>(x + (base_row + t) * C + c, v);
+    *reinterpret_cast<float4*>(lds + r * CCH + cq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// y[b,t,c] = sum_k x[b, t + k - pad, c] * w[c, flip ? K-1-k : k]  ; optional affine+act+mask epilogue; optional stats
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                     T* __restrict__ y, int B, int T_, int C, int K, int flip,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     int act, const int32_t* __restrict__ lens,
+                                                     float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int pad = (K - 1) / 2;
+  const int nrows = TT + K - 1;
+  float* lx = smem;                 // [nrows][256]
+  float* lw = smem + nrows * CCH;   // [K][256]
+  float* lred = lw + K * CCH;       // [2][4][256] (stats only)
+  const int t0 = blockIdx.x * TT;
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.z * CCH;
+  stage_rows<T>(lx, x, (int64_t)b * T_, T_, C, c0, t0 - pad, nrows);
+  for (int idx = threadIdx.x; idx < K * CCH; idx += 256) {
+    const int k = idx / CCH, c = idx % CCH;
+    lw[idx] = (c0 + c < C) ? w[(int64_t)(c0 + c) * K + (flip ? K - 1 - k : k)] : 0.f;
+  }
+  __syncthreads();
+  const int cq = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  float acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float4 w4 = *reinterpret_cast<const float4*>(lw + k * CCH + cq * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 x4 = *reinterpret_cast<const float4*>(lx + (tg * 8 + i + k) * CCH + cq * 4);
+      acc[i][0] += w4.x * x4.x;
+      acc[i][1] += w4.y * x4.y;
+      acc[i][2] += w4.z * x4.z;
+      acc[i][3] += w4.w * x4.w;
+    }
+  }
+  const int c = c0 + cq * 4;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (scale && c < C) {
+    ld4_as_f32<float>(scale + c, sc);
+    ld4_as_f32<float>(shift + c, sh);
+  }
+  const int len = lens ? lens[b] : T_;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int t = t0 + tg * 8 + i;
+    if (t < T_ && c < C) {
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[r] += acc[i][r];
+        s2[r] += acc[i][r] * acc[i][r];
+        o[r] = acc[i][r];
+        if (scale) o[r] = (t < len) ? act_apply(act, o[r] * sc[r] + sh[r]) : 0.f;
+      }
+      st4_from_f32<T>(y + ((int64_t)b * T_ + t) * C + c, o);
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lred[(0 * 4 + tg) * CCH + cq * 4 + r] = s1[r];
+      lred[(1 * 4 + tg) * CCH + cq * 4 + r] = s2[r];
+    }
+    __syncthreads();
+    const int cc = threadIdx.x;
+    if (c0 + cc < C) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        a += lred[(0 * 4 + g) * CCH + cc];
+        q += lred[(1 * 4 + g) * CCH + cc];
+      }
+      atomicAdd(stats + c0 + cc, a);
+      atomicAdd(stats + C + c0 + cc, q);
+    }
+  }
+}
+
+// dw[c,k] += sum_{b,t} dD[b,t,c] * G[b, t + k - pad, c]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ G, const T* __restrict__ dD,
+                                                           float* __restrict__ dw, int B, int T_, int C, int K,
+                                                           int tiles_t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int pad = (K - 1) / 2;
+  const int nrows = TT + K - 1;
+  float* lg = smem;                 // [nrows][256]
+  float* ld_ = smem + nrows * CCH;  // [TT][256]
+  const int c0 = blockIdx.z * CCH;
+  const int cq = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  float acc[8][4];  // k = tg + 4*kk
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  const int total = B * tiles_t;
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int b = tile / tiles_t, t0 = (tile % tiles_t) * TT;
+    __syncthreads();
+    stage_rows<T>(lg, G, (int64_t)b * T_, T_, C, c0, t0 - pad, nrows);
+    stage_rows<T>(ld_, dD, (int64_t)b * T_, T_, C, c0, t0, TT);
+    __syncthreads();
+    for (int t = 0; t < TT; ++t) {
+      const float4 d4 = *reinterpret_cast<const float4*>(ld_ + t * CCH + cq * 4);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = tg + 4 * kk;
+        if (k < K) {
+          const float4 g4 = *reinterpret_cast<const float4*>(lg + (t + k) * CCH + cq * 4);
+          acc[kk][0] += d4.x * g4.x;
+          acc[kk][1] += d4.y * g4.y;
+          acc[kk][2] += d4.z * g4.z;
+          acc[kk][3] += d4.w * g4.w;
+        }
+      }
+    }
+  }
+  const int c = c0 + cq * 4;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int k = tg + 4 * kk;
+    if (k < K) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (c + r < C) atomicAdd(dw + (int64_t)(c + r) * K + k, acc[kk][r]);
+    }
+  }
+}
+
+// per-channel BatchNorm bookkeeping (one workgroup): stats -> (scale, shift, mean, rstd) and running-stat update
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps, int training,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                   float* __restrict__ rstd_o, int C) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mean, var;
+    if (training) {
+      mean = stats[c] / count;
+      var = fmaxf(stats[C + c] / count - mean * mean, 0.f);
+      if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
+    }
+    const float rstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (mean_o) {
+      mean_o[c] = mean;
+      rstd_o[c] = rstd;
+    }
+  }
+}
+
+// out = act(D*scale + shift), padded rows -> 0
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ D, T* __restrict__ out,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act, int64_t rows, int C,
+                                                         const int32_t* __restrict__ lens, int Tn) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vpr = C / 4;
+  if (idx >= rows * vpr) return;
+  const int64_t row = idx / vpr;
+  const int c = (int)(idx % vpr) * 4;
+  float d[4], sc[4], sh[4], o[4];
+  ld4_as_f32<T>(D + row * C + c, d);
+  ld4_as_f32<float>(scale + c, sc);
+  ld4_as_f32<float>(shift + c, sh);
+  const bool masked = lens && (int)(row % Tn) >= lens[row / Tn];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = masked ? 0.f : act_apply(act, d[r] * sc[r] + sh[r]);
+  st4_from_f32<T>(out + row * C + c, o);
+}
+
+// pass 1 of the backward: sums[c] += du, sums[C+c] += du * xhat with du = dOut * act'(u), u = D*scale+shift
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ D, const T* __restrict__ dOut,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, int act, int64_t rows,
+                                                                int C, const int32_t* __restrict__ lens, int Tn,
+                                                                float* __restrict__ sums) {
+  __shared__ float red[2][4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    float sc[4], sh[4], mu[4], rs[4];
+    ld4_as_f32<float>(scale + c, sc);
+    ld4_as_f32<float>(shift + c, sh);
+    ld4_as_f32<float>(mean + c, mu);
+    ld4_as_f32<float>(rstd + c, rs);
+    for (int64_t m = (int64_t)blockIdx.y * 4 + w; m < rows; m += (int64_t)gridDim.y * 4) {
+      if (lens && (int)(m % Tn) >= lens[m / Tn]) continue;
+      float d[4], g[4];
+      ld4_as_f32<T>(D + m * C + c, d);
+      ld4_as_f32<T>(dOut + m * C + c, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float du = g[r] * act_grad(act, d[r] * sc[r] + sh[r]);
+        a1[r] += du;
+        a2[r] += du * (d[r] - mu[r]) * rs[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[0][w][lane * 4 + r] = a1[r];
+    red[1][w][lane * 4 + r] = a2[r];
+  }
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < C) {
+    atomicAdd(sums + cc, red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+    atomicAdd(sums + C + cc, red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+  }
+}
+
+// pass 2: dD = gamma*rstd * (du - s1/n - xhat * s2/n)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ D, const T* __restrict__ dOut,
+                                                               T* __restrict__ dD, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ sums, float count, int act,
+                                                               int64_t rows, int C, const int32_t* __restrict__ lens,
+                                                               int Tn) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vpr = C / 4;
+  if (idx >= rows * vpr) return;
+  const int64_t row = idx / vpr;
+  const int c = (int)(idx % vpr) * 4;
+  float d[4], g[4], sc[4], sh[4], mu[4], rs[4], s1[4], s2[4], o[4];
+  ld4_as_f32<T>(D + row * C + c, d);
+  ld4_as_f32<T>(dOut + row * C + c, g);
+  ld4_as_f32<float>(scale + c, sc);
+  ld4_as_f32<float>(shift + c, sh);
+  ld4_as_f32<float>(mean + c, mu);
+  ld4_as_f32<float>(rstd + c, rs);
+  ld4_as_f32<float>(sums + c, s1);
+  ld4_as_f32<float>(sums + C + c, s2);
+  const bool masked = lens && (int)(row % Tn) >= lens[row / Tn];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float du = masked ? 0.f : g[r] * act_grad(act, d[r] * sc[r] + sh[r]);
+    const float xh = (d[r] - mu[r]) * rs[r];
+    o[r] = sc[r] * (du - s1[r] / count - xh * s2[r] / count);  // scale = gamma * rstd
+  }
+  st4_from_f32<T>(dD + row * C + c, o);
+}
+
+// dynamic LDS above the 64 KiB default needs a one-time opt-in per kernel (never inside a stream capture)
+void ensure_lds_optin() {
+  static bool done = false;
+  if (done) return;
+  hipFuncSetAttribute((const void*)dwconv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  hipFuncSetAttribute((const void*)dwconv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  hipFuncSetAttribute((const void*)dwconv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  hipFuncSetAttribute((const void*)dwconv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  done = true;
+}
+
+}  // namespace
+
+extern "C" int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, int flip,
+                              const float* scale, const float* shift, int act, const int32_t* lens, float* stats,
+                              void* stream) {
+  if (!x || !w || !y || B <= 0 || T <= 0 || C <= 0 || K <= 0 || !(K & 1) || C % 4) return S2T_ERR_ARG;
+  if (K > 31) return S2T_ERR_UNSUPPORTED;
+  if ((scale == nullptr) != (shift == nullptr)) return S2T_ERR_ARG;
+  const size_t shm = (size_t)((TT + K - 1) * CCH + K * CCH + (stats ? 8 * CCH : 0)) * sizeof(float);
+  dim3 grid((T + TT - 1) / TT, B, (C + CCH - 1) / CCH), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  ensure_lds_optin();
+  if (dtype == S2T_F32) {
+    hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, shm, s, (const float*)x, w, (float*)y, B, T, C, K, flip, scale,
+                       shift, act, lens, stats);
+  } else if (dtype == S2T_BF16) {
+    hipLaunchKernelGGL(dwconv_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)x, w, (bf16_t*)y, B, T, C, K, flip,
+                       scale, shift, act, lens, stats);
+  } else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, int B, int T, int C, int K,
+                                     void* stream) {
+  if (!G || !dD || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || !(K & 1) || C % 4) return S2T_ERR_ARG;
+  if (K > 31) return S2T_ERR_UNSUPPORTED;
+  const size_t shm = (size_t)((TT + K - 1) * CCH + TT * CCH) * sizeof(float);
+  const int tiles_t = (T + TT - 1) / TT;
+  int nb = B * tiles_t;
+  if (nb > 256) nb = 256;
+  dim3 grid(nb, 1, (C + CCH - 1) / CCH), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  ensure_lds_optin();
+  if (dtype == S2T_F32) {
+    hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, grid, block, shm, s, (const float*)G, (const float*)dD, dw, B, T, C, K, tiles_t);
+  } else if (dtype == S2T_BF16) {
+    hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)G, (const bf16_t*)dD, dw, B, T, C, K, tiles_t);
+  } else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_bn_finalize(const float* stats, float count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, int training,
+                               float* scale, float* shift, float* mean, float* rstd, int C, void* stream) {
+  if (!gamma || !beta || !scale || !shift || C <= 0) return S2T_ERR_ARG;
+  if (training && !stats) return S2T_ERR_ARG;
+  if (!training && (!running_mean || !running_var)) return S2T_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, C);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_bn_act_fwd(int dtype, const void* D, void* out, const float* scale, const float* shift, int act,
+                              int64_t rows, int C, const int32_t* lens, int T, void* stream) {
+  if (!D || !out || !scale || !shift || rows < 0 || C <= 0 || C % 4) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)((rows * (C / 4) + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, block, 0, s, (const float*)D, (float*)out, scale, shift, act, rows, C, lens, T);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)D, (bf16_t*)out, scale, shift, act, rows, C, lens, T);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, float* sums /* [2C], zeroed */,
+                              float count, int act, int64_t rows, int C, const int32_t* lens, int T, void* stream) {
+  if (!D || !dOut || !dD || !scale || !shift || !mean || !rstd || !sums || rows <= 0 || C <= 0 || C % 4) return S2T_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t slices = (rows + 63) / 64;
+  if (slices > 128) slices = 128;
+  dim3 rgrid((C + 255) / 256, (unsigned)slices), block(256);
+  dim3 agrid((unsigned)((rows * (C / 4) + 255) / 256));
+  if (dtype == S2T_F32) {
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, rgrid, block, 0, s, (const float*)D, (const float*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, sums);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, agrid, block, 0, s, (const float*)D, (const float*)dOut, (float*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
+  } else if (dtype == S2T_BF16) {
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, rgrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, sums);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, agrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, (bf16_t*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
+  } else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}

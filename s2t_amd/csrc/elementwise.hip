@@ -1,0 +1,342 @@
+// HBM-bound elementwise / gather / reduction kernels of the S2T path.  All: fp32 arithmetic, 4-element
+// (8-byte bf16 / 16-byte f32) vectors per lane, consecutive lanes on consecutive addresses.
+#include "common.h"
+
+namespace {
+
+// ---- x[b,t,:] = scale * x[b,t,:] + (t < len[b] ? tab[t + pos_offset] : 0) ; optional row mask of x first ----
+// Encoder position step (s2t_transformer.py:1765-1787): sinusoidal positions of NON-PAD frames start at
+// padding_idx+1 = 2, padded frames get the zero row.
+template <typename T>
+__global__ __launch_bounds__(256) void add_pos_kernel(T* __restrict__ x, const float* __restrict__ tab,
+                                                      const int32_t* __restrict__ lens, int64_t rows, int Tn, int d,
+                                                      float scale, int pos_offset) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vec_per_row = d / 4;
+  if (idx >= rows * vec_per_row) return;
+  const int64_t row = idx / vec_per_row;
+  const int c = (int)(idx % vec_per_row) * 4;
+  const int b = (int)(row / Tn), t = (int)(row % Tn);
+  float v[4];
+  ld4_as_f32<T>(x + row * d + c, v);
+  const bool valid = !lens || t < lens[b];
+  float p[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid && tab) ld4_as_f32<float>(tab + (int64_t)(t + pos_offset) * d + c, p);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = v[r] * scale + p[r];
+  st4_from_f32<T>(x + row * d + c, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mask_rows_kernel(T* __restrict__ x, const int32_t* __restrict__ lens,
+                                                        int64_t rows, int Tn, int d) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vec_per_row = d / 4;
+  if (idx >= rows * vec_per_row) return;
+  const int64_t row = idx / vec_per_row;
+  const int c = (int)(idx % vec_per_row) * 4;
+  if ((int)(row % Tn) >= lens[row / Tn]) {
+    const float z[4] = {0.f, 0.f, 0.f, 0.f};
+    st4_from_f32<T>(x + row * d + c, z);
+  }
+}
+
+// ---- decoder embedding: out[n,:] = scale * E[tok[n],:] + tab[pos[n],:]  (models/transformer.py:1304-1323) ----
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const int32_t* __restrict__ pos,
+                                                        const T* __restrict__ E, const float* __restrict__ tab,
+                                                        T* __restrict__ out, int64_t n, int d, float scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vec_per_row = d / 4;
+  if (idx >= n * vec_per_row) return;
+  const int64_t row = idx / vec_per_row;
+  const int c = (int)(idx % vec_per_row) * 4;
+  float e[4], p[4] = {0.f, 0.f, 0.f, 0.f};
+  ld4_as_f32<T>(E + tok[row] * d + c, e);
+  if (tab) ld4_as_f32<float>(tab + (int64_t)pos[row] * d + c, p);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[r] = e[r] * scale + p[r];
+  st4_from_f32<T>(out + row * d + c, e);
+}
+// dE[tok[n],:] += scale * dOut[n,:]   (fp32 atomics; rows of one token collide only within a batch)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, const T* __restrict__ dout,
+                                                        float* __restrict__ dE, int64_t n, int d, float scale,
+                                                        int64_t pad_idx) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vec_per_row = d / 4;
+  if (idx >= n * vec_per_row) return;
+  const int64_t row = idx / vec_per_row;
+  const int c = (int)(idx % vec_per_row) * 4;
+  const int64_t t = tok[row];
+  if (t == pad_idx) return;  // nn.Embedding(padding_idx): no gradient for the pad row
+  float g[4];
+  ld4_as_f32<T>(dout + row * d + c, g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) atomicAdd(dE + t * d + c + r, g[r] * scale);
+}
+
+// ---- GLU backward: Z = [a | g] (M x 2n), dY (M x n) -> dZ (M x 2n); optional padded-row mask ----
+template <typename T>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ dY,
+                                                      T* __restrict__ dZ, int64_t rows, int n,
+                                                      const int32_t* __restrict__ lens, int Tn) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vec_per_row = n / 4;
+  if (idx >= rows * vec_per_row) return;
+  const int64_t row = idx / vec_per_row;
+  const int c = (int)(idx % vec_per_row) * 4;
+  float a[4], g[4], dy[4], da[4], dg[4];
+  ld4_as_f32<T>(Z + row * 2 * n + c, a);
+  ld4_as_f32<T>(Z + row * 2 * n + n + c, g);
+  ld4_as_f32<T>(dY + row * n + c, dy);
+  const bool masked = lens && (int)(row % Tn) >= lens[row / Tn];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float s = sigmoidf_(g[r]);
+    const float d = masked ? 0.f : dy[r];
+    da[r] = d * s;
+    dg[r] = d * a[r] * s * (1.f - s);
+  }
+  st4_from_f32<T>(dZ + row * 2 * n + c, da);
+  st4_from_f32<T>(dZ + row * 2 * n + n + c, dg);
+}
+
+// ---- bias gradient: db[n] += sum_m dY[m,n]  (fp32 accumulate) ----
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, int64_t ld, float* __restrict__ db,
+                                                     int64_t rows, int n) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < n) {
+    for (int64_t m = (int64_t)blockIdx.y * 4 + w; m < rows; m += (int64_t)gridDim.y * 4) {
+      float v[4];
+      if (c + 3 < n) ld4_as_f32<T>(dY + m * ld + c, v);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = c + r < n ? ld_as_f32<T>(dY + m * ld + c + r) : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += v[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][lane * 4 + r] = acc[r];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < n) atomicAdd(db + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- fp32 -> bf16 cast of a flat buffer (bf16 shadow of the fp32 master weights) ----
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                        int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float v[4];
+    ld4_as_f32<float>(src + i * 4, v);
+    st4_from_f32<bf16_t>(dst + i * 4, v);
+  }
+}
+
+// ---- y = a + alpha * b  (flat, same dtype) ----
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                                                   float alpha, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float u[4], v[4];
+    ld4_as_f32<T>(a + i * 4, u);
+    ld4_as_f32<T>(b + i * 4, v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] += alpha * v[r];
+    st4_from_f32<T>(y + i * 4, u);
+  }
+}
+
+// ---- fused Adam on flat fp32 buffers (optim/adam.py:146-226) + bf16 shadow refresh ----
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; p -= wd*lr*p ; p -= step_size * m / (sqrt(v) + eps)
+//   g is pre-multiplied by grad_scale (clip coefficient x 1/sample_size).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16_t* __restrict__ shadow, int64_t n4, float b1, float b2,
+                                                   float eps, float wd, const float* __restrict__ hyper) {
+  // hyper[0] = lr, hyper[1] = step_size = lr*sqrt(1-b2^t)/(1-b1^t), hyper[2] = grad_scale (device-resident so a
+  // captured hipGraph replays with fresh values)
+  const float lr = hyper[0], step_size = hyper[1], grad_scale = hyper[2];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float pv[4], gv[4], mv[4], vv[4];
+    ld4_as_f32<float>(p + i * 4, pv);
+    ld4_as_f32<float>(g + i * 4, gv);
+    ld4_as_f32<float>(m + i * 4, mv);
+    ld4_as_f32<float>(v + i * 4, vv);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gr = gv[r] * grad_scale;
+      mv[r] = b1 * mv[r] + (1.f - b1) * gr;
+      vv[r] = b2 * vv[r] + (1.f - b2) * gr * gr;
+      float pr = pv[r];
+      if (wd != 0.f) pr -= wd * lr * pr;
+      pr -= step_size * mv[r] / (sqrtf(vv[r]) + eps);
+      pv[r] = pr;
+    }
+    st4_from_f32<float>(p + i * 4, pv);
+    st4_from_f32<float>(m + i * 4, mv);
+    st4_from_f32<float>(v + i * 4, vv);
+    if (shadow) st4_from_f32<bf16_t>(shadow + i * 4, pv);
+  }
+}
+
+// ---- sum of squares of a flat fp32 buffer (grad-norm for clipping, utils.py:328-369) ----
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n4, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float v[4];
+    ld4_as_f32<float>(g + i * 4, v);
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+inline unsigned flat_grid(int64_t work_items) {
+  int64_t nb = (work_items + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  return (unsigned)nb;
+}
+
+}  // namespace
+
+extern "C" int s2t_add_positions(int dtype, void* x, const float* tab, const int32_t* lens, int64_t rows, int T, int d,
+                                 float scale, int pos_offset, void* stream) {
+  if (!x || rows < 0 || T <= 0 || d <= 0 || d % 4) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)((rows * (d / 4) + 255) / 256));
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(add_pos_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (float*)x, tab, lens, rows, T, d, scale, pos_offset);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(add_pos_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, tab, lens, rows, T, d, scale, pos_offset);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_mask_rows(int dtype, void* x, const int32_t* lens, int64_t rows, int T, int d, void* stream) {
+  if (!x || !lens || rows < 0 || T <= 0 || d <= 0 || d % 4) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)((rows * (d / 4) + 255) / 256));
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(mask_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (float*)x, lens, rows, T, d);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(mask_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, lens, rows, T, d);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_embedding_fwd(int dtype, const int64_t* tokens, const int32_t* pos, const void* E, const float* tab,
+                                 void* out, int64_t n, int d, float scale, void* stream) {
+  if (!tokens || !E || !out || n < 0 || d <= 0 || d % 4 || (tab && !pos)) return S2T_ERR_ARG;
+  if (n == 0) return S2T_OK;
+  dim3 grid((unsigned)((n * (d / 4) + 255) / 256));
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(embed_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, tokens, pos, (const float*)E, tab, (float*)out, n, d, scale);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, tokens, pos, (const bf16_t*)E, tab, (bf16_t*)out, n, d, scale);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_embedding_bwd(int dtype, const int64_t* tokens, const void* dout, float* dE, int64_t n, int d,
+                                 float scale, int64_t pad_idx, void* stream) {
+  if (!tokens || !dout || !dE || n < 0 || d <= 0 || d % 4) return S2T_ERR_ARG;
+  if (n == 0) return S2T_OK;
+  dim3 grid((unsigned)((n * (d / 4) + 255) / 256));
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, tokens, (const float*)dout, dE, n, d, scale, pad_idx);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, tokens, (const bf16_t*)dout, dE, n, d, scale, pad_idx);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_glu_bwd(int dtype, const void* Z, const void* dY, void* dZ, int64_t rows, int n,
+                           const int32_t* lens, int T, void* stream) {
+  if (!Z || !dY || !dZ || rows < 0 || n <= 0 || n % 4) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)((rows * (n / 4) + 255) / 256));
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)Z, (const float*)dY, (float*)dZ, rows, n, lens, T);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Z, (const bf16_t*)dY, (bf16_t*)dZ, rows, n, lens, T);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db, int64_t rows, int n, void* stream) {
+  if (!dY || !db || rows < 0 || n <= 0) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  if (ld % 4 || ((uintptr_t)dY % 16)) return S2T_ERR_ALIGN;
+  int64_t slices = (rows + 63) / 64;
+  if (slices > 128) slices = 128;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)slices);
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dY, ld, db, rows, n);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dY, ld, db, rows, n);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 0 || n % 4) return S2T_ERR_ARG;
+  if (n == 0) return S2T_OK;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_axpy(int dtype, const void* a, const void* b, void* y, float alpha, int64_t n, void* stream) {
+  if (!a || !b || !y || n < 0 || n % 4) return S2T_ERR_ARG;
+  if (n == 0) return S2T_OK;
+  dim3 grid(flat_grid(n / 4));
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(axpy_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)y, alpha, n / 4);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(axpy_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, alpha, n / 4);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, int64_t n, float beta1,
+                             float beta2, float eps, float weight_decay, const float* hyper, void* stream) {
+  if (!p || !g || !m || !v || !hyper || n < 0 || n % 4) return S2T_ERR_ARG;
+  if (n == 0) return S2T_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (bf16_t*)bf16_shadow, n / 4, beta1, beta2, eps, weight_decay, hyper);
+  return S2T_LAUNCH_CHECK();
+}
+
+// hyper[2] = mult * min(1, max_norm / (sqrt(sumsq)*mult + 1e-6)) ; hyper[3] = sqrt(sumsq)*mult (the reported grad norm)
+// (trainer.py:729-741: grads are multiplied by world/sample_size, then clipped by their global norm, utils.py:328-369)
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float mult, float* __restrict__ hyper) {
+  const float norm = sqrtf(sumsq[0]) * mult;
+  float c = 1.f;
+  if (max_norm > 0.f) c = fminf(1.f, max_norm / (norm + 1e-6f));
+  hyper[2] = mult * c;
+  hyper[3] = norm;
+}
+extern "C" int s2t_clip_coef(const float* sumsq, float max_norm, float mult, float* hyper, void* stream) {
+  if (!sumsq || !hyper) return S2T_ERR_ARG;
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, mult, hyper);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_sumsq_accum(const float* g, int64_t n, float* out, void* stream) {
+  if (!g || !out || n < 0 || n % 4) return S2T_ERR_ARG;
+  if (n == 0) return S2T_OK;
+  int64_t nb = (n / 4 + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, n / 4, out);
+  return S2T_LAUNCH_CHECK();
+}

@@ -249,15 +249,15 @@ struct Epi {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+    if (row_masked(grow)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = 0.f;
+    }
     if (R) {
       float q[4];
       ld<TC>(R + (int64_t)m * p.ldr + n0, vec_r, nv, q);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] += q[r];
-    }
-    if (row_masked(grow)) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = 0.f;
     }
     st<TC>(C + (int64_t)m * p.ldc + n0, vec_c, nv, v);
   }

@@ -1,0 +1,414 @@
+// Vocabulary-wide row kernels: log-softmax statistics / arg-max (CTC greedy decode), label-smoothed
+// cross-entropy (+gradient), CTC loss (alpha/beta in log space, +gradient).  All statistics in fp32,
+// whatever the logits' storage type (reference contract: utils.py:470-481 log_softmax in fp32).
+#include "common.h"
+
+namespace {
+
+struct MaxIdx {
+  float v;
+  int i;
+};
+__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {
+  // larger value wins; ties -> LOWER index (torch.topk(1)/argmax on CPU return the first maximal element)
+  if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+  return a;
+}
+
+// one workgroup per row: max, argmax (first), logsumexp
+template <typename T>
+__device__ __forceinline__ void row_stats(const T* __restrict__ row, int V, float& mx, int& arg, float& lse) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ float ss[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  MaxIdx m{-INFINITY, 0x7fffffff};
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float x = ld_as_f32<T>(row + c);
+    m = better(m, MaxIdx{x, c});
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxIdx t{__shfl_xor(m.v, o, 64), __shfl_xor(m.i, o, 64)};
+    m = better(m, t);
+  }
+  if (lane == 0) {
+    sv[w] = m.v;
+    si[w] = m.i;
+  }
+  __syncthreads();
+  m = MaxIdx{sv[0], si[0]};
+#pragma unroll
+  for (int k = 1; k < 4; ++k) m = better(m, MaxIdx{sv[k], si[k]});
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) s += __expf(ld_as_f32<T>(row + c) - m.v);
+  s = wave_sum(s);
+  if (lane == 0) ss[w] = s;
+  __syncthreads();
+  s = ss[0] + ss[1] + ss[2] + ss[3];
+  mx = m.v;
+  arg = m.i;
+  lse = m.v + __logf(s);
+  __syncthreads();
+}
+
+// ---- CTC greedy, stage 1: per frame arg-max + its log-probability (s2t_ctc.py:312-328) ----
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_lse_kernel(const T* __restrict__ logits, int64_t ld, int V,
+                                                         int32_t* __restrict__ idx, float* __restrict__ top_lp,
+                                                         float* __restrict__ lse_out) {
+  const int64_t row = blockIdx.x;
+  float mx, lse;
+  int arg;
+  row_stats<T>(logits + row * ld, V, mx, arg, lse);
+  if (threadIdx.x == 0) {
+    if (idx) idx[row] = arg;
+    if (top_lp) top_lp[row] = mx - lse;
+    if (lse_out) lse_out[row] = lse;
+  }
+}
+
+// ---- CTC greedy, stage 2: pad->blank, unique_consecutive, drop blank (s2t_ctc.py:329-347); one WG / utterance ----
+__global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ top_lp,
+                                                            const int32_t* __restrict__ lens, int T, int blank,
+                                                            int64_t* __restrict__ out_tokens,
+                                                            int32_t* __restrict__ out_lens,
+                                                            float* __restrict__ out_scores) {
+  __shared__ int scan[1024];
+  __shared__ float sred[16];
+  __shared__ int carry;
+  const int b = blockIdx.x;
+  const int len = lens[b];
+  if (threadIdx.x == 0) carry = 0;
+  float score = 0.f;
+  __syncthreads();
+  for (int base = 0; base < T; base += 1024) {
+    const int t = base + threadIdx.x;
+    int cur = blank, prev = -1;
+    if (t < T) {
+      const int raw = idx[(int64_t)b * T + t];
+      cur = t < len ? raw : blank;
+      if (t > 0) {
+        const int rawp = idx[(int64_t)b * T + t - 1];
+        prev = (t - 1) < len ? rawp : blank;
+      }
+      // the score uses the UNMASKED arg-max (s2t_ctc.py:327-328)
+      if (raw != blank) score += top_lp[(int64_t)b * T + t];
+    }
+    const int keep = (t < T && cur != blank && cur != prev) ? 1 : 0;
+    scan[threadIdx.x] = keep;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int v = threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+      __syncthreads();
+      scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int pos = carry + scan[threadIdx.x] - keep;
+    if (keep) out_tokens[(int64_t)b * T + pos] = cur;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += scan[1023];
+    __syncthreads();
+  }
+  score = wave_sum(score);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = score;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int k = 0; k < 16; ++k) s += sred[k];
+    out_scores[b] = -s;
+    out_lens[b] = carry;
+  }
+}
+
+// ---- label-smoothed cross entropy, forward + unit gradient (label_smoothed_cross_entropy.py:42-60) ----
+// per row r (token): lp = log_softmax(x); nll = -lp[y]; smooth = -sum(lp)
+//   loss += (1-eps-eps_i)*nll + eps_i*smooth  with eps_i = eps/(V-1);  pad rows contribute nothing.
+//   d loss / d x[c] = (1-eps-eps_i)*(p[c] - [c==y]) + eps_i*(V*p[c] - 1)
+// sums[0] += loss, sums[1] += nll, sums[2] += n_correct, sums[3] += n_total (atomics, fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void ls_ce_kernel(const T* __restrict__ logits, int64_t ld, int V,
+                                                    const int64_t* __restrict__ target, int64_t pad_idx, float eps,
+                                                    T* __restrict__ dlogits, int64_t ldd, float* __restrict__ sums) {
+  __shared__ float ssum[4];
+  const int64_t row = blockIdx.x;
+  const int64_t y = target[row];
+  const T* x = logits + row * ld;
+  T* dx = dlogits ? dlogits + row * ldd : nullptr;
+  if (y == pad_idx) {
+    if (dx)
+      for (int c = threadIdx.x; c < V; c += 256) st_from_f32<T>(dx + c, 0.f);
+    return;
+  }
+  float mx, lse;
+  int arg;
+  row_stats<T>(x, V, mx, arg, lse);
+  const float eps_i = eps / (V - 1);
+  const float wn = 1.f - eps - eps_i;
+  float sx = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float xv = ld_as_f32<T>(x + c);
+    sx += xv;
+    if (dx) {
+      const float p = __expf(xv - lse);
+      st_from_f32<T>(dx + c, wn * (p - (c == y ? 1.f : 0.f)) + eps_i * (V * p - 1.f));
+    }
+  }
+  sx = wave_sum(sx);
+  if ((threadIdx.x & 63) == 0) ssum[threadIdx.x >> 6] = sx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sx = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    const float nll = lse - ld_as_f32<T>(x + y);
+    const float smooth = V * lse - sx;
+    atomicAdd(sums + 0, wn * nll + eps_i * smooth);
+    atomicAdd(sums + 1, nll);
+    atomicAdd(sums + 2, arg == (int)y ? 1.f : 0.f);
+    atomicAdd(sums + 3, 1.f);
+  }
+}
+
+// ---- CTC loss (torch.nn.CTCLoss(blank, reduction='none', zero_infinity=True), criterions/ctc.py:243-245,467-472) ----
+// logits are batch-major [B][T][V] (row = b*T + t); log-probs are formed on the fly as x - lse[row].
+// One workgroup per utterance, one thread per extended-label state s in [0, 2S+1) (S <= 511).
+__device__ __forceinline__ float lse2(float a, float b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  const float m = fmaxf(a, b);
+  return m + __logf(__expf(a - m) + __expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) { return lse2(lse2(a, b), c); }
+
+template <typename T>
+__global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restrict__ logits, int64_t ld, int V, int T_,
+                                                              const float* __restrict__ lse,
+                                                              const int64_t* __restrict__ targets, int ldt,
+                                                              const int32_t* __restrict__ tgt_lens,
+                                                              const int32_t* __restrict__ in_lens, int blank,
+                                                              float* __restrict__ alpha, float* __restrict__ beta,
+                                                              int Lmax, float* __restrict__ nll_out) {
+  extern __shared__ float sh[];  // [2][Lmax+2] ping-pong
+  const int b = blockIdx.x;
+  const int S = tgt_lens[b];
+  const int L = 2 * S + 1;
+  const int Tb = min(in_lens[b], T_);
+  const int s = threadIdx.x;
+  const bool act = s < L;
+  int lab = blank;
+  bool skip = false;
+  if (act && (s & 1)) {
+    lab = (int)targets[(int64_t)b * ldt + (s >> 1)];
+    if (s >= 3) skip = lab != (int)targets[(int64_t)b * ldt + (s >> 1) - 1];
+  }
+  bool skipn = false;  // transition s -> s+2 allowed (for beta)
+  if (act && (s & 1) && s + 2 < L) skipn = lab != (int)targets[(int64_t)b * ldt + (s >> 1) + 1];
+  float* bufA = sh;
+  float* bufB = sh + (Lmax + 2);
+  const int64_t row0 = (int64_t)b * T_;
+  float* al = alpha + (int64_t)b * T_ * Lmax;
+  float* be = beta + (int64_t)b * T_ * Lmax;
+  if (Tb <= 0) {
+    if (s == 0) nll_out[b] = 0.f;
+    return;
+  }
+  // ---- alpha
+  {
+    float a = -INFINITY;
+    if (act && s < 2) a = ld_as_f32<T>(logits + row0 * ld + lab) - lse[row0];
+    if (act) {
+      al[s] = a;
+      bufA[s] = a;
+    }
+    __syncthreads();
+    float* cur = bufA;
+    float* nxt = bufB;
+    for (int t = 1; t < Tb; ++t) {
+      float v = -INFINITY;
+      if (act) {
+        const float a0 = cur[s];
+        const float a1 = s >= 1 ? cur[s - 1] : -INFINITY;
+        const float a2 = (s >= 2 && skip) ? cur[s - 2] : -INFINITY;
+        const float lp = ld_as_f32<T>(logits + (row0 + t) * ld + lab) - lse[row0 + t];
+        const float m = lse3(a0, a1, a2);
+        v = m == -INFINITY ? -INFINITY : m + lp;
+        nxt[s] = v;
+        al[(int64_t)t * Lmax + s] = v;
+      }
+      __syncthreads();
+      float* tmp = cur;
+      cur = nxt;
+      nxt = tmp;
+    }
+    if (s == 0) {
+      const float l1 = cur[L - 1];
+      const float l2 = L >= 2 ? cur[L - 2] : -INFINITY;
+      const float ll = lse2(l1, l2);
+      nll_out[b] = -ll;  // +inf when no alignment exists; zero_infinity is applied by the gradient kernel / host
+    }
+    __syncthreads();
+  }
+  // ---- beta
+  {
+    float v = -INFINITY;
+    if (act && s >= L - 2) v = ld_as_f32<T>(logits + (row0 + Tb - 1) * ld + lab) - lse[row0 + Tb - 1];
+    if (act) {
+      be[(int64_t)(Tb - 1) * Lmax + s] = v;
+      bufA[s] = v;
+    }
+    __syncthreads();
+    float* cur = bufA;
+    float* nxt = bufB;
+    for (int t = Tb - 2; t >= 0; --t) {
+      if (act) {
+        const float b0 = cur[s];
+        const float b1 = s + 1 < L ? cur[s + 1] : -INFINITY;
+        const float b2 = (s + 2 < L && skipn) ? cur[s + 2] : -INFINITY;
+        const float lp = ld_as_f32<T>(logits + (row0 + t) * ld + lab) - lse[row0 + t];
+        const float m = lse3(b0, b1, b2);
+        const float r = m == -INFINITY ? -INFINITY : m + lp;
+        nxt[s] = r;
+        be[(int64_t)t * Lmax + s] = r;
+      }
+      __syncthreads();
+      float* tmp = cur;
+      cur = nxt;
+      nxt = tmp;
+    }
+  }
+}
+
+// grad[b,t,c] = gscale * ( p[c] - sum_{s: ext[s]==c} exp(alpha+beta + nll - lp[c]) )   for t < len, finite nll; else 0
+// one workgroup per frame row; the <= 2S+1 states are merged per label in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ logits, int64_t ld, int V, int T_,
+                                                       const float* __restrict__ lse,
+                                                       const int64_t* __restrict__ targets, int ldt,
+                                                       const int32_t* __restrict__ tgt_lens,
+                                                       const int32_t* __restrict__ in_lens, int blank,
+                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                       int Lmax, const float* __restrict__ nll, float gscale,
+                                                       T* __restrict__ grad, int64_t ldg) {
+  extern __shared__ float occ[];  // [Lmax] exp(alpha+beta+nll) per state, then merged per label
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / T_), t = (int)(row % T_);
+  T* g = grad + row * ldg;
+  const float n = nll[b];
+  const int Tb = min(in_lens[b], T_);
+  if (t >= Tb || !(n < INFINITY)) {
+    for (int c = threadIdx.x; c < V; c += 256) st_from_f32<T>(g + c, 0.f);
+    return;
+  }
+  const int S = tgt_lens[b];
+  const int L = 2 * S + 1;
+  const T* x = logits + row * ld;
+  const float l = lse[row];
+  for (int c = threadIdx.x; c < V; c += 256) st_from_f32<T>(g + c, gscale * __expf(ld_as_f32<T>(x + c) - l));
+  const float* al = alpha + ((int64_t)b * T_ + t) * Lmax;
+  const float* be = beta + ((int64_t)b * T_ + t) * Lmax;
+  for (int s = threadIdx.x; s < L; s += 256) {
+    const float ab = al[s] + be[s];
+    occ[s] = (ab == -INFINITY || ab != ab) ? 0.f : __expf(ab + n);  // = exp(alpha+beta)/P(y|x)
+  }
+  __syncthreads();
+  // owner of a label = its first state; blanks (even s) are owned by s = 0
+  for (int s = threadIdx.x; s < L; s += 256) {
+    int lab;
+    bool owner;
+    if (!(s & 1)) {
+      lab = blank;
+      owner = s == 0;
+    } else {
+      lab = (int)targets[(int64_t)b * ldt + (s >> 1)];
+      owner = true;
+      for (int q = 0; q < (s >> 1); ++q)
+        if ((int)targets[(int64_t)b * ldt + q] == lab) { owner = false; break; }
+      if (lab == blank) owner = false;  // (labels never equal blank in valid input)
+    }
+    if (!owner) continue;
+    float sum = 0.f;
+    if (!(s & 1)) {
+      for (int q = 0; q < L; q += 2) sum += occ[q];
+    } else {
+      for (int q = (s >> 1); q < S; ++q)
+        if ((int)targets[(int64_t)b * ldt + q] == lab) sum += occ[2 * q + 1];
+    }
+    // occ holds exp(alpha+beta+nll); alpha*beta double counts lp[t,lab] once -> divide by p
+    const float xv = ld_as_f32<T>(x + lab);
+    const float lp = xv - l;
+    const float p = __expf(lp);
+    st_from_f32<T>(g + lab, gscale * (p - sum * __expf(-lp)));
+  }
+}
+
+}  // namespace
+
+extern "C" int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int V, int32_t* idx,
+                              float* top_lp, float* lse, void* stream) {
+  if (!logits || rows < 0 || V <= 0 || ld < V) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)rows), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(argmax_lse_kernel<float>, grid, block, 0, s, (const float*)logits, ld, V, idx, top_lp, lse);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(argmax_lse_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)logits, ld, V, idx, top_lp, lse);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens, int B, int T, int blank,
+                                int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream) {
+  if (!idx || !top_lp || !lens || !out_tokens || !out_lens || !out_scores || B <= 0 || T <= 0) return S2T_ERR_ARG;
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, idx, top_lp, lens, T, blank,
+                     out_tokens, out_lens, out_scores);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V,
+                                    const int64_t* target, int64_t pad_idx, float eps, void* dlogits, int64_t ldd,
+                                    float* sums, void* stream) {
+  if (!logits || !target || !sums || rows < 0 || V <= 1 || ld < V) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)rows), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(ls_ce_kernel<float>, grid, block, 0, s, (const float*)logits, ld, V, target, pad_idx, eps, (float*)dlogits, ldd, sums);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(ls_ce_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)logits, ld, V, target, pad_idx, eps, (bf16_t*)dlogits, ldd, sums);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
+                                const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens,
+                                int blank, float* alpha, float* beta, int Lmax, float* nll, void* stream) {
+  if (!logits || !lse || !targets || !tgt_lens || !in_lens || !alpha || !beta || !nll) return S2T_ERR_ARG;
+  if (B <= 0 || T <= 0 || V <= 0 || Lmax <= 0 || Lmax > 1023 || !(Lmax & 1)) return S2T_ERR_ARG;
+  int threads = (Lmax + 63) / 64 * 64;
+  const size_t shm = 2 * (size_t)(Lmax + 2) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B), dim3(threads), shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B), dim3(threads), shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
+                                const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens,
+                                int blank, const float* alpha, const float* beta, int Lmax, const float* nll,
+                                float gscale, void* grad, int64_t ldg, void* stream) {
+  if (!logits || !lse || !targets || !tgt_lens || !in_lens || !alpha || !beta || !nll || !grad) return S2T_ERR_ARG;
+  if (B <= 0 || T <= 0 || V <= 0 || Lmax <= 0) return S2T_ERR_ARG;
+  const size_t shm = (size_t)Lmax * sizeof(float);
+  dim3 grid((unsigned)((int64_t)B * T)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(ctc_grad_kernel<float>, grid, block, shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (float*)grad, ldg);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (bf16_t*)grad, ldg);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}

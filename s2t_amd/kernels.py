@@ -1,0 +1,187 @@
+"""Thin, allocation-explicit Python wrappers over the C-ABI kernels (no autograd here)."""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(
+    A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int,
+    lda: int, ldb: int, ldc: int, a_kmajor=False, b_kmajor=False,
+    batch=1, zdiv=1, a_s=(0, 0), b_s=(0, 0), c_s=(0, 0),
+    bias: Optional[torch.Tensor] = None, act=None, alpha=1.0,
+    residual: Optional[torch.Tensor] = None, ldr=0,
+    preact: Optional[torch.Tensor] = None, ldp=0, p_s=(0, 0),
+    dact_z: Optional[torch.Tensor] = None, ldz=0, dact=None,
+    row_lens: Optional[torch.Tensor] = None, row_T=0, split_k=1,
+):
+    """Raw s2t_gemm call: C = epilogue(A_op[M,K] @ B_op[K,N]); see include/s2t_hip.h."""
+    L.require_cuda(A, B, out, bias, residual, preact, dact_z, row_lens)
+    a = L.GemmArgs()
+    a.dtype = L.dtype_id(A.dtype)
+    assert B.dtype == A.dtype
+    a.c_dtype = L.dtype_id(out.dtype)
+    a.M, a.N, a.K = M, N, K
+    a.a_kmajor, a.b_kmajor = int(a_kmajor), int(b_kmajor)
+    a.A, a.lda = A.data_ptr(), lda
+    a.B, a.ldb = B.data_ptr(), ldb
+    a.C, a.ldc = out.data_ptr(), ldc
+    a.batch, a.zdiv = batch, zdiv
+    a.a_s0, a.a_s1 = a_s
+    a.b_s0, a.b_s1 = b_s
+    a.c_s0, a.c_s1 = c_s
+    a.bias = _ptr(bias)
+    a.bias_dtype = L.dtype_id(bias.dtype) if bias is not None else 0
+    a.act = L.ACT_IDS[act]
+    a.alpha = alpha
+    a.residual, a.ldr = _ptr(residual), ldr
+    if residual is not None:
+        assert residual.dtype == out.dtype
+    a.preact, a.ldp = _ptr(preact), ldp
+    a.p_s0, a.p_s1 = p_s
+    if preact is not None:
+        assert preact.dtype == out.dtype
+    a.dact_z, a.ldz, a.dact = _ptr(dact_z), ldz, L.ACT_IDS[dact]
+    if dact_z is not None:
+        assert dact_z.dtype == out.dtype
+    a.row_lens, a.row_T = _ptr(row_lens), row_T
+    if row_lens is not None:
+        assert row_lens.dtype == torch.int32
+    a.split_k = split_k
+    L.check(L.lib().s2t_gemm(C.byref(a), L.stream_ptr()), "s2t_gemm")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# flat-argument entry points
+# ----------------------------------------------------------------------------------------------
+def _call(name, *args):
+    L.check(getattr(L.lib(), name)(*args, L.stream_ptr()), name)
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, row_lens=None, row_T=0):
+    L.require_cuda(x, y)
+    _call("s2t_layernorm_fwd", L.dtype_id(x.dtype), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+          _ptr(mean), _ptr(rstd), rows, cols, eps, _ptr(row_lens), row_T)
+
+
+def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0):
+    _call("s2t_layernorm_bwd", L.dtype_id(x.dtype), x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), mean.data_ptr(),
+          rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, cols, _ptr(row_lens), row_T)
+
+
+def attn_softmax_fwd(S, ldS, BD, ldBD, P, ldP, Z, H, Tq, Tk, scale, key_lens=None, causal=False, clamp=False):
+    assert S.dtype == torch.float32 and (BD is None or BD.dtype == torch.float32)
+    _call("s2t_attn_softmax_fwd", L.dtype_id(P.dtype), S.data_ptr(), ldS, _ptr(BD), ldBD, P.data_ptr(), ldP, Z, H, Tq,
+          Tk, scale, _ptr(key_lens), int(causal), int(clamp))
+
+
+def attn_softmax_bwd(P, ldP, dP, ldDP, dS, ldDS, dBD, ldDBD, Z, Tq, Tk, scale):
+    assert dP.dtype == torch.float32
+    _call("s2t_attn_softmax_bwd", L.dtype_id(P.dtype), P.data_ptr(), ldP, dP.data_ptr(), ldDP, dS.data_ptr(), ldDS,
+          _ptr(dBD), ldDBD, Z, Tq, Tk, scale)
+
+
+def add_positions(x, tab, lens, rows, T, d, scale=1.0, pos_offset=2):
+    _call("s2t_add_positions", L.dtype_id(x.dtype), x.data_ptr(), _ptr(tab), _ptr(lens), rows, T, d, scale, pos_offset)
+
+
+def mask_rows(x, lens, rows, T, d):
+    _call("s2t_mask_rows", L.dtype_id(x.dtype), x.data_ptr(), lens.data_ptr(), rows, T, d)
+
+
+def embedding_fwd(tokens, pos, E, tab, out, n, d, scale):
+    _call("s2t_embedding_fwd", L.dtype_id(E.dtype), tokens.data_ptr(), _ptr(pos), E.data_ptr(), _ptr(tab), out.data_ptr(),
+          n, d, scale)
+
+
+def embedding_bwd(tokens, dout, dE, n, d, scale, pad_idx):
+    _call("s2t_embedding_bwd", L.dtype_id(dout.dtype), tokens.data_ptr(), dout.data_ptr(), dE.data_ptr(), n, d, scale,
+          pad_idx)
+
+
+def glu_bwd(Z, dY, dZ, rows, n, lens=None, T=0):
+    _call("s2t_glu_bwd", L.dtype_id(Z.dtype), Z.data_ptr(), dY.data_ptr(), dZ.data_ptr(), rows, n, _ptr(lens), T)
+
+
+def colsum_accum(dY, ld, db, rows, n):
+    _call("s2t_colsum_accum", L.dtype_id(dY.dtype), dY.data_ptr(), ld, db.data_ptr(), rows, n)
+
+
+def cast_f32_to_bf16(src, dst, n):
+    _call("s2t_cast_f32_to_bf16", src.data_ptr(), dst.data_ptr(), n)
+
+
+def axpy(a, b, y, alpha, n):
+    _call("s2t_axpy", L.dtype_id(a.dtype), a.data_ptr(), b.data_ptr(), y.data_ptr(), alpha, n)
+
+
+def adam_step(p, g, m, v, shadow, n, beta1, beta2, eps, wd, hyper):
+    _call("s2t_adam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow), n, beta1, beta2, eps,
+          wd, hyper.data_ptr())
+
+
+def clip_coef(sumsq, max_norm, mult, hyper):
+    _call("s2t_clip_coef", sumsq.data_ptr(), max_norm, mult, hyper.data_ptr())
+
+
+def sumsq_accum(g, n, out):
+    _call("s2t_sumsq_accum", g.data_ptr(), n, out.data_ptr())
+
+
+def dwconv_fwd(x, w, y, B, T, C, K, flip=False, scale=None, shift=None, act=None, lens=None, stats=None):
+    _call("s2t_dwconv_fwd", L.dtype_id(x.dtype), x.data_ptr(), w.data_ptr(), y.data_ptr(), B, T, C, K, int(flip),
+          _ptr(scale), _ptr(shift), L.ACT_IDS[act], _ptr(lens), _ptr(stats))
+
+
+def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
+    _call("s2t_dwconv_bwd_weight", L.dtype_id(G.dtype), G.data_ptr(), dD.data_ptr(), dw.data_ptr(), B, T, C, K)
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, C):
+    _call("s2t_bn_finalize", _ptr(stats), float(count), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean),
+          _ptr(running_var), momentum, eps, int(training), scale.data_ptr(), shift.data_ptr(), _ptr(mean), _ptr(rstd), C)
+
+
+def bn_act_fwd(D, out, scale, shift, act, rows, C, lens=None, T=0):
+    _call("s2t_bn_act_fwd", L.dtype_id(D.dtype), D.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+          L.ACT_IDS[act], rows, C, _ptr(lens), T)
+
+
+def bn_act_bwd(D, dOut, dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens=None, T=0):
+    _call("s2t_bn_act_bwd", L.dtype_id(D.dtype), D.data_ptr(), dOut.data_ptr(), dD.data_ptr(), scale.data_ptr(),
+          shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), float(count), L.ACT_IDS[act], rows, C,
+          _ptr(lens), T)
+
+
+def argmax_lse(logits, ld, rows, V, idx=None, top_lp=None, lse=None):
+    _call("s2t_argmax_lse", L.dtype_id(logits.dtype), logits.data_ptr(), ld, rows, V, _ptr(idx), _ptr(top_lp), _ptr(lse))
+
+
+def ctc_collapse(idx, top_lp, lens, B, T, blank, out_tokens, out_lens, out_scores):
+    _call("s2t_ctc_collapse", idx.data_ptr(), top_lp.data_ptr(), lens.data_ptr(), B, T, blank, out_tokens.data_ptr(),
+          out_lens.data_ptr(), out_scores.data_ptr())
+
+
+def ls_cross_entropy(logits, ld, rows, V, target, pad_idx, eps, dlogits, ldd, sums):
+    _call("s2t_ls_cross_entropy", L.dtype_id(logits.dtype), logits.data_ptr(), ld, rows, V, target.data_ptr(), pad_idx,
+          eps, _ptr(dlogits), ldd, sums.data_ptr())
+
+
+def ctc_loss_fwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll):
+    _call("s2t_ctc_loss_fwd", L.dtype_id(logits.dtype), logits.data_ptr(), ld, B, T, V, lse.data_ptr(),
+          targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), beta.data_ptr(),
+          Lmax, nll.data_ptr())
+
+
+def ctc_loss_bwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale,
+                 grad, ldg):
+    _call("s2t_ctc_loss_bwd", L.dtype_id(logits.dtype), logits.data_ptr(), ld, B, T, V, lse.data_ptr(),
+          targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), beta.data_ptr(),
+          Lmax, nll.data_ptr(), gscale, grad.data_ptr(), ldg)

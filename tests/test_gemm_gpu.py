@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from s2t_amd import ops  # noqa: E402
+from s2t_amd import kernels as ops  # noqa: E402
 
 
 def _mk(shape, dtype, g, scale=1.0):
@@ -74,9 +74,10 @@ def test_epilogue_bias_act_residual_mask(dtype):
                  residual=R.to(dev), ldr=N, preact=pre if act else None, ldp=N, row_lens=lens.to(dev), row_T=T)
         z = A.double() @ W.double().t() + bias.double()
         a = {"relu": torch.relu, "swish": lambda v: v * torch.sigmoid(v), None: lambda v: v}[act](z)
-        ref = R.double() + 0.5 * a
         mask = (torch.arange(T)[None, :] >= lens[:, None]).reshape(-1)
-        ref[mask] = 0
+        br = 0.5 * a
+        br[mask] = 0  # the branch is masked, the residual is not
+        ref = R.double() + br
         rtol, atol = _tol(dtype, K)
         np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=rtol, atol=atol * 4)
         if act:

@@ -1,0 +1,350 @@
+"""GPU parity of the non-GEMM HIP kernels against the CPU oracle (oracle/s2t_oracle.py) / plain fp32 maths.
+Every test runs the f32 and the bf16 storage flavour; statistics are fp32 in both."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import s2t_oracle as O  # noqa: E402
+from s2t_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+def rnd(shape, dtype, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def close(got, ref, dtype, mul=1.0):
+    t = tol(dtype)
+    np.testing.assert_allclose(got.detach().cpu().double().numpy(), ref.detach().double().numpy(), rtol=t["rtol"] * mul,
+                               atol=t["atol"] * mul)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cols", [32, 256, 260])
+def test_layernorm_fwd_bwd(dtype, cols):
+    g = torch.Generator().manual_seed(cols)
+    B, T = 3, 11
+    rows = B * T
+    x = rnd((rows, cols), dtype, g)
+    w = 1 + 0.1 * torch.randn(cols, generator=g)
+    b = 0.1 * torch.randn(cols, generator=g)
+    dy = rnd((rows, cols), dtype, g)
+    lens = torch.tensor([11, 7, 1], dtype=torch.int32)
+    for use_mask in (False, True):
+        xd, y = x.to(DEV), torch.empty(rows, cols, dtype=dtype, device=DEV)
+        mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+        ld = lens.to(DEV) if use_mask else None
+        K.layernorm_fwd(xd, w.to(DEV), b.to(DEV), y, mean, rstd, rows, cols, 1e-5, ld, T)
+        xr = x.float().clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = O.layer_norm(xr, wr, br)
+        if use_mask:
+            m = (torch.arange(T)[None] >= lens[:, None]).reshape(-1)
+            ref = ref.masked_fill(m[:, None], 0.0)
+        close(y, ref, dtype)
+        ref.backward(dy.float())
+        dx = torch.empty_like(xd)
+        dg, db = torch.ones(cols, device=DEV), torch.ones(cols, device=DEV)  # accumulate semantics
+        K.layernorm_bwd(xd, w.to(DEV), dy.to(DEV), mean, rstd, dx, dg, db, rows, cols, ld, T)
+        close(dx, xr.grad, dtype, 2)
+        close(dg - 1, wr.grad, dtype, 8)
+        close(db - 1, br.grad, dtype, 8)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Tq,Tk,causal,rel", [(50, 50, False, False), (9, 70, False, False), (13, 13, True, False),
+                                              (50, 50, False, True), (300, 300, False, True)])
+def test_attn_softmax_fwd_bwd(dtype, Tq, Tk, causal, rel):
+    g = torch.Generator().manual_seed(Tq * 3 + Tk)
+    Bz, H = 2, 2
+    Z = Bz * H
+    ldS = (Tk + 7) // 8 * 8
+    ldB = (2 * Tq - 1 + 7) // 8 * 8
+    S = torch.randn(Z, Tq, ldS, generator=g) * 3
+    BD = torch.randn(Z, Tq, ldB, generator=g) * 3 if rel else None
+    klen = torch.tensor([Tk, max(1, Tk - 5)], dtype=torch.int32)
+    scale = 0.37
+    P = torch.full((Z, Tq, ldS), 9.0, dtype=dtype, device=DEV)
+    K.attn_softmax_fwd(S.to(DEV), ldS, BD.to(DEV) if rel else None, ldB, P, ldS, Z, H, Tq, Tk, scale, klen.to(DEV),
+                       causal, rel)
+    s = S[..., :Tk].clone().requires_grad_(True)
+    bdr = None
+    sc = s
+    if rel:
+        bdr = BD.clone().requires_grad_(True)
+        idx = (Tq - 1) - torch.arange(Tq)[:, None] + torch.arange(Tk)[None, :]
+        sc = s + torch.gather(bdr, 2, idx[None].expand(Z, Tq, Tk))
+    sc = sc * scale
+    kmask = torch.arange(Tk)[None, :] >= klen[:, None]  # (B, Tk)
+    sc = sc.masked_fill(kmask.repeat_interleave(H, 0)[:, None, :], float("-inf"))
+    if causal:
+        sc = sc + torch.triu(torch.full((Tq, Tk), float("-inf")), 1)
+    if rel:
+        sc = sc.clamp(-1e8, 1e8)
+    ref = torch.softmax(sc, -1)
+    close(P[..., :Tk], ref, dtype)
+    assert (P[..., Tk:] == 0).all()
+    dP = torch.randn(Z, Tq, ldS, generator=g)
+    ref.backward(dP[..., :Tk])
+    dS = torch.empty(Z, Tq, ldS, dtype=dtype, device=DEV)
+    dBD = torch.full((Z, Tq, ldB), 5.0, dtype=dtype, device=DEV) if rel else None
+    # backward consumes the probabilities as stored (bf16-rounded in bf16 mode)
+    K.attn_softmax_bwd(P, ldS, dP.to(DEV), ldS, dS, ldS, dBD, ldB, Z, Tq, Tk, scale)
+    close(dS[..., :Tk], s.grad, dtype, 2)
+    if rel:
+        close(dBD[..., : 2 * Tq - 1], bdr.grad[..., : 2 * Tq - 1], dtype, 2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_positions_mask_embedding(dtype):
+    g = torch.Generator().manual_seed(3)
+    B, T, d = 3, 9, 32
+    x = rnd((B, T, d), dtype, g)
+    lens = torch.tensor([9, 6, 4], dtype=torch.int32)
+    tab = O.sinusoidal_table(T + 2, d)
+    xd = x.to(DEV)
+    K.add_positions(xd, tab.to(DEV), lens.to(DEV), B * T, T, d, 1.0, 2)
+    mask = O.lengths_to_padding_mask(lens.long(), T)
+    ref = x.float() + O.sinusoidal_positions(mask, d)
+    close(xd, ref, dtype)
+    xd = x.to(DEV)
+    K.mask_rows(xd, lens.to(DEV), B * T, T, d)
+    close(xd, x.float().masked_fill(mask[:, :, None], 0.0), dtype)
+    # embedding fwd/bwd
+    V = 17
+    E = rnd((V, d), dtype, g)
+    tok = torch.tensor([[2, 5, 6, 7, 1], [2, 9, 1, 1, 1]])
+    pos = ((tok != 1).long().cumsum(1) * (tok != 1).long() + 1).int()
+    tab2 = O.sinusoidal_table(8, d)
+    out = torch.empty(2, 5, d, dtype=dtype, device=DEV)
+    K.embedding_fwd(tok.to(DEV), pos.to(DEV), E.to(DEV), tab2.to(DEV), out, 10, d, math.sqrt(d))
+    ref = math.sqrt(d) * E.float()[tok] + O.sinusoidal_positions(tok, d)
+    close(out, ref, dtype, 4)
+    dout = rnd((2, 5, d), dtype, g)
+    dE = torch.zeros(V, d, device=DEV)
+    K.embedding_bwd(tok.to(DEV), dout.to(DEV), dE, 10, d, math.sqrt(d), 1)
+    refE = torch.zeros(V, d)
+    refE.index_add_(0, tok.reshape(-1), dout.float().reshape(-1, d) * math.sqrt(d))
+    refE[1] = 0
+    close(dE, refE, torch.float32, 4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_glu_bwd_colsum_cast_axpy(dtype):
+    g = torch.Generator().manual_seed(4)
+    B, T, n = 2, 7, 24
+    rows = B * T
+    Z = rnd((rows, 2 * n), dtype, g)
+    dY = rnd((rows, n), dtype, g)
+    lens = torch.tensor([7, 3], dtype=torch.int32)
+    dZ = torch.empty(rows, 2 * n, dtype=dtype, device=DEV)
+    K.glu_bwd(Z.to(DEV), dY.to(DEV), dZ, rows, n, lens.to(DEV), T)
+    zr = Z.float().clone().requires_grad_(True)
+    y = O.glu_channels(zr)
+    m = (torch.arange(T)[None] >= lens[:, None]).reshape(-1)
+    y.backward(dY.float().masked_fill(m[:, None], 0.0))
+    close(dZ, zr.grad, dtype)
+    # colsum over a strided view, odd width
+    M, N = 1000, 70
+    dy = rnd((M, 72), dtype, g)
+    db = torch.ones(N, device=DEV)
+    K.colsum_accum(dy.to(DEV), 72, db, M, N)
+    close(db - 1, dy.float()[:, :N].sum(0), torch.float32, 50 if dtype == torch.bfloat16 else 5)
+    src = torch.randn(1024, generator=g)
+    dst = torch.empty(1024, dtype=torch.bfloat16, device=DEV)
+    K.cast_f32_to_bf16(src.to(DEV), dst, 1024)
+    assert torch.equal(dst.cpu(), src.to(torch.bfloat16))
+    a, b = rnd((512,), dtype, g), rnd((512,), dtype, g)
+    yv = torch.empty(512, dtype=dtype, device=DEV)
+    K.axpy(a.to(DEV), b.to(DEV), yv, 0.5, 512)
+    close(yv, a.float() + 0.5 * b.float(), dtype)
+
+
+def test_adam_clip_matches_fairseq_formula():
+    g = torch.Generator().manual_seed(5)
+    n = 4096
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = p.to(DEV), gr.to(DEV), m.to(DEV), v.to(DEV)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    hyper = torch.zeros(4, device=DEV)
+    sumsq = torch.zeros(1, device=DEV)
+    lr, b1, b2, eps, max_norm, mult = 2e-3, 0.9, 0.98, 1e-8, 10.0, 0.25
+    pr, mr, vr = p.clone().double(), m.clone().double(), v.clone().double()
+    for step in (1, 2, 3):
+        sumsq.zero_()
+        K.sumsq_accum(gd, n, sumsq)
+        K.clip_coef(sumsq, max_norm, mult, hyper)
+        bc1, bc2 = 1 - b1**step, 1 - b2**step
+        hyper[0] = lr
+        hyper[1] = lr * math.sqrt(bc2) / bc1
+        K.adam_step(pd, gd, md, vd, shadow, n, b1, b2, eps, 0.0, hyper)
+        # reference: trainer.py:729-741 (multiply, clip) + optim/adam.py:146-226
+        ge = gr.double() * mult
+        norm = ge.norm()
+        ge = ge * min(1.0, max_norm / (norm + 1e-6))
+        mr = b1 * mr + (1 - b1) * ge
+        vr = b2 * vr + (1 - b2) * ge * ge
+        pr = pr - (lr * math.sqrt(bc2) / bc1) * mr / (vr.sqrt() + eps)
+        assert abs(hyper[3].item() - norm.item()) < 1e-3 * norm.item()
+    np.testing.assert_allclose(pd.cpu().double().numpy(), pr.numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Kw", [15, 31])
+def test_dwconv_bn_act_fwd_bwd(dtype, Kw):
+    g = torch.Generator().manual_seed(Kw)
+    B, T, C = 3, 45, 32
+    lens = torch.tensor([45, 30, 8], dtype=torch.int32)
+    x = rnd((B, T, C), dtype, g)
+    w = torch.randn(C, Kw, generator=g) * 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    rm, rv = 0.1 * torch.randn(C, generator=g), 1 + 0.2 * torch.rand(C, generator=g)
+    dOut = rnd((B, T, C), dtype, g)
+    for act in ("relu", "swish"):
+        # ---- training path: conv (+stats) -> finalize -> bn_act
+        xd = x.to(DEV)
+        D = torch.empty_like(xd)
+        stats = torch.zeros(2 * C, device=DEV)
+        K.dwconv_fwd(xd, w.to(DEV), D, B, T, C, Kw, stats=stats)
+        scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+        rmd, rvd = rm.to(DEV), rv.to(DEV)
+        K.bn_finalize(stats, B * T, gamma.to(DEV), beta.to(DEV), rmd, rvd, 0.1, 1e-5, True, scale, shift, mean, rstd, C)
+        out = torch.empty_like(xd)
+        K.bn_act_fwd(D, out, scale, shift, act, B * T, C, lens.to(DEV), T)
+        xr = x.float().clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        gr_, br_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        conv = torch.nn.functional.conv1d(xr.transpose(1, 2), wr[:, None, :], None, padding=(Kw - 1) // 2, groups=C).transpose(1, 2)
+        mu = conv.mean((0, 1))
+        var = ((conv - mu) ** 2).mean((0, 1))
+        u = (conv - mu) / torch.sqrt(var + 1e-5) * gr_ + br_
+        pm = O.lengths_to_padding_mask(lens.long(), T)
+        ref = O.activation(act, u).masked_fill(pm[:, :, None], 0.0)
+        close(D, conv, dtype, 2)
+        close(out, ref, dtype, 4)
+        n = B * T
+        close(rmd, 0.9 * rm + 0.1 * mu, torch.float32, 200 if dtype == torch.bfloat16 else 5)
+        close(rvd, 0.9 * rv + 0.1 * var * n / (n - 1), torch.float32, 200 if dtype == torch.bfloat16 else 5)
+        # ---- backward
+        ref.backward(dOut.float())
+        dD = torch.empty_like(xd)
+        sums = torch.zeros(2 * C, device=DEV)
+        K.bn_act_bwd(D, dOut.to(DEV), dD, scale, shift, mean, rstd, sums, n, act, n, C, lens.to(DEV), T)
+        dG = torch.empty_like(xd)
+        K.dwconv_fwd(dD, w.to(DEV), dG, B, T, C, Kw, flip=True)
+        dw = torch.zeros(C, Kw, device=DEV)
+        K.dwconv_bwd_weight(xd, dD, dw, B, T, C, Kw)
+        m = 1 if dtype == torch.float32 else 1
+        close(dG, xr.grad, dtype, 8 * m)
+        # bf16: ~135 products of bf16-rounded dD and x per entry, |dw| up to ~10 -> absolute error ~2e-2
+        close(dw, wr.grad, torch.float32, 2500 if dtype == torch.bfloat16 else 20)
+        close(sums[:C], br_.grad, torch.float32, 400 if dtype == torch.bfloat16 else 20)
+        close(sums[C:], gr_.grad, torch.float32, 400 if dtype == torch.bfloat16 else 20)
+        # ---- eval path: BN folded into the conv epilogue
+        K.bn_finalize(None, 0, gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 0.1, 1e-5, False, scale, shift, None, None, C)
+        out2 = torch.empty_like(xd)
+        K.dwconv_fwd(xd, w.to(DEV), out2, B, T, C, Kw, scale=scale, shift=shift, act=act, lens=lens.to(DEV))
+        ue = (conv.detach() - rm) / torch.sqrt(rv + 1e-5) * gamma + beta
+        close(out2, O.activation(act, ue).masked_fill(pm[:, :, None], 0.0), dtype, 4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_ctc_greedy_kernels(dtype):
+    g = torch.Generator().manual_seed(6)
+    B, T, V = 4, 1100, 300  # T > 1024 exercises the chunked scan
+    logits = rnd((B, T, V), dtype, g, 2.0)
+    # long runs + blanks so that collapse matters
+    runs = torch.randint(0, 6, (B, T // 4 + 1), generator=g).repeat_interleave(4, 1)[:, :T]
+    logits.scatter_(2, runs[:, :, None], 20.0)
+    lens = torch.tensor([1100, 900, 513, 1], dtype=torch.int32)
+    ld = logits.to(DEV)
+    idx = torch.empty(B * T, dtype=torch.int32, device=DEV)
+    top = torch.empty(B * T, device=DEV)
+    K.argmax_lse(ld, V, B * T, V, idx, top, None)
+    toks = torch.zeros(B, T, dtype=torch.int64, device=DEV)
+    olen = torch.zeros(B, dtype=torch.int32, device=DEV)
+    osc = torch.zeros(B, device=DEV)
+    K.ctc_collapse(idx, top, lens.to(DEV), B, T, 0, toks, olen, osc)
+    hyps, scores = O.ctc_greedy(logits.float().transpose(0, 1), O.lengths_to_padding_mask(lens.long(), T))
+    for b in range(B):
+        n = int(olen[b])
+        assert n == len(hyps[b])
+        assert toks[b, :n].cpu().tolist() == hyps[b].tolist()  # bit-exact ids
+    np.testing.assert_allclose(osc.cpu().numpy(), scores.numpy(), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_argmax_ties_pick_lowest_index(dtype):
+    x = torch.zeros(3, 500, dtype=dtype)
+    x[0, [7, 300]] = 5.0
+    x[1, [499, 2, 256]] = 1.0
+    idx = torch.empty(3, dtype=torch.int32, device=DEV)
+    K.argmax_lse(x.to(DEV), 500, 3, 500, idx, None, None)
+    assert idx.cpu().tolist() == [7, 2, 0]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_label_smoothed_ce(dtype):
+    g = torch.Generator().manual_seed(7)
+    rows, V = 23, 1000
+    logits = rnd((rows, V), dtype, g, 2.0)
+    tgt = torch.randint(2, V, (rows,), generator=g)
+    tgt[[3, 9, 22]] = 1
+    sums = torch.zeros(4, device=DEV)
+    dl = torch.empty(rows, V, dtype=dtype, device=DEV)
+    K.ls_cross_entropy(logits.to(DEV), V, rows, V, tgt.to(DEV), 1, 0.1, dl, V, sums)
+    lr = logits.float().clone().requires_grad_(True)
+    loss, nll = O.label_smoothed_nll(lr, tgt, 0.1)
+    loss.backward()
+    nc, tot = O.ce_accuracy(logits.float(), tgt)
+    s = sums.cpu()
+    assert abs(s[0].item() - loss.item()) < 2e-4 * abs(loss.item())
+    assert abs(s[1].item() - nll.item()) < 2e-4 * abs(nll.item())
+    assert int(s[2]) == nc and int(s[3]) == tot
+    close(dl, lr.grad, dtype, 1 if dtype == torch.float32 else 0.5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_ctc_loss_fwd_bwd(dtype):
+    g = torch.Generator().manual_seed(8)
+    B, T, V = 5, 40, 23
+    logits = rnd((B, T, V), dtype, g, 1.5)
+    tg = [torch.tensor([4, 4, 5, 9]), torch.tensor([3]), torch.tensor([], dtype=torch.long),
+          torch.tensor([7, 8, 7, 8, 7, 8, 7, 8, 7, 8, 7, 8]), torch.randint(1, V, (15,), generator=g)]
+    in_lens = torch.tensor([40, 33, 10, 11, 40], dtype=torch.int32)  # utt 3: 12 labels in 11 frames -> infeasible
+    S = max(len(t) for t in tg)
+    tmat = torch.zeros(B, S, dtype=torch.int64)
+    for b, t in enumerate(tg):
+        tmat[b, : len(t)] = t
+    tl = torch.tensor([len(t) for t in tg], dtype=torch.int32)
+    Lmax = 2 * S + 1
+    ld = logits.to(DEV)
+    lse = torch.empty(B * T, device=DEV)
+    K.argmax_lse(ld, V, B * T, V, None, None, lse)
+    alpha = torch.full((B, T, Lmax), float("nan"), device=DEV)
+    beta = torch.full((B, T, Lmax), float("nan"), device=DEV)
+    nll = torch.empty(B, device=DEV)
+    K.ctc_loss_fwd(ld, V, B, T, V, lse, tmat.to(DEV), S, tl.to(DEV), in_lens.to(DEV), 0, alpha, beta, Lmax, nll)
+    lr = logits.float().clone().requires_grad_(True)
+    lp = torch.log_softmax(lr.transpose(0, 1), -1)
+    ref = O.ctc_nll(lp, tg, in_lens.long())
+    got = nll.cpu()
+    assert torch.isinf(got[3])  # raw nll; zero_infinity is applied by the caller / gradient kernel
+    got = torch.where(torch.isinf(got), torch.zeros_like(got), got)
+    np.testing.assert_allclose(got.numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-3 if dtype == torch.float32 else 5e-2)
+    (0.3 * ref.sum()).backward()
+    grad = torch.empty(B, T, V, dtype=dtype, device=DEV)
+    K.ctc_loss_bwd(ld, V, B, T, V, lse, tmat.to(DEV), S, tl.to(DEV), in_lens.to(DEV), 0, alpha, beta, Lmax, nll, 0.3, grad, V)
+    close(grad, lr.grad, dtype, 5 if dtype == torch.float32 else 1)
