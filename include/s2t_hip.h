@@ -73,6 +73,7 @@ typedef struct s2t_gemm_args {
   const void* dact_z;   int64_t ldz; int32_t dact; /* multiply by act'(z) with act = dact; z is c_dtype, same batch strides as C */
   const int32_t* row_lens; int32_t row_T;
   int32_t split_k;
+  int32_t c_atomic; /* 1: add alpha*acc to fp32 C with atomics even when split_k == 1 (several batches share one C) */
 } s2t_gemm_args;
 
 int s2t_gemm(const s2t_gemm_args* args, void* stream);
@@ -101,8 +102,10 @@ int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* 
 int s2t_attn_softmax_fwd(int p_dtype, const float* S, int64_t ldS, const float* BD, int64_t ldBD, void* P, int64_t ldP,
                          int Z, int H, int Tq, int Tk, float scale, const int32_t* key_lens, int causal, int clamp,
                          void* stream);
+/* dBD rows are laid out HEAD-major ((h*B + b)*Tq + i) so that per head the (b,i) rows form one matrix for the
+ * linear_pos weight-gradient GEMM; S/P/dP/dS rows are z-major (z = b*H + h). */
 int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP, int64_t ldDP, void* dS, int64_t ldDS,
-                         void* dBD, int64_t ldDBD, int Z, int Tq, int Tk, float scale, void* stream);
+                         void* dBD, int64_t ldDBD, int Z, int H, int Tq, int Tk, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / gather pieces of S2TTransformerEncoder.forward and TransformerDecoder
@@ -116,6 +119,9 @@ int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP,
 int s2t_add_positions(int dtype, void* x, const float* tab, const int32_t* lens, int64_t rows, int T, int d,
                       float scale, int pos_offset, void* stream);
 int s2t_mask_rows(int dtype, void* x, const int32_t* lens, int64_t rows, int T, int d, void* stream);
+/* out[m, 0:n] = x[m, 0:n] + bias[0:n]  (q + pos_bias_u / q + pos_bias_v, espnet_multihead_attention.py:335-337) */
+int s2t_bias_add_rows(int dtype, const void* x, int64_t ldx, const float* bias, void* out, int64_t ldo, int64_t rows,
+                      int n, void* stream);
 int s2t_embedding_fwd(int dtype, const int64_t* tokens, const int32_t* pos, const void* E, const float* tab, void* out,
                       int64_t n, int d, float scale, void* stream);
 int s2t_embedding_bwd(int dtype, const int64_t* tokens, const void* dout, float* dE, int64_t n, int d, float scale,

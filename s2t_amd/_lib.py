@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("dact_z", C.c_void_p), ("ldz", C.c_int64), ("dact", C.c_int32),
         ("row_lens", C.c_void_p), ("row_T", C.c_int32),
         ("split_k", C.c_int32),
+        ("c_atomic", C.c_int32),
     ]
 
 

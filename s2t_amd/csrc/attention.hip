@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const TP* __restr
                                                                const float* __restrict__ dP, int64_t ldDP,
                                                                TP* __restrict__ dS, int64_t ldDS,
                                                                TP* __restrict__ dBD, int64_t ldDBD,
-                                                               int64_t rows_total, int Tq, int Tk, float scale) {
+                                                               int64_t rows_total, int H, int Tq, int Tk, float scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_total) return;
@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const TP* __restr
   }
   if (dBD) {
     // row of width ldDBD: entries n in [Tq-1-i, Tq-1-i+Tk) carry dS[j], everything else is zero
-    TP* o = dBD + row * ldDBD;
+    const int64_t z = row / Tq;
+    const int64_t nb = rows_total / Tq / H;  // utterances
+    const int64_t orow = ((z % H) * nb + z / H) * Tq + i;  // head-major row
+    TP* o = dBD + orow * ldDBD;
     const int n0 = Tq - 1 - i;
     for (int n = lane; n < n0; n += 64) st_from_f32<TP>(o + n, 0.f);
 #pragma unroll
@@ -133,9 +136,9 @@ extern "C" int s2t_attn_softmax_fwd(int p_dtype, const float* S, int64_t ldS, co
 }
 
 extern "C" int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP, int64_t ldDP, void* dS,
-                                    int64_t ldDS, void* dBD, int64_t ldDBD, int Z, int Tq, int Tk, float scale,
+                                    int64_t ldDS, void* dBD, int64_t ldDBD, int Z, int H, int Tq, int Tk, float scale,
                                     void* stream) {
-  if (!P || !dP || !dS || Z <= 0 || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
+  if (!P || !dP || !dS || Z <= 0 || H <= 0 || Z % H || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
   if (Tk > 3072 || ldP < Tk || ldDP < Tk || ldDS < Tk) return S2T_ERR_UNSUPPORTED;
   if (dBD && (Tq != Tk || ldDBD < 2 * Tq - 1)) return S2T_ERR_ARG;
   const int64_t rows = (int64_t)Z * Tq;
@@ -143,10 +146,10 @@ extern "C" int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
     DISPATCH_NPL(float, attn_softmax_bwd_kernel, (const float*)P, ldP, dP, ldDP, (float*)dS, ldDS, (float*)dBD, ldDBD,
-                 rows, Tq, Tk, scale);
+                 rows, H, Tq, Tk, scale);
   else if (dtype == S2T_BF16)
     DISPATCH_NPL(bf16_t, attn_softmax_bwd_kernel, (const bf16_t*)P, ldP, dP, ldDP, (bf16_t*)dS, ldDS, (bf16_t*)dBD,
-                 ldDBD, rows, Tq, Tk, scale);
+                 ldDBD, rows, H, Tq, Tk, scale);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

@@ -41,6 +41,24 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(T* __restrict__ x, const
   }
 }
 
+// ---- out[m, :n] = x[m, :n] + bias[:n] (strided rows) ----
+template <typename T>
+__global__ __launch_bounds__(256) void bias_add_rows_kernel(const T* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ bias, T* __restrict__ out,
+                                                            int64_t ldo, int64_t rows, int n) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vpr = n / 4;
+  if (idx >= rows * vpr) return;
+  const int64_t row = idx / vpr;
+  const int c = (int)(idx % vpr) * 4;
+  float v[4], b[4];
+  ld4_as_f32<T>(x + row * ldx + c, v);
+  ld4_as_f32<float>(bias + c, b);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] += b[r];
+  st4_from_f32<T>(out + row * ldo + c, v);
+}
+
 // ---- decoder embedding: out[n,:] = scale * E[tok[n],:] + tab[pos[n],:]  (models/transformer.py:1304-1323) ----
 template <typename T>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const int32_t* __restrict__ pos,
@@ -231,6 +249,19 @@ extern "C" int s2t_mask_rows(int dtype, void* x, const int32_t* lens, int64_t ro
     hipLaunchKernelGGL(mask_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (float*)x, lens, rows, T, d);
   else if (dtype == S2T_BF16)
     hipLaunchKernelGGL(mask_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, lens, rows, T, d);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_bias_add_rows(int dtype, const void* x, int64_t ldx, const float* bias, void* out, int64_t ldo,
+                                 int64_t rows, int n, void* stream) {
+  if (!x || !bias || !out || rows < 0 || n <= 0 || n % 4 || ldx % 4 || ldo % 4) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)((rows * (n / 4) + 255) / 256));
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(bias_add_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, bias, (float*)out, ldo, rows, n);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(bias_add_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, bias, (bf16_t*)out, ldo, rows, n);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

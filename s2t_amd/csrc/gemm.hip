@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   }
 
   // ---------------- epilogue ----------------
-  if (p.split_k > 1) {
+  if (p.split_k > 1 || p.c_atomic) {
     float* C = reinterpret_cast<float*>(p.C) + coff;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -447,7 +447,7 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   if (p.dtype == S2T_F32 && p.c_dtype != S2T_F32) return S2T_ERR_DTYPE;
   if ((p.lda % epb) || (p.ldb % epb) || ((uintptr_t)p.A % 16) || ((uintptr_t)p.B % 16)) return S2T_ERR_ALIGN;
   if ((p.a_s0 % epb) || (p.a_s1 % epb) || (p.b_s0 % epb) || (p.b_s1 % epb)) return S2T_ERR_ALIGN;
-  if (p.split_k > 1) {
+  if (p.split_k > 1 || p.c_atomic) {
     if (p.c_dtype != S2T_F32 || p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens)
       return S2T_ERR_UNSUPPORTED;
   }

@@ -1,0 +1,96 @@
+"""Flat parameter storage sized for 288 GB of HBM3E: ONE contiguous fp32 master buffer, ONE fp32 gradient
+buffer and (bf16 mode) ONE bf16 shadow buffer for the whole model.
+
+Why (MI355X-first, not the reference's layout):
+  * the optimizer, the gradient norm and the fp32->bf16 weight refresh are single launches over the buffer;
+  * data-parallel gradient all-reduce works on contiguous slices of the gradient buffer (buckets are views,
+    no copy-in / copy-out as in the reference's LegacyDistributedDataParallel, legacy_distributed_data_parallel.py:82-120);
+  * parameters that are consumed together (q/k/v projection weights) are placed adjacently so one GEMM reads them
+    as a single [3d, d] matrix while the state_dict keeps the reference's per-tensor keys.
+"""
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+ALIGN = 64  # elements; keeps every tensor 128-byte aligned in the bf16 shadow (256 B in fp32)
+
+
+class FlatParameters:
+    def __init__(self, module: nn.Module, compute_dtype: torch.dtype = torch.float32):
+        self.module = module
+        self.compute_dtype = compute_dtype
+        params: List[nn.Parameter] = []
+        seen = set()
+
+        def add(p):
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+
+        # adjacency groups first (in declaration order), then everything else in registration order
+        for m in module.modules():
+            groups = getattr(m, "flat_groups", None)
+            if groups is not None:
+                for grp in groups():
+                    for p in grp:
+                        add(p)
+        for p in module.parameters():
+            add(p)
+        self.params = params
+        self.offsets: Dict[int, int] = {}
+        off = 0
+        groups_flat = set()
+        for m in module.modules():
+            groups = getattr(m, "flat_groups", None)
+            if groups is not None:
+                for grp in groups():
+                    for p in grp[:-1]:
+                        groups_flat.add(id(p))
+        for p in params:
+            self.offsets[id(p)] = off
+            n = p.numel()
+            # members of a group (except the last) must be followed immediately by the next member
+            if id(p) in groups_flat:
+                assert n % 8 == 0, "grouped parameters must keep 16-byte alignment"
+                off += n
+            else:
+                off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        dev = params[0].device
+        self.master = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        for p in params:
+            o, n = self.offsets[id(p)], p.numel()
+            self.master[o:o + n].copy_(p.data.reshape(-1).float())
+            p.data = self.master[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+            p._s2t_shadow = self.shadow[o:o + n].view(p.shape) if self.shadow is not None else None
+        self.refresh_shadow()
+
+    def refresh_shadow(self):
+        """fp32 master -> bf16 shadow (after loading a checkpoint; Adam refreshes it itself each step)."""
+        if self.shadow is not None:
+            if self.master.is_cuda:
+                from . import kernels as K
+
+                K.cast_f32_to_bf16(self.master, self.shadow, self.numel)
+            else:
+                self.shadow.copy_(self.master)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def view(self, first: nn.Parameter, rows: int, cols: int, what: str = "compute") -> torch.Tensor:
+        """A [rows, cols] matrix starting at ``first`` (spanning an adjacency group)."""
+        o = self.offsets[id(first)]
+        buf = {"compute": self.shadow if self.shadow is not None else self.master, "master": self.master,
+               "grad": self.grad}[what]
+        return buf[o:o + rows * cols].view(rows, cols)
+
+
+def cw(p: nn.Parameter) -> torch.Tensor:
+    """Compute-dtype view of a parameter (bf16 shadow in bf16 mode, the fp32 master otherwise)."""
+    s = getattr(p, "_s2t_shadow", None)
+    return s if s is not None else p.data

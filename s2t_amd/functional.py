@@ -1,0 +1,623 @@
+"""Autograd functions of the S2T hot path: each forward/backward is a short sequence of libs2t_hip kernels.
+
+Everything here is batch-major: activations are row matrices ``[B*T, C]`` (row = b*T + t).  Weight
+gradients are ACCUMULATED in place into the flat fp32 gradient buffer (``p.grad`` are views of it, see
+flat_params.py), so ``backward`` returns ``None`` for parameters; this is what lets the data-parallel
+wrapper all-reduce contiguous buckets while the rest of backward is still running.
+
+There is no CPU path: every function raises if its inputs are not on the GPU.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import kernels as K
+from .flat_params import cw
+
+_HOOKS = {"grad_ready": None}  # set by the DDP wrapper: called with a parameter once its gradient is final
+
+
+def _ready(*params):
+    cb = _HOOKS["grad_ready"]
+    if cb is not None:
+        for p in params:
+            if p is not None:
+                cb(p)
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def fused(params, rows, cols):
+    """[rows, cols] compute-dtype view over adjacent parameters (flat_params adjacency group)."""
+    first = cw(params[0])
+    exp = first.data_ptr()
+    for p in params:
+        t = cw(p)
+        assert t.data_ptr() == exp, "parameters are not adjacent in the flat buffer (call flatten first)"
+        exp += t.numel() * t.element_size()
+    return first.as_strided((rows, cols), (cols, 1))
+
+
+def fused_grad(params, rows, cols):
+    first = params[0].grad
+    return first.as_strided((rows, cols), (cols, 1))
+
+
+def fused_master(params, n):
+    return params[0].data.as_strided((n,), (1,))
+
+
+def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0):
+    """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M with fp32 atomics)."""
+    tiles = ((Nout + 127) // 128) * ((Kin + 127) // 128)
+    ktiles = (M + (63 if dY.dtype == torch.bfloat16 else 31)) // (64 if dY.dtype == torch.bfloat16 else 32)
+    split = max(1, min(ktiles, (512 + tiles - 1) // tiles))
+    K.gemm(dY, X, dW, M=Nout, N=Kin, K=M, lda=ldy, ldb=ldx, ldc=Kin, a_kmajor=True, b_kmajor=True, alpha=alpha,
+           split_k=split, c_atomic=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    """modules/layer_norm.py:30-35; optional fused padded-row mask on the output."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, lens, T):
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        K.layernorm_fwd(x, gamma.data, beta.data, y, mean, rstd, rows, cols, 1e-5, lens, T)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta, ctx.lens, ctx.T = gamma, beta, lens, T
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        rows, cols = x.shape
+        dx = torch.empty_like(x)
+        K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, ctx.gamma.grad, ctx.beta.grad, rows, cols,
+                        ctx.lens, ctx.T)
+        _ready(ctx.gamma, ctx.beta)
+        return dx, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, lens=None, T=0):
+    return LayerNormFn.apply(x, gamma, beta, lens, T)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear (+ residual)
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = residual + alpha * (x @ W^T + b)   (F.linear; out_dtype lets logits come out in fp32).
+    The output buffer's row stride is padded to a multiple of 8 elements (16-byte row starts for any
+    vocabulary size); the returned tensor is the [:, :N] view of it."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, alpha, residual, out_dtype):
+        M, Kin = x.shape
+        Nout = w.shape[0]
+        ldc = _pad8(Nout)
+        y = torch.empty(M, ldc, dtype=out_dtype or x.dtype, device=x.device)
+        ldr = residual.stride(0) if residual is not None else 0
+        K.gemm(x, cw(w), y, M=M, N=Nout, K=Kin, lda=Kin, ldb=Kin, ldc=ldc, bias=b.data if b is not None else None,
+               alpha=alpha, residual=residual, ldr=ldr)
+        ctx.save_for_backward(x)
+        ctx.w, ctx.b, ctx.alpha, ctx.has_res = w, b, alpha, residual is not None
+        return y[:, :Nout] if ldc != Nout else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        M, Kin = x.shape
+        Nout = w.shape[0]
+        ld = _pad8(Nout)
+        if dy.dtype != x.dtype or dy.stride(1) != 1 or dy.stride(0) % 8 or dy.data_ptr() % 16:
+            buf = torch.zeros(M, ld, dtype=x.dtype, device=x.device) if ld != Nout else torch.empty(M, ld, dtype=x.dtype, device=x.device)
+            buf[:, :Nout].copy_(dy)
+            dy = buf[:, :Nout]
+        ldy = dy.stride(0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            K.gemm(dy, cw(w), dx, M=M, N=Kin, K=Nout, lda=ldy, ldb=Kin, ldc=Kin, b_kmajor=True, alpha=ctx.alpha)
+        _wgrad(dy, x, w.grad, Nout, Kin, M, ldy, Kin, ctx.alpha)
+        if b is not None:
+            # bias gradient carries the same alpha
+            if ctx.alpha == 1.0:
+                K.colsum_accum(dy, ldy, b.grad, M, Nout)
+            else:
+                tmp = torch.zeros_like(b.grad)
+                K.colsum_accum(dy, ldy, tmp, M, Nout)
+                b.grad.add_(tmp, alpha=ctx.alpha)
+        _ready(w, b)
+        return dx, None, None, None, (dy if ctx.has_res else None), None
+
+
+def linear(x, w, b=None, alpha=1.0, residual=None, out_dtype=None):
+    return LinearFn.apply(x, w, b, alpha, residual, out_dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# Feed-forward block
+# ------------------------------------------------------------------------------------------------
+class FFNFn(torch.autograd.Function):
+    """out = residual + alpha * (W2 act(W1 x + b1) + b2)   (modules/s2t_transformer_layer.py:55-66, :258-265, :311-317;
+    decoder FFN modules/transformer_layer.py:520-530)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, alpha, residual, train):
+        M, d = x.shape
+        F_ = w1.shape[0]
+        h = torch.empty(M, F_, dtype=x.dtype, device=x.device)
+        z = torch.empty(M, F_, dtype=x.dtype, device=x.device) if train else None
+        K.gemm(x, cw(w1), h, M=M, N=F_, K=d, lda=d, ldb=d, ldc=F_, bias=b1.data, act=act, preact=z, ldp=F_)
+        y = torch.empty(M, d, dtype=x.dtype, device=x.device)
+        K.gemm(h, cw(w2), y, M=M, N=d, K=F_, lda=F_, ldb=F_, ldc=d, bias=b2.data, alpha=alpha, residual=residual, ldr=d)
+        if train:
+            ctx.save_for_backward(x, z, h)
+        ctx.p = (w1, b1, w2, b2)
+        ctx.act, ctx.alpha = act, alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, h = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.p
+        M, d = x.shape
+        F_ = w1.shape[0]
+        dy = dy.contiguous()
+        # dZ = alpha * (dY @ W2) * act'(Z)
+        dz = torch.empty(M, F_, dtype=x.dtype, device=x.device)
+        K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
+               dact=ctx.act)
+        _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha)
+        if ctx.alpha == 1.0:
+            K.colsum_accum(dy, d, b2.grad, M, d)
+        else:
+            tmp = torch.zeros_like(b2.grad)
+            K.colsum_accum(dy, d, tmp, M, d)
+            b2.grad.add_(tmp, alpha=ctx.alpha)
+        _ready(w2, b2)
+        _wgrad(dz, x, w1.grad, F_, d, M, F_, d)
+        K.colsum_accum(dz, F_, b1.grad, M, F_)
+        dx = torch.empty_like(x)
+        K.gemm(dz, cw(w1), dx, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
+        _ready(w1, b1)
+        return dx, None, None, None, None, None, None, dy, None
+
+
+def ffn(x, w1, b1, w2, b2, act, alpha, residual):
+    return FFNFn.apply(x, w1, b1, w2, b2, act, alpha, residual, torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------
+# Attention
+# ------------------------------------------------------------------------------------------------
+class AttentionFn(torch.autograd.Function):
+    """out = residual + out_proj(softmax(scores) V) for
+         kind == "abs": fairseq MultiheadAttention (modules/multihead_attention.py:161-431), self (fused q/k/v
+                        projection) or encoder-decoder (q from xq, k/v from xkv), optional causal mask;
+         kind == "rel": ESPnet RelPositionMultiHeadedAttention (modules/espnet_multihead_attention.py:313-356).
+
+    The score matrix is materialised in fp32 ([B*H, Tq, Tk]) by a batched MFMA GEMM, turned into probabilities by
+    the softmax kernel (mask / rel-shift / clamp fused) and consumed by a second batched GEMM.
+    """
+
+    @staticmethod
+    def forward(ctx, xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, train):
+        d = xq.shape[1]
+        dk = d // H
+        dt = xq.dtype
+        dev = xq.device
+        self_attn = xkv is None
+        Mq, Mk = B * Tq, B * Tk
+        if self_attn:
+            wqkv = fused([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
+            bqkv = fused_master([prm["q_b"], prm["k_b"], prm["v_b"]], 3 * d)
+            qkv = torch.empty(Mq, 3 * d, dtype=dt, device=dev)
+            K.gemm(xq, wqkv, qkv, M=Mq, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+            q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
+            ldq = ldk = 3 * d
+        else:
+            q = torch.empty(Mq, d, dtype=dt, device=dev)
+            K.gemm(xq, cw(prm["q_w"]), q, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["q_b"].data)
+            wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
+            bkv = fused_master([prm["k_b"], prm["v_b"]], 2 * d)
+            kv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
+            K.gemm(xkv, wkv, kv, M=Mk, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, bias=bkv)
+            k, v = kv, kv[:, d:]
+            ldq, ldk = d, 2 * d
+        Z = B * H
+        ldS = _pad8(Tk)
+        S = torch.empty(Z, Tq, ldS, dtype=torch.float32, device=dev)
+        BD = None
+        ldB = 0
+        qu = qv = p = None
+        if kind == "rel":
+            assert self_attn and Tq == Tk
+            n_pos = 2 * Tq - 1
+            ldB = _pad8(n_pos)
+            p = torch.empty(n_pos, d, dtype=dt, device=dev)
+            K.gemm(pos_tab, cw(prm["pos_w"]), p, M=n_pos, N=d, K=d, lda=d, ldb=d, ldc=d)
+            qu = torch.empty(Mq, d, dtype=dt, device=dev)
+            qv = torch.empty(Mq, d, dtype=dt, device=dev)
+            K.bias_add_rows(q, ldq, prm["pos_u"].data, qu, d, Mq, d)
+            K.bias_add_rows(q, ldq, prm["pos_v"].data, qv, d, Mq, d)
+            K.gemm(qu, k, S, M=Tq, N=Tk, K=dk, lda=d, ldb=ldk, ldc=ldS, batch=Z, zdiv=H, a_s=(Tq * d, dk),
+                   b_s=(Tk * ldk, dk), c_s=(H * Tq * ldS, Tq * ldS))
+            BD = torch.empty(Z, Tq, ldB, dtype=torch.float32, device=dev)
+            K.gemm(qv, p, BD, M=Tq, N=n_pos, K=dk, lda=d, ldb=d, ldc=ldB, batch=Z, zdiv=H, a_s=(Tq * d, dk),
+                   b_s=(0, dk), c_s=(H * Tq * ldB, Tq * ldB))
+            scale = 1.0 / math.sqrt(dk)
+        else:
+            K.gemm(q, k, S, M=Tq, N=Tk, K=dk, lda=ldq, ldb=ldk, ldc=ldS, batch=Z, zdiv=H, a_s=(Tq * ldq, dk),
+                   b_s=(Tk * ldk, dk), c_s=(H * Tq * ldS, Tq * ldS))
+            scale = dk ** -0.5
+        P = torch.empty(Z, Tq, ldS, dtype=dt, device=dev)
+        K.attn_softmax_fwd(S, ldS, BD, ldB, P, ldS, Z, H, Tq, Tk, scale, key_lens, causal, kind == "rel")
+        del S, BD
+        O = torch.empty(Mq, d, dtype=dt, device=dev)
+        K.gemm(P, v, O, M=Tq, N=dk, K=Tk, lda=ldS, ldb=ldk, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
+               a_s=(H * Tq * ldS, Tq * ldS), b_s=(Tk * ldk, dk), c_s=(Tq * d, dk))
+        y = torch.empty(Mq, d, dtype=dt, device=dev)
+        K.gemm(O, cw(prm["o_w"]), y, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual, ldr=d)
+        if train:
+            ctx.save_for_backward(xq, xkv, q, k, v, P, O, qu, qv, p, pos_tab)
+        ctx.prm, ctx.dims = prm, (H, B, Tq, Tk, d, dk, ldq, ldk, ldS, ldB, scale)
+        ctx.kind, ctx.self_attn, ctx.has_res = kind, self_attn, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xq, xkv, q, k, v, P, O, qu, qv, p, pos_tab = ctx.saved_tensors
+        prm = ctx.prm
+        H, B, Tq, Tk, d, dk, ldq, ldk, ldS, ldB, scale = ctx.dims
+        dt, dev = xq.dtype, xq.device
+        Mq, Mk = B * Tq, B * Tk
+        Z = B * H
+        dy = dy.contiguous()
+        # out_proj
+        dO = torch.empty(Mq, d, dtype=dt, device=dev)
+        K.gemm(dy, cw(prm["o_w"]), dO, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+        _wgrad(dy, O, prm["o_w"].grad, d, d, Mq, d, d)
+        K.colsum_accum(dy, d, prm["o_b"].grad, Mq, d)
+        _ready(prm["o_w"], prm["o_b"])
+        # gradient buffers in the projection layout so that one GEMM handles dW / dx
+        if ctx.self_attn:
+            dqkv = torch.empty(Mq, 3 * d, dtype=dt, device=dev)
+            dq, dk_, dv = dqkv, dqkv[:, d:], dqkv[:, 2 * d:]
+        else:
+            dq = torch.empty(Mq, d, dtype=dt, device=dev)
+            dkv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
+            dk_, dv = dkv, dkv[:, d:]
+        # dP = dO V^T ; dV = P^T dO
+        dP = torch.empty(Z, Tq, ldS, dtype=torch.float32, device=dev)
+        K.gemm(dO, v, dP, M=Tq, N=Tk, K=dk, lda=d, ldb=ldk, ldc=ldS, batch=Z, zdiv=H, a_s=(Tq * d, dk),
+               b_s=(Tk * ldk, dk), c_s=(H * Tq * ldS, Tq * ldS))
+        K.gemm(P, dO, dv, M=Tk, N=dk, K=Tq, lda=ldS, ldb=d, ldc=ldk, a_kmajor=True, b_kmajor=True, batch=Z, zdiv=H,
+               a_s=(H * Tq * ldS, Tq * ldS), b_s=(Tq * d, dk), c_s=(Tk * ldk, dk))
+        dS = torch.empty(Z, Tq, ldS, dtype=dt, device=dev)
+        dBD = torch.empty(H, B, Tq, ldB, dtype=dt, device=dev) if ctx.kind == "rel" else None
+        K.attn_softmax_bwd(P, ldS, dP, ldS, dS, ldS, dBD, ldB, Z, H, Tq, Tk, scale)
+        del dP
+        qa = qu if ctx.kind == "rel" else q  # the matrix that multiplied K^T in the forward
+        lda_q = d if ctx.kind == "rel" else ldq
+        # dQ(ac) = dS K ; dK = dS^T (q [+u])
+        K.gemm(dS, k, dq, M=Tq, N=dk, K=Tk, lda=ldS, ldb=ldk, ldc=ldq, b_kmajor=True, batch=Z, zdiv=H,
+               a_s=(H * Tq * ldS, Tq * ldS), b_s=(Tk * ldk, dk), c_s=(Tq * ldq, dk))
+        K.gemm(dS, qa, dk_, M=Tk, N=dk, K=Tq, lda=ldS, ldb=lda_q, ldc=ldk, a_kmajor=True, b_kmajor=True, batch=Z, zdiv=H,
+               a_s=(H * Tq * ldS, Tq * ldS), b_s=(Tq * lda_q, dk), c_s=(Tk * ldk, dk))
+        if ctx.kind == "rel":
+            n_pos = 2 * Tq - 1
+            # pos_bias_u gradient = column sums of d(q+u) (only the ac term so far)
+            K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
+            # d(q+v) = dBD p  (per head); kept separately for pos_bias_v, then added into dq
+            dqv = torch.empty(Mq, d, dtype=dt, device=dev)
+            K.gemm(dBD, p, dqv, M=Tq, N=dk, K=n_pos, lda=ldB, ldb=d, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
+                   a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
+            K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
+            # dp[n, h, :] = sum_{b,i} dBD[h, (b,i), n] * (q+v)[(b,i), h, :]   (one GEMM per head, K = B*Tq)
+            dp = torch.zeros(n_pos, d, dtype=torch.float32, device=dev)
+            ktiles = (Mq + 63) // 64
+            K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
+                   a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=max(1, min(ktiles, 64)), c_atomic=True)
+            # linear_pos weight: dW[dout, din] += dp^T pos_tab  (fp32 GEMM on the fp32 table)
+            pos32 = pos_tab if pos_tab.dtype == torch.float32 else pos_tab.float()
+            K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
+                   split_k=1, c_atomic=True)
+            # dq += dqv   (strided add into the q slice of dqkv)
+            dq_view = dq[:, :d] if ctx.self_attn else dq
+            dq_view.add_(dqv)
+            _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
+        # projections
+        dxq = torch.empty(Mq, d, dtype=dt, device=dev)
+        if ctx.self_attn:
+            gw = fused_grad([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
+            gb = prm["q_b"].grad.as_strided((3 * d,), (1,))
+            wqkv = fused([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
+            _wgrad(dqkv, xq, gw, 3 * d, d, Mq, 3 * d, d)
+            K.colsum_accum(dqkv, 3 * d, gb, Mq, 3 * d)
+            K.gemm(dqkv, wqkv, dxq, M=Mq, N=d, K=3 * d, lda=3 * d, ldb=d, ldc=d, b_kmajor=True)
+            dxkv = None
+        else:
+            _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d)
+            K.colsum_accum(dq, d, prm["q_b"].grad, Mq, d)
+            K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+            gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
+            gb = prm["k_b"].grad.as_strided((2 * d,), (1,))
+            wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
+            _wgrad(dkv, xkv, gw, 2 * d, d, Mk, 2 * d, d)
+            K.colsum_accum(dkv, 2 * d, gb, Mk, 2 * d)
+            dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
+            K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
+        _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
+        return dxq, dxkv, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None, None, None
+
+
+def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False, kind="abs", pos_tab=None):
+    return AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
+                             torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------
+# Conformer convolution module
+# ------------------------------------------------------------------------------------------------
+class ConvModuleFn(torch.autograd.Function):
+    """out = residual + mask(pw2(act(BN(dwconv(GLU(pw1(x)))))))   (modules/convolution.py:76-120).
+    ``x`` is the conv_norm output with padded frames already zeroed (LayerNormFn with lens)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, prm, bn_buf, act, B, T, lens, training, momentum, train):
+        M, d = x.shape
+        dt, dev = x.dtype, x.device
+        Kw = prm["dw_w"].shape[-1]
+        w1 = cw(prm["pw1_w"]).view(2 * d, d)
+        z = torch.empty(M, 2 * d, dtype=dt, device=dev) if train else None
+        g = torch.empty(M, d, dtype=dt, device=dev)
+        K.gemm(x, w1, g, M=M, N=2 * d, K=d, lda=d, ldb=d, ldc=d, act="glu", preact=z, ldp=2 * d)
+        scale = torch.empty(d, dtype=torch.float32, device=dev)
+        shift = torch.empty(d, dtype=torch.float32, device=dev)
+        wd = prm["dw_w"].data.view(d, Kw)
+        a = torch.empty(M, d, dtype=dt, device=dev)
+        D = mean = rstd = None
+        if training:
+            D = torch.empty(M, d, dtype=dt, device=dev)
+            stats = torch.zeros(2 * d, dtype=torch.float32, device=dev)
+            K.dwconv_fwd(g, wd, D, B, T, d, Kw, stats=stats)
+            mean = torch.empty(d, dtype=torch.float32, device=dev)
+            rstd = torch.empty(d, dtype=torch.float32, device=dev)
+            K.bn_finalize(stats, M, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
+                          momentum, 1e-5, True, scale, shift, mean, rstd, d)
+            K.bn_act_fwd(D, a, scale, shift, act, M, d, lens, T)
+        else:
+            K.bn_finalize(None, 0, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
+                          momentum, 1e-5, False, scale, shift, None, None, d)
+            K.dwconv_fwd(g, wd, a, B, T, d, Kw, scale=scale, shift=shift, act=act, lens=lens)
+        y = torch.empty(M, d, dtype=dt, device=dev)
+        K.gemm(a, cw(prm["pw2_w"]).view(d, d), y, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, residual=residual, ldr=d,
+               row_lens=lens, row_T=T)
+        if train:
+            assert training, "gradients through the convolution module need training-mode BatchNorm"
+            ctx.save_for_backward(x, z, g, D, a, scale, shift, mean, rstd)
+        ctx.prm, ctx.act, ctx.dims, ctx.lens, ctx.has_res = prm, act, (B, T, d, Kw), lens, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, g, D, a, scale, shift, mean, rstd = ctx.saved_tensors
+        prm = ctx.prm
+        B, T, d, Kw = ctx.dims
+        M = B * T
+        dt, dev = x.dtype, x.device
+        dy = dy.contiguous()
+        # pw2 (a's padded rows are zero, so the weight gradient needs no extra mask; dA's are zeroed in bn_act_bwd)
+        dA = torch.empty(M, d, dtype=dt, device=dev)
+        K.gemm(dy, cw(prm["pw2_w"]).view(d, d), dA, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+        _wgrad(dy, a, prm["pw2_w"].grad.view(d, d), d, d, M, d, d)
+        # here dy rows of padded frames must not reach pw2's weight gradient: a is zero there -> contributes nothing
+        dD = torch.empty(M, d, dtype=dt, device=dev)
+        sums = torch.zeros(2 * d, dtype=torch.float32, device=dev)
+        K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T)
+        prm["bn_b"].grad.add_(sums[:d])
+        prm["bn_w"].grad.add_(sums[d:])
+        wd = prm["dw_w"].data.view(d, Kw)
+        dG = torch.empty(M, d, dtype=dt, device=dev)
+        K.dwconv_fwd(dD, wd, dG, B, T, d, Kw, flip=True)
+        K.dwconv_bwd_weight(g, dD, prm["dw_w"].grad.view(d, Kw), B, T, d, Kw)
+        dZ = torch.empty(M, 2 * d, dtype=dt, device=dev)
+        K.glu_bwd(z, dG, dZ, M, d)
+        _wgrad(dZ, x, prm["pw1_w"].grad.view(2 * d, d), 2 * d, d, M, 2 * d, d)
+        dx = torch.empty(M, d, dtype=dt, device=dev)
+        K.gemm(dZ, cw(prm["pw1_w"]).view(2 * d, d), dx, M=M, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
+        _ready(prm["pw1_w"], prm["dw_w"], prm["bn_w"], prm["bn_b"], prm["pw2_w"])
+        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None, None
+
+
+def conv_module(x, residual, prm, bn_buf, act, B, T, lens, training, momentum=0.1):
+    return ConvModuleFn.apply(x, residual, prm, bn_buf, act, B, T, lens, training, momentum, torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv1d subsampler
+# ------------------------------------------------------------------------------------------------
+def _conv_out_len(T):
+    return (T - 1) // 2 + 1
+
+
+class SubsampleFn(torch.autograd.Function):
+    """2 x [Conv1d(k=5, stride 2, pad 2) -> GLU]  (modules/speech_to_text/subsampling.py:106-159) as overlapping-row
+    GEMMs over zero-padded (B, T+pad, C) buffers; the padded-frame mask of the encoder (s2t_transformer.py:1765)
+    is fused into the second GEMM's epilogue.  Weights are stored [Cout][k][Cin] (see Conv1dSubsampling)."""
+
+    @staticmethod
+    def forward(ctx, src, w0, b0, w1, b1, out_lens, dt, train):
+        B, T, Cin = src.shape
+        dev = src.device
+        kk = 5
+        C0, C1 = w0.shape[0], w1.shape[0]  # conv output channels (before GLU)
+        T1, = (_conv_out_len(T),)
+        T2 = _conv_out_len(T1)
+        Cin_p = _pad8(Cin)
+        assert Cin_p == Cin, "input feature dim must be a multiple of 8"
+        Tp0 = 2 * T1 + 4
+        xp = torch.zeros(B, Tp0, Cin, dtype=dt, device=dev)
+        xp[:, 2:2 + T].copy_(src)
+        H0 = C0 // 2
+        Tp1 = 2 * T2 + 4
+        y1p = torch.zeros(B, Tp1, H0, dtype=dt, device=dev)
+        z1 = torch.empty(B, T1, C0, dtype=dt, device=dev) if train else None
+        K.gemm(xp, cw(w0).view(C0, kk * Cin), y1p[:, 2:], M=T1, N=C0, K=kk * Cin, lda=2 * Cin, ldb=kk * Cin, ldc=H0,
+               batch=B, a_s=(Tp0 * Cin, 0), c_s=(Tp1 * H0, 0), bias=b0.data, act="glu", preact=z1, ldp=C0,
+               p_s=(T1 * C0, 0))
+        H1 = C1 // 2
+        y2 = torch.empty(B, T2, H1, dtype=dt, device=dev)
+        z2 = torch.empty(B, T2, C1, dtype=dt, device=dev) if train else None
+        K.gemm(y1p, cw(w1).view(C1, kk * H0), y2, M=T2, N=C1, K=kk * H0, lda=2 * H0, ldb=kk * H0, ldc=H1, batch=B,
+               a_s=(Tp1 * H0, 0), c_s=(T2 * H1, 0), bias=b1.data, act="glu", preact=z2, ldp=C1, p_s=(T2 * C1, 0),
+               row_lens=out_lens, row_T=T2)
+        if train:
+            ctx.save_for_backward(xp, y1p, z1, z2)
+        ctx.p = (w0, b0, w1, b1)
+        ctx.dims = (B, T, Cin, C0, C1, T1, T2, Tp0, Tp1)
+        ctx.out_lens = out_lens
+        return y2.view(B * T2, H1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, y1p, z1, z2 = ctx.saved_tensors
+        w0, b0, w1, b1 = ctx.p
+        B, T, Cin, C0, C1, T1, T2, Tp0, Tp1 = ctx.dims
+        kk = 5
+        H0, H1 = C0 // 2, C1 // 2
+        dt, dev = xp.dtype, xp.device
+        dy = dy.contiguous()
+        # layer 2: GLU backward (padded frames carry no gradient)
+        dz2 = torch.empty(B * T2, C1, dtype=dt, device=dev)
+        K.glu_bwd(z2.view(B * T2, C1), dy, dz2, B * T2, H1, ctx.out_lens, T2)
+        # dW1[C1, k*H0] += sum_b dz2[b]^T im2col(y1p[b])   (several batches share dW -> atomics)
+        K.gemm(dz2, y1p, w1.grad.view(C1, kk * H0), M=C1, N=kk * H0, K=T2, lda=C1, ldb=2 * H0, ldc=kk * H0,
+               a_kmajor=True, b_kmajor=True, batch=B, a_s=(T2 * C1, 0), b_s=(Tp1 * H0, 0), c_s=(0, 0), c_atomic=True)
+        K.colsum_accum(dz2, C1, b1.grad, B * T2, C1)
+        # d y1p: one GEMM per kernel tap (rows 2t+tap never collide inside one tap); accumulate tap by tap
+        dy1p = torch.zeros(B, Tp1, H0, dtype=dt, device=dev)
+        w1c = cw(w1).view(C1, kk * H0)
+        for tap in range(kk):
+            out = dy1p.view(-1)[tap * H0:]
+            K.gemm(dz2, w1c[:, tap * H0:], out, M=T2, N=H0, K=C1, lda=C1, ldb=kk * H0, ldc=2 * H0, b_kmajor=True, batch=B,
+                   a_s=(T2 * C1, 0), c_s=(Tp1 * H0, 0), residual=out, ldr=2 * H0)
+        # layer 1
+        dz1 = torch.empty(B * T1, C0, dtype=dt, device=dev)
+        dy1 = dy1p[:, 2:2 + T1].contiguous().view(B * T1, H0)
+        K.glu_bwd(z1.view(B * T1, C0), dy1, dz1, B * T1, H0)
+        K.gemm(dz1, xp, w0.grad.view(C0, kk * Cin), M=C0, N=kk * Cin, K=T1, lda=C0, ldb=2 * Cin, ldc=kk * Cin,
+               a_kmajor=True, b_kmajor=True, batch=B, a_s=(T1 * C0, 0), b_s=(Tp0 * Cin, 0), c_s=(0, 0), c_atomic=True)
+        K.colsum_accum(dz1, C0, b0.grad, B * T1, C0)
+        _ready(w0, b0, w1, b1)
+        return None, None, None, None, None, None, None, None
+
+
+def subsample(src, w0, b0, w1, b1, out_lens, dt):
+    return SubsampleFn.apply(src, w0, b0, w1, b1, out_lens, dt, torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------
+# Embedding
+# ------------------------------------------------------------------------------------------------
+class EmbeddingFn(torch.autograd.Function):
+    """x = scale * E[tokens] + sinusoid[pos]  (models/transformer.py:1304-1323)."""
+
+    @staticmethod
+    def forward(ctx, tokens, pos, E, tab, scale, pad_idx):
+        n = tokens.numel()
+        d = E.shape[1]
+        out = torch.empty(n, d, dtype=cw(E).dtype, device=tokens.device)
+        K.embedding_fwd(tokens, pos, cw(E), tab, out, n, d, scale)
+        ctx.save_for_backward(tokens)
+        ctx.E, ctx.scale, ctx.pad_idx = E, scale, pad_idx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tokens,) = ctx.saved_tensors
+        E = ctx.E
+        K.embedding_bwd(tokens, dout.contiguous(), E.grad, tokens.numel(), E.shape[1], ctx.scale, ctx.pad_idx)
+        _ready(E)
+        return None, None, None, None, None, None
+
+
+def embedding(tokens, pos, E, tab, scale, pad_idx):
+    return EmbeddingFn.apply(tokens, pos, E, tab, scale, pad_idx)
+
+
+# ------------------------------------------------------------------------------------------------
+# Losses
+# ------------------------------------------------------------------------------------------------
+class LabelSmoothedCEFn(torch.autograd.Function):
+    """criterions/label_smoothed_cross_entropy.py:42-60 — returns (loss, nll, n_correct, total) as a 4-vector;
+    the gradient w.r.t. the logits is produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, logits, target, eps, pad_idx, train):
+        rows, V = logits.shape
+        assert logits.stride(1) == 1
+        sums = torch.zeros(4, dtype=torch.float32, device=logits.device)
+        dl = None
+        if train:
+            dl = torch.empty(rows, _pad8(V), dtype=logits.dtype, device=logits.device)[:, :V]
+        K.ls_cross_entropy(logits, logits.stride(0), rows, V, target, pad_idx, eps, dl, dl.stride(0) if train else 0, sums)
+        if train:
+            ctx.save_for_backward(dl)
+        return sums
+
+    @staticmethod
+    def backward(ctx, dsums):
+        (dl,) = ctx.saved_tensors
+        # only sums[0] (the loss) is differentiable
+        return dl * dsums[0].to(dl.dtype), None, None, None, None
+
+
+def label_smoothed_ce(logits, target, eps, pad_idx):
+    return LabelSmoothedCEFn.apply(logits, target, eps, pad_idx, torch.is_grad_enabled() and logits.requires_grad)
+
+
+class CTCLossFn(torch.autograd.Function):
+    """sum_b CTC nll_b with zero_infinity (criterions/ctc.py:243-245,435-474); logits are batch-major [B*T, V]."""
+
+    @staticmethod
+    def forward(ctx, logits, B, T, targets, tgt_lens, in_lens, blank):
+        V = logits.shape[1]
+        dev = logits.device
+        S = targets.shape[1]
+        Lmax = 2 * S + 1
+        lse = torch.empty(B * T, dtype=torch.float32, device=dev)
+        assert logits.stride(1) == 1
+        ld = logits.stride(0)
+        K.argmax_lse(logits, ld, B * T, V, None, None, lse)
+        alpha = torch.empty(B, T, Lmax, dtype=torch.float32, device=dev)
+        beta = torch.empty(B, T, Lmax, dtype=torch.float32, device=dev)
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        K.ctc_loss_fwd(logits, ld, B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll)
+        ctx.save_for_backward(logits, lse, alpha, beta, nll, targets, tgt_lens, in_lens)
+        ctx.dims = (B, T, V, S, Lmax, blank)
+        return torch.where(torch.isinf(nll), torch.zeros_like(nll), nll).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse, alpha, beta, nll, targets, tgt_lens, in_lens = ctx.saved_tensors
+        B, T, V, S, Lmax, blank = ctx.dims
+        grad = torch.empty(B * T, _pad8(V), dtype=logits.dtype, device=logits.device)[:, :V]
+        K.ctc_loss_bwd(logits, logits.stride(0), B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll,
+                       1.0, grad, grad.stride(0))
+        return grad * g.to(grad.dtype), None, None, None, None, None, None
+
+
+def ctc_loss(logits, B, T, targets, tgt_lens, in_lens, blank=0):
+    return CTCLossFn.apply(logits, B, T, targets, tgt_lens, in_lens, blank)

@@ -19,7 +19,7 @@ def gemm(
     residual: Optional[torch.Tensor] = None, ldr=0,
     preact: Optional[torch.Tensor] = None, ldp=0, p_s=(0, 0),
     dact_z: Optional[torch.Tensor] = None, ldz=0, dact=None,
-    row_lens: Optional[torch.Tensor] = None, row_T=0, split_k=1,
+    row_lens: Optional[torch.Tensor] = None, row_T=0, split_k=1, c_atomic=False,
 ):
     """Raw s2t_gemm call: C = epilogue(A_op[M,K] @ B_op[K,N]); see include/s2t_hip.h."""
     L.require_cuda(A, B, out, bias, residual, preact, dact_z, row_lens)
@@ -54,6 +54,7 @@ def gemm(
     if row_lens is not None:
         assert row_lens.dtype == torch.int32
     a.split_k = split_k
+    a.c_atomic = int(c_atomic)
     L.check(L.lib().s2t_gemm(C.byref(a), L.stream_ptr()), "s2t_gemm")
     return out
 
@@ -82,10 +83,14 @@ def attn_softmax_fwd(S, ldS, BD, ldBD, P, ldP, Z, H, Tq, Tk, scale, key_lens=Non
           Tk, scale, _ptr(key_lens), int(causal), int(clamp))
 
 
-def attn_softmax_bwd(P, ldP, dP, ldDP, dS, ldDS, dBD, ldDBD, Z, Tq, Tk, scale):
+def attn_softmax_bwd(P, ldP, dP, ldDP, dS, ldDS, dBD, ldDBD, Z, H, Tq, Tk, scale):
     assert dP.dtype == torch.float32
     _call("s2t_attn_softmax_bwd", L.dtype_id(P.dtype), P.data_ptr(), ldP, dP.data_ptr(), ldDP, dS.data_ptr(), ldDS,
-          _ptr(dBD), ldDBD, Z, Tq, Tk, scale)
+          _ptr(dBD), ldDBD, Z, H, Tq, Tk, scale)
+
+
+def bias_add_rows(x, ldx, bias, out, ldo, rows, n):
+    _call("s2t_bias_add_rows", L.dtype_id(x.dtype), x.data_ptr(), ldx, bias.data_ptr(), out.data_ptr(), ldo, rows, n)
 
 
 def add_positions(x, tab, lens, rows, T, d, scale=1.0, pos_offset=2):

@@ -1,0 +1,411 @@
+"""Host-side mirrors of the reference's modules on the S2T path (same class names, constructor arguments,
+``state_dict`` keys and ``forward`` meaning), computing through the HIP kernels of ``libs2t_hip.so``.
+
+Reference files (relative to /root/reference/fairseq): modules/speech_to_text/subsampling.py,
+modules/s2t_transformer_layer.py, modules/multihead_attention.py, modules/espnet_multihead_attention.py,
+modules/convolution.py, modules/layer_norm.py, modules/positional_encoding.py,
+modules/sinusoidal_positional_embedding.py, modules/speech_to_text/ctc.py, modules/transformer_layer.py.
+
+Internal activation layout is batch-major ``[B*T, C]`` (the reference is time-major ``(T, B, C)``); the
+model classes transpose at the boundary.  Modules are parameter containers + a ``forward`` on 2-D row
+matrices; there is no CPU fallback.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+
+
+class Ctx:
+    """Per-forward geometry shared by the layers of one encoder/decoder pass."""
+
+    def __init__(self, B, T, lens_i32, dtype, pos_tab=None, mask_layers=False):
+        self.B, self.T, self.lens, self.dtype = B, T, lens_i32, dtype
+        self.pos_tab = pos_tab
+        self.mask_layers = mask_layers
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers with the reference's key names
+# ------------------------------------------------------------------------------------------------
+class LayerNorm(nn.Module):
+    """modules/layer_norm.py:30-35 (torch.nn.LayerNorm, eps 1e-5, affine)."""
+
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps = eps
+
+    def forward(self, x2d, lens=None, T=0):
+        return Fn.layer_norm(x2d, self.weight, self.bias, lens, T)
+
+
+class Linear(nn.Module):
+    """nn.Linear parameter holder (xavier-uniform weight like fairseq's Linear helper)."""
+
+    def __init__(self, in_f, out_f, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f))
+        nn.init.xavier_uniform_(self.weight)
+        self.bias = nn.Parameter(torch.zeros(out_f)) if bias else None
+
+    def forward(self, x2d, alpha=1.0, residual=None, out_dtype=None):
+        return Fn.linear(x2d, self.weight, self.bias, alpha, residual, out_dtype)
+
+
+class _Conv1dK(nn.Module):
+    """Conv1d weights stored [Cout][k][Cin] (GEMM layout); state_dict shows the reference's (Cout, Cin, k)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        w = torch.empty(cout, cin, k)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w.permute(0, 2, 1).contiguous())
+        bound = 1 / math.sqrt(cin * k)
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        self._register_state_dict_hook(self._to_ref)
+        self._register_load_state_dict_pre_hook(self._from_ref)
+
+    @staticmethod
+    def _to_ref(module, sd, prefix, local_metadata):
+        key = prefix + "weight"
+        if key in sd:
+            sd[key] = sd[key].permute(0, 2, 1).contiguous()
+
+    def _from_ref(self, sd, prefix, *args):
+        # state_dict() always shows (and load_state_dict always receives) the reference's (Cout, Cin, k) layout
+        key = prefix + "weight"
+        if key in sd and sd[key].dim() == 3:
+            sd[key] = sd[key].permute(0, 2, 1).contiguous()
+
+
+class Conv1dSubsampling(nn.Module):
+    """modules/speech_to_text/subsampling.py:106-159 — 2 x [Conv1d(k5, s2, p2) -> GLU]; keys layers.{i}.0.*"""
+
+    def __init__(self, num_layers, in_dim, filters, kernel_size, stride=2, norm="none", act="glu"):
+        super().__init__()
+        if num_layers != 2 or kernel_size != 5 or stride != 2 or norm != "none" or act != "glu":
+            raise NotImplementedError("HIP subsampler covers the recipes' 2-layer k5/s2 conv1d + GLU configuration")
+        chans = [in_dim, filters[0] // 2]
+        outs = [filters[0], filters[1] * 2]
+        self.layers = nn.ModuleList(
+            [nn.ModuleList([_Conv1dK(chans[i], outs[i], kernel_size)]) for i in range(num_layers)]
+        )
+
+    @staticmethod
+    def get_out_seq_lens_tensor(lens):
+        for _ in range(2):
+            lens = torch.div(lens - 1, 2, rounding_mode="floor") + 1
+        return lens
+
+    def forward(self, src_bt, out_lens_i32, dtype):
+        c0, c1 = self.layers[0][0], self.layers[1][0]
+        return Fn.subsample(src_bt, c0.weight, c0.bias, c1.weight, c1.bias, out_lens_i32, dtype)
+
+
+class FeedForwardModule(nn.Module):
+    """modules/s2t_transformer_layer.py:26-66 — keys w_1, w_2."""
+
+    def __init__(self, input_feat, hidden_units, dropout1, dropout2, activation_fn="relu", bias=True):
+        super().__init__()
+        self.w_1 = Linear(input_feat, hidden_units)
+        self.w_2 = Linear(hidden_units, input_feat)
+        self.activation_fn = activation_fn
+        if dropout1 or dropout2:
+            _no_dropout()
+
+    def forward(self, x_ln, residual, scale):
+        return Fn.ffn(x_ln, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, self.activation_fn, scale,
+                      residual)
+
+
+def _no_dropout():
+    raise NotImplementedError(
+        "dropout > 0 is not built yet on the HIP path (parity runs use p = 0, SURVEY.md §8b); set the dropout flags to 0")
+
+
+class MultiheadAttention(nn.Module):
+    """modules/multihead_attention.py:24-431 — keys k_proj, v_proj, q_proj, out_proj."""
+
+    def __init__(self, embed_dim, num_heads, kdim=None, vdim=None, dropout=0.0, bias=True, self_attention=False,
+                 encoder_decoder_attention=False, **unused):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.self_attention, self.encoder_decoder_attention = self_attention, encoder_decoder_attention
+        if dropout:
+            _no_dropout()
+        self.k_proj = Linear(embed_dim, embed_dim)
+        self.v_proj = Linear(embed_dim, embed_dim)
+        self.q_proj = Linear(embed_dim, embed_dim)
+        self.out_proj = Linear(embed_dim, embed_dim)
+        for p in (self.k_proj, self.v_proj, self.q_proj):  # multihead_attention.py:96-104
+            nn.init.xavier_uniform_(p.weight, gain=1 / math.sqrt(2))
+
+    def flat_groups(self):
+        if self.self_attention:
+            return [[self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
+                    [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]]
+        return [[self.k_proj.weight, self.v_proj.weight], [self.k_proj.bias, self.v_proj.bias]]
+
+    def _prm(self):
+        return {"q_w": self.q_proj.weight, "q_b": self.q_proj.bias, "k_w": self.k_proj.weight, "k_b": self.k_proj.bias,
+                "v_w": self.v_proj.weight, "v_b": self.v_proj.bias, "o_w": self.out_proj.weight, "o_b": self.out_proj.bias}
+
+    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False):
+        return Fn.attention(xq, xkv, residual, self._prm(), self.num_heads, B, Tq, Tk, key_lens, causal, "abs", None)
+
+
+class RelPositionMultiHeadedAttention(nn.Module):
+    """modules/espnet_multihead_attention.py:270-356 — keys linear_q/k/v/out, linear_pos, pos_bias_u/v."""
+
+    def __init__(self, n_feat, n_head, dropout, zero_triu=False):
+        super().__init__()
+        self.h, self.d_k = n_head, n_feat // n_head
+        if dropout:
+            _no_dropout()
+        if zero_triu:
+            raise NotImplementedError("zero_triu")
+        self.linear_q = Linear(n_feat, n_feat)
+        self.linear_k = Linear(n_feat, n_feat)
+        self.linear_v = Linear(n_feat, n_feat)
+        self.linear_out = Linear(n_feat, n_feat)
+        self.linear_pos = Linear(n_feat, n_feat, bias=False)
+        self.pos_bias_u = nn.Parameter(torch.empty(self.h, self.d_k))
+        self.pos_bias_v = nn.Parameter(torch.empty(self.h, self.d_k))
+        nn.init.xavier_uniform_(self.pos_bias_u)
+        nn.init.xavier_uniform_(self.pos_bias_v)
+
+    def flat_groups(self):
+        return [[self.linear_q.weight, self.linear_k.weight, self.linear_v.weight],
+                [self.linear_q.bias, self.linear_k.bias, self.linear_v.bias]]
+
+    def _prm(self):
+        return {"q_w": self.linear_q.weight, "q_b": self.linear_q.bias, "k_w": self.linear_k.weight,
+                "k_b": self.linear_k.bias, "v_w": self.linear_v.weight, "v_b": self.linear_v.bias,
+                "o_w": self.linear_out.weight, "o_b": self.linear_out.bias, "pos_w": self.linear_pos.weight,
+                "pos_u": self.pos_bias_u, "pos_v": self.pos_bias_v}
+
+    def forward(self, x, residual, B, T, key_lens, pos_tab):
+        return Fn.attention(x, None, residual, self._prm(), self.h, B, T, T, key_lens, False, "rel", pos_tab)
+
+
+class _BatchNorm1d(nn.Module):
+    """nn.BatchNorm1d holder (keys weight, bias, running_mean, running_var, num_batches_tracked)."""
+
+    def __init__(self, c, momentum=0.1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.momentum = momentum
+
+
+class _ConvW(nn.Module):
+    def __init__(self, shape, fan_in):
+        super().__init__()
+        bound = 1 / math.sqrt(fan_in)
+        self.weight = nn.Parameter(torch.empty(*shape).uniform_(-bound, bound))
+
+
+class ConvolutionModule(nn.Module):
+    """modules/convolution.py:11-120 — keys pointwise_conv1, depthwise_conv, norm, pointwise_conv2 (no biases)."""
+
+    def __init__(self, embed_dim, expand_embed_dim, depthwise_kernel_size, dropout, activation_fn="swish", bias=False,
+                 stride=1, padding=None, export=False, norm_type="batch_norm"):
+        super().__init__()
+        if bias or stride != 1 or padding is not None or norm_type != "batch_norm" or embed_dim != expand_embed_dim:
+            raise NotImplementedError("HIP conv module covers the recipes' configuration (batch_norm, no bias, stride 1)")
+        if dropout:
+            _no_dropout()
+        d, k = embed_dim, depthwise_kernel_size
+        self.pointwise_conv1 = _ConvW((2 * d, d, 1), d)
+        self.depthwise_conv = _ConvW((d, 1, k), k)
+        self.norm = _BatchNorm1d(d)
+        self.pointwise_conv2 = _ConvW((d, d, 1), d)
+        self.activation_fn = activation_fn
+
+    def forward(self, x_ln_masked, residual, B, T, lens):
+        prm = {"pw1_w": self.pointwise_conv1.weight, "dw_w": self.depthwise_conv.weight, "bn_w": self.norm.weight,
+               "bn_b": self.norm.bias, "pw2_w": self.pointwise_conv2.weight}
+        buf = {"running_mean": self.norm.running_mean, "running_var": self.norm.running_var}
+        if self.training:
+            self.norm.num_batches_tracked += 1
+        return Fn.conv_module(x_ln_masked, residual, prm, buf, self.activation_fn, B, T, lens, self.training,
+                              self.norm.momentum)
+
+
+class S2TTransformerEncoderLayer(nn.Module):
+    """modules/s2t_transformer_layer.py:69-322 (pre-LN; macaron / conv-module / rel_pos variants)."""
+
+    def __init__(self, args):
+        super().__init__()
+        d, ffn_dim = args.encoder_embed_dim, args.encoder_ffn_embed_dim
+        if not args.encoder_normalize_before:
+            raise NotImplementedError("post-LN encoder layers")
+        self.attn_type = getattr(args, "encoder_attention_type", "selfattn")
+        if self.attn_type == "selfattn":
+            self.self_attn = MultiheadAttention(d, args.encoder_attention_heads, dropout=args.dropout, self_attention=True)
+        elif self.attn_type == "rel_pos":
+            self.self_attn = RelPositionMultiHeadedAttention(d, args.encoder_attention_heads, dropout=args.dropout)
+        else:
+            raise NotImplementedError("encoder attention type %s (HIP path: selfattn, rel_pos)" % self.attn_type)
+        self.self_attn_layer_norm = LayerNorm(d)
+        act = getattr(args, "encoder_activation_fn", "relu")
+        if args.macaron_style:
+            self.macaron_ffn = FeedForwardModule(d, ffn_dim, args.dropout, args.dropout, act)
+            self.macaron_norm = LayerNorm(d)
+            self.ffn_scale = 0.5
+        else:
+            self.macaron_ffn = self.macaron_norm = None
+            self.ffn_scale = 1.0
+        if args.use_cnn_module:
+            self.conv_norm = LayerNorm(d)
+            # NB: the conv-module activation is --activation-fn, not --encoder-activation-fn (s2t_transformer_layer.py:125)
+            self.conv_module = ConvolutionModule(d, d, depthwise_kernel_size=args.cnn_module_kernel, dropout=args.dropout,
+                                                 activation_fn=getattr(args, "activation_fn", "swish"),
+                                                 norm_type=args.cnn_module_norm)
+            self.final_norm = LayerNorm(d)
+        else:
+            self.conv_norm = self.conv_module = self.final_norm = None
+        self.ffn = FeedForwardModule(d, ffn_dim, args.dropout, args.dropout, act)
+        self.ffn_norm = LayerNorm(d)
+
+    def forward(self, x, c: Ctx, mask_output: bool):
+        """x: [B*T, d].  ``mask_output``: zero padded frames of the result (the NEXT layer's layer_padding_mask)."""
+        B, T, lens = c.B, c.T, c.lens
+        if self.macaron_norm is not None:
+            x = self.macaron_ffn(self.macaron_norm(x), x, self.ffn_scale)
+        y = self.self_attn_layer_norm(x)
+        if self.attn_type == "rel_pos":
+            x = self.self_attn(y, x, B, T, lens, c.pos_tab)
+        else:
+            x = self.self_attn(y, None, x, B, T, T, lens)
+        if self.conv_module is not None:
+            y = self.conv_norm(x, lens, T)  # conv input mask fused (convolution.py:86-88)
+            x = self.conv_module(y, x, B, T, lens)
+        x = self.ffn(self.ffn_norm(x), x, self.ffn_scale)
+        if self.final_norm is not None:
+            x = self.final_norm(x, lens if mask_output else None, T)
+        elif mask_output:
+            x = MaskRows.apply(x, lens, T)
+        return x
+
+
+class MaskRows(torch.autograd.Function):
+    """x.masked_fill(pad, 0) on a row matrix (s2t_transformer.py:1828-1836)."""
+
+    @staticmethod
+    def forward(ctx, x, lens, T):
+        from . import kernels as K
+
+        y = x.clone()
+        K.mask_rows(y, lens, y.shape[0], T, y.shape[1])
+        ctx.lens, ctx.T = lens, T
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import kernels as K
+
+        g = dy.clone()
+        K.mask_rows(g, ctx.lens, g.shape[0], ctx.T, g.shape[1])
+        return g, None, None
+
+
+class CTC(nn.Module):
+    """modules/speech_to_text/ctc.py:17-75 — Linear(d -> V, bias), init N(0, d^-0.5)."""
+
+    def __init__(self, embed_dim, dictionary_size, dropout, need_layernorm=False, dictionary=None):
+        super().__init__()
+        if dropout:
+            _no_dropout()
+        self.ctc_projection = Linear(embed_dim, dictionary_size)
+        nn.init.normal_(self.ctc_projection.weight, mean=0, std=embed_dim ** -0.5)
+        nn.init.constant_(self.ctc_projection.bias, 0.0)
+        self.LayerNorm = LayerNorm(embed_dim) if need_layernorm else None
+        self.dictionary = dictionary
+        self.infer_decoding = False
+        self.blank_idx = 0
+
+    def set_infer(self, is_infer, text_post_process, dictionary, path):
+        self.infer_decoding, self.dictionary = is_infer, dictionary
+
+    def forward(self, x2d, out_dtype=None):
+        if self.LayerNorm is not None:
+            x2d = self.LayerNorm(x2d)
+        return self.ctc_projection(x2d, out_dtype=out_dtype)
+
+
+class TransformerDecoderLayer(nn.Module):
+    """modules/transformer_layer.py:240-546 (pre-LN) — keys self_attn, encoder_attn, *_layer_norm, fc1, fc2."""
+
+    def __init__(self, args):
+        super().__init__()
+        d = args.decoder_embed_dim
+        if not args.decoder_normalize_before:
+            raise NotImplementedError("post-LN decoder layers")
+        self.self_attn = MultiheadAttention(d, args.decoder_attention_heads, dropout=args.attention_dropout,
+                                            self_attention=True)
+        self.self_attn_layer_norm = LayerNorm(d)
+        self.encoder_attn = MultiheadAttention(d, args.decoder_attention_heads, dropout=args.attention_dropout,
+                                               encoder_decoder_attention=True)
+        self.encoder_attn_layer_norm = LayerNorm(d)
+        self.fc1 = Linear(d, args.decoder_ffn_embed_dim)
+        self.fc2 = Linear(args.decoder_ffn_embed_dim, d)
+        self.final_layer_norm = LayerNorm(d)
+        self.activation_fn = getattr(args, "activation_fn", "relu")
+        if args.dropout or getattr(args, "activation_dropout", 0):
+            _no_dropout()
+
+    def forward(self, x, mem, B, U, Tm, self_lens, mem_lens):
+        x = self.self_attn(self.self_attn_layer_norm(x), None, x, B, U, U, self_lens, causal=True)
+        x = self.encoder_attn(self.encoder_attn_layer_norm(x), mem, x, B, U, Tm, mem_lens)
+        return Fn.ffn(self.final_layer_norm(x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                      self.activation_fn, 1.0, x)
+
+
+# ------------------------------------------------------------------------------------------------
+# positional tables (host-built once, cached on device)
+# ------------------------------------------------------------------------------------------------
+def sinusoidal_table(n_pos: int, dim: int, padding_idx: int = 1) -> torch.Tensor:
+    """modules/sinusoidal_positional_embedding.py:36-58: [sin | cos] halves, step log(1e4)/(dim/2-1), pad row zero."""
+    half = dim // 2
+    step = math.log(10000.0) / (half - 1)
+    inv = torch.exp(torch.arange(half, dtype=torch.float32) * -step)
+    ang = torch.arange(n_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    if dim % 2 == 1:
+        tab = torch.cat([tab, torch.zeros(n_pos, 1)], dim=1)
+    tab[padding_idx] = 0.0
+    return tab
+
+
+def rel_pos_table(T: int, dim: int) -> torch.Tensor:
+    """modules/positional_encoding.py:121-166: (2T-1, dim), row n <-> offset T-1-n, interleaved sin/cos."""
+    rel = torch.arange(T - 1, -T, -1, dtype=torch.float32)[:, None]
+    inv = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    tab = torch.zeros(2 * T - 1, dim)
+    tab[:, 0::2] = torch.sin(rel * inv)
+    tab[:, 1::2] = torch.cos(rel * inv)
+    return tab
+
+
+class _TableCache:
+    def __init__(self):
+        self.c = {}
+
+    def get(self, kind, n, dim, device, dtype=torch.float32):
+        key = (kind, n, dim, str(device), dtype)
+        if key not in self.c:
+            t = sinusoidal_table(n, dim) if kind == "sin" else rel_pos_table(n, dim)
+            self.c[key] = t.to(device=device, dtype=dtype)
+        return self.c[key]
+
+
+TABLES = _TableCache()

@@ -1,0 +1,523 @@
+"""S2T Transformer / Conformer encoder-decoder on the HIP path, with the reference's registration names,
+constructor arguments, ``forward`` contracts and ``state_dict`` keys.
+
+Reference: fairseq/models/speech_to_text/s2t_transformer.py (S2TTransformerModel :41-886, S2TTransformerEncoder
+:887-2208, TransformerDecoderScriptable :2211-2253, architectures :2256-2470), fairseq/models/transformer.py
+(TransformerDecoder :789-1515).  Out of scope here (raise NotImplementedError when asked for): mixup,
+inter-CTC / XCTC / PAE, compression, DLCL history, layer-drop, quant-noise, adaptive softmax, incremental decoding.
+"""
+import math
+from argparse import Namespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .flat_params import FlatParameters
+from .modules import (CTC, TABLES, Conv1dSubsampling, Ctx, LayerNorm, Linear, MaskRows, S2TTransformerEncoderLayer,
+                      TransformerDecoderLayer)
+from .registry import register_model, register_model_architecture
+
+DEFAULT_MAX_SOURCE_POSITIONS = 6000
+DEFAULT_MAX_TARGET_POSITIONS = 1024
+
+
+def _unsupported(args, **flags):
+    for name, off in flags.items():
+        v = getattr(args, name, off)
+        if v != off and v not in (None, False, 0, "", "none"):
+            raise NotImplementedError("--%s=%r is outside the HIP hot path built so far" % (name.replace("_", "-"), v))
+
+
+class _SinPosHolder(nn.Module):
+    """Keeps the ``embed_positions._float_tensor`` buffer key of SinusoidalPositionalEmbedding."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("_float_tensor", torch.zeros(1))
+
+
+class S2TTransformerEncoder(nn.Module):
+    """Speech-to-text Transformer/Conformer encoder: Conv1d subsampler + N pre-LN layers (+ CTC head)."""
+
+    def __init__(self, args, task=None, decoder_embed_tokens=None):
+        super().__init__()
+        _unsupported(args, inter_mixup=False, use_enc_dlcl=False, inter_ctc_layers=None, inter_xctc_layers=None,
+                     xctc_weight=0, compression_layers=None, encoder_embed_linear=False, layer_out_norm=False,
+                     encoder_layerdrop=0.0)
+        self.args = args
+        d = args.encoder_embed_dim
+        self.embed_dim = d
+        self.padding_idx = 1
+        self.embed_scale = 1.0 if args.encoder_no_scale_embedding else math.sqrt(d)
+        if args.dropout:
+            raise NotImplementedError("dropout > 0 on the HIP path (parity runs use p = 0)")
+        filters = [args.subsampling_filter] * (args.subsampling_layers - 1) + [d]
+        self.subsample = Conv1dSubsampling(args.subsampling_layers, args.input_feat_per_channel * args.input_channels,
+                                           filters, args.subsampling_kernel, args.subsampling_stride,
+                                           args.subsampling_norm, args.subsampling_activation)
+        self.attn_type = getattr(args, "encoder_attention_type", "selfattn")
+        if self.attn_type != "rel_pos":
+            self.embed_positions = _SinPosHolder()  # keeps the reference's `embed_positions._float_tensor` key
+        self.embed_ln = LayerNorm(d) if getattr(args, "encoder_embed_norm", False) else None
+        self.layer_padding_mask = bool(getattr(args, "layer_padding_mask", False))
+        self.layers = nn.ModuleList([S2TTransformerEncoderLayer(args) for _ in range(args.encoder_layers)])
+        self.layer_norm = LayerNorm(d) if args.encoder_normalize_before else None
+        self.use_ctc = getattr(args, "ctc_weight", 0) > 0
+        if self.use_ctc:
+            if getattr(args, "ctc_layer", 0) not in (0, args.encoder_layers):
+                raise NotImplementedError("ctc_layer inside the stack")
+            vocab = len(task.source_dictionary) if task is not None else args.vocab_size
+            self.ctc = CTC(d, dictionary_size=vocab, dropout=args.dropout)
+            if getattr(args, "share_ctc_and_embed", False) and decoder_embed_tokens is not None:
+                self.ctc.ctc_projection.weight = decoder_embed_tokens.weight  # s2t_transformer.py:965-971
+        self.compute_dtype = torch.float32
+        self.ctc_out_dtype = None  # None -> compute dtype; eval sets fp32 (bit-exact greedy wants fp32 logits)
+        self.num_updates = 0
+
+    # -- fairseq encoder protocol ------------------------------------------------------------------
+    def max_positions(self):
+        return getattr(self.args, "max_source_positions", DEFAULT_MAX_SOURCE_POSITIONS)
+
+    def set_num_updates(self, n):
+        self.num_updates = n
+
+    def set_ctc_infer(self, ctc_infer, post_process, src_dict=None, tgt_dict=None, path=None):
+        if hasattr(self, "ctc"):
+            self.ctc.set_infer(ctc_infer, post_process, src_dict, path)
+
+    def set_flag(self, **kwargs):
+        pass
+
+    def dump(self, fstream, info=""):
+        pass
+
+    # -- forward -------------------------------------------------------------------------------------
+    def forward(self, src_tokens, src_lengths=None, **kwargs):
+        """src_tokens (B, T, C) float, src_lengths (B,) long -> dict of lists (s2t_transformer.py:2142-2154)."""
+        if not src_tokens.is_cuda:
+            raise RuntimeError("s2t_amd runs on the GPU only; there is no CPU fallback")
+        dt = self.compute_dtype
+        B, T, _ = src_tokens.shape
+        d = self.embed_dim
+        T1 = (T - 1) // 2 + 1
+        Tp = (T1 - 1) // 2 + 1
+        if src_lengths is None:
+            src_lengths = torch.full((B,), T, dtype=torch.long, device=src_tokens.device)
+        lens = self.subsample.get_out_seq_lens_tensor(src_lengths)
+        lens32 = lens.to(torch.int32)
+        x = self.subsample(src_tokens, lens32, dt)  # [B*T', d], padded frames zeroed (:1765)
+        encoder_padding_mask = torch.arange(Tp, device=x.device)[None, :] >= lens[:, None]
+        c = Ctx(B, Tp, lens32, dt)
+        if self.embed_ln is not None:
+            x = self.embed_ln(x)  # :1769
+        if self.attn_type == "rel_pos":
+            c.pos_tab = TABLES.get("rel", Tp, d, x.device, dt)  # not added to x (:1777-1778)
+            if self.embed_scale != 1.0:
+                x = x * self.embed_scale
+        else:
+            tab = TABLES.get("sin", max(self.max_positions(), Tp) + 2, d, x.device)
+            x = AddPositions.apply(x, tab, lens32, Tp, self.embed_scale)  # :1773-1787
+        if self.layer_padding_mask:
+            x = MaskRows.apply(x, lens32, Tp)  # layer 0's masked_fill (:1828-1836); later layers: fused in final_norm
+        n = len(self.layers)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, c, mask_output=self.layer_padding_mask and i + 1 < n)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        ctc_logit = None
+        if self.use_ctc:
+            logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype)
+            ctc_logit = logit2d.view(B, Tp, -1).transpose(0, 1)
+        return {
+            "encoder_out": [x.view(B, Tp, d).transpose(0, 1)],  # T x B x C (view of the batch-major buffer)
+            "ctc_logit": [] if ctc_logit is None else [ctc_logit],
+            "inter_ctc_logits": [],
+            "xctc_logit": [],
+            "inter_xctc_logits": [],
+            "encoder_padding_mask": [encoder_padding_mask],
+            "mixup": None,
+            "encoder_embedding": [],
+            "encoder_states": [],
+            "src_tokens": [],
+            "src_lengths": [],
+        }
+
+    def reorder_encoder_out(self, encoder_out, new_order):
+        """s2t_transformer.py:2156-2208."""
+        def sel(key, dim):
+            return [t.index_select(dim, new_order) for t in encoder_out.get(key, []) if t is not None]
+
+        return {
+            "encoder_out": sel("encoder_out", 1),
+            "ctc_logit": sel("ctc_logit", 1),
+            "xctc_logit": sel("xctc_logit", 1),
+            "encoder_padding_mask": sel("encoder_padding_mask", 0),
+            "encoder_embedding": sel("encoder_embedding", 0),
+            "encoder_states": [s.index_select(1, new_order) for s in encoder_out.get("encoder_states", [])],
+            "src_tokens": [],
+            "src_lengths": [],
+        }
+
+
+class AddPositions(torch.autograd.Function):
+    """x = scale*x + sinusoid(position of non-pad frame) (s2t_transformer.py:1773-1787; positions start at 2)."""
+
+    @staticmethod
+    def forward(ctx, x, tab, lens, T, scale):
+        from . import kernels as K
+
+        y = x.clone()
+        K.add_positions(y, tab, lens, y.shape[0], T, y.shape[1], scale, 2)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (dy if ctx.scale == 1.0 else dy * ctx.scale), None, None, None, None
+
+
+class Embedding(nn.Module):
+    """models/transformer.py:1518-1522 — N(0, d^-0.5), pad row zero."""
+
+    def __init__(self, num_embeddings, embedding_dim, padding_idx):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+        nn.init.normal_(self.weight, mean=0, std=embedding_dim ** -0.5)
+        with torch.no_grad():
+            self.weight[padding_idx].fill_(0)
+        self.padding_idx = padding_idx
+        self.embedding_dim = embedding_dim
+
+
+class TransformerDecoderScriptable(nn.Module):
+    """Teacher-forced cross-attention decoder (models/transformer.py:802-1448, s2t_transformer.py:2211-2253)."""
+
+    def __init__(self, args, dictionary, embed_tokens):
+        super().__init__()
+        _unsupported(args, use_dec_dlcl=False, decoder_layerdrop=0.0, adaptive_softmax_cutoff=None,
+                     layernorm_embedding=False, decoder_learned_pos=False, no_token_positional_embeddings=False)
+        self.args = args
+        self.dictionary = dictionary
+        d = args.decoder_embed_dim
+        self.embed_dim = d
+        self.padding_idx = embed_tokens.padding_idx
+        self.embed_tokens = embed_tokens
+        self.embed_scale = 1.0 if getattr(args, "no_scale_embedding", False) else math.sqrt(d)
+        self.embed_positions = _SinPosHolder()
+        self.register_buffer("version", torch.tensor([3.0]))
+        self.layers = nn.ModuleList([TransformerDecoderLayer(args) for _ in range(args.decoder_layers)])
+        self.layer_norm = LayerNorm(d) if args.decoder_normalize_before else None
+        self.output_projection = Linear(d, len(dictionary), bias=False)
+        if args.share_decoder_input_output_embed:
+            self.output_projection.weight = self.embed_tokens.weight
+        else:
+            nn.init.normal_(self.output_projection.weight, mean=0, std=d ** -0.5)
+        self.compute_dtype = torch.float32
+        self.logits_dtype = None
+
+    def max_positions(self):
+        return getattr(self.args, "max_target_positions", DEFAULT_MAX_TARGET_POSITIONS)
+
+    def extract_features(self, prev_output_tokens, encoder_out=None, incremental_state=None, **unused):
+        if incremental_state is not None:
+            raise NotImplementedError("incremental decoding (beam search) is a next-tier row (SURVEY.md §8f.1)")
+        B, U = prev_output_tokens.shape
+        d = self.embed_dim
+        dev = prev_output_tokens.device
+        nonpad = prev_output_tokens.ne(self.padding_idx)
+        pos = (torch.cumsum(nonpad, dim=1) * nonpad + self.padding_idx).to(torch.int32)  # utils.py:240-250
+        tab = TABLES.get("sin", self.max_positions() + self.padding_idx + 1, d, dev)
+        x = Fn.embedding(prev_output_tokens.contiguous(), pos.contiguous(), self.embed_tokens.weight, tab,
+                         self.embed_scale, self.padding_idx)
+        # key-padding of the target side: pads sit at the end for left-aligned targets; general masks
+        # (pads in the middle) would need a mask tensor, the collater never produces them
+        self_lens = nonpad.sum(1).to(torch.int32)
+        mem_tbc = encoder_out["encoder_out"][0]
+        Tm = mem_tbc.shape[0]
+        mem = mem_tbc.transpose(0, 1).contiguous().view(B * Tm, d)
+        mem_lens = (~encoder_out["encoder_padding_mask"][0]).sum(1).to(torch.int32)
+        # reference (:1340-1342): pad KEYS are masked for every query; pad queries still attend
+        for layer in self.layers:
+            x = layer(x, mem, B, U, Tm, self_lens, mem_lens)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        return x.view(B, U, d), {"attn": [None], "inner_states": [], "mixup": None}
+
+    def output_layer(self, features):
+        B, U, d = features.shape
+        y = self.output_projection(features.reshape(B * U, d), out_dtype=self.logits_dtype)
+        return y.view(B, U, -1)
+
+    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, features_only=False, **unused):
+        x, extra = self.extract_features(prev_output_tokens, encoder_out, incremental_state)
+        if not features_only:
+            x = self.output_layer(x)
+        return x, extra
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        logits = net_output[0].float()
+        return torch.log_softmax(logits, dim=-1) if log_probs else torch.softmax(logits, dim=-1)
+
+
+class _DictLike:
+    """Minimal stand-in for fairseq.data.Dictionary when fairseq is absent: bos=0 (CTC blank), pad=1, eos=2, unk=3."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def pad(self):
+        return 1
+
+    def eos(self):
+        return 2
+
+    def bos(self):
+        return 0
+
+    def unk(self):
+        return 3
+
+
+class FakeTask:
+    def __init__(self, vocab):
+        self.source_dictionary = self.target_dictionary = _DictLike(vocab)
+
+    def get_source_dictionary(self, i):
+        return self.source_dictionary
+
+
+class _HipModel(nn.Module):
+    flat: Optional[FlatParameters] = None
+
+    def prepare(self, dtype=torch.float32, device="cuda"):
+        """Move to the GPU, flatten parameters (fp32 master + grads + bf16 shadow) and set the compute dtype."""
+        self.to(device)
+        self.flat = FlatParameters(self, dtype)
+        for m in self.modules():
+            if hasattr(m, "compute_dtype"):
+                m.compute_dtype = dtype
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = nn.Module.load_state_dict(self, state_dict, strict=strict, **kw)
+        if self.flat is not None:
+            self.flat.refresh_shadow()
+        return r
+
+
+@register_model("s2t_transformer")
+class S2TTransformerModel(_HipModel):
+    """models/speech_to_text/s2t_transformer.py:41-886 — encoder + decoder, ``build_model(args, task)``."""
+
+    def __init__(self, encoder, decoder):
+        super().__init__()
+        self.encoder, self.decoder = encoder, decoder
+        self.flat: Optional[FlatParameters] = None
+
+    @staticmethod
+    def add_args(parser):  # the flags live on the reference's parser; listed for --user-dir use
+        for flag, typ in (("--encoder-embed-dim", int), ("--encoder-ffn-embed-dim", int), ("--encoder-layers", int),
+                          ("--encoder-attention-heads", int), ("--decoder-layers", int), ("--ctc-weight", float),
+                          ("--cnn-module-kernel", int), ("--encoder-attention-type", str)):
+            try:
+                parser.add_argument(flag, type=typ)
+            except Exception:  # noqa: BLE001 - already defined by fairseq
+                pass
+
+    @classmethod
+    def build_model(cls, args, task):
+        base_architecture(args)
+        tgt = task.target_dictionary
+        embed = Embedding(len(tgt), args.decoder_embed_dim, tgt.pad())
+        encoder = S2TTransformerEncoder(args, task, embed)
+        decoder = TransformerDecoderScriptable(args, tgt, embed)
+        return cls(encoder, decoder)
+
+    def forward(self, src_tokens, src_lengths, prev_output_tokens):
+        enc = self.encoder(src_tokens, src_lengths)
+        return self.decoder(prev_output_tokens, encoder_out=enc)
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        """s2t_transformer.py:857-866 — fp32 (log-)softmax tagged batch_first."""
+        if isinstance(net_output, (list, tuple)) and torch.is_tensor(net_output[0]) and net_output[0].dim() == 3:
+            logits = net_output[0].float()
+        else:
+            logits = net_output.float()
+        lp = torch.log_softmax(logits, -1) if log_probs else torch.softmax(logits, -1)
+        lp.batch_first = True
+        return lp
+
+    def max_positions(self):
+        return (self.encoder.max_positions(), self.decoder.max_positions())
+
+    def set_num_updates(self, n):
+        self.encoder.set_num_updates(n)
+
+
+@register_model("s2t_ctc")
+class S2TCTCModel(_HipModel):
+    """models/speech_to_text/s2t_ctc.py:28-171 — encoder-only CTC model (``--encoder-type transformer``)."""
+
+    def __init__(self, encoder):
+        super().__init__()
+        self.encoder = encoder
+        self.flat = None
+
+    @classmethod
+    def build_model(cls, args, task):
+        base_architecture(args)
+        if getattr(args, "ctc_weight", 0) <= 0:
+            args.ctc_weight = 1.0
+        if getattr(args, "encoder_type", "transformer") != "transformer":
+            raise NotImplementedError("s2t_ctc --encoder-type %s" % args.encoder_type)
+        return cls(S2TTransformerEncoder(args, task))
+
+    def forward(self, src_tokens, src_lengths, prev_output_tokens=None, **kwargs):
+        return self.encoder(src_tokens, src_lengths)
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        logits = net_output["ctc_logit"][0] if isinstance(net_output, dict) else net_output[0]
+        lp = torch.log_softmax(logits.float(), -1) if log_probs else torch.softmax(logits.float(), -1)
+        lp.batch_first = False
+        return lp
+
+
+class CTCDecoder:
+    """Greedy CTC decoding (models/speech_to_text/s2t_ctc.py:174-349): fp32 log-softmax -> arg-max (ties -> lowest
+    id) -> padded frames to blank -> unique_consecutive -> drop blank, all on the GPU; one D2H copy of the ids."""
+
+    def __init__(self, models, args=None, dictionary=None, blank_idx=0):
+        self.model = models[0] if isinstance(models, (list, tuple)) else models
+        self.blank = blank_idx
+        self.pad = 1 if dictionary is None else dictionary.pad()
+
+    @torch.no_grad()
+    def generate(self, models, sample, **kwargs):
+        from . import kernels as K
+
+        net_input = sample["net_input"]
+        enc = self.model(src_tokens=net_input["src_tokens"], src_lengths=net_input["src_lengths"])
+        logit_tbv = enc["xctc_logit"][0] if len(enc.get("xctc_logit", [])) else enc["ctc_logit"][0]
+        Tn, B, V = logit_tbv.shape
+        logits = logit_tbv.transpose(0, 1).reshape(B * Tn, V)  # batch-major rows (a view when it came from us)
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        lens = (~enc["encoder_padding_mask"][0]).sum(1).to(torch.int32)
+        dev = logits.device
+        idx = torch.empty(B * Tn, dtype=torch.int32, device=dev)
+        top = torch.empty(B * Tn, dtype=torch.float32, device=dev)
+        K.argmax_lse(logits, logits.stride(0), B * Tn, V, idx, top, None)
+        toks = torch.zeros(B, Tn, dtype=torch.int64, device=dev)
+        olen = torch.zeros(B, dtype=torch.int32, device=dev)
+        osc = torch.zeros(B, dtype=torch.float32, device=dev)
+        K.ctc_collapse(idx, top, lens, B, Tn, self.blank, toks, olen, osc)
+        toks, olen, osc = toks.cpu(), olen.cpu(), osc.cpu()
+        out = []
+        for b in range(B):
+            n = int(olen[b])
+            hyp = toks[b, :n]
+            out.append([{"tokens": hyp, "score": osc[b:b + 1], "attention": None, "alignment": None,
+                         "positional_scores": torch.full((n,), float(osc[b]) / max(n, 1))}])
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# architectures (defaults as in s2t_transformer.py:2256-2470)
+# ------------------------------------------------------------------------------------------------
+def _d(args, name, val):
+    if not hasattr(args, name):
+        setattr(args, name, val)
+
+
+@register_model_architecture("s2t_transformer", "s2t_transformer")
+def base_architecture(args):
+    _d(args, "input_feat_per_channel", 80)
+    _d(args, "input_channels", 1)
+    _d(args, "subsampling_type", "conv1d")
+    _d(args, "subsampling_layers", 2)
+    _d(args, "subsampling_filter", 1024)
+    _d(args, "subsampling_kernel", 5)
+    _d(args, "subsampling_stride", 2)
+    _d(args, "subsampling_norm", "none")
+    _d(args, "subsampling_activation", "glu")
+    _d(args, "encoder_embed_dim", 512)
+    _d(args, "encoder_ffn_embed_dim", 2048)
+    _d(args, "encoder_layers", 12)
+    _d(args, "encoder_attention_type", "selfattn")
+    _d(args, "encoder_attention_heads", 8)
+    _d(args, "encoder_normalize_before", True)
+    _d(args, "decoder_embed_dim", args.encoder_embed_dim)
+    _d(args, "decoder_ffn_embed_dim", args.encoder_ffn_embed_dim)
+    _d(args, "decoder_layers", 6)
+    _d(args, "decoder_attention_heads", 8)
+    _d(args, "decoder_normalize_before", True)
+    _d(args, "decoder_learned_pos", False)
+    _d(args, "dropout", 0.1)
+    _d(args, "attention_dropout", args.dropout)
+    _d(args, "activation_dropout", args.dropout)
+    _d(args, "activation_fn", "relu")
+    _d(args, "share_decoder_input_output_embed", False)
+    _d(args, "no_scale_embedding", False)
+    _d(args, "encoder_no_scale_embedding", False)
+    _d(args, "encoder_embed_norm", False)
+    _d(args, "layer_padding_mask", False)
+    _d(args, "ctc_layer", 0)
+    _d(args, "ctc_weight", 0.0)
+    _d(args, "share_ctc_and_embed", False)
+    _d(args, "encoder_activation_fn", "relu")
+    _d(args, "macaron_style", False)
+    _d(args, "use_cnn_module", False)
+    _d(args, "cnn_module_kernel", 31)
+    _d(args, "cnn_module_norm", "batch_norm")
+    _d(args, "max_source_positions", DEFAULT_MAX_SOURCE_POSITIONS)
+    _d(args, "max_target_positions", DEFAULT_MAX_TARGET_POSITIONS)
+
+
+@register_model_architecture("s2t_transformer", "s2t_transformer_s")
+def s2t_transformer_s(args):
+    _d(args, "encoder_embed_dim", 256)
+    _d(args, "encoder_ffn_embed_dim", 256 * 8)
+    _d(args, "encoder_attention_heads", 4)
+    _d(args, "decoder_attention_heads", 4)
+    _d(args, "dropout", 0.1)
+    base_architecture(args)
+
+
+@register_model_architecture("s2t_ctc", "s2t_ctc")
+def s2t_ctc_base(args):
+    base_architecture(args)
+
+
+@register_model_architecture("s2t_ctc", "s2t_ctc_s")
+def s2t_ctc_s(args):
+    s2t_transformer_s(args)
+
+
+def recipe_args(conformer=False, **over):
+    """Namespace equal to the reference's YAML stack base.yaml + ctc.yaml (+ conformer.yaml)
+    (egs/mustc/asr/conf/*.yaml) with dropout forced to 0 (not built yet on the HIP path)."""
+    a = Namespace(
+        arch="s2t_transformer_s", share_decoder_input_output_embed=True, encoder_embed_norm=True,
+        encoder_no_scale_embedding=True, subsampling_type="conv1d", subsampling_layers=2, subsampling_filter=1024,
+        subsampling_kernel=5, subsampling_stride=2, subsampling_norm="none", subsampling_activation="glu",
+        dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, activation_fn="relu", encoder_embed_dim=256,
+        encoder_ffn_embed_dim=2048, encoder_layers=12, decoder_layers=6, encoder_attention_heads=4,
+        decoder_embed_dim=256, decoder_ffn_embed_dim=2048, decoder_attention_heads=4, ctc_weight=0.3,
+        share_ctc_and_embed=True, input_feat_per_channel=80, input_channels=1,
+    )
+    if conformer:
+        a.macaron_style = True
+        a.use_cnn_module = True
+        a.cnn_module_kernel = 15
+        a.encoder_attention_type = "rel_pos"
+        a.encoder_activation_fn = "swish"
+        a.layer_padding_mask = True
+    for k, v in over.items():
+        setattr(a, k, v)
+    s2t_transformer_s(a)
+    return a

@@ -99,10 +99,12 @@ def test_attn_softmax_fwd_bwd(dtype, Tq, Tk, causal, rel):
     dS = torch.empty(Z, Tq, ldS, dtype=dtype, device=DEV)
     dBD = torch.full((Z, Tq, ldB), 5.0, dtype=dtype, device=DEV) if rel else None
     # backward consumes the probabilities as stored (bf16-rounded in bf16 mode)
-    K.attn_softmax_bwd(P, ldS, dP.to(DEV), ldS, dS, ldS, dBD, ldB, Z, Tq, Tk, scale)
+    K.attn_softmax_bwd(P, ldS, dP.to(DEV), ldS, dS, ldS, dBD, ldB, Z, H, Tq, Tk, scale)
     close(dS[..., :Tk], s.grad, dtype, 2)
     if rel:
-        close(dBD[..., : 2 * Tq - 1], bdr.grad[..., : 2 * Tq - 1], dtype, 2)
+        # dBD comes back head-major: row (h*B + b)*Tq + i
+        hm = bdr.grad.view(Bz, H, Tq, ldB).transpose(0, 1).reshape(Z, Tq, ldB)
+        close(dBD[..., : 2 * Tq - 1], hm[..., : 2 * Tq - 1], dtype, 2)
 
 
 @pytest.mark.parametrize("dtype", DT)
