@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: speech-frames/sec of one full training update (encoder + decoder forward + backward +
+gradient all-reduce + clip + Adam) of the 12-layer Conformer S2T model on synthetic 1000x80 filterbank batches.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement; roofline + cpu_baseline objects included).
+Workload = BASELINE.json configs[1] in its Conformer reading (SURVEY.md §8d config 2'): s2t_transformer_s,
+12 enc / 6 dec, d=256, F=2048, h=4, rel_pos + macaron + conv-module(K=15), V=10000, B=64 x T=1000 x 80, bf16,
+label-smoothed CE (0.1) + 0.3 CTC, Adam, clip 10.  Dropout is 0 (not built yet on the HIP path) — stated in config.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_BF16 = 2.5e15  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_F32 = 157.3e12
+
+
+def synthetic_batch(B, T, V, seed, device):
+    """randn features, row 0 full length, others U[ceil(.6T), T], sorted desc, tail zeroed;
+    targets 20..60 tokens uniform in [4, V) + eos; prev_output_tokens = eos-shifted (collater layout)."""
+    g = torch.Generator().manual_seed(seed)
+    lens = [T] + [int(torch.randint(int(math.ceil(0.6 * T)), T + 1, (1,), generator=g)) for _ in range(B - 1)]
+    lens = sorted(lens, reverse=True)
+    src = torch.randn(B, T, 80, generator=g)
+    for b, l in enumerate(lens):
+        src[b, l:] = 0
+    ul = [int(torch.randint(20, 61, (1,), generator=g)) for _ in range(B)]
+    U = max(ul) + 1
+    target = torch.full((B, U), 1, dtype=torch.long)
+    prev = torch.full((B, U), 1, dtype=torch.long)
+    for b, u in enumerate(ul):
+        toks = torch.randint(4, V, (u,), generator=g)
+        target[b, :u] = toks
+        target[b, u] = 2
+        prev[b, 0] = 2
+        prev[b, 1:u + 1] = toks
+    sample = {
+        "net_input": {"src_tokens": src.to(device), "src_lengths": torch.tensor(lens).to(device),
+                      "prev_output_tokens": prev.to(device)},
+        "target": target.to(device),
+        "ntokens": int(sum(ul) + B),
+    }
+    return sample, int(sum(lens))
+
+
+def cpu_baseline(args, V, conformer):
+    """Reference's PyTorch-CPU algorithm (the pinned oracle restatement, autograd for backward) timed on this box's
+    host cores on a bounded sample of the same workload: B=2 utterances of the same length/width."""
+    from oracle import s2t_oracle as O
+    from s2t_amd import s2t_transformer as M
+
+    torch.manual_seed(0)
+    a = M.recipe_args(conformer=conformer, vocab_size=V)
+    model = M.S2TTransformerModel.build_model(a, M.FakeTask(V))
+    W = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = {k: getattr(a, k) for k in vars(a)}
+    Bc = 2
+    sample, frames = synthetic_batch(Bc, args.frames, V, 123, "cpu")
+    ni = sample["net_input"]
+    cores = torch.get_num_threads()
+
+    def step():
+        for w in W.values():
+            w.grad = None
+        loss, _ = O.joint_loss(W, cfg, ni["src_tokens"], ni["src_lengths"], ni["prev_output_tokens"], sample["target"],
+                               eps=0.1, training=True, use_torch_ctc=True)
+        loss.backward()
+
+    step()
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < 12 and n < 20):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle (fp32 PyTorch-CPU restatement, autograd bwd) fwd+bwd of the same model on %d x %d x 80, "
+                      "%d timed iterations" % (Bc, args.frames, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", default="conformer", choices=["conformer", "transformer"])
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--vocab", type=int, default=10000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--enc-layers", type=int, default=12)
+    ap.add_argument("--dec-layers", type=int, default=6)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    import __graft_entry__ as entry
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, "s2t_amd", "lib", "libs2t_hip.so")):
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from s2t_amd import criterions as C
+    from s2t_amd import kernels as K
+    from s2t_amd import s2t_transformer as M
+    from s2t_amd.legacy_distributed_data_parallel import LegacyDistributedDataParallel
+    from s2t_amd.trainer import Trainer
+
+    V = args.vocab
+    conformer = args.arch == "conformer"
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(1)
+    margs = M.recipe_args(conformer=conformer, vocab_size=V, encoder_layers=args.enc_layers, decoder_layers=args.dec_layers)
+    model = M.S2TTransformerModel.build_model(margs, M.FakeTask(V)).prepare(dtype, dev)
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    ddp = LegacyDistributedDataParallel(model) if world > 1 else None
+    trainer = Trainer(model, crit, ddp=ddp)
+    sample, frames_local = synthetic_batch(args.batch, args.frames, V, 1 + rank, dev)
+    ft = torch.tensor([frames_local, sample["ntokens"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(ft)
+    frames_global, ntok_global = int(ft[0]), int(ft[1])
+
+    use_graph = not args.no_graph
+    if use_graph:
+        try:
+            if ddp is not None:  # learn the grad-ready counts eagerly before capturing
+                trainer.train_step(sample, ntok_global)
+            trainer.capture(sample, ntok_global)
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print("[bench] graph capture failed (%s: %s); falling back to eager launches" % (type(e).__name__, e),
+                      file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize()
+
+    def step():
+        if use_graph:
+            return trainer.replay()
+        return trainer.train_step(sample, ntok_global)
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt[0])
+    loss_val = float(out[0])
+
+    result = None
+    if rank == 0:
+        # ---- roofline leg: one instrumented eager step, HIP events around every GEMM launch on the launch stream
+        K.GEMM_PROFILE = []
+        trainer.train_step(sample, ntok_global)
+        torch.cuda.synchronize()
+        prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+        agg = {}
+        for sym, flops, e0, e1, shape in prof:
+            a = agg.setdefault(sym, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        sym, (fl, sec, cnt) = dom
+        peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
+        gemm_total = sum(v[1] for v in agg.values())
+        roofline = {"bound": "mfma", "kernel": sym, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                    "frac": fl / sec / peak, "traffic": None, "launches_per_step": cnt,
+                    "avg_launch_us": sec / cnt * 1e6, "all_gemm_ms_per_step": gemm_total * 1e3,
+                    "all_gemm_tflops": sum(v[0] for v in agg.values()) / gemm_total / 1e12}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, V, conformer)
+        result = {
+            "metric": "speech-frames/sec (enc+dec fwd+bwd+update), 12L Conformer, 1000x80 fbank",
+            "value": frames_global * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "s2t_transformer_s %s %d-enc/%d-dec d256 F2048 h4 V%d, per-GPU batch %dx%dx80, CE(ls0.1)+0.3*CTC, "
+                            "Adam+clip10, dropout 0" % (args.arch, args.enc_layers, args.dec_layers, V, args.batch, args.frames),
+                "global_batch": args.batch * world, "frames_per_step": frames_global, "parallelism": "dp%d" % world,
+                "hip_graph": use_graph, "final_loss": loss_val,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

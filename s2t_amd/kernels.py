@@ -11,6 +11,17 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# Optional per-launch timing of the GEMM symbols (bench.py's roofline leg): when a list is installed here every
+# s2t_gemm launch is bracketed by HIP events on the launch stream and (symbol, flops, ev0, ev1) is appended.
+GEMM_PROFILE = None
+
+
+def gemm_symbol(dtype, a_kmajor, b_kmajor, c_dtype, glu):
+    t = {torch.float32: "f32", torch.bfloat16: "bf16"}
+    return "gemm_kernel<%s,%s,%s,%s,%s>" % (t[dtype], "AK" if a_kmajor else "AR", "BK" if b_kmajor else "BR", t[c_dtype],
+                                            "glu" if glu else "lin")
+
+
 def gemm(
     A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int,
     lda: int, ldb: int, ldc: int, a_kmajor=False, b_kmajor=False,
@@ -55,6 +66,14 @@ def gemm(
         assert row_lens.dtype == torch.int32
     a.split_k = split_k
     a.c_atomic = int(c_atomic)
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().s2t_gemm(C.byref(a), L.stream_ptr()), "s2t_gemm")
+        e1.record()
+        GEMM_PROFILE.append((gemm_symbol(A.dtype, a_kmajor, b_kmajor, out.dtype, act == "glu"),
+                             2.0 * M * N * K * max(batch, 1), e0, e1, (M, N, K, batch)))
+        return out
     L.check(L.lib().s2t_gemm(C.byref(a), L.stream_ptr()), "s2t_gemm")
     return out
 

@@ -1,0 +1,137 @@
+"""Data-parallel gradient all-reduce over RCCL/xGMI for the flat gradient buffer.
+
+Mirrors the protocol of the reference's wrapper (fairseq/distributed/legacy_distributed_data_parallel.py:29-160,
+hooked from trainer.py:714-718 through optim/fairseq_optimizer.py:97-100): ``forward`` delegates to the wrapped
+module, ``no_sync()`` suppresses the reduction while accumulating, ``all_reduce_grads()`` leaves every gradient equal
+to ``sum_over_ranks(grad) / world_size`` (the trainer then multiplies by ``world / sample_size``, trainer.py:729-734).
+
+What is different (MI355X-first):
+  * gradients already live in ONE contiguous fp32 buffer (flat_params.py), so a bucket is a *view* — the reference's
+    copy-in / div_ / all_reduce / copy-out (:82-120) becomes a single in-place collective per bucket, with the
+    division folded into ``ReduceOp.AVG`` on RCCL;
+  * buckets are reduced while backward is still running: the autograd functions report each parameter whose
+    gradient is final (functional._ready); when the last parameter of a bucket has reported, its all-reduce is
+    launched on a side HIP stream behind an event.  xGMI is point-to-point (7 links per GPU): a few large buckets
+    (default 32 MiB) keep every link streaming instead of many latency-bound small rings;
+  * BatchNorm buffers are NOT synchronised, like the reference (":29-31 does not broadcast buffers").
+"""
+from contextlib import contextmanager
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import functional as Fn
+
+
+class LegacyDistributedDataParallel(nn.Module):
+    def __init__(self, module, process_group=None, buffer_size=2 ** 23, overlap=True):
+        """``buffer_size``: bucket size in ELEMENTS (2**23 fp32 = 32 MiB)."""
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.accumulate_grads = False
+        self.overlap = overlap
+        flat = module.flat
+        assert flat is not None, "call model.prepare() before wrapping it"
+        self.flat = flat
+        # buckets = contiguous slices of the flat gradient buffer, filled from the END (backward order)
+        n = flat.numel
+        bounds = list(range(n, 0, -buffer_size))[::-1]
+        starts = [max(0, b - buffer_size) for b in bounds]
+        self.buckets = [(s, e) for s, e in zip(starts, bounds)]
+        self._bucket_of: Dict[int, List[int]] = {}
+        for p in flat.params:
+            o, cnt = flat.offsets[id(p)], p.numel()
+            self._bucket_of[id(p)] = [i for i, (s, e) in enumerate(self.buckets) if o < e and o + cnt > s]
+        self._expected: Dict[int, int] = {}  # ready-calls per parameter, learned on the first step
+        self._seen: Dict[int, int] = {}
+        self._pending = None
+        self._launched = set()
+        self._work = []
+        self._side = torch.cuda.Stream() if (flat.grad.is_cuda and overlap) else None
+        self._learning = True
+
+    # -- module protocol ---------------------------------------------------------------------------
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("module"), name)  # distributed/module_proxy_wrapper.py behaviour
+
+    @contextmanager
+    def no_sync(self):
+        old = self.accumulate_grads
+        self.accumulate_grads = True
+        try:
+            yield
+        finally:
+            self.accumulate_grads = old
+
+    # -- overlap machinery ---------------------------------------------------------------------------
+    def begin_backward(self):
+        """Arm the grad-ready hook for one backward pass."""
+        self._seen = {}
+        self._launched = set()
+        self._work = []
+        if self.world_size == 1 or self.accumulate_grads:
+            Fn._HOOKS["grad_ready"] = None
+            return
+        if self._learning:
+            Fn._HOOKS["grad_ready"] = self._count
+        elif self.overlap:
+            self._pending = [0] * len(self.buckets)
+            for p in self.flat.params:
+                for b in self._bucket_of[id(p)]:
+                    self._pending[b] += self._expected.get(id(p), 0)
+            Fn._HOOKS["grad_ready"] = self._on_ready
+        else:
+            Fn._HOOKS["grad_ready"] = None
+
+    def _count(self, p):
+        self._seen[id(p)] = self._seen.get(id(p), 0) + 1
+
+    def _on_ready(self, p):
+        for b in self._bucket_of[id(p)]:
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        view = self.flat.grad[s:e]
+        self._launched.add(b)
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                self._reduce(view)
+        else:
+            self._reduce(view)
+
+    def _reduce(self, view):
+        if view.is_cuda:
+            dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.process_group)
+        else:  # gloo (CPU tests): no AVG
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group)
+            view.div_(self.world_size)
+
+    def all_reduce_grads(self):
+        """Finish the reduction: every gradient becomes sum_over_ranks / world_size (reference :76-160)."""
+        Fn._HOOKS["grad_ready"] = None
+        if self.world_size == 1 or self.accumulate_grads:
+            return
+        if self._learning:
+            self._expected = dict(self._seen)
+            self._learning = False
+        for b in range(len(self.buckets) - 1, -1, -1):
+            if b not in self._launched:
+                self._launch(b)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)

@@ -1,0 +1,105 @@
+"""Minimal training harness reproducing the ordering of the reference's ``Trainer.train_step``
+(fairseq/trainer.py:611-759): zero_grad -> forward/backward -> all-reduce gradients -> multiply by
+world/sample_size -> clip by global norm -> Adam step, with the inverse-sqrt schedule of the recipes
+(optim/lr_scheduler/inverse_square_root_schedule.py:59-85, egs/mustc/asr/conf/base.yaml:4-9).
+
+Everything after backward is three launches over the flat buffers (sum of squares, clip coefficient, Adam) with
+no host synchronisation, so a whole step can be captured in a hipGraph (``capture=True``) — the launch-bound
+regime the reference's eager PyTorch loop lives in is removed rather than tuned.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+
+class Trainer:
+    def __init__(self, model, criterion, ddp=None, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0,
+                 clip_norm=10.0, warmup_updates=10000, warmup_init_lr=1e-7):
+        self.model, self.criterion, self.ddp = model, criterion, ddp
+        self.flat = model.flat
+        self.lr, self.betas, self.eps, self.wd, self.clip_norm = lr, betas, eps, weight_decay, clip_norm
+        self.warmup_updates, self.warmup_init_lr = warmup_updates, warmup_init_lr
+        dev = self.flat.master.device
+        self.exp_avg = torch.zeros_like(self.flat.master)
+        self.exp_avg_sq = torch.zeros_like(self.flat.master)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)  # lr, step_size, grad_scale, grad_norm
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(2)
+        self.num_updates = 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._graph = None
+        self._static = None
+
+    # ---- schedule -----------------------------------------------------------------------------------
+    def lr_at(self, n):
+        """inverse_sqrt: linear warmup_init_lr -> lr over warmup_updates, then lr * sqrt(warmup / n)."""
+        if n < self.warmup_updates:
+            return self.warmup_init_lr + n * (self.lr - self.warmup_init_lr) / self.warmup_updates
+        return self.lr * math.sqrt(self.warmup_updates) / math.sqrt(max(n, 1))
+
+    def _push_hyper(self):
+        t = self.num_updates + 1
+        lr = self.lr_at(t)
+        b1, b2 = self.betas
+        self._hyper_host[0] = lr
+        self._hyper_host[1] = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        self.hyper[:2].copy_(self._hyper_host, non_blocking=True)
+
+    # ---- one update ----------------------------------------------------------------------------------
+    def _step_body(self, sample, sample_size_global):
+        self.flat.zero_grad()
+        if self.ddp is not None:
+            self.ddp.begin_backward()
+        loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
+        loss.backward()
+        if self.ddp is not None:
+            self.ddp.all_reduce_grads()  # grads = sum_ranks / world
+        n = self.flat.numel
+        self.sumsq.zero_()
+        K.sumsq_accum(self.flat.grad, n, self.sumsq)
+        K.clip_coef(self.sumsq, self.clip_norm, self.world / float(sample_size_global), self.hyper)
+        K.adam_step(self.flat.master, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.flat.shadow, n, self.betas[0],
+                    self.betas[1], self.eps, self.wd, self.hyper)
+        return loss.detach(), log
+
+    def train_step(self, sample, sample_size_global=None):
+        """Eager step.  ``sample_size_global``: sum of sample sizes over ranks (defaults to world * local)."""
+        self.model.train()
+        if sample_size_global is None:
+            sample_size_global = self.world * sample["ntokens"]
+        self._push_hyper()
+        loss, log = self._step_body(sample, sample_size_global)
+        self.num_updates += 1
+        log["gnorm"] = self.hyper[3]
+        log["lr"] = self.lr_at(self.num_updates)
+        return loss, log
+
+    # ---- graph-captured step (fixed shapes) -------------------------------------------------------------
+    def capture(self, sample, sample_size_global=None, warmup=2):
+        """Capture one full update for ``sample``'s shapes into a hipGraph; returns nothing, use ``replay``."""
+        self.model.train()
+        if sample_size_global is None:
+            sample_size_global = self.world * sample["ntokens"]
+        self._static = sample
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._push_hyper()
+                self._step_body(sample, sample_size_global)
+                self.num_updates += 1
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        self._push_hyper()
+        with torch.cuda.graph(self._graph):
+            self._graph_out = self._step_body(sample, sample_size_global)
+
+    def replay(self):
+        self._push_hyper()
+        self._graph.replay()
+        self.num_updates += 1
+        return self._graph_out
