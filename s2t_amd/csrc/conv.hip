@@ -331,7 +331,7 @@ extern "C" int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, f
   const size_t shm = (size_t)((TT + K - 1) * CCH + TT * CCH) * sizeof(float);
   const int tiles_t = (T + TT - 1) / TT;
   int nb = B * tiles_t;
-  if (nb > 256) nb = 256;
+  if (nb > 96) nb = 96;
   dim3 grid(nb, 1, (C + CCH - 1) / CCH), block(256);
   hipStream_t s = (hipStream_t)stream;
   ensure_lds_optin();

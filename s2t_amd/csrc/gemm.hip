@@ -193,7 +193,49 @@ __device__ __forceinline__ void mma(f32x4& acc, const Frag& first, const Frag& s
   }
 }
 
-// ---- epilogue on one lane's 4 consecutive output columns --------------------------------------
+// ---- epilogue: 8 consecutive output columns of one row per thread (after the LDS transpose) ------
+template <typename X>
+__device__ __forceinline__ void ld8(const X* ptr, bool vec, int nv, float (&o)[8]) {
+  if (vec && nv == 8) {
+    if constexpr (sizeof(X) == 2) {
+      const uint4 t = *reinterpret_cast<const uint4*>(ptr);
+      const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[2 * q] = __uint_as_float(w[q] << 16);
+        o[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+      }
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(ptr);
+      const float4 b = *reinterpret_cast<const float4*>(ptr + 4);
+      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = r < nv ? ld_as_f32<X>(ptr + r) : 0.f;
+  }
+}
+template <typename X>
+__device__ __forceinline__ void st8(X* ptr, bool vec, int nv, const float (&o)[8]) {
+  if (vec && nv == 8) {
+    if constexpr (sizeof(X) == 2) {
+      uint4 t;
+      t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+      t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+      t.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+      t.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+      *reinterpret_cast<uint4*>(ptr) = t;
+    } else {
+      *reinterpret_cast<float4*>(ptr) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(ptr + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r < nv) st_from_f32<X>(ptr + r, o[r]);
+  }
+}
+
 template <typename TC>
 struct Epi {
   const s2t_gemm_args& p;
@@ -204,64 +246,64 @@ struct Epi {
   int nout;        // output columns (N, or N/2 under GLU)
   bool vec_c, vec_r, vec_p, vec_z;
 
-  __device__ __forceinline__ float bias_at(int n) const {
-    if (!p.bias) return 0.f;
-    return p.bias_dtype == S2T_F32 ? reinterpret_cast<const float*>(p.bias)[n]
-                                   : bf2f(reinterpret_cast<const bf16_t*>(p.bias)[n]);
+  __device__ __forceinline__ void bias8(int n0, int nv, float (&b)[8]) const {
+    if (!p.bias) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) b[r] = 0.f;
+      return;
+    }
+    if (p.bias_dtype == S2T_F32) {
+      const float* bp = reinterpret_cast<const float*>(p.bias) + n0;
+      ld8<float>(bp, ((uintptr_t)bp % 16) == 0, nv, b);
+    } else {
+      const bf16_t* bp = reinterpret_cast<const bf16_t*>(p.bias) + n0;
+      ld8<bf16_t>(bp, ((uintptr_t)bp % 16) == 0, nv, b);
+    }
   }
   __device__ __forceinline__ bool row_masked(int64_t grow) const {
     if (!p.row_lens) return false;
     const int b = (int)(grow / p.row_T), t = (int)(grow % p.row_T);
     return t >= p.row_lens[b];
   }
-  template <typename X>
-  __device__ __forceinline__ void ld(const X* ptr, bool vec, int nv, float (&o)[4]) const {
-    if (vec && nv == 4) {
-      ld4_as_f32<X>(ptr, o);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = r < nv ? ld_as_f32<X>(ptr + r) : 0.f;
-    }
-  }
-  template <typename X>
-  __device__ __forceinline__ void st(X* ptr, bool vec, int nv, const float (&o)[4]) const {
-    if (vec && nv == 4) {
-      st4_from_f32<X>(ptr, o);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (r < nv) st_from_f32<X>(ptr + r, o[r]);
-    }
-  }
-  // v: post-bias (post-GLU) values for output columns n0..n0+3 of row m
-  __device__ __forceinline__ void finish(int m, int n0, int64_t grow, float (&v)[4]) const {
-    const int nv = min(4, nout - n0);
+  // v: post-bias (post-GLU) values for output columns n0..n0+7 of row m
+  __device__ __forceinline__ void finish(int m, int n0, int64_t grow, float (&v)[8]) const {
+    const int nv = min(8, nout - n0);
     if (p.act == S2T_ACT_RELU || p.act == S2T_ACT_SWISH) {
-      if (P) st<TC>(P + (int64_t)m * p.ldp + n0, vec_p, nv, v);
+      if (P) st8<TC>(P + (int64_t)m * p.ldp + n0, vec_p, nv, v);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = act_apply(p.act, v[r]);
+      for (int r = 0; r < 8; ++r) v[r] = act_apply(p.act, v[r]);
     }
     if (Z) {
-      float z[4];
-      ld<TC>(Z + (int64_t)m * p.ldz + n0, vec_z, nv, z);
+      float z[8];
+      ld8<TC>(Z + (int64_t)m * p.ldz + n0, vec_z, nv, z);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= act_grad(p.dact, z[r]);
+      for (int r = 0; r < 8; ++r) v[r] *= act_grad(p.dact, z[r]);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+    for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
     if (row_masked(grow)) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = 0.f;
+      for (int r = 0; r < 8; ++r) v[r] = 0.f;
     }
     if (R) {
-      float q[4];
-      ld<TC>(R + (int64_t)m * p.ldr + n0, vec_r, nv, q);
+      float q[8];
+      ld8<TC>(R + (int64_t)m * p.ldr + n0, vec_r, nv, q);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] += q[r];
+      for (int r = 0; r < 8; ++r) v[r] += q[r];
     }
-    st<TC>(C + (int64_t)m * p.ldc + n0, vec_c, nv, v);
+    st8<TC>(C + (int64_t)m * p.ldc + n0, vec_c, nv, v);
   }
 };
+
+// fp32 C tile in LDS: [128 rows][128 cols], 16-byte chunk c of row r at r*512 + ((c ^ (r&7))<<4)
+__device__ __forceinline__ float4 ctile_ld4(const char* smem, int row, int chunk) {
+  return *reinterpret_cast<const float4*>(smem + row * 512 + ((chunk ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ void ctile_ld8(const char* smem, int row, int col0, float (&v)[8]) {
+  const float4 a = ctile_ld4(smem, row, col0 >> 2);
+  const float4 b = ctile_ld4(smem, row, (col0 >> 2) + 1);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
 
 template <typename T, bool AKM, bool BKM, typename TC, bool GLU>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
@@ -342,18 +384,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   }
 
   // ---------------- epilogue ----------------
+  // Transpose the accumulators through LDS (the operand buffers are free after the loop's last barrier) so that
+  // every global access of the epilogue is a 16-byte vector on a full 128-byte row segment.
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wm * 64 + i * 16 + x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int chunk = wn * 16 + j * 4 + y;
+      *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
+    }
+  }
+  __syncthreads();
+
   if (p.split_k > 1 || p.c_atomic) {
+    // one float per lane, 64 consecutive columns per wave-instruction = 256 contiguous bytes per atomic instruction
     float* C = reinterpret_cast<float*>(p.C) + coff;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = tm * BM + wm * 64 + i * 16 + x;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n0 = tn * BN + wn * 64 + j * 16 + 4 * y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n0 + r < p.N) atomicAdd(C + (int64_t)m * p.ldc + n0 + r, p.alpha * acc[i][j][r]);
+    const int col = tid & 127;
+    const int n = tn * BN + col;
+    if (n < p.N) {
+#pragma unroll 4
+      for (int pass = 0; pass < 64; ++pass) {
+        const int row = pass * 2 + (tid >> 7);
+        const int m = tm * BM + row;
+        if (m < p.M) {
+          const float v = *reinterpret_cast<const float*>(smem + row * 512 + (((col >> 2) ^ (row & 7)) << 4) + ((col & 3) << 2));
+          atomicAdd(C + (int64_t)m * p.ldc + n, p.alpha * v);
+        }
       }
     }
     return;
@@ -366,45 +423,53 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
             p.dact_z ? reinterpret_cast<const TC*>(p.dact_z) + coff : nullptr,
             nout,
             false, false, false, false};
-  constexpr int VB = 4 * (int)sizeof(TC);  // vector bytes
-  e.vec_c = (p.ldc % 4 == 0) && (((uintptr_t)e.C) % VB == 0);
-  e.vec_r = e.R && (p.ldr % 4 == 0) && (((uintptr_t)e.R) % VB == 0);
-  e.vec_p = e.P && (p.ldp % 4 == 0) && (((uintptr_t)e.P) % VB == 0);
-  e.vec_z = e.Z && (p.ldz % 4 == 0) && (((uintptr_t)e.Z) % VB == 0);
+  auto vec_ok = [](const void* ptr, int64_t ld) { return ((ld * (int64_t)sizeof(TC)) % 16 == 0) && (((uintptr_t)ptr) % 16 == 0); };
+  e.vec_c = vec_ok(e.C, p.ldc);
+  e.vec_r = e.R && vec_ok(e.R, p.ldr);
+  e.vec_p = e.P && vec_ok(e.P, p.ldp);
+  e.vec_z = e.Z && vec_ok(e.Z, p.ldz);
 
+  const int c8 = tid & 7;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = tm * BM + wm * 64 + i * 16 + x;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = pass * 32 + (tid >> 3);
+    const int m = tm * BM + row;
     if (m >= p.M) continue;
     const int64_t grow = (int64_t)z * p.M + m;
     if constexpr (GLU) {
+      // LDS columns per 32-column group q: [16 value | 16 gate]; output column o = q*16 + (0..15)
+      const int o0 = c8 * 8;
+      const int n0 = tn * 64 + o0;
+      if (n0 >= nout) continue;
+      const int lcol = (o0 >> 4) * 32 + (o0 & 15);
+      const int nv = min(8, nout - n0);
+      float a[8], g[8], ba[8], bg[8], v[8];
+      ctile_ld8(smem, row, lcol, a);
+      ctile_ld8(smem, row, lcol + 16, g);
+      e.bias8(n0, nv, ba);
+      e.bias8(nout + n0, nv, bg);
 #pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        const int n0 = tn * 64 + wn * 32 + jp * 16 + 4 * y;
-        if (n0 >= nout) continue;
-        float a[4], g[4], v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = min(n0 + r, nout - 1);
-          a[r] = acc[i][2 * jp][r] + e.bias_at(n);
-          g[r] = acc[i][2 * jp + 1][r] + e.bias_at(nout + n);
-          v[r] = a[r] * sigmoidf_(g[r]);
-        }
-        if (e.P) {
-          const int nv = min(4, nout - n0);
-          e.template st<TC>(e.P + (int64_t)m * p.ldp + n0, e.vec_p, nv, a);
-          e.template st<TC>(e.P + (int64_t)m * p.ldp + nout + n0, e.vec_p && (nout % 4 == 0), nv, g);
-        }
-        e.finish(m, n0, grow, v);
+      for (int r = 0; r < 8; ++r) {
+        a[r] += ba[r];
+        g[r] += bg[r];
+        v[r] = a[r] * sigmoidf_(g[r]);
       }
+      if (e.P) {
+        st8<TC>(e.P + (int64_t)m * p.ldp + n0, e.vec_p, nv, a);
+        st8<TC>(e.P + (int64_t)m * p.ldp + nout + n0, e.vec_p && ((nout * (int)sizeof(TC)) % 16 == 0), nv, g);
+      }
+      e.finish(m, n0, grow, v);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n0 = tn * BN + wn * 64 + j * 16 + 4 * y;
+      for (int h = 0; h < 2; ++h) {
+        const int col0 = h * 64 + c8 * 8;
+        const int n0 = tn * BN + col0;
         if (n0 >= nout) continue;
-        float v[4];
+        float v[8], b[8];
+        ctile_ld8(smem, row, col0, v);
+        e.bias8(n0, min(8, nout - n0), b);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + e.bias_at(min(n0 + r, nout - 1));
+        for (int r = 0; r < 8; ++r) v[r] += b[r];
         e.finish(m, n0, grow, v);
       }
     }

@@ -15,6 +15,32 @@ __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {
   return a;
 }
 
+// visit every element of a row with 8/16-byte vector loads when the row start is 16-byte aligned
+template <typename T, typename F>
+__device__ __forceinline__ void row_foreach(const T* __restrict__ row, int V, F&& f) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  if ((((uintptr_t)row) & 15) == 0) {
+    const int nvec = V / EPV;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+      const uint4 t = *reinterpret_cast<const uint4*>(row + (int64_t)i * EPV);
+      const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f(i * 8 + 2 * q, __uint_as_float(w[q] << 16));
+          f(i * 8 + 2 * q + 1, __uint_as_float(w[q] & 0xffff0000u));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f(i * 4 + q, __uint_as_float(w[q]));
+      }
+    }
+    for (int c = nvec * EPV + threadIdx.x; c < V; c += 256) f(c, ld_as_f32<T>(row + c));
+  } else {
+    for (int c = threadIdx.x; c < V; c += 256) f(c, ld_as_f32<T>(row + c));
+  }
+}
+
 // one workgroup per row: max, argmax (first), logsumexp
 template <typename T>
 __device__ __forceinline__ void row_stats(const T* __restrict__ row, int V, float& mx, int& arg, float& lse) {
@@ -23,10 +49,7 @@ __device__ __forceinline__ void row_stats(const T* __restrict__ row, int V, floa
   __shared__ float ss[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   MaxIdx m{-INFINITY, 0x7fffffff};
-  for (int c = threadIdx.x; c < V; c += 256) {
-    const float x = ld_as_f32<T>(row + c);
-    m = better(m, MaxIdx{x, c});
-  }
+  row_foreach<T>(row, V, [&](int c, float x) { m = better(m, MaxIdx{x, c}); });
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     MaxIdx t{__shfl_xor(m.v, o, 64), __shfl_xor(m.i, o, 64)};
@@ -41,7 +64,8 @@ __device__ __forceinline__ void row_stats(const T* __restrict__ row, int V, floa
 #pragma unroll
   for (int k = 1; k < 4; ++k) m = better(m, MaxIdx{sv[k], si[k]});
   float s = 0.f;
-  for (int c = threadIdx.x; c < V; c += 256) s += __expf(ld_as_f32<T>(row + c) - m.v);
+  const float mv = m.v;
+  row_foreach<T>(row, V, [&](int c, float x) { s += __expf(x - mv); });
   s = wave_sum(s);
   if (lane == 0) ss[w] = s;
   __syncthreads();
@@ -50,6 +74,35 @@ __device__ __forceinline__ void row_stats(const T* __restrict__ row, int V, floa
   arg = m.i;
   lse = m.v + __logf(s);
   __syncthreads();
+}
+
+// write 8 (bf16) / 4 (f32) consecutive outputs of a row at once when aligned: out[c] = g(c, x[c])
+template <typename T, typename G>
+__device__ __forceinline__ void row_map(const T* __restrict__ row, T* __restrict__ out, int V, G&& g) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  if (((((uintptr_t)row) | ((uintptr_t)out)) & 15) == 0) {
+    const int nvec = V / EPV;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+      const uint4 t = *reinterpret_cast<const uint4*>(row + (int64_t)i * EPV);
+      const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+      uint32_t o[4];
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float a = g(i * 8 + 2 * q, __uint_as_float(w[q] << 16));
+          const float b = g(i * 8 + 2 * q + 1, __uint_as_float(w[q] & 0xffff0000u));
+          o[q] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = __float_as_uint(g(i * 4 + q, __uint_as_float(w[q])));
+      }
+      *reinterpret_cast<uint4*>(out + (int64_t)i * EPV) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    for (int c = nvec * EPV + threadIdx.x; c < V; c += 256) st_from_f32<T>(out + c, g(c, ld_as_f32<T>(row + c)));
+  } else {
+    for (int c = threadIdx.x; c < V; c += 256) st_from_f32<T>(out + c, g(c, ld_as_f32<T>(row + c)));
+  }
 }
 
 // ---- CTC greedy, stage 1: per frame arg-max + its log-probability (s2t_ctc.py:312-328) ----
@@ -147,13 +200,15 @@ __global__ __launch_bounds__(256) void ls_ce_kernel(const T* __restrict__ logits
   const float eps_i = eps / (V - 1);
   const float wn = 1.f - eps - eps_i;
   float sx = 0.f;
-  for (int c = threadIdx.x; c < V; c += 256) {
-    const float xv = ld_as_f32<T>(x + c);
-    sx += xv;
-    if (dx) {
+  if (dx) {
+    const int yi = (int)y;
+    row_map<T>(x, dx, V, [&](int c, float xv) {
+      sx += xv;
       const float p = __expf(xv - lse);
-      st_from_f32<T>(dx + c, wn * (p - (c == y ? 1.f : 0.f)) + eps_i * (V * p - 1.f));
-    }
+      return wn * (p - (c == yi ? 1.f : 0.f)) + eps_i * (V * p - 1.f);
+    });
+  } else {
+    row_foreach<T>(x, V, [&](int c, float xv) { sx += xv; });
   }
   sx = wave_sum(sx);
   if ((threadIdx.x & 63) == 0) ssum[threadIdx.x >> 6] = sx;
@@ -303,7 +358,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
   const int L = 2 * S + 1;
   const T* x = logits + row * ld;
   const float l = lse[row];
-  for (int c = threadIdx.x; c < V; c += 256) st_from_f32<T>(g + c, gscale * __expf(ld_as_f32<T>(x + c) - l));
+  row_map<T>(x, g, V, [&](int c, float xv) { return gscale * __expf(xv - l); });
   const float* al = alpha + ((int64_t)b * T_ + t) * Lmax;
   const float* be = beta + ((int64_t)b * T_ + t) * Lmax;
   for (int s = threadIdx.x; s < L; s += 256) {

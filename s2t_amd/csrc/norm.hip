@@ -181,7 +181,7 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, c
   if (cols % 4 || cols > LN_MAX_VEC * 256) return S2T_ERR_UNSUPPORTED;
   if (rows == 0) return S2T_OK;
   int64_t nb = (rows + 3) / 4;
-  if (nb > 512) nb = 512;
+  if (nb > 1024) nb = 1024;
   dim3 grid((unsigned)nb), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)

@@ -53,8 +53,11 @@ def fused_master(params, n):
 def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0):
     """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M with fp32 atomics)."""
     tiles = ((Nout + 127) // 128) * ((Kin + 127) // 128)
-    ktiles = (M + (63 if dY.dtype == torch.bfloat16 else 31)) // (64 if dY.dtype == torch.bfloat16 else 32)
-    split = max(1, min(ktiles, (512 + tiles - 1) // tiles))
+    bke = 64 if dY.dtype == torch.bfloat16 else 32
+    ktiles = (M + bke - 1) // bke
+    # about 2 workgroups per CU in total, but never fewer than 4 K-steps per workgroup (the atomics of a
+    # 128x128 fp32 tile cost about as much as 4 K-steps)
+    split = max(1, min((ktiles + 3) // 4, (512 + tiles - 1) // tiles))
     K.gemm(dY, X, dW, M=Nout, N=Kin, K=M, lda=ldy, ldb=ldx, ldc=Kin, a_kmajor=True, b_kmajor=True, alpha=alpha,
            split_k=split, c_atomic=True)
 
