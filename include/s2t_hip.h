@@ -51,7 +51,8 @@ int s2t_device_cu_count(void);
  *    the reference masks the branch output, not the residual: modules/convolution.py:109-116)];
  *   [residual: v += residual[m,n]]; store (c_dtype).   global_row = z*M + m.
  * split_k > 1 (wgrad): K is split over blockIdx.y and alpha*acc is atomically added to an fp32 C
- *   (no other epilogue stage allowed).
+ *   (no other epilogue stage allowed).  colsum_a (a_kmajor): the column sums of dY (= the bias gradient) are taken
+ *   from the staged A tiles by the workgroups of the first tile column and added atomically (fp32).
  * Alignment: A, B base pointers and strides must keep 16-byte alignment of every row start.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct s2t_gemm_args {
@@ -74,6 +75,7 @@ typedef struct s2t_gemm_args {
   const int32_t* row_lens; int32_t row_T;
   int32_t split_k;
   int32_t c_atomic; /* 1: add alpha*acc to fp32 C with atomics even when split_k == 1 (several batches share one C) */
+  float* colsum_a;  /* optional, a_kmajor only: colsum_a[m] += alpha * sum_k A_op[m][k]  (bias gradient fused into wgrad) */
 } s2t_gemm_args;
 
 int s2t_gemm(const s2t_gemm_args* args, void* stream);
@@ -83,13 +85,15 @@ int s2t_gemm(const s2t_gemm_args* args, void* stream);
  * `dtype`; gamma/beta and the saved statistics are fp32.  row_lens/row_T (optional): rows of padded
  * frames are written as 0 in forward and carry no gradient in backward (the reference's per-layer
  * masked_fill, s2t_transformer.py:1828-1836, and the conv-module input mask, convolution.py:86-88).
- * dgamma/dbeta are ACCUMULATED (fp32).
+ * dgamma/dbeta are ACCUMULATED (fp32).  ws: fp32 workspace [replicas][2][cols], zero on entry and left zero on exit
+ * (the column sums are first spread over `replicas` copies so that no address sees more than gridDim/replicas
+ * atomics, then folded and cleared), so one zero-initialised buffer can be reused by every call on the stream.
  * ------------------------------------------------------------------------------------------------ */
 int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
                       float* rstd, int64_t rows, int cols, float eps, const int32_t* row_lens, int row_T, void* stream);
 int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* dy, const float* mean,
-                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
-                      const int32_t* row_lens, int row_T, void* stream);
+                      const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int replicas, int64_t rows,
+                      int cols, const int32_t* row_lens, int row_T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention probabilities from raw scores (fp32 in, `p_dtype` out), one row per (z, query):
@@ -160,7 +164,8 @@ int s2t_sumsq_accum(const float* g, int64_t n, float* out, void* stream);
  * ------------------------------------------------------------------------------------------------ */
 int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, int flip,
                    const float* scale, const float* shift, int act, const int32_t* lens, float* stats, void* stream);
-int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, int B, int T, int C, int K, void* stream);
+int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, float* ws /* [replicas][C][K]: zero in, zero out */,
+                          int replicas, int B, int T, int C, int K, void* stream);
 int s2t_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                     float* mean, float* rstd, int C, void* stream);

@@ -42,6 +42,7 @@ class GemmArgs(C.Structure):
         ("row_lens", C.c_void_p), ("row_T", C.c_int32),
         ("split_k", C.c_int32),
         ("c_atomic", C.c_int32),
+        ("colsum_a", C.c_void_p),
     ]
 
 

@@ -1,0 +1,289 @@
+// Shared device code of the two GEMM kernels (gemm.hip: generic register-staged; gemm_ring.hip: persistent
+// LDS-DMA ring for bf16 with K % 64 == 0).  LDS images, MFMA fragment maps and the epilogue are identical.
+#pragma once
+#include "common.h"
+
+#define BM 128
+#define BN 128
+
+
+template <typename T>
+struct TileTraits;
+template <>
+struct TileTraits<float> {
+  static constexpr int EPB = 4;    // elements per 16-byte chunk
+  static constexpr int BKE = 32;   // K elements per tile
+};
+template <>
+struct TileTraits<bf16_t> {
+  static constexpr int EPB = 8;
+  static constexpr int BKE = 64;
+};
+
+template <typename T>
+__device__ __forceinline__ void mask_tail(uint4& v, int nvalid) {
+  // keep the first nvalid elements of the 16-byte chunk, zero the rest
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i >= nvalid) w[i] = 0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (2 * i >= nvalid) w[i] = 0;
+      else if (2 * i + 1 >= nvalid) w[i] &= 0xffffu;
+    }
+  }
+  v = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ int kswz(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
+
+// ---- global -> registers ---------------------------------------------------------------------
+// row-major operand: element (row, k) at base[row*ld + k]
+template <typename T, bool GLU_B>
+__device__ __forceinline__ void load_rowmajor(uint4 (&reg)[4], const T* __restrict__ base, int64_t ld, int row0,
+                                              int nrows, int k0, int K, bool ktail, int tid, int glu_half_rows) {
+  constexpr int EPB = TileTraits<T>::EPB;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int cid = tid + 256 * u;
+    const int r = cid >> 3, ch = cid & 7;
+    int grow;
+    bool rv;
+    if constexpr (GLU_B) {
+      // 16-row blocks alternate value / gate rows of the weight: block s -> half = s&1
+      const int s = r >> 4;
+      const int nloc = (s >> 1) * 16 + (r & 15);
+      const int o = row0 + nloc;  // output column; row0 = tn*64
+      rv = o < glu_half_rows;
+      grow = (s & 1) * glu_half_rows + o;
+    } else {
+      grow = row0 + r;
+      rv = grow < nrows;
+    }
+    const int k = k0 + ch * EPB;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (rv && k < K) {
+      v = *reinterpret_cast<const uint4*>(base + (int64_t)grow * ld + k);
+      if (ktail && k + EPB > K) mask_tail<T>(v, K - k);
+    }
+    reg[u] = v;
+  }
+}
+
+// k-major operand: element (k, col) at base[k*ld + col]
+template <typename T>
+__device__ __forceinline__ void load_kmajor(uint4 (&reg)[4], const T* __restrict__ base, int64_t ld, int col0,
+                                            int ncols, int k0, int K, bool ctail, int tid) {
+  constexpr int EPB = TileTraits<T>::EPB;
+  constexpr int CPR = 128 / EPB;  // chunks per k-row: 16 (bf16) / 32 (f32)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int cid = tid + 256 * u;
+    const int kr = cid / CPR, ch = cid % CPR;
+    const int gk = k0 + kr;
+    const int gc = col0 + ch * EPB;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gk < K && gc < ncols) {
+      v = *reinterpret_cast<const uint4*>(base + (int64_t)gk * ld + gc);
+      if (ctail && gc + EPB > ncols) mask_tail<T>(v, ncols - gc);
+    }
+    reg[u] = v;
+  }
+}
+
+// ---- registers -> LDS ------------------------------------------------------------------------
+__device__ __forceinline__ void store_rowmajor(char* lds, const uint4 (&reg)[4], int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int cid = tid + 256 * u;
+    const int r = cid >> 3, ch = cid & 7;
+    *reinterpret_cast<uint4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = reg[u];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_kmajor(char* lds, const uint4 (&reg)[4], int tid) {
+  constexpr int EPB = TileTraits<T>::EPB;
+  constexpr int CPR = 128 / EPB;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int cid = tid + 256 * u;
+    const int kr = cid / CPR, ch = cid % CPR;
+    if constexpr (sizeof(T) == 2)
+      *reinterpret_cast<uint4*>(lds + kr * 256 + ((ch ^ kswz(kr)) << 4)) = reg[u];
+    else
+      *reinterpret_cast<uint4*>(lds + kr * 512 + (ch << 4)) = reg[u];
+  }
+}
+
+// ---- LDS -> MFMA fragments -------------------------------------------------------------------
+// Fragment of a 16-row (row-major operand) / 16-column (k-major operand) block starting at blk0 of the tile,
+// for K sub-step ks (bf16: 32 k per sub-step, f32: 16 k per sub-step = 4 MFMAs of k=4).
+struct Frag {
+  uint4 v;  // bf16: 8 elements k = ks*32 + 8y + j; f32: 4 elements k = ks*16 + 4y + jj
+};
+
+template <typename T, bool KM>
+__device__ __forceinline__ Frag read_frag(const char* lds, int blk0, int ks, int x, int y) {
+  Frag f;
+  if constexpr (!KM) {
+    const int r = blk0 + x;
+    const int c = ks * 4 + y;
+    f.v = *reinterpret_cast<const uint4*>(lds + r * 128 + ((c ^ (r & 7)) << 4));
+  } else if constexpr (sizeof(T) == 2) {
+    const int q = x >> 2, p = x & 3;
+    const int col = blk0 + 4 * p;
+    const int chunk = col >> 3;
+    const int within = (p & 1) * 8;
+    uint32_t w[4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int R = ks * 32 + 8 * y + 4 * half + q;
+      const char* a = lds + R * 256 + ((chunk ^ kswz(R)) << 4) + within;
+      s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(a));
+      uint2 tt = __builtin_bit_cast(uint2, t);
+      w[2 * half] = tt.x;
+      w[2 * half + 1] = tt.y;
+    }
+    f.v = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    uint32_t w[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int R = ks * 16 + 4 * y + jj;
+      w[jj] = *reinterpret_cast<const uint32_t*>(lds + R * 512 + (blk0 + x) * 4);
+    }
+    f.v = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  return f;
+}
+
+template <typename T>
+__device__ __forceinline__ void mma(f32x4& acc, const Frag& first, const Frag& second) {
+  if constexpr (sizeof(T) == 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, first.v),
+                                                   __builtin_bit_cast(bf16x8, second.v), acc, 0, 0, 0);
+  } else {
+    const uint32_t a[4] = {first.v.x, first.v.y, first.v.z, first.v.w};
+    const uint32_t b[4] = {second.v.x, second.v.y, second.v.z, second.v.w};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[jj]), __uint_as_float(b[jj]), acc, 0, 0, 0);
+  }
+}
+
+// ---- epilogue: 8 consecutive output columns of one row per thread (after the LDS transpose) ------
+template <typename X>
+__device__ __forceinline__ void ld8(const X* ptr, bool vec, int nv, float (&o)[8]) {
+  if (vec && nv == 8) {
+    if constexpr (sizeof(X) == 2) {
+      const uint4 t = *reinterpret_cast<const uint4*>(ptr);
+      const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[2 * q] = __uint_as_float(w[q] << 16);
+        o[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+      }
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(ptr);
+      const float4 b = *reinterpret_cast<const float4*>(ptr + 4);
+      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = r < nv ? ld_as_f32<X>(ptr + r) : 0.f;
+  }
+}
+template <typename X>
+__device__ __forceinline__ void st8(X* ptr, bool vec, int nv, const float (&o)[8]) {
+  if (vec && nv == 8) {
+    if constexpr (sizeof(X) == 2) {
+      uint4 t;
+      t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+      t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+      t.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+      t.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+      *reinterpret_cast<uint4*>(ptr) = t;
+    } else {
+      *reinterpret_cast<float4*>(ptr) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(ptr + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r < nv) st_from_f32<X>(ptr + r, o[r]);
+  }
+}
+
+template <typename TC>
+struct Epi {
+  const s2t_gemm_args& p;
+  TC* C;
+  const TC* R;
+  TC* P;
+  const TC* Z;
+  int nout;        // output columns (N, or N/2 under GLU)
+  bool vec_c, vec_r, vec_p, vec_z;
+
+  __device__ __forceinline__ void bias8(int n0, int nv, float (&b)[8]) const {
+    if (!p.bias) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) b[r] = 0.f;
+      return;
+    }
+    if (p.bias_dtype == S2T_F32) {
+      const float* bp = reinterpret_cast<const float*>(p.bias) + n0;
+      ld8<float>(bp, ((uintptr_t)bp % 16) == 0, nv, b);
+    } else {
+      const bf16_t* bp = reinterpret_cast<const bf16_t*>(p.bias) + n0;
+      ld8<bf16_t>(bp, ((uintptr_t)bp % 16) == 0, nv, b);
+    }
+  }
+  __device__ __forceinline__ bool row_masked(int64_t grow) const {
+    if (!p.row_lens) return false;
+    const int b = (int)(grow / p.row_T), t = (int)(grow % p.row_T);
+    return t >= p.row_lens[b];
+  }
+  // v: post-bias (post-GLU) values for output columns n0..n0+7 of row m
+  __device__ __forceinline__ void finish(int m, int n0, int64_t grow, float (&v)[8]) const {
+    const int nv = min(8, nout - n0);
+    if (p.act == S2T_ACT_RELU || p.act == S2T_ACT_SWISH) {
+      if (P) st8<TC>(P + (int64_t)m * p.ldp + n0, vec_p, nv, v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = act_apply(p.act, v[r]);
+    }
+    if (Z) {
+      float z[8];
+      ld8<TC>(Z + (int64_t)m * p.ldz + n0, vec_z, nv, z);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] *= act_grad(p.dact, z[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+    if (row_masked(grow)) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = 0.f;
+    }
+    if (R) {
+      float q[8];
+      ld8<TC>(R + (int64_t)m * p.ldr + n0, vec_r, nv, q);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += q[r];
+    }
+    st8<TC>(C + (int64_t)m * p.ldc + n0, vec_c, nv, v);
+  }
+};
+
+// fp32 C tile in LDS: [128 rows][128 cols], 16-byte chunk c of row r at r*512 + ((c ^ (r&7))<<4)
+__device__ __forceinline__ float4 ctile_ld4(const char* smem, int row, int chunk) {
+  return *reinterpret_cast<const float4*>(smem + row * 512 + ((chunk ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ void ctile_ld8(const char* smem, int row, int col0, float (&v)[8]) {
+  const float4 a = ctile_ld4(smem, row, col0 >> 2);
+  const float4 b = ctile_ld4(smem, row, (col0 >> 2) + 1);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+

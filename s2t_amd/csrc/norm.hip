@@ -6,9 +6,9 @@
 
 namespace {
 
-constexpr int LN_MAX_VEC = 8;  // supports cols <= 64*4*8 = 2048
+constexpr int LN_MAX_VEC = 8;  // supports cols <= 64*4*8 = 2048 (kernels are instantiated for 1/2/4/8 vectors per lane)
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -18,11 +18,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const T* xr = x + row * cols;
-  float v[LN_MAX_VEC][4];
-  const int nvec = (cols + 255) / 256;
+  float v[NV][4];
+  constexpr int nvec = NV;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (i < nvec) {
       const int c = i * 256 + lane * 4;
       if (c < cols) ld4_as_f32<T>(xr + c, v[i]);
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const float mean = wave_sum(s) / cols;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (i < nvec) {
       const int c = i * 256 + lane * 4;
       if (c < cols) {
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
   T* yr = y + row * cols;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (i < nvec) {
       const int c = i * 256 + lane * 4;
       if (c < cols) {
@@ -72,19 +72,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)); dgamma += sum_rows dy*xhat; dbeta += sum_rows dy
 // A fixed grid of workgroups strides over the rows so that the per-column partial sums stay in registers and
 // each workgroup issues ONE set of atomics (avoids a chip-wide pile-up on the same 2*cols addresses).
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const T* __restrict__ dy, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ ws, int replicas,
                                                      int64_t rows, int cols, const int32_t* __restrict__ row_lens,
                                                      int row_T) {
-  __shared__ float red[2][4][LN_MAX_VEC * 256];
+  __shared__ float red[2][4][NV * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nvec = (cols + 255) / 256;
-  float ag[LN_MAX_VEC][4], ab[LN_MAX_VEC][4];
+  constexpr int nvec = NV;
+  float ag[NV][4], ab[NV][4];
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ag[i][r] = ab[i][r] = 0.f;
 
@@ -92,10 +92,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     bool masked = false;
     if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
     const float mu = mean[row], rs = rstd[row];
-    float xh[LN_MAX_VEC][4], dg[LN_MAX_VEC][4];
+    float xh[NV][4], dg[NV][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
       if (i < nvec) {
         const int c = i * 256 + lane * 4;
         if (c < cols) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     s1 = wave_sum(s1) / cols;
     s2 = wave_sum(s2) / cols;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_VEC; ++i) {
+    for (int i = 0; i < NV; ++i) {
       if (i < nvec) {
         const int c = i * 256 + lane * 4;
         if (c < cols) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
   }
   // block reduce over the 4 waves, then one atomic per column per workgroup
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (i < nvec) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -149,12 +149,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
   for (int c = threadIdx.x; c < cols; c += 256) {
     const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
     const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    atomicAdd(dgamma + c, g);
-    atomicAdd(dbeta + c, b);
+    // replica (blockIdx % replicas) of the [2][cols] partial sums: at most gridDim/replicas adders per address
+    float* w = ws + (int64_t)(blockIdx.x % replicas) * 2 * cols;
+    atomicAdd(w + c, g);
+    atomicAdd(w + cols + c, b);
   }
 }
 
+// dgamma += sum_r ws[r][0][:] ; dbeta += sum_r ws[r][1][:]
+__global__ void ln_bwd_finalize_kernel(float* __restrict__ ws, int replicas, int cols, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float g = 0.f, b = 0.f;
+#pragma unroll 8
+  for (int r = 0; r < replicas; ++r) {
+    g += ws[(int64_t)r * 2 * cols + c];
+    b += ws[(int64_t)r * 2 * cols + cols + c];
+  }
+  for (int r = 0; r < replicas; ++r) {  // leave the workspace zeroed for the next call (stream-ordered reuse)
+    ws[(int64_t)r * 2 * cols + c] = 0.f;
+    ws[(int64_t)r * 2 * cols + cols + c] = 0.f;
+  }
+  dgamma[c] += g;
+  dbeta[c] += b;
+}
+
 }  // namespace
+
+#define LN_DISPATCH(KERN, T_, ...)                                                        \
+  do {                                                                                    \
+    const int nv = (cols + 255) / 256;                                                    \
+    if (nv <= 1) hipLaunchKernelGGL((KERN<T_, 1>), grid, block, 0, s, __VA_ARGS__);       \
+    else if (nv <= 2) hipLaunchKernelGGL((KERN<T_, 2>), grid, block, 0, s, __VA_ARGS__);  \
+    else if (nv <= 4) hipLaunchKernelGGL((KERN<T_, 4>), grid, block, 0, s, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERN<T_, 8>), grid, block, 0, s, __VA_ARGS__);               \
+  } while (0)
 
 extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
                                  float* mean, float* rstd, int64_t rows, int cols, float eps,
@@ -165,31 +195,29 @@ extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, c
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd,
-                       rows, cols, eps, row_lens, row_T);
+    LN_DISPATCH(ln_fwd_kernel, float, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps, row_lens, row_T);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean,
-                       rstd, rows, cols, eps, row_lens, row_T);
+    LN_DISPATCH(ln_fwd_kernel, bf16_t, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, cols, eps, row_lens, row_T);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
 
 extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* dy, const float* mean,
-                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
-                                 const int32_t* row_lens, int row_T, void* stream) {
-  if (!x || !gamma || !dy || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || cols <= 0) return S2T_ERR_ARG;
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int replicas,
+                                 int64_t rows, int cols, const int32_t* row_lens, int row_T, void* stream) {
+  if (!x || !gamma || !dy || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || replicas <= 0 || rows < 0 || cols <= 0)
+    return S2T_ERR_ARG;
   if (cols % 4 || cols > LN_MAX_VEC * 256) return S2T_ERR_UNSUPPORTED;
   if (rows == 0) return S2T_OK;
   int64_t nb = (rows + 3) / 4;
-  if (nb > 1024) nb = 1024;
+  if (nb > 2048) nb = 2048;
   dim3 grid((unsigned)nb), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, s, (const float*)x, gamma, (const float*)dy, mean, rstd,
-                       (float*)dx, dgamma, dbeta, rows, cols, row_lens, row_T);
+    LN_DISPATCH(ln_bwd_kernel, float, (const float*)x, gamma, (const float*)dy, mean, rstd, (float*)dx, ws, replicas, rows, cols, row_lens, row_T);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean,
-                       rstd, (bf16_t*)dx, dgamma, dbeta, rows, cols, row_lens, row_T);
+    LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean, rstd, (bf16_t*)dx, ws, replicas, rows, cols, row_lens, row_T);
   else return S2T_ERR_DTYPE;
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, ws, replicas, cols, dgamma, dbeta);
   return S2T_LAUNCH_CHECK();
 }

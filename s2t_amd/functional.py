@@ -50,8 +50,9 @@ def fused_master(params, n):
     return params[0].data.as_strided((n,), (1,))
 
 
-def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0):
-    """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M with fp32 atomics)."""
+def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
+    """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M with fp32 atomics);
+    db[Nout] += alpha * column sums of dY when given (taken from the staged dY tiles inside the same kernel)."""
     tiles = ((Nout + 127) // 128) * ((Kin + 127) // 128)
     bke = 64 if dY.dtype == torch.bfloat16 else 32
     ktiles = (M + bke - 1) // bke
@@ -59,7 +60,7 @@ def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0):
     # 128x128 fp32 tile cost about as much as 4 K-steps)
     split = max(1, min((ktiles + 3) // 4, (512 + tiles - 1) // tiles))
     K.gemm(dY, X, dW, M=Nout, N=Kin, K=M, lda=ldy, ldb=ldx, ldc=Kin, a_kmajor=True, b_kmajor=True, alpha=alpha,
-           split_k=split, c_atomic=True)
+           split_k=split, c_atomic=True, colsum_a=db)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -131,15 +132,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             K.gemm(dy, cw(w), dx, M=M, N=Kin, K=Nout, lda=ldy, ldb=Kin, ldc=Kin, b_kmajor=True, alpha=ctx.alpha)
-        _wgrad(dy, x, w.grad, Nout, Kin, M, ldy, Kin, ctx.alpha)
-        if b is not None:
-            # bias gradient carries the same alpha
-            if ctx.alpha == 1.0:
-                K.colsum_accum(dy, ldy, b.grad, M, Nout)
-            else:
-                tmp = torch.zeros_like(b.grad)
-                K.colsum_accum(dy, ldy, tmp, M, Nout)
-                b.grad.add_(tmp, alpha=ctx.alpha)
+        _wgrad(dy, x, w.grad, Nout, Kin, M, ldy, Kin, ctx.alpha, b.grad if b is not None else None)
         _ready(w, b)
         return dx, None, None, None, (dy if ctx.has_res else None), None
 
@@ -181,16 +174,9 @@ class FFNFn(torch.autograd.Function):
         dz = torch.empty(M, F_, dtype=x.dtype, device=x.device)
         K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
                dact=ctx.act)
-        _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha)
-        if ctx.alpha == 1.0:
-            K.colsum_accum(dy, d, b2.grad, M, d)
-        else:
-            tmp = torch.zeros_like(b2.grad)
-            K.colsum_accum(dy, d, tmp, M, d)
-            b2.grad.add_(tmp, alpha=ctx.alpha)
+        _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad)
         _ready(w2, b2)
-        _wgrad(dz, x, w1.grad, F_, d, M, F_, d)
-        K.colsum_accum(dz, F_, b1.grad, M, F_)
+        _wgrad(dz, x, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)
         dx = torch.empty_like(x)
         K.gemm(dz, cw(w1), dx, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
         _ready(w1, b1)
@@ -290,8 +276,7 @@ class AttentionFn(torch.autograd.Function):
         # out_proj
         dO = torch.empty(Mq, d, dtype=dt, device=dev)
         K.gemm(dy, cw(prm["o_w"]), dO, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
-        _wgrad(dy, O, prm["o_w"].grad, d, d, Mq, d, d)
-        K.colsum_accum(dy, d, prm["o_b"].grad, Mq, d)
+        _wgrad(dy, O, prm["o_w"].grad, d, d, Mq, d, d, 1.0, prm["o_b"].grad)
         _ready(prm["o_w"], prm["o_b"])
         # gradient buffers in the projection layout so that one GEMM handles dW / dx
         if ctx.self_attn:
@@ -346,19 +331,16 @@ class AttentionFn(torch.autograd.Function):
             gw = fused_grad([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
             gb = prm["q_b"].grad.as_strided((3 * d,), (1,))
             wqkv = fused([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
-            _wgrad(dqkv, xq, gw, 3 * d, d, Mq, 3 * d, d)
-            K.colsum_accum(dqkv, 3 * d, gb, Mq, 3 * d)
+            _wgrad(dqkv, xq, gw, 3 * d, d, Mq, 3 * d, d, 1.0, gb)
             K.gemm(dqkv, wqkv, dxq, M=Mq, N=d, K=3 * d, lda=3 * d, ldb=d, ldc=d, b_kmajor=True)
             dxkv = None
         else:
-            _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d)
-            K.colsum_accum(dq, d, prm["q_b"].grad, Mq, d)
+            _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d, 1.0, prm["q_b"].grad)
             K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
             gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
             gb = prm["k_b"].grad.as_strided((2 * d,), (1,))
             wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
-            _wgrad(dkv, xkv, gw, 2 * d, d, Mk, 2 * d, d)
-            K.colsum_accum(dkv, 2 * d, gb, Mk, 2 * d)
+            _wgrad(dkv, xkv, gw, 2 * d, d, Mk, 2 * d, d, 1.0, gb)
             dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
             K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])

@@ -31,6 +31,7 @@ def gemm(
     preact: Optional[torch.Tensor] = None, ldp=0, p_s=(0, 0),
     dact_z: Optional[torch.Tensor] = None, ldz=0, dact=None,
     row_lens: Optional[torch.Tensor] = None, row_T=0, split_k=1, c_atomic=False,
+    colsum_a: Optional[torch.Tensor] = None,
 ):
     """Raw s2t_gemm call: C = epilogue(A_op[M,K] @ B_op[K,N]); see include/s2t_hip.h."""
     L.require_cuda(A, B, out, bias, residual, preact, dact_z, row_lens)
@@ -66,6 +67,9 @@ def gemm(
         assert row_lens.dtype == torch.int32
     a.split_k = split_k
     a.c_atomic = int(c_atomic)
+    a.colsum_a = _ptr(colsum_a)
+    if colsum_a is not None:
+        assert colsum_a.dtype == torch.float32 and a_kmajor
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -91,9 +95,27 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, row_lens=
           _ptr(mean), _ptr(rstd), rows, cols, eps, _ptr(row_lens), row_T)
 
 
+LN_REPLICAS = 32
+
+
+_WS = {}
+
+
+def _workspace(tag, n, device):
+    """Zero-initialised fp32 scratch reused by every call on the stream: the kernels leave it zeroed on exit."""
+    key = (tag, n, str(device))
+    t = _WS.get(key)
+    if t is None:
+        t = torch.zeros(n, dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
 def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0):
+    ws = _workspace("ln", LN_REPLICAS * 2 * cols, x.device)
     _call("s2t_layernorm_bwd", L.dtype_id(x.dtype), x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), mean.data_ptr(),
-          rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, cols, _ptr(row_lens), row_T)
+          rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), LN_REPLICAS, rows, cols,
+          _ptr(row_lens), row_T)
 
 
 def attn_softmax_fwd(S, ldS, BD, ldBD, P, ldP, Z, H, Tq, Tk, scale, key_lens=None, causal=False, clamp=False):
@@ -164,8 +186,13 @@ def dwconv_fwd(x, w, y, B, T, C, K, flip=False, scale=None, shift=None, act=None
           _ptr(scale), _ptr(shift), L.ACT_IDS[act], _ptr(lens), _ptr(stats))
 
 
+DW_REPLICAS = 16
+
+
 def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
-    _call("s2t_dwconv_bwd_weight", L.dtype_id(G.dtype), G.data_ptr(), dD.data_ptr(), dw.data_ptr(), B, T, C, K)
+    ws = _workspace("dw", DW_REPLICAS * C * K, G.device)
+    _call("s2t_dwconv_bwd_weight", L.dtype_id(G.dtype), G.data_ptr(), dD.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+          DW_REPLICAS, B, T, C, K)
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, C):
