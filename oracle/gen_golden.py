@@ -218,17 +218,14 @@ def encdec_case(name, outdir, arch, V, B, T, seed, train_bn=False, **kw):
         for k, b in model.named_buffers():
             if "running_" in k or "num_batches" in k:
                 out["bn_after::" + k] = np_(b)
-    # hyper-parameters the restatement needs
-    for k in (
-        "encoder_embed_dim encoder_ffn_embed_dim encoder_layers encoder_attention_heads decoder_layers "
-        "decoder_embed_dim decoder_ffn_embed_dim decoder_attention_heads subsampling_filter cnn_module_kernel "
-        "ctc_weight"
-    ).split():
-        out["cfg::" + k] = np.float64(getattr(args, k))
-    for k in "encoder_attention_type encoder_activation_fn activation_fn".split():
-        out["cfg::" + k] = np.array(getattr(args, k))
-    for k in "macaron_style use_cnn_module layer_padding_mask encoder_normalize_before".split():
-        out["cfg::" + k] = np.bool_(bool(getattr(args, k)))
+    # hyper-parameters the restatement needs: every scalar / string field of the resolved args
+    for k, v in sorted(vars(args).items()):
+        if isinstance(v, bool):
+            out["cfg::" + k] = np.bool_(v)
+        elif isinstance(v, (int, float)):
+            out["cfg::" + k] = np.float64(v)
+        elif isinstance(v, str):
+            out["cfg::" + k] = np.array(v)
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
     print(name, "loss", loss.item(), {k: v for k, v in log.items() if "loss" in k})
 
@@ -343,6 +340,26 @@ def main():
     encdec_case("conformer_small", outdir, "s2t_transformer_s", V=40, B=3, T=50, seed=2, train_bn=True, **small, **conf)
     # ragged: one full row + short rows; T not a multiple of 4; B=4
     encdec_case("conformer_ragged", outdir, "s2t_transformer_s", V=37, B=4, T=67, seed=3, train_bn=True, **small, **conf)
+    pds = dict(
+        encoder_embed_dim=32, encoder_ffn_embed_dim=64, encoder_attention_heads=2, decoder_attention_heads=2,
+        decoder_embed_dim=32, decoder_ffn_embed_dim=64, encoder_layers=4, decoder_layers=2,
+        pds_stages=4, pds_layers="1_1_1_1", pds_ratios="2_2_1_2", pds_fusion=False, pds_embed_dims="32_32_32_32",
+        pds_ds_method="conv", pds_embed_norm=True, pds_position_embed="1_1_1_1", pds_kernel_sizes="5_5_5_5",
+        pds_ffn_ratios="2_2_2_2", pds_attn_heads="2_2_2_2",
+    )
+    for k in ("subsampling_type", "subsampling_layers", "subsampling_kernel", "subsampling_stride", "subsampling_norm",
+              "subsampling_activation", "encoder_embed_norm", "encoder_no_scale_embedding"):
+        pass
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "pds"):
+        encdec_case("pds_small", outdir, "pdss2t_transformer_s_8", V=40, B=3, T=67, seed=6, **pds)
+        encdec_case("pds_conformer_small", outdir, "pdss2t_transformer_s_8", V=40, B=3, T=64, seed=7, train_bn=True, **pds, **conf)
+    sate = dict(small, text_encoder_layers=2, acoustic_encoder="transformer", adapter="inter_league",
+                textual_encoder_embed_norm=True, textual_encoder_no_scale_embedding=True, encoder_normalize_before=True,
+                decoder_normalize_before=True)
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "sate"):
+        encdec_case("sate_small", outdir, "s2t_sate", V=40, B=3, T=50, seed=8, **sate)
+    if os.environ.get("GOLDEN_ONLY", "") != "":
+        return
     small_ctc = {k: v for k, v in small.items() if not k.startswith("decoder")}
     ctc_greedy_case("ctc_greedy_transformer", outdir, V=40, B=4, T=64, seed=4, **small_ctc)
     ctc_greedy_case("ctc_greedy_conformer", outdir, V=40, B=4, T=64, seed=5, **small_ctc, **conf)

@@ -385,10 +385,10 @@ def ctc_targets(target, pad_idx=1, eos_idx=2):
 def joint_loss(W, cfg, src_tokens, src_lengths, prev_output_tokens, target, eps=0.1, training=True,
                use_torch_ctc=False, bn_stats=None):
     """criterions/label_smoothed_cross_entropy_with_ctc.py:74-165: CE(label-smoothed) + ctc_weight * CTC."""
-    enc = encoder_forward(src_tokens, src_lengths, W, cfg, training=training, bn_stats=bn_stats)
+    enc = ENCODERS[encoder_kind(cfg)](src_tokens, src_lengths, W, cfg, training=training, bn_stats=bn_stats)
     logits = decoder_forward(prev_output_tokens, enc, W, cfg)
     ce, nll = label_smoothed_nll(logits, target, eps)
-    lens = (~enc["encoder_padding_mask"][0]).long().sum(-1)
+    lens = (~enc.get("ctc_padding_mask", enc["encoder_padding_mask"])[0]).long().sum(-1)
     lp = torch.log_softmax(enc["ctc_logit"][0].float(), dim=-1)
     tg = ctc_targets(target)
     if use_torch_ctc:
@@ -442,6 +442,113 @@ def utterance_cmvn(x, norm_means=True, norm_vars=True):
 
 
 # ----------------------------------------------------------------------------------------------
+# PDS encoder (progressive down-sampling), a16
+# ----------------------------------------------------------------------------------------------
+def _ints(v):
+    return [int(t) for t in str(v).split("_")]
+
+
+def pds_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None):
+    """models/speech_to_text/pdss2t_transformer.py:1042-1281 (no fusion / inter-CTC / mixup):
+    pad T up to the NEXT multiple of prod(ratios) (always pads: +prod when already aligned, :1050-1055);
+    per stage: mask -> Conv1d(k, stride r, pad (k-1)//2) -> LayerNorm -> mask (Downsampling.forward :107-144),
+    lengths floor((l-1)/r + 1); + sinusoidal positions (or rel-pos table); layers = PDSTransformerEncoderLayer
+    (modules/pds_layer.py:263-359: the S2T layer, conv-module activation = encoder_activation_fn)."""
+    ratios, dims = _ints(cfg["pds_ratios"]), _ints(cfg["pds_embed_dims"])
+    layers, heads = _ints(cfg["pds_layers"]), _ints(cfg["pds_attn_heads"])
+    ksz, ffr = _ints(cfg["pds_kernel_sizes"]), _ints(cfg["pds_ffn_ratios"])
+    posf = _ints(cfg["pds_position_embed"])
+    B, T, _ = src_tokens.shape
+    total = 1
+    for r in ratios:
+        total *= max(1, r)
+    pad_to = total - T % total
+    x = src_tokens
+    if total > 1 and pad_to > 0:
+        x = torch.cat([x, x.new_zeros(B, pad_to, x.size(2))], dim=1)
+    lens = src_lengths
+    lcfg = dict(cfg)
+    lcfg["activation_fn"] = cfg.get("encoder_activation_fn", "relu")  # conv-module activation rule of PDS layers
+    for i in range(int(cfg["pds_stages"])):
+        st = i + 1
+        Tn = x.size(1)
+        mask = lengths_to_padding_mask(lens, Tn)
+        x = x.masked_fill(mask[:, :, None], 0.0)
+        w, b = W[f"{prefix}downsampling{st}.conv.0.weight"], W[f"{prefix}downsampling{st}.conv.0.bias"]
+        r = ratios[i]
+        x = F.conv1d(x.transpose(1, 2), w, b, stride=r, padding=(ksz[i] - 1) // 2).transpose(1, 2)
+        lens = torch.floor((lens.float() - 1) / r + 1).long()
+        if cfg.get("pds_embed_norm", False):
+            x = layer_norm(x, W[f"{prefix}downsampling{st}.norm.weight"], W[f"{prefix}downsampling{st}.norm.bias"])
+        Tn = x.size(1)
+        mask = lengths_to_padding_mask(lens, Tn)
+        x = x.masked_fill(mask[:, :, None], 0.0)
+        pos_tab = None
+        if posf[i]:
+            if cfg["encoder_attention_type"] == "rel_pos":
+                pos_tab = rel_pos_table(Tn, dims[i])
+            else:
+                x = x + sinusoidal_positions(mask, dims[i], padding_idx=1)
+        lcfg["encoder_attention_heads"] = heads[i]
+        for j in range(layers[i]):
+            x = encoder_layer(x, mask, pos_tab, W, f"{prefix}stage{st}.{j}.", lcfg, training, bn_stats)
+    x = layer_norm(x, W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"])
+    out = {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": [mask], "ctc_logit": []}
+    if prefix + "ctc.ctc_projection.weight" in W:
+        logit = linear(x, W[prefix + "ctc.ctc_projection.weight"], W[prefix + "ctc.ctc_projection.bias"])
+        out["ctc_logit"] = [logit.transpose(0, 1)]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# SATE stacked acoustic + textual encoder, a17
+# ----------------------------------------------------------------------------------------------
+def sate_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None):
+    """models/speech_to_text/s2t_sate.py:973-1075: acoustic encoder (a6) -> adapter `inter_league`
+    (modules/speech_to_text/adapter.py:214-217,264-266,296-297: x + softmax(ctc_logit / tau) @ W_embed) ->
+    TextualEncoder.forward (:641-827): embed LN, scale, + sinusoidal positions, N x TransformerEncoderLayer
+    (modules/transformer_layer.py:164-237, pre-LN, fc1/fc2), final LayerNorm."""
+    ac = encoder_forward(src_tokens, src_lengths, W, cfg, training, prefix + "acoustic_encoder.", bn_stats)
+    x = ac["encoder_out"][0].transpose(0, 1)  # (B, T', d)
+    mask = ac["encoder_padding_mask"][0]
+    d = x.size(-1)
+    if cfg.get("adapter", "none") == "inter_league":
+        logit = ac["ctc_logit"][0].transpose(0, 1)
+        dist = torch.softmax(logit / float(cfg.get("adapter_temperature", 1.0)), dim=-1)
+        x = x + dist @ W[prefix + "adapter.embed_adapter.weight"]
+    elif cfg.get("adapter", "none") != "none":
+        raise NotImplementedError(cfg["adapter"])
+    p = prefix + "textual_encoder."
+    if cfg.get("textual_encoder_embed_norm", False):
+        x = layer_norm(x, W[p + "embed_ln.weight"], W[p + "embed_ln.bias"])
+    if not cfg.get("textual_encoder_no_scale_embedding", False):
+        x = x * math.sqrt(d)
+    x = x + sinusoidal_positions(mask, d, padding_idx=1)
+    h = cfg["encoder_attention_heads"]
+    for i in range(int(cfg["text_encoder_layers"])):
+        q = f"{p}layers.{i}."
+        y = layer_norm(x, W[q + "self_attn_layer_norm.weight"], W[q + "self_attn_layer_norm.bias"])
+        x = x + mha(y, y, W, q + "self_attn.", h, mask)
+        y = layer_norm(x, W[q + "final_layer_norm.weight"], W[q + "final_layer_norm.bias"])
+        x = x + ffn(y, W, q, cfg.get("activation_fn", "relu"), n1="fc1", n2="fc2")
+    x = layer_norm(x, W[p + "layer_norm.weight"], W[p + "layer_norm.bias"])
+    return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": [mask], "ctc_padding_mask": [mask],
+            "ctc_logit": ac["ctc_logit"]}
+
+
+ENCODERS = {"s2t_transformer": encoder_forward, "pds": pds_encoder_forward, "sate": sate_encoder_forward}
+
+
+def encoder_kind(cfg):
+    arch = str(cfg.get("arch", ""))
+    if arch.startswith("pdss2t"):
+        return "pds"
+    if arch.startswith("s2t_sate"):
+        return "sate"
+    return "s2t_transformer"
+
+
+# ----------------------------------------------------------------------------------------------
 # helpers for tests / bench
 # ----------------------------------------------------------------------------------------------
 def cfg_from_golden(z) -> dict:
@@ -456,7 +563,7 @@ def cfg_from_golden(z) -> dict:
                 cfg[name] = bool(v)
             else:
                 f = float(v)
-                cfg[name] = int(f) if f == int(f) and name != "ctc_weight" else f
+                cfg[name] = int(f) if f == int(f) and "weight" not in name and "dropout" not in name and "temperature" not in name else f
     cfg.setdefault("encoder_embed_norm", True)
     cfg.setdefault("encoder_no_scale_embedding", True)
     return cfg

@@ -8,7 +8,7 @@ import torch
 
 from oracle import s2t_oracle as O
 
-CASES = ["transformer_small", "conformer_small", "conformer_ragged"]
+CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small"]
 
 
 def _load(golden_dir, name):
@@ -41,7 +41,7 @@ def test_eval_forward(golden_dir, name):
     cfg, W = O.cfg_from_golden(z), O.weights_from_golden(z)
     src, lens = torch.from_numpy(z["in::src_tokens"]), torch.from_numpy(z["in::src_lengths"])
     with torch.no_grad():
-        enc = O.encoder_forward(src, lens, W, cfg, training=False)
+        enc = O.ENCODERS[O.encoder_kind(cfg)](src, lens, W, cfg, training=False)
         logits = O.decoder_forward(torch.from_numpy(z["in::prev_output_tokens"]), enc, W, cfg)
     assert (enc["encoder_padding_mask"][0].numpy() == z["out::encoder_padding_mask"]).all()
     _close(enc["encoder_out"][0], z["out::encoder_out"], rtol=1e-4, atol=2e-5)
@@ -67,7 +67,11 @@ def test_loss_and_grads(golden_dir, name, torch_ctc):
     assert abs(float(log["ctc_loss"]) - float(z["out::ctc_loss"])) <= 1e-4 * abs(float(z["out::ctc_loss"]))
     assert log["n_correct"] == int(z["out::n_correct"]) and log["total"] == int(z["out::total"])
     loss.backward()
-    tied = ["decoder.embed_tokens.weight", "decoder.output_projection.weight", "encoder.ctc.ctc_projection.weight"]
+    # the reference ties these (share_decoder_input_output_embed / share_ctc_and_embed; SATE also the text embedding);
+    # its named_parameters() reports the shared gradient once, under the first-registered name
+    tied = [k for k in ("decoder.embed_tokens.weight", "decoder.output_projection.weight",
+                        "encoder.ctc.ctc_projection.weight", "encoder.acoustic_encoder.ctc.ctc_projection.weight",
+                        "encoder.textual_encoder.embed_tokens.weight") if k in W]
     n = 0
     for k in z.files:
         if not k.startswith("grad::"):
