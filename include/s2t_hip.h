@@ -186,6 +186,12 @@ int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const f
  * ------------------------------------------------------------------------------------------------ */
 int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int V, int32_t* idx, float* top_lp,
                    float* lse, void* stream);
+/* SATE adapter distribution (modules/speech_to_text/adapter.py:214-217): P = softmax(x * inv_tau) per row, and its
+ * backward dx = P * (dP - sum P dP) * inv_tau */
+int s2t_row_softmax_fwd(int dtype, const void* x, int64_t ldx, void* p, int64_t ldp, int64_t rows, int V, float inv_tau,
+                        void* stream);
+int s2t_row_softmax_bwd(int dtype, const void* p, int64_t ldp, const void* dp, int64_t lddp, void* dx, int64_t lddx,
+                        int64_t rows, int V, float inv_tau, void* stream);
 int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens, int B, int T, int blank,
                      int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
 int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V, const int64_t* target,

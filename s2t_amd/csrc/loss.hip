@@ -396,6 +396,50 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
   }
 }
 
+// ---- row softmax over a wide vocabulary (SATE adapter: softmax(ctc_logit / tau), adapter.py:214-217) ----
+template <typename T>
+__global__ __launch_bounds__(256) void row_softmax_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ p,
+                                                              int64_t ldp, int V, float inv_tau,
+                                                              const int32_t* __restrict__ lens, int Tn) {
+  const int64_t row = blockIdx.x;
+  const T* xr = x + row * ldx;
+  T* pr = p + row * ldp;
+  float mx, lse;
+  int arg;
+  // statistics of x * inv_tau: max scales, logsumexp is recomputed on the scaled values
+  __shared__ float ss2[4];
+  row_stats<T>(xr, V, mx, arg, lse);
+  float s = 0.f;
+  const float m2 = mx * inv_tau;
+  row_foreach<T>(xr, V, [&](int c, float v) { s += __expf(v * inv_tau - m2); });
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) ss2[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float inv = 1.f / (ss2[0] + ss2[1] + ss2[2] + ss2[3]);
+  (void)lens; (void)Tn;
+  row_map<T>(xr, pr, V, [&](int c, float v) { return __expf(v * inv_tau - m2) * inv; });
+}
+
+// dx = P * (dP - sum_j P dP) * inv_tau
+template <typename T>
+__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const T* __restrict__ p, int64_t ldp,
+                                                              const T* __restrict__ dp, int64_t lddp,
+                                                              T* __restrict__ dx, int64_t lddx, int V, float inv_tau) {
+  __shared__ float sd[4];
+  const int64_t row = blockIdx.x;
+  const T* pr = p + row * ldp;
+  const T* dr = dp + row * lddp;
+  float dot = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) dot += ld_as_f32<T>(pr + c) * ld_as_f32<T>(dr + c);
+  dot = wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  dot = sd[0] + sd[1] + sd[2] + sd[3];
+  T* xr = dx + row * lddx;
+  for (int c = threadIdx.x; c < V; c += 256)
+    st_from_f32<T>(xr + c, ld_as_f32<T>(pr + c) * (ld_as_f32<T>(dr + c) - dot) * inv_tau);
+}
+
 }  // namespace
 
 extern "C" int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int V, int32_t* idx,
@@ -464,6 +508,34 @@ extern "C" int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B
     hipLaunchKernelGGL(ctc_grad_kernel<float>, grid, block, shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (float*)grad, ldg);
   else if (dtype == S2T_BF16)
     hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (bf16_t*)grad, ldg);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_row_softmax_fwd(int dtype, const void* x, int64_t ldx, void* p, int64_t ldp, int64_t rows, int V,
+                                   float inv_tau, void* stream) {
+  if (!x || !p || rows < 0 || V <= 0 || ldx < V || ldp < V) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)rows), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(row_softmax_fwd_kernel<float>, grid, block, 0, s, (const float*)x, ldx, (float*)p, ldp, V, inv_tau, (const int32_t*)nullptr, 0);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(row_softmax_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ldx, (bf16_t*)p, ldp, V, inv_tau, (const int32_t*)nullptr, 0);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_row_softmax_bwd(int dtype, const void* p, int64_t ldp, const void* dp, int64_t lddp, void* dx,
+                                   int64_t lddx, int64_t rows, int V, float inv_tau, void* stream) {
+  if (!p || !dp || !dx || rows < 0 || V <= 0) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)rows), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(row_softmax_bwd_kernel<float>, grid, block, 0, s, (const float*)p, ldp, (const float*)dp, lddp, (float*)dx, lddx, V, inv_tau);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(row_softmax_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)p, ldp, (const bf16_t*)dp, lddp, (bf16_t*)dx, lddx, V, inv_tau);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

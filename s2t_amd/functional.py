@@ -606,3 +606,101 @@ class CTCLossFn(torch.autograd.Function):
 
 def ctc_loss(logits, B, T, targets, tgt_lens, in_lens, blank=0):
     return CTCLossFn.apply(logits, B, T, targets, tgt_lens, in_lens, blank)
+
+
+# ------------------------------------------------------------------------------------------------
+# Strided Conv1d (k odd, pad (k-1)/2) over time as an overlapping-row GEMM — PDS down-sampling
+# ------------------------------------------------------------------------------------------------
+class Conv1dFn(torch.autograd.Function):
+    """y[b,t,:] = bias + sum_tap W[:, tap, :] x[b, stride*t + tap - pad, :]  (nn.Conv1d on (B,C,T), channels-last here).
+    Reference: Downsampling.conv in models/speech_to_text/pdss2t_transformer.py:72-90,127-129.
+    ``x`` is [B*T, Cin] with padded frames already zeroed; weight is stored [Cout][k][Cin]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, B, T, stride, train):
+        Cout, kk, Cin = w.shape
+        pad = (kk - 1) // 2
+        dt, dev = x.dtype, x.device
+        Tout = (T + 2 * pad - kk) // stride + 1
+        Tp = stride * (Tout - 1) + kk  # rows touched
+        Tp = max(Tp, T + pad) + 1
+        xp = torch.zeros(B, Tp, Cin, dtype=dt, device=dev)
+        xp[:, pad:pad + T].copy_(x.view(B, T, Cin))
+        y = torch.empty(B * Tout, Cout, dtype=dt, device=dev)
+        K.gemm(xp, cw(w).view(Cout, kk * Cin), y, M=Tout, N=Cout, K=kk * Cin, lda=stride * Cin, ldb=kk * Cin, ldc=Cout,
+               batch=B, a_s=(Tp * Cin, 0), c_s=(Tout * Cout, 0), bias=b.data)
+        if train:
+            ctx.save_for_backward(xp)
+        ctx.p, ctx.dims = (w, b), (B, T, Tout, Tp, Cin, Cout, kk, pad, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xp,) = ctx.saved_tensors
+        w, b = ctx.p
+        B, T, Tout, Tp, Cin, Cout, kk, pad, stride = ctx.dims
+        dt, dev = xp.dtype, xp.device
+        dy = dy.contiguous()
+        K.gemm(dy, xp, w.grad.view(Cout, kk * Cin), M=Cout, N=kk * Cin, K=Tout, lda=Cout, ldb=stride * Cin, ldc=kk * Cin,
+               a_kmajor=True, b_kmajor=True, batch=B, a_s=(Tout * Cout, 0), b_s=(Tp * Cin, 0), c_s=(0, 0), c_atomic=True)
+        K.colsum_accum(dy, Cout, b.grad, B * Tout, Cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxp = torch.zeros(B, Tp, Cin, dtype=dt, device=dev)
+            wc = cw(w).view(Cout, kk * Cin)
+            for tap in range(kk):
+                out = dxp.view(-1)[tap * Cin:]
+                K.gemm(dy, wc[:, tap * Cin:], out, M=Tout, N=Cin, K=Cout, lda=Cout, ldb=kk * Cin, ldc=stride * Cin,
+                       b_kmajor=True, batch=B, a_s=(Tout * Cout, 0), c_s=(Tp * Cin, 0), residual=out, ldr=stride * Cin)
+            dx = dxp[:, pad:pad + T].contiguous().view(B * T, Cin)
+        _ready(w, b)
+        return dx, None, None, None, None, None, None
+
+
+def conv1d(x, w, b, B, T, stride):
+    return Conv1dFn.apply(x, w, b, B, T, stride, torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------
+# SATE adapter (inter_league)
+# ------------------------------------------------------------------------------------------------
+class AdapterFn(torch.autograd.Function):
+    """out = x + softmax(ctc_logit / tau) @ W_embed   (modules/speech_to_text/adapter.py:214-217,264-266,296-297)."""
+
+    @staticmethod
+    def forward(ctx, x, logit, w, tau, train):
+        M, d = x.shape
+        V = w.shape[0]
+        assert logit.stride(1) == 1
+        dt, dev = x.dtype, x.device
+        lg = logit if logit.dtype == dt else logit.to(dt)
+        ldp = _pad8(V)
+        P = torch.empty(M, ldp, dtype=dt, device=dev)
+        K.row_softmax_fwd(lg, lg.stride(0), P, ldp, M, V, 1.0 / tau)
+        y = torch.empty(M, d, dtype=dt, device=dev)
+        K.gemm(P, cw(w), y, M=M, N=d, K=V, lda=ldp, ldb=d, ldc=d, b_kmajor=True, residual=x, ldr=d)
+        if train:
+            ctx.save_for_backward(P)
+        ctx.w, ctx.tau, ctx.V, ctx.ldt = w, tau, V, logit.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (P,) = ctx.saved_tensors
+        w, V = ctx.w, ctx.V
+        M, ldp = P.shape
+        d = w.shape[1]
+        dt, dev = P.dtype, P.device
+        dy = dy.contiguous()
+        dP = torch.empty(M, ldp, dtype=dt, device=dev)
+        K.gemm(dy, cw(w), dP, M=M, N=V, K=d, lda=d, ldb=d, ldc=ldp)
+        dlogit = torch.empty(M, ldp, dtype=dt, device=dev)
+        K.row_softmax_bwd(P, ldp, dP, ldp, dlogit, ldp, M, V, 1.0 / ctx.tau)
+        _wgrad(P, dy, w.grad, V, d, M, ldp, d)
+        _ready(w)
+        dl = dlogit[:, :V]
+        return dy, (dl if ctx.ldt == dt else dl.to(ctx.ldt)), None, None, None
+
+
+def adapter_inter_league(x, logit, w, tau=1.0):
+    return AdapterFn.apply(x, logit, w, tau, torch.is_grad_enabled())

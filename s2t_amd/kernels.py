@@ -236,3 +236,12 @@ def ctc_loss_bwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blan
     _call("s2t_ctc_loss_bwd", L.dtype_id(logits.dtype), logits.data_ptr(), ld, B, T, V, lse.data_ptr(),
           targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), beta.data_ptr(),
           Lmax, nll.data_ptr(), gscale, grad.data_ptr(), ldg)
+
+
+def row_softmax_fwd(x, ldx, p, ldp, rows, V, inv_tau=1.0):
+    _call("s2t_row_softmax_fwd", L.dtype_id(x.dtype), x.data_ptr(), ldx, p.data_ptr(), ldp, rows, V, inv_tau)
+
+
+def row_softmax_bwd(p, ldp, dp, lddp, dx, lddx, rows, V, inv_tau=1.0):
+    _call("s2t_row_softmax_bwd", L.dtype_id(p.dtype), p.data_ptr(), ldp, dp.data_ptr(), lddp, dx.data_ptr(), lddx, rows, V,
+          inv_tau)

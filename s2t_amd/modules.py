@@ -243,16 +243,18 @@ class ConvolutionModule(nn.Module):
 class S2TTransformerEncoderLayer(nn.Module):
     """modules/s2t_transformer_layer.py:69-322 (pre-LN; macaron / conv-module / rel_pos variants)."""
 
-    def __init__(self, args):
+    def __init__(self, args, embed_dim=None, ffn_dim=None, num_heads=None, conv_activation=None, cnn_kernel=None):
         super().__init__()
-        d, ffn_dim = args.encoder_embed_dim, args.encoder_ffn_embed_dim
+        d = embed_dim or args.encoder_embed_dim
+        ffn_dim = ffn_dim or args.encoder_ffn_embed_dim
+        heads = num_heads or args.encoder_attention_heads
         if not args.encoder_normalize_before:
             raise NotImplementedError("post-LN encoder layers")
         self.attn_type = getattr(args, "encoder_attention_type", "selfattn")
         if self.attn_type == "selfattn":
-            self.self_attn = MultiheadAttention(d, args.encoder_attention_heads, dropout=args.dropout, self_attention=True)
+            self.self_attn = MultiheadAttention(d, heads, dropout=args.dropout, self_attention=True)
         elif self.attn_type == "rel_pos":
-            self.self_attn = RelPositionMultiHeadedAttention(d, args.encoder_attention_heads, dropout=args.dropout)
+            self.self_attn = RelPositionMultiHeadedAttention(d, heads, dropout=args.dropout)
         else:
             raise NotImplementedError("encoder attention type %s (HIP path: selfattn, rel_pos)" % self.attn_type)
         self.self_attn_layer_norm = LayerNorm(d)
@@ -267,9 +269,10 @@ class S2TTransformerEncoderLayer(nn.Module):
         if args.use_cnn_module:
             self.conv_norm = LayerNorm(d)
             # NB: the conv-module activation is --activation-fn, not --encoder-activation-fn (s2t_transformer_layer.py:125)
-            self.conv_module = ConvolutionModule(d, d, depthwise_kernel_size=args.cnn_module_kernel, dropout=args.dropout,
-                                                 activation_fn=getattr(args, "activation_fn", "swish"),
-                                                 norm_type=args.cnn_module_norm)
+            self.conv_module = ConvolutionModule(d, d, depthwise_kernel_size=cnn_kernel or args.cnn_module_kernel,
+                                                 dropout=args.dropout,
+                                                 activation_fn=conv_activation or getattr(args, "activation_fn", "swish"),
+                                                 norm_type=getattr(args, "cnn_module_norm", "batch_norm"))
             self.final_norm = LayerNorm(d)
         else:
             self.conv_norm = self.conv_module = self.final_norm = None

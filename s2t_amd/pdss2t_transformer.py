@@ -1,0 +1,187 @@
+"""PDS (progressive down-sampling) S2T encoder on the HIP path — BASELINE config 3.
+
+Reference: fairseq/models/speech_to_text/pdss2t_transformer.py (Downsampling :53-144, PDSS2TTransformerEncoder
+ctor :290-960 / forward :1042-1281, architectures :1358-1723) and fairseq/modules/pds_layer.py:263-359.
+Built: the recipe configuration of egs/mustc/asr/conf/pds_base_8.yaml (`pds-ds-method conv`, `pds-embed-norm`, sinusoidal or
+rel-pos position embedding per stage, no fusion, no inter-CTC); other options raise NotImplementedError.
+state_dict keys: downsampling{i}.conv.0.{weight,bias}, downsampling{i}.norm.*, pos_embed{i}._float_tensor, stage{i}.N.*,
+layer_norm.*, ctc.ctc_projection.*.
+"""
+from functools import reduce
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .modules import (CTC, TABLES, Ctx, LayerNorm, MaskRows, S2TTransformerEncoderLayer, _Conv1dK)
+from .registry import register_model, register_model_architecture
+from .s2t_transformer import (AddPositions, Embedding, S2TTransformerModel, TransformerDecoderScriptable, _HipModel,
+                              _SinPosHolder, _d, _unsupported, base_architecture as _s2t_base)
+
+
+def _ints(v):
+    return [int(t) for t in str(v).split("_")]
+
+
+class Downsampling(nn.Module):
+    """pdss2t_transformer.py:53-144 (`conv` way): mask -> Conv1d(k, stride, (k-1)//2) -> LayerNorm -> mask."""
+
+    def __init__(self, reduced_way, embed_norm, in_channels, out_channels, kernel_sizes, stride, padding):
+        super().__init__()
+        if reduced_way != "conv" or padding != (kernel_sizes - 1) // 2 or stride < 1:
+            raise NotImplementedError("PDS down-sampling: only the `conv` way of the recipes is built")
+        self.stride = stride
+        self.conv = nn.ModuleList([_Conv1dK(in_channels, out_channels, kernel_sizes)])
+        self.norm = LayerNorm(out_channels) if embed_norm else None
+
+    def forward(self, x2d, B, T, lens32):
+        x2d = MaskRows.apply(x2d, lens32, T)
+        c = self.conv[0]
+        y = Fn.conv1d(x2d, c.weight, c.bias, B, T, self.stride)
+        kk = c.weight.shape[1]
+        Tout = (T + 2 * ((kk - 1) // 2) - kk) // self.stride + 1
+        out_lens = torch.floor((lens32.float() - 1) / self.stride + 1).to(torch.int32)
+        if self.norm is not None:
+            y = self.norm(y, out_lens, Tout)  # LayerNorm + the trailing mask, fused
+        else:
+            y = MaskRows.apply(y, out_lens, Tout)
+        return y, Tout, out_lens
+
+
+class PDSS2TTransformerEncoder(nn.Module):
+    def __init__(self, args, task=None, embed_tokens=None):
+        super().__init__()
+        _unsupported(args, inter_mixup=False, pds_fusion=False, inter_ctc_layers=None, inter_xctc_layers=None, xctc_weight=0,
+                     pds_final_layers=0)
+        if args.dropout or getattr(args, "pds_dropout", 0):
+            raise NotImplementedError("dropout > 0 on the HIP path")
+        self.args = args
+        self.pds_stages = int(args.pds_stages)
+        self.pds_layers = _ints(args.pds_layers)
+        self.pds_ratios = _ints(args.pds_ratios)
+        self.pds_embed_dims = _ints(args.pds_embed_dims)
+        self.pds_kernel_sizes = _ints(args.pds_kernel_sizes)
+        self.pds_ffn_ratios = _ints(args.pds_ffn_ratios)
+        self.pds_attn_heads = _ints(args.pds_attn_heads)
+        self.pds_position_embed = _ints(args.pds_position_embed)
+        self.attn_type = getattr(args, "encoder_attention_type", "selfattn")
+        self.embed_dim = self.pds_embed_dims[-1]
+        self.padding_idx = 1
+        in_dim = args.input_feat_per_channel * args.input_channels
+        for i in range(self.pds_stages):
+            d = self.pds_embed_dims[i]
+            ds = Downsampling(args.pds_ds_method, bool(args.pds_embed_norm), in_dim if i == 0 else self.pds_embed_dims[i - 1], d,
+                              self.pds_kernel_sizes[i], self.pds_ratios[i], (self.pds_kernel_sizes[i] - 1) // 2)
+            setattr(self, f"downsampling{i + 1}", ds)
+            if self.pds_position_embed[i] and self.attn_type != "rel_pos":
+                setattr(self, f"pos_embed{i + 1}", _SinPosHolder())
+            # PDS layers take their conv-module activation from --encoder-activation-fn (pds_layer.py:67,104)
+            stage = nn.ModuleList([
+                S2TTransformerEncoderLayer(args, embed_dim=d, ffn_dim=d * self.pds_ffn_ratios[i], num_heads=self.pds_attn_heads[i],
+                                           conv_activation=getattr(args, "encoder_activation_fn", "relu"))
+                for _ in range(self.pds_layers[i])])
+            setattr(self, f"stage{i + 1}", stage)
+        self.layer_norm = LayerNorm(self.embed_dim) if args.encoder_normalize_before else None
+        self.use_ctc = getattr(args, "ctc_weight", 0) > 0
+        if self.use_ctc:
+            if getattr(args, "ctc_layer", 0) != 0:
+                raise NotImplementedError("ctc_layer inside the stack")
+            vocab = len(task.source_dictionary) if task is not None else args.vocab_size
+            self.ctc = CTC(self.embed_dim, dictionary_size=vocab, dropout=args.dropout)
+            if getattr(args, "share_ctc_and_embed", False) and embed_tokens is not None \
+                    and self.embed_dim == embed_tokens.embedding_dim:
+                self.ctc.ctc_projection.weight = embed_tokens.weight
+        self.compute_dtype = torch.float32
+        self.ctc_out_dtype = None
+
+    def max_positions(self):
+        return getattr(self.args, "max_source_positions", 6000)
+
+    def set_num_updates(self, n):
+        pass
+
+    def forward(self, src_tokens, src_lengths, **kwargs):
+        if not src_tokens.is_cuda:
+            raise RuntimeError("s2t_amd runs on the GPU only; there is no CPU fallback")
+        dt = self.compute_dtype
+        B, T, C = src_tokens.shape
+        total = reduce(lambda a, b: max(1, a) * max(1, b), self.pds_ratios)
+        pad_to = total - T % total  # always pads, + total when already aligned (pdss2t_transformer.py:1050-1055)
+        Tn = T + (pad_to if total > 1 else 0)
+        x = torch.zeros(B, Tn, C, dtype=dt, device=src_tokens.device)
+        x[:, :T].copy_(src_tokens)
+        x = x.view(B * Tn, C)
+        lens32 = src_lengths.to(torch.int32)
+        for i in range(self.pds_stages):
+            x, Tn, lens32 = getattr(self, f"downsampling{i + 1}")(x, B, Tn, lens32)
+            d = self.pds_embed_dims[i]
+            c = Ctx(B, Tn, lens32, dt)
+            if self.pds_position_embed[i]:
+                if self.attn_type == "rel_pos":
+                    c.pos_tab = TABLES.get("rel", Tn, d, x.device, dt)
+                else:
+                    tab = TABLES.get("sin", max(self.max_positions(), Tn) + 2, d, x.device)
+                    x = AddPositions.apply(x, tab, lens32, Tn, 1.0)
+            for layer in getattr(self, f"stage{i + 1}"):
+                x = layer(x, c, mask_output=False)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        lens = lens32.long()
+        mask = torch.arange(Tn, device=x.device)[None, :] >= lens[:, None]
+        ctc_logit = None
+        if self.use_ctc:
+            ctc_logit = self.ctc(x, out_dtype=self.ctc_out_dtype).view(B, Tn, -1).transpose(0, 1)
+        return {
+            "encoder_out": [x.view(B, Tn, self.embed_dim).transpose(0, 1)],
+            "ctc_logit": [] if ctc_logit is None else [ctc_logit],
+            "inter_ctc_logits": [], "xctc_logit": [], "inter_xctc_logits": [],
+            "encoder_padding_mask": [mask], "mixup": None, "encoder_embedding": [], "encoder_states": [],
+            "src_tokens": [], "src_lengths": [],
+        }
+
+    reorder_encoder_out = None  # set below (shared implementation)
+
+
+from .s2t_transformer import S2TTransformerEncoder as _Enc  # noqa: E402
+
+PDSS2TTransformerEncoder.reorder_encoder_out = _Enc.reorder_encoder_out
+
+
+@register_model("pdss2t_transformer")
+class PDSS2TTransformerModel(S2TTransformerModel):
+    """models/speech_to_text/pdss2t_transformer.py:147-288."""
+
+    @classmethod
+    def build_model(cls, args, task):
+        base_architecture(args)
+        tgt = task.target_dictionary
+        embed = Embedding(len(tgt), args.decoder_embed_dim, tgt.pad())
+        return cls(PDSS2TTransformerEncoder(args, task, embed), TransformerDecoderScriptable(args, tgt, embed))
+
+
+@register_model_architecture("pdss2t_transformer", "pdss2t_transformer")
+def base_architecture(args):
+    _d(args, "pds_stages", 4)
+    _d(args, "pds_layers", "3_3_3_3")
+    _d(args, "pds_ratios", "2_2_1_2")
+    _d(args, "pds_ds_method", "conv")
+    _d(args, "pds_embed_dims", "256_256_256_256")
+    _d(args, "pds_embed_norm", False)
+    _d(args, "pds_position_embed", "1_1_1_1")
+    _d(args, "pds_attn_heads", "4_4_4_4")
+    _d(args, "pds_ffn_ratios", "8_8_8_8")
+    _d(args, "pds_kernel_sizes", "5_5_5_5")
+    _d(args, "pds_fusion", False)
+    _d(args, "pds_dropout", 0)
+    _s2t_base(args)
+
+
+@register_model_architecture("pdss2t_transformer", "pdss2t_transformer_s_8")
+def pdss2t_transformer_s_8(args):
+    """set_pds_base_8 (pdss2t_transformer.py:1496-1501) + pdss2t_transformer_s (:1561-1575)."""
+    _d(args, "encoder_embed_dim", 256)
+    _d(args, "pds_embed_norm", True)
+    _d(args, "encoder_attention_heads", 4)
+    _d(args, "decoder_attention_heads", 4)
+    _d(args, "encoder_ffn_embed_dim", 256 * 8)
+    base_architecture(args)

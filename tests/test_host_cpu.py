@@ -41,15 +41,20 @@ def test_gemm_struct_matches_header_field_order():
 
 
 def _build(golden_dir, name):
+    from s2t_amd import pdss2t_transformer as PDS
+    from s2t_amd import s2t_sate as SATE
     from tests.test_model_parity_gpu import args_from_cfg
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = O.cfg_from_golden(z)
-    vocab = z["w::encoder.ctc.ctc_projection.weight"].shape[0]
-    model = M.S2TTransformerModel.build_model(args_from_cfg(cfg, vocab), M.FakeTask(vocab))
+    vocab = z["w::decoder.embed_tokens.weight"].shape[0]
+    arch = str(cfg.get("arch", ""))
+    cls = PDS.PDSS2TTransformerModel if arch.startswith("pdss2t") else SATE.S2TSATEModel if arch.startswith("s2t_sate") \
+        else M.S2TTransformerModel
+    model = cls.build_model(args_from_cfg(cfg, vocab), M.FakeTask(vocab))
     return model, z
 
 
-@pytest.mark.parametrize("name", ["transformer_small", "conformer_small"])
+@pytest.mark.parametrize("name", ["transformer_small", "conformer_small", "pds_small", "pds_conformer_small", "sate_small"])
 def test_state_dict_keys_and_roundtrip(golden_dir, name):
     """Checkpoint compatibility: same keys and shapes as the reference's state_dict."""
     model, z = _build(golden_dir, name)
@@ -64,10 +69,15 @@ def test_state_dict_keys_and_roundtrip(golden_dir, name):
         np.testing.assert_array_equal(sd2[k].numpy(), v)
     # tied weights stay tied (s2t_transformer.py:965-971, transformer.py:901-907)
     assert model.decoder.embed_tokens.weight is model.decoder.output_projection.weight
-    assert model.encoder.ctc.ctc_projection.weight is model.decoder.embed_tokens.weight
+    if name.startswith("sate"):
+        assert model.encoder.acoustic_encoder.ctc.ctc_projection.weight is model.decoder.embed_tokens.weight
+        assert model.encoder.textual_encoder.embed_tokens.weight is model.decoder.embed_tokens.weight
+    else:
+        assert model.encoder.ctc.ctc_projection.weight is model.decoder.embed_tokens.weight
     # conv weights are held [Cout][k][Cin] internally
-    w = model.encoder.subsample.layers[0][0].weight
-    np.testing.assert_array_equal(w.detach().numpy(), ref["encoder.subsample.layers.0.0.weight"].transpose(0, 2, 1))
+    if not name.startswith(("pds", "sate")):
+        w = model.encoder.subsample.layers[0][0].weight
+        np.testing.assert_array_equal(w.detach().numpy(), ref["encoder.subsample.layers.0.0.weight"].transpose(0, 2, 1))
 
 
 def test_flat_parameters_adjacency_and_views(golden_dir):
@@ -95,9 +105,10 @@ def test_flat_parameters_adjacency_and_views(golden_dir):
 
 
 def test_registry_names():
-    for n in ("s2t_transformer", "s2t_ctc"):
+    import s2t_amd.pdss2t_transformer, s2t_amd.s2t_sate  # noqa: F401,E401
+    for n in ("s2t_transformer", "s2t_ctc", "pdss2t_transformer", "s2t_sate"):
         assert n in MODEL_REGISTRY
-    for n in ("s2t_transformer", "s2t_transformer_s", "s2t_ctc", "s2t_ctc_s"):
+    for n in ("s2t_transformer", "s2t_transformer_s", "s2t_ctc", "s2t_ctc_s", "pdss2t_transformer_s_8", "s2t_sate"):
         assert n in ARCH_MODEL_REGISTRY
     assert "label_smoothed_cross_entropy_with_ctc" in CRITERION_REGISTRY
 
