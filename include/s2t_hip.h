@@ -196,13 +196,21 @@ int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* len
                      int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
 int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V, const int64_t* target,
                          int64_t pad_idx, float eps, void* dlogits, int64_t ldd, float* sums, void* stream);
+/* force_emits (optional, [B][T] int64, -1 = free): imputer loss of torch_imputer/imputer.cu:57-215,339-477 (a frame
+ * pinned to one extended-label state).  paths (optional, [B][T][Lmax] int32): max-product (Viterbi) recursion with
+ * back-pointers of torch_imputer/best_alignment.cu:57-201 instead of log-sum-exp (then beta may be NULL).
+ * wrt_logprobs = 1: gradient w.r.t. log-probabilities (what torch_imputer returns) instead of w.r.t. logits. */
 int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                      const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens, int blank,
-                     float* alpha, float* beta, int Lmax, float* nll, void* stream);
+                     float* alpha, float* beta, int Lmax, float* nll, const int64_t* force_emits, int32_t* paths,
+                     void* stream);
 int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                      const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens, int blank,
                      const float* alpha, const float* beta, int Lmax, const float* nll, float gscale, void* grad,
-                     int64_t ldg, void* stream);
+                     int64_t ldg, int wrt_logprobs, void* stream);
+/* best-alignment backtrace (torch_imputer/imputer.py:245-259,311-323) on the device: states[b][t], -1 beyond the length */
+int s2t_ctc_backtrace(const float* alpha, const int32_t* paths, const int32_t* tgt_lens, const int32_t* in_lens, int B,
+                      int T, int Lmax, int32_t* states, void* stream);
 
 #ifdef __cplusplus
 }

@@ -549,6 +549,88 @@ def encoder_kind(cfg):
 
 
 # ----------------------------------------------------------------------------------------------
+# imputer loss / best alignment (a21) — restated from fairseq/torch_imputer/{imputer,best_alignment}.cu
+# ----------------------------------------------------------------------------------------------
+def _ext_labels(y, blank):
+    L = 2 * len(y) + 1
+    ext = [blank] * L
+    ext[1::2] = list(y)
+    return ext
+
+
+def imputer_nll(log_probs, targets, force_emits, input_lengths, blank=0):
+    """torch_imputer/imputer.cu:57-215 — CTC alpha recursion where frame t, when force_emits[b][t] >= 0, may only
+    occupy that extended-label state (every other state -inf).  Pure-Python loops (small cases only).
+    log_probs (T,B,V); targets: list of label lists; force_emits (B,T).  Returns nll per utterance (inf kept)."""
+    T, B, V = log_probs.shape
+    out = []
+    for b in range(B):
+        ext = _ext_labels([int(v) for v in targets[b]], blank)
+        L, Tb = len(ext), int(input_lengths[b])
+        ninf = float("-inf")
+        a = [ninf] * L
+        for s in range(min(2, L)):
+            a[s] = float(log_probs[0, b, ext[s]])
+        fe = int(force_emits[b][0])
+        if fe > -1:
+            a = [v if s == fe else ninf for s, v in enumerate(a)]
+        for t in range(1, Tb):
+            fe = int(force_emits[b][t])
+            n = [ninf] * L
+            for s in range(L):
+                if fe > -1 and fe != s:
+                    continue
+                c = [a[s]]
+                if s > 0:
+                    c.append(a[s - 1])
+                if s > 1 and ext[s] != blank and ext[s] != ext[s - 2]:
+                    c.append(a[s - 2])
+                m = max(c)
+                if m == ninf:
+                    continue
+                n[s] = m + math.log(sum(math.exp(v - m) for v in c)) + float(log_probs[t, b, ext[s]])
+            a = n
+        c = [a[L - 1]] + ([a[L - 2]] if L > 1 else [])
+        m = max(c)
+        out.append(float("inf") if m == ninf else -(m + math.log(sum(math.exp(v - m) for v in c))))
+    return torch.tensor(out)
+
+
+def best_alignment(log_probs, targets, input_lengths, blank=0):
+    """torch_imputer/best_alignment.cu:57-201 + imputer.py:245-259: Viterbi over CTC states (first max in the order
+    s, s-1, s-2), backtrace from argmax(alpha[T-1, L-2:]) (first max; state 0 when L == 1)."""
+    T, B, V = log_probs.shape
+    res = []
+    for b in range(B):
+        ext = _ext_labels([int(v) for v in targets[b]], blank)
+        L, Tb = len(ext), int(input_lengths[b])
+        ninf = float("-inf")
+        a = [ninf] * L
+        for s in range(min(2, L)):
+            a[s] = float(log_probs[0, b, ext[s]])
+        bp = [[s for s in range(L)]]
+        for t in range(1, Tb):
+            n, p = [ninf] * L, [0] * L
+            for s in range(L):
+                m, arg = a[s], s
+                if s > 0 and a[s - 1] > m:
+                    m, arg = a[s - 1], s - 1
+                if s > 1 and ext[s] != blank and ext[s] != ext[s - 2] and a[s - 2] > m:
+                    m, arg = a[s - 2], s - 2
+                n[s] = m + float(log_probs[t, b, ext[s]])
+                p[s] = arg
+            a = n
+            bp.append(p)
+        cur = 0 if L == 1 else (L - 1 if a[L - 1] > a[L - 2] else L - 2)
+        path = [cur]
+        for t in range(Tb - 1, 0, -1):
+            cur = bp[t][cur]
+            path.append(cur)
+        res.append(path[::-1])
+    return res
+
+
+# ----------------------------------------------------------------------------------------------
 # helpers for tests / bench
 # ----------------------------------------------------------------------------------------------
 def cfg_from_golden(z) -> dict:

@@ -242,7 +242,12 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
                                                               const int32_t* __restrict__ tgt_lens,
                                                               const int32_t* __restrict__ in_lens, int blank,
                                                               float* __restrict__ alpha, float* __restrict__ beta,
-                                                              int Lmax, float* __restrict__ nll_out) {
+                                                              int Lmax, float* __restrict__ nll_out,
+                                                              const int64_t* __restrict__ force_emits,
+                                                              int32_t* __restrict__ paths) {
+  // force_emits (imputer loss, torch_imputer/imputer.cu:114-152): fe[b,t] >= 0 pins frame t to state fe, every other
+  // state gets -inf.  paths != NULL (best alignment, torch_imputer/best_alignment.cu:57-201): max-product recursion
+  // with back-pointers instead of log-sum-exp; beta is not computed.
   extern __shared__ float sh[];  // [2][Lmax+2] ping-pong
   const int b = blockIdx.x;
   const int S = tgt_lens[b];
@@ -271,9 +276,14 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
   {
     float a = -INFINITY;
     if (act && s < 2) a = ld_as_f32<T>(logits + row0 * ld + lab) - lse[row0];
+    if (force_emits) {
+      const int64_t fe = force_emits[(int64_t)b * T_];
+      if (fe > -1 && fe != s) a = -INFINITY;
+    }
     if (act) {
       al[s] = a;
       bufA[s] = a;
+      if (paths) paths[(int64_t)b * T_ * Lmax + s] = s;
     }
     __syncthreads();
     float* cur = bufA;
@@ -285,8 +295,22 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
         const float a1 = s >= 1 ? cur[s - 1] : -INFINITY;
         const float a2 = (s >= 2 && skip) ? cur[s - 2] : -INFINITY;
         const float lp = ld_as_f32<T>(logits + (row0 + t) * ld + lab) - lse[row0 + t];
-        const float m = lse3(a0, a1, a2);
-        v = m == -INFINITY ? -INFINITY : m + lp;
+        if (paths) {
+          // Viterbi: first maximum in the order s, s-1, s-2 (strict > to move on), best_alignment.cu:141-160
+          float m = a0;
+          int arg = s;
+          if (a1 > m) { m = a1; arg = s - 1; }
+          if (a2 > m) { m = a2; arg = s - 2; }
+          v = m + lp;
+          paths[((int64_t)b * T_ + t) * Lmax + s] = arg;
+        } else {
+          const float m = lse3(a0, a1, a2);
+          v = m == -INFINITY ? -INFINITY : m + lp;
+        }
+        if (force_emits) {
+          const int64_t fe = force_emits[(int64_t)b * T_ + t];
+          if (fe > -1 && fe != s) v = -INFINITY;
+        }
         nxt[s] = v;
         al[(int64_t)t * Lmax + s] = v;
       }
@@ -304,9 +328,13 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
     __syncthreads();
   }
   // ---- beta
-  {
+  if (beta) {
     float v = -INFINITY;
     if (act && s >= L - 2) v = ld_as_f32<T>(logits + (row0 + Tb - 1) * ld + lab) - lse[row0 + Tb - 1];
+    if (force_emits) {
+      const int64_t fe = force_emits[(int64_t)b * T_ + Tb - 1];
+      if (fe > -1 && fe != s) v = -INFINITY;
+    }
     if (act) {
       be[(int64_t)(Tb - 1) * Lmax + s] = v;
       bufA[s] = v;
@@ -321,7 +349,11 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
         const float b2 = (s + 2 < L && skipn) ? cur[s + 2] : -INFINITY;
         const float lp = ld_as_f32<T>(logits + (row0 + t) * ld + lab) - lse[row0 + t];
         const float m = lse3(b0, b1, b2);
-        const float r = m == -INFINITY ? -INFINITY : m + lp;
+        float r = m == -INFINITY ? -INFINITY : m + lp;
+        if (force_emits) {
+          const int64_t fe = force_emits[(int64_t)b * T_ + t];
+          if (fe > -1 && fe != s) r = -INFINITY;
+        }
         nxt[s] = r;
         be[(int64_t)t * Lmax + s] = r;
       }
@@ -343,7 +375,9 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                                                        const int32_t* __restrict__ in_lens, int blank,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        int Lmax, const float* __restrict__ nll, float gscale,
-                                                       T* __restrict__ grad, int64_t ldg) {
+                                                       T* __restrict__ grad, int64_t ldg, int wrt_logprobs) {
+  // wrt_logprobs = 0: gradient w.r.t. the LOGITS (softmax - occupancy); 1: w.r.t. log-probabilities (- occupancy),
+  // the quantity torch_imputer returns (imputer.cu:561-638)
   extern __shared__ float occ[];  // [Lmax] exp(alpha+beta+nll) per state, then merged per label
   const int64_t row = blockIdx.x;
   const int b = (int)(row / T_), t = (int)(row % T_);
@@ -358,7 +392,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
   const int L = 2 * S + 1;
   const T* x = logits + row * ld;
   const float l = lse[row];
-  row_map<T>(x, g, V, [&](int c, float xv) { return gscale * __expf(xv - l); });
+  row_map<T>(x, g, V, [&](int c, float xv) { return wrt_logprobs ? 0.f : gscale * __expf(xv - l); });
   const float* al = alpha + ((int64_t)b * T_ + t) * Lmax;
   const float* be = beta + ((int64_t)b * T_ + t) * Lmax;
   for (int s = threadIdx.x; s < L; s += 256) {
@@ -392,7 +426,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     const float xv = ld_as_f32<T>(x + lab);
     const float lp = xv - l;
     const float p = __expf(lp);
-    st_from_f32<T>(g + lab, gscale * (p - sum * __expf(-lp)));
+    st_from_f32<T>(g + lab, gscale * ((wrt_logprobs ? 0.f : p) - sum * __expf(-lp)));
   }
 }
 
@@ -440,6 +474,27 @@ __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const T* __restric
     st_from_f32<T>(xr + c, ld_as_f32<T>(pr + c) * (ld_as_f32<T>(dr + c) - dot) * inv_tau);
 }
 
+// best-alignment backtrace (torch_imputer/imputer.py:245-259): start at argmax(alpha[T-1, L-2:]) + L-2 (state 0 when
+// L == 1; first maximum on ties), follow the back-pointers; one thread per utterance, states[b, t] (-1 beyond the length)
+__global__ void ctc_backtrace_kernel(const float* __restrict__ alpha, const int32_t* __restrict__ paths,
+                                     const int32_t* __restrict__ tgt_lens, const int32_t* __restrict__ in_lens, int B,
+                                     int T_, int Lmax, int32_t* __restrict__ states) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int L = 2 * tgt_lens[b] + 1;
+  const int Tb = min(in_lens[b], T_);
+  for (int t = Tb; t < T_; ++t) states[(int64_t)b * T_ + t] = -1;
+  if (Tb <= 0) return;
+  const float* al = alpha + ((int64_t)b * T_ + (Tb - 1)) * Lmax;
+  int cur = 0;
+  if (L > 1) cur = (al[L - 1] > al[L - 2]) ? L - 1 : L - 2;
+  states[(int64_t)b * T_ + Tb - 1] = cur;
+  for (int t = Tb - 1; t > 0; --t) {
+    cur = paths[((int64_t)b * T_ + t) * Lmax + cur];
+    states[(int64_t)b * T_ + t - 1] = cur;
+  }
+}
+
 }  // namespace
 
 extern "C" int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int V, int32_t* idx,
@@ -481,16 +536,18 @@ extern "C" int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, i
 
 extern "C" int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                                 const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens,
-                                int blank, float* alpha, float* beta, int Lmax, float* nll, void* stream) {
-  if (!logits || !lse || !targets || !tgt_lens || !in_lens || !alpha || !beta || !nll) return S2T_ERR_ARG;
+                                int blank, float* alpha, float* beta, int Lmax, float* nll, const int64_t* force_emits,
+                                int32_t* paths, void* stream) {
+  if (!logits || !lse || !targets || !tgt_lens || !in_lens || !alpha || !nll) return S2T_ERR_ARG;
+  if (!beta && !paths) return S2T_ERR_ARG;
   if (B <= 0 || T <= 0 || V <= 0 || Lmax <= 0 || Lmax > 1023 || !(Lmax & 1)) return S2T_ERR_ARG;
   int threads = (Lmax + 63) / 64 * 64;
   const size_t shm = 2 * (size_t)(Lmax + 2) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B), dim3(threads), shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll);
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B), dim3(threads), shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B), dim3(threads), shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll);
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B), dim3(threads), shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
@@ -498,17 +555,25 @@ extern "C" int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B
 extern "C" int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                                 const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens,
                                 int blank, const float* alpha, const float* beta, int Lmax, const float* nll,
-                                float gscale, void* grad, int64_t ldg, void* stream) {
+                                float gscale, void* grad, int64_t ldg, int wrt_logprobs, void* stream) {
   if (!logits || !lse || !targets || !tgt_lens || !in_lens || !alpha || !beta || !nll || !grad) return S2T_ERR_ARG;
   if (B <= 0 || T <= 0 || V <= 0 || Lmax <= 0) return S2T_ERR_ARG;
   const size_t shm = (size_t)Lmax * sizeof(float);
   dim3 grid((unsigned)((int64_t)B * T)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ctc_grad_kernel<float>, grid, block, shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (float*)grad, ldg);
+    hipLaunchKernelGGL(ctc_grad_kernel<float>, grid, block, shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (float*)grad, ldg, wrt_logprobs);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (bf16_t*)grad, ldg);
+    hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (bf16_t*)grad, ldg, wrt_logprobs);
   else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_ctc_backtrace(const float* alpha, const int32_t* paths, const int32_t* tgt_lens, const int32_t* in_lens,
+                                 int B, int T, int Lmax, int32_t* states, void* stream) {
+  if (!alpha || !paths || !tgt_lens || !in_lens || !states || B <= 0 || T <= 0 || Lmax <= 0) return S2T_ERR_ARG;
+  hipLaunchKernelGGL(ctc_backtrace_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, alpha, paths, tgt_lens,
+                     in_lens, B, T, Lmax, states);
   return S2T_LAUNCH_CHECK();
 }
 

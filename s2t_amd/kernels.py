@@ -225,17 +225,23 @@ def ls_cross_entropy(logits, ld, rows, V, target, pad_idx, eps, dlogits, ldd, su
           eps, _ptr(dlogits), ldd, sums.data_ptr())
 
 
-def ctc_loss_fwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll):
+def ctc_loss_fwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll,
+                 force_emits=None, paths=None):
     _call("s2t_ctc_loss_fwd", L.dtype_id(logits.dtype), logits.data_ptr(), ld, B, T, V, lse.data_ptr(),
-          targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), beta.data_ptr(),
-          Lmax, nll.data_ptr())
+          targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), _ptr(beta),
+          Lmax, nll.data_ptr(), _ptr(force_emits), _ptr(paths))
 
 
 def ctc_loss_bwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale,
-                 grad, ldg):
+                 grad, ldg, wrt_logprobs=False):
     _call("s2t_ctc_loss_bwd", L.dtype_id(logits.dtype), logits.data_ptr(), ld, B, T, V, lse.data_ptr(),
           targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), beta.data_ptr(),
-          Lmax, nll.data_ptr(), gscale, grad.data_ptr(), ldg)
+          Lmax, nll.data_ptr(), gscale, grad.data_ptr(), ldg, int(wrt_logprobs))
+
+
+def ctc_backtrace(alpha, paths, tgt_lens, in_lens, B, T, Lmax, states):
+    _call("s2t_ctc_backtrace", alpha.data_ptr(), paths.data_ptr(), tgt_lens.data_ptr(), in_lens.data_ptr(), B, T, Lmax,
+          states.data_ptr())
 
 
 def row_softmax_fwd(x, ldx, p, ldp, rows, V, inv_tau=1.0):

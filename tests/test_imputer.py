@@ -1,0 +1,112 @@
+"""a21: imputer loss / best alignment.  The reference's kernels are CUDA-only and cannot run in the build container
+(SURVEY.md §8c), so the oracle restatement is checked through the known-answer identities listed there (CPU tests),
+and the HIP kernels are checked against the oracle (GPU tests).  Parity beyond these identities is unpinned."""
+import itertools
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2t_oracle as O
+
+
+def _rand_lp(T, B, V, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.log_softmax(torch.randn(T, B, V, generator=g) * 1.5, -1)
+
+
+def test_oracle_imputer_free_equals_ctc():
+    lp = _rand_lp(9, 3, 6, 0)
+    tg = [[1, 2, 2], [3], []]
+    il = torch.tensor([9, 7, 4])
+    fe = torch.full((3, 9), -1)
+    got = O.imputer_nll(lp, tg, fe, il)
+    ref = O.ctc_nll(lp, [torch.tensor(t, dtype=torch.long) for t in tg], il)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_oracle_best_alignment_is_the_brute_force_maximum_and_forcing_it_gives_its_score():
+    lp = _rand_lp(6, 2, 5, 1)
+    tg = [[1, 2], [3, 3, 4]]
+    il = torch.tensor([6, 6])
+    paths = O.best_alignment(lp, tg, il)
+    for b in range(2):
+        ext = O._ext_labels(tg[b], 0)
+        L, T = len(ext), 6
+        best, best_score = None, -1e30
+        for seq in itertools.product(range(L), repeat=T):  # brute force over monotone CTC state paths
+            if seq[0] > 1 or seq[-1] < L - 2:
+                continue
+            ok = True
+            for a, c in zip(seq, seq[1:]):
+                if c < a or c > a + 2 or (c == a + 2 and (ext[c] == 0 or ext[c] == ext[a])):
+                    ok = False
+                    break
+            if not ok:
+                continue
+            sc = sum(float(lp[t, b, ext[s]]) for t, s in enumerate(seq))
+            if sc > best_score + 1e-9:
+                best, best_score = list(seq), sc
+        assert paths[b] == best
+        # collapsing the state path reproduces the target
+        labels = [ext[s] for s in paths[b]]
+        coll = [l for i, l in enumerate(labels) if l != 0 and (i == 0 or labels[i - 1] != l or paths[b][i] != paths[b][i - 1])]
+        dedup = []
+        prev_state = None
+        for s in paths[b]:
+            if ext[s] != 0 and s != prev_state:
+                dedup.append(ext[s])
+            prev_state = s
+        assert dedup == tg[b]
+        # forcing every frame to the Viterbi state leaves exactly that path
+        fe = torch.full((2, 6), -1)
+        fe[b] = torch.tensor(paths[b])
+        forced = O.imputer_nll(lp, tg, fe, il)[b]
+        assert abs(float(forced) + best_score) < 1e-5
+
+
+def test_oracle_imputer_infeasible_is_inf():
+    lp = _rand_lp(3, 1, 4, 2)
+    assert math.isinf(float(O.imputer_nll(lp, [[1, 1, 2]], torch.full((1, 3), -1), torch.tensor([3]))[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32])
+def test_hip_imputer_and_best_alignment_match_oracle(dtype):
+    from s2t_amd.torch_imputer import best_alignment, imputer_loss
+    T, B, V = 14, 4, 9
+    lp = _rand_lp(T, B, V, 3)
+    tg = [[1, 2, 2, 5], [3], [], [4, 4, 4]]
+    S = 4
+    tmat = torch.zeros(B, S, dtype=torch.long)
+    for b, t in enumerate(tg):
+        tmat[b, : len(t)] = torch.tensor(t, dtype=torch.long)
+    tl = torch.tensor([len(t) for t in tg])
+    il = torch.tensor([14, 9, 5, 12])
+    fe = torch.full((B, T), -1)
+    vit = O.best_alignment(lp, tg, il)
+    fe[0, 3] = vit[0][3]
+    fe[0, 8] = vit[0][8]
+    fe[3, :12] = torch.tensor(vit[3])
+    fe[1, 2] = 1
+    lpd = lp.cuda().requires_grad_(True)
+    loss = imputer_loss(lpd, tmat.cuda(), fe.cuda(), il.cuda(), tl.cuda(), blank=0, reduction="none", zero_infinity=True)
+    ref = O.imputer_nll(lp, tg, fe, il)
+    ref0 = torch.where(torch.isinf(ref), torch.zeros_like(ref), ref)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), ref0.numpy(), rtol=1e-4, atol=1e-4)
+    # free imputer == CTC, including gradients w.r.t. the log-probabilities
+    lpd2 = lp.cuda().requires_grad_(True)
+    free = imputer_loss(lpd2, tmat.cuda(), torch.full((B, T), -1).cuda(), il.cuda(), tl.cuda(), reduction="sum", zero_infinity=True)
+    free.backward()
+    lpr = lp.clone().requires_grad_(True)
+    ctc = torch.nn.functional.ctc_loss(lpr, torch.cat([torch.tensor(t, dtype=torch.long) for t in tg]), il, tl, blank=0,
+                                       reduction="sum", zero_infinity=True)
+    ctc.backward()
+    assert abs(float(free) - float(ctc)) < 1e-3
+    # ATen's ctc_loss backward assumes log_softmax inputs and returns the logits-gradient (p - occupancy); the imputer
+    # API returns d/d log_prob = -occupancy: they differ by exp(lp) on valid frames
+    mask = (torch.arange(T)[:, None] < il[None, :])[:, :, None].float()
+    np.testing.assert_allclose(lpd2.grad.cpu().numpy(), (lpr.grad - lp.exp() * mask).numpy(), rtol=1e-3, atol=1e-4)
+    got = best_alignment(lp.cuda(), tmat.cuda(), il.cuda(), tl.cuda())
+    assert got == vit
