@@ -7,7 +7,7 @@ gradient all-reduce + clip + Adam) of the 12-layer Conformer S2T model on synthe
 Prints ONE JSON line on rank 0 (contract in the task statement; roofline + cpu_baseline objects included).
 Workload = BASELINE.json configs[1] in its Conformer reading (SURVEY.md §8d config 2'): s2t_transformer_s,
 12 enc / 6 dec, d=256, F=2048, h=4, rel_pos + macaron + conv-module(K=15), V=10000, B=64 x T=1000 x 80, bf16,
-label-smoothed CE (0.1) + 0.3 CTC, Adam, clip 10.  Dropout is 0 (not built yet on the HIP path) — stated in config.
+label-smoothed CE (0.1) + 0.3 CTC, Adam, clip 10, dropout 0.1 (recipe value; masks fused into the GEMM epilogues).
 """
 import argparse
 import json
@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.1, help="dropout / attention-dropout / activation-dropout (base.yaml: 0.1)")
     ap.add_argument("--enc-layers", type=int, default=12)
     ap.add_argument("--dec-layers", type=int, default=6)
     args = ap.parse_args()
@@ -132,7 +133,8 @@ def main():
     conformer = args.arch == "conformer"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(1)
-    margs = M.recipe_args(conformer=conformer, vocab_size=V, encoder_layers=args.enc_layers, decoder_layers=args.dec_layers)
+    margs = M.recipe_args(conformer=conformer, vocab_size=V, encoder_layers=args.enc_layers, decoder_layers=args.dec_layers,
+                          dropout=args.dropout, attention_dropout=args.dropout, activation_dropout=args.dropout)
     model = M.S2TTransformerModel.build_model(margs, M.FakeTask(V)).prepare(dtype, dev)
     crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
     ddp = LegacyDistributedDataParallel(model) if world > 1 else None
@@ -219,7 +221,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "s2t_transformer_s %s %d-enc/%d-dec d256 F2048 h4 V%d, per-GPU batch %dx%dx80, CE(ls0.1)+0.3*CTC, "
-                            "Adam+clip10, dropout 0" % (args.arch, args.enc_layers, args.dec_layers, V, args.batch, args.frames),
+                            "Adam+clip10, dropout %.2f" % (args.arch, args.enc_layers, args.dec_layers, V, args.batch, args.frames, args.dropout),
                 "global_batch": args.batch * world, "frames_per_step": frames_global, "parallelism": "dp%d" % world,
                 "hip_graph": use_graph, "final_loss": loss_val,
             },

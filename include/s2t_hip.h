@@ -46,7 +46,7 @@ int s2t_device_cu_count(void);
  * Epilogue, in order (v = fp32 accumulator):
  *   v += bias[n]; [GLU: out column c pairs accumulator columns c (value) and c + N/2 (gate),
  *   v = value*sigmoid(gate), C has N/2 columns]; [preact: store v before the activation];
- *   v = act(v); [dact_z: v *= act'(dact_z[m,n])]; v *= alpha;
+ *   v = act(v); [dact_z: v *= act'(dact_z[m,n])]; [drop_p: inverted dropout, FairseqDropout of fairseq_dropout.py]; v *= alpha;
  *   [row_lens: v = 0 on rows with (global_row % row_T) >= row_lens[global_row / row_T]  (padded frames;
  *    the reference masks the branch output, not the residual: modules/convolution.py:109-116)];
  *   [residual: v += residual[m,n]]; store (c_dtype).   global_row = z*M + m.
@@ -76,6 +76,9 @@ typedef struct s2t_gemm_args {
   int32_t split_k;
   int32_t c_atomic; /* 1: add alpha*acc to fp32 C with atomics even when split_k == 1 (several batches share one C) */
   float* colsum_a;  /* optional, a_kmajor only: colsum_a[m] += alpha * sum_k A_op[m][k]  (bias gradient fused into wgrad) */
+  float drop_p;     /* > 0: v = keep(seed, site, global_row*Nout + n) ? v/(1-p) : 0 after the activation / act' stage */
+  uint32_t drop_site;
+  const uint64_t* drop_seed; /* device pointer (a captured hipGraph replays with a fresh seed) */
 } s2t_gemm_args;
 
 int s2t_gemm(const s2t_gemm_args* args, void* stream);
@@ -105,11 +108,13 @@ int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* 
  * ------------------------------------------------------------------------------------------------ */
 int s2t_attn_softmax_fwd(int p_dtype, const float* S, int64_t ldS, const float* BD, int64_t ldBD, void* P, int64_t ldP,
                          int Z, int H, int Tq, int Tk, float scale, const int32_t* key_lens, int causal, int clamp,
-                         void* stream);
+                         void* Pdrop /* optional: dropout(P), same layout */, float drop_p, const uint64_t* drop_seed,
+                         uint32_t drop_site, void* stream);
 /* dBD rows are laid out HEAD-major ((h*B + b)*Tq + i) so that per head the (b,i) rows form one matrix for the
  * linear_pos weight-gradient GEMM; S/P/dP/dS rows are z-major (z = b*H + h). */
 int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP, int64_t ldDP, void* dS, int64_t ldDS,
-                         void* dBD, int64_t ldDBD, int Z, int H, int Tq, int Tk, float scale, void* stream);
+                         void* dBD, int64_t ldDBD, int Z, int H, int Tq, int Tk, float scale, float drop_p,
+                         const uint64_t* drop_seed, uint32_t drop_site, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / gather pieces of S2TTransformerEncoder.forward and TransformerDecoder
@@ -134,6 +139,10 @@ int s2t_glu_bwd(int dtype, const void* Z, const void* dY, void* dZ, int64_t rows
                 void* stream);
 int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db, int64_t rows, int n, void* stream);
 int s2t_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* out[r, c] = keep(seed, site, r*cols + c) ? x[r, c] / (1-p) : 0   (FairseqDropout, modules/fairseq_dropout.py; the same
+ * call on a gradient is its backward) */
+int s2t_dropout(int dtype, const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int cols, float p,
+                const uint64_t* seed, uint32_t site, void* stream);
 int s2t_axpy(int dtype, const void* a, const void* b, void* y, float alpha, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -43,10 +43,11 @@ class GemmArgs(C.Structure):
         ("split_k", C.c_int32),
         ("c_atomic", C.c_int32),
         ("colsum_a", C.c_void_p),
+        ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("drop_seed", C.c_void_p),
     ]
 
 
-_CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float}
+_CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "uint32_t": C.c_uint32}
 
 
 def header_prototypes(path=HEADER_PATH):

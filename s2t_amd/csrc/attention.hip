@@ -15,7 +15,8 @@ template <typename TP, int NPL>
 __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(
     const float* __restrict__ S, int64_t ldS, const float* __restrict__ BD, int64_t ldBD, TP* __restrict__ P,
     int64_t ldP, int64_t rows_total, int H, int Tq, int Tk, float scale, const int32_t* __restrict__ key_lens,
-    int causal, int clamp) {
+    int causal, int clamp, TP* __restrict__ Pdrop, float drop_p, const uint64_t* __restrict__ drop_seed,
+    uint32_t drop_site) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_total) return;
@@ -52,10 +53,18 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(
   sum = wave_sum(sum);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
   TP* p = P + row * ldP;
+  TP* pd = Pdrop ? Pdrop + row * ldP : nullptr;
+  const uint64_t key = pd ? s2t_drop_key(drop_seed, drop_site) : 0ull;
+  const uint32_t th = s2t_drop_thresh(drop_p);
+  const float dinv = 1.f / (1.f - drop_p);
 #pragma unroll
   for (int k = 0; k < NPL; ++k) {
     const int j = lane + 64 * k;
-    if (j < ldP) st_from_f32<TP>(p + j, j < Tk ? v[k] * inv : 0.f);
+    if (j < ldP) {
+      const float pv = j < Tk ? v[k] * inv : 0.f;
+      st_from_f32<TP>(p + j, pv);
+      if (pd) st_from_f32<TP>(pd + j, (j < Tk && s2t_rand_u32(key, (uint64_t)row * Tk + j) >= th) ? pv * dinv : 0.f);
+    }
   }
 }
 
@@ -65,7 +74,9 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const TP* __restr
                                                                const float* __restrict__ dP, int64_t ldDP,
                                                                TP* __restrict__ dS, int64_t ldDS,
                                                                TP* __restrict__ dBD, int64_t ldDBD,
-                                                               int64_t rows_total, int H, int Tq, int Tk, float scale) {
+                                                               int64_t rows_total, int H, int Tq, int Tk, float scale,
+                                                               float drop_p, const uint64_t* __restrict__ drop_seed,
+                                                               uint32_t drop_site) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_total) return;
@@ -74,11 +85,16 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const TP* __restr
   const float* dp = dP + row * ldDP;
   float pv[NPL], dv[NPL];
   float dot = 0.f;
+  const uint64_t key = drop_p > 0.f ? s2t_drop_key(drop_seed, drop_site) : 0ull;
+  const uint32_t th = s2t_drop_thresh(drop_p);
+  const float dinv = 1.f / (1.f - drop_p);
 #pragma unroll
   for (int k = 0; k < NPL; ++k) {
     const int j = lane + 64 * k;
     pv[k] = j < Tk ? ld_as_f32<TP>(p + j) : 0.f;
     dv[k] = j < Tk ? dp[j] : 0.f;
+    // dP arrives as the gradient of dropout(P): route it through the regenerated mask
+    if (drop_p > 0.f && j < Tk) dv[k] = s2t_rand_u32(key, (uint64_t)row * Tk + j) >= th ? dv[k] * dinv : 0.f;
     dot += pv[k] * dv[k];
   }
   dot = wave_sum(dot);
@@ -118,7 +134,10 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const TP* __restr
 
 extern "C" int s2t_attn_softmax_fwd(int p_dtype, const float* S, int64_t ldS, const float* BD, int64_t ldBD, void* P,
                                     int64_t ldP, int Z, int H, int Tq, int Tk, float scale, const int32_t* key_lens,
-                                    int causal, int clamp, void* stream) {
+                                    int causal, int clamp, void* Pdrop, float drop_p, const uint64_t* drop_seed,
+                                    uint32_t drop_site, void* stream) {
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !Pdrop)) return S2T_ERR_ARG;
+  if (drop_p == 0.f) Pdrop = nullptr;
   if (!S || !P || Z <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
   if (Tk > 3072 || ldP < Tk || ldS < Tk) return S2T_ERR_UNSUPPORTED;
   if (BD && (Tq != Tk || ldBD < 2 * Tq - 1)) return S2T_ERR_ARG;
@@ -127,17 +146,18 @@ extern "C" int s2t_attn_softmax_fwd(int p_dtype, const float* S, int64_t ldS, co
   hipStream_t s = (hipStream_t)stream;
   if (p_dtype == S2T_F32)
     DISPATCH_NPL(float, attn_softmax_fwd_kernel, S, ldS, BD, ldBD, (float*)P, ldP, rows, H, Tq, Tk, scale, key_lens,
-                 causal, clamp);
+                 causal, clamp, (float*)Pdrop, drop_p, drop_seed, drop_site);
   else if (p_dtype == S2T_BF16)
     DISPATCH_NPL(bf16_t, attn_softmax_fwd_kernel, S, ldS, BD, ldBD, (bf16_t*)P, ldP, rows, H, Tq, Tk, scale, key_lens,
-                 causal, clamp);
+                 causal, clamp, (bf16_t*)Pdrop, drop_p, drop_seed, drop_site);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
 
 extern "C" int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP, int64_t ldDP, void* dS,
                                     int64_t ldDS, void* dBD, int64_t ldDBD, int Z, int H, int Tq, int Tk, float scale,
-                                    void* stream) {
+                                    float drop_p, const uint64_t* drop_seed, uint32_t drop_site, void* stream) {
+  if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
   if (!P || !dP || !dS || Z <= 0 || H <= 0 || Z % H || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
   if (Tk > 3072 || ldP < Tk || ldDP < Tk || ldDS < Tk) return S2T_ERR_UNSUPPORTED;
   if (dBD && (Tq != Tk || ldDBD < 2 * Tq - 1)) return S2T_ERR_ARG;
@@ -146,10 +166,10 @@ extern "C" int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
     DISPATCH_NPL(float, attn_softmax_bwd_kernel, (const float*)P, ldP, dP, ldDP, (float*)dS, ldDS, (float*)dBD, ldDBD,
-                 rows, H, Tq, Tk, scale);
+                 rows, H, Tq, Tk, scale, drop_p, drop_seed, drop_site);
   else if (dtype == S2T_BF16)
     DISPATCH_NPL(bf16_t, attn_softmax_bwd_kernel, (const bf16_t*)P, ldP, dP, ldDP, (bf16_t*)dS, ldDS, (bf16_t*)dBD,
-                 ldDBD, rows, H, Tq, Tk, scale);
+                 ldDBD, rows, H, Tq, Tk, scale, drop_p, drop_seed, drop_site);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

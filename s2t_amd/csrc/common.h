@@ -91,5 +91,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Counter-based dropout RNG: keep(seed, site, element index) is a pure function, so the backward pass regenerates
+// the mask instead of storing it.  splitmix64 finaliser over (seed * golden + site) ^ idx.
+__device__ __forceinline__ uint32_t s2t_rand_u32(uint64_t key, uint64_t idx) {
+  uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ uint64_t s2t_drop_key(const uint64_t* seed_ptr, uint32_t site) {
+  const uint64_t seed = seed_ptr ? *seed_ptr : 0ull;
+  return (seed * 0xD1342543DE82EF95ull) ^ ((uint64_t)site * 0xA24BAED4963EE407ull);
+}
+__device__ __forceinline__ uint32_t s2t_drop_thresh(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f); }
+
 static inline int s2t_hip_status(hipError_t e) { return e == hipSuccess ? S2T_OK : (int)e; }
 #define S2T_LAUNCH_CHECK() s2t_hip_status(hipGetLastError())

@@ -59,6 +59,26 @@ __global__ __launch_bounds__(256) void bias_add_rows_kernel(const T* __restrict_
   st4_from_f32<T>(out + row * ldo + c, v);
 }
 
+// ---- inverted dropout on a strided row matrix (mask index = row*cols + col, the GEMM epilogue's convention) ----
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out,
+                                                      int64_t ldo, int64_t rows, int cols, float p,
+                                                      const uint64_t* __restrict__ seed, uint32_t site) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int vpr = cols / 4;
+  if (idx >= rows * vpr) return;
+  const int64_t row = idx / vpr;
+  const int c = (int)(idx % vpr) * 4;
+  const uint64_t key = s2t_drop_key(seed, site);
+  const uint32_t th = s2t_drop_thresh(p);
+  const float inv = 1.f / (1.f - p);
+  float v[4];
+  ld4_as_f32<T>(x + row * ldx + c, v);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = s2t_rand_u32(key, (uint64_t)row * cols + c + r) >= th ? v[r] * inv : 0.f;
+  st4_from_f32<T>(out + row * ldo + c, v);
+}
+
 // ---- decoder embedding: out[n,:] = scale * E[tok[n],:] + tab[pos[n],:]  (models/transformer.py:1304-1323) ----
 template <typename T>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const int32_t* __restrict__ pos,
@@ -262,6 +282,19 @@ extern "C" int s2t_bias_add_rows(int dtype, const void* x, int64_t ldx, const fl
     hipLaunchKernelGGL(bias_add_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, bias, (float*)out, ldo, rows, n);
   else if (dtype == S2T_BF16)
     hipLaunchKernelGGL(bias_add_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, bias, (bf16_t*)out, ldo, rows, n);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_dropout(int dtype, const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int cols, float p,
+                           const uint64_t* seed, uint32_t site, void* stream) {
+  if (!x || !out || rows < 0 || cols <= 0 || cols % 4 || ldx % 4 || ldo % 4 || p < 0.f || p >= 1.f) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  dim3 grid((unsigned)((rows * (cols / 4) + 255) / 256));
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(dropout_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)out, ldo, rows, cols, p, seed, site);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, rows, cols, p, seed, site);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

@@ -295,10 +295,11 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   if ((p.lda % epb) || (p.ldb % epb) || ((uintptr_t)p.A % 16) || ((uintptr_t)p.B % 16)) return S2T_ERR_ALIGN;
   if ((p.a_s0 % epb) || (p.a_s1 % epb) || (p.b_s0 % epb) || (p.b_s1 % epb)) return S2T_ERR_ALIGN;
   if (p.split_k > 1 || p.c_atomic) {
-    if (p.c_dtype != S2T_F32 || p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens)
+    if (p.c_dtype != S2T_F32 || p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens || p.drop_p > 0.f)
       return S2T_ERR_UNSUPPORTED;
   }
   if (p.row_lens && p.row_T <= 0) return S2T_ERR_ARG;
+  if (p.drop_p < 0.f || p.drop_p >= 1.f) return S2T_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (p.dtype == S2T_BF16 && p.K % 64 == 0 && p.K > 0 && use_ring()) {
     const int rc = s2t_gemm_ring_launch(p, stream);

@@ -30,6 +30,66 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
+class _DropoutState:
+    """Seed (device-resident, so a captured hipGraph replays with fresh masks) + a per-step site counter.  Every
+    dropout site of a step gets a unique id at forward time and hands it to its backward, which regenerates the mask."""
+
+    def __init__(self):
+        self.seed = None
+        self.site = 0
+
+    def begin_step(self, device):
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if self.seed is None or self.seed.device != dev:
+            self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.site = 0
+
+    def set_seed(self, value):
+        self.seed.fill_(int(value))
+
+    def next(self, p, device):
+        """(p, seed tensor, site id) for an active site, None when p == 0."""
+        if not p or p <= 0.0:
+            return None
+        if self.seed is None:
+            self.begin_step(device)
+        self.site += 1
+        return (float(p), self.seed, self.site)
+
+
+DROPOUT = _DropoutState()
+
+
+def _drop_rows(x, drop):
+    """x * mask / (1-p) for a [rows, cols] matrix (mask convention of the GEMM epilogue); identity when drop is None."""
+    if drop is None:
+        return x
+    rows, cols = x.shape
+    out = torch.empty(rows, cols, dtype=x.dtype, device=x.device)
+    K.dropout(x, x.stride(0), out, cols, rows, cols, drop)
+    return out
+
+
+class DropoutFn(torch.autograd.Function):
+    """FairseqDropout (modules/fairseq_dropout.py) on a row matrix."""
+
+    @staticmethod
+    def forward(ctx, x, drop):
+        ctx.drop = drop
+        return _drop_rows(x.contiguous(), drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _drop_rows(dy.contiguous(), ctx.drop), None
+
+
+def dropout(x, p, training):
+    drop = DROPOUT.next(p if training else 0.0, x.device)
+    return x if drop is None else DropoutFn.apply(x, drop)
+
+
 def fused(params, rows, cols):
     """[rows, cols] compute-dtype view over adjacent parameters (flat_params adjacency group)."""
     first = cw(params[0])
@@ -149,14 +209,16 @@ class FFNFn(torch.autograd.Function):
     decoder FFN modules/transformer_layer.py:520-530)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act, alpha, residual, train):
+    def forward(ctx, x, w1, b1, w2, b2, act, alpha, residual, train, drop_h, drop_o):
         M, d = x.shape
         F_ = w1.shape[0]
         h = torch.empty(M, F_, dtype=x.dtype, device=x.device)
         z = torch.empty(M, F_, dtype=x.dtype, device=x.device) if train else None
-        K.gemm(x, cw(w1), h, M=M, N=F_, K=d, lda=d, ldb=d, ldc=F_, bias=b1.data, act=act, preact=z, ldp=F_)
+        K.gemm(x, cw(w1), h, M=M, N=F_, K=d, lda=d, ldb=d, ldc=F_, bias=b1.data, act=act, preact=z, ldp=F_, drop=drop_h)
         y = torch.empty(M, d, dtype=x.dtype, device=x.device)
-        K.gemm(h, cw(w2), y, M=M, N=d, K=F_, lda=F_, ldb=F_, ldc=d, bias=b2.data, alpha=alpha, residual=residual, ldr=d)
+        K.gemm(h, cw(w2), y, M=M, N=d, K=F_, lda=F_, ldb=F_, ldc=d, bias=b2.data, alpha=alpha, residual=residual, ldr=d,
+               drop=drop_o)
+        ctx.drops = (drop_h, drop_o)
         if train:
             ctx.save_for_backward(x, z, h)
         ctx.p = (w1, b1, w2, b2)
@@ -169,22 +231,26 @@ class FFNFn(torch.autograd.Function):
         w1, b1, w2, b2 = ctx.p
         M, d = x.shape
         F_ = w1.shape[0]
-        dy = dy.contiguous()
-        # dZ = alpha * (dY @ W2) * act'(Z)
+        dres = dy.contiguous()
+        drop_h, drop_o = ctx.drops
+        dy = _drop_rows(dres, drop_o)  # gradient of the branch behind the output dropout
+        # dZ = alpha * dropout_h(dY @ W2) * act'(Z)
         dz = torch.empty(M, F_, dtype=x.dtype, device=x.device)
         K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
-               dact=ctx.act)
+               dact=ctx.act, drop=drop_h)
         _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad)
         _ready(w2, b2)
         _wgrad(dz, x, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)
         dx = torch.empty_like(x)
         K.gemm(dz, cw(w1), dx, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
         _ready(w1, b1)
-        return dx, None, None, None, None, None, None, dy, None
+        return dx, None, None, None, None, None, None, dres, None, None, None
 
 
-def ffn(x, w1, b1, w2, b2, act, alpha, residual):
-    return FFNFn.apply(x, w1, b1, w2, b2, act, alpha, residual, torch.is_grad_enabled())
+def ffn(x, w1, b1, w2, b2, act, alpha, residual, p_hidden=0.0, p_out=0.0, training=False):
+    drop_h = DROPOUT.next(p_hidden if training else 0.0, x.device)
+    drop_o = DROPOUT.next(p_out if training else 0.0, x.device)
+    return FFNFn.apply(x, w1, b1, w2, b2, act, alpha, residual, torch.is_grad_enabled(), drop_h, drop_o)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -201,7 +267,7 @@ class AttentionFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, train):
+    def forward(ctx, xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, train, drop_a, drop_o):
         d = xq.shape[1]
         dk = d // H
         dt = xq.dtype
@@ -251,28 +317,35 @@ class AttentionFn(torch.autograd.Function):
                    b_s=(Tk * ldk, dk), c_s=(H * Tq * ldS, Tq * ldS))
             scale = dk ** -0.5
         P = torch.empty(Z, Tq, ldS, dtype=dt, device=dev)
-        K.attn_softmax_fwd(S, ldS, BD, ldB, P, ldS, Z, H, Tq, Tk, scale, key_lens, causal, kind == "rel")
+        Pd = torch.empty(Z, Tq, ldS, dtype=dt, device=dev) if drop_a is not None else None
+        K.attn_softmax_fwd(S, ldS, BD, ldB, P, ldS, Z, H, Tq, Tk, scale, key_lens, causal, kind == "rel", Pd, drop_a)
         del S, BD
+        Pv = Pd if Pd is not None else P  # probabilities that multiply V (dropout applied)
         O = torch.empty(Mq, d, dtype=dt, device=dev)
-        K.gemm(P, v, O, M=Tq, N=dk, K=Tk, lda=ldS, ldb=ldk, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
+        K.gemm(Pv, v, O, M=Tq, N=dk, K=Tk, lda=ldS, ldb=ldk, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
                a_s=(H * Tq * ldS, Tq * ldS), b_s=(Tk * ldk, dk), c_s=(Tq * d, dk))
         y = torch.empty(Mq, d, dtype=dt, device=dev)
-        K.gemm(O, cw(prm["o_w"]), y, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual, ldr=d)
+        K.gemm(O, cw(prm["o_w"]), y, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual, ldr=d,
+               drop=drop_o)
+        ctx.drops = (drop_a, drop_o)
         if train:
-            ctx.save_for_backward(xq, xkv, q, k, v, P, O, qu, qv, p, pos_tab)
+            ctx.save_for_backward(xq, xkv, q, k, v, P, O, qu, qv, p, pos_tab, Pd)
         ctx.prm, ctx.dims = prm, (H, B, Tq, Tk, d, dk, ldq, ldk, ldS, ldB, scale)
         ctx.kind, ctx.self_attn, ctx.has_res = kind, self_attn, residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xq, xkv, q, k, v, P, O, qu, qv, p, pos_tab = ctx.saved_tensors
+        xq, xkv, q, k, v, P, O, qu, qv, p, pos_tab, Pd = ctx.saved_tensors
         prm = ctx.prm
         H, B, Tq, Tk, d, dk, ldq, ldk, ldS, ldB, scale = ctx.dims
         dt, dev = xq.dtype, xq.device
         Mq, Mk = B * Tq, B * Tk
         Z = B * H
-        dy = dy.contiguous()
+        drop_a, drop_o = ctx.drops
+        dres = dy.contiguous()
+        dy = _drop_rows(dres, drop_o)
+        Pv = Pd if Pd is not None else P
         # out_proj
         dO = torch.empty(Mq, d, dtype=dt, device=dev)
         K.gemm(dy, cw(prm["o_w"]), dO, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
@@ -290,11 +363,11 @@ class AttentionFn(torch.autograd.Function):
         dP = torch.empty(Z, Tq, ldS, dtype=torch.float32, device=dev)
         K.gemm(dO, v, dP, M=Tq, N=Tk, K=dk, lda=d, ldb=ldk, ldc=ldS, batch=Z, zdiv=H, a_s=(Tq * d, dk),
                b_s=(Tk * ldk, dk), c_s=(H * Tq * ldS, Tq * ldS))
-        K.gemm(P, dO, dv, M=Tk, N=dk, K=Tq, lda=ldS, ldb=d, ldc=ldk, a_kmajor=True, b_kmajor=True, batch=Z, zdiv=H,
+        K.gemm(Pv, dO, dv, M=Tk, N=dk, K=Tq, lda=ldS, ldb=d, ldc=ldk, a_kmajor=True, b_kmajor=True, batch=Z, zdiv=H,
                a_s=(H * Tq * ldS, Tq * ldS), b_s=(Tq * d, dk), c_s=(Tk * ldk, dk))
         dS = torch.empty(Z, Tq, ldS, dtype=dt, device=dev)
         dBD = torch.empty(H, B, Tq, ldB, dtype=dt, device=dev) if ctx.kind == "rel" else None
-        K.attn_softmax_bwd(P, ldS, dP, ldS, dS, ldS, dBD, ldB, Z, H, Tq, Tk, scale)
+        K.attn_softmax_bwd(P, ldS, dP, ldS, dS, ldS, dBD, ldB, Z, H, Tq, Tk, scale, drop_a)
         del dP
         qa = qu if ctx.kind == "rel" else q  # the matrix that multiplied K^T in the forward
         lda_q = d if ctx.kind == "rel" else ldq
@@ -344,12 +417,15 @@ class AttentionFn(torch.autograd.Function):
             dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
             K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
-        return dxq, dxkv, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None, None, None
+        return dxq, dxkv, (dres if ctx.has_res else None), None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False, kind="abs", pos_tab=None):
+def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False, kind="abs", pos_tab=None,
+              p_attn=0.0, p_out=0.0, training=False):
+    drop_a = DROPOUT.next(p_attn if training else 0.0, xq.device)
+    drop_o = DROPOUT.next(p_out if training else 0.0, xq.device)
     return AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
-                             torch.is_grad_enabled())
+                             torch.is_grad_enabled(), drop_a, drop_o)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -360,7 +436,7 @@ class ConvModuleFn(torch.autograd.Function):
     ``x`` is the conv_norm output with padded frames already zeroed (LayerNormFn with lens)."""
 
     @staticmethod
-    def forward(ctx, x, residual, prm, bn_buf, act, B, T, lens, training, momentum, train):
+    def forward(ctx, x, residual, prm, bn_buf, act, B, T, lens, training, momentum, train, drop_o):
         M, d = x.shape
         dt, dev = x.dtype, x.device
         Kw = prm["dw_w"].shape[-1]
@@ -388,7 +464,8 @@ class ConvModuleFn(torch.autograd.Function):
             K.dwconv_fwd(g, wd, a, B, T, d, Kw, scale=scale, shift=shift, act=act, lens=lens)
         y = torch.empty(M, d, dtype=dt, device=dev)
         K.gemm(a, cw(prm["pw2_w"]).view(d, d), y, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, residual=residual, ldr=d,
-               row_lens=lens, row_T=T)
+               row_lens=lens, row_T=T, drop=drop_o)
+        ctx.drop_o = drop_o
         if train:
             assert training, "gradients through the convolution module need training-mode BatchNorm"
             ctx.save_for_backward(x, z, g, D, a, scale, shift, mean, rstd)
@@ -402,7 +479,8 @@ class ConvModuleFn(torch.autograd.Function):
         B, T, d, Kw = ctx.dims
         M = B * T
         dt, dev = x.dtype, x.device
-        dy = dy.contiguous()
+        dres = dy.contiguous()
+        dy = _drop_rows(dres, ctx.drop_o)
         # pw2 (a's padded rows are zero, so the weight gradient needs no extra mask; dA's are zeroed in bn_act_bwd)
         dA = torch.empty(M, d, dtype=dt, device=dev)
         K.gemm(dy, cw(prm["pw2_w"]).view(d, d), dA, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
@@ -423,11 +501,13 @@ class ConvModuleFn(torch.autograd.Function):
         dx = torch.empty(M, d, dtype=dt, device=dev)
         K.gemm(dZ, cw(prm["pw1_w"]).view(2 * d, d), dx, M=M, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["pw1_w"], prm["dw_w"], prm["bn_w"], prm["bn_b"], prm["pw2_w"])
-        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None, None
+        return dx, (dres if ctx.has_res else None), None, None, None, None, None, None, None, None, None, None
 
 
-def conv_module(x, residual, prm, bn_buf, act, B, T, lens, training, momentum=0.1):
-    return ConvModuleFn.apply(x, residual, prm, bn_buf, act, B, T, lens, training, momentum, torch.is_grad_enabled())
+def conv_module(x, residual, prm, bn_buf, act, B, T, lens, training, momentum=0.1, p_out=0.0):
+    drop_o = DROPOUT.next(p_out if training else 0.0, x.device)
+    return ConvModuleFn.apply(x, residual, prm, bn_buf, act, B, T, lens, training, momentum, torch.is_grad_enabled(),
+                              drop_o)
 
 
 # ------------------------------------------------------------------------------------------------

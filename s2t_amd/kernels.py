@@ -31,7 +31,7 @@ def gemm(
     preact: Optional[torch.Tensor] = None, ldp=0, p_s=(0, 0),
     dact_z: Optional[torch.Tensor] = None, ldz=0, dact=None,
     row_lens: Optional[torch.Tensor] = None, row_T=0, split_k=1, c_atomic=False,
-    colsum_a: Optional[torch.Tensor] = None,
+    colsum_a: Optional[torch.Tensor] = None, drop=None,
 ):
     """Raw s2t_gemm call: C = epilogue(A_op[M,K] @ B_op[K,N]); see include/s2t_hip.h."""
     L.require_cuda(A, B, out, bias, residual, preact, dact_z, row_lens)
@@ -68,6 +68,8 @@ def gemm(
     a.split_k = split_k
     a.c_atomic = int(c_atomic)
     a.colsum_a = _ptr(colsum_a)
+    if drop is not None and drop[0] > 0:  # (p, seed tensor (int64 on device), site)
+        a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), drop[1].data_ptr(), int(drop[2])
     if colsum_a is not None:
         assert colsum_a.dtype == torch.float32 and a_kmajor
     if GEMM_PROFILE is not None:
@@ -118,16 +120,30 @@ def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_l
           _ptr(row_lens), row_T)
 
 
-def attn_softmax_fwd(S, ldS, BD, ldBD, P, ldP, Z, H, Tq, Tk, scale, key_lens=None, causal=False, clamp=False):
+def _drop3(drop):
+    if drop is None or drop[0] <= 0:
+        return 0.0, None, 0
+    return float(drop[0]), drop[1].data_ptr(), int(drop[2])
+
+
+def attn_softmax_fwd(S, ldS, BD, ldBD, P, ldP, Z, H, Tq, Tk, scale, key_lens=None, causal=False, clamp=False,
+                     Pdrop=None, drop=None):
     assert S.dtype == torch.float32 and (BD is None or BD.dtype == torch.float32)
+    dp, ds, dsite = _drop3(drop)
     _call("s2t_attn_softmax_fwd", L.dtype_id(P.dtype), S.data_ptr(), ldS, _ptr(BD), ldBD, P.data_ptr(), ldP, Z, H, Tq,
-          Tk, scale, _ptr(key_lens), int(causal), int(clamp))
+          Tk, scale, _ptr(key_lens), int(causal), int(clamp), _ptr(Pdrop), dp, ds, dsite)
 
 
-def attn_softmax_bwd(P, ldP, dP, ldDP, dS, ldDS, dBD, ldDBD, Z, H, Tq, Tk, scale):
+def attn_softmax_bwd(P, ldP, dP, ldDP, dS, ldDS, dBD, ldDBD, Z, H, Tq, Tk, scale, drop=None):
     assert dP.dtype == torch.float32
+    dp, ds, dsite = _drop3(drop)
     _call("s2t_attn_softmax_bwd", L.dtype_id(P.dtype), P.data_ptr(), ldP, dP.data_ptr(), ldDP, dS.data_ptr(), ldDS,
-          _ptr(dBD), ldDBD, Z, H, Tq, Tk, scale)
+          _ptr(dBD), ldDBD, Z, H, Tq, Tk, scale, dp, ds, dsite)
+
+
+def dropout(x, ldx, out, ldo, rows, cols, drop):
+    dp, ds, dsite = _drop3(drop)
+    _call("s2t_dropout", L.dtype_id(x.dtype), x.data_ptr(), ldx, out.data_ptr(), ldo, rows, cols, dp, ds, dsite)
 
 
 def bias_add_rows(x, ldx, bias, out, ldo, rows, n):

@@ -115,17 +115,11 @@ class FeedForwardModule(nn.Module):
         self.w_1 = Linear(input_feat, hidden_units)
         self.w_2 = Linear(hidden_units, input_feat)
         self.activation_fn = activation_fn
-        if dropout1 or dropout2:
-            _no_dropout()
+        self.dropout1, self.dropout2 = float(dropout1 or 0.0), float(dropout2 or 0.0)
 
     def forward(self, x_ln, residual, scale):
         return Fn.ffn(x_ln, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, self.activation_fn, scale,
-                      residual)
-
-
-def _no_dropout():
-    raise NotImplementedError(
-        "dropout > 0 is not built yet on the HIP path (parity runs use p = 0, SURVEY.md §8b); set the dropout flags to 0")
+                      residual, self.dropout1, self.dropout2, self.training)
 
 
 class MultiheadAttention(nn.Module):
@@ -136,8 +130,8 @@ class MultiheadAttention(nn.Module):
         super().__init__()
         self.embed_dim, self.num_heads = embed_dim, num_heads
         self.self_attention, self.encoder_decoder_attention = self_attention, encoder_decoder_attention
-        if dropout:
-            _no_dropout()
+        self.attn_dropout = float(dropout or 0.0)  # on the probabilities (multihead_attention.py:411-413)
+        self.out_dropout = 0.0                     # the owning layer's dropout_module on the branch output
         self.k_proj = Linear(embed_dim, embed_dim)
         self.v_proj = Linear(embed_dim, embed_dim)
         self.q_proj = Linear(embed_dim, embed_dim)
@@ -156,7 +150,8 @@ class MultiheadAttention(nn.Module):
                 "v_w": self.v_proj.weight, "v_b": self.v_proj.bias, "o_w": self.out_proj.weight, "o_b": self.out_proj.bias}
 
     def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False):
-        return Fn.attention(xq, xkv, residual, self._prm(), self.num_heads, B, Tq, Tk, key_lens, causal, "abs", None)
+        return Fn.attention(xq, xkv, residual, self._prm(), self.num_heads, B, Tq, Tk, key_lens, causal, "abs", None,
+                            self.attn_dropout, self.out_dropout, self.training)
 
 
 class RelPositionMultiHeadedAttention(nn.Module):
@@ -165,8 +160,8 @@ class RelPositionMultiHeadedAttention(nn.Module):
     def __init__(self, n_feat, n_head, dropout, zero_triu=False):
         super().__init__()
         self.h, self.d_k = n_head, n_feat // n_head
-        if dropout:
-            _no_dropout()
+        self.attn_dropout = float(dropout or 0.0)  # espnet_multihead_attention.py:41,147
+        self.out_dropout = 0.0
         if zero_triu:
             raise NotImplementedError("zero_triu")
         self.linear_q = Linear(n_feat, n_feat)
@@ -190,7 +185,8 @@ class RelPositionMultiHeadedAttention(nn.Module):
                 "pos_u": self.pos_bias_u, "pos_v": self.pos_bias_v}
 
     def forward(self, x, residual, B, T, key_lens, pos_tab):
-        return Fn.attention(x, None, residual, self._prm(), self.h, B, T, T, key_lens, False, "rel", pos_tab)
+        return Fn.attention(x, None, residual, self._prm(), self.h, B, T, T, key_lens, False, "rel", pos_tab,
+                            self.attn_dropout, self.out_dropout, self.training)
 
 
 class _BatchNorm1d(nn.Module):
@@ -221,8 +217,7 @@ class ConvolutionModule(nn.Module):
         super().__init__()
         if bias or stride != 1 or padding is not None or norm_type != "batch_norm" or embed_dim != expand_embed_dim:
             raise NotImplementedError("HIP conv module covers the recipes' configuration (batch_norm, no bias, stride 1)")
-        if dropout:
-            _no_dropout()
+        self.dropout_p = float(dropout or 0.0)
         d, k = embed_dim, depthwise_kernel_size
         self.pointwise_conv1 = _ConvW((2 * d, d, 1), d)
         self.depthwise_conv = _ConvW((d, 1, k), k)
@@ -237,7 +232,7 @@ class ConvolutionModule(nn.Module):
         if self.training:
             self.norm.num_batches_tracked += 1
         return Fn.conv_module(x_ln_masked, residual, prm, buf, self.activation_fn, B, T, lens, self.training,
-                              self.norm.momentum)
+                              self.norm.momentum, self.dropout_p)
 
 
 class S2TTransformerEncoderLayer(nn.Module):
@@ -257,6 +252,7 @@ class S2TTransformerEncoderLayer(nn.Module):
             self.self_attn = RelPositionMultiHeadedAttention(d, heads, dropout=args.dropout)
         else:
             raise NotImplementedError("encoder attention type %s (HIP path: selfattn, rel_pos)" % self.attn_type)
+        self.self_attn.out_dropout = float(args.dropout or 0.0)  # dropout_module(x) before the residual (:291)
         self.self_attn_layer_norm = LayerNorm(d)
         act = getattr(args, "encoder_activation_fn", "relu")
         if args.macaron_style:
@@ -326,8 +322,7 @@ class CTC(nn.Module):
 
     def __init__(self, embed_dim, dictionary_size, dropout, need_layernorm=False, dictionary=None):
         super().__init__()
-        if dropout:
-            _no_dropout()
+        self.dropout_p = float(dropout or 0.0)
         self.ctc_projection = Linear(embed_dim, dictionary_size)
         nn.init.normal_(self.ctc_projection.weight, mean=0, std=embed_dim ** -0.5)
         nn.init.constant_(self.ctc_projection.bias, 0.0)
@@ -342,6 +337,7 @@ class CTC(nn.Module):
     def forward(self, x2d, out_dtype=None):
         if self.LayerNorm is not None:
             x2d = self.LayerNorm(x2d)
+        x2d = Fn.dropout(x2d, self.dropout_p, self.training)  # ctc_dropout_module (ctc.py:59)
         return self.ctc_projection(x2d, out_dtype=out_dtype)
 
 
@@ -363,14 +359,17 @@ class TransformerDecoderLayer(nn.Module):
         self.fc2 = Linear(args.decoder_ffn_embed_dim, d)
         self.final_layer_norm = LayerNorm(d)
         self.activation_fn = getattr(args, "activation_fn", "relu")
-        if args.dropout or getattr(args, "activation_dropout", 0):
-            _no_dropout()
+        # transformer_layer.py:271-280: dropout_module on every branch output, activation_dropout after fc1's activation
+        self.dropout_p = float(args.dropout or 0.0)
+        self.activation_dropout_p = float(getattr(args, "activation_dropout", 0) or 0.0)
+        self.self_attn.out_dropout = self.dropout_p
+        self.encoder_attn.out_dropout = self.dropout_p
 
     def forward(self, x, mem, B, U, Tm, self_lens, mem_lens):
         x = self.self_attn(self.self_attn_layer_norm(x), None, x, B, U, U, self_lens, causal=True)
         x = self.encoder_attn(self.encoder_attn_layer_norm(x), mem, x, B, U, Tm, mem_lens)
         return Fn.ffn(self.final_layer_norm(x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                      self.activation_fn, 1.0, x)
+                      self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -53,8 +53,8 @@ class PDSS2TTransformerEncoder(nn.Module):
         super().__init__()
         _unsupported(args, inter_mixup=False, pds_fusion=False, inter_ctc_layers=None, inter_xctc_layers=None, xctc_weight=0,
                      pds_final_layers=0)
-        if args.dropout or getattr(args, "pds_dropout", 0):
-            raise NotImplementedError("dropout > 0 on the HIP path")
+        self.dropout_p = float(args.dropout or 0.0)
+        self.pds_dropout_p = float(getattr(args, "pds_dropout", args.dropout) or 0.0)
         self.args = args
         self.pds_stages = int(args.pds_stages)
         self.pds_layers = _ints(args.pds_layers)
@@ -122,6 +122,7 @@ class PDSS2TTransformerEncoder(nn.Module):
                 else:
                     tab = TABLES.get("sin", max(self.max_positions(), Tn) + 2, d, x.device)
                     x = AddPositions.apply(x, tab, lens32, Tn, 1.0)
+            x = Fn.dropout(x, self.dropout_p if i == 0 else self.pds_dropout_p, self.training)  # :1118-1121
             for layer in getattr(self, f"stage{i + 1}"):
                 x = layer(x, c, mask_output=False)
         if self.layer_norm is not None:

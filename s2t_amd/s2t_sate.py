@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from .modules import TABLES, LayerNorm, Linear, MultiheadAttention, _no_dropout
+from .modules import TABLES, LayerNorm, Linear, MultiheadAttention
 from .registry import register_model, register_model_architecture
 from .s2t_transformer import (AddPositions, Embedding, S2TTransformerEncoder, S2TTransformerModel,
                               TransformerDecoderScriptable, _d, _SinPosHolder, _unsupported,
@@ -45,9 +45,11 @@ class TransformerEncoderLayer(nn.Module):
         d = args.encoder_embed_dim
         if not args.encoder_normalize_before:
             raise NotImplementedError("post-LN textual encoder layers")
-        if args.dropout or getattr(args, "attention_dropout", 0) or getattr(args, "activation_dropout", 0):
-            _no_dropout()
-        self.self_attn = MultiheadAttention(d, args.encoder_attention_heads, self_attention=True)
+        self.dropout_p = float(args.dropout or 0.0)
+        self.activation_dropout_p = float(getattr(args, "activation_dropout", 0) or 0.0)
+        self.self_attn = MultiheadAttention(d, args.encoder_attention_heads, dropout=getattr(args, "attention_dropout", 0.0),
+                                            self_attention=True)
+        self.self_attn.out_dropout = self.dropout_p
         self.self_attn_layer_norm = LayerNorm(d)
         self.fc1 = Linear(d, args.encoder_ffn_embed_dim)
         self.fc2 = Linear(args.encoder_ffn_embed_dim, d)
@@ -57,7 +59,7 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, x, B, T, lens):
         x = self.self_attn(self.self_attn_layer_norm(x), None, x, B, T, T, lens)
         return Fn.ffn(self.final_layer_norm(x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                      self.activation_fn, 1.0, x)
+                      self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
 
 
 class TextualEncoder(nn.Module):
@@ -79,12 +81,14 @@ class TextualEncoder(nn.Module):
         self.layers = nn.ModuleList([TransformerEncoderLayer(args) for _ in range(args.text_encoder_layers)])
         self.layer_norm = LayerNorm(d) if args.encoder_normalize_before else None
         self.max_pos = getattr(args, "max_source_positions", 6000)
+        self.dropout_p = float(args.dropout or 0.0)
 
     def forward(self, x, B, T, lens32):
         if self.embed_ln is not None:
             x = self.embed_ln(x)
         tab = TABLES.get("sin", max(self.max_pos, T) + 2, self.embed_dim, x.device)
         x = AddPositions.apply(x, tab, lens32, T, self.embed_scale)
+        x = Fn.dropout(x, self.dropout_p, self.training)  # dropout_module (s2t_sate.py:650)
         for layer in self.layers:
             x = layer(x, B, T, lens32)
         if self.layer_norm is not None:

@@ -51,8 +51,7 @@ class S2TTransformerEncoder(nn.Module):
         self.embed_dim = d
         self.padding_idx = 1
         self.embed_scale = 1.0 if args.encoder_no_scale_embedding else math.sqrt(d)
-        if args.dropout:
-            raise NotImplementedError("dropout > 0 on the HIP path (parity runs use p = 0)")
+        self.dropout_p = float(args.dropout or 0.0)
         filters = [args.subsampling_filter] * (args.subsampling_layers - 1) + [d]
         self.subsample = Conv1dSubsampling(args.subsampling_layers, args.input_feat_per_channel * args.input_channels,
                                            filters, args.subsampling_kernel, args.subsampling_stride,
@@ -119,6 +118,7 @@ class S2TTransformerEncoder(nn.Module):
         else:
             tab = TABLES.get("sin", max(self.max_positions(), Tp) + 2, d, x.device)
             x = AddPositions.apply(x, tab, lens32, Tp, self.embed_scale)  # :1773-1787
+        x = Fn.dropout(x, self.dropout_p, self.training)  # dropout_module (:1794)
         if self.layer_padding_mask:
             x = MaskRows.apply(x, lens32, Tp)  # layer 0's masked_fill (:1828-1836); later layers: fused in final_norm
         n = len(self.layers)
@@ -231,6 +231,7 @@ class TransformerDecoderScriptable(nn.Module):
         tab = TABLES.get("sin", self.max_positions() + self.padding_idx + 1, d, dev)
         x = Fn.embedding(prev_output_tokens.contiguous(), pos.contiguous(), self.embed_tokens.weight, tab,
                          self.embed_scale, self.padding_idx)
+        x = Fn.dropout(x, float(self.args.dropout or 0.0), self.training)  # dropout_module (transformer.py:1328)
         # key-padding of the target side: pads sit at the end for left-aligned targets; general masks
         # (pads in the middle) would need a mask tensor, the collater never produces them
         self_lens = nonpad.sum(1).to(torch.int32)
@@ -500,7 +501,8 @@ def s2t_ctc_s(args):
 
 def recipe_args(conformer=False, **over):
     """Namespace equal to the reference's YAML stack base.yaml + ctc.yaml (+ conformer.yaml)
-    (egs/mustc/asr/conf/*.yaml) with dropout forced to 0 (not built yet on the HIP path)."""
+    (egs/mustc/asr/conf/*.yaml); dropout defaults to 0 here (parity runs), pass dropout=0.1, attention_dropout=0.1,
+    activation_dropout=0.1 for the recipe values."""
     a = Namespace(
         arch="s2t_transformer_s", share_decoder_input_output_embed=True, encoder_embed_norm=True,
         encoder_no_scale_embedding=True, subsampling_type="conv1d", subsampling_layers=2, subsampling_filter=1024,

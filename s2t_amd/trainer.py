@@ -12,6 +12,7 @@ import math
 import torch
 import torch.distributed as dist
 
+from . import functional as Fn
 from . import kernels as K
 
 
@@ -50,6 +51,10 @@ class Trainer:
 
     # ---- one update ----------------------------------------------------------------------------------
     def _step_body(self, sample, sample_size_global):
+        # dropout masks are a function of (seed, site, element): the device-resident seed advances once per update
+        # (trainer.py:1093-1097 seeds every step with seed + num_updates), sites restart at 0
+        Fn.DROPOUT.begin_step(self.flat.master.device)
+        Fn.DROPOUT.seed.add_(1)
         self.flat.zero_grad()
         if self.ddp is not None:
             self.ddp.begin_backward()
