@@ -117,6 +117,27 @@ int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP,
                          const uint64_t* drop_seed, uint32_t drop_site, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused (flash-style) attention, bf16, head dim 64: O = softmax(mask(scale * (Q K^T [+ rel-shift((Q+v) P^T)]))) V with the
+ * score matrix kept on chip (same reference lines as above).  q/k/v/o element (b, t, h, c) at X[b*X_sb + t*X_sr + h*64 + c].
+ * pos_p != NULL selects the relative-position form: Q+pos_u multiplies K, Q+pos_v multiplies pos_p[n][h*64 + c] with
+ * n = Tq-1-i+j.  lse[(b*H+h)*Tq + i] = log-sum-exp of the scaled, masked scores (for the backward).  Dropout is applied to
+ * the probabilities that multiply V (mask index ((b*H+h)*Tq + i)*Tk + j, as in s2t_attn_softmax_fwd).
+ * Backward: delta[z][i] = sum_c dO*O; dq/dk/dv in the layouts of q/k/v; for the relative form dq receives only the
+ * (Q+u) K^T part and `dbd` ([H][B][Tq][ldb], row n = Tq-1-i+j) receives the skewed dS for the position projections.
+ * ------------------------------------------------------------------------------------------------ */
+int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
+                       int64_t v_sb, int64_t v_sr, void* o, int64_t o_sb, int64_t o_sr, float* lse, int B, int H, int Tq,
+                       int Tk, int dk, const int32_t* key_lens, int causal, float scale, const void* pos_p, int64_t p_sr,
+                       const float* pos_u, const float* pos_v, float drop_p, const uint64_t* drop_seed,
+                       uint32_t drop_site, void* stream);
+int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
+                       int64_t v_sb, int64_t v_sr, const void* o, const void* dO, int64_t o_sb, int64_t o_sr,
+                       const float* lse, float* delta, void* dq, void* dk, void* dv, void* dbd, int64_t ldb, int B, int H,
+                       int Tq, int Tk, int dk_dim, const int32_t* key_lens, int causal, float scale, const void* pos_p,
+                       int64_t p_sr, const float* pos_u, const float* pos_v, float drop_p, const uint64_t* drop_seed,
+                       uint32_t drop_site, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Elementwise / gather pieces of S2TTransformerEncoder.forward and TransformerDecoder
  *   s2t_add_positions : x = scale*x + (t < lens[b] ? tab[t+pos_offset] : 0)       s2t_transformer.py:1773-1787
  *   s2t_mask_rows     : zero padded frames in place                                s2t_transformer.py:1765,1828-1836

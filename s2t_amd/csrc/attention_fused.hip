@@ -1,0 +1,671 @@
+// Fused (flash-style) multi-head attention for gfx950, bf16 storage / fp32 softmax, head dim 64.
+//
+// Replaces, for the bf16 path, the GEMM-composed attention (batched QK^T GEMM -> softmax kernel -> batched PV GEMM,
+// functional.AttentionFn) whose fp32 score tensors [B*h, T, T] dominated its cost: scores never leave the chip.
+//   modules/multihead_attention.py:161-431          kind "abs": scores = (q*dk^-.5) k^T, key-pad / causal -> -inf
+//   modules/espnet_multihead_attention.py:313-356   kind "rel": scores = ((q+u) k^T + (q+v) p[T-1-i+j]^T) / sqrt(dk),
+//                                                   key-pad -> -inf, clamp(+-1e8), fp32 softmax
+//
+// Work decomposition: workgroup = 4 waves = 64 query rows of one (utterance, head); wave = 16 query rows; the key axis
+// is walked in blocks of 64 keys staged in LDS (K and V images share one layout: 128-byte rows, 16-byte chunk c of row r
+// at r*128 + ((c ^ (r&7))<<4); K is read row-wise with ds_read_b128, V column-wise with ds_read_b64_tr_b16 — both
+// conflict-free).  All products are "swapped" MFMAs (16x16x32 bf16) producing S^T / O^T tiles, so that a lane owns ONE
+// query row (lane&15) and the softmax statistics, the dropout mask, the O rescale and the P -> PV operand hand-over are
+// lane-local (P's accumulator registers ARE the B-operand fragments of the PV product, k-order permuted consistently
+// with the V fragments).
+//
+// Relative positions: bd[i][j] = (q_i+v) . p[T-1-i+j].  Per (16 queries x 64 keys) the 79 needed rows of p form a
+// contiguous band; BD^T[n][q] for the band is produced by 10 MFMAs and re-indexed (the reference's rel_shift) through a
+// small wave-private LDS scratch: element (q, key) reads band row 15 - q_local + key_local.
+#include "common.h"
+
+namespace {
+
+constexpr int DK = 64;      // head dimension
+constexpr int KB = 64;      // keys per block
+constexpr int SC = 20;      // scratch row stride (floats) for the rel-shift band
+constexpr int BAND = 80;    // band rows per (16 q x 64 keys)
+
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+
+struct FusedArgs {
+  const bf16_t *q, *k, *v;
+  int64_t q_sb, q_sr, k_sb, k_sr, v_sb, v_sr;
+  bf16_t* o;
+  int64_t o_sb, o_sr;
+  float* lse;  // [Z][Tq]
+  int B, H, Tq, Tk;
+  const int32_t* key_lens;
+  int causal;
+  float scale;
+  int rel;
+  const bf16_t* pos_p;  // [2Tq-1][p_sr], head offset h*DK
+  int64_t p_sr;
+  const float *pos_u, *pos_v;  // [H*DK]
+  float drop_p;
+  const uint64_t* drop_seed;
+  uint32_t drop_site;
+  // backward
+  const bf16_t* dO;  // layout of o
+  const float* delta;  // [Z][Tq] rowsum(dO * O)
+  bf16_t *dq, *dk, *dv;  // layouts of q, k, v
+  bf16_t* dbd;           // [H][B][Tq][ldb] (rel): skewed dS for the position projections, may be null
+  int64_t ldb;
+};
+
+__device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+__device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// add a per-column fp32 bias to 8 bf16 values (q + pos_bias_u / q + pos_bias_v), round to bf16
+__device__ __forceinline__ uint4 add_bias8(uint4 qv, const float* __restrict__ bias) {
+  const uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float a = __uint_as_float(w[t] << 16) + bias[2 * t];
+    const float b = __uint_as_float(w[t] & 0xffff0000u) + bias[2 * t + 1];
+    o[t] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// stage a 64-row x 64-col bf16 tile (rows row0.., zero beyond nrows) into the shared K/V image
+__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* __restrict__ base, int64_t sr, int row0, int nrows,
+                                           int tid) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = tid + 256 * u;
+    const int r = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + r < nrows) v = ldg16(base + (int64_t)(row0 + r) * sr + ch * 8);
+    *reinterpret_cast<uint4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = v;
+  }
+}
+
+// row-wise fragment (A operand, rows = tile rows): 8 consecutive k of row (blk*16 + x), k-step ks
+__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int blk, int ks, int x, int y) {
+  const int r = blk * 16 + x;
+  const int c = ks * 4 + y;
+  return as_frag(*reinterpret_cast<const uint4*>(lds + r * 128 + ((c ^ (r & 7)) << 4)));
+}
+
+// column-wise fragment (A operand = tile^T): rows of the product = tile columns (cblk*16 + x), k = tile rows in the
+// permuted order kappa(y, j) = 32*s + 16*(j>>2) + 4*y + (j&3)  (matches P's accumulator registers)
+__device__ __forceinline__ bf16x8 frag_cols_perm(const char* lds, int cblk, int s, int x, int y) {
+  const int qq = x >> 2, p = x & 3;
+  uint32_t w[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int R = 32 * s + 16 * h + 4 * y + qq;
+    const int chunk = 2 * cblk + (p >> 1);
+    const char* a = lds + R * 128 + ((chunk ^ (R & 7)) << 4) + (p & 1) * 8;
+    s16x4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(a));
+    const uint2 tt = __builtin_bit_cast(uint2, t);
+    w[2 * h] = tt.x;
+    w[2 * h + 1] = tt.y;
+  }
+  return as_frag(make_uint4(w[0], w[1], w[2], w[3]));
+}
+
+// column-wise fragment in NATURAL k order: k = 32*s + 8*y + j (tile rows), product rows = tile columns
+__device__ __forceinline__ bf16x8 frag_cols_nat(const char* lds, int cblk, int s, int x, int y) {
+  const int qq = x >> 2, p = x & 3;
+  uint32_t w[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int R = 32 * s + 8 * y + 4 * h + qq;
+    const int chunk = 2 * cblk + (p >> 1);
+    const char* a = lds + R * 128 + ((chunk ^ (R & 7)) << 4) + (p & 1) * 8;
+    s16x4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(a));
+    const uint2 tt = __builtin_bit_cast(uint2, t);
+    w[2 * h] = tt.x;
+    w[2 * h + 1] = tt.y;
+  }
+  return as_frag(make_uint4(w[0], w[1], w[2], w[3]));
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// pack 8 fp32 -> bf16x8 fragment
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+  uint32_t o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = (uint32_t)f2bf(v[2 * t]) | ((uint32_t)f2bf(v[2 * t + 1]) << 16);
+  return as_frag(make_uint4(o[0], o[1], o[2], o[3]));
+}
+
+// ---- S^T tile block: st[kt][r] = score(q = q0w + x, key = k0 + 16*kt + 4*y + r), scaled and masked -------------------
+struct QFrags {
+  bf16x8 qa[2];   // q (abs) or q+u (rel), k-steps 0/1
+  bf16x8 qv[2];   // q+v (rel only)
+};
+
+template <bool REL>
+__device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& qf, const char* lk, float* scratch,
+                                             int h, int q0w, int k0, int klen, int x, int y, f32x4 (&st)[4]) {
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) acc = mfma16(frag_rows(lk, kt, ks, x, y), qf.qa[ks], acc);
+    st[kt] = acc;
+  }
+  if constexpr (REL) {
+    // band of position rows n = nbase + (0..79), nbase = Tq-1-(q0w+15)+k0
+    const int nbase = a.Tq - 1 - (q0w + 15) + k0;
+    const int nmax = 2 * a.Tq - 2;
+    const bf16_t* pp = a.pos_p + h * DK;
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      int n = nbase + 16 * nt + x;
+      n = n < 0 ? 0 : (n > nmax ? nmax : n);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = as_frag(ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8));
+        acc = mfma16(pf, qf.qv[ks], acc);
+      }
+      // lane (x = q, y) holds band rows 16nt + 4y + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scratch[(16 * nt + 4 * y + r) * SC + x] = acc[r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[kt][r] += scratch[(15 - x + 16 * kt + 4 * y + r) * SC + x];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  const int i = q0w + x;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = k0 + 16 * kt + 4 * y + r;
+      float s = st[kt][r] * a.scale;
+      if (j >= klen || (a.causal && j > i)) s = -INFINITY;
+      st[kt][r] = s;
+    }
+}
+
+__device__ __forceinline__ void load_qfrags(const FusedArgs& a, QFrags& qf, int b, int h, int i, int y, bool rel) {
+  const int ic = i < a.Tq ? i : a.Tq - 1;
+  const bf16_t* qp = a.q + (int64_t)b * a.q_sb + (int64_t)ic * a.q_sr + h * DK;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint4 raw = ldg16(qp + (ks * 4 + y) * 8);
+    if (rel) {
+      qf.qa[ks] = as_frag(add_bias8(raw, a.pos_u + h * DK + (ks * 4 + y) * 8));
+      qf.qv[ks] = as_frag(add_bias8(raw, a.pos_v + h * DK + (ks * 4 + y) * 8));
+    } else {
+      qf.qa[ks] = as_frag(raw);
+      qf.qv[ks] = as_frag(raw);
+    }
+  }
+}
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+template <bool REL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4];
+  char* lk = lds;
+  char* lv = lds + 8192;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int x = lane & 15, y = lane >> 4;
+  float* scratch = reinterpret_cast<float*>(lds + 16384) + w * BAND * SC;
+  const int z = blockIdx.y;
+  const int b = z / a.H, h = z % a.H;
+  const int q0 = blockIdx.x * 64;
+  const int q0w = q0 + 16 * w;
+  const int i = q0w + x;
+  const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
+
+  QFrags qf;
+  load_qfrags(a, qf, b, h, i, y, REL);
+
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+
+  const bf16_t* kb = a.k + (int64_t)b * a.k_sb + h * DK;
+  const bf16_t* vb = a.v + (int64_t)b * a.v_sb + h * DK;
+  int kend = a.Tk;
+  if (a.causal) kend = min(a.Tk, q0 + 64);  // keys beyond the last query of the workgroup are masked for all its rows
+  const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
+  const uint32_t dth = s2t_drop_thresh(a.drop_p);
+  const float dinv = 1.f / (1.f - a.drop_p);
+
+  for (int k0 = 0; k0 < kend; k0 += KB) {
+    __syncthreads();
+    stage_tile(lk, kb, a.k_sr, k0, a.Tk, tid);
+    stage_tile(lv, vb, a.v_sr, k0, a.Tk, tid);
+    __syncthreads();
+    f32x4 st[4];
+    scores_block<REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st);
+    // ---- online softmax (row = lane's query; its 16 keys in registers, the other 48 in the 3 other y-groups)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = (mn == -INFINITY) ? 1.f : __expf(m - mn);
+    float rs = 0.f;
+    float pr[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (mn == -INFINITY) ? 0.f : __expf(st[kt][r] - mn);
+        rs += p;
+        pr[kt][r] = p;
+      }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+    if (a.drop_p > 0.f) {
+      const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)(i < a.Tq ? i : 0)) * (uint64_t)a.Tk;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = k0 + 16 * kt + 4 * y + r;
+          pr[kt][r] = s2t_rand_u32(dkey, rowbase + j) >= dth ? pr[kt][r] * dinv : 0.f;
+        }
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float pv8[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv8[r] = pr[2 * s][r];
+        pv8[4 + r] = pr[2 * s + 1][r];
+      }
+      const bf16x8 pf = pack8(pv8);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_cols_perm(lv, dt, s, x, y), pf, o[dt]);
+    }
+  }
+  // ---- epilogue: O = O^T / l ; lane (x = query, y) holds d = 16dt + 4y + r
+  if (i < a.Tq) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)i * a.o_sr + h * DK;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      float v4[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+      st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
+    }
+    if (y == 0 && a.lse) a.lse[(int64_t)z * a.Tq + i] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+  }
+}
+
+// =====================================================================================================================
+// backward
+// =====================================================================================================================
+// delta[z][i] = sum_c dO[b,i,h,c] * O[b,i,h,c]   (one 16-lane group per (row, head))
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO,
+                                                         int64_t sb, int64_t sr, float* __restrict__ delta, int B, int H,
+                                                         int Tq) {
+  const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // (b, i, h) index
+  const int l = threadIdx.x & 15;
+  if (gid >= (int64_t)B * Tq * H) return;
+  const int h = (int)(gid % H);
+  const int64_t bi = gid / H;
+  const int i = (int)(bi % Tq), b = (int)(bi / Tq);
+  const int64_t off = (int64_t)b * sb + (int64_t)i * sr + h * DK + l * 4;
+  float a[4], g[4];
+  ld4_as_f32<bf16_t>(o + off, a);
+  ld4_as_f32<bf16_t>(dO + off, g);
+  float s = a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+  s += __shfl_xor(s, 8, 64);
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 1, 64);
+  if (l == 0) delta[((int64_t)b * H + h) * Tq + i] = s;
+}
+
+// ---- dQ: workgroup = 64 queries of one (b,h), wave = 16 queries; walks the key blocks ------------------------------
+template <bool REL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4];
+  char* lk = lds;
+  char* lv = lds + 8192;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int x = lane & 15, y = lane >> 4;
+  float* scratch = reinterpret_cast<float*>(lds + 16384) + w * BAND * SC;
+  const int z = blockIdx.y;
+  const int b = z / a.H, h = z % a.H;
+  const int q0 = blockIdx.x * 64;
+  const int q0w = q0 + 16 * w;
+  const int i = q0w + x;
+  const int ic = i < a.Tq ? i : a.Tq - 1;
+  const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
+
+  QFrags qf;
+  load_qfrags(a, qf, b, h, i, y, REL);
+  bf16x8 dof[2];
+  {
+    const bf16_t* dp = a.dO + (int64_t)b * a.o_sb + (int64_t)ic * a.o_sr + h * DK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) dof[ks] = as_frag(ldg16(dp + (ks * 4 + y) * 8));
+  }
+  const float lse_i = a.lse[(int64_t)z * a.Tq + ic];
+  const float del_i = a.delta[(int64_t)z * a.Tq + ic];
+
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* kb = a.k + (int64_t)b * a.k_sb + h * DK;
+  const bf16_t* vb = a.v + (int64_t)b * a.v_sb + h * DK;
+  int kend = a.Tk;
+  if (a.causal) kend = min(a.Tk, q0 + 64);
+  const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
+  const uint32_t dth = s2t_drop_thresh(a.drop_p);
+  const float dinv = 1.f / (1.f - a.drop_p);
+  bf16_t* dbd_row = nullptr;
+  if (REL && a.dbd && i < a.Tq) dbd_row = a.dbd + (((int64_t)h * a.B + b) * a.Tq + i) * a.ldb;
+  if (REL && a.dbd) {
+    // zero the part of each of this wave's rows that lies outside the band n in [Tq-1-i, Tq-1-i+Tk)
+    for (int rr = 0; rr < 16; ++rr) {
+      const int ii = q0w + rr;
+      if (ii >= a.Tq) break;
+      bf16_t* row = a.dbd + (((int64_t)h * a.B + b) * a.Tq + ii) * a.ldb;
+      const int lo = a.Tq - 1 - ii, hi = lo + a.Tk;
+      for (int n = lane; n < a.ldb; n += 64)
+        if (n < lo || n >= hi) row[n] = 0;
+    }
+  }
+
+  for (int k0 = 0; k0 < kend; k0 += KB) {
+    __syncthreads();
+    stage_tile(lk, kb, a.k_sr, k0, a.Tk, tid);
+    stage_tile(lv, vb, a.v_sr, k0, a.Tk, tid);
+    __syncthreads();
+    f32x4 st[4];
+    scores_block<REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st);
+    // dP^T[key][q] = V[key] . dO[q]
+    f32x4 dpt[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc = mfma16(frag_rows(lv, kt, ks, x, y), dof[ks], acc);
+      dpt[kt] = acc;
+    }
+    const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)ic) * (uint64_t)a.Tk;
+    float ds[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = k0 + 16 * kt + 4 * y + r;
+        const float p = (st[kt][r] == -INFINITY) ? 0.f : __expf(st[kt][r] - lse_i);
+        float dp = dpt[kt][r];
+        if (a.drop_p > 0.f) dp = s2t_rand_u32(dkey, rowbase + j) >= dth ? dp * dinv : 0.f;
+        ds[kt][r] = p * (dp - del_i) * a.scale;
+      }
+    if (dbd_row) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = k0 + 16 * kt + 4 * y + r;
+          if (j < a.Tk) dbd_row[a.Tq - 1 - i + j] = f2bf(ds[kt][r]);
+        }
+    }
+    // dQ^T[c][q] += K^T[c][key] dS^T[key][q]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float d8[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d8[r] = ds[2 * s][r];
+        d8[4 + r] = ds[2 * s + 1][r];
+      }
+      const bf16x8 df = pack8(d8);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(frag_cols_perm(lk, dt, s, x, y), df, dq[dt]);
+    }
+  }
+  if (i < a.Tq) {
+    bf16_t* op = a.dq + (int64_t)b * a.q_sb + (int64_t)i * a.q_sr + h * DK;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      float v4[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+      st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
+    }
+  }
+}
+
+// ---- dK, dV: workgroup = 64 keys of one (b,h), wave = 16 keys; walks the query blocks ------------------------------
+// stage 64 query-side rows (+ optional per-column bias, rounded to bf16) into the shared tile image
+__device__ __forceinline__ void stage_tile_bias(char* lds, const bf16_t* __restrict__ base, int64_t sr, int row0, int nrows,
+                                                const float* __restrict__ bias, int tid) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = tid + 256 * u;
+    const int r = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + r < nrows) {
+      v = ldg16(base + (int64_t)(row0 + r) * sr + ch * 8);
+      if (bias) v = add_bias8(v, bias + ch * 8);
+    }
+    *reinterpret_cast<uint4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = v;
+  }
+}
+
+constexpr int SC2 = 36;  // scratch row stride (floats) of the [16 q][32 n] band in the dK/dV kernel
+
+template <bool REL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[3 * 8192 + 4 * 16 * SC2 * 4 + 512];
+  char* lqa = lds;            // q (abs) / q+u (rel)
+  char* ldo = lds + 8192;     // dO
+  char* lqv = lds + 16384;    // q+v (rel)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int x = lane & 15, y = lane >> 4;
+  float* scratch = reinterpret_cast<float*>(lds + 3 * 8192) + w * 16 * SC2;
+  float* lse_s = reinterpret_cast<float*>(lds + 3 * 8192 + 4 * 16 * SC2 * 4);
+  float* del_s = lse_s + 64;
+  const int z = blockIdx.y;
+  const int b = z / a.H, h = z % a.H;
+  const int k0 = blockIdx.x * 64;
+  const int k0w = k0 + 16 * w;
+  const int j = k0w + x;                       // this lane's key
+  const int jc = j < a.Tk ? j : a.Tk - 1;
+  const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
+  const bool key_ok = j < klen;
+
+  // K and V fragments of this lane's key (B operands: k = 32ks + 8y + jj)
+  bf16x8 kf[2], vf[2];
+  {
+    const bf16_t* kp = a.k + (int64_t)b * a.k_sb + (int64_t)jc * a.k_sr + h * DK;
+    const bf16_t* vp = a.v + (int64_t)b * a.v_sb + (int64_t)jc * a.v_sr + h * DK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[ks] = as_frag(ldg16(kp + (ks * 4 + y) * 8));
+      vf[ks] = as_frag(ldg16(vp + (ks * 4 + y) * 8));
+    }
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    dk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bf16_t* qb = a.q + (int64_t)b * a.q_sb + h * DK;
+  const bf16_t* dob = a.dO + (int64_t)b * a.o_sb + h * DK;
+  const bf16_t* pp = REL ? a.pos_p + h * DK : nullptr;
+  const int nmax = 2 * a.Tq - 2;
+  const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
+  const uint32_t dth = s2t_drop_thresh(a.drop_p);
+  const float dinv = 1.f / (1.f - a.drop_p);
+
+  const int qstart = a.causal ? (k0 / 64) * 64 : 0;  // queries before the key block see none of its keys
+  for (int q0 = qstart; q0 < a.Tq; q0 += 64) {
+    __syncthreads();
+    stage_tile_bias(lqa, qb, a.q_sr, q0, a.Tq, REL ? a.pos_u + h * DK : nullptr, tid);
+    stage_tile(ldo, dob, a.o_sr, q0, a.Tq, tid);
+    if (REL) stage_tile_bias(lqv, qb, a.q_sr, q0, a.Tq, a.pos_v + h * DK, tid);
+    if (tid < 64) {
+      const int qi = min(q0 + tid, a.Tq - 1);
+      lse_s[tid] = a.lse[(int64_t)z * a.Tq + qi];
+      del_s[tid] = a.delta[(int64_t)z * a.Tq + qi];
+    }
+    __syncthreads();
+    float pd[4][4], ds[4][4];  // [q tile][r]: q = q0 + 16qt + 4y + r, key = this lane's
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      // S[q][key] = qa[q] . K[key]
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) s4 = mfma16(frag_rows(lqa, qt, ks, x, y), kf[ks], s4);
+      if constexpr (REL) {
+        // band for (16 q x 16 keys): n = nb + (0..30), nb = Tq-1-(q0+16qt+15)+k0w ; element (ql, key x): 15 - ql + x
+        const int nb = a.Tq - 1 - (q0 + 16 * qt + 15) + k0w;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          int n = nb + 16 * nt + x;
+          n = n < 0 ? 0 : (n > nmax ? nmax : n);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            acc = mfma16(frag_rows(lqv, qt, ks, x, y), as_frag(ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8)), acc);
+          // lane (x = n index, y) holds q_local = 4y + r
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scratch[(4 * y + r) * SC2 + 16 * nt + x] = acc[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s4[r] += scratch[(4 * y + r) * SC2 + 15 - (4 * y + r) + x];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      // dP[q][key] = dO[q] . V[key]
+      f32x4 dp4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) dp4 = mfma16(frag_rows(ldo, qt, ks, x, y), vf[ks], dp4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * qt + 4 * y + r;
+        const int i = q0 + ql;
+        const bool ok = key_ok && i < a.Tq && !(a.causal && j > i);
+        const float p = ok ? __expf(s4[r] * a.scale - lse_s[ql]) : 0.f;
+        float dp = dp4[r];
+        float pdrop = p;
+        if (a.drop_p > 0.f) {
+          const bool keep = s2t_rand_u32(dkey, ((uint64_t)z * a.Tq + (uint64_t)min(i, a.Tq - 1)) * (uint64_t)a.Tk + jc) >= dth;
+          dp = keep ? dp * dinv : 0.f;
+          pdrop = keep ? p * dinv : 0.f;
+        }
+        pd[qt][r] = pdrop;
+        ds[qt][r] = p * (dp - del_s[ql]) * a.scale;
+      }
+    }
+    // dV^T[c][key] += dO^T[c][q] Pd[q][key] ; dK^T[c][key] += qa^T[c][q] dS[q][key]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float p8[8], d8[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p8[r] = pd[2 * s][r];
+        p8[4 + r] = pd[2 * s + 1][r];
+        d8[r] = ds[2 * s][r];
+        d8[4 + r] = ds[2 * s + 1][r];
+      }
+      const bf16x8 pf = pack8(p8), df = pack8(d8);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        dv[ct] = mfma16(frag_cols_perm(ldo, ct, s, x, y), pf, dv[ct]);
+        dk[ct] = mfma16(frag_cols_perm(lqa, ct, s, x, y), df, dk[ct]);
+      }
+    }
+  }
+  if (j < a.Tk) {
+    bf16_t* kp = a.dk + (int64_t)b * a.k_sb + (int64_t)j * a.k_sr + h * DK;
+    bf16_t* vp = a.dv + (int64_t)b * a.v_sb + (int64_t)j * a.v_sr + h * DK;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float k4[4] = {dk[ct][0], dk[ct][1], dk[ct][2], dk[ct][3]};
+      float v4[4] = {dv[ct][0], dv[ct][1], dv[ct][2], dv[ct][3]};
+      st4_from_f32<bf16_t>(kp + 16 * ct + 4 * y, k4);
+      st4_from_f32<bf16_t>(vp + 16 * ct + 4 * y, v4);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr,
+                                  const void* v, int64_t v_sb, int64_t v_sr, void* o, int64_t o_sb, int64_t o_sr,
+                                  float* lse, int B, int H, int Tq, int Tk, int dk, const int32_t* key_lens, int causal,
+                                  float scale, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
+                                  float drop_p, const uint64_t* drop_seed, uint32_t drop_site, void* stream) {
+  if (!q || !k || !v || !o || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
+  if (dk != DK) return S2T_ERR_UNSUPPORTED;
+  if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
+  if (pos_p && (!pos_u || !pos_v || Tq != Tk)) return S2T_ERR_ARG;
+  if ((q_sr % 8) || (k_sr % 8) || (v_sr % 8) || (o_sr % 4) || ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16))
+    return S2T_ERR_ALIGN;
+  FusedArgs a = {};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr;
+  a.o = (bf16_t*)o; a.o_sb = o_sb; a.o_sr = o_sr; a.lse = lse;
+  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.key_lens = key_lens; a.causal = causal; a.scale = scale;
+  a.rel = pos_p != nullptr; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.pos_u = pos_u; a.pos_v = pos_v;
+  a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site;
+  dim3 grid((Tq + 63) / 64, B * H), block(256);
+  if (a.rel) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr,
+                                  const void* v, int64_t v_sb, int64_t v_sr, const void* o, const void* dO, int64_t o_sb,
+                                  int64_t o_sr, const float* lse, float* delta, void* dq, void* dk_, void* dv, void* dbd,
+                                  int64_t ldb, int B, int H, int Tq, int Tk, int dk, const int32_t* key_lens, int causal,
+                                  float scale, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
+                                  float drop_p, const uint64_t* drop_seed, uint32_t drop_site, void* stream) {
+  if (!q || !k || !v || !o || !dO || !lse || !delta || !dq || !dk_ || !dv || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0)
+    return S2T_ERR_ARG;
+  if (dk != DK) return S2T_ERR_UNSUPPORTED;
+  if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
+  if (pos_p && (!pos_u || !pos_v || Tq != Tk)) return S2T_ERR_ARG;
+  if (dbd && ldb < 2 * Tq - 1) return S2T_ERR_ARG;
+  FusedArgs a = {};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr;
+  a.o = (bf16_t*)const_cast<void*>(o); a.o_sb = o_sb; a.o_sr = o_sr; a.lse = const_cast<float*>(lse);
+  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.key_lens = key_lens; a.causal = causal; a.scale = scale;
+  a.rel = pos_p != nullptr; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.pos_u = pos_u; a.pos_v = pos_v;
+  a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site;
+  a.dO = (const bf16_t*)dO; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk_; a.dv = (bf16_t*)dv;
+  a.dbd = (bf16_t*)dbd; a.ldb = ldb;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t groups = (int64_t)B * Tq * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, (const bf16_t*)o,
+                     (const bf16_t*)dO, o_sb, o_sr, delta, B, H, Tq);
+  dim3 gq((Tq + 63) / 64, B * H), gk((Tk + 63) / 64, B * H), block(256);
+  if (a.rel) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, block, 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, block, 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, block, 0, s, a);
+  }
+  return S2T_LAUNCH_CHECK();
+}

@@ -267,3 +267,21 @@ def row_softmax_fwd(x, ldx, p, ldp, rows, V, inv_tau=1.0):
 def row_softmax_bwd(p, ldp, dp, lddp, dx, lddx, rows, V, inv_tau=1.0):
     _call("s2t_row_softmax_bwd", L.dtype_id(p.dtype), p.data_ptr(), ldp, dp.data_ptr(), lddp, dx.data_ptr(), lddx, rows, V,
           inv_tau)
+
+
+def attn_fused_fwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, o_sb, o_sr, lse, B, H, Tq, Tk, dk, key_lens, causal, scale,
+                   pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None):
+    assert q.dtype == torch.bfloat16
+    dp, ds, dsite = _drop3(drop)
+    _call("s2t_attn_fused_fwd", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
+          o_sb, o_sr, _ptr(lse), B, H, Tq, Tk, dk, _ptr(key_lens), int(causal), scale, _ptr(pos_p), p_sr, _ptr(pos_u),
+          _ptr(pos_v), dp, ds, dsite)
+
+
+def attn_fused_bwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, dO, o_sb, o_sr, lse, delta, dq, dk, dv, dbd, ldb, B, H, Tq,
+                   Tk, dkd, key_lens, causal, scale, pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None):
+    dp, ds, dsite = _drop3(drop)
+    _call("s2t_attn_fused_bwd", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
+          dO.data_ptr(), o_sb, o_sr, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _ptr(dbd),
+          ldb, B, H, Tq, Tk, dkd, _ptr(key_lens), int(causal), scale, _ptr(pos_p), p_sr, _ptr(pos_u), _ptr(pos_v), dp, ds,
+          dsite)

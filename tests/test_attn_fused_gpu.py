@@ -1,0 +1,184 @@
+"""Fused attention kernels (bf16, head dim 64) vs a float64 CPU attention on the bf16-rounded operands."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from s2t_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+
+
+def ref_attention(q, k, v, klen, causal, scale, p=None, u=None, vb=None):
+    """q,k,v: (B,T,H,dk) float64; returns O (B,Tq,H,dk), lse (B,H,Tq), probabilities."""
+    B, Tq, H, dk = q.shape
+    Tk = k.shape[1]
+    qh, kh, vh = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+    if p is not None:
+        # the kernel rounds q+u / q+v to bf16 (as the composed path does)
+        qu = (qh + u[None, :, None, :]).to(torch.bfloat16).double()
+        qv = (qh + vb[None, :, None, :]).to(torch.bfloat16).double()
+        ac = qu @ kh.transpose(-1, -2)
+        bd_full = qv @ p.permute(1, 2, 0)[None]  # p: (2T-1, H, dk) -> (H, dk, 2T-1)
+        idx = (Tq - 1) - torch.arange(Tq)[:, None] + torch.arange(Tk)[None, :]
+        bd = torch.gather(bd_full, 3, idx[None, None].expand(B, H, Tq, Tk))
+        s = (ac + bd) * scale
+    else:
+        s = (qh @ kh.transpose(-1, -2)) * scale
+    mask = torch.arange(Tk)[None, :] >= klen[:, None]
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    if causal:
+        s = s + torch.triu(torch.full((Tq, Tk), float("-inf"), dtype=torch.float64), 1)
+    lse = torch.logsumexp(s, -1)
+    pr = torch.softmax(s, -1)
+    o = (pr @ vh).permute(0, 2, 1, 3)
+    return o, lse, pr
+
+
+@pytest.mark.parametrize("Tq,Tk,causal,rel", [(250, 250, False, False), (61, 61, True, False), (61, 250, False, False),
+                                              (250, 250, False, True), (100, 100, False, True), (17, 17, False, True)])
+def test_fused_forward(Tq, Tk, causal, rel):
+    g = torch.Generator().manual_seed(Tq * 7 + Tk + rel)
+    B, H, dk = 3, 4, 64
+    d = H * dk
+    bf = torch.bfloat16
+    qkv = (torch.randn(B, Tq, 3 * d, generator=g) * 0.7).to(bf)
+    if Tq == Tk:
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        qd = kd = vd = qkv.to(DEV)
+        qs = (Tq * 3 * d, 3 * d)
+        qp, kp, vp = qd, qd[..., d:], qd[..., 2 * d:]
+        ks = vs = qs
+    else:
+        q = qkv[..., :d].contiguous()
+        kv = (torch.randn(B, Tk, 2 * d, generator=g) * 0.7).to(bf)
+        k, v = kv[..., :d], kv[..., d:]
+        qp = q.to(DEV)
+        kvd = kv.to(DEV)
+        kp, vp = kvd, kvd[..., d:]
+        qs, ks, vs = (Tq * d, d), (Tk * 2 * d, 2 * d), (Tk * 2 * d, 2 * d)
+    klen = torch.tensor([Tk, max(1, Tk - 7), max(1, Tk // 2)], dtype=torch.int32)
+    scale = 1.0 / math.sqrt(dk)
+    o = torch.full((B, Tq, d), 9.0, dtype=bf, device=DEV)
+    lse = torch.empty(B * H, Tq, dtype=torch.float32, device=DEV)
+    pos = u = vb = None
+    pp = None
+    if rel:
+        pos = (torch.randn(2 * Tq - 1, d, generator=g) * 0.7).to(bf)
+        u = torch.randn(H, dk, generator=g) * 0.3
+        vb = torch.randn(H, dk, generator=g) * 0.3
+        pp = pos.to(DEV)
+    K.attn_fused_fwd(qp, qs[0], qs[1], kp, ks[0], ks[1], vp, vs[0], vs[1], o, Tq * d, d, lse, B, H, Tq, Tk, dk,
+                     klen.to(DEV), causal, scale, pp, d if rel else 0, u.reshape(-1).to(DEV) if rel else None,
+                     vb.reshape(-1).to(DEV) if rel else None)
+    torch.cuda.synchronize()
+    oref, lref, _ = ref_attention(q.double().view(B, Tq, H, dk), k.double().view(B, Tk, H, dk), v.double().view(B, Tk, H, dk),
+                                  klen.long(), causal, scale, pos.double().view(-1, H, dk) if rel else None,
+                                  u.double() if rel else None, vb.double() if rel else None)
+    got = o.cpu().double().view(B, Tq, H, dk)
+    # P is rounded to bf16 before multiplying V and O is stored in bf16
+    np.testing.assert_allclose(got.numpy(), oref.numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(lse.cpu().double().view(B, H, Tq).numpy(), lref.numpy(), rtol=1e-3, atol=2e-3)
+
+
+def _dropout_mask(Z, Tq, Tk, drop):
+    """Keep-mask of the attention-dropout site, read back through the composed path's softmax kernel (same hash of
+    ((z*Tq+i)*Tk+j)): uniform probabilities in, dropped probabilities out."""
+    ld = (Tk + 7) // 8 * 8
+    S = torch.zeros(Z, Tq, ld, dtype=torch.float32, device=DEV)
+    P = torch.empty(Z, Tq, ld, dtype=torch.float32, device=DEV)
+    Pd = torch.empty(Z, Tq, ld, dtype=torch.float32, device=DEV)
+    K.attn_softmax_fwd(S, ld, None, 0, P, ld, Z, 1, Tq, Tk, 1.0, None, False, False, Pd, drop)
+    torch.cuda.synchronize()
+    return (Pd[:, :, :Tk] != 0).cpu()
+
+
+@pytest.mark.parametrize("Tq,Tk,causal,rel,pdrop", [(250, 250, False, False, 0.0), (61, 61, True, False, 0.0),
+                                                    (61, 250, False, False, 0.0), (130, 130, False, False, 0.1),
+                                                    (250, 250, False, True, 0.0), (100, 100, False, True, 0.1),
+                                                    (17, 17, False, True, 0.0)])
+def test_fused_backward(Tq, Tk, causal, rel, pdrop):
+    g = torch.Generator().manual_seed(Tq * 11 + Tk + rel)
+    B, H, dk = 3, 4, 64
+    d = H * dk
+    Z = B * H
+    bf = torch.bfloat16
+    q = (torch.randn(B, Tq, d, generator=g) * 0.7).to(bf)
+    k = (torch.randn(B, Tk, d, generator=g) * 0.7).to(bf)
+    v = (torch.randn(B, Tk, d, generator=g) * 0.7).to(bf)
+    dO = (torch.randn(B, Tq, d, generator=g) * 0.5).to(bf)
+    klen = torch.tensor([Tk, max(1, Tk - 7), max(1, Tk // 2)], dtype=torch.int32)
+    scale = 1.0 / math.sqrt(dk)
+    pos = u = vb = None
+    if rel:
+        pos = (torch.randn(2 * Tq - 1, d, generator=g) * 0.7).to(bf)
+        u = torch.randn(H, dk, generator=g) * 0.3
+        vb = torch.randn(H, dk, generator=g) * 0.3
+    seed = torch.full((1,), 1234, dtype=torch.int64, device=DEV)
+    drop = (pdrop, seed, 5) if pdrop > 0 else None
+    qd, kd, vd, dOd = q.to(DEV), k.to(DEV), v.to(DEV), dO.to(DEV)
+    o = torch.empty(B, Tq, d, dtype=bf, device=DEV)
+    lse = torch.empty(Z, Tq, dtype=torch.float32, device=DEV)
+    pp = pos.to(DEV) if rel else None
+    ud = u.reshape(-1).to(DEV) if rel else None
+    vbd = vb.reshape(-1).to(DEV) if rel else None
+    kl = klen.to(DEV)
+    K.attn_fused_fwd(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, Tq * d, d, lse, B, H, Tq, Tk, dk, kl, causal, scale, pp,
+                     d if rel else 0, ud, vbd, drop)
+    delta = torch.empty(Z, Tq, dtype=torch.float32, device=DEV)
+    dq = torch.full((B, Tq, d), 7.0, dtype=bf, device=DEV)
+    dkk = torch.full((B, Tk, d), 7.0, dtype=bf, device=DEV)
+    dv = torch.full((B, Tk, d), 7.0, dtype=bf, device=DEV)
+    ldb = (2 * Tq - 1 + 7) // 8 * 8
+    dbd = torch.full((H, B, Tq, ldb), 7.0, dtype=bf, device=DEV) if rel else None
+    K.attn_fused_bwd(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, dOd, Tq * d, d, lse, delta, dq, dkk, dv, dbd, ldb, B, H,
+                     Tq, Tk, dk, kl, causal, scale, pp, d if rel else 0, ud, vbd, drop)
+    torch.cuda.synchronize()
+
+    # ---- float64 autograd reference on the same bf16-rounded operands
+    qh = q.double().view(B, Tq, H, dk).permute(0, 2, 1, 3)
+    kh = k.double().view(B, Tk, H, dk).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    vh = v.double().view(B, Tk, H, dk).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    if rel:
+        qu = (qh + u.double()[None, :, None, :]).to(bf).double().requires_grad_(True)
+        qv = (qh + vb.double()[None, :, None, :]).to(bf).double()
+        ph = pos.double().view(-1, H, dk).permute(1, 2, 0)
+        bd_full = (qv @ ph[None]).requires_grad_(True)
+        idx = (Tq - 1) - torch.arange(Tq)[:, None] + torch.arange(Tk)[None, :]
+        s = (qu @ kh.transpose(-1, -2) + torch.gather(bd_full, 3, idx[None, None].expand(B, H, Tq, Tk))) * scale
+        qleaf = qu
+    else:
+        qleaf = qh.clone().requires_grad_(True)
+        s = (qleaf @ kh.transpose(-1, -2)) * scale
+    mask = torch.arange(Tk)[None, :] >= klen.long()[:, None]
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    if causal:
+        s = s + torch.triu(torch.full((Tq, Tk), float("-inf"), dtype=torch.float64), 1)
+    pr = torch.softmax(s, -1)
+    if pdrop > 0:
+        keep = _dropout_mask(Z, Tq, Tk, drop).view(B, H, Tq, Tk)
+        pr = pr * keep / (1.0 - pdrop)
+    oref = pr @ vh
+    (oref * dO.double().view(B, Tq, H, dk).permute(0, 2, 1, 3)).sum().backward()
+
+    def rel_err(got, ref):
+        return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+    np.testing.assert_allclose(o.cpu().double().view(B, Tq, H, dk).permute(0, 2, 1, 3).numpy(), oref.detach().numpy(),
+                               rtol=3e-2, atol=3e-2)
+    got_dq = dq.cpu().double().view(B, Tq, H, dk).permute(0, 2, 1, 3)
+    got_dk = dkk.cpu().double().view(B, Tk, H, dk).permute(0, 2, 1, 3)
+    got_dv = dv.cpu().double().view(B, Tk, H, dk).permute(0, 2, 1, 3)
+    assert rel_err(got_dq, qleaf.grad) < 1.5e-2
+    assert rel_err(got_dk, kh.grad) < 1.5e-2
+    assert rel_err(got_dv, vh.grad) < 1.5e-2
+    # padded keys get exactly zero gradient
+    for b in range(B):
+        assert float(got_dk[b, :, int(klen[b]):].abs().max() if int(klen[b]) < Tk else 0.0) == 0.0
+    if rel:
+        got = dbd.cpu().double()[..., :2 * Tq - 1].permute(1, 0, 2, 3)  # (B, H, Tq, 2T-1)
+        assert rel_err(got, bd_full.grad) < 1.5e-2
+        assert float(dbd.cpu().double()[..., 2 * Tq - 1:].abs().max() if ldb > 2 * Tq - 1 else 0.0) == 0.0
