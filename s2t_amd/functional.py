@@ -8,6 +8,7 @@ wrapper all-reduce contiguous buckets while the rest of backward is still runnin
 There is no CPU path: every function raises if its inputs are not on the GPU.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -256,6 +257,12 @@ def ffn(x, w1, b1, w2, b2, act, alpha, residual, p_hidden=0.0, p_out=0.0, traini
 # ------------------------------------------------------------------------------------------------
 # Attention
 # ------------------------------------------------------------------------------------------------
+def _use_fused_attention(dtype, dk):
+    """bf16 with 64-wide heads runs the fused kernels; fp32 (parity mode) and other head sizes the GEMM-composed path.
+    S2T_ATTN_COMPOSED=1 forces the composed path (A/B measurements)."""
+    return dtype == torch.bfloat16 and dk == 64 and os.environ.get("S2T_ATTN_COMPOSED", "0") != "1"
+
+
 class AttentionFn(torch.autograd.Function):
     """out = residual + out_proj(softmax(scores) V) for
          kind == "abs": fairseq MultiheadAttention (modules/multihead_attention.py:161-431), self (fused q/k/v
@@ -291,6 +298,33 @@ class AttentionFn(torch.autograd.Function):
             k, v = kv, kv[:, d:]
             ldq, ldk = d, 2 * d
         Z = B * H
+        if _use_fused_attention(dt, dk):
+            # scores never leave the chip (csrc/attention_fused.hip)
+            p = None
+            if kind == "rel":
+                assert self_attn and Tq == Tk
+                n_pos = 2 * Tq - 1
+                p = torch.empty(n_pos, d, dtype=dt, device=dev)
+                K.gemm(pos_tab, cw(prm["pos_w"]), p, M=n_pos, N=d, K=d, lda=d, ldb=d, ldc=d)
+                scale = 1.0 / math.sqrt(dk)
+            else:
+                scale = dk ** -0.5
+            O = torch.empty(Mq, d, dtype=dt, device=dev)
+            lse = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
+            K.attn_fused_fwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, Tq * d, d, lse, B, H, Tq, Tk, dk,
+                             key_lens, causal, scale, p, d, prm["pos_u"].data.view(-1) if p is not None else None,
+                             prm["pos_v"].data.view(-1) if p is not None else None, drop_a)
+            y = torch.empty(Mq, d, dtype=dt, device=dev)
+            K.gemm(O, cw(prm["o_w"]), y, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual,
+                   ldr=d, drop=drop_o)
+            ctx.drops = (drop_a, drop_o)
+            ctx.fused = True
+            if train:
+                ctx.save_for_backward(xq, xkv, q, k, v, O, lse, p, pos_tab, key_lens)
+            ctx.prm, ctx.dims = prm, (H, B, Tq, Tk, d, dk, ldq, ldk, 0, 0, scale)
+            ctx.kind, ctx.self_attn, ctx.has_res, ctx.causal = kind, self_attn, residual is not None, causal
+            return y
+        ctx.fused = False
         ldS = _pad8(Tk)
         S = torch.empty(Z, Tq, ldS, dtype=torch.float32, device=dev)
         BD = None
@@ -335,7 +369,76 @@ class AttentionFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    def _backward_fused(ctx, dy):
+        xq, xkv, q, k, v, O, lse, p, pos_tab, key_lens = ctx.saved_tensors
+        prm = ctx.prm
+        H, B, Tq, Tk, d, dk, ldq, ldk, _, _, scale = ctx.dims
+        dt, dev = xq.dtype, xq.device
+        Mq, Mk = B * Tq, B * Tk
+        Z = B * H
+        drop_a, drop_o = ctx.drops
+        dres = dy.contiguous()
+        dy = _drop_rows(dres, drop_o)
+        dO = torch.empty(Mq, d, dtype=dt, device=dev)
+        K.gemm(dy, cw(prm["o_w"]), dO, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+        _wgrad(dy, O, prm["o_w"].grad, d, d, Mq, d, d, 1.0, prm["o_b"].grad)
+        _ready(prm["o_w"], prm["o_b"])
+        if ctx.self_attn:
+            dqkv = torch.empty(Mq, 3 * d, dtype=dt, device=dev)
+            dq, dk_, dv = dqkv, dqkv[:, d:], dqkv[:, 2 * d:]
+        else:
+            dq = torch.empty(Mq, d, dtype=dt, device=dev)
+            dkv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
+            dk_, dv = dkv, dkv[:, d:]
+        rel = ctx.kind == "rel"
+        delta = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
+        n_pos = 2 * Tq - 1
+        ldB = _pad8(n_pos)
+        dBD = torch.empty(H, B, Tq, ldB, dtype=dt, device=dev) if rel else None
+        K.attn_fused_bwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, dO, Tq * d, d, lse, delta, dq, dk_, dv, dBD,
+                         ldB, B, H, Tq, Tk, dk, key_lens, ctx.causal, scale, p, d,
+                         prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a)
+        if rel:
+            K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
+            dqv = torch.empty(Mq, d, dtype=dt, device=dev)
+            K.gemm(dBD, p, dqv, M=Tq, N=dk, K=n_pos, lda=ldB, ldb=d, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
+                   a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
+            K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
+            qv = torch.empty(Mq, d, dtype=dt, device=dev)
+            K.bias_add_rows(q, ldq, prm["pos_v"].data, qv, d, Mq, d)
+            dp = torch.zeros(n_pos, d, dtype=torch.float32, device=dev)
+            ktiles = (Mq + 63) // 64
+            K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
+                   a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=max(1, min(ktiles, 64)), c_atomic=True)
+            pos32 = pos_tab if pos_tab.dtype == torch.float32 else pos_tab.float()
+            K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
+                   split_k=1, c_atomic=True)
+            dq[:, :d].add_(dqv)
+            _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
+        dxq = torch.empty(Mq, d, dtype=dt, device=dev)
+        if ctx.self_attn:
+            gw = fused_grad([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
+            gb = prm["q_b"].grad.as_strided((3 * d,), (1,))
+            wqkv = fused([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
+            _wgrad(dqkv, xq, gw, 3 * d, d, Mq, 3 * d, d, 1.0, gb)
+            K.gemm(dqkv, wqkv, dxq, M=Mq, N=d, K=3 * d, lda=3 * d, ldb=d, ldc=d, b_kmajor=True)
+            dxkv = None
+        else:
+            _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d, 1.0, prm["q_b"].grad)
+            K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+            gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
+            gb = prm["k_b"].grad.as_strided((2 * d,), (1,))
+            wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
+            _wgrad(dkv, xkv, gw, 2 * d, d, Mk, 2 * d, d, 1.0, gb)
+            dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
+            K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
+        _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
+        return dxq, dxkv, (dres if ctx.has_res else None), None, None, None, None, None, None, None, None, None, None, None, None
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.fused:
+            return AttentionFn._backward_fused(ctx, dy)
         xq, xkv, q, k, v, P, O, qu, qv, p, pos_tab, Pd = ctx.saved_tensors
         prm = ctx.prm
         H, B, Tq, Tk, d, dk, ldq, ldk, ldS, ldB, scale = ctx.dims

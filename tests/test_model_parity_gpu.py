@@ -223,3 +223,70 @@ def test_fresh_inputs_against_oracle(conformer):
     dec.model = _EncOnly(model.encoder)
     hyps = dec.generate(None, {"net_input": {"src_tokens": src.to(DEV), "src_lengths": lens.to(DEV)}})
     assert [h[0]["tokens"].tolist() for h in hyps] == [h.tolist() for h in hy]
+
+
+@pytest.mark.parametrize("conformer", [False, True])
+def test_bf16_fused_attention_model_vs_oracle_and_composed(conformer, monkeypatch):
+    """64-wide heads in bf16 take the fused attention kernels (csrc/attention_fused.hip): loss and gradients against the
+    fp32 CPU oracle (bf16-sized tolerance) and, tighter, against the GEMM-composed path on the same bf16 weights."""
+    torch.manual_seed(7)
+    V = 61
+    args = M.recipe_args(conformer=conformer, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_layers=2,
+                         decoder_layers=2, decoder_embed_dim=128, decoder_ffn_embed_dim=256, encoder_attention_heads=2,
+                         decoder_attention_heads=2, subsampling_filter=96, vocab_size=V)
+    model = M.S2TTransformerModel.build_model(args, M.FakeTask(V))
+    W = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = {k: getattr(args, k) for k in vars(args)}
+    model.prepare(torch.bfloat16, DEV)
+    model.train()
+    g = torch.Generator().manual_seed(3)
+    B, T = 4, 300
+    lens = torch.tensor([300, 290, 211, 150])
+    src = torch.randn(B, T, 80, generator=g)
+    for b in range(B):
+        src[b, lens[b]:] = 0
+    U = 9
+    target = torch.randint(4, V, (B, U), generator=g)
+    target[:, -1] = 2
+    target[2, 6:] = 1
+    target[2, 5] = 2
+    prev = torch.roll(target, 1, 1)
+    prev[:, 0] = 2
+    prev[2, 6:] = 1
+    ntok = int((target != 1).sum())
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    sample = {"net_input": {"src_tokens": src.to(DEV), "src_lengths": lens.to(DEV), "prev_output_tokens": prev.to(DEV)},
+              "target": target.to(DEV), "ntokens": ntok}
+
+    def run():
+        model.flat.zero_grad()
+        loss, _, log = crit(model, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
+
+    loss_f, grads_f = run()
+    monkeypatch.setenv("S2T_ATTN_COMPOSED", "1")
+    loss_c, grads_c = run()
+    monkeypatch.delenv("S2T_ATTN_COMPOSED")
+    loss_o, _ = O.joint_loss(W, cfg, src, lens, prev, target, eps=0.1, training=True, use_torch_ctc=True)
+    loss_o.backward()
+    assert abs(loss_f - float(loss_o.detach())) < 2e-2 * abs(float(loss_o.detach()))
+    assert abs(loss_f - loss_c) < 5e-3 * abs(loss_c)
+    worst_o, worst_c = ("", 0.0), ("", 0.0)
+    # tied tensors (decoder embedding = output projection = CTC projection) are separate leaves on the oracle side
+    ptr = {k: v.data_ptr() for k, v in model.state_dict().items()}
+    for k, gf in grads_f.items():
+        if k.endswith("k_proj.bias") or k.endswith("linear_k.bias"):
+            continue  # mathematically zero gradient, rounding noise on both sides
+        go = sum(W[k2].grad for k2 in W if ptr[k2] == ptr[k] and W[k2].grad is not None)
+        if "subsample" in k and go.dim() == 3:
+            go = go.permute(0, 2, 1)
+        eo = float((gf - go).norm() / go.norm().clamp_min(1e-3))
+        ec = float((gf - grads_c[k]).norm() / grads_c[k].norm().clamp_min(1e-3))
+        if eo > worst_o[1]:
+            worst_o = (k, eo)
+        if ec > worst_c[1]:
+            worst_c = (k, ec)
+    assert worst_o[1] < 1.5e-1, worst_o
+    assert worst_c[1] < 8e-2, worst_c
