@@ -11,7 +11,8 @@ import re
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libs2t_hip.so")
+# S2T_HIP_LIB points the binding at another build of the same C-ABI (kernel experiments, a system-wide install)
+LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(HERE, "lib", "libs2t_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "s2t_hip.h")
 
 S2T_F32, S2T_BF16 = 0, 1

@@ -20,11 +20,29 @@
 //                      f32: [k][128 cols] 512 B per k-row, plain; read with ds_read_b32.
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "gemm_common.h"
 
 namespace {
 
-template <typename T, bool AKM, bool BKM, typename TC, bool GLU>
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// Position of one K-step in a workgroup's persistent walk: tile ordinal (tile id = w + ord * G), tile coordinates and
+// K-tile index.  All members are workgroup-uniform (SGPRs).
+struct Cursor {
+  int ord, kt, tm, tn;
+};
+
+template <typename T, bool AKM, bool BKM, typename TC, bool GLU, int D, bool KT, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   constexpr int BKE = TileTraits<T>::BKE;
   constexpr int EPB = TileTraits<T>::EPB;
@@ -38,7 +56,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   const int nout = GLU ? p.N / 2 : p.N;
   const int bn_out = GLU ? 64 : 128;  // output columns per tile
   const int tiles_n = (nout + bn_out - 1) / bn_out;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int ntiles = ((p.M + BM - 1) / BM) * tiles_n;
+
+  // Persistent walk: workgroup w takes tiles w, w+G, w+2G, ... (consecutive tile ids share the A row block).  Workgroup
+  // ids are dealt round-robin to the 8 XCDs, so w is permuted to give every XCD a contiguous range of tile ids: the
+  // workgroups that share an A row block then also share an L2.
+  const int G = gridDim.x;
+  int w = blockIdx.x;
+  if ((G & 7) == 0) w = (w & 7) * (G >> 3) + (w >> 3);
+  if (w >= ntiles) return;
+  const int my_tiles = (ntiles - w + G - 1) / G;
 
   const int z = blockIdx.z;
   const int z0 = z / p.zdiv, z1 = z % p.zdiv;
@@ -50,73 +77,257 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   const int per = (ktiles + p.split_k - 1) / p.split_k;
   const int kt0 = blockIdx.y * per;
   const int kt1 = min(ktiles, kt0 + per);
+  if (kt0 >= kt1) return;  // empty K split (atomic accumulation only; the host rejects K <= 0)
+  // K-steps per tile, padded to a multiple of the D register sets so that a tile always ends at the same rotation
+  // phase; padding steps (kt >= kt1) re-load the last real step and are zeroed before they reach the LDS
+  const int kt_end = kt0 + (kt1 - kt0 + D - 1) / D * D;
+  const int S = my_tiles * (kt_end - kt0);  // K-steps of this workgroup, all its tiles back to back
 
-  const bool a_tail = AKM ? (p.M % EPB) != 0 : (p.K % EPB) != 0;
-  const bool b_tail = BKM ? (p.N % EPB) != 0 : (p.K % EPB) != 0;
+  auto cursor_at = [&](int ord) __attribute__((always_inline)) {
+    const int t = w + ord * G;
+    return Cursor{ord, kt0, t / tiles_n, t % tiles_n};
+  };
+  auto advance = [&](Cursor& c) __attribute__((always_inline)) {
+    if (c.kt + 1 < kt_end) {
+      ++c.kt;
+    } else if (c.ord + 1 < my_tiles) {
+      c = cursor_at(c.ord + 1);
+    }  // else: stays on the very last step (clamped duplicate loads at the end of the walk)
+  };
 
   f32x4 acc[4][4];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  uint4 ra[4], rb[4];
-  auto gload = [&](int kt) {
-    const int k0 = kt * BKE;
-    if constexpr (AKM) load_kmajor<T>(ra, A, p.lda, tm * BM, p.M, k0, p.K, a_tail, tid);
-    else load_rowmajor<T, false>(ra, A, p.lda, tm * BM, p.M, k0, p.K, a_tail, tid, 0);
-    if constexpr (BKM) load_kmajor<T>(rb, B, p.ldb, tn * BN, p.N, k0, p.K, b_tail, tid);
-    else load_rowmajor<T, GLU>(rb, B, p.ldb, tn * bn_out, p.N, k0, p.K, b_tail, tid, nout);
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
-  auto lstore = [&](int buf) {
+  zero_acc();
+
+  // D register sets: the global loads of the next D K-steps are in flight while a step is multiplied, ACROSS tile
+  // boundaries (the loads of the next tile's first steps overlap this tile's epilogue).  The load latency (~1.5 us per
+  // dependent round on MI355X), not the MFMA rate, bounds a shallower pipeline.
+  uint4 ra[D][4], rb[D][4];
+  auto gload = [&](uint4 (&qa)[4], uint4 (&qb)[4], const Cursor& c) __attribute__((always_inline)) {
+    const int k0 = min(c.kt, kt1 - 1) * BKE;
+    if constexpr (AKM) load_kmajor<T, KT>(qa, A, p.lda, c.tm * BM, p.M, k0, p.K, tid);
+    else load_rowmajor<T, false, KT>(qa, A, p.lda, c.tm * BM, p.M, k0, p.K, tid, 0);
+    if constexpr (BKM) load_kmajor<T, KT>(qb, B, p.ldb, c.tn * BN, p.N, k0, p.K, tid);
+    else load_rowmajor<T, GLU, KT>(qb, B, p.ldb, c.tn * bn_out, p.N, k0, p.K, tid, nout);
+  };
+  // once the data has landed: zero a padding step entirely; K % BKE != 0 (KT instantiations only): zero what lies
+  // beyond K in the last K-step of the problem
+  auto gfix = [&](uint4 (&qa)[4], uint4 (&qb)[4], int kt) __attribute__((always_inline)) {
+    if (kt >= kt1) {  // workgroup-uniform
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qa[u] = qb[u] = make_uint4(0, 0, 0, 0);
+    } else if constexpr (KT) {
+      const int k0 = kt * BKE;
+      if (k0 + BKE > p.K) {
+        if constexpr (AKM) fix_kmajor<T>(qa, k0, p.K, tid); else fix_rowmajor<T>(qa, k0, p.K, tid);
+        if constexpr (BKM) fix_kmajor<T>(qb, k0, p.K, tid); else fix_rowmajor<T>(qb, k0, p.K, tid);
+      }
+    }
+  };
+  auto lstore = [&](int buf, const uint4 (&qa)[4], const uint4 (&qb)[4]) __attribute__((always_inline)) {
     char* la = smem + buf * 32768;
     char* lb = la + 16384;
-    if constexpr (AKM) store_kmajor<T>(la, ra, tid); else store_rowmajor(la, ra, tid);
-    if constexpr (BKM) store_kmajor<T>(lb, rb, tid); else store_rowmajor(lb, rb, tid);
+    if constexpr (AKM) store_kmajor<T>(la, qa, tid); else store_rowmajor(la, qa, tid);
+    if constexpr (BKM) store_kmajor<T>(lb, qb, tid); else store_rowmajor(lb, qb, tid);
   };
 
   // optional fused bias gradient: column sums of the (k-major) A operand, taken from the staged registers by the
   // workgroups of the first tile column (every A tile is staged exactly once per such workgroup)
   constexpr int CPR_A = 128 / EPB;
-  const bool do_colsum = AKM && p.colsum_a != nullptr && tn == 0;
+  const bool want_colsum = AKM && p.colsum_a != nullptr;
   float csum[EPB];
 #pragma unroll
   for (int e = 0; e < EPB; ++e) csum[e] = 0.f;
-  auto colsum_acc = [&]() {
+  auto colsum_acc = [&](const uint4 (&qa)[4], int tn) __attribute__((always_inline)) {
     if constexpr (AKM) {
-      if (do_colsum) {
+      if (want_colsum && tn == 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const uint32_t w[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w};
+          const uint32_t w4[4] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w};
           if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              csum[2 * q] += __uint_as_float(w[q] << 16);
-              csum[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
+              csum[2 * q] += __uint_as_float(w4[q] << 16);
+              csum[2 * q + 1] += __uint_as_float(w4[q] & 0xffff0000u);
             }
           } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) csum[q] += __uint_as_float(w[q]);
+            for (int q = 0; q < 4; ++q) csum[q] += __uint_as_float(w4[q]);
           }
         }
       }
     }
   };
 
-  if (kt0 < kt1) {
-    gload(kt0);
-    colsum_acc();
-    lstore(0);
-  }
-  __syncthreads();
-
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) {
-      gload(kt + 1);
-      colsum_acc();
+  // ---------------- epilogue of one tile (single call site) ----------------
+  // Stored outputs go straight from the accumulators: a lane owns 4 consecutive columns of one row per 16-column MFMA
+  // tile; lanes y and y^1 swap halves of a tile pair so that each ends up with 8 consecutive columns (one 16-byte
+  // bf16 store; a wave store covers 16 rows x 64 contiguous bytes, the second half of each 128-byte line follows in
+  // the next instruction).  No LDS, no workgroup barrier: waves run their epilogues independently.
+  // Atomic accumulation (split-K / c_atomic weight gradients) still transposes through LDS: float atomics are only
+  // fast when a wave instruction covers 256 contiguous bytes.
+  auto pair8 = [&](const f32x4& t0, const f32x4& t1, float (&v)[8]) __attribute__((always_inline)) {
+    // t0 / t1: this lane's 4 columns of the even / odd tile of a pair -> 8 consecutive columns of tile (y & 1)
+    const bool odd = y & 1;
+    const f32x4 send = odd ? t0 : t1;
+    f32x4 recv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) recv[r] = __shfl_xor(send[r], 16, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = odd ? recv[r] : t0[r];
+      v[4 + r] = odd ? t1[r] : recv[r];
     }
-    const char* la = smem + buf * 32768;
+  };
+  auto epilogue = [&](const Cursor& c) __attribute__((always_inline)) {
+    const int tm = c.tm, tn = c.tn;
+#if S2T_DBG_EPI == 2
+    if (nout >= 0) return;
+#endif
+    if (p.split_k > 1 || p.c_atomic) {
+      __syncthreads();  // every wave is done reading the operand buffers
+      if constexpr (AKM) {
+        if (want_colsum && tn == 0) {  // workgroup-uniform
+          float* lc = reinterpret_cast<float*>(smem);
+#pragma unroll
+          for (int e = 0; e < EPB; ++e) {
+            lc[tid * EPB + e] = csum[e];
+            csum[e] = 0.f;
+          }
+          __syncthreads();
+          if (tid < 128) {
+            const int ch = tid / EPB, e = tid % EPB;
+            float sum = 0.f;
+            for (int j = 0; j < 256 / CPR_A; ++j) sum += lc[(ch + CPR_A * j) * EPB + e];
+            const int m = tm * BM + tid;
+            if (m < p.M) atomicAdd(p.colsum_a + m, p.alpha * sum);
+          }
+          __syncthreads();
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int chunk = wn * 16 + j * 4 + y;
+          *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
+        }
+      }
+      __syncthreads();
+      // one float per lane, 64 consecutive columns per wave-instruction = 256 contiguous bytes per atomic instruction
+      float* C = reinterpret_cast<float*>(p.C) + coff;
+      const int col = tid & 127;
+      const int n = tn * BN + col;
+      if (n < p.N) {
+#pragma unroll 2
+        for (int pass = 0; pass < 64; ++pass) {
+          const int row = pass * 2 + (tid >> 7);
+          const int m = tm * BM + row;
+          if (m < p.M) {
+            const float v = *reinterpret_cast<const float*>(smem + row * 512 + (((col >> 2) ^ (row & 7)) << 4) + ((col & 3) << 2));
+            atomicAdd(C + (int64_t)m * p.ldc + n, p.alpha * v);
+          }
+        }
+      }
+      __syncthreads();  // the LDS scratch is free again
+      return;
+    }
+    Epi<TC, VEC> e{p,
+                   reinterpret_cast<TC*>(p.C) + coff,
+                   p.residual ? reinterpret_cast<const TC*>(p.residual) + coff : nullptr,
+                   p.preact ? reinterpret_cast<TC*>(p.preact) + (z0 * p.p_s0 + z1 * p.p_s1) : nullptr,
+                   p.dact_z ? reinterpret_cast<const TC*>(p.dact_z) + coff : nullptr,
+                   nout,
+                   false, false, false, false};
+    if constexpr (!VEC) {
+      auto vec_ok = [](const void* ptr, int64_t ld) { return ((ld * (int64_t)sizeof(TC)) % 16 == 0) && (((uintptr_t)ptr) % 16 == 0); };
+      e.vec_c = vec_ok(e.C, p.ldc);
+      e.vec_r = e.R && vec_ok(e.R, p.ldr);
+      e.vec_p = e.P && vec_ok(e.P, p.ldp);
+      e.vec_z = e.Z && vec_ok(e.Z, p.ldz);
+    }
+    // One copy of the (long) fused epilogue code: the loop is NOT unrolled; every trip consumes the first tile pair
+    // (GLU: quad) of the flattened accumulator array and shifts the rest down (register moves), so that all
+    // accumulator indices stay compile-time constants.  The accumulators are dead (re-zeroed) afterwards.
+    f32x4 (&af)[16] = reinterpret_cast<f32x4 (&)[16]>(acc);
+    if constexpr (GLU) {
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int m = tm * BM + wm * 64 + i * 16 + x;
+        const int64_t grow = (int64_t)z * p.M + m;
+        // tiles j = 0, 2 hold the value columns of output groups q = 2wn, 2wn+1 and j = 1, 3 their gate columns
+        float a[8], g[8], ba[8], bg[8], v[8];
+        pair8(af[0], af[2], a);
+        pair8(af[1], af[3], g);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) af[k] = af[k + 4];
+        const int n0 = tn * 64 + (wn * 2 + (y & 1)) * 16 + 8 * (y >> 1);
+        if (m < p.M && n0 < nout) {
+          const int nv = min(8, nout - n0);
+          e.bias8(n0, nv, ba);
+          e.bias8(nout + n0, nv, bg);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            a[r] += ba[r];
+            g[r] += bg[r];
+            v[r] = a[r] * sigmoidf_(g[r]);
+          }
+          if (e.P) {
+            st8<TC>(e.P + (int64_t)m * p.ldp + n0, VEC || e.vec_p, VEC ? 8 : nv, a);
+            st8<TC>(e.P + (int64_t)m * p.ldp + nout + n0, VEC || (e.vec_p && ((nout * (int)sizeof(TC)) % 16 == 0)), VEC ? 8 : nv, g);
+          }
+          e.finish(m, n0, grow, v);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int it = 0; it < 8; ++it) {
+        const int i = it >> 1, jp = it & 1;
+        const int m = tm * BM + wm * 64 + i * 16 + x;
+        const int64_t grow = (int64_t)z * p.M + m;
+        float v[8], b[8];
+        pair8(af[0], af[1], v);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) af[k] = af[k + 2];
+        const int n0 = tn * BN + wn * 64 + (2 * jp + (y & 1)) * 16 + 8 * (y >> 1);
+        if (m < p.M && n0 < nout) {
+          e.bias8(n0, min(8, nout - n0), b);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += b[r];
+          e.finish(m, n0, grow, v);
+        }
+      }
+    }
+  };
+
+  // ---------------- the walk ----------------
+  Cursor L = cursor_at(0);   // next K-step to load
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    gload(ra[u], rb[u], L);
+    advance(L);
+  }
+  Cursor C = cursor_at(0);   // K-step being multiplied (register set s % D, LDS buffer s & 1)
+  gfix(ra[0], rb[0], C.kt);
+  colsum_acc(ra[0], C.tn);
+  lstore(0, ra[0], rb[0]);
+  __syncthreads();
+  Cursor Nx = C;             // K-step after C: the one whose registers are stored to LDS next
+  advance(Nx);
+  int s = 0;
+
+  // multiply step s (register set u, LDS buffer s & 1) while re-filling set u with the step D ahead
+  auto multiply = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    gload(ra[u], rb[u], L);  // set u was stored to LDS at the end of step s-1; unconditional (clamped at the end)
+    advance(L);
+    const char* la = smem + (s & 1) * 32768;
     const char* lb = la + 16384;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -128,130 +339,65 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], fb[j], fa[i]);
-    }
-    if (kt + 1 < kt1) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  if constexpr (AKM) {
-    if (do_colsum) {  // workgroup-uniform
-      float* lc = reinterpret_cast<float*>(smem);
-#pragma unroll
-      for (int e = 0; e < EPB; ++e) lc[tid * EPB + e] = csum[e];
-      __syncthreads();
-      if (tid < 128) {
-        const int ch = tid / EPB, e = tid % EPB;
-        float sum = 0.f;
-        for (int j = 0; j < 256 / CPR_A; ++j) sum += lc[(ch + CPR_A * j) * EPB + e];
-        const int m = tm * BM + tid;
-        if (m < p.M) atomicAdd(p.colsum_a + m, p.alpha * sum);
-      }
-      __syncthreads();
-    }
-  }
-
-  // ---------------- epilogue ----------------
-  // Transpose the accumulators through LDS (the operand buffers are free after the loop's last barrier) so that
-  // every global access of the epilogue is a 16-byte vector on a full 128-byte row segment.
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wm * 64 + i * 16 + x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int chunk = wn * 16 + j * 4 + y;
-      *reinterpret_cast<f32x4*>(smem + row * 512 + ((chunk ^ (row & 7)) << 4)) = acc[i][j];
-    }
-  }
-  __syncthreads();
-
-  if (p.split_k > 1 || p.c_atomic) {
-    // one float per lane, 64 consecutive columns per wave-instruction = 256 contiguous bytes per atomic instruction
-    float* C = reinterpret_cast<float*>(p.C) + coff;
-    const int col = tid & 127;
-    const int n = tn * BN + col;
-    if (n < p.N) {
-#pragma unroll 4
-      for (int pass = 0; pass < 64; ++pass) {
-        const int row = pass * 2 + (tid >> 7);
-        const int m = tm * BM + row;
-        if (m < p.M) {
-          const float v = *reinterpret_cast<const float*>(smem + row * 512 + (((col >> 2) ^ (row & 7)) << 4) + ((col & 3) << 2));
-          atomicAdd(C + (int64_t)m * p.ldc + n, p.alpha * v);
+        for (int j = 0; j < 4; ++j) {
+#if S2T_DBG_EPI == 3
+          if (i + j > 0) continue;
+#endif
+          mma<T>(acc[i][j], fb[j], fa[i]);
         }
-      }
     }
-    return;
-  }
+  };
+  // land step s+1 (set (u+1) % D) in the other LDS buffer and move on to it
+  auto land_next = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int un = (decltype(uc)::value + 1) % D;
+    gfix(ra[un], rb[un], Nx.kt);
+    colsum_acc(ra[un], Nx.tn);
+    lstore((s & 1) ^ 1, ra[un], rb[un]);
+    __syncthreads();
+    C = Nx;
+    advance(Nx);
+    ++s;
+  };
 
-  Epi<TC> e{p,
-            reinterpret_cast<TC*>(p.C) + coff,
-            p.residual ? reinterpret_cast<const TC*>(p.residual) + coff : nullptr,
-            p.preact ? reinterpret_cast<TC*>(p.preact) + (z0 * p.p_s0 + z1 * p.p_s1) : nullptr,
-            p.dact_z ? reinterpret_cast<const TC*>(p.dact_z) + coff : nullptr,
-            nout,
-            false, false, false, false};
-  auto vec_ok = [](const void* ptr, int64_t ld) { return ((ld * (int64_t)sizeof(TC)) % 16 == 0) && (((uintptr_t)ptr) % 16 == 0); };
-  e.vec_c = vec_ok(e.C, p.ldc);
-  e.vec_r = e.R && vec_ok(e.R, p.ldr);
-  e.vec_p = e.P && vec_ok(e.P, p.ldp);
-  e.vec_z = e.Z && vec_ok(e.Z, p.ldz);
-
-  const int c8 = tid & 7;
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int row = pass * 32 + (tid >> 3);
-    const int m = tm * BM + row;
-    if (m >= p.M) continue;
-    const int64_t grow = (int64_t)z * p.M + m;
-    if constexpr (GLU) {
-      // LDS columns per 32-column group q: [16 value | 16 gate]; output column o = q*16 + (0..15)
-      const int o0 = c8 * 8;
-      const int n0 = tn * 64 + o0;
-      if (n0 >= nout) continue;
-      const int lcol = (o0 >> 4) * 32 + (o0 & 15);
-      const int nv = min(8, nout - n0);
-      float a[8], g[8], ba[8], bg[8], v[8];
-      ctile_ld8(smem, row, lcol, a);
-      ctile_ld8(smem, row, lcol + 16, g);
-      e.bias8(n0, nv, ba);
-      e.bias8(nout + n0, nv, bg);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        a[r] += ba[r];
-        g[r] += bg[r];
-        v[r] = a[r] * sigmoidf_(g[r]);
-      }
-      if (e.P) {
-        st8<TC>(e.P + (int64_t)m * p.ldp + n0, e.vec_p, nv, a);
-        st8<TC>(e.P + (int64_t)m * p.ldp + nout + n0, e.vec_p && ((nout * (int)sizeof(TC)) % 16 == 0), nv, g);
-      }
-      e.finish(m, n0, grow, v);
-    } else {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int col0 = h * 64 + c8 * 8;
-        const int n0 = tn * BN + col0;
-        if (n0 >= nout) continue;
-        float v[8], b[8];
-        ctile_ld8(smem, row, col0, v);
-        e.bias8(n0, min(8, nout - n0), b);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += b[r];
-        e.finish(m, n0, grow, v);
-      }
+  // one iteration = D K-steps through the D register sets (compile-time indices); tiles end on iteration boundaries
+  for (;;) {
+    static_for<D>([&](auto uc) __attribute__((always_inline)) {
+      multiply(uc);
+      if constexpr (decltype(uc)::value + 1 < D) land_next(uc);
+    });
+    if (C.kt + 1 == kt_end) {  // workgroup-uniform
+      epilogue(C);
+      if (s + 1 == S) break;
+      zero_acc();
     }
+    land_next(std::integral_constant<int, D - 1>{});
   }
 }
 
-template <typename T, typename TC>
-int launch(const s2t_gemm_args& p, hipStream_t s) {
+constexpr int PFD = 2;  // K-steps of global loads in flight per workgroup
+
+template <typename TC>
+static bool epilogue_vectorisable(const s2t_gemm_args& p, int nout) {
+  const int epb = 16 / (int)sizeof(TC);
+  auto ok = [&](const void* ptr, int64_t ld) { return !ptr || (((uintptr_t)ptr % 16) == 0 && ld % epb == 0); };
+  if (nout % 8) return false;
+  if (!ok(p.C, p.ldc) || !ok(p.residual, p.ldr) || !ok(p.preact, p.ldp) || !ok(p.dact_z, p.ldz)) return false;
+  if ((p.c_s0 % epb) || (p.c_s1 % epb) || (p.p_s0 % epb) || (p.p_s1 % epb)) return false;
+  if (p.bias && ((uintptr_t)p.bias % 16)) return false;
+  return true;
+}
+
+template <typename T, typename TC, bool KT, bool VEC>
+int launch2(const s2t_gemm_args& p, hipStream_t s) {
   const bool glu = p.act == S2T_ACT_GLU;
   const int nout = glu ? p.N / 2 : p.N;
   const int bn_out = glu ? 64 : 128;
   const int tiles = ((p.M + BM - 1) / BM) * ((nout + bn_out - 1) / bn_out);
-  dim3 grid(tiles, p.split_k, p.batch), block(256);
-#define GO(AK, BK, G) hipLaunchKernelGGL((gemm_kernel<T, AK, BK, TC, G>), grid, block, 0, s, p)
+  // persistent workgroups: two per CU (64 KiB LDS each), each walks tiles w, w+G, ...
+  const int slots = 2 * s2t_device_cu_count();
+  dim3 grid(tiles < slots ? tiles : slots, p.split_k, p.batch), block(256);
+#define GO(AK, BK, G) \
+  hipLaunchKernelGGL((gemm_kernel<T, AK, BK, TC, G, (AK && !BK) ? 2 : PFD, KT, VEC>), grid, block, 0, s, p)  // AK/BR: 3 sets spill
   if (glu) {
     if (p.a_kmajor || p.b_kmajor) return S2T_ERR_UNSUPPORTED;
     GO(false, false, true);
@@ -261,6 +407,15 @@ int launch(const s2t_gemm_args& p, hipStream_t s) {
   else GO(true, true, false);
 #undef GO
   return S2T_LAUNCH_CHECK();
+}
+
+template <typename T, typename TC>
+int launch(const s2t_gemm_args& p, hipStream_t s) {
+  const int nout = p.act == S2T_ACT_GLU ? p.N / 2 : p.N;
+  const bool kt = (p.K % TileTraits<T>::BKE) != 0;
+  const bool vec = epilogue_vectorisable<TC>(p, nout);
+  if (kt) return vec ? launch2<T, TC, true, true>(p, s) : launch2<T, TC, true, false>(p, s);
+  return vec ? launch2<T, TC, false, true>(p, s) : launch2<T, TC, false, false>(p, s);
 }
 
 }  // namespace
@@ -282,7 +437,7 @@ static bool use_ring() {
 extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return S2T_ERR_ARG;
   s2t_gemm_args p = *a;
-  if (p.M <= 0 || p.N <= 0 || p.K < 0) return S2T_ERR_ARG;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return S2T_ERR_ARG;
   if (p.batch <= 0) p.batch = 1;
   if (p.zdiv <= 0) p.zdiv = 1;
   if (p.split_k <= 0) p.split_k = 1;

@@ -3,6 +3,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef S2T_DBG_EPI
+#define S2T_DBG_EPI 0  // kernel-experiment switch (tools/dbg_build.sh); 0 in every shipped build
+#endif
+
 #define BM 128
 #define BN 128
 
@@ -38,59 +42,88 @@ __device__ __forceinline__ void mask_tail(uint4& v, int nvalid) {
   v = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// 16-byte global load as a native vector (a HIP_vector_type struct copy lowers to llvm.memcpy into the private
+// array, which kept the staging registers in scratch memory)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ldg_u4(const void* ptr) {
+  const u32x4_t t = *reinterpret_cast<const u32x4_t*>(ptr);
+  return make_uint4(t.x, t.y, t.z, t.w);
+}
+
 __device__ __forceinline__ int kswz(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
 
 // ---- global -> registers ---------------------------------------------------------------------
+// The loads are UNCONDITIONAL and branch-free: a bounds branch or a tail mask next to a load makes the compiler wait
+// for every load individually (s_waitcnt vmcnt(0) after each), which serialises the 8 loads of a K-step, and the
+// zero-fill code of ragged tiles bloats a kernel whose per-tile fixed cost is instruction fetch.
+//   * rows / columns beyond M or N are CLAMPED to the last valid one: they only feed accumulator rows / columns that
+//     the epilogue never stores (an MFMA output element depends on its own operand row and column only);
+//   * K beyond the problem's K must be ZERO.  Only the KT (K % BKE != 0) instantiations carry that code: chunks past
+//     K read offset 0 of the row and are zeroed / tail-masked by fix_*() right before the LDS store.
 // row-major operand: element (row, k) at base[row*ld + k]
 template <typename T, bool GLU_B>
+__device__ __forceinline__ int rowmajor_row(int r, int row0, int nrows, int glu_half_rows) {
+  if constexpr (GLU_B) {
+    // 16-row blocks alternate value / gate rows of the weight: block s -> half = s&1
+    const int s = r >> 4;
+    const int o = min(row0 + (s >> 1) * 16 + (r & 15), glu_half_rows - 1);  // output column; row0 = tn*64
+    return (s & 1) * glu_half_rows + o;
+  } else {
+    return min(row0 + r, nrows - 1);
+  }
+}
+
+template <typename T, bool GLU_B, bool KT>
 __device__ __forceinline__ void load_rowmajor(uint4 (&reg)[4], const T* __restrict__ base, int64_t ld, int row0,
-                                              int nrows, int k0, int K, bool ktail, int tid, int glu_half_rows) {
+                                              int nrows, int k0, int K, int tid, int glu_half_rows) {
   constexpr int EPB = TileTraits<T>::EPB;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int cid = tid + 256 * u;
     const int r = cid >> 3, ch = cid & 7;
-    int grow;
-    bool rv;
-    if constexpr (GLU_B) {
-      // 16-row blocks alternate value / gate rows of the weight: block s -> half = s&1
-      const int s = r >> 4;
-      const int nloc = (s >> 1) * 16 + (r & 15);
-      const int o = row0 + nloc;  // output column; row0 = tn*64
-      rv = o < glu_half_rows;
-      grow = (s & 1) * glu_half_rows + o;
-    } else {
-      grow = row0 + r;
-      rv = grow < nrows;
-    }
+    const int grow = rowmajor_row<T, GLU_B>(r, row0, nrows, glu_half_rows);
+    int k = k0 + ch * EPB;
+    if constexpr (KT) k = k < K ? k : 0;
+    reg[u] = ldg_u4(base + (int64_t)grow * ld + k);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void fix_rowmajor(uint4 (&reg)[4], int k0, int K, int tid) {
+  constexpr int EPB = TileTraits<T>::EPB;
+  const bool ktail = (K % EPB) != 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int ch = (tid + 256 * u) & 7;
     const int k = k0 + ch * EPB;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (rv && k < K) {
-      v = *reinterpret_cast<const uint4*>(base + (int64_t)grow * ld + k);
-      if (ktail && k + EPB > K) mask_tail<T>(v, K - k);
-    }
-    reg[u] = v;
+    if (k >= K) reg[u] = make_uint4(0, 0, 0, 0);
+    else if (ktail && k + EPB > K) mask_tail<T>(reg[u], K - k);
   }
 }
 
 // k-major operand: element (k, col) at base[k*ld + col]
-template <typename T>
+template <typename T, bool KT>
 __device__ __forceinline__ void load_kmajor(uint4 (&reg)[4], const T* __restrict__ base, int64_t ld, int col0,
-                                            int ncols, int k0, int K, bool ctail, int tid) {
+                                            int ncols, int k0, int K, int tid) {
   constexpr int EPB = TileTraits<T>::EPB;
   constexpr int CPR = 128 / EPB;  // chunks per k-row: 16 (bf16) / 32 (f32)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int cid = tid + 256 * u;
     const int kr = cid / CPR, ch = cid % CPR;
-    const int gk = k0 + kr;
-    const int gc = col0 + ch * EPB;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gk < K && gc < ncols) {
-      v = *reinterpret_cast<const uint4*>(base + (int64_t)gk * ld + gc);
-      if (ctail && gc + EPB > ncols) mask_tail<T>(v, ncols - gc);
-    }
-    reg[u] = v;
+    int gk = k0 + kr;
+    if constexpr (KT) gk = gk < K ? gk : 0;
+    int gc = col0 + ch * EPB;
+    gc = gc < ncols ? gc : 0;
+    reg[u] = ldg_u4(base + (int64_t)gk * ld + gc);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void fix_kmajor(uint4 (&reg)[4], int k0, int K, int tid) {
+  constexpr int CPR = 128 / TileTraits<T>::EPB;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int kr = (tid + 256 * u) / CPR;
+    if (k0 + kr >= K) reg[u] = make_uint4(0, 0, 0, 0);
   }
 }
 
@@ -218,7 +251,9 @@ __device__ __forceinline__ void st8(X* ptr, bool vec, int nv, const float (&o)[8
   }
 }
 
-template <typename TC>
+// VEC instantiations assume 16-byte aligned rows / pointers and N % 8 == 0 for every tensor the epilogue touches
+// (checked on the host): they carry no scalar fallbacks, which keeps the once-per-tile epilogue code short.
+template <typename TC, bool VEC = false>
 struct Epi {
   const s2t_gemm_args& p;
   TC* C;
@@ -236,10 +271,10 @@ struct Epi {
     }
     if (p.bias_dtype == S2T_F32) {
       const float* bp = reinterpret_cast<const float*>(p.bias) + n0;
-      ld8<float>(bp, ((uintptr_t)bp % 16) == 0, nv, b);
+      ld8<float>(bp, VEC || ((uintptr_t)bp % 16) == 0, VEC ? 8 : nv, b);
     } else {
       const bf16_t* bp = reinterpret_cast<const bf16_t*>(p.bias) + n0;
-      ld8<bf16_t>(bp, ((uintptr_t)bp % 16) == 0, nv, b);
+      ld8<bf16_t>(bp, VEC || ((uintptr_t)bp % 16) == 0, VEC ? 8 : nv, b);
     }
   }
   __device__ __forceinline__ bool row_masked(int64_t grow) const {
@@ -249,15 +284,15 @@ struct Epi {
   }
   // v: post-bias (post-GLU) values for output columns n0..n0+7 of row m
   __device__ __forceinline__ void finish(int m, int n0, int64_t grow, float (&v)[8]) const {
-    const int nv = min(8, nout - n0);
+    const int nv = VEC ? 8 : min(8, nout - n0);
     if (p.act == S2T_ACT_RELU || p.act == S2T_ACT_SWISH) {
-      if (P) st8<TC>(P + (int64_t)m * p.ldp + n0, vec_p, nv, v);
+      if (P) st8<TC>(P + (int64_t)m * p.ldp + n0, VEC || vec_p, nv, v);
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = act_apply(p.act, v[r]);
     }
     if (Z) {
       float z[8];
-      ld8<TC>(Z + (int64_t)m * p.ldz + n0, vec_z, nv, z);
+      ld8<TC>(Z + (int64_t)m * p.ldz + n0, VEC || vec_z, nv, z);
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] *= act_grad(p.dact, z[r]);
     }
@@ -277,11 +312,14 @@ struct Epi {
     }
     if (R) {
       float q[8];
-      ld8<TC>(R + (int64_t)m * p.ldr + n0, vec_r, nv, q);
+      ld8<TC>(R + (int64_t)m * p.ldr + n0, VEC || vec_r, nv, q);
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] += q[r];
     }
-    st8<TC>(C + (int64_t)m * p.ldc + n0, vec_c, nv, v);
+#if S2T_DBG_EPI == 1
+    if (nout < 0)
+#endif
+    st8<TC>(C + (int64_t)m * p.ldc + n0, VEC || vec_c, nv, v);
   }
 };
 
