@@ -63,7 +63,8 @@ __device__ __forceinline__ void st4_from_f32<bf16_t>(bf16_t* p, const float (&v)
   *reinterpret_cast<uint2*>(p) = t;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: the fused GEMM epilogues are VALU-issue bound
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float act_apply(int act, float x) {
   if (act == S2T_ACT_RELU) return x > 0.f ? x : 0.f;

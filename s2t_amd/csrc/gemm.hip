@@ -108,12 +108,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   // boundaries (the loads of the next tile's first steps overlap this tile's epilogue).  The load latency (~1.5 us per
   // dependent round on MI355X), not the MFMA rate, bounds a shallower pipeline.
   uint4 ra[D][4], rb[D][4];
+  LoadPlan pa, pb;  // byte offsets of this thread's chunks in the tile the load cursor is on
+  auto plan_tile = [&](const Cursor& c) __attribute__((always_inline)) {
+    if constexpr (AKM) plan_kmajor<T>(pa, p.lda, c.tm * BM, p.M, tid);
+    else plan_rowmajor<T, false>(pa, p.lda, c.tm * BM, p.M, tid, 0);
+    if constexpr (BKM) plan_kmajor<T>(pb, p.ldb, c.tn * BN, p.N, tid);
+    else plan_rowmajor<T, GLU>(pb, p.ldb, c.tn * bn_out, p.N, tid, nout);
+  };
   auto gload = [&](uint4 (&qa)[4], uint4 (&qb)[4], const Cursor& c) __attribute__((always_inline)) {
     const int k0 = min(c.kt, kt1 - 1) * BKE;
-    if constexpr (AKM) load_kmajor<T, KT>(qa, A, p.lda, c.tm * BM, p.M, k0, p.K, tid);
-    else load_rowmajor<T, false, KT>(qa, A, p.lda, c.tm * BM, p.M, k0, p.K, tid, 0);
-    if constexpr (BKM) load_kmajor<T, KT>(qb, B, p.ldb, c.tn * BN, p.N, k0, p.K, tid);
-    else load_rowmajor<T, GLU, KT>(qb, B, p.ldb, c.tn * bn_out, p.N, k0, p.K, tid, nout);
+    if constexpr (AKM) load_kmajor<T, KT>(qa, reinterpret_cast<const char*>(A), pa, p.lda, k0, p.K, tid);
+    else load_rowmajor<T, KT>(qa, reinterpret_cast<const char*>(A), pa, k0, p.K, tid);
+    if constexpr (BKM) load_kmajor<T, KT>(qb, reinterpret_cast<const char*>(B), pb, p.ldb, k0, p.K, tid);
+    else load_rowmajor<T, KT>(qb, reinterpret_cast<const char*>(B), pb, k0, p.K, tid);
+  };
+  // the load cursor re-plans when it enters a new tile
+  auto advance_load = [&](Cursor& c) __attribute__((always_inline)) {
+    if (c.kt + 1 < kt_end) {
+      ++c.kt;
+    } else if (c.ord + 1 < my_tiles) {
+      c = cursor_at(c.ord + 1);
+      plan_tile(c);
+    }
   };
   // once the data has landed: zero a padding step entirely; K % BKE != 0 (KT instantiations only): zero what lies
   // beyond K in the last K-step of the problem
@@ -308,10 +324,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
 
   // ---------------- the walk ----------------
   Cursor L = cursor_at(0);   // next K-step to load
+  plan_tile(L);
 #pragma unroll
   for (int u = 0; u < D; ++u) {
     gload(ra[u], rb[u], L);
-    advance(L);
+    advance_load(L);
   }
   Cursor C = cursor_at(0);   // K-step being multiplied (register set s % D, LDS buffer s & 1)
   gfix(ra[0], rb[0], C.kt);
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   auto multiply = [&](auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
     gload(ra[u], rb[u], L);  // set u was stored to LDS at the end of step s-1; unconditional (clamped at the end)
-    advance(L);
+    advance_load(L);
     const char* la = smem + (s & 1) * 32768;
     const char* lb = la + 16384;
 #pragma unroll
@@ -452,6 +469,12 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   if (p.split_k > 1 || p.c_atomic) {
     if (p.c_dtype != S2T_F32 || p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens || p.drop_p > 0.f)
       return S2T_ERR_UNSUPPORTED;
+  }
+  {
+    // the kernels address each operand with 32-bit byte offsets from its (batch-adjusted) base
+    const int64_t a_span = (int64_t)(p.a_kmajor ? p.K : p.M) * p.lda * esz;
+    const int64_t b_span = (int64_t)(p.b_kmajor ? p.K : p.N) * p.ldb * esz;
+    if (a_span >= (1ll << 32) || b_span >= (1ll << 32)) return S2T_ERR_UNSUPPORTED;
   }
   if (p.row_lens && p.row_T <= 0) return S2T_ERR_ARG;
   if (p.drop_p < 0.f || p.drop_p >= 1.f) return S2T_ERR_ARG;

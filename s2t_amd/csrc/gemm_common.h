@@ -73,18 +73,40 @@ __device__ __forceinline__ int rowmajor_row(int r, int row0, int nrows, int glu_
   }
 }
 
-template <typename T, bool GLU_B, bool KT>
-__device__ __forceinline__ void load_rowmajor(uint4 (&reg)[4], const T* __restrict__ base, int64_t ld, int row0,
-                                              int nrows, int k0, int K, int tid, int glu_half_rows) {
-  constexpr int EPB = TileTraits<T>::EPB;
+// Per-thread load plan of one operand tile: 32-bit BYTE offsets (from the operand base) of the thread's four 16-byte
+// chunks at K-step 0.  A K-step's loads are then "uniform 64-bit base + 32-bit VGPR offset" (the global_load saddr
+// form): no per-load 64-bit address arithmetic in the main loop, whose cost on a wave64 is VALU issue slots.
+// The host guarantees every operand spans less than 4 GiB.
+struct LoadPlan {
+  uint32_t off[4];
+};
+
+template <typename T, bool GLU_B>
+__device__ __forceinline__ void plan_rowmajor(LoadPlan& pl, int64_t ld, int row0, int nrows, int tid, int glu_half_rows) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int cid = tid + 256 * u;
     const int r = cid >> 3, ch = cid & 7;
     const int grow = rowmajor_row<T, GLU_B>(r, row0, nrows, glu_half_rows);
-    int k = k0 + ch * EPB;
-    if constexpr (KT) k = k < K ? k : 0;
-    reg[u] = ldg_u4(base + (int64_t)grow * ld + k);
+    pl.off[u] = (uint32_t)((int64_t)grow * ld * (int64_t)sizeof(T)) + (uint32_t)(ch * 16);
+  }
+}
+template <typename T, bool KT>
+__device__ __forceinline__ void load_rowmajor(uint4 (&reg)[4], const char* __restrict__ base, const LoadPlan& pl, int k0,
+                                              int K, int tid) {
+  constexpr int EPB = TileTraits<T>::EPB;
+  if constexpr (!KT) {
+    const char* bk = base + (int64_t)k0 * (int64_t)sizeof(T);  // workgroup-uniform
+#pragma unroll
+    for (int u = 0; u < 4; ++u) reg[u] = ldg_u4(bk + pl.off[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ch = (tid + 256 * u) & 7;
+      // chunks beyond K read the start of their row (zeroed by fix_rowmajor)
+      const uint32_t kterm = (k0 + ch * EPB < K) ? (uint32_t)(k0 * (int)sizeof(T)) : (uint32_t)(-(ch * 16));
+      reg[u] = ldg_u4(base + (uint32_t)(pl.off[u] + kterm));
+    }
   }
 }
 template <typename T>
@@ -101,20 +123,36 @@ __device__ __forceinline__ void fix_rowmajor(uint4 (&reg)[4], int k0, int K, int
 }
 
 // k-major operand: element (k, col) at base[k*ld + col]
-template <typename T, bool KT>
-__device__ __forceinline__ void load_kmajor(uint4 (&reg)[4], const T* __restrict__ base, int64_t ld, int col0,
-                                            int ncols, int k0, int K, int tid) {
+template <typename T>
+__device__ __forceinline__ void plan_kmajor(LoadPlan& pl, int64_t ld, int col0, int ncols, int tid) {
   constexpr int EPB = TileTraits<T>::EPB;
   constexpr int CPR = 128 / EPB;  // chunks per k-row: 16 (bf16) / 32 (f32)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int cid = tid + 256 * u;
     const int kr = cid / CPR, ch = cid % CPR;
-    int gk = k0 + kr;
-    if constexpr (KT) gk = gk < K ? gk : 0;
     int gc = col0 + ch * EPB;
     gc = gc < ncols ? gc : 0;
-    reg[u] = ldg_u4(base + (int64_t)gk * ld + gc);
+    pl.off[u] = (uint32_t)((int64_t)kr * ld * (int64_t)sizeof(T)) + (uint32_t)(gc * (int)sizeof(T));
+  }
+}
+template <typename T, bool KT>
+__device__ __forceinline__ void load_kmajor(uint4 (&reg)[4], const char* __restrict__ base, const LoadPlan& pl, int64_t ld,
+                                            int k0, int K, int tid) {
+  constexpr int CPR = 128 / TileTraits<T>::EPB;
+  if constexpr (!KT) {
+    const char* bk = base + (int64_t)k0 * ld * (int64_t)sizeof(T);  // workgroup-uniform
+#pragma unroll
+    for (int u = 0; u < 4; ++u) reg[u] = ldg_u4(bk + pl.off[u]);
+  } else {
+    const uint32_t ldb = (uint32_t)(ld * (int64_t)sizeof(T));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kr = (tid + 256 * u) / CPR;
+      // k-rows beyond K read k-row 0 (zeroed by fix_kmajor)
+      const uint32_t kterm = (k0 + kr < K) ? (uint32_t)k0 * ldb : (uint32_t)(-kr) * ldb;
+      reg[u] = ldg_u4(base + (uint32_t)(pl.off[u] + kterm));
+    }
   }
 }
 template <typename T>

@@ -412,7 +412,7 @@ class AttentionFn(torch.autograd.Function):
                    a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=max(1, min(ktiles, 64)), c_atomic=True)
             pos32 = pos_tab if pos_tab.dtype == torch.float32 else pos_tab.float()
             K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
-                   split_k=1, c_atomic=True)
+                   split_k=max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
             dq[:, :d].add_(dqv)
             _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
         dxq = torch.empty(Mq, d, dtype=dt, device=dev)
@@ -496,7 +496,7 @@ class AttentionFn(torch.autograd.Function):
             # linear_pos weight: dW[dout, din] += dp^T pos_tab  (fp32 GEMM on the fp32 table)
             pos32 = pos_tab if pos_tab.dtype == torch.float32 else pos_tab.float()
             K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
-                   split_k=1, c_atomic=True)
+                   split_k=max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
             # dq += dqv   (strided add into the q slice of dqkv)
             dq_view = dq[:, :d] if ctx.self_attn else dq
             dq_view.add_(dqv)
