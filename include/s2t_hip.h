@@ -50,8 +50,10 @@ int s2t_device_cu_count(void);
  *   [row_lens: v = 0 on rows with (global_row % row_T) >= row_lens[global_row / row_T]  (padded frames;
  *    the reference masks the branch output, not the residual: modules/convolution.py:109-116)];
  *   [residual: v += residual[m,n]]; store (c_dtype).   global_row = z*M + m.
- * split_k > 1 (wgrad): K is split over blockIdx.y and alpha*acc is atomically added to an fp32 C
- *   (no other epilogue stage allowed).  colsum_a (a_kmajor): the column sums of dY (= the bias gradient) are taken
+ * split_k > 1 (wgrad): K is split over blockIdx.y and alpha*acc is ADDED to an fp32 C (no other epilogue stage
+ *   allowed): through the fp32 workspace `ws` when it holds at least s2t_gemm_ws_floats() floats (every split stores
+ *   its partial tiles with plain coalesced stores, a second kernel sums them into C — float atomics execute at the
+ *   memory side on a multi-XCD part and are several times slower), with float atomics otherwise.  colsum_a (a_kmajor): the column sums of dY (= the bias gradient) are taken
  *   from the staged A tiles by the workgroups of the first tile column and added atomically (fp32).
  * Alignment: A, B base pointers and strides must keep 16-byte alignment of every row start.
  * ------------------------------------------------------------------------------------------------ */
@@ -79,9 +81,13 @@ typedef struct s2t_gemm_args {
   float drop_p;     /* > 0: v = keep(seed, site, global_row*Nout + n) ? v/(1-p) : 0 after the activation / act' stage */
   uint32_t drop_site;
   const uint64_t* drop_seed; /* device pointer (a captured hipGraph replays with a fresh seed) */
+  float* ws;         /* optional split-K workspace (see above); contents are scratch */
+  int64_t ws_floats; /* its size in floats */
 } s2t_gemm_args;
 
 int s2t_gemm(const s2t_gemm_args* args, void* stream);
+/* floats of workspace a split-K call needs for the two-phase (non-atomic) reduction; 0 when not applicable */
+int64_t s2t_gemm_ws_floats(const s2t_gemm_args* args);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (modules/layer_norm.py:30-35 -> torch.nn.LayerNorm, eps 1e-5).  x,y,dy,dx: [rows][cols] in

@@ -45,19 +45,24 @@ class GemmArgs(C.Structure):
         ("c_atomic", C.c_int32),
         ("colsum_a", C.c_void_p),
         ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("drop_seed", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 
 _CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "uint32_t": C.c_uint32}
 
 
+RESTYPES = {}
+
+
 def header_prototypes(path=HEADER_PATH):
-    """Parse ``int s2t_*(...);`` declarations of the header -> {name: [ctypes argtypes]}."""
+    """Parse ``int|int64_t s2t_*(...);`` declarations of the header -> {name: [ctypes argtypes]} (+ RESTYPES)."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(s2t_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
-        name, args = m.group(1), m.group(2).strip()
+    for m in re.finditer(r"\b(int|int64_t)\s+(s2t_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(2), m.group(3).strip()
+        RESTYPES[name] = _CTYPE[m.group(1)]
         argtypes = []
         if args and args != "void":
             for a in args.split(","):
@@ -83,7 +88,7 @@ def lib():
         l = C.CDLL(LIB_PATH)
         for name, argtypes in header_prototypes().items():
             fn = getattr(l, name)  # AttributeError here = header declares a symbol the library lacks
-            fn.restype = C.c_int
+            fn.restype = RESTYPES[name]
             fn.argtypes = argtypes
         _lib = l
     return _lib

@@ -205,6 +205,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
 #if S2T_DBG_EPI == 2
     if (nout >= 0) return;
 #endif
+    if (p.ws) {
+      // two-phase split-K: this split's partial tile goes to the workspace in register-native order (every wave
+      // instruction stores 1 KiB contiguous); splitk_reduce_kernel sums the splits into C
+      float* wt = p.ws + ((((int64_t)z * p.split_k + blockIdx.y) * ntiles) + (w + c.ord * G)) * (int64_t)(BM * BN);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(wt + ((i * 4 + j) * 256 + tid) * 4) = acc[i][j];
+      if constexpr (AKM) {
+        if (want_colsum && tn == 0) {  // workgroup-uniform: bias gradient stays atomic (128 floats per tile)
+          __syncthreads();
+          float* lc = reinterpret_cast<float*>(smem);
+#pragma unroll
+          for (int e = 0; e < EPB; ++e) {
+            lc[tid * EPB + e] = csum[e];
+            csum[e] = 0.f;
+          }
+          __syncthreads();
+          if (tid < 128) {
+            const int ch = tid / EPB, e = tid % EPB;
+            float sum = 0.f;
+            for (int j = 0; j < 256 / CPR_A; ++j) sum += lc[(ch + CPR_A * j) * EPB + e];
+            const int m = tm * BM + tid;
+            if (m < p.M) atomicAdd(p.colsum_a + m, p.alpha * sum);
+          }
+          __syncthreads();
+        }
+      }
+      return;
+    }
     if (p.split_k > 1 || p.c_atomic) {
       __syncthreads();  // every wave is done reading the operand buffers
       if constexpr (AKM) {
@@ -391,6 +421,52 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   }
 }
 
+// Second phase of the workspace split-K: C[m][n] += alpha * sum_s partial_s[m][n].  One workgroup per (tile,
+// accumulator fragment f = i*4+j): thread t owns the same fragment element it owned in gemm_kernel (lane map of
+// the swapped 16x16 MFMA: row = x, 4 consecutive columns at 4y).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args p, int ntiles, int tiles_n) {
+  const int tile = blockIdx.x, f = blockIdx.y, z = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, x = lane & 15, y = lane >> 4;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int z0 = z / p.zdiv, z1 = z % p.zdiv;
+  float* C = reinterpret_cast<float*>(p.C) + z0 * p.c_s0 + z1 * p.c_s1;
+  const int64_t sstride = (int64_t)ntiles * (BM * BN);
+  const float* src = p.ws + (int64_t)z * p.split_k * sstride + (int64_t)tile * (BM * BN) + (f * 256 + tid) * 4;
+  const int i = f >> 2, j = f & 3;
+  const int m = tm * BM + wm * 64 + i * 16 + x;
+  const int n = tn * BN + wn * 64 + j * 16 + 4 * y;
+  // four independent partial sums keep four 16-byte loads in flight per thread
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int s = 0;
+  for (; s + 4 <= p.split_k; s += 4) {
+    s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * sstride);
+    s1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 1) * sstride);
+    s2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 2) * sstride);
+    s3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 3) * sstride);
+  }
+  for (; s < p.split_k; ++s) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * sstride);
+  const f32x4 sum = (s0 + s1) + (s2 + s3);
+  if (m < p.M && n < p.N) {
+    float* dst = C + (int64_t)m * p.ldc + n;
+    if (n + 3 < p.N && (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
+      f32x4 c = *reinterpret_cast<f32x4*>(dst);
+      c += sum * p.alpha;
+      *reinterpret_cast<f32x4*>(dst) = c;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) dst[r] += p.alpha * sum[r];
+    }
+  }
+}
+
+static int64_t splitk_ws_floats(const s2t_gemm_args& p) {
+  if (p.split_k <= 1 || p.act == S2T_ACT_GLU) return 0;
+  const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  return (int64_t)(p.batch > 0 ? p.batch : 1) * p.split_k * tiles * (BM * BN);
+}
+
 constexpr int PFD = 2;  // K-steps of global loads in flight per workgroup
 
 template <typename TC>
@@ -431,8 +507,16 @@ int launch(const s2t_gemm_args& p, hipStream_t s) {
   const int nout = p.act == S2T_ACT_GLU ? p.N / 2 : p.N;
   const bool kt = (p.K % TileTraits<T>::BKE) != 0;
   const bool vec = epilogue_vectorisable<TC>(p, nout);
-  if (kt) return vec ? launch2<T, TC, true, true>(p, s) : launch2<T, TC, true, false>(p, s);
-  return vec ? launch2<T, TC, false, true>(p, s) : launch2<T, TC, false, false>(p, s);
+  int rc;
+  if (kt) rc = vec ? launch2<T, TC, true, true>(p, s) : launch2<T, TC, true, false>(p, s);
+  else rc = vec ? launch2<T, TC, false, true>(p, s) : launch2<T, TC, false, false>(p, s);
+  if (rc == S2T_OK && p.ws) {
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int ntiles = ((p.M + BM - 1) / BM) * tiles_n;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ntiles, 16, p.batch), dim3(256), 0, s, p, ntiles, tiles_n);
+    rc = S2T_LAUNCH_CHECK();
+  }
+  return rc;
 }
 
 }  // namespace
@@ -478,12 +562,30 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   }
   if (p.row_lens && p.row_T <= 0) return S2T_ERR_ARG;
   if (p.drop_p < 0.f || p.drop_p >= 1.f) return S2T_ERR_ARG;
+  // two-phase split-K only with a large enough workspace and when every K split is non-empty (an empty split would
+  // leave its workspace slice unwritten)
+  {
+    const int bke = p.dtype == S2T_F32 ? 32 : 64;
+    const int ktiles = (p.K + bke - 1) / bke;
+    const int per = (ktiles + p.split_k - 1) / p.split_k;
+    p.split_k = (ktiles + per - 1) / per;  // same partition without the empty trailing splits
+    const bool all_splits_busy = true;
+    const int64_t need = splitk_ws_floats(p);
+    // batches must own disjoint parts of C (the reduction is a plain read-modify-write)
+    const bool disjoint = p.batch == 1 || (p.zdiv == 1 && (p.c_s0 >= p.N || p.c_s0 >= (int64_t)p.M * p.ldc));
+    if (!(p.ws && need > 0 && p.ws_floats >= need && all_splits_busy && disjoint && ((uintptr_t)p.ws % 16) == 0)) p.ws = nullptr;
+  }
   hipStream_t s = (hipStream_t)stream;
-  if (p.dtype == S2T_BF16 && p.K % 64 == 0 && p.K > 0 && use_ring()) {
+  if (p.dtype == S2T_BF16 && p.K % 64 == 0 && p.K > 0 && use_ring() && !p.ws) {
     const int rc = s2t_gemm_ring_launch(p, stream);
     if (rc != S2T_ERR_UNSUPPORTED) return rc;
   }
   if (p.dtype == S2T_F32) return launch<float, float>(p, s);
   if (p.c_dtype == S2T_F32) return launch<bf16_t, float>(p, s);
   return launch<bf16_t, bf16_t>(p, s);
+}
+
+extern "C" int64_t s2t_gemm_ws_floats(const s2t_gemm_args* a) {
+  if (!a || a->c_dtype != S2T_F32 || a->M <= 0 || a->N <= 0) return 0;
+  return splitk_ws_floats(*a);
 }

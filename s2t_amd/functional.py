@@ -117,9 +117,9 @@ def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
     tiles = ((Nout + 127) // 128) * ((Kin + 127) // 128)
     bke = 64 if dY.dtype == torch.bfloat16 else 32
     ktiles = (M + bke - 1) // bke
-    # about 2 workgroups per CU in total, but never fewer than 4 K-steps per workgroup (the atomics of a
-    # 128x128 fp32 tile cost about as much as 4 K-steps)
-    split = max(1, min((ktiles + 3) // 4, (512 + tiles - 1) // tiles))
+    # about 2 workgroups per CU in total, but never fewer than 8 K-steps per workgroup: storing and re-reading a
+    # 128x128 fp32 partial tile costs about as much as a few K-steps (measured: tools/wgrad_bench.py)
+    split = max(1, min((ktiles + 7) // 8, (512 + tiles - 1) // tiles))
     K.gemm(dY, X, dW, M=Nout, N=Kin, K=M, lda=ldy, ldb=ldx, ldc=Kin, a_kmajor=True, b_kmajor=True, alpha=alpha,
            split_k=split, c_atomic=True, colsum_a=db)
 

@@ -31,7 +31,7 @@ def gemm(
     preact: Optional[torch.Tensor] = None, ldp=0, p_s=(0, 0),
     dact_z: Optional[torch.Tensor] = None, ldz=0, dact=None,
     row_lens: Optional[torch.Tensor] = None, row_T=0, split_k=1, c_atomic=False,
-    colsum_a: Optional[torch.Tensor] = None, drop=None,
+    colsum_a: Optional[torch.Tensor] = None, drop=None, splitk_workspace=True,
 ):
     """Raw s2t_gemm call: C = epilogue(A_op[M,K] @ B_op[K,N]); see include/s2t_hip.h."""
     L.require_cuda(A, B, out, bias, residual, preact, dact_z, row_lens)
@@ -72,6 +72,11 @@ def gemm(
         a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), drop[1].data_ptr(), int(drop[2])
     if colsum_a is not None:
         assert colsum_a.dtype == torch.float32 and a_kmajor
+    if split_k > 1 and splitk_workspace:
+        need = L.lib().s2t_gemm_ws_floats(C.byref(a))
+        if need > 0:
+            ws = _scratch("gemm_splitk", need, out.device)
+            a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -101,6 +106,16 @@ LN_REPLICAS = 32
 
 
 _WS = {}
+
+
+def _scratch(tag, n, device):
+    """Uninitialised fp32 scratch that only grows (split-K partial tiles); one buffer per tag and device."""
+    key = (tag, str(device))
+    t = _WS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(n, dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
 
 
 def _workspace(tag, n, device):
