@@ -144,6 +144,22 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        uint32_t drop_site, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Feature front-end (dataloader stage of the reference, here on the device)
+ *   s2t_fbank: data/audio/audio_utils.py:59-79 (_get_torchaudio_fbank -> torchaudio.compliance.kaldi.fbank with its
+ *     defaults: snip_edges, dither 0, DC removal, pre-emphasis, window, zero-pad to nfft, power spectrum, mel, log).
+ *     wave: [B][wave_stride] fp32 in int16 range (audio_utils.py:31-32), n_samples[B]; feat: [B][max_frames][n_mel]
+ *     fp32, rows >= 1 + (n_samples - win) / shift are zero-filled (collater padding).  window: [win]; mel_t:
+ *     [nfft/2+1][n_mel] (transposed mel bank matrix); both built by the host (s2t_amd/audio.py).
+ *   s2t_utterance_cmvn: data/audio/feature_transforms/utterance_cmvn.py:31-45 over the first n_frames[b] rows of
+ *     each utterance; x, y: [B][stride_b] fp32 with rows of C features; may alias.
+ * ------------------------------------------------------------------------------------------------ */
+int s2t_fbank(const float* wave, int64_t wave_stride, const int32_t* n_samples, float* feat, int64_t feat_stride_b,
+              int max_frames, int B, int win, int shift, int nfft, const float* window, const float* mel_t, int n_mel,
+              float preemph, int remove_dc, float log_floor, void* stream);
+int s2t_utterance_cmvn(const float* x, float* y, const int32_t* n_frames, int64_t stride_b, int B, int C, int norm_means,
+                       int norm_vars, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Elementwise / gather pieces of S2TTransformerEncoder.forward and TransformerDecoder
  *   s2t_add_positions : x = scale*x + (t < lens[b] ? tab[t+pos_offset] : 0)       s2t_transformer.py:1773-1787
  *   s2t_mask_rows     : zero padded frames in place                                s2t_transformer.py:1765,1828-1836

@@ -6,7 +6,9 @@ path named in BASELINE.json.  Only ``tests/``, ``__graft_entry_
 package ``s2t_amd`` never imports it and has no CPU fallback.
 
 Pinning: every function here is checked against golden vectors dumped from the reference itself
-(``oracle/gen_golden.py`` -> ``tests/golden/*.npz``) by ``tests/test_oracle_golden.py``.
+(``oracle/gen_golden.py`` -> ``tests/golden/*.npz``) by ``tests/test_oracle_golden.py`` — EXCEPT ``kaldi_fbank``
+(row a1): the reference delegates it to torchaudio.compliance.kaldi.fbank, a third-party dependency that is neither in
+/root/reference nor in this image, so that function restates torchaudio's published algorithm and its PARITY IS UNPINNED.
 
 All tensors are batch-major ``(B, T, C)`` inside the oracle; the reference is time-major between
 modules (``(T, B, C)``), so boundary outputs are transposed back where the reference returns them.
@@ -439,6 +441,64 @@ def utterance_cmvn(x, norm_means=True, norm_vars=True):
         var = sq / x.size(0) - mean**2
         y = y / torch.sqrt(torch.clamp_min(var, 1e-10))
     return y
+
+
+# ----------------------------------------------------------------------------------------------
+# Kaldi-compatible log-mel filterbank (dataloader stage, a1) — PARITY UNPINNED
+# ----------------------------------------------------------------------------------------------
+def kaldi_mel_banks(num_bins, padded_window_size, sample_freq, low_freq=20.0, high_freq=0.0):
+    """torchaudio.compliance.kaldi.get_mel_banks (torchaudio is a third-party dependency absent from /root/reference and
+    from this image; this restates its published algorithm, no VTLN): triangular filters equally spaced on
+    mel(f) = 1127 ln(1 + f/700) between low_freq and nyquist + high_freq; returns (num_bins, padded/2 + 1) with the
+    Nyquist column zero (torchaudio pads one zero column)."""
+    import numpy as np
+    num_fft_bins = padded_window_size // 2
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    fft_bin_width = sample_freq / padded_window_size
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    mel_low, mel_high = mel(low_freq), mel(high_freq)
+    delta = (mel_high - mel_low) / (num_bins + 1)
+    b = np.arange(num_bins, dtype=np.float64)[:, None]
+    left, center, right = mel_low + b * delta, mel_low + (b + 1.0) * delta, mel_low + (b + 2.0) * delta
+    m = mel(fft_bin_width * np.arange(num_fft_bins, dtype=np.float64))[None, :]
+    up = (m - left) / (center - left)
+    down = (right - m) / (right - center)
+    banks = np.maximum(0.0, np.minimum(up, down))
+    return np.concatenate([banks, np.zeros((num_bins, 1))], 1)
+
+
+def povey_window(n):
+    """torchaudio.compliance.kaldi._feature_window_function('povey'): hann(n, periodic=False) ** 0.85."""
+    import numpy as np
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n, dtype=np.float64) / (n - 1))) ** 0.85
+
+
+def kaldi_fbank(wave, sample_rate=16000, num_mel_bins=80, frame_length_ms=25.0, frame_shift_ms=10.0, preemph=0.97,
+                low_freq=20.0, high_freq=0.0):
+    """data/audio/audio_utils.py:59-79 -> torchaudio.compliance.kaldi.fbank(waveform (int16 range), num_mel_bins=80,
+    sample_frequency=sr) with torchaudio's defaults: snip_edges, dither 0, remove_dc_offset, pre-emphasis 0.97 (first
+    sample against itself), povey window, zero-pad to the next power of two, power spectrum, mel banks (20 Hz ..
+    Nyquist), log(max(., float32 eps)).  float64 numpy; wave: 1-D array.  Returns (T, num_mel_bins)."""
+    import numpy as np
+    wave = np.asarray(wave, dtype=np.float64)
+    win = int(sample_rate * frame_length_ms * 0.001)
+    shift = int(sample_rate * frame_shift_ms * 0.001)
+    padded = 1 << (win - 1).bit_length()
+    if wave.shape[0] < win:
+        return np.zeros((0, num_mel_bins))
+    T = 1 + (wave.shape[0] - win) // shift
+    idx = np.arange(T)[:, None] * shift + np.arange(win)[None, :]
+    fr = wave[idx]
+    fr = fr - fr.mean(1, keepdims=True)
+    prev = np.concatenate([fr[:, :1], fr[:, :-1]], 1)
+    fr = fr - preemph * prev
+    fr = fr * povey_window(win)[None, :]
+    spec = np.fft.rfft(fr, n=padded, axis=1)
+    power = spec.real ** 2 + spec.imag ** 2
+    mel = power @ kaldi_mel_banks(num_mel_bins, padded, float(sample_rate), low_freq, high_freq).T
+    return np.log(np.maximum(mel, np.finfo(np.float32).eps))
 
 
 # ----------------------------------------------------------------------------------------------

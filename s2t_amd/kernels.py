@@ -300,3 +300,18 @@ def attn_fused_bwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, dO, o_sb, o_s
           dO.data_ptr(), o_sb, o_sr, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _ptr(dbd),
           ldb, B, H, Tq, Tk, dkd, _ptr(key_lens), int(causal), scale, _ptr(pos_p), p_sr, _ptr(pos_u), _ptr(pos_v), dp, ds,
           dsite)
+
+
+def fbank(wave, n_samples, feat, max_frames, win, shift, nfft, window, mel_t, preemph=0.97, remove_dc=True,
+          log_floor=1.1920928955078125e-07):
+    B = wave.shape[0]
+    assert wave.dtype == torch.float32 and feat.dtype == torch.float32 and n_samples.dtype == torch.int32
+    _call("s2t_fbank", wave.data_ptr(), wave.stride(0), n_samples.data_ptr(), feat.data_ptr(), feat.stride(0), max_frames, B,
+          win, shift, nfft, window.data_ptr(), mel_t.data_ptr(), mel_t.shape[1], preemph, int(remove_dc), log_floor)
+
+
+def utterance_cmvn(x, y, n_frames, norm_means=True, norm_vars=True):
+    B, T, Cf = x.shape
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and n_frames.dtype == torch.int32 and x.is_contiguous()
+    _call("s2t_utterance_cmvn", x.data_ptr(), y.data_ptr(), n_frames.data_ptr(), T * Cf, B, Cf, int(norm_means),
+          int(norm_vars))

@@ -1,0 +1,104 @@
+"""Feature front-end.
+
+CPU: properties of the oracle's Kaldi-fbank restatement (a1 is third-party in the reference: parity unpinned, so the
+oracle is anchored on the algorithm's own invariants) and the CMVN oracle against the reference's formula.
+GPU: ``s2t_fbank`` / ``s2t_utterance_cmvn`` through the C-ABI against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2t_oracle as O
+
+
+def _tone(freq, n=16000, sr=16000, amp=0.3):
+    t = np.arange(n) / sr
+    return amp * np.sin(2 * np.pi * freq * t) * 32768.0
+
+
+def test_oracle_fbank_frame_count_and_shapes():
+    # snip_edges: 1 + (N - 400) // 160 frames of 80 bins; shorter than one window -> no frames
+    assert O.kaldi_fbank(np.zeros(399)).shape == (0, 80)
+    assert O.kaldi_fbank(np.zeros(400)).shape == (1, 80)
+    assert O.kaldi_fbank(np.zeros(16000)).shape == (98, 80)
+    assert O.kaldi_fbank(np.zeros(16000 + 79)).shape == (98, 80)
+    assert O.kaldi_fbank(np.zeros(16000 + 80)).shape == (99, 80)
+    # silence -> log(float32 eps) everywhere
+    np.testing.assert_allclose(O.kaldi_fbank(np.zeros(1000)), np.log(np.finfo(np.float32).eps))
+
+
+def test_oracle_fbank_tone_lands_in_its_mel_bin_and_dc_is_removed():
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    lo, hi = mel(20.0), mel(8000.0)
+    delta = (hi - lo) / 81
+    for freq in (300.0, 1000.0, 3000.0, 6000.0):
+        f = O.kaldi_fbank(_tone(freq))
+        centre = lo + (f[20].argmax() + 1) * delta
+        assert abs(centre - mel(freq)) <= delta, freq
+    w = _tone(1000.0)
+    np.testing.assert_allclose(O.kaldi_fbank(w + 5000.0), O.kaldi_fbank(w), atol=1e-6)  # remove_dc_offset
+    # energies scale quadratically with the amplitude: +2 log 2 per doubling
+    np.testing.assert_allclose(O.kaldi_fbank(2 * w)[:, 20:40], O.kaldi_fbank(w)[:, 20:40] + 2 * np.log(2.0), atol=1e-6)
+
+
+def test_oracle_mel_banks_partition():
+    mb = O.kaldi_mel_banks(80, 512, 16000.0)
+    assert mb.shape == (80, 257) and (mb >= 0).all() and mb[:, 256].max() == 0.0
+    # neighbouring triangles overlap so that interior FFT bins get total weight 1
+    tot = mb.sum(0)
+    k = np.arange(257) * 16000.0 / 512
+    inner = (k > 100) & (k < 7700)  # between the first and the last filter centre (42 Hz .. 7745 Hz)
+    np.testing.assert_allclose(tot[inner], 1.0, atol=1e-9)
+
+
+def test_oracle_cmvn_formula():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(57, 80, generator=g) * 3 + 1.5
+    y = O.utterance_cmvn(x)
+    xn = x.numpy().astype(np.float64)
+    mean = xn.mean(0)
+    std = np.sqrt(np.maximum((xn ** 2).sum(0) / xn.shape[0] - mean ** 2, 1e-10))
+    np.testing.assert_allclose(y.numpy(), (xn - mean) / std, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_fbank_kernel_matches_oracle():
+    from s2t_amd import audio as A
+    rng = np.random.default_rng(3)
+    lens = [16000, 12345, 400, 399, 8000]
+    waves = []
+    for i, n in enumerate(lens):
+        w = _tone(200.0 * (i + 1), n) + rng.normal(0, 300.0, n) + 40.0 * i
+        waves.append(torch.from_numpy(w.astype(np.float32)).cuda())
+    feat, n_frames = A.fbank_batch(waves, sample_rate=16000, n_bins=80)
+    torch.cuda.synchronize()
+    assert feat.shape == (5, 98, 80)
+    assert n_frames.tolist() == [98, 75, 1, 0, 48]
+    for i, n in enumerate(lens):
+        ref = O.kaldi_fbank(waves[i].cpu().numpy().astype(np.float64))
+        got = feat[i].cpu().numpy()
+        T = ref.shape[0]
+        # fp32 FFT / mel accumulation vs float64: log-mel values of O(10), agreement to ~1e-4 absolute
+        np.testing.assert_allclose(got[:T], ref, rtol=0, atol=2e-3)
+        assert np.abs(got[T:]).max(initial=0.0) == 0.0  # collater padding
+    single = A.get_torchaudio_fbank(waves[1].cpu().numpy(), 16000, n_bins=80)
+    np.testing.assert_allclose(single, feat[1, :75].cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_cmvn_kernel_matches_oracle():
+    from s2t_amd import audio as A
+    g = torch.Generator().manual_seed(1)
+    B, T, Cf = 4, 300, 80
+    x = torch.randn(B, T, Cf, generator=g) * 4 + 2
+    n = torch.tensor([300, 123, 1, 77], dtype=torch.int32)
+    for b in range(B):
+        x[b, n[b]:] = 0
+    for means, vars_ in ((True, True), (True, False), (False, True)):
+        tr = A.UtteranceCMVN(means, vars_)
+        y = tr.apply_batch(x.cuda(), n.cuda()).cpu()
+        for b in range(B):
+            ref = O.utterance_cmvn(x[b, :n[b]].double(), means, vars_)
+            np.testing.assert_allclose(y[b, :n[b]].numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+            assert y[b, n[b]:].abs().max().item() == 0.0 if n[b] < T else True
+    one = A.get_audio_feature_transform("utterance_cmvn").from_config_dict({"norm_vars": True})(x[1, :123].numpy())
+    np.testing.assert_allclose(one, O.utterance_cmvn(x[1, :123].double()).numpy(), rtol=1e-4, atol=1e-4)
