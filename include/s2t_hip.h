@@ -88,6 +88,8 @@ typedef struct s2t_gemm_args {
 int s2t_gemm(const s2t_gemm_args* args, void* stream);
 /* floats of workspace a split-K call needs for the two-phase (non-atomic) reduction; 0 when not applicable */
 int64_t s2t_gemm_ws_floats(const s2t_gemm_args* args);
+/* writes the (demangled) name of the kernel s2t_gemm would launch for args, as a profiler prints it */
+int s2t_gemm_describe(const s2t_gemm_args* args, char* buf, int buflen);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (modules/layer_norm.py:30-35 -> torch.nn.LayerNorm, eps 1e-5).  x,y,dy,dx: [rows][cols] in
@@ -102,7 +104,9 @@ int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
                       float* rstd, int64_t rows, int cols, float eps, const int32_t* row_lens, int row_T, void* stream);
 int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* dy, const float* mean,
                       const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int replicas, int64_t rows,
-                      int cols, const int32_t* row_lens, int row_T, void* stream);
+                      int cols, const int32_t* row_lens, int row_T,
+                      const void* dres /* optional [rows][cols]: dx += dres (gradient of the residual branch of a pre-LN block) */,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention probabilities from raw scores (fp32 in, `p_dtype` out), one row per (z, query):

@@ -218,9 +218,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int x = lane & 15, y = lane >> 4;
   float* scratch = reinterpret_cast<float*>(lds + 16384) + w * BAND * SC;
-  const int z = blockIdx.y;
+  const int z = blockIdx.x;  // (utterance, head) fastest: the row blocks of one (b, h) share an XCD's L2 (K/V re-reads)
   const int b = z / a.H, h = z % a.H;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.y * 64;
   const int q0w = q0 + 16 * w;
   const int i = q0w + x;
   const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int x = lane & 15, y = lane >> 4;
   float* scratch = reinterpret_cast<float*>(lds + 16384) + w * BAND * SC;
-  const int z = blockIdx.y;
+  const int z = blockIdx.x;  // (utterance, head) fastest: the row blocks of one (b, h) share an XCD's L2 (K/V re-reads)
   const int b = z / a.H, h = z % a.H;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.y * 64;
   const int q0w = q0 + 16 * w;
   const int i = q0w + x;
   const int ic = i < a.Tq ? i : a.Tq - 1;
@@ -482,9 +482,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   float* scratch = reinterpret_cast<float*>(lds + 3 * 8192) + w * 16 * SC2;
   float* lse_s = reinterpret_cast<float*>(lds + 3 * 8192 + 4 * 16 * SC2 * 4);
   float* del_s = lse_s + 64;
-  const int z = blockIdx.y;
+  const int z = blockIdx.x;  // (utterance, head) fastest: the row blocks of one (b, h) share an XCD's L2 (K/V re-reads)
   const int b = z / a.H, h = z % a.H;
-  const int k0 = blockIdx.x * 64;
+  const int k0 = blockIdx.y * 64;
   const int k0w = k0 + 16 * w;
   const int j = k0w + x;                       // this lane's key
   const int jc = j < a.Tk ? j : a.Tk - 1;
@@ -628,7 +628,7 @@ extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, con
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.key_lens = key_lens; a.causal = causal; a.scale = scale;
   a.rel = pos_p != nullptr; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.pos_u = pos_u; a.pos_v = pos_v;
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site;
-  dim3 grid((Tq + 63) / 64, B * H), block(256);
+  dim3 grid(B * H, (Tq + 63) / 64), block(256);
   if (a.rel) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
   return S2T_LAUNCH_CHECK();
@@ -659,7 +659,7 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
   const int64_t groups = (int64_t)B * Tq * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, (const bf16_t*)o,
                      (const bf16_t*)dO, o_sb, o_sr, delta, B, H, Tq);
-  dim3 gq((Tq + 63) / 64, B * H), gk((Tk + 63) / 64, B * H), block(256);
+  dim3 gq(B * H, (Tq + 63) / 64), gk(B * H, (Tk + 63) / 64), block(256);
   if (a.rel) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, block, 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, block, 0, s, a);

@@ -93,13 +93,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // Counter-based dropout RNG: keep(seed, site, element index) is a pure function, so the backward pass regenerates
-// the mask instead of storing it.  splitmix64 finaliser over (seed * golden + site) ^ idx.
+// the mask instead of storing it.  Two rounds of a 32-bit multiply/xor-shift finaliser ("lowbias32") over the low
+// words of (key, index), the high words injected between the rounds: 64-bit multiplies (splitmix64) cost three times
+// the VALU slots, and the fused GEMM epilogues that draw 8 masks per 16-byte store are VALU-issue bound.
+__device__ __forceinline__ uint32_t s2t_mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ uint32_t s2t_rand_u32(uint64_t key, uint64_t idx) {
-  uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  uint32_t x = s2t_mix32((uint32_t)idx ^ (uint32_t)key);
+  x += (uint32_t)(idx >> 32) * 0x9E3779B9U + (uint32_t)(key >> 32);
+  return s2t_mix32(x);
 }
 __device__ __forceinline__ uint64_t s2t_drop_key(const uint64_t* seed_ptr, uint32_t site) {
   const uint64_t seed = seed_ptr ? *seed_ptr : 0ull;

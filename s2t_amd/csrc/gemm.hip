@@ -18,6 +18,7 @@
 //                      swz(k) = 2*((k&3) | ((k>>3)&1)<<2): the 8 k-rows one half-wave touches in a
 //                      ds_read_b64_tr_b16 land on 8 distinct 32-B column pairs = all 64 banks once.
 //                      f32: [k][128 cols] 512 B per k-row, plain; read with ds_read_b32.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -588,4 +589,23 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
 extern "C" int64_t s2t_gemm_ws_floats(const s2t_gemm_args* a) {
   if (!a || a->c_dtype != S2T_F32 || a->M <= 0 || a->N <= 0) return 0;
   return splitk_ws_floats(*a);
+}
+
+// The demangled name of the kernel s2t_gemm launches for these arguments, exactly as rocprofv3 prints it, so that a
+// host-side timing table and a kernel trace can be joined on it (bench.py roofline leg).
+extern "C" int s2t_gemm_describe(const s2t_gemm_args* a, char* buf, int buflen) {
+  if (!a || !buf || buflen <= 0) return S2T_ERR_ARG;
+  const bool f32 = a->dtype == S2T_F32;
+  const bool cf32 = a->c_dtype == S2T_F32;
+  const bool glu = a->act == S2T_ACT_GLU;
+  const int nout = glu ? a->N / 2 : a->N;
+  const bool kt = (a->K % (f32 ? 32 : 64)) != 0;
+  const bool vec = cf32 ? epilogue_vectorisable<float>(*a, nout) : epilogue_vectorisable<bf16_t>(*a, nout);
+  const bool ak = a->a_kmajor != 0, bk = a->b_kmajor != 0;
+  const char* t = f32 ? "float" : "unsigned short";
+  const char* tc = cf32 ? "float" : "unsigned short";
+  auto b = [](bool v) { return v ? "true" : "false"; };
+  const int n = snprintf(buf, buflen, "gemm_kernel<%s, %s, %s, %s, %s, %d, %s, %s>", t, b(ak), b(bk), tc, b(glu),
+                         (ak && !bk) ? 2 : PFD, b(kt), b(vec));
+  return (n > 0 && n < buflen) ? S2T_OK : S2T_ERR_ARG;
 }

@@ -76,7 +76,7 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const T* __restrict__ dy, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ ws, int replicas,
+                                                     const T* __restrict__ dres, float* __restrict__ ws, int replicas,
                                                      int64_t rows, int cols, const int32_t* __restrict__ row_lens,
                                                      int row_T) {
   __shared__ float red[2][4][NV * 256];
@@ -129,6 +129,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
           float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = rs * (dg[i][r] - s1 - xh[i][r] * s2);
+          if (dres) {  // gradient arriving at x through the residual branch, added here instead of by a separate kernel
+            float q[4];
+            ld4_as_f32<T>(dres + row * cols + c, q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += q[r];
+          }
           st4_from_f32<T>(dx + row * cols + c, o);
         }
       }
@@ -204,7 +210,8 @@ extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, c
 
 extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* dy, const float* mean,
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int replicas,
-                                 int64_t rows, int cols, const int32_t* row_lens, int row_T, void* stream) {
+                                 int64_t rows, int cols, const int32_t* row_lens, int row_T, const void* dres,
+                                 void* stream) {
   if (!x || !gamma || !dy || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || replicas <= 0 || rows < 0 || cols <= 0)
     return S2T_ERR_ARG;
   if (cols % 4 || cols > LN_MAX_VEC * 256) return S2T_ERR_UNSUPPORTED;
@@ -214,9 +221,9 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, c
   dim3 grid((unsigned)nb), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    LN_DISPATCH(ln_bwd_kernel, float, (const float*)x, gamma, (const float*)dy, mean, rstd, (float*)dx, ws, replicas, rows, cols, row_lens, row_T);
+    LN_DISPATCH(ln_bwd_kernel, float, (const float*)x, gamma, (const float*)dy, mean, rstd, (float*)dx, (const float*)dres, ws, replicas, rows, cols, row_lens, row_T);
   else if (dtype == S2T_BF16)
-    LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean, rstd, (bf16_t*)dx, ws, replicas, rows, cols, row_lens, row_T);
+    LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean, rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, cols, row_lens, row_T);
   else return S2T_ERR_DTYPE;
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, ws, replicas, cols, dgamma, dbeta);
   return S2T_LAUNCH_CHECK();

@@ -128,10 +128,12 @@ def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
 # LayerNorm
 # ------------------------------------------------------------------------------------------------
 class LayerNormFn(torch.autograd.Function):
-    """modules/layer_norm.py:30-35; optional fused padded-row mask on the output."""
+    """modules/layer_norm.py:30-35; optional fused padded-row mask on the output.
+    ``fork``: also return x itself for the residual branch of a pre-LN block (x + f(LN(x))); the two gradients that
+    meet at x are then added inside the LayerNorm backward kernel instead of by a separate elementwise pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, lens, T):
+    def forward(ctx, x, gamma, beta, lens, T, fork):
         rows, cols = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -139,21 +141,25 @@ class LayerNormFn(torch.autograd.Function):
         K.layernorm_fwd(x, gamma.data, beta.data, y, mean, rstd, rows, cols, 1e-5, lens, T)
         ctx.save_for_backward(x, mean, rstd)
         ctx.gamma, ctx.beta, ctx.lens, ctx.T = gamma, beta, lens, T
+        if fork:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, mean, rstd = ctx.saved_tensors
         rows, cols = x.shape
         dx = torch.empty_like(x)
+        if dres is not None:
+            dres = dres.contiguous()
         K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, ctx.gamma.grad, ctx.beta.grad, rows, cols,
-                        ctx.lens, ctx.T)
+                        ctx.lens, ctx.T, dres)
         _ready(ctx.gamma, ctx.beta)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, lens=None, T=0):
-    return LayerNormFn.apply(x, gamma, beta, lens, T)
+def layer_norm(x, gamma, beta, lens=None, T=0, fork=False):
+    return LayerNormFn.apply(x, gamma, beta, lens, T, fork)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -16,10 +16,11 @@ def _ptr(t: Optional[torch.Tensor]):
 GEMM_PROFILE = None
 
 
-def gemm_symbol(dtype, a_kmajor, b_kmajor, c_dtype, glu):
-    t = {torch.float32: "f32", torch.bfloat16: "bf16"}
-    return "gemm_kernel<%s,%s,%s,%s,%s>" % (t[dtype], "AK" if a_kmajor else "AR", "BK" if b_kmajor else "BR", t[c_dtype],
-                                            "glu" if glu else "lin")
+def gemm_symbol(args):
+    """Name of the kernel s2t_gemm launches for ``args`` exactly as rocprofv3 prints it (s2t_gemm_describe)."""
+    buf = C.create_string_buffer(160)
+    L.check(L.lib().s2t_gemm_describe(C.byref(args), buf, 160), "s2t_gemm_describe")
+    return buf.value.decode()
 
 
 def gemm(
@@ -82,8 +83,7 @@ def gemm(
         e0.record()
         L.check(L.lib().s2t_gemm(C.byref(a), L.stream_ptr()), "s2t_gemm")
         e1.record()
-        GEMM_PROFILE.append((gemm_symbol(A.dtype, a_kmajor, b_kmajor, out.dtype, act == "glu"),
-                             2.0 * M * N * K * max(batch, 1), e0, e1, (M, N, K, batch)))
+        GEMM_PROFILE.append((gemm_symbol(a), 2.0 * M * N * K * max(batch, 1), e0, e1, (M, N, K, batch)))
         return out
     L.check(L.lib().s2t_gemm(C.byref(a), L.stream_ptr()), "s2t_gemm")
     return out
@@ -128,11 +128,11 @@ def _workspace(tag, n, device):
     return t
 
 
-def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0):
+def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0, dres=None):
     ws = _workspace("ln", LN_REPLICAS * 2 * cols, x.device)
     _call("s2t_layernorm_bwd", L.dtype_id(x.dtype), x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), mean.data_ptr(),
           rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), LN_REPLICAS, rows, cols,
-          _ptr(row_lens), row_T)
+          _ptr(row_lens), row_T, _ptr(dres))
 
 
 def _drop3(drop):

@@ -40,8 +40,10 @@ class LayerNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(dim))
         self.eps = eps
 
-    def forward(self, x2d, lens=None, T=0):
-        return Fn.layer_norm(x2d, self.weight, self.bias, lens, T)
+    def forward(self, x2d, lens=None, T=0, fork=False):
+        """``fork=True`` returns ``(LN(x), x)``: use the second value as the residual input of the block (see
+        functional.LayerNormFn)."""
+        return Fn.layer_norm(x2d, self.weight, self.bias, lens, T, fork)
 
 
 class Linear(nn.Module):
@@ -279,16 +281,18 @@ class S2TTransformerEncoderLayer(nn.Module):
         """x: [B*T, d].  ``mask_output``: zero padded frames of the result (the NEXT layer's layer_padding_mask)."""
         B, T, lens = c.B, c.T, c.lens
         if self.macaron_norm is not None:
-            x = self.macaron_ffn(self.macaron_norm(x), x, self.ffn_scale)
-        y = self.self_attn_layer_norm(x)
+            y, x = self.macaron_norm(x, fork=True)
+            x = self.macaron_ffn(y, x, self.ffn_scale)
+        y, x = self.self_attn_layer_norm(x, fork=True)
         if self.attn_type == "rel_pos":
             x = self.self_attn(y, x, B, T, lens, c.pos_tab)
         else:
             x = self.self_attn(y, None, x, B, T, T, lens)
         if self.conv_module is not None:
-            y = self.conv_norm(x, lens, T)  # conv input mask fused (convolution.py:86-88)
+            y, x = self.conv_norm(x, lens, T, fork=True)  # conv input mask fused (convolution.py:86-88)
             x = self.conv_module(y, x, B, T, lens)
-        x = self.ffn(self.ffn_norm(x), x, self.ffn_scale)
+        y, x = self.ffn_norm(x, fork=True)
+        x = self.ffn(y, x, self.ffn_scale)
         if self.final_norm is not None:
             x = self.final_norm(x, lens if mask_output else None, T)
         elif mask_output:
@@ -366,9 +370,12 @@ class TransformerDecoderLayer(nn.Module):
         self.encoder_attn.out_dropout = self.dropout_p
 
     def forward(self, x, mem, B, U, Tm, self_lens, mem_lens):
-        x = self.self_attn(self.self_attn_layer_norm(x), None, x, B, U, U, self_lens, causal=True)
-        x = self.encoder_attn(self.encoder_attn_layer_norm(x), mem, x, B, U, Tm, mem_lens)
-        return Fn.ffn(self.final_layer_norm(x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+        y, x = self.self_attn_layer_norm(x, fork=True)
+        x = self.self_attn(y, None, x, B, U, U, self_lens, causal=True)
+        y, x = self.encoder_attn_layer_norm(x, fork=True)
+        x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens)
+        y, x = self.final_layer_norm(x, fork=True)
+        return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
                       self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
 
 

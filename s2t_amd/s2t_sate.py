@@ -57,8 +57,10 @@ class TransformerEncoderLayer(nn.Module):
         self.activation_fn = getattr(args, "activation_fn", "relu")
 
     def forward(self, x, B, T, lens):
-        x = self.self_attn(self.self_attn_layer_norm(x), None, x, B, T, T, lens)
-        return Fn.ffn(self.final_layer_norm(x), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+        y, x = self.self_attn_layer_norm(x, fork=True)
+        x = self.self_attn(y, None, x, B, T, T, lens)
+        y, x = self.final_layer_norm(x, fork=True)
+        return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
                       self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
 
 

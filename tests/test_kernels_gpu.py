@@ -59,6 +59,12 @@ def test_layernorm_fwd_bwd(dtype, cols):
         close(dx, xr.grad, dtype, 2)
         close(dg - 1, wr.grad, dtype, 8)
         close(db - 1, br.grad, dtype, 8)
+        # fused residual-branch gradient: dx = LN-backward(dy) + dres
+        dres = rnd((rows, cols), dtype, g)
+        dx2 = torch.empty_like(xd)
+        dg2, db2 = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+        K.layernorm_bwd(xd, w.to(DEV), dy.to(DEV), mean, rstd, dx2, dg2, db2, rows, cols, ld, T, dres.to(DEV))
+        close(dx2, xr.grad + dres.float(), dtype, 2)
 
 
 @pytest.mark.parametrize("dtype", DT)

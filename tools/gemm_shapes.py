@@ -30,4 +30,4 @@ for sym, fl, e0, e1, shape in prof:
 tot = sum(a[1] for a in agg.values())
 print("step %.2f ms, gemm %.2f ms" % (t0.elapsed_time(t1), tot * 1e3))
 for (sym, shape), (fl, sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print("%-38s M,N,K,b=%-24s n=%3d avg %7.1f us  tot %6.2f ms  %6.1f TF/s" % (sym[12:-1], shape, n, sec / n * 1e6, sec * 1e3, fl / sec / 1e12))
+    print("%-38s M,N,K,b=%-24s n=%3d avg %7.1f us  tot %6.2f ms  %6.1f TF/s" % (sym[12:-1].replace("unsigned short", "bf16").replace("float", "f32"), shape, n, sec / n * 1e6, sec * 1e3, fl / sec / 1e12))
