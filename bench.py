@@ -199,10 +199,40 @@ def main():
         sym, (fl, sec, cnt) = dom
         peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
         gemm_total = sum(v[1] for v in agg.values())
+        # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the per-launch figure comes
+        # from the committed rocprofv3 --pmc passes of this same command (tools/pmc.sh + tools/pmc_traffic.py)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                for row in json.load(f)["kernels"]:
+                    if sym in row["kernel"]:
+                        traffic = row["hbm_bytes_per_launch"]
+                        break
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "mfma", "kernel": sym, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                    "frac": fl / sec / peak, "traffic": None, "launches_per_step": cnt,
+                    "frac": fl / sec / peak, "traffic": traffic, "launches_per_step": cnt,
                     "avg_launch_us": sec / cnt * 1e6, "all_gemm_ms_per_step": gemm_total * 1e3,
                     "all_gemm_tflops": sum(v[0] for v in agg.values()) / gemm_total / 1e12}
+        # encoder-forward-only fraction of the MFMA roofline (18.0 MFLOP per input frame for the 12-layer
+        # Conformer encoder, 9.7 for the Transformer one; + 1.28 with the CTC head), eval mode, no autograd
+        model.eval()
+        ni = sample["net_input"]
+        with torch.no_grad():
+            for _ in range(2):
+                model.encoder(ni["src_tokens"], ni["src_lengths"])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                model.encoder(ni["src_tokens"], ni["src_lengths"])
+            e1.record()
+            torch.cuda.synchronize()
+        model.train()
+        enc_s = e0.elapsed_time(e1) * 1e-3 / 5
+        per_frame = (18.0e6 if conformer else 9.7e6) * (args.enc_layers / 12.0) + 1.28e6
+        enc_flop = per_frame * args.batch * args.frames
+        roofline["encoder_fwd"] = {"ms": enc_s * 1e3, "tflops": enc_flop / enc_s / 1e12, "frac": enc_flop / enc_s / peak,
+                                   "flop_per_input_frame": per_frame}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, V, conformer)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): tools/kstats.sh <outdir> <nsteps_total> -- bench args...
+# rocprofv3 --kernel-trace --stats of `python bench.py <args>`; prints the per-step kernel table.
 out=$1; n=$2; shift 3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$out -- python bench.py "$@" > gpurun_out/${out}_bench.log 2>&1
