@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(
   TP* pd = Pdrop ? Pdrop + row * ldP : nullptr;
   const uint64_t key = pd ? s2t_drop_key(drop_seed, drop_site) : 0ull;
   const uint32_t th = s2t_drop_thresh(drop_p);
-  const float dinv = 1.f / (1.f - drop_p);
+  const float dinv = s2t_drop_scale(drop_p);
 #pragma unroll
   for (int k = 0; k < NPL; ++k) {
     const int j = lane + 64 * k;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const TP* __restr
   float dot = 0.f;
   const uint64_t key = drop_p > 0.f ? s2t_drop_key(drop_seed, drop_site) : 0ull;
   const uint32_t th = s2t_drop_thresh(drop_p);
-  const float dinv = 1.f / (1.f - drop_p);
+  const float dinv = s2t_drop_scale(drop_p);
 #pragma unroll
   for (int k = 0; k < NPL; ++k) {
     const int j = lane + 64 * k;

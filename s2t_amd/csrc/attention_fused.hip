@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
   if (a.causal) kend = min(a.Tk, q0 + 64);  // keys beyond the last query of the workgroup are masked for all its rows
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
-  const float dinv = 1.f / (1.f - a.drop_p);
+  const float dinv = s2t_drop_scale(a.drop_p);
 
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
@@ -279,12 +279,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
     if (a.drop_p > 0.f) {
       const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)(i < a.Tq ? i : 0)) * (uint64_t)a.Tk;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt) {
+        uint32_t r16[4];
+        s2t_rand_run<4>(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), r16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = k0 + 16 * kt + 4 * y + r;
-          pr[kt][r] = s2t_rand_u32(dkey, rowbase + j) >= dth ? pr[kt][r] * dinv : 0.f;
-        }
+        for (int r = 0; r < 4; ++r) pr[kt][r] = r16[r] >= dth ? pr[kt][r] * dinv : 0.f;
+      }
     }
     // ---- O^T += V^T P^T
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   if (a.causal) kend = min(a.Tk, q0 + 64);
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
-  const float dinv = 1.f / (1.f - a.drop_p);
+  const float dinv = s2t_drop_scale(a.drop_p);
   bf16_t* dbd_row = nullptr;
   if (REL && a.dbd && i < a.Tq) dbd_row = a.dbd + (((int64_t)h * a.B + b) * a.Tq + i) * a.ldb;
   if (REL && a.dbd) {
@@ -410,15 +410,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)ic) * (uint64_t)a.Tk;
     float ds[4][4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < 4; ++kt) {
+      uint32_t r16[4] = {65535u, 65535u, 65535u, 65535u};
+      if (a.drop_p > 0.f) s2t_rand_run<4>(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), r16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = k0 + 16 * kt + 4 * y + r;
         const float p = (st[kt][r] == -INFINITY) ? 0.f : __expf(st[kt][r] - lse_i);
         float dp = dpt[kt][r];
-        if (a.drop_p > 0.f) dp = s2t_rand_u32(dkey, rowbase + j) >= dth ? dp * dinv : 0.f;
+        if (a.drop_p > 0.f) dp = r16[r] >= dth ? dp * dinv : 0.f;
         ds[kt][r] = p * (dp - del_i) * a.scale;
       }
+    }
     if (dbd_row) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   const int nmax = 2 * a.Tq - 2;
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
-  const float dinv = 1.f / (1.f - a.drop_p);
+  const float dinv = s2t_drop_scale(a.drop_p);
 
   const int qstart = a.causal ? (k0 / 64) * 64 : 0;  // queries before the key block see none of its keys
   for (int q0 = qstart; q0 < a.Tq; q0 += 64) {

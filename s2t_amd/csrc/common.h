@@ -93,9 +93,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // Counter-based dropout RNG: keep(seed, site, element index) is a pure function, so the backward pass regenerates
-// the mask instead of storing it.  Two rounds of a 32-bit multiply/xor-shift finaliser ("lowbias32") over the low
-// words of (key, index), the high words injected between the rounds: 64-bit multiplies (splitmix64) cost three times
-// the VALU slots, and the fused GEMM epilogues that draw 8 masks per 16-byte store are VALU-issue bound.
+// the mask instead of storing it.  One 32-bit hash serves TWO consecutive elements (16 random bits each; the keep
+// probability is quantised to 1/65536 and the survivors are scaled by the quantised value's inverse): the fused GEMM
+// and attention epilogues draw a mask per stored element and are VALU-issue bound, and 32-bit integer multiplies and
+// 64-bit arithmetic (the first version was splitmix64 per element) are the expensive part.
+// hash = two rounds of the "lowbias32" multiply/xor-shift finaliser over the pair index, the key's halves injected.
 __device__ __forceinline__ uint32_t s2t_mix32(uint32_t x) {
   x ^= x >> 16;
   x *= 0x7feb352dU;
@@ -104,16 +106,43 @@ __device__ __forceinline__ uint32_t s2t_mix32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ uint32_t s2t_rand_u32(uint64_t key, uint64_t idx) {
-  uint32_t x = s2t_mix32((uint32_t)idx ^ (uint32_t)key);
-  x += (uint32_t)(idx >> 32) * 0x9E3779B9U + (uint32_t)(key >> 32);
+__device__ __forceinline__ uint32_t s2t_pair_hash(uint64_t key, uint64_t pair) {
+  uint32_t x = s2t_mix32((uint32_t)pair ^ (uint32_t)key);
+  x += (uint32_t)(pair >> 32) * 0x9E3779B9U + (uint32_t)(key >> 32);
   return s2t_mix32(x);
+}
+// 16 uniform random bits of element idx
+__device__ __forceinline__ uint32_t s2t_rand_u32(uint64_t key, uint64_t idx) {
+  const uint32_t h = s2t_pair_hash(key, idx >> 1);
+  return (idx & 1) ? (h >> 16) : (h & 0xffffu);
+}
+// the same for N consecutive elements starting at base: N/2 hashes when base is even (+1 when odd)
+template <int N>
+__device__ __forceinline__ void s2t_rand_run(uint64_t key, uint64_t base, uint32_t (&r16)[N]) {
+  static_assert(N % 2 == 0, "even run length");
+  const uint64_t p0 = base >> 1;
+  uint32_t h[N / 2];
+#pragma unroll
+  for (int q = 0; q < N / 2; ++q) h[q] = s2t_pair_hash(key, p0 + q);
+  if ((base & 1) == 0) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) r16[r] = (r & 1) ? (h[r >> 1] >> 16) : (h[r >> 1] & 0xffffu);
+  } else {
+    const uint32_t hl = s2t_pair_hash(key, p0 + N / 2);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const uint32_t hh = ((r + 1) >> 1) < N / 2 ? h[((r + 1) >> 1) < N / 2 ? ((r + 1) >> 1) : 0] : hl;
+      r16[r] = ((r + 1) & 1) ? (hh >> 16) : (hh & 0xffffu);
+    }
+  }
 }
 __device__ __forceinline__ uint64_t s2t_drop_key(const uint64_t* seed_ptr, uint32_t site) {
   const uint64_t seed = seed_ptr ? *seed_ptr : 0ull;
   return (seed * 0xD1342543DE82EF95ull) ^ ((uint64_t)site * 0xA24BAED4963EE407ull);
 }
-__device__ __forceinline__ uint32_t s2t_drop_thresh(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f); }
+// element kept iff its 16 random bits >= thresh; survivors scaled by s2t_drop_scale
+__device__ __forceinline__ uint32_t s2t_drop_thresh(float p) { return (uint32_t)fminf(p * 65536.0f + 0.5f, 65535.0f); }
+__device__ __forceinline__ float s2t_drop_scale(float p) { return 65536.0f / (65536.0f - (float)s2t_drop_thresh(p)); }
 
 static inline int s2t_hip_status(hipError_t e) { return e == hipSuccess ? S2T_OK : (int)e; }
 #define S2T_LAUNCH_CHECK() s2t_hip_status(hipGetLastError())

@@ -406,8 +406,8 @@ extern "C" int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* 
                               float count, int act, int64_t rows, int C, const int32_t* lens, int T, void* stream) {
   if (!D || !dOut || !dD || !scale || !shift || !mean || !rstd || !sums || rows <= 0 || C <= 0 || C % 4) return S2T_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int64_t slices = (rows + 63) / 64;
-  if (slices > 128) slices = 128;
+  int64_t slices = (rows + 31) / 32;  // 8 rows per wave: the pass is latency bound with fewer workgroups
+  if (slices > 512) slices = 512;
   dim3 rgrid((C + 255) / 256, (unsigned)slices), block(256);
   dim3 agrid((unsigned)((rows * (C / 4) + 255) / 256));
   if (dtype == S2T_F32) {

@@ -71,11 +71,13 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, i
   const int c = (int)(idx % vpr) * 4;
   const uint64_t key = s2t_drop_key(seed, site);
   const uint32_t th = s2t_drop_thresh(p);
-  const float inv = 1.f / (1.f - p);
+  const float inv = s2t_drop_scale(p);
   float v[4];
   ld4_as_f32<T>(x + row * ldx + c, v);
+  uint32_t r16[4];
+  s2t_rand_run<4>(key, (uint64_t)row * cols + c, r16);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = s2t_rand_u32(key, (uint64_t)row * cols + c + r) >= th ? v[r] * inv : 0.f;
+  for (int r = 0; r < 4; ++r) v[r] = r16[r] >= th ? v[r] * inv : 0.f;
   st4_from_f32<T>(out + row * ldo + c, v);
 }
 
@@ -149,7 +151,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, i
   const int c = blockIdx.x * 256 + lane * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < n) {
-    for (int64_t m = (int64_t)blockIdx.y * 4 + w; m < rows; m += (int64_t)gridDim.y * 4) {
+    const int64_t step = (int64_t)gridDim.y * 4;
+    int64_t m = (int64_t)blockIdx.y * 4 + w;
+    if (c + 3 < n) {
+      // four rows per trip: four independent 8/16-byte loads in flight per lane (the pass is latency bound otherwise)
+      float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, a3[4] = {0.f, 0.f, 0.f, 0.f};
+      for (; m + 3 * step < rows; m += 4 * step) {
+        float v0[4], v1[4], v2[4], v3[4];
+        ld4_as_f32<T>(dY + m * ld + c, v0);
+        ld4_as_f32<T>(dY + (m + step) * ld + c, v1);
+        ld4_as_f32<T>(dY + (m + 2 * step) * ld + c, v2);
+        ld4_as_f32<T>(dY + (m + 3 * step) * ld + c, v3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[r] += v0[r];
+          a1[r] += v1[r];
+          a2[r] += v2[r];
+          a3[r] += v3[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += a1[r] + a2[r] + a3[r];
+    }
+    for (; m < rows; m += step) {
       float v[4];
       if (c + 3 < n) ld4_as_f32<T>(dY + m * ld + c, v);
       else {
@@ -342,8 +366,8 @@ extern "C" int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db
   if (!dY || !db || rows < 0 || n <= 0) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   if (ld % 4 || ((uintptr_t)dY % 16)) return S2T_ERR_ALIGN;
-  int64_t slices = (rows + 63) / 64;
-  if (slices > 128) slices = 128;
+  int64_t slices = (rows + 31) / 32;  // 8 rows per wave
+  if (slices > 1024) slices = 1024;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)slices);
   if (dtype == S2T_F32)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dY, ld, db, rows, n);

@@ -337,10 +337,12 @@ struct Epi {
     if (p.drop_p > 0.f) {
       const uint64_t key = s2t_drop_key(p.drop_seed, p.drop_site);
       const uint32_t th = s2t_drop_thresh(p.drop_p);
-      const float inv = 1.f / (1.f - p.drop_p);
+      const float inv = s2t_drop_scale(p.drop_p);
       const uint64_t base = (uint64_t)grow * (uint64_t)nout + (uint64_t)n0;
+      uint32_t r16[8];
+      s2t_rand_run<8>(key, base, r16);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = s2t_rand_u32(key, base + r) >= th ? v[r] * inv : 0.f;
+      for (int r = 0; r < 8; ++r) v[r] = r16[r] >= th ? v[r] * inv : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
