@@ -113,7 +113,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # S2T_FORCE_DDP=1 (under torch.distributed.run with one rank) exercises the RCCL + hipGraph path on a single GPU
+    force_ddp = os.environ.get("S2T_FORCE_DDP") == "1" and "RANK" in os.environ
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
@@ -137,7 +139,7 @@ def main():
                           dropout=args.dropout, attention_dropout=args.dropout, activation_dropout=args.dropout)
     model = M.S2TTransformerModel.build_model(margs, M.FakeTask(V)).prepare(dtype, dev)
     crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
-    ddp = LegacyDistributedDataParallel(model) if world > 1 else None
+    ddp = LegacyDistributedDataParallel(model) if (world > 1 or force_ddp) else None
     trainer = Trainer(model, crit, ddp=ddp)
     sample, frames_local = synthetic_batch(args.batch, args.frames, V, 1 + rank, dev)
     ft = torch.tensor([frames_local, sample["ntokens"]], dtype=torch.float64, device=dev)
@@ -259,7 +261,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 
