@@ -139,7 +139,7 @@ def main():
                           dropout=args.dropout, attention_dropout=args.dropout, activation_dropout=args.dropout)
     model = M.S2TTransformerModel.build_model(margs, M.FakeTask(V)).prepare(dtype, dev)
     crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
-    ddp = LegacyDistributedDataParallel(model) if (world > 1 or force_ddp) else None
+    ddp = LegacyDistributedDataParallel(model, single_rank_collectives=force_ddp) if (world > 1 or force_ddp) else None
     trainer = Trainer(model, crit, ddp=ddp)
     sample, frames_local = synthetic_batch(args.batch, args.frames, V, 1 + rank, dev)
     ft = torch.tensor([frames_local, sample["ntokens"]], dtype=torch.float64, device=dev)

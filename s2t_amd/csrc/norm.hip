@@ -162,6 +162,141 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
   }
 }
 
+// ---- cols == 256, bf16: half a wave per row (32 lanes x 8 elements = one 16-byte access per lane), two rows per
+// wave: half the instructions per row and twice the bytes per memory instruction of the generic kernels, which are
+// issue/latency bound on 512-byte rows (the model width of every recipe is 256).
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void unpack8(const uint4 t, float (&v)[8]) {
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[2 * q] = __uint_as_float(w[q] << 16);
+    v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8f(const float (&o)[8]) {
+  uint4 t;
+  t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+  t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+  t.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+  t.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+  return t;
+}
+
+__global__ __launch_bounds__(256) void ln256_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                        int64_t rows, float eps, const int32_t* __restrict__ row_lens,
+                                                        int row_T) {
+  const int lane = threadIdx.x & 63, l = lane & 31;
+  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5);
+  const bool valid = row < rows;
+  const int64_t rr = valid ? row : rows - 1;
+  float v[8];
+  unpack8(*reinterpret_cast<const uint4*>(x + rr * 256 + l * 8), v);
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) s += v[r];
+  const float mean = half_sum(s) * (1.f / 256.f);
+  float q = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float d = v[r] - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(half_sum(q) * (1.f / 256.f) + eps);
+  if (!valid) return;
+  bool masked = false;
+  if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
+  float g[8], b[8], o[8];
+  ld4_as_f32<float>(gamma + l * 8, reinterpret_cast<float (&)[4]>(g[0]));
+  ld4_as_f32<float>(gamma + l * 8 + 4, reinterpret_cast<float (&)[4]>(g[4]));
+  ld4_as_f32<float>(beta + l * 8, reinterpret_cast<float (&)[4]>(b[0]));
+  ld4_as_f32<float>(beta + l * 8 + 4, reinterpret_cast<float (&)[4]>(b[4]));
+#pragma unroll
+  for (int r = 0; r < 8; ++r) o[r] = masked ? 0.f : (v[r] - mean) * rstd * g[r] + b[r];
+  *reinterpret_cast<uint4*>(y + row * 256 + l * 8) = pack8f(o);
+  if (l == 0 && mean_out) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+__global__ __launch_bounds__(256) void ln256_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        const bf16_t* __restrict__ dy, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                        const bf16_t* __restrict__ dres, float* __restrict__ ws,
+                                                        int replicas, int64_t rows, const int32_t* __restrict__ row_lens,
+                                                        int row_T) {
+  __shared__ float red[2][8][256];
+  const int lane = threadIdx.x & 63, l = lane & 31, hw = (threadIdx.x >> 6) * 2 + (lane >> 5);
+  float g[8];
+  ld4_as_f32<float>(gamma + l * 8, reinterpret_cast<float (&)[4]>(g[0]));
+  ld4_as_f32<float>(gamma + l * 8 + 4, reinterpret_cast<float (&)[4]>(g[4]));
+  float ag[8], ab[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) ag[r] = ab[r] = 0.f;
+  // all 64 lanes of a wave take the same number of trips (shuffles are wave-wide): out-of-range halves work on a
+  // clamped row and discard the result
+  const int64_t trips = (rows + (int64_t)gridDim.x * 8 - 1) / ((int64_t)gridDim.x * 8);
+  for (int64_t it = 0; it < trips; ++it) {
+    const int64_t row = (it * gridDim.x + blockIdx.x) * 8 + hw;
+    const bool valid = row < rows;
+    const int64_t rr = valid ? row : rows - 1;
+    bool masked = !valid;
+    if (valid && row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
+    const float mu = mean[rr], rs = rstd[rr];
+    float xv[8], dv[8], xh[8], dg[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + rr * 256 + l * 8), xv);
+    unpack8(*reinterpret_cast<const uint4*>(dy + rr * 256 + l * 8), dv);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float d = masked ? 0.f : dv[r];
+      xh[r] = (xv[r] - mu) * rs;
+      dg[r] = d * g[r];
+      s1 += dg[r];
+      s2 += dg[r] * xh[r];
+      ag[r] += d * xh[r];
+      ab[r] += d;
+    }
+    s1 = half_sum(s1) * (1.f / 256.f);
+    s2 = half_sum(s2) * (1.f / 256.f);
+    if (valid) {
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = rs * (dg[r] - s1 - xh[r] * s2);
+      if (dres) {
+        float q[8];
+        unpack8(*reinterpret_cast<const uint4*>(dres + row * 256 + l * 8), q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] += q[r];
+      }
+      *reinterpret_cast<uint4*>(dx + row * 256 + l * 8) = pack8f(o);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    red[0][hw][l * 8 + r] = ag[r];
+    red[1][hw][l * 8 + r] = ab[r];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  float sg = 0.f, sb = 0.f;
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    sg += red[0][h][c];
+    sb += red[1][h][c];
+  }
+  float* w = ws + (int64_t)(blockIdx.x % replicas) * 512;
+  atomicAdd(w + c, sg);
+  atomicAdd(w + 256 + c, sb);
+}
+
 // dgamma += sum_r ws[r][0][:] ; dbeta += sum_r ws[r][1][:]
 __global__ void ln_bwd_finalize_kernel(float* __restrict__ ws, int replicas, int cols, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta) {
@@ -202,6 +337,9 @@ extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, c
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
     LN_DISPATCH(ln_fwd_kernel, float, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps, row_lens, row_T);
+  else if (dtype == S2T_BF16 && cols == 256 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0)
+    hipLaunchKernelGGL(ln256_fwd_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const bf16_t*)x, gamma, beta,
+                       (bf16_t*)y, mean, rstd, rows, eps, row_lens, row_T);
   else if (dtype == S2T_BF16)
     LN_DISPATCH(ln_fwd_kernel, bf16_t, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, cols, eps, row_lens, row_T);
   else return S2T_ERR_DTYPE;
@@ -222,7 +360,13 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, c
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
     LN_DISPATCH(ln_bwd_kernel, float, (const float*)x, gamma, (const float*)dy, mean, rstd, (float*)dx, (const float*)dres, ws, replicas, rows, cols, row_lens, row_T);
-  else if (dtype == S2T_BF16)
+  else if (dtype == S2T_BF16 && cols == 256 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
+           ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dres % 16) == 0) {
+    int64_t nb8 = (rows + 7) / 8;
+    if (nb8 > 2048) nb8 = 2048;
+    hipLaunchKernelGGL(ln256_bwd_kernel, dim3((unsigned)nb8), block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean,
+                       rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, row_lens, row_T);
+  } else if (dtype == S2T_BF16)
     LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean, rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, cols, row_lens, row_T);
   else return S2T_ERR_DTYPE;
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, ws, replicas, cols, dgamma, dbeta);

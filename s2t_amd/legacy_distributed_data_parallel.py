@@ -26,12 +26,15 @@ from . import functional as Fn
 
 
 class LegacyDistributedDataParallel(nn.Module):
-    def __init__(self, module, process_group=None, buffer_size=2 ** 23, overlap=True):
-        """``buffer_size``: bucket size in ELEMENTS (2**23 fp32 = 32 MiB)."""
+    def __init__(self, module, process_group=None, buffer_size=2 ** 23, overlap=True, single_rank_collectives=False):
+        """``buffer_size``: bucket size in ELEMENTS (2**23 fp32 = 32 MiB).
+        ``single_rank_collectives``: issue the (trivial) collectives even when the group has one rank, so that the
+        RCCL + side-stream + hipGraph-capture path can be exercised on a single GPU."""
         super().__init__()
         self.module = module
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._idle = self.world_size == 1 and not single_rank_collectives
         self.accumulate_grads = False
         self.overlap = overlap
         flat = module.flat
@@ -74,17 +77,22 @@ class LegacyDistributedDataParallel(nn.Module):
             self.accumulate_grads = old
 
     # -- overlap machinery ---------------------------------------------------------------------------
-    def begin_backward(self):
-        """Arm the grad-ready hook for one backward pass."""
+    @property
+    def active(self):
+        """True when all_reduce_grads() issues collectives."""
+        return not self._idle
+
+    def begin_backward(self, overlap=True):
+        """Arm the grad-ready hook for one backward pass (``overlap=False``: reduce everything in all_reduce_grads)."""
         self._seen = {}
         self._launched = set()
         self._work = []
-        if self.world_size == 1 or self.accumulate_grads:
+        if self._idle or self.accumulate_grads:
             Fn._HOOKS["grad_ready"] = None
             return
         if self._learning:
             Fn._HOOKS["grad_ready"] = self._count
-        elif self.overlap:
+        elif self.overlap and overlap:
             self._pending = [0] * len(self.buckets)
             for p in self.flat.params:
                 for b in self._bucket_of[id(p)]:
@@ -125,7 +133,7 @@ class LegacyDistributedDataParallel(nn.Module):
     def all_reduce_grads(self):
         """Finish the reduction: every gradient becomes sum_over_ranks / world_size (reference :76-160)."""
         Fn._HOOKS["grad_ready"] = None
-        if self.world_size == 1 or self.accumulate_grads:
+        if self._idle or self.accumulate_grads:
             return
         if self._learning:
             self._expected = dict(self._seen)

@@ -50,25 +50,32 @@ class Trainer:
         self.hyper[:2].copy_(self._hyper_host, non_blocking=True)
 
     # ---- one update ----------------------------------------------------------------------------------
-    def _step_body(self, sample, sample_size_global):
+    def _fwd_bwd(self, sample, overlap=True):
         # dropout masks are a function of (seed, site, element): the device-resident seed advances once per update
         # (trainer.py:1093-1097 seeds every step with seed + num_updates), sites restart at 0
         Fn.DROPOUT.begin_step(self.flat.master.device)
         Fn.DROPOUT.seed.add_(1)
         self.flat.zero_grad()
         if self.ddp is not None:
-            self.ddp.begin_backward()
+            self.ddp.begin_backward(overlap=overlap)
         loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
         loss.backward()
-        if self.ddp is not None:
-            self.ddp.all_reduce_grads()  # grads = sum_ranks / world
+        return loss.detach(), log
+
+    def _update(self, sample_size_global):
         n = self.flat.numel
         self.sumsq.zero_()
         K.sumsq_accum(self.flat.grad, n, self.sumsq)
         K.clip_coef(self.sumsq, self.clip_norm, self.world / float(sample_size_global), self.hyper)
         K.adam_step(self.flat.master, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.flat.shadow, n, self.betas[0],
                     self.betas[1], self.eps, self.wd, self.hyper)
-        return loss.detach(), log
+
+    def _step_body(self, sample, sample_size_global):
+        out = self._fwd_bwd(sample)
+        if self.ddp is not None:
+            self.ddp.all_reduce_grads()  # grads = sum_ranks / world
+        self._update(sample_size_global)
+        return out
 
     def train_step(self, sample, sample_size_global=None):
         """Eager step.  ``sample_size_global``: sum of sample sizes over ranks (defaults to world * local)."""
@@ -99,12 +106,29 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
+        self._graph2 = None
         self._push_hyper()
-        with torch.cuda.graph(self._graph):
-            self._graph_out = self._step_body(sample, sample_size_global)
+        if self.ddp is not None and self.ddp.active:
+            # RCCL collectives stay OUTSIDE the capture (the process-group watchdog thread polls events, which a
+            # capturing stream forbids): graph 1 = forward + backward, eager bucketed all-reduce, graph 2 = clip + Adam.
+            # The reduction is then not overlapped with backward (it is in the eager path).
+            with torch.cuda.graph(self._graph):
+                self._graph_out = self._fwd_bwd(sample, overlap=False)
+            self.ddp.all_reduce_grads()
+            self._graph2 = torch.cuda.CUDAGraph()
+            self._ssg = sample_size_global
+            with torch.cuda.graph(self._graph2, pool=self._graph.pool()):
+                self._update(sample_size_global)
+        else:
+            with torch.cuda.graph(self._graph):
+                self._graph_out = self._step_body(sample, sample_size_global)
 
     def replay(self):
         self._push_hyper()
         self._graph.replay()
+        if self._graph2 is not None:
+            self.ddp.begin_backward(overlap=False)
+            self.ddp.all_reduce_grads()
+            self._graph2.replay()
         self.num_updates += 1
         return self._graph_out
