@@ -1,0 +1,89 @@
+"""Trainer on the GPU: eager steps, one captured hipGraph per update, and the data-parallel variant (two graphs around
+an eager RCCL all-reduce, here with a one-rank group) must walk the same parameter trajectory."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+from s2t_amd import criterions as C  # noqa: E402
+from s2t_amd import s2t_transformer as M  # noqa: E402
+from s2t_amd.legacy_distributed_data_parallel import LegacyDistributedDataParallel  # noqa: E402
+from s2t_amd.trainer import Trainer  # noqa: E402
+
+DEV = "cuda"
+V = 61
+
+
+def _model(seed):
+    torch.manual_seed(seed)
+    args = M.recipe_args(conformer=True, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_layers=2, decoder_layers=1,
+                         decoder_embed_dim=128, decoder_ffn_embed_dim=256, encoder_attention_heads=2,
+                         decoder_attention_heads=2, subsampling_filter=96, vocab_size=V, dropout=0.1,
+                         attention_dropout=0.1, activation_dropout=0.1)
+    return M.S2TTransformerModel.build_model(args, M.FakeTask(V)).prepare(torch.bfloat16, DEV)
+
+
+def _sample():
+    g = torch.Generator().manual_seed(3)
+    B, T, U = 4, 200, 9
+    lens = torch.tensor([200, 190, 111, 150])
+    src = torch.randn(B, T, 80, generator=g)
+    for b in range(B):
+        src[b, lens[b]:] = 0
+    target = torch.randint(4, V, (B, U), generator=g)
+    target[:, -1] = 2
+    prev = torch.roll(target, 1, 1)
+    prev[:, 0] = 2
+    return {"net_input": {"src_tokens": src.to(DEV), "src_lengths": lens.to(DEV), "prev_output_tokens": prev.to(DEV)},
+            "target": target.to(DEV), "ntokens": int((target != 1).sum())}
+
+
+def _run(mode, steps=4):
+    from s2t_amd import functional as Fn
+    model = _model(5)
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    ddp = None
+    if mode == "ddp_graph":
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        ddp = LegacyDistributedDataParallel(model, single_rank_collectives=True, buffer_size=2 ** 18)
+    tr = Trainer(model, crit, ddp=ddp)
+    sample = _sample()
+    Fn.DROPOUT.begin_step(torch.device(DEV))
+    Fn.DROPOUT.set_seed(100)
+    losses = []
+    if mode == "eager":
+        for _ in range(steps + 3):
+            losses.append(float(tr.train_step(sample)[0]))
+    else:
+        if ddp is not None:
+            losses.append(float(tr.train_step(sample)[0]))  # learns the ready counts (as bench.py does)
+        else:
+            losses.append(float(tr.train_step(sample)[0]))
+        tr.capture(sample, warmup=2)
+        losses += [None, None]
+        for _ in range(steps):
+            losses.append(float(tr.replay()[0]))
+    torch.cuda.synchronize()
+    return losses, model.flat.master.detach().float().cpu().clone()
+
+
+def test_graph_and_ddp_graph_follow_the_eager_trajectory():
+    le, pe = _run("eager")
+    lg, pg = _run("graph")
+    ld, pd = _run("ddp_graph")
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    # same seeds, same masks, same arithmetic: the captured variants replay the eager step kernel for kernel
+    for a, b in zip(le[3:], lg[3:]):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+    for a, b in zip(le[3:], ld[3:]):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, ld)
+    assert le[-1] < le[0]  # and it trains
+    assert (pe - pg).abs().max() <= 1e-3 * pe.abs().max()
+    assert (pe - pd).abs().max() <= 1e-3 * pe.abs().max()
