@@ -111,8 +111,63 @@ def fused_master(params, n):
     return params[0].data.as_strided((n,), (1,))
 
 
+# Weight gradients are off the critical path of backward (nothing consumes them before the optimizer), so they CAN run
+# on a second HIP stream, forked behind an event when their operands are ready and joined at the end of the backward
+# pass (an autograd engine callback); their operands are kept alive until the join so the caching allocator cannot hand
+# the memory to main-stream kernels.  Opt-in (S2T_WGRAD_STREAM=1): measured on MI355X it LOSES 5 % (24.6 vs 23.4 ms per
+# step) — two persistent GEMM grids competing for the two 64-KiB-LDS workgroup slots of each CU and for L2 cost more
+# than the idle CU time of the critical-path kernels they were meant to fill.
+_WG = {"stream": None, "keep": [], "armed": False, "enabled": os.environ.get("S2T_WGRAD_STREAM", "0") == "1"}
+
+
+def wgrad_stream():
+    """The side stream weight-gradient kernels are queued on (None when the feature is off or unused so far)."""
+    return _WG["stream"]
+
+
+def _wgrad_join():
+    s = _WG["stream"]
+    if s is not None:
+        torch.cuda.current_stream().wait_stream(s)
+    _WG["keep"].clear()
+    _WG["armed"] = False
+
+
+class _on_wgrad_stream:
+    """Context manager: run the enclosed launches on the weight-gradient stream, ordered after everything queued on the
+    current stream so far; ``keep`` tensors stay referenced until the end-of-backward join."""
+
+    def __init__(self, *keep):
+        self.keep = keep
+        self.ctx = None
+
+    def __enter__(self):
+        if not _WG["enabled"] or not torch.cuda.is_available():
+            return self
+        if _WG["stream"] is None:
+            _WG["stream"] = torch.cuda.Stream()
+        side = _WG["stream"]
+        side.wait_stream(torch.cuda.current_stream())
+        _WG["keep"].append(self.keep)
+        if not _WG["armed"]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join)
+            except RuntimeError:  # not inside a backward pass: stay on the current stream
+                _WG["keep"].pop()
+                return self
+            _WG["armed"] = True
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
-    """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M with fp32 atomics);
+    """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M, two-phase workspace reduction);
     db[Nout] += alpha * column sums of dY when given (taken from the staged dY tiles inside the same kernel)."""
     tiles = ((Nout + 127) // 128) * ((Kin + 127) // 128)
     bke = 64 if dY.dtype == torch.bfloat16 else 32
@@ -120,8 +175,9 @@ def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
     # about 2 workgroups per CU in total, but never fewer than 8 K-steps per workgroup: storing and re-reading a
     # 128x128 fp32 partial tile costs about as much as a few K-steps (measured: tools/wgrad_bench.py)
     split = max(1, min((ktiles + 7) // 8, (512 + tiles - 1) // tiles))
-    K.gemm(dY, X, dW, M=Nout, N=Kin, K=M, lda=ldy, ldb=ldx, ldc=Kin, a_kmajor=True, b_kmajor=True, alpha=alpha,
-           split_k=split, c_atomic=True, colsum_a=db)
+    with _on_wgrad_stream(dY, X):
+        K.gemm(dY, X, dW, M=Nout, N=Kin, K=M, lda=ldy, ldb=ldx, ldc=Kin, a_kmajor=True, b_kmajor=True, alpha=alpha,
+               split_k=split, c_atomic=True, colsum_a=db)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -722,7 +778,9 @@ class EmbeddingFn(torch.autograd.Function):
     def backward(ctx, dout):
         (tokens,) = ctx.saved_tensors
         E = ctx.E
-        K.embedding_bwd(tokens, dout.contiguous(), E.grad, tokens.numel(), E.shape[1], ctx.scale, ctx.pad_idx)
+        dout = dout.contiguous()
+        with _on_wgrad_stream(tokens, dout):  # the table may be tied to a projection whose wgrad runs on that stream
+            K.embedding_bwd(tokens, dout, E.grad, tokens.numel(), E.shape[1], ctx.scale, ctx.pad_idx)
         _ready(E)
         return None, None, None, None, None, None
 

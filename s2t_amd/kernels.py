@@ -110,7 +110,7 @@ _WS = {}
 
 def _scratch(tag, n, device):
     """Uninitialised fp32 scratch that only grows (split-K partial tiles); one buffer per tag and device."""
-    key = (tag, str(device))
+    key = (tag, str(device), L.stream_ptr())  # per stream: concurrent streams must not share scratch
     t = _WS.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(n, dtype=torch.float32, device=device)

@@ -114,13 +114,18 @@ class LegacyDistributedDataParallel(nn.Module):
         s, e = self.buckets[b]
         view = self.flat.grad[s:e]
         self._launched.add(b)
+        wg = Fn.wgrad_stream() if view.is_cuda else None  # weight gradients are produced on their own stream
         if self._side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._side.wait_event(ev)
+            if wg is not None:
+                self._side.wait_stream(wg)
             with torch.cuda.stream(self._side):
                 self._reduce(view)
         else:
+            if wg is not None:
+                torch.cuda.current_stream().wait_stream(wg)
             self._reduce(view)
 
     def _reduce(self, view):
