@@ -230,6 +230,54 @@ def encdec_case(name, outdir, arch, V, B, T, seed, train_bn=False, **kw):
     print(name, "loss", loss.item(), {k: v for k, v in log.items() if "loss" in k})
 
 
+EOS_LIFT = float(os.environ.get("EOS_LIFT", "9.0"))
+
+
+def beam_case(name, outdir, V, B, T, seed, beam, max_len_b, sharpen, eos_lift, **kw):
+    """fairseq/sequence_generator.py:191-614 (SequenceGenerator._generate, BeamSearch of search.py:101-150) on a small
+    s2t_transformer with the incremental decoder (KV cache, modules/multihead_attention.py:302-339).  The output
+    projection (untied from the input embedding, so that a token does not simply vote for itself) is sharpened so that
+    candidate margins dwarf fp32 re-association noise."""
+    from fairseq.sequence_generator import SequenceGenerator
+
+    torch.manual_seed(seed)
+    model, args, task = build("s2t_transformer_s", V, **kw)
+    seed_weights(model, seed + 100)
+    with torch.no_grad():
+        model.decoder.output_projection.weight.mul_(sharpen)  # untied from the input embedding for this case
+        # a constant lift of the </s> logit through the final LayerNorm's bias: hypotheses of different lengths
+        bln = model.decoder.layer_norm.bias
+        model.decoder.output_projection.weight[2].add_(eos_lift * bln / (bln * bln).sum())
+    src, lens, _, _, _ = make_batch(B, T, V, seed + 200)
+    model.eval()
+    gen = SequenceGenerator([model], task.target_dictionary, beam_size=beam, max_len_a=0, max_len_b=max_len_b, min_len=1,
+                            normalize_scores=True, len_penalty=1.0, unk_penalty=0.0)
+    sample = {"id": torch.arange(B), "net_input": {"src_tokens": src, "src_lengths": lens}}
+    with torch.no_grad():
+        hyps = gen.generate([model], sample)
+    out = {}
+    out.update(sd_np(model))
+    out["in::src_tokens"] = np_(src)
+    out["in::src_lengths"] = np_(lens)
+    out["gen::beam"] = np.int64(beam)
+    out["gen::max_len_b"] = np.int64(max_len_b)
+    out["gen::n_hyps"] = np.array([len(h) for h in hyps], dtype=np.int64)
+    for b, hb in enumerate(hyps):
+        for k, h in enumerate(hb):
+            out["out::tokens_%d_%d" % (b, k)] = np_(h["tokens"])
+            out["out::score_%d_%d" % (b, k)] = np.float64(float(h["score"]))
+            out["out::pos_scores_%d_%d" % (b, k)] = np_(h["positional_scores"])
+    for k, v in sorted(vars(args).items()):
+        if isinstance(v, bool):
+            out["cfg::" + k] = np.bool_(v)
+        elif isinstance(v, (int, float)):
+            out["cfg::" + k] = np.float64(v)
+        elif isinstance(v, str):
+            out["cfg::" + k] = np.array(v)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    print(name, [[h["tokens"].tolist() for h in hb[:2]] for hb in hyps], [float(hb[0]["score"]) for hb in hyps])
+
+
 def ctc_greedy_case(name, outdir, V, B, T, seed, **kw):
     from fairseq.models.speech_to_text.s2t_ctc import CTCDecoder
 
@@ -335,6 +383,11 @@ def main():
         encoder_activation_fn="swish",
         layer_padding_mask=True,
     )
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "beam"):
+        beam_case("beam_search_transformer", outdir, V=40, B=3, T=50, seed=9, beam=4, max_len_b=12, sharpen=6.0, eos_lift=EOS_LIFT,
+                  share_decoder_input_output_embed=False, share_ctc_and_embed=False, **small)
+    if os.environ.get("GOLDEN_ONLY", "") == "beam":
+        return
     module_cases(outdir)
     encdec_case("transformer_small", outdir, "s2t_transformer_s", V=40, B=3, T=50, seed=1, **small)
     encdec_case("conformer_small", outdir, "s2t_transformer_s", V=40, B=3, T=50, seed=2, train_bn=True, **small, **conf)

@@ -319,6 +319,68 @@ def decoder_forward(prev_output_tokens, enc_out, W, cfg, prefix="decoder.", pad_
 
 
 # ----------------------------------------------------------------------------------------------
+# beam search
+# ----------------------------------------------------------------------------------------------
+def beam_search(src_tokens, src_lengths, W, cfg, beam, max_len_a=0.0, max_len_b=200, min_len=1, len_penalty=1.0,
+                unk_penalty=0.0, normalize_scores=True, pad=1, eos=2, unk=3, blank=0, max_decoder_positions=1024):
+    """fairseq/sequence_generator.py:191-614 (_generate) + search.py:101-150 (BeamSearch.step) + :650-786
+    (finalize_hypos / is_finished), restated one sentence at a time with plain Python lists and NO incremental state
+    (every step re-runs the teacher-forced decoder on the whole prefix):
+      * step 0 expands the first beam only; later steps rank all (beam, token) pairs by cumulative log-probability;
+      * pad and blank (= <s>, index 0) are never selected, unk is penalised, </s> is forbidden before min_len and
+        forced at max_len = min(int(a * src_len + b), max_decoder_positions - 1);
+      * of the best 2*beam candidates, an </s> among the FIRST beam is finalised with score / (step+1)^len_penalty
+        (while fewer than beam hypotheses are finished); the first beam non-</s> candidates continue;
+      * a sentence stops once beam hypotheses are finished or step == max_len; hypotheses are sorted by score.
+    Returns, per sentence, a list of dicts {tokens, score, positional_scores}."""
+    enc = encoder_forward(src_tokens, src_lengths, W, cfg, training=False)
+    B, src_len = src_tokens.shape[:2]
+    max_len = min(int(max_len_a * src_len + max_len_b), max_decoder_positions - 1)
+    results = []
+    for b in range(B):
+        enc_b = {"encoder_out": [enc["encoder_out"][0][:, b:b + 1]],
+                 "encoder_padding_mask": [enc["encoder_padding_mask"][0][b:b + 1]]}
+        hyps = [([eos], [])]  # (tokens incl. the leading </s>, cumulative scores per position)
+        finished = []
+        for step in range(max_len + 1):
+            cands = []
+            for bi, (toks, cum) in enumerate(hyps):
+                logits = decoder_forward(torch.tensor([toks]), enc_b, W, cfg)[0, -1]
+                lp = torch.log_softmax(logits.float(), -1)
+                lp[lp != lp] = NEG_INF
+                lp[pad] = NEG_INF
+                lp[blank] = NEG_INF
+                lp[unk] -= unk_penalty
+                if step >= max_len:
+                    lp[:eos] = NEG_INF
+                    lp[eos + 1:] = NEG_INF
+                elif step < min_len:
+                    lp[eos] = NEG_INF
+                base = cum[-1] if cum else 0.0
+                for v in range(lp.numel()):
+                    cands.append((float(lp[v]) + base, bi, v))
+                if step == 0:
+                    break  # all beams are identical at the first step
+            cands.sort(key=lambda c: -c[0])
+            cands = cands[:min(2 * beam, len(cands) - 1)]
+            for sc, bi, v in cands[:beam]:
+                if v == eos and sc != NEG_INF and len(finished) < beam:
+                    toks, cum = hyps[bi]
+                    cumall = cum + [sc]
+                    pos = [cumall[0]] + [cumall[i] - cumall[i - 1] for i in range(1, len(cumall))]
+                    finished.append({"tokens": toks[1:] + [eos],
+                                     "score": sc / (step + 1) ** len_penalty if normalize_scores else sc,
+                                     "positional_scores": pos})
+            if len(finished) == beam or step == max_len:
+                break
+            nxt = [(hyps[bi][0] + [v], hyps[bi][1] + [sc]) for sc, bi, v in cands if not (v == eos and sc != NEG_INF)]
+            hyps = nxt[:beam]
+        finished.sort(key=lambda h: -h["score"])
+        results.append(finished)
+    return results
+
+
+# ----------------------------------------------------------------------------------------------
 # losses
 # ----------------------------------------------------------------------------------------------
 def label_smoothed_nll(logits, target, eps, pad_idx=1):

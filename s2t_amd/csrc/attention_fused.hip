@@ -70,15 +70,31 @@ __device__ __forceinline__ uint4 add_bias8(uint4 qv, const float* __restrict__ b
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// stage a 64-row x 64-col bf16 tile (rows row0.., zero beyond nrows) into the shared K/V image
-__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* __restrict__ base, int64_t sr, int row0, int nrows,
+// A 64-row x 64-col bf16 tile travels global -> registers -> LDS in two steps so that the loads of the NEXT tile are in
+// flight while the current one is being multiplied (sequences are short: 4 key blocks at T' = 250, so an unhidden load
+// round trip per block is a large part of the kernel).  Loads are unconditional (rows clamped); rows beyond nrows are
+// zeroed, and an optional per-column fp32 bias (q + pos_bias_u / q + pos_bias_v) is added, on the way into the LDS.
+struct TileRegs {
+  uint4 v[2];
+};
+__device__ __forceinline__ void tile_load(TileRegs& t, const bf16_t* __restrict__ base, int64_t sr, int row0, int nrows,
+                                          int tid) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = tid + 256 * u;
+    const int r = min(row0 + (c >> 3), nrows - 1), ch = c & 7;
+    t.v[u] = ldg16(base + (int64_t)r * sr + ch * 8);
+  }
+}
+__device__ __forceinline__ void tile_store(char* lds, const TileRegs& t, int row0, int nrows, const float* __restrict__ bias,
                                            int tid) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int c = tid + 256 * u;
     const int r = c >> 3, ch = c & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + r < nrows) v = ldg16(base + (int64_t)(row0 + r) * sr + ch * 8);
+    uint4 v = t.v[u];
+    if (row0 + r >= nrows) v = make_uint4(0, 0, 0, 0);
+    else if (bias) v = add_bias8(v, bias + ch * 8);
     *reinterpret_cast<uint4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = v;
   }
 }
@@ -241,11 +257,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
 
+  TileRegs tk, tv;
+  tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
+  tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
-    stage_tile(lk, kb, a.k_sr, k0, a.Tk, tid);
-    stage_tile(lv, vb, a.v_sr, k0, a.Tk, tid);
+    tile_store(lk, tk, k0, a.Tk, nullptr, tid);
+    tile_store(lv, tv, k0, a.Tk, nullptr, tid);
     __syncthreads();
+    if (k0 + KB < kend) {  // next block's K/V in flight during this block's MFMAs
+      tile_load(tk, kb, a.k_sr, k0 + KB, a.Tk, tid);
+      tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
+    }
     f32x4 st[4];
     scores_block<REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st);
     // ---- online softmax (row = lane's query; its 16 keys in registers, the other 48 in the 3 other y-groups)
@@ -391,11 +414,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     }
   }
 
+  TileRegs tk, tv;
+  tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
+  tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
-    stage_tile(lk, kb, a.k_sr, k0, a.Tk, tid);
-    stage_tile(lv, vb, a.v_sr, k0, a.Tk, tid);
+    tile_store(lk, tk, k0, a.Tk, nullptr, tid);
+    tile_store(lv, tv, k0, a.Tk, nullptr, tid);
     __syncthreads();
+    if (k0 + KB < kend) {  // next block's K/V in flight during this block's MFMAs
+      tile_load(tk, kb, a.k_sr, k0 + KB, a.Tk, tid);
+      tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
+    }
     f32x4 st[4];
     scores_block<REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st);
     // dP^T[key][q] = V[key] . dO[q]
@@ -455,22 +485,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
 }
 
 // ---- dK, dV: workgroup = 64 keys of one (b,h), wave = 16 keys; walks the query blocks ------------------------------
-// stage 64 query-side rows (+ optional per-column bias, rounded to bf16) into the shared tile image
-__device__ __forceinline__ void stage_tile_bias(char* lds, const bf16_t* __restrict__ base, int64_t sr, int row0, int nrows,
-                                                const float* __restrict__ bias, int tid) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int c = tid + 256 * u;
-    const int r = c >> 3, ch = c & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + r < nrows) {
-      v = ldg16(base + (int64_t)(row0 + r) * sr + ch * 8);
-      if (bias) v = add_bias8(v, bias + ch * 8);
-    }
-    *reinterpret_cast<uint4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = v;
-  }
-}
-
 constexpr int SC2 = 36;  // scratch row stride (floats) of the [16 q][32 n] band in the dK/dV kernel
 
 template <bool REL>
@@ -519,17 +533,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   const float dinv = s2t_drop_scale(a.drop_p);
 
   const int qstart = a.causal ? (k0 / 64) * 64 : 0;  // queries before the key block see none of its keys
-  for (int q0 = qstart; q0 < a.Tq; q0 += 64) {
-    __syncthreads();
-    stage_tile_bias(lqa, qb, a.q_sr, q0, a.Tq, REL ? a.pos_u + h * DK : nullptr, tid);
-    stage_tile(ldo, dob, a.o_sr, q0, a.Tq, tid);
-    if (REL) stage_tile_bias(lqv, qb, a.q_sr, q0, a.Tq, a.pos_v + h * DK, tid);
+  TileRegs tq, tdo;
+  float nlse = 0.f, ndel = 0.f;
+  auto prefetch = [&](int q0) __attribute__((always_inline)) {
+    tile_load(tq, qb, a.q_sr, q0, a.Tq, tid);
+    tile_load(tdo, dob, a.o_sr, q0, a.Tq, tid);
     if (tid < 64) {
       const int qi = min(q0 + tid, a.Tq - 1);
-      lse_s[tid] = a.lse[(int64_t)z * a.Tq + qi];
-      del_s[tid] = a.delta[(int64_t)z * a.Tq + qi];
+      nlse = a.lse[(int64_t)z * a.Tq + qi];
+      ndel = a.delta[(int64_t)z * a.Tq + qi];
+    }
+  };
+  if (qstart < a.Tq) prefetch(qstart);
+  for (int q0 = qstart; q0 < a.Tq; q0 += 64) {
+    __syncthreads();
+    tile_store(lqa, tq, q0, a.Tq, REL ? a.pos_u + h * DK : nullptr, tid);
+    tile_store(ldo, tdo, q0, a.Tq, nullptr, tid);
+    if (REL) tile_store(lqv, tq, q0, a.Tq, a.pos_v + h * DK, tid);
+    if (tid < 64) {
+      lse_s[tid] = nlse;
+      del_s[tid] = ndel;
     }
     __syncthreads();
+    if (q0 + 64 < a.Tq) prefetch(q0 + 64);  // next query block in flight during this block's MFMAs
     float pd[4][4], ds[4][4];  // [q tile][r]: q = q0 + 16qt + 4y + r, key = this lane's
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {

@@ -594,6 +594,62 @@ def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False,
 
 
 # ------------------------------------------------------------------------------------------------
+# Incremental decoding (beam search): one query position per sequence against cached keys / values
+# ------------------------------------------------------------------------------------------------
+def attention_step(xq, residual, prm, H, kv, n_keys, key_lens, self_attention):
+    """One decoding step of fairseq MultiheadAttention with incremental state (modules/multihead_attention.py:302-339):
+    ``xq`` [Bb, d] is the (layer-normed) current position of every hypothesis, ``kv`` [Bb, cap, 2d] the cache of
+    projected keys | values.  Self-attention appends this position's k | v at row ``n_keys - 1`` (projected here, by
+    the same fused QKV GEMM as training); encoder-decoder attention reads the static projected memory.  Inference only
+    (no autograd).  Returns residual + out_proj(softmax(q k^T / sqrt(dk)) v)."""
+    Bb, d = xq.shape
+    dk = d // H
+    dt, dev = xq.dtype, xq.device
+    cap = kv.shape[1]
+    if self_attention:
+        wqkv = fused([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
+        bqkv = fused_master([prm["q_b"], prm["k_b"], prm["v_b"]], 3 * d)
+        qkv = torch.empty(Bb, 3 * d, dtype=dt, device=dev)
+        K.gemm(xq, wqkv, qkv, M=Bb, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+        kv[:, n_keys - 1].copy_(qkv[:, d:])
+        q, ldq = qkv, 3 * d
+    else:
+        q = torch.empty(Bb, d, dtype=dt, device=dev)
+        K.gemm(xq, cw(prm["q_w"]), q, M=Bb, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["q_b"].data)
+        ldq = d
+    k, v = kv, kv[:, :, d:]
+    kv_sb, ldk = cap * 2 * d, 2 * d
+    Z = Bb * H
+    scale = dk ** -0.5
+    O = torch.empty(Bb, d, dtype=dt, device=dev)
+    if _use_fused_attention(dt, dk):
+        K.attn_fused_fwd(q, ldq, ldq, k, kv_sb, ldk, v, kv_sb, ldk, O, d, d, None, Bb, H, 1, n_keys, dk, key_lens, False, scale)
+    else:
+        ldS = _pad8(n_keys)
+        S = torch.empty(Z, 1, ldS, dtype=torch.float32, device=dev)
+        K.gemm(q, k, S, M=1, N=n_keys, K=dk, lda=ldq, ldb=ldk, ldc=ldS, batch=Z, zdiv=H, a_s=(ldq, dk), b_s=(kv_sb, dk),
+               c_s=(H * ldS, ldS))
+        P = torch.empty(Z, 1, ldS, dtype=dt, device=dev)
+        K.attn_softmax_fwd(S, ldS, None, 0, P, ldS, Z, H, 1, n_keys, scale, key_lens, False, False, None, None)
+        K.gemm(P, v, O, M=1, N=dk, K=n_keys, lda=ldS, ldb=ldk, ldc=d, b_kmajor=True, batch=Z, zdiv=H, a_s=(H * ldS, ldS),
+               b_s=(kv_sb, dk), c_s=(d, dk))
+    y = torch.empty(Bb, d, dtype=dt, device=dev)
+    K.gemm(O, cw(prm["o_w"]), y, M=Bb, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual, ldr=d)
+    return y
+
+
+def project_memory(mem, prm, rows):
+    """k | v projections of the encoder memory for encoder-decoder attention, computed once per sentence batch:
+    mem [rows, d] -> [rows, 2d]."""
+    d = mem.shape[1]
+    wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
+    bkv = fused_master([prm["k_b"], prm["v_b"]], 2 * d)
+    kv = torch.empty(rows, 2 * d, dtype=mem.dtype, device=mem.device)
+    K.gemm(mem, wkv, kv, M=rows, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, bias=bkv)
+    return kv
+
+
+# ------------------------------------------------------------------------------------------------
 # Conformer convolution module
 # ------------------------------------------------------------------------------------------------
 class ConvModuleFn(torch.autograd.Function):

@@ -369,6 +369,28 @@ class TransformerDecoderLayer(nn.Module):
         self.self_attn.out_dropout = self.dropout_p
         self.encoder_attn.out_dropout = self.dropout_p
 
+    def step(self, x, state, n_keys, mem, Bb, Tm, mem_lens):
+        """One incremental decoding step (inference): ``x`` [Bb, d] is the current position; ``state`` holds this
+        layer's caches: "self_kv" [Bb, cap, 2d] (grown geometrically) and "mem_kv" [Bb, Tm, 2d] (projected once)."""
+        d = x.shape[1]
+        kv = state.get("self_kv")
+        if kv is None or kv.shape[1] < n_keys:
+            cap = max(16, 2 * (n_keys - 1), n_keys)
+            new = torch.zeros(Bb, cap, 2 * d, dtype=x.dtype, device=x.device)
+            if kv is not None:
+                new[:, :kv.shape[1]].copy_(kv)
+            state["self_kv"] = kv = new
+        if "mem_kv" not in state:
+            state["mem_kv"] = Fn.project_memory(mem, self.encoder_attn._prm(), Bb * Tm).view(Bb, Tm, 2 * d)
+        y = self.self_attn_layer_norm(x)
+        x = Fn.attention_step(y, x, self.self_attn._prm(), self.self_attn.num_heads, kv, n_keys, None, True)
+        y = self.encoder_attn_layer_norm(x)
+        x = Fn.attention_step(y, x, self.encoder_attn._prm(), self.encoder_attn.num_heads, state["mem_kv"], Tm, mem_lens,
+                              False)
+        y = self.final_layer_norm(x)
+        return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.activation_fn, 1.0, x,
+                      0.0, 0.0, False)
+
     def forward(self, x, mem, B, U, Tm, self_lens, mem_lens):
         y, x = self.self_attn_layer_norm(x, fork=True)
         x = self.self_attn(y, None, x, B, U, U, self_lens, causal=True)

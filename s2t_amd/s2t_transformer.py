@@ -222,7 +222,7 @@ class TransformerDecoderScriptable(nn.Module):
 
     def extract_features(self, prev_output_tokens, encoder_out=None, incremental_state=None, **unused):
         if incremental_state is not None:
-            raise NotImplementedError("incremental decoding (beam search) is a next-tier row (SURVEY.md §8f.1)")
+            return self._extract_features_incremental(prev_output_tokens, encoder_out, incremental_state)
         B, U = prev_output_tokens.shape
         d = self.embed_dim
         dev = prev_output_tokens.device
@@ -245,6 +245,44 @@ class TransformerDecoderScriptable(nn.Module):
         if self.layer_norm is not None:
             x = self.layer_norm(x)
         return x.view(B, U, d), {"attn": [None], "inner_states": [], "mixup": None}
+
+    def _extract_features_incremental(self, prev_output_tokens, encoder_out, incremental_state):
+        """models/transformer.py:1290-1312 with ``incremental_state``: only the last position is embedded and pushed
+        through the layers; self-attention keys/values of earlier positions come from the per-layer caches kept in
+        ``incremental_state`` (modules/multihead_attention.py:302-339), the projected encoder memory is cached too."""
+        if torch.is_grad_enabled():
+            raise RuntimeError("incremental decoding is inference only: wrap the generator in torch.no_grad()")
+        Bb, U = prev_output_tokens.shape
+        d = self.embed_dim
+        dev = prev_output_tokens.device
+        nonpad = prev_output_tokens.ne(self.padding_idx)
+        pos = (torch.cumsum(nonpad, dim=1) * nonpad + self.padding_idx).to(torch.int32)[:, -1:].contiguous()
+        tab = TABLES.get("sin", self.max_positions() + self.padding_idx + 1, d, dev)
+        x = Fn.embedding(prev_output_tokens[:, -1:].contiguous(), pos, self.embed_tokens.weight, tab, self.embed_scale,
+                         self.padding_idx)
+        mem_tbc = encoder_out["encoder_out"][0]
+        Tm = mem_tbc.shape[0]
+        mem_lens = (~encoder_out["encoder_padding_mask"][0]).sum(1).to(torch.int32)
+        state = incremental_state.setdefault("s2t_amd.decoder", {"layers": [dict() for _ in self.layers]})
+        mem = None
+        if "mem_kv" not in state["layers"][0]:
+            mem = mem_tbc.transpose(0, 1).contiguous().view(Bb * Tm, d)
+        for layer, st in zip(self.layers, state["layers"]):
+            x = layer.step(x, st, U, mem, Bb, Tm, mem_lens)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        return x.view(Bb, 1, d), {"attn": [None], "inner_states": [], "mixup": None}
+
+    def reorder_incremental_state(self, incremental_state, new_order):
+        """modules/multihead_attention.py:574-592 / fairseq_incremental_decoder.py: caches follow the surviving beams."""
+        state = incremental_state.get("s2t_amd.decoder")
+        if state is None:
+            return
+        for st in state["layers"]:
+            for k in list(st.keys()):
+                st[k] = st[k].index_select(0, new_order)
+
+    reorder_incremental_state_scripting = reorder_incremental_state
 
     def output_layer(self, features):
         B, U, d = features.shape

@@ -153,3 +153,24 @@ def test_utterance_cmvn():
     x = torch.randn(50, 80, generator=torch.Generator().manual_seed(2)) * 3 + 1
     y = O.utterance_cmvn(x)
     assert y.mean(0).abs().max() < 1e-5 and (y.std(0, unbiased=False) - 1).abs().max() < 1e-4
+
+
+def test_beam_search_matches_reference_generator(golden_dir):
+    """the oracle's list-based beam search (no incremental state) against hypotheses produced by
+    the reference's SequenceGenerator (incremental decoder) on the same weights."""
+    z = np.load(os.path.join(golden_dir, "beam_search_transformer.npz"))
+    W = O.weights_from_golden(z)
+    cfg = O.cfg_from_golden(z)
+    src = torch.from_numpy(z["in::src_tokens"])
+    lens = torch.from_numpy(z["in::src_lengths"])
+    beam, mlb = int(z["gen::beam"]), int(z["gen::max_len_b"])
+    hyps = O.beam_search(src, lens, W, cfg, beam=beam, max_len_b=mlb)
+    assert [len(h) for h in hyps] == z["gen::n_hyps"].tolist()
+    lengths = set()
+    for b, hb in enumerate(hyps):
+        for k, h in enumerate(hb):
+            assert h["tokens"] == z["out::tokens_%d_%d" % (b, k)].tolist(), (b, k)
+            assert abs(h["score"] - float(z["out::score_%d_%d" % (b, k)])) < 1e-4
+            np.testing.assert_allclose(np.array(h["positional_scores"]), z["out::pos_scores_%d_%d" % (b, k)], atol=1e-4)
+            lengths.add(len(h["tokens"]))
+    assert len(lengths) > 2  # the fixture exercises early </s> as well as the forced one at max_len
