@@ -162,6 +162,11 @@ int s2t_fbank(const float* wave, int64_t wave_stride, const int32_t* n_samples, 
               float preemph, int remove_dc, float log_floor, void* stream);
 int s2t_utterance_cmvn(const float* x, float* y, const int32_t* n_frames, int64_t stride_b, int B, int C, int norm_means,
                        int norm_vars, void* stream);
+/* SpecAugment frequency / time masking (data/audio/feature_transforms/specaugment.py:79-131, no time warp), in place on
+ * x [B][stride_b] (rows of C features, first n_frames[b] rows): masks [B][n_freq + n_time][2] int32 = (start, width),
+ * frequency intervals first; masked cells := value[b], or the utterance mean when value_is_mean (value is then output). */
+int s2t_specaugment(float* x, const int32_t* n_frames, int64_t stride_b, int B, int max_frames, int C, const int32_t* masks,
+                    int n_freq, int n_time, float* value, int value_is_mean, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / gather pieces of S2TTransformerEncoder.forward and TransformerDecoder

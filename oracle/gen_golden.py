@@ -278,6 +278,26 @@ def beam_case(name, outdir, V, B, T, seed, beam, max_len_b, sharpen, eos_lift, *
     print(name, [[h["tokens"].tolist() for h in hb[:2]] for hb in hyps], [float(hb[0]["score"]) for hb in hyps])
 
 
+def specaug_case(outdir):
+    """data/audio/feature_transforms/specaugment.py:79-131 with numpy's global RNG seeded: inputs, parameters, outputs."""
+    from fairseq.data.audio.feature_transforms.specaugment import SpecAugmentTransform
+
+    out = {}
+    rng = np.random.RandomState(11)
+    cases = [(0, 2, 27, 2, 40, 0.5, 0.0), (1, 1, 13, 3, 100, 0.2, None), (2, 2, 27, 2, 100, 1.0, 0.0)]
+    for i, (seed, fn, ff, tn, tt, tp, mv) in enumerate(cases):
+        x = rng.randn(60 + 70 * i, 80).astype(np.float32) * 2 + 0.5
+        tr = SpecAugmentTransform(0, fn, ff, tn, tt, tp, mv)
+        np.random.seed(100 + seed)
+        y = tr(x)
+        out["in::x_%d" % i] = x
+        out["out::y_%d" % i] = y
+        out["cfg::params_%d" % i] = np.array([100 + seed, fn, ff, tn, tt, tp, -1.0 if mv is None else mv], dtype=np.float64)
+    out["cfg::n"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(outdir, "specaugment.npz"), **out)
+    print("specaugment", [int((out["out::y_%d" % i] != out["in::x_%d" % i]).sum()) for i in range(len(cases))])
+
+
 def ctc_greedy_case(name, outdir, V, B, T, seed, **kw):
     from fairseq.models.speech_to_text.s2t_ctc import CTCDecoder
 
@@ -383,6 +403,10 @@ def main():
         encoder_activation_fn="swish",
         layer_padding_mask=True,
     )
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "specaug"):
+        specaug_case(outdir)
+    if os.environ.get("GOLDEN_ONLY", "") == "specaug":
+        return
     if os.environ.get("GOLDEN_ONLY", "") in ("", "beam"):
         beam_case("beam_search_transformer", outdir, V=40, B=3, T=50, seed=9, beam=4, max_len_b=12, sharpen=6.0, eos_lift=EOS_LIFT,
                   share_decoder_input_output_embed=False, share_ctc_and_embed=False, **small)

@@ -506,6 +506,37 @@ def utterance_cmvn(x, norm_means=True, norm_vars=True):
 
 
 # ----------------------------------------------------------------------------------------------
+# SpecAugment masking (dataloader stage)
+# ----------------------------------------------------------------------------------------------
+def spec_augment(x, freq_mask_n, freq_mask_f, time_mask_n, time_mask_t, time_mask_p, mask_value, rng=None):
+    """data/audio/feature_transforms/specaugment.py:79-131 (time_warp_W = 0): numpy array (T, C) in, masked copy out.
+    Draw order per mask: width in [0, max), then start in [0, size - width); frequency masks first; the fill value is
+    ``mask_value`` or the mean of the un-masked spectrogram when None; no time masks when
+    min(time_mask_T, floor(T * time_mask_p)) < 1; nothing at all when T == 0 or C < freq_mask_F."""
+    import numpy as np
+    rng = np.random if rng is None else rng
+    y = x.copy()
+    T, C = x.shape
+    val = x.mean() if mask_value is None else mask_value
+    if T == 0 or C < freq_mask_f:
+        return x
+    for _ in range(freq_mask_n):
+        f = rng.randint(0, freq_mask_f)
+        f0 = rng.randint(0, C - f)
+        if f != 0:
+            y[:, f0:f0 + f] = val
+    max_t = min(time_mask_t, math.floor(T * time_mask_p))
+    if max_t < 1:
+        return y
+    for _ in range(time_mask_n):
+        t = rng.randint(0, max_t)
+        t0 = rng.randint(0, T - t)
+        if t != 0:
+            y[t0:t0 + t, :] = val
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
 # Kaldi-compatible log-mel filterbank (dataloader stage, a1) — PARITY UNPINNED
 # ----------------------------------------------------------------------------------------------
 def kaldi_mel_banks(num_bins, padded_window_size, sample_freq, low_freq=20.0, high_freq=0.0):

@@ -146,3 +146,83 @@ class UtteranceCMVN:
         n = torch.tensor([t.shape[1]], dtype=torch.int32, device=t.device)
         y = self.apply_batch(t, n)[0]
         return y.cpu().numpy() if as_numpy else y
+
+
+@register_audio_feature_transform("specaugment")
+class SpecAugmentTransform:
+    """data/audio/feature_transforms/specaugment.py — SpecAugment frequency and time masking.  The interval draws use
+    ``numpy.random`` in exactly the reference's order (per mask: width, then start; frequency masks first), so a seeded
+    run masks the same cells; the masking itself runs on the device for the whole batch (``s2t_specaugment``).
+    ``time_warp_W > 0`` (cv2 resize) is not built — the recipes leave it at 0."""
+
+    @classmethod
+    def from_config_dict(cls, config: Optional[Dict] = None):
+        _config = {} if config is None else config
+        return SpecAugmentTransform(_config.get("time_warp_W", 0), _config.get("freq_mask_N", 0), _config.get("freq_mask_F", 0),
+                                    _config.get("time_mask_N", 0), _config.get("time_mask_T", 0),
+                                    _config.get("time_mask_p", 0.0), _config.get("mask_value", None))
+
+    def __init__(self, time_warp_w=0, freq_mask_n=0, freq_mask_f=0, time_mask_n=0, time_mask_t=0, time_mask_p=0.0,
+                 mask_value=0.0):
+        if time_warp_w > 0:
+            raise NotImplementedError("time warping (cv2.resize) is not built on the HIP path")
+        if freq_mask_n > 0:
+            assert freq_mask_f > 0, f"freq_mask_F ({freq_mask_f}) must be larger than 0 when doing freq masking."
+        if time_mask_n > 0:
+            assert time_mask_t > 0, f"time_mask_T ({time_mask_t}) must be larger than 0 when doing time masking."
+        self.time_warp_w, self.freq_mask_n, self.freq_mask_f = time_warp_w, freq_mask_n, freq_mask_f
+        self.time_mask_n, self.time_mask_t, self.time_mask_p, self.mask_value = time_mask_n, time_mask_t, time_mask_p, mask_value
+
+    def __repr__(self):
+        return (self.__class__.__name__ + f"(time_warp_w={self.time_warp_w}, freq_mask_n={self.freq_mask_n}, "
+                f"freq_mask_f={self.freq_mask_f}, time_mask_n={self.time_mask_n}, time_mask_t={self.time_mask_t}, "
+                f"time_mask_p={self.time_mask_p})")
+
+    def draw(self, num_frames: int, num_freqs: int):
+        """The reference's random draws for one utterance -> (freq intervals, time intervals) as (start, width) lists
+        padded with empty intervals to freq_mask_n / time_mask_n entries."""
+        fm = [(0, 0)] * self.freq_mask_n
+        tm = [(0, 0)] * self.time_mask_n
+        if num_frames == 0 or num_freqs < self.freq_mask_f:
+            return fm, tm
+        for i in range(self.freq_mask_n):
+            f = np.random.randint(0, self.freq_mask_f)
+            f0 = np.random.randint(0, num_freqs - f)
+            fm[i] = (int(f0), int(f))
+        max_t = min(self.time_mask_t, math.floor(num_frames * self.time_mask_p))
+        if max_t < 1:
+            return fm, tm
+        for i in range(self.time_mask_n):
+            t = np.random.randint(0, max_t)
+            t0 = np.random.randint(0, num_frames - t)
+            tm[i] = (int(t0), int(t))
+        return fm, tm
+
+    def apply_batch(self, feat: torch.Tensor, n_frames: torch.Tensor) -> torch.Tensor:
+        """In place on feat (B, T, C) fp32 CUDA; utterances are drawn in batch order."""
+        if not feat.is_cuda:
+            raise RuntimeError("s2t_amd.audio runs on the GPU only; there is no CPU fallback")
+        assert feat.is_contiguous() and feat.dtype == torch.float32
+        B, T, Cf = feat.shape
+        nf = n_frames.to(torch.int32)
+        rows = []
+        for n in nf.tolist():
+            fm, tm = self.draw(int(n), Cf)
+            rows.append(fm + tm)
+        nm = self.freq_mask_n + self.time_mask_n
+        if nm == 0:
+            return feat
+        masks = torch.tensor(rows, dtype=torch.int32).view(B, nm, 2).to(feat.device)
+        use_mean = self.mask_value is None
+        value = torch.full((B,), 0.0 if use_mean else float(self.mask_value), dtype=torch.float32, device=feat.device)
+        K.specaugment(feat, nf.to(feat.device), masks, self.freq_mask_n, self.time_mask_n, value, use_mean)
+        return feat
+
+    def __call__(self, spectrogram):
+        as_numpy = isinstance(spectrogram, np.ndarray)
+        t = torch.from_numpy(np.ascontiguousarray(spectrogram, dtype=np.float32)) if as_numpy else spectrogram.float()
+        assert t.dim() == 2, "spectrogram must be a 2-D tensor."
+        t = t.cuda().clone().unsqueeze(0).contiguous()
+        n = torch.tensor([t.shape[1]], dtype=torch.int32)
+        out = self.apply_batch(t, n)[0]
+        return out.cpu().numpy() if as_numpy else out

@@ -127,6 +127,44 @@ __global__ __launch_bounds__(512) void cmvn_kernel(const float* __restrict__ x, 
   }
 }
 
+// SpecAugment masks (feature_transforms/specaugment.py:79-131): the host draws the intervals (numpy RandomState order of
+// the reference), the device applies them to the whole batch in place.  masks: [B][n_masks][2] int32 = (start, width),
+// the first n_freq of each utterance along the feature axis, the rest along time; value[b] fills the masked cells.
+__global__ __launch_bounds__(256) void specaug_kernel(float* __restrict__ x, const int32_t* __restrict__ n_frames,
+                                                      int64_t stride_b, int C, const int32_t* __restrict__ masks,
+                                                      int n_freq, int n_time, const float* __restrict__ value) {
+  const int b = blockIdx.y;
+  const int T = n_frames[b];
+  const int32_t* m = masks + (int64_t)b * (n_freq + n_time) * 2;
+  const float val = value[b];
+  float* xb = x + (int64_t)b * stride_b;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < (int64_t)T * C; idx += (int64_t)gridDim.x * 256) {
+    const int t = (int)(idx / C), c = (int)(idx % C);
+    bool hit = false;
+    for (int i = 0; i < n_freq; ++i) hit |= (c >= m[2 * i] && c < m[2 * i] + m[2 * i + 1]);
+    for (int i = n_freq; i < n_freq + n_time; ++i) hit |= (t >= m[2 * i] && t < m[2 * i] + m[2 * i + 1]);
+    if (hit) xb[idx] = val;
+  }
+}
+
+// mean over the first n_frames[b] rows of each utterance (mask_value = None: "use local mean")
+__global__ __launch_bounds__(256) void utt_mean_kernel(const float* __restrict__ x, const int32_t* __restrict__ n_frames,
+                                                       int64_t stride_b, int C, float* __restrict__ mean) {
+  __shared__ double red[256];
+  const int b = blockIdx.x;
+  const int64_t n = (int64_t)n_frames[b] * C;
+  const float* xb = x + (int64_t)b * stride_b;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += xb[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) mean[b] = n > 0 ? (float)(red[0] / (double)n) : 0.f;
+}
+
 }  // namespace
 
 extern "C" int s2t_fbank(const float* wave, int64_t wave_stride, const int32_t* n_samples, float* feat,
@@ -148,5 +186,20 @@ extern "C" int s2t_utterance_cmvn(const float* x, float* y, const int32_t* n_fra
   if (!x || !y || !n_frames || B <= 0 || C <= 0) return S2T_ERR_ARG;
   hipLaunchKernelGGL(cmvn_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, x, y, n_frames, stride_b, C, norm_means,
                      norm_vars);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_specaugment(float* x, const int32_t* n_frames, int64_t stride_b, int B, int max_frames, int C,
+                               const int32_t* masks, int n_freq, int n_time, float* value, int value_is_mean,
+                               void* stream) {
+  if (!x || !n_frames || !value || B <= 0 || C <= 0 || n_freq < 0 || n_time < 0) return S2T_ERR_ARG;
+  if (n_freq + n_time == 0 || max_frames <= 0) return S2T_OK;
+  if (!masks) return S2T_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (value_is_mean) hipLaunchKernelGGL(utt_mean_kernel, dim3(B), dim3(256), 0, s, x, n_frames, stride_b, C, value);
+  int64_t nb = ((int64_t)max_frames * C + 255) / 256;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(specaug_kernel, dim3((unsigned)nb, B), dim3(256), 0, s, x, n_frames, stride_b, C, masks, n_freq, n_time,
+                     value);
   return S2T_LAUNCH_CHECK();
 }

@@ -315,3 +315,10 @@ def utterance_cmvn(x, y, n_frames, norm_means=True, norm_vars=True):
     assert x.dtype == torch.float32 and y.dtype == torch.float32 and n_frames.dtype == torch.int32 and x.is_contiguous()
     _call("s2t_utterance_cmvn", x.data_ptr(), y.data_ptr(), n_frames.data_ptr(), T * Cf, B, Cf, int(norm_means),
           int(norm_vars))
+
+
+def specaugment(x, n_frames, masks, n_freq, n_time, value, value_is_mean):
+    B, T, Cf = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and masks.dtype == torch.int32 and value.dtype == torch.float32
+    _call("s2t_specaugment", x.data_ptr(), n_frames.data_ptr(), T * Cf, B, T, Cf, masks.data_ptr(), n_freq, n_time,
+          value.data_ptr(), int(value_is_mean))

@@ -102,3 +102,47 @@ def test_cmvn_kernel_matches_oracle():
             assert y[b, n[b]:].abs().max().item() == 0.0 if n[b] < T else True
     one = A.get_audio_feature_transform("utterance_cmvn").from_config_dict({"norm_vars": True})(x[1, :123].numpy())
     np.testing.assert_allclose(one, O.utterance_cmvn(x[1, :123].double()).numpy(), rtol=1e-4, atol=1e-4)
+
+
+def _specaug_cases(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "specaugment.npz"))
+    for i in range(int(z["cfg::n"])):
+        seed, fn, ff, tn, tt, tp, mv = z["cfg::params_%d" % i].tolist()
+        yield z["in::x_%d" % i], z["out::y_%d" % i], int(seed), int(fn), int(ff), int(tn), int(tt), tp, (None if mv < 0 else mv)
+
+
+def test_oracle_specaugment_matches_reference(golden_dir):
+    for x, y, seed, fn, ff, tn, tt, tp, mv in _specaug_cases(golden_dir):
+        np.random.seed(seed)
+        got = O.spec_augment(x, fn, ff, tn, tt, tp, mv)
+        np.testing.assert_array_equal(got, y)
+        assert (y != x).any()
+
+
+@pytest.mark.gpu
+def test_specaugment_kernel_matches_reference(golden_dir):
+    from s2t_amd import audio as A
+    for x, y, seed, fn, ff, tn, tt, tp, mv in _specaug_cases(golden_dir):
+        tr = A.SpecAugmentTransform(0, fn, ff, tn, tt, tp, mv)
+        np.random.seed(seed)
+        got = tr(x)
+        if mv is None:  # fill value = utterance mean, accumulated on the device
+            np.testing.assert_allclose(got, y, rtol=0, atol=1e-5)
+        else:
+            np.testing.assert_array_equal(got, y)
+    # batched: utterances are drawn in batch order, padded frames stay untouched
+    x0, y0, seed, fn, ff, tn, tt, tp, mv = next(_specaug_cases(golden_dir))
+    T = x0.shape[0]
+    feat = torch.zeros(2, T + 9, 80)
+    feat[0, :T] = torch.from_numpy(x0)
+    feat[1, :T - 5] = torch.from_numpy(x0[:T - 5])
+    tr = A.SpecAugmentTransform(0, fn, ff, tn, tt, tp, mv)
+    np.random.seed(seed)
+    out = tr.apply_batch(feat.cuda(), torch.tensor([T, T - 5])).cpu()
+    np.random.seed(seed)
+    r0 = O.spec_augment(x0, fn, ff, tn, tt, tp, mv)
+    r1 = O.spec_augment(x0[:T - 5], fn, ff, tn, tt, tp, mv)
+    np.testing.assert_array_equal(out[0, :T].numpy(), r0)
+    np.testing.assert_array_equal(out[1, :T - 5].numpy(), r1)
+    assert out[0, T:].abs().max() == 0 and out[1, T - 5:].abs().max() == 0
