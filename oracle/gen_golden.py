@@ -162,6 +162,7 @@ def criterion_for(task, args):
     cfg.sentence_avg = False
     cfg.zero_infinity = True
     cfg.post_process = "none"
+    cfg.inter_ctc_weight = float(getattr(args, "inter_ctc_weight", 0.0) or 0.0)
     crit = LabelSmoothedCrossEntropyCriterionWithCTC(
         task, label_smoothing=0.1, sentence_avg=False, cfg=cfg, ctc_weight=args.ctc_weight
     )
@@ -208,6 +209,10 @@ def encdec_case(name, outdir, arch, V, B, T, seed, train_bn=False, **kw):
     out["out::trans_loss"] = np.float64(log["trans_loss"])
     out["out::nll_loss"] = np.float64(log["nll_loss"])
     out["out::ctc_loss"] = np.float64(log["ctc_loss"])
+    if "inter_ctc_loss" in log:
+        out["out::inter_ctc_loss"] = np.float64(log["inter_ctc_loss"])
+        for i, il in enumerate(enc["inter_ctc_logits"]):
+            out["out::inter_ctc_logit_%d" % i] = np_(il[0] if isinstance(il, (list, tuple)) else il)
     out["out::n_correct"] = np.int64(log["n_correct"])
     out["out::total"] = np.int64(log["total"])
     out["out::sample_size"] = np.int64(sample_size)
@@ -403,6 +408,13 @@ def main():
         encoder_activation_fn="swish",
         layer_padding_mask=True,
     )
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "interctc"):
+        # egs/mustc/asr/conf/inter.yaml: intermediate CTC heads sharing the top projection, own LayerNorms
+        encdec_case("conformer_interctc", outdir, "s2t_transformer_s", V=40, B=3, T=50, seed=12, train_bn=True,
+                    **dict(small, encoder_layers=4), **conf, inter_ctc_layers="2,3", share_inter_ctc=True,
+                    inter_ctc_weight=0.2, ctc_pae="none")
+    if os.environ.get("GOLDEN_ONLY", "") == "interctc":
+        return
     if os.environ.get("GOLDEN_ONLY", "") in ("", "specaug"):
         specaug_case(outdir)
     if os.environ.get("GOLDEN_ONLY", "") == "specaug":

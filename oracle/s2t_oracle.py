@@ -256,8 +256,21 @@ def encoder_layer(x, pad_mask, pos_tab, W, prefix, cfg, training, bn_stats=None)
     return x
 
 
+def inter_ctc_layer_list(cfg):
+    """--inter-ctc-layers "6,9" -> [6, 9] (1-based: the head reads the output of that layer; values <= 0 count from the
+    top, s2t_transformer.py:1004-1013)."""
+    spec = cfg.get("inter_ctc_layers", None)
+    if spec is None or str(spec) in ("", "None"):
+        return []
+    out = []
+    for t in str(spec).split(","):
+        L = int(t)
+        out.append(L + int(cfg["encoder_layers"]) if L <= 0 else L)
+    return out
+
+
 def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None):
-    """models/speech_to_text/s2t_transformer.py:1714-2154 (no mixup / inter-CTC / PAE branches).
+    """models/speech_to_text/s2t_transformer.py:1714-2154 (no mixup / PAE branches; intermediate CTC heads included).
 
     Returns the reference's dict (time-major tensors in lists)."""
     d = cfg["encoder_embed_dim"]
@@ -275,15 +288,26 @@ def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="enc
     else:
         x = x + sinusoidal_positions(pad_mask, d, padding_idx=1)  # :1785-1787
     any_valid = not bool(pad_mask.all())
+    inter_layers = inter_ctc_layer_list(cfg)
+    inter_logits = []
     for i in range(cfg["encoder_layers"]):
         if cfg.get("layer_padding_mask", False) and any_valid:
             x = x.masked_fill(pad_mask[:, :, None], 0.0)  # :1828-1836
         x = encoder_layer(x, pad_mask, pos_tab, W, f"{prefix}layers.{i}.", cfg, training, bn_stats)
+        if (i + 1) in inter_layers:
+            # intermediate CTC (:1881-1946, ctc_pae none): own LayerNorm ctc_norm{L} (or the final one when
+            # share_inter_ctc_norm), then the shared top projection (share_inter_ctc) or the layer's own head
+            L = i + 1
+            npre = prefix + ("layer_norm." if cfg.get("share_inter_ctc_norm", False) else "ctc_norm%d." % L)
+            hpre = prefix + ("ctc." if cfg.get("share_inter_ctc", False) else "inter_ctc%d." % L)
+            nx = layer_norm(x, W[npre + "weight"], W[npre + "bias"])
+            inter_logits.append(linear(nx, W[hpre + "ctc_projection.weight"], W[hpre + "ctc_projection.bias"]).transpose(0, 1))
     x = layer_norm(x, W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"])
     out = {
         "encoder_out": [x.transpose(0, 1)],
         "encoder_padding_mask": [pad_mask],
         "ctc_logit": [],
+        "inter_ctc_logits": inter_logits,
     }
     if prefix + "ctc.ctc_projection.weight" in W:
         logit = linear(x, W[prefix + "ctc.ctc_projection.weight"], W[prefix + "ctc.ctc_projection.bias"])
@@ -462,9 +486,22 @@ def joint_loss(W, cfg, src_tokens, src_lengths, prev_output_tokens, target, eps=
     else:
         ctc = ctc_nll(lp, tg, lens).sum()
     loss = ce + cfg["ctc_weight"] * ctc
+    inter = None
+    iw = float(cfg.get("inter_ctc_weight", 0.0) or 0.0)
+    if iw > 0 and len(enc.get("inter_ctc_logits", [])) > 0:
+        # criterions/ctc.py:568-633: the same targets for every intermediate head, losses averaged over the heads
+        inter = 0.0
+        for lg in enc["inter_ctc_logits"]:
+            ilp = torch.log_softmax(lg.float(), dim=-1)
+            if use_torch_ctc:
+                inter = inter + F.ctc_loss(ilp, flat, lens, tl, blank=0, reduction="none", zero_infinity=True).sum()
+            else:
+                inter = inter + ctc_nll(ilp, tg, lens).sum()
+        inter = inter / len(enc["inter_ctc_logits"])
+        loss = loss + iw * inter
     n_correct, total = ce_accuracy(logits, target)
-    return loss, {"trans_loss": ce, "nll_loss": nll, "ctc_loss": ctc, "n_correct": n_correct, "total": total,
-                  "logits": logits, "enc": enc}
+    return loss, {"trans_loss": ce, "nll_loss": nll, "ctc_loss": ctc, "inter_ctc_loss": inter, "n_correct": n_correct,
+                  "total": total, "logits": logits, "enc": enc}
 
 
 # ----------------------------------------------------------------------------------------------

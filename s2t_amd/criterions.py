@@ -20,7 +20,8 @@ def ctc_targets(target, pad_idx, eos_idx):
 
 @register_criterion("label_smoothed_cross_entropy_with_ctc")
 class LabelSmoothedCrossEntropyCriterionWithCTC(nn.Module):
-    def __init__(self, task, label_smoothing=0.1, sentence_avg=False, cfg=None, ctc_weight=0.0, **unused):
+    def __init__(self, task, label_smoothing=0.1, sentence_avg=False, cfg=None, ctc_weight=0.0, inter_ctc_weight=None,
+                 **unused):
         super().__init__()
         d = task.target_dictionary
         self.padding_idx, self.eos_idx = d.pad(), d.eos()
@@ -28,6 +29,10 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(nn.Module):
         self.eps = float(label_smoothing)
         self.sentence_avg = sentence_avg
         self.ctc_weight = ctc_weight
+        # criterions/ctc.py:65,204 (CtcCriterionConfig.inter_ctc_weight; the reference reads it from ``cfg``)
+        if inter_ctc_weight is None:
+            inter_ctc_weight = float(getattr(cfg, "inter_ctc_weight", 0.0) or 0.0) if cfg is not None else 0.0
+        self.inter_ctc_weight = float(inter_ctc_weight)
         self.report_accuracy = True
 
     def forward(self, model, sample, reduce=True, sync_logging=True):
@@ -50,8 +55,20 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(nn.Module):
             l2d = ctc_tbv.transpose(0, 1).reshape(B * Tn, -1)  # a view: the encoder's buffer is batch-major
             ctc = Fn.ctc_loss(l2d, B, Tn, tmat, tl, in_lens, self.blank_idx)
             log["ctc_loss"] = ctc.detach()
-            log["all_ctc_loss"] = (self.ctc_weight * ctc).detach()
-            loss = loss + self.ctc_weight * ctc
+            all_ctc = self.ctc_weight * ctc
+            inter = enc.get("inter_ctc_logits", [])
+            if self.inter_ctc_weight > 0 and len(inter) > 0:
+                # criterions/ctc.py:568-633: every intermediate head against the same targets, averaged over the heads
+                total = None
+                for il in inter:
+                    lg = il[0] if isinstance(il, (list, tuple)) else il
+                    li = Fn.ctc_loss(lg.transpose(0, 1).reshape(B * Tn, -1), B, Tn, tmat, tl, in_lens, self.blank_idx)
+                    total = li if total is None else total + li
+                inter_loss = total / len(inter)
+                log["inter_ctc_loss"] = inter_loss.detach()
+                all_ctc = all_ctc + self.inter_ctc_weight * inter_loss
+            log["all_ctc_loss"] = all_ctc.detach()
+            loss = loss + all_ctc
         log["loss"] = loss.detach()
         if sync_logging:
             log = {k: (v.item() if torch.is_tensor(v) else v) for k, v in log.items()}

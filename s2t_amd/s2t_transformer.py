@@ -43,9 +43,9 @@ class S2TTransformerEncoder(nn.Module):
 
     def __init__(self, args, task=None, decoder_embed_tokens=None):
         super().__init__()
-        _unsupported(args, inter_mixup=False, use_enc_dlcl=False, inter_ctc_layers=None, inter_xctc_layers=None,
+        _unsupported(args, inter_mixup=False, use_enc_dlcl=False, inter_xctc_layers=None,
                      xctc_weight=0, compression_layers=None, encoder_embed_linear=False, layer_out_norm=False,
-                     encoder_layerdrop=0.0)
+                     encoder_layerdrop=0.0, inter_ctc_drop_prob=0, inter_ctc_mlo="")
         self.args = args
         d = args.encoder_embed_dim
         self.embed_dim = d
@@ -71,6 +71,28 @@ class S2TTransformerEncoder(nn.Module):
             self.ctc = CTC(d, dictionary_size=vocab, dropout=args.dropout)
             if getattr(args, "share_ctc_and_embed", False) and decoder_embed_tokens is not None:
                 self.ctc.ctc_projection.weight = decoder_embed_tokens.weight  # s2t_transformer.py:965-971
+        # intermediate CTC heads (egs/mustc/asr/conf/inter.yaml; s2t_transformer.py:975-1031, forward :1881-1946 with
+        # ctc_pae none): after layer L (1-based; <= 0 counts from the top) a LayerNorm ``ctc_norm{L}`` (or the final
+        # one, --share-inter-ctc-norm) feeds the shared top head (--share-inter-ctc) or the layer's own ``inter_ctc{L}``
+        self.inter_ctc_layers = []
+        spec = getattr(args, "inter_ctc_layers", None)
+        if spec is not None and str(spec) not in ("", "None"):
+            if getattr(args, "ctc_pae", "none") != "none":
+                raise NotImplementedError("prediction-aware encoding (ctc_pae) on the HIP path")
+            self.share_inter_ctc = bool(getattr(args, "share_inter_ctc", False))
+            self.share_inter_ctc_norm = bool(getattr(args, "share_inter_ctc_norm", False))
+            vocab = len(task.source_dictionary) if task is not None else args.vocab_size
+            for t in str(spec).split(","):
+                L = int(t)
+                L = L + args.encoder_layers if L <= 0 else L
+                if not self.share_inter_ctc_norm:
+                    setattr(self, "ctc_norm%d" % L, LayerNorm(d))
+                if not (self.use_ctc and self.share_inter_ctc):
+                    head = CTC(d, dictionary_size=vocab, dropout=args.dropout)
+                    if getattr(args, "share_ctc_and_embed", False) and decoder_embed_tokens is not None:
+                        head.ctc_projection.weight = decoder_embed_tokens.weight
+                    setattr(self, "inter_ctc%d" % L, head)
+                self.inter_ctc_layers.append(L)
         self.compute_dtype = torch.float32
         self.ctc_out_dtype = None  # None -> compute dtype; eval sets fp32 (bit-exact greedy wants fp32 logits)
         self.num_updates = 0
@@ -122,8 +144,18 @@ class S2TTransformerEncoder(nn.Module):
         if self.layer_padding_mask:
             x = MaskRows.apply(x, lens32, Tp)  # layer 0's masked_fill (:1828-1836); later layers: fused in final_norm
         n = len(self.layers)
+        inter_ctc_logits = []
         for i, layer in enumerate(self.layers):
-            x = layer(x, c, mask_output=self.layer_padding_mask and i + 1 < n)
+            tap = (i + 1) in self.inter_ctc_layers  # the head reads the layer output BEFORE the next layer's mask
+            x = layer(x, c, mask_output=self.layer_padding_mask and i + 1 < n and not tap)
+            if tap:
+                L = i + 1
+                norm = self.layer_norm if self.share_inter_ctc_norm else getattr(self, "ctc_norm%d" % L)
+                head = self.ctc if (self.use_ctc and self.share_inter_ctc) else getattr(self, "inter_ctc%d" % L)
+                il = head(norm(x), out_dtype=self.ctc_out_dtype).view(B, Tp, -1).transpose(0, 1)
+                inter_ctc_logits.append([il, encoder_padding_mask])  # the reference's [logit, padding mask] pairs
+                if self.layer_padding_mask and i + 1 < n:
+                    x = MaskRows.apply(x, lens32, Tp)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
         ctc_logit = None
@@ -133,7 +165,7 @@ class S2TTransformerEncoder(nn.Module):
         return {
             "encoder_out": [x.view(B, Tp, d).transpose(0, 1)],  # T x B x C (view of the batch-major buffer)
             "ctc_logit": [] if ctc_logit is None else [ctc_logit],
-            "inter_ctc_logits": [],
+            "inter_ctc_logits": inter_ctc_logits,
             "xctc_logit": [],
             "inter_xctc_logits": [],
             "encoder_padding_mask": [encoder_padding_mask],

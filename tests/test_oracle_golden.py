@@ -8,7 +8,8 @@ import torch
 
 from oracle import s2t_oracle as O
 
-CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small"]
+CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small",
+         "conformer_interctc"]
 
 
 def _load(golden_dir, name):
@@ -47,6 +48,10 @@ def test_eval_forward(golden_dir, name):
     _close(enc["encoder_out"][0], z["out::encoder_out"], rtol=1e-4, atol=2e-5)
     _close(enc["ctc_logit"][0], z["out::ctc_logit"], rtol=1e-4, atol=2e-5)
     _close(logits, z["out::decoder_logits"], rtol=1e-4, atol=2e-5)
+    i = 0
+    while "out::inter_ctc_logit_%d" % i in z.files:  # intermediate CTC heads (inter.yaml)
+        _close(enc["inter_ctc_logits"][i], z["out::inter_ctc_logit_%d" % i], rtol=1e-4, atol=2e-5)
+        i += 1
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -65,6 +70,8 @@ def test_loss_and_grads(golden_dir, name, torch_ctc):
     assert abs(float(log["trans_loss"]) - float(z["out::trans_loss"])) <= 1e-4 * abs(float(z["out::trans_loss"]))
     assert abs(float(log["nll_loss"]) - float(z["out::nll_loss"])) <= 1e-4 * abs(float(z["out::nll_loss"]))
     assert abs(float(log["ctc_loss"]) - float(z["out::ctc_loss"])) <= 1e-4 * abs(float(z["out::ctc_loss"]))
+    if "out::inter_ctc_loss" in z.files:
+        assert abs(float(log["inter_ctc_loss"]) - float(z["out::inter_ctc_loss"])) <= 1e-4 * abs(float(z["out::inter_ctc_loss"]))
     assert log["n_correct"] == int(z["out::n_correct"]) and log["total"] == int(z["out::total"])
     loss.backward()
     # the reference ties these (share_decoder_input_output_embed / share_ctc_and_embed; SATE also the text embedding);
