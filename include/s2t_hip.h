@@ -148,6 +148,30 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        uint32_t drop_site, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Grouped weight gradients: all dW[M=Nout][N=Kin] += alpha * dY[K=rows][M]^T @ X[K][N] (bf16 in, fp32 accumulate) of one
+ * backward pass in one persistent launch + one reduce launch (csrc/gemm_grouped.hip).  The host cuts the problems into
+ * work items (one 128x128 output tile x `ksteps` K-steps of 64 rows) and lists the output tiles for the reduction;
+ * all three tables live in device memory.  colsum (optional): colsum[m] += alpha * sum_k dY[k][m] (bias gradient).
+ *   items_dev: [n_items][4] int32 = (problem, tile row, tile column, K split)
+ *   tiles_dev: [n_tiles][4] int32 = (problem, tile row, tile column, 0)
+ *   ws: fp32 scratch, problem p uses [ws_base, ws_base + tiles_p * nsplit * 16384)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct s2t_wgrad_problem {
+  const void* A;  /* dY: element (k, m) at A[k*lda + m], bf16 */
+  const void* B;  /* X:  element (k, n) at B[k*ldb + n], bf16 */
+  float* C;       /* dW [M][ldc], accumulated into */
+  float* colsum;  /* [M] or NULL */
+  int64_t lda, ldb, ldc, ws_base;
+  int32_t M, N, K, tiles_n, ksteps, nsplit;
+  float alpha;
+  int32_t next;   /* index of the next problem accumulating into the same C (tied weights; same M, N), or -1:
+                     only the first problem of such a chain appears in tiles_dev */
+} s2t_wgrad_problem;
+
+int s2t_wgrad_grouped(const s2t_wgrad_problem* problems_dev, int n_problems, const int32_t* items_dev, int n_items,
+                      const int32_t* tiles_dev, int n_tiles, float* ws, int any_k_tail, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Feature front-end (dataloader stage of the reference, here on the device)
  *   s2t_fbank: data/audio/audio_utils.py:59-79 (_get_torchaudio_fbank -> torchaudio.compliance.kaldi.fbank with its
  *     defaults: snip_edges, dither 0, DC removal, pre-emphasis, window, zero-pad to nfft, power spectrum, mel, log).

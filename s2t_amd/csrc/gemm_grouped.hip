@@ -1,0 +1,302 @@
+// Grouped weight-gradient GEMM: every dW[Nout, Kin] += alpha * dY[rows, Nout]^T @ X[rows, Kin] of one backward pass in
+// ONE persistent launch (+ one reduce launch), instead of one small split-K GEMM per parameter.
+//
+// Why: the ~160 weight-gradient GEMMs of a training step are individually small (4 to 32 output tiles, K = B*T' = 16 000):
+// each launch pays its own ramp-up, tail and split-K reduction, and the small ones run at 50-150 TFLOP/s.  Nothing in
+// backward consumes a weight gradient before the optimizer, so the host queues (dY, X, dW) triples and flushes them
+// at the end of backward (functional._wgrad / flush_wgrads).  The work list is cut into items of one 128x128 output tile
+// x up to `ksteps` K-steps; persistent workgroups (2 per CU) walk the items back to back with the same register
+// prefetch across item boundaries as gemm.hip, store fp32 partial tiles to a workspace in register-native order, and a
+// second kernel sums the partials of each tile into dW.  Bias gradients (column sums of dY) are taken from the staged
+// dY tiles as in gemm.hip.
+//
+// Reference semantics replaced: the autograd backward of every F.linear / pointwise Conv1d on the path
+// (modules/s2t_transformer_layer.py:55-66, multihead_attention.py:239-263, espnet_multihead_attention.py:88-106,
+// convolution.py:91,106, speech_to_text/ctc.py:59, models/transformer.py:1442).
+#include <type_traits>
+#include <utility>
+
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int GD = 2;  // register sets (K-steps of global loads in flight per workgroup)
+
+struct Item {  // one work item, 16 bytes
+  int32_t prob, tm, tn, split;
+};
+
+// position of a K-step in the walk (all workgroup-uniform)
+struct GCursor {
+  int ord;             // item ordinal of this workgroup
+  int kt, kt1, kt_end; // current K-tile, end of the item's real K-tiles, end incl. padding to a multiple of GD
+};
+
+template <bool KT>
+__global__ __launch_bounds__(256, 2) void wgrad_grouped_kernel(const s2t_wgrad_problem* __restrict__ probs,
+                                                               const Item* __restrict__ items, int n_items,
+                                                               float* __restrict__ ws) {
+  typedef bf16_t T;
+  constexpr int BKE = 64, EPB = 8;
+  __shared__ __attribute__((aligned(16))) char smem[65536];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int x = lane & 15, y = lane >> 4;
+
+  const int G = gridDim.x;
+  int w = blockIdx.x;
+  if ((G & 7) == 0) w = (w & 7) * (G >> 3) + (w >> 3);  // XCD-contiguous item ranges (see gemm.hip)
+  if (w >= n_items) return;
+  const int my_items = (n_items - w + G - 1) / G;
+
+  // ---- load side state
+  Item li;
+  const s2t_wgrad_problem* lp;
+  LoadPlan pa, pb;
+  auto load_item = [&](int ord, GCursor& c) __attribute__((always_inline)) {
+    li = items[w + ord * G];
+    lp = probs + li.prob;
+    const int ktiles = (lp->K + BKE - 1) / BKE;
+    c.ord = ord;
+    c.kt = li.split * lp->ksteps;
+    c.kt1 = min(ktiles, c.kt + lp->ksteps);
+    c.kt_end = c.kt + (c.kt1 - c.kt + GD - 1) / GD * GD;
+    plan_kmajor<T>(pa, lp->lda, li.tm * BM, lp->M, tid);
+    plan_kmajor<T>(pb, lp->ldb, li.tn * BN, lp->N, tid);
+  };
+  uint4 ra[GD][4], rb[GD][4];
+  auto gload = [&](uint4 (&qa)[4], uint4 (&qb)[4], const GCursor& c) __attribute__((always_inline)) {
+    const int k0 = min(c.kt, c.kt1 - 1) * BKE;
+    load_kmajor<T, KT>(qa, reinterpret_cast<const char*>(lp->A), pa, lp->lda, k0, lp->K, tid);
+    load_kmajor<T, KT>(qb, reinterpret_cast<const char*>(lp->B), pb, lp->ldb, k0, lp->K, tid);
+  };
+  auto advance_load = [&](GCursor& c) __attribute__((always_inline)) {
+    if (c.kt + 1 < c.kt_end) ++c.kt;
+    else if (c.ord + 1 < my_items) load_item(c.ord + 1, c);
+  };
+
+  // ---- compute side state (the step being multiplied and the one landing in LDS next)
+  struct CItem {
+    Item it;
+    const s2t_wgrad_problem* p;
+    int kt, kt1, kt_end, K;
+  };
+  auto citem_at = [&](int ord) __attribute__((always_inline)) {
+    CItem c;
+    c.it = items[w + ord * G];
+    c.p = probs + c.it.prob;
+    c.K = c.p->K;
+    const int ktiles = (c.K + BKE - 1) / BKE;
+    c.kt = c.it.split * c.p->ksteps;
+    c.kt1 = min(ktiles, c.kt + c.p->ksteps);
+    c.kt_end = c.kt + (c.kt1 - c.kt + GD - 1) / GD * GD;
+    return c;
+  };
+
+  f32x4 acc[4][4];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+  float csum[EPB];
+#pragma unroll
+  for (int e = 0; e < EPB; ++e) csum[e] = 0.f;
+
+  auto gfix = [&](uint4 (&qa)[4], uint4 (&qb)[4], int kt, int kt1, int K) __attribute__((always_inline)) {
+    if (kt >= kt1) {  // padding step
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qa[u] = qb[u] = make_uint4(0, 0, 0, 0);
+    } else if constexpr (KT) {
+      const int k0 = kt * BKE;
+      if (k0 + BKE > K) {
+        fix_kmajor<T>(qa, k0, K, tid);
+        fix_kmajor<T>(qb, k0, K, tid);
+      }
+    }
+  };
+  auto colsum_acc = [&](const uint4 (&qa)[4], bool on) __attribute__((always_inline)) {
+    if (on) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t w4[4] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          csum[2 * q] += __uint_as_float(w4[q] << 16);
+          csum[2 * q + 1] += __uint_as_float(w4[q] & 0xffff0000u);
+        }
+      }
+    }
+  };
+  auto lstore = [&](int buf, const uint4 (&qa)[4], const uint4 (&qb)[4]) __attribute__((always_inline)) {
+    char* la = smem + buf * 32768;
+    store_kmajor<T>(la, qa, tid);
+    store_kmajor<T>(la + 16384, qb, tid);
+  };
+
+  // ---- epilogue of one item: partial tile -> workspace (register-native order), bias-gradient partial -> atomics
+  auto epilogue = [&](const CItem& c) __attribute__((always_inline)) {
+    const s2t_wgrad_problem* p = c.p;
+    const int tile = c.it.tm * p->tiles_n + c.it.tn;
+    float* wt = ws + p->ws_base + ((int64_t)tile * p->nsplit + c.it.split) * (int64_t)(BM * BN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(wt + ((i * 4 + j) * 256 + tid) * 4) = acc[i][j];
+    if (p->colsum && c.it.tn == 0) {  // workgroup-uniform
+      constexpr int CPR_A = 128 / EPB;
+      __syncthreads();
+      float* lc = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int e = 0; e < EPB; ++e) {
+        lc[tid * EPB + e] = csum[e];
+        csum[e] = 0.f;
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int ch = tid / EPB, e = tid % EPB;
+        float sum = 0.f;
+        for (int j = 0; j < 256 / CPR_A; ++j) sum += lc[(ch + CPR_A * j) * EPB + e];
+        const int m = c.it.tm * BM + tid;
+        if (m < p->M) atomicAdd(p->colsum + m, p->alpha * sum);
+      }
+      __syncthreads();
+    }
+  };
+
+  // ---- the walk
+  GCursor L;
+  load_item(0, L);
+#pragma unroll
+  for (int u = 0; u < GD; ++u) {
+    gload(ra[u], rb[u], L);
+    advance_load(L);
+  }
+  CItem C = citem_at(0);
+  gfix(ra[0], rb[0], C.kt, C.kt1, C.K);
+  colsum_acc(ra[0], C.p->colsum != nullptr && C.it.tn == 0);
+  lstore(0, ra[0], rb[0]);
+  __syncthreads();
+  int c_ord = 0;
+  int s = 0;  // global step counter of this workgroup (LDS buffer parity)
+
+  auto multiply = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    gload(ra[u], rb[u], L);
+    advance_load(L);
+    const char* la = smem + (s & 1) * 32768;
+    const char* lb = la + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<T, true>(la, wm * 64 + i * 16, ks, x, y);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<T, true>(lb, wn * 64 + j * 16, ks, x, y);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], fb[j], fa[i]);
+    }
+  };
+  // land the step after (C.kt) in the other LDS buffer; `nx` describes that step's item
+  auto land_next = [&](auto uc, const CItem& nx, int nkt) __attribute__((always_inline)) {
+    constexpr int un = (decltype(uc)::value + 1) % GD;
+    gfix(ra[un], rb[un], nkt, nx.kt1, nx.K);
+    colsum_acc(ra[un], nx.p->colsum != nullptr && nx.it.tn == 0 && nkt < nx.kt1);
+    lstore((s & 1) ^ 1, ra[un], rb[un]);
+    __syncthreads();
+    ++s;
+  };
+
+  for (;;) {
+    // GD steps of the current item (items are padded to multiples of GD steps, so they end on iteration boundaries)
+    static_assert(GD == 2, "the iteration below is written for two register sets");
+    multiply(std::integral_constant<int, 0>{});
+    land_next(std::integral_constant<int, 0>{}, C, C.kt + 1);
+    ++C.kt;
+    multiply(std::integral_constant<int, 1>{});
+    if (C.kt + 1 == C.kt_end) {  // workgroup-uniform: last step of the item
+      epilogue(C);
+      if (c_ord + 1 == my_items) break;
+      zero_acc();
+      ++c_ord;
+      C = citem_at(c_ord);
+      land_next(std::integral_constant<int, 1>{}, C, C.kt);
+    } else {
+      land_next(std::integral_constant<int, 1>{}, C, C.kt + 1);
+      ++C.kt;
+    }
+  }
+}
+
+// dW[m][n] += alpha * sum_split partial[tile][split]: one workgroup per (output tile, accumulator fragment)
+struct TileRef {
+  int32_t prob, tm, tn, pad;
+};
+__global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const s2t_wgrad_problem* __restrict__ probs,
+                                                                   const TileRef* __restrict__ tiles,
+                                                                   const float* __restrict__ ws) {
+  const TileRef t = tiles[blockIdx.x];
+  const s2t_wgrad_problem* p = probs + t.prob;
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, x = lane & 15, y = lane >> 4;
+  const int i = f >> 2, j = f & 3;
+  const int m = t.tm * BM + wm * 64 + i * 16 + x;
+  const int n = t.tn * BN + wn * 64 + j * 16 + 4 * y;
+  const int tile = t.tm * p->tiles_n + t.tn;
+  // problems that accumulate into the SAME dW (tied weights) are chained through `next` and summed by this one
+  // workgroup, so that every dW element has exactly one (non-atomic) writer
+  f32x4 total = {0.f, 0.f, 0.f, 0.f};
+  for (const s2t_wgrad_problem* q = p;;) {
+    const float* src = ws + q->ws_base + (int64_t)tile * q->nsplit * (BM * BN) + (f * 256 + tid) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int s = 0;
+    const int ns = q->nsplit;
+    for (; s + 4 <= ns; s += 4) {
+      s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * (BM * BN));
+      s1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 1) * (BM * BN));
+      s2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 2) * (BM * BN));
+      s3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 3) * (BM * BN));
+    }
+    for (; s < ns; ++s) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * (BM * BN));
+    total += ((s0 + s1) + (s2 + s3)) * q->alpha;
+    if (q->next < 0) break;
+    q = probs + q->next;
+  }
+  if (m < p->M && n < p->N) {
+    float* dst = p->C + (int64_t)m * p->ldc + n;
+    if (n + 3 < p->N && (p->ldc & 3) == 0 && (((uintptr_t)p->C) & 15) == 0) {
+      f32x4 c = *reinterpret_cast<f32x4*>(dst);
+      c += total;
+      *reinterpret_cast<f32x4*>(dst) = c;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p->N) dst[r] += total[r];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int s2t_wgrad_grouped(const s2t_wgrad_problem* problems_dev, int n_problems, const int32_t* items_dev,
+                                 int n_items, const int32_t* tiles_dev, int n_tiles, float* ws, int any_k_tail,
+                                 void* stream) {
+  if (!problems_dev || !items_dev || !tiles_dev || !ws || n_problems <= 0 || n_items <= 0 || n_tiles <= 0) return S2T_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int slots = 2 * s2t_device_cu_count();
+  dim3 grid(n_items < slots ? n_items : slots), block(256);
+  if (any_k_tail)
+    hipLaunchKernelGGL(wgrad_grouped_kernel<true>, grid, block, 0, s, problems_dev, reinterpret_cast<const Item*>(items_dev),
+                       n_items, ws);
+  else
+    hipLaunchKernelGGL(wgrad_grouped_kernel<false>, grid, block, 0, s, problems_dev,
+                       reinterpret_cast<const Item*>(items_dev), n_items, ws);
+  hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(n_tiles, 16), dim3(256), 0, s, problems_dev,
+                     reinterpret_cast<const TileRef*>(tiles_dev), ws);
+  return S2T_LAUNCH_CHECK();
+}

@@ -21,6 +21,9 @@ _HOOKS = {"grad_ready": None}  # set by the DDP wrapper: called with a parameter
 
 def _ready(*params):
     cb = _HOOKS["grad_ready"]
+    if cb is not None and _WGQ["armed"]:  # weight gradients are still queued: notify after the grouped launch
+        _WGQ["ready"].extend(p for p in params if p is not None)
+        return
     if cb is not None:
         for p in params:
             if p is not None:
@@ -166,9 +169,109 @@ class _on_wgrad_stream:
         return False
 
 
+# Deferred, grouped weight gradients (csrc/gemm_grouped.hip): nothing consumes a weight gradient before the optimizer,
+# so the bf16 (dY, X, dW) triples of a backward pass are queued and executed by ONE persistent launch (+ one reduction)
+# from an autograd engine callback at the end of backward.  Operands stay referenced until then.  The parameters'
+# grad-ready notifications (DDP bucket hooks) are deferred with them.  S2T_WGRAD_GROUPED=0 restores one GEMM per weight.
+_WGQ = {"probs": [], "ready": [], "armed": False, "enabled": os.environ.get("S2T_WGRAD_GROUPED", "1") == "1",
+        "bufs": {}, "captured": []}
+_WG_KSTEPS = 32  # K-steps (of 64 rows) per work item
+_WG_DTYPE = None
+
+
+def _wg_dtype():
+    global _WG_DTYPE
+    if _WG_DTYPE is None:
+        import numpy as np
+        _WG_DTYPE = np.dtype([("A", "u8"), ("B", "u8"), ("C", "u8"), ("colsum", "u8"), ("lda", "i8"), ("ldb", "i8"),
+                              ("ldc", "i8"), ("ws_base", "i8"), ("M", "i4"), ("N", "i4"), ("K", "i4"), ("tiles_n", "i4"),
+                              ("ksteps", "i4"), ("nsplit", "i4"), ("alpha", "f4"), ("next", "i4")])
+        assert _WG_DTYPE.itemsize == 96
+    return _WG_DTYPE
+
+
+def flush_wgrads():
+    """Run every queued weight gradient (called by the end-of-backward callback; safe to call with an empty queue)."""
+    import numpy as np
+    q, _WGQ["probs"] = _WGQ["probs"], []
+    ready, _WGQ["ready"] = _WGQ["ready"], []
+    _WGQ["armed"] = False
+    if q:
+        dev = q[0][0].device
+        probs = np.zeros(len(q), dtype=_wg_dtype())
+        items, tiles = [], []
+        ws_floats = 0
+        k_tail = False
+        last_of = {}
+        for i, (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db) in enumerate(q):
+            tm_n, tn_n = (Nout + 127) // 128, (Kin + 127) // 128
+            ktiles = (M + 63) // 64
+            nsplit = (ktiles + _WG_KSTEPS - 1) // _WG_KSTEPS
+            k_tail |= (M % 64) != 0
+            probs[i] = (dY.data_ptr(), X.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, ldy, ldx,
+                        Kin, ws_floats, Nout, Kin, M, tn_n, _WG_KSTEPS, nsplit, alpha, -1)
+            prev = last_of.get(dW.data_ptr())  # tied weights: chain the problems, reduce them in one workgroup
+            last_of[dW.data_ptr()] = i
+            if prev is not None:
+                assert probs[prev]["M"] == Nout and probs[prev]["N"] == Kin
+                probs[prev]["next"] = i
+            ws_floats += tm_n * tn_n * nsplit * 16384
+            t = np.empty((tm_n, nsplit, tn_n, 4), dtype=np.int32)  # order: tile row, K split, tile column (A slab reuse)
+            t[..., 0] = i
+            t[..., 1] = np.arange(tm_n, dtype=np.int32)[:, None, None]
+            t[..., 2] = np.arange(tn_n, dtype=np.int32)[None, None, :]
+            t[..., 3] = np.arange(nsplit, dtype=np.int32)[None, :, None]
+            items.append(t.reshape(-1, 4))
+            if prev is not None:
+                continue  # its tiles are reduced by the head of the chain
+            tl = np.zeros((tm_n, tn_n, 4), dtype=np.int32)
+            tl[..., 0] = i
+            tl[..., 1] = np.arange(tm_n, dtype=np.int32)[:, None]
+            tl[..., 2] = np.arange(tn_n, dtype=np.int32)[None, :]
+            tiles.append(tl.reshape(-1, 4))
+        items = np.concatenate(items)
+        tiles = np.concatenate(tiles)
+        blob = np.concatenate([probs.view(np.uint8), items.view(np.uint8).reshape(-1), tiles.view(np.uint8).reshape(-1)])
+        nbytes = (blob.size + 15) // 16 * 16
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = str(dev)
+        bufs = _WGQ["bufs"].get(key)
+        if bufs is None or bufs[0].numel() < nbytes:
+            cap = max(nbytes, 1 << 20)
+            bufs = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=dev))
+            _WGQ["bufs"][key] = bufs
+        if capturing:
+            # a captured graph replays the host-to-device copy from THIS pinned block on every replay: dedicate the
+            # staging pair (allocated by the eager warm-up steps, no allocation while capturing) to the graph
+            _WGQ["captured"].append(bufs)
+            del _WGQ["bufs"][key]
+        host, devb = bufs
+        host[:blob.size].copy_(torch.from_numpy(blob))
+        devb[:nbytes].copy_(host[:nbytes], non_blocking=True)
+        o1 = probs.nbytes
+        o2 = o1 + items.nbytes
+        ws = K._scratch("wgrad_grouped", ws_floats, dev)
+        K.wgrad_grouped(devb, len(q), devb[o1:], items.shape[0], devb[o2:], tiles.shape[0], ws, k_tail)
+    cb = _HOOKS["grad_ready"]
+    if cb is not None:
+        for p in ready:
+            cb(p)
+
+
 def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
     """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M, two-phase workspace reduction);
-    db[Nout] += alpha * column sums of dY when given (taken from the staged dY tiles inside the same kernel)."""
+    db[Nout] += alpha * column sums of dY when given (taken from the staged dY tiles inside the same kernel).
+    bf16 problems inside a backward pass are queued for the grouped launch (flush_wgrads)."""
+    if _WGQ["enabled"] and dY.dtype == torch.bfloat16 and dY.is_cuda:
+        if not _WGQ["armed"]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+                _WGQ["armed"] = True
+            except RuntimeError:  # not inside a backward pass
+                pass
+        if _WGQ["armed"]:
+            _WGQ["probs"].append((dY, X, dW, Nout, Kin, M, ldy, ldx, float(alpha), db))
+            return
     tiles = ((Nout + 127) // 128) * ((Kin + 127) // 128)
     bke = 64 if dY.dtype == torch.bfloat16 else 32
     ktiles = (M + bke - 1) // bke

@@ -322,3 +322,8 @@ def specaugment(x, n_frames, masks, n_freq, n_time, value, value_is_mean):
     assert x.dtype == torch.float32 and x.is_contiguous() and masks.dtype == torch.int32 and value.dtype == torch.float32
     _call("s2t_specaugment", x.data_ptr(), n_frames.data_ptr(), T * Cf, B, T, Cf, masks.data_ptr(), n_freq, n_time,
           value.data_ptr(), int(value_is_mean))
+
+
+def wgrad_grouped(problems, n_problems, items, n_items, tiles, n_tiles, ws, any_k_tail):
+    _call("s2t_wgrad_grouped", problems.data_ptr(), n_problems, items.data_ptr(), n_items, tiles.data_ptr(), n_tiles,
+          ws.data_ptr(), int(any_k_tail))

@@ -183,3 +183,34 @@ def test_splitk_workspace_matches_atomics_and_reference(dtype):
     refp = torch.stack([A.double()[h, :, :P].t() @ Q.double()[:, h * dk:(h + 1) * dk] for h in range(H)], 1).reshape(P, H * dk)
     refp = refp.view(P, H, dk).reshape(P, H * dk)
     np.testing.assert_allclose(dp.cpu().double().numpy(), refp.numpy(), rtol=1e-3, atol=1e-3 * refp.abs().max().item())
+
+
+def test_grouped_wgrad_matches_reference():
+    """csrc/gemm_grouped.hip through functional.flush_wgrads: several weight gradients of different shapes (ragged tiles,
+    K tails, bias gradients, alpha, accumulation into non-zero dW) in one launch vs float64."""
+    from s2t_amd import functional as Fn
+    g = torch.Generator().manual_seed(9)
+    dev = "cuda"
+    specs = [(300, 200, 2100, 1.0, True), (128, 128, 64, 0.5, False), (40, 520, 4000, 1.0, True), (256, 256, 6464, 2.0, True)]
+    probs, refs = [], []
+    for Nout, Kin, M, alpha, bias in specs:
+        ldy, ldx = (Nout + 7) // 8 * 8, (Kin + 7) // 8 * 8
+        dY = torch.zeros(M, ldy, dtype=torch.bfloat16); dY[:, :Nout] = _mk((M, Nout), torch.bfloat16, g)
+        X = torch.zeros(M, ldx, dtype=torch.bfloat16); X[:, :Kin] = _mk((M, Kin), torch.bfloat16, g)
+        dW = torch.full((Nout, Kin), 0.25, dtype=torch.float32, device=dev)
+        db = torch.full((Nout,), -1.0, dtype=torch.float32, device=dev) if bias else None
+        probs.append((dY.to(dev), X.to(dev), dW, Nout, Kin, M, ldy, ldx, alpha, db))
+        refs.append((0.25 + alpha * dY[:, :Nout].double().t() @ X[:, :Kin].double(),
+                     -1.0 + alpha * dY[:, :Nout].double().sum(0) if bias else None))
+    # + a second problem accumulating into the first one's dW (tied weights): chained, one writer per element
+    dY2 = _mk((1000, 304), torch.bfloat16, g); X2 = _mk((1000, 200), torch.bfloat16, g)
+    dY2[:, 300:] = 0
+    tied = (dY2.to(dev), X2.to(dev), probs[0][2], 300, 200, 1000, 304, 200, 3.0, None)
+    refs[0] = (refs[0][0] + 3.0 * dY2[:, :300].double().t() @ X2.double(), refs[0][1])
+    Fn._WGQ["probs"] = list(probs) + [tied]
+    Fn.flush_wgrads()
+    torch.cuda.synchronize()
+    for (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db), (rw, rb) in zip(probs, refs):
+        np.testing.assert_allclose(dW.cpu().double().numpy(), rw.numpy(), rtol=1e-3, atol=1e-3 * rw.abs().max().item())
+        if db is not None:
+            np.testing.assert_allclose(db.cpu().double().numpy(), rb.numpy(), rtol=1e-3, atol=1e-3 * rb.abs().max().item())
