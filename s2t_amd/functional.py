@@ -175,7 +175,7 @@ class _on_wgrad_stream:
 # grad-ready notifications (DDP bucket hooks) are deferred with them.  S2T_WGRAD_GROUPED=0 restores one GEMM per weight.
 _WGQ = {"probs": [], "ready": [], "armed": False, "enabled": os.environ.get("S2T_WGRAD_GROUPED", "1") == "1",
         "bufs": {}, "captured": []}
-_WG_KSTEPS = 32  # K-steps (of 64 rows) per work item
+_WG_KSTEPS = int(os.environ.get("S2T_WG_KSTEPS", "64"))  # K-steps (of 64 rows) per work item
 _WG_DTYPE = None
 
 
