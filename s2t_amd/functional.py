@@ -216,11 +216,13 @@ def flush_wgrads():
                 assert probs[prev]["M"] == Nout and probs[prev]["N"] == Kin
                 probs[prev]["next"] = i
             ws_floats += tm_n * tn_n * nsplit * 16384
-            t = np.empty((tm_n, nsplit, tn_n, 4), dtype=np.int32)  # order: tile row, K split, tile column (A slab reuse)
+            # order: K split, tile row, tile column — the ~64 items an XCD works on at a time then read the SAME K-range
+            # of both operands (its 4 MiB L2 serves the re-reads; measured 15 GB -> fabric traffic per launch before)
+            t = np.empty((nsplit, tm_n, tn_n, 4), dtype=np.int32)
             t[..., 0] = i
-            t[..., 1] = np.arange(tm_n, dtype=np.int32)[:, None, None]
+            t[..., 1] = np.arange(tm_n, dtype=np.int32)[None, :, None]
             t[..., 2] = np.arange(tn_n, dtype=np.int32)[None, None, :]
-            t[..., 3] = np.arange(nsplit, dtype=np.int32)[None, :, None]
+            t[..., 3] = np.arange(nsplit, dtype=np.int32)[:, None, None]
             items.append(t.reshape(-1, 4))
             if prev is not None:
                 continue  # its tiles are reduced by the head of the chain
