@@ -235,18 +235,40 @@ def flush_wgrads():
         tiles = np.concatenate(tiles)
         blob = np.concatenate([probs.view(np.uint8), items.view(np.uint8).reshape(-1), tiles.view(np.uint8).reshape(-1)])
         nbytes = (blob.size + 15) // 16 * 16
+        # Staging: the tables are written into pinned memory by the CPU and copied to the device by the stream.  The CPU
+        # runs ahead of the GPU, so a staging block may only be rewritten once the copy AND the kernels that read the
+        # device copy have executed: a ring of blocks, each guarded by an event (host-side wait only on wrap-around).
         capturing = torch.cuda.is_current_stream_capturing()
         key = str(dev)
-        bufs = _WGQ["bufs"].get(key)
-        if bufs is None or bufs[0].numel() < nbytes:
-            cap = max(nbytes, 1 << 20)
-            bufs = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=dev))
-            _WGQ["bufs"][key] = bufs
+        ring = _WGQ["bufs"].setdefault(key, {"slots": [], "i": 0})
+        cap = max(nbytes, 1 << 20)
         if capturing:
-            # a captured graph replays the host-to-device copy from THIS pinned block on every replay: dedicate the
-            # staging pair (allocated by the eager warm-up steps, no allocation while capturing) to the graph
-            _WGQ["captured"].append(bufs)
-            del _WGQ["bufs"][key]
+            # a captured graph replays the host-to-device copy from ITS pinned block on every replay: take a block the
+            # eager warm-up steps allocated (no allocation while capturing) and dedicate it to the graph
+            big = [sl for sl in ring["slots"] if sl[0].numel() >= nbytes]
+            if big:
+                slot = big[0]
+                ring["slots"].remove(slot)  # its last eager use has completed: capture() synchronises before capturing
+            else:
+                slot = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=dev), None]
+            _WGQ["captured"].append(slot)
+            bufs = (slot[0], slot[1])
+            slot_ev = None
+        else:
+            if len(ring["slots"]) < 4:
+                ring["slots"].append([torch.empty(cap, dtype=torch.uint8).pin_memory(),
+                                      torch.empty(cap, dtype=torch.uint8, device=dev), None])
+                slot = ring["slots"][-1]
+            else:
+                ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+                slot = ring["slots"][ring["i"]]
+                if slot[2] is not None:
+                    slot[2].synchronize()
+                if slot[0].numel() < nbytes:
+                    slot[0] = torch.empty(cap, dtype=torch.uint8).pin_memory()
+                    slot[1] = torch.empty(cap, dtype=torch.uint8, device=dev)
+            bufs = (slot[0], slot[1])
+            slot_ev = slot
         host, devb = bufs
         host[:blob.size].copy_(torch.from_numpy(blob))
         devb[:nbytes].copy_(host[:nbytes], non_blocking=True)
@@ -254,6 +276,10 @@ def flush_wgrads():
         o2 = o1 + items.nbytes
         ws = K._scratch("wgrad_grouped", ws_floats, dev)
         K.wgrad_grouped(devb, len(q), devb[o1:], items.shape[0], devb[o2:], tiles.shape[0], ws, k_tail)
+        if slot_ev is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            slot_ev[2] = ev
     cb = _HOOKS["grad_ready"]
     if cb is not None:
         for p in ready:

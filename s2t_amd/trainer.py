@@ -28,7 +28,9 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.flat.master)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)  # lr, step_size, grad_scale, grad_norm
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(2)
+        # pinned staging rows for (lr, step_size): the CPU runs ahead of the stream, so a row is only rewritten 16 updates
+        # later (a launch queue never holds that many steps)
+        self._hyper_host = torch.zeros(16, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(16, 2)
         self.num_updates = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self._graph = None
@@ -45,9 +47,10 @@ class Trainer:
         t = self.num_updates + 1
         lr = self.lr_at(t)
         b1, b2 = self.betas
-        self._hyper_host[0] = lr
-        self._hyper_host[1] = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-        self.hyper[:2].copy_(self._hyper_host, non_blocking=True)
+        row = self._hyper_host[t % 16]
+        row[0] = lr
+        row[1] = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        self.hyper[:2].copy_(row, non_blocking=True)
 
     # ---- one update ----------------------------------------------------------------------------------
     def _fwd_bwd(self, sample, overlap=True):
