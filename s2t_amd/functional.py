@@ -173,8 +173,21 @@ class _on_wgrad_stream:
 # so the bf16 (dY, X, dW) triples of a backward pass are queued and executed by ONE persistent launch (+ one reduction)
 # from an autograd engine callback at the end of backward.  Operands stay referenced until then.  The parameters'
 # grad-ready notifications (DDP bucket hooks) are deferred with them.  S2T_WGRAD_GROUPED=0 restores one GEMM per weight.
-_WGQ = {"probs": [], "ready": [], "armed": False, "enabled": os.environ.get("S2T_WGRAD_GROUPED", "1") == "1",
+# Policy (S2T_WGRAD_GROUPED): "graph" (default) = only while a hipGraph is being captured — in eager mode the host
+# cannot enqueue the (now much shorter) backward kernels fast enough once the weight-gradient launches are gone, the
+# GPU starves and a step takes 34-48 ms instead of 23; "1" = always, "0" = never.
+_WGQ = {"probs": [], "ready": [], "armed": False, "mode": os.environ.get("S2T_WGRAD_GROUPED", "graph"),
         "bufs": {}, "captured": []}
+
+
+def reserve_wgrad_staging(device, nbytes=8 << 20):
+    """Allocate a pinned/device staging pair ahead of a graph capture (nothing may be allocated from the host
+    allocator while a stream is capturing)."""
+    key = str(torch.device(device) if not isinstance(device, torch.device) else device)
+    ring = _WGQ["bufs"].setdefault(key, {"slots": [], "i": 0})
+    if not any(sl[0].numel() >= nbytes for sl in ring["slots"]):
+        ring["slots"].append([torch.empty(nbytes, dtype=torch.uint8).pin_memory(),
+                              torch.empty(nbytes, dtype=torch.uint8, device=device), None])
 _WG_KSTEPS = int(os.environ.get("S2T_WG_KSTEPS", "64"))  # K-steps (of 64 rows) per work item
 _WG_DTYPE = None
 
@@ -290,7 +303,8 @@ def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
     """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M, two-phase workspace reduction);
     db[Nout] += alpha * column sums of dY when given (taken from the staged dY tiles inside the same kernel).
     bf16 problems inside a backward pass are queued for the grouped launch (flush_wgrads)."""
-    if _WGQ["enabled"] and dY.dtype == torch.bfloat16 and dY.is_cuda:
+    mode = _WGQ["mode"]
+    if dY.dtype == torch.bfloat16 and dY.is_cuda and (mode == "1" or (mode == "graph" and torch.cuda.is_current_stream_capturing())):
         if not _WGQ["armed"]:
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)

@@ -108,6 +108,7 @@ class Trainer:
                 self.num_updates += 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        Fn.reserve_wgrad_staging(self.flat.master.device)  # the grouped weight-gradient tables of the captured step
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         self._push_hyper()
