@@ -291,8 +291,9 @@ int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B, int T, in
                      void* stream);
 int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                      const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens, int blank,
-                     const float* alpha, const float* beta, int Lmax, const float* nll, float gscale, void* grad,
-                     int64_t ldg, int wrt_logprobs, void* stream);
+                     const float* alpha, const float* beta, int Lmax, const float* nll, float gscale,
+                     const float* gscale_dev /* optional device scalar multiplied into gscale (upstream gradient) */,
+                     void* grad, int64_t ldg, int wrt_logprobs, void* stream);
 /* best-alignment backtrace (torch_imputer/imputer.py:245-259,311-323) on the device: states[b][t], -1 beyond the length */
 int s2t_ctc_backtrace(const float* alpha, const int32_t* paths, const int32_t* tgt_lens, const int32_t* in_lens, int B,
                       int T, int Lmax, int32_t* states, void* stream);

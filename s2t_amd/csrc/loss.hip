@@ -249,6 +249,7 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
   // state gets -inf.  paths != NULL (best alignment, torch_imputer/best_alignment.cu:57-201): max-product recursion
   // with back-pointers instead of log-sum-exp; beta is not computed.
   extern __shared__ float sh[];  // [2][Lmax+2] ping-pong
+  constexpr int CH = 16;
   const int b = blockIdx.x;
   const int S = tgt_lens[b];
   const int L = 2 * S + 1;
@@ -272,8 +273,10 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
     if (s == 0) nll_out[b] = 0.f;
     return;
   }
+  // alpha and beta are independent recursions: blockIdx.y = 0 runs alpha (+ nll), 1 runs beta
+  const bool do_alpha = blockIdx.y == 0, do_beta = (gridDim.y == 1 || blockIdx.y == 1) && beta != nullptr;
   // ---- alpha
-  {
+  if (do_alpha) {
     float a = -INFINITY;
     if (act && s < 2) a = ld_as_f32<T>(logits + row0 * ld + lab) - lse[row0];
     if (force_emits) {
@@ -288,36 +291,48 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
     __syncthreads();
     float* cur = bufA;
     float* nxt = bufB;
-    for (int t = 1; t < Tb; ++t) {
-      float v = -INFINITY;
-      if (act) {
-        const float a0 = cur[s];
-        const float a1 = s >= 1 ? cur[s - 1] : -INFINITY;
-        const float a2 = (s >= 2 && skip) ? cur[s - 2] : -INFINITY;
-        const float lp = ld_as_f32<T>(logits + (row0 + t) * ld + lab) - lse[row0 + t];
-        if (paths) {
-          // Viterbi: first maximum in the order s, s-1, s-2 (strict > to move on), best_alignment.cu:141-160
-          float m = a0;
-          int arg = s;
-          if (a1 > m) { m = a1; arg = s - 1; }
-          if (a2 > m) { m = a2; arg = s - 2; }
-          v = m + lp;
-          paths[((int64_t)b * T_ + t) * Lmax + s] = arg;
-        } else {
-          const float m = lse3(a0, a1, a2);
-          v = m == -INFINITY ? -INFINITY : m + lp;
-        }
-        if (force_emits) {
-          const int64_t fe = force_emits[(int64_t)b * T_ + t];
-          if (fe > -1 && fe != s) v = -INFINITY;
-        }
-        nxt[s] = v;
-        al[(int64_t)t * Lmax + s] = v;
+    // the emission log-probabilities do not depend on the recursion: fetch CH frames at a time (CH independent loads
+    // in flight) so that one memory round trip is paid per chunk instead of per frame
+    for (int t0 = 1; t0 < Tb; t0 += CH) {
+      float lpq[CH];
+      int64_t feq[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int t = min(t0 + i, Tb - 1);
+        lpq[i] = act ? ld_as_f32<T>(logits + (row0 + t) * ld + lab) - lse[row0 + t] : 0.f;
+        feq[i] = force_emits ? force_emits[(int64_t)b * T_ + t] : -1;
       }
-      __syncthreads();
-      float* tmp = cur;
-      cur = nxt;
-      nxt = tmp;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int t = t0 + i;
+        if (t >= Tb) break;  // workgroup-uniform
+        float v = -INFINITY;
+        if (act) {
+          const float a0 = cur[s];
+          const float a1 = s >= 1 ? cur[s - 1] : -INFINITY;
+          const float a2 = (s >= 2 && skip) ? cur[s - 2] : -INFINITY;
+          const float lp = lpq[i];
+          if (paths) {
+            // Viterbi: first maximum in the order s, s-1, s-2 (strict > to move on), best_alignment.cu:141-160
+            float m = a0;
+            int arg = s;
+            if (a1 > m) { m = a1; arg = s - 1; }
+            if (a2 > m) { m = a2; arg = s - 2; }
+            v = m + lp;
+            paths[((int64_t)b * T_ + t) * Lmax + s] = arg;
+          } else {
+            const float m = lse3(a0, a1, a2);
+            v = m == -INFINITY ? -INFINITY : m + lp;
+          }
+          if (feq[i] > -1 && feq[i] != s) v = -INFINITY;
+          nxt[s] = v;
+          al[(int64_t)t * Lmax + s] = v;
+        }
+        __syncthreads();
+        float* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+      }
     }
     if (s == 0) {
       const float l1 = cur[L - 1];
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
     __syncthreads();
   }
   // ---- beta
-  if (beta) {
+  if (do_beta) {
     float v = -INFINITY;
     if (act && s >= L - 2) v = ld_as_f32<T>(logits + (row0 + Tb - 1) * ld + lab) - lse[row0 + Tb - 1];
     if (force_emits) {
@@ -342,25 +357,34 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
     __syncthreads();
     float* cur = bufA;
     float* nxt = bufB;
-    for (int t = Tb - 2; t >= 0; --t) {
-      if (act) {
-        const float b0 = cur[s];
-        const float b1 = s + 1 < L ? cur[s + 1] : -INFINITY;
-        const float b2 = (s + 2 < L && skipn) ? cur[s + 2] : -INFINITY;
-        const float lp = ld_as_f32<T>(logits + (row0 + t) * ld + lab) - lse[row0 + t];
-        const float m = lse3(b0, b1, b2);
-        float r = m == -INFINITY ? -INFINITY : m + lp;
-        if (force_emits) {
-          const int64_t fe = force_emits[(int64_t)b * T_ + t];
-          if (fe > -1 && fe != s) r = -INFINITY;
-        }
-        nxt[s] = r;
-        be[(int64_t)t * Lmax + s] = r;
+    for (int t0 = Tb - 2; t0 >= 0; t0 -= CH) {
+      float lpq[CH];
+      int64_t feq[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int t = max(t0 - i, 0);
+        lpq[i] = act ? ld_as_f32<T>(logits + (row0 + t) * ld + lab) - lse[row0 + t] : 0.f;
+        feq[i] = force_emits ? force_emits[(int64_t)b * T_ + t] : -1;
       }
-      __syncthreads();
-      float* tmp = cur;
-      cur = nxt;
-      nxt = tmp;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int t = t0 - i;
+        if (t < 0) break;  // workgroup-uniform
+        if (act) {
+          const float b0 = cur[s];
+          const float b1 = s + 1 < L ? cur[s + 1] : -INFINITY;
+          const float b2 = (s + 2 < L && skipn) ? cur[s + 2] : -INFINITY;
+          const float m = lse3(b0, b1, b2);
+          float r = m == -INFINITY ? -INFINITY : m + lpq[i];
+          if (feq[i] > -1 && feq[i] != s) r = -INFINITY;
+          nxt[s] = r;
+          be[(int64_t)t * Lmax + s] = r;
+        }
+        __syncthreads();
+        float* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+      }
     }
   }
 }
@@ -374,8 +398,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                                                        const int32_t* __restrict__ tgt_lens,
                                                        const int32_t* __restrict__ in_lens, int blank,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                       int Lmax, const float* __restrict__ nll, float gscale,
-                                                       T* __restrict__ grad, int64_t ldg, int wrt_logprobs) {
+                                                       int Lmax, const float* __restrict__ nll, float gscale_host,
+                                                       const float* __restrict__ gscale_dev, T* __restrict__ grad,
+                                                       int64_t ldg, int wrt_logprobs) {
+  // the upstream gradient of the summed loss usually lives on the device (a 0-dim autograd tensor): multiply here
+  // instead of in a separate pass over the [B*T, V] gradient
+  const float gscale = gscale_dev ? gscale_host * gscale_dev[0] : gscale_host;
   // wrt_logprobs = 0: gradient w.r.t. the LOGITS (softmax - occupancy); 1: w.r.t. log-probabilities (- occupancy),
   // the quantity torch_imputer returns (imputer.cu:561-638)
   extern __shared__ float occ[];  // [Lmax] exp(alpha+beta+nll) per state, then merged per label
@@ -545,9 +573,9 @@ extern "C" int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B
   const size_t shm = 2 * (size_t)(Lmax + 2) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B), dim3(threads), shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B, (beta && !paths) ? 2 : 1), dim3(threads), shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B), dim3(threads), shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B, (beta && !paths) ? 2 : 1), dim3(threads), shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
@@ -555,16 +583,17 @@ extern "C" int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B
 extern "C" int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                                 const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens,
                                 int blank, const float* alpha, const float* beta, int Lmax, const float* nll,
-                                float gscale, void* grad, int64_t ldg, int wrt_logprobs, void* stream) {
+                                float gscale, const float* gscale_dev, void* grad, int64_t ldg, int wrt_logprobs,
+                                void* stream) {
   if (!logits || !lse || !targets || !tgt_lens || !in_lens || !alpha || !beta || !nll || !grad) return S2T_ERR_ARG;
   if (B <= 0 || T <= 0 || V <= 0 || Lmax <= 0) return S2T_ERR_ARG;
   const size_t shm = (size_t)Lmax * sizeof(float);
   dim3 grid((unsigned)((int64_t)B * T)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ctc_grad_kernel<float>, grid, block, shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (float*)grad, ldg, wrt_logprobs);
+    hipLaunchKernelGGL(ctc_grad_kernel<float>, grid, block, shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, gscale_dev, (float*)grad, ldg, wrt_logprobs);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, (bf16_t*)grad, ldg, wrt_logprobs);
+    hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, gscale_dev, (bf16_t*)grad, ldg, wrt_logprobs);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

@@ -1047,9 +1047,10 @@ class CTCLossFn(torch.autograd.Function):
         logits, lse, alpha, beta, nll, targets, tgt_lens, in_lens = ctx.saved_tensors
         B, T, V, S, Lmax, blank = ctx.dims
         grad = torch.empty(B * T, _pad8(V), dtype=logits.dtype, device=logits.device)[:, :V]
+        gs = g.detach().reshape(1).float().contiguous()  # upstream gradient of the summed loss, stays on the device
         K.ctc_loss_bwd(logits, logits.stride(0), B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll,
-                       1.0, grad, grad.stride(0))
-        return grad * g.to(grad.dtype), None, None, None, None, None, None
+                       1.0, grad, grad.stride(0), gscale_dev=gs)
+        return grad, None, None, None, None, None, None
 
 
 def ctc_loss(logits, B, T, targets, tgt_lens, in_lens, blank=0):

@@ -264,10 +264,10 @@ def ctc_loss_fwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blan
 
 
 def ctc_loss_bwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale,
-                 grad, ldg, wrt_logprobs=False):
+                 grad, ldg, wrt_logprobs=False, gscale_dev=None):
     _call("s2t_ctc_loss_bwd", L.dtype_id(logits.dtype), logits.data_ptr(), ld, B, T, V, lse.data_ptr(),
           targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), beta.data_ptr(),
-          Lmax, nll.data_ptr(), gscale, grad.data_ptr(), ldg, int(wrt_logprobs))
+          Lmax, nll.data_ptr(), gscale, _ptr(gscale_dev), grad.data_ptr(), ldg, int(wrt_logprobs))
 
 
 def ctc_backtrace(alpha, paths, tgt_lens, in_lens, B, T, Lmax, states):
