@@ -107,6 +107,17 @@ int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* 
                       int cols, const int32_t* row_lens, int row_T,
                       const void* dres /* optional [rows][cols]: dx += dres (gradient of the residual branch of a pre-LN block) */,
                       void* stream);
+/* dgamma == dbeta == NULL in s2t_layernorm_bwd leaves the per-replica partial sums in ws ([replicas][2][cols], zeroed
+ * before); s2t_layernorm_fold then adds them into the parameter gradients of MANY LayerNorms in one launch and zeroes
+ * the workspaces again.  `entries` is a host array (passed to the kernel by value). */
+typedef struct s2t_ln_fold_entry {
+  float* ws;
+  float* dgamma;
+  float* dbeta;
+  int32_t cols;
+  int32_t reserved;
+} s2t_ln_fold_entry;
+int s2t_layernorm_fold(const s2t_ln_fold_entry* entries, int n, int replicas, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention probabilities from raw scores (fp32 in, `p_dtype` out), one row per (z, query):

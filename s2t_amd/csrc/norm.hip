@@ -350,7 +350,7 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, c
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int replicas,
                                  int64_t rows, int cols, const int32_t* row_lens, int row_T, const void* dres,
                                  void* stream) {
-  if (!x || !gamma || !dy || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || replicas <= 0 || rows < 0 || cols <= 0)
+  if (!x || !gamma || !dy || !mean || !rstd || !dx || (!dgamma != !dbeta) || !ws || replicas <= 0 || rows < 0 || cols <= 0)
     return S2T_ERR_ARG;
   if (cols % 4 || cols > LN_MAX_VEC * 256) return S2T_ERR_UNSUPPORTED;
   if (rows == 0) return S2T_OK;
@@ -369,6 +369,48 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, c
   } else if (dtype == S2T_BF16)
     LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean, rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, cols, row_lens, row_T);
   else return S2T_ERR_DTYPE;
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, ws, replicas, cols, dgamma, dbeta);
+  if (dgamma)  // NULL: the partial sums stay in ws, the caller folds many LayerNorms at once (s2t_layernorm_fold)
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, ws, replicas, cols, dgamma, dbeta);
+  return S2T_LAUNCH_CHECK();
+}
+
+namespace {
+constexpr int FOLD_MAX = 96;  // entries per launch (passed by value: 3 KiB of kernel arguments)
+struct FoldBatch {
+  s2t_ln_fold_entry e[FOLD_MAX];
+};
+__global__ void ln_fold_kernel(const FoldBatch batch, int replicas) {
+  const s2t_ln_fold_entry en = batch.e[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= en.cols) return;
+  float g = 0.f, b = 0.f;
+#pragma unroll 8
+  for (int r = 0; r < replicas; ++r) {
+    g += en.ws[(int64_t)r * 2 * en.cols + c];
+    b += en.ws[(int64_t)r * 2 * en.cols + en.cols + c];
+  }
+  for (int r = 0; r < replicas; ++r) {  // leave the workspace zeroed for its next use
+    en.ws[(int64_t)r * 2 * en.cols + c] = 0.f;
+    en.ws[(int64_t)r * 2 * en.cols + en.cols + c] = 0.f;
+  }
+  en.dgamma[c] += g;
+  en.dbeta[c] += b;
+}
+}  // namespace
+
+extern "C" int s2t_layernorm_fold(const s2t_ln_fold_entry* entries, int n, int replicas, void* stream) {
+  if (!entries || n < 0 || replicas <= 0) return S2T_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += FOLD_MAX) {
+    FoldBatch batch;
+    const int m = n - i0 < FOLD_MAX ? n - i0 : FOLD_MAX;
+    int maxc = 0;
+    for (int i = 0; i < m; ++i) {
+      batch.e[i] = entries[i0 + i];
+      if (!batch.e[i].ws || !batch.e[i].dgamma || !batch.e[i].dbeta || batch.e[i].cols <= 0) return S2T_ERR_ARG;
+      if (batch.e[i].cols > maxc) maxc = batch.e[i].cols;
+    }
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((maxc + 63) / 64, m), dim3(64), 0, s, batch, replicas);
+  }
   return S2T_LAUNCH_CHECK();
 }

@@ -21,8 +21,8 @@ _HOOKS = {"grad_ready": None}  # set by the DDP wrapper: called with a parameter
 
 def _ready(*params):
     cb = _HOOKS["grad_ready"]
-    if cb is not None and _WGQ["armed"]:  # weight gradients are still queued: notify after the grouped launch
-        _WGQ["ready"].extend(p for p in params if p is not None)
+    if cb is not None and _BE["armed"]:  # gradient work is still queued for the end of backward: notify after it ran
+        _BE["ready"].extend(p for p in params if p is not None)
         return
     if cb is not None:
         for p in params:
@@ -169,6 +169,52 @@ class _on_wgrad_stream:
         return False
 
 
+# Work deferred to the end of the backward pass (an autograd engine callback): the fold of every LayerNorm's
+# per-replica dgamma/dbeta partial sums (one launch instead of one per LayerNorm) and the grouped weight gradients.
+_BE = {"armed": False, "ready": []}
+_LNQ = {"entries": [], "pools": {}, "off": {}}
+
+
+def _arm_backward_end():
+    """True when running inside a backward pass with the end-of-backward callback installed."""
+    if not _BE["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_on_backward_end)
+            _BE["armed"] = True
+        except RuntimeError:  # not inside a backward pass
+            return False
+    return True
+
+
+def _ln_workspace(cols, device):
+    """A zeroed [replicas][2][cols] slice of the per-device pool (the fold kernel leaves it zeroed again)."""
+    key = str(device)
+    n = K.LN_REPLICAS * 2 * cols
+    pool = _LNQ["pools"].get(key)
+    off = _LNQ["off"].get(key, 0)
+    if pool is None or off + n > pool.numel():
+        pool = torch.zeros(max(1 << 22, 2 * (off + n)), dtype=torch.float32, device=device)
+        _LNQ["pools"][key] = pool  # slices of the previous pool stay alive through the queued entries
+        off = 0
+    _LNQ["off"][key] = off + n
+    return pool[off:off + n]
+
+
+def _on_backward_end():
+    entries, _LNQ["entries"] = _LNQ["entries"], []
+    for k in _LNQ["off"]:
+        _LNQ["off"][k] = 0
+    if entries:
+        K.layernorm_fold(entries)
+    flush_wgrads()
+    ready, _BE["ready"] = _BE["ready"], []
+    _BE["armed"] = False
+    cb = _HOOKS["grad_ready"]
+    if cb is not None:
+        for p in ready:
+            cb(p)
+
+
 # Deferred, grouped weight gradients (csrc/gemm_grouped.hip): nothing consumes a weight gradient before the optimizer,
 # so the bf16 (dY, X, dW) triples of a backward pass are queued and executed by ONE persistent launch (+ one reduction)
 # from an autograd engine callback at the end of backward.  Operands stay referenced until then.  The parameters'
@@ -176,7 +222,7 @@ class _on_wgrad_stream:
 # Policy (S2T_WGRAD_GROUPED): "graph" (default) = only while a hipGraph is being captured — in eager mode the host
 # cannot enqueue the (now much shorter) backward kernels fast enough once the weight-gradient launches are gone, the
 # GPU starves and a step takes 34-48 ms instead of 23; "1" = always, "0" = never.
-_WGQ = {"probs": [], "ready": [], "armed": False, "mode": os.environ.get("S2T_WGRAD_GROUPED", "graph"),
+_WGQ = {"probs": [], "mode": os.environ.get("S2T_WGRAD_GROUPED", "graph"),
         "bufs": {}, "captured": []}
 
 
@@ -207,8 +253,6 @@ def flush_wgrads():
     """Run every queued weight gradient (called by the end-of-backward callback; safe to call with an empty queue)."""
     import numpy as np
     q, _WGQ["probs"] = _WGQ["probs"], []
-    ready, _WGQ["ready"] = _WGQ["ready"], []
-    _WGQ["armed"] = False
     if q:
         dev = q[0][0].device
         probs = np.zeros(len(q), dtype=_wg_dtype())
@@ -293,10 +337,6 @@ def flush_wgrads():
             ev = torch.cuda.Event()
             ev.record()
             slot_ev[2] = ev
-    cb = _HOOKS["grad_ready"]
-    if cb is not None:
-        for p in ready:
-            cb(p)
 
 
 def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
@@ -305,13 +345,7 @@ def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
     bf16 problems inside a backward pass are queued for the grouped launch (flush_wgrads)."""
     mode = _WGQ["mode"]
     if dY.dtype == torch.bfloat16 and dY.is_cuda and (mode == "1" or (mode == "graph" and torch.cuda.is_current_stream_capturing())):
-        if not _WGQ["armed"]:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
-                _WGQ["armed"] = True
-            except RuntimeError:  # not inside a backward pass
-                pass
-        if _WGQ["armed"]:
+        if _arm_backward_end():
             _WGQ["probs"].append((dY, X, dW, Nout, Kin, M, ldy, ldx, float(alpha), db))
             return
     tiles = ((Nout + 127) // 128) * ((Kin + 127) // 128)
@@ -353,8 +387,15 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         if dres is not None:
             dres = dres.contiguous()
-        K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, ctx.gamma.grad, ctx.beta.grad, rows, cols,
-                        ctx.lens, ctx.T, dres)
+        if x.is_cuda and _arm_backward_end():
+            # partial sums into a private workspace slice; ONE fold launch for all LayerNorms at the end of backward
+            ws = _ln_workspace(cols, x.device)
+            K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, None, None, rows, cols, ctx.lens, ctx.T,
+                            dres, ws=ws)
+            _LNQ["entries"].append((ws, ctx.gamma.grad, ctx.beta.grad, cols))
+        else:
+            K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, ctx.gamma.grad, ctx.beta.grad, rows, cols,
+                            ctx.lens, ctx.T, dres)
         _ready(ctx.gamma, ctx.beta)
         return dx, None, None, None, None, None
 

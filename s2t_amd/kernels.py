@@ -128,11 +128,28 @@ def _workspace(tag, n, device):
     return t
 
 
-def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0, dres=None):
-    ws = _workspace("ln", LN_REPLICAS * 2 * cols, x.device)
+def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0, dres=None, ws=None):
+    """``ws`` given and ``dgamma is None``: leave the partial sums in ``ws`` for layernorm_fold."""
+    if ws is None:
+        ws = _workspace("ln", LN_REPLICAS * 2 * cols, x.device)
     _call("s2t_layernorm_bwd", L.dtype_id(x.dtype), x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), mean.data_ptr(),
-          rstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), LN_REPLICAS, rows, cols,
+          rstd.data_ptr(), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), LN_REPLICAS, rows, cols,
           _ptr(row_lens), row_T, _ptr(dres))
+
+
+class _LnFoldEntry(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("cols", C.c_int32), ("reserved", C.c_int32)]
+
+
+def layernorm_fold(entries):
+    """entries: list of (ws, dgamma, dbeta, cols) tensors/ints."""
+    n = len(entries)
+    if n == 0:
+        return
+    arr = (_LnFoldEntry * n)()
+    for i, (ws, dg, db, cols) in enumerate(entries):
+        arr[i].ws, arr[i].dgamma, arr[i].dbeta, arr[i].cols = ws.data_ptr(), dg.data_ptr(), db.data_ptr(), cols
+    _call("s2t_layernorm_fold", C.cast(arr, C.c_void_p), n, LN_REPLICAS)
 
 
 def _drop3(drop):
