@@ -235,6 +235,9 @@ __device__ __forceinline__ float lse2(float a, float b) {
 }
 __device__ __forceinline__ float lse3(float a, float b, float c) { return lse2(lse2(a, b), c); }
 
+// workgroup barrier that orders LDS traffic only (no s_waitcnt vmcnt: outstanding global stores / prefetches keep flying)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <typename T>
 __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restrict__ logits, int64_t ld, int V, int T_,
                                                               const float* __restrict__ lse,
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
           nxt[s] = v;
           al[(int64_t)t * Lmax + s] = v;
         }
-        __syncthreads();
+        lds_barrier();  // LDS hand-over only: the alpha/beta stores to HBM drain in the background
         float* tmp = cur;
         cur = nxt;
         nxt = tmp;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
           nxt[s] = r;
           be[(int64_t)t * Lmax + s] = r;
         }
-        __syncthreads();
+        lds_barrier();  // LDS hand-over only: the alpha/beta stores to HBM drain in the background
         float* tmp = cur;
         cur = nxt;
         nxt = tmp;
