@@ -1,0 +1,125 @@
+"""Size-independent properties at the BASELINE.json configuration-2' size (12-layer Conformer, 64 x 1000 x 80, bf16,
+V = 10 000), where the CPU oracle is too slow to serve as the checker:
+
+  * utterances are independent in eval mode: permuting the batch permutes the outputs BIT-EXACTLY (every GEMM row,
+    attention (utterance, head) and depthwise-conv column is computed by the same arithmetic wherever it sits);
+  * padding invariance: appending zero frames beyond every utterance's length changes no CTC-greedy token id;
+  * the summed loss is additive over utterances (eval-mode BatchNorm, dropout 0);
+  * the grouped weight-gradient launch, the per-weight split-K GEMMs and (through the trainer test) graph replay give
+    the same gradients.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bench  # noqa: E402
+from s2t_amd import criterions as C  # noqa: E402
+from s2t_amd import functional as Fn  # noqa: E402
+from s2t_amd import s2t_transformer as M  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+V = 10000
+B, T = 64, 1000
+
+
+@pytest.fixture(scope="module")
+def model():
+    torch.manual_seed(1)
+    m = M.S2TTransformerModel.build_model(M.recipe_args(conformer=True, vocab_size=V), M.FakeTask(V)).prepare(torch.bfloat16, DEV)
+    m.encoder.ctc_out_dtype = torch.float32
+    return m
+
+
+@pytest.fixture(scope="module")
+def sample():
+    return bench.synthetic_batch(B, T, V, 7, DEV)[0]
+
+
+class _EncOnly(torch.nn.Module):
+    def __init__(self, e):
+        super().__init__()
+        self.e = e
+
+    def forward(self, src_tokens, src_lengths):
+        return self.e(src_tokens, src_lengths)
+
+
+def _greedy(model, src, lens):
+    dec = M.CTCDecoder([model.encoder], None, None)
+    dec.model = _EncOnly(model.encoder)
+    with torch.no_grad():
+        hyps = dec.generate(None, {"net_input": {"src_tokens": src, "src_lengths": lens}})
+    return [h[0]["tokens"].tolist() for h in hyps]
+
+
+def test_batch_permutation_is_bit_exact(model, sample):
+    model.eval()
+    ni = sample["net_input"]
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        a = model.encoder(ni["src_tokens"], ni["src_lengths"])
+        b = model.encoder(ni["src_tokens"][perm].contiguous(), ni["src_lengths"][perm].contiguous())
+    assert torch.equal(a["encoder_out"][0][:, perm], b["encoder_out"][0])
+    assert torch.equal(a["ctc_logit"][0][:, perm], b["ctc_logit"][0])
+    ids = _greedy(model, ni["src_tokens"], ni["src_lengths"])
+    ids_p = _greedy(model, ni["src_tokens"][perm].contiguous(), ni["src_lengths"][perm].contiguous())
+    assert [ids[i] for i in perm.tolist()] == ids_p
+    assert sum(len(x) for x in ids) > 0
+
+
+def test_extra_padding_changes_no_token(model, sample):
+    """Holds for utterances that end at least a few frames before the batch's T: like the reference's Conv1dSubsampling
+    (no mask between its two convolutions, subsampling.py:145-159), the second convolution of a FULL-length utterance
+    sees the zero padding of the buffer edge where a longer buffer holds GLU(bias) of the padded frames."""
+    model.eval()
+    ni = sample["net_input"]
+    src = ni["src_tokens"].clone()
+    lens = ni["src_lengths"].clamp(max=T - 16)
+    for b in range(B):
+        src[b, int(lens[b]):] = 0
+    padded = torch.zeros(B, T + 40, 80, device=DEV)
+    padded[:, :T] = src
+    assert _greedy(model, src, lens) == _greedy(model, padded, lens)
+
+
+def test_loss_is_additive_over_utterances(model, sample):
+    model.eval()  # BatchNorm with running statistics: no coupling between utterances
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    ni = sample["net_input"]
+    with torch.no_grad():
+        full = float(crit(model, sample)[0])
+        parts = 0.0
+        for i in range(0, B, 16):
+            sub = {"net_input": {k: v[i:i + 16].contiguous() for k, v in ni.items()}, "target": sample["target"][i:i + 16].contiguous(),
+                   "ntokens": 1}
+            parts += float(crit(model, sub)[0])
+    assert abs(full - parts) <= 2e-3 * abs(full), (full, parts)
+
+
+def test_grouped_and_per_weight_gradients_agree(sample):
+    """On the 12-layer Transformer (config 2): its data path has no order-dependent reduction, so two identical passes
+    give identical activation gradients and the two weight-gradient paths differ only in their fp32 summation trees.
+    (The Conformer's training-mode BatchNorm statistics are accumulated with float atomics; in bf16 that last-bit noise
+    is amplified to percent-level run-to-run differences of the gradients, with either path.)"""
+    torch.manual_seed(2)
+    model = M.S2TTransformerModel.build_model(M.recipe_args(conformer=False, vocab_size=V), M.FakeTask(V)).prepare(torch.bfloat16, DEV)
+    model.train()
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    grads = {}
+    old = Fn._WGQ["mode"]
+    try:
+        for tag, mode in (("grouped", "1"), ("per_weight", "0"), ("per_weight_again", "0")):
+            Fn._WGQ["mode"] = mode
+            model.flat.zero_grad()
+            loss, _, _ = crit(model, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads[tag] = model.flat.grad.clone()
+    finally:
+        Fn._WGQ["mode"] = old
+    ref = grads["per_weight"]
+    assert torch.isfinite(ref).all() and torch.isfinite(grads["grouped"]).all()
+    noise = float((grads["per_weight_again"] - ref).norm() / ref.norm())  # LayerNorm / bias partial sums use atomics
+    assert noise < 1e-4, noise
+    assert float((grads["grouped"] - ref).norm() / ref.norm()) < 1e-3
