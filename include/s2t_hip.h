@@ -250,25 +250,29 @@ int s2t_sumsq_accum(const float* g, int64_t n, float* out, void* stream);
  * Conformer convolution module core (modules/convolution.py:94-104), channels-last (B,T,C):
  *   s2t_dwconv_fwd : y[b,t,c] = sum_k x[b,t+k-(K-1)/2,c] * w[c, flip ? K-1-k : k]   (zero outside [0,T)).
  *        scale/shift != NULL : y = act(y*scale[c] + shift[c]), frames t >= lens[b] -> 0   (eval: BN folded)
- *        stats != NULL       : stats[c] += sum y, stats[C+c] += sum y^2 over all (b,t)     (train: BN batch stats)
+ *        stats != NULL       : one row [2][C] of partial sums (sum y | sum y^2) per workgroup, s2t_dwconv_stat_partials(B,T)
+ *                              rows in all (train: BN batch stats; no atomics — s2t_bn_finalize adds the rows in a fixed order)
  *        flip = 1 gives the input gradient of the same convolution.
  *   s2t_dwconv_bwd_weight : dw[c,k] += sum_{b,t} dD[b,t,c] * G[b,t+k-(K-1)/2,c]
  *   s2t_bn_finalize : stats -> scale = gamma*rstd, shift = beta - mean*scale (+ running-stat update, momentum,
  *                     unbiased variance) ; training = 0 uses the running statistics.
  *   s2t_bn_act_fwd  : out = act(D*scale + shift), padded frames -> 0
- *   s2t_bn_act_bwd  : dD from dOut (two passes); sums[0:C] = sum du (= dbeta), sums[C:2C] = sum du*xhat (= dgamma)
+ *   s2t_bn_act_bwd  : dD from dOut (reduce, fixed-order fold, apply); sums[0:C] = sum du (= dbeta), sums[C:2C] = sum du*xhat
+ *                     (= dgamma); ws: s2t_bn_bwd_partials(rows) x 2C floats of scratch
  * ------------------------------------------------------------------------------------------------ */
 int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, int flip,
                    const float* scale, const float* shift, int act, const int32_t* lens, float* stats, void* stream);
 int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, float* ws /* [replicas][C][K]: zero in, zero out */,
                           int replicas, int B, int T, int C, int K, void* stream);
-int s2t_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
+int s2t_dwconv_stat_partials(int B, int T);
+int s2t_bn_bwd_partials(int64_t rows);
+int s2t_bn_finalize(const float* stats, int partials, float count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                     float* mean, float* rstd, int C, void* stream);
 int s2t_bn_act_fwd(int dtype, const void* D, void* out, const float* scale, const float* shift, int act, int64_t rows,
                    int C, const int32_t* lens, int T, void* stream);
 int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const float* scale, const float* shift,
-                   const float* mean, const float* rstd, float* sums, float count, int act, int64_t rows, int C,
+                   const float* mean, const float* rstd, float* sums, float* ws, float count, int act, int64_t rows, int C,
                    const int32_t* lens, int T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -118,8 +118,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
         a += lred[(0 * 4 + g) * CCH + cc];
         q += lred[(1 * 4 + g) * CCH + cc];
       }
-      atomicAdd(stats + c0 + cc, a);
-      atomicAdd(stats + C + c0 + cc, q);
+      // one row of partial sums per workgroup (no atomics: bn_finalize adds the rows in a fixed order, so the batch
+      // statistics — and with them the whole forward pass — are reproducible run to run)
+      float* row = stats + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+      row[c0 + cc] = a;
+      row[C + c0 + cc] = q;
     }
   }
 }
@@ -191,34 +194,69 @@ __global__ void fold_replicas_kernel(float* __restrict__ ws, int replicas, int64
   out[i] += s;
 }
 
-// per-channel BatchNorm bookkeeping (one workgroup): stats -> (scale, shift, mean, rstd) and running-stat update
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float momentum, float eps, int training,
-                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
-                                   float* __restrict__ rstd_o, int C) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float mean, var;
-    if (training) {
-      mean = stats[c] / count;
-      var = fmaxf(stats[C + c] / count - mean * mean, 0.f);
-      if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-      }
-    } else {
-      mean = running_mean[c];
-      var = running_var[c];
+// Fixed-order column sum of `rows` partial rows (row stride `ld` floats) for 16 adjacent columns per 1024-thread
+// workgroup.  Thread (g = tid / 16, cl = tid % 16) adds rows g, g + 64, ... in order (loads issued four at a time), the
+// four g of a wave are combined by two xor shuffles, the 16 waves through LDS in wave order: the summation tree depends on
+// `rows` only, never on scheduling.  Every thread returns the total for its column.
+__device__ __forceinline__ float fold_partial_rows(const float* __restrict__ col, int rows, int64_t ld, bool live,
+                                                   float (*red)[16]) {
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, wv = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (live) {
+    int r = g;
+    for (; r + 192 < rows; r += 256) {
+      const float v0 = col[(int64_t)r * ld], v1 = col[(int64_t)(r + 64) * ld], v2 = col[(int64_t)(r + 128) * ld],
+                  v3 = col[(int64_t)(r + 192) * ld];
+      acc = (((acc + v0) + v1) + v2) + v3;
     }
-    const float rstd = rsqrtf(var + eps);
-    const float sc = gamma[c] * rstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
-    if (mean_o) {
-      mean_o[c] = mean;
-      rstd_o[c] = rstd;
+    for (; r < rows; r += 64) acc += col[(int64_t)r * ld];
+  }
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  __syncthreads();  // `red` may still be read from a previous call
+  if ((threadIdx.x & 63) < 16) red[wv][cl] = acc;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += red[i][cl];
+  return t;
+}
+
+// per-channel BatchNorm bookkeeping: partial rows -> (scale, shift, mean, rstd) and running-stat update
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int partials, float count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float momentum, float eps, int training,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o, int C) {
+  __shared__ float red[16][16];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  float t1 = 0.f, t2 = 0.f;
+  if (training) {
+    t1 = fold_partial_rows(stats + c, partials, 2 * (int64_t)C, c < C, red);
+    t2 = fold_partial_rows(stats + C + c, partials, 2 * (int64_t)C, c < C, red);
+  }
+  if (threadIdx.x >= 16 || c >= C) return;
+  float mean, var;
+  if (training) {
+    mean = t1 / count;
+    var = fmaxf(t2 / count - mean * mean, 0.f);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float rstd = rsqrtf(var + eps);
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  if (mean_o) {
+    mean_o[c] = mean;
+    rstd_o[c] = rstd;
   }
 }
 
@@ -282,10 +320,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
   }
   __syncthreads();
   const int cc = blockIdx.x * 256 + threadIdx.x;
-  if (cc < C) {
-    atomicAdd(sums + cc, red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
-    atomicAdd(sums + C + cc, red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+  if (cc < C) {  // `sums` is this pass's partial buffer [gridDim.y][2][C]; bn_bwd_fold_kernel adds the rows in order
+    float* row = sums + (int64_t)blockIdx.y * 2 * C;
+    row[cc] = ((red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + red[0][2][threadIdx.x]) + red[0][3][threadIdx.x];
+    row[C + cc] = ((red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + red[1][2][threadIdx.x]) + red[1][3][threadIdx.x];
   }
+}
+
+// sums[0:2C] = fixed-order sum of the partial rows
+__global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(const float* __restrict__ partial, int rows, int C,
+                                                           float* __restrict__ sums) {
+  __shared__ float red[16][16];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);  // over 2C columns
+  const float t = fold_partial_rows(partial + c, rows, 2 * (int64_t)C, c < 2 * C, red);
+  if (threadIdx.x < 16 && c < 2 * C) sums[c] = t;
 }
 
 // pass 2: dD = gamma*rstd * (du - s1/n - xhat * s2/n)
@@ -376,14 +424,20 @@ extern "C" int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, f
   return S2T_LAUNCH_CHECK();
 }
 
-extern "C" int s2t_bn_finalize(const float* stats, float count, const float* gamma, const float* beta,
+extern "C" int s2t_dwconv_stat_partials(int B, int T) { return B * ((T + TT - 1) / TT); }
+extern "C" int s2t_bn_bwd_partials(int64_t rows) {
+  int64_t slices = (rows + 31) / 32;  // 8 rows per wave: the pass is latency bound with fewer workgroups
+  return (int)(slices > 512 ? 512 : slices);
+}
+
+extern "C" int s2t_bn_finalize(const float* stats, int partials, float count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, int training,
                                float* scale, float* shift, float* mean, float* rstd, int C, void* stream) {
   if (!gamma || !beta || !scale || !shift || C <= 0) return S2T_ERR_ARG;
-  if (training && !stats) return S2T_ERR_ARG;
+  if (training && (!stats || partials <= 0)) return S2T_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return S2T_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, stats, partials, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, C);
   return S2T_LAUNCH_CHECK();
 }
 
@@ -402,19 +456,22 @@ extern "C" int s2t_bn_act_fwd(int dtype, const void* D, void* out, const float* 
 }
 
 extern "C" int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const float* scale,
-                              const float* shift, const float* mean, const float* rstd, float* sums /* [2C], zeroed */,
-                              float count, int act, int64_t rows, int C, const int32_t* lens, int T, void* stream) {
-  if (!D || !dOut || !dD || !scale || !shift || !mean || !rstd || !sums || rows <= 0 || C <= 0 || C % 4) return S2T_ERR_ARG;
+                              const float* shift, const float* mean, const float* rstd, float* sums /* [2C] out */,
+                              float* ws /* [s2t_bn_bwd_partials(rows)][2C] scratch */, float count, int act,
+                              int64_t rows, int C, const int32_t* lens, int T, void* stream) {
+  if (!D || !dOut || !dD || !scale || !shift || !mean || !rstd || !sums || !ws || rows <= 0 || C <= 0 || C % 4) return S2T_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int64_t slices = (rows + 31) / 32;  // 8 rows per wave: the pass is latency bound with fewer workgroups
-  if (slices > 512) slices = 512;
+  const int slices = s2t_bn_bwd_partials(rows);
   dim3 rgrid((C + 255) / 256, (unsigned)slices), block(256);
   dim3 agrid((unsigned)((rows * (C / 4) + 255) / 256));
+  dim3 fgrid((2 * C + 15) / 16), fblock(1024);
   if (dtype == S2T_F32) {
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, rgrid, block, 0, s, (const float*)D, (const float*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, sums);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, rgrid, block, 0, s, (const float*)D, (const float*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, ws);
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, fgrid, fblock, 0, s, ws, slices, C, sums);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, agrid, block, 0, s, (const float*)D, (const float*)dOut, (float*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
   } else if (dtype == S2T_BF16) {
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, rgrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, sums);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, rgrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, ws);
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, fgrid, fblock, 0, s, ws, slices, C, sums);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, agrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, (bf16_t*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();

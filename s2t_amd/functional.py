@@ -858,7 +858,7 @@ class ConvModuleFn(torch.autograd.Function):
         D = mean = rstd = None
         if training:
             D = torch.empty(M, d, dtype=dt, device=dev)
-            stats = torch.zeros(2 * d, dtype=torch.float32, device=dev)
+            stats = torch.empty(K.dwconv_stat_partials(B, T), 2, d, dtype=torch.float32, device=dev)
             K.dwconv_fwd(g, wd, D, B, T, d, Kw, stats=stats)
             mean = torch.empty(d, dtype=torch.float32, device=dev)
             rstd = torch.empty(d, dtype=torch.float32, device=dev)
@@ -894,7 +894,7 @@ class ConvModuleFn(torch.autograd.Function):
         _wgrad(dy, a, prm["pw2_w"].grad.view(d, d), d, d, M, d, d)
         # here dy rows of padded frames must not reach pw2's weight gradient: a is zero there -> contributes nothing
         dD = torch.empty(M, d, dtype=dt, device=dev)
-        sums = torch.zeros(2 * d, dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * d, dtype=torch.float32, device=dev)
         K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T)
         prm["bn_b"].grad.add_(sums[:d])
         prm["bn_w"].grad.add_(sums[d:])

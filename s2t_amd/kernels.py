@@ -243,8 +243,13 @@ def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
           DW_REPLICAS, B, T, C, K)
 
 
+def dwconv_stat_partials(B, T):
+    return L.lib().s2t_dwconv_stat_partials(B, T)
+
+
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, C):
-    _call("s2t_bn_finalize", _ptr(stats), float(count), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean),
+    """``stats``: [partials][2][C] rows written by dwconv_fwd (training) or None."""
+    _call("s2t_bn_finalize", _ptr(stats), stats.shape[0] if stats is not None else 0, float(count), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean),
           _ptr(running_var), momentum, eps, int(training), scale.data_ptr(), shift.data_ptr(), _ptr(mean), _ptr(rstd), C)
 
 
@@ -254,9 +259,10 @@ def bn_act_fwd(D, out, scale, shift, act, rows, C, lens=None, T=0):
 
 
 def bn_act_bwd(D, dOut, dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens=None, T=0):
+    ws = _scratch("bn_bwd", L.lib().s2t_bn_bwd_partials(rows) * 2 * C, D.device)
     _call("s2t_bn_act_bwd", L.dtype_id(D.dtype), D.data_ptr(), dOut.data_ptr(), dD.data_ptr(), scale.data_ptr(),
-          shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), float(count), L.ACT_IDS[act], rows, C,
-          _ptr(lens), T)
+          shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), ws.data_ptr(), float(count), L.ACT_IDS[act],
+          rows, C, _ptr(lens), T)
 
 
 def argmax_lse(logits, ld, rows, V, idx=None, top_lp=None, lse=None):

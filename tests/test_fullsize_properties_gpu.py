@@ -99,9 +99,7 @@ def test_loss_is_additive_over_utterances(model, sample):
 
 def test_grouped_and_per_weight_gradients_agree(sample):
     """On the 12-layer Transformer (config 2): its data path has no order-dependent reduction, so two identical passes
-    give identical activation gradients and the two weight-gradient paths differ only in their fp32 summation trees.
-    (The Conformer's training-mode BatchNorm statistics are accumulated with float atomics; in bf16 that last-bit noise
-    is amplified to percent-level run-to-run differences of the gradients, with either path.)"""
+    give identical activation gradients and the two weight-gradient paths differ only in their fp32 summation trees."""
     torch.manual_seed(2)
     model = M.S2TTransformerModel.build_model(M.recipe_args(conformer=False, vocab_size=V), M.FakeTask(V)).prepare(torch.bfloat16, DEV)
     model.train()
@@ -123,3 +121,25 @@ def test_grouped_and_per_weight_gradients_agree(sample):
     noise = float((grads["per_weight_again"] - ref).norm() / ref.norm())  # LayerNorm / bias partial sums use atomics
     assert noise < 1e-4, noise
     assert float((grads["grouped"] - ref).norm() / ref.norm()) < 1e-3
+
+
+def test_conformer_training_pass_repeats(sample):
+    """The Conformer's training-mode data path holds no order-dependent reduction either: BatchNorm batch statistics and
+    the BatchNorm backward sums are per-workgroup partial rows added in a fixed order (conv.hip), so two identical passes
+    give the same loss and the same activation gradients; what is left is the fp32 atomics in the
+    per-parameter sums (LayerNorm dgamma/dbeta folds, bias column sums)."""
+    torch.manual_seed(2)
+    model = M.S2TTransformerModel.build_model(M.recipe_args(conformer=True, vocab_size=V), M.FakeTask(V)).prepare(torch.bfloat16, DEV)
+    model.train()
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    out = []
+    for _ in range(2):
+        model.flat.zero_grad()
+        loss, _, _ = crit(model, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((float(loss.detach()), model.flat.grad.clone()))
+    noise = float((out[1][1] - out[0][1]).norm() / out[0][1].norm())
+    print("loss", out[0][0], out[1][0], "grad noise", noise)
+    assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[0][0])  # the loss scalar itself is an atomic sum over rows
+    assert noise < 1e-4, noise

@@ -224,7 +224,7 @@ def test_dwconv_bn_act_fwd_bwd(dtype, Kw):
         # ---- training path: conv (+stats) -> finalize -> bn_act
         xd = x.to(DEV)
         D = torch.empty_like(xd)
-        stats = torch.zeros(2 * C, device=DEV)
+        stats = torch.full((K.dwconv_stat_partials(B, T), 2, C), float("nan"), device=DEV)  # every row must be written
         K.dwconv_fwd(xd, w.to(DEV), D, B, T, C, Kw, stats=stats)
         scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
         rmd, rvd = rm.to(DEV), rv.to(DEV)
@@ -248,7 +248,7 @@ def test_dwconv_bn_act_fwd_bwd(dtype, Kw):
         # ---- backward
         ref.backward(dOut.float())
         dD = torch.empty_like(xd)
-        sums = torch.zeros(2 * C, device=DEV)
+        sums = torch.full((2 * C,), float("nan"), device=DEV)
         K.bn_act_bwd(D, dOut.to(DEV), dD, scale, shift, mean, rstd, sums, n, act, n, C, lens.to(DEV), T)
         dG = torch.empty_like(xd)
         K.dwconv_fwd(dD, w.to(DEV), dG, B, T, C, Kw, flip=True)
