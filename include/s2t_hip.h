@@ -313,6 +313,22 @@ int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B, int T, in
 int s2t_ctc_backtrace(const float* alpha, const int32_t* paths, const int32_t* tgt_lens, const int32_t* in_lens, int B,
                       int T, int Lmax, int32_t* states, void* stream);
 
+/* ---- CTC prefix scores for joint attention/CTC beam search ------------------------------------
+ * Replaces the host-side scorer the reference drives from fairseq/sequence_generator.py:255-388
+ * (espnet.nets.ctc_prefix_score.CTCPrefixScore: initial_state / __call__; third-party, numpy, one hypothesis at a time).
+ * lp: fp32 log-probabilities, frame t of sentence b at lp + (b*T + t)*ld; sent[r]: sentence of hypothesis row r;
+ * state r: [T][2] fp32 per hypothesis (log-prob of the prefix over frames 0..t ending in its last label | in blank).
+ * s2t_ctc_prefix_init : the empty prefix's state for R rows.
+ * s2t_ctc_prefix_score: for R rows x K candidate tokens: psi[r][k] = log prefix probability of (prefix_r + cand[r][k])
+ *                       (</s>: probability of the prefix ending there; blank: -1e10), and, if r_new != NULL, the extended
+ *                       prefix's state r_new[r][k][T][2].  out_len = labels already in the prefix (the decoding step),
+ *                       last[r] = the prefix's last token. */
+int s2t_ctc_prefix_init(const float* lp, int64_t ld, int T, const int32_t* in_lens, const int32_t* sent, int R, int blank,
+                        float* r0, void* stream);
+int s2t_ctc_prefix_score(const float* lp, int64_t ld, int T, const int32_t* in_lens, const int32_t* sent,
+                         const float* r_prev, const int64_t* last, int out_len, const int64_t* cand, int R, int K, int blank,
+                         int eos, float* psi, float* r_new, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ Reference file:line citations are relative to ``/root/reference/fairseq``.
 import math
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -345,8 +346,56 @@ def decoder_forward(prev_output_tokens, enc_out, W, cfg, prefix="decoder.", pad_
 # ----------------------------------------------------------------------------------------------
 # beam search
 # ----------------------------------------------------------------------------------------------
+class CTCPrefixScore:
+    """Restatement of the scorer the reference imports at fairseq/sequence_generator.py:17 and drives at :255-388 —
+    ``espnet.nets.ctc_prefix_score.CTCPrefixScore`` (ESPnet is an unpinned third-party dependency, setup.py:205, absent
+    from the reference tree; algorithm: Watanabe et al. 2017, eq. 51-54; numpy float32, ``logzero = -1e10``).
+
+    x: (T, V) float32 log-probabilities of ONE utterance.  State of a prefix: r (T, 2) — log-probability that frames
+    0..t emit the prefix and end in its last label (column 0) / in blank (column 1).  PARITY UNPINNED against ESPnet
+    itself; pinned instead by the identity psi(y + </s>) == -CTC-NLL(y) against ATen's ctc_loss (tests)."""
+
+    logzero = -10000000000.0
+
+    def __init__(self, x, blank, eos):
+        self.x = np.asarray(x, dtype=np.float32)
+        self.blank, self.eos = blank, eos
+        self.input_length = len(self.x)
+
+    def initial_state(self):
+        r = np.full((self.input_length, 2), self.logzero, dtype=np.float32)
+        r[:, 1] = np.cumsum(self.x[:, self.blank], dtype=np.float32)
+        return r
+
+    def __call__(self, y, cs, r_prev):
+        """y: prefix INCLUDING the leading </s>-as-<sos>; cs: candidate ids.  -> (log_psi (K,), states (K, T, 2))"""
+        cs = np.asarray(cs, dtype=np.int64)
+        T, K = self.input_length, len(cs)
+        out_len = len(y) - 1
+        r = np.full((T, 2, K), self.logzero, dtype=np.float32)  # rows below out_len-1 are dead (never read again)
+        xs = self.x[:, cs]
+        if out_len == 0:
+            r[0, 0] = xs[0]
+        r_sum = np.logaddexp(r_prev[:, 0], r_prev[:, 1])
+        log_phi = np.repeat(r_sum[:, None], K, axis=1)
+        if out_len > 0:
+            log_phi[:, cs == int(y[-1])] = r_prev[:, 1:2]
+        start = max(out_len, 1)
+        log_psi = r[start - 1, 0].copy()
+        for t in range(start, T):
+            r[t, 0] = np.logaddexp(r[t - 1, 0], log_phi[t - 1]) + xs[t]
+            r[t, 1] = np.logaddexp(r[t - 1, 0], r[t - 1, 1]) + self.x[t, self.blank]
+            log_psi = np.logaddexp(log_psi, log_phi[t - 1] + xs[t])
+        log_psi[cs == self.eos] = r_sum[-1]
+        log_psi[cs == self.blank] = self.logzero
+        return log_psi.astype(np.float32), np.moveaxis(r, 2, 0)
+
+
+CTC_SCORING_RATIO = 1.5  # sequence_generator.py:19
+
+
 def beam_search(src_tokens, src_lengths, W, cfg, beam, max_len_a=0.0, max_len_b=200, min_len=1, len_penalty=1.0,
-                unk_penalty=0.0, normalize_scores=True, pad=1, eos=2, unk=3, blank=0, max_decoder_positions=1024):
+                unk_penalty=0.0, normalize_scores=True, pad=1, eos=2, unk=3, blank=0, max_decoder_positions=1024, ctc_weight=0.0):
     """fairseq/sequence_generator.py:191-614 (_generate) + search.py:101-150 (BeamSearch.step) + :650-786
     (finalize_hypos / is_finished), restated one sentence at a time with plain Python lists and NO incremental state
     (every step re-runs the teacher-forced decoder on the whole prefix):
@@ -356,6 +405,11 @@ def beam_search(src_tokens, src_lengths, W, cfg, beam, max_len_a=0.0, max_len_b=
       * of the best 2*beam candidates, an </s> among the FIRST beam is finalised with score / (step+1)^len_penalty
         (while fewer than beam hypotheses are finished); the first beam non-</s> candidates continue;
       * a sentence stops once beam hypotheses are finished or step == max_len; hypotheses are sorted by score.
+    ``ctc_weight > 0`` (sequence_generator.py:255-271,355-388): while step <= T', the ``int(1.5 * beam)`` best non-blank
+    tokens of every hypothesis get ``(1-w) * lprob + w * (psi(prefix + token) - psi(prefix))`` with psi from
+    CTCPrefixScore on the encoder's CTC log-probabilities; the other tokens keep their plain lprob (as in the reference).
+    The reference scores every sentence against utterance 0's CTC output (``ctc_lprobs[0]``, i.e. it is a batch-size-1
+    path); here each sentence uses its own unpadded frames, which is the same thing at batch size 1.
     Returns, per sentence, a list of dicts {tokens, score, positional_scores}."""
     enc = encoder_forward(src_tokens, src_lengths, W, cfg, training=False)
     B, src_len = src_tokens.shape[:2]
@@ -366,11 +420,31 @@ def beam_search(src_tokens, src_lengths, W, cfg, beam, max_len_a=0.0, max_len_b=
                  "encoder_padding_mask": [enc["encoder_padding_mask"][0][b:b + 1]]}
         hyps = [([eos], [])]  # (tokens incl. the leading </s>, cumulative scores per position)
         finished = []
+        if ctc_weight > 0:
+            Tb = int((~enc["encoder_padding_mask"][0][b]).sum())
+            ctc_lp = torch.log_softmax(enc["ctc_logit"][0][:Tb, b].float(), -1).numpy()
+            scorer = CTCPrefixScore(ctc_lp, blank, eos)
+            ctc_beam = min(ctc_lp.shape[-1], int(beam * CTC_SCORING_RATIO))
+            ctc_state = {(eos,): (scorer.initial_state(), 0.0)}  # prefix -> (state, psi of the prefix)
         for step in range(max_len + 1):
             cands = []
             for bi, (toks, cum) in enumerate(hyps):
                 logits = decoder_forward(torch.tensor([toks]), enc_b, W, cfg)[0, -1]
                 lp = torch.log_softmax(logits.float(), -1)
+                if ctc_weight > 0 and step <= Tb:
+                    masked = lp.clone()
+                    masked[blank] = NEG_INF
+                    ids = torch.topk(masked, ctc_beam).indices.numpy()
+                    key = tuple(toks)
+                    if key not in ctc_state:  # continued with a token outside its parent's ctc_beam (:363-374)
+                        st, _ = ctc_state[key[:-1]]
+                        ps, rs = scorer(list(key[:-1]), [key[-1]], st)
+                        ctc_state[key] = (rs[0], float(ps[0]))
+                    st, prev = ctc_state[key]
+                    psi, states = scorer(toks, ids, st)
+                    lp[ids] = (1 - ctc_weight) * lp[ids] + ctc_weight * torch.from_numpy(psi - np.float32(prev))
+                    for j, v in enumerate(ids.tolist()):
+                        ctc_state[key + (v,)] = (states[j], float(psi[j]))
                 lp[lp != lp] = NEG_INF
                 lp[pad] = NEG_INF
                 lp[blank] = NEG_INF

@@ -298,6 +298,19 @@ def ctc_backtrace(alpha, paths, tgt_lens, in_lens, B, T, Lmax, states):
           states.data_ptr())
 
 
+def ctc_prefix_init(lp, T, in_lens, sent, blank, r0):
+    """lp: fp32 [B*T, V] log-probabilities (batch-major rows); r0: [R, T, 2]."""
+    _call("s2t_ctc_prefix_init", lp.data_ptr(), lp.stride(0), T, in_lens.data_ptr(), sent.data_ptr(), r0.shape[0], blank,
+          r0.data_ptr())
+
+
+def ctc_prefix_score(lp, T, in_lens, sent, r_prev, last, out_len, cand, blank, eos, psi, r_new=None):
+    """cand: int64 [R, K]; psi: fp32 [R, K]; r_new: optional fp32 [R, K, T, 2]."""
+    R, Kc = cand.shape
+    _call("s2t_ctc_prefix_score", lp.data_ptr(), lp.stride(0), T, in_lens.data_ptr(), sent.data_ptr(), r_prev.data_ptr(),
+          last.data_ptr(), out_len, cand.data_ptr(), R, Kc, blank, eos, psi.data_ptr(), _ptr(r_new))
+
+
 def row_softmax_fwd(x, ldx, p, ldp, rows, V, inv_tau=1.0):
     _call("s2t_row_softmax_fwd", L.dtype_id(x.dtype), x.data_ptr(), ldx, p.data_ptr(), ldp, rows, V, inv_tau)
 

@@ -15,14 +15,23 @@ Mirrors the contract of the reference's ``fairseq/sequence_generator.py`` (``Seq
 The decoder runs incrementally (``TransformerDecoderScriptable`` with ``incremental_state``: per-layer key/value caches
 in HBM, one query row per hypothesis, ``reorder_incremental_state`` after every step).  Finished sentences stay in the
 batch (their rows are ignored) instead of being compacted away, which keeps every tensor shape static per step.
+Joint CTC rescoring (``ctc_weight > 0``, reference :255-271 and :355-388): the reference pulls every hypothesis to the
+host each step and scores it with ESPnet's numpy ``CTCPrefixScore`` through a dict keyed by the token string; here the
+prefix states live in HBM ([rows, T', 2] fp32) and two launches of ``s2t_ctc_prefix_score`` per step score the
+``int(1.5 * beam)`` candidates of every row and then advance the surviving rows' states — no per-token D2H.  The
+reference scores all sentences against utterance 0 (``ctc_lprobs[0]``: a batch-size-1 path); this one scores each
+sentence against its own frames, which is identical at batch size 1.
 Not built (reference options that the recipes' generation configs leave off): sampling / diverse / constrained search,
-LM fusion, n-gram blocking, prefix tokens, joint CTC prefix rescoring (the reference scores prefixes on the CPU with
-numpy, ``ctc_prefix_score.py``; an on-device scorer is the remaining part of §8f row 1).
+LM fusion, n-gram blocking, prefix tokens.
 """
 import math
 from typing import Dict, List, Optional
 
 import torch
+
+from . import kernels as K
+
+CTC_SCORING_RATIO = 1.5  # sequence_generator.py:19
 
 
 class SequenceGenerator:
@@ -33,7 +42,7 @@ class SequenceGenerator:
         models = list(models) if isinstance(models, (list, tuple)) else [models]
         if len(models) != 1:
             raise NotImplementedError("model ensembles")
-        if match_source_len or no_repeat_ngram_size or search_strategy is not None or lm_model is not None or ctc_weight:
+        if match_source_len or no_repeat_ngram_size or search_strategy is not None or lm_model is not None:
             raise NotImplementedError("only plain beam search is built on the HIP path (see module docstring)")
         self.model = models[0]
         self.tgt_dict = tgt_dict
@@ -45,6 +54,7 @@ class SequenceGenerator:
         self.max_len_a, self.max_len_b, self.min_len = max_len_a, max_len_b, min_len
         self.normalize_scores, self.len_penalty, self.unk_penalty = normalize_scores, len_penalty, unk_penalty
         self.temperature = temperature
+        self.ctc_weight = float(ctc_weight)
         assert temperature > 0, "--temperature must be greater than 0"
 
     @torch.no_grad()
@@ -64,6 +74,9 @@ class SequenceGenerator:
 
         enc = model.encoder(src_tokens, src_lengths)
         order = torch.arange(bsz, device=dev).view(-1, 1).repeat(1, beam).view(-1)
+        ctc = None
+        if self.ctc_weight > 0:
+            ctc = self._ctc_prepare(enc, order, beam)
         enc = model.encoder.reorder_encoder_out(enc, order)
 
         tokens = torch.full((bsz * beam, max_len + 2), self.pad, dtype=torch.long, device=dev)
@@ -84,6 +97,8 @@ class SequenceGenerator:
                 enc = model.encoder.reorder_encoder_out(enc, reorder)
             logits, _ = model.decoder(tokens[:, :step + 1], encoder_out=enc, incremental_state=incremental_state)
             lprobs = torch.log_softmax(logits[:, -1, :].float() / self.temperature, dim=-1)
+            if ctc is not None:
+                self._ctc_rescore(ctc, lprobs, tokens, step)
             lprobs[lprobs != lprobs] = NEG
             lprobs[:, self.pad] = NEG
             lprobs[:, self.blank] = NEG
@@ -144,7 +159,50 @@ class SequenceGenerator:
                 scores[:, :step] = scores[:, :step].index_select(0, active_bbsz)
             scores.view(bsz, beam, -1)[:, :, step] = torch.gather(cand_scores, 1, active_hypos)
             reorder = active_bbsz
+            if ctc is not None:
+                self._ctc_advance(ctc, active_bbsz, tokens, step)
 
         for sent in range(bsz):
             finalized[sent].sort(key=lambda h: -float(h["score"]))
         return finalized
+
+    # ---- joint CTC rescoring (reference :255-271, :355-388) -----------------------------------------------------------
+    def _ctc_prepare(self, enc, order, beam):
+        key = "xctc_logit" if len(enc.get("xctc_logit", [])) > 0 else "ctc_logit"  # :257-260
+        logit = enc[key][0]  # (T', B, V), a view of the encoder's batch-major buffer
+        Tn, B, V = logit.shape
+        lp = torch.log_softmax(logit.transpose(0, 1).float(), dim=-1).reshape(B * Tn, V).contiguous()
+        in_lens = (~enc["encoder_padding_mask"][0]).sum(1).to(torch.int32)
+        sent = order.to(torch.int32).contiguous()
+        R = sent.numel()
+        state = torch.empty(R, Tn, 2, dtype=torch.float32, device=lp.device)
+        K.ctc_prefix_init(lp, Tn, in_lens, sent, self.blank, state)
+        return {"lp": lp, "T": Tn, "in_lens": in_lens, "sent": sent, "state": state,
+                "prev": torch.zeros(R, dtype=torch.float32, device=lp.device),
+                "row_len": in_lens.long().index_select(0, order), "k": min(V, int(beam * CTC_SCORING_RATIO))}
+
+    def _ctc_rescore(self, ctc, lprobs, tokens, step):
+        """lprobs[r, ids] <- (1 - w) * lprobs[r, ids] + w * (psi(prefix_r + ids) - psi(prefix_r)) for the ctc_beam best
+        non-blank ids of every row, while step <= T' of the row's utterance (:355-382)."""
+        masked = lprobs.clone()
+        masked[:, self.blank] = -math.inf
+        ids = torch.topk(masked, ctc["k"], dim=-1).indices.contiguous()
+        psi = torch.empty(ids.shape, dtype=torch.float32, device=lprobs.device)
+        K.ctc_prefix_score(ctc["lp"], ctc["T"], ctc["in_lens"], ctc["sent"], ctc["state"], tokens[:, step].contiguous(), step,
+                           ids, self.blank, self.eos, psi)
+        old = lprobs.gather(1, ids)
+        new = (1.0 - self.ctc_weight) * old + self.ctc_weight * (psi - ctc["prev"].unsqueeze(1))
+        live = (ctc["row_len"] >= step).unsqueeze(1)
+        lprobs.scatter_(1, ids, torch.where(live, new, old))
+
+    def _ctc_advance(self, ctc, parents, tokens, step):
+        """The surviving rows' prefix states: parent state + the token just appended (tokens[:, step + 1]); ``tokens`` has
+        already been re-ordered, so tokens[:, step] is the parent's last token."""
+        parent_state = ctc["state"].index_select(0, parents)
+        cand = tokens[:, step + 1].contiguous().view(-1, 1)
+        psi = torch.empty(cand.shape, dtype=torch.float32, device=cand.device)
+        new_state = torch.empty_like(parent_state).unsqueeze(1)
+        K.ctc_prefix_score(ctc["lp"], ctc["T"], ctc["in_lens"], ctc["sent"], parent_state, tokens[:, step].contiguous(), step,
+                           cand, self.blank, self.eos, psi, new_state)
+        ctc["state"] = new_state.squeeze(1)
+        ctc["prev"] = psi.view(-1)

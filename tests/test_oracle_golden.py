@@ -181,3 +181,44 @@ def test_beam_search_matches_reference_generator(golden_dir):
             np.testing.assert_allclose(np.array(h["positional_scores"]), z["out::pos_scores_%d_%d" % (b, k)], atol=1e-4)
             lengths.add(len(h["tokens"]))
     assert len(lengths) > 2  # the fixture exercises early </s> as well as the forced one at max_len
+
+
+def test_ctc_prefix_scorer_identities():
+    """The prefix scorer restated from ESPnet's published algorithm has no reference-side fixture (third-party, absent);
+    it is pinned through identities against ATen's CTC loss: walking a label sequence y token by token and closing with
+    </s> gives log p_ctc(y | x) = -ctc_loss(y), and the prefix probabilities of all one-token prefixes plus the
+    probability of the empty output sum to one."""
+    g = torch.Generator().manual_seed(5)
+    T, V, blank, eos = 23, 9, 0, 2
+    lp = torch.log_softmax(torch.randn(T, V, generator=g) * 2, -1)
+    sc = O.CTCPrefixScore(lp.numpy(), blank, eos)
+    for y in ([4], [3, 3, 5], [6, 7, 6, 6, 8, 3], []):
+        state, prefix, psi_prev = sc.initial_state(), [eos], 0.0
+        for tok in y:
+            psi, st = sc(prefix, [tok, 5], state)
+            assert psi[0] <= psi_prev + 1e-5  # a longer prefix is never more probable
+            state, psi_prev, prefix = st[0], float(psi[0]), prefix + [tok]
+        psi, _ = sc(prefix, [eos, blank], state)
+        ref = torch.nn.functional.ctc_loss(lp[:, None, :], torch.tensor([y], dtype=torch.long).view(1, -1), torch.tensor([T]),
+                                           torch.tensor([len(y)]), blank=blank, reduction="none", zero_infinity=False)
+        assert abs(float(psi[0]) + float(ref[0])) < 1e-3, (y, float(psi[0]), float(ref[0]))
+        assert psi[1] == np.float32(O.CTCPrefixScore.logzero)
+    # sum over first tokens of p(prefix = c) + p(empty output) == 1
+    # (index 2 is also an ordinary CTC label: its prefix probability comes from a scorer whose </s> id matches nothing)
+    cs = [c for c in range(V) if c != blank]
+    psi, _ = O.CTCPrefixScore(lp.numpy(), blank, -1)([eos], cs, sc.initial_state())
+    p_first = np.exp(psi.astype(np.float64)).sum()
+    p_empty = np.exp(float(sc([eos], [eos], sc.initial_state())[0][0]))
+    assert abs(p_first + p_empty - 1.0) < 1e-4
+
+
+def test_joint_ctc_beam_search_runs_and_differs(golden_dir):
+    """ctc_weight > 0 changes scores (and is well formed); ctc_weight == 0 is the plain search pinned above."""
+    z = np.load(os.path.join(golden_dir, "beam_search_transformer.npz"))
+    W, cfg = O.weights_from_golden(z), O.cfg_from_golden(z)
+    src, lens = torch.from_numpy(z["in::src_tokens"])[:1], torch.from_numpy(z["in::src_lengths"])[:1]
+    beam, mlb = int(z["gen::beam"]), int(z["gen::max_len_b"])
+    plain = O.beam_search(src, lens, W, cfg, beam=beam, max_len_b=mlb)
+    joint = O.beam_search(src, lens, W, cfg, beam=beam, max_len_b=mlb, ctc_weight=0.3)
+    assert len(joint[0]) >= 1 and all(h["tokens"][-1] == 2 for h in joint[0])
+    assert [h["score"] for h in joint[0]] != [h["score"] for h in plain[0]]
