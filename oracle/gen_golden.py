@@ -341,6 +341,134 @@ def ctc_greedy_case(name, outdir, V, B, T, seed, **kw):
     print(name, "hyp lens", [len(t) for t in toks])
 
 
+def _cfg_dump(out, args):
+    for k, v in sorted(vars(args).items()):
+        if isinstance(v, bool):
+            out["cfg::" + k] = np.bool_(v)
+        elif isinstance(v, (int, float)):
+            out["cfg::" + k] = np.float64(v)
+        elif isinstance(v, str):
+            out["cfg::" + k] = np.array(v)
+
+
+def nast_case(name, outdir, V, B, T, seed, **kw):
+    """SURVEY.md §8f row 2 — the reproduction_nast.yaml stack at toy size: ``s2t_ctc --encoder-type sate`` (models/
+    speech_to_text/s2t_ctc.py:28-126 -> S2TSATEEncoder s2t_sate.py:837-1075, TextualEncoder :333-827 with
+    TransformerS2EncoderLayer modules/transformer_s2_layer.py:214-336, XCTC / inter-XCTC heads, PAE adapter.py:189-297),
+    CtcCriterion (criterions/ctc.py:258-1016) and CTCDecoder greedy on xctc_logit (s2t_ctc.py:236-349).
+    The reference's random draws in the training pass (``torch.rand`` of the PAE ground-truth mask, numpy ``uniform`` of the
+    league drop-net) are recorded so that the restatement can replay them."""
+    from fairseq.criterions.ctc import CtcCriterion, CtcCriterionConfig
+    from fairseq.models.speech_to_text.s2t_ctc import CTCDecoder
+    import fairseq.modules.transformer_s2_layer as s2mod
+
+    torch.manual_seed(seed)
+    model, args, task = build("s2t_ctc", V, **kw)
+    seed_weights(model, seed + 100)
+    with torch.no_grad():  # non-trivial greedy output / alignments
+        model.encoder.textual_encoder.xctc.ctc_projection.weight.mul_(3.0)
+        model.encoder.acoustic_encoder.ctc.ctc_projection.weight.mul_(3.0)
+    src, lens, prev, target, ntokens = make_batch(B, T, V, seed + 200, umin=3, umax=7)
+    _, _, _, transcript, _ = make_batch(B, T, V, seed + 300, umin=3, umax=7)
+    out = {}
+    out.update(sd_np(model))
+    out["in::src_tokens"], out["in::src_lengths"] = np_(src), np_(lens)
+    out["in::prev_output_tokens"], out["in::target"], out["in::transcript"] = np_(prev), np_(target), np_(transcript)
+    out["in::ntokens"] = np.int64(ntokens)
+
+    model.eval()
+    with torch.no_grad():
+        enc = model.encoder(src, lens)
+        dargs = Namespace(beam=1, ctc_self_ensemble=False, ctc_inter_logit=0, cal_flops=False, print_alignment=False)
+        hyps = CTCDecoder([model], dargs, task.target_dictionary, blank_idx=0).generate(
+            [model], {"net_input": {"src_tokens": src, "src_lengths": lens, "prev_output_tokens": prev}, "target": target})
+    out["out::encoder_out"] = np_(enc["encoder_out"][0])
+    out["out::ctc_logit"] = np_(enc["ctc_logit"][0])
+    out["out::xctc_logit"] = np_(enc["xctc_logit"][0])
+    out["out::encoder_padding_mask"] = np_(enc["encoder_padding_mask"][0])
+    for i, il in enumerate(enc["inter_ctc_logits"]):
+        out["out::inter_ctc_logit_%d" % i] = np_(il[0] if isinstance(il, (list, tuple)) else il)
+    for i, il in enumerate(enc["inter_xctc_logits"]):
+        out["out::inter_xctc_logit_%d" % i] = np_(il[0] if isinstance(il, (list, tuple)) else il)
+    toks = [np_(h[0]["tokens"]).astype(np.int64) for h in hyps]
+    out["out::hyp_lengths"] = np.array([len(t) for t in toks], dtype=np.int64)
+    out["out::hyp_tokens"] = np.concatenate(toks) if sum(len(t) for t in toks) else np.zeros(0, np.int64)
+    out["out::hyp_scores"] = np.array([float(h[0]["score"]) for h in hyps])
+
+    # ---- CtcCriterion in training mode (dropout 0), random draws recorded
+    cfg = CtcCriterionConfig()
+    cfg.sentence_avg, cfg.zero_infinity, cfg.post_process = False, True, "none"
+    cfg.xctc_weight = float(args.xctc_weight)
+    cfg.inter_ctc_weight = float(getattr(args, "inter_ctc_weight", 0.0))
+    cfg.inter_xctc_weight = float(getattr(args, "inter_xctc_weight", 0.0))
+    crit = CtcCriterion(cfg, task, ctc_weight=float(args.ctc_weight))
+    model.train()
+    crit.train()
+    sample = {"id": torch.arange(B), "net_input": {"src_tokens": src, "src_lengths": lens, "prev_output_tokens": prev},
+              "target": target, "transcript": {"tokens": transcript}, "ntokens": ntokens}
+    rand_draws, unif_draws = [], []
+    real_rand, real_unif = torch.rand, s2mod.uniform
+
+    def rec_rand(*a, **k):
+        r = real_rand(*a, **k)
+        rand_draws.append(r.clone())
+        return r
+
+    def rec_unif(*a, **k):
+        r = real_unif(*a, **k)
+        unif_draws.append(float(r))
+        return r
+
+    # criterions/ctc.py:290 calls torch_imputer's best_alignment, a CUDA extension that cannot be built or run in this
+    # container (fairseq.torch_imputer is blocked by ref_stubs).  For the curriculum fixture the Viterbi alignment is
+    # therefore supplied by the oracle's restatement (oracle/s2t_oracle.py: best_alignment); everything downstream of it
+    # (oracle labels, mistake flags, masks, PAE mixing, losses, gradients) is the reference's own code.
+    import fairseq.criterions.ctc as ctc_mod
+    import s2t_oracle as ORC
+
+    def best_alignment_standin(log_prob, targets, input_lengths, target_lengths, blank=0, zero_infinity=False):
+        return ORC.best_alignment(log_prob, [targets[b][: int(target_lengths[b])].tolist() for b in range(targets.size(0))],
+                                  input_lengths, blank)
+
+    had = getattr(ctc_mod, "best_alignment", None)
+    ctc_mod.best_alignment = best_alignment_standin
+    torch.rand, s2mod.uniform = rec_rand, rec_unif
+    try:
+        model.zero_grad()
+        loss, sample_size, log = crit(model, sample)
+        loss.backward()
+    finally:
+        torch.rand, s2mod.uniform = real_rand, real_unif
+        if had is None:
+            del ctc_mod.best_alignment
+        else:
+            ctc_mod.best_alignment = had
+    out["out::loss"] = np.float64(loss.item())
+    for k in ("ctc_loss", "inter_ctc_loss", "xctc_loss", "inter_xctc_loss"):
+        if k in log:
+            out["out::" + k] = np.float64(log[k])
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out["grad::" + k] = np_(p.grad)
+    for k, b in model.named_buffers():
+        if "running_" in k:
+            out["bn_after::" + k] = np_(b)
+    gt = float(getattr(args, "xctc_pae_ground_truth_ratio", 0) or 0)
+    if gt > 0:
+        big = [r for r in rand_draws if r.numel() > 1]
+        assert len(big) == 1, [tuple(r.shape) for r in rand_draws]
+        out["aux::xctc_rand_mask"] = np_(big[0] < gt)
+    # the criterion runs the encoder twice when gt > 0 (alignment pass first): keep the draws of the LAST pass
+    n_s2 = int(args.text_encoder_layers) - int(args.cross_attn_start_layer) + 1
+    prob = float(args.cross_attn_league_drop_net_prob)
+    out["aux::drop_self_attn_all"] = np.array([u < prob for u in unif_draws], dtype=np.bool_)
+    out["aux::n_s2_layers"] = np.int64(n_s2)
+    _cfg_dump(out, args)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    print(name, "loss", loss.item(), {k: v for k, v in log.items() if "loss" in k}, "hyps", [len(t) for t in toks],
+          "uniform draws", len(unif_draws), "rand draws", [tuple(r.shape) for r in rand_draws])
+
+
 def module_cases(outdir):
     from fairseq.modules import LayerNorm
     from fairseq.modules.positional_encoding import RelPositionalEncoding
@@ -408,6 +536,21 @@ def main():
         encoder_activation_fn="swish",
         layer_padding_mask=True,
     )
+    nast = dict(small, encoder_layers=4, encoder_type="sate", text_encoder_layers=4, acoustic_encoder="transformer",
+                adapter="inter_league", xctc_weight=1.0, ctc_weight=1.0, share_ctc_and_embed=True, share_xctc_and_embed=True,
+                text_no_pos_emb=True, textual_encoder_embed_norm=False, textual_encoder_no_scale_embedding=True,
+                encoder_normalize_before=True, share_inter_ctc=True, inter_ctc_weight=1.0, inter_ctc_layers="2,3",
+                inter_xctc_weight=1.0, inter_xctc_layers="2,3", ctc_pae="inter_league", xctc_pae="inter_league",
+                xctc_cross_attn=True, cross_attn_start_layer=3, cross_attn_layer=2, cross_attn_collaboration_mode="serial",
+                cross_attn_league_drop_net=True, xctc_pae_ground_truth_only_mistake=True, pae_oracle_smooth=True)
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "nast"):
+        # egs/mustc/st/conf/reproduction_nast.yaml at toy size; first without, then with the curriculum randomness
+        nast_case("nast_small", outdir, V=40, B=3, T=60, seed=21, **nast, **conf, cross_attn_league_drop_net_prob=0.0,
+                  xctc_pae_ground_truth_ratio=0.0)
+        nast_case("nast_pae_oracle", outdir, V=40, B=3, T=60, seed=22, **nast, **conf, cross_attn_league_drop_net_prob=0.5,
+                  xctc_pae_ground_truth_ratio=0.8)
+    if os.environ.get("GOLDEN_ONLY", "") == "nast":
+        return
     if os.environ.get("GOLDEN_ONLY", "") in ("", "interctc"):
         # egs/mustc/asr/conf/inter.yaml: intermediate CTC heads sharing the top projection, own LayerNorms
         encdec_case("conformer_interctc", outdir, "s2t_transformer_s", V=40, B=3, T=50, seed=12, train_bn=True,

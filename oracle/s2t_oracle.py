@@ -270,8 +270,38 @@ def inter_ctc_layer_list(cfg):
     return out
 
 
-def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None):
-    """models/speech_to_text/s2t_transformer.py:1714-2154 (no mixup / PAE branches; intermediate CTC heads included).
+def pae_inter_league(x, logit, w_embed, temperature=1.0, oracle=None, oracle_mask=None, oracle_smooth=False):
+    """modules/speech_to_text/adapter.py:189-297, ``inter_league``: x + dist @ W_embed with dist = softmax(logit / tau)
+    (:213-217); frames under ``oracle_mask`` take the one-hot distribution of the oracle label instead (:245-262; with
+    ``oracle_smooth`` 0.9 + 0.1/V on the label and 0.1/V elsewhere).  x (B,T,d), logit (B,T,V), oracle/mask (B,T)."""
+    dist = torch.softmax(logit / float(temperature), dim=-1)
+    if oracle is not None:
+        V = logit.size(-1)
+        od = F.one_hot(oracle, V).to(dist.dtype)
+        if oracle_smooth:
+            od = torch.where(od == 1, 0.9 + 0.1 / V, 0.1 / V).to(dist.dtype)
+        dist = torch.where(oracle_mask[..., None], od, dist)
+    return x + dist @ w_embed
+
+
+def pae_oracle_mask(entry, gt_ratio, adaptive=False, only_mistake=False, mask=None):
+    """s2t_transformer.py:1904-1935 / s2t_sate.py:774-797: which frames are fed the ground-truth label.
+    entry = (oracle (B,T), best_aligns_pad (B,T), mistake_flag (B,T), mistake_ratio (B,)).  ``mask`` overrides the
+    ``torch.rand(...) < prob`` draw (fixtures record the reference's draw).  -> (oracle, mask, force_emit)"""
+    oracle, aligns, mistake_flag, mistake_ratio = entry
+    if mask is None:
+        prob = gt_ratio * mistake_ratio.unsqueeze(-1) if adaptive else gt_ratio
+        mask = torch.rand(oracle.size()) < prob
+    mask = mask.bool().clone()
+    if only_mistake:
+        mask = mask & mistake_flag
+    return oracle, mask, aligns.masked_fill(~mask, -1)
+
+
+def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None,
+                    ctc_alignment_oracle=None, oracle_masks=None):
+    """models/speech_to_text/s2t_transformer.py:1714-2154 (no mixup; intermediate CTC heads and prediction-aware encoding
+    ``ctc_pae inter_league`` included).
 
     Returns the reference's dict (time-major tensors in lists)."""
     d = cfg["encoder_embed_dim"]
@@ -291,6 +321,7 @@ def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="enc
     any_valid = not bool(pad_mask.all())
     inter_layers = inter_ctc_layer_list(cfg)
     inter_logits = []
+    ctc_force_emit = ctc_orc = None
     for i in range(cfg["encoder_layers"]):
         if cfg.get("layer_padding_mask", False) and any_valid:
             x = x.masked_fill(pad_mask[:, :, None], 0.0)  # :1828-1836
@@ -302,13 +333,31 @@ def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="enc
             npre = prefix + ("layer_norm." if cfg.get("share_inter_ctc_norm", False) else "ctc_norm%d." % L)
             hpre = prefix + ("ctc." if cfg.get("share_inter_ctc", False) else "inter_ctc%d." % L)
             nx = layer_norm(x, W[npre + "weight"], W[npre + "bias"])
-            inter_logits.append(linear(nx, W[hpre + "ctc_projection.weight"], W[hpre + "ctc_projection.bias"]).transpose(0, 1))
+            logit = linear(nx, W[hpre + "ctc_projection.weight"], W[hpre + "ctc_projection.bias"])
+            inter_logits.append(logit.transpose(0, 1))
+            if cfg.get("ctc_pae", "none") == "inter_league":  # :1937-1944
+                ppre = prefix + ("pae." if cfg.get("share_inter_ctc", False) else "pae%d." % L)
+                orc = msk = None
+                gt = float(cfg.get("ctc_pae_ground_truth_ratio", 0) or 0)
+                if gt > 0 and ctc_alignment_oracle is not None and ctc_alignment_oracle.get("ctc") is not None:
+                    if ctc_force_emit is None:
+                        ctc_orc = pae_oracle_mask(ctc_alignment_oracle["ctc"], gt,
+                                                  cfg.get("xctc_pae_ground_truth_ratio_adaptive", False),
+                                                  cfg.get("xctc_pae_ground_truth_only_mistake", False),
+                                                  (oracle_masks or {}).get("ctc"))
+                        ctc_force_emit = ctc_orc[2]
+                    orc, msk = ctc_orc[0], ctc_orc[1]
+                x = pae_inter_league(x if cfg.get("pae_unnorm_input", False) else nx, logit,
+                                     W[ppre + "embed_adapter.weight"], cfg.get("pae_ctc_temperature", 1.0), orc, msk, False)
+            elif cfg.get("ctc_pae", "none") != "none":
+                raise NotImplementedError(cfg["ctc_pae"])
     x = layer_norm(x, W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"])
     out = {
         "encoder_out": [x.transpose(0, 1)],
         "encoder_padding_mask": [pad_mask],
         "ctc_logit": [],
         "inter_ctc_logits": inter_logits,
+        "ctc_force_emit": ctc_force_emit,
     }
     if prefix + "ctc.ctc_projection.weight" in W:
         logit = linear(x, W[prefix + "ctc.ctc_projection.weight"], W[prefix + "ctc.ctc_projection.bias"])
@@ -767,19 +816,34 @@ def pds_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix=
 # ----------------------------------------------------------------------------------------------
 # SATE stacked acoustic + textual encoder, a17
 # ----------------------------------------------------------------------------------------------
-def sate_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None):
+def _layer_list(spec, n_layers):
+    if spec is None or str(spec) in ("", "None", "none"):
+        return []
+    return [int(t) + n_layers if int(t) <= 0 else int(t) for t in str(spec).split(",")]
+
+
+def sate_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None,
+                         ctc_alignment_oracle=None, oracle_masks=None, drop_self_attn=None):
     """models/speech_to_text/s2t_sate.py:973-1075: acoustic encoder (a6) -> adapter `inter_league`
     (modules/speech_to_text/adapter.py:214-217,264-266,296-297: x + softmax(ctc_logit / tau) @ W_embed) ->
-    TextualEncoder.forward (:641-827): embed LN, scale, + sinusoidal positions, N x TransformerEncoderLayer
-    (modules/transformer_layer.py:164-237, pre-LN, fc1/fc2), final LayerNorm."""
-    ac = encoder_forward(src_tokens, src_lengths, W, cfg, training, prefix + "acoustic_encoder.", bn_stats)
+    TextualEncoder.forward (:641-827): [embed LN], scale, [+ sinusoidal positions unless text_no_pos_emb], N layers,
+    final LayerNorm, with the NAST extras of SURVEY.md §8f row 2:
+      * layers from ``cross_attn_start_layer`` on are TransformerS2EncoderLayer (modules/transformer_s2_layer.py:214-336,
+        ``serial``): self-attention block, then a second pre-LN attention block (``s2_attn_norm`` -> ``s2_attn`` with
+        keys/values = ``attn_norm`` of layer ``cross_attn_layer``'s output) and the FFN block; in training the
+        self-attention block is skipped with probability ``cross_attn_league_drop_net_prob`` (``drop_self_attn``: list of
+        bools, one per S2 layer, overrides the draw);
+      * XCTC head on the output (``xctc``), intermediate XCTC after ``inter_xctc_layers`` (``xctc_norm{L}`` -> shared
+        head) followed by prediction-aware encoding ``xctc_pae`` (inter_league, with the ground-truth mixing of
+        :774-797 when ``xctc_pae_ground_truth_ratio`` > 0 and an alignment oracle is passed)."""
+    ac = encoder_forward(src_tokens, src_lengths, W, cfg, training, prefix + "acoustic_encoder.", bn_stats,
+                         ctc_alignment_oracle, oracle_masks)
     x = ac["encoder_out"][0].transpose(0, 1)  # (B, T', d)
     mask = ac["encoder_padding_mask"][0]
     d = x.size(-1)
     if cfg.get("adapter", "none") == "inter_league":
-        logit = ac["ctc_logit"][0].transpose(0, 1)
-        dist = torch.softmax(logit / float(cfg.get("adapter_temperature", 1.0)), dim=-1)
-        x = x + dist @ W[prefix + "adapter.embed_adapter.weight"]
+        x = pae_inter_league(x, ac["ctc_logit"][0].transpose(0, 1), W[prefix + "adapter.embed_adapter.weight"],
+                             cfg.get("adapter_temperature", 1.0))
     elif cfg.get("adapter", "none") != "none":
         raise NotImplementedError(cfg["adapter"])
     p = prefix + "textual_encoder."
@@ -787,17 +851,137 @@ def sate_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix
         x = layer_norm(x, W[p + "embed_ln.weight"], W[p + "embed_ln.bias"])
     if not cfg.get("textual_encoder_no_scale_embedding", False):
         x = x * math.sqrt(d)
-    x = x + sinusoidal_positions(mask, d, padding_idx=1)
+    if not cfg.get("text_no_pos_emb", False):
+        x = x + sinusoidal_positions(mask, d, padding_idx=1)
     h = cfg["encoder_attention_heads"]
-    for i in range(int(cfg["text_encoder_layers"])):
+    n_layers = int(cfg["text_encoder_layers"])
+    use_xctc = float(cfg.get("xctc_weight", 0) or 0) > 0
+    inter_x = _layer_list(cfg.get("inter_xctc_layers"), n_layers) if float(cfg.get("inter_xctc_weight", 0) or 0) > 0 else []
+    cross = bool(cfg.get("xctc_cross_attn", False)) and cfg.get("cross_attn_start_layer") is not None
+    start, src_layer = int(cfg.get("cross_attn_start_layer", 0) or 0), int(cfg.get("cross_attn_layer", 0) or 0)
+    gt = float(cfg.get("xctc_pae_ground_truth_ratio", 0) or 0)
+    xh = p + "xctc.ctc_projection."
+    attn_x, xorc, x_force_emit, inter_xlogits, s2_i = None, None, None, [], 0
+    for i in range(n_layers):
         q = f"{p}layers.{i}."
+        s2 = attn_x if (cross and i >= start - 1) else None
         y = layer_norm(x, W[q + "self_attn_layer_norm.weight"], W[q + "self_attn_layer_norm.bias"])
-        x = x + mha(y, y, W, q + "self_attn.", h, mask)
+        sa = mha(y, y, W, q + "self_attn.", h, mask)
+        is_s2_layer = cross and i >= start - 1
+        skip = False
+        if is_s2_layer and training and cfg.get("cross_attn_league_drop_net", False):
+            if drop_self_attn is not None:
+                skip = bool(drop_self_attn[s2_i])
+            else:
+                skip = float(np.random.uniform(0, 1)) < float(cfg.get("cross_attn_league_drop_net_prob", 0))
+        if is_s2_layer:
+            s2_i += 1
+        if not skip:
+            x = x + sa
+        if s2 is not None:  # serial collaboration (:281-296)
+            y = layer_norm(x, W[q + "s2_attn_norm.weight"], W[q + "s2_attn_norm.bias"])
+            x = x + mha(y, s2, W, q + "s2_attn.", h, mask)
         y = layer_norm(x, W[q + "final_layer_norm.weight"], W[q + "final_layer_norm.bias"])
         x = x + ffn(y, W, q, cfg.get("activation_fn", "relu"), n1="fc1", n2="fc2")
+        L = i + 1
+        if cross and L == src_layer:
+            attn_x = layer_norm(x, W[p + "attn_norm.weight"], W[p + "attn_norm.bias"])
+        if L in inter_x:
+            npre = p + ("layer_norm." if cfg.get("share_inter_xctc_norm", False) else "xctc_norm%d." % L)
+            nx = layer_norm(x, W[npre + "weight"], W[npre + "bias"])
+            logit = linear(nx, W[xh + "weight"], W[xh + "bias"])
+            orc = msk = None
+            if gt > 0 and ctc_alignment_oracle is not None and ctc_alignment_oracle.get("xctc") is not None:
+                if xorc is None:
+                    xorc = pae_oracle_mask(ctc_alignment_oracle["xctc"], gt,
+                                           cfg.get("xctc_pae_ground_truth_ratio_adaptive", False),
+                                           cfg.get("xctc_pae_ground_truth_only_mistake", False),
+                                           (oracle_masks or {}).get("xctc"))
+                    x_force_emit = xorc[2]
+                orc, msk = xorc[0], xorc[1]
+            if cfg.get("xctc_pae", "none") == "inter_league":
+                x = pae_inter_league(x if cfg.get("pae_unnorm_input", False) else nx, logit,
+                                     W[p + "xctc_pae.embed_adapter.weight"], cfg.get("pae_ctc_temperature", 1.0), orc, msk,
+                                     cfg.get("pae_oracle_smooth", False))
+            elif cfg.get("xctc_pae", "none") != "none":
+                raise NotImplementedError(cfg["xctc_pae"])
+            inter_xlogits.append(logit.transpose(0, 1))
     x = layer_norm(x, W[p + "layer_norm.weight"], W[p + "layer_norm.bias"])
-    return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": [mask], "ctc_padding_mask": [mask],
-            "ctc_logit": ac["ctc_logit"]}
+    out = {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": [mask], "ctc_padding_mask": [mask],
+           "ctc_logit": ac["ctc_logit"], "inter_ctc_logits": ac.get("inter_ctc_logits", []), "xctc_logit": [],
+           "inter_xctc_logits": inter_xlogits, "ctc_force_emit": ac.get("ctc_force_emit"), "xctc_force_emit": x_force_emit}
+    if use_xctc:
+        out["xctc_logit"] = [linear(x, W[xh + "weight"], W[xh + "bias"]).transpose(0, 1)]
+    return out
+
+
+def ctc_align_oracle(logit_tbv, tokens, input_lengths, pad_idx=1, eos_idx=2, blank=0):
+    """criterions/ctc.py:286-312 (get_ctc_align): Viterbi CTC alignment of the reference text (torch_imputer
+    best_alignment), padded with state 0; oracle label per frame (blank on even states); mistake_flag = the model's
+    arg-max differs from the oracle label; mistake_ratio = mistakes / input length.  tokens (B,U) with pad/eos."""
+    lp = torch.log_softmax(logit_tbv.float(), dim=-1)
+    T, B, _ = lp.shape
+    keep = (tokens != pad_idx) & (tokens != eos_idx)
+    tlens = keep.sum(-1)
+    aligns = best_alignment(lp, [tokens[b][: int(tlens[b])].tolist() for b in range(B)], input_lengths, blank)
+    pad = torch.tensor([list(a) + [0] * (T - len(a)) for a in aligns], dtype=tokens.dtype)
+    pos = torch.div(pad, 2, rounding_mode="floor").clip(max=tokens.shape[1] - 1)
+    oracle = tokens.gather(-1, pos)
+    oracle = oracle.masked_fill(pad % 2 == 0, blank)
+    mistake_flag = lp.argmax(-1).transpose(0, 1) != oracle
+    mistake_ratio = mistake_flag.sum(-1) / input_lengths
+    return oracle, pad, mistake_flag, mistake_ratio
+
+
+def ctc_criterion_loss(W, cfg, src_tokens, src_lengths, target, transcript=None, training=True, weights=None,
+                       bn_stats=None, oracle_masks=None, drop_self_attn=None, drop_self_attn_first=None, pad_idx=1,
+                       eos_idx=2, blank=0):
+    """criterions/ctc.py:258-281 (forward) + :542-1016 (compute_ctc_loss) for an encoder-only model (s2t_ctc):
+    loss = ctc_weight * CTC(ctc_logit, transcript) + inter_ctc_weight * mean_i CTC(inter_ctc_logit_i, transcript)
+         + xctc_weight * CTC(xctc_logit, target) + inter_xctc_weight * mean_i CTC(inter_xctc_logit_i, target)
+    (summed over utterances, zero_infinity; transcript defaults to target).  In training with a PAE ground-truth ratio,
+    a first no-grad pass produces the alignment oracle (:283-433).  ``weights``: dict with ctc/inter_ctc/xctc/inter_xctc.
+    Returns (loss, log, encoder_out)."""
+    w = {"ctc": float(cfg.get("ctc_weight", 0) or 0), "inter_ctc": float(cfg.get("inter_ctc_weight", 0) or 0),
+         "xctc": float(cfg.get("xctc_weight", 0) or 0), "inter_xctc": float(cfg.get("inter_xctc_weight", 0) or 0)}
+    w.update(weights or {})
+    fwd = ENCODERS[encoder_kind(cfg)]
+    transcript = target if transcript is None else transcript
+    gt = float(cfg.get("ctc_pae_ground_truth_ratio", 0) or 0) + float(cfg.get("xctc_pae_ground_truth_ratio", 0) or 0)
+    kw = {}
+    if encoder_kind(cfg) == "sate":
+        kw["drop_self_attn"] = drop_self_attn
+    if training and gt != 0:
+        with torch.no_grad():
+            kw1 = dict(kw, drop_self_attn=drop_self_attn_first) if "drop_self_attn" in kw else kw
+            first = fwd(src_tokens, src_lengths, W, cfg, training=training, bn_stats=None, **kw1)
+        in_lens = (~first["encoder_padding_mask"][0]).sum(-1)
+        orc = {}
+        if len(first["ctc_logit"]) > 0:
+            orc["ctc"] = ctc_align_oracle(first["ctc_logit"][0], transcript, in_lens, pad_idx, eos_idx, blank)
+        if len(first.get("xctc_logit", [])) > 0:
+            orc["xctc"] = ctc_align_oracle(first["xctc_logit"][0], target, in_lens, pad_idx, eos_idx, blank)
+        kw.update(ctc_alignment_oracle=orc, oracle_masks=oracle_masks)
+    enc = fwd(src_tokens, src_lengths, W, cfg, training=training, bn_stats=bn_stats, **kw)
+    in_lens = (~enc["encoder_padding_mask"][0]).sum(-1)
+
+    def one(logit_tbv, toks):
+        return ctc_nll(torch.log_softmax(logit_tbv.float(), -1), ctc_targets(toks, pad_idx, eos_idx), in_lens, blank).sum()
+
+    log, loss = {}, 0.0
+    if w["inter_ctc"] > 0 and len(enc.get("inter_ctc_logits", [])) > 0:
+        log["inter_ctc_loss"] = sum(one(l, transcript) for l in enc["inter_ctc_logits"]) / len(enc["inter_ctc_logits"])
+        loss = loss + w["inter_ctc"] * log["inter_ctc_loss"]
+    if w["ctc"] > 0 and len(enc["ctc_logit"]) > 0:
+        log["ctc_loss"] = one(enc["ctc_logit"][0], transcript)
+        loss = loss + w["ctc"] * log["ctc_loss"]
+    if w["inter_xctc"] > 0 and len(enc.get("inter_xctc_logits", [])) > 0:
+        log["inter_xctc_loss"] = sum(one(l, target) for l in enc["inter_xctc_logits"]) / len(enc["inter_xctc_logits"])
+        loss = loss + w["inter_xctc"] * log["inter_xctc_loss"]
+    if w["xctc"] > 0 and len(enc.get("xctc_logit", [])) > 0:
+        log["xctc_loss"] = one(enc["xctc_logit"][0], target)
+        loss = loss + w["xctc"] * log["xctc_loss"]
+    return loss, log, enc
 
 
 ENCODERS = {"s2t_transformer": encoder_forward, "pds": pds_encoder_forward, "sate": sate_encoder_forward}
@@ -805,9 +989,10 @@ ENCODERS = {"s2t_transformer": encoder_forward, "pds": pds_encoder_forward, "sat
 
 def encoder_kind(cfg):
     arch = str(cfg.get("arch", ""))
-    if arch.startswith("pdss2t"):
+    etype = str(cfg.get("encoder_type", "")) if arch.startswith("s2t_ctc") else ""  # s2t_ctc.py:60-68
+    if arch.startswith("pdss2t") or etype == "pds":
         return "pds"
-    if arch.startswith("s2t_sate"):
+    if arch.startswith("s2t_sate") or etype == "sate":
         return "sate"
     return "s2t_transformer"
 

@@ -222,3 +222,65 @@ def test_joint_ctc_beam_search_runs_and_differs(golden_dir):
     joint = O.beam_search(src, lens, W, cfg, beam=beam, max_len_b=mlb, ctc_weight=0.3)
     assert len(joint[0]) >= 1 and all(h["tokens"][-1] == 2 for h in joint[0])
     assert [h["score"] for h in joint[0]] != [h["score"] for h in plain[0]]
+
+
+# ---- the NAST stack (s2t_ctc --encoder-type sate, XCTC, PAE, cross-layer attention) ---------------
+def _nast_inputs(z):
+    return (torch.from_numpy(z["in::src_tokens"]), torch.from_numpy(z["in::src_lengths"]),
+            torch.from_numpy(z["in::target"]), torch.from_numpy(z["in::transcript"]))
+
+
+def test_nast_eval_forward_and_greedy(golden_dir):
+    z = _load(golden_dir, "nast_small")
+    cfg, W = O.cfg_from_golden(z), O.weights_from_golden(z)
+    assert O.encoder_kind(cfg) == "sate"
+    src, lens, _, _ = _nast_inputs(z)
+    with torch.no_grad():
+        enc = O.sate_encoder_forward(src, lens, W, cfg, training=False)
+    _close(enc["encoder_out"][0], z["out::encoder_out"], rtol=1e-4, atol=2e-5)
+    _close(enc["ctc_logit"][0], z["out::ctc_logit"], rtol=1e-4, atol=5e-5)
+    _close(enc["xctc_logit"][0], z["out::xctc_logit"], rtol=1e-4, atol=5e-5)
+    for key in ("inter_ctc_logit", "inter_xctc_logit"):
+        i = 0
+        while "out::%s_%d" % (key, i) in z.files:
+            _close(enc[key + "s"][i], z["out::%s_%d" % (key, i)], rtol=1e-4, atol=5e-5)
+            i += 1
+        assert i == 2
+    hyps, scores = O.ctc_greedy(enc["xctc_logit"][0], enc["encoder_padding_mask"][0])  # s2t_ctc.py:262-268: xctc first
+    assert [len(h) for h in hyps] == z["out::hyp_lengths"].tolist()
+    assert torch.cat(hyps).tolist() == z["out::hyp_tokens"].tolist()
+    _close(scores, z["out::hyp_scores"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["nast_small", "nast_pae_oracle"])
+def test_nast_ctc_criterion_loss_and_grads(golden_dir, name):
+    z = _load(golden_dir, name)
+    cfg, W = O.cfg_from_golden(z), O.weights_from_golden(z, requires_grad=True)
+    src, lens, target, transcript = _nast_inputs(z)
+    n_s2 = int(z["aux::n_s2_layers"])
+    drops = z["aux::drop_self_attn_all"].tolist()
+    masks = {"xctc": torch.from_numpy(z["aux::xctc_rand_mask"])} if "aux::xctc_rand_mask" in z.files else None
+    loss, log, enc = O.ctc_criterion_loss(W, cfg, src, lens, target, transcript, training=True, oracle_masks=masks,
+                                          drop_self_attn=drops[-n_s2:], drop_self_attn_first=drops[:n_s2])
+    for k in ("ctc_loss", "inter_ctc_loss", "xctc_loss", "inter_xctc_loss"):
+        assert abs(float(log[k]) - float(z["out::" + k])) <= 2e-4 * abs(float(z["out::" + k])), k
+    assert abs(float(loss) - float(z["out::loss"])) <= 2e-4 * abs(float(z["out::loss"]))
+    if name == "nast_pae_oracle":
+        assert any(drops) and enc["xctc_force_emit"] is not None and bool((enc["xctc_force_emit"] >= 0).any())
+    loss.backward()
+    tied = [k for k in W if k.endswith(("embed_tokens.weight", "ctc.ctc_projection.weight", "xctc.ctc_projection.weight"))]
+    n = 0
+    for k in z.files:
+        if not k.startswith("grad::"):
+            continue
+        key = k[6:]
+        g = sum(W[t].grad for t in tied if W[t].grad is not None) if key in tied else W[key].grad
+        ref = z[k]
+        # key-projection biases have a mathematically zero gradient (softmax shift invariance): rounding noise on both
+        # sides, proportional to the loss scale (~2000 here)
+        floor = 2e-2 if key.endswith(("linear_k.bias", "k_proj.bias")) else 1e-3
+        scale = max(np.abs(ref).max(), floor)
+        assert g is not None, key
+        assert np.abs(g.numpy() - ref).max() / scale < 2e-3, key
+        n += 1
+    assert n > 60
