@@ -77,3 +77,160 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(nn.Module):
     @staticmethod
     def logging_outputs_can_be_summed():
         return True
+
+
+@register_criterion("ctc")
+class CtcCriterion(nn.Module):
+    """criterions/ctc.py:156-1101 for encoder-only models (``s2t_ctc``): ``forward`` :258-281,
+    ``get_ground_truth_alignment`` :283-433, ``compute_ctc_loss`` :542-1016.
+
+        loss = ctc_weight * CTC(ctc_logit, transcript) + inter_ctc_weight * mean_i CTC(inter_ctc_logits[i], transcript)
+             + xctc_weight * CTC(xctc_logit, target)   + inter_xctc_weight * mean_i CTC(inter_xctc_logits[i], target)
+
+    every CTC summed over the batch with zero_infinity, fp32 log-softmax inside the loss kernel.  ``transcript`` =
+    ``sample["transcript"]["tokens"]`` when present, else the target.  Logit entries may be the reference's lists
+    ``[logit, padding_mask or None, force_emit]``; with ``ctc_masked_loss`` a force-emit entry switches the loss to the
+    imputer loss (torch_imputer).  In training, when the encoder has a PAE ground-truth ratio, a first no-grad pass
+    yields the alignment oracle that the second pass consumes (``ctc_alignment_oracle=``).
+    Not built: AXCTC, self-distillation, entropy and mixup-consistency terms, the validation-time WER/CER counters."""
+
+    def __init__(self, cfg=None, task=None, ctc_weight=1.0, save_dir=None, **over):
+        super().__init__()
+        d = task.target_dictionary
+        self.pad_idx, self.eos_idx, self.blank_idx = d.pad(), d.eos(), 0
+
+        def g(name, default=0.0):
+            return over[name] if name in over else (getattr(cfg, name, default) if cfg is not None else default)
+
+        self.sentence_avg = bool(g("sentence_avg", False))
+        self.ctc_weight = float(ctc_weight)
+        self.inter_ctc_weight = float(g("inter_ctc_weight"))
+        self.xctc_weight = float(g("xctc_weight"))
+        self.inter_xctc_weight = float(g("inter_xctc_weight"))
+        self.ctc_masked_loss = bool(g("ctc_masked_loss", False))
+        for name in ("axctc_weight", "inter_axctc_weight", "ctc_self_distill_weight", "xctc_self_distill_weight",
+                     "ctc_entropy_weight", "ctc_mixup_consistent_weight", "inter_ctc_mixup_consistent_weight"):
+            if float(g(name) or 0) != 0:
+                raise NotImplementedError("CtcCriterion --%s on the HIP path" % name.replace("_", "-"))
+        if g("inter_ctc_mlo", None) not in (None, ""):
+            raise NotImplementedError("inter_ctc_mlo")
+        self.use_ctc = self.ctc_weight + self.inter_ctc_weight > 0
+        self.use_xctc = self.xctc_weight + self.inter_xctc_weight > 0
+
+    # ---- criterions/ctc.py:283-433 ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_ground_truth_alignment(self, model, sample, **enc_kwargs):
+        from .torch_imputer import best_alignment
+
+        ni = sample["net_input"]
+        enc = model.encoder(ni["src_tokens"], ni["src_lengths"], **enc_kwargs)
+        mask = enc["ctc_padding_mask"][0] if "ctc_padding_mask" in enc else enc["encoder_padding_mask"][0]
+        in_lens = (~mask).long().sum(-1)
+
+        def pick(top, inter):
+            lg = enc.get(top, [])
+            lg = lg[0] if len(lg) else (enc.get(inter, [None])[-1] if len(enc.get(inter, [])) else None)
+            return lg[0] if isinstance(lg, (list, tuple)) else lg
+
+        def align(logit_tbv, tokens):
+            lp = torch.log_softmax(logit_tbv.float(), dim=-1)  # (T, B, V)
+            keep = (tokens != self.pad_idx) & (tokens != self.eos_idx)
+            best = best_alignment(lp, tokens, in_lens, keep.sum(-1), self.blank_idx, zero_infinity=True)
+            T = lp.size(0)
+            pad = torch.tensor([a + [0] * (T - len(a)) for a in best], device=lp.device, dtype=tokens.dtype)
+            pos = torch.div(pad, 2, rounding_mode="floor").clip(max=tokens.shape[1] - 1)
+            oracle = tokens.gather(-1, pos)
+            oracle.masked_fill_(pad % 2 == 0, self.blank_idx)
+            mistake_flag = lp.argmax(dim=-1).transpose(0, 1) != oracle
+            return oracle, pad, mistake_flag, mistake_flag.sum(-1) / in_lens
+
+        out = {}
+        ctc_logit = pick("ctc_logit", "inter_ctc_logits")
+        if ctc_logit is not None:
+            out["ctc"] = align(ctc_logit, sample["transcript"]["tokens"] if "transcript" in sample else sample["target"])
+        xctc_logit = pick("xctc_logit", "inter_xctc_logits")
+        if xctc_logit is not None:
+            out["xctc"] = align(xctc_logit, self.get_ctc_target_text(sample))
+        return out
+
+    def get_ctc_target_text(self, sample):
+        return sample["ctc_target"]["tokens"] if "ctc_target" in sample else sample["target"]
+
+    # ---- one CTC term ----------------------------------------------------------------------------------------------
+    def _ctc(self, entry, tmat, tl, in_lens):
+        force_emit = None
+        if isinstance(entry, (list, tuple)):
+            logit = entry[0]
+            if len(entry) > 1 and entry[1] is not None:
+                in_lens = (~entry[1]).sum(-1).to(torch.int32)
+            if len(entry) >= 3:
+                force_emit = entry[2]
+        else:
+            logit = entry
+        Tn, B, V = logit.shape
+        if force_emit is not None and self.ctc_masked_loss:
+            from .torch_imputer import imputer_loss
+            lp = torch.log_softmax(logit.float(), dim=-1)
+            return imputer_loss(lp, tmat, force_emit, in_lens, tl, blank=self.blank_idx, reduction="none",
+                                zero_infinity=True).sum()
+        l2d = logit.transpose(0, 1).reshape(B * Tn, V)  # a view: the encoders' buffers are batch-major
+        return Fn.ctc_loss(l2d, B, Tn, tmat, tl, in_lens, self.blank_idx)
+
+    def forward(self, model, sample, reduce=True, sync_logging=True, **enc_kwargs):
+        ni = sample["net_input"]
+        enc_kw = dict(enc_kwargs)
+        first_kw = enc_kw.pop("first_pass_kwargs", {})
+        if self.training and getattr(model.encoder, "pae_ground_truth_ratio", 0) != 0:
+            enc_kw["ctc_alignment_oracle"] = self.get_ground_truth_alignment(model, sample, **first_kw)
+        enc = model.encoder(ni["src_tokens"], ni["src_lengths"], **enc_kw)
+        ntokens = sample["ntokens"]
+        sample_size = sample["target"].size(0) if self.sentence_avg else ntokens
+        log = {"ntokens": ntokens, "nsentences": sample["target"].size(0), "sample_size": sample_size}
+        loss = self.compute_ctc_loss(model, sample, enc, log)
+        log["loss"] = loss.detach()
+        if sync_logging:
+            log = {k: (v.item() if torch.is_tensor(v) else v) for k, v in log.items()}
+        return loss, sample_size, log
+
+    def compute_ctc_loss(self, model, sample, enc, log):
+        transcript = sample["transcript"]["tokens"] if "transcript" in sample else sample["target"]
+        mask = enc["ctc_padding_mask"][0] if "ctc_padding_mask" in enc else enc["encoder_padding_mask"][0]
+        in_lens = (~mask).sum(-1).to(torch.int32)
+        log["nfeatures"] = in_lens.sum()
+        total = None
+
+        def add(name, weight, value):
+            nonlocal total
+            log[name] = value.detach()
+            total = weight * value if total is None else total + weight * value
+
+        def mean_of(entries, tmat, tl):
+            acc = None
+            for e in entries:
+                v = self._ctc(e, tmat, tl, in_lens)
+                acc = v if acc is None else acc + v
+            return acc / len(entries)
+
+        if self.use_ctc:
+            tmat, tl = ctc_targets(transcript, self.pad_idx, self.eos_idx)
+            inter = enc.get("inter_ctc_logits", [])
+            if self.inter_ctc_weight > 0 and len(inter) > 0:
+                add("inter_ctc_loss", self.inter_ctc_weight, mean_of(inter, tmat, tl))
+            if self.ctc_weight > 0 and len(enc.get("ctc_logit", [])) > 0:
+                add("ctc_loss", self.ctc_weight, self._ctc(enc["ctc_logit"][0], tmat, tl, in_lens))
+        if self.use_xctc:
+            tmat, tl = ctc_targets(self.get_ctc_target_text(sample), self.pad_idx, self.eos_idx)
+            inter = enc.get("inter_xctc_logits", [])
+            if self.inter_xctc_weight > 0 and len(inter) > 0:
+                add("inter_xctc_loss", self.inter_xctc_weight, mean_of(inter, tmat, tl))
+            if self.xctc_weight > 0:
+                assert len(enc.get("xctc_logit", [])) > 0
+                add("xctc_loss", self.xctc_weight, self._ctc(enc["xctc_logit"][0], tmat, tl, in_lens))
+        if total is None:
+            raise RuntimeError("CtcCriterion: no CTC term is active for this model output")
+        log["all_ctc_loss"] = total.detach()
+        return total
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return True

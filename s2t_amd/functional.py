@@ -1155,10 +1155,12 @@ def conv1d(x, w, b, B, T, stride):
 # SATE adapter (inter_league)
 # ------------------------------------------------------------------------------------------------
 class AdapterFn(torch.autograd.Function):
-    """out = x + softmax(ctc_logit / tau) @ W_embed   (modules/speech_to_text/adapter.py:214-217,264-266,296-297)."""
+    """out = x + dist @ W_embed, dist = softmax(ctc_logit / tau)   (modules/speech_to_text/adapter.py:214-217,264-266,
+    296-297); rows flagged by ``rows`` take the (optionally smoothed) one-hot distribution of ``oracle`` instead
+    (adapter.py:245-262, the PAE ground-truth curriculum) and pass no gradient to the logits."""
 
     @staticmethod
-    def forward(ctx, x, logit, w, tau, train):
+    def forward(ctx, x, logit, w, tau, train, oracle, rows, smooth):
         M, d = x.shape
         V = w.shape[0]
         assert logit.stride(1) == 1
@@ -1167,11 +1169,18 @@ class AdapterFn(torch.autograd.Function):
         ldp = _pad8(V)
         P = torch.empty(M, ldp, dtype=dt, device=dev)
         K.row_softmax_fwd(lg, lg.stride(0), P, ldp, M, V, 1.0 / tau)
+        if oracle is not None:
+            on, off = (0.9 + 0.1 / V, 0.1 / V) if smooth else (1.0, 0.0)
+            Pv = P[:, :V]
+            Pv.masked_fill_(rows[:, None], off)
+            idx = oracle.view(-1, 1)
+            Pv.scatter_(1, idx, torch.where(rows[:, None], torch.full_like(Pv[:, :1], on), Pv.gather(1, idx)))
         y = torch.empty(M, d, dtype=dt, device=dev)
         K.gemm(P, cw(w), y, M=M, N=d, K=V, lda=ldp, ldb=d, ldc=d, b_kmajor=True, residual=x, ldr=d)
         if train:
             ctx.save_for_backward(P)
         ctx.w, ctx.tau, ctx.V, ctx.ldt = w, tau, V, logit.dtype
+        ctx.rows = rows if oracle is not None else None
         return y
 
     @staticmethod
@@ -1186,11 +1195,14 @@ class AdapterFn(torch.autograd.Function):
         K.gemm(dy, cw(w), dP, M=M, N=V, K=d, lda=d, ldb=d, ldc=ldp)
         dlogit = torch.empty(M, ldp, dtype=dt, device=dev)
         K.row_softmax_bwd(P, ldp, dP, ldp, dlogit, ldp, M, V, 1.0 / ctx.tau)
+        if ctx.rows is not None:
+            dlogit.masked_fill_(ctx.rows[:, None], 0.0)
         _wgrad(P, dy, w.grad, V, d, M, ldp, d)
         _ready(w)
         dl = dlogit[:, :V]
-        return dy, (dl if ctx.ldt == dt else dl.to(ctx.ldt)), None, None, None
+        return dy, (dl if ctx.ldt == dt else dl.to(ctx.ldt)), None, None, None, None, None, None
 
 
-def adapter_inter_league(x, logit, w, tau=1.0):
-    return AdapterFn.apply(x, logit, w, tau, torch.is_grad_enabled())
+def adapter_inter_league(x, logit, w, tau=1.0, oracle=None, oracle_rows=None, oracle_smooth=False):
+    """x [M, d], logit [M, V]; oracle int64 [M] labels, oracle_rows bool [M] (both or neither)."""
+    return AdapterFn.apply(x, logit, w, tau, torch.is_grad_enabled(), oracle, oracle_rows, bool(oracle_smooth))

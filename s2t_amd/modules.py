@@ -345,6 +345,55 @@ class CTC(nn.Module):
         return self.ctc_projection(x2d, out_dtype=out_dtype)
 
 
+class Adapter(nn.Module):
+    """modules/speech_to_text/adapter.py:89-349 — `inter_league`: x + dist @ embed_adapter.weight with
+    dist = softmax(ctc_logit / tau); with ``gt_ratio`` > 0 and an oracle, the flagged frames take the one-hot
+    (``oracle_smooth``: 0.9 / 0.1-spread) distribution of the ground-truth label (:245-262)."""
+
+    def __init__(self, dim, adapter_type, dictionary_size, embed_tokens=None, strategy=None):
+        super().__init__()
+        if adapter_type not in ("inter_league", "none"):
+            raise NotImplementedError("adapter %s (HIP path: inter_league, none)" % adapter_type)
+        strategy = strategy or {}
+        for k in ("embed_norm", "out_norm", "gumbel", "distribution_hard"):
+            if strategy.get(k):
+                raise NotImplementedError("adapter strategy %s" % k)
+        self.adapter_type = adapter_type
+        if adapter_type == "inter_league":
+            if embed_tokens is not None:
+                self.embed_adapter = embed_tokens
+            else:  # nn.Linear(dim, V, bias=False) in the reference ("reverse for initialization"), N(0, dim^-0.5)
+                self.embed_adapter = Linear(dim, dictionary_size, bias=False)
+                nn.init.normal_(self.embed_adapter.weight, mean=0, std=dim ** -0.5)
+        self.temperature = float(strategy.get("ctc_temperature", strategy.get("distribution_temperature", 1.0)))
+        self.ground_truth_ratio = float(strategy.get("gt_ratio", 0) or 0)
+        self.oracle_smooth = bool(strategy.get("oracle_smooth", False))
+
+    def forward(self, x2d, logit2d, oracle=None, oracle_mask=None):
+        """x2d [B*T, d], logit2d [B*T, V]; oracle / oracle_mask (B, T) as produced by ``pae_oracle_mask``."""
+        if self.adapter_type == "none":
+            return x2d
+        if self.ground_truth_ratio > 0 and oracle is not None:
+            return Fn.adapter_inter_league(x2d, logit2d, self.embed_adapter.weight, self.temperature,
+                                           oracle.reshape(-1), oracle_mask.reshape(-1), self.oracle_smooth)
+        return Fn.adapter_inter_league(x2d, logit2d, self.embed_adapter.weight, self.temperature)
+
+
+def pae_oracle_mask(entry, gt_ratio, adaptive=False, only_mistake=False, mask=None):
+    """s2t_transformer.py:1904-1935 / s2t_sate.py:774-797: frames that are fed the ground-truth label.
+    entry = (oracle, best_aligns_pad, mistake_flag, mistake_ratio) from CtcCriterion.get_ground_truth_alignment;
+    ``mask`` (B, T) bool replaces the ``torch.rand(...) < prob`` draw (tests replay the reference's draw).
+    -> (oracle, mask, force_emit)"""
+    oracle, aligns, mistake_flag, mistake_ratio = entry
+    if mask is None:
+        prob = gt_ratio * mistake_ratio.unsqueeze(-1) if adaptive else gt_ratio
+        mask = torch.rand(oracle.size(), device=oracle.device) < prob
+    mask = mask.to(device=oracle.device, dtype=torch.bool).clone()
+    if only_mistake:
+        mask &= mistake_flag
+    return oracle, mask, aligns.masked_fill(~mask, -1)
+
+
 class TransformerDecoderLayer(nn.Module):
     """modules/transformer_layer.py:240-546 (pre-LN) — keys self_attn, encoder_attn, *_layer_norm, fc1, fc2."""
 

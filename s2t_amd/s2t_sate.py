@@ -3,38 +3,24 @@
 Reference: fairseq/models/speech_to_text/s2t_sate.py (S2TSATEModel :37-330, TextualEncoder :333-835, S2TSATEEncoder
 :837-1125, architectures :1128-1387), fairseq/modules/speech_to_text/adapter.py:17-349 (`inter_league`),
 fairseq/modules/transformer_layer.py:24-237 (TransformerEncoderLayer).
-Built: the recipe configuration of egs/mustc/st/conf/sate.yaml (`acoustic-encoder transformer`, `adapter inter_league`,
-selfattn textual encoder with positions, no XCTC / cross-layer attention / history); other options raise.
+Built: the recipe configurations of egs/mustc/st/conf/sate.yaml (`acoustic-encoder transformer`, `adapter inter_league`,
+selfattn textual encoder) and of egs/mustc/st/conf/reproduction_nast.yaml (XCTC / intermediate XCTC
+heads, prediction-aware encoding with the ground-truth curriculum, cross-layer attention with TransformerS2EncoderLayer,
+modules/transformer_s2_layer.py:214-336); DLCL history, AXCTC and the remaining options raise.
 """
+import copy
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from .modules import TABLES, LayerNorm, Linear, MultiheadAttention
+from .modules import TABLES, Adapter, CTC, LayerNorm, Linear, MultiheadAttention, pae_oracle_mask
 from .registry import register_model, register_model_architecture
 from .s2t_transformer import (AddPositions, Embedding, S2TTransformerEncoder, S2TTransformerModel,
                               TransformerDecoderScriptable, _d, _SinPosHolder, _unsupported,
                               base_architecture as _s2t_base)
-
-
-class Adapter(nn.Module):
-    """modules/speech_to_text/adapter.py — `inter_league`: x + softmax(ctc_logit / tau) @ embed_adapter.weight."""
-
-    def __init__(self, dim, adapter_type, dictionary_size, embed_tokens=None, strategy=None):
-        super().__init__()
-        if adapter_type not in ("inter_league", "none"):
-            raise NotImplementedError("adapter %s (HIP path: inter_league, none)" % adapter_type)
-        self.adapter_type = adapter_type
-        if adapter_type == "inter_league":
-            self.embed_adapter = Embedding(dictionary_size, dim, padding_idx=1) if embed_tokens is None else embed_tokens
-        self.temperature = float((strategy or {}).get("distribution_temperature", 1.0))
-
-    def forward(self, x2d, logit2d):
-        if self.adapter_type == "none":
-            return x2d
-        return Fn.adapter_inter_league(x2d, logit2d, self.embed_adapter.weight, self.temperature)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -64,38 +50,186 @@ class TransformerEncoderLayer(nn.Module):
                       self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
 
 
-class TextualEncoder(nn.Module):
-    """s2t_sate.py:333-835 — embed LN, scale, + sinusoidal positions, N layers, final LN."""
+class TransformerS2EncoderLayer(TransformerEncoderLayer):
+    """modules/transformer_s2_layer.py:24-336, ``serial`` collaboration: the self-attention block, then a second pre-LN
+    attention block whose keys/values are another layer's (normalised) output — ``s2_attn_norm`` -> ``s2_attn`` ->
+    dropout -> residual — then the FFN block.  With ``league_drop_net`` the self-attention block is skipped in training
+    with probability ``league_drop_net_prob`` (host-side ``numpy.random.uniform`` draw, as in the reference :277-279).
+    ``s2_norm`` exists for checkpoint compatibility (the textual encoder never asks for it: ``s2_need_norm=False``)."""
 
-    def __init__(self, args, dictionary, embed_tokens=None):
+    def __init__(self, args):
+        super().__init__(args)
+        d = args.encoder_embed_dim
+        if getattr(args, "encoder_collaboration_mode", "serial") != "serial":
+            raise NotImplementedError("encoder collaboration mode %s" % args.encoder_collaboration_mode)
+        _unsupported(args, encoder_league_out_norm=False, encoder_league_gated=False, squeeze_excitation=False)
+        if getattr(args, "encoder_use_s2_attn_norm", True):
+            self.s2_norm = LayerNorm(d)
+        self.s2_attn_norm = LayerNorm(d)
+        self.s2_attn = MultiheadAttention(d, args.encoder_attention_heads, dropout=getattr(args, "attention_dropout", 0.0),
+                                          self_attention=False)
+        self.s2_attn.out_dropout = self.dropout_p
+        self.league_drop_net = bool(getattr(args, "encoder_league_drop_net", False))
+        self.league_drop_net_prob = float(getattr(args, "encoder_league_drop_net_prob", 0.0) or 0.0)
+
+    def forward(self, x, B, T, lens, s2=None, skip_self_attn=None):
+        skip = False
+        if self.training and self.league_drop_net:
+            draw = float(np.random.uniform(0, 1)) < self.league_drop_net_prob  # always drawn, like the reference
+            skip = draw if skip_self_attn is None else bool(skip_self_attn)
+        if not skip:
+            y, x = self.self_attn_layer_norm(x, fork=True)
+            x = self.self_attn(y, None, x, B, T, T, lens)
+        if s2 is not None:
+            y, x = self.s2_attn_norm(x, fork=True)
+            x = self.s2_attn(y, s2, x, B, T, T, lens)
+        y, x = self.final_layer_norm(x, fork=True)
+        return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                      self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
+
+
+def _layer_list(spec, n_layers):
+    if spec is None or str(spec) in ("", "None", "none"):
+        return []
+    out = []
+    for t in str(spec).split(","):
+        L = int(t)
+        assert L <= n_layers, (L, n_layers)
+        out.append(L + n_layers if L <= 0 else L)
+    return out
+
+
+class TextualEncoder(nn.Module):
+    """s2t_sate.py:333-835 — [embed LN], scale, [+ sinusoidal positions], N layers, final LN, plus the NAST extras
+    (SURVEY.md §8f row 2): XCTC head on the output, intermediate XCTC heads (``xctc_norm{L}`` -> shared ``xctc``) with
+    prediction-aware encoding ``xctc_pae`` and its ground-truth curriculum, cross-layer attention (layers from
+    ``cross_attn_start_layer`` on are TransformerS2EncoderLayer attending to ``attn_norm`` of layer
+    ``cross_attn_layer``'s output)."""
+
+    def __init__(self, args, dictionary, embed_tokens=None, target_dictionary=None):
         super().__init__()
-        _unsupported(args, text_no_pos_emb=False, text_use_s2t_layer=False, xctc_weight=0, inter_xctc_layers=None,
-                     axctc_weight=0)
+        _unsupported(args, text_use_s2t_layer=False, axctc_weight=0, inter_axctc_layers=None, inter_ctc_drop_prob=0,
+                     xctc_pae_ground_truth_ratio_decay=None, share_pae_and_xctc=False, cross_attn_ctc_logit=False,
+                     xctc_layer=0)
         if getattr(args, "text_attention_type", "selfattn") != "selfattn":
             raise NotImplementedError("text attention type")
         d = args.encoder_embed_dim
+        n = args.text_encoder_layers
         self.embed_dim = d
         self.register_buffer("version", torch.tensor([3.0]))
         self.embed_tokens = embed_tokens if embed_tokens is not None else Embedding(len(dictionary), d, 1)
         self.embed_scale = 1.0 if getattr(args, "textual_encoder_no_scale_embedding", False) else math.sqrt(d)
         self.embed_ln = LayerNorm(d) if getattr(args, "textual_encoder_embed_norm", False) else None
-        self.embed_positions = _SinPosHolder()
-        self.layers = nn.ModuleList([TransformerEncoderLayer(args) for _ in range(args.text_encoder_layers)])
-        self.layer_norm = LayerNorm(d) if args.encoder_normalize_before else None
+        self.text_no_pos_emb = bool(getattr(args, "text_no_pos_emb", False))
+        if not self.text_no_pos_emb:
+            self.embed_positions = _SinPosHolder()
+        self.layer_norm = LayerNorm(d) if (args.encoder_normalize_before and n > 0) else None
         self.max_pos = getattr(args, "max_source_positions", 6000)
         self.dropout_p = float(args.dropout or 0.0)
+        tgt = target_dictionary if target_dictionary is not None else dictionary
+        vocab = self.embed_tokens.weight.shape[0] if embed_tokens is not None else len(tgt)
 
-    def forward(self, x, B, T, lens32):
+        def xctc_head():
+            head = CTC(d, dictionary_size=vocab, dropout=args.dropout)
+            if embed_tokens is not None and getattr(args, "share_xctc_and_embed", False) \
+                    and head.ctc_projection.weight.shape == embed_tokens.weight.shape:
+                head.ctc_projection.weight = embed_tokens.weight
+            return head
+
+        # XCTC (s2t_sate.py:387-415)
+        self.use_xctc = float(getattr(args, "xctc_weight", 0) or 0) > 0
+        if self.use_xctc:
+            self.xctc = xctc_head()
+        # intermediate XCTC + PAE (:417-476)
+        self.gt_ratio = float(getattr(args, "xctc_pae_ground_truth_ratio", 0) or 0)
+        self.pae_unnorm_input = bool(getattr(args, "pae_unnorm_input", False))
+        self.pae_adaptive_gt = bool(getattr(args, "xctc_pae_ground_truth_ratio_adaptive", False))
+        self.pae_gt_only_mistake = bool(getattr(args, "xctc_pae_ground_truth_only_mistake", False))
+        self.inter_xctc_layers = []
+        if float(getattr(args, "inter_xctc_weight", 0) or 0) > 0:
+            self.inter_xctc_layers = _layer_list(getattr(args, "inter_xctc_layers", None), n)
+        if self.inter_xctc_layers:
+            self.share_inter_xctc_norm = bool(getattr(args, "share_inter_xctc_norm", False))
+            if not self.share_inter_xctc_norm:
+                for L in self.inter_xctc_layers:
+                    setattr(self, "xctc_norm%d" % L, LayerNorm(d))
+            if not hasattr(self, "xctc"):
+                self.xctc = xctc_head()
+            strategy = {"embed_norm": getattr(args, "pae_embed_norm", False), "out_norm": getattr(args, "pae_out_norm", False),
+                        "ctc_temperature": getattr(args, "pae_ctc_temperature", 1.0), "gumbel": getattr(args, "pae_gumbel", False),
+                        "distribution_hard": getattr(args, "pae_distribution_hard", None), "gt_ratio": self.gt_ratio,
+                        "oracle_smooth": getattr(args, "pae_oracle_smooth", False)}
+            self.xctc_pae = Adapter(d, getattr(args, "xctc_pae", "none"), len(tgt), strategy=strategy)
+        # cross-layer attention (:536-611)
+        self.use_cross_attn = False
+        layers = [TransformerEncoderLayer(args) for _ in range(n)]
+        if getattr(args, "xctc_cross_attn", False) and getattr(args, "cross_attn_start_layer", None) is not None \
+                and getattr(args, "cross_attn_layer", None) is not None:
+            self.use_cross_attn = True
+            self.cross_attn_start_layer = int(args.cross_attn_start_layer)
+            self.cross_attn_layer = int(args.cross_attn_layer)
+            self.attn_norm = LayerNorm(d)
+            s2_args = copy.copy(args)
+            for k in ("collaboration_mode", "league_s1_ratio", "league_s2_ratio", "league_drop_net", "league_drop_net_prob",
+                      "league_drop_net_mix", "league_out_norm", "league_gated"):
+                setattr(s2_args, "encoder_" + k, getattr(args, "cross_attn_" + k, None))
+            _unsupported(s2_args, encoder_league_drop_net_mix=False)
+            layers = layers[: self.cross_attn_start_layer - 1] + [
+                TransformerS2EncoderLayer(s2_args) for _ in range(n - self.cross_attn_start_layer + 1)]
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x, B, T, lens32, encoder_padding_mask=None, **kwargs):
+        """x [B*T, d] -> (x, xctc_logit, inter_xctc_logits); logits are (T, B, V) views, inter entries follow the
+        reference: plain tensor, or [logit, None, force_emit] under the ground-truth curriculum (:774-797)."""
         if self.embed_ln is not None:
             x = self.embed_ln(x)
-        tab = TABLES.get("sin", max(self.max_pos, T) + 2, self.embed_dim, x.device)
-        x = AddPositions.apply(x, tab, lens32, T, self.embed_scale)
-        x = Fn.dropout(x, self.dropout_p, self.training)  # dropout_module (s2t_sate.py:650)
-        for layer in self.layers:
-            x = layer(x, B, T, lens32)
+        if not self.text_no_pos_emb:
+            tab = TABLES.get("sin", max(self.max_pos, T) + 2, self.embed_dim, x.device)
+            x = AddPositions.apply(x, tab, lens32, T, self.embed_scale)
+            x = Fn.dropout(x, self.dropout_p, self.training)  # dropout_module (s2t_sate.py:650)
+        elif self.embed_scale != 1.0:
+            x = x * self.embed_scale
+        skips = kwargs.get("drop_self_attn")  # test hook: replay of the reference's league drop-net draws
+        attn_x = xorc = x_force_emit = None
+        inter_xctc_logits, s2_i = [], 0
+        for i, layer in enumerate(self.layers):
+            if self.use_cross_attn and i >= self.cross_attn_start_layer - 1:
+                x = layer(x, B, T, lens32, s2=attn_x, skip_self_attn=None if skips is None else skips[s2_i])
+                s2_i += 1
+            else:
+                x = layer(x, B, T, lens32)
+            L = i + 1
+            if self.use_cross_attn and L == self.cross_attn_layer:
+                attn_x = self.attn_norm(x)
+            if L in self.inter_xctc_layers:
+                norm = self.layer_norm if self.share_inter_xctc_norm else getattr(self, "xctc_norm%d" % L)
+                norm_x = norm(x)
+                logit2d = self.xctc(norm_x, out_dtype=self.ctc_out_dtype)
+                il = logit2d.view(B, T, -1).transpose(0, 1)
+                inter_logit = il
+                orc = msk = None
+                if self.gt_ratio > 0:
+                    oracle = (kwargs.get("ctc_alignment_oracle") or {}).get("xctc")
+                    if oracle is not None:
+                        if xorc is None:
+                            xorc = pae_oracle_mask(oracle, self.gt_ratio, self.pae_adaptive_gt, self.pae_gt_only_mistake,
+                                                   (kwargs.get("pae_oracle_masks") or {}).get("xctc"))
+                            x_force_emit = xorc[2]
+                        orc, msk = xorc[0], xorc[1]
+                        inter_logit = [il, None, x_force_emit]
+                if self.xctc_pae.adapter_type != "none":
+                    x = self.xctc_pae(x if self.pae_unnorm_input else norm_x, logit2d, orc, msk)
+                inter_xctc_logits.append(inter_logit)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
-        return x
+        xctc_logit = None
+        if self.use_xctc:
+            xctc_logit = self.xctc(x, out_dtype=self.ctc_out_dtype).view(B, T, -1).transpose(0, 1)
+            if x_force_emit is not None:
+                xctc_logit = [xctc_logit, None, x_force_emit]
+        return x, xctc_logit, inter_xctc_logits
+
+    ctc_out_dtype = None  # None -> compute dtype; eval decoding sets fp32
 
 
 class S2TSATEEncoder(nn.Module):
@@ -103,38 +237,55 @@ class S2TSATEEncoder(nn.Module):
 
     def __init__(self, args, task=None, decoder_embed_tokens=None):
         super().__init__()
-        _unsupported(args, use_enc_dlcl=False, freeze_acoustic_encoder=False, freeze_textual_encoder=False)
+        _unsupported(args, use_enc_dlcl=False, freeze_acoustic_encoder=False, freeze_textual_encoder=False,
+                     adapter_ground_truth_ratio=0, share_adapter_and_ctc=False, share_adapter_and_embed=False)
         if getattr(args, "acoustic_encoder", "transformer") != "transformer":
             raise NotImplementedError("acoustic encoder %s" % args.acoustic_encoder)
+        if args.text_encoder_layers > 0:
+            setattr(args, "disable_xctc", True)  # :841-842
         self.acoustic_encoder = S2TTransformerEncoder(args, task, decoder_embed_tokens)
         vocab = len(task.source_dictionary)
-        strategy = {"distribution_temperature": getattr(args, "adapter_temperature", 1.0)}
+        strategy = {"ctc_temperature": getattr(args, "adapter_temperature", 1.0)}
         self.adapter = Adapter(args.encoder_embed_dim, getattr(args, "adapter", "none"), vocab, strategy=strategy)
-        # the reference ties the text embedding to the decoder's (s2t_sate.py build_model; golden state_dict)
-        self.textual_encoder = TextualEncoder(args, task.source_dictionary, decoder_embed_tokens)
+        # the reference hands the decoder's embedding to the textual encoder (s2t_sate.py:906)
+        self.textual_encoder = TextualEncoder(args, task.source_dictionary, decoder_embed_tokens,
+                                              getattr(task, "target_dictionary", None))
+        self.pae_ground_truth_ratio = (float(getattr(args, "ctc_pae_ground_truth_ratio", 0) or 0)
+                                       + float(getattr(args, "adapter_ground_truth_ratio", 0) or 0)
+                                       + float(getattr(args, "xctc_pae_ground_truth_ratio", 0) or 0))  # :857-861
         self.compute_dtype = torch.float32
 
     def max_positions(self):
         return self.acoustic_encoder.max_positions()
 
     def set_num_updates(self, n):
-        pass
+        self.acoustic_encoder.set_num_updates(n)
+
+    def set_ctc_infer(self, ctc_infer, post_process, src_dict=None, tgt_dict=None, path=None):
+        if hasattr(self.acoustic_encoder, "ctc"):
+            self.acoustic_encoder.ctc.set_infer(ctc_infer, post_process, src_dict, path)
+        if hasattr(self.textual_encoder, "xctc"):
+            self.textual_encoder.xctc.set_infer(ctc_infer, post_process, tgt_dict, path)
 
     def forward(self, src_tokens, src_lengths=None, **kwargs):
-        ac = self.acoustic_encoder(src_tokens, src_lengths)
+        ac = self.acoustic_encoder(src_tokens, src_lengths, **kwargs)
         x_tbc = ac["encoder_out"][0]
         Tn, B, d = x_tbc.shape
         x = x_tbc.transpose(0, 1).reshape(B * Tn, d)
         mask = ac["encoder_padding_mask"][0]
         lens32 = (~mask).sum(1).to(torch.int32)
         if self.adapter.adapter_type != "none":
-            logit = ac["ctc_logit"][0].transpose(0, 1).reshape(B * Tn, -1)
-            x = self.adapter(x, logit)
-        x = self.textual_encoder(x, B, Tn, lens32)
+            ctc_logit = ac["ctc_logit"][0]
+            logit = ctc_logit[0] if isinstance(ctc_logit, (list, tuple)) else ctc_logit  # :1008-1012
+            x = self.adapter(x, logit.transpose(0, 1).reshape(B * Tn, -1))
+        self.textual_encoder.ctc_out_dtype = self.acoustic_encoder.ctc_out_dtype
+        x, xctc_logit, inter_xctc_logits = self.textual_encoder(x, B, Tn, lens32, mask, **kwargs)
         return {
             "encoder_out": [x.view(B, Tn, d).transpose(0, 1)],
             "ctc_logit": ac["ctc_logit"],
-            "inter_ctc_logits": [], "xctc_logit": [], "inter_xctc_logits": [], "axctc_logit": [], "inter_axctc_logits": [],
+            "inter_ctc_logits": ac.get("inter_ctc_logits", []),
+            "xctc_logit": [] if xctc_logit is None else [xctc_logit],
+            "inter_xctc_logits": inter_xctc_logits, "axctc_logit": [], "inter_axctc_logits": [],
             "ctc_padding_mask": [mask],
             "encoder_padding_mask": [mask],
             "mixup": None, "encoder_embedding": [], "encoder_states": [], "src_tokens": [], "src_lengths": [],
@@ -167,6 +318,9 @@ def base_architecture(args):
     _d(args, "textual_encoder_embed_norm", False)
     _d(args, "textual_encoder_no_scale_embedding", False)
     _d(args, "text_attention_type", "selfattn")
+    _d(args, "cross_attn_collaboration_mode", "serial")
+    _d(args, "cross_attn_league_drop_net", False)
+    _d(args, "cross_attn_league_drop_net_prob", 0.0)
     _s2t_base(args)
 
 

@@ -15,8 +15,8 @@ import torch.nn as nn
 
 from . import functional as Fn
 from .flat_params import FlatParameters
-from .modules import (CTC, TABLES, Conv1dSubsampling, Ctx, LayerNorm, Linear, MaskRows, S2TTransformerEncoderLayer,
-                      TransformerDecoderLayer)
+from .modules import (CTC, TABLES, Adapter, Conv1dSubsampling, Ctx, LayerNorm, Linear, MaskRows,
+                      S2TTransformerEncoderLayer, TransformerDecoderLayer, pae_oracle_mask)
 from .registry import register_model, register_model_architecture
 
 DEFAULT_MAX_SOURCE_POSITIONS = 6000
@@ -43,9 +43,10 @@ class S2TTransformerEncoder(nn.Module):
 
     def __init__(self, args, task=None, decoder_embed_tokens=None):
         super().__init__()
-        _unsupported(args, inter_mixup=False, use_enc_dlcl=False, inter_xctc_layers=None,
-                     xctc_weight=0, compression_layers=None, encoder_embed_linear=False, layer_out_norm=False,
-                     encoder_layerdrop=0.0, inter_ctc_drop_prob=0, inter_ctc_mlo="")
+        _unsupported(args, inter_mixup=False, use_enc_dlcl=False, compression_layers=None, encoder_embed_linear=False,
+                     layer_out_norm=False, encoder_layerdrop=0.0, inter_ctc_drop_prob=0, inter_ctc_mlo="")
+        if not getattr(args, "disable_xctc", False):  # SATE sets it: XCTC then lives in the textual encoder (s2t_sate.py:842)
+            _unsupported(args, inter_xctc_layers=None, xctc_weight=0)
         self.args = args
         d = args.encoder_embed_dim
         self.embed_dim = d
@@ -71,14 +72,16 @@ class S2TTransformerEncoder(nn.Module):
             self.ctc = CTC(d, dictionary_size=vocab, dropout=args.dropout)
             if getattr(args, "share_ctc_and_embed", False) and decoder_embed_tokens is not None:
                 self.ctc.ctc_projection.weight = decoder_embed_tokens.weight  # s2t_transformer.py:965-971
-        # intermediate CTC heads (egs/mustc/asr/conf/inter.yaml; s2t_transformer.py:975-1031, forward :1881-1946 with
-        # ctc_pae none): after layer L (1-based; <= 0 counts from the top) a LayerNorm ``ctc_norm{L}`` (or the final
-        # one, --share-inter-ctc-norm) feeds the shared top head (--share-inter-ctc) or the layer's own ``inter_ctc{L}``
+        # intermediate CTC heads (egs/mustc/asr/conf/inter.yaml; s2t_transformer.py:975-1100, forward :1881-1946):
+        # after layer L (1-based; <= 0 counts from the top) a LayerNorm ``ctc_norm{L}`` (or the final one,
+        # --share-inter-ctc-norm) feeds the shared top head (--share-inter-ctc) or the layer's own ``inter_ctc{L}``;
+        # with --ctc-pae inter_league the layer output is then replaced by PAE(norm_x, logit) (``pae`` / ``pae{L}``)
         self.inter_ctc_layers = []
+        self.ctc_pae_ground_truth_ratio = float(getattr(args, "ctc_pae_ground_truth_ratio", 0) or 0)
+        self.pae_ground_truth_ratio = self.ctc_pae_ground_truth_ratio + float(
+            getattr(args, "xctc_pae_ground_truth_ratio", 0) or 0)  # s2t_transformer.py:947-949 (read by CtcCriterion)
         spec = getattr(args, "inter_ctc_layers", None)
         if spec is not None and str(spec) not in ("", "None"):
-            if getattr(args, "ctc_pae", "none") != "none":
-                raise NotImplementedError("prediction-aware encoding (ctc_pae) on the HIP path")
             self.share_inter_ctc = bool(getattr(args, "share_inter_ctc", False))
             self.share_inter_ctc_norm = bool(getattr(args, "share_inter_ctc_norm", False))
             vocab = len(task.source_dictionary) if task is not None else args.vocab_size
@@ -93,6 +96,20 @@ class S2TTransformerEncoder(nn.Module):
                         head.ctc_projection.weight = decoder_embed_tokens.weight
                     setattr(self, "inter_ctc%d" % L, head)
                 self.inter_ctc_layers.append(L)
+            self.pae_unnorm_input = bool(getattr(args, "pae_unnorm_input", False))
+            self.pae_adaptive_gt = bool(getattr(args, "xctc_pae_ground_truth_ratio_adaptive", False))  # sic (:1129-1134)
+            self.pae_gt_only_mistake = bool(getattr(args, "xctc_pae_ground_truth_only_mistake", False))
+            _unsupported(args, share_pae_and_ctc=False, ctc_pae_ground_truth_ratio_decay=None)
+            strategy = {"embed_norm": getattr(args, "pae_embed_norm", False), "out_norm": getattr(args, "pae_out_norm", False),
+                        "ctc_temperature": getattr(args, "pae_ctc_temperature", 1.0), "gumbel": getattr(args, "pae_gumbel", False),
+                        "distribution_hard": getattr(args, "pae_distribution_hard", None),
+                        "gt_ratio": self.ctc_pae_ground_truth_ratio}
+            pae_type = getattr(args, "ctc_pae", "none")
+            if self.share_inter_ctc:
+                self.pae = Adapter(d, pae_type, vocab, strategy=strategy)
+            else:
+                for L in self.inter_ctc_layers:
+                    setattr(self, "pae%d" % L, Adapter(d, pae_type, vocab, strategy=strategy))
         self.compute_dtype = torch.float32
         self.ctc_out_dtype = None  # None -> compute dtype; eval sets fp32 (bit-exact greedy wants fp32 logits)
         self.num_updates = 0
@@ -145,6 +162,7 @@ class S2TTransformerEncoder(nn.Module):
             x = MaskRows.apply(x, lens32, Tp)  # layer 0's masked_fill (:1828-1836); later layers: fused in final_norm
         n = len(self.layers)
         inter_ctc_logits = []
+        ctc_orc = ctc_force_emit = None
         for i, layer in enumerate(self.layers):
             tap = (i + 1) in self.inter_ctc_layers  # the head reads the layer output BEFORE the next layer's mask
             x = layer(x, c, mask_output=self.layer_padding_mask and i + 1 < n and not tap)
@@ -152,8 +170,24 @@ class S2TTransformerEncoder(nn.Module):
                 L = i + 1
                 norm = self.layer_norm if self.share_inter_ctc_norm else getattr(self, "ctc_norm%d" % L)
                 head = self.ctc if (self.use_ctc and self.share_inter_ctc) else getattr(self, "inter_ctc%d" % L)
-                il = head(norm(x), out_dtype=self.ctc_out_dtype).view(B, Tp, -1).transpose(0, 1)
-                inter_ctc_logits.append([il, encoder_padding_mask])  # the reference's [logit, padding mask] pairs
+                pae = self.pae if self.share_inter_ctc else getattr(self, "pae%d" % L)
+                norm_x = norm(x)
+                logit2d = head(norm_x, out_dtype=self.ctc_out_dtype)
+                il = logit2d.view(B, Tp, -1).transpose(0, 1)
+                inter_logit = [il, encoder_padding_mask]  # the reference's [logit, padding mask] pairs
+                orc = msk = None
+                if self.ctc_pae_ground_truth_ratio > 0:  # :1904-1935
+                    oracle = (kwargs.get("ctc_alignment_oracle") or {}).get("ctc")
+                    if oracle is not None:
+                        if ctc_orc is None:
+                            ctc_orc = pae_oracle_mask(oracle, self.ctc_pae_ground_truth_ratio, self.pae_adaptive_gt,
+                                                      self.pae_gt_only_mistake, (kwargs.get("pae_oracle_masks") or {}).get("ctc"))
+                            ctc_force_emit = ctc_orc[2]
+                        orc, msk = ctc_orc[0], ctc_orc[1]
+                        inter_logit = [il, None, ctc_force_emit]
+                if pae.adapter_type != "none":
+                    x = pae(x if self.pae_unnorm_input else norm_x, logit2d, orc, msk)
+                inter_ctc_logits.append(inter_logit)
                 if self.layer_padding_mask and i + 1 < n:
                     x = MaskRows.apply(x, lens32, Tp)
         if self.layer_norm is not None:
@@ -162,6 +196,8 @@ class S2TTransformerEncoder(nn.Module):
         if self.use_ctc:
             logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype)
             ctc_logit = logit2d.view(B, Tp, -1).transpose(0, 1)
+            if ctc_force_emit is not None:
+                ctc_logit = [ctc_logit, None, ctc_force_emit]  # :2137-2138
         return {
             "encoder_out": [x.view(B, Tp, d).transpose(0, 1)],  # T x B x C (view of the batch-major buffer)
             "ctc_logit": [] if ctc_logit is None else [ctc_logit],
@@ -432,7 +468,7 @@ class S2TTransformerModel(_HipModel):
 
 @register_model("s2t_ctc")
 class S2TCTCModel(_HipModel):
-    """models/speech_to_text/s2t_ctc.py:28-171 — encoder-only CTC model (``--encoder-type transformer``)."""
+    """models/speech_to_text/s2t_ctc.py:28-171 — encoder-only CTC model (``--encoder-type transformer | sate``)."""
 
     def __init__(self, encoder):
         super().__init__()
@@ -444,12 +480,19 @@ class S2TCTCModel(_HipModel):
         base_architecture(args)
         if getattr(args, "ctc_weight", 0) <= 0:
             args.ctc_weight = 1.0
-        if getattr(args, "encoder_type", "transformer") != "transformer":
-            raise NotImplementedError("s2t_ctc --encoder-type %s" % args.encoder_type)
-        return cls(S2TTransformerEncoder(args, task))
+        etype = getattr(args, "encoder_type", "transformer")
+        if etype == "transformer":
+            return cls(S2TTransformerEncoder(args, task))
+        if etype == "sate":  # s2t_ctc.py:50-68: the embedding the textual encoder / XCTC head may share
+            from .s2t_sate import S2TSATEEncoder, base_architecture as sate_base
+            sate_base(args)
+            tgt = task.target_dictionary
+            embed = Embedding(len(tgt), args.encoder_embed_dim, tgt.pad())
+            return cls(S2TSATEEncoder(args, task, embed))
+        raise NotImplementedError("s2t_ctc --encoder-type %s" % etype)
 
     def forward(self, src_tokens, src_lengths, prev_output_tokens=None, **kwargs):
-        return self.encoder(src_tokens, src_lengths)
+        return self.encoder(src_tokens, src_lengths, **kwargs)
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):
         logits = net_output["ctc_logit"][0] if isinstance(net_output, dict) else net_output[0]

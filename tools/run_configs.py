@@ -7,6 +7,9 @@
   3   pdss2t_transformer_s_8 (+ Conformer flags), 64 x 2000 x 80, bf16, training step
   4   s2t_sate 12+6 / 6, 64 x 1000 x 80, bf16, training step (per-GPU share of the 8-GPU config)
   5a  s2t_ctc 12L Conformer encoder, 256 x 1000 x 80, bf16 eval, CTC greedy
+  5b  the full reproduction_nast.yaml stack (s2t_ctc --encoder-type sate: 12L Conformer acoustic + 12 textual layers with
+      cross-layer attention, d=512/h=8/F=2048, inter-(X)CTC at 6,9 with PAE), 256 x 1000 x 80 bf16 eval, greedy on
+      xctc_logit; plus one eager training step of the same stack (CtcCriterion with the ground-truth curriculum) at 64 x 1000
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -92,3 +95,35 @@ if "5a" in which:
     m = M.S2TCTCModel.build_model(a, task).prepare(torch.bfloat16, dev)
     m.encoder.ctc_out_dtype = torch.float32
     greedy_cfg("5a", m, 256, 1000, torch.bfloat16)
+if "5b" in which:
+    nast = dict(encoder_type="sate", text_encoder_layers=12, acoustic_encoder="transformer", adapter="inter_league",
+                xctc_weight=1.0, ctc_weight=1.0, share_ctc_and_embed=True, share_xctc_and_embed=True, text_no_pos_emb=True,
+                textual_encoder_embed_norm=False, textual_encoder_no_scale_embedding=True, encoder_normalize_before=True,
+                share_inter_ctc=True, inter_ctc_weight=1.0, inter_ctc_layers="6,9", inter_xctc_weight=1.0,
+                inter_xctc_layers="6,9", ctc_pae="inter_league", xctc_pae="inter_league", xctc_cross_attn=True,
+                cross_attn_start_layer=4, cross_attn_layer=3, cross_attn_collaboration_mode="serial",
+                cross_attn_league_drop_net=True, cross_attn_league_drop_net_prob=0.1, xctc_pae_ground_truth_ratio=0.8,
+                xctc_pae_ground_truth_only_mistake=True, pae_oracle_smooth=True, encoder_embed_dim=512,
+                encoder_ffn_embed_dim=2048, encoder_attention_heads=8, subsampling_filter=2048, activation_fn="relu")
+    a = M.recipe_args(conformer=True, vocab_size=V, dropout=0.15, attention_dropout=0.15, activation_dropout=0.15, **nast)
+    m = M.S2TCTCModel.build_model(a, task).prepare(torch.bfloat16, dev)
+    print("5b   params %.1f M" % (m.flat.master.numel() / 1e6), flush=True)
+    m.encoder.acoustic_encoder.ctc_out_dtype = torch.float32
+    greedy_cfg("5b", m, 256, 1000, torch.bfloat16)
+    m.encoder.acoustic_encoder.ctc_out_dtype = None
+    m.train()
+    crit = C.CtcCriterion(None, task, ctc_weight=1.0, inter_ctc_weight=1.0, xctc_weight=1.0, inter_xctc_weight=1.0)
+    crit.train()
+    tr = Trainer(m, crit)
+    sample, frames = bench.synthetic_batch(64, 1000, V, 1, dev)
+    sample["transcript"] = {"tokens": sample["target"]}
+    for _ in range(2):
+        out = tr.train_step(sample)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        out = tr.train_step(sample)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 4
+    print("5b   train (eager, 2 encoder passes: alignment oracle + curriculum)  64 x 1000 : %7.2f ms/step  %7.3f M frames/s  loss %.1f  peak mem %.1f GB" % (
+        dt * 1e3, frames / dt / 1e6, float(out[0]), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
