@@ -169,10 +169,13 @@ def criterion_for(task, args):
     return crit
 
 
-def encdec_case(name, outdir, arch, V, B, T, seed, train_bn=False, **kw):
+def encdec_case(name, outdir, arch, V, B, T, seed, train_bn=False, tweak=None, **kw):
     torch.manual_seed(seed)
     model, args, task = build(arch, V, **kw)
     seed_weights(model, seed + 100)
+    if tweak is not None:
+        with torch.no_grad():
+            tweak(model)
     src, lens, prev, target, ntokens = make_batch(B, T, V, seed + 200)
     out = {}
     out.update(sd_np(model))
@@ -191,6 +194,9 @@ def encdec_case(name, outdir, arch, V, B, T, seed, train_bn=False, **kw):
     out["out::ctc_logit"] = np_(enc["ctc_logit"][0])  # (T', B, V)
     out["out::encoder_padding_mask"] = np_(enc["encoder_padding_mask"][0])
     out["out::decoder_logits"] = np_(logits)  # (B, U, V)
+    for i, il in enumerate(enc.get("inter_ctc_logits", [])):
+        if isinstance(il, (list, tuple)) and il[1] is not None:
+            out["out::inter_ctc_mask_%d" % i] = np_(il[1])
 
     # ---- loss + grads (training mode, dropout 0; BatchNorm uses batch statistics when present)
     model.train()
@@ -543,6 +549,25 @@ def main():
                 inter_xctc_weight=1.0, inter_xctc_layers="2,3", ctc_pae="inter_league", xctc_pae="inter_league",
                 xctc_cross_attn=True, cross_attn_start_layer=3, cross_attn_layer=2, cross_attn_collaboration_mode="serial",
                 cross_attn_league_drop_net=True, xctc_pae_ground_truth_only_mistake=True, pae_oracle_smooth=True)
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "compress"):
+        # egs/*/conf/dynamic.yaml on top of inter.yaml: CTC-guided compression after the intermediate CTC layers.
+        # The blank logit is lifted so that the blank posterior straddles the threshold (seeded weights alone would
+        # keep every frame); ragged batch, Conformer (relative positions re-derived) and Transformer (absolute positions
+        # re-added) variants.
+        def lift_blank(m, lift=3.5):
+            m.encoder.ctc.ctc_projection.weight.mul_(4.0)
+            m.encoder.ctc.ctc_projection.bias[0] += lift
+
+        comp = dict(inter_ctc_layers="2,3", share_inter_ctc=True, inter_ctc_weight=0.2, ctc_pae="none",
+                    compression_metric="threshold", compression_mode="create", compression_layers="2,3",
+                    compression_threshold="0.5", compression_norm=True, compression_pos=True)
+        encdec_case("conformer_compress", outdir, "s2t_transformer_s", V=40, B=4, T=90, seed=31, train_bn=True,
+                    tweak=lift_blank, **dict(small, encoder_layers=4), **conf, **comp)
+        encdec_case("transformer_compress", outdir, "s2t_transformer_s", V=40, B=4, T=90, seed=32,
+                    tweak=lambda m: lift_blank(m, float(os.environ.get("BLANK_LIFT", "7.0"))),
+                    **dict(small, encoder_layers=4), **dict(comp, ctc_pae="inter_league"))
+    if os.environ.get("GOLDEN_ONLY", "") == "compress":
+        return
     if os.environ.get("GOLDEN_ONLY", "") in ("", "nast"):
         # egs/mustc/st/conf/reproduction_nast.yaml at toy size; first without, then with the curriculum randomness
         nast_case("nast_small", outdir, V=40, B=3, T=60, seed=21, **nast, **conf, cross_attn_league_drop_net_prob=0.0,

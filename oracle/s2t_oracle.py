@@ -298,6 +298,10 @@ def pae_oracle_mask(entry, gt_ratio, adaptive=False, only_mistake=False, mask=No
     return oracle, mask, aligns.masked_fill(~mask, -1)
 
 
+def _ints_csv(spec):
+    return [] if spec is None or str(spec) in ("", "None", "none") else [int(t) for t in str(spec).split(",")]
+
+
 def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None,
                     ctc_alignment_oracle=None, oracle_masks=None):
     """models/speech_to_text/s2t_transformer.py:1714-2154 (no mixup; intermediate CTC heads and prediction-aware encoding
@@ -320,7 +324,10 @@ def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="enc
         x = x + sinusoidal_positions(pad_mask, d, padding_idx=1)  # :1785-1787
     any_valid = not bool(pad_mask.all())
     inter_layers = inter_ctc_layer_list(cfg)
-    inter_logits = []
+    inter_logits, inter_masks = [], []
+    comp_layers = _ints_csv(cfg.get("compression_layers"))
+    comp_thr = [float(t) for t in str(cfg.get("compression_threshold", "1.0")).split(",")]
+    comp_thr = comp_thr if len(comp_thr) == len(comp_layers) else comp_thr * len(comp_layers)
     ctc_force_emit = ctc_orc = None
     for i in range(cfg["encoder_layers"]):
         if cfg.get("layer_padding_mask", False) and any_valid:
@@ -335,6 +342,7 @@ def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="enc
             nx = layer_norm(x, W[npre + "weight"], W[npre + "bias"])
             logit = linear(nx, W[hpre + "ctc_projection.weight"], W[hpre + "ctc_projection.bias"])
             inter_logits.append(logit.transpose(0, 1))
+            inter_masks.append(pad_mask)  # the reference's [logit, encoder_padding_mask] pair (:1903)
             if cfg.get("ctc_pae", "none") == "inter_league":  # :1937-1944
                 ppre = prefix + ("pae." if cfg.get("share_inter_ctc", False) else "pae%d." % L)
                 orc = msk = None
@@ -351,12 +359,44 @@ def encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="enc
                                      W[ppre + "embed_adapter.weight"], cfg.get("pae_ctc_temperature", 1.0), orc, msk, False)
             elif cfg.get("ctc_pae", "none") != "none":
                 raise NotImplementedError(cfg["ctc_pae"])
+            if L in comp_layers:
+                # CTC-guided compression (:1948-2040, ``threshold`` metric): drop the frames whose blank posterior reaches
+                # the layer's threshold; ``create`` left-packs the kept frames of every utterance (new T = longest),
+                # ``mask`` only extends the padding mask; then [compression_norm{L}], [positions for the new layout],
+                # padded frames -> 0
+                if cfg.get("compression_metric", "ratio") != "threshold":
+                    raise NotImplementedError(cfg.get("compression_metric"))
+                thr = comp_thr[comp_layers.index(L)]
+                blank_prob = torch.softmax(logit, dim=-1)[:, :, 0]
+                keep = (blank_prob < thr) & ~pad_mask
+                cnt = keep.sum(1)
+                if cfg.get("compression_mode", "create") == "create":
+                    if int(cnt.min()) > 0 and not bool(keep.all()):
+                        Tn = int(cnt.max())
+                        out_x = x.new_zeros(x.size(0), Tn, x.size(2))
+                        for b in range(x.size(0)):
+                            out_x[b, : int(cnt[b])] = x[b][keep[b]]
+                        x = out_x
+                        pad_mask = lengths_to_padding_mask(cnt, Tn)
+                elif cfg["compression_mode"] == "mask":
+                    pad_mask = pad_mask | ~keep
+                else:
+                    raise NotImplementedError(cfg["compression_mode"])
+                if cfg.get("compression_norm", False):
+                    x = layer_norm(x, W[prefix + "compression_norm%d.weight" % L], W[prefix + "compression_norm%d.bias" % L])
+                if cfg.get("compression_pos", False) and cfg["encoder_attention_type"] != "rel_pos":
+                    x = x + sinusoidal_positions(pad_mask, d, padding_idx=1)
+                x = x.masked_fill(pad_mask[:, :, None], 0.0)
+                any_valid = not bool(pad_mask.all())
+        if pos_tab is not None and pos_tab.size(0) != 2 * x.size(1) - 1:
+            pos_tab = rel_pos_table(x.size(1), d)  # :1838-1843 / :2021-2026: relative positions follow the new length
     x = layer_norm(x, W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"])
     out = {
         "encoder_out": [x.transpose(0, 1)],
         "encoder_padding_mask": [pad_mask],
         "ctc_logit": [],
         "inter_ctc_logits": inter_logits,
+        "inter_ctc_padding_masks": inter_masks,
         "ctc_force_emit": ctc_force_emit,
     }
     if prefix + "ctc.ctc_projection.weight" in W:
@@ -614,12 +654,14 @@ def joint_loss(W, cfg, src_tokens, src_lengths, prev_output_tokens, target, eps=
     if iw > 0 and len(enc.get("inter_ctc_logits", [])) > 0:
         # criterions/ctc.py:568-633: the same targets for every intermediate head, losses averaged over the heads
         inter = 0.0
-        for lg in enc["inter_ctc_logits"]:
+        for j, lg in enumerate(enc["inter_ctc_logits"]):
             ilp = torch.log_softmax(lg.float(), dim=-1)
+            # every entry is scored with the lengths of ITS padding mask (criterions/ctc.py:580-590: logit[1])
+            il = (~enc["inter_ctc_padding_masks"][j]).long().sum(-1) if "inter_ctc_padding_masks" in enc else lens
             if use_torch_ctc:
-                inter = inter + F.ctc_loss(ilp, flat, lens, tl, blank=0, reduction="none", zero_infinity=True).sum()
+                inter = inter + F.ctc_loss(ilp, flat, il, tl, blank=0, reduction="none", zero_infinity=True).sum()
             else:
-                inter = inter + ctc_nll(ilp, tg, lens).sum()
+                inter = inter + ctc_nll(ilp, tg, il).sum()
         inter = inter / len(enc["inter_ctc_logits"])
         loss = loss + iw * inter
     n_correct, total = ce_accuracy(logits, target)
@@ -965,12 +1007,15 @@ def ctc_criterion_loss(W, cfg, src_tokens, src_lengths, target, transcript=None,
     enc = fwd(src_tokens, src_lengths, W, cfg, training=training, bn_stats=bn_stats, **kw)
     in_lens = (~enc["encoder_padding_mask"][0]).sum(-1)
 
-    def one(logit_tbv, toks):
-        return ctc_nll(torch.log_softmax(logit_tbv.float(), -1), ctc_targets(toks, pad_idx, eos_idx), in_lens, blank).sum()
+    def one(logit_tbv, toks, lens=None):
+        return ctc_nll(torch.log_softmax(logit_tbv.float(), -1), ctc_targets(toks, pad_idx, eos_idx),
+                       in_lens if lens is None else lens, blank).sum()
 
     log, loss = {}, 0.0
     if w["inter_ctc"] > 0 and len(enc.get("inter_ctc_logits", [])) > 0:
-        log["inter_ctc_loss"] = sum(one(l, transcript) for l in enc["inter_ctc_logits"]) / len(enc["inter_ctc_logits"])
+        masks = enc.get("inter_ctc_padding_masks")
+        log["inter_ctc_loss"] = sum(one(l, transcript, None if masks is None else (~masks[j]).sum(-1))
+                                    for j, l in enumerate(enc["inter_ctc_logits"])) / len(enc["inter_ctc_logits"])
         loss = loss + w["inter_ctc"] * log["inter_ctc_loss"]
     if w["ctc"] > 0 and len(enc["ctc_logit"]) > 0:
         log["ctc_loss"] = one(enc["ctc_logit"][0], transcript)

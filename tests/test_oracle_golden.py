@@ -9,7 +9,7 @@ import torch
 from oracle import s2t_oracle as O
 
 CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small",
-         "conformer_interctc"]
+         "conformer_interctc", "conformer_compress", "transformer_compress"]
 
 
 def _load(golden_dir, name):
@@ -51,7 +51,11 @@ def test_eval_forward(golden_dir, name):
     i = 0
     while "out::inter_ctc_logit_%d" % i in z.files:  # intermediate CTC heads (inter.yaml)
         _close(enc["inter_ctc_logits"][i], z["out::inter_ctc_logit_%d" % i], rtol=1e-4, atol=2e-5)
+        if "out::inter_ctc_mask_%d" % i in z.files:  # with CTC-guided compression (dynamic.yaml) T shrinks on the way
+            assert (enc["inter_ctc_padding_masks"][i].numpy() == z["out::inter_ctc_mask_%d" % i]).all()
         i += 1
+    if name.endswith("_compress"):
+        assert enc["encoder_out"][0].shape[0] < enc["inter_ctc_logits"][0].shape[0]
 
 
 @pytest.mark.parametrize("name", CASES)
