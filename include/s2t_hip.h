@@ -329,6 +329,19 @@ int s2t_ctc_prefix_score(const float* lp, int64_t ld, int T, const int32_t* in_l
                          const float* r_prev, const int64_t* last, int out_len, const int64_t* cand, int R, int K, int blank,
                          int eos, float* psi, float* r_new, void* stream);
 
+/* ---- CTC-guided compression of the frame axis -------------------------------------------------
+ * Replaces the per-utterance boolean indexing of S2TTransformerEncoder.forward, s2t_transformer.py:1948-1986
+ * (--compression-metric threshold, --compression-mode create).
+ * s2t_ctc_compress_plan : keep[b][t] = t < lens[b] && exp(logits[b*T+t][blank] - lse[b*T+t]) < threshold;
+ *                         src[b][j] = frame index of the j-th kept frame, new_lens[b] = number kept (lse from s2t_argmax_lse)
+ * s2t_compress_rows     : scatter = 0: out[b][j][:] = j < new_lens[b] ? in[b][src[b][j]][:] : 0   (in [B][T][C], out [B][Tn][C])
+ *                         scatter = 1: out[b][src[b][j]][:] = in[b][j][:] for j < new_lens[b]      (in [B][Tn][C], out [B][T][C],
+ *                         the backward pass; the caller zero-fills out).  Rows must be multiples of 16 bytes. */
+int s2t_ctc_compress_plan(int dtype, const void* logits, int64_t ld, const float* lse, const int32_t* lens, int B, int T,
+                          int blank, float threshold, int32_t* src, int32_t* new_lens, void* stream);
+int s2t_compress_rows(int dtype, const void* in, void* out, const int32_t* src, const int32_t* new_lens, int B, int T,
+                      int Tn, int C, int scatter, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,8 +61,12 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(nn.Module):
                 # criterions/ctc.py:568-633: every intermediate head against the same targets, averaged over the heads
                 total = None
                 for il in inter:
-                    lg = il[0] if isinstance(il, (list, tuple)) else il
-                    li = Fn.ctc_loss(lg.transpose(0, 1).reshape(B * Tn, -1), B, Tn, tmat, tl, in_lens, self.blank_idx)
+                    lg, il_lens = (il[0], il[1]) if isinstance(il, (list, tuple)) else (il, None)
+                    # an entry carries the padding mask in force when it was produced (criterions/ctc.py:580-590): with
+                    # CTC-guided compression the frame axis shrinks between the heads
+                    il_lens = in_lens if il_lens is None else (~il_lens).sum(1).to(torch.int32)
+                    Ti = lg.shape[0]
+                    li = Fn.ctc_loss(lg.transpose(0, 1).reshape(B * Ti, -1), B, Ti, tmat, tl, il_lens, self.blank_idx)
                     total = li if total is None else total + li
                 inter_loss = total / len(inter)
                 log["inter_ctc_loss"] = inter_loss.detach()

@@ -1,0 +1,101 @@
+// CTC-guided compression of the frame axis (reference: S2TTransformerEncoder.forward,
+// fairseq/models/speech_to_text/s2t_transformer.py:1948-1986, ``--compression-metric threshold --compression-mode create``):
+// after an intermediate CTC head, frames whose blank posterior reaches the layer's threshold are dropped and every
+// utterance's remaining frames are left-packed.  The reference loops over the batch on the host with boolean indexing;
+// here one workgroup per utterance turns the keep flags into source indices with a ballot/popcount prefix sum, and a
+// row-gather (forward) / row-scatter (backward) moves the d-wide frames.  HBM-bound byte movers: no LDS tiles, 16-byte
+// accesses, one row segment per thread.
+#include "common.h"
+
+namespace {
+
+// keep[t] = t < len && softmax(logit[t])[blank] < thr  ->  src[b][j] = t of the j-th kept frame, new_lens[b] = #kept
+template <typename T>
+__global__ __launch_bounds__(256) void compress_plan_kernel(const T* __restrict__ logits, int64_t ld,
+                                                            const float* __restrict__ lse,
+                                                            const int32_t* __restrict__ lens, int Tn, int blank, float thr,
+                                                            int32_t* __restrict__ src, int32_t* __restrict__ new_lens) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = min(lens[b], Tn);
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < Tn; t0 += 256) {
+    const int t = t0 + tid;
+    bool keep = false;
+    if (t < len) {
+      const int64_t row = (int64_t)b * Tn + t;
+      const float p = __expf(ld_as_f32<T>(logits + row * ld + blank) - lse[row]);
+      keep = p < thr;
+    }
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (keep) src[(int64_t)b * Tn + off + before] = t;
+    __syncthreads();
+    if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) new_lens[b] = base_s;
+}
+
+// forward: y[b][j][:] = j < new_lens[b] ? x[b][src[b][j]][:] : 0      (x: [B][T][C], y: [B][Tn][C], 16-byte vectors)
+// backward (scatter = true): dx[b][src[b][j]][:] = dy[b][j][:] for j < new_lens[b] (dx zero-filled by the caller)
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void compress_rows_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                            const int32_t* __restrict__ src,
+                                                            const int32_t* __restrict__ new_lens, int B, int T, int Tn,
+                                                            int vec_per_row) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * Tn * vec_per_row;
+  if (idx >= total) return;
+  const int v = (int)(idx % vec_per_row);
+  const int64_t r = idx / vec_per_row;
+  const int j = (int)(r % Tn), b = (int)(r / Tn);
+  const bool live = j < new_lens[b];
+  if (SCATTER) {
+    if (live) out[((int64_t)b * T + src[(int64_t)b * T + j]) * vec_per_row + v] = in[idx];
+  } else {
+    out[idx] = live ? in[((int64_t)b * T + src[(int64_t)b * T + j]) * vec_per_row + v] : make_uint4(0, 0, 0, 0);
+  }
+}
+
+}  // namespace
+
+extern "C" int s2t_ctc_compress_plan(int dtype, const void* logits, int64_t ld, const float* lse, const int32_t* lens,
+                                     int B, int T, int blank, float threshold, int32_t* src, int32_t* new_lens,
+                                     void* stream) {
+  if (!logits || !lse || !lens || !src || !new_lens || B <= 0 || T <= 0 || blank < 0 || blank >= ld) return S2T_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == S2T_F32)
+    hipLaunchKernelGGL(compress_plan_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, ld, lse, lens, T, blank,
+                       threshold, src, new_lens);
+  else if (dtype == S2T_BF16)
+    hipLaunchKernelGGL(compress_plan_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, ld, lse, lens, T,
+                       blank, threshold, src, new_lens);
+  else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_compress_rows(int dtype, const void* in, void* out, const int32_t* src, const int32_t* new_lens, int B,
+                                 int T, int Tn, int C, int scatter, void* stream) {
+  if (!in || !out || !src || !new_lens || B <= 0 || T <= 0 || Tn <= 0 || Tn > T || C <= 0) return S2T_ERR_ARG;
+  const int esz = dtype == S2T_F32 ? 4 : dtype == S2T_BF16 ? 2 : 0;
+  if (!esz) return S2T_ERR_DTYPE;
+  if ((C * esz) % 16 || ((uintptr_t)in % 16) || ((uintptr_t)out % 16)) return S2T_ERR_ARG;
+  const int vpr = C * esz / 16;
+  const int64_t total = (int64_t)B * Tn * vpr;
+  dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (scatter)
+    hipLaunchKernelGGL(compress_rows_kernel<true>, grid, dim3(256), 0, s, (const uint4*)in, (uint4*)out, src, new_lens, B, T,
+                       Tn, vpr);
+  else
+    hipLaunchKernelGGL(compress_rows_kernel<false>, grid, dim3(256), 0, s, (const uint4*)in, (uint4*)out, src, new_lens, B,
+                       T, Tn, vpr);
+  return S2T_LAUNCH_CHECK();
+}

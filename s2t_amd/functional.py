@@ -1152,6 +1152,40 @@ def conv1d(x, w, b, B, T, stride):
 
 
 # ------------------------------------------------------------------------------------------------
+# CTC-guided compression of the frame axis (s2t_transformer.py:1948-1986)
+# ------------------------------------------------------------------------------------------------
+class CompressRowsFn(torch.autograd.Function):
+    """y[b][j] = x[b][src[b][j]] for j < new_lens[b], zero rows beyond; backward scatters the rows back."""
+
+    @staticmethod
+    def forward(ctx, x, src, new_lens, B, T, Tn):
+        d = x.shape[1]
+        y = torch.empty(B * Tn, d, dtype=x.dtype, device=x.device)
+        K.compress_rows(x.contiguous(), y, src, new_lens, B, T, Tn, d)
+        ctx.src, ctx.new_lens, ctx.dims = src, new_lens, (B, T, Tn, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, Tn, d = ctx.dims
+        dx = torch.zeros(B * T, d, dtype=dy.dtype, device=dy.device)
+        K.compress_rows(dy.contiguous(), dx, ctx.src, ctx.new_lens, B, T, Tn, d, scatter=True)
+        return dx, None, None, None, None, None
+
+
+def ctc_compress_plan(logit2d, lens32, B, T, blank, threshold):
+    """-> (src [B, T] int32, new_lens [B] int32): frames kept = blank posterior < threshold (fp32 softmax)."""
+    V = logit2d.shape[1]
+    dev = logit2d.device
+    lse = torch.empty(B * T, dtype=torch.float32, device=dev)
+    K.argmax_lse(logit2d, logit2d.stride(0), B * T, V, None, None, lse)
+    src = torch.zeros(B, T, dtype=torch.int32, device=dev)
+    new_lens = torch.empty(B, dtype=torch.int32, device=dev)
+    K.ctc_compress_plan(logit2d, lse, lens32, B, T, blank, threshold, src, new_lens)
+    return src, new_lens
+
+
+# ------------------------------------------------------------------------------------------------
 # SATE adapter (inter_league)
 # ------------------------------------------------------------------------------------------------
 class AdapterFn(torch.autograd.Function):

@@ -311,6 +311,16 @@ def ctc_prefix_score(lp, T, in_lens, sent, r_prev, last, out_len, cand, blank, e
           last.data_ptr(), out_len, cand.data_ptr(), R, Kc, blank, eos, psi.data_ptr(), _ptr(r_new))
 
 
+def ctc_compress_plan(logits, lse, lens, B, T, blank, threshold, src, new_lens):
+    _call("s2t_ctc_compress_plan", L.dtype_id(logits.dtype), logits.data_ptr(), logits.stride(0), lse.data_ptr(),
+          lens.data_ptr(), B, T, blank, float(threshold), src.data_ptr(), new_lens.data_ptr())
+
+
+def compress_rows(x, out, src, new_lens, B, T, Tn, C, scatter=False):
+    _call("s2t_compress_rows", L.dtype_id(x.dtype), x.data_ptr(), out.data_ptr(), src.data_ptr(), new_lens.data_ptr(), B, T,
+          Tn, C, 1 if scatter else 0)
+
+
 def row_softmax_fwd(x, ldx, p, ldp, rows, V, inv_tau=1.0):
     _call("s2t_row_softmax_fwd", L.dtype_id(x.dtype), x.data_ptr(), ldx, p.data_ptr(), ldp, rows, V, inv_tau)
 

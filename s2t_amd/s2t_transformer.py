@@ -43,7 +43,7 @@ class S2TTransformerEncoder(nn.Module):
 
     def __init__(self, args, task=None, decoder_embed_tokens=None):
         super().__init__()
-        _unsupported(args, inter_mixup=False, use_enc_dlcl=False, compression_layers=None, encoder_embed_linear=False,
+        _unsupported(args, inter_mixup=False, use_enc_dlcl=False, encoder_embed_linear=False,
                      layer_out_norm=False, encoder_layerdrop=0.0, inter_ctc_drop_prob=0, inter_ctc_mlo="")
         if not getattr(args, "disable_xctc", False):  # SATE sets it: XCTC then lives in the textual encoder (s2t_sate.py:842)
             _unsupported(args, inter_xctc_layers=None, xctc_weight=0)
@@ -110,6 +110,29 @@ class S2TTransformerEncoder(nn.Module):
             else:
                 for L in self.inter_ctc_layers:
                     setattr(self, "pae%d" % L, Adapter(d, pae_type, vocab, strategy=strategy))
+        # CTC-guided compression (egs/*/conf/dynamic.yaml; ctor :1301-1359, forward :1948-2040): after the intermediate
+        # CTC head of a listed layer, frames whose blank posterior reaches the threshold are dropped (``create``: every
+        # utterance left-packed, T' shrinks to the longest), then ``compression_norm{L}`` and fresh positions
+        self.compression_layers = []
+        spec = getattr(args, "compression_layers", None)
+        if spec is not None and str(spec) not in ("", "None", "none"):
+            if getattr(args, "compression_metric", "ratio") != "threshold":
+                raise NotImplementedError("--compression-metric %s" % getattr(args, "compression_metric", "ratio"))
+            if getattr(args, "compression_mode", "create") != "create":
+                raise NotImplementedError("--compression-mode mask (key masks with holes; the attention kernels take lengths)")
+            self.compression_layers = [int(t) for t in str(spec).split(",")]
+            assert all(L in self.inter_ctc_layers for L in self.compression_layers), "compression needs an inter-CTC head"
+            thr = [float(t) for t in str(getattr(args, "compression_threshold", "1.0")).split(",")]
+            assert len(thr) in (1, len(self.compression_layers))
+            thr = thr if len(thr) == len(self.compression_layers) else thr * len(self.compression_layers)
+            self.compression_thresholds = dict(zip(self.compression_layers, thr))
+            self.compression_pos = bool(getattr(args, "compression_pos", False))
+            self.compression_norm = bool(getattr(args, "compression_norm", False))
+            if self.compression_pos and self.attn_type != "rel_pos":
+                self.compression_embed_positions = _SinPosHolder()
+            if self.compression_norm:
+                for L in self.compression_layers:
+                    setattr(self, "compression_norm%d" % L, LayerNorm(d))
         self.compute_dtype = torch.float32
         self.ctc_out_dtype = None  # None -> compute dtype; eval sets fp32 (bit-exact greedy wants fp32 logits)
         self.num_updates = 0
@@ -188,7 +211,12 @@ class S2TTransformerEncoder(nn.Module):
                 if pae.adapter_type != "none":
                     x = pae(x if self.pae_unnorm_input else norm_x, logit2d, orc, msk)
                 inter_ctc_logits.append(inter_logit)
-                if self.layer_padding_mask and i + 1 < n:
+                if L in self.compression_layers:
+                    x, lens32, Tp, encoder_padding_mask = self._compress(x, logit2d, L, B, Tp, lens32, encoder_padding_mask)
+                    c = Ctx(B, Tp, lens32, dt)
+                    if self.attn_type == "rel_pos":
+                        c.pos_tab = TABLES.get("rel", Tp, d, x.device, dt)  # :1838-1843: positions follow the new length
+                elif self.layer_padding_mask and i + 1 < n:
                     x = MaskRows.apply(x, lens32, Tp)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
@@ -211,6 +239,25 @@ class S2TTransformerEncoder(nn.Module):
             "src_tokens": [],
             "src_lengths": [],
         }
+
+    def _compress(self, x, logit2d, L, B, T, lens32, mask):
+        """s2t_transformer.py:1948-2040 for layer L.  One D2H copy of the B new lengths decides the new T' (the reference
+        synchronises on ``max(keep_flag.sum(0))`` as well), so this path is eager-only (no hipGraph capture)."""
+        src, new_lens = Fn.ctc_compress_plan(logit2d.detach(), lens32, B, T, 0, self.compression_thresholds[L])
+        nl = new_lens.cpu()
+        kept_all = int(nl.sum()) == B * T  # keep_flag.all(): padded frames count as dropped
+        if int(nl.min()) > 0 and not kept_all:
+            Tn = int(nl.max())
+            x = Fn.CompressRowsFn.apply(x, src, new_lens, B, T, Tn)
+            T, lens32 = Tn, new_lens
+            mask = torch.arange(T, device=x.device)[None, :] >= lens32[:, None]
+        if self.compression_norm:
+            x = getattr(self, "compression_norm%d" % L)(x)
+        if self.compression_pos and self.attn_type != "rel_pos":
+            tab = TABLES.get("sin", max(self.max_positions(), T) + 2, self.embed_dim, x.device)
+            x = AddPositions.apply(x, tab, lens32, T, 1.0)
+        x = MaskRows.apply(x, lens32, T)  # :2037-2040
+        return x, lens32, T, mask
 
     def reorder_encoder_out(self, encoder_out, new_order):
         """s2t_transformer.py:2156-2208."""

@@ -356,3 +356,40 @@ def test_ctc_loss_fwd_bwd(dtype):
     grad = torch.empty(B, T, V, dtype=dtype, device=DEV)
     K.ctc_loss_bwd(ld, V, B, T, V, lse, tmat.to(DEV), S, tl.to(DEV), in_lens.to(DEV), 0, alpha, beta, Lmax, nll, 0.3, grad, V)
     close(grad, lr.grad, dtype, 5 if dtype == torch.float32 else 1)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_ctc_compress_plan_and_rows(dtype):
+    """s2t_ctc_compress_plan + s2t_compress_rows (s2t_transformer.py:1948-1986) against boolean indexing in torch:
+    ragged lengths, an utterance that keeps nothing, T > 256 (several scan rounds), forward gather and backward scatter."""
+    from s2t_amd import functional as Fn
+    g = torch.Generator().manual_seed(12)
+    B, T, V, d = 5, 300, 17, 64
+    lens = torch.tensor([300, 257, 256, 31, 7], dtype=torch.int32)
+    logits = rnd((B * T, V), dtype, g, scale=2.0)
+    logits[:, 0] += 1.5
+    logits.view(B, T, V)[4, :, 0] = 30.0  # utterance 4 is all blank
+    x = rnd((B * T, d), dtype, g)
+    thr = 0.4
+    ld = logits.to(DEV)
+    src, new_lens = Fn.ctc_compress_plan(ld, lens.to(DEV), B, T, 0, thr)
+    pb = torch.softmax(ld.float().view(B, T, V), -1)[:, :, 0].cpu()  # the same rounded logits the kernel saw
+    margin = (pb - thr).abs()
+    keep = (pb < thr) & (torch.arange(T)[None, :] < lens[:, None])
+    assert float(margin[torch.arange(T)[None, :] < lens[:, None]].min()) > 1e-4  # no decision sits on the threshold
+    assert new_lens.cpu().tolist() == keep.sum(1).tolist() and int(new_lens[4]) == 0
+    for b in range(B):
+        assert src[b, : int(new_lens[b])].cpu().tolist() == torch.nonzero(keep[b]).view(-1).tolist()
+    Tn = int(new_lens.max())
+    xd = x.to(DEV).requires_grad_(True)
+    y = Fn.CompressRowsFn.apply(xd, src, new_lens, B, T, Tn)
+    ref = torch.zeros(B, Tn, d, dtype=x.dtype)
+    for b in range(B):
+        ref[b, : int(keep[b].sum())] = x.view(B, T, d)[b][keep[b]]
+    assert torch.equal(y.detach().cpu().view(B, Tn, d), ref)  # pure data movement: bit-exact
+    dy = rnd((B * Tn, d), dtype, g)
+    y.backward(dy.to(DEV))
+    dref = torch.zeros(B, T, d, dtype=x.dtype)
+    for b in range(B):
+        dref[b][keep[b]] = dy.view(B, Tn, d)[b, : int(keep[b].sum())]
+    assert torch.equal(xd.grad.cpu().view(B, T, d), dref)

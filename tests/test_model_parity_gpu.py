@@ -20,7 +20,7 @@ from s2t_amd import s2t_transformer as M  # noqa: E402
 
 DEV = "cuda"
 CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small",
-         "conformer_interctc"]
+         "conformer_interctc", "conformer_compress", "transformer_compress"]
 
 
 def load(golden_dir, name):
@@ -62,6 +62,13 @@ def build(z, dtype, ctc_only=False):
     return model, cfg
 
 
+def _skip_bf16_compress(name, dtype):
+    if name.endswith("_compress") and dtype == torch.bfloat16:
+        # which frames survive is a hard threshold on a posterior: bf16 logits move some across it, after which the
+        # tensors are no longer comparable frame by frame (kernel-level bf16 coverage: test_kernels_gpu.py)
+        pytest.skip("CTC-guided compression is compared in fp32 only")
+
+
 def rel_err(got, ref):
     got = got.detach().float().cpu().numpy()
     return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)
@@ -70,6 +77,7 @@ def rel_err(got, ref):
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
 def test_eval_forward_matches_reference(golden_dir, name, dtype, tol):
+    _skip_bf16_compress(name, dtype)
     z = load(golden_dir, name)
     model, cfg = build(z, dtype)
     model.eval()
@@ -88,12 +96,15 @@ def test_eval_forward_matches_reference(golden_dir, name, dtype, tol):
     i = 0
     while "out::inter_ctc_logit_%d" % i in z.files:
         assert rel_err(enc["inter_ctc_logits"][i][0], z["out::inter_ctc_logit_%d" % i]) < tol
+        if "out::inter_ctc_mask_%d" % i in z.files:
+            assert (enc["inter_ctc_logits"][i][1].cpu().numpy() == z["out::inter_ctc_mask_%d" % i]).all()
         i += 1
 
 
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-4, 5e-3), (torch.bfloat16, 2e-2, 1.5e-1)])
 def test_loss_and_grads_match_reference(golden_dir, name, dtype, tol, gtol):
+    _skip_bf16_compress(name, dtype)
     z = load(golden_dir, name)
     model, cfg = build(z, dtype)
     model.train()
@@ -173,7 +184,8 @@ def test_ctc_greedy_ids_bit_exact(golden_dir, name):
 
 def test_state_dict_keys_match_reference(golden_dir):
     """Checkpoint compatibility: same keys and shapes as the reference's state_dict."""
-    for name in ("transformer_small", "conformer_small", "pds_small", "sate_small"):
+    for name in ("transformer_small", "conformer_small", "pds_small", "sate_small", "conformer_interctc",
+                 "conformer_compress", "transformer_compress"):
         z = load(golden_dir, name)
         model, _ = build(z, torch.float32)
         sd = model.state_dict()
