@@ -475,6 +475,85 @@ def nast_case(name, outdir, V, B, T, seed, **kw):
           "uniform draws", len(unif_draws), "rand draws", [tuple(r.shape) for r in rand_draws])
 
 
+def dataset_case(outdir):
+    """SURVEY.md §8 rows a2/a3 and f3 (on-disk format): a small dataset in the reference's own format — TSV manifest
+    (speech_to_text_dataset.py:594-652), features as .npy members of an UNCOMPRESSED zip addressed by byte offset
+    (:193-264; written like examples/speech_to_text/data_utils.py:101-126), config yaml, dictionary — loaded with the
+    reference's SpeechToTextDatasetCreator.from_tsv; items, ``ordered_indices`` and collated batches (:411-485) are dumped.
+    The dataset directory itself (tests/golden/s2t_dataset/) is data written by this script."""
+    import zipfile
+    from fairseq.data.audio.speech_to_text_dataset import S2TDataConfig, SpeechToTextDatasetCreator
+
+    root = os.path.join(outdir, "s2t_dataset")
+    os.makedirs(root, exist_ok=True)
+    rng = np.random.RandomState(3)
+    n_utt, V = 7, 24
+    words = ["w%d" % i for i in range(V)]
+    with open(os.path.join(root, "dict.txt"), "w") as f:
+        for i, w in enumerate(words):
+            f.write("%s %d\n" % (w, 100 - i))
+    feats, texts = [], []
+    for i in range(n_utt):
+        n = int(rng.randint(20, 60))
+        feats.append((rng.randn(n, 80) * (1 + 0.3 * i) + 0.2 * i).astype(np.float32))
+        toks = [words[int(t)] for t in rng.randint(0, V, size=int(rng.randint(2, 7)))]
+        if i == 2:
+            toks[1] = "oov"  # -> <unk>
+        texts.append(" ".join(toks))
+    zpath = os.path.join(root, "fbank80.zip")
+    with zipfile.ZipFile(zpath, "w", zipfile.ZIP_STORED) as zf:
+        for i, x in enumerate(feats):
+            tmp = os.path.join(root, "utt%d.npy" % i)
+            np.save(tmp, x)
+            zf.write(tmp, arcname="utt%d.npy" % i)
+            os.remove(tmp)
+    with zipfile.ZipFile(zpath, "r") as zf:
+        info = {i.filename: (i.header_offset + 30 + len(i.filename), i.file_size) for i in zf.infolist()}
+    np.save(os.path.join(root, "utt_plain.npy"), feats[0])  # one plain .npy path as well
+    with open(os.path.join(root, "train.tsv"), "w") as f:
+        f.write("id\taudio\tn_frames\ttgt_text\tspeaker\n")
+        for i in range(n_utt):
+            off, size = info["utt%d.npy" % i]
+            audio = "utt_plain.npy" if i == 0 else "fbank80.zip:%d:%d" % (off, size)
+            f.write("utt%d\t%s\t%d\t%s\tspk%d\n" % (i, audio, feats[i].shape[0], texts[i], i % 2))
+    allf = np.concatenate(feats, 0)
+    np.savez(os.path.join(root, "gcmvn.npz"), mean=allf.mean(0), std=allf.std(0))
+    for name, extra in (("config_utt.yaml", "transforms:\n  '*': [utterance_cmvn]\n"),
+                        ("config_global.yaml", "transforms:\n  '*': [global_cmvn]\ncmvn: global\ncmvn_path: gcmvn.npz\n")):
+        with open(os.path.join(root, name), "w") as f:
+            f.write("audio_root: %s\ninput_feat_per_channel: 80\ninput_channels: 1\nvocab_filename: dict.txt\n%s" % ("AUDIO_ROOT", extra))
+    out = {}
+    d = Dictionary.load(os.path.join(root, "dict.txt"))
+    for cfg_name in ("config_utt.yaml", "config_global.yaml"):
+        # the manifest's audio paths are relative: point audio_root at this checkout for the reference run
+        tmp_cfg = os.path.join(root, "_tmp_" + cfg_name)
+        with open(os.path.join(root, cfg_name)) as f, open(tmp_cfg, "w") as g:
+            g.write(f.read().replace("AUDIO_ROOT", root))
+        cfg = S2TDataConfig(tmp_cfg)
+        ds = SpeechToTextDatasetCreator.from_tsv(root, cfg, "train", d, None, None, is_train_split=False, epoch=1, seed=1)
+        os.remove(tmp_cfg)
+        tag = cfg_name.split(".")[0]
+        out[tag + "::ordered_indices"] = np.asarray(ds.ordered_indices(), dtype=np.int64)
+        idx = [4, 0, 6, 2, 5]
+        items = [ds[i] for i in idx]
+        for i, it in zip(idx, items):
+            out[tag + "::item_%d_source" % i] = np_(it[1])
+            out[tag + "::item_%d_target" % i] = np_(it[2])
+        b = ds.collater(items)
+        out[tag + "::batch_idx"] = np.array(idx, dtype=np.int64)
+        out[tag + "::id"] = np_(b["id"])
+        out[tag + "::src_tokens"] = np_(b["net_input"]["src_tokens"])
+        out[tag + "::src_lengths"] = np_(b["net_input"]["src_lengths"])
+        out[tag + "::prev_output_tokens"] = np_(b["net_input"]["prev_output_tokens"])
+        out[tag + "::target"] = np_(b["target"])
+        out[tag + "::target_lengths"] = np_(b["target_lengths"])
+        out[tag + "::ntokens"] = np.int64(b["ntokens"])
+        out[tag + "::nsentences"] = np.int64(b["nsentences"])
+        out[tag + "::sizes"] = np.asarray(ds.sizes, dtype=np.int64)
+    np.savez_compressed(os.path.join(outdir, "s2t_dataset_expected.npz"), **out)
+    print("dataset ok", out["config_utt::src_tokens"].shape, out["config_utt::target"].tolist())
+
+
 def module_cases(outdir):
     from fairseq.modules import LayerNorm
     from fairseq.modules.positional_encoding import RelPositionalEncoding
@@ -549,6 +628,10 @@ def main():
                 inter_xctc_weight=1.0, inter_xctc_layers="2,3", ctc_pae="inter_league", xctc_pae="inter_league",
                 xctc_cross_attn=True, cross_attn_start_layer=3, cross_attn_layer=2, cross_attn_collaboration_mode="serial",
                 cross_attn_league_drop_net=True, xctc_pae_ground_truth_only_mistake=True, pae_oracle_smooth=True)
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "dataset"):
+        dataset_case(outdir)
+    if os.environ.get("GOLDEN_ONLY", "") == "dataset":
+        return
     if os.environ.get("GOLDEN_ONLY", "") in ("", "compress"):
         # egs/*/conf/dynamic.yaml on top of inter.yaml: CTC-guided compression after the intermediate CTC layers.
         # The blank logit is lifted so that the blank posterior straddles the threshold (seeded weights alone would

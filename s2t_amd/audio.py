@@ -148,6 +148,72 @@ class UtteranceCMVN:
         return y.cpu().numpy() if as_numpy else y
 
 
+@register_audio_feature_transform("global_cmvn")
+class GlobalCMVN:
+    """data/audio/feature_transforms/global_cmvn.py — (x - mean) / std with the per-bin statistics of a ``.npz``
+    (keys ``mean``, ``std``).  One per-column affine launch (``s2t_bn_act_fwd`` with the identity activation:
+    y = x * (1/std) + (-mean/std))."""
+
+    @classmethod
+    def from_config_dict(cls, config: Optional[Dict] = None):
+        _config = {} if config is None else config
+        return GlobalCMVN(_config.get("stats_npz_path"))
+
+    def __init__(self, stats_npz_path):
+        self.stats_npz_path = stats_npz_path
+        stats = np.load(stats_npz_path)
+        self.mean, self.std = stats["mean"], stats["std"]
+        self._dev = None
+
+    def __repr__(self):
+        return self.__class__.__name__ + f'(stats_npz_path="{self.stats_npz_path}")'
+
+    def apply_batch(self, feat: torch.Tensor, n_frames: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feat (B, T, C) fp32 CUDA; rows at or beyond n_frames[b] come out zero (the collater's padding)."""
+        if not feat.is_cuda:
+            raise RuntimeError("s2t_amd.audio runs on the GPU only; there is no CPU fallback")
+        if self._dev is None or self._dev[0].device != feat.device:
+            inv = 1.0 / np.asarray(self.std, dtype=np.float64)
+            self._dev = (torch.tensor(inv, dtype=torch.float32, device=feat.device),
+                         torch.tensor(-np.asarray(self.mean, dtype=np.float64) * inv, dtype=torch.float32, device=feat.device))
+        feat = feat.contiguous()
+        B, T, C = feat.shape
+        out = torch.empty_like(feat)
+        lens = None if n_frames is None else n_frames.to(device=feat.device, dtype=torch.int32)
+        K.bn_act_fwd(feat, out, self._dev[0], self._dev[1], "none", B * T, C, lens, T)
+        return out
+
+    def __call__(self, x):
+        as_numpy = isinstance(x, np.ndarray)
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if as_numpy else x.float()
+        y = self.apply_batch(t.cuda().unsqueeze(0))[0]
+        return y.cpu().numpy() if as_numpy else y
+
+
+class CompositeAudioFeatureTransform:
+    """feature_transforms/__init__.py:51-82 — the configured transforms applied in order."""
+
+    @classmethod
+    def from_config_dict(cls, config=None):
+        _config = {} if config is None else config
+        _transforms = _config.get("transforms")
+        if _transforms is None:
+            return None
+        return CompositeAudioFeatureTransform(
+            [get_audio_feature_transform(t).from_config_dict(_config.get(t)) for t in _transforms])
+
+    def __init__(self, transforms):
+        self.transforms = [t for t in transforms if t is not None]
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+    def __repr__(self):
+        return self.__class__.__name__ + "(" + ", ".join(repr(t) for t in self.transforms) + ")"
+
+
 @register_audio_feature_transform("specaugment")
 class SpecAugmentTransform:
     """data/audio/feature_transforms/specaugment.py — SpecAugment frequency and time masking.  The interval draws use
