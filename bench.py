@@ -111,13 +111,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    # S2T_DIST_BACKEND=gloo rehearses the multi-rank choreography on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("S2T_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # S2T_FORCE_DDP=1 (under torch.distributed.run with one rank) exercises the RCCL + hipGraph path on a single GPU
     force_ddp = os.environ.get("S2T_FORCE_DDP") == "1" and "RANK" in os.environ
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     import __graft_entry__ as entry
@@ -185,11 +192,12 @@ def main():
     loss_val = float(out[0])
 
     result = None
+    # ---- roofline leg: one instrumented eager step, HIP events around every GEMM launch on the launch stream.  EVERY rank
+    # takes the step (its gradient all-reduce must pair up across ranks); only rank 0 records and reports.
+    K.GEMM_PROFILE = [] if rank == 0 else None
+    trainer.train_step(sample, ntok_global)
+    torch.cuda.synchronize()
     if rank == 0:
-        # ---- roofline leg: one instrumented eager step, HIP events around every GEMM launch on the launch stream
-        K.GEMM_PROFILE = []
-        trainer.train_step(sample, ntok_global)
-        torch.cuda.synchronize()
         prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
         agg = {}
         for sym, flops, e0, e1, shape in prof:
