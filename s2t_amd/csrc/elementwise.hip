@@ -142,6 +142,56 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ Z, c
   st4_from_f32<T>(dZ + row * 2 * n + n + c, dg);
 }
 
+// bf16 fast path for row widths of 256 / 512 / 1024 / 2048: one 16-byte load per lane (8 columns), TPR = n / 8 lanes per
+// row, 256 / TPR rows per pass, eight passes in flight; the rows are cut into at most 128 slices so that the closing
+// atomics (n per workgroup, executed at the memory side) stay few.
+template <int TPR>
+__global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __restrict__ dY, int64_t ld,
+                                                            float* __restrict__ db, int64_t rows) {
+  constexpr int RPP = 256 / TPR;  // rows per pass
+  __shared__ float red[RPP][TPR * 8];
+  const int cl = threadIdx.x % TPR, rg = threadIdx.x / TPR;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const bf16_t* base = dY + cl * 8;
+  int64_t m = r0 + rg;
+  for (; m + 7 * RPP < r1; m += 8 * RPP) {
+    uint4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const uint4*>(base + (m + u * RPP) * ld);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t w4[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[2 * q] += __uint_as_float(w4[q] << 16);
+        acc[2 * q + 1] += __uint_as_float(w4[q] & 0xffff0000u);
+      }
+    }
+  }
+  for (; m < r1; m += RPP) {
+    const uint4 t = *reinterpret_cast<const uint4*>(base + m * ld);
+    const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[2 * q] += __uint_as_float(w4[q] << 16);
+      acc[2 * q + 1] += __uint_as_float(w4[q] & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rg][cl * 8 + i] = acc[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < TPR * 8; c += 256) {
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < RPP; ++g) sum += red[g][c];
+    atomicAdd(db + c, sum);
+  }
+}
+
 // ---- bias gradient: db[n] += sum_m dY[m,n]  (fp32 accumulate) ----
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, int64_t ld, float* __restrict__ db,
@@ -366,6 +416,18 @@ extern "C" int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db
   if (!dY || !db || rows < 0 || n <= 0) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   if (ld % 4 || ((uintptr_t)dY % 16)) return S2T_ERR_ALIGN;
+  if (dtype == S2T_BF16 && ld % 8 == 0 && (n == 256 || n == 512 || n == 1024 || n == 2048) && rows >= 512) {
+    int64_t sl = (rows + 63) / 64;
+    if (sl > 128) sl = 128;
+    dim3 g((unsigned)sl);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* src = (const bf16_t*)dY;
+    if (n == 256) hipLaunchKernelGGL(colsum_bf16x8_kernel<32>, g, dim3(256), 0, st, src, ld, db, rows);
+    else if (n == 512) hipLaunchKernelGGL(colsum_bf16x8_kernel<64>, g, dim3(256), 0, st, src, ld, db, rows);
+    else if (n == 1024) hipLaunchKernelGGL(colsum_bf16x8_kernel<128>, g, dim3(256), 0, st, src, ld, db, rows);
+    else hipLaunchKernelGGL(colsum_bf16x8_kernel<256>, g, dim3(256), 0, st, src, ld, db, rows);
+    return S2T_LAUNCH_CHECK();
+  }
   int64_t slices = (rows + 31) / 32;  // 8 rows per wave
   if (slices > 1024) slices = 1024;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)slices);

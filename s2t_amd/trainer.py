@@ -116,12 +116,15 @@ class Trainer:
             # RCCL collectives stay OUTSIDE the capture (the process-group watchdog thread polls events, which a
             # capturing stream forbids): graph 1 = forward + backward, eager bucketed all-reduce, graph 2 = clip + Adam.
             # The reduction is then not overlapped with backward (it is in the eager path).
-            with torch.cuda.graph(self._graph):
+            # capture_error_mode="thread_local": the watchdog thread may still be querying the events of the eager
+            # all-reduce that preceded the capture; under the default global mode that query is an error that aborts
+            # the process (an intermittent SIGABRT, depending on when the watchdog last polled)
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self._graph_out = self._fwd_bwd(sample, overlap=False)
             self.ddp.all_reduce_grads()
             self._graph2 = torch.cuda.CUDAGraph()
             self._ssg = sample_size_global
-            with torch.cuda.graph(self._graph2, pool=self._graph.pool()):
+            with torch.cuda.graph(self._graph2, pool=self._graph.pool(), capture_error_mode="thread_local"):
                 self._update(sample_size_global)
         else:
             with torch.cuda.graph(self._graph):

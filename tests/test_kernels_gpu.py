@@ -168,6 +168,12 @@ def test_glu_bwd_colsum_cast_axpy(dtype):
     db = torch.ones(N, device=DEV)
     K.colsum_accum(dy.to(DEV), 72, db, M, N)
     close(db - 1, dy.float()[:, :N].sum(0), torch.float32, 50 if dtype == torch.bfloat16 else 5)
+    # the 16-byte fast path (bf16, widths 256..2048, strided rows, ragged last slice)
+    for Nw, Mr, ldw in ((256, 16000, 256), (512, 4099, 520), (1024, 777, 1024), (2048, 513, 2048)):
+        dyw = rnd((Mr, ldw), dtype, g)
+        dbw = torch.full((Nw,), 2.0, device=DEV)
+        K.colsum_accum(dyw.to(DEV), ldw, dbw, Mr, Nw)
+        close(dbw - 2, dyw.float()[:, :Nw].sum(0), torch.float32, 400 if dtype == torch.bfloat16 else 20)
     src = torch.randn(1024, generator=g)
     dst = torch.empty(1024, dtype=torch.bfloat16, device=DEV)
     K.cast_f32_to_bf16(src.to(DEV), dst, 1024)
