@@ -1062,11 +1062,34 @@ def label_smoothed_ce(logits, target, eps, pad_idx):
     return LabelSmoothedCEFn.apply(logits, target, eps, pad_idx, torch.is_grad_enabled() and logits.requires_grad)
 
 
+_SIDE = {"streams": {}, "pending": []}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE["streams"]:
+        _SIDE["streams"][key] = torch.cuda.Stream(device=device)
+    return _SIDE["streams"][key]
+
+
+def join_side_streams():
+    """Make the current stream wait for every side-stream branch opened since the last join (``ctc_loss(side=True)``)."""
+    cur = torch.cuda.current_stream()
+    for st, _keep in _SIDE["pending"]:
+        cur.wait_stream(st)
+    _SIDE["pending"] = []  # the buffers kept alive for the side branches may now return to the allocator
+
+
 class CTCLossFn(torch.autograd.Function):
-    """sum_b CTC nll_b with zero_infinity (criterions/ctc.py:243-245,435-474); logits are batch-major [B*T, V]."""
+    """sum_b CTC nll_b with zero_infinity (criterions/ctc.py:243-245,435-474); logits are batch-major [B*T, V].
+
+    ``side=True``: the forward kernels (row logsumexp, alpha/beta: one or two workgroups per utterance walking T' dependent
+    steps, i.e. a long thin launch that leaves most CUs idle) are issued on a side stream so that they run beside whatever
+    the caller launches next (the decoder); every buffer is allocated on the calling stream first, so allocator lifetimes
+    stay ordered on it, and the caller must ``join_side_streams()`` before it consumes the returned loss."""
 
     @staticmethod
-    def forward(ctx, logits, B, T, targets, tgt_lens, in_lens, blank):
+    def forward(ctx, logits, B, T, targets, tgt_lens, in_lens, blank, side):
         V = logits.shape[1]
         dev = logits.device
         S = targets.shape[1]
@@ -1074,14 +1097,31 @@ class CTCLossFn(torch.autograd.Function):
         lse = torch.empty(B * T, dtype=torch.float32, device=dev)
         assert logits.stride(1) == 1
         ld = logits.stride(0)
-        K.argmax_lse(logits, ld, B * T, V, None, None, lse)
         alpha = torch.empty(B, T, Lmax, dtype=torch.float32, device=dev)
         beta = torch.empty(B, T, Lmax, dtype=torch.float32, device=dev)
         nll = torch.empty(B, dtype=torch.float32, device=dev)
-        K.ctc_loss_fwd(logits, ld, B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll)
+        clean = torch.empty(B, dtype=torch.float32, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+
+        def run():
+            K.argmax_lse(logits, ld, B * T, V, None, None, lse)
+            K.ctc_loss_fwd(logits, ld, B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll)
+            torch.nan_to_num(nll, nan=float("nan"), posinf=0.0, out=clean)  # zero_infinity
+            torch.sum(clean, dim=0, out=out)
+
+        if side:
+            st = _side_stream(dev)
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                run()
+            # every buffer the branch touches was allocated on the calling stream: it must not go back to that stream's
+            # allocator (e.g. under no_grad, where nothing is saved for backward) before the join
+            _SIDE["pending"].append((st, (logits, lse, alpha, beta, nll, clean, out, targets, tgt_lens, in_lens)))
+        else:
+            run()
         ctx.save_for_backward(logits, lse, alpha, beta, nll, targets, tgt_lens, in_lens)
         ctx.dims = (B, T, V, S, Lmax, blank)
-        return torch.where(torch.isinf(nll), torch.zeros_like(nll), nll).sum()
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -1091,11 +1131,11 @@ class CTCLossFn(torch.autograd.Function):
         gs = g.detach().reshape(1).float().contiguous()  # upstream gradient of the summed loss, stays on the device
         K.ctc_loss_bwd(logits, logits.stride(0), B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll,
                        1.0, grad, grad.stride(0), gscale_dev=gs)
-        return grad, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None
 
 
-def ctc_loss(logits, B, T, targets, tgt_lens, in_lens, blank=0):
-    return CTCLossFn.apply(logits, B, T, targets, tgt_lens, in_lens, blank)
+def ctc_loss(logits, B, T, targets, tgt_lens, in_lens, blank=0, side=False):
+    return CTCLossFn.apply(logits, B, T, targets, tgt_lens, in_lens, blank, bool(side))
 
 
 # ------------------------------------------------------------------------------------------------
