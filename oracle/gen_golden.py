@@ -693,6 +693,13 @@ def main():
     if os.environ.get("GOLDEN_ONLY", "") in ("", "pds"):
         encdec_case("pds_small", outdir, "pdss2t_transformer_s_8", V=40, B=3, T=67, seed=6, **pds)
         encdec_case("pds_conformer_small", outdir, "pdss2t_transformer_s_8", V=40, B=3, T=64, seed=7, train_bn=True, **pds, **conf)
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "pdsfusion"):
+        # pds_base_8.yaml's fusion settings switched on (the recipes ship them with pds-fusion False)
+        encdec_case("pds_fusion_small", outdir, "pdss2t_transformer_s_8", V=40, B=3, T=67, seed=41, train_bn=True,
+                    **dict(pds, pds_fusion=True), pds_fusion_method="all_conv2", pds_fusion_layers="0_1_1_1",
+                    pds_fusion_weight="0.2_0.3_0.5")
+    if os.environ.get("GOLDEN_ONLY", "") == "pdsfusion":
+        return
     sate = dict(small, text_encoder_layers=2, acoustic_encoder="transformer", adapter="inter_league",
                 textual_encoder_embed_norm=True, textual_encoder_no_scale_embedding=True, encoder_normalize_before=True,
                 decoder_normalize_before=True)

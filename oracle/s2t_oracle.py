@@ -803,6 +803,23 @@ def _ints(v):
     return [int(t) for t in str(v).split("_")]
 
 
+def pds_fusion_stages(cfg):
+    """pdss2t_transformer.py:357-391,588-600: the 0-based stages whose outputs are fused (method ``all``; ``conv2``
+    transform); fewer than two flagged stages switch fusion off."""
+    if not cfg.get("pds_fusion", False):
+        return []
+    method = str(cfg.get("pds_fusion_method", "none"))
+    if method in ("none", "None", ""):
+        return []
+    kind, _, transform = method.partition("_")
+    if kind != "all" or (transform or "conv") != "conv2":
+        raise NotImplementedError("pds_fusion_method %s" % method)
+    flags = _ints(cfg["pds_fusion_layers"])
+    stages = [i for i, f in enumerate(flags) if f]
+    n = min(int(cfg["pds_stages"]), len(stages))
+    return stages if n > 1 else []
+
+
 def pds_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix="encoder.", bn_stats=None):
     """models/speech_to_text/pdss2t_transformer.py:1042-1281 (no fusion / inter-CTC / mixup):
     pad T up to the NEXT multiple of prod(ratios) (always pads: +prod when already aligned, :1050-1055);
@@ -824,6 +841,7 @@ def pds_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix=
     lens = src_lengths
     lcfg = dict(cfg)
     lcfg["activation_fn"] = cfg.get("encoder_activation_fn", "relu")  # conv-module activation rule of PDS layers
+    prev_state, prev_mask = [], []
     for i in range(int(cfg["pds_stages"])):
         st = i + 1
         Tn = x.size(1)
@@ -847,6 +865,44 @@ def pds_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix=
         lcfg["encoder_attention_heads"] = heads[i]
         for j in range(layers[i]):
             x = encoder_layer(x, mask, pos_tab, W, f"{prefix}stage{st}.{j}.", lcfg, training, bn_stats)
+        prev_state.append(x)
+        prev_mask.append(mask)
+    fusion = pds_fusion_stages(cfg)
+    if fusion:
+        # multi-scale representation fusion (:1187-1233, ``all_conv2``): every flagged stage output -> pre LayerNorm ->
+        # DownSampleConvolutionModule (modules/downsample_convolution.py:75-123: mask, pointwise conv (bias), depthwise
+        # conv kernel = stride = the remaining down-sampling ratio (bias, no padding), BatchNorm, Swish, pointwise conv
+        # (bias), mask at floor(len / stride)) -> post LayerNorm; x = sum_i fusion_weight_i * state_i
+        fw = [float(t) for t in str(cfg["pds_fusion_weight"]).split("_")]
+        acc = None
+        for n_f, i in enumerate(fusion):
+            st = i + 1
+            s_, m_ = prev_state[i], prev_mask[i]
+            if cfg.get("pds_fusion_mask", False):
+                s_ = s_.masked_fill(m_[:, :, None], 0.0)
+            if not cfg.get("pds_fusion_no_prenorm", False):
+                s_ = layer_norm(s_, W[f"{prefix}fusion_pre_layer_norm{st}.weight"], W[f"{prefix}fusion_pre_layer_norm{st}.bias"])
+            q = f"{prefix}fusion_downsampling{st}."
+            s_ = s_.masked_fill(m_[:, :, None], 0.0)
+            y = linear(s_, W[q + "pointwise_conv1.weight"][:, :, 0], W[q + "pointwise_conv1.bias"])
+            wd = W[q + "depthwise_conv.weight"]
+            r = wd.size(2)
+            y = F.conv1d(y.transpose(1, 2), wd, W[q + "depthwise_conv.bias"], stride=r, groups=wd.size(0)).transpose(1, 2)
+            if training:
+                mean = y.mean(dim=(0, 1))
+                var = ((y - mean) ** 2).mean(dim=(0, 1))
+                if bn_stats is not None:
+                    bn_stats[q[:-1] + ".norm"] = (mean, var, y.size(0) * y.size(1))
+            else:
+                mean, var = W[q + "norm.running_mean"], W[q + "norm.running_var"]
+            y = (y - mean) / torch.sqrt(var + 1e-5) * W[q + "norm.weight"] + W[q + "norm.bias"]
+            y = activation("swish", y)
+            y = linear(y, W[q + "pointwise_conv2.weight"][:, :, 0], W[q + "pointwise_conv2.bias"])
+            ol = ((~m_).sum(-1) / r).long()
+            y = y.masked_fill(lengths_to_padding_mask(ol, y.size(1))[:, :, None], 0.0)
+            y = layer_norm(y, W[f"{prefix}fusion_post_layer_norm{st}.weight"], W[f"{prefix}fusion_post_layer_norm{st}.bias"])
+            acc = fw[n_f] * y if acc is None else acc + fw[n_f] * y
+        x = acc
     x = layer_norm(x, W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"])
     out = {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": [mask], "ctc_logit": []}
     if prefix + "ctc.ctc_projection.weight" in W:

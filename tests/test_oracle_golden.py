@@ -9,7 +9,7 @@ import torch
 from oracle import s2t_oracle as O
 
 CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small",
-         "conformer_interctc", "conformer_compress", "transformer_compress"]
+         "conformer_interctc", "conformer_compress", "transformer_compress", "pds_fusion_small"]
 
 
 def _load(golden_dir, name):
