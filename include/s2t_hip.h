@@ -342,6 +342,19 @@ int s2t_ctc_compress_plan(int dtype, const void* logits, int64_t ld, const float
 int s2t_compress_rows(int dtype, const void* in, void* out, const int32_t* src, const int32_t* new_lens, int B, int T,
                       int Tn, int C, int scatter, void* stream);
 
+/* ---- PDS multi-scale fusion: depthwise convolution with kernel = stride = r, no padding --------
+ * The depthwise stage of DownSampleConvolutionModule (fairseq/modules/downsample_convolution.py:45-54,97-100) as used by
+ * PDSS2TTransformerEncoder.forward, pdss2t_transformer.py:1187-1233.  x [B][Tin][C] channels-last, w [C][r] fp32,
+ * y / dy [B][Tout = Tin / r][C]; r <= 8.
+ * s2t_dwpool_fwd : y = bias + sum_k x[t*r + k] * w[k]; stats != NULL: one row [2][C] of partial (sum y | sum y^2) per
+ *                  workgroup, s2t_dwpool_stat_partials(B, Tout) rows, for s2t_bn_finalize.
+ * s2t_dwpool_bwd : dx (rows t < Tout*r; the caller zero-fills a ragged tail), dw[c][k] += sum dy*x, db[c] += sum dy. */
+int s2t_dwpool_stat_partials(int B, int Tout);
+int s2t_dwpool_fwd(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int Tin, int C, int r,
+                   float* stats, void* stream);
+int s2t_dwpool_bwd(int dtype, const void* x, const float* w, const void* dy, void* dx, float* dw, float* db, int B, int Tin,
+                   int C, int r, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -918,6 +918,66 @@ def conv_module(x, residual, prm, bn_buf, act, B, T, lens, training, momentum=0.
 
 
 # ------------------------------------------------------------------------------------------------
+# PDS multi-scale fusion: depthwise (kernel = stride = r) conv + BatchNorm + activation
+# ------------------------------------------------------------------------------------------------
+class PoolBnActFn(torch.autograd.Function):
+    """a = act(BN(bias + sum_k x[t*r + k] * w[k])) on channels-last rows: the middle of DownSampleConvolutionModule
+    (fairseq/modules/downsample_convolution.py:97-106).  BatchNorm statistics over all B*T' rows, padded ones included,
+    like nn.BatchNorm1d on the (B, C, T') tensor."""
+
+    @staticmethod
+    def forward(ctx, x, prm, bn_buf, act, B, T, r, training, momentum, train):
+        M, d = x.shape
+        dt, dev = x.dtype, x.device
+        To = T // r
+        Mo = B * To
+        wd = prm["dw_w"].data.view(d, r)
+        D = torch.empty(Mo, d, dtype=dt, device=dev)
+        scale = torch.empty(d, dtype=torch.float32, device=dev)
+        shift = torch.empty(d, dtype=torch.float32, device=dev)
+        mean = rstd = None
+        if training:
+            stats = torch.empty(K.dwpool_stat_partials(B, To), 2, d, dtype=torch.float32, device=dev)
+            K.dwpool_fwd(x, wd, prm["dw_b"].data, D, B, T, d, r, stats=stats)
+            mean = torch.empty(d, dtype=torch.float32, device=dev)
+            rstd = torch.empty(d, dtype=torch.float32, device=dev)
+            K.bn_finalize(stats, Mo, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
+                          momentum, 1e-5, True, scale, shift, mean, rstd, d)
+        else:
+            K.dwpool_fwd(x, wd, prm["dw_b"].data, D, B, T, d, r)
+            K.bn_finalize(None, 0, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
+                          momentum, 1e-5, False, scale, shift, None, None, d)
+        a = torch.empty(Mo, d, dtype=dt, device=dev)
+        K.bn_act_fwd(D, a, scale, shift, act, Mo, d)
+        if train:
+            assert training, "gradients through the fusion convolution need training-mode BatchNorm"
+            ctx.save_for_backward(x, D, scale, shift, mean, rstd)
+        ctx.prm, ctx.act, ctx.dims = prm, act, (B, T, To, d, r)
+        return a
+
+    @staticmethod
+    def backward(ctx, dA):
+        x, D, scale, shift, mean, rstd = ctx.saved_tensors
+        prm = ctx.prm
+        B, T, To, d, r = ctx.dims
+        Mo = B * To
+        dt, dev = x.dtype, x.device
+        dD = torch.empty(Mo, d, dtype=dt, device=dev)
+        sums = torch.empty(2 * d, dtype=torch.float32, device=dev)
+        K.bn_act_bwd(D, dA.contiguous(), dD, scale, shift, mean, rstd, sums, Mo, ctx.act, Mo, d)
+        prm["bn_b"].grad.add_(sums[:d])
+        prm["bn_w"].grad.add_(sums[d:])
+        dx = (torch.zeros if To * r != T else torch.empty)(B * T, d, dtype=dt, device=dev)
+        K.dwpool_bwd(x, prm["dw_w"].data.view(d, r), dD, dx, prm["dw_w"].grad.view(d, r), prm["dw_b"].grad, B, T, d, r)
+        _ready(prm["dw_w"], prm["dw_b"], prm["bn_w"], prm["bn_b"])
+        return dx, None, None, None, None, None, None, None, None, None
+
+
+def pool_bn_act(x, prm, bn_buf, act, B, T, r, training, momentum=0.1):
+    return PoolBnActFn.apply(x, prm, bn_buf, act, B, T, r, training, momentum, torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------
 # Conv1d subsampler
 # ------------------------------------------------------------------------------------------------
 def _conv_out_len(T):

@@ -311,6 +311,20 @@ def ctc_prefix_score(lp, T, in_lens, sent, r_prev, last, out_len, cand, blank, e
           last.data_ptr(), out_len, cand.data_ptr(), R, Kc, blank, eos, psi.data_ptr(), _ptr(r_new))
 
 
+def dwpool_stat_partials(B, Tout):
+    return L.lib().s2t_dwpool_stat_partials(B, Tout)
+
+
+def dwpool_fwd(x, w, bias, y, B, Tin, C, r, stats=None):
+    _call("s2t_dwpool_fwd", L.dtype_id(x.dtype), x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), B, Tin, C, r,
+          _ptr(stats))
+
+
+def dwpool_bwd(x, w, dy, dx, dw, db, B, Tin, C, r):
+    _call("s2t_dwpool_bwd", L.dtype_id(x.dtype), x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+          db.data_ptr(), B, Tin, C, r)
+
+
 def ctc_compress_plan(logits, lse, lens, B, T, blank, threshold, src, new_lens):
     _call("s2t_ctc_compress_plan", L.dtype_id(logits.dtype), logits.data_ptr(), logits.stride(0), lse.data_ptr(),
           lens.data_ptr(), B, T, blank, float(threshold), src.data_ptr(), new_lens.data_ptr())

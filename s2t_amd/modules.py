@@ -237,6 +237,49 @@ class ConvolutionModule(nn.Module):
                               self.norm.momentum, self.dropout_p)
 
 
+class _ConvWB(nn.Module):
+    """Conv1d weight + bias holder with nn.Conv1d's default initialisation."""
+
+    def __init__(self, shape, fan_in):
+        super().__init__()
+        bound = 1 / math.sqrt(fan_in)
+        self.weight = nn.Parameter(torch.empty(*shape).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(shape[0]).uniform_(-bound, bound))
+
+
+class DownSampleConvolutionModule(nn.Module):
+    """fairseq/modules/downsample_convolution.py:15-123 — keys pointwise_conv1, depthwise_conv, norm, pointwise_conv2 (all
+    with biases): mask -> pointwise conv -> depthwise conv with kernel = stride = ratio, no padding -> BatchNorm ->
+    Swish -> pointwise conv -> mask at floor(len / ratio).  Used by the PDS multi-scale fusion
+    (pdss2t_transformer.py:1187-1233, transform ``conv2``)."""
+
+    def __init__(self, channels, kernel_size, input_channels=None, stride=1):
+        super().__init__()
+        if kernel_size != stride:
+            raise NotImplementedError("DownSampleConvolutionModule with kernel != stride")
+        cin = input_channels or channels
+        self.stride = stride
+        self.pointwise_conv1 = _ConvWB((channels, cin, 1), cin)
+        self.depthwise_conv = _ConvWB((channels, 1, kernel_size), kernel_size)
+        self.norm = _BatchNorm1d(channels)
+        self.pointwise_conv2 = _ConvWB((channels, channels, 1), channels)
+
+    def forward(self, x, B, T, lens):
+        """x [B*T, Cin] -> ([B*(T // stride), C], T // stride, new lens)."""
+        x = MaskRows.apply(x, lens, T)
+        y = Fn.linear(x, self.pointwise_conv1.weight, self.pointwise_conv1.bias)
+        prm = {"dw_w": self.depthwise_conv.weight, "dw_b": self.depthwise_conv.bias, "bn_w": self.norm.weight,
+               "bn_b": self.norm.bias}
+        buf = {"running_mean": self.norm.running_mean, "running_var": self.norm.running_var}
+        if self.training:
+            self.norm.num_batches_tracked += 1
+        a = Fn.pool_bn_act(y, prm, buf, "swish", B, T, self.stride, self.training, self.norm.momentum)
+        To = T // self.stride
+        y = Fn.linear(a, self.pointwise_conv2.weight, self.pointwise_conv2.bias)
+        out_lens = torch.div(lens, self.stride, rounding_mode="floor").to(torch.int32)
+        return MaskRows.apply(y, out_lens, To), To, out_lens
+
+
 class S2TTransformerEncoderLayer(nn.Module):
     """modules/s2t_transformer_layer.py:69-322 (pre-LN; macaron / conv-module / rel_pos variants)."""
 

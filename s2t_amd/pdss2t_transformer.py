@@ -13,7 +13,8 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from .modules import (CTC, TABLES, Ctx, LayerNorm, MaskRows, S2TTransformerEncoderLayer, _Conv1dK)
+from .modules import (CTC, TABLES, Ctx, DownSampleConvolutionModule, LayerNorm, MaskRows, S2TTransformerEncoderLayer,
+                      _Conv1dK)
 from .registry import register_model, register_model_architecture
 from .s2t_transformer import (AddPositions, Embedding, S2TTransformerModel, TransformerDecoderScriptable, _HipModel,
                               _SinPosHolder, _d, _unsupported, base_architecture as _s2t_base)
@@ -51,7 +52,7 @@ class Downsampling(nn.Module):
 class PDSS2TTransformerEncoder(nn.Module):
     def __init__(self, args, task=None, embed_tokens=None):
         super().__init__()
-        _unsupported(args, inter_mixup=False, pds_fusion=False, inter_ctc_layers=None, inter_xctc_layers=None, xctc_weight=0,
+        _unsupported(args, inter_mixup=False, inter_ctc_layers=None, inter_xctc_layers=None, xctc_weight=0,
                      pds_final_layers=0)
         self.dropout_p = float(args.dropout or 0.0)
         self.pds_dropout_p = float(getattr(args, "pds_dropout", args.dropout) or 0.0)
@@ -81,6 +82,32 @@ class PDSS2TTransformerEncoder(nn.Module):
                                            conv_activation=getattr(args, "encoder_activation_fn", "relu"))
                 for _ in range(self.pds_layers[i])])
             setattr(self, f"stage{i + 1}", stage)
+        # multi-scale representation fusion (pdss2t_transformer.py:357-391,588-640,1187-1233; ``all_conv2``): the flagged
+        # stage outputs -> fusion_pre_layer_norm{i} -> DownSampleConvolutionModule down to the last stage's frame rate ->
+        # fusion_post_layer_norm{i}; x = sum_i fusion_weight_i * state_i (fixed weights from --pds-fusion-weight)
+        self.fusion_stages = []
+        method = str(getattr(args, "pds_fusion_method", "none") or "none")
+        if getattr(args, "pds_fusion", False) and method not in ("none", "None"):
+            kind, _, transform = method.partition("_")
+            if kind != "all" or (transform or "conv") != "conv2":
+                raise NotImplementedError("--pds-fusion-method %s (HIP path: all_conv2)" % method)
+            if getattr(args, "pds_fusion_weight", None) is None:
+                raise NotImplementedError("learned fusion weights (give --pds-fusion-weight)")
+            flags = _ints(args.pds_fusion_layers)
+            stages = [i for i, f in enumerate(flags) if f]
+            if min(self.pds_stages, len(stages)) > 1:
+                self.fusion_stages = stages
+                self.fusion_weight = [float(t) for t in str(args.pds_fusion_weight).split("_")]
+                assert len(self.fusion_weight) == len(stages)
+                self.fusion_mask = bool(getattr(args, "pds_fusion_mask", False))
+                self.fusion_no_prenorm = bool(getattr(args, "pds_fusion_no_prenorm", False))
+                for i in stages:
+                    ratio = reduce(lambda a, b: a * b, self.pds_ratios[i + 1:], 1)
+                    setattr(self, f"fusion_downsampling{i + 1}",
+                            DownSampleConvolutionModule(self.embed_dim, kernel_size=ratio, stride=ratio,
+                                                        input_channels=self.pds_embed_dims[i]))
+                    setattr(self, f"fusion_pre_layer_norm{i + 1}", LayerNorm(self.pds_embed_dims[i]))
+                    setattr(self, f"fusion_post_layer_norm{i + 1}", LayerNorm(self.embed_dim))
         self.layer_norm = LayerNorm(self.embed_dim) if args.encoder_normalize_before else None
         self.use_ctc = getattr(args, "ctc_weight", 0) > 0
         if self.use_ctc:
@@ -112,6 +139,7 @@ class PDSS2TTransformerEncoder(nn.Module):
         x[:, :T].copy_(src_tokens)
         x = x.view(B * Tn, C)
         lens32 = src_lengths.to(torch.int32)
+        states = []
         for i in range(self.pds_stages):
             x, Tn, lens32 = getattr(self, f"downsampling{i + 1}")(x, B, Tn, lens32)
             d = self.pds_embed_dims[i]
@@ -125,6 +153,20 @@ class PDSS2TTransformerEncoder(nn.Module):
             x = Fn.dropout(x, self.dropout_p if i == 0 else self.pds_dropout_p, self.training)  # :1118-1121
             for layer in getattr(self, f"stage{i + 1}"):
                 x = layer(x, c, mask_output=False)
+            states.append((x, Tn, lens32))
+        if self.fusion_stages:
+            fused = None
+            for wgt, i in zip(self.fusion_weight, self.fusion_stages):
+                s_, Ti, li = states[i]
+                if self.fusion_mask:
+                    s_ = MaskRows.apply(s_, li, Ti)
+                if not self.fusion_no_prenorm:
+                    s_ = getattr(self, f"fusion_pre_layer_norm{i + 1}")(s_)
+                s_, To, _ = getattr(self, f"fusion_downsampling{i + 1}")(s_, B, Ti, li)
+                assert To == Tn, "fusion branches must end at the last stage's frame rate"
+                s_ = getattr(self, f"fusion_post_layer_norm{i + 1}")(s_)
+                fused = wgt * s_ if fused is None else fused + wgt * s_  # three small elementwise passes (torch)
+            x = fused
         if self.layer_norm is not None:
             x = self.layer_norm(x)
         lens = lens32.long()

@@ -399,3 +399,47 @@ def test_ctc_compress_plan_and_rows(dtype):
     for b in range(B):
         dref[b][keep[b]] = dy.view(B, Tn, d)[b, : int(keep[b].sum())]
     assert torch.equal(xd.grad.cpu().view(B, T, d), dref)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("r", [1, 2, 4])
+def test_dwpool_bn_act_fwd_bwd(dtype, r):
+    """s2t_dwpool_fwd/_bwd + BatchNorm + Swish (downsample_convolution.py:97-106) against torch: ragged tail (T % r != 0),
+    statistics over all rows, running-stat update, gradients of x, depthwise weight / bias and BatchNorm affine."""
+    from s2t_amd import functional as Fn
+    g = torch.Generator().manual_seed(20 + r)
+    B, T, C = 3, 70 + (1 if r > 1 else 0), 32
+    x = rnd((B * T, C), dtype, g)
+    w = torch.nn.Parameter((torch.randn(C, 1, r, generator=g) * 0.5).to(DEV))
+    b = torch.nn.Parameter((torch.randn(C, generator=g) * 0.1).to(DEV))
+    gamma = torch.nn.Parameter((1 + 0.1 * torch.randn(C, generator=g)).to(DEV))
+    beta = torch.nn.Parameter((0.1 * torch.randn(C, generator=g)).to(DEV))
+    for p in (w, b, gamma, beta):
+        p.grad = torch.zeros_like(p)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    prm = {"dw_w": w, "dw_b": b, "bn_w": gamma, "bn_b": beta}
+    a = Fn.pool_bn_act(xd, prm, {"running_mean": rm, "running_var": rv}, "swish", B, T, r, True)
+    To = T // r
+    dA = rnd((B * To, C), dtype, g)
+    a.backward(dA.to(DEV))
+    xr = x.float().view(B, T, C).clone().requires_grad_(True)
+    wr, br = w.detach().cpu().clone().requires_grad_(True), b.detach().cpu().clone().requires_grad_(True)
+    gr_, ber = gamma.detach().cpu().clone().requires_grad_(True), beta.detach().cpu().clone().requires_grad_(True)
+    D = torch.nn.functional.conv1d(xr.transpose(1, 2), wr, br, stride=r, groups=C).transpose(1, 2)
+    mu, var = D.mean((0, 1)), ((D - D.mean((0, 1))) ** 2).mean((0, 1))
+    u = (D - mu) / torch.sqrt(var + 1e-5) * gr_ + ber
+    ref = u * torch.sigmoid(u)
+    ref.backward(dA.float().view(B, To, C))
+    m = 4 if dtype == torch.bfloat16 else 1
+    close(a.view(B, To, C), ref, dtype, 4)
+    n = B * To
+    close(rm, 0.1 * mu, torch.float32, 200 if dtype == torch.bfloat16 else 5)
+    close(rv, 0.9 + 0.1 * var * n / (n - 1), torch.float32, 200 if dtype == torch.bfloat16 else 5)
+    close(xd.grad.view(B, T, C), xr.grad, dtype, 10 * m)
+    # BatchNorm removes a per-channel scale / shift of its input, so dw and db are differences of large, nearly
+    # cancelling sums (for r = 1 they are mathematically zero up to eps): compare on the scale of the gamma gradient
+    gs = float(gr_.grad.abs().max())
+    for got, want in ((w.grad, wr.grad), (b.grad, br.grad), (gamma.grad, gr_.grad), (beta.grad, ber.grad)):
+        err = float((got.detach().cpu() - want).abs().max())
+        assert err <= (0.2 if dtype == torch.bfloat16 else 2e-3) * max(gs, float(want.abs().max())), (err, gs)  # bf16: dD is stored rounded

@@ -20,7 +20,7 @@ from s2t_amd import s2t_transformer as M  # noqa: E402
 
 DEV = "cuda"
 CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small",
-         "conformer_interctc", "conformer_compress", "transformer_compress"]
+         "conformer_interctc", "conformer_compress", "transformer_compress", "pds_fusion_small"]
 
 
 def load(golden_dir, name):
@@ -140,12 +140,20 @@ def test_loss_and_grads_match_reference(golden_dir, name, dtype, tol, gtol):
         key = k[6:]
         ref = z[k]
         g = params[key].grad.detach().float().cpu().numpy()
-        if ("subsample" in key or "downsampling" in key) and ref.ndim == 3:
+        if ("subsample" in key or ("downsampling" in key and ".conv." in key)) and ref.ndim == 3:
             g = g.transpose(0, 2, 1)  # stored [Cout][k][Cin]
         if key.endswith("k_proj.bias") or key.endswith("linear_k.bias"):
             # mathematically ZERO gradient (softmax is invariant to a per-row score shift): both sides hold rounding
             # noise only, so compare against the size of the sibling q-bias gradient instead of its own
             sib = z["grad::" + key.replace("k_proj", "q_proj").replace("linear_k", "linear_q")]
+            assert np.abs(g - ref).max() < gtol * max(np.abs(sib).max(), 1e-3), key
+            continue
+        if "fusion_downsampling" in key and (key.endswith(("depthwise_conv.bias", "pointwise_conv1.bias")) or
+                                             (key.endswith("depthwise_conv.weight") and ref.shape[-1] == 1)):
+            # a per-channel shift (or, for a 1-tap kernel, scale) in front of BatchNorm: mathematically ZERO gradient
+            # (up to eps), rounding noise on both sides;
+            # compare on the scale of the BatchNorm gain's gradient
+            sib = z["grad::" + key.rsplit(".", 2)[0] + ".norm.weight"]
             assert np.abs(g - ref).max() < gtol * max(np.abs(sib).max(), 1e-3), key
             continue
         if dtype == torch.float32:
@@ -158,8 +166,9 @@ def test_loss_and_grads_match_reference(golden_dir, name, dtype, tol, gtol):
             worst = (key, err)
         n += 1
     assert n > 20
-    # the 4-layer fixture accumulates twice the bf16 rounding of the 2-layer ones (measured 0.27 on a depthwise kernel)
-    assert worst[1] < (2 * gtol if (dtype == torch.bfloat16 and name == "conformer_interctc") else gtol), worst
+    # the 4-layer fixture accumulates twice the bf16 rounding of the 2-layer ones (measured 0.27 on a depthwise kernel);
+    # so do the three fused branches of the PDS fusion fixture (0.25 on a LayerNorm bias of stage 2)
+    assert worst[1] < (2 * gtol if (dtype == torch.bfloat16 and name in ("conformer_interctc", "pds_fusion_small")) else gtol), worst
     # BatchNorm running statistics moved exactly as nn.BatchNorm1d moves them
     bufs = dict(model.named_buffers())
     for k in z.files:
@@ -185,7 +194,7 @@ def test_ctc_greedy_ids_bit_exact(golden_dir, name):
 def test_state_dict_keys_match_reference(golden_dir):
     """Checkpoint compatibility: same keys and shapes as the reference's state_dict."""
     for name in ("transformer_small", "conformer_small", "pds_small", "sate_small", "conformer_interctc",
-                 "conformer_compress", "transformer_compress"):
+                 "conformer_compress", "transformer_compress", "pds_fusion_small"):
         z = load(golden_dir, name)
         model, _ = build(z, torch.float32)
         sd = model.state_dict()
