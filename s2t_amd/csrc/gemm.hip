@@ -26,6 +26,11 @@
 
 #include "gemm_common.h"
 
+#ifndef S2T_EPI_UNROLL
+#define S2T_EPI_UNROLL 4  // tile pairs per copy of the fused epilogue code (1, 2, 4 or 8); measured on the training
+                          // step: 1 -> 21.35 ms, 2 -> 21.12, 4 -> 20.90, 8 -> 21.38 (instruction-cache pressure)
+#endif
+
 namespace {
 
 template <int N, typename F, int... I>
@@ -189,16 +194,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   // Atomic accumulation (split-K / c_atomic weight gradients) still transposes through LDS: float atomics are only
   // fast when a wave instruction covers 256 contiguous bytes.
   auto pair8 = [&](const f32x4& t0, const f32x4& t1, float (&v)[8]) __attribute__((always_inline)) {
-    // t0 / t1: this lane's 4 columns of the even / odd tile of a pair -> 8 consecutive columns of tile (y & 1)
-    const bool odd = y & 1;
-    const f32x4 send = odd ? t0 : t1;
-    f32x4 recv;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) recv[r] = __shfl_xor(send[r], 16, 64);
+    // t0 / t1: this lane's 4 columns of the even / odd tile of a pair -> 8 consecutive columns of tile (y & 1).
+    // v_permlane16_swap_b32 (gfx950) swaps the odd 16-lane rows of its first operand with the even rows of its second:
+    // odd y receives its partner's t1 in t0's place, even y its partner's t0 in t1's place — no selects.
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      v[r] = odd ? recv[r] : t0[r];
-      v[4 + r] = odd ? t1[r] : recv[r];
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(t0[r]), __float_as_uint(t1[r]), false, false);
+      v[r] = __uint_as_float(sw[0]);
+      v[4 + r] = __uint_as_float(sw[1]);
     }
   };
   auto epilogue = [&](const Cursor& c) __attribute__((always_inline)) {
@@ -304,35 +307,82 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
     // accumulator indices stay compile-time constants.  The accumulators are dead (re-zeroed) afterwards.
     f32x4 (&af)[16] = reinterpret_cast<f32x4 (&)[16]>(acc);
     if constexpr (GLU) {
+      // two row blocks per trip (static accumulator indices 0..7), then shift the remaining accumulators down by eight
 #pragma unroll 1
-      for (int i = 0; i < 4; ++i) {
-        const int m = tm * BM + wm * 64 + i * 16 + x;
-        const int64_t grow = (int64_t)z * p.M + m;
-        // tiles j = 0, 2 hold the value columns of output groups q = 2wn, 2wn+1 and j = 1, 3 their gate columns
-        float a[8], g[8], ba[8], bg[8], v[8];
-        pair8(af[0], af[2], a);
-        pair8(af[1], af[3], g);
+      for (int i2 = 0; i2 < 2; ++i2) {
+        static_for<2>([&](auto hc) __attribute__((always_inline)) {
+          constexpr int h = decltype(hc)::value;
+          const int i = i2 * 2 + h;
+          const int m = tm * BM + wm * 64 + i * 16 + x;
+          const int64_t grow = (int64_t)z * p.M + m;
+          // tiles j = 0, 2 hold the value columns of output groups q = 2wn, 2wn+1 and j = 1, 3 their gate columns
+          float a[8], g[8], ba[8], bg[8], v[8];
+          pair8(af[4 * h], af[4 * h + 2], a);
+          pair8(af[4 * h + 1], af[4 * h + 3], g);
+          const int n0 = tn * 64 + (wn * 2 + (y & 1)) * 16 + 8 * (y >> 1);
+          if (m < p.M && n0 < nout) {
+            const int nv = min(8, nout - n0);
+            e.bias8(n0, nv, ba);
+            e.bias8(nout + n0, nv, bg);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) af[k] = af[k + 4];
-        const int n0 = tn * 64 + (wn * 2 + (y & 1)) * 16 + 8 * (y >> 1);
-        if (m < p.M && n0 < nout) {
-          const int nv = min(8, nout - n0);
-          e.bias8(n0, nv, ba);
-          e.bias8(nout + n0, nv, bg);
+            for (int r = 0; r < 8; ++r) {
+              a[r] += ba[r];
+              g[r] += bg[r];
+              v[r] = a[r] * sigmoidf_(g[r]);
+            }
+            if (e.P) {
+              st8<TC>(e.P + (int64_t)m * p.ldp + n0, VEC || e.vec_p, VEC ? 8 : nv, a);
+              st8<TC>(e.P + (int64_t)m * p.ldp + nout + n0, VEC || (e.vec_p && ((nout * (int)sizeof(TC)) % 16 == 0)), VEC ? 8 : nv, g);
+            }
+            e.finish(m, n0, grow, v);
+          }
+        });
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            a[r] += ba[r];
-            g[r] += bg[r];
-            v[r] = a[r] * sigmoidf_(g[r]);
-          }
-          if (e.P) {
-            st8<TC>(e.P + (int64_t)m * p.ldp + n0, VEC || e.vec_p, VEC ? 8 : nv, a);
-            st8<TC>(e.P + (int64_t)m * p.ldp + nout + n0, VEC || (e.vec_p && ((nout * (int)sizeof(TC)) % 16 == 0)), VEC ? 8 : nv, g);
-          }
-          e.finish(m, n0, grow, v);
-        }
+        for (int k = 0; k < 8; ++k) af[k] = af[k + 8];
       }
     } else {
+#if S2T_EPI_UNROLL == 8
+      static_for<8>([&](auto itc) __attribute__((always_inline)) {
+        constexpr int it = decltype(itc)::value;
+        const int i = it >> 1, jp = it & 1;
+        const int m = tm * BM + wm * 64 + i * 16 + x;
+        const int64_t grow = (int64_t)z * p.M + m;
+        float v[8], b[8];
+        pair8(af[2 * it], af[2 * it + 1], v);
+        const int n0 = tn * BN + wn * 64 + (2 * jp + (y & 1)) * 16 + 8 * (y >> 1);
+        if (m < p.M && n0 < nout) {
+          e.bias8(n0, min(8, nout - n0), b);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += b[r];
+          e.finish(m, n0, grow, v);
+        }
+      });
+#elif S2T_EPI_UNROLL == 2 || S2T_EPI_UNROLL == 4
+      // U tile pairs per trip (static accumulator indices 0..2U-1), then shift the remaining accumulators down by 2U:
+      // U copies of the fused epilogue code, 1/U of the register moves of the single-copy form
+      constexpr int U = S2T_EPI_UNROLL;
+#pragma unroll 1
+      for (int it2 = 0; it2 < 8 / U; ++it2) {
+        static_for<U>([&](auto hc) __attribute__((always_inline)) {
+          constexpr int h = decltype(hc)::value;
+          const int it = it2 * U + h;
+          const int i = it >> 1, jp = it & 1;
+          const int m = tm * BM + wm * 64 + i * 16 + x;
+          const int64_t grow = (int64_t)z * p.M + m;
+          float v[8], b[8];
+          pair8(af[2 * h], af[2 * h + 1], v);
+          const int n0 = tn * BN + wn * 64 + (2 * jp + (y & 1)) * 16 + 8 * (y >> 1);
+          if (m < p.M && n0 < nout) {
+            e.bias8(n0, min(8, nout - n0), b);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += b[r];
+            e.finish(m, n0, grow, v);
+          }
+        });
+#pragma unroll
+        for (int k = 0; k < 16 - 2 * U; ++k) af[k] = af[k + 2 * U];
+      }
+#else
 #pragma unroll 1
       for (int it = 0; it < 8; ++it) {
         const int i = it >> 1, jp = it & 1;
@@ -350,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
           e.finish(m, n0, grow, v);
         }
       }
+#endif
     }
   };
 
