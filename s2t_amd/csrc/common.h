@@ -97,7 +97,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // probability is quantised to 1/65536 and the survivors are scaled by the quantised value's inverse): the fused GEMM
 // and attention epilogues draw a mask per stored element and are VALU-issue bound, and 32-bit integer multiplies and
 // 64-bit arithmetic (the first version was splitmix64 per element) are the expensive part.
-// hash = two rounds of the "lowbias32" multiply/xor-shift finaliser over the pair index, the key's halves injected.
+// hash = ONE round of the "lowbias32" multiply/xor-shift finaliser over (pair index ^ low key half), the high key half
+// (and, for tensors beyond 2^33 elements, the pair index's high word) added behind it with full-rate ops: two quarter-rate
+// 32-bit multiplies per 32 random bits (the first form took five).
 __device__ __forceinline__ uint32_t s2t_mix32(uint32_t x) {
   x ^= x >> 16;
   x *= 0x7feb352dU;
@@ -107,9 +109,8 @@ __device__ __forceinline__ uint32_t s2t_mix32(uint32_t x) {
   return x;
 }
 __device__ __forceinline__ uint32_t s2t_pair_hash(uint64_t key, uint64_t pair) {
-  uint32_t x = s2t_mix32((uint32_t)pair ^ (uint32_t)key);
-  x += (uint32_t)(pair >> 32) * 0x9E3779B9U + (uint32_t)(key >> 32);
-  return s2t_mix32(x);
+  const uint32_t hi = (uint32_t)(pair >> 32);
+  return s2t_mix32((uint32_t)pair ^ (uint32_t)key) ^ ((uint32_t)(key >> 32) + ((hi << 16) | (hi >> 16)));
 }
 // 16 uniform random bits of element idx
 __device__ __forceinline__ uint32_t s2t_rand_u32(uint64_t key, uint64_t idx) {
