@@ -307,6 +307,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
     // accumulator indices stay compile-time constants.  The accumulators are dead (re-zeroed) afterwards.
     f32x4 (&af)[16] = reinterpret_cast<f32x4 (&)[16]>(acc);
     if constexpr (GLU) {
+      // this lane's output columns (and with them the bias values) are the same for all four row blocks: load once
+      const int gn0 = tn * 64 + (wn * 2 + (y & 1)) * 16 + 8 * (y >> 1);
+      float gba[8], gbg[8];
+      {
+        const int nvb = max(0, min(8, nout - gn0));
+        e.bias8(nvb > 0 ? gn0 : 0, nvb, gba);
+        e.bias8(nvb > 0 ? nout + gn0 : 0, nvb, gbg);
+      }
       // two row blocks per trip (static accumulator indices 0..7), then shift the remaining accumulators down by eight
 #pragma unroll 1
       for (int i2 = 0; i2 < 2; ++i2) {
@@ -316,18 +324,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
           const int m = tm * BM + wm * 64 + i * 16 + x;
           const int64_t grow = (int64_t)z * p.M + m;
           // tiles j = 0, 2 hold the value columns of output groups q = 2wn, 2wn+1 and j = 1, 3 their gate columns
-          float a[8], g[8], ba[8], bg[8], v[8];
+          float a[8], g[8], v[8];
           pair8(af[4 * h], af[4 * h + 2], a);
           pair8(af[4 * h + 1], af[4 * h + 3], g);
-          const int n0 = tn * 64 + (wn * 2 + (y & 1)) * 16 + 8 * (y >> 1);
+          const int n0 = gn0;
           if (m < p.M && n0 < nout) {
             const int nv = min(8, nout - n0);
-            e.bias8(n0, nv, ba);
-            e.bias8(nout + n0, nv, bg);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-              a[r] += ba[r];
-              g[r] += bg[r];
+              a[r] += gba[r];
+              g[r] += gbg[r];
               v[r] = a[r] * sigmoidf_(g[r]);
             }
             if (e.P) {
@@ -341,19 +347,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
         for (int k = 0; k < 8; ++k) af[k] = af[k + 8];
       }
     } else {
+      // a lane's output columns depend on the tile pair's parity only: the two bias vectors are loaded once per tile
+      float bpre[2][8];
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int nb = tn * BN + wn * 64 + (2 * jp + (y & 1)) * 16 + 8 * (y >> 1);
+        const int nvb = max(0, min(8, nout - nb));
+        e.bias8(nvb > 0 ? nb : 0, nvb, bpre[jp]);
+      }
 #if S2T_EPI_UNROLL == 8
       static_for<8>([&](auto itc) __attribute__((always_inline)) {
         constexpr int it = decltype(itc)::value;
         const int i = it >> 1, jp = it & 1;
         const int m = tm * BM + wm * 64 + i * 16 + x;
         const int64_t grow = (int64_t)z * p.M + m;
-        float v[8], b[8];
+        float v[8];
         pair8(af[2 * it], af[2 * it + 1], v);
         const int n0 = tn * BN + wn * 64 + (2 * jp + (y & 1)) * 16 + 8 * (y >> 1);
         if (m < p.M && n0 < nout) {
-          e.bias8(n0, min(8, nout - n0), b);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += b[r];
+          for (int r = 0; r < 8; ++r) v[r] += bpre[jp][r];
           e.finish(m, n0, grow, v);
         }
       });
@@ -366,16 +379,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
         static_for<U>([&](auto hc) __attribute__((always_inline)) {
           constexpr int h = decltype(hc)::value;
           const int it = it2 * U + h;
-          const int i = it >> 1, jp = it & 1;
+          const int i = it >> 1;
+          constexpr int jp = h & 1;  // U is even
           const int m = tm * BM + wm * 64 + i * 16 + x;
           const int64_t grow = (int64_t)z * p.M + m;
-          float v[8], b[8];
+          float v[8];
           pair8(af[2 * h], af[2 * h + 1], v);
           const int n0 = tn * BN + wn * 64 + (2 * jp + (y & 1)) * 16 + 8 * (y >> 1);
           if (m < p.M && n0 < nout) {
-            e.bias8(n0, min(8, nout - n0), b);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += b[r];
+  #pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += bpre[jp][r];
             e.finish(m, n0, grow, v);
           }
         });
@@ -388,15 +401,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
         const int i = it >> 1, jp = it & 1;
         const int m = tm * BM + wm * 64 + i * 16 + x;
         const int64_t grow = (int64_t)z * p.M + m;
-        float v[8], b[8];
+        float v[8];
         pair8(af[0], af[1], v);
 #pragma unroll
         for (int k = 0; k < 14; ++k) af[k] = af[k + 2];
         const int n0 = tn * BN + wn * 64 + (2 * jp + (y & 1)) * 16 + 8 * (y >> 1);
         if (m < p.M && n0 < nout) {
-          e.bias8(n0, min(8, nout - n0), b);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += b[r];
+          for (int r = 0; r < 8; ++r) v[r] += jp ? bpre[1][r] : bpre[0][r];
           e.finish(m, n0, grow, v);
         }
       }
@@ -613,6 +625,7 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
     if (a_span >= (1ll << 32) || b_span >= (1ll << 32)) return S2T_ERR_UNSUPPORTED;
   }
   if (p.row_lens && p.row_T <= 0) return S2T_ERR_ARG;
+  if (p.row_lens && (int64_t)p.batch * p.M >= ((int64_t)1 << 31)) return S2T_ERR_UNSUPPORTED;  // 32-bit row arithmetic in the mask
   if (p.drop_p < 0.f || p.drop_p >= 1.f) return S2T_ERR_ARG;
   // two-phase split-K only with a large enough workspace and when every K split is non-empty (an empty split would
   // leave its workspace slice unwritten)
