@@ -192,37 +192,49 @@ __global__ __launch_bounds__(256) void ln256_fwd_kernel(const bf16_t* __restrict
                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                         int64_t rows, float eps, const int32_t* __restrict__ row_lens,
                                                         int row_T) {
+  // two rows per half-wave, both 16-byte loads issued before either is used (the pass is latency bound: one row per
+  // half-wave leaves a single load in flight per lane)
+  constexpr int RPH = 2;
   const int lane = threadIdx.x & 63, l = lane & 31;
-  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5);
-  const bool valid = row < rows;
-  const int64_t rr = valid ? row : rows - 1;
-  float v[8];
-  unpack8(*reinterpret_cast<const uint4*>(x + rr * 256 + l * 8), v);
-  float s = 0.f;
+  const int64_t row0 = ((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5)) * RPH;
+  float v[RPH][8];
+  bool valid[RPH];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) s += v[r];
-  const float mean = half_sum(s) * (1.f / 256.f);
-  float q = 0.f;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const float d = v[r] - mean;
-    q += d * d;
+  for (int u = 0; u < RPH; ++u) {
+    valid[u] = row0 + u < rows;
+    const int64_t rr = valid[u] ? row0 + u : rows - 1;
+    unpack8(*reinterpret_cast<const uint4*>(x + rr * 256 + l * 8), v[u]);
   }
-  const float rstd = rsqrtf(half_sum(q) * (1.f / 256.f) + eps);
-  if (!valid) return;
-  bool masked = false;
-  if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
-  float g[8], b[8], o[8];
+  float g[8], b[8];
   ld4_as_f32<float>(gamma + l * 8, reinterpret_cast<float (&)[4]>(g[0]));
   ld4_as_f32<float>(gamma + l * 8 + 4, reinterpret_cast<float (&)[4]>(g[4]));
   ld4_as_f32<float>(beta + l * 8, reinterpret_cast<float (&)[4]>(b[0]));
   ld4_as_f32<float>(beta + l * 8 + 4, reinterpret_cast<float (&)[4]>(b[4]));
 #pragma unroll
-  for (int r = 0; r < 8; ++r) o[r] = masked ? 0.f : (v[r] - mean) * rstd * g[r] + b[r];
-  *reinterpret_cast<uint4*>(y + row * 256 + l * 8) = pack8f(o);
-  if (l == 0 && mean_out) {
-    mean_out[row] = mean;
-    rstd_out[row] = rstd;
+  for (int u = 0; u < RPH; ++u) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += v[u][r];
+    const float mean = half_sum(s) * (1.f / 256.f);
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float d = v[u][r] - mean;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(half_sum(q) * (1.f / 256.f) + eps);
+    if (!valid[u]) continue;  // (after the wave-wide shuffles)
+    const int64_t row = row0 + u;
+    bool masked = false;
+    if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
+    float o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = masked ? 0.f : (v[u][r] - mean) * rstd * g[r] + b[r];
+    *reinterpret_cast<uint4*>(y + row * 256 + l * 8) = pack8f(o);
+    if (l == 0 && mean_out) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
   }
 }
 
@@ -338,7 +350,7 @@ extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, c
   if (dtype == S2T_F32)
     LN_DISPATCH(ln_fwd_kernel, float, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps, row_lens, row_T);
   else if (dtype == S2T_BF16 && cols == 256 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0)
-    hipLaunchKernelGGL(ln256_fwd_kernel, dim3((unsigned)((rows + 7) / 8)), block, 0, s, (const bf16_t*)x, gamma, beta,
+    hipLaunchKernelGGL(ln256_fwd_kernel, dim3((unsigned)((rows + 15) / 16)), block, 0, s, (const bf16_t*)x, gamma, beta,
                        (bf16_t*)y, mean, rstd, rows, eps, row_lens, row_T);
   else if (dtype == S2T_BF16)
     LN_DISPATCH(ln_fwd_kernel, bf16_t, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, cols, eps, row_lens, row_T);
