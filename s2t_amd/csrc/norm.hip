@@ -254,41 +254,53 @@ __global__ __launch_bounds__(256) void ln256_bwd_kernel(const bf16_t* __restrict
   for (int r = 0; r < 8; ++r) ag[r] = ab[r] = 0.f;
   // all 64 lanes of a wave take the same number of trips (shuffles are wave-wide): out-of-range halves work on a
   // clamped row and discard the result
-  const int64_t trips = (rows + (int64_t)gridDim.x * 8 - 1) / ((int64_t)gridDim.x * 8);
+  // two rows per half-wave and trip; x, dy and dres of both rows are requested before any of them is used
+  constexpr int RPH = 2;
+  const int64_t per_trip = (int64_t)gridDim.x * 8 * RPH;
+  const int64_t trips = (rows + per_trip - 1) / per_trip;
   for (int64_t it = 0; it < trips; ++it) {
-    const int64_t row = (it * gridDim.x + blockIdx.x) * 8 + hw;
-    const bool valid = row < rows;
-    const int64_t rr = valid ? row : rows - 1;
-    bool masked = !valid;
-    if (valid && row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
-    const float mu = mean[rr], rs = rstd[rr];
-    float xv[8], dv[8], xh[8], dg[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + rr * 256 + l * 8), xv);
-    unpack8(*reinterpret_cast<const uint4*>(dy + rr * 256 + l * 8), dv);
-    float s1 = 0.f, s2 = 0.f;
+    const int64_t row0 = ((it * gridDim.x + blockIdx.x) * 8 + hw) * RPH;
+    uint4 tx[RPH], td[RPH], tr[RPH];
+    float mu[RPH], rs[RPH];
+    bool valid[RPH], masked[RPH];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float d = masked ? 0.f : dv[r];
-      xh[r] = (xv[r] - mu) * rs;
-      dg[r] = d * g[r];
-      s1 += dg[r];
-      s2 += dg[r] * xh[r];
-      ag[r] += d * xh[r];
-      ab[r] += d;
+    for (int u = 0; u < RPH; ++u) {
+      const int64_t row = row0 + u;
+      valid[u] = row < rows;
+      const int64_t rr = valid[u] ? row : rows - 1;
+      tx[u] = *reinterpret_cast<const uint4*>(x + rr * 256 + l * 8);
+      td[u] = *reinterpret_cast<const uint4*>(dy + rr * 256 + l * 8);
+      tr[u] = dres ? *reinterpret_cast<const uint4*>(dres + rr * 256 + l * 8) : make_uint4(0, 0, 0, 0);
+      mu[u] = mean[rr];
+      rs[u] = rstd[rr];
+      masked[u] = !valid[u];
+      if (valid[u] && row_lens) masked[u] = (int)(row % row_T) >= row_lens[row / row_T];
     }
-    s1 = half_sum(s1) * (1.f / 256.f);
-    s2 = half_sum(s2) * (1.f / 256.f);
-    if (valid) {
-      float o[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = rs * (dg[r] - s1 - xh[r] * s2);
-      if (dres) {
-        float q[8];
-        unpack8(*reinterpret_cast<const uint4*>(dres + row * 256 + l * 8), q);
+    for (int u = 0; u < RPH; ++u) {
+      float xv[8], dv[8], xh[8], dg[8];
+      unpack8(tx[u], xv);
+      unpack8(td[u], dv);
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] += q[r];
+      for (int r = 0; r < 8; ++r) {
+        const float d = masked[u] ? 0.f : dv[r];
+        xh[r] = (xv[r] - mu[u]) * rs[u];
+        dg[r] = d * g[r];
+        s1 += dg[r];
+        s2 += dg[r] * xh[r];
+        ag[r] += d * xh[r];
+        ab[r] += d;
       }
-      *reinterpret_cast<uint4*>(dx + row * 256 + l * 8) = pack8f(o);
+      s1 = half_sum(s1) * (1.f / 256.f);
+      s2 = half_sum(s2) * (1.f / 256.f);
+      if (valid[u]) {
+        float o[8], q[8];
+        unpack8(tr[u], q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = rs[u] * (dg[r] - s1 - xh[r] * s2) + q[r];
+        *reinterpret_cast<uint4*>(dx + (row0 + u) * 256 + l * 8) = pack8f(o);
+      }
     }
   }
 #pragma unroll
@@ -374,8 +386,10 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, c
     LN_DISPATCH(ln_bwd_kernel, float, (const float*)x, gamma, (const float*)dy, mean, rstd, (float*)dx, (const float*)dres, ws, replicas, rows, cols, row_lens, row_T);
   else if (dtype == S2T_BF16 && cols == 256 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
            ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dres % 16) == 0) {
-    int64_t nb8 = (rows + 7) / 8;
-    if (nb8 > 2048) nb8 = 2048;
+    // 32 rows per workgroup and trip; at most 512 workgroups: every workgroup closes with 512 float atomics into the
+    // replica workspace, which are executed at the memory side (2000 workgroups made that a million per call)
+    int64_t nb8 = (rows + 31) / 32;
+    if (nb8 > 512) nb8 = 512;
     hipLaunchKernelGGL(ln256_bwd_kernel, dim3((unsigned)nb8), block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean,
                        rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, row_lens, row_T);
   } else if (dtype == S2T_BF16)
