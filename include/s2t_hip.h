@@ -258,7 +258,8 @@ int s2t_sumsq_accum(const float* g, int64_t n, float* out, void* stream);
  *                     unbiased variance) ; training = 0 uses the running statistics.
  *   s2t_bn_act_fwd  : out = act(D*scale + shift), padded frames -> 0
  *   s2t_bn_act_bwd  : dD from dOut (reduce, fixed-order fold, apply); sums[0:C] = sum du (= dbeta), sums[C:2C] = sum du*xhat
- *                     (= dgamma); ws: s2t_bn_bwd_partials(rows) x 2C floats of scratch
+ *                     (= dgamma); ws: s2t_bn_bwd_partials(rows) x 2C floats of scratch; dgamma / dbeta (optional): the sums are also
+ *                     added to these parameter-gradient vectors
  * ------------------------------------------------------------------------------------------------ */
 int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, int flip,
                    const float* scale, const float* shift, int act, const int32_t* lens, float* stats, void* stream);
@@ -272,8 +273,8 @@ int s2t_bn_finalize(const float* stats, int partials, float count, const float* 
 int s2t_bn_act_fwd(int dtype, const void* D, void* out, const float* scale, const float* shift, int act, int64_t rows,
                    int C, const int32_t* lens, int T, void* stream);
 int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const float* scale, const float* shift,
-                   const float* mean, const float* rstd, float* sums, float* ws, float count, int act, int64_t rows, int C,
-                   const int32_t* lens, int T, void* stream);
+                   const float* mean, const float* rstd, float* sums, float* ws, float* dgamma, float* dbeta, float count,
+                   int act, int64_t rows, int C, const int32_t* lens, int T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Vocabulary-wide kernels.  logits are row matrices [rows][ld] (batch-major: row = b*T + t).

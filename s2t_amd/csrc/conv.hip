@@ -329,11 +329,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
 
 // sums[0:2C] = fixed-order sum of the partial rows
 __global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(const float* __restrict__ partial, int rows, int C,
-                                                           float* __restrict__ sums) {
+                                                           float* __restrict__ sums, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
   __shared__ float red[16][16];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);  // over 2C columns
   const float t = fold_partial_rows(partial + c, rows, 2 * (int64_t)C, c < 2 * C, red);
-  if (threadIdx.x < 16 && c < 2 * C) sums[c] = t;
+  if (threadIdx.x < 16 && c < 2 * C) {
+    sums[c] = t;
+    // sums[0:C] = sum du = dbeta, sums[C:2C] = sum du*xhat = dgamma: optionally accumulated into the parameter gradients
+    if (c < C) {
+      if (dbeta) dbeta[c] += t;
+    } else if (dgamma) {
+      dgamma[c - C] += t;
+    }
+  }
 }
 
 // pass 2: dD = gamma*rstd * (du - s1/n - xhat * s2/n)
@@ -457,7 +466,8 @@ extern "C" int s2t_bn_act_fwd(int dtype, const void* D, void* out, const float* 
 
 extern "C" int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* sums /* [2C] out */,
-                              float* ws /* [s2t_bn_bwd_partials(rows)][2C] scratch */, float count, int act,
+                              float* ws /* [s2t_bn_bwd_partials(rows)][2C] scratch */, float* dgamma, float* dbeta,
+                              float count, int act,
                               int64_t rows, int C, const int32_t* lens, int T, void* stream) {
   if (!D || !dOut || !dD || !scale || !shift || !mean || !rstd || !sums || !ws || rows <= 0 || C <= 0 || C % 4) return S2T_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -467,11 +477,11 @@ extern "C" int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* 
   dim3 fgrid((2 * C + 15) / 16), fblock(1024);
   if (dtype == S2T_F32) {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, rgrid, block, 0, s, (const float*)D, (const float*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, ws);
-    hipLaunchKernelGGL(bn_bwd_fold_kernel, fgrid, fblock, 0, s, ws, slices, C, sums);
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, fgrid, fblock, 0, s, ws, slices, C, sums, dgamma, dbeta);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, agrid, block, 0, s, (const float*)D, (const float*)dOut, (float*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
   } else if (dtype == S2T_BF16) {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, rgrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, ws);
-    hipLaunchKernelGGL(bn_bwd_fold_kernel, fgrid, fblock, 0, s, ws, slices, C, sums);
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, fgrid, fblock, 0, s, ws, slices, C, sums, dgamma, dbeta);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, agrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, (bf16_t*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();

@@ -658,7 +658,7 @@ class AttentionFn(torch.autograd.Function):
             ktiles = (Mq + 63) // 64
             K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
                    a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=max(1, min(ktiles, 64)), c_atomic=True)
-            pos32 = pos_tab if pos_tab.dtype == torch.float32 else pos_tab.float()
+            pos32 = _pos_table_f32(pos_tab)
             K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
                    split_k=max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
             dq[:, :d].add_(dqv)
@@ -742,7 +742,7 @@ class AttentionFn(torch.autograd.Function):
             K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
                    a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=max(1, min(ktiles, 64)), c_atomic=True)
             # linear_pos weight: dW[dout, din] += dp^T pos_tab  (fp32 GEMM on the fp32 table)
-            pos32 = pos_tab if pos_tab.dtype == torch.float32 else pos_tab.float()
+            pos32 = _pos_table_f32(pos_tab)
             K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
                    split_k=max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
             # dq += dqv   (strided add into the q slice of dqkv)
@@ -895,9 +895,8 @@ class ConvModuleFn(torch.autograd.Function):
         # here dy rows of padded frames must not reach pw2's weight gradient: a is zero there -> contributes nothing
         dD = torch.empty(M, d, dtype=dt, device=dev)
         sums = torch.empty(2 * d, dtype=torch.float32, device=dev)
-        K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T)
-        prm["bn_b"].grad.add_(sums[:d])
-        prm["bn_w"].grad.add_(sums[d:])
+        K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T,
+                     dgamma=prm["bn_w"].grad, dbeta=prm["bn_b"].grad)
         wd = prm["dw_w"].data.view(d, Kw)
         dG = torch.empty(M, d, dtype=dt, device=dev)
         K.dwconv_fwd(dD, wd, dG, B, T, d, Kw, flip=True)
@@ -964,9 +963,8 @@ class PoolBnActFn(torch.autograd.Function):
         dt, dev = x.dtype, x.device
         dD = torch.empty(Mo, d, dtype=dt, device=dev)
         sums = torch.empty(2 * d, dtype=torch.float32, device=dev)
-        K.bn_act_bwd(D, dA.contiguous(), dD, scale, shift, mean, rstd, sums, Mo, ctx.act, Mo, d)
-        prm["bn_b"].grad.add_(sums[:d])
-        prm["bn_w"].grad.add_(sums[d:])
+        K.bn_act_bwd(D, dA.contiguous(), dD, scale, shift, mean, rstd, sums, Mo, ctx.act, Mo, d,
+                     dgamma=prm["bn_w"].grad, dbeta=prm["bn_b"].grad)
         dx = (torch.zeros if To * r != T else torch.empty)(B * T, d, dtype=dt, device=dev)
         K.dwpool_bwd(x, prm["dw_w"].data.view(d, r), dD, dx, prm["dw_w"].grad.view(d, r), prm["dw_b"].grad, B, T, d, r)
         _ready(prm["dw_w"], prm["dw_b"], prm["bn_w"], prm["bn_b"])
@@ -1288,6 +1286,22 @@ def ctc_compress_plan(logit2d, lens32, B, T, blank, threshold):
 # ------------------------------------------------------------------------------------------------
 # SATE adapter (inter_league)
 # ------------------------------------------------------------------------------------------------
+_POS32 = {}
+
+
+def _pos_table_f32(pos_tab):
+    """fp32 copy of a (cached, constant) relative-position table: made once, not once per layer and step."""
+    if pos_tab.dtype == torch.float32:
+        return pos_tab
+    key = (pos_tab.data_ptr(), tuple(pos_tab.shape), str(pos_tab.device))
+    hit = _POS32.get(key)
+    if hit is None or hit[0] is not pos_tab:
+        if len(_POS32) > 64:
+            _POS32.clear()
+        hit = _POS32[key] = (pos_tab, pos_tab.float())
+    return hit[1]
+
+
 class AdapterFn(torch.autograd.Function):
     """out = x + dist @ W_embed, dist = softmax(ctc_logit / tau)   (modules/speech_to_text/adapter.py:214-217,264-266,
     296-297); rows flagged by ``rows`` take the (optionally smoothed) one-hot distribution of ``oracle`` instead

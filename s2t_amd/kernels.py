@@ -258,11 +258,12 @@ def bn_act_fwd(D, out, scale, shift, act, rows, C, lens=None, T=0):
           L.ACT_IDS[act], rows, C, _ptr(lens), T)
 
 
-def bn_act_bwd(D, dOut, dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens=None, T=0):
+def bn_act_bwd(D, dOut, dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens=None, T=0, dgamma=None, dbeta=None):
+    """``dgamma`` / ``dbeta`` (fp32 [C], optional): the folded sums are also ADDED to them (the parameter gradients)."""
     ws = _scratch("bn_bwd", L.lib().s2t_bn_bwd_partials(rows) * 2 * C, D.device)
     _call("s2t_bn_act_bwd", L.dtype_id(D.dtype), D.data_ptr(), dOut.data_ptr(), dD.data_ptr(), scale.data_ptr(),
-          shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), ws.data_ptr(), float(count), L.ACT_IDS[act],
-          rows, C, _ptr(lens), T)
+          shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), ws.data_ptr(), _ptr(dgamma), _ptr(dbeta),
+          float(count), L.ACT_IDS[act], rows, C, _ptr(lens), T)
 
 
 def argmax_lse(logits, ld, rows, V, idx=None, top_lp=None, lse=None):
