@@ -225,6 +225,10 @@ int s2t_embedding_bwd(int dtype, const int64_t* tokens, const void* dout, float*
 int s2t_glu_bwd(int dtype, const void* Z, const void* dY, void* dZ, int64_t rows, int n, const int32_t* lens, int T,
                 void* stream);
 int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db, int64_t rows, int n, void* stream);
+/* relative-position attention backward glue: a[row][0:n] += b[row][0:n] in place, du[c] += column sums of the OLD a,
+ * dv[c] += column sums of b (pos_bias_u / pos_bias_v gradients, espnet_multihead_attention.py:313-356); bf16, n = 256 */
+int s2t_add_colsum2(int dtype, void* a, int64_t lda, const void* b, int64_t ldb, float* du, float* dv, int64_t rows, int n,
+                    void* stream);
 int s2t_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* out[r, c] = keep(seed, site, r*cols + c) ? x[r, c] / (1-p) : 0   (FairseqDropout, modules/fairseq_dropout.py; the same
  * call on a gradient is its backward) */

@@ -192,6 +192,72 @@ __global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __rest
   }
 }
 
+// Relative-position attention backward glue (espnet_multihead_attention.py:313-356, autograd of (q + pos_bias_u) and
+// (q + pos_bias_v)): a[row][:] += b[row][:] in place, du[c] += sum_rows a_old, dv[c] += sum_rows b — one pass instead of two
+// column-sum launches and an element-wise add.  bf16 rows of 256 columns (8 per lane, 32 lanes per row).
+__global__ __launch_bounds__(256) void add_colsum2_bf16_kernel(bf16_t* __restrict__ a, int64_t lda,
+                                                               const bf16_t* __restrict__ b, int64_t ldb,
+                                                               float* __restrict__ du, float* __restrict__ dv, int64_t rows) {
+  constexpr int TPR = 32, RPP = 8;
+  __shared__ float red[2][RPP][256];
+  const int cl = threadIdx.x % TPR, rg = threadIdx.x / TPR;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  float su[8], sv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) su[i] = sv[i] = 0.f;
+  auto one = [&](const uint4 ta, const uint4 tb, bf16_t* dst) __attribute__((always_inline)) {
+    const uint32_t wa[4] = {ta.x, ta.y, ta.z, ta.w}, wb[4] = {tb.x, tb.y, tb.z, tb.w};
+    float o[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float a0 = __uint_as_float(wa[q] << 16), a1 = __uint_as_float(wa[q] & 0xffff0000u);
+      const float b0 = __uint_as_float(wb[q] << 16), b1 = __uint_as_float(wb[q] & 0xffff0000u);
+      su[2 * q] += a0;
+      su[2 * q + 1] += a1;
+      sv[2 * q] += b0;
+      sv[2 * q + 1] += b1;
+      o[2 * q] = a0 + b0;
+      o[2 * q + 1] = a1 + b1;
+    }
+    uint4 t;
+    t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+    t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    t.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
+    t.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+    *reinterpret_cast<uint4*>(dst) = t;
+  };
+  int64_t m = r0 + rg;
+  for (; m + 3 * RPP < r1; m += 4 * RPP) {
+    uint4 ta[4], tb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ta[u] = *reinterpret_cast<const uint4*>(a + (m + u * RPP) * lda + cl * 8);
+      tb[u] = *reinterpret_cast<const uint4*>(b + (m + u * RPP) * ldb + cl * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(ta[u], tb[u], a + (m + u * RPP) * lda + cl * 8);
+  }
+  for (; m < r1; m += RPP)
+    one(*reinterpret_cast<const uint4*>(a + m * lda + cl * 8), *reinterpret_cast<const uint4*>(b + m * ldb + cl * 8),
+        a + m * lda + cl * 8);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    red[0][rg][cl * 8 + i] = su[i];
+    red[1][rg][cl * 8 + i] = sv[i];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  float tu = 0.f, tv = 0.f;
+#pragma unroll
+  for (int g = 0; g < RPP; ++g) {
+    tu += red[0][g][c];
+    tv += red[1][g][c];
+  }
+  atomicAdd(du + c, tu);
+  atomicAdd(dv + c, tv);
+}
+
 // ---- bias gradient: db[n] += sum_m dY[m,n]  (fp32 accumulate) ----
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, int64_t ld, float* __restrict__ db,
@@ -436,6 +502,19 @@ extern "C" int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db
   else if (dtype == S2T_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dY, ld, db, rows, n);
   else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_add_colsum2(int dtype, void* a, int64_t lda, const void* b, int64_t ldb, float* du, float* dv,
+                               int64_t rows, int n, void* stream) {
+  if (!a || !b || !du || !dv || rows < 0 || n <= 0) return S2T_ERR_ARG;
+  if (dtype != S2T_BF16 || n != 256) return S2T_ERR_UNSUPPORTED;
+  if (lda % 8 || ldb % 8 || ((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return S2T_ERR_ALIGN;
+  if (rows == 0) return S2T_OK;
+  int64_t sl = (rows + 63) / 64;
+  if (sl > 128) sl = 128;
+  hipLaunchKernelGGL(add_colsum2_bf16_kernel, dim3((unsigned)sl), dim3(256), 0, (hipStream_t)stream, (bf16_t*)a, lda,
+                     (const bf16_t*)b, ldb, du, dv, rows);
   return S2T_LAUNCH_CHECK();
 }
 

@@ -647,11 +647,14 @@ class AttentionFn(torch.autograd.Function):
                          ldB, B, H, Tq, Tk, dk, key_lens, ctx.causal, scale, p, d,
                          prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a)
         if rel:
-            K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
+            fuse_glue = dt == torch.bfloat16 and d == 256 and ldq % 8 == 0
+            if not fuse_glue:
+                K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
             dqv = torch.empty(Mq, d, dtype=dt, device=dev)
             K.gemm(dBD, p, dqv, M=Tq, N=dk, K=n_pos, lda=ldB, ldb=d, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
                    a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
-            K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
+            if not fuse_glue:
+                K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
             qv = torch.empty(Mq, d, dtype=dt, device=dev)
             K.bias_add_rows(q, ldq, prm["pos_v"].data, qv, d, Mq, d)
             dp = torch.zeros(n_pos, d, dtype=torch.float32, device=dev)
@@ -660,8 +663,11 @@ class AttentionFn(torch.autograd.Function):
                    a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=max(1, min(ktiles, 64)), c_atomic=True)
             pos32 = _pos_table_f32(pos_tab)
             K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
-                   split_k=max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
-            dq[:, :d].add_(dqv)
+                   split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
+            if fuse_glue:  # dq += dqv, pos_u.grad += colsum(dq), pos_v.grad += colsum(dqv) in one pass
+                K.add_colsum2(dq, ldq, dqv, d, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), Mq, d)
+            else:
+                dq[:, :d].add_(dqv)
             _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
         dxq = torch.empty(Mq, d, dtype=dt, device=dev)
         if ctx.self_attn:
@@ -1287,6 +1293,7 @@ def ctc_compress_plan(logit2d, lens32, B, T, blank, threshold):
 # SATE adapter (inter_league)
 # ------------------------------------------------------------------------------------------------
 _POS32 = {}
+_POSW_SPLIT = int(os.environ.get("S2T_POSW_SPLIT", "0"))  # experiment: K split of the small fp32 linear_pos weight-gradient GEMM
 
 
 def _pos_table_f32(pos_tab):

@@ -270,6 +270,10 @@ def argmax_lse(logits, ld, rows, V, idx=None, top_lp=None, lse=None):
     _call("s2t_argmax_lse", L.dtype_id(logits.dtype), logits.data_ptr(), ld, rows, V, _ptr(idx), _ptr(top_lp), _ptr(lse))
 
 
+def add_colsum2(a, lda, b, ldb, du, dv, rows, n):
+    _call("s2t_add_colsum2", L.dtype_id(a.dtype), a.data_ptr(), lda, b.data_ptr(), ldb, du.data_ptr(), dv.data_ptr(), rows, n)
+
+
 def ctc_collapse(idx, top_lp, lens, B, T, blank, out_tokens, out_lens, out_scores):
     _call("s2t_ctc_collapse", idx.data_ptr(), top_lp.data_ptr(), lens.data_ptr(), B, T, blank, out_tokens.data_ptr(),
           out_lens.data_ptr(), out_scores.data_ptr())

@@ -443,3 +443,19 @@ def test_dwpool_bn_act_fwd_bwd(dtype, r):
     for got, want in ((w.grad, wr.grad), (b.grad, br.grad), (gamma.grad, gr_.grad), (beta.grad, ber.grad)):
         err = float((got.detach().cpu() - want).abs().max())
         assert err <= (0.2 if dtype == torch.bfloat16 else 2e-3) * max(gs, float(want.abs().max())), (err, gs)  # bf16: dD is stored rounded
+
+
+def test_add_colsum2_relpos_glue():
+    """s2t_add_colsum2: a += b in place with the column sums of the old a and of b (strided a, ragged last slice)."""
+    g = torch.Generator().manual_seed(33)
+    rows, n = 16003, 256
+    a = rnd((rows, 3 * n), torch.bfloat16, g)
+    b = rnd((rows, n), torch.bfloat16, g)
+    ad, bd = a.to(DEV), b.to(DEV)
+    du, dv = torch.full((n,), 1.0, device=DEV), torch.full((n,), -2.0, device=DEV)
+    K.add_colsum2(ad, 3 * n, bd, n, du, dv, rows, n)
+    close(du - 1, a[:, :n].float().sum(0), torch.float32, 400)
+    close(dv + 2, b.float().sum(0), torch.float32, 400)
+    want = (a[:, :n].float() + b.float()).to(torch.bfloat16)
+    assert torch.equal(ad[:, :n].cpu(), want)
+    assert torch.equal(ad[:, n:].cpu(), a[:, n:])  # the k / v slices are untouched
