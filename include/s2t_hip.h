@@ -76,7 +76,8 @@ typedef struct s2t_gemm_args {
   const void* dact_z;   int64_t ldz; int32_t dact; /* multiply by act'(z) with act = dact; z is c_dtype, same batch strides as C */
   const int32_t* row_lens; int32_t row_T;
   int32_t split_k;
-  int32_t c_atomic; /* 1: add alpha*acc to fp32 C with atomics even when split_k == 1 (several batches share one C) */
+  int32_t c_atomic; /* 1: add alpha*acc to fp32 C with atomics even when split_k == 1 (several batches share one C);
+                       2: split-K through the workspace with C = alpha*sum (overwrite: C need not be zeroed; split_k > 1) */
   float* colsum_a;  /* optional, a_kmajor only: colsum_a[m] += alpha * sum_k A_op[m][k]  (bias gradient fused into wgrad) */
   float drop_p;     /* > 0: v = keep(seed, site, global_row*Nout + n) ? v/(1-p) : 0 after the activation / act' stage */
   uint32_t drop_site;

@@ -513,14 +513,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args 
   const f32x4 sum = (s0 + s1) + (s2 + s3);
   if (m < p.M && n < p.N) {
     float* dst = C + (int64_t)m * p.ldc + n;
+    const bool overwrite = p.c_atomic == 2;  // C = alpha * sum: the caller need not zero C first
     if (n + 3 < p.N && (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
-      f32x4 c = *reinterpret_cast<f32x4*>(dst);
+      f32x4 c = overwrite ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(dst);
       c += sum * p.alpha;
       *reinterpret_cast<f32x4*>(dst) = c;
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < p.N) dst[r] += p.alpha * sum[r];
+        if (n + r < p.N) dst[r] = (overwrite ? 0.f : dst[r]) + p.alpha * sum[r];
     }
   }
 }
@@ -639,6 +640,7 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
     // batches must own disjoint parts of C (the reduction is a plain read-modify-write)
     const bool disjoint = p.batch == 1 || (p.zdiv == 1 && (p.c_s0 >= p.N || p.c_s0 >= (int64_t)p.M * p.ldc));
     if (!(p.ws && need > 0 && p.ws_floats >= need && all_splits_busy && disjoint && ((uintptr_t)p.ws % 16) == 0)) p.ws = nullptr;
+    if (p.c_atomic == 2 && !p.ws) return S2T_ERR_UNSUPPORTED;  // overwrite needs the two-phase (workspace) reduction
   }
   hipStream_t s = (hipStream_t)stream;
   if (p.dtype == S2T_BF16 && p.K % 64 == 0 && p.K > 0 && use_ring() && !p.ws) {

@@ -657,10 +657,12 @@ class AttentionFn(torch.autograd.Function):
                 K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
             qv = torch.empty(Mq, d, dtype=dt, device=dev)
             K.bias_add_rows(q, ldq, prm["pos_v"].data, qv, d, Mq, d)
-            dp = torch.zeros(n_pos, d, dtype=torch.float32, device=dev)
             ktiles = (Mq + 63) // 64
+            sk = max(1, min(ktiles, 64))
+            # two-phase split-K in overwrite mode (c_atomic = 2) needs no zero fill of dp
+            dp = (torch.empty if sk > 1 else torch.zeros)(n_pos, d, dtype=torch.float32, device=dev)
             K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
-                   a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=max(1, min(ktiles, 64)), c_atomic=True)
+                   a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=sk, c_atomic=2 if sk > 1 else True)
             pos32 = _pos_table_f32(pos_tab)
             K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
                    split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
@@ -743,10 +745,12 @@ class AttentionFn(torch.autograd.Function):
                    a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
             K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
             # dp[n, h, :] = sum_{b,i} dBD[h, (b,i), n] * (q+v)[(b,i), h, :]   (one GEMM per head, K = B*Tq)
-            dp = torch.zeros(n_pos, d, dtype=torch.float32, device=dev)
             ktiles = (Mq + 63) // 64
+            sk = max(1, min(ktiles, 64))
+            # two-phase split-K in overwrite mode (c_atomic = 2) needs no zero fill of dp
+            dp = (torch.empty if sk > 1 else torch.zeros)(n_pos, d, dtype=torch.float32, device=dev)
             K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
-                   a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=max(1, min(ktiles, 64)), c_atomic=True)
+                   a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=sk, c_atomic=2 if sk > 1 else True)
             # linear_pos weight: dW[dout, din] += dp^T pos_tab  (fp32 GEMM on the fp32 table)
             pos32 = _pos_table_f32(pos_tab)
             K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
