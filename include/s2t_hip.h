@@ -107,7 +107,9 @@ int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* 
                       const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int replicas, int64_t rows,
                       int cols, const int32_t* row_lens, int row_T,
                       const void* dres /* optional [rows][cols]: dx += dres (gradient of the residual branch of a pre-LN block) */,
-                      void* stream);
+                      void* dx_drop /* optional second output (bf16, cols == 256 only): s2t_dropout(dx) under the mask
+                                       (drop_p, drop_seed, drop_site) — the branch gradient of the block in front */,
+                      float drop_p, const uint64_t* drop_seed, uint32_t drop_site, void* stream);
 /* dgamma == dbeta == NULL in s2t_layernorm_bwd leaves the per-replica partial sums in ws ([replicas][2][cols], zeroed
  * before); s2t_layernorm_fold then adds them into the parameter gradients of MANY LayerNorms in one launch and zeroes
  * the workspaces again.  `entries` is a host array (passed to the kernel by value). */

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void ln256_bwd_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ rstd, bf16_t* __restrict__ dx,
                                                         const bf16_t* __restrict__ dres, float* __restrict__ ws,
                                                         int replicas, int64_t rows, const int32_t* __restrict__ row_lens,
-                                                        int row_T) {
+                                                        int row_T, bf16_t* __restrict__ dx_drop, float drop_p,
+                                                        const uint64_t* __restrict__ drop_seed, uint32_t drop_site) {
   __shared__ float red[2][8][256];
   const int lane = threadIdx.x & 63, l = lane & 31, hw = (threadIdx.x >> 6) * 2 + (lane >> 5);
   float g[8];
@@ -299,7 +300,22 @@ __global__ __launch_bounds__(256) void ln256_bwd_kernel(const bf16_t* __restrict
         unpack8(tr[u], q);
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[r] = rs[u] * (dg[r] - s1 - xh[r] * s2) + q[r];
-        *reinterpret_cast<uint4*>(dx + (row0 + u) * 256 + l * 8) = pack8f(o);
+        const uint4 packed = pack8f(o);
+        *reinterpret_cast<uint4*>(dx + (row0 + u) * 256 + l * 8) = packed;
+        if (dx_drop) {
+          // second output: the inverted-dropout image of dx under the mask of the block that PRODUCED this LayerNorm's
+          // input (its branch gradient), bit-identical to s2t_dropout applied to the stored bf16 dx
+          float v[8];
+          unpack8(packed, v);
+          const uint64_t key = s2t_drop_key(drop_seed, drop_site);
+          const uint32_t th = s2t_drop_thresh(drop_p);
+          const float inv = s2t_drop_scale(drop_p);
+          uint32_t r16[8];
+          s2t_rand_run<8>(key, (uint64_t)(row0 + u) * 256 + l * 8, r16);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = r16[r] >= th ? v[r] * inv : 0.f;
+          *reinterpret_cast<uint4*>(dx_drop + (row0 + u) * 256 + l * 8) = pack8f(v);
+        }
       }
     }
   }
@@ -373,6 +389,7 @@ extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, c
 extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, const void* dy, const float* mean,
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, int replicas,
                                  int64_t rows, int cols, const int32_t* row_lens, int row_T, const void* dres,
+                                 void* dx_drop, float drop_p, const uint64_t* drop_seed, uint32_t drop_site,
                                  void* stream) {
   if (!x || !gamma || !dy || !mean || !rstd || !dx || (!dgamma != !dbeta) || !ws || replicas <= 0 || rows < 0 || cols <= 0)
     return S2T_ERR_ARG;
@@ -382,16 +399,19 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, c
   if (nb > 2048) nb = 2048;
   dim3 grid((unsigned)nb), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const bool fast256 = dtype == S2T_BF16 && cols == 256 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
+                       ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dres % 16) == 0;
+  if (dx_drop && (!fast256 || ((uintptr_t)dx_drop % 16) || !(drop_p > 0.f && drop_p < 1.f))) return S2T_ERR_UNSUPPORTED;
   if (dtype == S2T_F32)
     LN_DISPATCH(ln_bwd_kernel, float, (const float*)x, gamma, (const float*)dy, mean, rstd, (float*)dx, (const float*)dres, ws, replicas, rows, cols, row_lens, row_T);
-  else if (dtype == S2T_BF16 && cols == 256 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
-           ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dres % 16) == 0) {
+  else if (fast256) {
     // 32 rows per workgroup and trip; at most 512 workgroups: every workgroup closes with 512 float atomics into the
     // replica workspace, which are executed at the memory side (2000 workgroups made that a million per call)
     int64_t nb8 = (rows + 31) / 32;
     if (nb8 > 512) nb8 = 512;
     hipLaunchKernelGGL(ln256_bwd_kernel, dim3((unsigned)nb8), block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean,
-                       rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, row_lens, row_T);
+                       rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, row_lens, row_T, (bf16_t*)dx_drop, drop_p,
+                       drop_seed, drop_site);
   } else if (dtype == S2T_BF16)
     LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean, rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, cols, row_lens, row_T);
   else return S2T_ERR_DTYPE;

@@ -66,10 +66,31 @@ class _DropoutState:
 DROPOUT = _DropoutState()
 
 
+_FUSE_LN_DROP = os.environ.get("S2T_FUSE_LN_DROP", "1") != "0"
+DROP_STATS = {"handed_over": 0, "launched": 0}  # how the dropped branch gradients of backward passes were obtained
+
+
+def _same_drop(a, b):
+    return a is not None and b is not None and a[0] == b[0] and a[2] == b[2] and a[1].data_ptr() == b[1].data_ptr()
+
+
+def _tag_drop(y, drop):
+    """Mark a block output with the mask of its output dropout: the LayerNorm that consumes it can then produce the
+    dropped branch gradient in its own backward pass (LayerNormFn), instead of a separate dropout launch."""
+    if drop is not None and _FUSE_LN_DROP and y is not None:
+        y._s2t_drop_o = drop
+    return y
+
+
 def _drop_rows(x, drop):
     """x * mask / (1-p) for a [rows, cols] matrix (mask convention of the GEMM epilogue); identity when drop is None."""
     if drop is None:
         return x
+    ready = getattr(x, "_s2t_dropped", None)  # left there by the LayerNorm backward that produced x
+    if ready is not None and _same_drop(ready[0], drop) and ready[1].shape == x.shape:
+        DROP_STATS["handed_over"] += 1
+        return ready[1]
+    DROP_STATS["launched"] += 1
     rows, cols = x.shape
     out = torch.empty(rows, cols, dtype=x.dtype, device=x.device)
     K.dropout(x, x.stride(0), out, cols, rows, cols, drop)
@@ -376,6 +397,8 @@ class LayerNormFn(torch.autograd.Function):
         K.layernorm_fwd(x, gamma.data, beta.data, y, mean, rstd, rows, cols, 1e-5, lens, T)
         ctx.save_for_backward(x, mean, rstd)
         ctx.gamma, ctx.beta, ctx.lens, ctx.T = gamma, beta, lens, T
+        up = getattr(x, "_s2t_drop_o", None)  # output-dropout mask of the block that produced x (see _tag_drop)
+        ctx.up_drop = up if (up is not None and x.dtype == torch.bfloat16 and cols == 256) else None
         if fork:
             return y, x.view_as(x)
         return y
@@ -387,16 +410,19 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         if dres is not None:
             dres = dres.contiguous()
+        dxd = torch.empty_like(x) if ctx.up_drop is not None else None
         if x.is_cuda and _arm_backward_end():
             # partial sums into a private workspace slice; ONE fold launch for all LayerNorms at the end of backward
             ws = _ln_workspace(cols, x.device)
             K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, None, None, rows, cols, ctx.lens, ctx.T,
-                            dres, ws=ws)
+                            dres, ws=ws, dx_drop=dxd, drop=ctx.up_drop)
             _LNQ["entries"].append((ws, ctx.gamma.grad, ctx.beta.grad, cols))
         else:
             K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, ctx.gamma.grad, ctx.beta.grad, rows, cols,
-                            ctx.lens, ctx.T, dres)
+                            ctx.lens, ctx.T, dres, dx_drop=dxd, drop=ctx.up_drop)
         _ready(ctx.gamma, ctx.beta)
+        if dxd is not None:
+            dx._s2t_dropped = (ctx.up_drop, dxd)  # picked up by _drop_rows in the producing block's backward
         return dx, None, None, None, None, None
 
 
@@ -499,7 +525,7 @@ class FFNFn(torch.autograd.Function):
 def ffn(x, w1, b1, w2, b2, act, alpha, residual, p_hidden=0.0, p_out=0.0, training=False):
     drop_h = DROPOUT.next(p_hidden if training else 0.0, x.device)
     drop_o = DROPOUT.next(p_out if training else 0.0, x.device)
-    return FFNFn.apply(x, w1, b1, w2, b2, act, alpha, residual, torch.is_grad_enabled(), drop_h, drop_o)
+    return _tag_drop(FFNFn.apply(x, w1, b1, w2, b2, act, alpha, residual, torch.is_grad_enabled(), drop_h, drop_o), drop_o)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -785,8 +811,8 @@ def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False,
               p_attn=0.0, p_out=0.0, training=False):
     drop_a = DROPOUT.next(p_attn if training else 0.0, xq.device)
     drop_o = DROPOUT.next(p_out if training else 0.0, xq.device)
-    return AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
-                             torch.is_grad_enabled(), drop_a, drop_o)
+    return _tag_drop(AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
+                                       torch.is_grad_enabled(), drop_a, drop_o), drop_o)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -922,8 +948,8 @@ class ConvModuleFn(torch.autograd.Function):
 
 def conv_module(x, residual, prm, bn_buf, act, B, T, lens, training, momentum=0.1, p_out=0.0):
     drop_o = DROPOUT.next(p_out if training else 0.0, x.device)
-    return ConvModuleFn.apply(x, residual, prm, bn_buf, act, B, T, lens, training, momentum, torch.is_grad_enabled(),
-                              drop_o)
+    return _tag_drop(ConvModuleFn.apply(x, residual, prm, bn_buf, act, B, T, lens, training, momentum,
+                                        torch.is_grad_enabled(), drop_o), drop_o)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -128,13 +128,16 @@ def _workspace(tag, n, device):
     return t
 
 
-def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0, dres=None, ws=None):
-    """``ws`` given and ``dgamma is None``: leave the partial sums in ``ws`` for layernorm_fold."""
+def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0, dres=None, ws=None,
+                  dx_drop=None, drop=None):
+    """``ws`` given and ``dgamma is None``: leave the partial sums in ``ws`` for layernorm_fold.
+    ``dx_drop`` + ``drop`` = (p, seed tensor, site): also write dropout(dx) under that mask (bf16, cols == 256)."""
     if ws is None:
         ws = _workspace("ln", LN_REPLICAS * 2 * cols, x.device)
+    p, seed, site = (float(drop[0]), drop[1].data_ptr(), int(drop[2])) if dx_drop is not None else (0.0, None, 0)
     _call("s2t_layernorm_bwd", L.dtype_id(x.dtype), x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), mean.data_ptr(),
           rstd.data_ptr(), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), LN_REPLICAS, rows, cols,
-          _ptr(row_lens), row_T, _ptr(dres))
+          _ptr(row_lens), row_T, _ptr(dres), _ptr(dx_drop), p, seed, site)
 
 
 class _LnFoldEntry(C.Structure):

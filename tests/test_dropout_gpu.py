@@ -94,3 +94,62 @@ def test_forward_and_backward_share_masks(conformer):
     with torch.no_grad():
         le, _, _ = crit(model, sample, sync_logging=False)
     assert abs(float(le) - l0) > 1e-5 * abs(l0)
+
+
+def test_layernorm_backward_hands_over_the_dropped_branch_gradient():
+    """The LayerNorm backward (bf16, d = 256) also writes dropout(dx) under the mask of the block in front; the kernel's
+    second output is bit-identical to s2t_dropout on dx, the hand-over really happens in a model backward, and switching
+    it off gives the same gradients."""
+    from s2t_amd import functional as Fn
+    g = torch.Generator().manual_seed(2)
+    rows, cols = 777, 256
+    x = (torch.randn(rows, cols, generator=g)).to(torch.bfloat16).to(DEV)
+    dy = (torch.randn(rows, cols, generator=g)).to(torch.bfloat16).to(DEV)
+    dres = (torch.randn(rows, cols, generator=g)).to(torch.bfloat16).to(DEV)
+    w = (1 + 0.1 * torch.randn(cols, generator=g)).to(DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    y = torch.empty_like(x)
+    K.layernorm_fwd(x, w, torch.zeros(cols, device=DEV), y, mean, rstd, rows, cols)
+    seed = torch.tensor([99], dtype=torch.int64, device=DEV)
+    drop = (0.25, seed, 5)
+    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    dg, db = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    K.layernorm_bwd(x, w, dy, mean, rstd, dx, dg, db, rows, cols, dres=dres, dx_drop=dxd, drop=drop)
+    ref = torch.empty_like(x)
+    K.dropout(dx, cols, ref, cols, rows, cols, drop)
+    assert torch.equal(dxd, ref) and float((dxd == 0).float().mean()) > 0.2
+
+    def grads(fuse):
+        torch.manual_seed(4)
+        V = 50
+        args = M.recipe_args(conformer=True, encoder_layers=2, decoder_layers=1, vocab_size=V, dropout=0.2,
+                             attention_dropout=0.2, activation_dropout=0.2)  # d = 256: the fast LayerNorm kernels
+        model = M.S2TTransformerModel.build_model(args, M.FakeTask(V)).prepare(torch.bfloat16, DEV)
+        model.train()
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+        gg = torch.Generator().manual_seed(1)
+        B, T = 2, 83
+        src = torch.randn(B, T, 80, generator=gg).to(DEV)
+        lens = torch.tensor([83, 61]).to(DEV)
+        tgt = torch.randint(4, V, (B, 7), generator=gg)
+        tgt[:, -1] = 2
+        prev = torch.roll(tgt, 1, 1)
+        sample = {"net_input": {"src_tokens": src, "src_lengths": lens, "prev_output_tokens": prev.to(DEV)},
+                  "target": tgt.to(DEV), "ntokens": 14}
+        Fn._FUSE_LN_DROP = fuse
+        Fn.DROP_STATS.update(handed_over=0, launched=0)
+        Fn.DROPOUT.begin_step(torch.device(DEV))
+        Fn.DROPOUT.set_seed(7)
+        model.flat.zero_grad()
+        crit(model, sample)[0].backward()
+        torch.cuda.synchronize()
+        return model.flat.grad.clone(), dict(Fn.DROP_STATS)
+
+    try:
+        g1, st1 = grads(True)
+        g0, st0 = grads(False)
+    finally:
+        Fn._FUSE_LN_DROP = True
+    assert st0["handed_over"] == 0 and st0["launched"] > 8
+    assert st1["handed_over"] >= 8, st1  # 4 per Conformer layer + decoder blocks
+    assert float((g1 - g0).norm() / g0.norm()) < 1e-5  # same arithmetic; parameter-level sums use float atomics
