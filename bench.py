@@ -246,13 +246,32 @@ def main():
         # Conformer encoder, 9.7 for the Transformer one; + 1.28 with the CTC head), eval mode, no autograd
         model.eval()
         ni = sample["net_input"]
+        enc_graph = None
         with torch.no_grad():
             for _ in range(2):
                 model.encoder(ni["src_tokens"], ni["src_lengths"])
+            torch.cuda.synchronize()
+            if use_graph:
+                # ~450 launches of a few microseconds each: timed eagerly this leg measures the host's launch rate, not the
+                # GPU; capture one encoder forward and time replays (falls back to eager launches if capture fails)
+                try:
+                    gph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gph, capture_error_mode="thread_local"):
+                        model.encoder(ni["src_tokens"], ni["src_lengths"])
+                    gph.replay()
+                    torch.cuda.synchronize()
+                    enc_graph = gph
+                except Exception as e:  # noqa: BLE001
+                    print("[bench] encoder-forward capture failed (%s: %s); timing eager launches" % (type(e).__name__, e),
+                          file=sys.stderr)
+                    torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                model.encoder(ni["src_tokens"], ni["src_lengths"])
+                if enc_graph is not None:
+                    enc_graph.replay()
+                else:
+                    model.encoder(ni["src_tokens"], ni["src_lengths"])
             e1.record()
             torch.cuda.synchronize()
         model.train()
@@ -260,7 +279,7 @@ def main():
         per_frame = (18.0e6 if conformer else 9.7e6) * (args.enc_layers / 12.0) + 1.28e6
         enc_flop = per_frame * args.batch * args.frames
         roofline["encoder_fwd"] = {"ms": enc_s * 1e3, "tflops": enc_flop / enc_s / 1e12, "frac": enc_flop / enc_s / peak,
-                                   "flop_per_input_frame": per_frame}
+                                   "flop_per_input_frame": per_frame, "hip_graph": enc_graph is not None}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, V, conformer)
