@@ -272,6 +272,7 @@ int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int
                    const float* scale, const float* shift, int act, const int32_t* lens, float* stats, void* stream);
 int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, float* ws /* [replicas][C][K]: zero in, zero out */,
                           int replicas, int B, int T, int C, int K, void* stream);
+int s2t_dwconv_wgrad_partials(int B, int T); /* rows of C*K floats s2t_dwconv_bwd_weight needs in ws (pass as `replicas`) */
 int s2t_dwconv_stat_partials(int B, int T);
 int s2t_bn_bwd_partials(int64_t rows);
 int s2t_bn_finalize(const float* stats, int partials, float count, const float* gamma, const float* beta, float* running_mean,

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
       }
     }
   }
-  // transpose the per-thread partials through LDS so that a wave-instruction adds 64 CONSECUTIVE floats
-  // (scattered float atomics run ~17x slower than 256-byte-contiguous ones on this chip)
+  // transpose the per-thread partials through LDS and store this workgroup's [channels][K] partial as one contiguous row
+  // of the workspace (no atomics: dwconv_wgrad_fold_kernel adds the rows in a fixed order)
   __syncthreads();
   float* lt = smem;  // [256 channels][K]
 #pragma unroll
@@ -179,20 +179,11 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     }
   }
   __syncthreads();
-  float* dw = dw_ws + (int64_t)(blockIdx.x % replicas) * C * K + (int64_t)c0 * K;
+  float* dw = dw_ws + (int64_t)blockIdx.x * C * K + (int64_t)c0 * K;
   const int nvalid = min(CCH, C - c0) * K;
-  for (int idx = threadIdx.x; idx < nvalid; idx += 256) atomicAdd(dw + idx, lt[idx]);
+  for (int idx = threadIdx.x; idx < nvalid; idx += 256) dw[idx] = lt[idx];
 }
 
-__global__ void fold_replicas_kernel(float* __restrict__ ws, int replicas, int64_t n, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-#pragma unroll 8
-  for (int r = 0; r < replicas; ++r) s += ws[(int64_t)r * n + i];
-  for (int r = 0; r < replicas; ++r) ws[(int64_t)r * n + i] = 0.f;  // leave the workspace zeroed for the next call
-  out[i] += s;
-}
 
 // Fixed-order column sum of `rows` partial rows (row stride `ld` floats) for 16 adjacent columns per 1024-thread
 // workgroup.  Thread (g = tid / 16, cl = tid % 16) adds rows g, g + 64, ... in order (loads issued four at a time), the
@@ -345,6 +336,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(const float* __restri
   }
 }
 
+// out[0:n] += fixed-order sum of the partial rows [rows][n]
+__global__ __launch_bounds__(1024) void rows_fold_add_kernel(const float* __restrict__ partial, int rows, int64_t n,
+                                                             float* __restrict__ out) {
+  __shared__ float red[16][16];
+  const int64_t c = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const float t = fold_partial_rows(partial + c, rows, n, c < n, red);
+  if (threadIdx.x < 16 && c < n) out[c] += t;
+}
+
 // pass 2: dD = gamma*rstd * (du - s1/n - xhat * s2/n)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ D, const T* __restrict__ dOut,
@@ -420,6 +420,7 @@ extern "C" int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, f
   const int tiles_t = (T + TT - 1) / TT;
   int nb = B * tiles_t;
   if (nb > 1024) nb = 1024;
+  if (replicas < nb) return S2T_ERR_ARG;  // ws: one row of C*K floats per workgroup (s2t_dwconv_wgrad_partials)
   dim3 grid(nb, 1, (C + CCH - 1) / CCH), block(256);
   hipStream_t s = (hipStream_t)stream;
   ensure_lds_optin();
@@ -429,8 +430,13 @@ extern "C" int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, f
     hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)G, (const bf16_t*)dD, ws, replicas, B, T, C, K, tiles_t);
   } else return S2T_ERR_DTYPE;
   const int64_t n = (int64_t)C * K;
-  hipLaunchKernelGGL(fold_replicas_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, replicas, n, dw);
+  hipLaunchKernelGGL(rows_fold_add_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, s, ws, nb, n, dw);
   return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_dwconv_wgrad_partials(int B, int T) {
+  const int nb = B * ((T + TT - 1) / TT);
+  return nb > 1024 ? 1024 : nb;
 }
 
 extern "C" int s2t_dwconv_stat_partials(int B, int T) { return B * ((T + TT - 1) / TT); }

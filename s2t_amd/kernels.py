@@ -241,9 +241,10 @@ DW_REPLICAS = 16
 
 
 def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
-    ws = _workspace("dw", DW_REPLICAS * C * K, G.device)
+    rows = L.lib().s2t_dwconv_wgrad_partials(B, T)  # one plain-stored partial row per workgroup, folded in fixed order
+    ws = _scratch("dw", rows * C * K, G.device)
     _call("s2t_dwconv_bwd_weight", L.dtype_id(G.dtype), G.data_ptr(), dD.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-          DW_REPLICAS, B, T, C, K)
+          rows, B, T, C, K)
 
 
 def dwconv_stat_partials(B, T):
