@@ -21,21 +21,26 @@ __device__ __forceinline__ void stage_rows(float* lds, const T* __restrict__ x, 
   const int total = nrows * 64;
   for (int base = threadIdx.x; base < total; base += 256 * NB) {
     float v[NB][4];
+    bool ok[NB];
+    // The loads are UNCONDITIONAL (clamped addresses, results discarded by a select afterwards): a load under a branch
+    // makes the compiler wait for it on the spot, which serialises the whole batch (one memory latency per load).
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      const int idx = base + q * 256;
+      const int idx = min(base + q * 256, total - 1);
       const int r = idx >> 6, cq = idx & 63;
       const int t = t_first + r;
       const int c = c0 + cq * 4;
-      v[q][0] = v[q][1] = v[q][2] = v[q][3] = 0.f;
-      if (idx < total && t >= 0 && t < T_ && c < C) ld4_as_f32<T>(x + (base_row + t) * C + c, v[q]);
+      ok[q] = base + q * 256 < total && t >= 0 && t < T_ && c < C;
+      const int tc = min(max(t, 0), T_ - 1), cc = min(c, C - 4);
+      ld4_as_f32<T>(x + (base_row + tc) * C + cc, v[q]);
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       const int idx = base + q * 256;
       if (idx < total) {
         const int r = idx >> 6, cq = idx & 63;
-        *reinterpret_cast<float4*>(lds + r * CCH + cq * 4) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+        *reinterpret_cast<float4*>(lds + r * CCH + cq * 4) =
+            make_float4(ok[q] ? v[q][0] : 0.f, ok[q] ? v[q][1] : 0.f, ok[q] ? v[q][2] : 0.f, ok[q] ? v[q][3] : 0.f);
       }
     }
   }
