@@ -296,17 +296,28 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     ld4_as_f32<float>(shift + c, sh);
     ld4_as_f32<float>(mean + c, mu);
     ld4_as_f32<float>(rstd + c, rs);
-    for (int64_t m = (int64_t)blockIdx.y * 4 + w; m < rows; m += (int64_t)gridDim.y * 4) {
-      if (lens && (int)(m % Tn) >= lens[m / Tn]) continue;
-      float d[4], g[4];
-      ld4_as_f32<T>(D + m * C + c, d);
-      ld4_as_f32<T>(dOut + m * C + c, g);
+    // four rows per trip, all eight loads issued unconditionally (rows past the end re-read the last row, masked rows
+    // are loaded anyway) and discarded by a select: loads under a branch are waited for one at a time
+    const int64_t step = (int64_t)gridDim.y * 4;
+    for (int64_t m0 = (int64_t)blockIdx.y * 4 + w; m0 < rows; m0 += 4 * step) {
+      float d[4][4], g[4][4];
+      bool ok[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float du = g[r] * act_grad(act, d[r] * sc[r] + sh[r]);
-        a1[r] += du;
-        a2[r] += du * (d[r] - mu[r]) * rs[r];
+      for (int u = 0; u < 4; ++u) {
+        const int64_t m = m0 + u * step;
+        const int64_t mc = m < rows ? m : rows - 1;
+        ok[u] = m < rows && !(lens && (int)(mc % Tn) >= lens[mc / Tn]);
+        ld4_as_f32<T>(D + mc * C + c, d[u]);
+        ld4_as_f32<T>(dOut + mc * C + c, g[u]);
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float du = ok[u] ? g[u][r] * act_grad(act, d[u][r] * sc[r] + sh[r]) : 0.f;
+          a1[r] += du;
+          a2[r] += du * (d[u][r] - mu[r]) * rs[r];
+        }
     }
   }
 #pragma unroll
