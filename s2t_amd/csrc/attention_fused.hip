@@ -159,9 +159,29 @@ struct QFrags {
   bf16x8 qv[2];   // q+v (rel only)
 };
 
-template <bool REL>
+// the 80 position rows (5 MFMA tiles x 2 k-steps) a (16-query x 64-key) block needs: nbase + (0..79) with
+// nbase = Tq-1-(q0w+15)+k0, clamped.  Loaded from global (L2-resident, shared by every workgroup of a head) one block AHEAD
+// of their use: issued together with a block's MFMAs, their round trip no longer sits on every block's critical path.
+struct PFrags {
+  uint4 v[5][2];
+};
+__device__ __forceinline__ void load_pfrags(const FusedArgs& a, PFrags& pf, int h, int q0w, int k0, int x, int y) {
+  const int nbase = a.Tq - 1 - (q0w + 15) + k0;
+  const int nmax = 2 * a.Tq - 2;
+  const bf16_t* pp = a.pos_p + h * DK;
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt) {
+    int n = nbase + 16 * nt + x;
+    n = n < 0 ? 0 : (n > nmax ? nmax : n);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) pf.v[nt][ks] = ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8);
+  }
+}
+
+template <bool REL, bool PRE = false>
 __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& qf, const char* lk, float* scratch,
-                                             int h, int q0w, int k0, int klen, int x, int y, f32x4 (&st)[4]) {
+                                             int h, int q0w, int k0, int klen, int x, int y, f32x4 (&st)[4],
+                                             const PFrags* pre = nullptr) {
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -181,7 +201,9 @@ __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& q
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 pf = as_frag(ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8));
+        bf16x8 pf;
+        if constexpr (PRE) pf = as_frag(pre->v[nt][ks]);  // compile-time choice: a load under a run-time test is
+        else pf = as_frag(ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8));  // waited for on the spot
         acc = mfma16(pf, qf.qv[ks], acc);
       }
       // lane (x = q, y) holds band rows 16nt + 4y + r
@@ -260,6 +282,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
   TileRegs tk, tv;
   tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
   tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
+  PFrags pnext;  // position rows of the block about to be scored (one register set: re-filled right after its MFMAs)
+  if constexpr (REL) load_pfrags(a, pnext, h, q0w, 0, x, y);
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
     tile_store(lk, tk, k0, a.Tk, nullptr, tid);
@@ -270,7 +294,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
       tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
     }
     f32x4 st[4];
-    scores_block<REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st);
+    scores_block<REL, REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
+    if constexpr (REL) {  // the next block's position rows travel during this block's softmax and PV product
+      if (k0 + KB < kend) load_pfrags(a, pnext, h, q0w, k0 + KB, x, y);
+    }
     // ---- online softmax (row = lane's query; its 16 keys in registers, the other 48 in the 3 other y-groups)
     float mx = -INFINITY;
 #pragma unroll
@@ -417,6 +444,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   TileRegs tk, tv;
   tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
   tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
+  PFrags pnext;  // position rows of the block about to be scored (one register set: re-filled right after its MFMAs)
+  if constexpr (REL) load_pfrags(a, pnext, h, q0w, 0, x, y);
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
     tile_store(lk, tk, k0, a.Tk, nullptr, tid);
@@ -427,7 +456,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
     }
     f32x4 st[4];
-    scores_block<REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st);
+    scores_block<REL, REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
+    if constexpr (REL) {  // the next block's position rows travel during this block's softmax and PV product
+      if (k0 + KB < kend) load_pfrags(a, pnext, h, q0w, k0 + KB, x, y);
+    }
     // dP^T[key][q] = V[key] . dO[q]
     f32x4 dpt[4];
 #pragma unroll
