@@ -577,6 +577,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
     }
   };
   if (qstart < a.Tq) prefetch(qstart);
+  // Position rows of a whole 64-query block against this wave's 16 keys: n = nb64 + (0..79), nb64 = Tq-1-(q0+63)+k0w —
+  // the band of query tile qt, position tile nt is tile 3 - qt + nt of these five.  One register set, fetched once per
+  // query block (16 fragment loads on the tiles' critical paths before) and one block ahead of its use.
+  PFrags pfr;
+  auto load_band = [&](int q0) __attribute__((always_inline)) {
+    const int nb64 = a.Tq - 1 - (q0 + 63) + k0w;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      int n = nb64 + 16 * t + x;
+      n = n < 0 ? 0 : (n > nmax ? nmax : n);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) pfr.v[t][ks] = ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8);
+    }
+  };
+  if constexpr (REL) {
+    if (qstart < a.Tq) load_band(qstart);
+  }
   for (int q0 = qstart; q0 < a.Tq; q0 += 64) {
     __syncthreads();
     tile_store(lqa, tq, q0, a.Tq, REL ? a.pos_u + h * DK : nullptr, tid);
@@ -597,15 +614,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
       for (int ks = 0; ks < 2; ++ks) s4 = mfma16(frag_rows(lqa, qt, ks, x, y), kf[ks], s4);
       if constexpr (REL) {
         // band for (16 q x 16 keys): n = nb + (0..30), nb = Tq-1-(q0+16qt+15)+k0w ; element (ql, key x): 15 - ql + x
-        const int nb = a.Tq - 1 - (q0 + 16 * qt + 15) + k0w;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          int n = nb + 16 * nt + x;
-          n = n < 0 ? 0 : (n > nmax ? nmax : n);
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
-            acc = mfma16(frag_rows(lqv, qt, ks, x, y), as_frag(ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8)), acc);
+            acc = mfma16(frag_rows(lqv, qt, ks, x, y), as_frag(pfr.v[3 - qt + nt][ks]), acc);
           // lane (x = n index, y) holds q_local = 4y + r
 #pragma unroll
           for (int r = 0; r < 4; ++r) scratch[(4 * y + r) * SC2 + 16 * nt + x] = acc[r];
@@ -635,6 +649,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
         pd[qt][r] = pdrop;
         ds[qt][r] = p * (dp - del_s[ql]) * a.scale;
       }
+    }
+    if constexpr (REL) {  // the next query block's position rows travel during the dK/dV products below
+      if (q0 + 64 < a.Tq) load_band(q0 + 64);
     }
     // dV^T[c][key] += dO^T[c][q] Pd[q][key] ; dK^T[c][key] += qa^T[c][q] dS[q][key]
 #pragma unroll
