@@ -304,7 +304,9 @@ int s2t_row_softmax_bwd(int dtype, const void* p, int64_t ldp, const void* dp, i
 int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens, int B, int T, int blank,
                      int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
 int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V, const int64_t* target,
-                         int64_t pad_idx, float eps, void* dlogits, int64_t ldd, float* sums, void* stream);
+                         int64_t pad_idx, float eps, void* dlogits, int64_t ldd, float* sums,
+                         float* ws /* rows x 4 floats of scratch: per-row terms, folded into sums in a fixed order */,
+                         void* stream);
 /* force_emits (optional, [B][T] int64, -1 = free): imputer loss of torch_imputer/imputer.cu:57-215,339-477 (a frame
  * pinned to one extended-label state).  paths (optional, [B][T][Lmax] int32): max-product (Viterbi) recursion with
  * back-pointers of torch_imputer/best_alignment.cu:57-201 instead of log-sum-exp (then beta may be NULL).

@@ -179,11 +179,13 @@ __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int32_t* __res
 // per row r (token): lp = log_softmax(x); nll = -lp[y]; smooth = -sum(lp)
 //   loss += (1-eps-eps_i)*nll + eps_i*smooth  with eps_i = eps/(V-1);  pad rows contribute nothing.
 //   d loss / d x[c] = (1-eps-eps_i)*(p[c] - [c==y]) + eps_i*(V*p[c] - 1)
-// sums[0] += loss, sums[1] += nll, sums[2] += n_correct, sums[3] += n_total (atomics, fp32)
+// per row: part[row][0..3] = loss, nll, correct, counted (pad rows: zeros); ls_ce_fold_kernel adds the rows into sums in a
+// fixed order.  (Every row's workgroup adding into the same four floats with atomics took 160 us for 2 624 rows: same-address
+// float atomics are executed one after the other at the memory side.)
 template <typename T>
 __global__ __launch_bounds__(256) void ls_ce_kernel(const T* __restrict__ logits, int64_t ld, int V,
                                                     const int64_t* __restrict__ target, int64_t pad_idx, float eps,
-                                                    T* __restrict__ dlogits, int64_t ldd, float* __restrict__ sums) {
+                                                    T* __restrict__ dlogits, int64_t ldd, float* __restrict__ part) {
   __shared__ float ssum[4];
   const int64_t row = blockIdx.x;
   const int64_t y = target[row];
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(256) void ls_ce_kernel(const T* __restrict__ logits
   if (y == pad_idx) {
     if (dx)
       for (int c = threadIdx.x; c < V; c += 256) st_from_f32<T>(dx + c, 0.f);
+    if (threadIdx.x < 4) part[row * 4 + threadIdx.x] = 0.f;
     return;
   }
   float mx, lse;
@@ -217,11 +220,34 @@ __global__ __launch_bounds__(256) void ls_ce_kernel(const T* __restrict__ logits
     sx = ssum[0] + ssum[1] + ssum[2] + ssum[3];
     const float nll = lse - ld_as_f32<T>(x + y);
     const float smooth = V * lse - sx;
-    atomicAdd(sums + 0, wn * nll + eps_i * smooth);
-    atomicAdd(sums + 1, nll);
-    atomicAdd(sums + 2, arg == (int)y ? 1.f : 0.f);
-    atomicAdd(sums + 3, 1.f);
+    part[row * 4 + 0] = wn * nll + eps_i * smooth;
+    part[row * 4 + 1] = nll;
+    part[row * 4 + 2] = arg == (int)y ? 1.f : 0.f;
+    part[row * 4 + 3] = 1.f;
   }
+}
+
+// sums[k] += sum_rows part[row][k]: one workgroup, thread (g = tid / 4, k = tid % 4) adds rows g, g + 256, ... in order,
+// then a fixed tree over the 256 groups
+__global__ __launch_bounds__(1024) void ls_ce_fold_kernel(const float* __restrict__ part, int64_t rows,
+                                                          float* __restrict__ sums) {
+  __shared__ float red[256][4];
+  const int k = threadIdx.x & 3, g = threadIdx.x >> 2;
+  float acc = 0.f;
+  int64_t r = g;
+  for (; r + 768 < rows; r += 1024) {
+    const float v0 = part[r * 4 + k], v1 = part[(r + 256) * 4 + k], v2 = part[(r + 512) * 4 + k],
+                v3 = part[(r + 768) * 4 + k];
+    acc = (((acc + v0) + v1) + v2) + v3;
+  }
+  for (; r < rows; r += 256) acc += part[r * 4 + k];
+  red[g][k] = acc;
+  __syncthreads();
+  for (int half = 128; half > 0; half >>= 1) {
+    if (g < half) red[g][k] += red[g + half][k];
+    __syncthreads();
+  }
+  if (g == 0) sums[k] += red[0][k];
 }
 
 // ---- CTC loss (torch.nn.CTCLoss(blank, reduction='none', zero_infinity=True), criterions/ctc.py:243-245,467-472) ----
@@ -552,16 +578,17 @@ extern "C" int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const i
 
 extern "C" int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V,
                                     const int64_t* target, int64_t pad_idx, float eps, void* dlogits, int64_t ldd,
-                                    float* sums, void* stream) {
-  if (!logits || !target || !sums || rows < 0 || V <= 1 || ld < V) return S2T_ERR_ARG;
+                                    float* sums, float* ws /* [rows][4] scratch */, void* stream) {
+  if (!logits || !target || !sums || !ws || rows < 0 || V <= 1 || ld < V) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   dim3 grid((unsigned)rows), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ls_ce_kernel<float>, grid, block, 0, s, (const float*)logits, ld, V, target, pad_idx, eps, (float*)dlogits, ldd, sums);
+    hipLaunchKernelGGL(ls_ce_kernel<float>, grid, block, 0, s, (const float*)logits, ld, V, target, pad_idx, eps, (float*)dlogits, ldd, ws);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ls_ce_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)logits, ld, V, target, pad_idx, eps, (bf16_t*)dlogits, ldd, sums);
+    hipLaunchKernelGGL(ls_ce_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)logits, ld, V, target, pad_idx, eps, (bf16_t*)dlogits, ldd, ws);
   else return S2T_ERR_DTYPE;
+  hipLaunchKernelGGL(ls_ce_fold_kernel, dim3(1), dim3(1024), 0, s, ws, rows, sums);
   return S2T_LAUNCH_CHECK();
 }
 
