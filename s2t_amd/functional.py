@@ -684,7 +684,7 @@ class AttentionFn(torch.autograd.Function):
             qv = torch.empty(Mq, d, dtype=dt, device=dev)
             K.bias_add_rows(q, ldq, prm["pos_v"].data, qv, d, Mq, d)
             ktiles = (Mq + 63) // 64
-            sk = max(1, min(ktiles, 64))
+            sk = max(1, min(ktiles, _DP_SPLIT))
             # two-phase split-K in overwrite mode (c_atomic = 2) needs no zero fill of dp
             dp = (torch.empty if sk > 1 else torch.zeros)(n_pos, d, dtype=torch.float32, device=dev)
             K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
@@ -772,7 +772,7 @@ class AttentionFn(torch.autograd.Function):
             K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
             # dp[n, h, :] = sum_{b,i} dBD[h, (b,i), n] * (q+v)[(b,i), h, :]   (one GEMM per head, K = B*Tq)
             ktiles = (Mq + 63) // 64
-            sk = max(1, min(ktiles, 64))
+            sk = max(1, min(ktiles, _DP_SPLIT))
             # two-phase split-K in overwrite mode (c_atomic = 2) needs no zero fill of dp
             dp = (torch.empty if sk > 1 else torch.zeros)(n_pos, d, dtype=torch.float32, device=dev)
             K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
@@ -1323,6 +1323,7 @@ def ctc_compress_plan(logit2d, lens32, B, T, blank, threshold):
 # SATE adapter (inter_league)
 # ------------------------------------------------------------------------------------------------
 _POS32 = {}
+_DP_SPLIT = int(os.environ.get("S2T_DP_SPLIT", "16"))  # K split of the position-table gradient GEMM (M = 2T-1, N = 64 per head, K = B*T)
 _POSW_SPLIT = int(os.environ.get("S2T_POSW_SPLIT", "0"))  # experiment: K split of the small fp32 linear_pos weight-gradient GEMM
 
 
