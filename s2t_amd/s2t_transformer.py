@@ -556,6 +556,12 @@ class CTCDecoder:
         self.model = models[0] if isinstance(models, (list, tuple)) else models
         self.blank = blank_idx
         self.pad = 1 if dictionary is None else dictionary.pad()
+        # --ctc-inter-logit k (s2t_ctc.py:196,276-284): decode from the k-th intermediate head counted from the top
+        self.ctc_inter_logit = int(getattr(args, "ctc_inter_logit", 0) or 0)
+        if getattr(args, "ctc_self_ensemble", False):
+            raise NotImplementedError("--ctc-self-ensemble (the reference's branch refers to an undefined name, s2t_ctc.py:316)")
+        if int(getattr(args, "beam", 1) or 1) > 1 and getattr(args, "ctc_infer", "greedy") == "beam":
+            raise NotImplementedError("CTC beam decoding (third-party ctcdecode in the reference)")
 
     @torch.no_grad()
     def generate(self, models, sample, **kwargs):
@@ -563,12 +569,30 @@ class CTCDecoder:
 
         net_input = sample["net_input"]
         enc = self.model(src_tokens=net_input["src_tokens"], src_lengths=net_input["src_lengths"])
-        logit_tbv = enc["xctc_logit"][0] if len(enc.get("xctc_logit", [])) else enc["ctc_logit"][0]
+        has_x = len(enc.get("xctc_logit", [])) > 0
+        logit_tbv = enc["xctc_logit"][0] if has_x else enc["ctc_logit"][0]
+        if isinstance(logit_tbv, (list, tuple)):
+            logit_tbv = logit_tbv[0]
+        mask = enc["encoder_padding_mask"][0]
+        if self.ctc_inter_logit != 0:
+            # s2t_ctc.py:262-284: the intermediate heads of the same family (XCTC when the encoder has one — note that the
+            # reference then overwrites the list with the CTC family's whenever it is non-empty, :270-271)
+            inter = enc.get("inter_xctc_logits", []) if has_x else []
+            if not has_x or len(inter) > 0:
+                inter = enc.get("inter_ctc_logits", [])
+            if len(inter) != 0:
+                assert self.ctc_inter_logit <= len(inter)
+                item = inter[-self.ctc_inter_logit]
+                if isinstance(item, (list, tuple)):
+                    logit_tbv = item[0]
+                    if len(item) >= 2 and item[1] is not None:
+                        mask = item[1]
+                # (a bare tensor entry leaves ctc_logit untouched in the reference, :278-283)
         Tn, B, V = logit_tbv.shape
         logits = logit_tbv.transpose(0, 1).reshape(B * Tn, V)  # batch-major rows (a view when it came from us)
         if logits.stride(1) != 1:
             logits = logits.contiguous()
-        lens = (~enc["encoder_padding_mask"][0]).sum(1).to(torch.int32)
+        lens = (~mask).sum(1).to(torch.int32)
         dev = logits.device
         idx = torch.empty(B * Tn, dtype=torch.int32, device=dev)
         top = torch.empty(B * Tn, dtype=torch.float32, device=dev)

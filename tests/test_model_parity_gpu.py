@@ -320,3 +320,33 @@ def test_bf16_fused_attention_model_vs_oracle_and_composed(conformer, monkeypatc
             worst_c = (k, ec)
     assert worst_o[1] < 1.5e-1, worst_o
     assert worst_c[1] < 8e-2, worst_c
+
+
+def test_ctc_decoder_inter_logit_option(golden_dir):
+    """--ctc-inter-logit k (s2t_ctc.py:276-284): greedy decoding from an intermediate CTC head with ITS padding mask; on
+    the compression fixture the heads have different frame counts.  Checked against the oracle's greedy decode of the
+    reference's own intermediate logits."""
+    from argparse import Namespace
+    z = load(golden_dir, "conformer_compress")
+    model, cfg = build(z, torch.float32)
+    model.eval()
+    sample = {"net_input": {"src_tokens": torch.from_numpy(z["in::src_tokens"]).to(DEV),
+                            "src_lengths": torch.from_numpy(z["in::src_lengths"]).to(DEV)}}
+
+    class _Enc(torch.nn.Module):
+        def __init__(self, e):
+            super().__init__()
+            self.e = e
+
+        def forward(self, src_tokens, src_lengths):
+            return self.e(src_tokens, src_lengths)
+
+    for k in (1, 2):
+        dec = M.CTCDecoder([model], Namespace(ctc_inter_logit=k), None, blank_idx=0)
+        dec.model = _Enc(model.encoder)
+        hyps = dec.generate(None, sample)
+        i = 2 - k  # inter_logits[-k] of two heads
+        ref_h, _ = O.ctc_greedy(torch.from_numpy(z["out::inter_ctc_logit_%d" % i]), torch.from_numpy(z["out::inter_ctc_mask_%d" % i]))
+        assert [h[0]["tokens"].tolist() for h in hyps] == [t.tolist() for t in ref_h]
+    with pytest.raises(NotImplementedError):
+        M.CTCDecoder([model], Namespace(ctc_self_ensemble=True), None)
