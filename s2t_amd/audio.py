@@ -11,7 +11,7 @@ The reference runs both per utterance on dataloader CPU workers; here a whole ba
 launches (``s2t_fbank``, ``s2t_utterance_cmvn`` in ``csrc/frontend.hip``).  There is no CPU fallback.
 """
 import math
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from typing import Dict, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch

@@ -9,7 +9,6 @@ There is no CPU path: every function raises if its inputs are not on the GPU.
 """
 import math
 import os
-from typing import Optional
 
 import torch
 

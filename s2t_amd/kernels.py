@@ -237,9 +237,6 @@ def dwconv_fwd(x, w, y, B, T, C, K, flip=False, scale=None, shift=None, act=None
           _ptr(scale), _ptr(shift), L.ACT_IDS[act], _ptr(lens), _ptr(stats))
 
 
-DW_REPLICAS = 16
-
-
 def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
     rows = L.lib().s2t_dwconv_wgrad_partials(B, T)  # one plain-stored partial row per workgroup, folded in fixed order
     ws = _scratch("dw", rows * C * K, G.device)

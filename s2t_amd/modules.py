@@ -11,7 +11,6 @@ model classes transpose at the boundary.  Modules are parameter containers + a `
 matrices; there is no CPU fallback.
 """
 import math
-from typing import Optional
 
 import torch
 import torch.nn as nn

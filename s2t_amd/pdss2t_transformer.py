@@ -16,7 +16,7 @@ from . import functional as Fn
 from .modules import (CTC, TABLES, Ctx, DownSampleConvolutionModule, LayerNorm, MaskRows, S2TTransformerEncoderLayer,
                       _Conv1dK)
 from .registry import register_model, register_model_architecture
-from .s2t_transformer import (AddPositions, Embedding, S2TTransformerModel, TransformerDecoderScriptable, _HipModel,
+from .s2t_transformer import (AddPositions, Embedding, S2TTransformerModel, TransformerDecoderScriptable,
                               _SinPosHolder, _d, _unsupported, base_architecture as _s2t_base)
 
 

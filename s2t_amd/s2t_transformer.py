@@ -8,7 +8,7 @@ inter-CTC / XCTC / PAE, compression, DLCL history, layer-drop, quant-noise, adap
 """
 import math
 from argparse import Namespace
-from typing import Dict, List, Optional
+from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -15,12 +15,11 @@ Not built: flac decoding, speed perturbation, temperature-based resampling of co
 """
 import csv
 import io
-import os
 import os.path as op
 import re
 import struct
 from copy import deepcopy
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 import torch
