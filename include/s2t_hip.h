@@ -366,6 +366,46 @@ int s2t_dwpool_fwd(int dtype, const void* x, const float* w, const float* bias, 
 int s2t_dwpool_bwd(int dtype, const void* x, const float* w, const void* dy, void* dx, float* dw, float* db, int B, int Tin,
                    int C, int r, void* stream);
 
+/* ---- Row-block kernels (csrc/rowblock.hip): a workgroup owns 64 complete rows of a [rows][256] bf16 activation -------
+ * s2t_ffn_fused_fwd: one launch for the whole position-wise feed-forward block of a pre-LN layer,
+ *     xn  = ln_gamma ? LayerNorm(x; ln_gamma, ln_beta, ln_eps) : x                      (modules/layer_norm.py:30-35)
+ *     h   = drop_h(act(xn W1^T + b1))          z = the pre-activation                    (s2t_transformer_layer.py:55-66)
+ *     y   = residual + alpha * drop_o(h W2^T + b2)            (the half-step residual of :258-265 / :311-317; bf16)
+ *     y_ln = eln_gamma ? LayerNorm(y; eln_gamma, eln_beta, ln_eps), rows of padded frames (eln_lens / eln_T) zeroed
+ *                                                             (final_norm, s2t_transformer_layer.py:318-320)
+ * replacing F.layer_norm + two F.linear + activation + two dropouts + the residual add (+ F.layer_norm) of the reference.
+ * The [rows][F] hidden activation stays on the chip; z / h / x_ln / ln_mean / ln_rstd are written only when given
+ * (what the backward pass of the unfused kernels needs: dgrad through s2t_gemm with dact_z = z, wgrad operands h and x_ln,
+ * s2t_layernorm_bwd statistics).  Dropout masks are those of s2t_gemm's epilogue for the same (seed, site, element):
+ * element index row*F + f for drop_h, row*256 + n for drop_o.
+ * Constraints: d == 256, F % 64 == 0, F <= 4096, bf16 activations and weights (W1 [F][256], W2 [256][F], row-major as
+ * nn.Linear stores them), fp32 biases / LayerNorm parameters / statistics, every pointer 16-byte aligned.
+ * y may be NULL when y_ln is given (eval). */
+typedef struct s2t_ffn_args {
+  const void* x;          /* [M][256] bf16 */
+  const float* ln_gamma;  /* NULL: x is used as it is */
+  const float* ln_beta;
+  float ln_eps;
+  int32_t d;              /* must be 256 */
+  const void* w1; const float* b1;
+  const void* w2; const float* b2;
+  const void* residual;   /* [M][256] bf16 or NULL */
+  void* y;                /* [M][256] bf16 */
+  const float* eln_gamma; const float* eln_beta; /* optional LayerNorm behind the block */
+  void* y_ln;             /* [M][256] bf16, required iff eln_gamma */
+  float* eln_mean; float* eln_rstd; /* optional [M] fp32 statistics of that LayerNorm */
+  const int32_t* eln_lens; int32_t eln_T; /* optional padded-frame mask on y_ln */
+  void* x_ln; float* ln_mean; float* ln_rstd; /* optional saves of the leading LayerNorm */
+  void* z; void* h;       /* optional [M][F] bf16 saves */
+  int32_t M, F;
+  int32_t act;            /* S2T_ACT_NONE | RELU | SWISH */
+  float alpha;
+  float drop_h_p; uint32_t drop_h_site;
+  float drop_o_p; uint32_t drop_o_site;
+  const uint64_t* drop_seed;
+} s2t_ffn_args;
+int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

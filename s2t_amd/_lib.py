@@ -49,6 +49,23 @@ class GemmArgs(C.Structure):
     ]
 
 
+class FfnArgs(C.Structure):
+    """Mirror of ``struct s2t_ffn_args`` (include/s2t_hip.h)."""
+
+    _fields_ = [
+        ("x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("d", C.c_int32),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("residual", C.c_void_p), ("y", C.c_void_p),
+        ("eln_gamma", C.c_void_p), ("eln_beta", C.c_void_p), ("y_ln", C.c_void_p),
+        ("eln_mean", C.c_void_p), ("eln_rstd", C.c_void_p), ("eln_lens", C.c_void_p), ("eln_T", C.c_int32),
+        ("x_ln", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p),
+        ("z", C.c_void_p), ("h", C.c_void_p),
+        ("M", C.c_int32), ("F", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
+        ("drop_h_p", C.c_float), ("drop_h_site", C.c_uint32), ("drop_o_p", C.c_float), ("drop_o_site", C.c_uint32),
+        ("drop_seed", C.c_void_p),
+    ]
+
+
 _CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "uint32_t": C.c_uint32}
 
 
@@ -68,7 +85,12 @@ def header_prototypes(path=HEADER_PATH):
             for a in args.split(","):
                 a = a.strip()
                 if "*" in a:
-                    argtypes.append(C.POINTER(GemmArgs) if "s2t_gemm_args" in a else C.c_void_p)
+                    if "s2t_gemm_args" in a:
+                        argtypes.append(C.POINTER(GemmArgs))
+                    elif "s2t_ffn_args" in a:
+                        argtypes.append(C.POINTER(FfnArgs))
+                    else:
+                        argtypes.append(C.c_void_p)
                 else:
                     ty = a.replace("const", "").split()[0]
                     argtypes.append(_CTYPE[ty])

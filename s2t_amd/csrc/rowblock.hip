@@ -1,0 +1,547 @@
+// Row-block kernels for d = 256 activations on gfx950: a workgroup owns 64 complete rows of the [B*T, 256] activation
+// matrix, so everything row-wise (LayerNorm in front, bias / activation / dropout / residual / LayerNorm behind) is
+// fused around the MFMA products and a chain of two products keeps its intermediate on the chip.
+//
+//   s2t_ffn_fused_fwd   out = residual + alpha * drop_o( W2 drop_h(act(W1 LN(x) + b1)) + b2 ) [-> LayerNorm]
+//                       modules/s2t_transformer_layer.py:55-66 (FeedForwardModule), :258-265, :311-317 (macaron / final
+//                       half-step residuals), :318-320 (final_norm); modules/layer_norm.py:30-35.
+//
+// The 16000 x 2048 hidden activation of the headline configuration (65 MB in bf16) is never written in eval mode and
+// never re-read in training mode (training stores the pre-activation and the dropped activation once, for backward).
+//
+// Decomposition (one workgroup = 4 waves = 64 rows; 16000 rows -> 250 workgroups on 256 CUs):
+//   wave (mp, fh): rows 32*mp .. +32 (two 16-row MFMA column tiles), hidden units 32*fh .. +32 of every 64-unit chunk.
+//   All products are "swapped" 16x16x32 bf16 MFMAs that produce TRANSPOSED tiles (D row = output feature, D column =
+//   activation row), so a lane owns ONE activation row (lane & 15):
+//     G1 (chunk c):  H^T[f][m] = sum_k W1[f][k] Xn[m][k]      A = W1 rows from LDS, B = Xn fragments in registers
+//                    The two 16-unit tiles of a wave interleave the hidden units in groups of four (tile ft, MFMA row
+//                    4g + r  <->  unit 32 fh + 8g + 4 ft + r), so that lane (x, g) ends up with EIGHT CONSECUTIVE
+//                    hidden units of activation row x in its two accumulators:
+//     E1          :  bias (the initial accumulator), activation, dropout, bf16 pack — lane-local; the packed registers
+//                    ARE the B fragment (k = 8g + j) of the next product, and one 16-byte store saves them for backward
+//     G2 (chunk c):  Y^T[n][m] += sum_f W2[n][f] H^T[f][m]    A = W2 rows from LDS (one ds_read_b128), B = H fragment
+//   Weights stream through LDS by LDS-DMA (buffer_load ... lds, no staging registers, no ds_write): per chunk 32 KiB of
+//   W1 (64 rows x 512 B) and 32 KiB of W2 (256 rows x 128 B), double buffered, issued one chunk ahead.
+//   LDS images are lane-linear per DMA instruction; the XOR swizzles that make the fragment reads conflict-free are
+//   applied to the per-lane SOURCE address and to the read address.
+//   The two fh halves of a row block hold partial Y sums; they meet in LDS (the weight buffers, free by then) where
+//   the final row-wise epilogue runs on whole 512-byte rows (coalesced stores, LayerNorm statistics by shuffles).
+#include "common.h"
+
+#ifndef S2T_RB_DBG
+#define S2T_RB_DBG 0  // kernel-experiment switches (tools/rb_dbg_build.sh): 1 no DMA inside the loop, 2 no MFMAs, 4 no E1
+#endif
+
+namespace {
+
+constexpr int D = 256;    // model width (fixed)
+constexpr int TM = 64;    // rows per workgroup
+constexpr int FC = 64;    // hidden units per chunk
+constexpr int STAGE = 32768;             // bytes of one W1 or W2 chunk image
+constexpr int LDS_W1 = 0;                // two W1 stages
+constexpr int LDS_W2 = 2 * STAGE;        // two W2 stages
+constexpr int LDS_B1 = 4 * STAGE;        // fp32 b1[F]
+constexpr int MAXF = 4096;
+constexpr int LDS_MBOX = LDS_B1 + MAXF * 4;   // 2 x 8 waves x 2 tiles x 64 lanes x 8 B of packed activations
+constexpr int LDS_BYTES = LDS_MBOX + 16384;   // 160 KiB in all
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes, global (srd base + voff + soff) -> LDS (lds_base + lane*16).
+// The compiler neither counts nor waits for it: every wait below is a hand-placed counted vmcnt.
+__device__ __forceinline__ void dma16(uint32_t lds_base, uint32_t voff, i32x4 srd, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
+// the same with an instruction offset (0..4095) that moves BOTH the global source and the LDS destination
+template <int OFF>
+__device__ __forceinline__ void dma16_off(uint32_t lds_base, uint32_t voff, i32x4 srd, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:%4 lds"
+               :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff), "i"(OFF) : "memory");
+}
+
+__device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
+  const uint64_t b = (uint64_t)base;
+  i32x4 s;
+  s.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  s.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  s.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  s.w = __builtin_amdgcn_readfirstlane(0x00020000);
+  return s;
+}
+
+__device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+#if S2T_RB_DBG & 2
+  asm volatile("" :: "v"(a), "v"(b));
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+// swizzle key of row r (0..63) of a W1 chunk image: the 16 rows one fragment read touches (r = 32 fh + 8 (x>>2) + 4 ft +
+// (x&3), x = 0..15) get 16 different keys
+__device__ __forceinline__ int w1key(int r) { return (r & 3) | (((r >> 3) & 3) << 2); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Eight waves per workgroup, two per SIMD (<= 256 registers each), so that one wave's LDS latency, DMA issue and E1
+// arithmetic sit beside its SIMD partner's MFMAs.  wave = (mp, fh, nh):
+//   rows 32*mp .. +32 (two 16-row tiles mt), hidden units 32*fh .. +32 of every chunk, and
+//   G1: the nh-th of the two interleaved 16-unit tiles of that hidden range (MFMA row 4g + r <-> unit 32 fh + 8g + 4 nh + r),
+//   G2: output columns 128*nh .. +128 (8 tiles), K = the full 32 hidden units of (fh): lane (x, g)'s B fragment is
+//       [its own four packed values | its partner wave's four] — the SAME lane of wave (mp, fh, 1-nh) — exchanged through
+//       a 16 KiB LDS mailbox (double buffered by chunk parity; the chunk barrier orders it).
+// Schedule (one barrier per chunk, the second product lags the first by one chunk):
+//   iteration c:  [stores of chunk c-1's saves]  DMA W1(c+1), W2(c)
+//                 G1(c)   : 16 MFMAs per wave         G2(c-1) : 16 MFMAs per wave
+//                 E1(c)   : bias (initial accumulator), activation, dropout, pack; mailbox write
+//                 s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier
+template <bool TRAIN, int ACT, bool DROP>
+__global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_args p) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mp = wave & 1, fh = (wave >> 1) & 1, nh = wave >> 2;
+  const int x = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * TM;
+  const int M = p.M, F = p.F;
+  const int nchunks = F / FC;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  const i32x4 srd1 = make_srd(p.w1, (uint32_t)F * D * 2u);
+  const i32x4 srd2 = make_srd(p.w2, (uint32_t)F * D * 2u);
+
+  // ---- DMA plans.  W1 chunk: wave w loads hidden rows 8w .. 8w+7 of the chunk, instruction i rows 8w+2i, +1
+  // (512 B each): lane l -> row r = 8w + 2i + (l>>5), LDS slot s = l&31 holds 16-byte k-chunk s ^ w1key(r).
+  // W2 chunk: instruction i of wave w covers output rows 32w + 8i .. +7 (128 B each): lane l -> row r = 32w+8i+(l>>3),
+  // slot s = l&7 holds 16-byte f-chunk s ^ ((r>>1)&7).
+  // Two per-lane offsets per weight serve all four instructions: rows 8w + 2i + hi differ between even and odd i only in
+  // bit 1 of the swizzle key (byte offset ^ 32), the rest is the instruction offset i*1024 (global and LDS alike);
+  // W2 rows 32w + 8i + (l>>3): odd i flips bit 2 of the key (byte offset ^ 64), i*8 rows go into the scalar offset.
+  uint32_t v1e, v1o, v2e, v2o;
+  {
+    const int hi = lane >> 5, s = lane & 31;
+    const int r = 8 * wave + hi;
+    v1e = (uint32_t)(r * 512 + 16 * (s ^ w1key(r)));
+    v1o = v1e ^ 32u;
+    const int r2 = 32 * wave + (lane >> 3), s2 = lane & 7;
+    v2e = (uint32_t)r2 * (uint32_t)(F * 2) + (uint32_t)(16 * (s2 ^ ((r2 >> 1) & 7)));
+    v2o = v2e ^ 64u;
+  }
+  const uint32_t w2step = (uint32_t)(8 * F * 2);
+  auto issue_w1 = [&](int c) __attribute__((always_inline)) {
+    const uint32_t base = lds0 + LDS_W1 + (c & 1) * STAGE + wave * 4096;
+    const uint32_t soff = (uint32_t)c * (FC * 512);
+    dma16_off<0>(base, v1e, srd1, soff);
+    dma16_off<1024>(base, v1o, srd1, soff);
+    dma16_off<2048>(base, v1e, srd1, soff);
+    dma16_off<3072>(base, v1o, srd1, soff);
+  };
+  auto issue_w2 = [&](int c) __attribute__((always_inline)) {
+    const uint32_t base = lds0 + LDS_W2 + (c & 1) * STAGE + wave * 4096;
+    const uint32_t soff = (uint32_t)c * (FC * 2);
+    dma16(base, v2e, srd2, soff);
+    dma16(base + 1024, v2o, srd2, soff + w2step);
+    dma16(base + 2048, v2e, srd2, soff + 2 * w2step);
+    dma16(base + 3072, v2o, srd2, soff + 3 * w2step);
+  };
+  issue_w1(0);
+  issue_w2(0);
+
+  // b1 -> LDS (fp32)
+  {
+    float* lb = reinterpret_cast<float*>(smem + LDS_B1);
+    for (int i = tid; i < F; i += 512) lb[i] = p.b1[i];
+  }
+
+  // ---- prologue: LayerNorm of the 64 rows, one 16-byte piece (8 columns) per thread and pass: 32 lanes per row, 16 rows
+  // per pass.  The normalised bf16 tile is staged in the (still unused) second W1 buffer with the W1 image's swizzle:
+  // 16-byte chunk c of row r at r*512 + 16*(c ^ (r & 15)).
+  {
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
+    char* stage = smem + LDS_W1 + STAGE;
+    const int cch = tid & 31;  // 16-byte column chunk
+    float gm[8], bt[8];
+    if (p.ln_gamma) {
+      const float4 g0 = *reinterpret_cast<const float4*>(p.ln_gamma + 8 * cch);
+      const float4 g1 = *reinterpret_cast<const float4*>(p.ln_gamma + 8 * cch + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.ln_beta + 8 * cch);
+      const float4 b1v = *reinterpret_cast<const float4*>(p.ln_beta + 8 * cch + 4);
+      gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
+      bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1v.x; bt[5] = b1v.y; bt[6] = b1v.z; bt[7] = b1v.w;
+    }
+    uint4 raw[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int mc = min(row0 + 16 * ps + (tid >> 5), M - 1);
+      raw[ps] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * D + 8 * cch);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int rl = 16 * ps + (tid >> 5);
+      const int m = row0 + rl;
+      uint4 o = raw[ps];
+      if (p.ln_gamma) {
+        const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[2 * q] = __uint_as_float(w4[q] << 16);
+          v[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[j];
+#pragma unroll
+        for (int sh = 16; sh > 0; sh >>= 1) sum += __shfl_xor(sum, sh, 64);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dd = v[j] - mean;
+          sq += dd * dd;
+        }
+#pragma unroll
+        for (int sh = 16; sh > 0; sh >>= 1) sq += __shfl_xor(sq, sh, 64);
+        const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
+        uint32_t ow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          ow[q] = pack2((v[2 * q] - mean) * rstd * gm[2 * q] + bt[2 * q], (v[2 * q + 1] - mean) * rstd * gm[2 * q + 1] + bt[2 * q + 1]);
+        o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        if constexpr (TRAIN) {
+          if (m < M) {
+            if (p.x_ln) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.x_ln) + (int64_t)m * D + 8 * cch) = o;
+            if (cch == 0) {
+              if (p.ln_mean) p.ln_mean[m] = mean;
+              if (p.ln_rstd) p.ln_rstd[m] = rstd;
+            }
+          }
+        }
+      }
+      *reinterpret_cast<uint4*>(stage + rl * 512 + 16 * (cch ^ (rl & 15))) = o;
+    }
+  }
+  // chunk 0 of both weights, b1, the staged tile and the compiler's own prologue loads / stores have landed (the builtin
+  // form also tells the compiler that its loads are complete: no vmcnt waits of its own inside the loop)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  // this wave's 32 rows as B fragments: lane (x, g) owns k = 32*ks + 8g .. +8 of row 32 mp + 16 mt + x
+  bf16x8 xn[2][8];
+  {
+    const char* stage = smem + LDS_W1 + STAGE;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int rl = 32 * mp + 16 * mt + x;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        xn[mt][ks] = as_frag(*reinterpret_cast<const uint4*>(stage + rl * 512 + 16 * ((4 * ks + g) ^ x)));
+    }
+  }
+  // every wave holds its fragments before the DMA of chunk 1 overwrites the staging buffer
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  f32x4 yacc[8][2];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) yacc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const uint64_t key_h = DROP ? s2t_drop_key(p.drop_seed, p.drop_h_site) : 0ull;
+  const uint32_t th_h = s2t_drop_thresh(p.drop_h_p);
+  const float inv_h = s2t_drop_scale(p.drop_h_p);
+
+  // mailbox: [parity][wave][mt][lane] 8 bytes
+  char* mbox = smem + LDS_MBOX;
+  const int partner = wave ^ 4;
+
+  // G1 of chunk c: this wave's 16-unit tile for both row tiles (fragments in two groups of four k-steps)
+  const int g1row = 32 * fh + 8 * (x >> 2) + 4 * nh + (x & 3);
+  auto g1_read = [&](int c, int k0, uint4 (&af)[4]) __attribute__((always_inline)) {
+    const char* l1 = smem + LDS_W1 + (c & 1) * STAGE;
+    const int key = w1key(g1row);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const uint4*>(l1 + g1row * 512 + 16 * ((4 * (k0 + j) + g) ^ key));
+  };
+  auto g1_mma = [&](int k0, const uint4 (&af)[4], f32x4 (&hacc)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hacc[0] = mfma16(as_frag(af[j]), xn[0][k0 + j], hacc[0]);
+      hacc[1] = mfma16(as_frag(af[j]), xn[1][k0 + j], hacc[1]);
+    }
+  };
+  auto g1_bias = [&](int c, f32x4 (&hacc)[2]) __attribute__((always_inline)) {
+    const float* lb = reinterpret_cast<const float*>(smem + LDS_B1) + c * FC + 32 * fh + 8 * g + 4 * nh;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(lb);  // the bias rides in as the initial accumulator
+    hacc[0] = bb;
+    hacc[1] = bb;
+  };
+  // lane (x, g): v[r] = H[row x of tile mt][unit c*64 + 32 fh + 8 g + 4 nh + r]; packed halves go to the mailbox
+  auto e1 = [&](int c, const f32x4 (&hacc)[2], uint2 (&zp)[2], uint2 (&hp)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = hacc[mt][r];
+      if constexpr (TRAIN) zp[mt] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+      if constexpr ((S2T_RB_DBG & 4) != 0) {
+      } else if constexpr (ACT == S2T_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if constexpr (ACT == S2T_ACT_SWISH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_(v[r]);
+      }
+      if constexpr (DROP) {
+        const int m = row0 + 32 * mp + 16 * mt + x;
+        const uint64_t base = (uint64_t)m * (uint64_t)F + (uint64_t)(c * FC + 32 * fh + 8 * g + 4 * nh);
+        uint32_t r16[4];
+        s2t_rand_run<4>(key_h, base, r16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = r16[r] >= th_h ? v[r] * inv_h : 0.f;
+      }
+      hp[mt] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+      *reinterpret_cast<uint2*>(mbox + ((((c & 1) * 8 + wave) * 2 + mt) * 64 + lane) * 8) = hp[mt];
+    }
+  };
+  // G2 of chunk c: own packed values hp + the partner's from the mailbox (B fragment: k = 8g + j <-> unit 32 fh + 8g + j)
+  auto g2_hb = [&](int c, const uint2 (&hp)[2], bf16x8 (&hb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const uint2 o = *reinterpret_cast<const uint2*>(mbox + ((((c & 1) * 8 + partner) * 2 + mt) * 64 + lane) * 8);
+      hb[mt] = nh == 0 ? as_frag(make_uint4(hp[mt].x, hp[mt].y, o.x, o.y)) : as_frag(make_uint4(o.x, o.y, hp[mt].x, hp[mt].y));
+    }
+  };
+  // row n = 128 nh + 16 nt + x: 16-byte f-chunk 4 fh + g at slot (4 fh + g) ^ ((n >> 1) & 7), (n >> 1) & 7 == (x >> 1) & 7
+  const int g2off = (128 * nh + x) * 128 + 16 * ((4 * fh + g) ^ ((x >> 1) & 7));
+  auto g2_read = [&](int c, int n0, uint4 (&af)[4]) __attribute__((always_inline)) {
+    const char* pa = smem + LDS_W2 + (c & 1) * STAGE + g2off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const uint4*>(pa + (n0 + j) * 2048);
+  };
+  auto g2_mma = [&](int n0, const uint4 (&af)[4], const bf16x8 (&hb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      yacc[n0 + j][0] = mfma16(as_frag(af[j]), hb[0], yacc[n0 + j][0]);
+      yacc[n0 + j][1] = mfma16(as_frag(af[j]), hb[1], yacc[n0 + j][1]);
+    }
+  };
+  auto save = [&](int c, const uint2 (&zp)[2], const uint2 (&hp)[2]) __attribute__((always_inline)) {
+    if constexpr (TRAIN) {
+      bf16_t* Z = reinterpret_cast<bf16_t*>(p.z);
+      bf16_t* H = reinterpret_cast<bf16_t*>(p.h);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int m = row0 + 32 * mp + 16 * mt + x;
+        if (m < M) {
+          const int64_t o = (int64_t)m * F + c * FC + 32 * fh + 8 * g + 4 * nh;
+          if (Z) *reinterpret_cast<uint2*>(Z + o) = zp[mt];
+          if (H) *reinterpret_cast<uint2*>(H + o) = hp[mt];
+        }
+      }
+    }
+  };
+
+  uint2 zp[2], hp[2];
+  {
+    f32x4 hacc[2];
+    uint4 a0[4], a1[4];
+    if (nchunks > 1) issue_w1(1);
+    g1_bias(0, hacc);
+    g1_read(0, 0, a0);
+    g1_read(0, 4, a1);
+    g1_mma(0, a0, hacc);
+    g1_mma(4, a1, hacc);
+    e1(0, hacc, zp, hp);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  for (int c = 1; c < nchunks; ++c) {
+    save(c - 1, zp, hp);
+#if !(S2T_RB_DBG & 1)
+    if (c + 1 < nchunks) issue_w1(c + 1);
+    issue_w2(c);
+#endif
+    f32x4 hacc[2];
+    uint2 zn[2], hn[2];
+    bf16x8 hb[2];
+    uint4 a0[4], a1[4];
+    g1_bias(c, hacc);
+    g2_hb(c - 1, hp, hb);
+    g1_read(c, 0, a0);
+    g1_read(c, 4, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    g1_mma(0, a0, hacc);
+    g2_read(c - 1, 0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    g1_mma(4, a1, hacc);
+    g2_read(c - 1, 4, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    g2_mma(0, a0, hb);
+    e1(c, hacc, zn, hn);
+    g2_mma(4, a1, hb);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      zp[mt] = zn[mt];
+      hp[mt] = hn[mt];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  save(nchunks - 1, zp, hp);
+  {
+    bf16x8 hb[2];
+    uint4 b0[4], b1[4];
+    g2_hb(nchunks - 1, hp, hb);
+    g2_read(nchunks - 1, 0, b0);
+    g2_read(nchunks - 1, 4, b1);
+    g2_mma(0, b0, hb);
+    g2_mma(4, b1, hb);
+  }
+  __syncthreads();
+
+  // ---- partial sums of the two hidden halves meet in LDS: region fh, fp32 [64 rows][256], 16-byte chunk cc of row m at
+  // m*1024 + 16*(cc ^ (m & 7))
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int ml = 32 * mp + 16 * mt + x;
+    char* rowp = smem + fh * 65536 + ml * 1024;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<f32x4*>(rowp + 16 * ((32 * nh + 4 * nt + g) ^ (ml & 7))) = yacc[nt][mt];
+  }
+  __syncthreads();
+
+  // ---- row epilogue: wave w, pass ps: rows 8w + 2ps + (lane >> 5); lane s = lane & 31 owns columns 4s..4s+3 and
+  // 128+4s..+3 of its row
+  {
+    const int hi = lane >> 5, s = lane & 31;
+    const uint64_t key_o = DROP ? s2t_drop_key(p.drop_seed, p.drop_o_site) : 0ull;
+    const uint32_t th_o = s2t_drop_thresh(p.drop_o_p);
+    const float inv_o = s2t_drop_scale(p.drop_o_p);
+    const bf16_t* R = reinterpret_cast<const bf16_t*>(p.residual);
+    bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
+    bf16_t* YL = reinterpret_cast<bf16_t*>(p.y_ln);
+    float b2v[2][4], eg[2][4], eb[2][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(p.b2 + 128 * q + 4 * s);
+      b2v[q][0] = t.x; b2v[q][1] = t.y; b2v[q][2] = t.z; b2v[q][3] = t.w;
+      if (p.eln_gamma) {
+        const float4 a = *reinterpret_cast<const float4*>(p.eln_gamma + 128 * q + 4 * s);
+        const float4 b = *reinterpret_cast<const float4*>(p.eln_beta + 128 * q + 4 * s);
+        eg[q][0] = a.x; eg[q][1] = a.y; eg[q][2] = a.z; eg[q][3] = a.w;
+        eb[q][0] = b.x; eb[q][1] = b.y; eb[q][2] = b.z; eb[q][3] = b.w;
+      }
+    }
+#pragma unroll 2
+    for (int ps = 0; ps < 4; ++ps) {
+      const int ml = 8 * wave + 2 * ps + hi;
+      const int m = row0 + ml;
+      const bool live = m < M;
+      float v[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int cc = 32 * q + s;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(smem + ml * 1024 + 16 * (cc ^ (ml & 7)));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(smem + 65536 + ml * 1024 + 16 * (cc ^ (ml & 7)));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q][r] = a[r] + b[r] + b2v[q][r];
+        if (DROP && p.drop_o_p > 0.f) {
+          uint32_t r16[4];
+          s2t_rand_run<4>(key_o, (uint64_t)m * D + (uint64_t)(128 * q + 4 * s), r16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[q][r] = r16[r] >= th_o ? v[q][r] * inv_o : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q][r] *= p.alpha;
+        if (R) {
+          const int mc = live ? m : M - 1;
+          float rr[4];
+          ld4_as_f32<bf16_t>(R + (int64_t)mc * D + 128 * q + 4 * s, rr);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[q][r] += rr[r];
+        }
+        // the block output is a bf16 tensor: a LayerNorm behind it sees the rounded values
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q][r] = bf2f(f2bf(v[q][r]));
+        if (Y && live) st4_from_f32<bf16_t>(Y + (int64_t)m * D + 128 * q + 4 * s, v[q]);
+      }
+      if (p.eln_gamma) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sum += v[q][r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = v[q][r] - mean;
+            sq += d * d;
+          }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
+        const bool masked = p.eln_lens && live && (m % p.eln_T) >= p.eln_lens[m / p.eln_T];
+        if (live) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float o4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = masked ? 0.f : (v[q][r] - mean) * rstd * eg[q][r] + eb[q][r];
+            st4_from_f32<bf16_t>(YL + (int64_t)m * D + 128 * q + 4 * s, o4);
+          }
+          if (s == 0) {
+            if (p.eln_mean) p.eln_mean[m] = mean;
+            if (p.eln_rstd) p.eln_rstd[m] = rstd;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
+  if (!a || !a->x || !a->w1 || !a->b1 || !a->w2 || !a->b2) return S2T_ERR_ARG;
+  if (a->M <= 0 || a->F <= 0) return S2T_ERR_ARG;
+  if (a->d != D) return S2T_ERR_UNSUPPORTED;
+  if (a->F % FC || a->F > MAXF) return S2T_ERR_UNSUPPORTED;
+  if (a->act != S2T_ACT_NONE && a->act != S2T_ACT_RELU && a->act != S2T_ACT_SWISH) return S2T_ERR_ARG;
+  if (!a->y && !a->y_ln) return S2T_ERR_ARG;
+  if ((a->eln_gamma != nullptr) != (a->y_ln != nullptr) || (a->eln_gamma && !a->eln_beta)) return S2T_ERR_ARG;
+  if ((a->ln_gamma != nullptr) != (a->ln_beta != nullptr)) return S2T_ERR_ARG;
+  if (a->eln_lens && a->eln_T <= 0) return S2T_ERR_ARG;
+  if (a->drop_h_p < 0.f || a->drop_h_p >= 1.f || a->drop_o_p < 0.f || a->drop_o_p >= 1.f) return S2T_ERR_ARG;
+  if ((a->drop_h_p > 0.f || a->drop_o_p > 0.f) && !a->drop_seed) return S2T_ERR_ARG;
+  const void* ptrs[] = {a->x, a->w1, a->w2, a->residual, a->y, a->y_ln, a->x_ln, a->z, a->h, a->b1, a->b2,
+                        a->ln_gamma, a->ln_beta, a->eln_gamma, a->eln_beta};
+  for (const void* q : ptrs)
+    if (q && ((uintptr_t)q % 16)) return S2T_ERR_ALIGN;
+  const bool train = a->z || a->h || a->x_ln || a->ln_mean || a->ln_rstd;
+  const dim3 grid((a->M + TM - 1) / TM), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  const bool drop = a->drop_h_p > 0.f || a->drop_o_p > 0.f;
+#define GO(T, A, DR) hipLaunchKernelGGL((ffn_fused_fwd_kernel<T, A, DR>), grid, block, 0, s, *a)
+#define GO_A(T, DR)                                     \
+  do {                                                  \
+    if (a->act == S2T_ACT_RELU) GO(T, S2T_ACT_RELU, DR); \
+    else if (a->act == S2T_ACT_SWISH) GO(T, S2T_ACT_SWISH, DR); \
+    else GO(T, S2T_ACT_NONE, DR);                       \
+  } while (0)
+  if (train) {
+    if (drop) GO_A(true, true); else GO_A(true, false);
+  } else {
+    if (drop) GO_A(false, true); else GO_A(false, false);
+  }
+#undef GO_A
+#undef GO
+  return S2T_LAUNCH_CHECK();
+}

@@ -81,12 +81,21 @@ def _tag_drop(y, drop):
     return y
 
 
+def _hand_over(dx, drop, dxd):
+    """Leave dropout(dx) under ``drop`` beside dx for the backward of the block in front (picked up by _drop_rows)."""
+    dx._s2t_dropped = (drop, dxd, dx.data_ptr(), dx._version)
+
+
 def _drop_rows(x, drop):
     """x * mask / (1-p) for a [rows, cols] matrix (mask convention of the GEMM epilogue); identity when drop is None."""
     if drop is None:
         return x
     ready = getattr(x, "_s2t_dropped", None)  # left there by the LayerNorm backward that produced x
-    if ready is not None and _same_drop(ready[0], drop) and ready[1].shape == x.shape:
+    # The hand-over only stands while x still IS the buffer that LayerNorm backward wrote: when the tagged activation has
+    # a second consumer the autograd engine accumulates the other branch's gradient into it IN PLACE (old.add_(new); the
+    # Python object and its attribute survive), which bumps the version counter — then the dropped copy is stale.
+    if (ready is not None and _same_drop(ready[0], drop) and ready[1].shape == x.shape
+            and ready[2] == x.data_ptr() and ready[3] == x._version):
         DROP_STATS["handed_over"] += 1
         return ready[1]
     DROP_STATS["launched"] += 1
@@ -421,7 +430,7 @@ class LayerNormFn(torch.autograd.Function):
                             ctx.lens, ctx.T, dres, dx_drop=dxd, drop=ctx.up_drop)
         _ready(ctx.gamma, ctx.beta)
         if dxd is not None:
-            dx._s2t_dropped = (ctx.up_drop, dxd)  # picked up by _drop_rows in the producing block's backward
+            _hand_over(dx, ctx.up_drop, dxd)
         return dx, None, None, None, None, None
 
 
@@ -519,6 +528,116 @@ class FFNFn(torch.autograd.Function):
         K.gemm(dz, cw(w1), dx, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
         _ready(w1, b1)
         return dx, None, None, None, None, None, None, dres, None, None, None
+
+
+_FFN_FUSED = os.environ.get("S2T_FFN_FUSED", "1") != "0"
+_FFN_FUSED_MIN_ROWS = int(os.environ.get("S2T_FFN_FUSED_MIN_ROWS", "8192"))  # 64-row blocks: fewer rows leave CUs idle
+
+
+class FFNBlockFn(torch.autograd.Function):
+    """One launch for a whole pre-LN feed-forward block (csrc/rowblock.hip, s2t_ffn_fused_fwd):
+         y = x + alpha * drop_o(W2 drop_h(act(W1 LN(x) + b1)) + b2)      [-> LN_end(y), padded rows zeroed]
+    (modules/s2t_transformer_layer.py:55-66, :258-265, :311-320).  The backward pass is the unfused one (dgrad GEMMs,
+    grouped weight gradients, s2t_layernorm_bwd with the residual gradient folded in) on the tensors the kernel saved.
+    Returns LN_end(y) when ``end`` = (gamma, beta) is given (the pre-norm y has no other consumer), y otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, act, alpha, train, drop_h, drop_o, end_g, end_b, end_lens, end_T):
+        M, d = x.shape
+        F_ = w1.shape[0]
+        dev = x.device
+        bf = torch.bfloat16
+        y = torch.empty(M, d, dtype=bf, device=dev) if (train or end_g is None) else None
+        y_ln = torch.empty(M, d, dtype=bf, device=dev) if end_g is not None else None
+        x_ln = mean = rstd = z = h = emean = erstd = None
+        if train:
+            x_ln = torch.empty(M, d, dtype=bf, device=dev)
+            mean = torch.empty(M, dtype=torch.float32, device=dev)
+            rstd = torch.empty(M, dtype=torch.float32, device=dev)
+            z = torch.empty(M, F_, dtype=bf, device=dev)
+            h = torch.empty(M, F_, dtype=bf, device=dev)
+            if end_g is not None:
+                emean = torch.empty(M, dtype=torch.float32, device=dev)
+                erstd = torch.empty(M, dtype=torch.float32, device=dev)
+        K.ffn_fused_fwd(x, cw(w1), b1.data, cw(w2), b2.data, y, act=act, alpha=alpha, residual=x,
+                        ln=(gamma.data, beta.data), end_ln=(end_g.data, end_b.data) if end_g is not None else None,
+                        y_ln=y_ln, end_stats=(emean, erstd) if emean is not None else None, end_lens=end_lens, end_T=end_T,
+                        x_ln=x_ln, ln_stats=(mean, rstd) if train else None, z=z, h=h, drop_h=drop_h, drop_o=drop_o)
+        if train:
+            ctx.save_for_backward(x, x_ln, mean, rstd, z, h, y if end_g is not None else None, emean, erstd)
+        ctx.p = (gamma, beta, w1, b1, w2, b2, end_g, end_b)
+        ctx.act, ctx.alpha, ctx.drops, ctx.end_lens, ctx.end_T = act, alpha, (drop_h, drop_o), end_lens, end_T
+        up = getattr(x, "_s2t_drop_o", None)  # output-dropout mask of the block that produced x (see _tag_drop)
+        ctx.up_drop = up
+        return y_ln if end_g is not None else y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, x_ln, mean, rstd, z, h, y, emean, erstd = ctx.saved_tensors
+        gamma, beta, w1, b1, w2, b2, end_g, end_b = ctx.p
+        M, d = x.shape
+        F_ = w1.shape[0]
+        drop_h, drop_o = ctx.drops
+        dout = dout.contiguous()
+        queued = x.is_cuda and _arm_backward_end()
+
+        def ln_bwd(xx, g_, b_, dy_, mean_, rstd_, lens, T, dres, dx_drop, drop):
+            dx_ = torch.empty_like(xx)
+            if queued:
+                ws = _ln_workspace(d, xx.device)
+                K.layernorm_bwd(xx, g_.data, dy_, mean_, rstd_, dx_, None, None, M, d, lens, T, dres, ws=ws, dx_drop=dx_drop,
+                                drop=drop)
+                _LNQ["entries"].append((ws, g_.grad, b_.grad, d))
+            else:
+                K.layernorm_bwd(xx, g_.data, dy_, mean_, rstd_, dx_, g_.grad, b_.grad, M, d, lens, T, dres, dx_drop=dx_drop,
+                                drop=drop)
+            _ready(g_, b_)
+            return dx_
+
+        if end_g is not None:
+            # gradient of the trailing LayerNorm w.r.t. y; dropout(dy) under this block's own output mask comes with it
+            dyd = torch.empty_like(x) if drop_o is not None else None
+            dres = ln_bwd(y, end_g, end_b, dout, emean, erstd, ctx.end_lens, ctx.end_T, None, dyd, drop_o)
+            dy = dyd if dyd is not None else dres
+        else:
+            dres = dout
+            dy = _drop_rows(dres, drop_o)
+        # dZ = alpha * dropout_h(dY @ W2) * act'(Z)
+        dz = torch.empty(M, F_, dtype=x.dtype, device=x.device)
+        K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
+               dact=ctx.act, drop=drop_h)
+        _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad)
+        _ready(w2, b2)
+        _wgrad(dz, x_ln, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)
+        dxl = torch.empty_like(x)
+        K.gemm(dz, cw(w1), dxl, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
+        _ready(w1, b1)
+        dxd = torch.empty_like(x) if ctx.up_drop is not None else None
+        dx = ln_bwd(x, gamma, beta, dxl, mean, rstd, None, 0, dres, dxd, ctx.up_drop)
+        if dxd is not None:
+            _hand_over(dx, ctx.up_drop, dxd)
+        return (dx,) + (None,) * 15
+
+
+def ffn_block(x, norm_g, norm_b, w1, b1, w2, b2, act, alpha, p_hidden=0.0, p_out=0.0, training=False, end_norm=None,
+              end_lens=None, end_T=0):
+    """Pre-LN feed-forward block with its residual (and the layer's trailing LayerNorm when ``end_norm`` = (gamma, beta)):
+    the row-block kernel when it applies, the LayerNorm / GEMM composition otherwise."""
+    M, d = x.shape
+    F_ = w1.shape[0]
+    if (_FFN_FUSED and K.ffn_fused_supported(x, F_) and M >= _FFN_FUSED_MIN_ROWS and x.is_contiguous()
+            and act in ("relu", "swish")):
+        drop_h = DROPOUT.next(p_hidden if training else 0.0, x.device)
+        drop_o = DROPOUT.next(p_out if training else 0.0, x.device)
+        eg, eb = end_norm if end_norm is not None else (None, None)
+        out = FFNBlockFn.apply(x, norm_g, norm_b, w1, b1, w2, b2, act, alpha, torch.is_grad_enabled(), drop_h, drop_o, eg,
+                               eb, end_lens, end_T)
+        return out if end_norm is not None else _tag_drop(out, drop_o)
+    y, xr = layer_norm(x, norm_g, norm_b, fork=True)
+    out = ffn(y, w1, b1, w2, b2, act, alpha, xr, p_hidden, p_out, training)
+    if end_norm is not None:
+        out = layer_norm(out, end_norm[0], end_norm[1], end_lens, end_T)
+    return out
 
 
 def ffn(x, w1, b1, w2, b2, act, alpha, residual, p_hidden=0.0, p_out=0.0, training=False):

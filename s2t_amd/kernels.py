@@ -89,6 +89,55 @@ def gemm(
     return out
 
 
+def ffn_fused_supported(x, F, M=None):
+    """The row-block kernel covers the recipes' encoder width: bf16, d = 256, F a multiple of 64 up to 4096."""
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 256 and F % 64 == 0 and F <= 4096
+
+
+def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=None, ln_eps=1e-5, end_ln=None, y_ln=None,
+                  end_stats=None, end_lens=None, end_T=0, x_ln=None, ln_stats=None, z=None, h=None, drop_h=None,
+                  drop_o=None):
+    """s2t_ffn_fused_fwd (include/s2t_hip.h): ``ln`` / ``end_ln`` = (gamma, beta) fp32 of the LayerNorm in front of /
+    behind the block; ``ln_stats`` / ``end_stats`` = (mean, rstd) outputs; drops = (p, seed tensor, site) or None."""
+    L.require_cuda(x, w1, w2, y, y_ln, residual, x_ln, z, h)
+    M, d = x.shape
+    F = w1.shape[0]
+    a = L.FfnArgs()
+    a.x, a.d, a.M, a.F = x.data_ptr(), d, M, F
+    a.ln_gamma, a.ln_beta = (ln[0].data_ptr(), ln[1].data_ptr()) if ln is not None else (None, None)
+    a.ln_eps = ln_eps
+    a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and b1.dtype == torch.float32
+    a.residual, a.y = _ptr(residual), _ptr(y)
+    if end_ln is not None:
+        a.eln_gamma, a.eln_beta, a.y_ln = end_ln[0].data_ptr(), end_ln[1].data_ptr(), y_ln.data_ptr()
+        if end_stats is not None:
+            a.eln_mean, a.eln_rstd = end_stats[0].data_ptr(), end_stats[1].data_ptr()
+        if end_lens is not None:
+            assert end_lens.dtype == torch.int32
+            a.eln_lens, a.eln_T = end_lens.data_ptr(), end_T
+    a.x_ln = _ptr(x_ln)
+    if ln_stats is not None:
+        a.ln_mean, a.ln_rstd = ln_stats[0].data_ptr(), ln_stats[1].data_ptr()
+    a.z, a.h = _ptr(z), _ptr(h)
+    a.act, a.alpha = L.ACT_IDS[act], alpha
+    seed = None
+    if drop_h is not None and drop_h[0] > 0:
+        a.drop_h_p, a.drop_h_site, seed = float(drop_h[0]), int(drop_h[2]), drop_h[1]
+    if drop_o is not None and drop_o[0] > 0:
+        assert seed is None or seed.data_ptr() == drop_o[1].data_ptr()
+        a.drop_o_p, a.drop_o_site, seed = float(drop_o[0]), int(drop_o[2]), drop_o[1]
+    a.drop_seed = _ptr(seed)
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
+        e1.record()
+        GEMM_PROFILE.append(("ffn_fused_fwd_kernel", 4.0 * M * F * d, e0, e1, (M, F, d, 1)))
+        return
+    L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
+
+
 # ----------------------------------------------------------------------------------------------
 # flat-argument entry points
 # ----------------------------------------------------------------------------------------------

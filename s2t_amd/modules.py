@@ -122,6 +122,12 @@ class FeedForwardModule(nn.Module):
         return Fn.ffn(x_ln, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, self.activation_fn, scale,
                       residual, self.dropout1, self.dropout2, self.training)
 
+    def block(self, x, norm, scale, end_norm=None, end_lens=None, end_T=0):
+        """x + scale * ffn(norm(x)) [-> end_norm]: the whole pre-LN block, one launch when the row-block kernel applies."""
+        en = (end_norm.weight, end_norm.bias) if end_norm is not None else None
+        return Fn.ffn_block(x, norm.weight, norm.bias, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
+                            self.activation_fn, scale, self.dropout1, self.dropout2, self.training, en, end_lens, end_T)
+
 
 class MultiheadAttention(nn.Module):
     """modules/multihead_attention.py:24-431 — keys k_proj, v_proj, q_proj, out_proj."""
@@ -323,8 +329,7 @@ class S2TTransformerEncoderLayer(nn.Module):
         """x: [B*T, d].  ``mask_output``: zero padded frames of the result (the NEXT layer's layer_padding_mask)."""
         B, T, lens = c.B, c.T, c.lens
         if self.macaron_norm is not None:
-            y, x = self.macaron_norm(x, fork=True)
-            x = self.macaron_ffn(y, x, self.ffn_scale)
+            x = self.macaron_ffn.block(x, self.macaron_norm, self.ffn_scale)
         y, x = self.self_attn_layer_norm(x, fork=True)
         if self.attn_type == "rel_pos":
             x = self.self_attn(y, x, B, T, lens, c.pos_tab)
@@ -333,11 +338,8 @@ class S2TTransformerEncoderLayer(nn.Module):
         if self.conv_module is not None:
             y, x = self.conv_norm(x, lens, T, fork=True)  # conv input mask fused (convolution.py:86-88)
             x = self.conv_module(y, x, B, T, lens)
-        y, x = self.ffn_norm(x, fork=True)
-        x = self.ffn(y, x, self.ffn_scale)
-        if self.final_norm is not None:
-            x = self.final_norm(x, lens if mask_output else None, T)
-        elif mask_output:
+        x = self.ffn.block(x, self.ffn_norm, self.ffn_scale, self.final_norm, lens if mask_output else None, T)
+        if self.final_norm is None and mask_output:
             x = MaskRows.apply(x, lens, T)
         return x
 

@@ -1,0 +1,187 @@
+"""GPU parity of the row-block kernels (csrc/rowblock.hip) through the C-ABI.
+
+s2t_ffn_fused_fwd is compared with (a) plain fp32 maths on the same bf16-rounded operands — the reference's
+FeedForwardModule (fairseq/modules/s2t_transformer_layer.py:55-66) between its LayerNorm and residual — and (b) the
+unfused kernels (s2t_layernorm_fwd + two s2t_gemm) for the dropout masks, which must be the SAME masks element for
+element because the unfused backward regenerates them."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from s2t_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+
+
+def _mk(M, F, seed, d=256):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, d, generator=g).bfloat16()
+    w1 = (torch.randn(F, d, generator=g) * d ** -0.5).bfloat16()
+    b1 = 0.1 * torch.randn(F, generator=g)
+    w2 = (torch.randn(d, F, generator=g) * F ** -0.5).bfloat16()
+    b2 = 0.1 * torch.randn(d, generator=g)
+    gam = 1 + 0.1 * torch.randn(d, generator=g)
+    bet = 0.1 * torch.randn(d, generator=g)
+    eg = 1 + 0.1 * torch.randn(d, generator=g)
+    eb = 0.1 * torch.randn(d, generator=g)
+    return x, w1, b1, w2, b2, gam, bet, eg, eb
+
+
+def _act(v, act):
+    if act == "relu":
+        return torch.relu(v)
+    if act == "swish":
+        return v * torch.sigmoid(v)
+    return v
+
+
+def _ref(x, w1, b1, w2, b2, gam, bet, eg, eb, act, alpha, use_ln, use_eln, lens=None, T=0):
+    """fp32 maths with the rounding points of the bf16 contract: LN output, hidden activation and block output are bf16."""
+    xf = x.float()
+    xn = torch.nn.functional.layer_norm(xf, (xf.shape[1],), gam, bet, 1e-5).bfloat16().float() if use_ln else xf
+    z = xn @ w1.float().t() + b1
+    h = _act(z, act).bfloat16().float()
+    y = (xf + alpha * (h @ w2.float().t() + b2)).bfloat16().float()
+    yl = None
+    if use_eln:
+        yl = torch.nn.functional.layer_norm(y, (y.shape[1],), eg, eb, 1e-5)
+        if lens is not None:
+            B = lens.numel()
+            pad = (torch.arange(T)[None] >= lens[:, None]).reshape(-1)
+            yl = yl.masked_fill(pad[:, None], 0.0)
+    return xn, z, h, y, yl
+
+
+@pytest.mark.parametrize("M,F,act,use_ln,use_eln", [
+    (64, 64, "relu", False, False),
+    (64, 128, "swish", True, False),
+    (200, 2048, "swish", True, True),     # ragged last row block
+    (1000, 512, "relu", True, True),
+    (16000, 2048, "swish", True, True),   # the headline configuration's encoder FFN
+])
+def test_ffn_fused_eval(M, F, act, use_ln, use_eln):
+    x, w1, b1, w2, b2, gam, bet, eg, eb = _mk(M, F, 7 + F)
+    T = 50
+    lens = None
+    if use_eln and M % T == 0:
+        B = M // T
+        lens = torch.randint(1, T + 1, (B,), generator=torch.Generator().manual_seed(3)).int()
+    alpha = 0.5
+    _, _, _, y_ref, yl_ref = _ref(x, w1, b1, w2, b2, gam, bet, eg, eb, act, alpha, use_ln, use_eln, lens, T)
+    xd = x.to(DEV)
+    y = torch.full((M, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    yl = torch.full((M, 256), float("nan"), dtype=torch.bfloat16, device=DEV) if use_eln else None
+    K.ffn_fused_fwd(xd, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), y, act=act, alpha=alpha, residual=xd,
+                    ln=(gam.to(DEV), bet.to(DEV)) if use_ln else None,
+                    end_ln=(eg.to(DEV), eb.to(DEV)) if use_eln else None, y_ln=yl,
+                    end_lens=lens.to(DEV) if lens is not None else None, end_T=T)
+    torch.cuda.synchronize()
+    err = (y.float().cpu() - y_ref).abs().max() / y_ref.abs().max()
+    assert float(err) < 1.5e-2, float(err)
+    if use_eln:
+        err = (yl.float().cpu() - yl_ref).abs().max() / yl_ref.abs().max()
+        assert float(err) < 2.5e-2, float(err)
+        if lens is not None:
+            pad = (torch.arange(T)[None] >= lens[:, None]).reshape(-1)
+            assert float(yl.float().cpu()[pad].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,F,act", [(200, 256, "swish"), (4096, 2048, "relu")])
+def test_ffn_fused_train_saves_and_masks(M, F, act):
+    """Training flavour: the saves equal what the unfused kernels produce on the same inputs with the same dropout sites."""
+    x, w1, b1, w2, b2, gam, bet, eg, eb = _mk(M, F, 11)
+    d = 256
+    alpha = 0.5
+    xd, w1d, b1d, w2d, b2d = x.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV)
+    gd, bd = gam.to(DEV), bet.to(DEV)
+    seed = torch.tensor([12345], dtype=torch.int64, device=DEV)
+    drop_h, drop_o = (0.1, seed, 3), (0.1, seed, 4)
+    # unfused: LayerNorm kernel, GEMM (bias + act + preact + dropout), GEMM (bias + dropout + alpha + residual)
+    xl_u = torch.empty_like(xd)
+    mean_u, rstd_u = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    K.layernorm_fwd(xd, gd, bd, xl_u, mean_u, rstd_u, M, d)
+    h_u = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    z_u = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    K.gemm(xl_u, w1d, h_u, M=M, N=F, K=d, lda=d, ldb=d, ldc=F, bias=b1d, act=act, preact=z_u, ldp=F, drop=drop_h)
+    y_u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    K.gemm(h_u, w2d, y_u, M=M, N=d, K=F, lda=F, ldb=F, ldc=d, bias=b2d, alpha=alpha, residual=xd, ldr=d, drop=drop_o)
+    # fused
+    xl_f = torch.empty_like(xd)
+    mean_f, rstd_f = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    h_f = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
+    z_f = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y_f = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    K.ffn_fused_fwd(xd, w1d, b1d, w2d, b2d, y_f, act=act, alpha=alpha, residual=xd, ln=(gd, bd), x_ln=xl_f,
+                    ln_stats=(mean_f, rstd_f), z=z_f, h=h_f, drop_h=drop_h, drop_o=drop_o)
+    torch.cuda.synchronize()
+    assert float((mean_f - mean_u).abs().max()) < 1e-5
+    assert float(((rstd_f - rstd_u) / rstd_u).abs().max()) < 1e-5
+    assert float((xl_f.float() - xl_u.float()).abs().max()) <= 2 ** -6  # one bf16 ulp at |x| < 4
+    zf, zu = z_f.float(), z_u.float()
+    assert float((zf - zu).abs().max() / zu.abs().max()) < 2e-2
+    # identical masks: an element is zero in one exactly when it is zero in the other (apart from true zeros of relu)
+    hf, hu = h_f.float(), h_u.float()
+    nz_f, nz_u = hf != 0, hu != 0
+    mism = (nz_f != nz_u) & (zu.abs() > 0.05)
+    assert int(mism.sum()) == 0, int(mism.sum())
+    keep = float(nz_u.float().mean())
+    assert keep < (0.96 if act == "swish" else 0.6)  # dropout really was applied
+    assert float((hf - hu).abs().max() / hu.abs().max()) < 2e-2
+    assert float((y_f.float() - y_u.float()).abs().max() / y_u.float().abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("end_norm,mask", [(False, False), (True, False), (True, True)])
+def test_ffn_block_fused_vs_composed_training(end_norm, mask):
+    """functional.ffn_block: the fused launch and the LayerNorm / GEMM composition give the same output and gradients
+    (same dropout sites, so the same masks) — modules/s2t_transformer_layer.py:258-265, :311-320."""
+    from s2t_amd import functional as Fn
+    from s2t_amd import modules as Md
+    from s2t_amd.flat_params import FlatParameters
+
+    torch.manual_seed(5)
+    d, F, B, T = 256, 512, 4, 40
+    M = B * T
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.norm = Md.LayerNorm(d)
+            self.ffn = Md.FeedForwardModule(d, F, 0.1, 0.1, "swish")
+            self.end = Md.LayerNorm(d)
+            self.pre = Md.Linear(d, d)
+
+    blk = Blk().to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    flat = FlatParameters(blk, torch.bfloat16)
+    blk.train()
+    lens = torch.tensor([40, 33, 17, 5], dtype=torch.int32, device=DEV) if mask else None
+    x0 = torch.randn(M, d, device=DEV).bfloat16()
+    dy = torch.randn(M, d, device=DEV).bfloat16()
+    outs = {}
+    old = (Fn._FFN_FUSED, Fn._FFN_FUSED_MIN_ROWS)
+    try:
+        for fused in (True, False):
+            Fn._FFN_FUSED, Fn._FFN_FUSED_MIN_ROWS = fused, 0
+            Fn.DROPOUT.begin_step(DEV)
+            Fn.DROPOUT.set_seed(77)
+            flat.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            xin = blk.pre(x)  # a producer in front, so that dx flows through a real graph
+            y = blk.ffn.block(xin, blk.norm, 0.5, blk.end if end_norm else None, lens, T)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            outs[fused] = (y.detach().float(), x.grad.float().clone(), flat.grad.clone())
+    finally:
+        Fn._FFN_FUSED, Fn._FFN_FUSED_MIN_ROWS = old
+    (yf, dxf, gf), (yc, dxc, gc) = outs[True], outs[False]
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+
+    assert rel(yf, yc) < 1e-2, rel(yf, yc)
+    assert rel(dxf, dxc) < 2e-2, rel(dxf, dxc)
+    assert rel(gf, gc) < 2e-2, rel(gf, gc)
