@@ -29,7 +29,8 @@
 #include "common.h"
 
 #ifndef S2T_RB_DBG
-#define S2T_RB_DBG 0  // kernel-experiment switches (tools/rb_dbg_build.sh): 1 no DMA inside the loop, 2 no MFMAs, 4 no E1
+#define S2T_RB_DBG 0  // kernel-experiment switches (tools/rb_dbg_build.sh): 1 no DMA inside the loop, 2 no MFMAs, 4 no E1,
+                      // 8 no z / h saves
 #endif
 
 namespace {
@@ -133,21 +134,35 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     v2o = v2e ^ 64u;
   }
   const uint32_t w2step = (uint32_t)(8 * F * 2);
-  auto issue_w1 = [&](int c) __attribute__((always_inline)) {
+  auto issue_w1_half = [&](int c, int half) __attribute__((always_inline)) {
     const uint32_t base = lds0 + LDS_W1 + (c & 1) * STAGE + wave * 4096;
     const uint32_t soff = (uint32_t)c * (FC * 512);
-    dma16_off<0>(base, v1e, srd1, soff);
-    dma16_off<1024>(base, v1o, srd1, soff);
-    dma16_off<2048>(base, v1e, srd1, soff);
-    dma16_off<3072>(base, v1o, srd1, soff);
+    if (half == 0) {
+      dma16_off<0>(base, v1e, srd1, soff);
+      dma16_off<1024>(base, v1o, srd1, soff);
+    } else {
+      dma16_off<2048>(base, v1e, srd1, soff);
+      dma16_off<3072>(base, v1o, srd1, soff);
+    }
   };
-  auto issue_w2 = [&](int c) __attribute__((always_inline)) {
+  auto issue_w2_half = [&](int c, int half) __attribute__((always_inline)) {
     const uint32_t base = lds0 + LDS_W2 + (c & 1) * STAGE + wave * 4096;
     const uint32_t soff = (uint32_t)c * (FC * 2);
-    dma16(base, v2e, srd2, soff);
-    dma16(base + 1024, v2o, srd2, soff + w2step);
-    dma16(base + 2048, v2e, srd2, soff + 2 * w2step);
-    dma16(base + 3072, v2o, srd2, soff + 3 * w2step);
+    if (half == 0) {
+      dma16(base, v2e, srd2, soff);
+      dma16(base + 1024, v2o, srd2, soff + w2step);
+    } else {
+      dma16(base + 2048, v2e, srd2, soff + 2 * w2step);
+      dma16(base + 3072, v2o, srd2, soff + 3 * w2step);
+    }
+  };
+  auto issue_w1 = [&](int c) __attribute__((always_inline)) {
+    issue_w1_half(c, 0);
+    issue_w1_half(c, 1);
+  };
+  auto issue_w2 = [&](int c) __attribute__((always_inline)) {
+    issue_w2_half(c, 0);
+    issue_w2_half(c, 1);
   };
   issue_w1(0);
   issue_w2(0);
@@ -330,22 +345,36 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
       yacc[n0 + j][1] = mfma16(as_frag(af[j]), hb[1], yacc[n0 + j][1]);
     }
   };
+  // Saves for backward: ALWAYS exactly four store instructions per wave and chunk (the closing wait of the loop counts
+  // on it): buffer stores whose descriptor drops rows >= M (and everything when the tensor was not asked for).
+  const __amdgpu_buffer_rsrc_t zsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.z), 0, p.z ? (int)((uint32_t)M * (uint32_t)F * 2u) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t hsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.h), 0, p.h ? (int)((uint32_t)M * (uint32_t)F * 2u) : 0, 0x00020000);
   auto save = [&](int c, const uint2 (&zp)[2], const uint2 (&hp)[2]) __attribute__((always_inline)) {
-    if constexpr (TRAIN) {
-      bf16_t* Z = reinterpret_cast<bf16_t*>(p.z);
-      bf16_t* H = reinterpret_cast<bf16_t*>(p.h);
+    if constexpr (TRAIN && !(S2T_RB_DBG & 8)) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const int m = row0 + 32 * mp + 16 * mt + x;
-        if (m < M) {
-          const int64_t o = (int64_t)m * F + c * FC + 32 * fh + 8 * g + 4 * nh;
-          if (Z) *reinterpret_cast<uint2*>(Z + o) = zp[mt];
-          if (H) *reinterpret_cast<uint2*>(H + o) = hp[mt];
-        }
+        const uint32_t m = (uint32_t)(row0 + 32 * mp + 16 * mt + x);
+        const uint32_t o = (m * (uint32_t)F + (uint32_t)(c * FC + 32 * fh + 8 * g + 4 * nh)) * 2u;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){zp[mt].x, zp[mt].y}, zsrd, o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){hp[mt].x, hp[mt].y}, hsrd, o, 0, 0);
       }
     }
   };
 
+#if S2T_RB_DBG & 16
+  unsigned long long stamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                   \
+  do {                                             \
+    __builtin_amdgcn_sched_barrier(0);             \
+    stamp[i] = __builtin_amdgcn_s_memtime();       \
+    __builtin_amdgcn_sched_barrier(0);             \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
   uint2 zp[2], hp[2];
   {
     f32x4 hacc[2];
@@ -360,36 +389,58 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   for (int c = 1; c < nchunks; ++c) {
-    save(c - 1, zp, hp);
-#if !(S2T_RB_DBG & 1)
-    if (c + 1 < nchunks) issue_w1(c + 1);
-    issue_w2(c);
-#endif
+    // The first fragment reads go out before anything else; the DMAs of the next chunks follow (they must be OLDER than
+    // the chunk's saves, see the closing wait), then the MFMA groups with the next group's reads behind them.
+    // sched_barrier pins the order of the groups.
+    const bool more = c + 1 < nchunks;
     f32x4 hacc[2];
     uint2 zn[2], hn[2];
     bf16x8 hb[2];
     uint4 a0[4], a1[4];
+    STAMP(0);
     g1_bias(c, hacc);
     g2_hb(c - 1, hp, hb);
     g1_read(c, 0, a0);
     g1_read(c, 4, a1);
     __builtin_amdgcn_sched_barrier(0);
+#if !(S2T_RB_DBG & 1)
+    if (more) issue_w1(c + 1);
+    issue_w2(c);
+#endif
+    save(c - 1, zp, hp);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
     g1_mma(0, a0, hacc);
     g2_read(c - 1, 0, a0);
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(2);
     g1_mma(4, a1, hacc);
     g2_read(c - 1, 4, a1);
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(3);
     g2_mma(0, a0, hb);
     e1(c, hacc, zn, hn);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(4);
     g2_mma(4, a1, hb);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       zp[mt] = zn[mt];
       hp[mt] = hn[mt];
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    STAMP(7);
+    // TRAIN: the four buffer stores of save() are the wave's youngest vector-memory operations and may stay in flight
+    // across the barrier (vmcnt counts in issue order); what must have landed are the DMAs in front of them
+    if constexpr (TRAIN && !(S2T_RB_DBG & 8)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    STAMP(8);
   }
+#if S2T_RB_DBG & 16
+  if (lane == 0 && p.eln_mean && !p.eln_gamma && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.eln_mean) + (blockIdx.x ? 128 : 0) + wave * 16;
+    for (int i = 0; i < 9; ++i) dbg[i] = stamp[i];
+  }
+#endif
   save(nchunks - 1, zp, hp);
   {
     bf16x8 hb[2];

@@ -41,9 +41,9 @@ def unfused(train, act):
     K.gemm(h, w2, y, M=M, N=d, K=F, lda=F, ldb=F, ldc=d, bias=b2, alpha=0.5, residual=x, ldr=d, drop=do)
 
 
-def fused(train, act, eln=False):
-    dh = (0.1, seed, 1) if train else None
-    do = (0.1, seed, 2) if train else None
+def fused(train, act, eln=False, drop=True):
+    dh = (0.1, seed, 1) if (train and drop) else None
+    do = (0.1, seed, 2) if (train and drop) else None
     K.ffn_fused_fwd(x, w1, b1, w2, b2, y, act=act, alpha=0.5, residual=x, ln=(gam, bet),
                     x_ln=xl if train else None, ln_stats=(mean, rstd) if train else None, z=z if train else None,
                     h=h if train else None, drop_h=dh, drop_o=do, end_ln=(gam, bet) if eln else None,
@@ -57,5 +57,7 @@ for act in ("swish", "relu"):
         tf = timeit(lambda: fused(train, act))
         print("act=%s train=%d  unfused %.1f us (%.0f TF/s)   fused %.1f us (%.0f TF/s)" % (
             act, train, tu, flop / tu / 1e6, tf, flop / tf / 1e6), flush=True)
+tf = timeit(lambda: fused(True, "swish", False, False))
+print("fused train swish without dropout: %.1f us" % tf)
 tf = timeit(lambda: fused(False, "swish", True))
 print("fused eval swish + end LayerNorm: %.1f us" % tf)
