@@ -2,7 +2,10 @@
 """Headline benchmark: speech-frames/sec of one full training update (encoder + decoder forward + backward +
 gradient all-reduce + clip + Adam) of the 12-layer Conformer S2T model on synthetic 1000x80 filterbank batches.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
+N > 1: one process per GPU.  Under torch.distributed.run (RANK set) this process IS a rank; started plainly it first
+launches the N ranks itself as child processes (before anything here touches the GPU) and passes their line through —
+compare fairseq/distributed/utils.py:332-364 (the reference spawns its ranks itself).
 
 Prints ONE JSON line on rank 0 (contract in the task statement; roofline + cpu_baseline objects included).
 Workload = BASELINE.json configs[1] in its Conformer reading (SURVEY.md §8d config 2'): s2t_transformer_s,
@@ -16,9 +19,6 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -26,9 +26,29 @@ MFMA_PEAK_BF16 = 2.5e15  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.
 MFMA_PEAK_F32 = 157.3e12
 
 
+def _launch_ranks(n):
+    """Start ``n`` ranks of this script under torch.distributed.run as a CHILD process and return its exit code.  Nothing
+    in this (parent) process has initialised the GPU: torch is not even imported yet."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def synthetic_batch(B, T, V, seed, device):
     """BASELINE.md §3: randn features, row 0 full length, others U[ceil(.6T), T], sorted desc, tail zeroed;
     targets 20..60 tokens uniform in [4, V) + eos; prev_output_tokens = eos-shifted (collater layout)."""
+    import torch
+
     g = torch.Generator().manual_seed(seed)
     lens = [T] + [int(torch.randint(int(math.ceil(0.6 * T)), T + 1, (1,), generator=g)) for _ in range(B - 1)]
     lens = sorted(lens, reverse=True)
@@ -57,6 +77,8 @@ def synthetic_batch(B, T, V, seed, device):
 def cpu_baseline(args, V, conformer):
     """Reference's PyTorch-CPU algorithm (the pinned oracle restatement, autograd for backward) timed on this box's
     host cores on a bounded sample of the same workload: B=2 utterances of the same length/width."""
+    import torch
+
     from oracle import s2t_oracle as O
     from s2t_amd import s2t_transformer as M
 
@@ -106,38 +128,49 @@ def main():
     ap.add_argument("--dec-layers", type=int, default=6)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(_launch_ranks(args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
-    # S2T_DIST_BACKEND=gloo rehearses the multi-rank choreography on a box with fewer GPUs than ranks (ranks share devices)
-    backend = os.environ.get("S2T_DIST_BACKEND", "nccl")
-    if backend != "nccl":
+    # Gradient all-reduce: the library's own RCCL communicator (s2t_amd/comm.py, capturable in the step's hipGraph);
+    # torch.distributed (gloo) only carries the rendezvous, the unique id and a few host scalars.
+    # S2T_DIST_BACKEND=gloo rehearses the multi-rank choreography on a box with fewer GPUs than ranks: ranks share
+    # devices and the gradients go through torch.distributed instead (RCCL needs one device per rank).
+    backend = os.environ.get("S2T_DIST_BACKEND", "rccl")
+    if backend != "rccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # S2T_FORCE_DDP=1 (under torch.distributed.run with one rank) exercises the RCCL + hipGraph path on a single GPU
-    force_ddp = os.environ.get("S2T_FORCE_DDP") == "1" and "RANK" in os.environ
-    if world > 1 or force_ddp:
+    # S2T_FORCE_DDP=1 exercises the RCCL + side-stream + hipGraph path with a one-rank communicator on a single GPU
+    force_ddp = os.environ.get("S2T_FORCE_DDP") == "1"
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+        dist.init_process_group("gloo")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d runs %d ranks: start it plainly (it launches its ranks itself) or under "
+                         "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
 
     import __graft_entry__ as entry
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "s2t_amd", "lib", "libs2t_hip.so")):
         entry.build()
     if world > 1:
         dist.barrier()
+    from s2t_amd import comm as Comm
     from s2t_amd import criterions as C
     from s2t_amd import kernels as K
     from s2t_amd import s2t_transformer as M
     from s2t_amd.legacy_distributed_data_parallel import LegacyDistributedDataParallel
     from s2t_amd.trainer import Trainer
 
+    if (world > 1 or force_ddp) and backend == "rccl":
+        Comm.init(rank, world, dev)
     V = args.vocab
     conformer = args.arch == "conformer"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -149,7 +182,7 @@ def main():
     ddp = LegacyDistributedDataParallel(model, single_rank_collectives=force_ddp) if (world > 1 or force_ddp) else None
     trainer = Trainer(model, crit, ddp=ddp)
     sample, frames_local = synthetic_batch(args.batch, args.frames, V, 1 + rank, dev)
-    ft = torch.tensor([frames_local, sample["ntokens"]], dtype=torch.float64, device=dev)
+    ft = torch.tensor([frames_local, sample["ntokens"]], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(ft)
     frames_global, ntok_global = int(ft[0]), int(ft[1])
@@ -185,7 +218,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt[0])
@@ -301,13 +334,17 @@ def main():
                             "Adam+clip10, dropout %.2f" % (args.arch, args.enc_layers, args.dec_layers, V, args.batch, args.frames, args.dropout),
                 "global_batch": args.batch * world, "frames_per_step": frames_global, "parallelism": "dp%d" % world,
                 "hip_graph": use_graph, "final_loss": loss_val,
+                "grad_allreduce": ("rccl (s2t_allreduce_bucket) inside the step graph, overlapped with backward"
+                                   if Comm.initialized() else ("torch.distributed/%s" % backend if world > 1 else "none")),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
-    if world > 1 or force_ddp:
+    if world > 1:
         dist.barrier()
+    Comm.destroy()
+    if world > 1:
         dist.destroy_process_group()
 
 

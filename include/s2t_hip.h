@@ -406,6 +406,22 @@ typedef struct s2t_ffn_args {
 } s2t_ffn_args;
 int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
 
+/* ---- Gradient all-reduce over RCCL / xGMI (csrc/comm.hip) ------------------------------------------------
+ * Replaces torch.distributed.all_reduce in LegacyDistributedDataParallel.all_reduce_grads
+ * (distributed/legacy_distributed_data_parallel.py:107-120): one process-global communicator (one process per GPU),
+ * created from a 128-byte RCCL unique id that rank 0 draws with s2t_comm_unique_id and hands to the other ranks over any
+ * host channel (the Python side uses torch.distributed's store / gloo).  s2t_allreduce_bucket is an in-place,
+ * stream-ordered all-reduce of `count` elements (S2T_F32 or S2T_BF16); average != 0 divides by the world size inside
+ * the collective (the reference's pre-division, :107-110).  No thread watches the communicator, so the call can be
+ * captured into a hipGraph and issued on a side stream beside backward.
+ * RCCL is bound at run time; S2T_ERR_UNSUPPORTED = no librccl, no communicator, or a second s2t_comm_init.
+ * RCCL errors come back as 10000 + ncclResult_t. */
+int s2t_comm_unique_id(void* out128);
+int s2t_comm_init(int rank, int world, const void* unique_id128);
+int s2t_comm_world(void);
+int s2t_allreduce_bucket(void* ptr, int64_t count, int dtype, int average, void* stream);
+int s2t_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

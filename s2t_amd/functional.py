@@ -229,19 +229,47 @@ def _ln_workspace(cols, device):
     return pool[off:off + n]
 
 
-def _on_backward_end():
+def _flush_deferred():
+    """Run the gradient work queued so far (LayerNorm parameter folds, grouped weight gradients) and deliver the
+    grad-ready notifications that were waiting for it."""
     entries, _LNQ["entries"] = _LNQ["entries"], []
-    for k in _LNQ["off"]:
-        _LNQ["off"][k] = 0
     if entries:
         K.layernorm_fold(entries)
     flush_wgrads()
     ready, _BE["ready"] = _BE["ready"], []
-    _BE["armed"] = False
     cb = _HOOKS["grad_ready"]
     if cb is not None:
         for p in ready:
             cb(p)
+
+
+def _on_backward_end():
+    _flush_deferred()
+    for k in _LNQ["off"]:
+        _LNQ["off"][k] = 0
+    _BE["armed"] = False
+
+
+class GradStageFn(torch.autograd.Function):
+    """Identity in forward.  In backward it closes a STAGE: the weight gradients queued by everything behind this point
+    (decoder, upper encoder layers, ...) run now instead of at the end of the pass, so that their parameters are final
+    while the rest of backward is still ahead — which is what lets the data-parallel wrapper start reducing those buckets
+    beside the remaining backward kernels (the reference reduces after backward: legacy_distributed_data_parallel.py:76-160).
+    Only active when a grad-ready hook is installed (a data-parallel step): a single-GPU step keeps one grouped launch."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if _HOOKS["grad_ready"] is not None and _BE["armed"]:
+            _flush_deferred()
+        return dy
+
+
+def grad_stage(x):
+    return GradStageFn.apply(x) if (torch.is_grad_enabled() and x.requires_grad) else x
 
 
 # Deferred, grouped weight gradients (csrc/gemm_grouped.hip): nothing consumes a weight gradient before the optimizer,
@@ -255,14 +283,17 @@ _WGQ = {"probs": [], "mode": os.environ.get("S2T_WGRAD_GROUPED", "graph"),
         "bufs": {}, "captured": []}
 
 
-def reserve_wgrad_staging(device, nbytes=8 << 20):
-    """Allocate a pinned/device staging pair ahead of a graph capture (nothing may be allocated from the host
-    allocator while a stream is capturing)."""
+def reserve_wgrad_staging(device, nbytes=8 << 20, count=1):
+    """Allocate ``count`` pinned/device staging pairs ahead of a graph capture (nothing may be allocated from the host
+    allocator while a stream is capturing; every flush of a captured step dedicates one pair to the graph)."""
     key = str(torch.device(device) if not isinstance(device, torch.device) else device)
     ring = _WGQ["bufs"].setdefault(key, {"slots": [], "i": 0})
-    if not any(sl[0].numel() >= nbytes for sl in ring["slots"]):
+    have = sum(1 for sl in ring["slots"] if sl[0].numel() >= nbytes)
+    for _ in range(max(0, count - have)):
         ring["slots"].append([torch.empty(nbytes, dtype=torch.uint8).pin_memory(),
                               torch.empty(nbytes, dtype=torch.uint8, device=device), None])
+
+
 _WG_KSTEPS = int(os.environ.get("S2T_WG_KSTEPS", "64"))  # K-steps (of 64 rows) per work item
 _WG_DTYPE = None
 

@@ -13,7 +13,11 @@ What is different (MI355X-first):
     gradient is final (functional._ready); when the last parameter of a bucket has reported, its all-reduce is
     launched on a side HIP stream behind an event.  xGMI is point-to-point (7 links per GPU): a few large buckets
     (default 32 MiB) keep every link streaming instead of many latency-bound small rings;
-  * BatchNorm buffers are NOT synchronised, like the reference (":29-31 does not broadcast buffers").
+  * BatchNorm buffers are NOT synchronised, like the reference (":29-31 does not broadcast buffers");
+  * on the GPU the collective is the library's own RCCL communicator (s2t_amd/comm.py -> s2t_allreduce_bucket): a plain
+    stream-ordered launch with no watchdog thread, so the whole update — backward, the bucketed all-reduce on its side
+    stream, clip and Adam — is ONE captured hipGraph.  ``torch.distributed`` collectives remain for CPU tensors (the
+    gloo tests) and when no communicator was created.
 """
 from contextlib import contextmanager
 from typing import Dict, List
@@ -22,6 +26,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import comm as Comm
 from . import functional as Fn
 
 
@@ -34,6 +39,8 @@ class LegacyDistributedDataParallel(nn.Module):
         self.module = module
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if Comm.initialized():
+            self.world_size = Comm.world_size()
         self._idle = self.world_size == 1 and not single_rank_collectives
         self.accumulate_grads = False
         self.overlap = overlap
@@ -129,9 +136,11 @@ class LegacyDistributedDataParallel(nn.Module):
             self._reduce(view)
 
     def _reduce(self, view):
-        if view.is_cuda:
+        if view.is_cuda and Comm.initialized():
+            Comm.all_reduce_(view, average=True)
+        elif view.is_cuda and dist.get_backend(self.process_group) == "nccl":
             dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.process_group)
-        else:  # gloo (CPU tests): no AVG
+        else:  # gloo (CPU tests, multi-rank rehearsals on one GPU): no AVG
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.process_group)
             view.div_(self.world_size)
 

@@ -186,8 +186,11 @@ class S2TTransformerEncoder(nn.Module):
         n = len(self.layers)
         inter_ctc_logits = []
         ctc_orc = ctc_force_emit = None
+        stage_at = {n // 3, (2 * n) // 3} if n >= 6 else set()  # gradient stages (Fn.grad_stage): a third of the stack each
         for i, layer in enumerate(self.layers):
             tap = (i + 1) in self.inter_ctc_layers  # the head reads the layer output BEFORE the next layer's mask
+            if i in stage_at:
+                x = Fn.grad_stage(x)
             x = layer(x, c, mask_output=self.layer_padding_mask and i + 1 < n and not tap)
             if tap:
                 L = i + 1
@@ -220,6 +223,7 @@ class S2TTransformerEncoder(nn.Module):
                     x = MaskRows.apply(x, lens32, Tp)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
+        x = Fn.grad_stage(x)  # everything behind the encoder output (decoder, CTC head) forms the first gradient stage
         ctc_logit = None
         if self.use_ctc:
             logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype)

@@ -28,11 +28,13 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.flat.master)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)  # lr, step_size, grad_scale, grad_norm
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-        # pinned staging rows for (lr, step_size): the CPU runs ahead of the stream, so a row is only rewritten 16 updates
-        # later (a launch queue never holds that many steps)
+        # pinned staging rows for (lr, step_size): the CPU runs ahead of the stream and the copy reads the row when it
+        # EXECUTES, so a row may only be rewritten once its copy has run: one event per row, waited for on wrap-around
         self._hyper_host = torch.zeros(16, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(16, 2)
+        self._hyper_ev = [None] * 16
         self.num_updates = 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        from . import comm as Comm
+        self.world = Comm.world_size() if Comm.initialized() else (dist.get_world_size() if dist.is_initialized() else 1)
         self._graph = None
         self._static = None
 
@@ -44,13 +46,24 @@ class Trainer:
         return self.lr * math.sqrt(self.warmup_updates) / math.sqrt(max(n, 1))
 
     def _push_hyper(self):
+        """Hyper-parameters of the update that brings the count to ``num_updates + 1``.  The reference sets the learning
+        rate AFTER each update (trainer.py:802 -> lr_step_update -> inverse_square_root_schedule.py:69-85), so update t
+        runs with lr(t - 1) and the very first one with warmup_init_lr; Adam's bias correction uses t (optim/adam.py:199-204)."""
         t = self.num_updates + 1
-        lr = self.lr_at(t)
+        lr = self.lr_at(self.num_updates)
         b1, b2 = self.betas
-        row = self._hyper_host[t % 16]
+        slot = t % 16
+        ev = self._hyper_ev[slot]
+        if ev is not None:
+            ev.synchronize()  # the copy that read this row 16 updates ago has executed
+        row = self._hyper_host[slot]
         row[0] = lr
         row[1] = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
         self.hyper[:2].copy_(row, non_blocking=True)
+        if self.hyper.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_ev[slot] = ev
 
     # ---- one update ----------------------------------------------------------------------------------
     def _fwd_bwd(self, sample, overlap=True):
@@ -89,7 +102,7 @@ class Trainer:
         loss, log = self._step_body(sample, sample_size_global)
         self.num_updates += 1
         log["gnorm"] = self.hyper[3]
-        log["lr"] = self.lr_at(self.num_updates)
+        log["lr"] = self.lr_at(self.num_updates - 1)  # the rate this update ran with
         return loss, log
 
     # ---- graph-captured step (fixed shapes) -------------------------------------------------------------
@@ -108,12 +121,15 @@ class Trainer:
                 self.num_updates += 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        Fn.reserve_wgrad_staging(self.flat.master.device)  # the grouped weight-gradient tables of the captured step
+        # the grouped weight-gradient tables of the captured step: one pinned/device block per flush (a data-parallel step
+        # flushes once per gradient stage)
+        Fn.reserve_wgrad_staging(self.flat.master.device, count=8 if self.ddp is not None else 1)
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         self._push_hyper()
-        if self.ddp is not None and self.ddp.active:
-            # RCCL collectives stay OUTSIDE the capture (the process-group watchdog thread polls events, which a
+        from . import comm as Comm
+        if self.ddp is not None and self.ddp.active and not Comm.initialized():
+            # torch.distributed's RCCL collectives stay OUTSIDE the capture (the process-group watchdog thread polls events, which a
             # capturing stream forbids): graph 1 = forward + backward, eager bucketed all-reduce, graph 2 = clip + Adam.
             # The reduction is then not overlapped with backward (it is in the eager path).
             # capture_error_mode="thread_local": the watchdog thread may still be querying the events of the eager
@@ -127,6 +143,8 @@ class Trainer:
             with torch.cuda.graph(self._graph2, pool=self._graph.pool(), capture_error_mode="thread_local"):
                 self._update(sample_size_global)
         else:
+            # single GPU, or the library's own communicator: the whole update — backward, the bucketed all-reduce on its
+            # side stream (forked and joined inside the capture), clip and Adam — is ONE graph
             with torch.cuda.graph(self._graph):
                 self._graph_out = self._step_body(sample, sample_size_global)
 
