@@ -601,6 +601,65 @@ def module_cases(outdir):
     print("modules ok")
 
 
+def trainer_case(name, outdir, arch, V, B, T, seed, updates=5, **kw):
+    """Row a22 pinned to the reference: ``updates`` optimizer updates of a small model with the reference's own classes in
+    the order of Trainer.train_step (fairseq/trainer.py:611-759): zero_grad -> criterion forward/backward -> [all-reduce:
+    one rank, LegacyDDP's pre-division by 1] -> multiply_grads(world / sample_size) (:729-734) -> clip_grad_norm
+    (fairseq/utils.py:328-369 through optim/fairseq_optimizer.py:109-111) -> FairseqAdam.step (optim/adam.py:146-226) ->
+    lr_scheduler.step_update(num_updates) (optim/lr_scheduler/inverse_square_root_schedule.py:79-85, from trainer.py:802).
+    Recipe hyper-parameters (egs/mustc/asr/conf/base.yaml:4-9) with a short warm-up so that the schedule moves."""
+    from fairseq.optim.adam import FairseqAdam
+    from fairseq.optim.lr_scheduler.inverse_square_root_schedule import InverseSquareRootSchedule
+
+    torch.manual_seed(seed)
+    model, args, task = build(arch, V, **kw)
+    seed_weights(model, seed + 100)
+    src, lens, prev, target, ntokens = make_batch(B, T, V, seed + 200)
+    out = {}
+    out.update(sd_np(model))
+    out["in::src_tokens"], out["in::src_lengths"] = np_(src), np_(lens)
+    out["in::prev_output_tokens"], out["in::target"], out["in::ntokens"] = np_(prev), np_(target), np.int64(ntokens)
+    hp = dict(lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, clip_norm=10.0, warmup_updates=3, warmup_init_lr=1e-7)
+    ocfg = Namespace(lr=[hp["lr"]], adam_betas=str(hp["betas"]), adam_eps=hp["eps"], weight_decay=hp["weight_decay"],
+                     use_old_adam=True, tpu=False)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = FairseqAdam(ocfg, params)
+    scfg = Namespace(lr=[hp["lr"]], warmup_updates=hp["warmup_updates"], warmup_init_lr=hp["warmup_init_lr"])
+    sched = InverseSquareRootSchedule(scfg, opt)
+    sched.step_update(0)  # trainer.py:_build_optimizer -> lr_step_update(0)
+    crit = criterion_for(task, args)
+    model.train()
+    crit.train()
+    sample = {"id": torch.arange(B), "net_input": {"src_tokens": src, "src_lengths": lens, "prev_output_tokens": prev},
+              "target": target, "ntokens": ntokens}
+    losses, gnorms, lrs = [], [], []
+    for n in range(updates):
+        opt.zero_grad()
+        loss, sample_size, log = crit(model, sample)
+        opt.backward(loss)
+        opt.multiply_grads(1.0 / float(sample_size))  # one rank: world / sample_size
+        gnorm = opt.clip_grad_norm(hp["clip_norm"])
+        lrs.append(opt.get_lr())  # the rate this update runs with
+        opt.step()
+        sched.step_update(n + 1)
+        losses.append(float(loss.item()))
+        gnorms.append(float(gnorm))
+    out["out::loss"], out["out::gnorm"], out["out::lr"] = np.array(losses), np.array(gnorms), np.array(lrs)
+    for k, v in model.state_dict().items():
+        out["after::" + k] = v.detach().cpu().numpy().copy()
+    for k, v in hp.items():
+        out["hp::" + k] = np.array(v, dtype=np.float64)
+    for k, v in sorted(vars(args).items()):
+        if isinstance(v, bool):
+            out["cfg::" + k] = np.bool_(v)
+        elif isinstance(v, (int, float)):
+            out["cfg::" + k] = np.float64(v)
+        elif isinstance(v, str):
+            out["cfg::" + k] = np.array(v)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    print(name, "losses", losses, "gnorm", gnorms, "lr", lrs)
+
+
 def main():
     outdir = sys.argv[1]
     os.makedirs(outdir, exist_ok=True)
@@ -628,6 +687,10 @@ def main():
                 inter_xctc_weight=1.0, inter_xctc_layers="2,3", ctc_pae="inter_league", xctc_pae="inter_league",
                 xctc_cross_attn=True, cross_attn_start_layer=3, cross_attn_layer=2, cross_attn_collaboration_mode="serial",
                 cross_attn_league_drop_net=True, xctc_pae_ground_truth_only_mistake=True, pae_oracle_smooth=True)
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "trainer"):
+        trainer_case("trainer_conformer_small", outdir, "s2t_transformer_s", V=40, B=3, T=50, seed=2, **small, **conf)
+    if os.environ.get("GOLDEN_ONLY", "") == "trainer":
+        return
     if os.environ.get("GOLDEN_ONLY", "") in ("", "dataset"):
         dataset_case(outdir)
     if os.environ.get("GOLDEN_ONLY", "") == "dataset":

@@ -1183,6 +1183,80 @@ def best_alignment(log_probs, targets, input_lengths, blank=0):
 # ----------------------------------------------------------------------------------------------
 # helpers for tests / bench
 # ----------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------
+# Row a22: the update after backward (one rank) — scale, clip, Adam, inverse-sqrt schedule
+# ----------------------------------------------------------------------------------------------
+def inverse_sqrt_lr(num_updates, lr, warmup_updates, warmup_init_lr):
+    """optim/lr_scheduler/inverse_square_root_schedule.py:59-85: the rate SET by step_update(num_updates), i.e. the one
+    the NEXT update runs with (trainer.py:802 calls it after the optimizer step; _build_optimizer calls it with 0)."""
+    if num_updates < warmup_updates:
+        return warmup_init_lr + num_updates * (lr - warmup_init_lr) / warmup_updates
+    return lr * warmup_updates ** 0.5 * num_updates ** -0.5
+
+
+def clip_coef(grads, max_norm):
+    """utils.clip_grad_norm_ (utils.py:328-369): total = || per-tensor fp32 norms ||_2, coef = min(1, max / (total + 1e-6))."""
+    total = torch.norm(torch.stack([torch.norm(g.detach().float()) for g in grads]))
+    return total, float((max_norm / (total + 1e-6)).clamp(max=1.0))
+
+
+def adam_update(p, g, m, v, t, lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0):
+    """optim/adam.py:146-226 (fairseq's Adam, AdamW-style decay): in-place update number t >= 1 of one tensor."""
+    b1, b2 = betas
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = v.sqrt().add_(eps)
+    step = lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+    if weight_decay != 0:
+        p.add_(p, alpha=-weight_decay * lr)
+    p.addcdiv_(m, denom, value=-step)
+
+
+def train_trajectory(W, cfg, src_tokens, src_lengths, prev_output_tokens, target, sample_size, updates, lr, betas, eps,
+                     weight_decay, clip_norm, warmup_updates, warmup_init_lr):
+    """``updates`` updates in the order of Trainer.train_step (trainer.py:611-759) on one rank: backward of the joint loss,
+    grads * (1 / sample_size) (:729-734), clip (:737), Adam with the rate step_update set after the previous update.
+    BatchNorm running statistics follow nn.BatchNorm1d (momentum 0.1, unbiased variance).  Returns per-update loss, norm, lr."""
+    params = {k: t for k, t in W.items() if t.is_floating_point() and t.requires_grad}
+    # tied weights (share_decoder_input_output_embed: transformer.py:918-933, share_ctc_and_embed: s2t_transformer.py:965-971)
+    # are ONE parameter in the reference: one summed gradient, one Adam state.  The state dict lists them under every name.
+    alias = {}
+    tie = [k for k in ("decoder.embed_tokens.weight", "decoder.output_projection.weight", "encoder.ctc.ctc_projection.weight")
+           if k in params]
+    for k in tie[1:]:
+        if params[k].shape == params[tie[0]].shape and torch.equal(params[k], params[tie[0]]):
+            alias[k] = tie[0]
+    m = {k: torch.zeros_like(t) for k, t in params.items() if k not in alias}
+    v = {k: torch.zeros_like(t) for k, t in params.items() if k not in alias}
+    losses, gnorms, lrs = [], [], []
+    for n in range(updates):
+        for t in params.values():
+            t.grad = None
+        bn = {}
+        loss, _ = joint_loss(W, cfg, src_tokens, src_lengths, prev_output_tokens, target, eps=0.1, training=True,
+                             use_torch_ctc=True, bn_stats=bn)
+        loss.backward()
+        with torch.no_grad():
+            grads = {}
+            for k, t in params.items():
+                if t.grad is not None:
+                    root = alias.get(k, k)
+                    grads[root] = grads.get(root, 0) + t.grad / float(sample_size)
+            total, coef = clip_coef(list(grads.values()), clip_norm)
+            cur = inverse_sqrt_lr(n, lr, warmup_updates, warmup_init_lr)
+            for k, g in grads.items():
+                adam_update(params[k], g * coef, m[k], v[k], n + 1, cur, betas, eps, weight_decay)
+            for k, root in alias.items():
+                params[k].copy_(params[root])
+            for name, (mean, var, cnt) in bn.items():
+                W[name + ".running_mean"].mul_(0.9).add_(0.1 * mean)
+                W[name + ".running_var"].mul_(0.9).add_(0.1 * var * cnt / (cnt - 1))
+        losses.append(float(loss))
+        gnorms.append(float(total))
+        lrs.append(cur)
+    return losses, gnorms, lrs
+
+
 def cfg_from_golden(z) -> dict:
     cfg = {}
     for k in z.files:

@@ -288,3 +288,29 @@ def test_nast_ctc_criterion_loss_and_grads(golden_dir, name):
         assert np.abs(g.numpy() - ref).max() / scale < 2e-3, key
         n += 1
     assert n > 60
+
+
+def test_oracle_trainer_trajectory(golden_dir):
+    """Row a22: the oracle's restatement of scale -> clip -> Adam -> inverse-sqrt schedule (trainer.py:714-759,
+    utils.py:328-369, optim/adam.py:146-226, inverse_square_root_schedule.py:59-85) against five updates run by the
+    reference's own FairseqAdam / clip_grad_norm / InverseSquareRootSchedule (oracle/gen_golden.py: trainer_case)."""
+    z = np.load(os.path.join(golden_dir, "trainer_conformer_small.npz"))
+    cfg = O.cfg_from_golden(z)
+    W = O.weights_from_golden(z, requires_grad=True)
+    hp = {k[4:]: z[k] for k in z.files if k.startswith("hp::")}
+    src, lens = torch.from_numpy(z["in::src_tokens"]), torch.from_numpy(z["in::src_lengths"])
+    prev, target = torch.from_numpy(z["in::prev_output_tokens"]), torch.from_numpy(z["in::target"])
+    n = len(z["out::loss"])
+    losses, gnorms, lrs = O.train_trajectory(
+        W, cfg, src, lens, prev, target, int(z["in::ntokens"]), n, float(hp["lr"]), tuple(float(b) for b in hp["betas"]),
+        float(hp["eps"]), float(hp["weight_decay"]), float(hp["clip_norm"]), int(hp["warmup_updates"]),
+        float(hp["warmup_init_lr"]))
+    np.testing.assert_allclose(lrs, z["out::lr"], rtol=1e-12)
+    np.testing.assert_allclose(losses, z["out::loss"], rtol=2e-4)
+    np.testing.assert_allclose(gnorms, z["out::gnorm"], rtol=2e-3)
+    for k in z.files:
+        # the key bias gradient is mathematically zero (softmax is shift invariant): what reaches Adam is rounding noise,
+        # which Adam normalises to steps of +-lr — neither implementation's value means anything
+        if k.startswith("after::") and z[k].dtype.kind == "f" and not k.endswith(("linear_k.bias", "k_proj.bias")):
+            got = W[k[7:]].detach().numpy()
+            assert np.abs(got - z[k]).max() <= 2e-3 * max(np.abs(z[k]).max(), 1e-3), k

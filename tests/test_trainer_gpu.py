@@ -93,3 +93,52 @@ def test_graph_and_ddp_graph_follow_the_eager_trajectory():
     assert (pe - pg).abs().max() <= 1e-3 * pe.abs().max()
     assert (pe - pd).abs().max() <= 1e-3 * pe.abs().max()
     assert (pe - px).abs().max() <= 1e-3 * pe.abs().max()
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_trainer_follows_the_reference_trajectory(golden_dir, mode):
+    """Row a22 against the reference itself: five updates of the fixture model in fp32 with s2t_amd.trainer.Trainer
+    (flat-buffer scale / clip / Adam kernels, inverse-sqrt schedule) vs the trajectory the reference's FairseqAdam,
+    clip_grad_norm_ and InverseSquareRootSchedule produced in Trainer.train_step's order (oracle/gen_golden.py:
+    trainer_case; fairseq/trainer.py:714-759, optim/adam.py:146-226, utils.py:328-369)."""
+    import os
+
+    import numpy as np
+
+    from test_model_parity_gpu import build  # the fixture -> HIP model loader of the parity tests (same directory)
+
+    z = np.load(os.path.join(golden_dir, "trainer_conformer_small.npz"))
+    model, cfg = build(z, torch.float32)
+    hp = {k[4:]: z[k] for k in z.files if k.startswith("hp::")}
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(40), label_smoothing=0.1, ctc_weight=float(cfg["ctc_weight"]))
+    tr = Trainer(model, crit, lr=float(hp["lr"]), betas=tuple(float(b) for b in hp["betas"]), eps=float(hp["eps"]),
+                 weight_decay=float(hp["weight_decay"]), clip_norm=float(hp["clip_norm"]),
+                 warmup_updates=int(hp["warmup_updates"]), warmup_init_lr=float(hp["warmup_init_lr"]))
+    sample = {"net_input": {"src_tokens": torch.from_numpy(z["in::src_tokens"]).to(DEV),
+                            "src_lengths": torch.from_numpy(z["in::src_lengths"]).to(DEV),
+                            "prev_output_tokens": torch.from_numpy(z["in::prev_output_tokens"]).to(DEV)},
+              "target": torch.from_numpy(z["in::target"]).to(DEV), "ntokens": int(z["in::ntokens"])}
+    n = len(z["out::loss"])
+    losses, gnorms, lrs = [], [], []
+    if mode == "eager":
+        for _ in range(n):
+            loss, log = tr.train_step(sample)
+            losses.append(float(loss))
+            gnorms.append(float(log["gnorm"]))
+            lrs.append(float(log["lr"]))
+    else:
+        tr.capture(sample, warmup=0)
+        for _ in range(n):
+            losses.append(float(tr.replay()[0]))
+            gnorms.append(float(tr.hyper[3]))
+            lrs.append(float(tr.hyper[0]))
+    np.testing.assert_allclose(lrs, z["out::lr"], rtol=1e-6)
+    np.testing.assert_allclose(losses, z["out::loss"], rtol=1e-3)
+    np.testing.assert_allclose(gnorms, z["out::gnorm"], rtol=5e-3)
+    sd = model.state_dict()
+    for k in z.files:
+        if k.startswith("after::") and z[k].dtype.kind == "f" and not k.endswith(("linear_k.bias", "k_proj.bias")):
+            if k[7:] not in sd or "_float_tensor" in k:
+                continue
+            got = sd[k[7:]].detach().float().cpu().numpy()
+            assert np.abs(got - z[k]).max() <= 5e-3 * max(np.abs(z[k]).max(), 1e-3), k
