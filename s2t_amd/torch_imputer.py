@@ -45,8 +45,12 @@ class _ImputerLoss(torch.autograd.Function):
         lp, lse0, alpha, beta, nll, tm, tl, il = ctx.saved_tensors
         B, T, V, L, blank, zero_infinity = ctx.dims
         grad = torch.empty_like(lp)
+        # The reference's kernel returns (exp(lp) - exp(log_alpha_beta + nll - lp)) * grad_out on valid frames, 0 beyond
+        # (imputer.cu:626-633) — ATen's CTC convention, i.e. the gradient w.r.t. the LOGITS under a log_softmax, not the
+        # plain derivative w.r.t. log_prob (-occupancy).  With lse = 0 the logits-gradient form of s2t_ctc_loss_bwd is
+        # exactly that expression.  (Through a log_softmax the two conventions give the same gradient.)
         K.ctc_loss_bwd(lp, V, B, T, V, lse0, tm, tm.shape[1], tl, il, blank, alpha, beta, L, nll, 1.0, grad, V,
-                       wrt_logprobs=True)
+                       wrt_logprobs=False)
         grad = grad.view(B, T, V) * g.view(B, 1, 1).to(grad.dtype)
         return grad.transpose(0, 1), None, None, None, None, None, None
 

@@ -39,7 +39,9 @@ def ref_attention(q, k, v, klen, causal, scale, p=None, u=None, vb=None):
 
 
 @pytest.mark.parametrize("Tq,Tk,causal,rel", [(250, 250, False, False), (61, 61, True, False), (61, 250, False, False),
-                                              (250, 250, False, True), (100, 100, False, True), (17, 17, False, True)])
+                                              (250, 250, False, True), (100, 100, False, True), (17, 17, False, True),
+                                              # BASELINE config 3 (PDS Conformer, 64 x 2000): stage lengths 1004 / 502 / 251
+                                              (1004, 1004, False, True), (502, 502, False, True), (251, 251, False, True)])
 def test_fused_forward(Tq, Tk, causal, rel):
     g = torch.Generator().manual_seed(Tq * 7 + Tk + rel)
     B, H, dk = 3, 4, 64
@@ -99,7 +101,9 @@ def _dropout_mask(Z, Tq, Tk, drop):
 @pytest.mark.parametrize("Tq,Tk,causal,rel,pdrop", [(250, 250, False, False, 0.0), (61, 61, True, False, 0.0),
                                                     (61, 250, False, False, 0.0), (130, 130, False, False, 0.1),
                                                     (250, 250, False, True, 0.0), (100, 100, False, True, 0.1),
-                                                    (17, 17, False, True, 0.0)])
+                                                    (17, 17, False, True, 0.0),
+                                                    (1004, 1004, False, True, 0.0), (502, 502, False, True, 0.0),
+                                                    (251, 251, False, True, 0.0)])
 def test_fused_backward(Tq, Tk, causal, rel, pdrop):
     g = torch.Generator().manual_seed(Tq * 11 + Tk + rel)
     B, H, dk = 3, 4, 64

@@ -1,0 +1,223 @@
+"""The literal BASELINE.json configurations at sizes the CPU oracle still finishes in seconds, HIP path
+against the oracle on the same seeded weights and inputs:
+
+  config 1   s2t_transformer_s 6 enc / 6 dec, d = 256, V = 10000, 32 x 400 x 80, fp32: logits within 1e-3 relative,
+             CTC-greedy token ids equal (models/speech_to_text/s2t_ctc.py:236-349)
+  config 5a  12-layer Conformer + CTC head, 8 x 1000 x 80 (the 256-utterance batch is 32 of these), fp32
+  config 3   PDS Conformer (4 stages, ratios 2-2-1-2, d = 256) at 4 x 2000 x 80: stage lengths 1004 / 502 / 502 / 251
+             (models/speech_to_text/pdss2t_transformer.py:1042-1281), fp32
+  config 2'  d = 256 / 64-wide heads in bf16 (fused attention, fused FFN blocks, ln256 kernels, V = 10000 loss kernels)
+             against the oracle run on the bf16-ROUNDED weights: forward and gradient error bounds at twice the measured error
+
+An argmax over 10 000 fp32 logits can legitimately differ between two correct fp32 implementations where the top two
+logits tie to rounding: a differing frame is accepted only when the oracle's own top-2 gap there is below 1e-4 of the
+logit scale, and at most two such frames per batch.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import s2t_oracle as O  # noqa: E402
+from s2t_amd import criterions as C  # noqa: E402
+from s2t_amd import pdss2t_transformer as PDS  # noqa: E402
+from s2t_amd import s2t_transformer as M  # noqa: E402
+
+DEV = "cuda"
+V = 10000
+CONF = dict(macaron_style=True, use_cnn_module=True, cnn_module_kernel=15, encoder_attention_type="rel_pos",
+            encoder_activation_fn="swish", layer_padding_mask=True)
+
+
+def _batch(B, T, seed, U=None):
+    g = torch.Generator().manual_seed(seed)
+    lens = sorted([T] + [int(torch.randint(int(0.6 * T), T + 1, (1,), generator=g)) for _ in range(B - 1)], reverse=True)
+    src = torch.randn(B, T, 80, generator=g)
+    for b, l in enumerate(lens):
+        src[b, l:] = 0
+    return src, torch.tensor(lens), g
+
+
+def _perturb(model, seed):
+    """Nothing left at a trivial initial value: LayerNorm / BatchNorm gains, biases and running statistics."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+        for n_, b in model.named_buffers():
+            if n_.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            if n_.endswith("running_var"):
+                b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g))
+
+
+def _rel(got, ref):
+    got = got.detach().float().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+
+
+def _greedy_equal_up_to_ties(model_enc, src, lens, logit_o, mask_o):
+    hy, _ = O.ctc_greedy(logit_o, mask_o)
+    dec = M.CTCDecoder([model_enc], None, None)
+
+    class _Enc(torch.nn.Module):
+        def __init__(self, e):
+            super().__init__()
+            self.e = e
+
+        def forward(self, src_tokens, src_lengths):
+            return self.e(src_tokens, src_lengths)
+
+    dec.model = _Enc(model_enc)
+    hyps = dec.generate(None, {"net_input": {"src_tokens": src.to(DEV), "src_lengths": lens.to(DEV)}})
+    got = [h[0]["tokens"].tolist() for h in hyps]
+    ref = [h.tolist() for h in hy]
+    bad = [b for b in range(len(ref)) if got[b] != ref[b]]
+    if bad:
+        top2 = logit_o.float().topk(2, dim=-1).values  # (T', B, 2)
+        gap = (top2[..., 0] - top2[..., 1]) / logit_o.float().abs().amax(-1).clamp_min(1e-6)
+        assert len(bad) <= 2, "CTC-greedy ids differ in %d utterances" % len(bad)
+        for b in bad:
+            assert float(gap[:, b].min()) < 1e-4, "utterance %d differs without a top-2 tie (min gap %.3g)" % (b, float(gap[:, b].min()))
+    return len(bad)
+
+
+def test_config1_transformer_6_6_fp32_logits_and_greedy_ids():
+    torch.manual_seed(21)
+    args = M.recipe_args(conformer=False, vocab_size=V, encoder_layers=6, decoder_layers=6)
+    model = M.S2TTransformerModel.build_model(args, M.FakeTask(V))
+    _perturb(model, 22)
+    W = {k: v.detach().clone().float() for k, v in model.state_dict().items()}
+    cfg = {k: getattr(args, k) for k in vars(args)}
+    model.prepare(torch.float32, DEV)
+    model.eval()
+    src, lens, g = _batch(32, 400, 23)
+    prev = torch.randint(4, V, (32, 12), generator=g)
+    prev[:, 0] = 2
+    with torch.no_grad():
+        enc = model.encoder(src.to(DEV), lens.to(DEV))
+        logits, _ = model.decoder(prev.to(DEV), encoder_out=enc)
+        enc_o = O.encoder_forward(src, lens, W, cfg, training=False)
+        logits_o = O.decoder_forward(prev, enc_o, W, cfg)
+    assert _rel(enc["encoder_out"][0], enc_o["encoder_out"][0]) < 1e-3
+    assert _rel(enc["ctc_logit"][0], enc_o["ctc_logit"][0]) < 1e-3
+    assert _rel(logits, logits_o) < 1e-3
+    model.encoder.ctc_out_dtype = torch.float32
+    _greedy_equal_up_to_ties(model.encoder, src, lens, enc_o["ctc_logit"][0], enc_o["encoder_padding_mask"][0])
+
+
+def test_config5a_conformer12_ctc_fp32_8x1000():
+    torch.manual_seed(31)
+    args = M.recipe_args(conformer=True, vocab_size=V, ctc_weight=1.0)
+    model = M.S2TCTCModel.build_model(args, M.FakeTask(V))
+    _perturb(model, 32)
+    W = {k: v.detach().clone().float() for k, v in model.state_dict().items()}
+    cfg = {k: getattr(args, k) for k in vars(args)}
+    model.prepare(torch.float32, DEV)
+    model.eval()
+    src, lens, g = _batch(8, 1000, 33)
+    with torch.no_grad():
+        enc = model.encoder(src.to(DEV), lens.to(DEV))
+        enc_o = O.encoder_forward(src, lens, W, cfg, training=False)
+    assert _rel(enc["encoder_out"][0], enc_o["encoder_out"][0]) < 1e-3
+    assert _rel(enc["ctc_logit"][0], enc_o["ctc_logit"][0]) < 1e-3
+    model.encoder.ctc_out_dtype = torch.float32
+    _greedy_equal_up_to_ties(model.encoder, src, lens, enc_o["ctc_logit"][0], enc_o["encoder_padding_mask"][0])
+
+
+def _pds_args(**kw):
+    return M.recipe_args(conformer=True, vocab_size=V, arch="pdss2t_transformer_s_8", pds_stages=4, pds_layers="3_3_3_3",
+                         pds_ratios="2_2_1_2", pds_fusion=False, pds_embed_dims="256_256_256_256", pds_ds_method="conv",
+                         pds_embed_norm=True, pds_position_embed="1_1_1_1", pds_kernel_sizes="5_5_5_5",
+                         pds_ffn_ratios="8_8_8_8", pds_attn_heads="4_4_4_4", **kw)
+
+
+def test_config3_pds_conformer_fp32_4x2000():
+    """The recipe's 4-stage PDS Conformer at the configuration's 2000-frame length (3 layers per stage, d = 256): the
+    relative-position attention runs at T' = 1004 and 502 — through the GEMM-composed fp32 path here, through the fused
+    bf16 kernels in test_attn_fused_gpu.py at the same lengths."""
+    torch.manual_seed(41)
+    args = _pds_args()
+    model = PDS.PDSS2TTransformerModel.build_model(args, M.FakeTask(V))
+    _perturb(model, 42)
+    W = {k: v.detach().clone().float() for k, v in model.state_dict().items()}
+    cfg = {k: getattr(args, k) for k in vars(args)}
+    model.prepare(torch.float32, DEV)
+    model.eval()
+    src, lens, g = _batch(4, 2000, 43)
+    prev = torch.randint(4, V, (4, 9), generator=g)
+    prev[:, 0] = 2
+    with torch.no_grad():
+        enc = model.encoder(src.to(DEV), lens.to(DEV))
+        logits, _ = model.decoder(prev.to(DEV), encoder_out=enc)
+        enc_o = O.pds_encoder_forward(src, lens, W, cfg, training=False)
+        logits_o = O.decoder_forward(prev, enc_o, W, cfg)
+    assert enc["encoder_out"][0].shape[0] == 251
+    assert _rel(enc["encoder_out"][0], enc_o["encoder_out"][0]) < 1e-3
+    assert _rel(enc["ctc_logit"][0], enc_o["ctc_logit"][0]) < 1e-3
+    assert _rel(logits, logits_o) < 1e-3
+
+
+def test_config2p_bf16_d256_against_oracle_on_rounded_weights():
+    """The kernels of the headline step (fused rel-pos attention with 64-wide heads, fused FFN row blocks, 256-wide
+    LayerNorm kernels, the grouped weight gradients of bench-shaped K, the V = 10000 loss kernels) inside a 4-layer d = 256
+    Conformer at 16 x 1000 (16 x 250 = 4000 rows >= the fused-FFN threshold set below), in bf16, against the fp32 oracle
+    evaluated on the SAME bf16-rounded weights and inputs: what is left is activation rounding only."""
+    from s2t_amd import functional as Fn
+
+    torch.manual_seed(51)
+    args = M.recipe_args(conformer=True, vocab_size=V, encoder_layers=4, decoder_layers=2)
+    model = M.S2TTransformerModel.build_model(args, M.FakeTask(V))
+    _perturb(model, 52)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.bfloat16().float())
+    W = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = {k: getattr(args, k) for k in vars(args)}
+    model.prepare(torch.bfloat16, DEV)
+    model.train()
+    B, T = 16, 1000
+    src, lens, g = _batch(B, T, 53)
+    src = src.bfloat16().float()
+    ul = [int(torch.randint(20, 41, (1,), generator=g)) for _ in range(B)]
+    U = max(ul) + 1
+    target = torch.full((B, U), 1, dtype=torch.long)
+    prev = torch.full((B, U), 1, dtype=torch.long)
+    for b, u in enumerate(ul):
+        toks = torch.randint(4, V, (u,), generator=g)
+        target[b, :u] = toks
+        target[b, u] = 2
+        prev[b, 0] = 2
+        prev[b, 1:u + 1] = toks
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    sample = {"net_input": {"src_tokens": src.to(DEV), "src_lengths": lens.to(DEV), "prev_output_tokens": prev.to(DEV)},
+              "target": target.to(DEV), "ntokens": int(sum(ul) + B)}
+    old = Fn._FFN_FUSED_MIN_ROWS
+    Fn._FFN_FUSED_MIN_ROWS = 1024
+    try:
+        model.flat.zero_grad()
+        loss, _, log = crit(model, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        Fn._FFN_FUSED_MIN_ROWS = old
+    loss_o, aux = O.joint_loss(W, cfg, src, lens, prev, target, eps=0.1, training=True, use_torch_ctc=True)
+    loss_o.backward()
+    lo = float(loss_o.detach())
+    assert abs(float(loss.detach()) - lo) < 5e-3 * abs(lo), (float(loss.detach()), lo)
+    ptr = {k: v.data_ptr() for k, v in model.state_dict().items()}
+    errs = {}
+    for k, p in model.named_parameters():
+        if k.endswith(("k_proj.bias", "linear_k.bias")):
+            continue  # mathematically zero
+        go = sum(W[k2].grad for k2 in W if ptr[k2] == ptr[k] and W[k2].grad is not None)
+        if "subsample" in k and go.dim() == 3:
+            go = go.permute(0, 2, 1)
+        gf = p.grad.detach().float().cpu()
+        errs[k] = float((gf - go).norm() / go.norm().clamp_min(1e-6))
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("bf16 d256 gradient relative L2: worst %s %.4f, median %.4f" % (worst[0], worst[1], float(np.median(list(errs.values())))))
+    assert worst[1] < 6e-2, worst
+    assert float(np.median(list(errs.values()))) < 2.5e-2

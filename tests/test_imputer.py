@@ -66,6 +66,31 @@ def test_oracle_best_alignment_is_the_brute_force_maximum_and_forcing_it_gives_i
         assert abs(float(forced) + best_score) < 1e-5
 
 
+def test_oracle_forced_emission_loss_is_the_brute_force_path_sum():
+    """imputer.cu:57-215: the forced-emit loss is -log of the probability mass of the CTC state paths that pass through
+    every pinned state — enumerated here for T <= 6, S <= 3 (SURVEY.md §8c known-answer check 3)."""
+    for seed, (T, tg, pins) in enumerate([(5, [1, 2], {1: 1, 3: 3}), (6, [3, 3, 4], {2: 2}), (4, [2], {0: 0, 3: 2}),
+                                          (6, [1, 2, 1], {0: 1, 5: 5}), (5, [], {2: 0})]):
+        lp = _rand_lp(T, 1, 6, 40 + seed)
+        ext = O._ext_labels(tg, 0)
+        L = len(ext)
+        fe = torch.full((1, T), -1)
+        for t, s_ in pins.items():
+            fe[0, t] = s_
+        total = -math.inf
+        for seq in itertools.product(range(L), repeat=T):
+            if seq[0] > min(1, L - 1) or seq[-1] < max(L - 2, 0):
+                continue
+            ok = all(not (c < a or c > a + 2 or (c == a + 2 and (ext[c] == 0 or ext[c] == ext[a]))) for a, c in zip(seq, seq[1:]))
+            ok = ok and all(seq[t] == s_ for t, s_ in pins.items())
+            if not ok:
+                continue
+            sc = sum(float(lp[t, 0, ext[s_]]) for t, s_ in enumerate(seq))
+            total = sc if total == -math.inf else (max(total, sc) + math.log1p(math.exp(-abs(total - sc))))
+        got = float(O.imputer_nll(lp, [tg], fe, torch.tensor([T]))[0])
+        assert (math.isinf(got) and total == -math.inf) or abs(got + total) < 1e-4, (T, tg, pins, got, -total)
+
+
 def test_oracle_imputer_infeasible_is_inf():
     lp = _rand_lp(3, 1, 4, 2)
     assert math.isinf(float(O.imputer_nll(lp, [[1, 1, 2]], torch.full((1, 3), -1), torch.tensor([3]))[0]))
@@ -103,10 +128,27 @@ def test_hip_imputer_and_best_alignment_match_oracle(dtype):
     ctc = torch.nn.functional.ctc_loss(lpr, torch.cat([torch.tensor(t, dtype=torch.long) for t in tg]), il, tl, blank=0,
                                        reduction="sum", zero_infinity=True)
     ctc.backward()
-    assert abs(float(free) - float(ctc)) < 1e-3
-    # ATen's ctc_loss backward assumes log_softmax inputs and returns the logits-gradient (p - occupancy); the imputer
-    # API returns d/d log_prob = -occupancy: they differ by exp(lp) on valid frames
+    assert abs(float(free.detach()) - float(ctc.detach())) < 1e-3
+    # the reference's kernel (imputer.cu:626-633) returns ATen's convention, (exp(lp) - occupancy) * grad_out on valid
+    # frames and 0 beyond: with no forced emission it IS ATen's ctc_loss gradient
+    np.testing.assert_allclose(lpd2.grad.cpu().numpy(), lpr.grad.numpy(), rtol=1e-3, atol=1e-4)
+    # forced emissions: (exp(lp) - occupancy) with the occupancy from the oracle's plain derivative (autograd gives
+    # d nll / d lp = -occupancy)
+    lpo = lp.clone().requires_grad_(True)
+    refl = O.imputer_nll(lpo, tg, fe, il)
+    torch.where(torch.isinf(refl), torch.zeros_like(refl), refl).sum().backward()
+    loss.sum().backward()
     mask = (torch.arange(T)[:, None] < il[None, :])[:, :, None].float()
-    np.testing.assert_allclose(lpd2.grad.cpu().numpy(), (lpr.grad - lp.exp() * mask).numpy(), rtol=1e-3, atol=1e-4)
+    finite = (~torch.isinf(ref)).float()[None, :, None]
+    np.testing.assert_allclose(lpd.grad.cpu().numpy(), ((lp.exp() * mask + lpo.grad) * finite).numpy(), rtol=1e-3, atol=1e-4)
+    # ... and through a log_softmax both conventions are the same gradient w.r.t. the logits
+    x = (torch.randn(T, B, V, generator=torch.Generator().manual_seed(8)) * 1.5)
+    xd = x.cuda().requires_grad_(True)
+    imputer_loss(torch.log_softmax(xd, -1), tmat.cuda(), fe.cuda(), il.cuda(), tl.cuda(), reduction="sum",
+                 zero_infinity=True).backward()
+    xo = x.clone().requires_grad_(True)
+    ro = O.imputer_nll(torch.log_softmax(xo, -1), tg, fe, il)
+    torch.where(torch.isinf(ro), torch.zeros_like(ro), ro).sum().backward()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-3, atol=1e-4)
     got = best_alignment(lp.cuda(), tmat.cuda(), il.cuda(), tl.cuda())
     assert got == vit
