@@ -219,5 +219,6 @@ def test_config2p_bf16_d256_against_oracle_on_rounded_weights():
         errs[k] = float((gf - go).norm() / go.norm().clamp_min(1e-6))
     worst = max(errs.items(), key=lambda kv: kv[1])
     print("bf16 d256 gradient relative L2: worst %s %.4f, median %.4f" % (worst[0], worst[1], float(np.median(list(errs.values())))))
-    assert worst[1] < 6e-2, worst
-    assert float(np.median(list(errs.values()))) < 2.5e-2
+    # measured on MI355X: worst 0.055 (layer-0 depthwise-conv weight), median 0.008; bounds at twice that
+    assert worst[1] < 1.1e-1, worst
+    assert float(np.median(list(errs.values()))) < 1.7e-2

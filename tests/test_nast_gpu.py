@@ -102,4 +102,5 @@ def test_nast_ctc_criterion_loss_and_grads(golden_dir, name, dtype, tol, gtol):
         if err > worst[1]:
             worst = (key, err)
         n += 1
+    print("nast %s %s worst gradient %s %.4f" % (name, str(dtype), worst[0], worst[1]))
     assert n > 60 and worst[1] < gtol, worst
