@@ -10,7 +10,9 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from .registry import register_criterion
+from .registry import criterion_base, register_criterion
+
+_CriterionBase = criterion_base()
 
 
 # S2T_CTC_SIDE=1 issues the CTC forward (alpha/beta: long thin launches) on a side stream beside the decoder.  Measured on
@@ -27,10 +29,10 @@ def ctc_targets(target, pad_idx, eos_idx):
 
 
 @register_criterion("label_smoothed_cross_entropy_with_ctc")
-class LabelSmoothedCrossEntropyCriterionWithCTC(nn.Module):
+class LabelSmoothedCrossEntropyCriterionWithCTC(_CriterionBase):
     def __init__(self, task, label_smoothing=0.1, sentence_avg=False, cfg=None, ctc_weight=0.0, inter_ctc_weight=None,
                  **unused):
-        super().__init__()
+        super().__init__(task)
         d = task.target_dictionary
         self.padding_idx, self.eos_idx = d.pad(), d.eos()
         self.blank_idx = 0
@@ -101,7 +103,7 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(nn.Module):
 
 
 @register_criterion("ctc")
-class CtcCriterion(nn.Module):
+class CtcCriterion(_CriterionBase):
     """criterions/ctc.py:156-1101 for encoder-only models (``s2t_ctc``): ``forward`` :258-281,
     ``get_ground_truth_alignment`` :283-433, ``compute_ctc_loss`` :542-1016.
 
@@ -116,7 +118,7 @@ class CtcCriterion(nn.Module):
     Not built: AXCTC, self-distillation, entropy and mixup-consistency terms, the validation-time WER/CER counters."""
 
     def __init__(self, cfg=None, task=None, ctc_weight=1.0, save_dir=None, **over):
-        super().__init__()
+        super().__init__(task)
         d = task.target_dictionary
         self.pad_idx, self.eos_idx, self.blank_idx = d.pad(), d.eos(), 0
 

@@ -82,6 +82,19 @@ class FlatParameters:
     def zero_grad(self):
         self.grad.zero_()
 
+    def reattach_grads(self):
+        """``p.grad`` views of the flat gradient buffer for every parameter whose ``.grad`` was dropped (fairseq's optimizers
+        zero gradients by setting them to None, optim/fairseq_optimizer.py:129-133); returns True when any was missing —
+        the flat buffer is then zeroed, which is what that zero_grad meant."""
+        missing = [p for p in self.params if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[id(p)]]
+        if not missing:
+            return False
+        self.grad.zero_()
+        for p in self.params:
+            o, n = self.offsets[id(p)], p.numel()
+            p.grad = self.grad[o:o + n].view(p.shape)
+        return True
+
     def view(self, first: nn.Parameter, rows: int, cols: int, what: str = "compute") -> torch.Tensor:
         """A [rows, cols] matrix starting at ``first`` (spanning an adjacency group)."""
         o = self.offsets[id(first)]

@@ -194,6 +194,8 @@ PDSS2TTransformerEncoder.reorder_encoder_out = _Enc.reorder_encoder_out
 class PDSS2TTransformerModel(S2TTransformerModel):
     """models/speech_to_text/pdss2t_transformer.py:147-288."""
 
+    _REF_NAME = "pdss2t_transformer"
+
     @classmethod
     def build_model(cls, args, task):
         base_architecture(args)

@@ -301,6 +301,8 @@ class S2TSATEEncoder(nn.Module):
 class S2TSATEModel(S2TTransformerModel):
     """models/speech_to_text/s2t_sate.py:37-330."""
 
+    _REF_NAME = "s2t_sate"
+
     @classmethod
     def build_model(cls, args, task):
         base_architecture(args)

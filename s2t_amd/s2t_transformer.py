@@ -17,7 +17,7 @@ from . import functional as Fn
 from .flat_params import FlatParameters
 from .modules import (CTC, TABLES, Adapter, Conv1dSubsampling, Ctx, LayerNorm, Linear, MaskRows,
                       S2TTransformerEncoderLayer, TransformerDecoderLayer, pae_oracle_mask)
-from .registry import register_model, register_model_architecture
+from .registry import model_base, reference_model_class, register_model, register_model_architecture
 
 DEFAULT_MAX_SOURCE_POSITIONS = 6000
 DEFAULT_MAX_TARGET_POSITIONS = 1024
@@ -449,22 +449,63 @@ class FakeTask:
         return self.source_dictionary
 
 
-class _HipModel(nn.Module):
+class _HipModel(model_base()):
+    """Common base of the HIP models: ``BaseFairseqModel`` under fairseq (so that its registry, checkpoint utilities and
+    trainer accept the class), ``nn.Module`` otherwise.
+
+    ``prepare`` flattens the parameters (fp32 master + gradient buffer + bf16 shadow, flat_params.py).  Callers of the
+    bundled harness call it themselves; under the reference's trainer nothing does, so the usual hooks fold it in:
+    ``model.bfloat16()`` / ``.half()`` (fairseq/trainer.py:85-90) only RECORD the compute dtype — the master weights stay
+    fp32, the reference's FP16Optimizer keeps fp32 masters too (optim/fp16_optimizer.py:30-60) — and the first forward
+    through the model prepares on the device the parameters were moved to.  Before every forward the gradient views are
+    re-attached when an optimizer dropped them and the bf16 shadow is refreshed when the master weights changed."""
+
     flat: Optional[FlatParameters] = None
+    _compute_dtype = None
+    _master_version = -1
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.register_forward_pre_hook(_HipModel._before_forward)
 
     def prepare(self, dtype=torch.float32, device="cuda"):
         """Move to the GPU, flatten parameters (fp32 master + grads + bf16 shadow) and set the compute dtype."""
-        self.to(device)
+        nn.Module.to(self, device)
         self.flat = FlatParameters(self, dtype)
+        self._compute_dtype = dtype
+        self._master_version = self.flat.master._version
         for m in self.modules():
             if hasattr(m, "compute_dtype"):
                 m.compute_dtype = dtype
         return self
 
-    def load_state_dict(self, state_dict, strict=True, **kw):
+    def bfloat16(self):
+        self._compute_dtype = torch.bfloat16
+        return self
+
+    def half(self):
+        self._compute_dtype = torch.bfloat16  # the HIP path's reduced precision is bf16 (fp32 accumulate and statistics)
+        return self
+
+    @staticmethod
+    def _before_forward(self, args):
+        if self.flat is None:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("s2t_amd models run on the GPU only: move the model with .cuda() / .to(device) first")
+            self.prepare(self._compute_dtype or torch.float32, dev)
+        else:
+            self.flat.reattach_grads()
+            if self.flat.master._version != self._master_version:  # an optimizer stepped the fp32 masters in place
+                self.flat.refresh_shadow()
+                self._master_version = self.flat.master._version
+        return None
+
+    def load_state_dict(self, state_dict, strict=True, model_cfg=None, args=None, **kw):
         r = nn.Module.load_state_dict(self, state_dict, strict=strict, **kw)
         if self.flat is not None:
             self.flat.refresh_shadow()
+            self._master_version = self.flat.master._version
         return r
 
 
@@ -477,15 +518,16 @@ class S2TTransformerModel(_HipModel):
         self.encoder, self.decoder = encoder, decoder
         self.flat: Optional[FlatParameters] = None
 
-    @staticmethod
-    def add_args(parser):  # the flags live on the reference's parser; listed for --user-dir use
-        for flag, typ in (("--encoder-embed-dim", int), ("--encoder-ffn-embed-dim", int), ("--encoder-layers", int),
-                          ("--encoder-attention-heads", int), ("--decoder-layers", int), ("--ctc-weight", float),
-                          ("--cnn-module-kernel", int), ("--encoder-attention-type", str)):
-            try:
-                parser.add_argument(flag, type=typ)
-            except Exception:  # noqa: BLE001 - already defined by fairseq
-                pass
+    _REF_NAME = "s2t_transformer"
+
+    @classmethod
+    def add_args(cls, parser):
+        """The command-line flags of the recipes are the reference's (s2t_transformer.py:60-800): under fairseq they are
+        taken from the reference class registered under the same name, so every recipe flag parses; without fairseq
+        the harness builds ``args`` namespaces directly (``recipe_args``)."""
+        ref = reference_model_class(cls._REF_NAME)
+        if ref is not None:
+            ref.add_args(parser)
 
     @classmethod
     def build_model(cls, args, task):
@@ -520,6 +562,12 @@ class S2TTransformerModel(_HipModel):
 @register_model("s2t_ctc")
 class S2TCTCModel(_HipModel):
     """models/speech_to_text/s2t_ctc.py:28-171 — encoder-only CTC model (``--encoder-type transformer | sate``)."""
+
+    @classmethod
+    def add_args(cls, parser):
+        ref = reference_model_class("s2t_ctc")
+        if ref is not None:
+            ref.add_args(parser)
 
     def __init__(self, encoder):
         super().__init__()
