@@ -586,20 +586,6 @@ int launch(const s2t_gemm_args& p, hipStream_t s) {
 
 }  // namespace
 
-int s2t_gemm_ring_launch(const s2t_gemm_args& p, void* stream);  // gemm_ring.hip
-
-// The persistent LDS-DMA ring kernel (gemm_ring.hip) is opt-in (S2T_GEMM_RING=1): measured on MI355X it ties the
-// generic kernel at K = 2048 and loses at K = 256 and on 8192^3 (512 vs 810 TFLOP/s) because one 4-wave workgroup per
-// CU leaves nothing to overlap the DMA issue / epilogue with (profiles/r01_gemm_microbench.txt).
-static bool use_ring() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("S2T_GEMM_RING");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
-
 extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return S2T_ERR_ARG;
   s2t_gemm_args p = *a;
@@ -643,10 +629,6 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
     if (p.c_atomic == 2 && !p.ws) return S2T_ERR_UNSUPPORTED;  // overwrite needs the two-phase (workspace) reduction
   }
   hipStream_t s = (hipStream_t)stream;
-  if (p.dtype == S2T_BF16 && p.K % 64 == 0 && p.K > 0 && use_ring() && !p.ws) {
-    const int rc = s2t_gemm_ring_launch(p, stream);
-    if (rc != S2T_ERR_UNSUPPORTED) return rc;
-  }
   if (p.dtype == S2T_F32) return launch<float, float>(p, s);
   if (p.c_dtype == S2T_F32) return launch<bf16_t, float>(p, s);
   return launch<bf16_t, bf16_t>(p, s);

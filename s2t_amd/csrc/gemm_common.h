@@ -1,5 +1,5 @@
-// Shared device code of the two GEMM kernels (gemm.hip: generic register-staged; gemm_ring.hip: persistent
-// LDS-DMA ring for bf16 with K % 64 == 0).  LDS images, MFMA fragment maps and the epilogue are identical.
+// Shared device code of the GEMM kernels (gemm.hip: generic register-staged; gemm_grouped.hip: grouped weight
+// gradients): LDS images, MFMA fragment maps and the fused epilogue.
 #pragma once
 #include "common.h"
 

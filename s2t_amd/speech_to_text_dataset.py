@@ -15,6 +15,7 @@ Not built: flac decoding, speed perturbation, temperature-based resampling of co
 """
 import csv
 import io
+import os
 import os.path as op
 import re
 import struct
@@ -136,57 +137,81 @@ class S2TDataConfig:
     speed_perturb = property(lambda s: s._get("speed_perturb", False))
     audio_root = property(lambda s: s._get("audio_root", ""))
 
-    def get_feature_transforms(self, split, is_train):
-        """:134-180 — split-specific transform list with the ``_train`` / ``_eval`` / ``*`` wildcards and the
-        ``cmvn: utterance|global`` (+ ``cmvn_path``) override."""
+    # -- feature-transform selection (behaviour of speech_to_text_dataset.py:134-180) ------------------------------------
+    def _transform_names(self, split, is_train):
+        """The transform list of ``split``: its own entry, else the ``_train`` / ``_eval`` wildcard of its kind, else ``*``."""
+        table = self.config.get("transforms") or {}
+        for key in (split, "_train" if is_train else "_eval", "*"):
+            if table.get(key) is not None:
+                return list(table[key])
+        return []
+
+    def _global_cmvn_stats(self):
+        """Where the global CMVN statistics live: ``cmvn_path`` (absolute, or relative to the YAML's directory) wins over a
+        ``global_cmvn`` section / the top-level ``stats_npz_path`` shorthand."""
+        path = self.config.get("cmvn_path")
+        if path:
+            return path if op.exists(path) else op.join(self.yaml_dir, path)
         if self.config.get("stats_npz_path"):
-            self.config["global_cmvn"] = {"stats_npz_path": self.config["stats_npz_path"]}
-        cfg = deepcopy(self.config)
-        _cur = cfg.get("transforms", {})
-        cur = _cur.get(split)
-        cur = _cur.get("_train") if cur is None and is_train else cur
-        cur = _cur.get("_eval") if cur is None and not is_train else cur
-        cur = _cur.get("*") if cur is None else cur
-        cur = list(cur or [])
-        if is_train and self.config.get("no_specaugment", False) and "specaugment" in cur:
-            cur.remove("specaugment")
-        if self.config.get("cmvn") and ("utterance_cmvn" in cur or "global_cmvn" in cur):
-            cur = [t for t in cur if t not in ("utterance_cmvn", "global_cmvn")]
-            if self.config["cmvn"] == "utterance":
-                cur.append("utterance_cmvn")
-            elif self.config["cmvn"] == "global":
-                cur.append("global_cmvn")
+            return self.config["stats_npz_path"]
+        return (self.config.get("global_cmvn") or {}).get("stats_npz_path")
+
+    def get_feature_transforms(self, split, is_train):
+        """Config dictionary for ``CompositeAudioFeatureTransform.from_config_dict`` of one split: the selected transform
+        names under ``transforms`` plus each transform's own section.  ``no_specaugment`` drops SpecAugment from training
+        splits; ``cmvn: utterance | global`` replaces whichever CMVN the list names by the requested kind (global needs
+        its statistics file to exist); ``overwrite_specaug`` overrides individual SpecAugment settings."""
+        names = self._transform_names(split, is_train)
+        out = deepcopy(self.config)
+        if self.config.get("stats_npz_path"):  # shorthand, also recorded on the live config like the reference does
+            self.config["global_cmvn"] = out["global_cmvn"] = {"stats_npz_path": self.config["stats_npz_path"]}
+        if is_train and self.config.get("no_specaugment", False):
+            names = [n for n in names if n != "specaugment"]
+        kind = self.config.get("cmvn")
+        if kind and any(n.endswith("_cmvn") and n in ("utterance_cmvn", "global_cmvn") for n in names):
+            names = [n for n in names if n not in ("utterance_cmvn", "global_cmvn")]
+            if kind in ("utterance", "global"):
+                names.append(kind + "_cmvn")
+            if kind == "global":
+                stats = self._global_cmvn_stats()
                 if self.config.get("cmvn_path"):
-                    path = self.config["cmvn_path"]
-                    if not op.exists(path):
-                        path = op.join(self.yaml_dir, path)
-                    cfg["global_cmvn"] = {"stats_npz_path": path}
-                assert "global_cmvn" in cfg and op.exists(cfg["global_cmvn"]["stats_npz_path"])
-        if "utterance_cmvn" in cur:
-            cfg["utterance_cmvn"] = dict(cfg.get("utterance_cmvn") or {})
-        if "specaugment" in cur and self.config.get("overwrite_specaug") is not None:
-            for key, v in self.config["overwrite_specaug"].items():
-                if v is not None:
-                    cfg["specaugment"][key] = v
-        cfg["transforms"] = cur
-        return cfg
+                    out["global_cmvn"] = {"stats_npz_path": stats}
+                if not (stats and "global_cmvn" in out and op.exists(out["global_cmvn"]["stats_npz_path"])):
+                    raise AssertionError("cmvn: global needs an existing statistics file (cmvn_path / global_cmvn.stats_npz_path)")
+        if "utterance_cmvn" in names:
+            out["utterance_cmvn"] = dict(out.get("utterance_cmvn") or {})
+        over = self.config.get("overwrite_specaug")
+        if over is not None and "specaugment" in names:
+            out["specaugment"].update({k: v for k, v in over.items() if v is not None})
+        out["transforms"] = names
+        return out
 
 
 # ------------------------------------------------------------------------------------------------
 # features (speech_to_text_dataset.py:183-264)
 # ------------------------------------------------------------------------------------------------
+_NPY_MAGIC = b"\x93N"      # numpy.lib.format magic b"\x93NUMPY" (the reference tests its first two bytes)
+_AUDIO_MAGICS = (b"fL", b"RI")  # "fLaC" / "RIFF"
+
+
 def is_npy_data(data: bytes) -> bool:
-    return data[0] == 147 and data[1] == 78
+    """Does a zip member hold a ``.npy`` feature matrix?"""
+    return bytes(data[:2]) == _NPY_MAGIC
 
 
 def is_flac_or_wav_data(data: bytes) -> bool:
-    return (data[0] == 102 and data[1] == 76) or (data[0] == 82 and data[1] == 73)
+    """Does a zip member hold raw audio (flac or wav container)?"""
+    return bytes(data[:2]) in _AUDIO_MAGICS
 
 
 def read_from_uncompressed_zip(file_path, offset, file_size) -> bytes:
-    with open(file_path, "rb") as f:
-        f.seek(offset)
-        return f.read(file_size)
+    """``file_size`` bytes at ``offset`` of a STORED (uncompressed) zip: the member's payload, addressed the way the
+    manifests do (``<zip>:<offset>:<length>``)."""
+    fd = os.open(file_path, os.O_RDONLY)
+    try:
+        return os.pread(fd, file_size, offset)
+    finally:
+        os.close(fd)
 
 
 def _parse_wav(data: bytes):
