@@ -406,6 +406,34 @@ typedef struct s2t_ffn_args {
 } s2t_ffn_args;
 int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
 
+/* s2t_rowblock_gemm: the K = 256 projections of an encoder layer on the same 64-row blocks, with the LayerNorm in front
+ * folded in:   out[M][Nout] = epilogue( xn[M][256] W[N][256]^T ),   xn = ln_gamma ? LayerNorm(x) (rows of padded frames
+ * zeroed when ln_lens is given: the conv-module input mask, convolution.py:86-88) : x.
+ * Replaces F.layer_norm + F.linear / Conv1d(k=1) of modules/multihead_attention.py:239-263, espnet_multihead_attention.py:
+ * 88-106, convolution.py:91,106 (+ GLU, :92).  Epilogue = s2t_gemm's, in its order: bias; act == S2T_ACT_GLU (out column c
+ * pairs weight rows c and N/2 + c, Nout = N/2, optional pre-activation copy [M][N] value | gate); dropout on element
+ * row*Nout + n; alpha; row_lens mask; residual.  x_ln / ln_mean / ln_rstd: optional saves of the LayerNorm for backward.
+ * Constraints: d == 256, bf16 x / W / out / residual / preact, fp32 bias and LayerNorm parameters, 16-byte aligned pointers,
+ * row strides multiples of 8 elements, N % 8 == 0 (GLU: N % 64 == 0). */
+typedef struct s2t_rowblock_args {
+  const void* x;          /* [M][256] bf16 */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  int32_t d;              /* must be 256 */
+  const int32_t* ln_lens; int32_t ln_T; /* optional padded-frame mask on the LayerNorm output */
+  void* x_ln; float* ln_mean; float* ln_rstd;
+  const void* w;          /* [N][256] bf16 */
+  const float* bias;      /* [N] fp32 or NULL */
+  int32_t M, N;
+  int32_t act;            /* S2T_ACT_NONE | S2T_ACT_GLU */
+  void* preact; int64_t ldp;
+  void* out; int64_t ldc;
+  float alpha;
+  const int32_t* row_lens; int32_t row_T;
+  const void* residual; int64_t ldr;
+  float drop_p; uint32_t drop_site; const uint64_t* drop_seed;
+} s2t_rowblock_args;
+int s2t_rowblock_gemm(const s2t_rowblock_args* args, void* stream);
+
 /* ---- Gradient all-reduce over RCCL / xGMI (csrc/comm.hip) ------------------------------------------------
  * Replaces torch.distributed.all_reduce in LegacyDistributedDataParallel.all_reduce_grads
  * (distributed/legacy_distributed_data_parallel.py:107-120): one process-global communicator (one process per GPU),

@@ -66,6 +66,20 @@ class FfnArgs(C.Structure):
     ]
 
 
+class RowblockArgs(C.Structure):
+    """Mirror of ``struct s2t_rowblock_args`` (include/s2t_hip.h)."""
+
+    _fields_ = [
+        ("x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("d", C.c_int32),
+        ("ln_lens", C.c_void_p), ("ln_T", C.c_int32),
+        ("x_ln", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("act", C.c_int32),
+        ("preact", C.c_void_p), ("ldp", C.c_int64), ("out", C.c_void_p), ("ldc", C.c_int64), ("alpha", C.c_float),
+        ("row_lens", C.c_void_p), ("row_T", C.c_int32), ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("drop_seed", C.c_void_p),
+    ]
+
+
 _CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float, "uint32_t": C.c_uint32}
 
 
@@ -89,6 +103,8 @@ def header_prototypes(path=HEADER_PATH):
                         argtypes.append(C.POINTER(GemmArgs))
                     elif "s2t_ffn_args" in a:
                         argtypes.append(C.POINTER(FfnArgs))
+                    elif "s2t_rowblock_args" in a:
+                        argtypes.append(C.POINTER(RowblockArgs))
                     else:
                         argtypes.append(C.c_void_p)
                 else:

@@ -83,6 +83,11 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
 
+// 8 fp32 -> 8 bf16, one 16-byte store
+__device__ __forceinline__ void st8row(bf16_t* ptr, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(ptr) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
 // swizzle key of row r (0..63) of a W1 chunk image: the 16 rows one fragment read touches (r = 32 fh + 8 (x>>2) + 4 ft +
 // (x&3), x = 0..15) get 16 different keys
 __device__ __forceinline__ int w1key(int r) { return (r & 3) | (((r >> 3) & 3) << 2); }
@@ -558,6 +563,245 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
   }
 }
 
+// ===============================================================================================================
+// s2t_rowblock_gemm: out = epilogue( LN(x)[M,256] W[N,256]^T ) for the K = 256 projections of an encoder layer (fused
+// QKV, pointwise conv 1 with GLU, attention output projection, pointwise conv 2): the same 64-row blocks, the LayerNorm
+// in front folded into the prologue, the epilogue of s2t_gemm (bias, GLU, pre-activation copy, dropout, alpha, padded-row
+// mask, residual) applied to whole 128-byte output rows.
+//   wave (mp, q): rows 32 mp .. +32 (two MFMA column tiles), output units 16 q .. +16 of every 64-unit chunk of W
+//   chunk pipeline: three 32 KiB LDS stages, the DMA runs two chunks ahead (counted vmcnt(4)), one barrier per chunk;
+//   the fp32 result tile of chunk c ([64 rows][64 units], 16 KiB, double buffered) is written to LDS by the MFMA owners
+//   and read back one chunk later by all 512 threads as (row, 8 consecutive columns): 16-byte residual loads and stores.
+//   GLU: the chunk holds 32 value rows (weight rows 32c .. +32) and the 32 gate rows of the SAME output columns (weight
+//   rows N/2 + 32c ..), so value and gate meet in one result tile.
+constexpr int PJ_STAGES = 3;
+constexpr int PJ_W = 0;                          // three weight stages
+constexpr int PJ_TILE = PJ_STAGES * STAGE;       // two fp32 result tiles of 16 KiB
+constexpr int PJ_BYTES = PJ_TILE + 2 * 16384;    // 128 KiB
+
+template <bool GLU, bool DROP>
+__global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowblock_args p) {
+  __shared__ __attribute__((aligned(16))) char smem[PJ_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mp = wave & 1, q = wave >> 1;
+  const int x = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * TM;
+  const int M = p.M, N = p.N;
+  const int nout = GLU ? N / 2 : N;
+  const int ncols = GLU ? 32 : 64;            // output columns per chunk
+  const int nchunks = (nout + ncols - 1) / ncols;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const i32x4 srd = make_srd(p.w, (uint32_t)N * D * 2u);  // rows beyond N read as zero (descriptor bounds)
+
+  // DMA plan: chunk row u = 8 wave + 2 i + hi (512 B each) at LDS slot s = l & 31 holding k-chunk s ^ (u & 15);
+  // weight row of chunk row u: plain 64 c + u; GLU u < 32: 32 c + u (value), u >= 32: N/2 + 32 c + u - 32 (gate)
+  // (instruction i covers rows u + 2i: key (u + 2i) & 15 = (u & 15) ^ 2i, i.e. byte offset ^ 32 i, and + 1024 i through the
+  // instruction offset, global and LDS alike)
+  uint32_t ve;
+  {
+    const int hi = lane >> 5, s_ = lane & 31;
+    const int u = 8 * wave + hi;
+    const int wrow = GLU ? (u < 32 ? u : N / 2 + u - 32) : u;
+    ve = (uint32_t)(wrow * 512 + 16 * (s_ ^ (u & 15)));
+  }
+  auto issue = [&](int c) __attribute__((always_inline)) {
+    const uint32_t base = lds0 + PJ_W + (c % PJ_STAGES) * STAGE + wave * 4096;
+    const uint32_t soff = (uint32_t)c * (uint32_t)(ncols * 512);
+    dma16_off<0>(base, ve, srd, soff);
+    dma16_off<1024>(base, ve ^ 32u, srd, soff);
+    dma16_off<2048>(base, ve ^ 64u, srd, soff);
+    dma16_off<3072>(base, ve ^ 96u, srd, soff);
+  };
+  issue(0);
+  if (nchunks > 1) issue(1);
+
+  // ---- prologue: (LayerNorm of) the 64 rows staged in the third weight stage, then this wave's B fragments --------
+  {
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
+    char* stage = smem + PJ_W + 2 * STAGE;
+    const int cch = tid & 31;
+    float gm[8], bt[8];
+    if (p.ln_gamma) {
+      const float4 g0 = *reinterpret_cast<const float4*>(p.ln_gamma + 8 * cch);
+      const float4 g1 = *reinterpret_cast<const float4*>(p.ln_gamma + 8 * cch + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.ln_beta + 8 * cch);
+      const float4 b1v = *reinterpret_cast<const float4*>(p.ln_beta + 8 * cch + 4);
+      gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
+      bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1v.x; bt[5] = b1v.y; bt[6] = b1v.z; bt[7] = b1v.w;
+    }
+    uint4 raw[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int mc = min(row0 + 16 * ps + (tid >> 5), M - 1);
+      raw[ps] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * D + 8 * cch);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int rl = 16 * ps + (tid >> 5);
+      const int m = row0 + rl;
+      uint4 o = raw[ps];
+      if (p.ln_gamma) {
+        const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[2 * k] = __uint_as_float(w4[k] << 16);
+          v[2 * k + 1] = __uint_as_float(w4[k] & 0xffff0000u);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[j];
+#pragma unroll
+        for (int sh = 16; sh > 0; sh >>= 1) sum += __shfl_xor(sum, sh, 64);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dd = v[j] - mean;
+          sq += dd * dd;
+        }
+#pragma unroll
+        for (int sh = 16; sh > 0; sh >>= 1) sq += __shfl_xor(sq, sh, 64);
+        const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
+        const bool masked = p.ln_lens && m < M && (m % p.ln_T) >= p.ln_lens[m / p.ln_T];
+        uint32_t ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          ow[k] = masked ? 0u : pack2((v[2 * k] - mean) * rstd * gm[2 * k] + bt[2 * k],
+                                      (v[2 * k + 1] - mean) * rstd * gm[2 * k + 1] + bt[2 * k + 1]);
+        o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        if (m < M) {
+          if (p.x_ln) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.x_ln) + (int64_t)m * D + 8 * cch) = o;
+          if (cch == 0) {
+            if (p.ln_mean) p.ln_mean[m] = mean;
+            if (p.ln_rstd) p.ln_rstd[m] = rstd;
+          }
+        }
+      }
+      *reinterpret_cast<uint4*>(stage + rl * 512 + 16 * (cch ^ (rl & 15))) = o;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): chunks 0 and 1, the staged rows and the compiler's own loads / stores
+  __syncthreads();
+  bf16x8 xn[2][8];
+  {
+    const char* stage = smem + PJ_W + 2 * STAGE;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int rl = 32 * mp + 16 * mt + x;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        xn[mt][ks] = as_frag(*reinterpret_cast<const uint4*>(stage + rl * 512 + 16 * ((4 * ks + g) ^ x)));
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // fragments held before chunk 2 lands in that stage
+
+  const uint64_t key = DROP ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
+  const uint32_t th = s2t_drop_thresh(p.drop_p);
+  const float inv = s2t_drop_scale(p.drop_p);
+  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.residual);
+  bf16_t* OUT = reinterpret_cast<bf16_t*>(p.out);
+  bf16_t* Z = reinterpret_cast<bf16_t*>(p.preact);
+
+  // result tile: fp32 [64 rows][64 units], 16-byte piece pc (4 units) of row r at r*256 + 16*(pc ^ (r & 15))
+  auto compute = [&](int c) __attribute__((always_inline)) {
+    const char* lw = smem + PJ_W + (c % PJ_STAGES) * STAGE + (16 * q + x) * 512;
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    uint4 af[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const uint4*>(lw + 16 * ((4 * ks + g) ^ x));
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      acc[0] = mfma16(as_frag(af[ks]), xn[0][ks], acc[0]);
+      acc[1] = mfma16(as_frag(af[ks]), xn[1][ks], acc[1]);
+    }
+    char* tile = smem + PJ_TILE + (c & 1) * 16384;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int r = 32 * mp + 16 * mt + x;
+      *reinterpret_cast<f32x4*>(tile + r * 256 + 16 * ((4 * q + g) ^ x)) = acc[mt];  // r & 15 == x
+    }
+  };
+  // read-out of chunk c's tile: thread (row r = tid >> 3, j = tid & 7) owns 8 consecutive units 8j .. 8j+7
+  auto emit = [&](int c) __attribute__((always_inline)) {
+    const char* tile = smem + PJ_TILE + (c & 1) * 16384;
+    const int r = tid >> 3, j = tid & 7;
+    const int m = row0 + r;
+    auto ld8t = [&](int j8, float (&v)[8]) __attribute__((always_inline)) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(tile + r * 256 + 16 * ((2 * j8) ^ (r & 15)));
+      const f32x4 b = *reinterpret_cast<const f32x4*>(tile + r * 256 + 16 * ((2 * j8 + 1) ^ (r & 15)));
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    };
+    auto add_bias = [&](int n0, float (&v)[8]) __attribute__((always_inline)) {
+      if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0);
+        const float4 b1v = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1v.x; v[5] += b1v.y; v[6] += b1v.z; v[7] += b1v.w;
+      }
+    };
+    float v[8];
+    int n0;
+    if constexpr (GLU) {
+      if (j >= 4) return;
+      n0 = 32 * c + 8 * j;
+      if (n0 >= nout || m >= M) return;
+      float gt[8];
+      ld8t(j, v);
+      ld8t(4 + j, gt);
+      add_bias(n0, v);
+      add_bias(nout + n0, gt);
+      if (Z) {
+        st8row(Z + (int64_t)m * p.ldp + n0, v);
+        st8row(Z + (int64_t)m * p.ldp + nout + n0, gt);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(gt[e]);
+    } else {
+      n0 = 64 * c + 8 * j;
+      if (n0 >= nout || m >= M) return;
+      ld8t(j, v);
+      add_bias(n0, v);
+    }
+    if constexpr (DROP) {
+      uint32_t r16[8];
+      s2t_rand_run<8>(key, (uint64_t)m * (uint64_t)nout + (uint64_t)n0, r16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = r16[e] >= th ? v[e] * inv : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    if (p.row_lens && (m % p.row_T) >= p.row_lens[m / p.row_T]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    if (R) {
+      const uint4 t = *reinterpret_cast<const uint4*>(R + (int64_t)m * p.ldr + n0);
+      const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] += __uint_as_float(w4[k] << 16);
+        v[2 * k + 1] += __uint_as_float(w4[k] & 0xffff0000u);
+      }
+    }
+    st8row(OUT + (int64_t)m * p.ldc + n0, v);
+  };
+
+  // iteration c: DMA of chunk c+2 (its stage held chunk c-1, read before the last barrier); product of chunk c into tile
+  // c & 1; read-out of tile (c-1) & 1.  The closing wait leaves the youngest DMA group (chunk c+2) in flight; the
+  // read-out's loads / stores are older than it, so they are covered — they had the whole iteration.
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 2 < nchunks;
+    if (c > 0) emit(c - 1);
+    if (more) issue(c + 2);
+    compute(c);
+    if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  emit(nchunks - 1);
+}
+
 }  // namespace
 
 extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
@@ -594,5 +838,36 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   }
 #undef GO_A
 #undef GO
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
+  if (!a || !a->x || !a->w || !a->out) return S2T_ERR_ARG;
+  if (a->M <= 0 || a->N <= 0) return S2T_ERR_ARG;
+  if (a->d != D) return S2T_ERR_UNSUPPORTED;
+  const bool glu = a->act == S2T_ACT_GLU;
+  if (a->act != S2T_ACT_NONE && !glu) return S2T_ERR_UNSUPPORTED;
+  const int nout = glu ? a->N / 2 : a->N;
+  if (glu ? (a->N % 64) : (a->N % 8)) return S2T_ERR_UNSUPPORTED;  // GLU: whole 32-column chunks of value and gate rows
+  if (a->preact && !glu) return S2T_ERR_UNSUPPORTED;
+  if ((a->ln_gamma != nullptr) != (a->ln_beta != nullptr)) return S2T_ERR_ARG;
+  if ((a->x_ln || a->ln_mean || a->ln_rstd || a->ln_lens) && !a->ln_gamma) return S2T_ERR_ARG;
+  if ((a->ln_lens && a->ln_T <= 0) || (a->row_lens && a->row_T <= 0)) return S2T_ERR_ARG;
+  if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->drop_seed)) return S2T_ERR_ARG;
+  if (a->ldc < nout || a->ldc % 8 || (a->residual && (a->ldr < nout || a->ldr % 8)) || (a->preact && (a->ldp < a->N || a->ldp % 8)))
+    return S2T_ERR_ALIGN;
+  const void* ptrs[] = {a->x, a->w, a->out, a->residual, a->preact, a->x_ln, a->bias, a->ln_gamma, a->ln_beta};
+  for (const void* q : ptrs)
+    if (q && ((uintptr_t)q % 16)) return S2T_ERR_ALIGN;
+  const dim3 grid((a->M + TM - 1) / TM), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  const bool drop = a->drop_p > 0.f;
+  if (glu) {
+    if (drop) hipLaunchKernelGGL((rowblock_gemm_kernel<true, true>), grid, block, 0, s, *a);
+    else hipLaunchKernelGGL((rowblock_gemm_kernel<true, false>), grid, block, 0, s, *a);
+  } else {
+    if (drop) hipLaunchKernelGGL((rowblock_gemm_kernel<false, true>), grid, block, 0, s, *a);
+    else hipLaunchKernelGGL((rowblock_gemm_kernel<false, false>), grid, block, 0, s, *a);
+  }
   return S2T_LAUNCH_CHECK();
 }

@@ -138,6 +138,51 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
 
 
+def rowblock_supported(x, N, act=None):
+    """s2t_rowblock_gemm covers the encoder width of the recipes: bf16, K = d = 256, N % 8 == 0 (GLU: N % 64 == 0)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
+            and (N % 64 == 0 if act == "glu" else N % 8 == 0))
+
+
+def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual=None, ldr=0, preact=None, ldp=0, ln=None,
+                  ln_eps=1e-5, ln_lens=None, ln_T=0, x_ln=None, ln_stats=None, row_lens=None, row_T=0, drop=None):
+    """s2t_rowblock_gemm (include/s2t_hip.h): out = epilogue(LN(x) @ w[:N]^T); ``ln`` = (gamma, beta) or None."""
+    L.require_cuda(x, w, out, residual, preact, x_ln)
+    M, d = x.shape
+    a = L.RowblockArgs()
+    a.x, a.d, a.M, a.N = x.data_ptr(), d, M, N
+    a.ln_eps = ln_eps
+    if ln is not None:
+        a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+        if ln_lens is not None:
+            assert ln_lens.dtype == torch.int32
+            a.ln_lens, a.ln_T = ln_lens.data_ptr(), ln_T
+        a.x_ln = _ptr(x_ln)
+        if ln_stats is not None:
+            a.ln_mean, a.ln_rstd = ln_stats[0].data_ptr(), ln_stats[1].data_ptr()
+    assert w.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
+    a.w, a.bias = w.data_ptr(), _ptr(bias)
+    a.act = L.ACT_IDS[act]
+    a.preact, a.ldp = _ptr(preact), ldp
+    a.out, a.ldc = out.data_ptr(), ldc
+    a.alpha = alpha
+    if row_lens is not None:
+        assert row_lens.dtype == torch.int32
+        a.row_lens, a.row_T = row_lens.data_ptr(), row_T
+    a.residual, a.ldr = _ptr(residual), ldr
+    if drop is not None and drop[0] > 0:
+        a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), drop[1].data_ptr(), int(drop[2])
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().s2t_rowblock_gemm(C.byref(a), L.stream_ptr()), "s2t_rowblock_gemm")
+        e1.record()
+        GEMM_PROFILE.append(("rowblock_gemm_kernel", 2.0 * M * N * d, e0, e1, (M, N, d, 1)))
+        return out
+    L.check(L.lib().s2t_rowblock_gemm(C.byref(a), L.stream_ptr()), "s2t_rowblock_gemm")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # flat-argument entry points
 # ----------------------------------------------------------------------------------------------

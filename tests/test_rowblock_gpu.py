@@ -185,3 +185,62 @@ def test_ffn_block_fused_vs_composed_training(end_norm, mask):
     assert rel(yf, yc) < 1e-2, rel(yf, yc)
     assert rel(dxf, dxc) < 2e-2, rel(dxf, dxc)
     assert rel(gf, gc) < 2e-2, rel(gf, gc)
+
+
+@pytest.mark.parametrize("M,N,act,use_ln,mask,res,p", [
+    (64, 64, None, False, False, False, 0.0),
+    (200, 768, None, True, False, False, 0.0),        # fused QKV projection behind self_attn_layer_norm, ragged last block
+    (1000, 512, "glu", True, True, False, 0.0),       # conv_norm (padded rows zeroed) -> pointwise conv 1 -> GLU
+    (1000, 256, None, False, True, True, 0.1),        # pointwise conv 2 / output projection: dropout, row mask, residual
+    (16000, 768, None, True, False, False, 0.0),
+    (16000, 512, "glu", True, True, False, 0.0),
+    (16000, 256, None, False, False, True, 0.1),
+])
+def test_rowblock_gemm_matches_layernorm_plus_gemm(M, N, act, use_ln, mask, res, p):
+    """s2t_rowblock_gemm against the kernels it replaces (s2t_layernorm_fwd + s2t_gemm with the same epilogue arguments and
+    dropout site), which are themselves pinned to the oracle; plus the saves of the LayerNorm."""
+    g = torch.Generator().manual_seed(M + N)
+    d, T = 256, 50
+    x = torch.randn(M, d, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, d, generator=g) * d ** -0.5).bfloat16().to(DEV)
+    bias = (0.1 * torch.randn(N, generator=g)).to(DEV) if act != "glu" else None
+    gam = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    bet = (0.1 * torch.randn(d, generator=g)).to(DEV)
+    nout = N // 2 if act == "glu" else N
+    lens = None
+    if mask and M % T == 0:
+        lens = torch.randint(1, T + 1, (M // T,), generator=g).int().to(DEV)
+    resid = torch.randn(M, nout, generator=g).bfloat16().to(DEV) if res else None
+    seed = torch.tensor([4242], dtype=torch.int64, device=DEV)
+    drop = (p, seed, 9) if p > 0 else None
+    # reference path
+    if use_ln:
+        xl = torch.empty_like(x)
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        K.layernorm_fwd(x, gam, bet, xl, mean, rstd, M, d, 1e-5, lens, T)
+    else:
+        xl = x
+    out_u = torch.empty(M, nout, dtype=torch.bfloat16, device=DEV)
+    z_u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if act == "glu" else None
+    K.gemm(xl, w, out_u, M=M, N=N, K=d, lda=d, ldb=d, ldc=nout, bias=bias, act=act, preact=z_u, ldp=N, alpha=0.5,
+           residual=resid, ldr=nout, row_lens=lens if not use_ln else None, row_T=T, drop=drop)
+    # fused
+    out_f = torch.full((M, nout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    z_f = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV) if act == "glu" else None
+    xl_f = torch.empty_like(x) if use_ln else None
+    mean_f, rstd_f = (torch.empty(M, device=DEV), torch.empty(M, device=DEV)) if use_ln else (None, None)
+    K.rowblock_gemm(x, w, out_f, N=N, ldc=nout, bias=bias, act=act, alpha=0.5, residual=resid, ldr=nout, preact=z_f, ldp=N,
+                    ln=(gam, bet) if use_ln else None, ln_lens=lens if use_ln else None, ln_T=T, x_ln=xl_f,
+                    ln_stats=(mean_f, rstd_f) if use_ln else None, row_lens=lens if not use_ln else None, row_T=T, drop=drop)
+    torch.cuda.synchronize()
+    if use_ln:
+        assert float((mean_f - mean).abs().max()) < 1e-5 and float(((rstd_f - rstd) / rstd).abs().max()) < 1e-5
+        assert float((xl_f.float() - xl.float()).abs().max()) <= 2 ** -5
+    ou, of = out_u.float(), out_f.float()
+    assert torch.isfinite(of).all()
+    assert float((of - ou).abs().max() / ou.abs().max()) < 2e-2
+    if p > 0:  # same masks: the dropped elements coincide (the residual shifts them away from zero: compare out - residual)
+        du, df = (ou - resid.float()).abs() < 1e-6, (of - resid.float()).abs() < 1e-6
+        assert float((du != df).float().mean()) < 2e-3
+    if act == "glu":
+        assert float((z_f.float() - z_u.float()).abs().max() / z_u.float().abs().max()) < 2e-2
