@@ -30,7 +30,7 @@
 
 #ifndef S2T_RB_DBG
 #define S2T_RB_DBG 0  // kernel-experiment switches (tools/rb_dbg_build.sh): 1 no DMA inside the loop, 2 no MFMAs, 4 no E1,
-                      // 8 no z / h saves
+                      // 8 no z / h saves, 16 s_memtime stamps, 32 no L2 warm-up loads
 #endif
 
 namespace {
@@ -369,6 +369,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     }
   };
 
+  // L2 warm-up two chunks ahead: inside a model every FFN brings its own 2 MiB of weights, whose first touch per XCD is
+  // an HBM miss (~2 us) that a DMA issued one chunk ahead cannot hide.  One 4-byte load per lane touches each 128-byte line
+  // of chunk c+2 (256 lines of W1, 256 of W2); its value is never used.  The load is the wave's YOUNGEST vector-memory
+  // operation at the closing wait of the iteration and stays in flight across it (counted vmcnt).
+  uint32_t pf_sink = 0;
+  const char* pf_base = tid < 256 ? reinterpret_cast<const char*>(p.w1) + (size_t)tid * 128
+                                  : reinterpret_cast<const char*>(p.w2) + (size_t)(tid - 256) * ((size_t)F * 2);
+  const uint32_t pf_step = tid < 256 ? (uint32_t)(FC * 512) : (uint32_t)(FC * 2);
+  auto l2_prefetch = [&](int c) __attribute__((always_inline)) {
+    const char* a = pf_base + (size_t)c * pf_step;
+    asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(a) : "memory");
+  };
 #if S2T_RB_DBG & 16
   unsigned long long stamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i)                                   \
@@ -413,6 +425,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     issue_w2(c);
 #endif
     save(c - 1, zp, hp);
+#if !(S2T_RB_DBG & 32)
+    const bool pf = c + 2 < nchunks && blockIdx.x < 8;  // one workgroup per XCD group warms the XCD's L2 for all
+    if (pf) l2_prefetch(c + 2);
+#else
+    const bool pf = false;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
     g1_mma(0, a0, hacc);
@@ -436,8 +454,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     STAMP(7);
     // TRAIN: the four buffer stores of save() are the wave's youngest vector-memory operations and may stay in flight
     // across the barrier (vmcnt counts in issue order); what must have landed are the DMAs in front of them
-    if constexpr (TRAIN && !(S2T_RB_DBG & 8)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (TRAIN && !(S2T_RB_DBG & 8)) {
+      if (pf) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      if (pf) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     STAMP(8);
   }
 #if S2T_RB_DBG & 16
@@ -446,6 +469,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     for (int i = 0; i < 9; ++i) dbg[i] = stamp[i];
   }
 #endif
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");  // the warm-up loads may no longer touch the register
   save(nchunks - 1, zp, hp);
   {
     bf16x8 hb[2];
@@ -577,7 +601,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
 constexpr int PJ_STAGES = 3;
 constexpr int PJ_W = 0;                          // three weight stages
 constexpr int PJ_TILE = PJ_STAGES * STAGE;       // two fp32 result tiles of 16 KiB
-constexpr int PJ_BYTES = PJ_TILE + 2 * 16384;    // 128 KiB
+constexpr int PJ_BIAS = PJ_TILE + 2 * 16384;     // fp32 bias[N] (N <= PJ_MAXN)
+constexpr int PJ_MAXN = 4096;
+constexpr int PJ_BYTES = PJ_BIAS + PJ_MAXN * 4;  // 144 KiB
 
 template <bool GLU, bool DROP>
 __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowblock_args p) {
@@ -616,6 +642,10 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   };
   issue(0);
   if (nchunks > 1) issue(1);
+  {  // bias -> LDS (zeros when absent): the read-out then never waits for a global load
+    float* lb = reinterpret_cast<float*>(smem + PJ_BIAS);
+    for (int i = tid; i < N; i += 512) lb[i] = p.bias ? p.bias[i] : 0.f;
+  }
 
   // ---- prologue: (LayerNorm of) the 64 rows staged in the third weight stage, then this wave's B fragments --------
   {
@@ -706,12 +736,13 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   bf16_t* Z = reinterpret_cast<bf16_t*>(p.preact);
 
   // result tile: fp32 [64 rows][64 units], 16-byte piece pc (4 units) of row r at r*256 + 16*(pc ^ (r & 15))
-  auto compute = [&](int c) __attribute__((always_inline)) {
+  auto read_a = [&](int c, uint4 (&af)[8]) __attribute__((always_inline)) {
     const char* lw = smem + PJ_W + (c % PJ_STAGES) * STAGE + (16 * q + x) * 512;
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    uint4 af[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const uint4*>(lw + 16 * ((4 * ks + g) ^ x));
+  };
+  auto mma_store = [&](int c, const uint4 (&af)[8]) __attribute__((always_inline)) {
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       acc[0] = mfma16(as_frag(af[ks]), xn[0][ks], acc[0]);
@@ -725,28 +756,32 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     }
   };
   // read-out of chunk c's tile: thread (row r = tid >> 3, j = tid & 7) owns 8 consecutive units 8j .. 8j+7
-  auto emit = [&](int c) __attribute__((always_inline)) {
+  const int er = tid >> 3, ej = tid & 7;
+  const int em = row0 + er;
+  const bool elive = em < M && (!GLU || ej < 4);
+  const float* lbias = reinterpret_cast<const float*>(smem + PJ_BIAS);
+  auto res_prefetch = [&](int c) __attribute__((always_inline)) -> uint4 {
+    const int n0 = ncols * c + 8 * ej;
+    if (R && elive && n0 < nout) return *reinterpret_cast<const uint4*>(R + (int64_t)em * p.ldr + n0);
+    return make_uint4(0, 0, 0, 0);
+  };
+  auto emit = [&](int c, const uint4 rres) __attribute__((always_inline)) {
     const char* tile = smem + PJ_TILE + (c & 1) * 16384;
-    const int r = tid >> 3, j = tid & 7;
-    const int m = row0 + r;
+    const int r = er, j = ej, m = em;
     auto ld8t = [&](int j8, float (&v)[8]) __attribute__((always_inline)) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(tile + r * 256 + 16 * ((2 * j8) ^ (r & 15)));
       const f32x4 b = *reinterpret_cast<const f32x4*>(tile + r * 256 + 16 * ((2 * j8 + 1) ^ (r & 15)));
       v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     };
     auto add_bias = [&](int n0, float (&v)[8]) __attribute__((always_inline)) {
-      if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0);
-        const float4 b1v = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1v.x; v[5] += b1v.y; v[6] += b1v.z; v[7] += b1v.w;
-      }
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(lbias + n0);
+      const f32x4 b1v = *reinterpret_cast<const f32x4*>(lbias + n0 + 4);
+      v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1v[0]; v[5] += b1v[1]; v[6] += b1v[2]; v[7] += b1v[3];
     };
+    const int n0 = ncols * c + 8 * j;
+    if (!elive || n0 >= nout) return;
     float v[8];
-    int n0;
     if constexpr (GLU) {
-      if (j >= 4) return;
-      n0 = 32 * c + 8 * j;
-      if (n0 >= nout || m >= M) return;
       float gt[8];
       ld8t(j, v);
       ld8t(4 + j, gt);
@@ -759,8 +794,6 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(gt[e]);
     } else {
-      n0 = 64 * c + 8 * j;
-      if (n0 >= nout || m >= M) return;
       ld8t(j, v);
       add_bias(n0, v);
     }
@@ -777,8 +810,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
     if (R) {
-      const uint4 t = *reinterpret_cast<const uint4*>(R + (int64_t)m * p.ldr + n0);
-      const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+      const uint32_t w4[4] = {rres.x, rres.y, rres.z, rres.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         v[2 * k] += __uint_as_float(w4[k] << 16);
@@ -788,18 +820,23 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     st8row(OUT + (int64_t)m * p.ldc + n0, v);
   };
 
-  // iteration c: DMA of chunk c+2 (its stage held chunk c-1, read before the last barrier); product of chunk c into tile
-  // c & 1; read-out of tile (c-1) & 1.  The closing wait leaves the youngest DMA group (chunk c+2) in flight; the
-  // read-out's loads / stores are older than it, so they are covered — they had the whole iteration.
+  // iteration c: the residual load of the pending read-out and the fragment reads of chunk c go out first; the read-out of
+  // tile (c-1) & 1 fills the time they take; DMA of chunk c+2 (its stage held chunk c-1, read before the last barrier);
+  // product of chunk c into tile c & 1.  The closing wait leaves the youngest DMA group (chunk c+2) in flight.
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 2 < nchunks;
-    if (c > 0) emit(c - 1);
+    // (a wait for this load also waits for the OLDER DMAs of chunk c+1, which have had an iteration; the DMAs of chunk c+2
+    // are issued behind the read-out, so no compiler-inserted wait ever covers them)
+    const uint4 rres = c > 0 ? res_prefetch(c - 1) : make_uint4(0, 0, 0, 0);
+    uint4 af[8];
+    read_a(c, af);
+    if (c > 0) emit(c - 1, rres);
     if (more) issue(c + 2);
-    compute(c);
+    mma_store(c, af);
     if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  emit(nchunks - 1);
+  emit(nchunks - 1, res_prefetch(nchunks - 1));
 }
 
 }  // namespace

@@ -469,6 +469,34 @@ def layer_norm(x, gamma, beta, lens=None, T=0, fork=False):
     return LayerNormFn.apply(x, gamma, beta, lens, T, fork)
 
 
+def _ln_backward(x, gamma, beta, dy, mean, rstd, lens, T, dres, up_drop):
+    """s2t_layernorm_bwd for a LayerNorm whose forward was folded into a row-block kernel: parameter gradients through the
+    queued fold (or directly outside a backward pass), the residual-branch gradient ``dres`` added in the kernel, and the
+    dropped copy for the block in front handed over when ``up_drop`` names its output mask."""
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    dxd = torch.empty_like(x) if up_drop is not None else None
+    if x.is_cuda and _arm_backward_end():
+        ws = _ln_workspace(cols, x.device)
+        K.layernorm_bwd(x, gamma.data, dy, mean, rstd, dx, None, None, rows, cols, lens, T, dres, ws=ws, dx_drop=dxd, drop=up_drop)
+        _LNQ["entries"].append((ws, gamma.grad, beta.grad, cols))
+    else:
+        K.layernorm_bwd(x, gamma.data, dy, mean, rstd, dx, gamma.grad, beta.grad, rows, cols, lens, T, dres, dx_drop=dxd,
+                        drop=up_drop)
+    _ready(gamma, beta)
+    if dxd is not None:
+        _hand_over(dx, up_drop, dxd)
+    return dx
+
+
+_RB = os.environ.get("S2T_ROWBLOCK", "1") != "0"          # row-block projection kernels (csrc/rowblock.hip)
+_RB_MIN_ROWS = int(os.environ.get("S2T_ROWBLOCK_MIN_ROWS", "8192"))  # 64-row blocks: fewer rows leave CUs idle
+
+
+def _rb_ok(x, N, act=None):
+    return _RB and K.rowblock_supported(x, N, act) and x.shape[0] >= _RB_MIN_ROWS
+
+
 # ------------------------------------------------------------------------------------------------
 # Linear (+ residual)
 # ------------------------------------------------------------------------------------------------
@@ -697,18 +725,34 @@ class AttentionFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, train, drop_a, drop_o):
+    def forward(ctx, xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, train, drop_a, drop_o,
+                ln_g=None, ln_b=None, pos_p=None):
         d = xq.shape[1]
         dk = d // H
         dt = xq.dtype
         dev = xq.device
         self_attn = xkv is None
         Mq, Mk = B * Tq, B * Tk
+        ctx.ln = None
         if self_attn:
             wqkv = fused([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
             bqkv = fused_master([prm["q_b"], prm["k_b"], prm["v_b"]], 3 * d)
             qkv = torch.empty(Mq, 3 * d, dtype=dt, device=dev)
-            K.gemm(xq, wqkv, qkv, M=Mq, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+            if ln_g is not None:
+                # xq is the block input BEFORE its LayerNorm (attention() only routes the row-block case here): the
+                # LayerNorm rides in the projection kernel's prologue; the residual branch is xq itself
+                x_pre, residual = xq, xq
+                xq = torch.empty_like(x_pre) if train else None
+                ln_mean = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
+                ln_rstd = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
+                K.rowblock_gemm(x_pre, wqkv, qkv, N=3 * d, ldc=3 * d, bias=bqkv, ln=(ln_g.data, ln_b.data), x_ln=xq,
+                                ln_stats=(ln_mean, ln_rstd) if train else None)
+                ctx.ln = (ln_g, ln_b, getattr(x_pre, "_s2t_drop_o", None))
+                ctx.ln_saved = (x_pre, ln_mean, ln_rstd)
+                if xq is None:
+                    xq = x_pre  # eval: only shapes / dtypes are read below
+            else:
+                K.gemm(xq, wqkv, qkv, M=Mq, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
             q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
             ldq = ldk = 3 * d
         else:
@@ -727,8 +771,11 @@ class AttentionFn(torch.autograd.Function):
             if kind == "rel":
                 assert self_attn and Tq == Tk
                 n_pos = 2 * Tq - 1
-                p = torch.empty(n_pos, d, dtype=dt, device=dev)
-                K.gemm(pos_tab, cw(prm["pos_w"]), p, M=n_pos, N=d, K=d, lda=d, ldb=d, ldc=d)
+                if pos_p is not None:  # projected for every layer of the stack by ONE batched launch (project_positions)
+                    p = pos_p
+                else:
+                    p = torch.empty(n_pos, d, dtype=dt, device=dev)
+                    K.gemm(pos_tab, cw(prm["pos_w"]), p, M=n_pos, N=d, K=d, lda=d, ldb=d, ldc=d)
                 scale = 1.0 / math.sqrt(dk)
             else:
                 scale = dk ** -0.5
@@ -738,8 +785,12 @@ class AttentionFn(torch.autograd.Function):
                              key_lens, causal, scale, p, d, prm["pos_u"].data.view(-1) if p is not None else None,
                              prm["pos_v"].data.view(-1) if p is not None else None, drop_a)
             y = torch.empty(Mq, d, dtype=dt, device=dev)
-            K.gemm(O, cw(prm["o_w"]), y, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual,
-                   ldr=d, drop=drop_o)
+            if _rb_ok(O, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1)):
+                K.rowblock_gemm(O, cw(prm["o_w"]), y, N=d, ldc=d, bias=prm["o_b"].data, residual=residual,
+                                ldr=residual.stride(0) if residual is not None else 0, drop=drop_o)
+            else:
+                K.gemm(O, cw(prm["o_w"]), y, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual,
+                       ldr=d, drop=drop_o)
             ctx.drops = (drop_a, drop_o)
             ctx.fused = True
             if train:
@@ -864,7 +915,12 @@ class AttentionFn(torch.autograd.Function):
             dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
             K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
-        return dxq, dxkv, (dres if ctx.has_res else None), None, None, None, None, None, None, None, None, None, None, None, None
+        if ctx.ln is not None:
+            ln_g, ln_b, up_drop = ctx.ln
+            x_pre, ln_mean, ln_rstd = ctx.ln_saved
+            dx = _ln_backward(x_pre, ln_g, ln_b, dxq, ln_mean, ln_rstd, None, 0, dres, up_drop)
+            return (dx, None, None) + (None,) * 15
+        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 15
 
     @staticmethod
     def backward(ctx, dy):
@@ -953,15 +1009,52 @@ class AttentionFn(torch.autograd.Function):
             dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
             K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
-        return dxq, dxkv, (dres if ctx.has_res else None), None, None, None, None, None, None, None, None, None, None, None, None
+        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 15
+
+
+def project_positions(pos_tab, weights):
+    """linear_pos (espnet_multihead_attention.py:331) of EVERY layer of a stack in one batched launch: the relative-position
+    table is the same for all of them and the [d, d] weights sit at a constant stride in the flat parameter buffer.
+    Returns one [2T-1, d] matrix per layer, or None when the layout (or dtype) does not allow it."""
+    if not weights or pos_tab is None or pos_tab.dtype != torch.bfloat16 or not pos_tab.is_cuda:
+        return None
+    ws = [cw(w) for w in weights]
+    d = ws[0].shape[1]
+    if any(w.shape != (d, d) or w.dtype != torch.bfloat16 for w in ws):
+        return None
+    esz = ws[0].element_size()
+    if len(ws) > 1:
+        stride = (ws[1].data_ptr() - ws[0].data_ptr()) // esz
+        if stride <= 0 or stride % 8 or any((ws[i].data_ptr() - ws[0].data_ptr()) != i * stride * esz for i in range(len(ws))):
+            return None
+    else:
+        stride = 0
+    n_pos = pos_tab.shape[0]
+    out = torch.empty(len(ws), n_pos, d, dtype=torch.bfloat16, device=pos_tab.device)
+    K.gemm(pos_tab, ws[0], out, M=n_pos, N=d, K=d, lda=d, ldb=d, ldc=d, batch=len(ws), a_s=(0, 0), b_s=(stride, 0),
+           c_s=(n_pos * d, 0))
+    return [out[i] for i in range(len(ws))]
 
 
 def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False, kind="abs", pos_tab=None,
-              p_attn=0.0, p_out=0.0, training=False):
+              p_attn=0.0, p_out=0.0, training=False, ln=None, pos_p=None):
+    """``ln`` = (gamma, beta) of the LayerNorm in front of a SELF-attention block: ``xq`` is then the block input before
+    that LayerNorm and doubles as the residual (``residual`` must be None).  Where the row-block projection kernel applies
+    the LayerNorm rides in its prologue; otherwise it runs as its own kernel first."""
+    if ln is not None:
+        assert xkv is None and residual is None
+        d = xq.shape[1]
+        if not (_use_fused_attention(xq.dtype, d // H) and _rb_ok(xq, 3 * d)):
+            y, xr = layer_norm(xq, ln[0], ln[1], fork=True)
+            return attention(y, None, xr, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, p_attn, p_out, training,
+                             pos_p=pos_p)
     drop_a = DROPOUT.next(p_attn if training else 0.0, xq.device)
     drop_o = DROPOUT.next(p_out if training else 0.0, xq.device)
+    lg, lb = ln if ln is not None else (None, None)
+    if not (kind == "rel" and _use_fused_attention(xq.dtype, xq.shape[1] // H)):
+        pos_p = None
     return _tag_drop(AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
-                                       torch.is_grad_enabled(), drop_a, drop_o), drop_o)
+                                       torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p), drop_o)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1028,14 +1121,27 @@ class ConvModuleFn(torch.autograd.Function):
     ``x`` is the conv_norm output with padded frames already zeroed (LayerNormFn with lens)."""
 
     @staticmethod
-    def forward(ctx, x, residual, prm, bn_buf, act, B, T, lens, training, momentum, train, drop_o):
+    def forward(ctx, x, residual, prm, bn_buf, act, B, T, lens, training, momentum, train, drop_o, ln_g=None, ln_b=None):
         M, d = x.shape
         dt, dev = x.dtype, x.device
         Kw = prm["dw_w"].shape[-1]
         w1 = cw(prm["pw1_w"]).view(2 * d, d)
         z = torch.empty(M, 2 * d, dtype=dt, device=dev) if train else None
         g = torch.empty(M, d, dtype=dt, device=dev)
-        K.gemm(x, w1, g, M=M, N=2 * d, K=d, lda=d, ldb=d, ldc=d, act="glu", preact=z, ldp=2 * d)
+        ctx.ln = None
+        if ln_g is not None:
+            # x is the block input BEFORE conv_norm (conv_module() only routes the row-block case here): LayerNorm and the
+            # padded-frame mask of the module input (convolution.py:86-88) ride in the projection kernel's prologue
+            x_pre, residual = x, x
+            x = torch.empty_like(x_pre) if train else x_pre
+            ln_mean = torch.empty(M, dtype=torch.float32, device=dev) if train else None
+            ln_rstd = torch.empty(M, dtype=torch.float32, device=dev) if train else None
+            K.rowblock_gemm(x_pre, w1, g, N=2 * d, ldc=d, act="glu", preact=z, ldp=2 * d, ln=(ln_g.data, ln_b.data),
+                            ln_lens=lens, ln_T=T, x_ln=x if train else None, ln_stats=(ln_mean, ln_rstd) if train else None)
+            ctx.ln = (ln_g, ln_b, getattr(x_pre, "_s2t_drop_o", None))
+            ctx.ln_saved = (x_pre, ln_mean, ln_rstd)
+        else:
+            K.gemm(x, w1, g, M=M, N=2 * d, K=d, lda=d, ldb=d, ldc=d, act="glu", preact=z, ldp=2 * d)
         scale = torch.empty(d, dtype=torch.float32, device=dev)
         shift = torch.empty(d, dtype=torch.float32, device=dev)
         wd = prm["dw_w"].data.view(d, Kw)
@@ -1055,8 +1161,12 @@ class ConvModuleFn(torch.autograd.Function):
                           momentum, 1e-5, False, scale, shift, None, None, d)
             K.dwconv_fwd(g, wd, a, B, T, d, Kw, scale=scale, shift=shift, act=act, lens=lens)
         y = torch.empty(M, d, dtype=dt, device=dev)
-        K.gemm(a, cw(prm["pw2_w"]).view(d, d), y, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, residual=residual, ldr=d,
-               row_lens=lens, row_T=T, drop=drop_o)
+        if _rb_ok(a, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1)):
+            K.rowblock_gemm(a, cw(prm["pw2_w"]).view(d, d), y, N=d, ldc=d, residual=residual,
+                            ldr=residual.stride(0) if residual is not None else 0, row_lens=lens, row_T=T, drop=drop_o)
+        else:
+            K.gemm(a, cw(prm["pw2_w"]).view(d, d), y, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, residual=residual, ldr=d,
+                   row_lens=lens, row_T=T, drop=drop_o)
         ctx.drop_o = drop_o
         if train:
             assert training, "gradients through the convolution module need training-mode BatchNorm"
@@ -1092,13 +1202,26 @@ class ConvModuleFn(torch.autograd.Function):
         dx = torch.empty(M, d, dtype=dt, device=dev)
         K.gemm(dZ, cw(prm["pw1_w"]).view(2 * d, d), dx, M=M, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["pw1_w"], prm["dw_w"], prm["bn_w"], prm["bn_b"], prm["pw2_w"])
-        return dx, (dres if ctx.has_res else None), None, None, None, None, None, None, None, None, None, None
+        if ctx.ln is not None:
+            ln_g, ln_b, up_drop = ctx.ln
+            x_pre, ln_mean, ln_rstd = ctx.ln_saved
+            dxp = _ln_backward(x_pre, ln_g, ln_b, dx, ln_mean, ln_rstd, ctx.lens, T, dres, up_drop)
+            return (dxp, None) + (None,) * 12
+        return (dx, (dres if ctx.has_res else None)) + (None,) * 12
 
 
-def conv_module(x, residual, prm, bn_buf, act, B, T, lens, training, momentum=0.1, p_out=0.0):
+def conv_module(x, residual, prm, bn_buf, act, B, T, lens, training, momentum=0.1, p_out=0.0, ln=None):
+    """``ln`` = (gamma, beta) of conv_norm: ``x`` is then the block input before that LayerNorm and doubles as the residual
+    (``residual`` must be None); the LayerNorm and the padded-frame mask ride in the row-block kernel where it applies."""
+    if ln is not None:
+        assert residual is None
+        if not _rb_ok(x, 2 * x.shape[1], "glu"):
+            y, xr = layer_norm(x, ln[0], ln[1], lens, T, fork=True)
+            return conv_module(y, xr, prm, bn_buf, act, B, T, lens, training, momentum, p_out)
     drop_o = DROPOUT.next(p_out if training else 0.0, x.device)
+    lg, lb = ln if ln is not None else (None, None)
     return _tag_drop(ConvModuleFn.apply(x, residual, prm, bn_buf, act, B, T, lens, training, momentum,
-                                        torch.is_grad_enabled(), drop_o), drop_o)
+                                        torch.is_grad_enabled(), drop_o, lg, lb), drop_o)
 
 
 # ------------------------------------------------------------------------------------------------

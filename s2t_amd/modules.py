@@ -156,9 +156,12 @@ class MultiheadAttention(nn.Module):
         return {"q_w": self.q_proj.weight, "q_b": self.q_proj.bias, "k_w": self.k_proj.weight, "k_b": self.k_proj.bias,
                 "v_w": self.v_proj.weight, "v_b": self.v_proj.bias, "o_w": self.out_proj.weight, "o_b": self.out_proj.bias}
 
-    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False):
+    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False, norm=None):
+        """``norm``: the LayerNorm in front of a self-attention block — ``xq`` is then the un-normalised block input and
+        the residual (pass ``residual=None``)."""
         return Fn.attention(xq, xkv, residual, self._prm(), self.num_heads, B, Tq, Tk, key_lens, causal, "abs", None,
-                            self.attn_dropout, self.out_dropout, self.training)
+                            self.attn_dropout, self.out_dropout, self.training,
+                            ln=(norm.weight, norm.bias) if norm is not None else None)
 
 
 class RelPositionMultiHeadedAttention(nn.Module):
@@ -191,9 +194,10 @@ class RelPositionMultiHeadedAttention(nn.Module):
                 "o_w": self.linear_out.weight, "o_b": self.linear_out.bias, "pos_w": self.linear_pos.weight,
                 "pos_u": self.pos_bias_u, "pos_v": self.pos_bias_v}
 
-    def forward(self, x, residual, B, T, key_lens, pos_tab):
+    def forward(self, x, residual, B, T, key_lens, pos_tab, norm=None, pos_p=None):
         return Fn.attention(x, None, residual, self._prm(), self.h, B, T, T, key_lens, False, "rel", pos_tab,
-                            self.attn_dropout, self.out_dropout, self.training)
+                            self.attn_dropout, self.out_dropout, self.training,
+                            ln=(norm.weight, norm.bias) if norm is not None else None, pos_p=pos_p)
 
 
 class _BatchNorm1d(nn.Module):
@@ -232,14 +236,15 @@ class ConvolutionModule(nn.Module):
         self.pointwise_conv2 = _ConvW((d, d, 1), d)
         self.activation_fn = activation_fn
 
-    def forward(self, x_ln_masked, residual, B, T, lens):
+    def forward(self, x_ln_masked, residual, B, T, lens, norm=None):
+        """``norm``: conv_norm — the first argument is then the un-normalised block input and the residual."""
         prm = {"pw1_w": self.pointwise_conv1.weight, "dw_w": self.depthwise_conv.weight, "bn_w": self.norm.weight,
                "bn_b": self.norm.bias, "pw2_w": self.pointwise_conv2.weight}
         buf = {"running_mean": self.norm.running_mean, "running_var": self.norm.running_var}
         if self.training:
             self.norm.num_batches_tracked += 1
         return Fn.conv_module(x_ln_masked, residual, prm, buf, self.activation_fn, B, T, lens, self.training,
-                              self.norm.momentum, self.dropout_p)
+                              self.norm.momentum, self.dropout_p, ln=(norm.weight, norm.bias) if norm is not None else None)
 
 
 class _ConvWB(nn.Module):
@@ -330,14 +335,13 @@ class S2TTransformerEncoderLayer(nn.Module):
         B, T, lens = c.B, c.T, c.lens
         if self.macaron_norm is not None:
             x = self.macaron_ffn.block(x, self.macaron_norm, self.ffn_scale)
-        y, x = self.self_attn_layer_norm(x, fork=True)
         if self.attn_type == "rel_pos":
-            x = self.self_attn(y, x, B, T, lens, c.pos_tab)
+            x = self.self_attn(x, None, B, T, lens, c.pos_tab, norm=self.self_attn_layer_norm,
+                               pos_p=getattr(c, "cur_pos_p", None))
         else:
-            x = self.self_attn(y, None, x, B, T, T, lens)
+            x = self.self_attn(x, None, None, B, T, T, lens, norm=self.self_attn_layer_norm)
         if self.conv_module is not None:
-            y, x = self.conv_norm(x, lens, T, fork=True)  # conv input mask fused (convolution.py:86-88)
-            x = self.conv_module(y, x, B, T, lens)
+            x = self.conv_module(x, None, B, T, lens, norm=self.conv_norm)  # conv input mask fused (convolution.py:86-88)
         x = self.ffn.block(x, self.ffn_norm, self.ffn_scale, self.final_norm, lens if mask_output else None, T)
         if self.final_norm is None and mask_output:
             x = MaskRows.apply(x, lens, T)

@@ -187,8 +187,12 @@ class S2TTransformerEncoder(nn.Module):
         inter_ctc_logits = []
         ctc_orc = ctc_force_emit = None
         stage_at = {n // 3, (2 * n) // 3} if n >= 6 else set()  # gradient stages (Fn.grad_stage): a third of the stack each
+        pos_all = None
+        if self.attn_type == "rel_pos":  # the position table is projected for all layers by one batched launch
+            pos_all = Fn.project_positions(c.pos_tab, [l.self_attn.linear_pos.weight for l in self.layers])
         for i, layer in enumerate(self.layers):
             tap = (i + 1) in self.inter_ctc_layers  # the head reads the layer output BEFORE the next layer's mask
+            c.cur_pos_p = pos_all[i] if (pos_all is not None and c.pos_tab is not None and pos_all[i].shape[0] == c.pos_tab.shape[0]) else None
             if i in stage_at:
                 x = Fn.grad_stage(x)
             x = layer(x, c, mask_output=self.layer_padding_mask and i + 1 < n and not tap)
