@@ -378,7 +378,7 @@ int s2t_dwpool_bwd(int dtype, const void* x, const float* w, const void* dy, voi
  * (what the backward pass of the unfused kernels needs: dgrad through s2t_gemm with dact_z = z, wgrad operands h and x_ln,
  * s2t_layernorm_bwd statistics).  Dropout masks are those of s2t_gemm's epilogue for the same (seed, site, element):
  * element index row*F + f for drop_h, row*256 + n for drop_o.
- * Constraints: d == 256, F % 64 == 0, F <= 4096, bf16 activations and weights (W1 [F][256], W2 [256][F], row-major as
+ * Constraints: d == 256, F % 64 == 0, bf16 activations and weights (W1 [F][256], W2 [256][F], row-major as
  * nn.Linear stores them), fp32 biases / LayerNorm parameters / statistics, every pointer 16-byte aligned.
  * y may be NULL when y_ln is given (eval). */
 typedef struct s2t_ffn_args {

@@ -41,10 +41,9 @@ constexpr int FC = 64;    // hidden units per chunk
 constexpr int STAGE = 32768;             // bytes of one W1 or W2 chunk image
 constexpr int LDS_W1 = 0;                // two W1 stages
 constexpr int LDS_W2 = 2 * STAGE;        // two W2 stages
-constexpr int LDS_B1 = 4 * STAGE;        // fp32 b1[F]
-constexpr int MAXF = 4096;
-constexpr int LDS_MBOX = LDS_B1 + MAXF * 4;   // 2 x 8 waves x 2 tiles x 64 lanes x 8 B of packed activations
-constexpr int LDS_BYTES = LDS_MBOX + 16384;   // 160 KiB in all
+constexpr int LDS_MBOX = 4 * STAGE;      // mailbox: 2 parities x 8 waves x 2 row tiles x 64 lanes x 16 B (h | z, packed bf16)
+constexpr int MAXF = 1 << 20;
+constexpr int LDS_BYTES = LDS_MBOX + 32768;   // 160 KiB in all
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -172,12 +171,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
   issue_w1(0);
   issue_w2(0);
 
-  // b1 -> LDS (fp32)
-  {
-    float* lb = reinterpret_cast<float*>(smem + LDS_B1);
-    for (int i = tid; i < F; i += 512) lb[i] = p.b1[i];
-  }
-
   // ---- prologue: LayerNorm of the 64 rows, one 16-byte piece (8 columns) per thread and pass: 32 lanes per row, 16 rows
   // per pass.  The normalised bf16 tile is staged in the (still unused) second W1 buffer with the W1 image's swizzle:
   // 16-byte chunk c of row r at r*512 + 16*(c ^ (r & 15)).
@@ -275,9 +268,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
   const uint32_t th_h = s2t_drop_thresh(p.drop_h_p);
   const float inv_h = s2t_drop_scale(p.drop_h_p);
 
-  // mailbox: [parity][wave][mt][lane] 8 bytes
+  // mailbox: [parity][wave][mt][lane] 16 bytes: packed h (8 B, what the SIMD partner's G2 needs) | packed z (8 B, training)
   char* mbox = smem + LDS_MBOX;
   const int partner = wave ^ 4;
+  auto mslot = [&](int c, int w, int mt, int ln) __attribute__((always_inline)) {
+    return mbox + ((((c & 1) * 8 + w) * 2 + mt) * 64 + ln) * 16;
+  };
 
   // G1 of chunk c: this wave's 16-unit tile for both row tiles (fragments in two groups of four k-steps)
   const int g1row = 32 * fh + 8 * (x >> 2) + 4 * nh + (x & 3);
@@ -294,9 +290,22 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
       hacc[1] = mfma16(as_frag(af[j]), xn[1][k0 + j], hacc[1]);
     }
   };
-  auto g1_bias = [&](int c, f32x4 (&hacc)[2]) __attribute__((always_inline)) {
-    const float* lb = reinterpret_cast<const float*>(smem + LDS_B1) + c * FC + 32 * fh + 8 * g + 4 * nh;
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(lb);  // the bias rides in as the initial accumulator
+  // b1[c*64 + 32 fh + 8 g + 4 nh + r]: four wave-uniform 16-byte loads per chunk through the scalar memory path (no LDS,
+  // no vector memory operation that a counted wait would have to know about), issued ONE CHUNK AHEAD of their use; the
+  // lane picks the one of its g.  The bias rides into the product as the initial accumulator.
+  struct Bias4 {
+    f32x4 q[4];
+  };
+  auto bias_load = [&](int c) __attribute__((always_inline)) -> Bias4 {
+    const uint64_t ba = (uint64_t)(p.b1 + c * FC + 32 * fh + 4 * nh);  // wave-uniform; made provably so for the compiler
+    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ba >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ba);
+    typedef const __attribute__((address_space(4))) f32x4* cptr4;  // constant address space: s_load_dwordx4
+    const cptr4 bp = (cptr4)bu;
+    return Bias4{{bp[0], bp[2], bp[4], bp[6]}};
+  };
+  auto g1_bias = [&](const Bias4& b, f32x4 (&hacc)[2]) __attribute__((always_inline)) {
+    const f32x4 bb = g == 0 ? b.q[0] : (g == 1 ? b.q[1] : (g == 2 ? b.q[2] : b.q[3]));
     hacc[0] = bb;
     hacc[1] = bb;
   };
@@ -325,14 +334,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
         for (int r = 0; r < 4; ++r) v[r] = r16[r] >= th_h ? v[r] * inv_h : 0.f;
       }
       hp[mt] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-      *reinterpret_cast<uint2*>(mbox + ((((c & 1) * 8 + wave) * 2 + mt) * 64 + lane) * 8) = hp[mt];
+      if constexpr (TRAIN) *reinterpret_cast<uint4*>(mslot(c, wave, mt, lane)) = make_uint4(hp[mt].x, hp[mt].y, zp[mt].x, zp[mt].y);
+      else *reinterpret_cast<uint2*>(mslot(c, wave, mt, lane)) = hp[mt];
     }
   };
   // G2 of chunk c: own packed values hp + the partner's from the mailbox (B fragment: k = 8g + j <-> unit 32 fh + 8g + j)
   auto g2_hb = [&](int c, const uint2 (&hp)[2], bf16x8 (&hb)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const uint2 o = *reinterpret_cast<const uint2*>(mbox + ((((c & 1) * 8 + partner) * 2 + mt) * 64 + lane) * 8);
+      const uint2 o = *reinterpret_cast<const uint2*>(mslot(c, partner, mt, lane));
       hb[mt] = nh == 0 ? as_frag(make_uint4(hp[mt].x, hp[mt].y, o.x, o.y)) : as_frag(make_uint4(o.x, o.y, hp[mt].x, hp[mt].y));
     }
   };
@@ -350,22 +360,26 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
       yacc[n0 + j][1] = mfma16(as_frag(af[j]), hb[1], yacc[n0 + j][1]);
     }
   };
-  // Saves for backward: ALWAYS exactly four store instructions per wave and chunk (the closing wait of the loop counts
-  // on it): buffer stores whose descriptor drops rows >= M (and everything when the tensor was not asked for).
+  // Saves for backward of chunk c, one chunk after its mailbox slots were written (the chunk barrier lies between): thread
+  // (row rr = tid >> 3, piece pp = tid & 7) assembles the 8 hidden units 8 pp .. 8 pp + 7 of its row from the two SIMD
+  // partners' slots and stores 16 bytes of z and 16 bytes of h: a wave instruction covers 8 whole 128-byte lines.
+  // ALWAYS exactly two store instructions per wave and chunk (the closing wait of the loop counts on it): buffer stores
+  // whose descriptor drops rows >= M (and everything when the tensor was not asked for).
   const __amdgpu_buffer_rsrc_t zsrd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.z), 0, p.z ? (int)((uint32_t)M * (uint32_t)F * 2u) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t hsrd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.h), 0, p.h ? (int)((uint32_t)M * (uint32_t)F * 2u) : 0, 0x00020000);
-  auto save = [&](int c, const uint2 (&zp)[2], const uint2 (&hp)[2]) __attribute__((always_inline)) {
+  auto save = [&](int c) __attribute__((always_inline)) {
     if constexpr (TRAIN && !(S2T_RB_DBG & 8)) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const uint32_t m = (uint32_t)(row0 + 32 * mp + 16 * mt + x);
-        const uint32_t o = (m * (uint32_t)F + (uint32_t)(c * FC + 32 * fh + 8 * g + 4 * nh)) * 2u;
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64((u32x2){zp[mt].x, zp[mt].y}, zsrd, o, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64((u32x2){hp[mt].x, hp[mt].y}, hsrd, o, 0, 0);
-      }
+      const int rr = tid >> 3, pp = tid & 7;
+      const int w0 = (rr >> 5) + 2 * (pp >> 2);  // wave (mp, fh, nh = 0); its partner is w0 + 4
+      const int smt = (rr >> 4) & 1, sl = 16 * (pp & 3) + (rr & 15);
+      const uint4 lo = *reinterpret_cast<const uint4*>(mslot(c, w0, smt, sl));      // units 8 pp + 0..3: h | z
+      const uint4 hi = *reinterpret_cast<const uint4*>(mslot(c, w0 + 4, smt, sl));  // units 8 pp + 4..7
+      const uint32_t o = ((uint32_t)(row0 + rr) * (uint32_t)F + (uint32_t)(c * FC + 8 * pp)) * 2u;
+      typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.z, lo.w, hi.z, hi.w}, zsrd, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.x, lo.y, hi.x, hi.y}, hsrd, o, 0, 0);
     }
   };
 
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     f32x4 hacc[2];
     uint4 a0[4], a1[4];
     if (nchunks > 1) issue_w1(1);
-    g1_bias(0, hacc);
+    g1_bias(bias_load(0), hacc);
     g1_read(0, 0, a0);
     g1_read(0, 4, a1);
     g1_mma(0, a0, hacc);
@@ -405,6 +419,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     e1(0, hacc, zp, hp);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  Bias4 bcur = bias_load(nchunks > 1 ? 1 : 0);
   for (int c = 1; c < nchunks; ++c) {
     // The first fragment reads go out before anything else; the DMAs of the next chunks follow (they must be OLDER than
     // the chunk's saves, see the closing wait), then the MFMA groups with the next group's reads behind them.
@@ -415,7 +430,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     bf16x8 hb[2];
     uint4 a0[4], a1[4];
     STAMP(0);
-    g1_bias(c, hacc);
+    g1_bias(bcur, hacc);
+    bcur = bias_load(c + 1 < nchunks ? c + 1 : c);
     g2_hb(c - 1, hp, hb);
     g1_read(c, 0, a0);
     g1_read(c, 4, a1);
@@ -424,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     if (more) issue_w1(c + 1);
     issue_w2(c);
 #endif
-    save(c - 1, zp, hp);
+    save(c - 1);
 #if !(S2T_RB_DBG & 32)
     const bool pf = c + 2 < nchunks && blockIdx.x < 8;  // one workgroup per XCD group warms the XCD's L2 for all
     if (pf) l2_prefetch(c + 2);
@@ -452,11 +468,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
       hp[mt] = hn[mt];
     }
     STAMP(7);
-    // TRAIN: the four buffer stores of save() are the wave's youngest vector-memory operations and may stay in flight
+    // TRAIN: the two buffer stores of save() are the wave's youngest vector-memory operations and may stay in flight
     // across the barrier (vmcnt counts in issue order); what must have landed are the DMAs in front of them
     if constexpr (TRAIN && !(S2T_RB_DBG & 8)) {
-      if (pf) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (pf) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
       if (pf) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -470,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
   }
 #endif
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");  // the warm-up loads may no longer touch the register
-  save(nchunks - 1, zp, hp);
+  save(nchunks - 1);
   {
     bf16x8 hb[2];
     uint4 b0[4], b1[4];
