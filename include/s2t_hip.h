@@ -246,7 +246,9 @@ int s2t_axpy(int dtype, const void* a, const void* b, void* y, float alpha, int6
  *                     by grad_scale first; refreshes the bf16 weight shadow when given.
  *   s2t_sumsq_accum : *out += sum g^2 (gradient norm, utils.py:328-369)
  *   s2t_clip_coef   : hyper[2] = mult*min(1, max_norm/(sqrt(sumsq)*mult+1e-6)), hyper[3] = grad norm
- *                     (trainer.py:729-741: multiply_grads(world/sample_size) then clip_grad_norm)
+ *                     (trainer.py:729-741: multiply_grads(world/sample_size) then clip_grad_norm);
+ *                     mult <= 0: the multiplier is read from hyper[2] (device-resident, so a captured update can
+ *                     be replayed on a batch with another sample size)
  * ------------------------------------------------------------------------------------------------ */
 int s2t_adam_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, int64_t n, float beta1, float beta2,
                   float eps, float weight_decay, const float* hyper, void* stream);

@@ -549,6 +549,7 @@ extern "C" int s2t_adam_step(float* p, const float* g, float* m, float* v, void*
 // hyper[2] = mult * min(1, max_norm / (sqrt(sumsq)*mult + 1e-6)) ; hyper[3] = sqrt(sumsq)*mult (the reported grad norm)
 // (trainer.py:729-741: grads are multiplied by world/sample_size, then clipped by their global norm, utils.py:328-369)
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float mult, float* __restrict__ hyper) {
+  if (mult <= 0.f) mult = hyper[2];  // the normaliser travels in the hyper row (a captured step replays with a new one)
   const float norm = sqrtf(sumsq[0]) * mult;
   float c = 1.f;
   if (max_norm > 0.f) c = fminf(1.f, max_norm / (norm + 1e-6f));

@@ -241,8 +241,8 @@ class ConvolutionModule(nn.Module):
         prm = {"pw1_w": self.pointwise_conv1.weight, "dw_w": self.depthwise_conv.weight, "bn_w": self.norm.weight,
                "bn_b": self.norm.bias, "pw2_w": self.pointwise_conv2.weight}
         buf = {"running_mean": self.norm.running_mean, "running_var": self.norm.running_var}
-        if self.training:
-            self.norm.num_batches_tracked += 1
+        if self.training and not getattr(self, "counter_elsewhere", False):
+            self.norm.num_batches_tracked += 1  # (the encoders bump all their layers' counters with one launch)
         return Fn.conv_module(x_ln_masked, residual, prm, buf, self.activation_fn, B, T, lens, self.training,
                               self.norm.momentum, self.dropout_p, ln=(norm.weight, norm.bias) if norm is not None else None)
 

@@ -187,6 +187,13 @@ class S2TTransformerEncoder(nn.Module):
         inter_ctc_logits = []
         ctc_orc = ctc_force_emit = None
         stage_at = {n // 3, (2 * n) // 3} if n >= 6 else set()  # gradient stages (Fn.grad_stage): a third of the stack each
+        if self.training:  # nn.BatchNorm1d's num_batches_tracked of every conv module: one launch instead of one per layer
+            ctrs = [l.conv_module.norm.num_batches_tracked for l in self.layers if getattr(l, "conv_module", None) is not None]
+            if ctrs:
+                for l in self.layers:
+                    if getattr(l, "conv_module", None) is not None:
+                        l.conv_module.counter_elsewhere = True
+                torch._foreach_add_(ctrs, 1)
         pos_all = None
         if self.attn_type == "rel_pos":  # the position table is projected for all layers by one batched launch
             pos_all = Fn.project_positions(c.pos_tab, [l.self_attn.linear_pos.weight for l in self.layers])

@@ -28,9 +28,9 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.flat.master)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)  # lr, step_size, grad_scale, grad_norm
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-        # pinned staging rows for (lr, step_size): the CPU runs ahead of the stream and the copy reads the row when it
+        # pinned staging rows for (lr, step_size, world/sample_size): the CPU runs ahead of the stream and the copy reads the row when it
         # EXECUTES, so a row may only be rewritten once its copy has run: one event per row, waited for on wrap-around
-        self._hyper_host = torch.zeros(16, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(16, 2)
+        self._hyper_host = torch.zeros(16, 3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(16, 3)
         self._hyper_ev = [None] * 16
         self.num_updates = 0
         from . import comm as Comm
@@ -45,7 +45,7 @@ class Trainer:
             return self.warmup_init_lr + n * (self.lr - self.warmup_init_lr) / self.warmup_updates
         return self.lr * math.sqrt(self.warmup_updates) / math.sqrt(max(n, 1))
 
-    def _push_hyper(self):
+    def _push_hyper(self, sample_size_global):
         """Hyper-parameters of the update that brings the count to ``num_updates + 1``.  The reference sets the learning
         rate AFTER each update (trainer.py:802 -> lr_step_update -> inverse_square_root_schedule.py:69-85), so update t
         runs with lr(t - 1) and the very first one with warmup_init_lr; Adam's bias correction uses t (optim/adam.py:199-204)."""
@@ -59,7 +59,8 @@ class Trainer:
         row = self._hyper_host[slot]
         row[0] = lr
         row[1] = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-        self.hyper[:2].copy_(row, non_blocking=True)
+        row[2] = self.world / float(sample_size_global)  # multiply_grads(world / sample_size), trainer.py:729-735
+        self.hyper[:3].copy_(row, non_blocking=True)
         if self.hyper.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
@@ -78,19 +79,19 @@ class Trainer:
         loss.backward()
         return loss.detach(), log
 
-    def _update(self, sample_size_global):
+    def _update(self):
         n = self.flat.numel
         self.sumsq.zero_()
         K.sumsq_accum(self.flat.grad, n, self.sumsq)
-        K.clip_coef(self.sumsq, self.clip_norm, self.world / float(sample_size_global), self.hyper)
+        K.clip_coef(self.sumsq, self.clip_norm, -1.0, self.hyper)  # normaliser from hyper[2], see _push_hyper
         K.adam_step(self.flat.master, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.flat.shadow, n, self.betas[0],
                     self.betas[1], self.eps, self.wd, self.hyper)
 
-    def _step_body(self, sample, sample_size_global):
+    def _step_body(self, sample):
         out = self._fwd_bwd(sample)
         if self.ddp is not None:
             self.ddp.all_reduce_grads()  # grads = sum_ranks / world
-        self._update(sample_size_global)
+        self._update()
         return out
 
     def train_step(self, sample, sample_size_global=None):
@@ -98,8 +99,8 @@ class Trainer:
         self.model.train()
         if sample_size_global is None:
             sample_size_global = self.world * sample["ntokens"]
-        self._push_hyper()
-        loss, log = self._step_body(sample, sample_size_global)
+        self._push_hyper(sample_size_global)
+        loss, log = self._step_body(sample)
         self.num_updates += 1
         log["gnorm"] = self.hyper[3]
         log["lr"] = self.lr_at(self.num_updates - 1)  # the rate this update ran with
@@ -116,8 +117,8 @@ class Trainer:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._push_hyper()
-                self._step_body(sample, sample_size_global)
+                self._push_hyper(sample_size_global)
+                self._step_body(sample)
                 self.num_updates += 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -126,7 +127,8 @@ class Trainer:
         Fn.reserve_wgrad_staging(self.flat.master.device, count=8 if self.ddp is not None else 1)
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
-        self._push_hyper()
+        self._ssg = sample_size_global
+        self._push_hyper(sample_size_global)
         from . import comm as Comm
         if self.ddp is not None and self.ddp.active and not Comm.initialized():
             # torch.distributed's RCCL collectives stay OUTSIDE the capture (the process-group watchdog thread polls events, which a
@@ -139,17 +141,38 @@ class Trainer:
                 self._graph_out = self._fwd_bwd(sample, overlap=False)
             self.ddp.all_reduce_grads()
             self._graph2 = torch.cuda.CUDAGraph()
-            self._ssg = sample_size_global
             with torch.cuda.graph(self._graph2, pool=self._graph.pool(), capture_error_mode="thread_local"):
-                self._update(sample_size_global)
+                self._update()
         else:
             # single GPU, or the library's own communicator: the whole update — backward, the bucketed all-reduce on its
             # side stream (forked and joined inside the capture), clip and Adam — is ONE graph
             with torch.cuda.graph(self._graph):
-                self._graph_out = self._step_body(sample, sample_size_global)
+                self._graph_out = self._step_body(sample)
 
-    def replay(self):
-        self._push_hyper()
+    def load_batch(self, sample):
+        """Copy a batch of the captured shapes into the static one the graph reads (tensors by key, recursively), then
+        redo the per-batch target bookkeeping that lives outside the graph."""
+        def fill(dst, src):
+            for k, v in src.items():
+                if isinstance(v, dict):
+                    fill(dst[k], v)
+                elif torch.is_tensor(v) and torch.is_tensor(dst.get(k)):
+                    if dst[k].shape != v.shape:
+                        raise ValueError(f"batch field {k}: shape {tuple(v.shape)} differs from the captured {tuple(dst[k].shape)}")
+                    dst[k].copy_(v, non_blocking=True)
+        fill(self._static, {k: v for k, v in sample.items() if k != "_s2t_targets"})
+        from .criterions import refresh_bookkeeping
+        c = self.criterion
+        refresh_bookkeeping(self._static, getattr(c, "padding_idx", getattr(c, "pad_idx", 1)), getattr(c, "eos_idx", 2))
+
+    def replay(self, sample=None, sample_size_global=None):
+        """One captured update; ``sample`` (same shapes as the captured batch) is copied into the static batch first."""
+        if sample is not None and sample is not self._static:
+            self.load_batch(sample)
+            self._ssg = self.world * sample["ntokens"]
+        if sample_size_global is not None:
+            self._ssg = sample_size_global
+        self._push_hyper(self._ssg)
         self._graph.replay()
         if self._graph2 is not None:
             self.ddp.begin_backward(overlap=False)

@@ -95,6 +95,65 @@ def test_graph_and_ddp_graph_follow_the_eager_trajectory():
     assert (pe - px).abs().max() <= 1e-3 * pe.abs().max()
 
 
+def _sample2():
+    """Same shapes as _sample, other frames / lengths / labels and two padded label positions (another sample size)."""
+    g = torch.Generator().manual_seed(11)
+    B, T, U = 4, 200, 9
+    lens = torch.tensor([200, 120, 177, 64])
+    src = torch.randn(B, T, 80, generator=g)
+    for b in range(B):
+        src[b, lens[b]:] = 0
+    target = torch.randint(4, V, (B, U), generator=g)
+    target[:, -1] = 2
+    target[1, -2:] = torch.tensor([2, 1])
+    target[3, -3:] = torch.tensor([2, 1, 1])
+    prev = torch.roll(target, 1, 1)
+    prev[:, 0] = 2
+    return {"net_input": {"src_tokens": src.to(DEV), "src_lengths": lens.to(DEV), "prev_output_tokens": prev.to(DEV)},
+            "target": target.to(DEV), "ntokens": int((target != 1).sum())}
+
+
+def test_a_captured_step_replays_on_new_batches():
+    """The per-batch target bookkeeping and the sample-size normaliser live OUTSIDE the graph (criterions.batch_bookkeeping,
+    the hyper row): replay(sample) must give what eager steps on the same sequence of batches give."""
+    from s2t_amd import functional as Fn
+    seq = [0, 1, 1, 0, 1]
+    out = []
+    for mode in ("eager", "graph"):
+        model = _model(5)
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+        tr = Trainer(model, crit, lr=2e-3, warmup_updates=2)
+        batches = [_sample(), _sample2()]
+        assert batches[0]["ntokens"] != batches[1]["ntokens"]
+        Fn.DROPOUT.begin_step(torch.device(DEV))
+        Fn.DROPOUT.set_seed(100)
+        losses = []
+        if mode == "eager":
+            for _ in range(3):
+                tr.train_step(batches[0])
+            for i in seq:
+                losses.append(float(tr.train_step(batches[i])[0]))
+        else:
+            static = _sample()
+            tr.train_step(static)
+            tr.capture(static, warmup=2)
+            for i in seq:
+                losses.append(float(tr.replay(batches[i])[0]))
+        torch.cuda.synchronize()
+        out.append((losses, model.flat.master.detach().float().cpu().clone()))
+    (le, pe), (lg, pg) = out
+    assert abs(le[0] - le[1]) > 1e-3 * abs(le[0])  # the two batches really differ
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+    # at lr 2e-3 Adam moves every parameter by about lr per update whatever the gradient's size, so the atomics' rounding
+    # noise on near-zero gradients shows as a few lr on single entries: compare the movement on average
+    p0 = _model(5).flat.master.detach().float().cpu()
+    moved = float((pe - p0).abs().mean())
+    assert moved > 1e-3
+    assert float((pe - pg).abs().mean()) <= 0.02 * moved, (float((pe - pg).abs().mean()), moved)
+    assert float((pe - pg).abs().max()) <= 4 * 2e-3
+
+
 @pytest.mark.parametrize("mode", ["eager", "graph"])
 def test_trainer_follows_the_reference_trajectory(golden_dir, mode):
     """Row a22 against the reference itself: five updates of the fixture model in fp32 with s2t_amd.trainer.Trainer
