@@ -408,6 +408,39 @@ typedef struct s2t_ffn_args {
 } s2t_ffn_args;
 int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
 
+/* s2t_ffn_fused_bwd: the input gradient of the same block's two products in one launch (what autograd derives from the
+ * two F.linear, the activation and the hidden dropout of s2t_transformer_layer.py:55-66):
+ *     dH  = dy W2                                  dy = gradient w.r.t. (h W2^T + b2), output dropout already undone
+ *     dz  = alpha * drop_h(dH * act'(z))           same mask as the forward (element row*F + f); written: it is the
+ *                                                  operand of the W1 / b1 weight gradients
+ *     dxn = dz W1                                  gradient w.r.t. the block's (normalised) input
+ * The products run on the forward kernel's schedule and therefore take the weights TRANSPOSED: w2t = W2^T [F][256],
+ * w1t = W1^T [256][F] (s2t_transpose_bf16_batched keeps such copies current).  The [rows][F] dH never leaves the chip.
+ * Constraints: as s2t_ffn_fused_fwd, and M * F * 2 < 2^32. */
+typedef struct s2t_ffn_bwd_args {
+  const void* dy;         /* [M][256] bf16 */
+  const void* w2t;        /* [F][256] bf16 */
+  const void* w1t;        /* [256][F] bf16 */
+  const void* z;          /* [M][F] bf16, saved by the forward */
+  void* dz;               /* [M][F] bf16 out */
+  void* dxn;              /* [M][256] bf16 out */
+  int32_t d;              /* must be 256 */
+  int32_t M, F;
+  int32_t act;            /* S2T_ACT_NONE | RELU | SWISH */
+  float alpha;
+  float drop_h_p; uint32_t drop_h_site;
+  const uint64_t* drop_seed;
+} s2t_ffn_bwd_args;
+int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* args, void* stream);
+
+/* dst_i [cols_i][rows_i] = src_i [rows_i][cols_i]^T for n bf16 matrices in one launch; items_dev: device array.
+ * max_rows / max_cols: the largest extents in the table (they size the grid). */
+typedef struct s2t_transpose_item {
+  const void* src; void* dst;
+  int32_t rows, cols;
+} s2t_transpose_item;
+int s2t_transpose_bf16_batched(const s2t_transpose_item* items_dev, int n, int max_rows, int max_cols, void* stream);
+
 /* s2t_rowblock_gemm: the K = 256 projections of an encoder layer on the same 64-row blocks, with the LayerNorm in front
  * folded in:   out[M][Nout] = epilogue( xn[M][256] W[N][256]^T ),   xn = ln_gamma ? LayerNorm(x) (rows of padded frames
  * zeroed when ln_lens is given: the conv-module input mask, convolution.py:86-88) : x.

@@ -66,6 +66,16 @@ class FfnArgs(C.Structure):
     ]
 
 
+class FfnBwdArgs(C.Structure):
+    """Mirror of ``struct s2t_ffn_bwd_args`` (include/s2t_hip.h)."""
+
+    _fields_ = [
+        ("dy", C.c_void_p), ("w2t", C.c_void_p), ("w1t", C.c_void_p), ("z", C.c_void_p), ("dz", C.c_void_p),
+        ("dxn", C.c_void_p), ("d", C.c_int32), ("M", C.c_int32), ("F", C.c_int32), ("act", C.c_int32),
+        ("alpha", C.c_float), ("drop_h_p", C.c_float), ("drop_h_site", C.c_uint32), ("drop_seed", C.c_void_p),
+    ]
+
+
 class RowblockArgs(C.Structure):
     """Mirror of ``struct s2t_rowblock_args`` (include/s2t_hip.h)."""
 
@@ -103,6 +113,8 @@ def header_prototypes(path=HEADER_PATH):
                         argtypes.append(C.POINTER(GemmArgs))
                     elif "s2t_ffn_args" in a:
                         argtypes.append(C.POINTER(FfnArgs))
+                    elif "s2t_ffn_bwd_args" in a:
+                        argtypes.append(C.POINTER(FfnBwdArgs))
                     elif "s2t_rowblock_args" in a:
                         argtypes.append(C.POINTER(RowblockArgs))
                     else:

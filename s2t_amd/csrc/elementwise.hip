@@ -562,6 +562,51 @@ extern "C" int s2t_clip_coef(const float* sumsq, float max_norm, float mult, flo
   return S2T_LAUNCH_CHECK();
 }
 
+// n bf16 matrices transposed by one launch: 64 x 64 tiles through LDS, grid (column tiles, row tiles, matrix)
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const s2t_transpose_item* __restrict__ items) {
+  __shared__ bf16_t tile[64][66];
+  const s2t_transpose_item it = items[blockIdx.z];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (r0 >= it.rows || c0 >= it.cols) return;
+  const bf16_t* src = reinterpret_cast<const bf16_t*>(it.src);
+  bf16_t* dst = reinterpret_cast<bf16_t*>(it.dst);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 2 elements per thread and pass, 8 rows per pass
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const int r = r0 + 8 * ps + ty, c = c0 + 2 * tx;
+    uint32_t v = 0;
+    if (r < it.rows) {
+      if (c + 1 < it.cols && (it.cols & 1) == 0) v = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * it.cols + c);
+      else {
+        if (c < it.cols) v = src[(int64_t)r * it.cols + c];
+        if (c + 1 < it.cols) v |= (uint32_t)src[(int64_t)r * it.cols + c + 1] << 16;
+      }
+    }
+    tile[8 * ps + ty][2 * tx] = (bf16_t)(v & 0xffffu);
+    tile[8 * ps + ty][2 * tx + 1] = (bf16_t)(v >> 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const int c = c0 + 8 * ps + ty, r = r0 + 2 * tx;  // output row c, output columns r, r + 1
+    if (c < it.cols) {
+      const uint32_t lo = tile[2 * tx][8 * ps + ty], hi = tile[2 * tx + 1][8 * ps + ty];
+      if (r + 1 < it.rows && (it.rows & 1) == 0) *reinterpret_cast<uint32_t*>(dst + (int64_t)c * it.rows + r) = lo | (hi << 16);
+      else {
+        if (r < it.rows) dst[(int64_t)c * it.rows + r] = (bf16_t)lo;
+        if (r + 1 < it.rows) dst[(int64_t)c * it.rows + r + 1] = (bf16_t)hi;
+      }
+    }
+  }
+}
+extern "C" int s2t_transpose_bf16_batched(const s2t_transpose_item* items_dev, int n, int max_rows, int max_cols, void* stream) {
+  if (!items_dev || n <= 0 || max_rows <= 0 || max_cols <= 0) return S2T_ERR_ARG;
+  if (n > 65535 || (max_rows + 63) / 64 > 65535) return S2T_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((max_cols + 63) / 64, (max_rows + 63) / 64, n), dim3(256), 0,
+                     (hipStream_t)stream, items_dev);
+  return S2T_LAUNCH_CHECK();
+}
+
 extern "C" int s2t_sumsq_accum(const float* g, int64_t n, float* out, void* stream) {
   if (!g || !out || n < 0 || n % 4) return S2T_ERR_ARG;
   if (n == 0) return S2T_OK;

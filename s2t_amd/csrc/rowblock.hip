@@ -42,6 +42,7 @@ constexpr int STAGE = 32768;             // bytes of one W1 or W2 chunk image
 constexpr int LDS_W1 = 0;                // two W1 stages
 constexpr int LDS_W2 = 2 * STAGE;        // two W2 stages
 constexpr int LDS_MBOX = 4 * STAGE;      // mailbox: 2 parities x 8 waves x 2 row tiles x 64 lanes x 16 B (h | z, packed bf16)
+constexpr int LDS_Z = LDS_MBOX + 16384;  // backward: two 8 KiB stages of the pre-activation tile (the mailbox slots are 8 bytes there)
 constexpr int MAXF = 1 << 20;
 constexpr int LDS_BYTES = LDS_MBOX + 32768;   // 160 KiB in all
 
@@ -104,8 +105,15 @@ __device__ __forceinline__ int w1key(int r) { return (r & 3) | (((r >> 3) & 3) <
 //                 G1(c)   : 16 MFMAs per wave         G2(c-1) : 16 MFMAs per wave
 //                 E1(c)   : bias (initial accumulator), activation, dropout, pack; mailbox write
 //                 s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier
-template <bool TRAIN, int ACT, bool DROP>
+//
+// MODE 2 is the BACKWARD of the two products on the same schedule (s2t_ffn_fused_bwd):
+//   dH = dY W2, dZ = alpha * drop_h(dH * act'(Z)), dXn = dZ W1.  With the TRANSPOSED weight copies W2^T [F][256] in the place
+//   of W1 and W1^T [256][F] in the place of W2 the two products are the forward ones; E1 becomes the activation derivative
+//   (the Z tile of the chunk arrives by one LDS-DMA instruction per wave, a chunk ahead), the single save is dZ (operand of
+//   the W1 weight gradient), there is no LayerNorm prologue, bias or output dropout.
+template <int MODE, int ACT, bool DROP>
 __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_args p) {
+  constexpr bool TRAIN = MODE == 1, BWD = MODE == 2;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -168,8 +176,20 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     issue_w2_half(c, 0);
     issue_w2_half(c, 1);
   };
+  // backward: the [64 rows][64 units] bf16 tile of Z of chunk c, 16-byte piece pp of row r at cell r*8 + (pp ^ ((r>>1)&7));
+  // lane l of wave w fills cell 64 w + l.  Rows >= M read as zero (descriptor bounds).
+  const i32x4 srdz = make_srd(p.z, BWD ? (uint32_t)M * (uint32_t)F * 2u : 0u);
+  uint32_t vz = 0;
+  if constexpr (BWD) {
+    const int zr = 8 * wave + (lane >> 3);
+    vz = (uint32_t)(row0 + zr) * (uint32_t)(F * 2) + (uint32_t)(16 * ((lane & 7) ^ ((zr >> 1) & 7)));
+  }
+  auto issue_z = [&](int c) __attribute__((always_inline)) {
+    if constexpr (BWD) dma16(lds0 + LDS_Z + (c & 1) * 8192 + wave * 1024, vz, srdz, (uint32_t)c * (FC * 2));
+  };
   issue_w1(0);
   issue_w2(0);
+  issue_z(0);
 
   // ---- prologue: LayerNorm of the 64 rows, one 16-byte piece (8 columns) per thread and pass: 32 lanes per row, 16 rows
   // per pass.  The normalised bf16 tile is staged in the (still unused) second W1 buffer with the W1 image's swizzle:
@@ -271,8 +291,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
   // mailbox: [parity][wave][mt][lane] 16 bytes: packed h (8 B, what the SIMD partner's G2 needs) | packed z (8 B, training)
   char* mbox = smem + LDS_MBOX;
   const int partner = wave ^ 4;
+  constexpr int MSLOT = BWD ? 8 : 16;
   auto mslot = [&](int c, int w, int mt, int ln) __attribute__((always_inline)) {
-    return mbox + ((((c & 1) * 8 + w) * 2 + mt) * 64 + ln) * 16;
+    return mbox + ((((c & 1) * 8 + w) * 2 + mt) * 64 + ln) * MSLOT;
   };
 
   // G1 of chunk c: this wave's 16-unit tile for both row tiles (fragments in two groups of four k-steps)
@@ -297,6 +318,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     f32x4 q[4];
   };
   auto bias_load = [&](int c) __attribute__((always_inline)) -> Bias4 {
+    if constexpr (BWD) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      return Bias4{{zero, zero, zero, zero}};
+    }
     const uint64_t ba = (uint64_t)(p.b1 + c * FC + 32 * fh + 4 * nh);  // wave-uniform; made provably so for the compiler
     const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ba >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ba);
@@ -309,7 +334,19 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     hacc[0] = bb;
     hacc[1] = bb;
   };
+  // backward: this lane's four pre-activation values of chunk c, row tile mt (8 bytes of the staged Z tile)
+  auto z_read = [&](int c, uint2 (&zq)[2]) __attribute__((always_inline)) {
+    if constexpr (BWD) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int rl = 32 * mp + 16 * mt + x;
+        const int cell = rl * 8 + ((4 * fh + g) ^ ((rl >> 1) & 7));
+        zq[mt] = *reinterpret_cast<const uint2*>(smem + LDS_Z + (c & 1) * 8192 + cell * 16 + 8 * nh);
+      }
+    }
+  };
   // lane (x, g): v[r] = H[row x of tile mt][unit c*64 + 32 fh + 8 g + 4 nh + r]; packed halves go to the mailbox
+  // (backward: zp holds the lane's Z values on entry, v = dH, the packed result is dZ)
   auto e1 = [&](int c, const f32x4 (&hacc)[2], uint2 (&zp)[2], uint2 (&hp)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -317,7 +354,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = hacc[mt][r];
       if constexpr (TRAIN) zp[mt] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-      if constexpr ((S2T_RB_DBG & 4) != 0) {
+      if constexpr (BWD) {
+        const float zf[4] = {__uint_as_float(zp[mt].x << 16), __uint_as_float(zp[mt].x & 0xffff0000u),
+                             __uint_as_float(zp[mt].y << 16), __uint_as_float(zp[mt].y & 0xffff0000u)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= act_grad(ACT, zf[r]);
+      } else if constexpr ((S2T_RB_DBG & 4) != 0) {
       } else if constexpr (ACT == S2T_ACT_RELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -332,6 +374,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
         s2t_rand_run<4>(key_h, base, r16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = r16[r] >= th_h ? v[r] * inv_h : 0.f;
+      }
+      if constexpr (BWD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
       }
       hp[mt] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
       if constexpr (TRAIN) *reinterpret_cast<uint4*>(mslot(c, wave, mt, lane)) = make_uint4(hp[mt].x, hp[mt].y, zp[mt].x, zp[mt].y);
@@ -370,6 +416,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
   const __amdgpu_buffer_rsrc_t hsrd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.h), 0, p.h ? (int)((uint32_t)M * (uint32_t)F * 2u) : 0, 0x00020000);
   auto save = [&](int c) __attribute__((always_inline)) {
+    if constexpr (BWD) {  // ONE store per wave and chunk: 16 bytes of dZ (units 8 pp .. 8 pp + 7 of row rr) into p.h
+      const int rr = tid >> 3, pp = tid & 7;
+      const int w0 = (rr >> 5) + 2 * (pp >> 2);
+      const int smt = (rr >> 4) & 1, sl = 16 * (pp & 3) + (rr & 15);
+      const uint2 lo = *reinterpret_cast<const uint2*>(mslot(c, w0, smt, sl));
+      const uint2 hi = *reinterpret_cast<const uint2*>(mslot(c, w0 + 4, smt, sl));
+      const uint32_t o = ((uint32_t)(row0 + rr) * (uint32_t)F + (uint32_t)(c * FC + 8 * pp)) * 2u;
+      typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.x, lo.y, hi.x, hi.y}, hsrd, o, 0, 0);
+    }
     if constexpr (TRAIN && !(S2T_RB_DBG & 8)) {
       const int rr = tid >> 3, pp = tid & 7;
       const int w0 = (rr >> 5) + 2 * (pp >> 2);  // wave (mp, fh, nh = 0); its partner is w0 + 4
@@ -410,10 +466,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
   {
     f32x4 hacc[2];
     uint4 a0[4], a1[4];
-    if (nchunks > 1) issue_w1(1);
+    if (nchunks > 1) {
+      issue_w1(1);
+      issue_z(1);
+    }
     g1_bias(bias_load(0), hacc);
     g1_read(0, 0, a0);
     g1_read(0, 4, a1);
+    z_read(0, zp);
     g1_mma(0, a0, hacc);
     g1_mma(4, a1, hacc);
     e1(0, hacc, zp, hp);
@@ -435,9 +495,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     g2_hb(c - 1, hp, hb);
     g1_read(c, 0, a0);
     g1_read(c, 4, a1);
+    z_read(c, zn);
     __builtin_amdgcn_sched_barrier(0);
 #if !(S2T_RB_DBG & 1)
-    if (more) issue_w1(c + 1);
+    if (more) {
+      issue_w1(c + 1);
+      issue_z(c + 1);
+    }
     issue_w2(c);
 #endif
     save(c - 1);
@@ -473,6 +537,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     if constexpr (TRAIN && !(S2T_RB_DBG & 8)) {
       if (pf) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if constexpr (BWD) {  // one dZ store (+ the warm-up load) may stay in flight
+      if (pf) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
       if (pf) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -522,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
     float b2v[2][4], eg[2][4], eb[2][4];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const float4 t = *reinterpret_cast<const float4*>(p.b2 + 128 * q + 4 * s);
+      const float4 t = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + 128 * q + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
       b2v[q][0] = t.x; b2v[q][1] = t.y; b2v[q][2] = t.z; b2v[q][3] = t.w;
       if (p.eln_gamma) {
         const float4 a = *reinterpret_cast<const float4*>(p.eln_gamma + 128 * q + 4 * s);
@@ -550,8 +617,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[q][r] = r16[r] >= th_o ? v[q][r] * inv_o : 0.f;
         }
+        if constexpr (!BWD) {  // (backward: alpha went into dZ)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[q][r] *= p.alpha;
+          for (int r = 0; r < 4; ++r) v[q][r] *= p.alpha;
+        }
         if (R) {
           const int mc = live ? m : M - 1;
           float rr[4];
@@ -885,11 +954,49 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
     else GO(T, S2T_ACT_NONE, DR);                       \
   } while (0)
   if (train) {
-    if (drop) GO_A(true, true); else GO_A(true, false);
+    if (drop) GO_A(1, true); else GO_A(1, false);
   } else {
-    if (drop) GO_A(false, true); else GO_A(false, false);
+    if (drop) GO_A(0, true); else GO_A(0, false);
   }
 #undef GO_A
+#undef GO
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
+  if (!b || !b->dy || !b->w2t || !b->w1t || !b->z || !b->dz || !b->dxn) return S2T_ERR_ARG;
+  if (b->M <= 0 || b->F <= 0) return S2T_ERR_ARG;
+  if (b->d != D) return S2T_ERR_UNSUPPORTED;
+  if (b->F % FC || b->F > MAXF) return S2T_ERR_UNSUPPORTED;
+  if ((int64_t)b->M * b->F * 2 >= ((int64_t)1 << 32)) return S2T_ERR_UNSUPPORTED;  // 32-bit byte offsets into Z / dZ
+  if (b->act != S2T_ACT_NONE && b->act != S2T_ACT_RELU && b->act != S2T_ACT_SWISH) return S2T_ERR_ARG;
+  if (b->drop_h_p < 0.f || b->drop_h_p >= 1.f || (b->drop_h_p > 0.f && !b->drop_seed)) return S2T_ERR_ARG;
+  const void* ptrs[] = {b->dy, b->w2t, b->w1t, b->z, b->dz, b->dxn};
+  for (const void* q : ptrs)
+    if ((uintptr_t)q % 16) return S2T_ERR_ALIGN;
+  // the kernel is the forward one with the transposed weights in the places of W1 / W2 (see MODE 2 there)
+  s2t_ffn_args a = {};
+  a.x = b->dy;
+  a.d = D;
+  a.w1 = b->w2t;
+  a.w2 = b->w1t;
+  a.y = b->dxn;
+  a.z = const_cast<void*>(b->z);
+  a.h = b->dz;
+  a.M = b->M;
+  a.F = b->F;
+  a.act = b->act;
+  a.alpha = b->alpha;
+  a.drop_h_p = b->drop_h_p;
+  a.drop_h_site = b->drop_h_site;
+  a.drop_seed = b->drop_seed;
+  const dim3 grid((a.M + TM - 1) / TM), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  const bool drop = a.drop_h_p > 0.f;
+#define GO(A, DR) hipLaunchKernelGGL((ffn_fused_fwd_kernel<2, A, DR>), grid, block, 0, s, a)
+  if (a.act == S2T_ACT_RELU) { if (drop) GO(S2T_ACT_RELU, true); else GO(S2T_ACT_RELU, false); }
+  else if (a.act == S2T_ACT_SWISH) { if (drop) GO(S2T_ACT_SWISH, true); else GO(S2T_ACT_SWISH, false); }
+  else { if (drop) GO(S2T_ACT_NONE, true); else GO(S2T_ACT_NONE, false); }
 #undef GO
   return S2T_LAUNCH_CHECK();
 }

@@ -67,6 +67,10 @@ class FlatParameters:
             p.data = self.master[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
             p._s2t_shadow = self.shadow[o:o + n].view(p.shape) if self.shadow is not None else None
+            p._s2t_flat = self
+        # transposed bf16 copies of 2-D weights for kernels that want them that way (s2t_ffn_fused_bwd): registered on first
+        # use, ALL refreshed by one launch at most once per backward pass (see transposed())
+        self._wt = {"params": [], "bufs": {}, "table": None, "fresh": False, "ext": (0, 0)}
         self.refresh_shadow()
 
     def refresh_shadow(self):
@@ -101,6 +105,39 @@ class FlatParameters:
         buf = {"compute": self.shadow if self.shadow is not None else self.master, "master": self.master,
                "grad": self.grad}[what]
         return buf[o:o + rows * cols].view(rows, cols)
+
+
+def transposed(p: nn.Parameter, in_backward: bool) -> torch.Tensor:
+    """bf16 [cols, rows] copy of the 2-D parameter ``p`` (bf16 mode only), current with the shadow.  The copies of every
+    registered parameter are rewritten by ONE s2t_transpose_bf16_batched launch, the first time any of them is asked for in a
+    backward pass (``in_backward``: the caller has the end-of-backward callback armed, which marks them stale again);
+    outside a backward pass every call refreshes."""
+    from . import kernels as K
+
+    flat = p._s2t_flat
+    st = flat._wt
+    key = id(p)
+    new = key not in st["bufs"]
+    if new:
+        assert p.dim() == 2 and flat.shadow is not None
+        st["bufs"][key] = torch.empty(p.shape[1], p.shape[0], dtype=torch.bfloat16, device=flat.shadow.device)
+        st["params"].append(p)
+        st["table"] = None
+    if new or not st["fresh"] or not in_backward:
+        if st["table"] is None:
+            import numpy as np
+
+            rec = np.zeros(len(st["params"]), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("rows", "i4"), ("cols", "i4")]))
+            for i, q in enumerate(st["params"]):
+                rec[i] = (q._s2t_shadow.data_ptr(), st["bufs"][id(q)].data_ptr(), q.shape[0], q.shape[1])
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("s2t_amd: a transposed weight copy was first asked for during graph capture; run one "
+                                   "eager step first")
+            st["table"] = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.shadow.device)
+            st["ext"] = (max(q.shape[0] for q in st["params"]), max(q.shape[1] for q in st["params"]))
+        K.transpose_batched(st["table"], len(st["params"]), st["ext"][0], st["ext"][1])
+        st["fresh"] = in_backward
+    return st["bufs"][key]
 
 
 def cw(p: nn.Parameter) -> torch.Tensor:

@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import kernels as K
-from .flat_params import cw
+from .flat_params import cw, transposed
 
 _HOOKS = {"grad_ready": None}  # set by the DDP wrapper: called with a parameter once its gradient is final
 
@@ -200,7 +200,7 @@ class _on_wgrad_stream:
 
 # Work deferred to the end of the backward pass (an autograd engine callback): the fold of every LayerNorm's
 # per-replica dgamma/dbeta partial sums (one launch instead of one per LayerNorm) and the grouped weight gradients.
-_BE = {"armed": False, "ready": []}
+_BE = {"armed": False, "ready": [], "flats": []}
 _LNQ = {"entries": [], "pools": {}, "off": {}}
 
 
@@ -245,6 +245,9 @@ def _flush_deferred():
 
 def _on_backward_end():
     _flush_deferred()
+    for flat in _BE["flats"]:
+        flat._wt["fresh"] = False  # the optimizer may change the weights before the next backward pass
+    _BE["flats"] = []
     for k in _LNQ["off"]:
         _LNQ["off"][k] = 0
     _BE["armed"] = False
@@ -590,6 +593,7 @@ class FFNFn(torch.autograd.Function):
 
 
 _FFN_FUSED = os.environ.get("S2T_FFN_FUSED", "1") != "0"
+_FFN_FUSED_BWD = os.environ.get("S2T_FFN_FUSED_BWD", "1") != "0"  # s2t_ffn_fused_bwd for the block's input gradient
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("S2T_FFN_FUSED_MIN_ROWS", "8192"))  # 64-row blocks: fewer rows leave CUs idle
 
 
@@ -661,15 +665,22 @@ class FFNBlockFn(torch.autograd.Function):
         else:
             dres = dout
             dy = _drop_rows(dres, drop_o)
-        # dZ = alpha * dropout_h(dY @ W2) * act'(Z)
+        # dZ = alpha * dropout_h(dY @ W2) * act'(Z), dXn = dZ @ W1
         dz = torch.empty(M, F_, dtype=x.dtype, device=x.device)
-        K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
-               dact=ctx.act, drop=drop_h)
+        dxl = torch.empty_like(x)
+        if _FFN_FUSED_BWD and getattr(w1, "_s2t_flat", None) is not None and w1._s2t_flat.shadow is not None \
+                and getattr(w2, "_s2t_flat", None) is w1._s2t_flat and M * F_ * 2 < 2 ** 32:
+            if queued and w1._s2t_flat not in _BE["flats"]:
+                _BE["flats"].append(w1._s2t_flat)
+            w2t, w1t = transposed(w2, queued), transposed(w1, queued)
+            K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxl, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h)
+        else:
+            K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
+                   dact=ctx.act, drop=drop_h)
+            K.gemm(dz, cw(w1), dxl, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
         _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad)
         _ready(w2, b2)
         _wgrad(dz, x_ln, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)
-        dxl = torch.empty_like(x)
-        K.gemm(dz, cw(w1), dxl, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
         _ready(w1, b1)
         dxd = torch.empty_like(x) if ctx.up_drop is not None else None
         dx = ln_bwd(x, gamma, beta, dxl, mean, rstd, None, 0, dres, dxd, ctx.up_drop)

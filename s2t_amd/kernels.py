@@ -138,6 +138,34 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
 
 
+def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None):
+    """s2t_ffn_fused_bwd (include/s2t_hip.h): dz = alpha * drop_h((dy W2) * act'(z)), dxn = dz W1, from the transposed
+    weight copies ``w2t`` [F, 256] and ``w1t`` [256, F]."""
+    L.require_cuda(dy, w2t, w1t, z, dz, dxn)
+    M, d = dy.shape
+    F = w2t.shape[0]
+    assert w2t.shape == (F, d) and w1t.shape == (d, F) and z.shape == (M, F) and dz.shape == (M, F) and dxn.shape == (M, d)
+    assert all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in (dy, w2t, w1t, z, dz, dxn))
+    a = L.FfnBwdArgs()
+    a.dy, a.w2t, a.w1t, a.z, a.dz, a.dxn = (t.data_ptr() for t in (dy, w2t, w1t, z, dz, dxn))
+    a.d, a.M, a.F, a.act, a.alpha = d, M, F, L.ACT_IDS[act], alpha
+    if drop_h is not None and drop_h[0] > 0:
+        a.drop_h_p, a.drop_h_site, a.drop_seed = float(drop_h[0]), int(drop_h[2]), drop_h[1].data_ptr()
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().s2t_ffn_fused_bwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_bwd")
+        e1.record()
+        GEMM_PROFILE.append(("ffn_fused_fwd_kernel<2", 4.0 * M * F * d, e0, e1, (M, F, d, 1)))
+        return
+    L.check(L.lib().s2t_ffn_fused_bwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_bwd")
+
+
+def transpose_batched(table, n, max_rows, max_cols):
+    """s2t_transpose_bf16_batched: ``table`` = device uint8 tensor holding n s2t_transpose_item records (24 bytes each)."""
+    _call("s2t_transpose_bf16_batched", table.data_ptr(), n, max_rows, max_cols)
+
+
 def rowblock_supported(x, N, act=None):
     """s2t_rowblock_gemm covers the encoder width of the recipes: bf16, K = d = 256, N % 8 == 0 (GLU: N % 64 == 0)."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()

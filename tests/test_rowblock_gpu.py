@@ -131,6 +131,79 @@ def test_ffn_fused_train_saves_and_masks(M, F, act):
     assert float((y_f.float() - y_u.float()).abs().max() / y_u.float().abs().max()) < 2e-2
 
 
+def _tr_table(pairs):
+    import numpy as np
+
+    rec = np.zeros(len(pairs), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("rows", "i4"), ("cols", "i4")]))
+    for i, (s_, d_) in enumerate(pairs):
+        rec[i] = (s_.data_ptr(), d_.data_ptr(), s_.shape[0], s_.shape[1])
+    return torch.from_numpy(rec.view(np.uint8).copy()).to(DEV)
+
+
+def test_transpose_batched():
+    """s2t_transpose_bf16_batched: several matrices (one ragged, one with odd extents) by one launch, bit exact."""
+    g = torch.Generator().manual_seed(2)
+    shapes = [(2048, 256), (256, 2048), (100, 72), (65, 33)]
+    src = [torch.randn(r, c, generator=g).bfloat16().to(DEV) for r, c in shapes]
+    dst = [torch.full((c, r), 7.0, dtype=torch.bfloat16, device=DEV) for r, c in shapes]
+    K.transpose_batched(_tr_table(list(zip(src, dst))), len(src), 2048, 2048)
+    torch.cuda.synchronize()
+    for s_, d_ in zip(src, dst):
+        assert torch.equal(d_, s_.t().contiguous())
+
+
+@pytest.mark.parametrize("M,F,act,p", [(64, 64, "relu", 0.0), (200, 256, "swish", 0.1), (4096, 2048, "swish", 0.1),
+                                       (1000, 512, "relu", 0.15), (130, 128, "none", 0.0)])
+def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p):
+    """s2t_ffn_fused_bwd against (a) fp32 maths on the same bf16 operands and (b) the unfused s2t_gemm pair it replaces:
+    dz = alpha * drop_h((dy W2) * act'(z)), dxn = dz W1 — the autograd backward of the two F.linear, the activation and the
+    hidden dropout of modules/s2t_transformer_layer.py:55-66.  (b) shares the dropout mask, so dz agrees to bf16 rounding."""
+    from s2t_amd import functional as Fn
+
+    d = 256
+    g = torch.Generator().manual_seed(M + F)
+    dy = torch.randn(M, d, generator=g).bfloat16().to(DEV)
+    z = torch.randn(M, F, generator=g).bfloat16().to(DEV)
+    w1 = (torch.randn(F, d, generator=g) * d ** -0.5).bfloat16().to(DEV)
+    w2 = (torch.randn(d, F, generator=g) * F ** -0.5).bfloat16().to(DEV)
+    alpha = 0.5
+    w2t, w1t = w2.t().contiguous(), w1.t().contiguous()
+    Fn.DROPOUT.begin_step(torch.device(DEV))
+    Fn.DROPOUT.set_seed(31)
+    drop = Fn.DROPOUT.next(p, torch.device(DEV))
+    dz = torch.full((M, F), 3.0, dtype=torch.bfloat16, device=DEV)
+    dxn = torch.full((M, d), 3.0, dtype=torch.bfloat16, device=DEV)
+    K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, act=act, alpha=alpha, drop_h=drop)
+    # (b) the unfused pair
+    dz_u = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    dx_u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    K.gemm(dy, w2, dz_u, M=M, N=F, K=d, lda=d, ldb=F, ldc=F, b_kmajor=True, alpha=alpha, dact_z=z, ldz=F, dact=act, drop=drop)
+    K.gemm(dz_u, w1, dx_u, M=M, N=d, K=F, lda=F, ldb=d, ldc=d, b_kmajor=True)
+    torch.cuda.synchronize()
+    assert ((dz.float() == 0) == (dz_u.float() == 0)).float().mean() > 0.999  # same mask (exact zeros of relu' aside)
+    err = (dz.float() - dz_u.float()).abs().max() / dz_u.float().abs().max()
+    assert err < 1e-2, float(err)
+    rel = (dxn.float() - dx_u.float()).norm() / dx_u.float().norm()
+    assert rel < 1e-2, float(rel)
+    # (a) fp32 maths, with the kernel's own mask (the zeros of dz_u where act' is not zero)
+    zf = z.float()
+    if act == "relu":
+        da = (zf > 0).float()
+    elif act == "swish":
+        sg = torch.sigmoid(zf)
+        da = sg * (1 + zf * (1 - sg))
+    else:
+        da = torch.ones_like(zf)
+    dh = dy.float() @ w2.float()
+    keep = torch.ones_like(zf) if p == 0 else ((dz_u.float() != 0) | (da == 0) | (dh == 0)).float()
+    ref_dz = alpha * dh * da * keep / (1 - p)
+    err = (dz.float() - ref_dz).abs().max() / ref_dz.abs().max()
+    assert err < 1.5e-2, float(err)
+    ref_dx = dz.float() @ w1.float()
+    rel = (dxn.float() - ref_dx).norm() / ref_dx.norm()
+    assert rel < 1e-2, float(rel)
+
+
 @pytest.mark.parametrize("end_norm,mask", [(False, False), (True, False), (True, True)])
 def test_ffn_block_fused_vs_composed_training(end_norm, mask):
     """functional.ffn_block: the fused launch and the LayerNorm / GEMM composition give the same output and gradients
