@@ -184,6 +184,11 @@ typedef struct s2t_wgrad_problem {
 
 int s2t_wgrad_grouped(const s2t_wgrad_problem* problems_dev, int n_problems, const int32_t* items_dev, int n_items,
                       const int32_t* tiles_dev, int n_tiles, float* ws, int any_k_tail, void* stream);
+/* The same tables cut for 256 x 256 output tiles and K-steps of 32 rows (`ksteps` counts those; ws: 65536 floats per
+ * tile and split), executed by the LDS-DMA fed kernel: both operands bf16 with lda % 8 == 0, ldb % 8 == 0, 16-byte aligned
+ * bases and spans below 2 GiB (the caller checks; s2t_wgrad_grouped takes everything else). */
+int s2t_wgrad_grouped256(const s2t_wgrad_problem* problems_dev, int n_problems, const int32_t* items_dev, int n_items,
+                         const int32_t* tiles_dev, int n_tiles, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Feature front-end (dataloader stage of the reference, here on the device)
@@ -416,6 +421,10 @@ int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
  *     dxn = dz W1                                  gradient w.r.t. the block's (normalised) input
  * The products run on the forward kernel's schedule and therefore take the weights TRANSPOSED: w2t = W2^T [F][256],
  * w1t = W1^T [256][F] (s2t_transpose_bf16_batched keeps such copies current).  The [rows][F] dH never leaves the chip.
+ * ln_x != NULL adds the backward of the block's leading LayerNorm (modules/layer_norm.py:30-35) on the fp32 dxn rows, with
+ * s2t_layernorm_bwd's arithmetic and outputs:  dx = LayerNorm'(dxn; ln_x, ln_gamma, ln_mean, ln_rstd) + dres,  dx_drop =
+ * dropout(dx) under (up_drop_p, up_drop_site) when given, and the partial sums of dgamma | dbeta added into
+ * ln_ws [ln_replicas][2][256] (fold them with s2t_layernorm_fold); dxn is then optional and not written.
  * Constraints: as s2t_ffn_fused_fwd, and M * F * 2 < 2^32. */
 typedef struct s2t_ffn_bwd_args {
   const void* dy;         /* [M][256] bf16 */
@@ -423,13 +432,20 @@ typedef struct s2t_ffn_bwd_args {
   const void* w1t;        /* [256][F] bf16 */
   const void* z;          /* [M][F] bf16, saved by the forward */
   void* dz;               /* [M][F] bf16 out */
-  void* dxn;              /* [M][256] bf16 out */
+  void* dxn;              /* [M][256] bf16 out (required unless ln_x is given) */
   int32_t d;              /* must be 256 */
   int32_t M, F;
   int32_t act;            /* S2T_ACT_NONE | RELU | SWISH */
   float alpha;
   float drop_h_p; uint32_t drop_h_site;
   const uint64_t* drop_seed;
+  const void* ln_x;       /* [M][256] bf16 input of the leading LayerNorm, or NULL */
+  const float* ln_gamma; const float* ln_mean; const float* ln_rstd;
+  const void* dres;       /* [M][256] bf16 residual-branch gradient added to dx, or NULL */
+  float* ln_ws; int32_t ln_replicas;
+  void* dx;               /* [M][256] bf16 out */
+  void* dx_drop;          /* optional [M][256] bf16 */
+  float up_drop_p; uint32_t up_drop_site;
 } s2t_ffn_bwd_args;
 int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* args, void* stream);
 

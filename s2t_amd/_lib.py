@@ -73,6 +73,9 @@ class FfnBwdArgs(C.Structure):
         ("dy", C.c_void_p), ("w2t", C.c_void_p), ("w1t", C.c_void_p), ("z", C.c_void_p), ("dz", C.c_void_p),
         ("dxn", C.c_void_p), ("d", C.c_int32), ("M", C.c_int32), ("F", C.c_int32), ("act", C.c_int32),
         ("alpha", C.c_float), ("drop_h_p", C.c_float), ("drop_h_site", C.c_uint32), ("drop_seed", C.c_void_p),
+        ("ln_x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p),
+        ("dres", C.c_void_p), ("ln_ws", C.c_void_p), ("ln_replicas", C.c_int32), ("dx", C.c_void_p),
+        ("dx_drop", C.c_void_p), ("up_drop_p", C.c_float), ("up_drop_site", C.c_uint32),
     ]
 
 

@@ -562,39 +562,42 @@ extern "C" int s2t_clip_coef(const float* sumsq, float max_norm, float mult, flo
   return S2T_LAUNCH_CHECK();
 }
 
-// n bf16 matrices transposed by one launch: 64 x 64 tiles through LDS, grid (column tiles, row tiles, matrix)
+// n bf16 matrices transposed by one launch: 64 x 64 tiles, each thread turns 2 x 2 element blocks in registers so that
+// every global and LDS access moves 4 bytes; grid (column tiles, row tiles, matrix)
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const s2t_transpose_item* __restrict__ items) {
-  __shared__ bf16_t tile[64][66];
+  __shared__ uint32_t tile[64][33];  // [output row in tile][pair of output columns]
   const s2t_transpose_item it = items[blockIdx.z];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   if (r0 >= it.rows || c0 >= it.cols) return;
   const bf16_t* src = reinterpret_cast<const bf16_t*>(it.src);
   bf16_t* dst = reinterpret_cast<bf16_t*>(it.dst);
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 2 elements per thread and pass, 8 rows per pass
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const bool src32 = (it.cols & 1) == 0, dst32 = (it.rows & 1) == 0;
+  auto ld2 = [&](int r, int c) -> uint32_t {  // elements (r, c) | (r, c + 1) << 16, zero outside
+    if (r >= it.rows || c >= it.cols) return 0u;
+    const bf16_t* q = src + (int64_t)r * it.cols + c;
+    if (src32 && c + 1 < it.cols) return *reinterpret_cast<const uint32_t*>(q);
+    return (uint32_t)q[0] | (c + 1 < it.cols ? (uint32_t)q[1] << 16 : 0u);
+  };
 #pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    const int r = r0 + 8 * ps + ty, c = c0 + 2 * tx;
-    uint32_t v = 0;
-    if (r < it.rows) {
-      if (c + 1 < it.cols && (it.cols & 1) == 0) v = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * it.cols + c);
-      else {
-        if (c < it.cols) v = src[(int64_t)r * it.cols + c];
-        if (c + 1 < it.cols) v |= (uint32_t)src[(int64_t)r * it.cols + c + 1] << 16;
-      }
-    }
-    tile[8 * ps + ty][2 * tx] = (bf16_t)(v & 0xffffu);
-    tile[8 * ps + ty][2 * tx + 1] = (bf16_t)(v >> 16);
+  for (int ps = 0; ps < 4; ++ps) {
+    const int rp = 8 * ps + ty;
+    const uint32_t a = ld2(r0 + 2 * rp, c0 + 2 * tx), b = ld2(r0 + 2 * rp + 1, c0 + 2 * tx);
+    tile[2 * tx][rp] = (a & 0xffffu) | (b << 16);
+    tile[2 * tx + 1][rp] = (a >> 16) | (b & 0xffff0000u);
   }
   __syncthreads();
 #pragma unroll
   for (int ps = 0; ps < 8; ++ps) {
-    const int c = c0 + 8 * ps + ty, r = r0 + 2 * tx;  // output row c, output columns r, r + 1
-    if (c < it.cols) {
-      const uint32_t lo = tile[2 * tx][8 * ps + ty], hi = tile[2 * tx + 1][8 * ps + ty];
-      if (r + 1 < it.rows && (it.rows & 1) == 0) *reinterpret_cast<uint32_t*>(dst + (int64_t)c * it.rows + r) = lo | (hi << 16);
+    const int orow = 8 * ps + ty;
+    const int c = c0 + orow, r = r0 + 2 * tx;  // output row c, output columns r, r + 1
+    if (c < it.cols && r < it.rows) {
+      const uint32_t v = tile[orow][tx];
+      bf16_t* q = dst + (int64_t)c * it.rows + r;
+      if (dst32 && r + 1 < it.rows) *reinterpret_cast<uint32_t*>(q) = v;
       else {
-        if (r < it.rows) dst[(int64_t)c * it.rows + r] = (bf16_t)lo;
-        if (r + 1 < it.rows) dst[(int64_t)c * it.rows + r + 1] = (bf16_t)hi;
+        q[0] = (bf16_t)(v & 0xffffu);
+        if (r + 1 < it.rows) q[1] = (bf16_t)(v >> 16);
       }
     }
   }

@@ -17,6 +17,7 @@
 #include <utility>
 
 #include "gemm_common.h"
+#include "lds_dma.h"
 
 namespace {
 
@@ -281,7 +282,222 @@ __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const s2t_wgr
   }
 }
 
+// ===============================================================================================================
+// The same work list on 256 x 256 output tiles fed by LDS-DMA (s2t_wgrad_grouped256).
+//
+// Why a second kernel: at 128 x 128 per workgroup the register-staged loop above moves 32 KiB per 64-row K-step per
+// workgroup through the vector-memory path (64 B/clk/CU with two workgroups per CU = all of it) and writes it to LDS with
+// ds_write_b128 (~79 B/clk/CU), both at the rate the MFMAs need it: three saturated pipes, 16-22 % of the MFMA peak.
+// Here one workgroup of 8 waves owns a 256 x 256 tile (wave: 128 dW rows x 64 dW columns, 8 x 4 accumulator tiles =
+// 128 VGPRs): half the operand bytes per flop, no staging registers and no LDS stores — both operands are K-major
+// ([k][column] rows, exactly the LDS image the transposing ds_read_b64_tr_b16 fragment reads want), so buffer_load ... lds
+// drops 512-byte k-rows of a tile straight into place (the XOR swizzle of the 16-byte chunks rides on the per-lane SOURCE
+// address).  Four 32 KiB stages of 32 k-rows each (A part 16 KiB | B part 16 KiB): the DMA runs three steps ahead,
+// counted vmcnt + one barrier per step.  Bias gradients: column sums of the A part read back from LDS (two 16-byte reads
+// per thread and step, only for tile column 0).  Operand rows beyond K and everything beyond the end of an operand read as
+// zero through the buffer descriptor's bounds; columns beyond M / N only feed accumulators that are never stored.
+// Requirements (checked by the host): bf16, lda % 8 == 0, ldb % 8 == 0, 16-byte aligned operands spanning < 2 GiB.
+constexpr int T2 = 256;
+constexpr int BK2 = 32;
+constexpr int NST = 4;
+constexpr int PART2 = BK2 * T2 * 2;   // 16 KiB: one operand's 32 k-rows of 512 B
+constexpr int STAGE2 = 2 * PART2;     // 32 KiB
+
+__global__ __launch_bounds__(512, 2) void wgrad256_kernel(const s2t_wgrad_problem* __restrict__ probs,
+                                                          const Item* __restrict__ items, int n_items,
+                                                          float* __restrict__ ws) {
+  typedef bf16_t T;
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int x = lane & 15, y = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  const int G = gridDim.x;
+  int w = blockIdx.x;
+  if ((G & 7) == 0) w = (w & 7) * (G >> 3) + (w >> 3);  // XCD-contiguous item ranges
+  if (w >= n_items) return;
+  const int my_items = (n_items - w + G - 1) / G;
+
+  // ---- fragment read offsets inside a part (bytes).  16-column block blk of the tile, lane (x, y): k-rows 8y + 4 half + q
+  // (q = x >> 2), columns 16 blk + 4 (x & 3) .. +4; chunk (2 blk + ((x&3) >> 1)) ^ kswz(row), kswz depends on q and y & 1
+  // only, so the second half is the first + 4 rows (2048 B).
+  uint32_t offA[8], offB[4];
+  {
+    const int q = x >> 2, pb = x & 3;
+    const int key = 2 * (q | ((y & 1) << 2));
+    const uint32_t base = (uint32_t)((8 * y + q) * 512 + 16 * (pb >> 1) + 8 * (pb & 1));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) offA[i] = base + 16u * (uint32_t)((16 * wm + 2 * i) ^ key);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offB[j] = base + 16u * (uint32_t)((8 * wn + 2 * j) ^ key);
+  }
+  // ---- DMA plan: instruction i of wave w covers k-rows 4w + 2i, +1 of a part (lane l: row + (l >> 5), slot l & 31 holds
+  // chunk (l & 31) ^ kswz(row)); kswz(4w + 2i + hi) = 2 * ((2i + hi) | (((w >> 1) & 1) << 2))
+  const int hi = lane >> 5, sl = lane & 31;
+  const int key0 = 2 * (hi | (((wave >> 1) & 1) << 2));
+  const uint32_t cp0 = 16u * (uint32_t)(sl ^ key0), cp1 = cp0 ^ 64u;  // i = 1: key ^ 4
+  const int r0 = 4 * wave + hi;
+  const uint32_t ldsw = lds0 + (uint32_t)(4 * wave) * 512u;
+  // ---- bias-gradient read: thread (c = tid & 31, rr = tid >> 5) sums chunk c of k-rows rr and rr + 16
+  const uint32_t offC = (uint32_t)((tid >> 5) * 512 + 16 * ((tid & 31) ^ kswz(tid >> 5)));
+
+  f32x4 acc[8][4];
+  float csum[8];
+  int sc = 0;  // running step counter (stage rotation)
+  for (int ord = 0; ord < my_items; ++ord) {
+    const Item it = items[w + ord * G];
+    const s2t_wgrad_problem* p = probs + it.prob;
+    const int K = p->K;
+    const uint32_t lda2 = (uint32_t)(p->lda * 2), ldb2 = (uint32_t)(p->ldb * 2);
+    const int ktiles = (K + BK2 - 1) / BK2;
+    const int kt0 = it.split * p->ksteps;
+    const int nst = min(ktiles, kt0 + p->ksteps) - kt0;
+    const bool do_cs = p->colsum != nullptr && it.tn == 0;
+    // descriptors: base moved to the tile's first column, bounds at the end of the operand (K rows)
+    const int64_t a_bytes = (int64_t)K * lda2 - (int64_t)it.tm * (T2 * 2);
+    const int64_t b_bytes = (int64_t)K * ldb2 - (int64_t)it.tn * (T2 * 2);
+    const i32x4 srdA = make_srd(reinterpret_cast<const char*>(p->A) + (int64_t)it.tm * (T2 * 2), (uint32_t)(a_bytes > 0 ? a_bytes : 0));
+    const i32x4 srdB = make_srd(reinterpret_cast<const char*>(p->B) + (int64_t)it.tn * (T2 * 2), (uint32_t)(b_bytes > 0 ? b_bytes : 0));
+    const uint32_t vA0 = (uint32_t)r0 * lda2 + cp0, vA1 = (uint32_t)(r0 + 2) * lda2 + cp1;
+    const uint32_t vB0 = (uint32_t)r0 * ldb2 + cp0, vB1 = (uint32_t)(r0 + 2) * ldb2 + cp1;
+    auto issue = [&](int kt, int st) __attribute__((always_inline)) {
+      const uint32_t la = ldsw + (uint32_t)st * STAGE2;
+      const uint32_t sa = (uint32_t)kt * (BK2 * lda2), sb = (uint32_t)kt * (BK2 * ldb2);
+      dma16(la, vA0, srdA, sa);
+      dma16(la + 1024, vA1, srdA, sa);
+      dma16(la + PART2, vB0, srdB, sb);
+      dma16(la + PART2 + 1024, vB1, srdB, sb);
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    // every wave is done with the previous item's stages (and its LDS scratch) before new rows land in them
+    __syncthreads();
+    for (int u = 0; u < 3; ++u)
+      if (u < nst) issue(kt0 + u, (sc + u) & (NST - 1));
+    for (int t = 0; t < nst; ++t) {
+      const int rem = nst - 1 - t;  // steps issued after this one
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (t + 3 < nst) issue(kt0 + t + 3, (sc + t + 3) & (NST - 1));
+      const char* pa = smem + ((sc + t) & (NST - 1)) * STAGE2;
+      const char* pb = pa + PART2;
+      auto tr8 = [&](const char* a) __attribute__((always_inline)) -> Frag {
+        typedef __attribute__((address_space(3))) s16x4* lptr;
+        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a)));
+        const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 2048)));
+        Frag f;
+        f.v = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+        return f;
+      };
+      Frag fa[8], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = tr8(pb + offB[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = tr8(pa + offA[i]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], fb[j], fa[i]);
+      if (do_cs) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const uint4 v = *reinterpret_cast<const uint4*>(pa + offC + h2 * 8192);
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            csum[2 * q4] += __uint_as_float(w4[q4] << 16);
+            csum[2 * q4 + 1] += __uint_as_float(w4[q4] & 0xffff0000u);
+          }
+        }
+      }
+    }
+    sc += nst;
+    // ---- partial tile -> workspace in register-native order; bias-gradient partial -> atomics
+    const int tile = it.tm * p->tiles_n + it.tn;
+    float* wt = ws + p->ws_base + ((int64_t)tile * p->nsplit + it.split) * (int64_t)(T2 * T2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(wt + ((i * 4 + j) * 512 + tid) * 4) = acc[i][j];
+    if (do_cs) {  // workgroup-uniform
+      __syncthreads();  // all fragment reads of the last stage are done: the stages are scratch now
+      float* lc = reinterpret_cast<float*>(smem);  // [16 row groups][256 columns]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lc[(tid >> 5) * 256 + 8 * (tid & 31) + e] = csum[e];
+      __syncthreads();
+      if (tid < 256) {
+        float sum = 0.f;
+#pragma unroll
+        for (int gI = 0; gI < 16; ++gI) sum += lc[gI * 256 + tid];
+        const int m = it.tm * T2 + tid;
+        if (m < p->M) atomicAdd(p->colsum + m, p->alpha * sum);
+      }
+    }
+  }
+}
+
+// dW[m][n] += alpha * sum_split partial[tile][split] for the 256 x 256 tiles: one workgroup per (tile, accumulator fragment)
+__global__ __launch_bounds__(512) void wgrad256_reduce_kernel(const s2t_wgrad_problem* __restrict__ probs,
+                                                              const TileRef* __restrict__ tiles,
+                                                              const float* __restrict__ ws) {
+  const TileRef t = tiles[blockIdx.x];
+  const s2t_wgrad_problem* p = probs + t.prob;
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1, x = lane & 15, y = lane >> 4;
+  const int i = f >> 2, j = f & 3;
+  const int m = t.tm * T2 + wm * 128 + i * 16 + x;
+  const int n = t.tn * T2 + wn * 64 + j * 16 + 4 * y;
+  const int tile = t.tm * p->tiles_n + t.tn;
+  f32x4 total = {0.f, 0.f, 0.f, 0.f};
+  for (const s2t_wgrad_problem* q = p;;) {  // tied weights: the chain's problems are summed by this one workgroup
+    const float* src = ws + q->ws_base + (int64_t)tile * q->nsplit * (T2 * T2) + (f * 512 + tid) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int s = 0;
+    const int ns = q->nsplit;
+    for (; s + 2 <= ns; s += 2) {
+      s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * (T2 * T2));
+      s1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 1) * (T2 * T2));
+    }
+    for (; s < ns; ++s) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * (T2 * T2));
+    total += (s0 + s1) * q->alpha;
+    if (q->next < 0) break;
+    q = probs + q->next;
+  }
+  if (m < p->M && n < p->N) {
+    float* dst = p->C + (int64_t)m * p->ldc + n;
+    if (n + 3 < p->N && (p->ldc & 3) == 0 && (((uintptr_t)p->C) & 15) == 0) {
+      f32x4 c = *reinterpret_cast<f32x4*>(dst);
+      c += total;
+      *reinterpret_cast<f32x4*>(dst) = c;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p->N) dst[r] += total[r];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int s2t_wgrad_grouped256(const s2t_wgrad_problem* problems_dev, int n_problems, const int32_t* items_dev,
+                                    int n_items, const int32_t* tiles_dev, int n_tiles, float* ws, void* stream) {
+  if (!problems_dev || !items_dev || !tiles_dev || !ws || n_problems <= 0 || n_items <= 0 || n_tiles <= 0) return S2T_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int slots = s2t_device_cu_count();  // 128 KiB of LDS per workgroup: one per CU
+  dim3 grid(n_items < slots ? n_items : slots), block(512);
+  hipLaunchKernelGGL(wgrad256_kernel, grid, block, 0, s, problems_dev, reinterpret_cast<const Item*>(items_dev), n_items, ws);
+  hipLaunchKernelGGL(wgrad256_reduce_kernel, dim3(n_tiles, 32), dim3(512), 0, s, problems_dev,
+                     reinterpret_cast<const TileRef*>(tiles_dev), ws);
+  return S2T_LAUNCH_CHECK();
+}
 
 extern "C" int s2t_wgrad_grouped(const s2t_wgrad_problem* problems_dev, int n_problems, const int32_t* items_dev,
                                  int n_items, const int32_t* tiles_dev, int n_tiles, float* ws, int any_k_tail,

@@ -27,6 +27,7 @@
 //   The two fh halves of a row block hold partial Y sums; they meet in LDS (the weight buffers, free by then) where
 //   the final row-wise epilogue runs on whole 512-byte rows (coalesced stores, LayerNorm statistics by shuffles).
 #include "common.h"
+#include "lds_dma.h"
 
 #ifndef S2T_RB_DBG
 #define S2T_RB_DBG 0  // kernel-experiment switches (tools/rb_dbg_build.sh): 1 no DMA inside the loop, 2 no MFMAs, 4 no E1,
@@ -46,31 +47,20 @@ constexpr int LDS_Z = LDS_MBOX + 16384;  // backward: two 8 KiB stages of the pr
 constexpr int MAXF = 1 << 20;
 constexpr int LDS_BYTES = LDS_MBOX + 32768;   // 160 KiB in all
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// One LDS-DMA instruction: 64 lanes x 16 bytes, global (srd base + voff + soff) -> LDS (lds_base + lane*16).
-// The compiler neither counts nor waits for it: every wait below is a hand-placed counted vmcnt.
-__device__ __forceinline__ void dma16(uint32_t lds_base, uint32_t voff, i32x4 srd, uint32_t soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory");
-}
-
-// the same with an instruction offset (0..4095) that moves BOTH the global source and the LDS destination
-template <int OFF>
-__device__ __forceinline__ void dma16_off(uint32_t lds_base, uint32_t voff, i32x4 srd, uint32_t soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:%4 lds"
-               :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff), "i"(OFF) : "memory");
-}
-
-__device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
-  const uint64_t b = (uint64_t)base;
-  i32x4 s;
-  s.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-  s.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
-  s.z = __builtin_amdgcn_readfirstlane((int)bytes);
-  s.w = __builtin_amdgcn_readfirstlane(0x00020000);
-  return s;
-}
+// kernel arguments: the forward's public struct + what only the backward flavour uses (LayerNorm backward in the epilogue)
+struct FfnK : s2t_ffn_args {
+  const void* lb_x;        // [M][256] bf16 input of the leading LayerNorm (NULL: the epilogue stores dxn as it is)
+  const float* lb_gamma;
+  const float* lb_mean;
+  const float* lb_rstd;
+  const void* lb_dres;     // gradient arriving on the residual branch, added to dx (may be NULL)
+  float* lb_ws;            // [replicas][2][256] fp32 partial sums of dgamma | dbeta (atomics)
+  int lb_replicas;
+  void* lb_dx;             // [M][256] bf16
+  void* lb_dx_drop;        // optional dropout(dx) under the mask (lb_drop_p, lb_drop_site)
+  float lb_drop_p;
+  uint32_t lb_drop_site;
+};
 
 __device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -112,7 +102,7 @@ __device__ __forceinline__ int w1key(int r) { return (r & 3) | (((r >> 3) & 3) <
 //   (the Z tile of the chunk arrives by one LDS-DMA instruction per wave, a chunk ahead), the single save is dZ (operand of
 //   the W1 weight gradient), there is no LayerNorm prologue, bias or output dropout.
 template <int MODE, int ACT, bool DROP>
-__global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_args p) {
+__global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
   constexpr bool TRAIN = MODE == 1, BWD = MODE == 2;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   const int tid = threadIdx.x;
@@ -598,6 +588,98 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const s2t_ffn_arg
         eb[q][0] = b.x; eb[q][1] = b.y; eb[q][2] = b.z; eb[q][3] = b.w;
       }
     }
+    if constexpr (BWD) {
+      if (p.lb_x) {
+        // ---- backward of the block's leading LayerNorm on the fp32 dXn rows (s2t_layernorm_bwd's arithmetic):
+        //   dx = rstd * (dxn*gamma - mean(dxn*gamma) - xhat * mean(dxn*gamma*xhat)) + dres   [+ its dropped copy]
+        //   dgamma += sum_rows dxn * xhat, dbeta += sum_rows dxn: lane sums over its 4 rows, 16 (wave, half) groups meet
+        //   in LDS (the mailbox region, idle by now), 512 atomics per workgroup into one replica of the workspace
+        const bf16_t* X = reinterpret_cast<const bf16_t*>(p.lb_x);
+        const bf16_t* DR = reinterpret_cast<const bf16_t*>(p.lb_dres);
+        bf16_t* DX = reinterpret_cast<bf16_t*>(p.lb_dx);
+        bf16_t* DXD = reinterpret_cast<bf16_t*>(p.lb_dx_drop);
+        const uint64_t key_u = DXD ? s2t_drop_key(p.drop_seed, p.lb_drop_site) : 0ull;
+        const uint32_t th_u = s2t_drop_thresh(p.lb_drop_p);
+        const float inv_u = s2t_drop_scale(p.lb_drop_p);
+        float gmm[2][4], ag[2][4], ab[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(p.lb_gamma + 128 * q + 4 * s);
+          gmm[q][0] = t.x; gmm[q][1] = t.y; gmm[q][2] = t.z; gmm[q][3] = t.w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ag[q][r] = ab[q][r] = 0.f;
+        }
+#pragma unroll 2
+        for (int ps = 0; ps < 4; ++ps) {
+          const int ml = 8 * wave + 2 * ps + hi;
+          const int m = row0 + ml;
+          const bool live = m < M;
+          const int mc = live ? m : M - 1;
+          const float mu = p.lb_mean[mc], rs = p.lb_rstd[mc];
+          float dv[2][4], xh[2][4], dg[2][4], rr[2][4];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int cc = 32 * q + s;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(smem + ml * 1024 + 16 * (cc ^ (ml & 7)));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(smem + 65536 + ml * 1024 + 16 * (cc ^ (ml & 7)));
+            float xv[4];
+            ld4_as_f32<bf16_t>(X + (int64_t)mc * D + 128 * q + 4 * s, xv);
+            if (DR) ld4_as_f32<bf16_t>(DR + (int64_t)mc * D + 128 * q + 4 * s, rr[q]);
+            else rr[q][0] = rr[q][1] = rr[q][2] = rr[q][3] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              dv[q][r] = live ? a[r] + b[r] : 0.f;
+              xh[q][r] = (xv[r] - mu) * rs;
+              dg[q][r] = dv[q][r] * gmm[q][r];
+              s1 += dg[q][r];
+              s2 += dg[q][r] * xh[q][r];
+              ag[q][r] += dv[q][r] * xh[q][r];
+              ab[q][r] += dv[q][r];
+            }
+          }
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+          }
+          s1 *= 1.0f / D;
+          s2 *= 1.0f / D;
+          if (live) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              float o4[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o4[r] = bf2f(f2bf(rs * (dg[q][r] - s1 - xh[q][r] * s2) + rr[q][r]));
+              st4_from_f32<bf16_t>(DX + (int64_t)m * D + 128 * q + 4 * s, o4);
+              if (DXD) {  // the dropped image of the STORED bf16 dx, as s2t_dropout would make it
+                uint32_t r16[4];
+                s2t_rand_run<4>(key_u, (uint64_t)m * D + (uint64_t)(128 * q + 4 * s), r16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] = r16[r] >= th_u ? o4[r] * inv_u : 0.f;
+                st4_from_f32<bf16_t>(DXD + (int64_t)m * D + 128 * q + 4 * s, o4);
+              }
+            }
+          }
+        }
+        float* red = reinterpret_cast<float*>(smem + LDS_MBOX);  // [2][16][256] fp32 = 32 KiB
+        const int grp = 2 * wave + hi;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          *reinterpret_cast<float4*>(red + (0 * 16 + grp) * 256 + 128 * q + 4 * s) = make_float4(ag[q][0], ag[q][1], ag[q][2], ag[q][3]);
+          *reinterpret_cast<float4*>(red + (1 * 16 + grp) * 256 + 128 * q + 4 * s) = make_float4(ab[q][0], ab[q][1], ab[q][2], ab[q][3]);
+        }
+        __syncthreads();
+        {
+          const int which = tid >> 8, c = tid & 255;
+          float sum = 0.f;
+#pragma unroll
+          for (int gI = 0; gI < 16; ++gI) sum += red[(which * 16 + gI) * 256 + c];
+          atomicAdd(p.lb_ws + (int64_t)(blockIdx.x % p.lb_replicas) * 512 + which * 256 + c, sum);
+        }
+        return;
+      }
+    }
 #pragma unroll 2
     for (int ps = 0; ps < 4; ++ps) {
       const int ml = 8 * wave + 2 * ps + hi;
@@ -946,7 +1028,9 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   const dim3 grid((a->M + TM - 1) / TM), block(512);
   hipStream_t s = (hipStream_t)stream;
   const bool drop = a->drop_h_p > 0.f || a->drop_o_p > 0.f;
-#define GO(T, A, DR) hipLaunchKernelGGL((ffn_fused_fwd_kernel<T, A, DR>), grid, block, 0, s, *a)
+  FfnK k = {};
+  static_cast<s2t_ffn_args&>(k) = *a;
+#define GO(T, A, DR) hipLaunchKernelGGL((ffn_fused_fwd_kernel<T, A, DR>), grid, block, 0, s, k)
 #define GO_A(T, DR)                                     \
   do {                                                  \
     if (a->act == S2T_ACT_RELU) GO(T, S2T_ACT_RELU, DR); \
@@ -964,18 +1048,33 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
 }
 
 extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
-  if (!b || !b->dy || !b->w2t || !b->w1t || !b->z || !b->dz || !b->dxn) return S2T_ERR_ARG;
+  if (!b || !b->dy || !b->w2t || !b->w1t || !b->z || !b->dz) return S2T_ERR_ARG;
+  if (b->ln_x) {
+    if (!b->ln_gamma || !b->ln_mean || !b->ln_rstd || !b->ln_ws || b->ln_replicas <= 0 || !b->dx) return S2T_ERR_ARG;
+    if (b->dx_drop && (b->up_drop_p <= 0.f || b->up_drop_p >= 1.f || !b->drop_seed)) return S2T_ERR_ARG;
+  } else if (!b->dxn) return S2T_ERR_ARG;
   if (b->M <= 0 || b->F <= 0) return S2T_ERR_ARG;
   if (b->d != D) return S2T_ERR_UNSUPPORTED;
   if (b->F % FC || b->F > MAXF) return S2T_ERR_UNSUPPORTED;
   if ((int64_t)b->M * b->F * 2 >= ((int64_t)1 << 32)) return S2T_ERR_UNSUPPORTED;  // 32-bit byte offsets into Z / dZ
   if (b->act != S2T_ACT_NONE && b->act != S2T_ACT_RELU && b->act != S2T_ACT_SWISH) return S2T_ERR_ARG;
   if (b->drop_h_p < 0.f || b->drop_h_p >= 1.f || (b->drop_h_p > 0.f && !b->drop_seed)) return S2T_ERR_ARG;
-  const void* ptrs[] = {b->dy, b->w2t, b->w1t, b->z, b->dz, b->dxn};
+  const void* ptrs[] = {b->dy, b->w2t, b->w1t, b->z, b->dz, b->dxn, b->ln_x, b->ln_gamma, b->dres, b->dx, b->dx_drop};
   for (const void* q : ptrs)
-    if ((uintptr_t)q % 16) return S2T_ERR_ALIGN;
+    if (q && ((uintptr_t)q % 16)) return S2T_ERR_ALIGN;
   // the kernel is the forward one with the transposed weights in the places of W1 / W2 (see MODE 2 there)
-  s2t_ffn_args a = {};
+  FfnK a = {};
+  a.lb_x = b->ln_x;
+  a.lb_gamma = b->ln_gamma;
+  a.lb_mean = b->ln_mean;
+  a.lb_rstd = b->ln_rstd;
+  a.lb_dres = b->dres;
+  a.lb_ws = b->ln_ws;
+  a.lb_replicas = b->ln_replicas;
+  a.lb_dx = b->dx;
+  a.lb_dx_drop = b->dx_drop;
+  a.lb_drop_p = b->up_drop_p;
+  a.lb_drop_site = b->up_drop_site;
   a.x = b->dy;
   a.d = D;
   a.w1 = b->w2t;

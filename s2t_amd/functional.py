@@ -298,6 +298,8 @@ def reserve_wgrad_staging(device, nbytes=8 << 20, count=1):
 
 
 _WG_KSTEPS = int(os.environ.get("S2T_WG_KSTEPS", "64"))  # K-steps (of 64 rows) per work item
+_WG_256 = os.environ.get("S2T_WG_256", "1") != "0"          # s2t_wgrad_grouped256 where the operands allow it
+_WG_KSTEPS256 = int(os.environ.get("S2T_WG_KSTEPS256", "128"))  # its K-steps (of 32 rows) per work item
 _WG_DTYPE = None
 
 
@@ -323,19 +325,23 @@ def flush_wgrads():
         ws_floats = 0
         k_tail = False
         last_of = {}
+        # the LDS-DMA kernel on 256 x 256 tiles (s2t_wgrad_grouped256) when every problem meets its operand layout rules
+        big = _WG_256 and all(ldy % 8 == 0 and ldx % 8 == 0 and dY.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0
+                              and M * ldy * 2 < 2 ** 31 and M * ldx * 2 < 2 ** 31 for (dY, X, _, _, _, M, ldy, ldx, _, _) in q)
+        TL, KS, per_item = (256, 32, _WG_KSTEPS256) if big else (128, 64, _WG_KSTEPS)
         for i, (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db) in enumerate(q):
-            tm_n, tn_n = (Nout + 127) // 128, (Kin + 127) // 128
-            ktiles = (M + 63) // 64
-            nsplit = (ktiles + _WG_KSTEPS - 1) // _WG_KSTEPS
+            tm_n, tn_n = (Nout + TL - 1) // TL, (Kin + TL - 1) // TL
+            ktiles = (M + KS - 1) // KS
+            nsplit = (ktiles + per_item - 1) // per_item
             k_tail |= (M % 64) != 0
             probs[i] = (dY.data_ptr(), X.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, ldy, ldx,
-                        Kin, ws_floats, Nout, Kin, M, tn_n, _WG_KSTEPS, nsplit, alpha, -1)
+                        Kin, ws_floats, Nout, Kin, M, tn_n, per_item, nsplit, alpha, -1)
             prev = last_of.get(dW.data_ptr())  # tied weights: chain the problems, reduce them in one workgroup
             last_of[dW.data_ptr()] = i
             if prev is not None:
                 assert probs[prev]["M"] == Nout and probs[prev]["N"] == Kin
                 probs[prev]["next"] = i
-            ws_floats += tm_n * tn_n * nsplit * 16384
+            ws_floats += tm_n * tn_n * nsplit * TL * TL
             # order: K split, tile row, tile column — the ~64 items an XCD works on at a time then read the SAME K-range
             # of both operands (its 4 MiB L2 serves the re-reads; measured 15 GB -> fabric traffic per launch before)
             t = np.empty((nsplit, tm_n, tn_n, 4), dtype=np.int32)
@@ -395,7 +401,10 @@ def flush_wgrads():
         o1 = probs.nbytes
         o2 = o1 + items.nbytes
         ws = K._scratch("wgrad_grouped", ws_floats, dev)
-        K.wgrad_grouped(devb, len(q), devb[o1:], items.shape[0], devb[o2:], tiles.shape[0], ws, k_tail)
+        if big:
+            K.wgrad_grouped256(devb, len(q), devb[o1:], items.shape[0], devb[o2:], tiles.shape[0], ws)
+        else:
+            K.wgrad_grouped(devb, len(q), devb[o1:], items.shape[0], devb[o2:], tiles.shape[0], ws, k_tail)
         if slot_ev is not None:
             ev = torch.cuda.Event()
             ev.record()
@@ -667,14 +676,26 @@ class FFNBlockFn(torch.autograd.Function):
             dy = _drop_rows(dres, drop_o)
         # dZ = alpha * dropout_h(dY @ W2) * act'(Z), dXn = dZ @ W1
         dz = torch.empty(M, F_, dtype=x.dtype, device=x.device)
-        dxl = torch.empty_like(x)
+        dxd = torch.empty_like(x) if ctx.up_drop is not None else None
+        dx = None
         if _FFN_FUSED_BWD and getattr(w1, "_s2t_flat", None) is not None and w1._s2t_flat.shadow is not None \
                 and getattr(w2, "_s2t_flat", None) is w1._s2t_flat and M * F_ * 2 < 2 ** 32:
             if queued and w1._s2t_flat not in _BE["flats"]:
                 _BE["flats"].append(w1._s2t_flat)
             w2t, w1t = transposed(w2, queued), transposed(w1, queued)
-            K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxl, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h)
+            if queued:  # the leading LayerNorm's backward rides in the kernel's epilogue (parameter sums through the fold)
+                dx = torch.empty_like(x)
+                ws = _ln_workspace(d, x.device)
+                K.ffn_fused_bwd(dy, w2t, w1t, z, dz, None, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h,
+                                ln=dict(x=x, gamma=gamma.data, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, dx_drop=dxd,
+                                        drop=ctx.up_drop))
+                _LNQ["entries"].append((ws, gamma.grad, beta.grad, d))
+                _ready(gamma, beta)
+            else:
+                dxl = torch.empty_like(x)
+                K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxl, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h)
         else:
+            dxl = torch.empty_like(x)
             K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
                    dact=ctx.act, drop=drop_h)
             K.gemm(dz, cw(w1), dxl, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
@@ -682,8 +703,8 @@ class FFNBlockFn(torch.autograd.Function):
         _ready(w2, b2)
         _wgrad(dz, x_ln, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)
         _ready(w1, b1)
-        dxd = torch.empty_like(x) if ctx.up_drop is not None else None
-        dx = ln_bwd(x, gamma, beta, dxl, mean, rstd, None, 0, dres, dxd, ctx.up_drop)
+        if dx is None:
+            dx = ln_bwd(x, gamma, beta, dxl, mean, rstd, None, 0, dres, dxd, ctx.up_drop)
         if dxd is not None:
             _hand_over(dx, ctx.up_drop, dxd)
         return (dx,) + (None,) * 15

@@ -138,19 +138,31 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
 
 
-def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None):
+def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=None):
     """s2t_ffn_fused_bwd (include/s2t_hip.h): dz = alpha * drop_h((dy W2) * act'(z)), dxn = dz W1, from the transposed
-    weight copies ``w2t`` [F, 256] and ``w1t`` [256, F]."""
+    weight copies ``w2t`` [F, 256] and ``w1t`` [256, F].  ``ln`` = dict(x, gamma, mean, rstd, ws, dx[, dres, dx_drop, drop])
+    adds the backward of the block's leading LayerNorm (``dxn`` may then be None)."""
     L.require_cuda(dy, w2t, w1t, z, dz, dxn)
     M, d = dy.shape
     F = w2t.shape[0]
-    assert w2t.shape == (F, d) and w1t.shape == (d, F) and z.shape == (M, F) and dz.shape == (M, F) and dxn.shape == (M, d)
-    assert all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in (dy, w2t, w1t, z, dz, dxn))
+    assert w2t.shape == (F, d) and w1t.shape == (d, F) and z.shape == (M, F) and dz.shape == (M, F)
+    assert dxn is None or dxn.shape == (M, d)
+    assert all(t is None or (t.dtype == torch.bfloat16 and t.is_contiguous()) for t in (dy, w2t, w1t, z, dz, dxn))
     a = L.FfnBwdArgs()
-    a.dy, a.w2t, a.w1t, a.z, a.dz, a.dxn = (t.data_ptr() for t in (dy, w2t, w1t, z, dz, dxn))
+    a.dy, a.w2t, a.w1t, a.z, a.dz, a.dxn = (_ptr(t) for t in (dy, w2t, w1t, z, dz, dxn))
     a.d, a.M, a.F, a.act, a.alpha = d, M, F, L.ACT_IDS[act], alpha
     if drop_h is not None and drop_h[0] > 0:
         a.drop_h_p, a.drop_h_site, a.drop_seed = float(drop_h[0]), int(drop_h[2]), drop_h[1].data_ptr()
+    if ln is not None:
+        x, dx = ln["x"], ln["dx"]
+        assert x.shape == (M, d) and dx.shape == (M, d) and x.dtype == torch.bfloat16 and x.is_contiguous() and dx.is_contiguous()
+        assert ln["ws"].numel() >= LN_REPLICAS * 2 * d and ln["gamma"].dtype == torch.float32
+        a.ln_x, a.ln_gamma, a.ln_mean, a.ln_rstd = x.data_ptr(), ln["gamma"].data_ptr(), ln["mean"].data_ptr(), ln["rstd"].data_ptr()
+        a.dres, a.ln_ws, a.ln_replicas, a.dx = _ptr(ln.get("dres")), ln["ws"].data_ptr(), LN_REPLICAS, dx.data_ptr()
+        if ln.get("dx_drop") is not None:
+            dr = ln["drop"]
+            assert a.drop_seed is None or a.drop_seed == dr[1].data_ptr()
+            a.dx_drop, a.up_drop_p, a.up_drop_site, a.drop_seed = ln["dx_drop"].data_ptr(), float(dr[0]), int(dr[2]), dr[1].data_ptr()
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -511,6 +523,11 @@ def specaugment(x, n_frames, masks, n_freq, n_time, value, value_is_mean):
     assert x.dtype == torch.float32 and x.is_contiguous() and masks.dtype == torch.int32 and value.dtype == torch.float32
     _call("s2t_specaugment", x.data_ptr(), n_frames.data_ptr(), T * Cf, B, T, Cf, masks.data_ptr(), n_freq, n_time,
           value.data_ptr(), int(value_is_mean))
+
+
+def wgrad_grouped256(problems, n_problems, items, n_items, tiles, n_tiles, ws):
+    _call("s2t_wgrad_grouped256", problems.data_ptr(), n_problems, items.data_ptr(), n_items, tiles.data_ptr(), n_tiles,
+          ws.data_ptr())
 
 
 def wgrad_grouped(problems, n_problems, items, n_items, tiles, n_tiles, ws, any_k_tail):

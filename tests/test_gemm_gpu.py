@@ -185,13 +185,18 @@ def test_splitk_workspace_matches_atomics_and_reference(dtype):
     np.testing.assert_allclose(dp.cpu().double().numpy(), refp.numpy(), rtol=1e-3, atol=1e-3 * refp.abs().max().item())
 
 
-def test_grouped_wgrad_matches_reference():
+@pytest.mark.parametrize("variant", ["tiles128", "tiles256_dma"])
+def test_grouped_wgrad_matches_reference(variant, monkeypatch):
     """csrc/gemm_grouped.hip through functional.flush_wgrads: several weight gradients of different shapes (ragged tiles,
-    K tails, bias gradients, alpha, accumulation into non-zero dW) in one launch vs float64."""
+    K tails, bias gradients, alpha, accumulation into non-zero dW) in one launch vs float64 — the register-staged
+    128 x 128 kernel and the LDS-DMA fed 256 x 256 one (s2t_wgrad_grouped256; there also an FFN-sized problem, a K range
+    that ends inside a 32-row step and operands that are column slices of a wider buffer)."""
     from s2t_amd import functional as Fn
+    monkeypatch.setattr(Fn, "_WG_256", variant == "tiles256_dma")
     g = torch.Generator().manual_seed(9)
     dev = "cuda"
-    specs = [(300, 200, 2100, 1.0, True), (128, 128, 64, 0.5, False), (40, 520, 4000, 1.0, True), (256, 256, 6464, 2.0, True)]
+    specs = [(300, 200, 2100, 1.0, True), (128, 128, 64, 0.5, False), (40, 520, 4000, 1.0, True), (256, 256, 6464, 2.0, True),
+             (2048, 256, 9011, 1.0, True), (256, 2048, 4100, 0.5, True)]
     probs, refs = [], []
     for Nout, Kin, M, alpha, bias in specs:
         ldy, ldx = (Nout + 7) // 8 * 8, (Kin + 7) // 8 * 8
@@ -207,9 +212,20 @@ def test_grouped_wgrad_matches_reference():
     dY2[:, 300:] = 0
     tied = (dY2.to(dev), X2.to(dev), probs[0][2], 300, 200, 1000, 304, 200, 3.0, None)
     refs[0] = (refs[0][0] + 3.0 * dY2[:, :300].double().t() @ X2.double(), refs[0][1])
-    Fn._WGQ["probs"] = list(probs) + [tied]
+    # + the three column slices of a fused [rows, 768] gradient against one input (the q / k / v projections)
+    dqkv = _mk((3000, 768), torch.bfloat16, g).to(dev)
+    xin = _mk((3000, 256), torch.bfloat16, g).to(dev)
+    sl_w = [torch.zeros(256, 256, dtype=torch.float32, device=dev) for _ in range(3)]
+    sl_b = [torch.zeros(256, dtype=torch.float32, device=dev) for _ in range(3)]
+    slices = [(dqkv[:, 256 * i:], xin, sl_w[i], 256, 256, 3000, 768, 256, 1.0, sl_b[i]) for i in range(3)]
+    Fn._WGQ["probs"] = list(probs) + [tied] + slices
     Fn.flush_wgrads()
     torch.cuda.synchronize()
+    for i in range(3):
+        rw = dqkv[:, 256 * i:256 * (i + 1)].double().t() @ xin.double()
+        np.testing.assert_allclose(sl_w[i].cpu().double().numpy(), rw.cpu().numpy(), rtol=1e-3, atol=1e-3 * rw.abs().max().item())
+        rb = dqkv[:, 256 * i:256 * (i + 1)].double().sum(0)
+        np.testing.assert_allclose(sl_b[i].cpu().double().numpy(), rb.cpu().numpy(), rtol=1e-3, atol=1e-3 * rb.abs().max().item())
     for (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db), (rw, rb) in zip(probs, refs):
         np.testing.assert_allclose(dW.cpu().double().numpy(), rw.numpy(), rtol=1e-3, atol=1e-3 * rw.abs().max().item())
         if db is not None:

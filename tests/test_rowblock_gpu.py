@@ -204,6 +204,57 @@ def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p):
     assert rel < 1e-2, float(rel)
 
 
+@pytest.mark.parametrize("M,F,up", [(200, 256, False), (4096, 2048, True), (1000, 512, True)])
+def test_ffn_fused_bwd_layernorm_epilogue(M, F, up):
+    """s2t_ffn_fused_bwd with ln_x: dx, its dropped copy and the dgamma / dbeta partial sums against s2t_layernorm_bwd run on
+    the dxn the plain form of the kernel writes (modules/layer_norm.py:30-35 backward + the residual-branch gradient)."""
+    from s2t_amd import functional as Fn
+
+    d = 256
+    g = torch.Generator().manual_seed(M)
+    dy = torch.randn(M, d, generator=g).bfloat16().to(DEV)
+    z = torch.randn(M, F, generator=g).bfloat16().to(DEV)
+    w1t = (torch.randn(d, F, generator=g) * d ** -0.5).bfloat16().to(DEV)
+    w2t = (torch.randn(F, d, generator=g) * F ** -0.5).bfloat16().to(DEV)
+    x = (2 * torch.randn(M, d, generator=g) + 0.3).bfloat16().to(DEV)
+    gam = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    dres = torch.randn(M, d, generator=g).bfloat16().to(DEV)
+    xf = x.float()
+    mean = xf.mean(1)
+    rstd = (xf.var(1, unbiased=False) + 1e-5).rsqrt()
+    Fn.DROPOUT.begin_step(torch.device(DEV))
+    Fn.DROPOUT.set_seed(9)
+    drop_h = Fn.DROPOUT.next(0.1, torch.device(DEV))
+    up_drop = Fn.DROPOUT.next(0.1, torch.device(DEV)) if up else None
+    dz0 = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
+    dxn = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    K.ffn_fused_bwd(dy, w2t, w1t, z, dz0, dxn, act="swish", alpha=0.5, drop_h=drop_h)
+    dx_u = torch.empty_like(x)
+    dxd_u = torch.empty_like(x) if up else None
+    dg_u = torch.zeros(d, device=DEV)
+    db_u = torch.zeros(d, device=DEV)
+    K.layernorm_bwd(x, gam, dxn, mean, rstd, dx_u, dg_u, db_u, M, d, None, 0, dres, dx_drop=dxd_u, drop=up_drop)
+    dz1 = torch.empty_like(dz0)
+    dx = torch.full_like(x, 5.0)
+    dxd = torch.full_like(x, 5.0) if up else None
+    ws = torch.zeros(K.LN_REPLICAS * 2 * d, device=DEV)
+    K.ffn_fused_bwd(dy, w2t, w1t, z, dz1, None, act="swish", alpha=0.5, drop_h=drop_h,
+                    ln=dict(x=x, gamma=gam, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, dx_drop=dxd, drop=up_drop))
+    torch.cuda.synchronize()
+    assert torch.equal(dz0, dz1)
+    rel = (dx.float() - dx_u.float()).norm() / dx_u.float().norm()
+    assert rel < 6e-3, float(rel)  # (the epilogue works on fp32 dxn, the separate kernel on its bf16 rounding)
+    w = ws.view(K.LN_REPLICAS, 2, d).sum(0)
+    assert (w[0] - dg_u).abs().max() <= 1e-2 * dg_u.abs().max() + 1e-3
+    assert (w[1] - db_u).abs().max() <= 1e-2 * db_u.abs().max() + 1e-3
+    if up:
+        # the dropped copy is the dropout of the STORED dx under the same mask
+        keep = dxd_u.float() != 0
+        assert ((dxd.float() != 0) == keep).float().mean() > 0.999
+        ref = torch.where(keep, dx.float() / 0.9, torch.zeros_like(dx.float()))
+        assert (dxd.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
 @pytest.mark.parametrize("end_norm,mask", [(False, False), (True, False), (True, True)])
 def test_ffn_block_fused_vs_composed_training(end_norm, mask):
     """functional.ffn_block: the fused launch and the LayerNorm / GEMM composition give the same output and gradients
