@@ -366,28 +366,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
-// delta[z][i] = sum_c dO[b,i,h,c] * O[b,i,h,c]   (one 16-lane group per (row, head))
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO,
-                                                         int64_t sb, int64_t sr, float* __restrict__ delta, int B, int H,
-                                                         int Tq) {
-  const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // (b, i, h) index
-  const int l = threadIdx.x & 15;
-  if (gid >= (int64_t)B * Tq * H) return;
-  const int h = (int)(gid % H);
-  const int64_t bi = gid / H;
-  const int i = (int)(bi % Tq), b = (int)(bi / Tq);
-  const int64_t off = (int64_t)b * sb + (int64_t)i * sr + h * DK + l * 4;
-  float a[4], g[4];
-  ld4_as_f32<bf16_t>(o + off, a);
-  ld4_as_f32<bf16_t>(dO + off, g);
-  float s = a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
-  s += __shfl_xor(s, 8, 64);
-  s += __shfl_xor(s, 4, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 1, 64);
-  if (l == 0) delta[((int64_t)b * H + h) * Tq + i] = s;
-}
-
 // ---- dQ: workgroup = 64 queries of one (b,h), wave = 16 queries; walks the key blocks ------------------------------
 template <bool REL>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
@@ -414,7 +392,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     for (int ks = 0; ks < 2; ++ks) dof[ks] = as_frag(ldg16(dp + (ks * 4 + y) * 8));
   }
   const float lse_i = a.lse[(int64_t)z * a.Tq + ic];
-  const float del_i = a.delta[(int64_t)z * a.Tq + ic];
+  // delta_i = sum_c dO[i][c] * O[i][c]: the four lanes of a query row hold a quarter of it each (the dO fragments);
+  // written out for the dK / dV kernel that follows
+  float del_i;
+  {
+    const bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)ic * a.o_sr + h * DK;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 ov = ldg16(op + (ks * 4 + y) * 8);
+      const uint4 dv = __builtin_bit_cast(uint4, dof[ks]);
+      const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        part += __uint_as_float(ow[t] << 16) * __uint_as_float(dw[t] << 16) +
+                __uint_as_float(ow[t] & 0xffff0000u) * __uint_as_float(dw[t] & 0xffff0000u);
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    del_i = part;
+    if (y == 0 && i < a.Tq) const_cast<float*>(a.delta)[(int64_t)z * a.Tq + i] = part;
+  }
 
   f32x4 dq[4];
 #pragma unroll
@@ -427,8 +425,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
-  bf16_t* dbd_row = nullptr;
-  if (REL && a.dbd && i < a.Tq) dbd_row = a.dbd + (((int64_t)h * a.B + b) * a.Tq + i) * a.ldb;
   if (REL && a.dbd) {
     // zero the part of each of this wave's rows that lies outside the band n in [Tq-1-i, Tq-1-i+Tk)
     for (int rr = 0; rr < 16; ++rr) {
@@ -483,14 +479,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
         ds[kt][r] = p * (dp - del_i) * a.scale;
       }
     }
-    if (dbd_row) {
+    if (REL && a.dbd) {
+      // dBD row of query i, entries Tq-1-i + (k0 .. k0+63): the wave's 16 x 64 dS tile goes through its LDS scratch
+      // ([query][key], stride DSS floats) so that ONE store instruction writes 64 consecutive entries of one row
+      constexpr int DSS = 68;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = k0 + 16 * kt + 4 * y + r;
-          if (j < a.Tk) dbd_row[a.Tq - 1 - i + j] = f2bf(ds[kt][r]);
-        }
+        *reinterpret_cast<f32x4*>(scratch + x * DSS + 16 * kt + 4 * y) = (f32x4){ds[kt][0], ds[kt][1], ds[kt][2], ds[kt][3]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int jj = k0 + lane;
+#pragma unroll 4
+      for (int rr = 0; rr < 16; ++rr) {
+        const int ii = q0w + rr;
+        const float v = scratch[rr * DSS + lane];
+        if (ii < a.Tq && jj < a.Tk)
+          a.dbd[(((int64_t)h * a.B + b) * a.Tq + ii) * a.ldb + (a.Tq - 1 - ii + jj)] = f2bf(v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // dQ^T[c][q] += K^T[c][key] dS^T[key][q]
 #pragma unroll
@@ -733,9 +738,7 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
   a.dO = (const bf16_t*)dO; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk_; a.dv = (bf16_t*)dv;
   a.dbd = (bf16_t*)dbd; a.ldb = ldb;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t groups = (int64_t)B * Tq * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, (const bf16_t*)o,
-                     (const bf16_t*)dO, o_sb, o_sr, delta, B, H, Tq);
+  // (delta = rowsum(dO * O) is produced by the dQ kernel, which runs first, and read by the dK / dV kernel)
   dim3 gq(B * H, (Tq + 63) / 64), gk(B * H, (Tk + 63) / 64), block(256);
   if (a.rel) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, block, 0, s, a);

@@ -229,12 +229,66 @@ def _ln_workspace(cols, device):
     return pool[off:off + n]
 
 
+_POSQ = {"entries": [], "pool": {}, "next": {}}
+_POSQ_CAP = 32
+
+
+def _posq_slot(n_pos, d, dev, zero):
+    """A [n_pos, d] fp32 slice for one layer's position-table gradient.  Slices are handed out from the END of a pooled
+    block, so that the layers' slices ascend in memory like their linear_pos weight gradients do (backward visits the
+    layers last to first) and one batched GEMM can walk both with positive strides."""
+    key = (str(dev), n_pos, d)
+    pool = _POSQ["pool"].get(key)
+    if pool is None:
+        pool = _POSQ["pool"][key] = torch.zeros(_POSQ_CAP, n_pos, d, dtype=torch.float32, device=dev)
+    k = _POSQ["next"].get(key, _POSQ_CAP) - 1
+    if k < 0:
+        return (torch.zeros if zero else torch.empty)(n_pos, d, dtype=torch.float32, device=dev)
+    _POSQ["next"][key] = k
+    sl = pool[k]
+    if zero:
+        sl.zero_()
+    return sl
+
+
+def _flush_posq():
+    """linear_pos weight gradients (espnet_multihead_attention.py:331 backward): dW_l += dp_l^T pos_tab for every queued
+    layer, as ONE batched GEMM per run of layers whose slices and gradients sit at constant strides."""
+    entries, _POSQ["entries"] = _POSQ["entries"], []
+    _POSQ["next"] = {}
+    if not entries:
+        return
+    entries.sort(key=lambda e: e[2].data_ptr())
+    i = 0
+    while i < len(entries):
+        dp, pos32, g, n_pos, d = entries[i]
+        j = i + 1
+        gs = ds = None
+        while j < len(entries):
+            e = entries[j]
+            if e[1] is not pos32 or e[3] != n_pos or e[4] != d:
+                break
+            gs_j = (e[2].data_ptr() - entries[j - 1][2].data_ptr()) // 4
+            ds_j = (e[0].data_ptr() - entries[j - 1][0].data_ptr()) // 4
+            if gs is None:
+                gs, ds = gs_j, ds_j
+            if gs_j != gs or ds_j != ds or gs < d * d or ds < n_pos * d or gs % 4 or ds % 4:
+                break
+            j += 1
+        L = j - i
+        K.gemm(dp, pos32, g, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=L,
+               a_s=(ds or 0, 0), b_s=(0, 0), c_s=(gs or 0, 0),
+               split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
+        i = j
+
+
 def _flush_deferred():
     """Run the gradient work queued so far (LayerNorm parameter folds, grouped weight gradients) and deliver the
     grad-ready notifications that were waiting for it."""
     entries, _LNQ["entries"] = _LNQ["entries"], []
     if entries:
         K.layernorm_fold(entries)
+    _flush_posq()
     flush_wgrads()
     ready, _BE["ready"] = _BE["ready"], []
     cb = _HOOKS["grad_ready"]
@@ -918,12 +972,17 @@ class AttentionFn(torch.autograd.Function):
             ktiles = (Mq + 63) // 64
             sk = max(1, min(ktiles, _DP_SPLIT))
             # two-phase split-K in overwrite mode (c_atomic = 2) needs no zero fill of dp
-            dp = (torch.empty if sk > 1 else torch.zeros)(n_pos, d, dtype=torch.float32, device=dev)
+            pos32 = _pos_table_f32(pos_tab)
+            queued = _arm_backward_end()
+            dp = _posq_slot(n_pos, d, dev, zero=sk <= 1) if queued else \
+                (torch.empty if sk > 1 else torch.zeros)(n_pos, d, dtype=torch.float32, device=dev)
             K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
                    a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=sk, c_atomic=2 if sk > 1 else True)
-            pos32 = _pos_table_f32(pos_tab)
-            K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
-                   split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
+            if queued:  # linear_pos weight gradients of all layers: one batched launch at the end of the pass
+                _POSQ["entries"].append((dp, pos32, prm["pos_w"].grad, n_pos, d))
+            else:
+                K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
+                       split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
             if fuse_glue:  # dq += dqv, pos_u.grad += colsum(dq), pos_v.grad += colsum(dqv) in one pass
                 K.add_colsum2(dq, ldq, dqv, d, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), Mq, d)
             else:
