@@ -147,7 +147,14 @@ int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP,
  * n = Tq-1-i+j.  lse[(b*H+h)*Tq + i] = log-sum-exp of the scaled, masked scores (for the backward).  Dropout is applied to
  * the probabilities that multiply V (mask index ((b*H+h)*Tq + i)*Tk + j, as in s2t_attn_softmax_fwd).
  * Backward: delta[z][i] = sum_c dO*O; dq/dk/dv in the layouts of q/k/v; for the relative form dq receives only the
- * (Q+u) K^T part and `dbd` ([H][B][Tq][ldb], row n = Tq-1-i+j) receives the skewed dS for the position projections.
+ * (Q+u) K^T part and `dbd` ([H][B][Tq][ldb], row n = Tq-1-i+j) receives the skewed dS for the position projections;
+ * dbd_band_only != 0: only the band Tq-1-i <= n < Tq-1-i+Tk of each row is written — the caller keeps the rest of the
+ * buffer zero (zero-filled once and reused: every call overwrites exactly the band).  delta is an OUTPUT (written by the
+ * dQ kernel, read by the dK / dV kernel).
+ * pos_pt != NULL (relative form): the TRANSPOSED projected positions, element (h*64 + c, n) at pos_pt[(h*64+c)*pt_ld + n],
+ * zero-padded so that n in [-16, 2Tq-2+96] is readable (pt_ld % 8 == 0, 16-byte aligned).  The dQ kernel then adds the
+ * (Q+v) P^T branch itself — dq is the complete gradient w.r.t. Q — and accumulates the pos_bias_u / pos_bias_v gradients
+ * (column sums of the two branches, espnet_multihead_attention.py:339-345) into dpos_u / dpos_v ([H*64] fp32, atomics).
  * ------------------------------------------------------------------------------------------------ */
 int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
                        int64_t v_sb, int64_t v_sr, void* o, int64_t o_sb, int64_t o_sr, float* lse, int B, int H, int Tq,
@@ -159,7 +166,8 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        const float* lse, float* delta, void* dq, void* dk, void* dv, void* dbd, int64_t ldb, int B, int H,
                        int Tq, int Tk, int dk_dim, const int32_t* key_lens, int causal, float scale, const void* pos_p,
                        int64_t p_sr, const float* pos_u, const float* pos_v, float drop_p, const uint64_t* drop_seed,
-                       uint32_t drop_site, void* stream);
+                       uint32_t drop_site, int dbd_band_only,
+                       const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grouped weight gradients: all dW[M=Nout][N=Kin] += alpha * dY[K=rows][M]^T @ X[K][N] (bf16 in, fp32 accumulate) of one

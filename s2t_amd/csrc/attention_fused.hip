@@ -19,6 +19,11 @@
 // small wave-private LDS scratch: element (q, key) reads band row 15 - q_local + key_local.
 #include "common.h"
 
+#ifndef S2T_ATT_DBG
+#define S2T_ATT_DBG 0  // kernel-experiment switches (tools/dbg_variant.sh): 1 no dBD zero-fill, 2 no dBD stores, 4 no
+                       // position band in the backward scores, 8 no dropout arithmetic in the backward
+#endif
+
 namespace {
 
 constexpr int DK = 64;      // head dimension
@@ -51,6 +56,10 @@ struct FusedArgs {
   bf16_t *dq, *dk, *dv;  // layouts of q, k, v
   bf16_t* dbd;           // [H][B][Tq][ldb] (rel): skewed dS for the position projections, may be null
   int64_t ldb;
+  int dbd_band_only;     // the out-of-band part of dbd is already zero
+  const bf16_t* pos_pt;  // (rel, optional) TRANSPOSED position projections: element (c, n) at pos_pt[(h*DK + c)*pt_ld + n],
+  int64_t pt_ld;         // readable (zeros) for n in [-16, 2Tq-2 + 96]; with it dq receives the (Q+v) branch too and
+  float *dpos_u, *dpos_v;  // the column sums of the two branches are added here ([H*DK] fp32 each)
 };
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -414,9 +423,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     if (y == 0 && i < a.Tq) const_cast<float*>(a.delta)[(int64_t)z * a.Tq + i] = part;
   }
 
-  f32x4 dq[4];
+  f32x4 dq[4], dqv[4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = dqv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool fuse_v = REL && a.pos_pt != nullptr;
 
   const bf16_t* kb = a.k + (int64_t)b * a.k_sb + h * DK;
   const bf16_t* vb = a.v + (int64_t)b * a.v_sb + h * DK;
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
-  if (REL && a.dbd) {
+  if (REL && a.dbd && !a.dbd_band_only && !(S2T_ATT_DBG & 1)) {
     // zero the part of each of this wave's rows that lies outside the band n in [Tq-1-i, Tq-1-i+Tk)
     for (int rr = 0; rr < 16; ++rr) {
       const int ii = q0w + rr;
@@ -440,8 +450,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   TileRegs tk, tv;
   tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
   tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
+  constexpr bool BAND_ON = REL && !(S2T_ATT_DBG & 4);
   PFrags pnext;  // position rows of the block about to be scored (one register set: re-filled right after its MFMAs)
-  if constexpr (REL) load_pfrags(a, pnext, h, q0w, 0, x, y);
+  if constexpr (BAND_ON) load_pfrags(a, pnext, h, q0w, 0, x, y);
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
     tile_store(lk, tk, k0, a.Tk, nullptr, tid);
@@ -452,8 +463,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
     }
     f32x4 st[4];
-    scores_block<REL, REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
-    if constexpr (REL) {  // the next block's position rows travel during this block's softmax and PV product
+    scores_block<BAND_ON, BAND_ON>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
+    if constexpr (BAND_ON) {  // the next block's position rows travel during this block's softmax and PV product
       if (k0 + KB < kend) load_pfrags(a, pnext, h, q0w, k0 + KB, x, y);
     }
     // dP^T[key][q] = V[key] . dO[q]
@@ -479,14 +490,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
         ds[kt][r] = p * (dp - del_i) * a.scale;
       }
     }
-    if (REL && a.dbd) {
-      // dBD row of query i, entries Tq-1-i + (k0 .. k0+63): the wave's 16 x 64 dS tile goes through its LDS scratch
-      // ([query][key], stride DSS floats) so that ONE store instruction writes 64 consecutive entries of one row
-      constexpr int DSS = 68;
+    constexpr int DSS = 68;
+    if (REL && (a.dbd || fuse_v)) {
+      // the wave's 16 x 64 dS tile in its LDS scratch, [query][key], stride DSS floats
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
         *reinterpret_cast<f32x4*>(scratch + x * DSS + 16 * kt + 4 * y) = (f32x4){ds[kt][0], ds[kt][1], ds[kt][2], ds[kt][3]};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (fuse_v) {
+      // (Q+v) branch: dQv^T[c][q] += sum_n P^T[c][n] band[n][q], band[n][q] = dS[q][key] at n = Tq-1-i+key — over the
+      // 96-wide window of positions starting at n0a (the block's lowest position, rounded down to a 16-byte boundary of the
+      // transposed table): lane (q = x, y) assembles its B fragments from its dS row, shifted by sh = (15 - x) + (nbase - n0a)
+      const int nbase = a.Tq - 1 - (q0w + 15) + k0;
+      const int n0a = nbase & ~7;
+      const int sh = 15 - x + (nbase - n0a);
+      const bf16_t* pt = a.pos_pt + (int64_t)(h * DK + x) * a.pt_ld + n0a + 8 * y;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        float b8[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int kl = 32 * ks + 8 * y + t - sh;
+#if S2T_ATT_DBG & 32
+          const float v = ds[t & 3][t >> 2];
+#else
+          const float v = scratch[x * DSS + (kl < 0 ? 0 : (kl > 63 ? 63 : kl))];
+#endif
+          b8[t] = (kl >= 0 && kl < 64) ? v : 0.f;
+        }
+        const bf16x8 bfr = pack8(b8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#if S2T_ATT_DBG & 16
+          dqv[dt] = mfma16(bfr, bfr, dqv[dt]);
+#else
+          dqv[dt] = mfma16(as_frag(ldg16(pt + (int64_t)(16 * dt) * a.pt_ld + 32 * ks)), bfr, dqv[dt]);
+#endif
+      }
+    }
+    if (REL && a.dbd && !(S2T_ATT_DBG & 2)) {
+      // dBD row of query i, entries Tq-1-i + (k0 .. k0+63): ONE store instruction writes 64 consecutive entries of one row
       const int jj = k0 + lane;
 #pragma unroll 4
       for (int rr = 0; rr < 16; ++rr) {
@@ -515,8 +559,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     bf16_t* op = a.dq + (int64_t)b * a.q_sb + (int64_t)i * a.q_sr + h * DK;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      float v4[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+      float v4[4] = {dq[dt][0] + dqv[dt][0], dq[dt][1] + dqv[dt][1], dq[dt][2] + dqv[dt][2], dq[dt][3] + dqv[dt][3]};
       st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
+    }
+  }
+  if (fuse_v) {
+    // pos_bias_u / pos_bias_v gradients: column sums of the two branches over the workgroup's 64 queries (16 lanes of a
+    // wave by shuffles, the four waves through LDS), one atomic per column, branch and workgroup
+    __syncthreads();  // the K / V tiles are no longer read
+    float* red = reinterpret_cast<float*>(lds);  // [4 waves][2][64]
+    const bool live = i < a.Tq;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float su = live ? dq[dt][r] : 0.f, sv = live ? dqv[dt][r] : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          su += __shfl_xor(su, o, 64);
+          sv += __shfl_xor(sv, o, 64);
+        }
+        if (x == 0) {
+          red[(w * 2 + 0) * 64 + 16 * dt + 4 * y + r] = su;
+          red[(w * 2 + 1) * 64 + 16 * dt + 4 * y + r] = sv;
+        }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int br = tid >> 6, c = tid & 63;
+      const float sum = red[(0 * 2 + br) * 64 + c] + red[(1 * 2 + br) * 64 + c] + red[(2 * 2 + br) * 64 + c] + red[(3 * 2 + br) * 64 + c];
+      atomicAdd((br ? a.dpos_v : a.dpos_u) + h * DK + c, sum);
     }
   }
 }
@@ -721,13 +793,15 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
                                   int64_t o_sr, const float* lse, float* delta, void* dq, void* dk_, void* dv, void* dbd,
                                   int64_t ldb, int B, int H, int Tq, int Tk, int dk, const int32_t* key_lens, int causal,
                                   float scale, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
-                                  float drop_p, const uint64_t* drop_seed, uint32_t drop_site, void* stream) {
+                                  float drop_p, const uint64_t* drop_seed, uint32_t drop_site, int dbd_band_only,
+                                  const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* stream) {
   if (!q || !k || !v || !o || !dO || !lse || !delta || !dq || !dk_ || !dv || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0)
     return S2T_ERR_ARG;
   if (dk != DK) return S2T_ERR_UNSUPPORTED;
   if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
   if (pos_p && (!pos_u || !pos_v || Tq != Tk)) return S2T_ERR_ARG;
   if (dbd && ldb < 2 * Tq - 1) return S2T_ERR_ARG;
+  if (pos_pt && (!pos_p || !dpos_u || !dpos_v || pt_ld % 8 || ((uintptr_t)pos_pt % 16))) return S2T_ERR_ARG;
   FusedArgs a = {};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr;
@@ -736,7 +810,8 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
   a.rel = pos_p != nullptr; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.pos_u = pos_u; a.pos_v = pos_v;
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site;
   a.dO = (const bf16_t*)dO; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk_; a.dv = (bf16_t*)dv;
-  a.dbd = (bf16_t*)dbd; a.ldb = ldb;
+  a.dbd = (bf16_t*)dbd; a.ldb = ldb; a.dbd_band_only = dbd_band_only;
+  a.pos_pt = (const bf16_t*)pos_pt; a.pt_ld = pt_ld; a.dpos_u = dpos_u; a.dpos_v = dpos_v;
   hipStream_t s = (hipStream_t)stream;
   // (delta = rowsum(dO * O) is produced by the dQ kernel, which runs first, and read by the dK / dV kernel)
   dim3 gq(B * H, (Tq + 63) / 64), gk(B * H, (Tk + 63) / 64), block(256);

@@ -229,6 +229,24 @@ def _ln_workspace(cols, device):
     return pool[off:off + n]
 
 
+_DBD = {}
+
+
+def _dbd_buffer(H, B, Tq, ldB, dt, dev):
+    """The [H, B, Tq, ldB] buffer of skewed dS shared by all layers of a shape: zero-filled once — every backward call
+    overwrites exactly the band of each row, the rest stays zero (s2t_attn_fused_bwd, dbd_band_only), and a layer's
+    consumers (the two position GEMMs) run on the same stream before the next layer's kernel writes it again."""
+    key = (str(dev), dt, H, B, Tq, ldB)
+    buf = _DBD.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("s2t_amd: a new attention-gradient shape appeared during graph capture; run one eager step first")
+        while len(_DBD) >= 4:  # a few bucketed shapes at most; evict the oldest
+            _DBD.pop(next(iter(_DBD)))
+        buf = _DBD[key] = torch.zeros(H, B, Tq, ldB, dtype=dt, device=dev)
+    return buf
+
+
 _POSQ = {"entries": [], "pool": {}, "next": {}}
 _POSQ_CAP = 32
 
@@ -879,6 +897,7 @@ class AttentionFn(torch.autograd.Function):
                        ldr=d, drop=drop_o)
             ctx.drops = (drop_a, drop_o)
             ctx.fused = True
+            ctx.pos_pt = getattr(pos_p, "_s2t_pt", None) if (kind == "rel" and pos_p is not None) else None
             if train:
                 ctx.save_for_backward(xq, xkv, q, k, v, O, lse, p, pos_tab, key_lens)
             ctx.prm, ctx.dims = prm, (H, B, Tq, Tk, d, dk, ldq, ldk, 0, 0, scale)
@@ -951,22 +970,27 @@ class AttentionFn(torch.autograd.Function):
             dkv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
             dk_, dv = dkv, dkv[:, d:]
         rel = ctx.kind == "rel"
+        pt = getattr(ctx, "pos_pt", None) if (rel and _ATTN_DQV_FUSED) else None
         delta = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
         n_pos = 2 * Tq - 1
         ldB = _pad8(n_pos)
-        dBD = torch.empty(H, B, Tq, ldB, dtype=dt, device=dev) if rel else None
+        dBD = _dbd_buffer(H, B, Tq, ldB, dt, dev) if rel else None
         K.attn_fused_bwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, dO, Tq * d, d, lse, delta, dq, dk_, dv, dBD,
                          ldB, B, H, Tq, Tk, dk, key_lens, ctx.causal, scale, p, d,
-                         prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a)
+                         prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a,
+                         dbd_band_only=rel, pos_pt=pt[0] if pt is not None else None, pt_ld=pt[1] if pt is not None else 0,
+                         dpos_u=prm["pos_u"].grad.view(-1) if pt is not None else None,
+                         dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None)
         if rel:
             fuse_glue = dt == torch.bfloat16 and d == 256 and ldq % 8 == 0
-            if not fuse_glue:
-                K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
-            dqv = torch.empty(Mq, d, dtype=dt, device=dev)
-            K.gemm(dBD, p, dqv, M=Tq, N=dk, K=n_pos, lda=ldB, ldb=d, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
-                   a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
-            if not fuse_glue:
-                K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
+            if pt is None:
+                if not fuse_glue:
+                    K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
+                dqv = torch.empty(Mq, d, dtype=dt, device=dev)
+                K.gemm(dBD, p, dqv, M=Tq, N=dk, K=n_pos, lda=ldB, ldb=d, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
+                       a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
+                if not fuse_glue:
+                    K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
             qv = torch.empty(Mq, d, dtype=dt, device=dev)
             K.bias_add_rows(q, ldq, prm["pos_v"].data, qv, d, Mq, d)
             ktiles = (Mq + 63) // 64
@@ -983,7 +1007,9 @@ class AttentionFn(torch.autograd.Function):
             else:
                 K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
                        split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
-            if fuse_glue:  # dq += dqv, pos_u.grad += colsum(dq), pos_v.grad += colsum(dqv) in one pass
+            if pt is not None:
+                pass  # the kernel wrote the complete dq and added both bias gradients
+            elif fuse_glue:  # dq += dqv, pos_u.grad += colsum(dq), pos_v.grad += colsum(dqv) in one pass
                 K.add_colsum2(dq, ldq, dqv, d, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), Mq, d)
             else:
                 dq[:, :d].add_(dqv)
@@ -1103,6 +1129,15 @@ class AttentionFn(torch.autograd.Function):
         return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 15
 
 
+_PT = {}
+_PT_OFF = 16  # zero columns in front of position 0 of the transposed projections (windows start up to 15 positions early)
+# (Q+v) branch of dQ and the two bias gradients inside the attention backward kernel (s2t_attn_fused_bwd, pos_pt).  Opt-in:
+# measured on the headline shape the dQ kernel grows from 54 to 119 us (12 more MFMAs per key block, but 250 registers and
+# a longer dependent chain in a kernel that is latency-bound already), more than the 46 us of the GEMM + column-sum launches
+# it replaces (profiles/README.md, r02 notes)
+_ATTN_DQV_FUSED = os.environ.get("S2T_ATTN_DQV_FUSED", "0") == "1"
+
+
 def project_positions(pos_tab, weights):
     """linear_pos (espnet_multihead_attention.py:331) of EVERY layer of a stack in one batched launch: the relative-position
     table is the same for all of them and the [d, d] weights sit at a constant stride in the flat parameter buffer.
@@ -1124,7 +1159,24 @@ def project_positions(pos_tab, weights):
     out = torch.empty(len(ws), n_pos, d, dtype=torch.bfloat16, device=pos_tab.device)
     K.gemm(pos_tab, ws[0], out, M=n_pos, N=d, K=d, lda=d, ldb=d, ldc=d, batch=len(ws), a_s=(0, 0), b_s=(stride, 0),
            c_s=(n_pos * d, 0))
-    return [out[i] for i in range(len(ws))]
+    res = [out[i] for i in range(len(ws))]
+    if torch.is_grad_enabled() and _ATTN_DQV_FUSED:
+        # the TRANSPOSED projections for the backward kernel (s2t_attn_fused_bwd, pos_pt): [layer][d][PT_OFF + n_pos + pad],
+        # zero outside the n_pos valid columns (the buffer is kept per stack: the GEMM rewrites exactly the valid part)
+        ld = _pad8(_PT_OFF + n_pos + 96)
+        key = (str(pos_tab.device), ws[0].data_ptr(), len(ws), n_pos, d)
+        buf = _PT.get(key)
+        if buf is None:
+            if torch.cuda.is_current_stream_capturing():
+                return res
+            while len(_PT) >= 4:
+                _PT.pop(next(iter(_PT)))
+            buf = _PT[key] = torch.zeros(len(ws), d, ld, dtype=torch.bfloat16, device=pos_tab.device)
+        K.gemm(ws[0], pos_tab, buf[0, :, _PT_OFF:], M=d, N=n_pos, K=d, lda=d, ldb=d, ldc=ld, batch=len(ws), a_s=(stride, 0),
+               b_s=(0, 0), c_s=(d * ld, 0))
+        for i, r in enumerate(res):
+            r._s2t_pt = (buf[i, :, _PT_OFF:], ld)
+    return res
 
 
 def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False, kind="abs", pos_tab=None,

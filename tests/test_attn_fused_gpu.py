@@ -141,6 +141,18 @@ def test_fused_backward(Tq, Tk, causal, rel, pdrop):
     K.attn_fused_bwd(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, dOd, Tq * d, d, lse, delta, dq, dkk, dv, dbd, ldb, B, H,
                      Tq, Tk, dk, kl, causal, scale, pp, d if rel else 0, ud, vbd, drop)
     torch.cuda.synchronize()
+    if rel:
+        # dbd_band_only: into a buffer that is already zero outside the band, twice (the second call overwrites the band)
+        dbd2 = torch.zeros_like(dbd)
+        for _ in range(2):
+            K.attn_fused_bwd(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, dOd, Tq * d, d, lse, torch.empty_like(delta),
+                             torch.empty_like(dq), torch.empty_like(dkk), torch.empty_like(dv), dbd2, ldb, B, H, Tq, Tk, dk, kl,
+                             causal, scale, pp, d, ud, vbd, drop, dbd_band_only=True)
+        torch.cuda.synchronize()
+        assert torch.equal(dbd2[..., :2 * Tq - 1], dbd[..., :2 * Tq - 1])
+    # delta is an output of the dQ kernel
+    ref_delta = (dOd.float().view(B, Tq, H, dk) * o.float().view(B, Tq, H, dk)).sum(-1).permute(0, 2, 1).reshape(Z, Tq)
+    assert (delta - ref_delta).abs().max() <= 1e-3 * ref_delta.abs().max() + 1e-5
 
     # ---- float64 autograd reference on the same bf16-rounded operands
     qh = q.double().view(B, Tq, H, dk).permute(0, 2, 1, 3)
@@ -186,3 +198,25 @@ def test_fused_backward(Tq, Tk, causal, rel, pdrop):
         got = dbd.cpu().double()[..., :2 * Tq - 1].permute(1, 0, 2, 3)  # (B, H, Tq, 2T-1)
         assert rel_err(got, bd_full.grad) < 1.5e-2
         assert float(dbd.cpu().double()[..., 2 * Tq - 1:].abs().max() if ldb > 2 * Tq - 1 else 0.0) == 0.0
+        # ---- pos_pt: the dQ kernel adds the (Q+v) P^T branch itself and accumulates the two bias gradients
+        OFF = 16
+        ld_t = (OFF + 2 * Tq - 1 + 96 + 7) // 8 * 8
+        ptb = torch.zeros(d, ld_t, dtype=bf, device=DEV)
+        ptb[:, OFF:OFF + 2 * Tq - 1] = pp.t()
+        du = torch.full((d,), 0.5, dtype=torch.float32, device=DEV)
+        dvv = torch.full((d,), -0.25, dtype=torch.float32, device=DEV)
+        dq3 = torch.full((B, Tq, d), 7.0, dtype=bf, device=DEV)
+        K.attn_fused_bwd(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, dOd, Tq * d, d, lse, torch.empty_like(delta), dq3,
+                         torch.empty_like(dkk), torch.empty_like(dv), None, ldb, B, H, Tq, Tk, dk, kl, causal, scale, pp, d, ud,
+                         vbd, drop, pos_pt=ptb[:, OFF:], pt_ld=ld_t, dpos_u=du, dpos_v=dvv)
+        torch.cuda.synchronize()
+        # gradient of the (Q+v) branch: dBD (reference) times the projected positions
+        dqv_ref = bd_full.grad @ ph[None].transpose(-1, -2)          # (B, H, Tq, dk)
+        tot_ref = qleaf.grad + dqv_ref
+        got3 = dq3.cpu().double().view(B, Tq, H, dk).permute(0, 2, 1, 3)
+        assert rel_err(got3, tot_ref) < 1.5e-2
+        got_u = du.cpu().double().view(H, dk) - 0.5
+        got_v = dvv.cpu().double().view(H, dk) + 0.25
+        ref_u, ref_v = qleaf.grad.sum((0, 2)), dqv_ref.sum((0, 2))
+        assert (got_u - ref_u).abs().max() <= 2e-2 * ref_u.abs().max() + 1e-4
+        assert (got_v - ref_v).abs().max() <= 2e-2 * ref_v.abs().max() + 1e-4
