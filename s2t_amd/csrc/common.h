@@ -137,6 +137,19 @@ __device__ __forceinline__ void s2t_rand_run(uint64_t key, uint64_t base, uint32
     }
   }
 }
+// The same bits for N consecutive elements starting at an EVEN index below 2^32 (32-bit arithmetic throughout, no odd-start
+// variant to select from): what the row-block kernels use, whose element indices are row * F + multiple of 4.
+template <int N>
+__device__ __forceinline__ void s2t_rand_run_even32(uint64_t key, uint32_t base, uint32_t (&r16)[N]) {
+  static_assert(N % 2 == 0, "even run length");
+  const uint32_t p0 = base >> 1, klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int q = 0; q < N / 2; ++q) {
+    const uint32_t h = s2t_mix32((p0 + (uint32_t)q) ^ klo) ^ khi;
+    r16[2 * q] = h & 0xffffu;
+    r16[2 * q + 1] = h >> 16;
+  }
+}
 __device__ __forceinline__ uint64_t s2t_drop_key(const uint64_t* seed_ptr, uint32_t site) {
   const uint64_t seed = seed_ptr ? *seed_ptr : 0ull;
   return (seed * 0xD1342543DE82EF95ull) ^ ((uint64_t)site * 0xA24BAED4963EE407ull);

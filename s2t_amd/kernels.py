@@ -91,7 +91,7 @@ def gemm(
 
 def ffn_fused_supported(x, F, M=None):
     """The row-block kernel covers the recipes' encoder width: bf16, d = 256, F a multiple of 64 up to 4096."""
-    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 256 and F % 64 == 0
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 256 and F % 64 == 0 and (x.shape[0] + 64) * F < 2 ** 31
 
 
 def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=None, ln_eps=1e-5, end_ln=None, y_ln=None,

@@ -29,9 +29,12 @@ def unfused(i, train):
     K.gemm(hs[i], ws2[i], y, M=M, N=d, K=F, lda=F, ldb=F, ldc=d, bias=b2, alpha=0.5, residual=xs[i], ldr=d, drop=do)
 
 
+NODROP = os.environ.get("PROBE_NODROP", "0") == "1"
+
+
 def fused(i, train):
-    dh = (0.1, seed, 1) if train else None
-    do = (0.1, seed, 2) if train else None
+    dh = (0.1, seed, 1) if (train and not NODROP) else None
+    do = (0.1, seed, 2) if (train and not NODROP) else None
     K.ffn_fused_fwd(xs[i], ws1[i], b1, ws2[i], b2, y, act="swish", alpha=0.5, residual=xs[i], ln=(gam, bet),
                     x_ln=xl if train else None, ln_stats=(mean, rstd) if train else None, z=zs[i] if train else None,
                     h=hs[i] if train else None, drop_h=dh, drop_o=do)
@@ -68,7 +71,7 @@ def bwd_unfused(i, train):
 
 
 def bwd_fused(i, train):
-    K.ffn_fused_bwd(dy, w2ts[i], w1ts[i], zs[i], hs[i], dxn, act="swish", alpha=0.5, drop_h=(0.1, seed, 1))
+    K.ffn_fused_bwd(dy, w2ts[i], w1ts[i], zs[i], hs[i], dxn, act="swish", alpha=0.5, drop_h=None if NODROP else (0.1, seed, 1))
 
 
 print("backward, cycling %d buffer sets:  two dgrad GEMMs %.1f us   fused %.1f us" % (NB, timeit(bwd_unfused, True), timeit(bwd_fused, True)), flush=True)
