@@ -269,7 +269,7 @@ def main():
         # from the committed rocprofv3 --pmc passes of this same command (tools/pmc.sh + tools/pmc_traffic.py)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 for row in json.load(f)["kernels"]:
                     if sym in row["kernel"]:
                         traffic = row["hbm_bytes_per_launch"]
