@@ -392,6 +392,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   const int ic = i < a.Tq ? i : a.Tq - 1;
   const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
 
+#if S2T_ATT_DBG & 64
+  unsigned long long stamp[40];
+  int nstamp = 0;
+#define ASTAMP()                                         \
+  do {                                                   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    if (nstamp < 40) stamp[nstamp++] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+#else
+#define ASTAMP()
+#endif
+  ASTAMP();
   QFrags qf;
   load_qfrags(a, qf, b, h, i, y, REL);
   bf16x8 dof[2];
@@ -453,17 +466,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   constexpr bool BAND_ON = REL && !(S2T_ATT_DBG & 4);
   PFrags pnext;  // position rows of the block about to be scored (one register set: re-filled right after its MFMAs)
   if constexpr (BAND_ON) load_pfrags(a, pnext, h, q0w, 0, x, y);
+  ASTAMP();
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
+    ASTAMP();
     tile_store(lk, tk, k0, a.Tk, nullptr, tid);
     tile_store(lv, tv, k0, a.Tk, nullptr, tid);
     __syncthreads();
+    ASTAMP();
     if (k0 + KB < kend) {  // next block's K/V in flight during this block's MFMAs
       tile_load(tk, kb, a.k_sr, k0 + KB, a.Tk, tid);
       tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
     }
     f32x4 st[4];
     scores_block<BAND_ON, BAND_ON>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
+    ASTAMP();
     if constexpr (BAND_ON) {  // the next block's position rows travel during this block's softmax and PV product
       if (k0 + KB < kend) load_pfrags(a, pnext, h, q0w, k0 + KB, x, y);
     }
@@ -490,6 +507,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
         ds[kt][r] = p * (dp - del_i) * a.scale;
       }
     }
+    ASTAMP();
     constexpr int DSS = 68;
     if (REL && (a.dbd || fuse_v)) {
       // the wave's 16 x 64 dS tile in its LDS scratch, [query][key], stride DSS floats
@@ -541,6 +559,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    ASTAMP();
     // dQ^T[c][q] += K^T[c][key] dS^T[key][q]
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -555,6 +574,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(frag_cols_perm(lk, dt, s, x, y), df, dq[dt]);
     }
   }
+  ASTAMP();
+#if S2T_ATT_DBG & 64
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && blockIdx.y == 1) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.delta) + (int64_t)a.B * a.H * a.Tq) +
+                              ((blockIdx.x ? 4 : 0) + w) * 40;
+    for (int t = 0; t < 40; ++t) dbg[t] = t < nstamp ? stamp[t] : 0ull;
+  }
+#endif
   if (i < a.Tq) {
     bf16_t* op = a.dq + (int64_t)b * a.q_sb + (int64_t)i * a.q_sr + h * DK;
 #pragma unroll
