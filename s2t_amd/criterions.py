@@ -30,30 +30,14 @@ def ctc_targets(target, pad_idx, eos_idx):
 
 def batch_bookkeeping(sample, pad_idx, eos_idx):
     """Everything about a batch that depends on its TARGETS only (CTC target matrix, label counts, the flattened target
-    vector of the cross-entropy) — a dozen small sort / scan / gather launches.  Computed once per batch and kept on the
-    sample, like the collater's own fields (speech_to_text_dataset.py:411-485), instead of once per forward pass: a captured
-    step then replays none of it."""
-    memo = sample.get("_s2t_targets")
-    target = sample["target"]
-    if memo is None or memo[0] is not target or memo[1] != target._version:
+    vector of the cross-entropy) — a dozen small sort / scan / gather launches.  Computed once per batch and kept
+    (functional.batch_memo), like the collater's own fields (speech_to_text_dataset.py:411-485), instead of once per forward
+    pass: a captured step then replays none of it."""
+    def fn(target):
         tmat, tl = ctc_targets(target, pad_idx, eos_idx)
-        memo = (target, target._version, tmat, tl, target.reshape(-1).contiguous())
-        sample["_s2t_targets"] = memo
-    return memo[2], memo[3], memo[4]
+        return tmat, tl, target.reshape(-1).contiguous()
 
-
-def refresh_bookkeeping(sample, pad_idx, eos_idx):
-    """After new targets were copied INTO a captured step's static batch: recompute the bookkeeping into the same tensors
-    (the graph holds their addresses)."""
-    memo = sample.get("_s2t_targets")
-    target = sample["target"]
-    if memo is None:
-        return
-    tmat, tl = ctc_targets(target, pad_idx, eos_idx)
-    memo[2].copy_(tmat)
-    memo[3].copy_(tl)
-    memo[4].copy_(target.reshape(-1))
-    sample["_s2t_targets"] = (target, target._version) + memo[2:]
+    return Fn.batch_memo(("targets", pad_idx, eos_idx), (sample["target"],), fn)
 
 
 @register_criterion("label_smoothed_cross_entropy_with_ctc")
@@ -85,7 +69,8 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(_CriterionBase):
         if self.ctc_weight > 0 and len(enc["ctc_logit"]) > 0:
             ctc_tbv = enc["ctc_logit"][0]
             Tn = ctc_tbv.shape[0]
-            in_lens = (~enc["encoder_padding_mask"][0]).sum(1).to(torch.int32)
+            (in_lens,) = Fn.batch_memo(("ctc_in_lens", id(self)), (enc["encoder_padding_mask"][0],),
+                                       lambda m: ((~m).sum(1).to(torch.int32),))
             tmat, tl, _ = batch_bookkeeping(sample, self.padding_idx, self.eos_idx)
             l2d = ctc_tbv.transpose(0, 1).reshape(B * Tn, -1)  # a view: the encoder's buffer is batch-major
             ctc = Fn.ctc_loss(l2d, B, Tn, tmat, tl, in_lens, self.blank_idx, side=_CTC_SIDE)

@@ -200,6 +200,38 @@ class _on_wgrad_stream:
 
 # Work deferred to the end of the backward pass (an autograd engine callback): the fold of every LayerNorm's
 # per-replica dgamma/dbeta partial sums (one launch instead of one per LayerNorm) and the grouped weight gradients.
+# Per-batch bookkeeping that depends only on a batch's LENGTHS / TOKEN IDS (subsampled lengths, padding masks, decoder
+# positions, CTC target matrices): a handful of tiny sort / scan / compare launches each.  batch_memo computes them once per
+# batch object (keyed by the identity and version of the source tensors) instead of once per forward pass, so a captured step
+# replays none of them; when new data is copied INTO a captured step's static batch (Trainer.load_batch),
+# refresh_batch_memos recomputes every memo into the SAME output tensors (the graph holds their addresses).
+_MEMO = {}
+
+
+def batch_memo(key, srcs, fn):
+    e = _MEMO.get(key)
+    if e is not None and len(e[0]) == len(srcs) and all(a is b and a._version == v for a, b, v in zip(e[0], srcs, e[1])):
+        return e[3]
+    outs = fn(*srcs)
+    _MEMO[key] = (tuple(srcs), tuple(t._version for t in srcs), fn, outs)
+    return outs
+
+
+def refresh_batch_memos(changed):
+    """``changed``: the tensors whose contents were just overwritten.  Every memo computed from one of them — or from the
+    output of a memo refreshed here (the padding mask feeds the length memos) — is recomputed into its existing tensors."""
+    dirty = {id(t) for t in changed}
+    for key, (srcs, _, fn, outs) in list(_MEMO.items()):  # insertion order = the order the forward pass made them
+        if not any(id(t) in dirty for t in srcs):
+            continue
+        new = fn(*srcs)
+        for o, n in zip(outs, new):
+            if torch.is_tensor(o):
+                o.copy_(n)
+                dirty.add(id(o))
+        _MEMO[key] = (srcs, tuple(t._version for t in srcs), fn, outs)
+
+
 _BE = {"armed": False, "ready": [], "flats": []}
 _LNQ = {"entries": [], "pools": {}, "off": {}}
 

@@ -166,10 +166,12 @@ class S2TTransformerEncoder(nn.Module):
         Tp = (T1 - 1) // 2 + 1
         if src_lengths is None:
             src_lengths = torch.full((B,), T, dtype=torch.long, device=src_tokens.device)
-        lens = self.subsample.get_out_seq_lens_tensor(src_lengths)
-        lens32 = lens.to(torch.int32)
+        def length_bookkeeping(sl):
+            ln = self.subsample.get_out_seq_lens_tensor(sl)
+            return ln, ln.to(torch.int32), torch.arange(Tp, device=sl.device)[None, :] >= ln[:, None]
+
+        lens, lens32, encoder_padding_mask = Fn.batch_memo(("enc_lens", id(self), Tp), (src_lengths,), length_bookkeeping)
         x = self.subsample(src_tokens, lens32, dt)  # [B*T', d], padded frames zeroed (:1765)
-        encoder_padding_mask = torch.arange(Tp, device=x.device)[None, :] >= lens[:, None]
         c = Ctx(B, Tp, lens32, dt)
         if self.embed_ln is not None:
             x = self.embed_ln(x)  # :1769
@@ -356,19 +358,24 @@ class TransformerDecoderScriptable(nn.Module):
         B, U = prev_output_tokens.shape
         d = self.embed_dim
         dev = prev_output_tokens.device
-        nonpad = prev_output_tokens.ne(self.padding_idx)
-        pos = (torch.cumsum(nonpad, dim=1) * nonpad + self.padding_idx).to(torch.int32)  # utils.py:240-250
+        pad_idx = self.padding_idx
+
+        def token_bookkeeping(tok):
+            nonpad = tok.ne(pad_idx)
+            pos = (torch.cumsum(nonpad, dim=1) * nonpad + pad_idx).to(torch.int32)  # utils.py:240-250
+            # key-padding of the target side: pads sit at the end for left-aligned targets; general masks
+            # (pads in the middle) would need a mask tensor, the collater never produces them
+            return tok.contiguous(), pos.contiguous(), nonpad.sum(1).to(torch.int32)
+
+        tok, pos, self_lens = Fn.batch_memo(("dec_tokens", id(self)), (prev_output_tokens,), token_bookkeeping)
         tab = TABLES.get("sin", self.max_positions() + self.padding_idx + 1, d, dev)
-        x = Fn.embedding(prev_output_tokens.contiguous(), pos.contiguous(), self.embed_tokens.weight, tab,
-                         self.embed_scale, self.padding_idx)
+        x = Fn.embedding(tok, pos, self.embed_tokens.weight, tab, self.embed_scale, self.padding_idx)
         x = Fn.dropout(x, float(self.args.dropout or 0.0), self.training)  # dropout_module (transformer.py:1328)
-        # key-padding of the target side: pads sit at the end for left-aligned targets; general masks
-        # (pads in the middle) would need a mask tensor, the collater never produces them
-        self_lens = nonpad.sum(1).to(torch.int32)
         mem_tbc = encoder_out["encoder_out"][0]
         Tm = mem_tbc.shape[0]
         mem = mem_tbc.transpose(0, 1).contiguous().view(B * Tm, d)
-        mem_lens = (~encoder_out["encoder_padding_mask"][0]).sum(1).to(torch.int32)
+        (mem_lens,) = Fn.batch_memo(("dec_mem_lens", id(self)), (encoder_out["encoder_padding_mask"][0],),
+                                    lambda m: ((~m).sum(1).to(torch.int32),))
         # reference (:1340-1342): pad KEYS are masked for every query; pad queries still attend
         for layer in self.layers:
             x = layer(x, mem, B, U, Tm, self_lens, mem_lens)

@@ -151,7 +151,7 @@ class Trainer:
 
     def load_batch(self, sample):
         """Copy a batch of the captured shapes into the static one the graph reads (tensors by key, recursively), then
-        redo the per-batch target bookkeeping that lives outside the graph."""
+        redo the per-batch bookkeeping that lives outside the graph (functional.batch_memo)."""
         def fill(dst, src):
             for k, v in src.items():
                 if isinstance(v, dict):
@@ -160,10 +160,17 @@ class Trainer:
                     if dst[k].shape != v.shape:
                         raise ValueError(f"batch field {k}: shape {tuple(v.shape)} differs from the captured {tuple(dst[k].shape)}")
                     dst[k].copy_(v, non_blocking=True)
-        fill(self._static, {k: v for k, v in sample.items() if k != "_s2t_targets"})
-        from .criterions import refresh_bookkeeping
-        c = self.criterion
-        refresh_bookkeeping(self._static, getattr(c, "padding_idx", getattr(c, "pad_idx", 1)), getattr(c, "eos_idx", 2))
+        fill(self._static, sample)
+
+        def tensors(dct):
+            for v in dct.values():
+                if isinstance(v, dict):
+                    yield from tensors(v)
+                elif torch.is_tensor(v):
+                    yield v
+
+        # lengths / positions / target matrices derived from the batch, recomputed in place
+        Fn.refresh_batch_memos(list(tensors(self._static)))
 
     def replay(self, sample=None, sample_size_global=None):
         """One captured update; ``sample`` (same shapes as the captured batch) is copied into the static batch first."""
