@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
 // backward
 // =====================================================================================================================
 // ---- dQ: workgroup = 64 queries of one (b,h), wave = 16 queries; walks the key blocks ------------------------------
-template <bool REL>
+template <bool REL, bool FUSEV = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4];
   char* lk = lds;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   f32x4 dq[4], dqv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dq[dt] = dqv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool fuse_v = REL && a.pos_pt != nullptr;
+  constexpr bool fuse_v = REL && FUSEV;  // a separate instantiation: its code costs the plain form 25 us when merely present
 
   const bf16_t* kb = a.k + (int64_t)b * a.k_sb + h * DK;
   const bf16_t* vb = a.v + (int64_t)b * a.v_sb + h * DK;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
         *reinterpret_cast<f32x4*>(scratch + x * DSS + 16 * kt + 4 * y) = (f32x4){ds[kt][0], ds[kt][1], ds[kt][2], ds[kt][3]};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if (fuse_v) {
+    if constexpr (fuse_v) {
       // (Q+v) branch: dQv^T[c][q] += sum_n P^T[c][n] band[n][q], band[n][q] = dS[q][key] at n = Tq-1-i+key — over the
       // 96-wide window of positions starting at n0a (the block's lowest position, rounded down to a 16-byte boundary of the
       // transposed table): lane (q = x, y) assembles its B fragments from its dS row, shifted by sh = (15 - x) + (nbase - n0a)
@@ -547,18 +547,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
 #endif
       }
     }
-    if (REL && a.dbd && !(S2T_ATT_DBG & 2)) {
-      // dBD row of query i, entries Tq-1-i + (k0 .. k0+63): ONE store instruction writes 64 consecutive entries of one row
-      const int jj = k0 + lane;
-#pragma unroll 4
-      for (int rr = 0; rr < 16; ++rr) {
-        const int ii = q0w + rr;
-        const float v = scratch[rr * DSS + lane];
-        if (ii < a.Tq && jj < a.Tk)
-          a.dbd[(((int64_t)h * a.B + b) * a.Tq + ii) * a.ldb + (a.Tq - 1 - ii + jj)] = f2bf(v);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     ASTAMP();
     // dQ^T[c][q] += K^T[c][key] dS^T[key][q]
 #pragma unroll
@@ -572,6 +560,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       const bf16x8 df = pack8(d8);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(frag_cols_perm(lk, dt, s, x, y), df, dq[dt]);
+    }
+    if (REL && a.dbd && !(S2T_ATT_DBG & 2)) {
+      // dBD row of query i, entries Tq-1-i + (k0 .. k0+63), from the scratch tile: ONE store instruction writes 64
+      // consecutive entries of one row.  All 16 row reads go out first (the dS registers are dead by now), then the stores:
+      // one LDS round trip per block instead of one per row.
+      const int jj = k0 + lane;
+      float rowv[16];
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) rowv[rr] = scratch[rr * DSS + lane];
+      bf16_t* rowp = a.dbd + (((int64_t)h * a.B + b) * a.Tq + q0w) * a.ldb + (a.Tq - 1 - q0w + jj);
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr)
+        if (q0w + rr < a.Tq && jj < a.Tk) rowp[(int64_t)rr * (a.ldb - 1)] = f2bf(rowv[rr]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
   ASTAMP();
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
     }
   }
-  if (fuse_v) {
+  if constexpr (fuse_v) {
     // pos_bias_u / pos_bias_v gradients: column sums of the two branches over the workgroup's 64 queries (16 lanes of a
     // wave by shuffles, the four waves through LDS), one atomic per column, branch and workgroup
     __syncthreads();  // the K / V tiles are no longer read
@@ -843,10 +845,11 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
   // (delta = rowsum(dO * O) is produced by the dQ kernel, which runs first, and read by the dK / dV kernel)
   dim3 gq(B * H, (Tq + 63) / 64), gk(B * H, (Tk + 63) / 64), block(256);
   if (a.rel) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, block, 0, s, a);
+    if (a.pos_pt) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), gq, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, block, 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, block, 0, s, a);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, block, 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, block, 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, block, 0, s, a);
   }
   return S2T_LAUNCH_CHECK();
