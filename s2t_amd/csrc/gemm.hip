@@ -494,7 +494,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args 
   const int wm = wave >> 1, wn = wave & 1, x = lane & 15, y = lane >> 4;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int z0 = z / p.zdiv, z1 = z % p.zdiv;
-  float* C = reinterpret_cast<float*>(p.C) + z0 * p.c_s0 + z1 * p.c_s1;
+  const int64_t coff = z0 * p.c_s0 + z1 * p.c_s1;
+  float* C = reinterpret_cast<float*>(p.C) + coff;
   const int64_t sstride = (int64_t)ntiles * (BM * BN);
   const float* src = p.ws + (int64_t)z * p.split_k * sstride + (int64_t)tile * (BM * BN) + (f * 256 + tid) * 4;
   const int i = f >> 2, j = f & 3;
@@ -511,6 +512,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args 
   }
   for (; s < p.split_k; ++s) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * sstride);
   const f32x4 sum = (s0 + s1) + (s2 + s3);
+  if (p.c_dtype == S2T_BF16) {  // overwrite mode only (the host checks): C = bf16(alpha * sum)
+    if (m < p.M && n < p.N) {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + coff + (int64_t)m * p.ldc + n;
+      if (n + 3 < p.N && (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 7) == 0 && (coff & 3) == 0) {
+        const uint32_t lo = (uint32_t)f2bf(p.alpha * sum[0]) | ((uint32_t)f2bf(p.alpha * sum[1]) << 16);
+        const uint32_t hi = (uint32_t)f2bf(p.alpha * sum[2]) | ((uint32_t)f2bf(p.alpha * sum[3]) << 16);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) dst[r] = f2bf(p.alpha * sum[r]);
+      }
+    }
+    return;
+  }
   if (m < p.M && n < p.N) {
     float* dst = C + (int64_t)m * p.ldc + n;
     const bool overwrite = p.c_atomic == 2;  // C = alpha * sum: the caller need not zero C first
@@ -601,8 +617,10 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   if (p.dtype == S2T_F32 && p.c_dtype != S2T_F32) return S2T_ERR_DTYPE;
   if ((p.lda % epb) || (p.ldb % epb) || ((uintptr_t)p.A % 16) || ((uintptr_t)p.B % 16)) return S2T_ERR_ALIGN;
   if ((p.a_s0 % epb) || (p.a_s1 % epb) || (p.b_s0 % epb) || (p.b_s1 % epb)) return S2T_ERR_ALIGN;
+  // split-K / atomic accumulation: fp32 C; the two-phase overwrite form (c_atomic == 2) may also round its result to bf16
+  const bool bf16_two_phase = p.c_dtype == S2T_BF16 && p.dtype == S2T_BF16 && p.split_k > 1 && p.c_atomic == 2;
   if (p.split_k > 1 || p.c_atomic) {
-    if (p.c_dtype != S2T_F32 || p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens || p.drop_p > 0.f)
+    if ((p.c_dtype != S2T_F32 && !bf16_two_phase) || p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens || p.drop_p > 0.f)
       return S2T_ERR_UNSUPPORTED;
   }
   {
@@ -630,12 +648,14 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (p.dtype == S2T_F32) return launch<float, float>(p, s);
-  if (p.c_dtype == S2T_F32) return launch<bf16_t, float>(p, s);
+  if (p.c_dtype == S2T_F32 || (bf16_two_phase && p.ws)) return launch<bf16_t, float>(p, s);  // (the partial tiles are fp32)
+  if (bf16_two_phase) return S2T_ERR_UNSUPPORTED;  // degenerated to one split without a workspace
   return launch<bf16_t, bf16_t>(p, s);
 }
 
 extern "C" int64_t s2t_gemm_ws_floats(const s2t_gemm_args* a) {
-  if (!a || a->c_dtype != S2T_F32 || a->M <= 0 || a->N <= 0) return 0;
+  if (!a || a->M <= 0 || a->N <= 0) return 0;
+  if (a->c_dtype != S2T_F32 && !(a->c_dtype == S2T_BF16 && a->c_atomic == 2)) return 0;
   return splitk_ws_floats(*a);
 }
 
@@ -644,7 +664,7 @@ extern "C" int64_t s2t_gemm_ws_floats(const s2t_gemm_args* a) {
 extern "C" int s2t_gemm_describe(const s2t_gemm_args* a, char* buf, int buflen) {
   if (!a || !buf || buflen <= 0) return S2T_ERR_ARG;
   const bool f32 = a->dtype == S2T_F32;
-  const bool cf32 = a->c_dtype == S2T_F32;
+  const bool cf32 = a->c_dtype == S2T_F32 || (a->c_dtype == S2T_BF16 && a->split_k > 1 && a->c_atomic == 2);
   const bool glu = a->act == S2T_ACT_GLU;
   const int nout = glu ? a->N / 2 : a->N;
   const bool kt = (a->K % (f32 ? 32 : 64)) != 0;

@@ -613,6 +613,24 @@ def _rb_ok(x, N, act=None):
     return _RB and K.rowblock_supported(x, N, act) and x.shape[0] >= _RB_MIN_ROWS
 
 
+_DGRAD_SPLITK = os.environ.get("S2T_DGRAD_SPLITK", "1") != "0"
+
+
+def _dgrad(dy, w, dx, M, N, Kd, lda, ldb, ldc, alpha=1.0):
+    """dx[M, N] = alpha * dy[M, Kd] @ w[Kd, N] (input gradient of a linear layer).  A long reduction over few output tiles —
+    the vocabulary projections (K = V = 10 000; M = B*U decoder rows: 32 tiles walking 157 K-steps each took 180 us) and the
+    decoder's FFN — is cut into K splits whose fp32 partial tiles meet in a workspace (two-phase split-K, bf16 result)."""
+    split = 1
+    if _DGRAD_SPLITK and dy.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and Kd >= 1024:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        if tiles < 384:
+            split = max(1, min(8, 512 // tiles, Kd // 256))
+    if split > 1:
+        K.gemm(dy, w, dx, M=M, N=N, K=Kd, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=True, alpha=alpha, split_k=split, c_atomic=2)
+    else:
+        K.gemm(dy, w, dx, M=M, N=N, K=Kd, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=True, alpha=alpha)
+
+
 # ------------------------------------------------------------------------------------------------
 # Linear (+ residual)
 # ------------------------------------------------------------------------------------------------
@@ -649,7 +667,7 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            K.gemm(dy, cw(w), dx, M=M, N=Kin, K=Nout, lda=ldy, ldb=Kin, ldc=Kin, b_kmajor=True, alpha=ctx.alpha)
+            _dgrad(dy, cw(w), dx, M, Kin, Nout, ldy, Kin, Kin, ctx.alpha)
         _wgrad(dy, x, w.grad, Nout, Kin, M, ldy, Kin, ctx.alpha, b.grad if b is not None else None)
         _ready(w, b)
         return dx, None, None, None, (dy if ctx.has_res else None), None
@@ -700,7 +718,7 @@ class FFNFn(torch.autograd.Function):
         _ready(w2, b2)
         _wgrad(dz, x, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)
         dx = torch.empty_like(x)
-        K.gemm(dz, cw(w1), dx, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
+        _dgrad(dz, cw(w1), dx, M, d, F_, F_, d, d)
         _ready(w1, b1)
         return dx, None, None, None, None, None, None, dres, None, None, None
 
@@ -802,7 +820,7 @@ class FFNBlockFn(torch.autograd.Function):
             dxl = torch.empty_like(x)
             K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
                    dact=ctx.act, drop=drop_h)
-            K.gemm(dz, cw(w1), dxl, M=M, N=d, K=F_, lda=F_, ldb=d, ldc=d, b_kmajor=True)
+            _dgrad(dz, cw(w1), dxl, M, d, F_, F_, d, d)
         _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad)
         _ready(w2, b2)
         _wgrad(dz, x_ln, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)

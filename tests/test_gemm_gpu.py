@@ -230,3 +230,23 @@ def test_grouped_wgrad_matches_reference(variant, monkeypatch):
         np.testing.assert_allclose(dW.cpu().double().numpy(), rw.numpy(), rtol=1e-3, atol=1e-3 * rw.abs().max().item())
         if db is not None:
             np.testing.assert_allclose(db.cpu().double().numpy(), rb.numpy(), rtol=1e-3, atol=1e-3 * rb.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K,split", [(1952, 256, 10000, 8), (300, 200, 2100, 4), (16000, 256, 4096, 2)])
+def test_two_phase_splitk_with_bf16_result(M, N, K, split):
+    """s2t_gemm, split_k > 1 with c_atomic = 2 and a bf16 C: fp32 partial tiles through the workspace, one rounding at the
+    end (the input-gradient GEMMs with a long reduction over few output tiles: vocabulary projection, decoder FFN)."""
+    g = torch.Generator().manual_seed(M + K)
+    dev = "cuda"
+    ldk, ldn = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+    A = torch.zeros(M, ldk, dtype=torch.bfloat16); A[:, :K] = _mk((M, K), torch.bfloat16, g)
+    B = torch.zeros(K, ldn, dtype=torch.bfloat16); B[:, :N] = _mk((K, N), torch.bfloat16, g)
+    out = torch.full((M, ldn), 9.0, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), out, M=M, N=N, K=K, lda=ldk, ldb=ldn, ldc=ldn, b_kmajor=True, alpha=0.5, split_k=split,
+             c_atomic=2)
+    torch.cuda.synchronize()
+    ref = 0.5 * A[:, :K].double() @ B[:, :N].double()
+    got = out.cpu().double()[:, :N]
+    assert (got - ref).abs().max() <= 1e-2 * ref.abs().max()
+    if ldn > N:
+        assert float((out.cpu().float()[:, N:] - 9.0).abs().max()) == 0.0  # columns beyond N untouched
