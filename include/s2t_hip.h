@@ -288,6 +288,15 @@ int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int
 int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, float* ws /* [replicas][C][K]: zero in, zero out */,
                           int replicas, int B, int T, int C, int K, void* stream);
 int s2t_dwconv_wgrad_partials(int B, int T); /* rows of C*K floats s2t_dwconv_bwd_weight needs in ws (pass as `replicas`) */
+/* s2t_conv_bwd_fused (bf16): the backward of the convolution module's middle in one launch + one fold —
+ *   dD = BatchNorm backward pass 2 on (D, dA) from the folded sums of s2t_bn_act_bwd (called with dD = NULL: reduce + fold
+ *   only), dG = depthwise conv of dD with the flipped kernel, dZ [B*T][2C] = GLU backward of dG on the saved value | gate
+ *   Z, dw[c][k] += sum_t dD[t][c] * G[t + k - pad][c] (G = the GLU output the forward convolved).  Replaces the apply pass of
+ *   s2t_bn_act_bwd, s2t_dwconv_fwd(flip), s2t_glu_bwd and s2t_dwconv_bwd_weight (convolution.py:92-104 backward) without
+ *   passing dD and dG through HBM.  ws: B * ceil(T/32) rows of C*K floats. */
+int s2t_conv_bwd_fused(const void* D, const void* dA, const void* G, const void* Z, const float* w, const float* scale,
+                       const float* shift, const float* mean, const float* rstd, const float* sums, float count, int act,
+                       const int32_t* lens, void* dZ, float* dw, float* ws, int B, int T, int C, int K, void* stream);
 int s2t_dwconv_stat_partials(int B, int T);
 int s2t_bn_bwd_partials(int64_t rows);
 int s2t_bn_finalize(const float* stats, int partials, float count, const float* gamma, const float* beta, float* running_mean,

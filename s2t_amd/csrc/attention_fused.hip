@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
   constexpr bool BAND_ON = REL && !(S2T_ATT_DBG & 4);
   PFrags pnext;  // position rows of the block about to be scored (one register set: re-filled right after its MFMAs)
-  if constexpr (BAND_ON) load_pfrags(a, pnext, h, q0w, 0, x, y);
+  constexpr bool PRE_ON = BAND_ON && !(S2T_ATT_DBG & 128);
+  if constexpr (PRE_ON) load_pfrags(a, pnext, h, q0w, 0, x, y);
   ASTAMP();
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
@@ -479,9 +480,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
     }
     f32x4 st[4];
-    scores_block<BAND_ON, BAND_ON>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
+    scores_block<BAND_ON, PRE_ON>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
     ASTAMP();
-    if constexpr (BAND_ON) {  // the next block's position rows travel during this block's softmax and PV product
+    if constexpr (PRE_ON) {  // the next block's position rows travel during this block's softmax and PV product
       if (k0 + KB < kend) load_pfrags(a, pnext, h, q0w, k0 + KB, x, y);
     }
     // dP^T[key][q] = V[key] . dO[q]

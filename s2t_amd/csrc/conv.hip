@@ -395,6 +395,172 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   st4_from_f32<T>(dD + row * C + c, o);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the convolution module's middle (BatchNorm + activation -> depthwise conv -> GLU) in ONE launch, bf16:
+//   dD  = gamma*rstd * (du - s1/n - xhat*s2/n),  du = dA * act'(D*scale + shift), padded frames: du = 0        (BatchNorm, pass 2)
+//   dG  = depthwise conv of dD with the flipped kernel                                         (s2t_dwconv_fwd, flip)
+//   dZ  = [dG * sigmoid(gate) | dG * value * sigmoid'(gate)]                                   (s2t_glu_bwd)
+//   dw[c][k] partial = sum_t dD[t][c] * G[t + k - pad][c]                                      (s2t_dwconv_bwd_weight)
+// replacing four launches that pass dD and dG through HBM (convolution.py:92-104 backward).  A workgroup owns 32 time
+// steps x 256 channels of one utterance: the dD window (32 + K - 1 rows, computed while staging, rounded to bf16 as the
+// stored tensor of the unfused path is) and the G window sit in LDS as bf16; thread (channel quad cq, time group tg)
+// produces 8 time steps of dG / dZ and its share of the weight-gradient partial, which leaves as one plain row per
+// workgroup (rows_fold_add_kernel adds them in a fixed order).
+__global__ __launch_bounds__(256) void conv_bwd_fused_kernel(
+    const bf16_t* __restrict__ D, const bf16_t* __restrict__ dA, const bf16_t* __restrict__ G, const bf16_t* __restrict__ Z,
+    const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ sums, float inv_count,
+    int act, const int32_t* __restrict__ lens, bf16_t* __restrict__ dZ, float* __restrict__ dw_ws, int B, int T_, int C,
+    int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int pad = (K - 1) / 2;
+  const int nrows = TT + K - 1;
+  bf16_t* ld_ = reinterpret_cast<bf16_t*>(smem);  // [nrows][256] dD window
+  bf16_t* lg = ld_ + nrows * CCH;                 // [nrows][256] G window
+  float* lw = reinterpret_cast<float*>(lg + nrows * CCH);  // [K][256] flipped weights; reused for the dw transpose
+  const int t0 = blockIdx.x * TT;
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.z * CCH;
+  const int len = lens ? lens[b] : T_;
+  for (int idx = threadIdx.x; idx < K * CCH; idx += 256) {
+    const int k = idx / CCH, c = idx % CCH;
+    lw[idx] = (c0 + c < C) ? w[(int64_t)(c0 + c) * K + (K - 1 - k)] : 0.f;
+  }
+  {  // ---- staging: dD computed on the way in, G copied; 8 independent row pieces per thread and batch
+    const int cq = threadIdx.x & 63;
+    const int c = c0 + cq * 4;
+    const int cc = min(c, C - 4);
+    float sc[4], sh[4], mu[4], rs[4], m1[4], m2[4];
+    ld4_as_f32<float>(scale + cc, sc);
+    ld4_as_f32<float>(shift + cc, sh);
+    ld4_as_f32<float>(mean + cc, mu);
+    ld4_as_f32<float>(rstd + cc, rs);
+    ld4_as_f32<float>(sums + cc, m1);
+    ld4_as_f32<float>(sums + C + cc, m2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      m1[r] *= inv_count;
+      m2[r] *= inv_count;
+    }
+    constexpr int NB = 4;
+    for (int r0 = threadIdx.x >> 6; r0 < nrows; r0 += 4 * NB) {
+      float dv[NB][4], av[NB][4], gv[NB][4];
+      bool ok[NB];
+      int tt[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {  // unconditional, clamped loads (a load under a branch is waited for on the spot)
+        const int r = min(r0 + 4 * q, nrows - 1);
+        const int t = t0 - pad + r;
+        tt[q] = t;
+        ok[q] = r0 + 4 * q < nrows && t >= 0 && t < T_ && c < C;
+        const int64_t row = (int64_t)b * T_ + min(max(t, 0), T_ - 1);
+        ld4_as_f32<bf16_t>(D + row * C + cc, dv[q]);
+        ld4_as_f32<bf16_t>(dA + row * C + cc, av[q]);
+        ld4_as_f32<bf16_t>(G + row * C + cc, gv[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int r = r0 + 4 * q;
+        if (r < nrows) {
+          float o[4], g4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float du = tt[q] < len ? av[q][e] * act_grad(act, dv[q][e] * sc[e] + sh[e]) : 0.f;
+            const float xh = (dv[q][e] - mu[e]) * rs[e];
+            o[e] = ok[q] ? sc[e] * (du - m1[e] - xh * m2[e]) : 0.f;
+            g4[e] = ok[q] ? gv[q][e] : 0.f;
+          }
+          st4_from_f32<bf16_t>(ld_ + r * CCH + cq * 4, o);
+          st4_from_f32<bf16_t>(lg + r * CCH + cq * 4, g4);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int cq = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = c0 + cq * 4;
+  {  // ---- dG = conv(dD, flipped w) for 8 time steps, GLU backward, dZ out
+    float acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float4 w4 = *reinterpret_cast<const float4*>(lw + k * CCH + cq * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float x4[4];
+        ld4_as_f32<bf16_t>(ld_ + (tg * 8 + i + k) * CCH + cq * 4, x4);
+        acc[i][0] += w4.x * x4[0];
+        acc[i][1] += w4.y * x4[1];
+        acc[i][2] += w4.z * x4[2];
+        acc[i][3] += w4.w * x4[3];
+      }
+    }
+    float zv[8][4], zg[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // all sixteen loads first
+      const int t = min(t0 + tg * 8 + i, T_ - 1);
+      const int64_t row = (int64_t)b * T_ + t;
+      const int cc = min(c, C - 4);
+      ld4_as_f32<bf16_t>(Z + row * 2 * C + cc, zv[i]);
+      ld4_as_f32<bf16_t>(Z + row * 2 * C + C + cc, zg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + tg * 8 + i;
+      if (t < T_ && c < C) {
+        float da[4], dg[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dy = bf2f(f2bf(acc[i][r]));  // the unfused path stores dG in bf16 before the GLU backward
+          const float sg = sigmoidf_(zg[i][r]);
+          da[r] = dy * sg;
+          dg[r] = dy * zv[i][r] * sg * (1.f - sg);
+        }
+        const int64_t row = (int64_t)b * T_ + t;
+        st4_from_f32<bf16_t>(dZ + row * 2 * C + c, da);
+        st4_from_f32<bf16_t>(dZ + row * 2 * C + C + c, dg);
+      }
+    }
+  }
+  // ---- weight-gradient partial: dw[c][k] = sum over the tile's 32 time steps of dD[t][c] * G[t + k - pad][c]
+  float accw[8][4];  // k = tg + 4*kk
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) accw[i][r] = 0.f;
+  for (int t = 0; t < TT; ++t) {
+    float d4[4];
+    ld4_as_f32<bf16_t>(ld_ + (t + pad) * CCH + cq * 4, d4);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k = tg + 4 * kk;
+      if (k < K) {
+        float g4[4];
+        ld4_as_f32<bf16_t>(lg + (t + k) * CCH + cq * 4, g4);
+        accw[kk][0] += d4[0] * g4[0];
+        accw[kk][1] += d4[1] * g4[1];
+        accw[kk][2] += d4[2] * g4[2];
+        accw[kk][3] += d4[3] * g4[3];
+      }
+    }
+  }
+  __syncthreads();  // the flipped weights are no longer read: lw becomes the [256 channels][K] transpose buffer
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int k = tg + 4 * kk;
+    if (k < K) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lw[(cq * 4 + r) * K + k] = accw[kk][r];
+    }
+  }
+  __syncthreads();
+  float* dwr = dw_ws + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * C * K + (int64_t)c0 * K;
+  const int nvalid = min(CCH, C - c0) * K;
+  for (int idx = threadIdx.x; idx < nvalid; idx += 256) dwr[idx] = lw[idx];
+}
+
 // dynamic LDS above the 64 KiB default needs a one-time opt-in per kernel (never inside a stream capture)
 void ensure_lds_optin() {
   static bool done = false;
@@ -403,6 +569,7 @@ void ensure_lds_optin() {
   hipFuncSetAttribute((const void*)dwconv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   hipFuncSetAttribute((const void*)dwconv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   hipFuncSetAttribute((const void*)dwconv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  hipFuncSetAttribute((const void*)conv_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   done = true;
 }
 
@@ -450,6 +617,28 @@ extern "C" int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, f
   return S2T_LAUNCH_CHECK();
 }
 
+extern "C" int s2t_conv_bwd_fused(const void* D, const void* dA, const void* G, const void* Z, const float* w,
+                                  const float* scale, const float* shift, const float* mean, const float* rstd,
+                                  const float* sums, float count, int act, const int32_t* lens, void* dZ, float* dw,
+                                  float* ws, int B, int T, int C, int K, void* stream) {
+  if (!D || !dA || !G || !Z || !w || !scale || !shift || !mean || !rstd || !sums || !dZ || !dw || !ws) return S2T_ERR_ARG;
+  if (B <= 0 || T <= 0 || C <= 0 || K <= 0 || !(K & 1) || C % 4 || count <= 0.f) return S2T_ERR_ARG;
+  if (K > 31) return S2T_ERR_UNSUPPORTED;
+  const void* ptrs[] = {D, dA, G, Z, dZ};
+  for (const void* q : ptrs)
+    if ((uintptr_t)q % 8) return S2T_ERR_ALIGN;
+  const int tiles_t = (T + TT - 1) / TT;
+  const size_t shm = (size_t)(2 * (TT + K - 1) * CCH) * sizeof(bf16_t) + (size_t)(K * CCH) * sizeof(float);
+  dim3 grid(tiles_t, B, (C + CCH - 1) / CCH), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  ensure_lds_optin();
+  hipLaunchKernelGGL(conv_bwd_fused_kernel, grid, block, shm, s, (const bf16_t*)D, (const bf16_t*)dA, (const bf16_t*)G,
+                     (const bf16_t*)Z, w, scale, shift, mean, rstd, sums, 1.0f / count, act, lens, (bf16_t*)dZ, ws, B, T, C, K);
+  const int64_t n = (int64_t)C * K;
+  hipLaunchKernelGGL(rows_fold_add_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, s, ws, B * tiles_t, n, dw);
+  return S2T_LAUNCH_CHECK();
+}
+
 extern "C" int s2t_dwconv_wgrad_partials(int B, int T) {
   const int nb = B * ((T + TT - 1) / TT);
   return nb > 1024 ? 1024 : nb;
@@ -491,7 +680,7 @@ extern "C" int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* 
                               float* ws /* [s2t_bn_bwd_partials(rows)][2C] scratch */, float* dgamma, float* dbeta,
                               float count, int act,
                               int64_t rows, int C, const int32_t* lens, int T, void* stream) {
-  if (!D || !dOut || !dD || !scale || !shift || !mean || !rstd || !sums || !ws || rows <= 0 || C <= 0 || C % 4) return S2T_ERR_ARG;
+  if (!D || !dOut || !scale || !shift || !mean || !rstd || !sums || !ws || rows <= 0 || C <= 0 || C % 4) return S2T_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int slices = s2t_bn_bwd_partials(rows);
   dim3 rgrid((C + 255) / 256, (unsigned)slices), block(256);
@@ -500,11 +689,11 @@ extern "C" int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* 
   if (dtype == S2T_F32) {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, rgrid, block, 0, s, (const float*)D, (const float*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, ws);
     hipLaunchKernelGGL(bn_bwd_fold_kernel, fgrid, fblock, 0, s, ws, slices, C, sums, dgamma, dbeta);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, agrid, block, 0, s, (const float*)D, (const float*)dOut, (float*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
+    if (dD) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, agrid, block, 0, s, (const float*)D, (const float*)dOut, (float*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
   } else if (dtype == S2T_BF16) {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, rgrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, scale, shift, mean, rstd, act, rows, C, lens, T, ws);
     hipLaunchKernelGGL(bn_bwd_fold_kernel, fgrid, fblock, 0, s, ws, slices, C, sums, dgamma, dbeta);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, agrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, (bf16_t*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
+    if (dD) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, agrid, block, 0, s, (const bf16_t*)D, (const bf16_t*)dOut, (bf16_t*)dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens, T);
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

@@ -1381,16 +1381,24 @@ class ConvModuleFn(torch.autograd.Function):
         K.gemm(dy, cw(prm["pw2_w"]).view(d, d), dA, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
         _wgrad(dy, a, prm["pw2_w"].grad.view(d, d), d, d, M, d, d)
         # here dy rows of padded frames must not reach pw2's weight gradient: a is zero there -> contributes nothing
-        dD = torch.empty(M, d, dtype=dt, device=dev)
         sums = torch.empty(2 * d, dtype=torch.float32, device=dev)
-        K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T,
-                     dgamma=prm["bn_w"].grad, dbeta=prm["bn_b"].grad)
         wd = prm["dw_w"].data.view(d, Kw)
-        dG = torch.empty(M, d, dtype=dt, device=dev)
-        K.dwconv_fwd(dD, wd, dG, B, T, d, Kw, flip=True)
-        K.dwconv_bwd_weight(g, dD, prm["dw_w"].grad.view(d, Kw), B, T, d, Kw)
         dZ = torch.empty(M, 2 * d, dtype=dt, device=dev)
-        K.glu_bwd(z, dG, dZ, M, d)
+        if _CONV_BWD_FUSED and dt == torch.bfloat16 and Kw <= 31:
+            # BatchNorm reduce + fold, then ONE launch for the apply pass, the depthwise dgrad, the GLU backward and the
+            # depthwise weight-gradient partials (dD and dG never reach HBM)
+            K.bn_act_bwd(D, dA, None, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T,
+                         dgamma=prm["bn_w"].grad, dbeta=prm["bn_b"].grad)
+            K.conv_bwd_fused(D, dA, g, z, wd, scale, shift, mean, rstd, sums, M, ctx.act, ctx.lens, dZ,
+                             prm["dw_w"].grad.view(d, Kw), B, T, d, Kw)
+        else:
+            dD = torch.empty(M, d, dtype=dt, device=dev)
+            K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T,
+                         dgamma=prm["bn_w"].grad, dbeta=prm["bn_b"].grad)
+            dG = torch.empty(M, d, dtype=dt, device=dev)
+            K.dwconv_fwd(dD, wd, dG, B, T, d, Kw, flip=True)
+            K.dwconv_bwd_weight(g, dD, prm["dw_w"].grad.view(d, Kw), B, T, d, Kw)
+            K.glu_bwd(z, dG, dZ, M, d)
         _wgrad(dZ, x, prm["pw1_w"].grad.view(2 * d, d), 2 * d, d, M, 2 * d, d)
         dx = torch.empty(M, d, dtype=dt, device=dev)
         K.gemm(dZ, cw(prm["pw1_w"]).view(2 * d, d), dx, M=M, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
@@ -1401,6 +1409,9 @@ class ConvModuleFn(torch.autograd.Function):
             dxp = _ln_backward(x_pre, ln_g, ln_b, dx, ln_mean, ln_rstd, ctx.lens, T, dres, up_drop)
             return (dxp, None) + (None,) * 12
         return (dx, (dres if ctx.has_res else None)) + (None,) * 12
+
+
+_CONV_BWD_FUSED = os.environ.get("S2T_CONV_BWD_FUSED", "1") != "0"  # s2t_conv_bwd_fused in ConvModuleFn.backward (bf16)
 
 
 def conv_module(x, residual, prm, bn_buf, act, B, T, lens, training, momentum=0.1, p_out=0.0, ln=None):

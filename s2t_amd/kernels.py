@@ -381,6 +381,17 @@ def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
           rows, B, T, C, K)
 
 
+def conv_bwd_fused(D, dA, G, Z, w, scale, shift, mean, rstd, sums, count, act, lens, dZ, dw, B, T, C, Kw):
+    """s2t_conv_bwd_fused (include/s2t_hip.h); bf16 only."""
+    L.require_cuda(D, dA, G, Z, dZ)
+    assert all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in (D, dA, G, Z, dZ))
+    rows = B * ((T + 31) // 32)
+    ws = _scratch("dw_fused", rows * C * Kw, D.device)
+    _call("s2t_conv_bwd_fused", D.data_ptr(), dA.data_ptr(), G.data_ptr(), Z.data_ptr(), w.data_ptr(), scale.data_ptr(),
+          shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), float(count), L.ACT_IDS[act], _ptr(lens),
+          dZ.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, T, C, Kw)
+
+
 def dwconv_stat_partials(B, T):
     return L.lib().s2t_dwconv_stat_partials(B, T)
 
@@ -399,7 +410,7 @@ def bn_act_fwd(D, out, scale, shift, act, rows, C, lens=None, T=0):
 def bn_act_bwd(D, dOut, dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens=None, T=0, dgamma=None, dbeta=None):
     """``dgamma`` / ``dbeta`` (fp32 [C], optional): the folded sums are also ADDED to them (the parameter gradients)."""
     ws = _scratch("bn_bwd", L.lib().s2t_bn_bwd_partials(rows) * 2 * C, D.device)
-    _call("s2t_bn_act_bwd", L.dtype_id(D.dtype), D.data_ptr(), dOut.data_ptr(), dD.data_ptr(), scale.data_ptr(),
+    _call("s2t_bn_act_bwd", L.dtype_id(D.dtype), D.data_ptr(), dOut.data_ptr(), _ptr(dD), scale.data_ptr(),
           shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), ws.data_ptr(), _ptr(dgamma), _ptr(dbeta),
           float(count), L.ACT_IDS[act], rows, C, _ptr(lens), T)
 

@@ -274,6 +274,51 @@ def test_dwconv_bn_act_fwd_bwd(dtype, Kw):
         close(out2, O.activation(act, ue).masked_fill(pm[:, :, None], 0.0), dtype, 4)
 
 
+@pytest.mark.parametrize("B,T,C,Kw,act", [(3, 45, 32, 15, "swish"), (2, 250, 256, 15, "swish"), (4, 70, 260, 31, "relu")])
+def test_conv_bwd_fused_matches_the_four_kernel_chain(B, T, C, Kw, act):
+    """s2t_conv_bwd_fused (bf16) against the chain it replaces on the same inputs: BatchNorm apply pass -> flipped depthwise
+    conv -> GLU backward, and the depthwise weight gradient (modules/convolution.py:92-104 backward).  dD and dG are rounded
+    to bf16 at the same points, so dZ agrees to a bf16 ulp or two and the weight gradient to fp32 summation order."""
+    g = torch.Generator().manual_seed(B * T + C)
+    bf = torch.bfloat16
+    lens = torch.tensor([T, max(1, T * 2 // 3), 8, T][:B], dtype=torch.int32).to(DEV)
+    G = rnd((B, T, C), bf, g).to(DEV)                       # GLU output the forward convolved
+    Z = rnd((B * T, 2 * C), bf, g).to(DEV)                  # value | gate
+    w = (torch.randn(C, Kw, generator=g) * 0.3).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    dA = rnd((B, T, C), bf, g).to(DEV)
+    n = B * T
+    D = torch.empty_like(G)
+    stats = torch.empty(K.dwconv_stat_partials(B, T), 2, C, device=DEV)
+    K.dwconv_fwd(G, w, D, B, T, C, Kw, stats=stats)
+    scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+    K.bn_finalize(stats, n, gamma, beta, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), 0.1, 1e-5, True, scale, shift,
+                  mean, rstd, C)
+    # the chain
+    dD = torch.empty_like(G)
+    sums = torch.empty(2 * C, device=DEV)
+    K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, n, act, n, C, lens, T)
+    dG = torch.empty_like(G)
+    K.dwconv_fwd(dD, w, dG, B, T, C, Kw, flip=True)
+    dw_ref = torch.full((C, Kw), 0.5, device=DEV)
+    K.dwconv_bwd_weight(G, dD, dw_ref, B, T, C, Kw)
+    dZ_ref = torch.empty_like(Z)
+    K.glu_bwd(Z, dG.view(n, C), dZ_ref, n, C)
+    # the fused launch (reduce + fold first, without the apply pass)
+    sums2 = torch.empty(2 * C, device=DEV)
+    K.bn_act_bwd(D, dA, None, scale, shift, mean, rstd, sums2, n, act, n, C, lens, T)
+    assert torch.equal(sums, sums2)
+    dZ = torch.full_like(Z, 3.0)
+    dw = torch.full((C, Kw), 0.5, device=DEV)
+    K.conv_bwd_fused(D.view(n, C), dA.view(n, C), G.view(n, C), Z, w, scale, shift, mean, rstd, sums2, n, act, lens, dZ, dw, B,
+                     T, C, Kw)
+    torch.cuda.synchronize()
+    err = (dZ.float() - dZ_ref.float()).abs().max() / dZ_ref.float().abs().max()
+    assert err < 1.6e-2, float(err)
+    assert (dZ.float() - dZ_ref.float()).norm() / dZ_ref.float().norm() < 4e-3
+    assert (dw - dw_ref).abs().max() <= 2e-3 * dw_ref.abs().max() + 1e-4
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_ctc_greedy_kernels(dtype):
     g = torch.Generator().manual_seed(6)
