@@ -239,7 +239,7 @@ int s2t_embedding_fwd(int dtype, const int64_t* tokens, const int32_t* pos, cons
 int s2t_embedding_bwd(int dtype, const int64_t* tokens, const void* dout, float* dE, int64_t n, int d, float scale,
                       int64_t pad_idx, void* stream);
 int s2t_glu_bwd(int dtype, const void* Z, const void* dY, void* dZ, int64_t rows, int n, const int32_t* lens, int T,
-                void* stream);
+                int out_pad /* dZ has out_pad extra rows behind every T rows, not written (T > 0 required) */, void* stream);
 int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db, int64_t rows, int n, void* stream);
 /* relative-position attention backward glue: a[row][0:n] += b[row][0:n] in place, du[c] += column sums of the OLD a,
  * dv[c] += column sums of b (pos_bias_u / pos_bias_v gradients, espnet_multihead_attention.py:313-356); bf16, n = 256 */

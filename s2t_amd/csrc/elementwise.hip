@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ dY,
                                                       T* __restrict__ dZ, int64_t rows, int n,
-                                                      const int32_t* __restrict__ lens, int Tn) {
+                                                      const int32_t* __restrict__ lens, int Tn, int out_pad) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int vec_per_row = n / 4;
   if (idx >= rows * vec_per_row) return;
@@ -138,8 +138,10 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ Z, c
     da[r] = d * s;
     dg[r] = d * a[r] * s * (1.f - s);
   }
-  st4_from_f32<T>(dZ + row * 2 * n + c, da);
-  st4_from_f32<T>(dZ + row * 2 * n + n + c, dg);
+  // out_pad: dZ keeps `out_pad` extra rows behind every block of Tn rows (left untouched here)
+  const int64_t orow = out_pad ? row + (row / Tn) * out_pad : row;
+  st4_from_f32<T>(dZ + orow * 2 * n + c, da);
+  st4_from_f32<T>(dZ + orow * 2 * n + n + c, dg);
 }
 
 // bf16 fast path for row widths of 256 / 512 / 1024 / 2048: one 16-byte load per lane (8 columns), TPR = n / 8 lanes per
@@ -466,14 +468,14 @@ extern "C" int s2t_embedding_bwd(int dtype, const int64_t* tokens, const void* d
 }
 
 extern "C" int s2t_glu_bwd(int dtype, const void* Z, const void* dY, void* dZ, int64_t rows, int n,
-                           const int32_t* lens, int T, void* stream) {
-  if (!Z || !dY || !dZ || rows < 0 || n <= 0 || n % 4) return S2T_ERR_ARG;
+                           const int32_t* lens, int T, int out_pad, void* stream) {
+  if (!Z || !dY || !dZ || rows < 0 || n <= 0 || n % 4 || out_pad < 0 || (out_pad > 0 && T <= 0)) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   dim3 grid((unsigned)((rows * (n / 4) + 255) / 256));
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)Z, (const float*)dY, (float*)dZ, rows, n, lens, T);
+    hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)Z, (const float*)dY, (float*)dZ, rows, n, lens, T, out_pad);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Z, (const bf16_t*)dY, (bf16_t*)dZ, rows, n, lens, T);
+    hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Z, (const bf16_t*)dY, (bf16_t*)dZ, rows, n, lens, T, out_pad);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

@@ -1509,12 +1509,14 @@ class SubsampleFn(torch.autograd.Function):
         T2 = _conv_out_len(T1)
         Cin_p = _pad8(Cin)
         assert Cin_p == Cin, "input feature dim must be a multiple of 8"
+        # (a tail of k rows behind the last utterance: the weight-gradient product reads every buffer as overlapping rows
+        # of k * C elements at a stride of 2 * C, junk rows of the last utterance included, see backward)
         Tp0 = 2 * T1 + 4
-        xp = torch.zeros(B, Tp0, Cin, dtype=dt, device=dev)
+        xp = torch.zeros(B * Tp0 + kk, Cin, dtype=dt, device=dev)[:B * Tp0].view(B, Tp0, Cin)
         xp[:, 2:2 + T].copy_(src)
         H0 = C0 // 2
         Tp1 = 2 * T2 + 4
-        y1p = torch.zeros(B, Tp1, H0, dtype=dt, device=dev)
+        y1p = torch.zeros(B * Tp1 + kk, H0, dtype=dt, device=dev)[:B * Tp1].view(B, Tp1, H0)
         z1 = torch.empty(B, T1, C0, dtype=dt, device=dev) if train else None
         K.gemm(xp, cw(w0).view(C0, kk * Cin), y1p[:, 2:], M=T1, N=C0, K=kk * Cin, lda=2 * Cin, ldb=kk * Cin, ldc=H0,
                batch=B, a_s=(Tp0 * Cin, 0), c_s=(Tp1 * H0, 0), bias=b0.data, act="glu", preact=z1, ldp=C0,
@@ -1541,27 +1543,32 @@ class SubsampleFn(torch.autograd.Function):
         H0, H1 = C0 // 2, C1 // 2
         dt, dev = xp.dtype, xp.device
         dy = dy.contiguous()
+        # Weight gradients as ONE product over all utterances: the padded input buffers hold Tp = 2 (T' + 2) rows per
+        # utterance, so with TWO extra all-zero gradient rows behind every utterance's T' the overlapping im2col rows
+        # (row r of the product = buffer offset r * 2 * C, length k * C) of all utterances form a single matrix with a
+        # uniform row stride — K = B (T' + 2) instead of B separate K = T' products accumulated with atomics; the two junk
+        # rows per utterance multiply zeros.  The products then join the grouped weight-gradient launch (bias included).
+        assert Tp1 == 2 * (T2 + 2) and Tp0 == 2 * (T1 + 2)
         # layer 2: GLU backward (padded frames carry no gradient)
-        dz2 = torch.empty(B * T2, C1, dtype=dt, device=dev)
-        K.glu_bwd(z2.view(B * T2, C1), dy, dz2, B * T2, H1, ctx.out_lens, T2)
-        # dW1[C1, k*H0] += sum_b dz2[b]^T im2col(y1p[b])   (several batches share dW -> atomics)
-        K.gemm(dz2, y1p, w1.grad.view(C1, kk * H0), M=C1, N=kk * H0, K=T2, lda=C1, ldb=2 * H0, ldc=kk * H0,
-               a_kmajor=True, b_kmajor=True, batch=B, a_s=(T2 * C1, 0), b_s=(Tp1 * H0, 0), c_s=(0, 0), c_atomic=True)
-        K.colsum_accum(dz2, C1, b1.grad, B * T2, C1)
+        dz2 = torch.empty(B, T2 + 2, C1, dtype=dt, device=dev)
+        dz2[:, T2:].zero_()
+        K.glu_bwd(z2.view(B * T2, C1), dy, dz2, B * T2, H1, ctx.out_lens, T2, out_pad=2)
+        _wgrad(dz2.view(B * (T2 + 2), C1), y1p, w1.grad.view(C1, kk * H0), C1, kk * H0, B * (T2 + 2), C1, 2 * H0, 1.0,
+               b1.grad)
         # d y1p: one GEMM per kernel tap (rows 2t+tap never collide inside one tap); accumulate tap by tap
         dy1p = torch.zeros(B, Tp1, H0, dtype=dt, device=dev)
         w1c = cw(w1).view(C1, kk * H0)
         for tap in range(kk):
             out = dy1p.view(-1)[tap * H0:]
             K.gemm(dz2, w1c[:, tap * H0:], out, M=T2, N=H0, K=C1, lda=C1, ldb=kk * H0, ldc=2 * H0, b_kmajor=True, batch=B,
-                   a_s=(T2 * C1, 0), c_s=(Tp1 * H0, 0), residual=out, ldr=2 * H0)
+                   a_s=((T2 + 2) * C1, 0), c_s=(Tp1 * H0, 0), residual=out, ldr=2 * H0)
         # layer 1
-        dz1 = torch.empty(B * T1, C0, dtype=dt, device=dev)
+        dz1 = torch.empty(B, T1 + 2, C0, dtype=dt, device=dev)
+        dz1[:, T1:].zero_()
         dy1 = dy1p[:, 2:2 + T1].contiguous().view(B * T1, H0)
-        K.glu_bwd(z1.view(B * T1, C0), dy1, dz1, B * T1, H0)
-        K.gemm(dz1, xp, w0.grad.view(C0, kk * Cin), M=C0, N=kk * Cin, K=T1, lda=C0, ldb=2 * Cin, ldc=kk * Cin,
-               a_kmajor=True, b_kmajor=True, batch=B, a_s=(T1 * C0, 0), b_s=(Tp0 * Cin, 0), c_s=(0, 0), c_atomic=True)
-        K.colsum_accum(dz1, C0, b0.grad, B * T1, C0)
+        K.glu_bwd(z1.view(B * T1, C0), dy1, dz1, B * T1, H0, None, T1, out_pad=2)
+        _wgrad(dz1.view(B * (T1 + 2), C0), xp, w0.grad.view(C0, kk * Cin), C0, kk * Cin, B * (T1 + 2), C0, 2 * Cin, 1.0,
+               b0.grad)
         _ready(w0, b0, w1, b1)
         return None, None, None, None, None, None, None, None
 

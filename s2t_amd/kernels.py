@@ -340,8 +340,9 @@ def embedding_bwd(tokens, dout, dE, n, d, scale, pad_idx):
           pad_idx)
 
 
-def glu_bwd(Z, dY, dZ, rows, n, lens=None, T=0):
-    _call("s2t_glu_bwd", L.dtype_id(Z.dtype), Z.data_ptr(), dY.data_ptr(), dZ.data_ptr(), rows, n, _ptr(lens), T)
+def glu_bwd(Z, dY, dZ, rows, n, lens=None, T=0, out_pad=0):
+    """``out_pad``: dZ is laid out with ``out_pad`` extra rows behind every T rows (those rows are not written)."""
+    _call("s2t_glu_bwd", L.dtype_id(Z.dtype), Z.data_ptr(), dY.data_ptr(), dZ.data_ptr(), rows, n, _ptr(lens), T, out_pad)
 
 
 def colsum_accum(dY, ld, db, rows, n):
