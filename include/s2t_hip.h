@@ -155,6 +155,8 @@ int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP,
  * zero-padded so that n in [-16, 2Tq-2+96] is readable (pt_ld % 8 == 0, 16-byte aligned).  The dQ kernel then adds the
  * (Q+v) P^T branch itself — dq is the complete gradient w.r.t. Q — and accumulates the pos_bias_u / pos_bias_v gradients
  * (column sums of the two branches, espnet_multihead_attention.py:339-345) into dpos_u / dpos_v ([H*64] fp32, atomics).
+ * qv_out != NULL (relative form): the dQ kernel also writes Q + pos_v ([B*Tq][H*64] bf16, the operand of the position-table
+ * gradient GEMM) instead of a separate s2t_bias_add_rows pass.
  * ------------------------------------------------------------------------------------------------ */
 int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
                        int64_t v_sb, int64_t v_sr, void* o, int64_t o_sb, int64_t o_sr, float* lse, int B, int H, int Tq,
@@ -167,7 +169,8 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        int Tq, int Tk, int dk_dim, const int32_t* key_lens, int causal, float scale, const void* pos_p,
                        int64_t p_sr, const float* pos_u, const float* pos_v, float drop_p, const uint64_t* drop_seed,
                        uint32_t drop_site, int dbd_band_only,
-                       const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* stream);
+                       const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* qv_out,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grouped weight gradients: all dW[M=Nout][N=Kin] += alpha * dY[K=rows][M]^T @ X[K][N] (bf16 in, fp32 accumulate) of one

@@ -60,6 +60,7 @@ struct FusedArgs {
   const bf16_t* pos_pt;  // (rel, optional) TRANSPOSED position projections: element (c, n) at pos_pt[(h*DK + c)*pt_ld + n],
   int64_t pt_ld;         // readable (zeros) for n in [-16, 2Tq-2 + 96]; with it dq receives the (Q+v) branch too and
   float *dpos_u, *dpos_v;  // the column sums of the two branches are added here ([H*DK] fp32 each)
+  bf16_t* qv_out;        // (rel, optional) [B*Tq][H*DK]: Q + pos_bias_v as the kernels round it, for the position-table gradient
 };
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -407,6 +408,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   ASTAMP();
   QFrags qf;
   load_qfrags(a, qf, b, h, i, y, REL);
+  if (REL && a.qv_out && i < a.Tq) {  // this lane's two 16-byte pieces of (q + v) of its query row
+    bf16_t* qo = a.qv_out + ((int64_t)b * a.Tq + i) * (a.H * DK) + h * DK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<uint4*>(qo + (ks * 4 + y) * 8) = __builtin_bit_cast(uint4, qf.qv[ks]);
+  }
   bf16x8 dof[2];
   {
     const bf16_t* dp = a.dO + (int64_t)b * a.o_sb + (int64_t)ic * a.o_sr + h * DK;
@@ -824,7 +830,8 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
                                   int64_t ldb, int B, int H, int Tq, int Tk, int dk, const int32_t* key_lens, int causal,
                                   float scale, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
                                   float drop_p, const uint64_t* drop_seed, uint32_t drop_site, int dbd_band_only,
-                                  const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* stream) {
+                                  const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* qv_out,
+                                  void* stream) {
   if (!q || !k || !v || !o || !dO || !lse || !delta || !dq || !dk_ || !dv || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0)
     return S2T_ERR_ARG;
   if (dk != DK) return S2T_ERR_UNSUPPORTED;
@@ -842,6 +849,8 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
   a.dO = (const bf16_t*)dO; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk_; a.dv = (bf16_t*)dv;
   a.dbd = (bf16_t*)dbd; a.ldb = ldb; a.dbd_band_only = dbd_band_only;
   a.pos_pt = (const bf16_t*)pos_pt; a.pt_ld = pt_ld; a.dpos_u = dpos_u; a.dpos_v = dpos_v;
+  a.qv_out = (bf16_t*)qv_out;
+  if (qv_out && (!pos_p || ((uintptr_t)qv_out % 16))) return S2T_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   // (delta = rowsum(dO * O) is produced by the dQ kernel, which runs first, and read by the dK / dV kernel)
   dim3 gq(B * H, (Tq + 63) / 64), gk(B * H, (Tk + 63) / 64), block(256);

@@ -1025,12 +1025,13 @@ class AttentionFn(torch.autograd.Function):
         n_pos = 2 * Tq - 1
         ldB = _pad8(n_pos)
         dBD = _dbd_buffer(H, B, Tq, ldB, dt, dev) if rel else None
+        qv = torch.empty(Mq, d, dtype=dt, device=dev) if rel else None  # q + pos_bias_v, written by the dQ kernel
         K.attn_fused_bwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, dO, Tq * d, d, lse, delta, dq, dk_, dv, dBD,
                          ldB, B, H, Tq, Tk, dk, key_lens, ctx.causal, scale, p, d,
                          prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a,
                          dbd_band_only=rel, pos_pt=pt[0] if pt is not None else None, pt_ld=pt[1] if pt is not None else 0,
                          dpos_u=prm["pos_u"].grad.view(-1) if pt is not None else None,
-                         dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None)
+                         dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv)
         if rel:
             fuse_glue = dt == torch.bfloat16 and d == 256 and ldq % 8 == 0
             if pt is None:
@@ -1041,8 +1042,6 @@ class AttentionFn(torch.autograd.Function):
                        a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
                 if not fuse_glue:
                     K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
-            qv = torch.empty(Mq, d, dtype=dt, device=dev)
-            K.bias_add_rows(q, ldq, prm["pos_v"].data, qv, d, Mq, d)
             ktiles = (Mq + 63) // 64
             sk = max(1, min(ktiles, _DP_SPLIT))
             # two-phase split-K in overwrite mode (c_atomic = 2) needs no zero fill of dp

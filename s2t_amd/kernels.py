@@ -511,13 +511,13 @@ def attn_fused_fwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, o_sb, o_sr, l
 
 def attn_fused_bwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, dO, o_sb, o_sr, lse, delta, dq, dk, dv, dbd, ldb, B, H, Tq,
                    Tk, dkd, key_lens, causal, scale, pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None, dbd_band_only=False,
-                   pos_pt=None, pt_ld=0, dpos_u=None, dpos_v=None):
+                   pos_pt=None, pt_ld=0, dpos_u=None, dpos_v=None, qv_out=None):
     """``pos_pt``: a VIEW starting at position n = 0 of the zero-padded transposed projections (see include/s2t_hip.h)."""
     dp, ds, dsite = _drop3(drop)
     _call("s2t_attn_fused_bwd", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
           dO.data_ptr(), o_sb, o_sr, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _ptr(dbd),
           ldb, B, H, Tq, Tk, dkd, _ptr(key_lens), int(causal), scale, _ptr(pos_p), p_sr, _ptr(pos_u), _ptr(pos_v), dp, ds,
-          dsite, int(dbd_band_only), _ptr(pos_pt), pt_ld, _ptr(dpos_u), _ptr(dpos_v))
+          dsite, int(dbd_band_only), _ptr(pos_pt), pt_ld, _ptr(dpos_u), _ptr(dpos_v), _ptr(qv_out))
 
 
 def fbank(wave, n_samples, feat, max_frames, win, shift, nfft, window, mel_t, preemph=0.97, remove_dc=True,

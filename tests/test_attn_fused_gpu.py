@@ -144,12 +144,16 @@ def test_fused_backward(Tq, Tk, causal, rel, pdrop):
     if rel:
         # dbd_band_only: into a buffer that is already zero outside the band, twice (the second call overwrites the band)
         dbd2 = torch.zeros_like(dbd)
+        qv_out = torch.full((B * Tq, d), 9.0, dtype=bf, device=DEV)
         for _ in range(2):
             K.attn_fused_bwd(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, dOd, Tq * d, d, lse, torch.empty_like(delta),
                              torch.empty_like(dq), torch.empty_like(dkk), torch.empty_like(dv), dbd2, ldb, B, H, Tq, Tk, dk, kl,
-                             causal, scale, pp, d, ud, vbd, drop, dbd_band_only=True)
+                             causal, scale, pp, d, ud, vbd, drop, dbd_band_only=True, qv_out=qv_out)
         torch.cuda.synchronize()
         assert torch.equal(dbd2[..., :2 * Tq - 1], dbd[..., :2 * Tq - 1])
+        # qv_out: q + pos_bias_v as the kernel rounds it (the operand of the position-table gradient)
+        ref_qv = (qd.float().view(B * Tq, d) + vbd.view(1, d)).to(bf)
+        assert torch.equal(qv_out, ref_qv)
     # delta is an output of the dQ kernel
     ref_delta = (dOd.float().view(B, Tq, H, dk) * o.float().view(B, Tq, H, dk)).sum(-1).permute(0, 2, 1).reshape(Z, Tq)
     assert (delta - ref_delta).abs().max() <= 1e-3 * ref_delta.abs().max() + 1e-5
