@@ -466,6 +466,15 @@ typedef struct s2t_ffn_bwd_args {
   void* dx;               /* [M][256] bf16 out */
   void* dx_drop;          /* optional [M][256] bf16 */
   float up_drop_p; uint32_t up_drop_site;
+  /* end_y != NULL: the block ended in a LayerNorm (final_norm).  `dy` is then the gradient w.r.t. that LayerNorm's OUTPUT;
+   * the prologue applies its backward (rows of padded frames, end_lens / end_T, carry no gradient): dres_out = gradient
+   * w.r.t. the block output y, dy_out = dropout(dres_out) under (drop_o_p, drop_o_site) when given — the products' input,
+   * also the operand of the W2 weight gradient — and the dgamma | dbeta partial sums go to end_ws. */
+  const void* end_y; const float* end_gamma; const float* end_mean; const float* end_rstd;
+  const int32_t* end_lens; int32_t end_T;
+  float* end_ws; int32_t end_replicas;
+  void* dres_out; void* dy_out;
+  float drop_o_p; uint32_t drop_o_site;
 } s2t_ffn_bwd_args;
 int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* args, void* stream);
 

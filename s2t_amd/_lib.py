@@ -76,6 +76,9 @@ class FfnBwdArgs(C.Structure):
         ("ln_x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p),
         ("dres", C.c_void_p), ("ln_ws", C.c_void_p), ("ln_replicas", C.c_int32), ("dx", C.c_void_p),
         ("dx_drop", C.c_void_p), ("up_drop_p", C.c_float), ("up_drop_site", C.c_uint32),
+        ("end_y", C.c_void_p), ("end_gamma", C.c_void_p), ("end_mean", C.c_void_p), ("end_rstd", C.c_void_p),
+        ("end_lens", C.c_void_p), ("end_T", C.c_int32), ("end_ws", C.c_void_p), ("end_replicas", C.c_int32),
+        ("dres_out", C.c_void_p), ("dy_out", C.c_void_p), ("drop_o_p", C.c_float), ("drop_o_site", C.c_uint32),
     ]
 
 

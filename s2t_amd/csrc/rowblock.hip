@@ -60,6 +60,18 @@ struct FfnK : s2t_ffn_args {
   void* lb_dx_drop;        // optional dropout(dx) under the mask (lb_drop_p, lb_drop_site)
   float lb_drop_p;
   uint32_t lb_drop_site;
+  // backward of the LayerNorm BEHIND the block (final_norm) in the prologue: x is then the gradient w.r.t. that LayerNorm's
+  // output, the kernel derives dres (gradient w.r.t. the block output y) and its dropped image (the products' input)
+  const void* pl_y;        // [M][256] bf16 block output the LayerNorm normalised (NULL: x is used as it is)
+  const float* pl_gamma;
+  const float* pl_mean;
+  const float* pl_rstd;
+  const int32_t* pl_lens;  // padded-frame mask of that LayerNorm's output (rows t >= lens[b] carry no gradient)
+  int pl_T;
+  float* pl_ws;            // [replicas][2][256] partial sums of its dgamma | dbeta
+  int pl_replicas;
+  void* pl_dres;           // [M][256] bf16 out
+  void* pl_dy;             // [M][256] bf16 out: dropout(dres) under (drop_o_p, drop_o_site); NULL without output dropout
 };
 
 __device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -226,6 +238,96 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
       const int mc = min(row0 + 16 * ps + (tid >> 5), M - 1);
       raw[ps] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * D + 8 * cch);
     }
+    if constexpr (BWD) {
+      if (p.pl_y) {
+        // ---- backward of the trailing LayerNorm on the way in (s2t_layernorm_bwd's arithmetic, 32 lanes per row):
+        //   d = masked ? 0 : dout;  dres = rstd * (d*gamma - mean(d*gamma) - xhat * mean(d*gamma*xhat));  staged tile =
+        //   dropout_o(dres).  dgamma / dbeta: per-thread sums over its 4 rows, the 16 row groups meet in the (idle)
+        //   mailbox region after the prologue barrier.
+        const bf16_t* Yp = reinterpret_cast<const bf16_t*>(p.pl_y);
+        bf16_t* DR = reinterpret_cast<bf16_t*>(p.pl_dres);
+        bf16_t* DY = reinterpret_cast<bf16_t*>(p.pl_dy);
+        const uint64_t key_e = DY ? s2t_drop_key(p.drop_seed, p.drop_o_site) : 0ull;
+        const uint32_t th_e = s2t_drop_thresh(p.drop_o_p);
+        const float inv_e = s2t_drop_scale(p.drop_o_p);
+        float pg[8], ag[8], ab[8];
+        {
+          const float4 g0 = *reinterpret_cast<const float4*>(p.pl_gamma + 8 * cch);
+          const float4 g1 = *reinterpret_cast<const float4*>(p.pl_gamma + 8 * cch + 4);
+          pg[0] = g0.x; pg[1] = g0.y; pg[2] = g0.z; pg[3] = g0.w; pg[4] = g1.x; pg[5] = g1.y; pg[6] = g1.z; pg[7] = g1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ag[j] = ab[j] = 0.f;
+        uint4 yraw[4];
+        float mu4[4], rs4[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int mc = min(row0 + 16 * ps + (tid >> 5), M - 1);
+          yraw[ps] = *reinterpret_cast<const uint4*>(Yp + (int64_t)mc * D + 8 * cch);
+          mu4[ps] = p.pl_mean[mc];
+          rs4[ps] = p.pl_rstd[mc];
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int rl = 16 * ps + (tid >> 5);
+          const int m = row0 + rl;
+          const bool live = m < M;
+          const bool masked = !live || (p.pl_lens && (m % p.pl_T) >= p.pl_lens[m / p.pl_T]);
+          const uint32_t dw4[4] = {raw[ps].x, raw[ps].y, raw[ps].z, raw[ps].w};
+          const uint32_t yw4[4] = {yraw[ps].x, yraw[ps].y, yraw[ps].z, yraw[ps].w};
+          float dgv[8], xh[8];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int j = 2 * q + e;
+              const float dv = masked ? 0.f : __uint_as_float(e ? (dw4[q] & 0xffff0000u) : (dw4[q] << 16));
+              const float yv = __uint_as_float(e ? (yw4[q] & 0xffff0000u) : (yw4[q] << 16));
+              xh[j] = (yv - mu4[ps]) * rs4[ps];
+              dgv[j] = dv * pg[j];
+              s1 += dgv[j];
+              s2 += dgv[j] * xh[j];
+              ag[j] += dv * xh[j];
+              ab[j] += dv;
+            }
+          }
+#pragma unroll
+          for (int sh = 16; sh > 0; sh >>= 1) {
+            s1 += __shfl_xor(s1, sh, 64);
+            s2 += __shfl_xor(s2, sh, 64);
+          }
+          s1 *= 1.0f / D;
+          s2 *= 1.0f / D;
+          uint32_t rw[4], yw[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            rw[q] = pack2(rs4[ps] * (dgv[2 * q] - s1 - xh[2 * q] * s2), rs4[ps] * (dgv[2 * q + 1] - s1 - xh[2 * q + 1] * s2));
+          uint4 o = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+          if (live) *reinterpret_cast<uint4*>(DR + (int64_t)m * D + 8 * cch) = o;
+          if (DY) {  // the dropped image of the STORED bf16 dres, as s2t_dropout would make it
+            uint32_t r16[8];
+            s2t_rand_run_even32<8>(key_e, (uint32_t)m * D + (uint32_t)(8 * cch), r16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float lo = __uint_as_float(rw[q] << 16), hi = __uint_as_float(rw[q] & 0xffff0000u);
+              yw[q] = pack2(r16[2 * q] >= th_e ? lo * inv_e : 0.f, r16[2 * q + 1] >= th_e ? hi * inv_e : 0.f);
+            }
+            o = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+            if (live) *reinterpret_cast<uint4*>(DY + (int64_t)m * D + 8 * cch) = o;
+          }
+          raw[ps] = o;  // what the plain path below stages
+        }
+        // [2][16][256] fp32 = 32 KiB in the second W2 stage: idle until chunk 1's W2 DMA (the mailbox region is not: the
+        // Z tile of chunk 0 is landing in its upper half)
+        float* red = reinterpret_cast<float*>(smem + LDS_W2 + STAGE);
+        const int grp = tid >> 5;
+        *reinterpret_cast<float4*>(red + (0 * 16 + grp) * 256 + 8 * cch) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+        *reinterpret_cast<float4*>(red + (0 * 16 + grp) * 256 + 8 * cch + 4) = make_float4(ag[4], ag[5], ag[6], ag[7]);
+        *reinterpret_cast<float4*>(red + (1 * 16 + grp) * 256 + 8 * cch) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+        *reinterpret_cast<float4*>(red + (1 * 16 + grp) * 256 + 8 * cch + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
+      }
+    }
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int rl = 16 * ps + (tid >> 5);
@@ -276,6 +378,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
   // form also tells the compiler that its loads are complete: no vmcnt waits of its own inside the loop)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
+  if constexpr (BWD) {
+    if (p.pl_y) {  // column sums of the trailing LayerNorm's parameter gradients: 512 atomics into one replica
+      const float* red = reinterpret_cast<const float*>(smem + LDS_W2 + STAGE);
+      const int which = tid >> 8, c = tid & 255;
+      float sum = 0.f;
+#pragma unroll
+      for (int gI = 0; gI < 16; ++gI) sum += red[(which * 16 + gI) * 256 + c];
+      atomicAdd(p.pl_ws + (int64_t)(blockIdx.x % p.pl_replicas) * 512 + which * 256 + c, sum);
+    }
+  }
   // this wave's 32 rows as B fragments: lane (x, g) owns k = 32*ks + 8g .. +8 of row 32 mp + 16 mt + x
   bf16x8 xn[2][8];
   {
@@ -1075,6 +1187,12 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
 
 extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   if (!b || !b->dy || !b->w2t || !b->w1t || !b->z || !b->dz) return S2T_ERR_ARG;
+  if (b->end_y) {
+    if (!b->end_gamma || !b->end_mean || !b->end_rstd || !b->end_ws || b->end_replicas <= 0 || !b->dres_out) return S2T_ERR_ARG;
+    if (b->end_lens && b->end_T <= 0) return S2T_ERR_ARG;
+    if (b->dy_out && (b->drop_o_p <= 0.f || b->drop_o_p >= 1.f || !b->drop_seed)) return S2T_ERR_ARG;
+    if (((uintptr_t)b->end_y % 16) || ((uintptr_t)b->dres_out % 16) || ((uintptr_t)b->dy_out % 16)) return S2T_ERR_ALIGN;
+  }
   if (b->ln_x) {
     if (!b->ln_gamma || !b->ln_mean || !b->ln_rstd || !b->ln_ws || b->ln_replicas <= 0 || !b->dx) return S2T_ERR_ARG;
     if (b->dx_drop && (b->up_drop_p <= 0.f || b->up_drop_p >= 1.f || !b->drop_seed)) return S2T_ERR_ARG;
@@ -1101,6 +1219,18 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   a.lb_dx_drop = b->dx_drop;
   a.lb_drop_p = b->up_drop_p;
   a.lb_drop_site = b->up_drop_site;
+  a.pl_y = b->end_y;
+  a.pl_gamma = b->end_gamma;
+  a.pl_mean = b->end_mean;
+  a.pl_rstd = b->end_rstd;
+  a.pl_lens = b->end_lens;
+  a.pl_T = b->end_T;
+  a.pl_ws = b->end_ws;
+  a.pl_replicas = b->end_replicas;
+  a.pl_dres = b->dres_out;
+  a.pl_dy = b->dy_out;
+  a.drop_o_p = b->dy_out ? b->drop_o_p : 0.f;
+  a.drop_o_site = b->drop_o_site;
   a.x = b->dy;
   a.d = D;
   a.w1 = b->w2t;

@@ -788,7 +788,20 @@ class FFNBlockFn(torch.autograd.Function):
             _ready(g_, b_)
             return dx_
 
-        if end_g is not None:
+        fused_bwd = (_FFN_FUSED_BWD and getattr(w1, "_s2t_flat", None) is not None and w1._s2t_flat.shadow is not None
+                     and getattr(w2, "_s2t_flat", None) is w1._s2t_flat and M * F_ * 2 < 2 ** 32)
+        end_in_kernel = None
+        if end_g is not None and fused_bwd and queued:
+            # the trailing LayerNorm's backward rides in the fused kernel's prologue: it writes dres (gradient w.r.t. y) and
+            # dropout(dres) under this block's own output mask (the products' input and W2's weight-gradient operand)
+            dres = torch.empty_like(x)
+            dy = torch.empty_like(x) if drop_o is not None else dres
+            ws_e = _ln_workspace(d, x.device)
+            end_in_kernel = dict(y=y, gamma=end_g.data, mean=emean, rstd=erstd, ws=ws_e, dres=dres, lens=ctx.end_lens,
+                                 T=ctx.end_T, dy=dy if drop_o is not None else None, drop=drop_o)
+            _LNQ["entries"].append((ws_e, end_g.grad, end_b.grad, d))
+            _ready(end_g, end_b)
+        elif end_g is not None:
             # gradient of the trailing LayerNorm w.r.t. y; dropout(dy) under this block's own output mask comes with it
             dyd = torch.empty_like(x) if drop_o is not None else None
             dres = ln_bwd(y, end_g, end_b, dout, emean, erstd, ctx.end_lens, ctx.end_T, None, dyd, drop_o)
@@ -800,15 +813,15 @@ class FFNBlockFn(torch.autograd.Function):
         dz = torch.empty(M, F_, dtype=x.dtype, device=x.device)
         dxd = torch.empty_like(x) if ctx.up_drop is not None else None
         dx = None
-        if _FFN_FUSED_BWD and getattr(w1, "_s2t_flat", None) is not None and w1._s2t_flat.shadow is not None \
-                and getattr(w2, "_s2t_flat", None) is w1._s2t_flat and M * F_ * 2 < 2 ** 32:
+        if fused_bwd:
             if queued and w1._s2t_flat not in _BE["flats"]:
                 _BE["flats"].append(w1._s2t_flat)
             w2t, w1t = transposed(w2, queued), transposed(w1, queued)
             if queued:  # the leading LayerNorm's backward rides in the kernel's epilogue (parameter sums through the fold)
                 dx = torch.empty_like(x)
                 ws = _ln_workspace(d, x.device)
-                K.ffn_fused_bwd(dy, w2t, w1t, z, dz, None, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h,
+                K.ffn_fused_bwd(dout if end_in_kernel is not None else dy, w2t, w1t, z, dz, None, act=ctx.act, alpha=ctx.alpha,
+                                drop_h=drop_h, end=end_in_kernel,
                                 ln=dict(x=x, gamma=gamma.data, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, dx_drop=dxd,
                                         drop=ctx.up_drop))
                 _LNQ["entries"].append((ws, gamma.grad, beta.grad, d))

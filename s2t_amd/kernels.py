@@ -140,7 +140,7 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
 
 
-def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=None):
+def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=None, end=None):
     """s2t_ffn_fused_bwd (include/s2t_hip.h): dz = alpha * drop_h((dy W2) * act'(z)), dxn = dz W1, from the transposed
     weight copies ``w2t`` [F, 256] and ``w1t`` [256, F].  ``ln`` = dict(x, gamma, mean, rstd, ws, dx[, dres, dx_drop, drop])
     adds the backward of the block's leading LayerNorm (``dxn`` may then be None)."""
@@ -165,6 +165,14 @@ def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=N
             dr = ln["drop"]
             assert a.drop_seed is None or a.drop_seed == dr[1].data_ptr()
             a.dx_drop, a.up_drop_p, a.up_drop_site, a.drop_seed = ln["dx_drop"].data_ptr(), float(dr[0]), int(dr[2]), dr[1].data_ptr()
+    if end is not None:  # dict(y, gamma, mean, rstd, ws, dres[, lens, T, dy, drop]): trailing LayerNorm's backward in front
+        a.end_y, a.end_gamma, a.end_mean, a.end_rstd = (end[k].data_ptr() for k in ("y", "gamma", "mean", "rstd"))
+        a.end_lens, a.end_T = _ptr(end.get("lens")), int(end.get("T") or 0)
+        a.end_ws, a.end_replicas, a.dres_out = end["ws"].data_ptr(), LN_REPLICAS, end["dres"].data_ptr()
+        if end.get("dy") is not None:
+            dr = end["drop"]
+            assert a.drop_seed is None or a.drop_seed == dr[1].data_ptr()
+            a.dy_out, a.drop_o_p, a.drop_o_site, a.drop_seed = end["dy"].data_ptr(), float(dr[0]), int(dr[2]), dr[1].data_ptr()
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
