@@ -340,7 +340,8 @@ def main():
                             "Adam+clip10, dropout %.2f" % (args.arch, args.enc_layers, args.dec_layers, V, args.batch, args.frames, args.dropout),
                 "global_batch": args.batch * world, "frames_per_step": frames_global, "parallelism": "dp%d" % world,
                 "hip_graph": use_graph, "final_loss": loss_val,
-                "grad_allreduce": ("rccl (s2t_allreduce_bucket) inside the step graph, overlapped with backward"
+                "grad_allreduce": (("rccl (s2t_allreduce_bucket, %s buckets) inside the step graph, overlapped with backward"
+                                    % ("bf16" if ddp is not None and ddp.reduce_dtype == torch.bfloat16 else "fp32"))
                                    if Comm.initialized() else ("torch.distributed/%s" % backend if world > 1 else "none")),
             },
             "roofline": roofline,

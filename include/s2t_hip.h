@@ -249,6 +249,8 @@ int s2t_colsum_accum(int dtype, const void* dY, int64_t ld, float* db, int64_t r
 int s2t_add_colsum2(int dtype, void* a, int64_t lda, const void* b, int64_t ldb, float* du, float* dv, int64_t rows, int n,
                     void* stream);
 int s2t_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst = scale * src (bf16 -> fp32; n % 4 == 0): the way back of a gradient bucket reduced in bf16 */
+int s2t_cast_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, void* stream);
 /* out[r, c] = keep(seed, site, r*cols + c) ? x[r, c] / (1-p) : 0   (FairseqDropout, modules/fairseq_dropout.py; the same
  * call on a gradient is its backward) */
 int s2t_dropout(int dtype, const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int cols, float p,

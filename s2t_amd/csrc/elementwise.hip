@@ -520,6 +520,23 @@ extern "C" int s2t_add_colsum2(int dtype, void* a, int64_t lda, const void* b, i
   return S2T_LAUNCH_CHECK();
 }
 
+// dst[i] = scale * float(src[i]) for n4 groups of four bf16 values
+__global__ __launch_bounds__(256) void cast_bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst,
+                                                               int64_t n4, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint2 v = *reinterpret_cast<const uint2*>(src + 4 * i);
+    *reinterpret_cast<float4*>(dst + 4 * i) = make_float4(scale * __uint_as_float(v.x << 16), scale * __uint_as_float(v.x & 0xffff0000u),
+                                                          scale * __uint_as_float(v.y << 16), scale * __uint_as_float(v.y & 0xffff0000u));
+  }
+}
+extern "C" int s2t_cast_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, void* stream) {
+  if (!src || !dst || n < 0 || n % 4) return S2T_ERR_ARG;
+  if (n == 0) return S2T_OK;
+  hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     dst, n / 4, scale);
+  return S2T_LAUNCH_CHECK();
+}
+
 extern "C" int s2t_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
   if (!src || !dst || n < 0 || n % 4) return S2T_ERR_ARG;
   if (n == 0) return S2T_OK;

@@ -357,6 +357,10 @@ def colsum_accum(dY, ld, db, rows, n):
     _call("s2t_colsum_accum", L.dtype_id(dY.dtype), dY.data_ptr(), ld, db.data_ptr(), rows, n)
 
 
+def cast_bf16_to_f32(src, dst, n, scale=1.0):
+    _call("s2t_cast_bf16_to_f32", src.data_ptr(), dst.data_ptr(), n, float(scale))
+
+
 def cast_f32_to_bf16(src, dst, n):
     _call("s2t_cast_f32_to_bf16", src.data_ptr(), dst.data_ptr(), n)
 

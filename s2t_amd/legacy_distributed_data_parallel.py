@@ -31,10 +31,15 @@ from . import functional as Fn
 
 
 class LegacyDistributedDataParallel(nn.Module):
-    def __init__(self, module, process_group=None, buffer_size=2 ** 23, overlap=True, single_rank_collectives=False):
+    def __init__(self, module, process_group=None, buffer_size=2 ** 23, overlap=True, single_rank_collectives=False,
+                 reduce_dtype=None):
         """``buffer_size``: bucket size in ELEMENTS (2**23 fp32 = 32 MiB).
         ``single_rank_collectives``: issue the (trivial) collectives even when the group has one rank, so that the
-        RCCL + side-stream + hipGraph-capture path can be exercised on a single GPU."""
+        RCCL + side-stream + hipGraph-capture path can be exercised on a single GPU.
+        ``reduce_dtype`` = torch.bfloat16: the buckets travel in bf16 (half the bytes on the xGMI links) — what the reference
+        does under ``--fp16``, where the wrapper's buffer has the parameters' half-precision dtype
+        (legacy_distributed_data_parallel.py:44-48,82-120): fp32 bucket -> bf16 staging copy -> all-reduce (sum) -> back to
+        fp32 divided by the world size.  Default (None, or S2T_DDP_REDUCE=bf16 in the environment): fp32."""
         super().__init__()
         self.module = module
         self.process_group = process_group
@@ -63,6 +68,15 @@ class LegacyDistributedDataParallel(nn.Module):
         self._work = []
         self._side = torch.cuda.Stream() if (flat.grad.is_cuda and overlap) else None
         self._learning = True
+        import os
+
+        if reduce_dtype is None and os.environ.get("S2T_DDP_REDUCE", "") == "bf16":
+            reduce_dtype = torch.bfloat16
+        assert reduce_dtype in (None, torch.float32, torch.bfloat16)
+        self.reduce_dtype = reduce_dtype if reduce_dtype is not None else torch.float32
+        # one bf16 staging block per bucket (buckets may be in flight together on the side stream)
+        self._stage = [torch.empty((e - s + 3) // 4 * 4, dtype=torch.bfloat16, device=flat.grad.device)
+                       for s, e in self.buckets] if self.reduce_dtype == torch.bfloat16 else None
 
     # -- module protocol ---------------------------------------------------------------------------
     def forward(self, *args, **kwargs):
@@ -129,13 +143,32 @@ class LegacyDistributedDataParallel(nn.Module):
             if wg is not None:
                 self._side.wait_stream(wg)
             with torch.cuda.stream(self._side):
-                self._reduce(view)
+                self._reduce(view, b)
         else:
             if wg is not None:
                 torch.cuda.current_stream().wait_stream(wg)
-            self._reduce(view)
+            self._reduce(view, b)
 
-    def _reduce(self, view):
+    def _reduce(self, view, b=None):
+        if self._stage is not None and b is not None:
+            # bf16 on the wire: cast, SUM all-reduce, cast back with the 1 / world division
+            st = self._stage[b][:view.numel()] if view.numel() % 4 == 0 else self._stage[b]
+            n = view.numel()
+            if view.is_cuda and n % 4 == 0:
+                from . import kernels as K
+
+                K.cast_f32_to_bf16(view, st, n)
+                if Comm.initialized():
+                    Comm.all_reduce_(st, average=False)
+                else:
+                    dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.process_group)
+                K.cast_bf16_to_f32(st, view, n, 1.0 / self.world_size)
+            else:
+                st = st[:n]
+                st.copy_(view)
+                dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.process_group)
+                view.copy_(st.float() / self.world_size)
+            return
         if view.is_cuda and Comm.initialized():
             Comm.all_reduce_(view, average=True)
         elif view.is_cuda and dist.get_backend(self.process_group) == "nccl":

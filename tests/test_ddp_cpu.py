@@ -28,7 +28,7 @@ class Toy(nn.Module):
         self.flat = None
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, reduce_dtype=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
 
         m = Toy()
         m.flat = FlatParameters(m, torch.float32)
-        ddp = LegacyDistributedDataParallel(m, buffer_size=2048)  # several buckets, parameters straddle them
+        ddp = LegacyDistributedDataParallel(m, buffer_size=2048, reduce_dtype=reduce_dtype)  # several buckets, parameters straddle them
         assert len(ddp.buckets) >= 3 and ddp.world_size == world
         params = [m.c, m.b, m.a]  # "backward order"
 
@@ -83,11 +83,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_ddp_world2_gloo():
+@pytest.mark.parametrize("reduce_dtype", [None, torch.bfloat16])
+def test_ddp_world2_gloo(reduce_dtype):
+    """(bf16: the buckets travel in half precision as under the reference's --fp16; the test values are exact in bf16)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, reduce_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

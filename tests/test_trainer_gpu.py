@@ -47,9 +47,10 @@ def _run(mode, steps=4):
     model = _model(5)
     crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
     ddp = None
-    if mode in ("ddp_graph", "ddp_eager"):
+    if mode in ("ddp_graph", "ddp_eager", "ddp_graph_bf16"):
         Comm.init(0, 1, torch.device("cuda", 0))
-        ddp = LegacyDistributedDataParallel(model, single_rank_collectives=True, buffer_size=2 ** 18)
+        ddp = LegacyDistributedDataParallel(model, single_rank_collectives=True, buffer_size=2 ** 18,
+                                            reduce_dtype=torch.bfloat16 if mode.endswith("bf16") else None)
     tr = Trainer(model, crit, ddp=ddp)
     sample = _sample()
     Fn.DROPOUT.begin_step(torch.device(DEV))
@@ -80,6 +81,7 @@ def test_graph_and_ddp_graph_follow_the_eager_trajectory():
     lg, pg = _run("graph")
     ld, pd = _run("ddp_graph")
     lx, px = _run("ddp_eager")
+    lb, pb = _run("ddp_graph_bf16")  # buckets reduced in bf16 (the reference's --fp16 wire format): gradients rounded once
     Comm.destroy()
     # same seeds, same masks, same arithmetic: the captured variants replay the eager step kernel for kernel
     for a, b in zip(le[3:], lg[3:]):
@@ -93,6 +95,9 @@ def test_graph_and_ddp_graph_follow_the_eager_trajectory():
     assert (pe - pg).abs().max() <= 1e-3 * pe.abs().max()
     assert (pe - pd).abs().max() <= 1e-3 * pe.abs().max()
     assert (pe - px).abs().max() <= 1e-3 * pe.abs().max()
+    assert (pe - pb).abs().max() <= 1e-3 * pe.abs().max()
+    for a, b in zip(le[3:], lb[3:]):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lb)
 
 
 def _sample2():
