@@ -290,6 +290,11 @@ int s2t_sumsq_accum(const float* g, int64_t n, float* out, void* stream);
  * ------------------------------------------------------------------------------------------------ */
 int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, int flip,
                    const float* scale, const float* shift, int act, const int32_t* lens, float* stats, void* stream);
+/* eval: depthwise conv + BatchNorm (running statistics) + activation + padded-frame mask in one launch — the affine
+ * gamma * rsqrt(running_var + eps), beta - running_mean * that is folded inside the kernel (convolution.py:94-104, eval) */
+int s2t_dwconv_bn_eval_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, const float* gamma,
+                           const float* beta, const float* running_mean, const float* running_var, float eps, int act,
+                           const int32_t* lens, void* stream);
 int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, float* ws /* [replicas][C][K]: zero in, zero out */,
                           int replicas, int B, int T, int C, int K, void* stream);
 int s2t_dwconv_wgrad_partials(int B, int T); /* rows of C*K floats s2t_dwconv_bwd_weight needs in ws (pass as `replicas`) */

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
                                                      T* __restrict__ y, int B, int T_, int C, int K, int flip,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      int act, const int32_t* __restrict__ lens,
-                                                     float* __restrict__ stats) {
+                                                     float* __restrict__ stats, const float* __restrict__ bn_mean,
+                                                     const float* __restrict__ bn_var, float bn_eps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int pad = (K - 1) / 2;
   const int nrows = TT + K - 1;
@@ -91,6 +92,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
   if (scale && c < C) {
     ld4_as_f32<float>(scale + c, sc);
     ld4_as_f32<float>(shift + c, sh);
+    if (bn_mean) {  // scale / shift are BatchNorm's gamma / beta: fold the running statistics here (eval)
+      float mu[4], var[4];
+      ld4_as_f32<float>(bn_mean + c, mu);
+      ld4_as_f32<float>(bn_var + c, var);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sc[r] *= rsqrtf(var[r] + bn_eps);
+        sh[r] -= mu[r] * sc[r];
+      }
+    }
   }
   const int len = lens ? lens[b] : T_;
 #pragma unroll
@@ -587,10 +598,30 @@ extern "C" int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y,
   ensure_lds_optin();
   if (dtype == S2T_F32) {
     hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, shm, s, (const float*)x, w, (float*)y, B, T, C, K, flip, scale,
-                       shift, act, lens, stats);
+                       shift, act, lens, stats, (const float*)nullptr, (const float*)nullptr, 0.f);
   } else if (dtype == S2T_BF16) {
     hipLaunchKernelGGL(dwconv_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)x, w, (bf16_t*)y, B, T, C, K, flip,
-                       scale, shift, act, lens, stats);
+                       scale, shift, act, lens, stats, (const float*)nullptr, (const float*)nullptr, 0.f);
+  } else return S2T_ERR_DTYPE;
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_dwconv_bn_eval_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K,
+                                      const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, int act, const int32_t* lens, void* stream) {
+  if (!x || !w || !y || !gamma || !beta || !running_mean || !running_var) return S2T_ERR_ARG;
+  if (B <= 0 || T <= 0 || C <= 0 || K <= 0 || !(K & 1) || C % 4) return S2T_ERR_ARG;
+  if (K > 31) return S2T_ERR_UNSUPPORTED;
+  const size_t shm = (size_t)((TT + K - 1) * CCH + K * CCH) * sizeof(float);
+  dim3 grid((T + TT - 1) / TT, B, (C + CCH - 1) / CCH), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  ensure_lds_optin();
+  if (dtype == S2T_F32) {
+    hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, shm, s, (const float*)x, w, (float*)y, B, T, C, K, 0, gamma, beta,
+                       act, lens, (float*)nullptr, running_mean, running_var, eps);
+  } else if (dtype == S2T_BF16) {
+    hipLaunchKernelGGL(dwconv_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)x, w, (bf16_t*)y, B, T, C, K, 0, gamma,
+                       beta, act, lens, (float*)nullptr, running_mean, running_var, eps);
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

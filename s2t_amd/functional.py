@@ -1347,12 +1347,13 @@ class ConvModuleFn(torch.autograd.Function):
             ctx.ln_saved = (x_pre, ln_mean, ln_rstd)
         else:
             K.gemm(x, w1, g, M=M, N=2 * d, K=d, lda=d, ldb=d, ldc=d, act="glu", preact=z, ldp=2 * d)
-        scale = torch.empty(d, dtype=torch.float32, device=dev)
-        shift = torch.empty(d, dtype=torch.float32, device=dev)
+        scale = shift = None
         wd = prm["dw_w"].data.view(d, Kw)
         a = torch.empty(M, d, dtype=dt, device=dev)
         D = mean = rstd = None
         if training:
+            scale = torch.empty(d, dtype=torch.float32, device=dev)
+            shift = torch.empty(d, dtype=torch.float32, device=dev)
             D = torch.empty(M, d, dtype=dt, device=dev)
             stats = torch.empty(K.dwconv_stat_partials(B, T), 2, d, dtype=torch.float32, device=dev)
             K.dwconv_fwd(g, wd, D, B, T, d, Kw, stats=stats)
@@ -1361,10 +1362,9 @@ class ConvModuleFn(torch.autograd.Function):
             K.bn_finalize(stats, M, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
                           momentum, 1e-5, True, scale, shift, mean, rstd, d)
             K.bn_act_fwd(D, a, scale, shift, act, M, d, lens, T)
-        else:
-            K.bn_finalize(None, 0, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
-                          momentum, 1e-5, False, scale, shift, None, None, d)
-            K.dwconv_fwd(g, wd, a, B, T, d, Kw, scale=scale, shift=shift, act=act, lens=lens)
+        else:  # eval: conv + BatchNorm on the running statistics + activation + mask in one launch
+            K.dwconv_bn_eval_fwd(g, wd, a, B, T, d, Kw, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"],
+                                 bn_buf["running_var"], 1e-5, act, lens)
         y = torch.empty(M, d, dtype=dt, device=dev)
         if _rb_ok(a, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1)):
             K.rowblock_gemm(a, cw(prm["pw2_w"]).view(d, d), y, N=d, ldc=d, residual=residual,

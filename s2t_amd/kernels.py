@@ -387,6 +387,11 @@ def dwconv_fwd(x, w, y, B, T, C, K, flip=False, scale=None, shift=None, act=None
           _ptr(scale), _ptr(shift), L.ACT_IDS[act], _ptr(lens), _ptr(stats))
 
 
+def dwconv_bn_eval_fwd(x, w, y, B, T, C, K, gamma, beta, running_mean, running_var, eps, act, lens=None):
+    _call("s2t_dwconv_bn_eval_fwd", L.dtype_id(x.dtype), x.data_ptr(), w.data_ptr(), y.data_ptr(), B, T, C, K, gamma.data_ptr(),
+          beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), float(eps), L.ACT_IDS[act], _ptr(lens))
+
+
 def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
     rows = L.lib().s2t_dwconv_wgrad_partials(B, T)  # one plain-stored partial row per workgroup, folded in fixed order
     ws = _scratch("dw", rows * C * K, G.device)
