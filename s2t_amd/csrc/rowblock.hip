@@ -472,7 +472,24 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
   };
   // lane (x, g): v[r] = H[row x of tile mt][unit c*64 + 32 fh + 8 g + 4 nh + r]; packed halves go to the mailbox
   // (backward: zp holds the lane's Z values on entry, v = dH, the packed result is dZ)
-  auto e1 = [&](int c, const f32x4 (&hacc)[2], uint2 (&zp)[2], uint2 (&hp)[2]) __attribute__((always_inline)) {
+  // dropout multipliers (scale or 0) of this lane's 2 x 4 hidden values of chunk c: they depend on indices only, so they are
+  // drawn EARLY in the iteration (beside the first G1 products) and only applied in E1 — the hash's multiply chain leaves the
+  // dependent chain G1 -> E1 -> mailbox -> barrier that paces the loop
+  auto drop_masks = [&](int c, float (&ms)[2][4]) __attribute__((always_inline)) {
+    if constexpr (DROP) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int m = row0 + 32 * mp + 16 * mt + x;
+        // (element index m*F + f: even and, by the launcher's check, below 2^32)
+        const uint32_t base = (uint32_t)m * (uint32_t)F + (uint32_t)(c * FC + 32 * fh + 8 * g + 4 * nh);
+        uint32_t r16[4];
+        s2t_rand_run_even32<4>(key_h, base, r16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ms[mt][r] = r16[r] >= th_h ? inv_h : 0.f;
+      }
+    }
+  };
+  auto e1 = [&](int c, const f32x4 (&hacc)[2], uint2 (&zp)[2], uint2 (&hp)[2], const float (&ms)[2][4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       float v[4];
@@ -493,13 +510,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
         for (int r = 0; r < 4; ++r) v[r] = v[r] * sigmoidf_(v[r]);
       }
       if constexpr (DROP) {
-        const int m = row0 + 32 * mp + 16 * mt + x;
-        // (element index m*F + f: even and, by the launcher's check, below 2^32)
-        const uint32_t base = (uint32_t)m * (uint32_t)F + (uint32_t)(c * FC + 32 * fh + 8 * g + 4 * nh);
-        uint32_t r16[4];
-        s2t_rand_run_even32<4>(key_h, base, r16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = r16[r] >= th_h ? v[r] * inv_h : 0.f;
+        for (int r = 0; r < 4; ++r) v[r] *= ms[mt][r];
       }
       if constexpr (BWD) {
 #pragma unroll
@@ -602,9 +614,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
     g1_read(0, 0, a0);
     g1_read(0, 4, a1);
     z_read(0, zp);
+    float ms0[2][4];
+    drop_masks(0, ms0);
     g1_mma(0, a0, hacc);
     g1_mma(4, a1, hacc);
-    e1(0, hacc, zp, hp);
+    e1(0, hacc, zp, hp, ms0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   Bias4 bcur = bias_load(nchunks > 1 ? 1 : 0);
@@ -641,6 +655,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
 #endif
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
+    float ms[2][4];
+    drop_masks(c, ms);
     g1_mma(0, a0, hacc);
     g2_read(c - 1, 0, a0);
     __builtin_amdgcn_sched_barrier(0);
@@ -650,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
     __builtin_amdgcn_sched_barrier(0);
     STAMP(3);
     g2_mma(0, a0, hb);
-    e1(c, hacc, zn, hn);
+    e1(c, hacc, zn, hn, ms);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4);
     g2_mma(4, a1, hb);
