@@ -521,6 +521,30 @@ typedef struct s2t_rowblock_args {
 } s2t_rowblock_args;
 int s2t_rowblock_gemm(const s2t_rowblock_args* args, void* stream);
 
+/* s2t_rowblock_dgrad: the input gradient of a 256 -> K projection that sits BEHIND a LayerNorm, and that
+ * LayerNorm's backward, in one launch on the same 64-row blocks (the autograd backward of F.layer_norm + F.linear /
+ * Conv1d(k=1): fused QKV projection, K = 768, multihead_attention.py:239-263 / espnet_multihead_attention.py:88-106;
+ * pointwise conv 1, K = 512, convolution.py:86-91):
+ *     dxn = dy W            dy [M][K] bf16 (gradient w.r.t. the projection's output), wt = W^T [256][K] bf16
+ *     dx  = LayerNorm'(dxn; ln_x, ln_gamma, ln_mean, ln_rstd) + dres      (rows t >= ln_lens[b] of each T block: dxn = 0,
+ *           the LayerNorm's output was masked there); dx_drop = dropout(dx) under (up_drop_p, up_drop_site) when given;
+ *           dgamma | dbeta partial sums into ln_ws [ln_replicas][2][256] (s2t_layernorm_fold)
+ * with s2t_layernorm_bwd's arithmetic on the fp32 dxn rows.  ln_x == NULL: dxn is stored as it is.
+ * Constraints: d == 256, K % 256 == 0, K <= 2048, bf16, 16-byte aligned pointers, (M + 64) * K * 2 < 2^32. */
+typedef struct s2t_rowblock_dgrad_args {
+  const void* dy; const void* wt;
+  int32_t d;              /* must be 256 */
+  int32_t M, K;
+  void* dxn;              /* [M][256] bf16 out, required iff ln_x == NULL */
+  const void* ln_x; const float* ln_gamma; const float* ln_mean; const float* ln_rstd;
+  const int32_t* ln_lens; int32_t ln_T;
+  const void* dres;
+  float* ln_ws; int32_t ln_replicas;
+  void* dx; void* dx_drop;
+  float up_drop_p; uint32_t up_drop_site; const uint64_t* drop_seed;
+} s2t_rowblock_dgrad_args;
+int s2t_rowblock_dgrad(const s2t_rowblock_dgrad_args* args, void* stream);
+
 /* ---- Gradient all-reduce over RCCL / xGMI (csrc/comm.hip) ------------------------------------------------
  * Replaces torch.distributed.all_reduce in LegacyDistributedDataParallel.all_reduce_grads
  * (distributed/legacy_distributed_data_parallel.py:107-120): one process-global communicator (one process per GPU),

@@ -82,6 +82,18 @@ class FfnBwdArgs(C.Structure):
     ]
 
 
+class RowblockDgradArgs(C.Structure):
+    """Mirror of ``struct s2t_rowblock_dgrad_args`` (include/s2t_hip.h)."""
+
+    _fields_ = [
+        ("dy", C.c_void_p), ("wt", C.c_void_p), ("d", C.c_int32), ("M", C.c_int32), ("K", C.c_int32), ("dxn", C.c_void_p),
+        ("ln_x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p),
+        ("ln_lens", C.c_void_p), ("ln_T", C.c_int32), ("dres", C.c_void_p), ("ln_ws", C.c_void_p), ("ln_replicas", C.c_int32),
+        ("dx", C.c_void_p), ("dx_drop", C.c_void_p), ("up_drop_p", C.c_float), ("up_drop_site", C.c_uint32),
+        ("drop_seed", C.c_void_p),
+    ]
+
+
 class RowblockArgs(C.Structure):
     """Mirror of ``struct s2t_rowblock_args`` (include/s2t_hip.h)."""
 
@@ -121,6 +133,8 @@ def header_prototypes(path=HEADER_PATH):
                         argtypes.append(C.POINTER(FfnArgs))
                     elif "s2t_ffn_bwd_args" in a:
                         argtypes.append(C.POINTER(FfnBwdArgs))
+                    elif "s2t_rowblock_dgrad_args" in a:
+                        argtypes.append(C.POINTER(RowblockDgradArgs))
                     elif "s2t_rowblock_args" in a:
                         argtypes.append(C.POINTER(RowblockArgs))
                     else:

@@ -1159,6 +1159,233 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   emit(nchunks - 1, res_prefetch(nchunks - 1));
 }
 
+// ===============================================================================================================
+// s2t_rowblock_dgrad: dx = LayerNorm'( dY[M,K] W ) + dres for the projections BEHIND a LayerNorm (fused QKV, K = 768;
+// pointwise conv 1, K = 512): the input-gradient GEMM of the projection and the backward of the LayerNorm in front of it
+// in one launch on the same 64-row blocks.  W arrives transposed (Wt [256][K], K contiguous: the forward kernel's weight
+// layout for a K -> 256 projection), the reduction runs in K-blocks of 256:
+//   K-block kb: the dY tile [64 rows][256] of the block lands in LDS by DMA (one block ahead), every wave takes its rows as
+//   B fragments; the four 64-column chunks of Wt's K-block stream through three 32 KiB stages (DMA two steps ahead) and
+//   accumulate into the wave's 4 x 2 result tiles, which stay in registers across the K-blocks;
+//   epilogue: the fp32 rows meet in LDS ([64][256], the free weight stages) and go through s2t_layernorm_bwd's arithmetic
+//   (mask, dgamma / dbeta partial sums into the fold workspace, residual gradient, dropped copy) as in the fused FFN backward.
+constexpr int DG_W = 0;                 // three weight stages
+constexpr int DG_A = 3 * STAGE;         // the dY tile of one K-block
+constexpr int DG_BYTES = 4 * STAGE;     // 128 KiB
+
+struct DgradK {
+  const void* dy;          // [M][K] bf16
+  const void* wt;          // [256][K] bf16
+  int M, K;
+  void* dxn;               // [M][256] bf16 out when ln_x == NULL
+  const void* ln_x; const float* ln_gamma; const float* ln_mean; const float* ln_rstd;
+  const int32_t* ln_lens; int ln_T;   // rows of padded frames carry no gradient into the LayerNorm (its output was masked)
+  const void* dres;
+  float* ws; int replicas;
+  void* dx; void* dx_drop;
+  float drop_p; uint32_t drop_site; const uint64_t* drop_seed;
+};
+
+__global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) {
+  __shared__ __attribute__((aligned(16))) char smem[DG_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mp = wave & 1, q = wave >> 1;
+  const int x = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * TM;
+  const int M = p.M, K = p.K;
+  const int KB = K / D;
+  const uint32_t K2 = (uint32_t)K * 2u;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const i32x4 srdw = make_srd(p.wt, (uint32_t)D * K2);
+  const i32x4 srda = make_srd(p.dy, (uint32_t)M * K2);  // rows >= M read as zero
+
+  // DMA plans: instruction i of wave w covers tile rows u = 8w + 2i + hi (512 B of one K-block each), LDS slot s = l & 31
+  // holds 16-byte k-chunk s ^ (u & 15); (u + 2i) & 15 = (u & 15) ^ 2i.  Weight chunk c: Wt rows 64c + u; dY tile: rows row0 + u.
+  uint32_t vw[4], va[4];
+  {
+    const int hi = lane >> 5, s_ = lane & 31;
+    const int u0 = 8 * wave + hi;
+    const uint32_t cp0 = (uint32_t)(16 * (s_ ^ (u0 & 15)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      vw[i] = (uint32_t)(u0 + 2 * i) * K2 + (cp0 ^ (uint32_t)(32 * i));
+      va[i] = (uint32_t)(row0 + u0 + 2 * i) * K2 + (cp0 ^ (uint32_t)(32 * i));
+    }
+  }
+  auto issue_w = [&](int s) __attribute__((always_inline)) {  // step s = 4 kb + c
+    const uint32_t base = lds0 + DG_W + (s % 3) * STAGE + wave * 4096;
+    const uint32_t soff = (uint32_t)(s & 3) * (64u * K2) + (uint32_t)(s >> 2) * 512u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(base + 1024 * i, vw[i], srdw, soff);
+  };
+  auto issue_a = [&](int kb) __attribute__((always_inline)) {
+    const uint32_t base = lds0 + DG_A + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(base + 1024 * i, va[i], srda, (uint32_t)kb * 512u);
+  };
+  const int S = 4 * KB;
+  issue_a(0);
+  issue_w(0);
+  issue_w(1);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c][0] = acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 xn[2][8];
+  auto read_xn = [&]() __attribute__((always_inline)) {
+    const char* stage = smem + DG_A;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int rl = 32 * mp + 16 * mt + x;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        xn[mt][ks] = as_frag(*reinterpret_cast<const uint4*>(stage + rl * 512 + 16 * ((4 * ks + g) ^ x)));
+    }
+  };
+  for (int kb = 0; kb < KB; ++kb) {
+    read_xn();  // (the tile of this K-block landed before the previous closing barrier)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int s = 4 * kb + c;
+      uint4 af[8];
+      {
+        const char* lw = smem + DG_W + (s % 3) * STAGE + (16 * q + x) * 512;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const uint4*>(lw + 16 * ((4 * ks + g) ^ x));
+      }
+      const bool w_more = s + 2 < S;
+      // the next K-block's dY tile goes out one step after this block's fragments were read by every wave (the closing
+      // barrier of step c = 0 lies between), behind this step's weight group
+      const bool a_more = c == 1 && kb + 1 < KB;
+      if (w_more) issue_w(s + 2);
+      if (a_more) issue_a(kb + 1);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        acc[c][0] = mfma16(as_frag(af[ks]), xn[0][ks], acc[c][0]);
+        acc[c][1] = mfma16(as_frag(af[ks]), xn[1][ks], acc[c][1]);
+      }
+      // counted wait: the groups issued in this step may stay in flight
+      if (w_more && a_more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (w_more || a_more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  }
+  // ---- fp32 rows into LDS: row m at m*1024 + 16*(cc ^ (m & 7)), cc = 4-column piece 16c + 4q + g
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int ml = 32 * mp + 16 * mt + x;
+      *reinterpret_cast<f32x4*>(smem + ml * 1024 + 16 * ((16 * c + 4 * q + g) ^ (ml & 7))) = acc[c][mt];
+    }
+  __syncthreads();
+  // ---- row epilogue: wave w, pass ps: rows 8w + 2ps + (lane >> 5); lane s = lane & 31 owns columns 4s.. and 128 + 4s..
+  const int hi = lane >> 5, sl = lane & 31;
+  if (!p.ln_x) {
+    bf16_t* Y = reinterpret_cast<bf16_t*>(p.dxn);
+#pragma unroll 2
+    for (int ps = 0; ps < 4; ++ps) {
+      const int ml = 8 * wave + 2 * ps + hi;
+      const int m = row0 + ml;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int cc = 32 * qq + sl;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(smem + ml * 1024 + 16 * (cc ^ (ml & 7)));
+        float v4[4] = {a[0], a[1], a[2], a[3]};
+        if (m < M) st4_from_f32<bf16_t>(Y + (int64_t)m * D + 128 * qq + 4 * sl, v4);
+      }
+    }
+    return;
+  }
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(p.ln_x);
+  const bf16_t* DR = reinterpret_cast<const bf16_t*>(p.dres);
+  bf16_t* DX = reinterpret_cast<bf16_t*>(p.dx);
+  bf16_t* DXD = reinterpret_cast<bf16_t*>(p.dx_drop);
+  const uint64_t key_u = DXD ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
+  const uint32_t th_u = s2t_drop_thresh(p.drop_p);
+  const float inv_u = s2t_drop_scale(p.drop_p);
+  float gmm[2][4], ag[2][4], ab[2][4];
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    const float4 t = *reinterpret_cast<const float4*>(p.ln_gamma + 128 * qq + 4 * sl);
+    gmm[qq][0] = t.x; gmm[qq][1] = t.y; gmm[qq][2] = t.z; gmm[qq][3] = t.w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ag[qq][r] = ab[qq][r] = 0.f;
+  }
+#pragma unroll 2
+  for (int ps = 0; ps < 4; ++ps) {
+    const int ml = 8 * wave + 2 * ps + hi;
+    const int m = row0 + ml;
+    const bool live = m < M;
+    const int mc = live ? m : M - 1;
+    const bool masked = !live || (p.ln_lens && (m % p.ln_T) >= p.ln_lens[m / p.ln_T]);
+    const float mu = p.ln_mean[mc], rs = p.ln_rstd[mc];
+    float dv[2][4], xh[2][4], dg[2][4], rr[2][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int cc = 32 * qq + sl;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(smem + ml * 1024 + 16 * (cc ^ (ml & 7)));
+      float xv[4];
+      ld4_as_f32<bf16_t>(X + (int64_t)mc * D + 128 * qq + 4 * sl, xv);
+      if (DR) ld4_as_f32<bf16_t>(DR + (int64_t)mc * D + 128 * qq + 4 * sl, rr[qq]);
+      else rr[qq][0] = rr[qq][1] = rr[qq][2] = rr[qq][3] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // (the separate kernels round the GEMM result to bf16 before the LayerNorm backward; fp32 here)
+        dv[qq][r] = masked ? 0.f : a[r];
+        xh[qq][r] = (xv[r] - mu) * rs;
+        dg[qq][r] = dv[qq][r] * gmm[qq][r];
+        s1 += dg[qq][r];
+        s2 += dg[qq][r] * xh[qq][r];
+        ag[qq][r] += dv[qq][r] * xh[qq][r];
+        ab[qq][r] += dv[qq][r];
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    s1 *= 1.0f / D;
+    s2 *= 1.0f / D;
+    if (live) {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        float o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = bf2f(f2bf(rs * (dg[qq][r] - s1 - xh[qq][r] * s2) + rr[qq][r]));
+        st4_from_f32<bf16_t>(DX + (int64_t)m * D + 128 * qq + 4 * sl, o4);
+        if (DXD) {
+          uint32_t r16[4];
+          s2t_rand_run_even32<4>(key_u, (uint32_t)m * D + (uint32_t)(128 * qq + 4 * sl), r16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4[r] = r16[r] >= th_u ? o4[r] * inv_u : 0.f;
+          st4_from_f32<bf16_t>(DXD + (int64_t)m * D + 128 * qq + 4 * sl, o4);
+        }
+      }
+    }
+  }
+  float* red = reinterpret_cast<float*>(smem + DG_A);  // [2][16][256] fp32 = 32 KiB (the dY tile region, idle now)
+  const int grp = 2 * wave + hi;
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    *reinterpret_cast<float4*>(red + (0 * 16 + grp) * 256 + 128 * qq + 4 * sl) = make_float4(ag[qq][0], ag[qq][1], ag[qq][2], ag[qq][3]);
+    *reinterpret_cast<float4*>(red + (1 * 16 + grp) * 256 + 128 * qq + 4 * sl) = make_float4(ab[qq][0], ab[qq][1], ab[qq][2], ab[qq][3]);
+  }
+  __syncthreads();
+  {
+    const int which = tid >> 8, c = tid & 255;
+    float sum = 0.f;
+#pragma unroll
+    for (int gI = 0; gI < 16; ++gI) sum += red[(which * 16 + gI) * 256 + c];
+    atomicAdd(p.ws + (int64_t)(blockIdx.x % p.replicas) * 512 + which * 256 + c, sum);
+  }
+}
+
 }  // namespace
 
 extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
@@ -1300,5 +1527,27 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
     if (drop) hipLaunchKernelGGL((rowblock_gemm_kernel<false, true>), grid, block, 0, s, *a);
     else hipLaunchKernelGGL((rowblock_gemm_kernel<false, false>), grid, block, 0, s, *a);
   }
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_rowblock_dgrad(const s2t_rowblock_dgrad_args* a, void* stream) {
+  if (!a || !a->dy || !a->wt) return S2T_ERR_ARG;
+  if (a->M <= 0 || a->K <= 0) return S2T_ERR_ARG;
+  if (a->d != D || a->K % D || a->K > 8 * D) return S2T_ERR_UNSUPPORTED;
+  if ((int64_t)(a->M + TM) * a->K * 2 >= ((int64_t)1 << 32)) return S2T_ERR_UNSUPPORTED;  // 32-bit byte offsets into dY
+  if (a->ln_x) {
+    if (!a->ln_gamma || !a->ln_mean || !a->ln_rstd || !a->ln_ws || a->ln_replicas <= 0 || !a->dx) return S2T_ERR_ARG;
+    if (a->ln_lens && a->ln_T <= 0) return S2T_ERR_ARG;
+    if (a->dx_drop && (a->up_drop_p <= 0.f || a->up_drop_p >= 1.f || !a->drop_seed)) return S2T_ERR_ARG;
+  } else if (!a->dxn) return S2T_ERR_ARG;
+  const void* ptrs[] = {a->dy, a->wt, a->dxn, a->ln_x, a->ln_gamma, a->dres, a->dx, a->dx_drop};
+  for (const void* q : ptrs)
+    if (q && ((uintptr_t)q % 16)) return S2T_ERR_ALIGN;
+  DgradK k = {};
+  k.dy = a->dy; k.wt = a->wt; k.M = a->M; k.K = a->K; k.dxn = a->dxn;
+  k.ln_x = a->ln_x; k.ln_gamma = a->ln_gamma; k.ln_mean = a->ln_mean; k.ln_rstd = a->ln_rstd;
+  k.ln_lens = a->ln_lens; k.ln_T = a->ln_T; k.dres = a->dres; k.ws = a->ln_ws; k.replicas = a->ln_replicas;
+  k.dx = a->dx; k.dx_drop = a->dx_drop; k.drop_p = a->up_drop_p; k.drop_site = a->up_drop_site; k.drop_seed = a->drop_seed;
+  hipLaunchKernelGGL(rowblock_dgrad_kernel, dim3((a->M + TM - 1) / TM), dim3(512), 0, (hipStream_t)stream, k);
   return S2T_LAUNCH_CHECK();
 }

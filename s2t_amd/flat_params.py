@@ -107,34 +107,37 @@ class FlatParameters:
         return buf[o:o + rows * cols].view(rows, cols)
 
 
-def transposed(p: nn.Parameter, in_backward: bool) -> torch.Tensor:
+def transposed(p: nn.Parameter, in_backward: bool, rows: int = 0, cols: int = 0) -> torch.Tensor:
     """bf16 [cols, rows] copy of the 2-D parameter ``p`` (bf16 mode only), current with the shadow.  The copies of every
     registered parameter are rewritten by ONE s2t_transpose_bf16_batched launch, the first time any of them is asked for in a
     backward pass (``in_backward``: the caller has the end-of-backward callback armed, which marks them stale again);
-    outside a backward pass every call refreshes."""
+    outside a backward pass every call refreshes.  ``rows`` / ``cols``: the [rows, cols] matrix STARTING at ``p`` in the flat
+    buffer instead (an adjacency group, e.g. the fused [3d, d] q | k | v projection; a Conv1d(k=1) weight as [out, in])."""
     from . import kernels as K
 
     flat = p._s2t_flat
     st = flat._wt
-    key = id(p)
+    key = (id(p), rows, cols)
     new = key not in st["bufs"]
     if new:
-        assert p.dim() == 2 and flat.shadow is not None
-        st["bufs"][key] = torch.empty(p.shape[1], p.shape[0], dtype=torch.bfloat16, device=flat.shadow.device)
-        st["params"].append(p)
+        assert flat.shadow is not None
+        src = flat.view(p, rows, cols) if rows else p._s2t_shadow
+        assert src.dim() == 2
+        st["bufs"][key] = torch.empty(src.shape[1], src.shape[0], dtype=torch.bfloat16, device=flat.shadow.device)
+        st["params"].append((key, src))
         st["table"] = None
     if new or not st["fresh"] or not in_backward:
         if st["table"] is None:
             import numpy as np
 
             rec = np.zeros(len(st["params"]), dtype=np.dtype([("src", "u8"), ("dst", "u8"), ("rows", "i4"), ("cols", "i4")]))
-            for i, q in enumerate(st["params"]):
-                rec[i] = (q._s2t_shadow.data_ptr(), st["bufs"][id(q)].data_ptr(), q.shape[0], q.shape[1])
+            for i, (kq, src) in enumerate(st["params"]):
+                rec[i] = (src.data_ptr(), st["bufs"][kq].data_ptr(), src.shape[0], src.shape[1])
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("s2t_amd: a transposed weight copy was first asked for during graph capture; run one "
                                    "eager step first")
             st["table"] = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.shadow.device)
-            st["ext"] = (max(q.shape[0] for q in st["params"]), max(q.shape[1] for q in st["params"]))
+            st["ext"] = (max(src.shape[0] for _, src in st["params"]), max(src.shape[1] for _, src in st["params"]))
         K.transpose_batched(st["table"], len(st["params"]), st["ext"][0], st["ext"][1])
         st["fresh"] = in_backward
     return st["bufs"][key]

@@ -616,6 +616,33 @@ def _rb_ok(x, N, act=None):
 _DGRAD_SPLITK = os.environ.get("S2T_DGRAD_SPLITK", "1") != "0"
 
 
+_RB_DGRAD = os.environ.get("S2T_RB_DGRAD", "1") != "0"  # s2t_rowblock_dgrad: projection dgrad + LayerNorm backward in one launch
+
+
+def _dgrad_ln_backward(dy, first_w, Kd, x_pre, gamma, beta, mean, rstd, lens, T, dres, up_drop):
+    """dx = LayerNorm'(dy @ W) + dres through s2t_rowblock_dgrad, or None when it does not apply (the caller then runs the
+    GEMM and s2t_layernorm_bwd).  ``first_w``: first parameter of the [Kd, 256] weight (group) in the flat buffer."""
+    flat = getattr(first_w, "_s2t_flat", None)
+    M = dy.shape[0]
+    if not (_RB_DGRAD and flat is not None and flat.shadow is not None and dy.dtype == torch.bfloat16 and dy.is_contiguous()
+            and x_pre.shape[1] == 256 and Kd % 256 == 0 and Kd <= 2048 and M >= _RB_MIN_ROWS and (M + 64) * Kd * 2 < 2 ** 32
+            and x_pre.is_contiguous() and _arm_backward_end()):
+        return None
+    if flat not in _BE["flats"]:
+        _BE["flats"].append(flat)
+    wt = transposed(first_w, True, Kd, 256)
+    dx = torch.empty_like(x_pre)
+    dxd = torch.empty_like(x_pre) if up_drop is not None else None
+    ws = _ln_workspace(256, x_pre.device)
+    K.rowblock_dgrad(dy, wt, ln=dict(x=x_pre, gamma=gamma.data, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, lens=lens, T=T,
+                                     dx_drop=dxd, drop=up_drop))
+    _LNQ["entries"].append((ws, gamma.grad, beta.grad, 256))
+    _ready(gamma, beta)
+    if dxd is not None:
+        _hand_over(dx, up_drop, dxd)
+    return dx
+
+
 def _dgrad(dy, w, dx, M, N, Kd, lda, ldb, ldc, alpha=1.0):
     """dx[M, N] = alpha * dy[M, Kd] @ w[Kd, N] (input gradient of a linear layer).  A long reduction over few output tiles —
     the vocabulary projections (K = V = 10 000; M = B*U decoder rows: 32 tiles walking 157 K-steps each took 180 us) and the
@@ -1076,15 +1103,23 @@ class AttentionFn(torch.autograd.Function):
             else:
                 dq[:, :d].add_(dqv)
             _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
-        dxq = torch.empty(Mq, d, dtype=dt, device=dev)
+        dxq = None
+        dx_ln = None
         if ctx.self_attn:
             gw = fused_grad([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
             gb = prm["q_b"].grad.as_strided((3 * d,), (1,))
             wqkv = fused([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
             _wgrad(dqkv, xq, gw, 3 * d, d, Mq, 3 * d, d, 1.0, gb)
-            K.gemm(dqkv, wqkv, dxq, M=Mq, N=d, K=3 * d, lda=3 * d, ldb=d, ldc=d, b_kmajor=True)
+            if ctx.ln is not None:  # projection dgrad + the LayerNorm's backward in one row-block launch
+                ln_g, ln_b, up_drop = ctx.ln
+                x_pre, ln_mean, ln_rstd = ctx.ln_saved
+                dx_ln = _dgrad_ln_backward(dqkv, prm["q_w"], 3 * d, x_pre, ln_g, ln_b, ln_mean, ln_rstd, None, 0, dres, up_drop)
+            if dx_ln is None:
+                dxq = torch.empty(Mq, d, dtype=dt, device=dev)
+                K.gemm(dqkv, wqkv, dxq, M=Mq, N=d, K=3 * d, lda=3 * d, ldb=d, ldc=d, b_kmajor=True)
             dxkv = None
         else:
+            dxq = torch.empty(Mq, d, dtype=dt, device=dev)
             _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d, 1.0, prm["q_b"].grad)
             K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
             gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
@@ -1094,6 +1129,8 @@ class AttentionFn(torch.autograd.Function):
             dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
             K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
+        if dx_ln is not None:
+            return (dx_ln, None, None) + (None,) * 15
         if ctx.ln is not None:
             ln_g, ln_b, up_drop = ctx.ln
             x_pre, ln_mean, ln_rstd = ctx.ln_saved
@@ -1412,9 +1449,15 @@ class ConvModuleFn(torch.autograd.Function):
             K.dwconv_bwd_weight(g, dD, prm["dw_w"].grad.view(d, Kw), B, T, d, Kw)
             K.glu_bwd(z, dG, dZ, M, d)
         _wgrad(dZ, x, prm["pw1_w"].grad.view(2 * d, d), 2 * d, d, M, 2 * d, d)
+        _ready(prm["pw1_w"], prm["dw_w"], prm["bn_w"], prm["bn_b"], prm["pw2_w"])
+        if ctx.ln is not None:
+            ln_g, ln_b, up_drop = ctx.ln
+            x_pre, ln_mean, ln_rstd = ctx.ln_saved
+            dxp = _dgrad_ln_backward(dZ, prm["pw1_w"], 2 * d, x_pre, ln_g, ln_b, ln_mean, ln_rstd, ctx.lens, T, dres, up_drop)
+            if dxp is not None:
+                return (dxp, None) + (None,) * 12
         dx = torch.empty(M, d, dtype=dt, device=dev)
         K.gemm(dZ, cw(prm["pw1_w"]).view(2 * d, d), dx, M=M, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
-        _ready(prm["pw1_w"], prm["dw_w"], prm["bn_w"], prm["bn_b"], prm["pw2_w"])
         if ctx.ln is not None:
             ln_g, ln_b, up_drop = ctx.ln
             x_pre, ln_mean, ln_rstd = ctx.ln_saved

@@ -184,6 +184,35 @@ def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=N
     L.check(L.lib().s2t_ffn_fused_bwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_bwd")
 
 
+def rowblock_dgrad(dy, wt, *, dxn=None, ln=None):
+    """s2t_rowblock_dgrad (include/s2t_hip.h): dxn = dy @ W from the transposed weight ``wt`` [256, K]; ``ln`` = dict(x, gamma,
+    mean, rstd, ws, dx[, dres, lens, T, dx_drop, drop]) adds the backward of the LayerNorm in front of the projection."""
+    L.require_cuda(dy, wt, dxn)
+    M, Kd = dy.shape
+    assert wt.shape == (256, Kd) and dy.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16
+    assert dy.is_contiguous() and wt.is_contiguous()
+    a = L.RowblockDgradArgs()
+    a.dy, a.wt, a.d, a.M, a.K, a.dxn = dy.data_ptr(), wt.data_ptr(), 256, M, Kd, _ptr(dxn)
+    if ln is not None:
+        x, dx = ln["x"], ln["dx"]
+        assert x.shape == (M, 256) and dx.shape == (M, 256) and x.is_contiguous() and dx.is_contiguous()
+        assert ln["ws"].numel() >= LN_REPLICAS * 2 * 256
+        a.ln_x, a.ln_gamma, a.ln_mean, a.ln_rstd = x.data_ptr(), ln["gamma"].data_ptr(), ln["mean"].data_ptr(), ln["rstd"].data_ptr()
+        a.ln_lens, a.ln_T = _ptr(ln.get("lens")), int(ln.get("T") or 0)
+        a.dres, a.ln_ws, a.ln_replicas, a.dx = _ptr(ln.get("dres")), ln["ws"].data_ptr(), LN_REPLICAS, dx.data_ptr()
+        if ln.get("dx_drop") is not None:
+            dr = ln["drop"]
+            a.dx_drop, a.up_drop_p, a.up_drop_site, a.drop_seed = ln["dx_drop"].data_ptr(), float(dr[0]), int(dr[2]), dr[1].data_ptr()
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().s2t_rowblock_dgrad(C.byref(a), L.stream_ptr()), "s2t_rowblock_dgrad")
+        e1.record()
+        GEMM_PROFILE.append(("rowblock_dgrad_kernel", 2.0 * M * 256 * Kd, e0, e1, (M, 256, Kd, 1)))
+        return
+    L.check(L.lib().s2t_rowblock_dgrad(C.byref(a), L.stream_ptr()), "s2t_rowblock_dgrad")
+
+
 def transpose_batched(table, n, max_rows, max_cols):
     """s2t_transpose_bf16_batched: ``table`` = device uint8 tensor holding n s2t_transpose_item records (24 bytes each)."""
     _call("s2t_transpose_bf16_batched", table.data_ptr(), n, max_rows, max_cols)

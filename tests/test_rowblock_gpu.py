@@ -255,6 +255,59 @@ def test_ffn_fused_bwd_layernorm_epilogue(M, F, up):
         assert (dxd.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
 
 
+@pytest.mark.parametrize("M,Kd,mask,up", [(200, 256, False, False), (4000, 768, False, True), (4 * 250, 512, True, True)])
+def test_rowblock_dgrad_matches_gemm_plus_layernorm_bwd(M, Kd, mask, up):
+    """s2t_rowblock_dgrad (input gradient of the projection behind a LayerNorm + that LayerNorm's backward) against the dgrad
+    GEMM followed by s2t_layernorm_bwd: dx, the dropped copy, the dgamma / dbeta partial sums; and its plain form (dxn)."""
+    from s2t_amd import functional as Fn
+
+    d = 256
+    g = torch.Generator().manual_seed(M + Kd)
+    dy = torch.randn(M, Kd, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(Kd, d, generator=g) * Kd ** -0.5).bfloat16().to(DEV)   # nn.Linear(d -> Kd) weight [Kd, d]
+    wt = w.t().contiguous()                                                  # [256, Kd]
+    x = (2 * torch.randn(M, d, generator=g) + 0.3).bfloat16().to(DEV)
+    gam = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    dres = torch.randn(M, d, generator=g).bfloat16().to(DEV)
+    xf = x.float()
+    mean = xf.mean(1)
+    rstd = (xf.var(1, unbiased=False) + 1e-5).rsqrt()
+    T = 250
+    lens = torch.tensor([250, 180, 37, 1][:M // T], dtype=torch.int32, device=DEV) if mask else None
+    Fn.DROPOUT.begin_step(torch.device(DEV))
+    Fn.DROPOUT.set_seed(4)
+    up_drop = Fn.DROPOUT.next(0.1, torch.device(DEV)) if up else None
+    # reference chain
+    dxn_u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    K.gemm(dy, w, dxn_u, M=M, N=d, K=Kd, lda=Kd, ldb=d, ldc=d, b_kmajor=True)
+    dx_u = torch.empty_like(x)
+    dxd_u = torch.empty_like(x) if up else None
+    dg_u, db_u = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    K.layernorm_bwd(x, gam, dxn_u, mean, rstd, dx_u, dg_u, db_u, M, d, lens, T if mask else 0, dres, dx_drop=dxd_u, drop=up_drop)
+    # plain form
+    dxn = torch.full((M, d), 5.0, dtype=torch.bfloat16, device=DEV)
+    K.rowblock_dgrad(dy, wt, dxn=dxn)
+    # with the LayerNorm backward
+    dx = torch.full_like(x, 5.0)
+    dxd = torch.full_like(x, 5.0) if up else None
+    ws = torch.zeros(K.LN_REPLICAS * 2 * d, device=DEV)
+    K.rowblock_dgrad(dy, wt, ln=dict(x=x, gamma=gam, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, lens=lens, T=T if mask else 0,
+                                     dx_drop=dxd, drop=up_drop))
+    torch.cuda.synchronize()
+    rel = (dxn.float() - dxn_u.float()).norm() / dxn_u.float().norm()
+    assert rel < 4e-3, float(rel)
+    rel = (dx.float() - dx_u.float()).norm() / dx_u.float().norm()
+    assert rel < 6e-3, float(rel)
+    wsum = ws.view(K.LN_REPLICAS, 2, d).sum(0)
+    assert (wsum[0] - dg_u).abs().max() <= 1e-2 * dg_u.abs().max() + 1e-3
+    assert (wsum[1] - db_u).abs().max() <= 1e-2 * db_u.abs().max() + 1e-3
+    if up:
+        keep = dxd_u.float() != 0
+        assert ((dxd.float() != 0) == keep).float().mean() > 0.999
+        ref = torch.where(keep, dx.float() / 0.9, torch.zeros_like(dx.float()))
+        assert (dxd.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
 @pytest.mark.parametrize("end_norm,mask", [(False, False), (True, False), (True, True)])
 def test_ffn_block_fused_vs_composed_training(end_norm, mask):
     """functional.ffn_block: the fused launch and the LayerNorm / GEMM composition give the same output and gradients
