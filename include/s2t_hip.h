@@ -485,13 +485,14 @@ typedef struct s2t_ffn_bwd_args {
 } s2t_ffn_bwd_args;
 int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* args, void* stream);
 
-/* dst_i [cols_i][rows_i] = src_i [rows_i][cols_i]^T for n bf16 matrices in one launch; items_dev: device array.
- * max_rows / max_cols: the largest extents in the table (they size the grid). */
+/* dst_i [cols_i][rows_i] = src_i [rows_i][cols_i]^T for n bf16 matrices in one launch; items_dev: device array;
+ * tiles_dev: device array of n_tiles (matrix index, row tile, column tile) int32 triples, 64 x 64 tiles, covering every
+ * matrix (one workgroup each). */
 typedef struct s2t_transpose_item {
   const void* src; void* dst;
   int32_t rows, cols;
 } s2t_transpose_item;
-int s2t_transpose_bf16_batched(const s2t_transpose_item* items_dev, int n, int max_rows, int max_cols, void* stream);
+int s2t_transpose_bf16_batched(const s2t_transpose_item* items_dev, int n, const int32_t* tiles_dev, int n_tiles, void* stream);
 
 /* s2t_rowblock_gemm: the K = 256 projections of an encoder layer on the same 64-row blocks, with the LayerNorm in front
  * folded in:   out[M][Nout] = epilogue( xn[M][256] W[N][256]^T ),   xn = ln_gamma ? LayerNorm(x) (rows of padded frames

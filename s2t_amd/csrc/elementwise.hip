@@ -581,15 +581,47 @@ extern "C" int s2t_clip_coef(const float* sumsq, float max_norm, float mult, flo
   return S2T_LAUNCH_CHECK();
 }
 
-// n bf16 matrices transposed by one launch: 64 x 64 tiles, each thread turns 2 x 2 element blocks in registers so that
-// every global and LDS access moves 4 bytes; grid (column tiles, row tiles, matrix)
-__global__ __launch_bounds__(256) void transpose_batched_kernel(const s2t_transpose_item* __restrict__ items) {
-  __shared__ uint32_t tile[64][33];  // [output row in tile][pair of output columns]
-  const s2t_transpose_item it = items[blockIdx.z];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+// n bf16 matrices transposed by one launch: 64 x 64 tiles, one workgroup per entry of the tile list (matrix, row tile,
+// column tile) the host made — a grid sized by the largest extents launched eight empty workgroups per busy one.
+// Fast path (both extents multiples of 8, 16-byte aligned bases): every thread moves two 16-byte pieces each way — rows of
+// the tile go into LDS as they are ([row][col], 136-byte pitch), the transposed rows are gathered from it eight 2-byte reads
+// per output piece.  Anything else takes the 4-byte path (2 x 2 element blocks turned in registers).
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const s2t_transpose_item* __restrict__ items,
+                                                                const int32_t* __restrict__ tiles) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 68];
+  const int32_t* td = tiles + 3 * (int64_t)blockIdx.x;
+  const s2t_transpose_item it = items[td[0]];
+  const int r0 = td[1] * 64, c0 = td[2] * 64;
   if (r0 >= it.rows || c0 >= it.cols) return;
   const bf16_t* src = reinterpret_cast<const bf16_t*>(it.src);
   bf16_t* dst = reinterpret_cast<bf16_t*>(it.dst);
+  const bool fast = (it.rows % 8) == 0 && (it.cols % 8) == 0 && (((uintptr_t)it.src | (uintptr_t)it.dst) & 15) == 0;
+  if (fast) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int v = threadIdx.x + 256 * ps;   // 512 pieces: row v >> 3, 8-column piece v & 7
+      const int r = v >> 3, pc = v & 7;
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (r0 + r < it.rows && c0 + 8 * pc < it.cols) q = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + r) * it.cols + c0 + 8 * pc);
+      *reinterpret_cast<uint2*>(tile + r * 68 + 8 * pc) = make_uint2(q.x, q.y);
+      *reinterpret_cast<uint2*>(tile + r * 68 + 8 * pc + 4) = make_uint2(q.z, q.w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int v = threadIdx.x + 256 * ps;   // output row (input column) v & 63, 8-row piece v >> 6
+      const int oc = v & 63, pr = v >> 6;
+      if (c0 + oc < it.cols && r0 + 8 * pr < it.rows) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          w[k] = (uint32_t)tile[(8 * pr + 2 * k) * 68 + oc] | ((uint32_t)tile[(8 * pr + 2 * k + 1) * 68 + oc] << 16);
+        *reinterpret_cast<uint4*>(dst + (int64_t)(c0 + oc) * it.rows + r0 + 8 * pr) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    return;
+  }
+  uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);  // [64 output rows][33 pairs of output columns]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const bool src32 = (it.cols & 1) == 0, dst32 = (it.rows & 1) == 0;
   auto ld2 = [&](int r, int c) -> uint32_t {  // elements (r, c) | (r, c + 1) << 16, zero outside
@@ -602,8 +634,8 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const s2t_transp
   for (int ps = 0; ps < 4; ++ps) {
     const int rp = 8 * ps + ty;
     const uint32_t a = ld2(r0 + 2 * rp, c0 + 2 * tx), b = ld2(r0 + 2 * rp + 1, c0 + 2 * tx);
-    tile[2 * tx][rp] = (a & 0xffffu) | (b << 16);
-    tile[2 * tx + 1][rp] = (a >> 16) | (b & 0xffff0000u);
+    t32[(2 * tx) * 33 + rp] = (a & 0xffffu) | (b << 16);
+    t32[(2 * tx + 1) * 33 + rp] = (a >> 16) | (b & 0xffff0000u);
   }
   __syncthreads();
 #pragma unroll
@@ -611,7 +643,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const s2t_transp
     const int orow = 8 * ps + ty;
     const int c = c0 + orow, r = r0 + 2 * tx;  // output row c, output columns r, r + 1
     if (c < it.cols && r < it.rows) {
-      const uint32_t v = tile[orow][tx];
+      const uint32_t v = t32[orow * 33 + tx];
       bf16_t* q = dst + (int64_t)c * it.rows + r;
       if (dst32 && r + 1 < it.rows) *reinterpret_cast<uint32_t*>(q) = v;
       else {
@@ -621,11 +653,10 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const s2t_transp
     }
   }
 }
-extern "C" int s2t_transpose_bf16_batched(const s2t_transpose_item* items_dev, int n, int max_rows, int max_cols, void* stream) {
-  if (!items_dev || n <= 0 || max_rows <= 0 || max_cols <= 0) return S2T_ERR_ARG;
-  if (n > 65535 || (max_rows + 63) / 64 > 65535) return S2T_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(transpose_batched_kernel, dim3((max_cols + 63) / 64, (max_rows + 63) / 64, n), dim3(256), 0,
-                     (hipStream_t)stream, items_dev);
+extern "C" int s2t_transpose_bf16_batched(const s2t_transpose_item* items_dev, int n, const int32_t* tiles_dev, int n_tiles,
+                                          void* stream) {
+  if (!items_dev || n <= 0 || !tiles_dev || n_tiles <= 0) return S2T_ERR_ARG;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, items_dev, tiles_dev);
   return S2T_LAUNCH_CHECK();
 }
 

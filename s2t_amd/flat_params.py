@@ -137,7 +137,8 @@ def transposed(p: nn.Parameter, in_backward: bool, rows: int = 0, cols: int = 0)
                 raise RuntimeError("s2t_amd: a transposed weight copy was first asked for during graph capture; run one "
                                    "eager step first")
             st["table"] = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.shadow.device)
-            st["ext"] = (max(src.shape[0] for _, src in st["params"]), max(src.shape[1] for _, src in st["params"]))
+            tl = K.transpose_tiles([tuple(src.shape) for _, src in st["params"]])
+            st["ext"] = (torch.from_numpy(tl).to(flat.shadow.device), int(tl.shape[0]))
         K.transpose_batched(st["table"], len(st["params"]), st["ext"][0], st["ext"][1])
         st["fresh"] = in_backward
     return st["bufs"][key]

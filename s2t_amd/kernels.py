@@ -213,9 +213,25 @@ def rowblock_dgrad(dy, wt, *, dxn=None, ln=None):
     L.check(L.lib().s2t_rowblock_dgrad(C.byref(a), L.stream_ptr()), "s2t_rowblock_dgrad")
 
 
-def transpose_batched(table, n, max_rows, max_cols):
-    """s2t_transpose_bf16_batched: ``table`` = device uint8 tensor holding n s2t_transpose_item records (24 bytes each)."""
-    _call("s2t_transpose_bf16_batched", table.data_ptr(), n, max_rows, max_cols)
+def transpose_tiles(shapes):
+    """int32 [n_tiles, 3] tile list (matrix, row tile, column tile) for s2t_transpose_bf16_batched; shapes = [(rows, cols)]."""
+    import numpy as np
+
+    out = []
+    for i, (r, c) in enumerate(shapes):
+        tr, tc = (r + 63) // 64, (c + 63) // 64
+        t = np.empty((tr, tc, 3), dtype=np.int32)
+        t[..., 0] = i
+        t[..., 1] = np.arange(tr, dtype=np.int32)[:, None]
+        t[..., 2] = np.arange(tc, dtype=np.int32)[None, :]
+        out.append(t.reshape(-1, 3))
+    return np.concatenate(out)
+
+
+def transpose_batched(table, n, tiles, n_tiles):
+    """s2t_transpose_bf16_batched: ``table`` = device uint8 tensor holding n s2t_transpose_item records (24 bytes each),
+    ``tiles`` = device int32 tile list (transpose_tiles)."""
+    _call("s2t_transpose_bf16_batched", table.data_ptr(), n, tiles.data_ptr(), n_tiles)
 
 
 def rowblock_supported(x, N, act=None):

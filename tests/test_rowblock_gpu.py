@@ -146,7 +146,8 @@ def test_transpose_batched():
     shapes = [(2048, 256), (256, 2048), (100, 72), (65, 33)]
     src = [torch.randn(r, c, generator=g).bfloat16().to(DEV) for r, c in shapes]
     dst = [torch.full((c, r), 7.0, dtype=torch.bfloat16, device=DEV) for r, c in shapes]
-    K.transpose_batched(_tr_table(list(zip(src, dst))), len(src), 2048, 2048)
+    tl = K.transpose_tiles(shapes)
+    K.transpose_batched(_tr_table(list(zip(src, dst))), len(src), torch.from_numpy(tl).to(DEV), int(tl.shape[0]))
     torch.cuda.synchronize()
     for s_, d_ in zip(src, dst):
         assert torch.equal(d_, s_.t().contiguous())
