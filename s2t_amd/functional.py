@@ -403,7 +403,7 @@ def reserve_wgrad_staging(device, nbytes=8 << 20, count=1):
 
 _WG_KSTEPS = int(os.environ.get("S2T_WG_KSTEPS", "64"))  # K-steps (of 64 rows) per work item
 _WG_256 = os.environ.get("S2T_WG_256", "1") != "0"          # s2t_wgrad_grouped256 where the operands allow it
-_WG_KSTEPS256 = int(os.environ.get("S2T_WG_KSTEPS256", "128"))  # its K-steps (of 32 rows) per work item
+_WG_KSTEPS256 = int(os.environ.get("S2T_WG_KSTEPS256", "256"))  # its K-steps (of 32 rows) per work item, about (splits are balanced)
 _WG_DTYPE = None
 
 
@@ -437,9 +437,14 @@ def flush_wgrads():
             tm_n, tn_n = (Nout + TL - 1) // TL, (Kin + TL - 1) // TL
             ktiles = (M + KS - 1) // KS
             nsplit = (ktiles + per_item - 1) // per_item
+            if big:  # balanced splits of about `per_item` K-steps (500 steps: 2 x 250, not 256 + 244 or 3 x 192 with a short one)
+                nsplit = max(1, (ktiles + per_item // 2) // per_item)
+                per_item_p = (ktiles + nsplit - 1) // nsplit
+            else:
+                per_item_p = per_item
             k_tail |= (M % 64) != 0
             probs[i] = (dY.data_ptr(), X.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, ldy, ldx,
-                        Kin, ws_floats, Nout, Kin, M, tn_n, per_item, nsplit, alpha, -1)
+                        Kin, ws_floats, Nout, Kin, M, tn_n, per_item_p, nsplit, alpha, -1)
             prev = last_of.get(dW.data_ptr())  # tied weights: chain the problems, reduce them in one workgroup
             last_of[dW.data_ptr()] = i
             if prev is not None:
