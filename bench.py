@@ -137,6 +137,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(_launch_ranks(args.gpus))
 
+    # stdout carries exactly ONE line (the JSON result, written by rank 0 at the end): libraries print banners there (gloo:
+    # "[Gloo] Rank 0 is connected to ...", RCCL's version line), from every rank, and a rank's stdout reaches the caller
+    # through the launcher.  File descriptor 1 is therefore pointed at stderr for the whole run; the real stdout is kept aside.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -175,8 +182,15 @@ def main():
     from s2t_amd.legacy_distributed_data_parallel import LegacyDistributedDataParallel
     from s2t_amd.trainer import Trainer
 
+    pg = None
     if (world > 1 or force_ddp) and backend == "rccl":
-        Comm.init(rank, world, dev)
+        try:
+            Comm.init(rank, world, dev)
+        except Exception as e:  # noqa: BLE001 — e.g. no loadable librccl: fall back to torch.distributed's own RCCL backend
+            print("[bench] rank %d: library communicator unavailable (%s: %s); using torch.distributed nccl" % (rank, type(e).__name__, e),
+                  file=sys.stderr)
+            if world > 1:
+                pg = dist.new_group(backend="nccl")
     V = args.vocab
     conformer = args.arch == "conformer"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -185,7 +199,7 @@ def main():
                           dropout=args.dropout, attention_dropout=args.dropout, activation_dropout=args.dropout)
     model = M.S2TTransformerModel.build_model(margs, M.FakeTask(V)).prepare(dtype, dev)
     crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
-    ddp = LegacyDistributedDataParallel(model, single_rank_collectives=force_ddp) if (world > 1 or force_ddp) else None
+    ddp = LegacyDistributedDataParallel(model, process_group=pg, single_rank_collectives=force_ddp) if (world > 1 or force_ddp) else None
     trainer = Trainer(model, crit, ddp=ddp)
     sample, frames_local = synthetic_batch(args.batch, args.frames, V, 1 + rank, dev)
     ft = torch.tensor([frames_local, sample["ntokens"]], dtype=torch.float64)
@@ -347,7 +361,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if world > 1:
         dist.barrier()
     Comm.destroy()
