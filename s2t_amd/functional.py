@@ -273,7 +273,7 @@ def _dbd_buffer(H, B, Tq, ldB, dt, dev):
     if buf is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("s2t_amd: a new attention-gradient shape appeared during graph capture; run one eager step first")
-        while len(_DBD) >= 4:  # a few bucketed shapes at most; evict the oldest
+        while len(_DBD) >= 8:  # a few shapes at most (PDS stages, bucketed lengths); evict the oldest
             _DBD.pop(next(iter(_DBD)))
         buf = _DBD[key] = torch.zeros(H, B, Tq, ldB, dtype=dt, device=dev)
     return buf
@@ -1273,7 +1273,7 @@ def project_positions(pos_tab, weights):
         if buf is None:
             if torch.cuda.is_current_stream_capturing():
                 return res
-            while len(_PT) >= 4:
+            while len(_PT) >= 8:
                 _PT.pop(next(iter(_PT)))
             buf = _PT[key] = torch.zeros(len(ws), d, ld, dtype=torch.bfloat16, device=pos_tab.device)
         K.gemm(ws[0], pos_tab, buf[0, :, _PT_OFF:], M=d, N=n_pos, K=d, lda=d, ldb=d, ldc=ld, batch=len(ws), a_s=(stride, 0),
