@@ -418,6 +418,108 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
   }
 }
 
+// Single-wave variant for 2S+1 <= 127 states, log-sum-exp recursion only (no force_emits / paths): lane l owns the
+// blank state 2l and the label state 2l+1, the neighbours' values arrive by DPP shuffles, so a frame step has no LDS
+// round trip and no barrier.  Same recursion and the same lse3 association order as ctc_alpha_beta_kernel.
+template <typename T>
+__global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __restrict__ logits, int64_t ld, int T_,
+                                                                 const float* __restrict__ lse,
+                                                                 const int64_t* __restrict__ targets, int ldt,
+                                                                 const int32_t* __restrict__ tgt_lens,
+                                                                 const int32_t* __restrict__ in_lens, int blank,
+                                                                 float* __restrict__ alpha, float* __restrict__ beta,
+                                                                 int Lmax, float* __restrict__ nll_out) {
+  constexpr int CH = 16;
+  const int b = blockIdx.x;
+  const int S = tgt_lens[b];
+  const int L = 2 * S + 1;
+  const int Tb = min(in_lens[b], T_);
+  const int lane = threadIdx.x;
+  const int s0 = 2 * lane, s1 = s0 + 1;
+  const bool act0 = s0 < L, act1 = s1 < L;
+  const int64_t* tg = targets + (int64_t)b * ldt;
+  const int lab = act1 ? (int)tg[lane] : blank;
+  const bool skip = act1 && lane >= 1 && lab != (int)tg[lane - 1];
+  const bool skipn = act1 && s1 + 2 < L && lab != (int)tg[lane + 1];
+  const int64_t row0 = (int64_t)b * T_;
+  if (Tb <= 0) {
+    if (lane == 0 && blockIdx.y == 0) nll_out[b] = 0.f;
+    return;
+  }
+  const T* lg = logits + row0 * ld;
+  const float* ls = lse + row0;
+  if (blockIdx.y == 0) {
+    float* al = alpha + row0 * Lmax;
+    float a0 = -INFINITY, a1 = -INFINITY;
+    if (lane == 0) {
+      a0 = ld_as_f32<T>(lg + blank) - ls[0];
+      if (act1) a1 = ld_as_f32<T>(lg + lab) - ls[0];
+    }
+    if (act0) al[s0] = a0;
+    if (act1) al[s1] = a1;
+    for (int t0 = 1; t0 < Tb; t0 += CH) {
+      float lpb[CH], lpl[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int t = min(t0 + i, Tb - 1);
+        const float z = ls[t];
+        lpb[i] = ld_as_f32<T>(lg + t * ld + blank) - z;
+        lpl[i] = ld_as_f32<T>(lg + t * ld + lab) - z;
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int t = t0 + i;
+        if (t >= Tb) break;  // wave-uniform
+        float p1 = __shfl_up(a1, 1);  // alpha[t-1][2l-1]
+        if (lane == 0) p1 = -INFINITY;
+        const float m0 = lse3(a0, p1, -INFINITY);
+        const float m1 = lse3(a1, a0, skip ? p1 : -INFINITY);
+        a0 = (act0 && m0 != -INFINITY) ? m0 + lpb[i] : -INFINITY;
+        a1 = (act1 && m1 != -INFINITY) ? m1 + lpl[i] : -INFINITY;
+        if (act0) al[(int64_t)t * Lmax + s0] = a0;
+        if (act1) al[(int64_t)t * Lmax + s1] = a1;
+      }
+    }
+    const float l1 = __shfl(a0, S);                                // state L-1 = 2S
+    const float l2 = L >= 2 ? __shfl(a1, max(S - 1, 0)) : -INFINITY;  // state L-2 = 2(S-1)+1
+    if (lane == 0) nll_out[b] = -lse2(l1, l2);
+  } else {
+    float* be = beta + row0 * Lmax;
+    float b0 = -INFINITY, b1 = -INFINITY;
+    {
+      const int t = Tb - 1;
+      const float z = ls[t];
+      if (act0 && s0 >= L - 2) b0 = ld_as_f32<T>(lg + t * ld + blank) - z;
+      if (act1 && s1 >= L - 2) b1 = ld_as_f32<T>(lg + t * ld + lab) - z;
+      if (act0) be[(int64_t)t * Lmax + s0] = b0;
+      if (act1) be[(int64_t)t * Lmax + s1] = b1;
+    }
+    for (int t0 = Tb - 2; t0 >= 0; t0 -= CH) {
+      float lpb[CH], lpl[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int t = max(t0 - i, 0);
+        const float z = ls[t];
+        lpb[i] = ld_as_f32<T>(lg + t * ld + blank) - z;
+        lpl[i] = ld_as_f32<T>(lg + t * ld + lab) - z;
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int t = t0 - i;
+        if (t < 0) break;  // wave-uniform
+        const float nb0 = __shfl_down(b0, 1);  // beta[t+1][2l+2]
+        const float nb1 = __shfl_down(b1, 1);  // beta[t+1][2l+3]
+        const float m0 = lse3(b0, s0 + 1 < L ? b1 : -INFINITY, -INFINITY);
+        const float m1 = lse3(b1, s1 + 1 < L ? nb0 : -INFINITY, skipn ? nb1 : -INFINITY);
+        b0 = (act0 && m0 != -INFINITY) ? m0 + lpb[i] : -INFINITY;
+        b1 = (act1 && m1 != -INFINITY) ? m1 + lpl[i] : -INFINITY;
+        if (act0) be[(int64_t)t * Lmax + s0] = b0;
+        if (act1) be[(int64_t)t * Lmax + s1] = b1;
+      }
+    }
+  }
+}
+
 // grad[b,t,c] = gscale * ( p[c] - sum_{s: ext[s]==c} exp(alpha+beta + nll - lp[c]) )   for t < len, finite nll; else 0
 // one workgroup per frame row; the <= 2S+1 states are merged per label in LDS.
 template <typename T>
@@ -602,6 +704,13 @@ extern "C" int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B
   int threads = (Lmax + 63) / 64 * 64;
   const size_t shm = 2 * (size_t)(Lmax + 2) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
+  if (Lmax <= 127 && beta && !paths && !force_emits && (dtype == S2T_F32 || dtype == S2T_BF16)) {
+    if (dtype == S2T_F32)
+      hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<float>, dim3(B, 2), dim3(64), 0, s, (const float*)logits, ld, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll);
+    else
+      hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<bf16_t>, dim3(B, 2), dim3(64), 0, s, (const bf16_t*)logits, ld, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll);
+    return S2T_LAUNCH_CHECK();
+  }
   if (dtype == S2T_F32)
     hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B, (beta && !paths) ? 2 : 1), dim3(threads), shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
   else if (dtype == S2T_BF16)

@@ -375,14 +375,16 @@ def test_label_smoothed_ce(dtype):
     close(dl, lr.grad, dtype, 1 if dtype == torch.float32 else 0.5)
 
 
+@pytest.mark.parametrize("longest", [15, 63, 70])
 @pytest.mark.parametrize("dtype", DT)
-def test_ctc_loss_fwd_bwd(dtype):
+def test_ctc_loss_fwd_bwd(dtype, longest):
+    """longest <= 63 labels (<= 127 states) runs the single-wave recursion, 70 the one-thread-per-state workgroup."""
     g = torch.Generator().manual_seed(8)
-    B, T, V = 5, 40, 23
+    B, T, V = 5, 40 if longest == 15 else 150, 23
     logits = rnd((B, T, V), dtype, g, 1.5)
     tg = [torch.tensor([4, 4, 5, 9]), torch.tensor([3]), torch.tensor([], dtype=torch.long),
-          torch.tensor([7, 8, 7, 8, 7, 8, 7, 8, 7, 8, 7, 8]), torch.randint(1, V, (15,), generator=g)]
-    in_lens = torch.tensor([40, 33, 10, 11, 40], dtype=torch.int32)  # utt 3: 12 labels in 11 frames -> infeasible
+          torch.tensor([7, 8, 7, 8, 7, 8, 7, 8, 7, 8, 7, 8]), torch.randint(1, V, (longest,), generator=g)]
+    in_lens = torch.tensor([40, 33, 10, 11, T], dtype=torch.int32)  # utt 3: 12 labels in 11 frames -> infeasible
     S = max(len(t) for t in tg)
     tmat = torch.zeros(B, S, dtype=torch.int64)
     for b, t in enumerate(tg):
