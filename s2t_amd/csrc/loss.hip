@@ -419,8 +419,29 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
 }
 
 // Single-wave variant for 2S+1 <= 127 states, log-sum-exp recursion only (no force_emits / paths): lane l owns the
-// blank state 2l and the label state 2l+1, the neighbours' values arrive by DPP shuffles, so a frame step has no LDS
-// round trip and no barrier.  Same recursion and the same lse3 association order as ctc_alpha_beta_kernel.
+// blank state 2l and the label state 2l+1 and the neighbour's values arrive by a DPP wave shift, so a frame step has
+// no LDS round trip and no barrier.  The step time is the latency of the dependent chain, so the chain is kept short:
+// values live in the log2 domain (raw v_exp_f32 / v_log_f32, converted to natural logs only on the way to memory), the
+// three-way sum is taken around one max3, "no predecessor" is -inf flowing through exp2 -> 0 instead of a branch, and
+// inactive states are kept at -inf by an emission term of -inf.
+__device__ __forceinline__ float wave_from_prev(float v) {  // lane l <- lane l-1, lane 0 <- -inf
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_from_next(float v) {  // lane l <- lane l+1, lane 63 <- -inf
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xff800000, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_value(float v, int l) {  // v of lane l (wave-uniform l), whatever the exec mask
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float l2se3(float a, float b, float c) {  // log2(2^a + 2^b + 2^c), -inf when all are -inf
+  const float m = fmaxf(__builtin_fmaxf(__builtin_fmaxf(a, b), c), -3.0e38f);
+  return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) + __builtin_amdgcn_exp2f(c - m));
+}
+__device__ __forceinline__ float l2se2(float a, float b) {
+  const float m = fmaxf(__builtin_fmaxf(a, b), -3.0e38f);
+  return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m));
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __restrict__ logits, int64_t ld, int T_,
                                                                  const float* __restrict__ lse,
@@ -430,6 +451,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
                                                                  float* __restrict__ alpha, float* __restrict__ beta,
                                                                  int Lmax, float* __restrict__ nll_out) {
   constexpr int CH = 16;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   const int b = blockIdx.x;
   const int S = tgt_lens[b];
   const int L = 2 * S + 1;
@@ -448,74 +470,96 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
   }
   const T* lg = logits + row0 * ld;
   const float* ls = lse + row0;
+  // Emission terms of CH frames at a time, fetched one chunk ahead of the recursion.  Every lane loads (lab is the
+  // blank for a lane without a label state) so that the loads go out back to back; the per-frame log-sum-exp comes in
+  // as one vector load, lane i holding frame i of the chunk.
+  struct Chunk {
+    float x0[CH], x1[CH], z;
+  };
+  auto fetch = [&](Chunk& c, int t0, int dir) {
+    c.z = ls[min(max(t0 + dir * (lane & (CH - 1)), 0), Tb - 1)];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int t = min(max(t0 + dir * i, 0), Tb - 1);
+      c.x0[i] = ld_as_f32<T>(lg + t * ld + blank);
+      c.x1[i] = ld_as_f32<T>(lg + t * ld + lab);
+    }
+  };
+  // log2-domain emission terms; -inf for a state this utterance does not have
+  auto emit0 = [&](const Chunk& c, int i) {
+    const float v = (c.x0[i] - lane_value(c.z, i)) * LOG2E;
+    return act0 ? v : -INFINITY;
+  };
+  auto emit1 = [&](const Chunk& c, int i) {
+    const float v = (c.x1[i] - lane_value(c.z, i)) * LOG2E;
+    return act1 ? v : -INFINITY;
+  };
+  Chunk cur, nxt;
   if (blockIdx.y == 0) {
     float* al = alpha + row0 * Lmax;
-    float a0 = -INFINITY, a1 = -INFINITY;
-    if (lane == 0) {
-      a0 = ld_as_f32<T>(lg + blank) - ls[0];
-      if (act1) a1 = ld_as_f32<T>(lg + lab) - ls[0];
-    }
-    if (act0) al[s0] = a0;
-    if (act1) al[s1] = a1;
+    fetch(cur, 0, 1);
+    float a0 = lane == 0 ? emit0(cur, 0) : -INFINITY;
+    float a1 = lane == 0 ? emit1(cur, 0) : -INFINITY;
+    if (act0) al[s0] = a0 * LN2;
+    if (act1) al[s1] = a1 * LN2;
+    fetch(cur, 1, 1);
     for (int t0 = 1; t0 < Tb; t0 += CH) {
-      float lpb[CH], lpl[CH];
+      fetch(nxt, t0 + CH, 1);
+      float e0[CH], e1[CH];
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        const int t = min(t0 + i, Tb - 1);
-        const float z = ls[t];
-        lpb[i] = ld_as_f32<T>(lg + t * ld + blank) - z;
-        lpl[i] = ld_as_f32<T>(lg + t * ld + lab) - z;
+        e0[i] = emit0(cur, i);
+        e1[i] = emit1(cur, i);
       }
+      float* row = al + (int64_t)t0 * Lmax;
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        const int t = t0 + i;
-        if (t >= Tb) break;  // wave-uniform
-        float p1 = __shfl_up(a1, 1);  // alpha[t-1][2l-1]
-        if (lane == 0) p1 = -INFINITY;
-        const float m0 = lse3(a0, p1, -INFINITY);
-        const float m1 = lse3(a1, a0, skip ? p1 : -INFINITY);
-        a0 = (act0 && m0 != -INFINITY) ? m0 + lpb[i] : -INFINITY;
-        a1 = (act1 && m1 != -INFINITY) ? m1 + lpl[i] : -INFINITY;
-        if (act0) al[(int64_t)t * Lmax + s0] = a0;
-        if (act1) al[(int64_t)t * Lmax + s1] = a1;
+        if (t0 + i >= Tb) break;  // wave-uniform
+        const float p1 = wave_from_prev(a1);  // alpha[t-1][2l-1]
+        const float n0 = l2se2(a0, p1) + e0[i];
+        const float n1 = l2se3(a1, a0, skip ? p1 : -INFINITY) + e1[i];
+        a0 = n0;
+        a1 = n1;
+        if (act0) row[s0] = a0 * LN2;
+        if (act1) row[s1] = a1 * LN2;
+        row += Lmax;
       }
+      cur = nxt;
     }
-    const float l1 = __shfl(a0, S);                                // state L-1 = 2S
-    const float l2 = L >= 2 ? __shfl(a1, max(S - 1, 0)) : -INFINITY;  // state L-2 = 2(S-1)+1
-    if (lane == 0) nll_out[b] = -lse2(l1, l2);
+    const float l1 = lane_value(a0, S);                                   // state L-1 = 2S
+    const float l2 = L >= 2 ? lane_value(a1, max(S - 1, 0)) : -INFINITY;  // state L-2 = 2(S-1)+1
+    if (lane == 0) nll_out[b] = -(l2se2(l1, l2) * LN2);
   } else {
     float* be = beta + row0 * Lmax;
-    float b0 = -INFINITY, b1 = -INFINITY;
-    {
-      const int t = Tb - 1;
-      const float z = ls[t];
-      if (act0 && s0 >= L - 2) b0 = ld_as_f32<T>(lg + t * ld + blank) - z;
-      if (act1 && s1 >= L - 2) b1 = ld_as_f32<T>(lg + t * ld + lab) - z;
-      if (act0) be[(int64_t)t * Lmax + s0] = b0;
-      if (act1) be[(int64_t)t * Lmax + s1] = b1;
-    }
+    fetch(cur, Tb - 1, -1);
+    float b0 = s0 >= L - 2 ? emit0(cur, 0) : -INFINITY;
+    float b1 = s1 >= L - 2 ? emit1(cur, 0) : -INFINITY;
+    if (act0) be[(int64_t)(Tb - 1) * Lmax + s0] = b0 * LN2;
+    if (act1) be[(int64_t)(Tb - 1) * Lmax + s1] = b1 * LN2;
+    fetch(cur, Tb - 2, -1);
     for (int t0 = Tb - 2; t0 >= 0; t0 -= CH) {
-      float lpb[CH], lpl[CH];
+      fetch(nxt, t0 - CH, -1);
+      float e0[CH], e1[CH];
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        const int t = max(t0 - i, 0);
-        const float z = ls[t];
-        lpb[i] = ld_as_f32<T>(lg + t * ld + blank) - z;
-        lpl[i] = ld_as_f32<T>(lg + t * ld + lab) - z;
+        e0[i] = emit0(cur, i);
+        e1[i] = emit1(cur, i);
       }
+      float* row = be + (int64_t)t0 * Lmax;
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        const int t = t0 - i;
-        if (t < 0) break;  // wave-uniform
-        const float nb0 = __shfl_down(b0, 1);  // beta[t+1][2l+2]
-        const float nb1 = __shfl_down(b1, 1);  // beta[t+1][2l+3]
-        const float m0 = lse3(b0, s0 + 1 < L ? b1 : -INFINITY, -INFINITY);
-        const float m1 = lse3(b1, s1 + 1 < L ? nb0 : -INFINITY, skipn ? nb1 : -INFINITY);
-        b0 = (act0 && m0 != -INFINITY) ? m0 + lpb[i] : -INFINITY;
-        b1 = (act1 && m1 != -INFINITY) ? m1 + lpl[i] : -INFINITY;
-        if (act0) be[(int64_t)t * Lmax + s0] = b0;
-        if (act1) be[(int64_t)t * Lmax + s1] = b1;
+        if (t0 - i < 0) break;  // wave-uniform
+        const float nb0 = wave_from_next(b0);  // beta[t+1][2l+2]  (-inf past the last state)
+        const float nb1 = wave_from_next(b1);  // beta[t+1][2l+3]
+        const float n0 = l2se2(b0, b1) + e0[i];
+        const float n1 = l2se3(b1, nb0, skipn ? nb1 : -INFINITY) + e1[i];
+        b0 = n0;
+        b1 = n1;
+        if (act0) row[s0] = b0 * LN2;
+        if (act1) row[s1] = b1 * LN2;
+        row -= Lmax;
       }
+      cur = nxt;
     }
   }
 }
