@@ -29,6 +29,9 @@
 #include "common.h"
 #include "lds_dma.h"
 
+#ifndef S2T_RB_SPREAD
+#define S2T_RB_SPREAD 1  // LDS-DMA pieces spread over the iteration's MFMA groups (0: all at the head of the iteration)
+#endif
 #ifndef S2T_RB_DBG
 #define S2T_RB_DBG 0  // kernel-experiment switches (tools/rb_dbg_build.sh): 1 no DMA inside the loop, 2 no MFMAs, 4 no E1,
                       // 8 no z / h saves, 16 s_memtime stamps, 32 no L2 warm-up loads
@@ -126,6 +129,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
   const int M = p.M, F = p.F;
   const int nchunks = F / FC;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+#if S2T_RB_DBG & 16
+  const unsigned long long k_t0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long k_t1 = 0, k_t2 = 0;
+#endif
 
   const i32x4 srd1 = make_srd(p.w1, (uint32_t)F * D * 2u);
   const i32x4 srd2 = make_srd(p.w2, (uint32_t)F * D * 2u);
@@ -602,6 +609,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
 #else
 #define STAMP(i)
 #endif
+#if S2T_RB_DBG & 16
+  __builtin_amdgcn_sched_barrier(0);
+  k_t1 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   uint2 zp[2], hp[2];
   {
     f32x4 hacc[2];
@@ -639,6 +651,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
     g1_read(c, 4, a1);
     z_read(c, zn);
     __builtin_amdgcn_sched_barrier(0);
+    // The 8 (SPLIT: 16) LDS-DMA pieces of the iteration are spread over its four MFMA groups: a piece issued into a phase
+    // that already carries the fragment reads and other pieces costs the wave 100+ cycles of issue, one issued behind a
+    // group of MFMAs a fraction of that.  The saves and the warm-up load follow the last piece (they must be the wave's
+    // YOUNGEST vector-memory operations at the closing wait).
+#if S2T_RB_SPREAD
+#if !(S2T_RB_DBG & 1)
+    if (more) {
+      if (dma_wave && S2T_RB_SPREAD != 2) issue_w1_half(c + 1, 0);
+      issue_z(c + 1);
+    }
+#endif
+#else
 #if !(S2T_RB_DBG & 1)
     if (more) {
       issue_w1(c + 1);
@@ -647,11 +671,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
     issue_w2(c);
 #endif
     save(c - 1);
+#endif
 #if !(S2T_RB_DBG & 32)
     const bool pf = c + 2 < nchunks && blockIdx.x < 8;  // one workgroup per XCD group warms the XCD's L2 for all
-    if (pf) l2_prefetch(c + 2);
 #else
     const bool pf = false;
+#endif
+#if !S2T_RB_SPREAD
+    if (pf) l2_prefetch(c + 2);
 #endif
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
@@ -659,13 +686,33 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
     drop_masks(c, ms);
     g1_mma(0, a0, hacc);
     g2_read(c - 1, 0, a0);
+#if S2T_RB_SPREAD && !(S2T_RB_DBG & 1)
+    if (more && dma_wave) {
+      if (S2T_RB_SPREAD == 2) issue_w1_half(c + 1, 0);
+      issue_w1_half(c + 1, 1);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     STAMP(2);
     g1_mma(4, a1, hacc);
     g2_read(c - 1, 4, a1);
+#if S2T_RB_SPREAD && !(S2T_RB_DBG & 1)
+    if (dma_wave) {
+      issue_w2_half(c, 0);
+      if (S2T_RB_SPREAD == 3) issue_w2_half(c, 1);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     STAMP(3);
     g2_mma(0, a0, hb);
+#if S2T_RB_SPREAD
+#if !(S2T_RB_DBG & 1)
+    if (dma_wave && S2T_RB_SPREAD != 3) issue_w2_half(c, 1);
+#endif
+    save(c - 1);
+    if (pf) l2_prefetch(c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     e1(c, hacc, zn, hn, ms);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4);
@@ -688,12 +735,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     STAMP(8);
+#if S2T_RB_DBG & 16
+    if (tid == 0 && p.eln_mean && !p.eln_gamma && (blockIdx.x == 0 || blockIdx.x == 100))
+      (reinterpret_cast<unsigned long long*>(p.eln_mean) + 256 + (blockIdx.x ? 64 : 0))[c] = stamp[8] - stamp[0];
+#endif
   }
 #if S2T_RB_DBG & 16
-  if (lane == 0 && p.eln_mean && !p.eln_gamma && (blockIdx.x == 0 || blockIdx.x == 100)) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.eln_mean) + (blockIdx.x ? 128 : 0) + wave * 16;
-    for (int i = 0; i < 9; ++i) dbg[i] = stamp[i];
-  }
+  __builtin_amdgcn_sched_barrier(0);
+  k_t2 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
 #endif
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");  // the warm-up loads may no longer touch the register
   save(nchunks - 1);
@@ -905,6 +955,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
       }
     }
   }
+#if S2T_RB_DBG & 16
+  if (lane == 0 && p.eln_mean && !p.eln_gamma && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long k_t3 = __builtin_amdgcn_s_memtime(), k_r1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.eln_mean) + (blockIdx.x ? 128 : 0) + wave * 16;
+    for (int i = 0; i < 9; ++i) dbg[i] = stamp[i];
+    dbg[9] = k_t1 - k_t0;
+    dbg[10] = k_t2 - k_t1;
+    dbg[11] = k_t3 - k_t2;
+    dbg[12] = k_r1 - k_r0;
+  }
+#endif
 }
 
 // ===============================================================================================================

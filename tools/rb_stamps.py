@@ -31,7 +31,17 @@ if train:
 for _ in range(3):
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "ffn")
 torch.cuda.synchronize()
-t = dbg.cpu()[:256].view(2, 8, 16)[:, :, :9]
+full = dbg.cpu()[:256].view(2, 8, 16)
+t = full[:, :, :9]
+for blk in range(2):
+    for w in (0, 4):
+        pro, loop, epi, real = (int(full[blk, w, i]) for i in (9, 10, 11, 12))
+        tot = pro + loop + epi
+        print("block %3d wave %d: prologue %6d  loop %6d  epilogue %6d cycles; %d ticks of 100 MHz -> %.0f MHz shader clock, kernel %.1f us"
+              % ([0, 100][blk], w, pro, loop, epi, real, tot / (real / 100.0), real / 100.0))
+per_it = dbg.cpu()[256:384].view(2, 64)[:, :32]
+for blk in range(2):
+    print("block %3d wave 0 cycles per iteration:" % [0, 100][blk], " ".join(str(int(v)) for v in per_it[blk]))
 names = []
 for blk in range(2):
     print("block", [0, 100][blk])
