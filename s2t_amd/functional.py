@@ -611,7 +611,7 @@ def _ln_backward(x, gamma, beta, dy, mean, rstd, lens, T, dres, up_drop):
 
 
 _RB = os.environ.get("S2T_ROWBLOCK", "1") != "0"          # row-block projection kernels (csrc/rowblock.hip)
-_RB_MIN_ROWS = int(os.environ.get("S2T_ROWBLOCK_MIN_ROWS", "8192"))  # 64-row blocks: fewer rows leave CUs idle
+_RB_MIN_ROWS = int(os.environ.get("S2T_ROWBLOCK_MIN_ROWS", "2048"))  # 64-row blocks: fewer rows leave most CUs idle (the decoder's ~3900 rows still gain: one launch instead of LayerNorm + GEMM)
 
 
 def _rb_ok(x, N, act=None):
@@ -925,12 +925,13 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, train, drop_a, drop_o,
-                ln_g=None, ln_b=None, pos_p=None):
+                ln_g=None, ln_b=None, pos_p=None, kv_all=None, kv_slot=None):
         d = xq.shape[1]
         dk = d // H
         dt = xq.dtype
         dev = xq.device
-        self_attn = xkv is None
+        self_attn = xkv is None and kv_all is None
+        ctx.kv_slot = kv_slot if kv_all is not None else None
         Mq, Mk = B * Tq, B * Tk
         ctx.ln = None
         if self_attn:
@@ -957,12 +958,18 @@ class AttentionFn(torch.autograd.Function):
         else:
             q = torch.empty(Mq, d, dtype=dt, device=dev)
             K.gemm(xq, cw(prm["q_w"]), q, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["q_b"].data)
-            wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
-            bkv = fused_master([prm["k_b"], prm["v_b"]], 2 * d)
-            kv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
-            K.gemm(xkv, wkv, kv, M=Mk, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, bias=bkv)
-            k, v = kv, kv[:, d:]
-            ldq, ldk = d, 2 * d
+            if kv_all is not None:  # k | v of every decoder layer were projected by one launch (CrossKVFn): columns of layer l
+                l, L, _ = kv_slot
+                assert _use_fused_attention(dt, dk)
+                k, v = kv_all[:, 2 * d * l:], kv_all[:, 2 * d * l + d:]
+                ldq, ldk = d, 2 * d * L
+            else:
+                wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
+                bkv = fused_master([prm["k_b"], prm["v_b"]], 2 * d)
+                kv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
+                K.gemm(xkv, wkv, kv, M=Mk, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, bias=bkv)
+                k, v = kv, kv[:, d:]
+                ldq, ldk = d, 2 * d
         Z = B * H
         if _use_fused_attention(dt, dk):
             # scores never leave the chip (csrc/attention_fused.hip)
@@ -1062,8 +1069,15 @@ class AttentionFn(torch.autograd.Function):
             dq, dk_, dv = dqkv, dqkv[:, d:], dqkv[:, 2 * d:]
         else:
             dq = torch.empty(Mq, d, dtype=dt, device=dev)
-            dkv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
-            dk_, dv = dkv, dkv[:, d:]
+            if ctx.kv_slot is not None:  # this layer's columns of the stack's shared [Mk, L*2d] gradient (CrossKVFn)
+                l, L, share = ctx.kv_slot
+                if share.get("dkv") is None:
+                    share["dkv"], share["done"] = torch.empty(Mk, 2 * d * L, dtype=dt, device=dev), 0
+                dkv = share["dkv"]
+                dk_, dv = dkv[:, 2 * d * l:], dkv[:, 2 * d * l + d:]
+            else:
+                dkv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
+                dk_, dv = dkv, dkv[:, d:]
         rel = ctx.kind == "rel"
         pt = getattr(ctx, "pos_pt", None) if (rel and _ATTN_DQV_FUSED) else None
         delta = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
@@ -1127,6 +1141,17 @@ class AttentionFn(torch.autograd.Function):
             dxq = torch.empty(Mq, d, dtype=dt, device=dev)
             _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d, 1.0, prm["q_b"].grad)
             K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+            if ctx.kv_slot is not None:
+                # weight and memory gradients of the k | v projections: CrossKVFn.backward, once for the stack.  The layer
+                # that completes the shared buffer hands it on as the gradient of kv_all; the others contribute nothing
+                # autograd would have to add.
+                l, L, share = ctx.kv_slot
+                share["done"] += 1
+                dkv_all = None
+                if share["done"] == L:
+                    dkv_all, share["dkv"], share["done"] = share["dkv"], None, 0
+                _ready(prm["q_w"], prm["q_b"])
+                return (dxq, None, (dres if ctx.has_res else None)) + (None,) * 15 + (dkv_all, None)
             gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
             gb = prm["k_b"].grad.as_strided((2 * d,), (1,))
             wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
@@ -1135,13 +1160,13 @@ class AttentionFn(torch.autograd.Function):
             K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
         if dx_ln is not None:
-            return (dx_ln, None, None) + (None,) * 15
+            return (dx_ln, None, None) + (None,) * 17
         if ctx.ln is not None:
             ln_g, ln_b, up_drop = ctx.ln
             x_pre, ln_mean, ln_rstd = ctx.ln_saved
             dx = _ln_backward(x_pre, ln_g, ln_b, dxq, ln_mean, ln_rstd, None, 0, dres, up_drop)
-            return (dx, None, None) + (None,) * 15
-        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 15
+            return (dx, None, None) + (None,) * 17
+        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 17
 
     @staticmethod
     def backward(ctx, dy):
@@ -1230,7 +1255,7 @@ class AttentionFn(torch.autograd.Function):
             dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
             K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
-        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 15
+        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 17
 
 
 _PT = {}
@@ -1283,8 +1308,55 @@ def project_positions(pos_tab, weights):
     return res
 
 
+_CROSS_KV = os.environ.get("S2T_CROSS_KV", "1") != "0"  # one k | v projection of the encoder memory for the whole decoder
+
+
+class CrossKVFn(torch.autograd.Function):
+    """k | v projections of the encoder output for the encoder-decoder attention of EVERY decoder layer
+    (modules/multihead_attention.py:205-215 with static key / value = encoder_out, once per layer in the reference):
+    kv_all[:, 2d*l : 2d*(l+1)] = mem W_kv,l^T + b_kv,l.  One GEMM with N = L*2d in place of L launches; in the backward the
+    L input gradients (and the L-1 additions autograd would make) are one GEMM with K = L*2d over the layers' shared
+    gradient buffer, which the attention kernels fill column block by column block (AttentionFn, kv_slot)."""
+
+    @staticmethod
+    def forward(ctx, mem, prms):
+        Mk, d = mem.shape
+        L = len(prms)
+        # the layers' [2d, d] weight pairs sit apart in the flat buffer: gather them (L * 256 KiB) into one operand
+        w_all = torch.cat([fused([p["k_w"], p["v_w"]], 2 * d, d) for p in prms], 0)
+        b_all = torch.cat([fused_master([p["k_b"], p["v_b"]], 2 * d) for p in prms], 0)
+        kv_all = torch.empty(Mk, 2 * d * L, dtype=mem.dtype, device=mem.device)
+        K.gemm(mem, w_all, kv_all, M=Mk, N=2 * d * L, K=d, lda=d, ldb=d, ldc=2 * d * L, bias=b_all)
+        ctx.save_for_backward(mem, w_all)
+        ctx.prms = prms
+        return kv_all
+
+    @staticmethod
+    def backward(ctx, dkv_all):
+        mem, w_all = ctx.saved_tensors
+        Mk, d = mem.shape
+        L = len(ctx.prms)
+        for l, prm in enumerate(ctx.prms):
+            gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
+            gb = prm["k_b"].grad.as_strided((2 * d,), (1,))
+            _wgrad(dkv_all[:, 2 * d * l:], mem, gw, 2 * d, d, Mk, 2 * d * L, d, 1.0, gb)
+            _ready(prm["k_w"], prm["v_w"], prm["k_b"], prm["v_b"])
+        dmem = torch.empty(Mk, d, dtype=mem.dtype, device=mem.device)
+        K.gemm(dkv_all, w_all, dmem, M=Mk, N=d, K=2 * d * L, lda=2 * d * L, ldb=d, ldc=d, b_kmajor=True)
+        return dmem, None
+
+
+def cross_kv(mem, prms, H):
+    """(kv_all, share) for ``attention(..., kv=(kv_all, l, L, share))`` of the L decoder layers, or None where the fused
+    attention kernels (which take the strided k / v) do not apply."""
+    d = mem.shape[1]
+    if not (_CROSS_KV and mem.is_cuda and len(prms) > 1 and _use_fused_attention(mem.dtype, d // H) and mem.is_contiguous()):
+        return None
+    return CrossKVFn.apply(mem, prms), {}
+
+
 def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False, kind="abs", pos_tab=None,
-              p_attn=0.0, p_out=0.0, training=False, ln=None, pos_p=None):
+              p_attn=0.0, p_out=0.0, training=False, ln=None, pos_p=None, kv=None):
     """``ln`` = (gamma, beta) of the LayerNorm in front of a SELF-attention block: ``xq`` is then the block input before
     that LayerNorm and doubles as the residual (``residual`` must be None).  Where the row-block projection kernel applies
     the LayerNorm rides in its prologue; otherwise it runs as its own kernel first."""
@@ -1300,6 +1372,11 @@ def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False,
     lg, lb = ln if ln is not None else (None, None)
     if not (kind == "rel" and _use_fused_attention(xq.dtype, xq.shape[1] // H)):
         pos_p = None
+    if kv is not None:  # pre-projected keys / values of the whole decoder stack (cross_kv)
+        kv_all, l, L, share = kv
+        return _tag_drop(AttentionFn.apply(xq, None, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
+                                           torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p, kv_all, (l, L, share)),
+                         drop_o)
     return _tag_drop(AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
                                        torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p), drop_o)
 

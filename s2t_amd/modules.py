@@ -156,12 +156,12 @@ class MultiheadAttention(nn.Module):
         return {"q_w": self.q_proj.weight, "q_b": self.q_proj.bias, "k_w": self.k_proj.weight, "k_b": self.k_proj.bias,
                 "v_w": self.v_proj.weight, "v_b": self.v_proj.bias, "o_w": self.out_proj.weight, "o_b": self.out_proj.bias}
 
-    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False, norm=None):
+    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False, norm=None, kv=None):
         """``norm``: the LayerNorm in front of a self-attention block — ``xq`` is then the un-normalised block input and
-        the residual (pass ``residual=None``)."""
+        the residual (pass ``residual=None``).  ``kv``: keys / values projected for the whole stack (Fn.cross_kv)."""
         return Fn.attention(xq, xkv, residual, self._prm(), self.num_heads, B, Tq, Tk, key_lens, causal, "abs", None,
                             self.attn_dropout, self.out_dropout, self.training,
-                            ln=(norm.weight, norm.bias) if norm is not None else None)
+                            ln=(norm.weight, norm.bias) if norm is not None else None, kv=kv)
 
 
 class RelPositionMultiHeadedAttention(nn.Module):
@@ -488,11 +488,11 @@ class TransformerDecoderLayer(nn.Module):
         return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.activation_fn, 1.0, x,
                       0.0, 0.0, False)
 
-    def forward(self, x, mem, B, U, Tm, self_lens, mem_lens):
+    def forward(self, x, mem, B, U, Tm, self_lens, mem_lens, mem_kv=None):
         y, x = self.self_attn_layer_norm(x, fork=True)
         x = self.self_attn(y, None, x, B, U, U, self_lens, causal=True)
         y, x = self.encoder_attn_layer_norm(x, fork=True)
-        x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens)
+        x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens, kv=mem_kv)
         y, x = self.final_layer_norm(x, fork=True)
         return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
                       self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)

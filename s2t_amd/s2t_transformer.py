@@ -377,8 +377,11 @@ class TransformerDecoderScriptable(nn.Module):
         (mem_lens,) = Fn.batch_memo(("dec_mem_lens", id(self)), (encoder_out["encoder_padding_mask"][0],),
                                     lambda m: ((~m).sum(1).to(torch.int32),))
         # reference (:1340-1342): pad KEYS are masked for every query; pad queries still attend
-        for layer in self.layers:
-            x = layer(x, mem, B, U, Tm, self_lens, mem_lens)
+        # k | v of the encoder memory for all layers' encoder-decoder attention in one projection (Fn.cross_kv)
+        L = len(self.layers)
+        ckv = Fn.cross_kv(mem, [layer.encoder_attn._prm() for layer in self.layers], self.layers[0].encoder_attn.num_heads)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, mem, B, U, Tm, self_lens, mem_lens, mem_kv=(ckv[0], i, L, ckv[1]) if ckv is not None else None)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
         return x.view(B, U, d), {"attn": [None], "inner_states": [], "mixup": None}
