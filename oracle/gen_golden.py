@@ -713,6 +713,56 @@ def main():
         encdec_case("transformer_compress", outdir, "s2t_transformer_s", V=40, B=4, T=90, seed=32,
                     tweak=lambda m: lift_blank(m, float(os.environ.get("BLANK_LIFT", "7.0"))),
                     **dict(small, encoder_layers=4), **dict(comp, ctc_pae="inter_league"))
+        # bf16-comparable variants: the SAME recipe with seeds and a sharpened blank logit chosen so that no frame's blank
+        # log-odds at a compression layer comes closer than MARGIN to the threshold's (eval and training forward alike):
+        # bf16 rounding then moves no frame across the threshold and the compressed tensors stay comparable frame by frame.
+        # (bf16 rounding is RELATIVE, so sharpening the posterior does not help: a frame is at risk when its blank log-odds
+        # lies within a few percent of the spread of the log-odds from the threshold's.  With ~1 % of the frames at risk
+        # per draw, a small batch and a search over seeds finds draws with none.)
+        MB, MT = 2, 48
+
+        def margin_of(seed, tweak, kw):
+            torch.manual_seed(seed)
+            model, args, task = build("s2t_transformer_s", 40, **kw)
+            seed_weights(model, seed + 100)
+            with torch.no_grad():
+                tweak(model)
+            src, lens, prev, target, ntokens = make_batch(MB, MT, 40, seed + 200)
+            worst, kept = 1e9, []
+            for mode in ("eval", "train"):
+                model.train(mode == "train")
+                with torch.no_grad():
+                    enc = model.encoder(src, lens)
+                for il in enc["inter_ctc_logits"]:
+                    logit, mask = il[0].float(), il[1]  # (T, B, V), (B, T)
+                    odds = logit[:, :, 0] - torch.logsumexp(logit[:, :, 1:], dim=-1)  # log p/(1-p); threshold 0.5 <-> 0
+                    valid = ~mask.transpose(0, 1)
+                    o = odds[valid]
+                    worst = min(worst, float(o.abs().min()))
+                    kept.append(float((o < 0).float().mean()))
+            return worst, kept
+
+        MARGIN = 0.45  # |log-odds| >= 0.45: the blank posterior of every frame is outside [0.39, 0.61], >= 0.11 from the threshold
+        for name, base_seed, kwm, lift, train_bn in (
+                ("conformer_compress_margin", 131, dict(**dict(small, encoder_layers=4), **conf, **comp), 3.5, True),
+                ("transformer_compress_margin", 231, dict(**dict(small, encoder_layers=4), **dict(comp, ctc_pae="inter_league")),
+                 7.0, False)):
+            def sharpen(m, lift=lift):
+                m.encoder.ctc.ctc_projection.weight.mul_(4.0)
+                m.encoder.ctc.ctc_projection.bias[0] += lift
+            found = None
+            best = 0.0
+            for seed in range(base_seed, base_seed + 1500):
+                worst, kept = margin_of(seed, sharpen, kwm)
+                ok = all(0.45 < k < 0.96 for k in kept)
+                if ok and worst > best:
+                    best = worst
+                    print(name, "seed", seed, "min |log-odds| %.3f" % worst, "kept", ["%.2f" % k for k in kept], flush=True)
+                if worst >= MARGIN and ok:
+                    found = seed
+                    break
+            assert found is not None, name
+            encdec_case(name, outdir, "s2t_transformer_s", V=40, B=MB, T=MT, seed=found, train_bn=train_bn, tweak=sharpen, **kwm)
     if os.environ.get("GOLDEN_ONLY", "") == "compress":
         return
     if os.environ.get("GOLDEN_ONLY", "") in ("", "nast"):

@@ -20,7 +20,8 @@ from s2t_amd import s2t_transformer as M  # noqa: E402
 
 DEV = "cuda"
 CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small",
-         "conformer_interctc", "conformer_compress", "transformer_compress", "pds_fusion_small"]
+         "conformer_interctc", "conformer_compress", "transformer_compress", "pds_fusion_small",
+         "conformer_compress_margin", "transformer_compress_margin"]
 
 
 def load(golden_dir, name):
@@ -64,9 +65,10 @@ def build(z, dtype, ctc_only=False):
 
 def _skip_bf16_compress(name, dtype):
     if name.endswith("_compress") and dtype == torch.bfloat16:
-        # which frames survive is a hard threshold on a posterior: bf16 logits move some across it, after which the
-        # tensors are no longer comparable frame by frame (kernel-level bf16 coverage: test_kernels_gpu.py)
-        pytest.skip("CTC-guided compression is compared in fp32 only")
+        # which frames survive is a hard threshold on a posterior: these two fixtures put blank posteriors right at it, bf16
+        # logits move some across, after which the tensors are no longer comparable frame by frame.  bf16 compression is
+        # compared on the *_compress_margin fixtures (every posterior >= 0.16 from the threshold), which are not skipped.
+        pytest.skip("threshold-straddling compression fixture: fp32 only (bf16: *_compress_margin)")
 
 
 def bf16_round_npz(z):
@@ -136,6 +138,10 @@ BF16_BOUNDS = {  # measured:              forward  loss     worst gradient tenso
     "sate_small": (2.2e-2, 1e-3, 0.13),           # 0.0109  0.00046  0.064  textual_encoder.layers.0.fc1.weight
     "conformer_interctc": (2.5e-2, 2e-4, 0.53),   # 0.0124  0.00003  0.267  layers.0.conv_module.depthwise_conv.weight (4 layers, d = 32)
     "pds_fusion_small": (1.9e-2, 3e-4, 0.38),     # 0.0093  0.00014  0.190  stage2.0.ffn_norm.bias
+    # CTC-guided compression with every frame's blank posterior >= 0.16 from the threshold (oracle/gen_golden.py searches
+    # the seeds): bf16 rounding moves no frame across it, so the compressed tensors compare frame by frame
+    "conformer_compress_margin": (2.3e-2, 5e-4, 0.23),    # 0.0113  0.00021  0.115  encoder.layers.1.conv_norm.bias
+    "transformer_compress_margin": (1.1e-2, 1e-3, 0.10),  # 0.0052  0.00049  0.049  decoder.layers.0.final_layer_norm.bias
 }
 
 

@@ -9,7 +9,8 @@ import torch
 from oracle import s2t_oracle as O
 
 CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small",
-         "conformer_interctc", "conformer_compress", "transformer_compress", "pds_fusion_small"]
+         "conformer_interctc", "conformer_compress", "transformer_compress", "pds_fusion_small",
+         "conformer_compress_margin", "transformer_compress_margin"]
 
 
 def _load(golden_dir, name):
