@@ -216,7 +216,15 @@ int s2t_fbank(const float* wave, int64_t wave_stride, const int32_t* n_samples, 
               float preemph, int remove_dc, float log_floor, void* stream);
 int s2t_utterance_cmvn(const float* x, float* y, const int32_t* n_frames, int64_t stride_b, int B, int C, int norm_means,
                        int norm_vars, void* stream);
-/* SpecAugment frequency / time masking (data/audio/feature_transforms/specaugment.py:79-131, no time warp), in place on
+/* SpecAugment time warp (data/audio/feature_transforms/specaugment.py:97-112: two cv2.resize(INTER_LINEAR) calls along
+ * time; OpenCV is a third-party dependency absent from the reference tree and this image, its published row mapping is
+ * restated — parity unpinned).  x, y: [B][max_frames][C] fp32, y != x; warp: [B][2] int32 = (w0, w) drawn by the host in
+ * the reference's numpy order, w0 <= 0 = no warp for that utterance; rows >= n_frames[b] are copied.
+ * mean_out (optional, [B]): mean of the un-warped utterance (the fill value of mask_value = None). */
+int s2t_time_warp(const float* x, float* y, const int32_t* n_frames, int64_t stride_b, int B, int max_frames, int C,
+                  const int32_t* warp, float* mean_out, void* stream);
+
+/* SpecAugment frequency / time masking (data/audio/feature_transforms/specaugment.py:114-131; the time warp in front is s2t_time_warp), in place on
  * x [B][stride_b] (rows of C features, first n_frames[b] rows): masks [B][n_freq + n_time][2] int32 = (start, width),
  * frequency intervals first; masked cells := value[b], or the utterance mean when value_is_mean (value is then output). */
 int s2t_specaugment(float* x, const int32_t* n_frames, int64_t stride_b, int B, int max_frames, int C, const int32_t* masks,

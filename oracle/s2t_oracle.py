@@ -710,10 +710,32 @@ def utterance_cmvn(x, norm_means=True, norm_vars=True):
 # ----------------------------------------------------------------------------------------------
 # SpecAugment masking (dataloader stage)
 # ----------------------------------------------------------------------------------------------
-def spec_augment(x, freq_mask_n, freq_mask_f, time_mask_n, time_mask_t, time_mask_p, mask_value, rng=None):
-    """data/audio/feature_transforms/specaugment.py:79-131 (time_warp_W = 0): numpy array (T, C) in, masked copy out.
+def resize_rows_linear(x, new_rows):
+    """cv2.resize(x, dsize=(x.shape[1], new_rows), interpolation=cv2.INTER_LINEAR) for a float32 (rows, cols) array whose
+    column count does not change — PARITY UNPINNED: OpenCV is a third-party dependency (unpinned in the reference's
+    setup.py, absent from /root/reference and from this image), this restates its published algorithm
+    (modules/imgproc/src/resize.cpp, resizeGeneric_ / VResizeLinear): output row dy reads the source coordinate
+    fy = (float)((dy + 0.5) * rows / new_rows - 0.5), rows sy = floor(fy) and sy + 1 clamped into [0, rows), blended in
+    fp32 as src[sy] * (1 - frac) + src[sy + 1] * frac.  With equal column counts the horizontal pass is the identity."""
+    import numpy as np
+    rows = x.shape[0]
+    dy = np.arange(new_rows, dtype=np.float64)
+    fy = ((dy + 0.5) * (float(rows) / float(new_rows)) - 0.5).astype(np.float32)
+    sy = np.floor(fy).astype(np.int64)
+    frac = (fy - sy.astype(np.float32)).astype(np.float32)
+    s0 = np.clip(sy, 0, rows - 1)
+    s1 = np.clip(sy + 1, 0, rows - 1)
+    x = x.astype(np.float32)
+    return (x[s0] * (np.float32(1.0) - frac)[:, None]).astype(np.float32) + (x[s1] * frac[:, None]).astype(np.float32)
+
+
+def spec_augment(x, freq_mask_n, freq_mask_f, time_mask_n, time_mask_t, time_mask_p, mask_value, rng=None, time_warp_w=0):
+    """data/audio/feature_transforms/specaugment.py:79-131: numpy array (T, C) in, augmented copy out.
+    time_warp_w > 0 and 2 * time_warp_w < T: split point w0 in [W, T - W) and shift w in [-W + 1, W) are drawn first, the
+    first w0 frames are resized to w0 + w and the rest to T - w0 - w frames (resize_rows_linear; pinned against the
+    reference's own fixture only for time_warp_w = 0).
     Draw order per mask: width in [0, max), then start in [0, size - width); frequency masks first; the fill value is
-    ``mask_value`` or the mean of the un-masked spectrogram when None; no time masks when
+    ``mask_value`` or the mean of the un-masked, un-warped spectrogram when None; no time masks when
     min(time_mask_T, floor(T * time_mask_p)) < 1; nothing at all when T == 0 or C < freq_mask_F."""
     import numpy as np
     rng = np.random if rng is None else rng
@@ -722,6 +744,10 @@ def spec_augment(x, freq_mask_n, freq_mask_f, time_mask_n, time_mask_t, time_mas
     val = x.mean() if mask_value is None else mask_value
     if T == 0 or C < freq_mask_f:
         return x
+    if time_warp_w > 0 and 2 * time_warp_w < T:
+        w0 = rng.randint(time_warp_w, T - time_warp_w)
+        w = rng.randint(-time_warp_w + 1, time_warp_w)
+        y = np.concatenate((resize_rows_linear(y[:w0], w0 + w), resize_rows_linear(y[w0:], T - w0 - w)), axis=0)
     for _ in range(freq_mask_n):
         f = rng.randint(0, freq_mask_f)
         f0 = rng.randint(0, C - f)

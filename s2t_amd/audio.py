@@ -219,7 +219,8 @@ class SpecAugmentTransform:
     """data/audio/feature_transforms/specaugment.py — SpecAugment frequency and time masking.  The interval draws use
     ``numpy.random`` in exactly the reference's order (per mask: width, then start; frequency masks first), so a seeded
     run masks the same cells; the masking itself runs on the device for the whole batch (``s2t_specaugment``).
-    ``time_warp_W > 0`` (cv2 resize) is not built — the recipes leave it at 0."""
+    ``time_warp_W > 0``: the split point and the shift are drawn first (specaugment.py:101-102), the two linear resizes
+    along time run on the device (``s2t_time_warp``: OpenCV's INTER_LINEAR row mapping restated, cv2 itself is absent)."""
 
     @classmethod
     def from_config_dict(cls, config: Optional[Dict] = None):
@@ -230,8 +231,6 @@ class SpecAugmentTransform:
 
     def __init__(self, time_warp_w=0, freq_mask_n=0, freq_mask_f=0, time_mask_n=0, time_mask_t=0, time_mask_p=0.0,
                  mask_value=0.0):
-        if time_warp_w > 0:
-            raise NotImplementedError("time warping (cv2.resize) is not built on the HIP path")
         if freq_mask_n > 0:
             assert freq_mask_f > 0, f"freq_mask_F ({freq_mask_f}) must be larger than 0 when doing freq masking."
         if time_mask_n > 0:
@@ -243,6 +242,14 @@ class SpecAugmentTransform:
         return (self.__class__.__name__ + f"(time_warp_w={self.time_warp_w}, freq_mask_n={self.freq_mask_n}, "
                 f"freq_mask_f={self.freq_mask_f}, time_mask_n={self.time_mask_n}, time_mask_t={self.time_mask_t}, "
                 f"time_mask_p={self.time_mask_p})")
+
+    def draw_warp(self, num_frames: int, num_freqs: int):
+        """(w0, w) of the time warp for one utterance, (0, 0) when none applies — drawn before the masks."""
+        if num_frames == 0 or num_freqs < self.freq_mask_f or self.time_warp_w <= 0 or 2 * self.time_warp_w >= num_frames:
+            return (0, 0)
+        w0 = np.random.randint(self.time_warp_w, num_frames - self.time_warp_w)
+        w = np.random.randint(-self.time_warp_w + 1, self.time_warp_w)
+        return (int(w0), int(w))
 
     def draw(self, num_frames: int, num_freqs: int):
         """The reference's random draws for one utterance -> (freq intervals, time intervals) as (start, width) lists
@@ -271,17 +278,26 @@ class SpecAugmentTransform:
         assert feat.is_contiguous() and feat.dtype == torch.float32
         B, T, Cf = feat.shape
         nf = n_frames.to(torch.int32)
-        rows = []
+        rows, warps = [], []
         for n in nf.tolist():
+            warps.append(self.draw_warp(int(n), Cf))
             fm, tm = self.draw(int(n), Cf)
             rows.append(fm + tm)
         nm = self.freq_mask_n + self.time_mask_n
+        use_mean = self.mask_value is None
+        value = torch.full((B,), 0.0 if use_mean else float(self.mask_value), dtype=torch.float32, device=feat.device)
+        nf_dev = nf.to(feat.device)
+        if any(w0 > 0 for w0, _ in warps):
+            warped = torch.empty_like(feat)
+            # the fill value of mask_value = None is the mean of the UN-warped utterance (specaugment.py:89-90)
+            K.time_warp(feat, warped, nf_dev, torch.tensor(warps, dtype=torch.int32).view(B, 2).to(feat.device),
+                        mean_out=value if use_mean else None)
+            feat.copy_(warped)
+            use_mean = False
         if nm == 0:
             return feat
         masks = torch.tensor(rows, dtype=torch.int32).view(B, nm, 2).to(feat.device)
-        use_mean = self.mask_value is None
-        value = torch.full((B,), 0.0 if use_mean else float(self.mask_value), dtype=torch.float32, device=feat.device)
-        K.specaugment(feat, nf.to(feat.device), masks, self.freq_mask_n, self.time_mask_n, value, use_mean)
+        K.specaugment(feat, nf_dev, masks, self.freq_mask_n, self.time_mask_n, value, use_mean)
         return feat
 
     def __call__(self, spectrogram):

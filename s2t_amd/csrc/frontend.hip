@@ -147,6 +147,41 @@ __global__ __launch_bounds__(256) void specaug_kernel(float* __restrict__ x, con
   }
 }
 
+// SpecAugment time warp (feature_transforms/specaugment.py:97-112): the first w0 frames are resized to w0 + w frames and the
+// remaining n - w0 to n - w0 - w, each by cv2.resize(..., interpolation=cv2.INTER_LINEAR) along the time axis only (the feature
+// axis keeps its size, so its interpolation is the identity).  OpenCV (third-party, absent here: parity unpinned) maps output
+// row dy of a segment to the source coordinate fy = (float)((dy + 0.5) * src/dst - 0.5), takes rows floor(fy) and floor(fy) + 1
+// clamped into the segment and blends them with weights (1 - frac, frac) in fp32.  warp: [B][2] int32 = (w0, w); w0 <= 0
+// leaves the utterance as it is; rows >= n_frames[b] are copied.
+__global__ __launch_bounds__(256) void time_warp_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const int32_t* __restrict__ n_frames, int64_t stride_b,
+                                                        int max_frames, int C, const int32_t* __restrict__ warp) {
+  const int b = blockIdx.y;
+  const int n = n_frames[b];
+  const int w0 = warp[2 * b], w = warp[2 * b + 1];
+  const float* xb = x + (int64_t)b * stride_b;
+  float* yb = y + (int64_t)b * stride_b;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < (int64_t)max_frames * C; idx += (int64_t)gridDim.x * 256) {
+    const int t = (int)(idx / C), c = (int)(idx % C);
+    if (t >= n || w0 <= 0) {
+      yb[idx] = xb[idx];
+      continue;
+    }
+    int seg0, src, dst, dy;  // source segment [seg0, seg0 + src) -> dst output rows, dy the row inside the output segment
+    if (t < w0 + w) {
+      seg0 = 0; src = w0; dst = w0 + w; dy = t;
+    } else {
+      seg0 = w0; src = n - w0; dst = n - w0 - w; dy = t - (w0 + w);
+    }
+    float fy = (float)(((double)dy + 0.5) * ((double)src / (double)dst) - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int s0 = min(max(sy, 0), src - 1), s1 = min(max(sy + 1, 0), src - 1);
+    const float a = xb[(int64_t)(seg0 + s0) * C + c], bb = xb[(int64_t)(seg0 + s1) * C + c];
+    yb[idx] = __fadd_rn(__fmul_rn(a, 1.0f - fy), __fmul_rn(bb, fy));  // no contraction: the oracle's two products and a sum
+  }
+}
+
 // mean over the first n_frames[b] rows of each utterance (mask_value = None: "use local mean")
 __global__ __launch_bounds__(256) void utt_mean_kernel(const float* __restrict__ x, const int32_t* __restrict__ n_frames,
                                                        int64_t stride_b, int C, float* __restrict__ mean) {
@@ -186,6 +221,19 @@ extern "C" int s2t_utterance_cmvn(const float* x, float* y, const int32_t* n_fra
   if (!x || !y || !n_frames || B <= 0 || C <= 0) return S2T_ERR_ARG;
   hipLaunchKernelGGL(cmvn_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, x, y, n_frames, stride_b, C, norm_means,
                      norm_vars);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_time_warp(const float* x, float* y, const int32_t* n_frames, int64_t stride_b, int B, int max_frames,
+                             int C, const int32_t* warp, float* mean_out, void* stream) {
+  if (!x || !y || x == y || !n_frames || !warp || B <= 0 || C <= 0 || max_frames < 0) return S2T_ERR_ARG;
+  if (max_frames == 0) return S2T_OK;
+  hipStream_t s = (hipStream_t)stream;
+  // (mask_value = None fills with the mean of the spectrogram BEFORE the warp, specaugment.py:89-90)
+  if (mean_out) hipLaunchKernelGGL(utt_mean_kernel, dim3(B), dim3(256), 0, s, x, n_frames, stride_b, C, mean_out);
+  int64_t nb = ((int64_t)max_frames * C + 255) / 256;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(time_warp_kernel, dim3((unsigned)nb, B), dim3(256), 0, s, x, y, n_frames, stride_b, max_frames, C, warp);
   return S2T_LAUNCH_CHECK();
 }
 

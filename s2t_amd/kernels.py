@@ -597,6 +597,14 @@ def utterance_cmvn(x, y, n_frames, norm_means=True, norm_vars=True):
           int(norm_vars))
 
 
+def time_warp(x, y, n_frames, warp, mean_out=None):
+    B, T, Cf = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
+    assert warp.dtype == torch.int32 and warp.shape == (B, 2) and n_frames.dtype == torch.int32
+    L.require_cuda(x, y, n_frames, warp, mean_out)
+    _call("s2t_time_warp", x.data_ptr(), y.data_ptr(), n_frames.data_ptr(), T * Cf, B, T, Cf, warp.data_ptr(), _ptr(mean_out))
+
+
 def specaugment(x, n_frames, masks, n_freq, n_time, value, value_is_mean):
     B, T, Cf = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and masks.dtype == torch.int32 and value.dtype == torch.float32

@@ -120,6 +120,57 @@ def test_oracle_specaugment_matches_reference(golden_dir):
         assert (y != x).any()
 
 
+def test_oracle_time_warp_properties():
+    """The restated INTER_LINEAR row mapping (cv2 is absent: parity unpinned): same size = identity; a ramp stays the same
+    ramp away from the clamped ends (half-pixel centres); the warp keeps the frame count and leaves the feature axis alone."""
+    x = np.random.RandomState(0).randn(50, 7).astype(np.float32)
+    np.testing.assert_array_equal(O.resize_rows_linear(x, 50), x)
+    ramp = np.arange(40, dtype=np.float32)[:, None] * np.ones((1, 3), np.float32)
+    up = O.resize_rows_linear(ramp, 80)
+    np.testing.assert_allclose(up[2:-2, 0], (np.arange(80) + 0.5)[2:-2] * 0.5 - 0.5, rtol=0, atol=1e-5)
+    assert up[0, 0] == 0.0 and up[-1, 0] == 39.0  # clamped, not extrapolated
+    np.random.seed(5)
+    y = O.spec_augment(x, 0, 0, 0, 0, 0.0, 0.0, time_warp_w=8)
+    np.random.seed(5)
+    w0, w = np.random.randint(8, 50 - 8), np.random.randint(-7, 8)
+    assert y.shape == x.shape and w != 0 and (y != x).any()
+    np.testing.assert_array_equal(y[:w0 + w], O.resize_rows_linear(x[:w0], w0 + w))
+    np.testing.assert_array_equal(y[w0 + w:], O.resize_rows_linear(x[w0:], 50 - w0 - w))
+    # T <= 2W: no warp and no draw
+    np.random.seed(5)
+    np.testing.assert_array_equal(O.spec_augment(x[:16], 0, 0, 0, 0, 0.0, 0.0, time_warp_w=8), x[:16])
+
+
+@pytest.mark.gpu
+def test_time_warp_kernel_matches_oracle():
+    from s2t_amd import audio as A
+    rs = np.random.RandomState(3)
+    for T, W, fn, ff, tn, tt, tp, mv in ((137, 5, 2, 27, 2, 40, 0.5, 0.0), (300, 40, 1, 10, 1, 100, 1.0, None), (9, 5, 1, 5, 1, 3, 1.0, 0.0)):
+        x = rs.randn(T, 80).astype(np.float32)
+        tr = A.SpecAugmentTransform(W, fn, ff, tn, tt, tp, mv)
+        np.random.seed(11)
+        got = tr(x)
+        np.random.seed(11)
+        ref = O.spec_augment(x, fn, ff, tn, tt, tp, mv, time_warp_w=W)
+        if mv is None:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)
+        else:
+            np.testing.assert_array_equal(got, ref)
+    # batched, ragged: draws in batch order (warp, then masks, per utterance); padded frames untouched
+    x0 = rs.randn(120, 80).astype(np.float32)
+    feat = torch.zeros(3, 130, 80)
+    lens = [120, 90, 14]
+    for b, n in enumerate(lens):
+        feat[b, :n] = torch.from_numpy(x0[:n])
+    tr = A.SpecAugmentTransform(10, 1, 20, 1, 30, 1.0, 0.0)
+    np.random.seed(2)
+    out = tr.apply_batch(feat.cuda(), torch.tensor(lens)).cpu()
+    np.random.seed(2)
+    for b, n in enumerate(lens):
+        np.testing.assert_array_equal(out[b, :n].numpy(), O.spec_augment(x0[:n], 1, 20, 1, 30, 1.0, 0.0, time_warp_w=10))
+        assert out[b, n:].abs().max() == 0
+
+
 @pytest.mark.gpu
 def test_specaugment_kernel_matches_reference(golden_dir):
     from s2t_amd import audio as A
