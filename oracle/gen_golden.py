@@ -815,6 +815,9 @@ def main():
         encdec_case("pds_fusion_small", outdir, "pdss2t_transformer_s_8", V=40, B=3, T=67, seed=41, train_bn=True,
                     **dict(pds, pds_fusion=True), pds_fusion_method="all_conv2", pds_fusion_layers="0_1_1_1",
                     pds_fusion_weight="0.2_0.3_0.5")
+        # the same with LEARNED fusion weights (no --pds-fusion-weight: nn.Parameter fusion_weight, :799-806)
+        encdec_case("pds_fusion_learned", outdir, "pdss2t_transformer_s_8", V=40, B=3, T=67, seed=43, train_bn=True,
+                    **dict(pds, pds_fusion=True), pds_fusion_method="all_conv2", pds_fusion_layers="0_1_1_1")
     if os.environ.get("GOLDEN_ONLY", "") == "pdsfusion":
         return
     sate = dict(small, text_encoder_layers=2, acoustic_encoder="transformer", adapter="inter_league",

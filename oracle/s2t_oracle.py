@@ -899,7 +899,9 @@ def pds_encoder_forward(src_tokens, src_lengths, W, cfg, training=False, prefix=
         # DownSampleConvolutionModule (modules/downsample_convolution.py:75-123: mask, pointwise conv (bias), depthwise
         # conv kernel = stride = the remaining down-sampling ratio (bias, no padding), BatchNorm, Swish, pointwise conv
         # (bias), mask at floor(len / stride)) -> post LayerNorm; x = sum_i fusion_weight_i * state_i
-        fw = [float(t) for t in str(cfg["pds_fusion_weight"]).split("_")]
+        # fixed weights from --pds-fusion-weight, or the learned parameter fusion_weight (:799-809)
+        fw_cfg = cfg.get("pds_fusion_weight", None)
+        fw = [float(t) for t in str(fw_cfg).split("_")] if fw_cfg not in (None, "None") else W[prefix + "fusion_weight"]
         acc = None
         for n_f, i in enumerate(fusion):
             st = i + 1

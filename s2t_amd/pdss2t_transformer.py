@@ -84,20 +84,21 @@ class PDSS2TTransformerEncoder(nn.Module):
             setattr(self, f"stage{i + 1}", stage)
         # multi-scale representation fusion (pdss2t_transformer.py:357-391,588-640,1187-1233; ``all_conv2``): the flagged
         # stage outputs -> fusion_pre_layer_norm{i} -> DownSampleConvolutionModule down to the last stage's frame rate ->
-        # fusion_post_layer_norm{i}; x = sum_i fusion_weight_i * state_i (fixed weights from --pds-fusion-weight)
+        # fusion_post_layer_norm{i}; x = sum_i fusion_weight_i * state_i (fixed weights from --pds-fusion-weight, or the learned parameter)
         self.fusion_stages = []
         method = str(getattr(args, "pds_fusion_method", "none") or "none")
         if getattr(args, "pds_fusion", False) and method not in ("none", "None"):
             kind, _, transform = method.partition("_")
             if kind != "all" or (transform or "conv") != "conv2":
                 raise NotImplementedError("--pds-fusion-method %s (HIP path: all_conv2)" % method)
-            if getattr(args, "pds_fusion_weight", None) is None:
-                raise NotImplementedError("learned fusion weights (give --pds-fusion-weight)")
             flags = _ints(args.pds_fusion_layers)
             stages = [i for i, f in enumerate(flags) if f]
             if min(self.pds_stages, len(stages)) > 1:
                 self.fusion_stages = stages
-                self.fusion_weight = [float(t) for t in str(args.pds_fusion_weight).split("_")]
+                if getattr(args, "pds_fusion_weight", None) is None:  # learned (:799-806): a parameter, uniform at start
+                    self.fusion_weight = torch.nn.Parameter(torch.full((len(stages),), 1.0 / len(stages)))
+                else:
+                    self.fusion_weight = [float(t) for t in str(args.pds_fusion_weight).split("_")]
                 assert len(self.fusion_weight) == len(stages)
                 self.fusion_mask = bool(getattr(args, "pds_fusion_mask", False))
                 self.fusion_no_prenorm = bool(getattr(args, "pds_fusion_no_prenorm", False))
@@ -156,7 +157,11 @@ class PDSS2TTransformerEncoder(nn.Module):
             states.append((x, Tn, lens32))
         if self.fusion_stages:
             fused = None
-            for wgt, i in zip(self.fusion_weight, self.fusion_stages):
+            learned = isinstance(self.fusion_weight, torch.nn.Parameter)
+            for k, i in enumerate(self.fusion_stages):
+                # (a learned weight is one element of the fp32 parameter: autograd's product rule gives its gradient
+                # <d fused, state_i> and accumulates it into the flat gradient buffer)
+                wgt = self.fusion_weight[k].to(states[i][0].dtype) if learned else self.fusion_weight[k]
                 s_, Ti, li = states[i]
                 if self.fusion_mask:
                     s_ = MaskRows.apply(s_, li, Ti)

@@ -10,7 +10,7 @@ from oracle import s2t_oracle as O
 
 CASES = ["transformer_small", "conformer_small", "conformer_ragged", "pds_small", "pds_conformer_small", "sate_small",
          "conformer_interctc", "conformer_compress", "transformer_compress", "pds_fusion_small",
-         "conformer_compress_margin", "transformer_compress_margin"]
+         "conformer_compress_margin", "transformer_compress_margin", "pds_fusion_learned"]
 
 
 def _load(golden_dir, name):
