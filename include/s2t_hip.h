@@ -172,6 +172,21 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* qv_out,
                        void* stream);
 
+/* Relative-position attention backward, the (Q + pos_bias_v) branch behind s2t_attn_fused_bwd
+ * (espnet_multihead_attention.py:331-337 backward; replaces a batched GEMM over the half-empty skewed dbd rows, the
+ * element-wise add into dq and two column-sum passes):
+ *   dqv[b,i,h,:] = sum_n dbd[h][b][i][n] * p[n][h*64 : h*64+64]  over the band n in [Tq-1-i, 2Tq-2-i] (dbd is zero elsewhere),
+ *   dq[b,i,h,:] += dqv  (bf16, in place; dq_sb / dq_sr = batch / row strides in elements),
+ *   dpos_u[h*64+c] += sum_{b,i} dq_before[b,i,h,c],   dpos_v[h*64+c] += sum_{b,i} dqv[b,i,h,c].
+ * pos_pt: the TRANSPOSED projected positions as s2t_attn_fused_bwd takes them (element (c, n) at pos_pt[(h*64+c)*pt_ld + n],
+ * zeros readable up to n = 2Tq-2+96).  The column sums go to one of `replicas` copies of dpos_u / dpos_v, `replica_stride`
+ * floats apart (1 and 0 to accumulate in place; with the [replicas][2][cols] workspace of s2t_layernorm_fold the adds of the
+ * thousand workgroups no longer serialise on 2 x 64 addresses per head).
+ * bf16, dk == 64, ldb % 8 == 0, 16-byte aligned dbd / pos_pt, 8-byte aligned dq rows. */
+int s2t_relpos_dqv(const void* dbd, int64_t ldb, const void* pos_pt, int64_t pt_ld, void* dq, int64_t dq_sb, int64_t dq_sr,
+                   float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, int B, int H, int Tq, int dk,
+                   void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Grouped weight gradients: all dW[M=Nout][N=Kin] += alpha * dY[K=rows][M]^T @ X[K][N] (bf16 in, fp32 accumulate) of one
  * backward pass in one persistent launch + one reduce launch (csrc/gemm_grouped.hip).  The host cuts the problems into

@@ -798,6 +798,139 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   }
 }
 
+// =====================================================================================================================
+// d(Q + pos_bias_v) of the relative form after the fused backward (espnet_multihead_attention.py:331-337 backward):
+//   dqv[i][c] = sum_n dbd[i][n] * p[n][c]   over the band n in [Tq-1-i, 2Tq-2-i] that dbd holds for query i,
+//   dq += dqv (in place),  dpos_u[h*64+c] += sum_i dq_old[i][c],  dpos_v[h*64+c] += sum_i dqv[i][c].
+// One launch in place of a batched GEMM (K = 2Tq-1 with half of every row zero, N = 64 in 128-wide tiles) and the add +
+// two column sums behind it.  Both operands come straight from global memory as 16-byte fragments — dbd rows (B operand,
+// n = query) and the TRANSPOSED projected positions (A operand, m = channel; project_positions keeps them, zero padded).
+// The kernel waits on memory, not on arithmetic: a workgroup is ONE wave that owns 64 queries (four 16-query tiles) of one
+// (utterance, head) and walks the union of their bands in K-steps of 32 with four steps in flight; the four position
+// fragments of a step serve all four query tiles.  The swapped product leaves lane (x = query, g) with channels
+// 16 nt + 4 g .. +4 of its query: 8-byte read-modify-writes of dq.
+__global__ __launch_bounds__(64) void relpos_dqv_kernel(const bf16_t* __restrict__ dbd, int64_t ldb,
+                                                        const bf16_t* __restrict__ pos_pt, int64_t pt_ld,
+                                                        bf16_t* __restrict__ dq, int64_t dq_sb, int64_t dq_sr,
+                                                        float* __restrict__ du, float* __restrict__ dv, int replicas,
+                                                        int64_t replica_stride, int B, int H, int Tq) {
+  const int lane = threadIdx.x;
+  const int x = lane & 15, g = lane >> 4;
+  const int z = blockIdx.x;
+  const int b = z / H, h = z % H;
+  const int i0 = blockIdx.y * 64;
+  f32x4 acc[4][4];  // [query tile][channel tile]
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[qt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int n_lo = max(Tq - 1 - (i0 + 63), 0) & ~7;
+  const int n_hi = 2 * Tq - 2 - i0;  // last band column of the first query
+  const int steps = (n_hi + 1 - n_lo + 31) / 32;
+  const bf16_t* abase = dbd + (((int64_t)h * B + b) * Tq) * ldb + 8 * g;
+  const bf16_t* prow = pos_pt + ((int64_t)h * DK + x) * pt_ld + 8 * g;
+  // the dq values this lane will update travel during the products
+  uint2 old[4][4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int i = min(i0 + 16 * qt + x, Tq - 1);
+    const bf16_t* qrow = dq + (int64_t)b * dq_sb + (int64_t)i * dq_sr + h * DK + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) old[qt][nt] = *reinterpret_cast<const uint2*>(qrow + 16 * nt);
+  }
+  struct Step {
+    uint4 a[4], p[4];
+  };
+  auto load = [&](int st, Step& t) __attribute__((always_inline)) {
+    const int n = n_lo + 32 * st;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) t.p[nt] = ldg16(prow + (int64_t)(16 * nt) * pt_ld + n);
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int i = i0 + 16 * qt + x;
+      // (columns outside the band of tile qt, still inside the union, hold zeros in dbd)
+      t.a[qt] = (i < Tq && n + 8 * g < ldb) ? ldg16(abase + (int64_t)i * ldb + n) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto mma = [&](const Step& t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[qt][nt] = mfma16(as_frag(t.p[nt]), as_frag(t.a[qt]), acc[qt][nt]);
+  };
+  {
+    Step s0, s1, s2, s3;
+    load(0, s0);
+    if (1 < steps) load(1, s1);
+    if (2 < steps) load(2, s2);
+    for (int st = 0; st < steps; st += 4) {
+      if (st + 3 < steps) load(st + 3, s3);
+      mma(s0);
+      if (st + 4 < steps) load(st + 4, s0);
+      if (st + 1 < steps) mma(s1);
+      if (st + 5 < steps) load(st + 5, s1);
+      if (st + 2 < steps) mma(s2);
+      if (st + 6 < steps) load(st + 6, s2);
+      if (st + 3 < steps) mma(s3);
+    }
+  }
+  float su[4][4], sv[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) su[nt][r] = sv[nt][r] = 0.f;
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int i = i0 + 16 * qt + x;
+    if (i < Tq) {
+      bf16_t* qrow = dq + (int64_t)b * dq_sb + (int64_t)i * dq_sr + h * DK + 4 * g;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const uint2 o = old[qt][nt];
+        const float o4[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u),
+                             __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u)};
+        float n4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          su[nt][r] += o4[r];
+          sv[nt][r] += acc[qt][nt][r];
+          n4[r] = o4[r] + acc[qt][nt][r];
+        }
+        st4_from_f32<bf16_t>(qrow + 16 * nt, n4);
+      }
+    }
+  }
+  // column sums over the wave's queries by lane exchanges, then one atomic per channel
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        su[nt][r] += __shfl_xor(su[nt][r], o, 64);
+        sv[nt][r] += __shfl_xor(sv[nt][r], o, 64);
+      }
+    }
+  // (a thousand workgroups adding to the same 2 x 64 floats of a head serialise in the L2 atomic units — measured: half of
+  // the kernel's time — so the sums are spread over `replicas` copies that a later fold adds up: the LayerNorm
+  // parameter-gradient workspace and its fold kernel serve)
+  // (two atomic instructions with one channel per lane instead of 32 with four live lanes each: the sums change hands in LDS)
+  __shared__ float red[2][DK];
+  if (x == 0) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[0][16 * nt + 4 * g + r] = su[nt][r];
+        red[1][16 * nt + 4 * g + r] = sv[nt][r];
+      }
+  }
+  __syncthreads();
+  const int64_t ro = (int64_t)((blockIdx.x / H + blockIdx.y * 7) % replicas) * replica_stride;
+  atomicAdd(du + ro + h * DK + lane, red[0][lane]);
+  atomicAdd(dv + ro + h * DK + lane, red[1][lane]);
+}
+
 }  // namespace
 
 extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr,
@@ -821,6 +954,18 @@ extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, con
   dim3 grid(B * H, (Tq + 63) / 64), block(256);
   if (a.rel) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_relpos_dqv(const void* dbd, int64_t ldb, const void* pos_pt, int64_t pt_ld, void* dq, int64_t dq_sb,
+                              int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, int B,
+                              int H, int Tq, int dk, void* stream) {
+  if (!dbd || !pos_pt || !dq || !dpos_u || !dpos_v || B <= 0 || H <= 0 || Tq <= 0 || replicas < 1) return S2T_ERR_ARG;
+  if (dk != DK) return S2T_ERR_UNSUPPORTED;
+  if (ldb < 2 * Tq - 1 || ldb % 8 || pt_ld % 8 || dq_sr % 4 || dq_sb % 4) return S2T_ERR_ARG;
+  if (((uintptr_t)dbd % 16) || ((uintptr_t)pos_pt % 16) || ((uintptr_t)dq % 8)) return S2T_ERR_ALIGN;
+  hipLaunchKernelGGL(relpos_dqv_kernel, dim3(B * H, (Tq + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)dbd,
+                     ldb, (const bf16_t*)pos_pt, pt_ld, (bf16_t*)dq, dq_sb, dq_sr, dpos_u, dpos_v, replicas, replica_stride, B, H, Tq);
   return S2T_LAUNCH_CHECK();
 }
 

@@ -1093,7 +1093,19 @@ class AttentionFn(torch.autograd.Function):
                          dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv)
         if rel:
             fuse_glue = dt == torch.bfloat16 and d == 256 and ldq % 8 == 0
-            if pt is None:
+            # the (Q+v) branch, the add into dq and both bias gradients in one band-limited launch (s2t_relpos_dqv) when the
+            # stack kept the transposed projections
+            pt_glue = getattr(ctx, "pos_pt", None) if (pt is None and _RELPOS_DQV and dt == torch.bfloat16 and ldq % 4 == 0) else None
+            if pt_glue is not None:
+                if _arm_backward_end():  # column sums into the replicated workspace, folded with the LayerNorm gradients
+                    ws = _ln_workspace(d, dev)
+                    K.relpos_dqv(dBD, ldB, pt_glue[0], pt_glue[1], dq, Tq * ldq, ldq, ws, ws[d:], B, H, Tq, dk,
+                                 replicas=K.LN_REPLICAS, replica_stride=2 * d)
+                    _LNQ["entries"].append((ws, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), d))
+                else:
+                    K.relpos_dqv(dBD, ldB, pt_glue[0], pt_glue[1], dq, Tq * ldq, ldq, prm["pos_u"].grad.view(-1),
+                                 prm["pos_v"].grad.view(-1), B, H, Tq, dk)
+            elif pt is None:
                 if not fuse_glue:
                     K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
                 dqv = torch.empty(Mq, d, dtype=dt, device=dev)
@@ -1115,7 +1127,7 @@ class AttentionFn(torch.autograd.Function):
             else:
                 K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
                        split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
-            if pt is not None:
+            if pt is not None or pt_glue is not None:
                 pass  # the kernel wrote the complete dq and added both bias gradients
             elif fuse_glue:  # dq += dqv, pos_u.grad += colsum(dq), pos_v.grad += colsum(dqv) in one pass
                 K.add_colsum2(dq, ldq, dqv, d, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), Mq, d)
@@ -1265,6 +1277,10 @@ _PT_OFF = 16  # zero columns in front of position 0 of the transposed projection
 # a longer dependent chain in a kernel that is latency-bound already), more than the 46 us of the GEMM + column-sum launches
 # it replaces (profiles/README.md, r02 notes)
 _ATTN_DQV_FUSED = os.environ.get("S2T_ATTN_DQV_FUSED", "0") == "1"
+# the same branch as ONE launch behind the attention backward kernels (s2t_relpos_dqv: band-limited product from the dBD rows
+# and the transposed projections, dq += dqv and both bias gradients in its epilogue) in place of a batched GEMM over the
+# half-empty dBD rows and the add + column-sum pass
+_RELPOS_DQV = os.environ.get("S2T_RELPOS_DQV", "1") != "0"
 
 
 def project_positions(pos_tab, weights):
@@ -1289,7 +1305,7 @@ def project_positions(pos_tab, weights):
     K.gemm(pos_tab, ws[0], out, M=n_pos, N=d, K=d, lda=d, ldb=d, ldc=d, batch=len(ws), a_s=(0, 0), b_s=(stride, 0),
            c_s=(n_pos * d, 0))
     res = [out[i] for i in range(len(ws))]
-    if torch.is_grad_enabled() and _ATTN_DQV_FUSED:
+    if torch.is_grad_enabled() and (_ATTN_DQV_FUSED or _RELPOS_DQV):
         # the TRANSPOSED projections for the backward kernel (s2t_attn_fused_bwd, pos_pt): [layer][d][PT_OFF + n_pos + pad],
         # zero outside the n_pos valid columns (the buffer is kept per stack: the GEMM rewrites exactly the valid part)
         ld = _pad8(_PT_OFF + n_pos + 96)

@@ -597,6 +597,14 @@ def utterance_cmvn(x, y, n_frames, norm_means=True, norm_vars=True):
           int(norm_vars))
 
 
+def relpos_dqv(dbd, ldb, pos_pt, pt_ld, dq, dq_sb, dq_sr, dpos_u, dpos_v, B, H, Tq, dk, replicas=1, replica_stride=0):
+    L.require_cuda(dbd, pos_pt, dq, dpos_u, dpos_v)
+    assert dbd.dtype == torch.bfloat16 and pos_pt.dtype == torch.bfloat16 and dq.dtype == torch.bfloat16
+    assert dpos_u.dtype == torch.float32 and dpos_v.dtype == torch.float32
+    _call("s2t_relpos_dqv", dbd.data_ptr(), ldb, pos_pt.data_ptr(), pt_ld, dq.data_ptr(), dq_sb, dq_sr, dpos_u.data_ptr(),
+          dpos_v.data_ptr(), replicas, replica_stride, B, H, Tq, dk)
+
+
 def time_warp(x, y, n_frames, warp, mean_out=None):
     B, T, Cf = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype

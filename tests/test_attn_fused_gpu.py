@@ -224,3 +224,40 @@ def test_fused_backward(Tq, Tk, causal, rel, pdrop):
         ref_u, ref_v = qleaf.grad.sum((0, 2)), dqv_ref.sum((0, 2))
         assert (got_u - ref_u).abs().max() <= 2e-2 * ref_u.abs().max() + 1e-4
         assert (got_v - ref_v).abs().max() <= 2e-2 * ref_v.abs().max() + 1e-4
+
+
+@pytest.mark.parametrize("Tq,B,H", [(250, 3, 4), (17, 2, 2), (100, 2, 4), (251, 1, 4), (1004, 1, 2)])
+def test_relpos_dqv(Tq, B, H):
+    """s2t_relpos_dqv against float64: dqv from the band of the skewed dS, the in-place add into (a strided) dq, both bias
+    gradients accumulated on top of what is there."""
+    g = torch.Generator().manual_seed(Tq + H)
+    dk, bf = 64, torch.bfloat16
+    d = H * dk
+    n_pos = 2 * Tq - 1
+    ldb = (n_pos + 7) // 8 * 8
+    # band-only content: row i holds columns Tq-1-i .. 2Tq-2-i, zero elsewhere (what the dQ kernel leaves)
+    dbd = torch.zeros(H, B, Tq, ldb)
+    ii = torch.arange(Tq)[:, None]
+    nn = torch.arange(ldb)[None, :]
+    band = (nn >= Tq - 1 - ii) & (nn <= 2 * Tq - 2 - ii)
+    dbd = torch.where(band[None, None], torch.randn(H, B, Tq, ldb, generator=g) * 0.5, dbd).to(bf)
+    p = (torch.randn(n_pos, d, generator=g) * 0.7).to(bf)
+    off = 16
+    pt_ld = (off + n_pos + 96 + 7) // 8 * 8
+    pt = torch.zeros(d, pt_ld, dtype=bf)
+    pt[:, off:off + n_pos] = p.t()
+    ldq = 3 * d
+    dqkv = (torch.randn(B * Tq, ldq, generator=g) * 0.5).to(bf)
+    du0, dv0 = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    dq_dev, du, dv = dqkv.to(DEV), du0.to(DEV), dv0.to(DEV)
+    pt_dev = pt.to(DEV)
+    K.relpos_dqv(dbd.to(DEV), ldb, pt_dev[:, off:], pt_ld, dq_dev, Tq * ldq, ldq, du, dv, B, H, Tq, dk)
+    torch.cuda.synchronize()
+    # reference
+    dqv = torch.einsum("hbin,nhc->bihc", dbd.double()[..., :n_pos], p.double().view(n_pos, H, dk)).reshape(B * Tq, d)
+    old = dqkv.double()[:, :d]
+    got = dq_dev.cpu().double()
+    np.testing.assert_allclose(got[:, :d].numpy(), (old + dqv).numpy(), rtol=1e-2, atol=2e-2)  # one bf16 rounding of the sum
+    np.testing.assert_array_equal(got[:, d:].numpy(), dqkv.double()[:, d:].numpy())  # k | v columns untouched
+    np.testing.assert_allclose(du.cpu().double().numpy(), (du0.double() + old.sum(0)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(dv.cpu().double().numpy(), (dv0.double() + dqv.sum(0)).numpy(), rtol=1e-4, atol=2e-3)
