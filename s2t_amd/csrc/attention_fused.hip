@@ -188,10 +188,40 @@ __device__ __forceinline__ void load_pfrags(const FusedArgs& a, PFrags& pf, int 
   }
 }
 
-template <bool REL, bool PRE = false>
+// PRE: where the position rows come from — 0 global memory on the spot, 1 the PFrags registers, 2 the workgroup's LDS
+// image of the 128 rows its four waves need (ptile_*; wave w's band tile nt is image tile pblk0 + nt)
+// The 128 position rows the four waves of a (64-query x 64-key) block need — nb3 + (0..127) with nb3 = Tq-1-(q0+63)+k0,
+// wave w's 80 rows start 48 - 16 w further — as ONE workgroup tile: whole 128-byte head slices by coalesced loads (a
+// fragment load straight from global memory is sixteen 64-byte strided requests per instruction, and ten of those per wave
+// and key block were a large part of these kernels), global -> registers -> LDS like the K / V tiles, same LDS layout.
+struct PTile {
+  uint4 v[4];
+};
+__device__ __forceinline__ void ptile_load(const FusedArgs& a, PTile& t, int h, int q0, int k0, int tid) {
+  const int nb3 = a.Tq - 1 - (q0 + 63) + k0;
+  const int nmax = 2 * a.Tq - 2;
+  const bf16_t* pp = a.pos_p + h * DK;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = tid + 256 * u;
+    int n = nb3 + (c >> 3);
+    n = n < 0 ? 0 : (n > nmax ? nmax : n);
+    t.v[u] = ldg16(pp + (int64_t)n * a.p_sr + (c & 7) * 8);
+  }
+}
+__device__ __forceinline__ void ptile_store(char* lp, const PTile& t, int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = tid + 256 * u;
+    const int r = c >> 3, ch = c & 7;
+    *reinterpret_cast<uint4*>(lp + r * 128 + ((ch ^ (r & 7)) << 4)) = t.v[u];
+  }
+}
+
+template <bool REL, int PRE = 0>
 __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& qf, const char* lk, float* scratch,
                                              int h, int q0w, int k0, int klen, int x, int y, f32x4 (&st)[4],
-                                             const PFrags* pre = nullptr) {
+                                             const PFrags* pre = nullptr, const char* lp = nullptr, int pblk0 = 0) {
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -212,7 +242,8 @@ __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& q
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 pf;
-        if constexpr (PRE) pf = as_frag(pre->v[nt][ks]);  // compile-time choice: a load under a run-time test is
+        if constexpr (PRE == 2) pf = frag_rows(lp, pblk0 + nt, ks, x, y);
+        else if constexpr (PRE == 1) pf = as_frag(pre->v[nt][ks]);  // compile-time choice: a load under a run-time test is
         else pf = as_frag(ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8));  // waited for on the spot
         acc = mfma16(pf, qf.qv[ks], acc);
       }
@@ -260,9 +291,10 @@ __device__ __forceinline__ void load_qfrags(const FusedArgs& a, QFrags& qf, int 
 // =====================================================================================================================
 template <bool REL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4];
+  __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4 + (REL ? 16384 : 0)];
   char* lk = lds;
   char* lv = lds + 8192;
+  char* lp = lds + 16384 + 4 * BAND * SC * 4;  // (REL) the block's 128 position rows
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int x = lane & 15, y = lane >> 4;
   float* scratch = reinterpret_cast<float*>(lds + 16384) + w * BAND * SC;
@@ -292,22 +324,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
   TileRegs tk, tv;
   tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
   tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
-  PFrags pnext;  // position rows of the block about to be scored (one register set: re-filled right after its MFMAs)
-  if constexpr (REL) load_pfrags(a, pnext, h, q0w, 0, x, y);
+  PTile tp;  // position rows of the next block (travels like the K / V tiles)
+  if constexpr (REL) ptile_load(a, tp, h, q0, 0, tid);
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
     tile_store(lk, tk, k0, a.Tk, nullptr, tid);
     tile_store(lv, tv, k0, a.Tk, nullptr, tid);
+    if constexpr (REL) ptile_store(lp, tp, tid);
     __syncthreads();
-    if (k0 + KB < kend) {  // next block's K/V in flight during this block's MFMAs
+    if (k0 + KB < kend) {  // next block's K/V (and position rows) in flight during this block's MFMAs
       tile_load(tk, kb, a.k_sr, k0 + KB, a.Tk, tid);
       tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
+      if constexpr (REL) ptile_load(a, tp, h, q0, k0 + KB, tid);
     }
     f32x4 st[4];
-    scores_block<REL, REL>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
-    if constexpr (REL) {  // the next block's position rows travel during this block's softmax and PV product
-      if (k0 + KB < kend) load_pfrags(a, pnext, h, q0w, k0 + KB, x, y);
-    }
+    scores_block<REL, REL ? 2 : 0>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, nullptr, lp, 3 - w);
     // ---- online softmax (row = lane's query; its 16 keys in registers, the other 48 in the 3 other y-groups)
     float mx = -INFINITY;
 #pragma unroll
@@ -379,7 +410,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
 // ---- dQ: workgroup = 64 queries of one (b,h), wave = 16 queries; walks the key blocks ------------------------------
 template <bool REL, bool FUSEV = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4];
+  __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4 + (REL ? 16384 : 0)];
+  char* lp = lds + 16384 + 4 * BAND * SC * 4;  // (REL) the block's 128 position rows (ptile_*)
   char* lk = lds;
   char* lv = lds + 8192;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -470,27 +502,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
   tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
   constexpr bool BAND_ON = REL && !(S2T_ATT_DBG & 4);
-  PFrags pnext;  // position rows of the block about to be scored (one register set: re-filled right after its MFMAs)
+  PTile tp;  // position rows of the next block (travels like the K / V tiles)
   constexpr bool PRE_ON = BAND_ON && !(S2T_ATT_DBG & 128);
-  if constexpr (PRE_ON) load_pfrags(a, pnext, h, q0w, 0, x, y);
+  if constexpr (PRE_ON) ptile_load(a, tp, h, q0, 0, tid);
   ASTAMP();
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
     ASTAMP();
     tile_store(lk, tk, k0, a.Tk, nullptr, tid);
     tile_store(lv, tv, k0, a.Tk, nullptr, tid);
+    if constexpr (PRE_ON) ptile_store(lp, tp, tid);
     __syncthreads();
     ASTAMP();
-    if (k0 + KB < kend) {  // next block's K/V in flight during this block's MFMAs
+    if (k0 + KB < kend) {  // next block's K/V (and position rows) in flight during this block's MFMAs
       tile_load(tk, kb, a.k_sr, k0 + KB, a.Tk, tid);
       tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
+      if constexpr (PRE_ON) ptile_load(a, tp, h, q0, k0 + KB, tid);
     }
     f32x4 st[4];
-    scores_block<BAND_ON, PRE_ON>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, &pnext);
+    scores_block<BAND_ON, PRE_ON ? 2 : 0>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, nullptr, lp, 3 - w);
     ASTAMP();
-    if constexpr (PRE_ON) {  // the next block's position rows travel during this block's softmax and PV product
-      if (k0 + KB < kend) load_pfrags(a, pnext, h, q0w, k0 + KB, x, y);
-    }
     // dP^T[key][q] = V[key] . dO[q]
     f32x4 dpt[4];
 #pragma unroll
@@ -634,7 +665,8 @@ constexpr int SC2 = 36;  // scratch row stride (floats) of the [16 q][32 n] band
 
 template <bool REL>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[3 * 8192 + 4 * 16 * SC2 * 4 + 512];
+  __shared__ __attribute__((aligned(16))) char lds[3 * 8192 + 4 * 16 * SC2 * 4 + 512 + (REL ? 16384 : 0)];
+  char* lp = lds + 3 * 8192 + 4 * 16 * SC2 * 4 + 512;  // (REL) the block's 128 position rows (ptile_*)
   char* lqa = lds;            // q (abs) / q+u (rel)
   char* ldo = lds + 8192;     // dO
   char* lqv = lds + 16384;    // q+v (rel)
@@ -691,33 +723,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   };
   if (qstart < a.Tq) prefetch(qstart);
   // Position rows of a whole 64-query block against this wave's 16 keys: n = nb64 + (0..79), nb64 = Tq-1-(q0+63)+k0w —
-  // the band of query tile qt, position tile nt is tile 3 - qt + nt of these five.  One register set, fetched once per
-  // query block (16 fragment loads on the tiles' critical paths before) and one block ahead of its use.
-  PFrags pfr;
-  auto load_band = [&](int q0) __attribute__((always_inline)) {
-    const int nb64 = a.Tq - 1 - (q0 + 63) + k0w;
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      int n = nb64 + 16 * t + x;
-      n = n < 0 ? 0 : (n > nmax ? nmax : n);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) pfr.v[t][ks] = ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8);
-    }
-  };
+  // the band of query tile qt, position tile nt is tile 3 - qt + nt of these five.  The four waves' bands (16 rows apart)
+  // are one 128-row workgroup tile starting at Tq-1-(q0+63)+k0, staged through LDS like the Q / dO tiles one block ahead
+  // (ptile_*): wave w's tile t is image tile w + t.
+  PTile tp;
   if constexpr (REL) {
-    if (qstart < a.Tq) load_band(qstart);
+    if (qstart < a.Tq) ptile_load(a, tp, h, qstart, k0, tid);
   }
+  (void)pp;
+  (void)nmax;
   for (int q0 = qstart; q0 < a.Tq; q0 += 64) {
     __syncthreads();
     tile_store(lqa, tq, q0, a.Tq, REL ? a.pos_u + h * DK : nullptr, tid);
     tile_store(ldo, tdo, q0, a.Tq, nullptr, tid);
     if (REL) tile_store(lqv, tq, q0, a.Tq, a.pos_v + h * DK, tid);
+    if constexpr (REL) ptile_store(lp, tp, tid);
     if (tid < 64) {
       lse_s[tid] = nlse;
       del_s[tid] = ndel;
     }
     __syncthreads();
-    if (q0 + 64 < a.Tq) prefetch(q0 + 64);  // next query block in flight during this block's MFMAs
+    if (q0 + 64 < a.Tq) {  // next query block (and its position rows) in flight during this block's MFMAs
+      prefetch(q0 + 64);
+      if constexpr (REL) ptile_load(a, tp, h, q0 + 64, k0, tid);
+    }
     float pd[4][4], ds[4][4];  // [q tile][r]: q = q0 + 16qt + 4y + r, key = this lane's
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
@@ -732,7 +761,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
-            acc = mfma16(frag_rows(lqv, qt, ks, x, y), as_frag(pfr.v[3 - qt + nt][ks]), acc);
+            acc = mfma16(frag_rows(lqv, qt, ks, x, y), frag_rows(lp, w + 3 - qt + nt, ks, x, y), acc);
           // lane (x = n index, y) holds q_local = 4y + r
 #pragma unroll
           for (int r = 0; r < 4; ++r) scratch[(4 * y + r) * SC2 + 16 * nt + x] = acc[r];
@@ -762,9 +791,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
         pd[qt][r] = pdrop;
         ds[qt][r] = p * (dp - del_s[ql]) * a.scale;
       }
-    }
-    if constexpr (REL) {  // the next query block's position rows travel during the dK/dV products below
-      if (q0 + 64 < a.Tq) load_band(q0 + 64);
     }
     // dV^T[c][key] += dO^T[c][q] Pd[q][key] ; dK^T[c][key] += qa^T[c][q] dS[q][key]
 #pragma unroll
