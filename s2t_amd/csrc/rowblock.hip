@@ -29,6 +29,9 @@
 #include "common.h"
 #include "lds_dma.h"
 
+#ifndef S2T_RB_SAVE_AUX
+#define S2T_RB_SAVE_AUX 0  // cache-policy bits of the stores of the saves (z, h, dZ): 2 = nt (streaming)
+#endif
 #ifndef S2T_RB_SPREAD
 #define S2T_RB_SPREAD 1  // LDS-DMA pieces spread over the iteration's MFMA groups (0: all at the head of the iteration)
 #endif
@@ -575,13 +578,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
       if constexpr (BWD) {  // 16 bytes of dZ (units 8 pp .. 8 pp + 7 of row rr) into p.h
         const uint2 lo = *reinterpret_cast<const uint2*>(mslot(c, w0, smt, sl));
         const uint2 hi = *reinterpret_cast<const uint2*>(mslot(c, w0 + 4, smt, sl));
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.x, lo.y, hi.x, hi.y}, hsrd, o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.x, lo.y, hi.x, hi.y}, hsrd, o, 0, S2T_RB_SAVE_AUX);
       }
       if constexpr (TRAIN && !(S2T_RB_DBG & 8)) {
         const uint4 lo = *reinterpret_cast<const uint4*>(mslot(c, w0, smt, sl));      // units 8 pp + 0..3: h | z
         const uint4 hi = *reinterpret_cast<const uint4*>(mslot(c, w0 + 4, smt, sl));  // units 8 pp + 4..7
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.z, lo.w, hi.z, hi.w}, zsrd, o, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.x, lo.y, hi.x, hi.y}, hsrd, o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.z, lo.w, hi.z, hi.w}, zsrd, o, 0, S2T_RB_SAVE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){lo.x, lo.y, hi.x, hi.y}, hsrd, o, 0, S2T_RB_SAVE_AUX);
       }
     }
   };
