@@ -199,7 +199,13 @@ def main():
                           dropout=args.dropout, attention_dropout=args.dropout, activation_dropout=args.dropout)
     model = M.S2TTransformerModel.build_model(margs, M.FakeTask(V)).prepare(dtype, dev)
     crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
-    ddp = LegacyDistributedDataParallel(model, process_group=pg, single_rank_collectives=force_ddp) if (world > 1 or force_ddp) else None
+    # gradient buckets travel in the training dtype, as in the reference's --fp16 runs (legacy_distributed_data_parallel.py
+    # all-reduces the fp16 gradients of an fp16 model; the fp32 master copy lives in the optimizer): bf16 here, half the
+    # bytes on the xGMI links.  S2T_DDP_REDUCE=fp32 keeps fp32 buckets.
+    red = os.environ.get("S2T_DDP_REDUCE", "bf16" if dtype == torch.bfloat16 else "fp32")
+    ddp = LegacyDistributedDataParallel(model, process_group=pg, single_rank_collectives=force_ddp,
+                                        reduce_dtype=torch.bfloat16 if red == "bf16" else torch.float32) \
+        if (world > 1 or force_ddp) else None
     trainer = Trainer(model, crit, ddp=ddp)
     sample, frames_local = synthetic_batch(args.batch, args.frames, V, 1 + rank, dev)
     ft = torch.tensor([frames_local, sample["ntokens"]], dtype=torch.float64)

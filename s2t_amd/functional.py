@@ -404,6 +404,7 @@ def reserve_wgrad_staging(device, nbytes=8 << 20, count=1):
 _WG_KSTEPS = int(os.environ.get("S2T_WG_KSTEPS", "64"))  # K-steps (of 64 rows) per work item
 _WG_256 = os.environ.get("S2T_WG_256", "1") != "0"          # s2t_wgrad_grouped256 where the operands allow it
 _WG_KSTEPS256 = int(os.environ.get("S2T_WG_KSTEPS256", "256"))  # its K-steps (of 32 rows) per work item, about (splits are balanced)
+_WG_AUTO = os.environ.get("S2T_WG_AUTO", "1") != "0"  # choose them per launch from the item count (flush_wgrads)
 _WG_DTYPE = None
 
 
@@ -433,6 +434,22 @@ def flush_wgrads():
         big = _WG_256 and all(ldy % 8 == 0 and ldx % 8 == 0 and dY.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0
                               and M * ldy * 2 < 2 ** 31 and M * ldx * 2 < 2 ** 31 for (dY, X, _, _, _, M, ldy, ldx, _, _) in q)
         TL, KS, per_item = (256, 32, _WG_KSTEPS256) if big else (128, 64, _WG_KSTEPS)
+        if big and _WG_AUTO:
+            # K-steps per work item chosen per launch: the items of a launch run in rounds of 512 (two workgroups per CU), so
+            # a data-parallel gradient stage with ~300 items of 250 steps leaves 40 % of the slots idle where 468 items of
+            # 167 steps fill them.  Estimated time = rounds x (longest item + the cost of its partial tile, ~60 steps).
+            best = None
+            for cand in (256, 200, 170, 128, 100, 64):
+                n_items, longest = 0, 0
+                for (_, _, _, Nout, Kin, M, _, _, _, _) in q:
+                    kt = (M + KS - 1) // KS
+                    ns = max(1, (kt + cand // 2) // cand)
+                    n_items += ((Nout + TL - 1) // TL) * ((Kin + TL - 1) // TL) * ns
+                    longest = max(longest, (kt + ns - 1) // ns)
+                cost = ((n_items + 511) // 512) * (longest + 60)
+                if best is None or cost < best[0] * 0.97:  # ties and near-ties go to the larger items (less workspace traffic)
+                    best = (cost, cand)
+            per_item = best[1]
         for i, (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db) in enumerate(q):
             tm_n, tn_n = (Nout + TL - 1) // TL, (Kin + TL - 1) // TL
             ktiles = (M + KS - 1) // KS
