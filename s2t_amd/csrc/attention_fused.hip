@@ -169,27 +169,8 @@ struct QFrags {
   bf16x8 qv[2];   // q+v (rel only)
 };
 
-// the 80 position rows (5 MFMA tiles x 2 k-steps) a (16-query x 64-key) block needs: nbase + (0..79) with
-// nbase = Tq-1-(q0w+15)+k0, clamped.  Loaded from global (L2-resident, shared by every workgroup of a head) one block AHEAD
-// of their use: issued together with a block's MFMAs, their round trip no longer sits on every block's critical path.
-struct PFrags {
-  uint4 v[5][2];
-};
-__device__ __forceinline__ void load_pfrags(const FusedArgs& a, PFrags& pf, int h, int q0w, int k0, int x, int y) {
-  const int nbase = a.Tq - 1 - (q0w + 15) + k0;
-  const int nmax = 2 * a.Tq - 2;
-  const bf16_t* pp = a.pos_p + h * DK;
-#pragma unroll
-  for (int nt = 0; nt < 5; ++nt) {
-    int n = nbase + 16 * nt + x;
-    n = n < 0 ? 0 : (n > nmax ? nmax : n);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) pf.v[nt][ks] = ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8);
-  }
-}
-
-// PRE: where the position rows come from — 0 global memory on the spot, 1 the PFrags registers, 2 the workgroup's LDS
-// image of the 128 rows its four waves need (ptile_*; wave w's band tile nt is image tile pblk0 + nt)
+// PRE: where the position rows come from — 0 global memory on the spot (experiment switch), 2 the workgroup's LDS image of
+// the 128 rows its four waves need (ptile_*; wave w's band tile nt is image tile pblk0 + nt)
 // The 128 position rows the four waves of a (64-query x 64-key) block need — nb3 + (0..127) with nb3 = Tq-1-(q0+63)+k0,
 // wave w's 80 rows start 48 - 16 w further — as ONE workgroup tile: whole 128-byte head slices by coalesced loads (a
 // fragment load straight from global memory is sixteen 64-byte strided requests per instruction, and ten of those per wave
@@ -221,7 +202,7 @@ __device__ __forceinline__ void ptile_store(char* lp, const PTile& t, int tid) {
 template <bool REL, int PRE = 0>
 __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& qf, const char* lk, float* scratch,
                                              int h, int q0w, int k0, int klen, int x, int y, f32x4 (&st)[4],
-                                             const PFrags* pre = nullptr, const char* lp = nullptr, int pblk0 = 0) {
+                                             const char* lp = nullptr, int pblk0 = 0) {
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -242,9 +223,8 @@ __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& q
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 pf;
-        if constexpr (PRE == 2) pf = frag_rows(lp, pblk0 + nt, ks, x, y);
-        else if constexpr (PRE == 1) pf = as_frag(pre->v[nt][ks]);  // compile-time choice: a load under a run-time test is
-        else pf = as_frag(ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8));  // waited for on the spot
+        if constexpr (PRE == 2) pf = frag_rows(lp, pblk0 + nt, ks, x, y);  // compile-time choice: a load under a run-time
+        else pf = as_frag(ldg16(pp + (int64_t)n * a.p_sr + (ks * 4 + y) * 8));  // test is waited for on the spot
         acc = mfma16(pf, qf.qv[ks], acc);
       }
       // lane (x = q, y) holds band rows 16nt + 4y + r
@@ -338,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
       if constexpr (REL) ptile_load(a, tp, h, q0, k0 + KB, tid);
     }
     f32x4 st[4];
-    scores_block<REL, REL ? 2 : 0>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, nullptr, lp, 3 - w);
+    scores_block<REL, REL ? 2 : 0>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, lp, 3 - w);
     // ---- online softmax (row = lane's query; its 16 keys in registers, the other 48 in the 3 other y-groups)
     float mx = -INFINITY;
 #pragma unroll
@@ -520,7 +500,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       if constexpr (PRE_ON) ptile_load(a, tp, h, q0, k0 + KB, tid);
     }
     f32x4 st[4];
-    scores_block<BAND_ON, PRE_ON ? 2 : 0>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, nullptr, lp, 3 - w);
+    scores_block<BAND_ON, PRE_ON ? 2 : 0>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, lp, 3 - w);
     ASTAMP();
     // dP^T[key][q] = V[key] . dO[q]
     f32x4 dpt[4];
