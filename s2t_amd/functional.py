@@ -379,6 +379,24 @@ def grad_stage(x):
     return GradStageFn.apply(x) if (torch.is_grad_enabled() and x.requires_grad) else x
 
 
+# Number of gradient stages of a data-parallel backward pass: 4 = behind the decoder and at each third of the encoder stack,
+# 3 (default) = decoder + upper third | middle third | lower third + front-end, 2 = one cut a third of the stack from the
+# bottom, 1 = none (one grouped launch, every bucket reduced after backward).  More stages start the all-reduce earlier but
+# each grouped launch is less efficient than one (single-rank data-parallel step on the headline configuration: 14.83 /
+# 14.56 / 14.48 / 14.24 ms for 4 / 3 / 2 / 1 stages, same-box alternation); with 60 MB of bf16 gradients per step the last stage's buckets are
+# what stays exposed.
+GRAD_STAGES = int(os.environ.get("S2T_GRAD_STAGES", "3"))
+
+
+def grad_stage_layers(n):
+    """Encoder layer indices in front of which a gradient stage closes in backward (see GradStageFn)."""
+    if n < 6 or GRAD_STAGES <= 1:
+        return set()
+    if GRAD_STAGES == 2:
+        return {n // 3}
+    return {n // 3, (2 * n) // 3}
+
+
 # Deferred, grouped weight gradients (csrc/gemm_grouped.hip): nothing consumes a weight gradient before the optimizer,
 # so the bf16 (dY, X, dW) triples of a backward pass are queued and executed by ONE persistent launch (+ one reduction)
 # from an autograd engine callback at the end of backward.  Operands stay referenced until then.  The parameters'

@@ -188,7 +188,9 @@ class S2TTransformerEncoder(nn.Module):
         n = len(self.layers)
         inter_ctc_logits = []
         ctc_orc = ctc_force_emit = None
-        stage_at = {n // 3, (2 * n) // 3} if n >= 6 else set()  # gradient stages (Fn.grad_stage): a third of the stack each
+        # gradient stages (Fn.grad_stage, data-parallel steps only): where the weight gradients queued so far run and their
+        # buckets start reducing beside the rest of backward (Fn.GRAD_STAGES)
+        stage_at = Fn.grad_stage_layers(n)
         if self.training:  # nn.BatchNorm1d's num_batches_tracked of every conv module: one launch instead of one per layer
             ctrs = [l.conv_module.norm.num_batches_tracked for l in self.layers if getattr(l, "conv_module", None) is not None]
             if ctrs:
@@ -236,7 +238,8 @@ class S2TTransformerEncoder(nn.Module):
                     x = MaskRows.apply(x, lens32, Tp)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
-        x = Fn.grad_stage(x)  # everything behind the encoder output (decoder, CTC head) forms the first gradient stage
+        if Fn.GRAD_STAGES >= 4:
+            x = Fn.grad_stage(x)  # everything behind the encoder output (decoder, CTC head) forms the first gradient stage
         ctc_logit = None
         if self.use_ctc:
             logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype)
