@@ -683,6 +683,26 @@ def _dgrad_ln_backward(dy, first_w, Kd, x_pre, gamma, beta, mean, rstd, lens, T,
     return dx
 
 
+_RB_DGRAD_PLAIN = os.environ.get("S2T_RB_DGRAD_PLAIN", "1") != "0"
+
+
+def _dgrad_rowblock(dy, w_param, Kd):
+    """dx[M, 256] = dy[M, Kd] @ W for a [Kd, 256] weight (attention output projection, pointwise conv 2: Kd = 256) through
+    the row-block dgrad kernel without a LayerNorm behind it, or None when it does not apply (the caller runs s2t_gemm)."""
+    flat = getattr(w_param, "_s2t_flat", None)
+    M = dy.shape[0]
+    if not (_RB_DGRAD_PLAIN and _RB_DGRAD and flat is not None and flat.shadow is not None and dy.dtype == torch.bfloat16
+            and dy.is_contiguous() and dy.shape[1] == Kd and Kd % 256 == 0 and Kd <= 2048 and M >= _RB_MIN_ROWS
+            and (M + 64) * Kd * 2 < 2 ** 32 and _arm_backward_end()):
+        return None
+    if flat not in _BE["flats"]:
+        _BE["flats"].append(flat)
+    wt = transposed(w_param, True, Kd, 256)
+    dx = torch.empty(M, 256, dtype=dy.dtype, device=dy.device)
+    K.rowblock_dgrad(dy, wt, dxn=dx)
+    return dx
+
+
 def _dgrad(dy, w, dx, M, N, Kd, lda, ldb, ldc, alpha=1.0):
     """dx[M, N] = alpha * dy[M, Kd] @ w[Kd, N] (input gradient of a linear layer).  A long reduction over few output tiles —
     the vocabulary projections (K = V = 10 000; M = B*U decoder rows: 32 tiles walking 157 K-steps each took 180 us) and the
@@ -1095,8 +1115,10 @@ class AttentionFn(torch.autograd.Function):
         drop_a, drop_o = ctx.drops
         dres = dy.contiguous()
         dy = _drop_rows(dres, drop_o)
-        dO = torch.empty(Mq, d, dtype=dt, device=dev)
-        K.gemm(dy, cw(prm["o_w"]), dO, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+        dO = _dgrad_rowblock(dy, prm["o_w"], d) if d == 256 else None
+        if dO is None:
+            dO = torch.empty(Mq, d, dtype=dt, device=dev)
+            K.gemm(dy, cw(prm["o_w"]), dO, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
         _wgrad(dy, O, prm["o_w"].grad, d, d, Mq, d, d, 1.0, prm["o_b"].grad)
         _ready(prm["o_w"], prm["o_b"])
         if ctx.self_attn:
@@ -1559,8 +1581,10 @@ class ConvModuleFn(torch.autograd.Function):
         dres = dy.contiguous()
         dy = _drop_rows(dres, ctx.drop_o)
         # pw2 (a's padded rows are zero, so the weight gradient needs no extra mask; dA's are zeroed in bn_act_bwd)
-        dA = torch.empty(M, d, dtype=dt, device=dev)
-        K.gemm(dy, cw(prm["pw2_w"]).view(d, d), dA, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+        dA = _dgrad_rowblock(dy, prm["pw2_w"], d) if d == 256 else None
+        if dA is None:
+            dA = torch.empty(M, d, dtype=dt, device=dev)
+            K.gemm(dy, cw(prm["pw2_w"]).view(d, d), dA, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
         _wgrad(dy, a, prm["pw2_w"].grad.view(d, d), d, d, M, d, d)
         # here dy rows of padded frames must not reach pw2's weight gradient: a is zero there -> contributes nothing
         sums = torch.empty(2 * d, dtype=torch.float32, device=dev)
