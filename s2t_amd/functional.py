@@ -1207,9 +1207,11 @@ class AttentionFn(torch.autograd.Function):
                 K.gemm(dqkv, wqkv, dxq, M=Mq, N=d, K=3 * d, lda=3 * d, ldb=d, ldc=d, b_kmajor=True)
             dxkv = None
         else:
-            dxq = torch.empty(Mq, d, dtype=dt, device=dev)
             _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d, 1.0, prm["q_b"].grad)
-            K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+            dxq = _dgrad_rowblock(dq, prm["q_w"], d) if d == 256 else None
+            if dxq is None:
+                dxq = torch.empty(Mq, d, dtype=dt, device=dev)
+                K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
             if ctx.kv_slot is not None:
                 # weight and memory gradients of the k | v projections: CrossKVFn.backward, once for the stack.  The layer
                 # that completes the shared buffer hands it on as the gradient of kv_all; the others contribute nothing
