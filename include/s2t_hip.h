@@ -542,6 +542,11 @@ typedef struct s2t_rowblock_args {
   const int32_t* row_lens; int32_t row_T;
   const void* residual; int64_t ldr;
   float drop_p; uint32_t drop_site; const uint64_t* drop_seed;
+  /* instead of the LayerNorm (ln_gamma == NULL): x_in = pre_act(x * pre_scale[c] + pre_shift[c]) per column, rows masked by
+   * (ln_lens, ln_T) set to zero — the BatchNorm affine + activation between the depthwise conv and pointwise conv 2
+   * (convolution.py:102-106, s2t_bn_act_fwd's arithmetic); x_ln then receives x_in (the operand of pointwise conv 2's
+   * weight gradient).  pre_act: S2T_ACT_* */
+  const float* pre_scale; const float* pre_shift; int32_t pre_act;
 } s2t_rowblock_args;
 int s2t_rowblock_gemm(const s2t_rowblock_args* args, void* stream);
 

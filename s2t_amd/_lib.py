@@ -105,6 +105,7 @@ class RowblockArgs(C.Structure):
         ("preact", C.c_void_p), ("ldp", C.c_int64), ("out", C.c_void_p), ("ldc", C.c_int64), ("alpha", C.c_float),
         ("row_lens", C.c_void_p), ("row_T", C.c_int32), ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("drop_seed", C.c_void_p),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("pre_act", C.c_int32),
     ]
 
 

@@ -1038,11 +1038,13 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     char* stage = smem + PJ_W + 2 * STAGE;
     const int cch = tid & 31;
     float gm[8], bt[8];
-    if (p.ln_gamma) {
-      const float4 g0 = *reinterpret_cast<const float4*>(p.ln_gamma + 8 * cch);
-      const float4 g1 = *reinterpret_cast<const float4*>(p.ln_gamma + 8 * cch + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(p.ln_beta + 8 * cch);
-      const float4 b1v = *reinterpret_cast<const float4*>(p.ln_beta + 8 * cch + 4);
+    if (p.ln_gamma || p.pre_scale) {
+      const float* pg = p.ln_gamma ? p.ln_gamma : p.pre_scale;
+      const float* pb = p.ln_gamma ? p.ln_beta : p.pre_shift;
+      const float4 g0 = *reinterpret_cast<const float4*>(pg + 8 * cch);
+      const float4 g1 = *reinterpret_cast<const float4*>(pg + 8 * cch + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(pb + 8 * cch);
+      const float4 b1v = *reinterpret_cast<const float4*>(pb + 8 * cch + 4);
       gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
       bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1v.x; bt[5] = b1v.y; bt[6] = b1v.z; bt[7] = b1v.w;
     }
@@ -1094,6 +1096,18 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
             if (p.ln_rstd) p.ln_rstd[m] = rstd;
           }
         }
+      } else if (p.pre_scale) {  // per-column affine + activation (BatchNorm apply), masked rows to zero
+        const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
+        const bool masked = p.ln_lens && m < M && (m % p.ln_T) >= p.ln_lens[m / p.ln_T];
+        uint32_t ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v0 = __uint_as_float(w4[k] << 16) * gm[2 * k] + bt[2 * k];
+          const float v1 = __uint_as_float(w4[k] & 0xffff0000u) * gm[2 * k + 1] + bt[2 * k + 1];
+          ow[k] = masked ? 0u : pack2(act_apply(p.pre_act, v0), act_apply(p.pre_act, v1));
+        }
+        o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        if (m < M && p.x_ln) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.x_ln) + (int64_t)m * D + 8 * cch) = o;
       }
       *reinterpret_cast<uint4*>(stage + rl * 512 + 16 * (cch ^ (rl & 15))) = o;
     }
@@ -1574,7 +1588,10 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   if (glu ? (a->N % 64) : (a->N % 8)) return S2T_ERR_UNSUPPORTED;  // GLU: whole 32-column chunks of value and gate rows
   if (a->preact && !glu) return S2T_ERR_UNSUPPORTED;
   if ((a->ln_gamma != nullptr) != (a->ln_beta != nullptr)) return S2T_ERR_ARG;
-  if ((a->x_ln || a->ln_mean || a->ln_rstd || a->ln_lens) && !a->ln_gamma) return S2T_ERR_ARG;
+  if ((a->pre_scale != nullptr) != (a->pre_shift != nullptr) || (a->pre_scale && a->ln_gamma)) return S2T_ERR_ARG;
+  if ((a->ln_mean || a->ln_rstd) && !a->ln_gamma) return S2T_ERR_ARG;
+  if ((a->x_ln || a->ln_lens) && !a->ln_gamma && !a->pre_scale) return S2T_ERR_ARG;
+  if (a->pre_scale && (((uintptr_t)a->pre_scale % 16) || ((uintptr_t)a->pre_shift % 16))) return S2T_ERR_ALIGN;
   if ((a->ln_lens && a->ln_T <= 0) || (a->row_lens && a->row_T <= 0)) return S2T_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->drop_seed)) return S2T_ERR_ARG;
   if (a->ldc < nout || a->ldc % 8 || (a->residual && (a->ldr < nout || a->ldr % 8)) || (a->preact && (a->ldp < a->N || a->ldp % 8)))

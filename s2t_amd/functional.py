@@ -684,6 +684,7 @@ def _dgrad_ln_backward(dy, first_w, Kd, x_pre, gamma, beta, mean, rstd, lens, T,
 
 
 _RB_DGRAD_PLAIN = os.environ.get("S2T_RB_DGRAD_PLAIN", "1") != "0"
+_BN_IN_PW2 = os.environ.get("S2T_BN_IN_PW2", "1") != "0"  # training BatchNorm apply + activation in pointwise conv 2's prologue
 
 
 def _dgrad_rowblock(dy, w_param, Kd):
@@ -1555,12 +1556,21 @@ class ConvModuleFn(torch.autograd.Function):
             rstd = torch.empty(d, dtype=torch.float32, device=dev)
             K.bn_finalize(stats, M, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
                           momentum, 1e-5, True, scale, shift, mean, rstd, d)
-            K.bn_act_fwd(D, a, scale, shift, act, M, d, lens, T)
         else:  # eval: conv + BatchNorm on the running statistics + activation + mask in one launch
             K.dwconv_bn_eval_fwd(g, wd, a, B, T, d, Kw, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"],
                                  bn_buf["running_var"], 1e-5, act, lens)
         y = torch.empty(M, d, dtype=dt, device=dev)
-        if _rb_ok(a, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1)):
+        rb2 = _rb_ok(a, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1))
+        fused_bn = training and rb2 and _BN_IN_PW2
+        if training and not fused_bn:
+            K.bn_act_fwd(D, a, scale, shift, act, M, d, lens, T)
+        if fused_bn:
+            # the BatchNorm apply + activation + mask ride in pointwise conv 2's prologue, which also writes their result
+            # (the operand of pw2's weight gradient): one launch and one pass over D fewer
+            K.rowblock_gemm(D, cw(prm["pw2_w"]).view(d, d), y, N=d, ldc=d, residual=residual,
+                            ldr=residual.stride(0) if residual is not None else 0, row_lens=lens, row_T=T, drop=drop_o,
+                            pre=(scale, shift, act), ln_lens=lens, ln_T=T, x_ln=a)
+        elif rb2:
             K.rowblock_gemm(a, cw(prm["pw2_w"]).view(d, d), y, N=d, ldc=d, residual=residual,
                             ldr=residual.stride(0) if residual is not None else 0, row_lens=lens, row_T=T, drop=drop_o)
         else:

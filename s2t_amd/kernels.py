@@ -241,8 +241,9 @@ def rowblock_supported(x, N, act=None):
 
 
 def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual=None, ldr=0, preact=None, ldp=0, ln=None,
-                  ln_eps=1e-5, ln_lens=None, ln_T=0, x_ln=None, ln_stats=None, row_lens=None, row_T=0, drop=None):
-    """s2t_rowblock_gemm (include/s2t_hip.h): out = epilogue(LN(x) @ w[:N]^T); ``ln`` = (gamma, beta) or None."""
+                  ln_eps=1e-5, ln_lens=None, ln_T=0, x_ln=None, ln_stats=None, row_lens=None, row_T=0, drop=None, pre=None):
+    """s2t_rowblock_gemm (include/s2t_hip.h): out = epilogue(LN(x) @ w[:N]^T); ``ln`` = (gamma, beta) or None;
+    ``pre`` = (scale, shift, act): a per-column affine + activation in place of the LayerNorm (masked by ln_lens / ln_T)."""
     L.require_cuda(x, w, out, residual, preact, x_ln)
     M, d = x.shape
     a = L.RowblockArgs()
@@ -256,6 +257,13 @@ def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual
         a.x_ln = _ptr(x_ln)
         if ln_stats is not None:
             a.ln_mean, a.ln_rstd = ln_stats[0].data_ptr(), ln_stats[1].data_ptr()
+    elif pre is not None:
+        assert pre[0].dtype == torch.float32 and pre[1].dtype == torch.float32
+        a.pre_scale, a.pre_shift, a.pre_act = pre[0].data_ptr(), pre[1].data_ptr(), L.ACT_IDS[pre[2]]
+        if ln_lens is not None:
+            assert ln_lens.dtype == torch.int32
+            a.ln_lens, a.ln_T = ln_lens.data_ptr(), ln_T
+        a.x_ln = _ptr(x_ln)
     assert w.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
     a.w, a.bias = w.data_ptr(), _ptr(bias)
     a.act = L.ACT_IDS[act]

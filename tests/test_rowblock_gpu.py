@@ -422,3 +422,35 @@ def test_rowblock_gemm_matches_layernorm_plus_gemm(M, N, act, use_ln, mask, res,
         assert float((du != df).float().mean()) < 2e-3
     if act == "glu":
         assert float((z_f.float() - z_u.float()).abs().max() / z_u.float().abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("M,mask,res,p", [(250, True, True, 0.0), (1000, True, True, 0.1), (130, False, False, 0.0)])
+def test_rowblock_gemm_affine_activation_prologue(M, mask, res, p):
+    """pre = (scale, shift, act): the BatchNorm apply + activation + mask in the prologue must give what s2t_bn_act_fwd
+    followed by the plain row-block projection gives — the staged tile (x_ln), the output and its dropout mask."""
+    g = torch.Generator().manual_seed(M)
+    d, T = 256, 125 if M % 125 == 0 else M
+    B = M // T
+    D = torch.randn(M, d, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(d, d, generator=g) * d ** -0.5).bfloat16().to(DEV)
+    scale = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV)
+    shift = (0.3 * torch.randn(d, generator=g)).to(DEV)
+    lens = torch.tensor([T - 3 * b for b in range(B)], dtype=torch.int32, device=DEV) if mask else None
+    resid = torch.randn(M, d, generator=g).bfloat16().to(DEV) if res else None
+    seed = torch.tensor([77], dtype=torch.int64, device=DEV)
+    drop = (p, seed, 9) if p > 0 else None
+    a_ref = torch.empty_like(D)
+    K.bn_act_fwd(D, a_ref, scale, shift, "swish", M, d, lens, T)
+    y_ref = torch.empty_like(D)
+    K.rowblock_gemm(a_ref, w, y_ref, N=d, ldc=d, residual=resid, ldr=d, row_lens=lens, row_T=T, drop=drop)
+    a = torch.full_like(D, float("nan"))
+    y = torch.empty_like(D)
+    K.rowblock_gemm(D, w, y, N=d, ldc=d, residual=resid, ldr=d, row_lens=lens, row_T=T, drop=drop,
+                    pre=(scale, shift, "swish"), ln_lens=lens, ln_T=T, x_ln=a)
+    torch.cuda.synchronize()
+    # the activation is evaluated by the same device function in both kernels; allow one bf16 ulp for contraction differences
+    torch.testing.assert_close(a.float(), a_ref.float(), rtol=8e-3, atol=1e-3)
+    torch.testing.assert_close(y.float(), y_ref.float(), rtol=2e-2, atol=2e-2)
+    if drop is not None:  # the same elements are dropped (residual-only values survive there)
+        base = resid.float() if res else torch.zeros_like(y.float())
+        assert ((y.float() == base) == (y_ref.float() == base)).all()
