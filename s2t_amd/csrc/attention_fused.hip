@@ -683,8 +683,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   }
   const bf16_t* qb = a.q + (int64_t)b * a.q_sb + h * DK;
   const bf16_t* dob = a.dO + (int64_t)b * a.o_sb + h * DK;
-  const bf16_t* pp = REL ? a.pos_p + h * DK : nullptr;
-  const int nmax = 2 * a.Tq - 2;
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
@@ -710,8 +708,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   if constexpr (REL) {
     if (qstart < a.Tq) ptile_load(a, tp, h, qstart, k0, tid);
   }
-  (void)pp;
-  (void)nmax;
   for (int q0 = qstart; q0 < a.Tq; q0 += 64) {
     __syncthreads();
     tile_store(lqa, tq, q0, a.Tq, REL ? a.pos_u + h * DK : nullptr, tid);
