@@ -238,15 +238,17 @@ __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& q
       for (int r = 0; r < 4; ++r) st[kt][r] += scratch[(15 - x + 16 * kt + 4 * y + r) * SC + x];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  // (bitwise predicates and a select: with short-circuit conditions the compiler builds an exec-mask branch per element,
+  // 16 per block and wave)
   const int i = q0w + x;
+  const int jlim = a.causal ? min(klen, i + 1) : klen;  // keys j >= jlim are masked for this lane's query
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = k0 + 16 * kt + 4 * y + r;
-      float s = st[kt][r] * a.scale;
-      if (j >= klen || (a.causal && j > i)) s = -INFINITY;
-      st[kt][r] = s;
+      const float s = st[kt][r] * a.scale;
+      st[kt][r] = j >= jlim ? -INFINITY : s;
     }
 }
 
@@ -328,14 +330,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
-    const float alpha = (mn == -INFINITY) ? 1.f : __expf(m - mn);
+    // branch-free: exp(-inf) = 0 covers masked keys and the first block (m = -inf: alpha = 0 scales l = 0 and O = 0); a row
+    // that has seen no valid key yet (mn = -inf) subtracts 0 instead
+    const float mref = (mn == -INFINITY) ? 0.f : mn;
+    const float alpha = __expf(m - mref);
     float rs = 0.f;
     float pr[4][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = (mn == -INFINITY) ? 0.f : __expf(st[kt][r] - mn);
+        const float p = __expf(st[kt][r] - mref);
         rs += p;
         pr[kt][r] = p;
       }
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       dpt[kt] = acc;
     }
     const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)ic) * (uint64_t)a.Tk;
+    const float lse_ref = (lse_i == -INFINITY) ? 0.f : lse_i;  // a row without a valid key: every p is exp(-inf - 0) = 0
     float ds[4][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       if (a.drop_p > 0.f) s2t_rand_run<4>(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), r16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = (st[kt][r] == -INFINITY) ? 0.f : __expf(st[kt][r] - lse_i);
+        const float p = __expf(st[kt][r] - lse_ref);  // masked keys: exp(-inf) = 0, no branch per element
         float dp = dpt[kt][r];
         if (a.drop_p > 0.f) dp = r16[r] >= dth ? dp * dinv : 0.f;
         ds[kt][r] = p * (dp - del_i) * a.scale;
@@ -587,10 +593,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       float rowv[16];
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) rowv[rr] = scratch[rr * DSS + lane];
-      bf16_t* rowp = a.dbd + (((int64_t)h * a.B + b) * a.Tq + q0w) * a.ldb + (a.Tq - 1 - q0w + jj);
+      // buffer stores into the (h, b) slab: a lane without an element gets an out-of-range offset, which the hardware
+      // drops — no exec-mask branch per row (16 per block and wave before)
+      const __amdgpu_buffer_rsrc_t dsrd = __builtin_amdgcn_make_buffer_rsrc(
+          a.dbd + ((int64_t)h * a.B + b) * a.Tq * a.ldb, 0, (int)((int64_t)a.Tq * a.ldb * 2), 0x00020000);
+      const bool jok = jj < a.Tk;
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr)
-        if (q0w + rr < a.Tq && jj < a.Tk) rowp[(int64_t)rr * (a.ldb - 1)] = f2bf(rowv[rr]);
+      for (int rr = 0; rr < 16; ++rr) {
+        const int ii = q0w + rr;
+        const uint32_t off = (jok && ii < a.Tq) ? (uint32_t)(((int64_t)ii * a.ldb + (a.Tq - 1 - ii + jj)) * 2) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(rowv[rr]), dsrd, off, 0, 0);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
@@ -756,7 +769,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
         const int ql = 16 * qt + 4 * y + r;
         const int i = q0 + ql;
         const bool ok = key_ok && i < a.Tq && !(a.causal && j > i);
-        const float p = ok ? __expf(s4[r] * a.scale - lse_s[ql]) : 0.f;
+        const float p = __expf(ok ? s4[r] * a.scale - lse_s[ql] : -INFINITY);  // select on the argument, no branch
         float dp = dp4[r];
         float pdrop = p;
         if (a.drop_p > 0.f) {
