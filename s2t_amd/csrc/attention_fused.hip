@@ -764,12 +764,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
       f32x4 dp4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) dp4 = mfma16(frag_rows(ldo, qt, ks, x, y), vf[ks], dp4);
+      // the row statistics of this lane's four queries: one 16-byte LDS read each, BEFORE the per-element code (left to the
+      // compiler they end up as a 4-byte read + wait inside an exec-mask branch per element)
+      const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * y);
+      const f32x4 del4 = *reinterpret_cast<const f32x4*>(del_s + 16 * qt + 4 * y);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = 16 * qt + 4 * y + r;
         const int i = q0 + ql;
-        const bool ok = key_ok && i < a.Tq && !(a.causal && j > i);
-        const float p = __expf(ok ? s4[r] * a.scale - lse_s[ql] : -INFINITY);  // select on the argument, no branch
+        const bool ok = key_ok & (i < a.Tq) & !((a.causal != 0) & (j > i));
+        const float p = __expf(ok ? s4[r] * a.scale - lse4[r] : -INFINITY);  // select on the argument, no branch
         float dp = dp4[r];
         float pdrop = p;
         if (a.drop_p > 0.f) {
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
           pdrop = keep ? p * dinv : 0.f;
         }
         pd[qt][r] = pdrop;
-        ds[qt][r] = p * (dp - del_s[ql]) * a.scale;
+        ds[qt][r] = p * (dp - del4[r]) * a.scale;
       }
     }
     // dV^T[c][key] += dO^T[c][q] Pd[q][key] ; dK^T[c][key] += qa^T[c][q] dS[q][key]
