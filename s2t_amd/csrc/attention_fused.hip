@@ -865,11 +865,15 @@ __global__ __launch_bounds__(64) void relpos_dqv_kernel(const bf16_t* __restrict
     const int n = n_lo + 32 * st;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) t.p[nt] = ldg16(prow + (int64_t)(16 * nt) * pt_ld + n);
+    // (columns outside the band of tile qt, still inside the union, hold zeros in dbd; rows / columns past the end: the load
+    // goes to a clamped address and the value is replaced — a load under a per-lane condition becomes an exec-mask branch)
+    const int nc = min(n, (int)ldb - 8 - 8 * g);
+    const bool col_ok = n + 8 * g < ldb;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const int i = i0 + 16 * qt + x;
-      // (columns outside the band of tile qt, still inside the union, hold zeros in dbd)
-      t.a[qt] = (i < Tq && n + 8 * g < ldb) ? ldg16(abase + (int64_t)i * ldb + n) : make_uint4(0, 0, 0, 0);
+      const uint4 v = ldg16(abase + (int64_t)min(i, Tq - 1) * ldb + nc);
+      t.a[qt] = (col_ok && i < Tq) ? v : make_uint4(0, 0, 0, 0);
     }
   };
   auto mma = [&](const Step& t) __attribute__((always_inline)) {
