@@ -563,6 +563,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
   Chunk cur, nxt;
   if (blockIdx.y == 0) {
     float* al = alpha + row0 * Lmax;
+    const __amdgpu_buffer_rsrc_t asrd = __builtin_amdgcn_make_buffer_rsrc(al, 0, (int)((int64_t)T_ * Lmax * 4), 0x00020000);
     fetch(cur, 0, 1);
     float a0 = lane == 0 ? emit0(cur, 0) : -INFINITY;
     float a1 = lane == 0 ? emit1(cur, 0) : -INFINITY;
@@ -577,18 +578,21 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
         e0[i] = emit0(cur, i);
         e1[i] = emit1(cur, i);
       }
-      float* row = al + (int64_t)t0 * Lmax;
+      // (a wave-uniform `if` per step, not a `break`: the loop then unrolls completely and e0 / e1 stay in fixed registers;
+      // the two stores of a step are bounds-checked buffer stores — a lane without the state gets an out-of-range offset —
+      // instead of two exec-mask branches)
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        if (t0 + i >= Tb) break;  // wave-uniform
-        const float p1 = wave_from_prev(a1);  // alpha[t-1][2l-1]
-        const float n0 = l2se2(a0, p1) + e0[i];
-        const float n1 = l2se3(a1, a0, skip ? p1 : -INFINITY) + e1[i];
-        a0 = n0;
-        a1 = n1;
-        if (act0) row[s0] = a0 * LN2;
-        if (act1) row[s1] = a1 * LN2;
-        row += Lmax;
+        if (t0 + i < Tb) {
+          const float p1 = wave_from_prev(a1);  // alpha[t-1][2l-1]
+          const float n0 = l2se2(a0, p1) + e0[i];
+          const float n1 = l2se3(a1, a0, skip ? p1 : -INFINITY) + e1[i];
+          a0 = n0;
+          a1 = n1;
+          const uint32_t ro = (uint32_t)(t0 + i) * (uint32_t)(Lmax * 4);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, a0 * LN2), asrd, act0 ? ro + 4u * s0 : 0xFFFFFFFFu, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, a1 * LN2), asrd, act1 ? ro + 4u * s1 : 0xFFFFFFFFu, 0, 0);
+        }
       }
       cur = nxt;
     }
@@ -597,6 +601,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
     if (lane == 0) nll_out[b] = -(l2se2(l1, l2) * LN2);
   } else {
     float* be = beta + row0 * Lmax;
+    const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(be, 0, (int)((int64_t)T_ * Lmax * 4), 0x00020000);
     fetch(cur, Tb - 1, -1);
     float b0 = s0 >= L - 2 ? emit0(cur, 0) : -INFINITY;
     float b1 = s1 >= L - 2 ? emit1(cur, 0) : -INFINITY;
@@ -611,19 +616,19 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
         e0[i] = emit0(cur, i);
         e1[i] = emit1(cur, i);
       }
-      float* row = be + (int64_t)t0 * Lmax;
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        if (t0 - i < 0) break;  // wave-uniform
-        const float nb0 = wave_from_next(b0);  // beta[t+1][2l+2]  (-inf past the last state)
-        const float nb1 = wave_from_next(b1);  // beta[t+1][2l+3]
-        const float n0 = l2se2(b0, b1) + e0[i];
-        const float n1 = l2se3(b1, nb0, skipn ? nb1 : -INFINITY) + e1[i];
-        b0 = n0;
-        b1 = n1;
-        if (act0) row[s0] = b0 * LN2;
-        if (act1) row[s1] = b1 * LN2;
-        row -= Lmax;
+        if (t0 - i >= 0) {
+          const float nb0 = wave_from_next(b0);  // beta[t+1][2l+2]  (-inf past the last state)
+          const float nb1 = wave_from_next(b1);  // beta[t+1][2l+3]
+          const float n0 = l2se2(b0, b1) + e0[i];
+          const float n1 = l2se3(b1, nb0, skipn ? nb1 : -INFINITY) + e1[i];
+          b0 = n0;
+          b1 = n1;
+          const uint32_t ro = (uint32_t)(t0 - i) * (uint32_t)(Lmax * 4);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, b0 * LN2), bsrd, act0 ? ro + 4u * s0 : 0xFFFFFFFFu, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, b1 * LN2), bsrd, act1 ? ro + 4u * s1 : 0xFFFFFFFFu, 0, 0);
+        }
       }
       cur = nxt;
     }
