@@ -700,6 +700,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
 
+  const bool fast_mask = (a.Tk & 1) == 0 && (uint64_t)a.B * a.H * (uint64_t)a.Tq * (uint64_t)(a.Tk >> 1) < (1ull << 32);
   const int qstart = a.causal ? (k0 / 64) * 64 : 0;  // queries before the key block see none of its keys
   TileRegs tq, tdo;
   float nlse = 0.f, ndel = 0.f;
@@ -769,6 +770,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
       const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * y);
       const f32x4 del4 = *reinterpret_cast<const f32x4*>(del_s + 16 * qt + 4 * y);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // dropout bits of this lane's four (query, key) elements.  One 32-bit hash serves the two elements of an even/odd key
+      // pair of a query row; this lane holds ONE key and four queries, so lanes x and x ^ 1 (the two keys of a pair) each
+      // hash one query of a pair of queries and swap: two hashes per lane and query tile instead of four, in 32-bit index
+      // arithmetic (the general form, one 64-bit-indexed hash per element, serves odd Tk and index spaces beyond 2^32)
+      uint32_t rbits[4] = {65535u, 65535u, 65535u, 65535u};
+      if (a.drop_p > 0.f) {
+        if (fast_mask) {
+#pragma unroll
+          for (int rb = 0; rb < 4; rb += 2) {
+            const int im = min(q0 + 16 * qt + 4 * y + rb + (x & 1), a.Tq - 1);
+            const uint32_t pair = ((uint32_t)z * (uint32_t)a.Tq + (uint32_t)im) * (uint32_t)(a.Tk >> 1) + (uint32_t)(jc >> 1);
+            const uint32_t hm = s2t_mix32(pair ^ (uint32_t)dkey) ^ (uint32_t)(dkey >> 32);
+            const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]: lane x ^ 1
+            const uint32_t h0 = (x & 1) ? ho : hm, h1 = (x & 1) ? hm : ho;  // hashes of queries rb, rb + 1
+            rbits[rb] = (jc & 1) ? (h0 >> 16) : (h0 & 0xffffu);
+            rbits[rb + 1] = (jc & 1) ? (h1 >> 16) : (h1 & 0xffffu);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = q0 + 16 * qt + 4 * y + r;
+            rbits[r] = s2t_rand_u32(dkey, ((uint64_t)z * a.Tq + (uint64_t)min(i, a.Tq - 1)) * (uint64_t)a.Tk + jc);
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = 16 * qt + 4 * y + r;
@@ -778,7 +804,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
         float dp = dp4[r];
         float pdrop = p;
         if (a.drop_p > 0.f) {
-          const bool keep = s2t_rand_u32(dkey, ((uint64_t)z * a.Tq + (uint64_t)min(i, a.Tq - 1)) * (uint64_t)a.Tk + jc) >= dth;
+          const bool keep = rbits[r] >= dth;
           dp = keep ? dp * dinv : 0.f;
           pdrop = keep ? p * dinv : 0.f;
         }
