@@ -18,9 +18,9 @@ DEV = "cuda"
 V = 61
 
 
-def _model(seed):
+def _model(seed, enc_layers=2):
     torch.manual_seed(seed)
-    args = M.recipe_args(conformer=True, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_layers=2, decoder_layers=1,
+    args = M.recipe_args(conformer=True, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_layers=enc_layers, decoder_layers=1,
                          decoder_embed_dim=128, decoder_ffn_embed_dim=256, encoder_attention_heads=2,
                          decoder_attention_heads=2, subsampling_filter=96, vocab_size=V, dropout=0.1,
                          attention_dropout=0.1, activation_dropout=0.1)
@@ -42,9 +42,9 @@ def _sample():
             "target": target.to(DEV), "ntokens": int((target != 1).sum())}
 
 
-def _run(mode, steps=4):
+def _run(mode, steps=4, enc_layers=2):
     from s2t_amd import functional as Fn
-    model = _model(5)
+    model = _model(5, enc_layers)
     crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
     ddp = None
     if mode in ("ddp_graph", "ddp_eager", "ddp_graph_bf16"):
@@ -98,6 +98,21 @@ def test_graph_and_ddp_graph_follow_the_eager_trajectory():
     assert (pe - pb).abs().max() <= 1e-3 * pe.abs().max()
     for a, b in zip(le[3:], lb[3:]):
         assert abs(a - b) <= 2e-3 * abs(a), (le, lb)
+
+
+@pytest.mark.parametrize("stages", [1, 2, 3, 4])
+def test_gradient_stage_counts_walk_the_same_trajectory(stages, monkeypatch):
+    """S2T_GRAD_STAGES: however many grouped weight-gradient launches a data-parallel backward pass is cut into (six encoder
+    layers: cuts in front of layers 2 and 4, plus the one behind the decoder at 4), the captured data-parallel step must end
+    where the single-launch eager step ends."""
+    from s2t_amd import functional as Fn
+    le, pe = _run("eager", enc_layers=6)
+    monkeypatch.setattr(Fn, "GRAD_STAGES", stages)
+    ld, pd = _run("ddp_graph", enc_layers=6)
+    Comm.destroy()
+    for a, b in zip(le[3:], ld[3:]):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, ld)
+    assert (pe - pd).abs().max() <= 1e-3 * pe.abs().max()
 
 
 def _sample2():
