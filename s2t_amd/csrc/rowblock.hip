@@ -761,6 +761,20 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
   }
   __syncthreads();
 
+  // the residual rows of this thread's epilogue passes travel during the LDS exchange below (issued inside the pass loop they
+  // were one global round trip per pass): thread (wave, hi, s) handles rows 8 wave + 2 ps + hi, columns 4s.. and 128 + 4s..
+  uint2 rpre[4][2];
+  if constexpr (!BWD) {
+    if (p.residual) {
+      const bf16_t* Rp = reinterpret_cast<const bf16_t*>(p.residual);
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int mc = min(row0 + 8 * wave + 2 * ps + (lane >> 5), M - 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rpre[ps][q] = *reinterpret_cast<const uint2*>(Rp + (int64_t)mc * D + 128 * q + 4 * (lane & 31));
+      }
+    }
+  }
   // ---- partial sums of the two hidden halves meet in LDS: region fh, fp32 [64 rows][256], 16-byte chunk cc of row m at
   // m*1024 + 16*(cc ^ (m & 7))
 #pragma unroll
@@ -886,7 +900,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
         return;
       }
     }
-#pragma unroll 2
+#pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int ml = 8 * wave + 2 * ps + hi;
       const int m = row0 + ml;
@@ -910,9 +924,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
           for (int r = 0; r < 4; ++r) v[q][r] *= p.alpha;
         }
         if (R) {
-          const int mc = live ? m : M - 1;
           float rr[4];
-          ld4_as_f32<bf16_t>(R + (int64_t)mc * D + 128 * q + 4 * s, rr);
+          if constexpr (BWD) {
+            const int mc = live ? m : M - 1;
+            ld4_as_f32<bf16_t>(R + (int64_t)mc * D + 128 * q + 4 * s, rr);
+          } else {
+            const uint2 t = rpre[ps][q];
+            rr[0] = __uint_as_float(t.x << 16); rr[1] = __uint_as_float(t.x & 0xffff0000u);
+            rr[2] = __uint_as_float(t.y << 16); rr[3] = __uint_as_float(t.y & 0xffff0000u);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[q][r] += rr[r];
         }
