@@ -764,6 +764,25 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
   // the residual rows of this thread's epilogue passes travel during the LDS exchange below (issued inside the pass loop they
   // were one global round trip per pass): thread (wave, hi, s) handles rows 8 wave + 2 ps + hi, columns 4s.. and 128 + 4s..
   uint2 rpre[4][2];
+  uint2 xpre[4][2];     // backward flavour: the LayerNorm input rows (lb_x) and the residual-branch gradient (lb_dres)
+  float mupre[4], rspre[4];
+  if constexpr (BWD) {
+    if (p.lb_x) {
+      const bf16_t* Xp = reinterpret_cast<const bf16_t*>(p.lb_x);
+      const bf16_t* Dp = reinterpret_cast<const bf16_t*>(p.lb_dres);
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int mc = min(row0 + 8 * wave + 2 * ps + (lane >> 5), M - 1);
+        mupre[ps] = p.lb_mean[mc];
+        rspre[ps] = p.lb_rstd[mc];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          xpre[ps][q] = *reinterpret_cast<const uint2*>(Xp + (int64_t)mc * D + 128 * q + 4 * (lane & 31));
+          rpre[ps][q] = Dp ? *reinterpret_cast<const uint2*>(Dp + (int64_t)mc * D + 128 * q + 4 * (lane & 31)) : make_uint2(0, 0);
+        }
+      }
+    }
+  }
   if constexpr (!BWD) {
     if (p.residual) {
       const bf16_t* Rp = reinterpret_cast<const bf16_t*>(p.residual);
@@ -829,13 +848,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) ag[q][r] = ab[q][r] = 0.f;
         }
-#pragma unroll 2
+#pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int ml = 8 * wave + 2 * ps + hi;
           const int m = row0 + ml;
           const bool live = m < M;
-          const int mc = live ? m : M - 1;
-          const float mu = p.lb_mean[mc], rs = p.lb_rstd[mc];
+          const float mu = mupre[ps], rs = rspre[ps];
           float dv[2][4], xh[2][4], dg[2][4], rr[2][4];
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -843,10 +861,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
             const int cc = 32 * q + s;
             const f32x4 a = *reinterpret_cast<const f32x4*>(smem + ml * 1024 + 16 * (cc ^ (ml & 7)));
             const f32x4 b = *reinterpret_cast<const f32x4*>(smem + 65536 + ml * 1024 + 16 * (cc ^ (ml & 7)));
-            float xv[4];
-            ld4_as_f32<bf16_t>(X + (int64_t)mc * D + 128 * q + 4 * s, xv);
-            if (DR) ld4_as_f32<bf16_t>(DR + (int64_t)mc * D + 128 * q + 4 * s, rr[q]);
-            else rr[q][0] = rr[q][1] = rr[q][2] = rr[q][3] = 0.f;
+            const uint2 tx = xpre[ps][q], tr = rpre[ps][q];
+            const float xv[4] = {__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u),
+                                 __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u)};
+            rr[q][0] = __uint_as_float(tr.x << 16); rr[q][1] = __uint_as_float(tr.x & 0xffff0000u);
+            rr[q][2] = __uint_as_float(tr.y << 16); rr[q][3] = __uint_as_float(tr.y & 0xffff0000u);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               dv[q][r] = live ? a[r] + b[r] : 0.f;
