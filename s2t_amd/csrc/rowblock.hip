@@ -1391,6 +1391,25 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
+  // the LayerNorm-backward operands of this thread's epilogue rows travel during the LDS exchange below (inside the pass
+  // loop they were one global round trip per pass)
+  uint2 xpre[4][2], rpre[4][2];
+  float mupre[4], rspre[4];
+  if (p.ln_x) {
+    const bf16_t* Xp = reinterpret_cast<const bf16_t*>(p.ln_x);
+    const bf16_t* Dp = reinterpret_cast<const bf16_t*>(p.dres);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int mc = min(row0 + 8 * wave + 2 * ps + (lane >> 5), M - 1);
+      mupre[ps] = p.ln_mean[mc];
+      rspre[ps] = p.ln_rstd[mc];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        xpre[ps][qq] = *reinterpret_cast<const uint2*>(Xp + (int64_t)mc * D + 128 * qq + 4 * (lane & 31));
+        rpre[ps][qq] = Dp ? *reinterpret_cast<const uint2*>(Dp + (int64_t)mc * D + 128 * qq + 4 * (lane & 31)) : make_uint2(0, 0);
+      }
+    }
+  }
   // ---- fp32 rows into LDS: row m at m*1024 + 16*(cc ^ (m & 7)), cc = 4-column piece 16c + 4q + g
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -1433,24 +1452,24 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) ag[qq][r] = ab[qq][r] = 0.f;
   }
-#pragma unroll 2
+#pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int ml = 8 * wave + 2 * ps + hi;
     const int m = row0 + ml;
     const bool live = m < M;
-    const int mc = live ? m : M - 1;
     const bool masked = !live || (p.ln_lens && (m % p.ln_T) >= p.ln_lens[m / p.ln_T]);
-    const float mu = p.ln_mean[mc], rs = p.ln_rstd[mc];
+    const float mu = mupre[ps], rs = rspre[ps];
     float dv[2][4], xh[2][4], dg[2][4], rr[2][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
       const int cc = 32 * qq + sl;
       const f32x4 a = *reinterpret_cast<const f32x4*>(smem + ml * 1024 + 16 * (cc ^ (ml & 7)));
-      float xv[4];
-      ld4_as_f32<bf16_t>(X + (int64_t)mc * D + 128 * qq + 4 * sl, xv);
-      if (DR) ld4_as_f32<bf16_t>(DR + (int64_t)mc * D + 128 * qq + 4 * sl, rr[qq]);
-      else rr[qq][0] = rr[qq][1] = rr[qq][2] = rr[qq][3] = 0.f;
+      const uint2 tx = xpre[ps][qq], tr = rpre[ps][qq];
+      const float xv[4] = {__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u),
+                           __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u)};
+      rr[qq][0] = __uint_as_float(tr.x << 16); rr[qq][1] = __uint_as_float(tr.x & 0xffff0000u);
+      rr[qq][2] = __uint_as_float(tr.y << 16); rr[qq][3] = __uint_as_float(tr.y & 0xffff0000u);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         // (the separate kernels round the GEMM result to bf16 before the LayerNorm backward; fp32 here)
