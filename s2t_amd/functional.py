@@ -453,9 +453,11 @@ def flush_wgrads():
                               and M * ldy * 2 < 2 ** 31 and M * ldx * 2 < 2 ** 31 for (dY, X, _, _, _, M, ldy, ldx, _, _) in q)
         TL, KS, per_item = (256, 32, _WG_KSTEPS256) if big else (128, 64, _WG_KSTEPS)
         if big and _WG_AUTO:
-            # K-steps per work item chosen per launch: the items of a launch run in rounds of 512 (two workgroups per CU), so
-            # a data-parallel gradient stage with ~300 items of 250 steps leaves 40 % of the slots idle where 468 items of
-            # 167 steps fill them.  Estimated time = rounds x (longest item + the cost of its partial tile, ~60 steps).
+            # K-steps per work item chosen per launch: the items of a launch run in rounds of one workgroup per CU (128 KiB of
+            # LDS each), so a data-parallel gradient stage with ~300 items of 250 steps runs two rounds, the second a fifth
+            # full, where 468 items of 167 steps fill both.  Estimated time = rounds x (longest item + the cost of its
+            # partial tile, ~60 steps).
+            slots = torch.cuda.get_device_properties(dev).multi_processor_count
             best = None
             for cand in (256, 200, 170, 128, 100, 64):
                 n_items, longest = 0, 0
@@ -464,7 +466,7 @@ def flush_wgrads():
                     ns = max(1, (kt + cand // 2) // cand)
                     n_items += ((Nout + TL - 1) // TL) * ((Kin + TL - 1) // TL) * ns
                     longest = max(longest, (kt + ns - 1) // ns)
-                cost = ((n_items + 511) // 512) * (longest + 60)
+                cost = ((n_items + slots - 1) // slots) * (longest + 60)
                 if best is None or cost < best[0] * 0.97:  # ties and near-ties go to the larger items (less workspace traffic)
                     best = (cost, cand)
             per_item = best[1]
