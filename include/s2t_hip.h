@@ -55,6 +55,9 @@ int s2t_device_cu_count(void);
  *   its partial tiles with plain coalesced stores, a second kernel sums them into C — float atomics execute at the
  *   memory side on a multi-XCD part and are several times slower), with float atomics otherwise.  colsum_a (a_kmajor): the column sums of dY (= the bias gradient) are taken
  *   from the staged A tiles by the workgroups of the first tile column and added atomically (fp32).
+ *   c_atomic == 2 (overwrite through the workspace; fp32 or bf16 C) also carries every epilogue stage above except GLU:
+ *   the second kernel runs them on the summed tiles (same dropout keys as the one-pass kernel).  Without a workspace
+ *   that form runs as one pass (split_k = 1), the same result.
  * Alignment: A, B base pointers and strides must keep 16-byte alignment of every row start.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct s2t_gemm_args {

@@ -542,6 +542,72 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args 
   }
 }
 
+// Second phase with the fused epilogue (c_atomic == 2 and any of bias / activation / dropout / row mask / residual):
+// C = epilogue(sum_s partial_s), the same Epi::finish the one-pass kernel runs, so that a long reduction over few output
+// tiles (the decoder's second FFN GEMM: 62 tiles x 32 K-steps) can be cut into splits without a separate bias / residual
+// pass.  One workgroup per (tile, fragment pair): lanes y and y^1 swap halves exactly as in gemm_kernel's epilogue, so
+// that a thread ends up with 8 consecutive columns of one row (and the dropout keys are those of the one-pass kernel).
+template <typename TC, bool VEC>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const s2t_gemm_args p, int ntiles, int tiles_n) {
+  const int tile = blockIdx.x, it = blockIdx.y, z = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, x = lane & 15, y = lane >> 4;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int z0 = z / p.zdiv, z1 = z % p.zdiv;
+  const int64_t coff = z0 * p.c_s0 + z1 * p.c_s1;
+  const int64_t sstride = (int64_t)ntiles * (BM * BN);
+  const int i = it >> 1, jp = it & 1;
+  const float* src = p.ws + (int64_t)z * p.split_k * sstride + (int64_t)tile * (BM * BN) + ((i * 4 + 2 * jp) * 256 + tid) * 4;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+  int s = 0;
+  for (; s + 2 <= p.split_k; s += 2) {
+    a0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * sstride);
+    a1 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * sstride + 1024);
+    b0 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 1) * sstride);
+    b1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(s + 1) * sstride + 1024);
+  }
+  if (s < p.split_k) {
+    a0 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * sstride);
+    a1 += *reinterpret_cast<const f32x4*>(src + (int64_t)s * sstride + 1024);
+  }
+  a0 += b0;
+  a1 += b1;
+  float v[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // (every lane is active here)
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a0[r]), __float_as_uint(a1[r]), false, false);
+    v[r] = __uint_as_float(sw[0]);
+    v[4 + r] = __uint_as_float(sw[1]);
+  }
+  Epi<TC, VEC> e{p,
+                 reinterpret_cast<TC*>(p.C) + coff,
+                 p.residual ? reinterpret_cast<const TC*>(p.residual) + coff : nullptr,
+                 p.preact ? reinterpret_cast<TC*>(p.preact) + (z0 * p.p_s0 + z1 * p.p_s1) : nullptr,
+                 p.dact_z ? reinterpret_cast<const TC*>(p.dact_z) + coff : nullptr,
+                 p.N,
+                 false, false, false, false};
+  if constexpr (!VEC) {
+    auto vec_ok = [](const void* ptr, int64_t ld) { return ((ld * (int64_t)sizeof(TC)) % 16 == 0) && (((uintptr_t)ptr) % 16 == 0); };
+    e.vec_c = vec_ok(e.C, p.ldc);
+    e.vec_r = e.R && vec_ok(e.R, p.ldr);
+    e.vec_p = e.P && vec_ok(e.P, p.ldp);
+    e.vec_z = e.Z && vec_ok(e.Z, p.ldz);
+  }
+  const int m = tm * BM + wm * 64 + i * 16 + x;
+  const int n0 = tn * BN + wn * 64 + (2 * jp + (y & 1)) * 16 + 8 * (y >> 1);
+  if (m < p.M && n0 < p.N) {
+    float b[8];
+    e.bias8(n0, min(8, p.N - n0), b);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += b[r];
+    e.finish(m, n0, (int64_t)z * p.M + m, v);
+  }
+}
+
+static bool has_fused_epilogue(const s2t_gemm_args& p) {
+  return p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens || p.drop_p > 0.f;
+}
+
 static int64_t splitk_ws_floats(const s2t_gemm_args& p) {
   if (p.split_k <= 1 || p.act == S2T_ACT_GLU) return 0;
   const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -594,7 +660,18 @@ int launch(const s2t_gemm_args& p, hipStream_t s) {
   if (rc == S2T_OK && p.ws) {
     const int tiles_n = (p.N + BN - 1) / BN;
     const int ntiles = ((p.M + BM - 1) / BM) * tiles_n;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ntiles, 16, p.batch), dim3(256), 0, s, p, ntiles, tiles_n);
+    if (has_fused_epilogue(p)) {
+      const dim3 g(ntiles, 8, p.batch), b(256);
+      if (p.c_dtype == S2T_BF16) {
+        if (epilogue_vectorisable<bf16_t>(p, p.N)) hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t, true>), g, b, 0, s, p, ntiles, tiles_n);
+        else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t, false>), g, b, 0, s, p, ntiles, tiles_n);
+      } else {
+        if (epilogue_vectorisable<float>(p, p.N)) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), g, b, 0, s, p, ntiles, tiles_n);
+        else hipLaunchKernelGGL((splitk_epilogue_kernel<float, false>), g, b, 0, s, p, ntiles, tiles_n);
+      }
+    } else {
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ntiles, 16, p.batch), dim3(256), 0, s, p, ntiles, tiles_n);
+    }
     rc = S2T_LAUNCH_CHECK();
   }
   return rc;
@@ -619,9 +696,12 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   if ((p.a_s0 % epb) || (p.a_s1 % epb) || (p.b_s0 % epb) || (p.b_s1 % epb)) return S2T_ERR_ALIGN;
   // split-K / atomic accumulation: fp32 C; the two-phase overwrite form (c_atomic == 2) may also round its result to bf16
   const bool bf16_two_phase = p.c_dtype == S2T_BF16 && p.dtype == S2T_BF16 && p.split_k > 1 && p.c_atomic == 2;
+  // ... and only that form carries the fused epilogue (its second phase runs Epi::finish; GLU pairs columns across
+  // tiles and stays one-pass)
+  const bool two_phase_overwrite = p.split_k > 1 && p.c_atomic == 2;
   if (p.split_k > 1 || p.c_atomic) {
-    if ((p.c_dtype != S2T_F32 && !bf16_two_phase) || p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens || p.drop_p > 0.f)
-      return S2T_ERR_UNSUPPORTED;
+    if (p.c_dtype != S2T_F32 && !bf16_two_phase) return S2T_ERR_UNSUPPORTED;
+    if (has_fused_epilogue(p) && !(two_phase_overwrite && p.act != S2T_ACT_GLU)) return S2T_ERR_UNSUPPORTED;
   }
   {
     // the kernels address each operand with 32-bit byte offsets from its (batch-adjusted) base
@@ -644,12 +724,16 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
     // batches must own disjoint parts of C (the reduction is a plain read-modify-write)
     const bool disjoint = p.batch == 1 || (p.zdiv == 1 && (p.c_s0 >= p.N || p.c_s0 >= (int64_t)p.M * p.ldc));
     if (!(p.ws && need > 0 && p.ws_floats >= need && all_splits_busy && disjoint && ((uintptr_t)p.ws % 16) == 0)) p.ws = nullptr;
-    if (p.c_atomic == 2 && !p.ws) return S2T_ERR_UNSUPPORTED;  // overwrite needs the two-phase (workspace) reduction
+    if (p.c_atomic == 2 && !p.ws) {
+      // overwrite needs the two-phase (workspace) reduction; without one the same result comes from a single pass
+      if (p.colsum_a) return S2T_ERR_UNSUPPORTED;
+      p.split_k = 1;
+      p.c_atomic = 0;
+    }
   }
   hipStream_t s = (hipStream_t)stream;
   if (p.dtype == S2T_F32) return launch<float, float>(p, s);
-  if (p.c_dtype == S2T_F32 || (bf16_two_phase && p.ws)) return launch<bf16_t, float>(p, s);  // (the partial tiles are fp32)
-  if (bf16_two_phase) return S2T_ERR_UNSUPPORTED;  // degenerated to one split without a workspace
+  if (p.c_dtype == S2T_F32 || p.ws) return launch<bf16_t, float>(p, s);  // (the partial tiles are fp32)
   return launch<bf16_t, bf16_t>(p, s);
 }
 

@@ -656,6 +656,7 @@ def _rb_ok(x, N, act=None):
 
 
 _DGRAD_SPLITK = os.environ.get("S2T_DGRAD_SPLITK", "1") != "0"
+_DGRAD_SPLITK_MINK = int(os.environ.get("S2T_DGRAD_SPLITK_MINK", "1024"))
 
 
 _RB_DGRAD = os.environ.get("S2T_RB_DGRAD", "1") != "0"  # s2t_rowblock_dgrad: projection dgrad + LayerNorm backward in one launch
@@ -711,7 +712,7 @@ def _dgrad(dy, w, dx, M, N, Kd, lda, ldb, ldc, alpha=1.0):
     the vocabulary projections (K = V = 10 000; M = B*U decoder rows: 32 tiles walking 157 K-steps each took 180 us) and the
     decoder's FFN — is cut into K splits whose fp32 partial tiles meet in a workspace (two-phase split-K, bf16 result)."""
     split = 1
-    if _DGRAD_SPLITK and dy.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and Kd >= 1024:
+    if _DGRAD_SPLITK and dy.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and Kd >= _DGRAD_SPLITK_MINK:
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         if tiles < 384:
             split = max(1, min(8, 512 // tiles, Kd // 256))
@@ -782,8 +783,15 @@ class FFNFn(torch.autograd.Function):
         z = torch.empty(M, F_, dtype=x.dtype, device=x.device) if train else None
         K.gemm(x, cw(w1), h, M=M, N=F_, K=d, lda=d, ldb=d, ldc=F_, bias=b1.data, act=act, preact=z, ldp=F_, drop=drop_h)
         y = torch.empty(M, d, dtype=x.dtype, device=x.device)
+        # the decoder's rows (B*U = 3904: 62 output tiles walking 32 K-steps each) leave three CUs in four idle: the long
+        # reduction is cut into splits and the epilogue runs in the second phase
+        split = 1
+        if _FWD_SPLITK and x.dtype == torch.bfloat16 and F_ >= 1024:
+            tiles = ((M + 127) // 128) * ((d + 127) // 128)
+            if tiles < 128:
+                split = max(1, min(_FWD_SPLITK, 512 // tiles, F_ // 256))
         K.gemm(h, cw(w2), y, M=M, N=d, K=F_, lda=F_, ldb=F_, ldc=d, bias=b2.data, alpha=alpha, residual=residual, ldr=d,
-               drop=drop_o)
+               drop=drop_o, split_k=split, c_atomic=2 if split > 1 else False)
         ctx.drops = (drop_h, drop_o)
         if train:
             ctx.save_for_backward(x, z, h)
@@ -814,6 +822,7 @@ class FFNFn(torch.autograd.Function):
 
 
 _FFN_FUSED = os.environ.get("S2T_FFN_FUSED", "1") != "0"
+_FWD_SPLITK = int(os.environ.get("S2T_FWD_SPLITK", "8"))  # most K splits of the (unfused) FFN's second forward GEMM; 0: one pass
 _FFN_FUSED_BWD = os.environ.get("S2T_FFN_FUSED_BWD", "1") != "0"  # s2t_ffn_fused_bwd for the block's input gradient
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("S2T_FFN_FUSED_MIN_ROWS", "8192"))  # 64-row blocks: fewer rows leave CUs idle
 

@@ -250,3 +250,55 @@ def test_two_phase_splitk_with_bf16_result(M, N, K, split):
     assert (got - ref).abs().max() <= 1e-2 * ref.abs().max()
     if ldn > N:
         assert float((out.cpu().float()[:, N:] - 9.0).abs().max()) == 0.0  # columns beyond N untouched
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K,split,act", [(3904, 256, 2048, 8, None), (300, 200, 1100, 3, "relu"), (130, 136, 640, 5, "swish")])
+def test_two_phase_splitk_runs_the_fused_epilogue(dtype, M, N, K, split, act):
+    """c_atomic = 2 with bias / activation (+ pre-activation output) / dropout / row mask / alpha / residual: the second
+    phase runs the epilogue of the one-pass kernel on the summed tiles — same dropout mask, values equal up to the order
+    of the fp32 sums (one bf16 ulp after rounding)."""
+    g = torch.Generator().manual_seed(M + K)
+    dev = "cuda"
+    ld = (lambda n: _pad_ld(n, dtype))
+    A = torch.zeros(M, ld(K), dtype=dtype); A[:, :K] = _mk((M, K), dtype, g, 0.5)
+    B = torch.zeros(N, ld(K), dtype=dtype); B[:, :K] = _mk((N, K), dtype, g, 0.1)
+    bias = _mk((N,), torch.float32, g)
+    res = torch.zeros(M, ld(N), dtype=dtype); res[:, :N] = _mk((M, N), dtype, g)
+    T = 50
+    nb = (M + T - 1) // T
+    lens = torch.randint(T // 2, T + 1, (nb,), generator=g).to(torch.int32).to(dev)
+    seed = torch.tensor([1234], dtype=torch.int64, device=dev)
+    outs = []
+    for sk in (1, split):
+        out = torch.full((M, ld(N)), 9.0, dtype=dtype, device=dev)
+        pre = torch.full((M, ld(N)), 9.0, dtype=dtype, device=dev) if act else None
+        ops.gemm(A.to(dev), B.to(dev), out, M=M, N=N, K=K, lda=ld(K), ldb=ld(K), ldc=ld(N), bias=bias.to(dev), act=act,
+                 alpha=0.5, residual=res.to(dev), ldr=ld(N), preact=pre, ldp=ld(N), row_lens=lens, row_T=T,
+                 drop=(0.1, seed, 7), split_k=sk, c_atomic=2 if sk > 1 else False)
+        torch.cuda.synchronize()
+        outs.append((out.cpu().double(), pre.cpu().double() if act else None))
+    (o1, p1), (o2, p2) = outs
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert (o1[:, :N] - o2[:, :N]).abs().max() <= tol * o1[:, :N].abs().max()
+    # the dropped / masked positions (value == residual exactly) coincide
+    r = res.double()[:, :N]
+    assert ((o1[:, :N] == r) == (o2[:, :N] == r)).float().mean() > 0.999
+    assert ((o1[:, :N] == r).float().mean() > 0.05)
+    if act:
+        assert (p1[:, :N] - p2[:, :N]).abs().max() <= tol * p1[:, :N].abs().max()
+    if ld(N) > N:
+        assert float((o2[:, N:] - 9.0).abs().max()) == 0.0
+    # against the float64 product
+    v = A[:, :K].double() @ B[:, :K].double().t() + bias.double()
+    if act == "relu":
+        v = v.clamp(min=0)
+    elif act == "swish":
+        v = v * torch.sigmoid(v)
+    rows = torch.arange(M)
+    masked = (rows % T) >= lens.cpu()[rows // T]
+    kept = (o2[:, :N] != r)
+    ref = 0.5 * v / 0.9 + r
+    err = ((o2[:, :N] - ref).abs() * kept)[~masked]
+    assert err.max() <= (3e-2 if dtype == torch.bfloat16 else 1e-4) * ref.abs().max()
+    assert float((o2[:, :N] - r)[masked].abs().max()) == 0.0
