@@ -27,8 +27,10 @@
 #include "gemm_common.h"
 
 #ifndef S2T_EPI_UNROLL
-#define S2T_EPI_UNROLL 4  // tile pairs per copy of the fused epilogue code (1, 2, 4 or 8); measured on the training
-                          // step: 1 -> 21.35 ms, 2 -> 21.12, 4 -> 20.90, 8 -> 21.38 (instruction-cache pressure)
+#define S2T_EPI_UNROLL 2  // tile pairs per copy of the fused epilogue code (1, 2, 4 or 8); measured on the training
+                          // step, round 1: 1 -> 21.35 ms, 2 -> 21.12, 4 -> 20.90, 8 -> 21.38 (instruction-cache
+                          // pressure); end of round 2, with most K = 256 products in the row-block kernels:
+                          // 1 -> 13.95, 2 -> 13.39, 4 -> 13.44, 8 -> 13.45 (same box, alternating)
 #endif
 
 namespace {
