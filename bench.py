@@ -251,20 +251,32 @@ def main():
     loss_val = float(out[0])
 
     result = None
-    # ---- roofline leg: one instrumented eager step, HIP events around every GEMM launch on the launch stream.  EVERY rank
+    # ---- roofline leg: instrumented eager steps, HIP events around every GEMM launch on the launch stream.  EVERY rank
     # takes the step (its gradient all-reduce must pair up across ranks); only rank 0 records and reports.
     # The weight gradients go through the grouped launch here as they do in the captured step (functional._WGQ mode "1"),
     # so that the kernel mix of this leg is the one the timed replays ran.
     from s2t_amd import functional as Fn
-    K.GEMM_PROFILE = [] if rank == 0 else None
+    # Three such steps; a launch's duration is the median of its three readings (the launch sequence is the same every step),
+    # so that one disturbed reading does not move the figure.
+    passes = []
     wg_mode, Fn._WGQ["mode"] = Fn._WGQ["mode"], ("1" if use_graph else Fn._WGQ["mode"])
     try:
-        trainer.train_step(sample, ntok_global)
+        for _ in range(3):
+            K.GEMM_PROFILE = [] if rank == 0 else None
+            trainer.train_step(sample, ntok_global)
+            torch.cuda.synchronize()
+            passes.append(K.GEMM_PROFILE)
     finally:
         Fn._WGQ["mode"] = wg_mode
-    torch.cuda.synchronize()
+        K.GEMM_PROFILE = None
     if rank == 0:
-        prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+        same = all(len(q) == len(passes[0]) and all(a[0] == b[0] for a, b in zip(q, passes[0])) for q in passes)
+        if not same:  # (never seen: the step is deterministic) fall back to the last pass alone
+            passes = passes[-1:]
+        prof = []
+        for recs in zip(*passes):
+            ms = sorted(r[2].elapsed_time(r[3]) for r in recs)[len(recs) // 2]
+            prof.append((recs[0][0], recs[0][1], ms, recs[0][4]))
         # An empty HIP event pair on this stack already reads ~4.8 us; calibrate that here (the MINIMUM over 64 empty pairs, so that the correction never flatters) and
         # take it off every launch's reading, which then agrees with the rocprofv3 kernel-trace durations.
         empty = []
@@ -276,10 +288,10 @@ def main():
         torch.cuda.synchronize()
         ev_over = min(x0.elapsed_time(x1) for x0, x1 in empty) * 1e-3
         agg = {}
-        for sym, flops, e0, e1, shape in prof:
+        for sym, flops, ms, shape in prof:
             a = agg.setdefault(sym, [0.0, 0.0, 0])
             a[0] += flops
-            a[1] += max(e0.elapsed_time(e1) * 1e-3 - ev_over, 1e-7)
+            a[1] += max(ms * 1e-3 - ev_over, 1e-7)
             a[2] += 1
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         sym, (fl, sec, cnt) = dom
