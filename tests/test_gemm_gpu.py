@@ -302,3 +302,21 @@ def test_two_phase_splitk_runs_the_fused_epilogue(dtype, M, N, K, split, act):
     err = ((o2[:, :N] - ref).abs() * kept)[~masked]
     assert err.max() <= (3e-2 if dtype == torch.bfloat16 else 1e-4) * ref.abs().max()
     assert float((o2[:, :N] - r)[masked].abs().max()) == 0.0
+
+
+def test_overwrite_splitk_without_a_workspace_runs_as_one_pass():
+    """c_atomic = 2 with no workspace handed over: s2t_gemm runs the one-pass kernel (split_k = 1) — bit-identical to it."""
+    g = torch.Generator().manual_seed(5)
+    dev = "cuda"
+    M, N, K = 260, 136, 1024
+    A = _mk((M, K), torch.bfloat16, g, 0.5).to(dev)
+    B = _mk((N, K), torch.bfloat16, g, 0.1).to(dev)
+    bias = _mk((N,), torch.float32, g).to(dev)
+    res = _mk((M, N), torch.bfloat16, g).to(dev)
+    outs = []
+    for kw in (dict(), dict(split_k=4, c_atomic=2, splitk_workspace=False)):
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, B, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act="relu", alpha=0.7, residual=res, ldr=N, **kw)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
