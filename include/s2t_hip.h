@@ -550,6 +550,14 @@ typedef struct s2t_rowblock_args {
    * (convolution.py:102-106, s2t_bn_act_fwd's arithmetic); x_ln then receives x_in (the operand of pointwise conv 2's
    * weight gradient).  pre_act: S2T_ACT_* */
   const float* pre_scale; const float* pre_shift; int32_t pre_act;
+  /* conv_w != NULL (needs pre_scale / pre_shift, no GLU, no dropout, conv_T >= 18): x is the GLU output G of the
+   * convolution module and x_in = pre_act(dwconv15(G)[m, c] * pre_scale[c] + pre_shift[c]) — the depthwise convolution over
+   * time (conv_w: fp32 [256][15], pad 7, zero padding per utterance of conv_T frames; modules/convolution.py:100-112 with
+   * the eval-mode BatchNorm folded into the affine), rows masked by ln_lens / ln_T; x_ln is not written in this mode */
+  const float* conv_w; int32_t conv_T;
+  /* conv mode only, bn_mean != NULL: pre_scale / pre_shift hold the BatchNorm's gamma / beta and the affine is folded in the
+   * kernel from the running statistics: scale = gamma * rsqrt(bn_var + bn_eps), shift = beta - bn_mean * scale */
+  const float* bn_mean; const float* bn_var; float bn_eps;
 } s2t_rowblock_args;
 int s2t_rowblock_gemm(const s2t_rowblock_args* args, void* stream);
 

@@ -106,6 +106,8 @@ class RowblockArgs(C.Structure):
         ("row_lens", C.c_void_p), ("row_T", C.c_int32), ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("drop_seed", C.c_void_p),
         ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("pre_act", C.c_int32),
+        ("conv_w", C.c_void_p), ("conv_T", C.c_int32),
+        ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p), ("bn_eps", C.c_float),
     ]
 
 

@@ -1029,7 +1029,7 @@ constexpr int PJ_BIAS = PJ_TILE + 2 * 16384;     // fp32 bias[N] (N <= PJ_MAXN)
 constexpr int PJ_MAXN = 4096;
 constexpr int PJ_BYTES = PJ_BIAS + PJ_MAXN * 4;  // 144 KiB
 
-template <bool GLU, bool DROP>
+template <bool GLU, bool DROP, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowblock_args p) {
   __shared__ __attribute__((aligned(16))) char smem[PJ_BYTES];
   const int tid = threadIdx.x;
@@ -1072,7 +1072,84 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   }
 
   // ---- prologue: (LayerNorm of) the 64 rows staged in the third weight stage, then this wave's B fragments --------
-  {
+  if constexpr (CONV) {
+    // Depthwise convolution over time (15 taps, pad 7, per-utterance zero padding) + per-channel affine (the folded
+    // eval-mode BatchNorm) + activation + padded-frame mask of the 64 rows, formed here instead of in a launch of its own
+    // (modules/convolution.py:100-112 in eval mode).  A wave owns 4 consecutive rows, a lane 4 channels of them: 18 input
+    // rows of 8 bytes and the 60 taps of its channels per lane, all in registers.
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
+    char* stage = smem + PJ_W + 2 * STAGE;
+    const int c4 = lane;
+    float wr[60];  // this lane's taps: channel 4 c4 + c, tap k at [15 c + k] (60 contiguous floats of conv_w)
+    {
+      const float4* wp = reinterpret_cast<const float4*>(p.conv_w + 60 * c4);
+#pragma unroll
+      for (int q4 = 0; q4 < 15; ++q4) {
+        const float4 t = wp[q4];
+        wr[4 * q4] = t.x; wr[4 * q4 + 1] = t.y; wr[4 * q4 + 2] = t.z; wr[4 * q4 + 3] = t.w;
+      }
+    }
+    float4 gm = *reinterpret_cast<const float4*>(p.pre_scale + 4 * c4);
+    float4 bt = *reinterpret_cast<const float4*>(p.pre_shift + 4 * c4);
+    if (p.bn_mean) {  // fold the running statistics: scale = gamma * rsqrt(var + eps), shift = beta - mean * scale
+      const float4 mu = *reinterpret_cast<const float4*>(p.bn_mean + 4 * c4);
+      const float4 va = *reinterpret_cast<const float4*>(p.bn_var + 4 * c4);
+      gm.x *= rsqrtf(va.x + p.bn_eps); gm.y *= rsqrtf(va.y + p.bn_eps);
+      gm.z *= rsqrtf(va.z + p.bn_eps); gm.w *= rsqrtf(va.w + p.bn_eps);
+      bt.x -= mu.x * gm.x; bt.y -= mu.y * gm.y; bt.z -= mu.z * gm.z; bt.w -= mu.w * gm.w;
+    }
+    const int T = p.conv_T;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const int rg = 8 * pass + wave;          // row group: rows 4 rg .. 4 rg + 3 of the block (wave-uniform)
+      const int m0 = row0 + 4 * rg;
+      const int b0 = min(m0, M - 1) / T;
+      const int t0 = m0 - b0 * T;              // frame of the group's first row (>= T only beyond the last row)
+      uint2 raw[18];
+#pragma unroll
+      for (int j = 0; j < 18; ++j) {
+        const int mj = min(max(m0 - 7 + j, 0), M - 1);
+        raw[j] = *reinterpret_cast<const uint2*>(X + (int64_t)mj * D + 4 * c4);
+      }
+      // rows of a neighbouring utterance (and beyond either end of the batch) read as zero padding
+      int ut[18];
+#pragma unroll
+      for (int j = 0; j < 18; ++j) {
+        const int tj = t0 - 7 + j;
+        ut[j] = tj < 0 ? -1 : (tj >= T ? 1 : 0);
+      }
+      float acc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        const float4 w = make_float4(wr[k], wr[15 + k], wr[30 + k], wr[45 + k]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ui = (t0 + i >= T) ? 1 : 0;  // wave-uniform: the group straddles an utterance boundary
+          const bool ok = ut[i + k] == ui;
+          const uint2 r = raw[i + k];
+          const float x0 = ok ? __uint_as_float(r.x << 16) : 0.f, x1 = ok ? __uint_as_float(r.x & 0xffff0000u) : 0.f;
+          const float x2 = ok ? __uint_as_float(r.y << 16) : 0.f, x3 = ok ? __uint_as_float(r.y & 0xffff0000u) : 0.f;
+          acc[i][0] = fmaf(w.x, x0, acc[i][0]);
+          acc[i][1] = fmaf(w.y, x1, acc[i][1]);
+          acc[i][2] = fmaf(w.z, x2, acc[i][2]);
+          acc[i][3] = fmaf(w.w, x3, acc[i][3]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = 4 * rg + i, m = row0 + rl;
+        const bool masked = m >= M || (p.ln_lens && (m % p.ln_T) >= p.ln_lens[m / p.ln_T]);
+        uint2 o;
+        o.x = masked ? 0u : pack2(act_apply(p.pre_act, acc[i][0] * gm.x + bt.x), act_apply(p.pre_act, acc[i][1] * gm.y + bt.y));
+        o.y = masked ? 0u : pack2(act_apply(p.pre_act, acc[i][2] * gm.z + bt.z), act_apply(p.pre_act, acc[i][3] * gm.w + bt.w));
+        *reinterpret_cast<uint2*>(stage + rl * 512 + 16 * ((c4 >> 1) ^ (rl & 15)) + 8 * (c4 & 1)) = o;
+      }
+    }
+  } else {
     const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x);
     char* stage = smem + PJ_W + 2 * STAGE;
     const int cch = tid & 31;
@@ -1654,6 +1731,12 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->drop_seed)) return S2T_ERR_ARG;
   if (a->ldc < nout || a->ldc % 8 || (a->residual && (a->ldr < nout || a->ldr % 8)) || (a->preact && (a->ldp < a->N || a->ldp % 8)))
     return S2T_ERR_ALIGN;
+  if (a->conv_w) {
+    if (!a->pre_scale || glu || a->drop_p > 0.f || a->x_ln || a->conv_T < 18 || (a->ln_lens && a->ln_T != a->conv_T)) return S2T_ERR_ARG;
+    if (a->M % a->conv_T) return S2T_ERR_ARG;
+    if ((uintptr_t)a->conv_w % 16) return S2T_ERR_ALIGN;
+    if (a->bn_mean && (!a->bn_var || ((uintptr_t)a->bn_mean % 16) || ((uintptr_t)a->bn_var % 16))) return S2T_ERR_ARG;
+  }
   const void* ptrs[] = {a->x, a->w, a->out, a->residual, a->preact, a->x_ln, a->bias, a->ln_gamma, a->ln_beta};
   for (const void* q : ptrs)
     if (q && ((uintptr_t)q % 16)) return S2T_ERR_ALIGN;
@@ -1663,6 +1746,8 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   if (glu) {
     if (drop) hipLaunchKernelGGL((rowblock_gemm_kernel<true, true>), grid, block, 0, s, *a);
     else hipLaunchKernelGGL((rowblock_gemm_kernel<true, false>), grid, block, 0, s, *a);
+  } else if (a->conv_w) {
+    hipLaunchKernelGGL((rowblock_gemm_kernel<false, false, true>), grid, block, 0, s, *a);
   } else {
     if (drop) hipLaunchKernelGGL((rowblock_gemm_kernel<false, true>), grid, block, 0, s, *a);
     else hipLaunchKernelGGL((rowblock_gemm_kernel<false, false>), grid, block, 0, s, *a);

@@ -1567,11 +1567,14 @@ class ConvModuleFn(torch.autograd.Function):
             rstd = torch.empty(d, dtype=torch.float32, device=dev)
             K.bn_finalize(stats, M, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
                           momentum, 1e-5, True, scale, shift, mean, rstd, d)
-        else:  # eval: conv + BatchNorm on the running statistics + activation + mask in one launch
+        rb2 = _rb_ok(a, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1))
+        # eval: conv + BatchNorm on the running statistics + activation + mask in pointwise conv 2's row-block prologue
+        conv_fused = (not training and rb2 and _CONV_EVAL_FUSED and Kw == 15 and T >= 18 and wd.dtype == torch.float32
+                      and wd.is_contiguous())
+        if not training and not conv_fused:  # ... or in one launch of their own
             K.dwconv_bn_eval_fwd(g, wd, a, B, T, d, Kw, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"],
                                  bn_buf["running_var"], 1e-5, act, lens)
         y = torch.empty(M, d, dtype=dt, device=dev)
-        rb2 = _rb_ok(a, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1))
         fused_bn = training and rb2 and _BN_IN_PW2
         if training and not fused_bn:
             K.bn_act_fwd(D, a, scale, shift, act, M, d, lens, T)
@@ -1581,6 +1584,11 @@ class ConvModuleFn(torch.autograd.Function):
             K.rowblock_gemm(D, cw(prm["pw2_w"]).view(d, d), y, N=d, ldc=d, residual=residual,
                             ldr=residual.stride(0) if residual is not None else 0, row_lens=lens, row_T=T, drop=drop_o,
                             pre=(scale, shift, act), ln_lens=lens, ln_T=T, x_ln=a)
+        elif conv_fused:
+            K.rowblock_gemm(g, cw(prm["pw2_w"]).view(d, d), y, N=d, ldc=d, residual=residual,
+                            ldr=residual.stride(0) if residual is not None else 0, row_lens=lens, row_T=T,
+                            pre=(prm["bn_w"].data, prm["bn_b"].data, act), ln_lens=lens, ln_T=T,
+                            conv=(wd, T, bn_buf["running_mean"], bn_buf["running_var"], 1e-5))
         elif rb2:
             K.rowblock_gemm(a, cw(prm["pw2_w"]).view(d, d), y, N=d, ldc=d, residual=residual,
                             ldr=residual.stride(0) if residual is not None else 0, row_lens=lens, row_T=T, drop=drop_o)
@@ -1646,6 +1654,7 @@ class ConvModuleFn(torch.autograd.Function):
         return (dx, (dres if ctx.has_res else None)) + (None,) * 12
 
 
+_CONV_EVAL_FUSED = os.environ.get("S2T_CONV_EVAL_FUSED", "1") != "0"  # eval: depthwise conv + BatchNorm + activation in pw2's prologue
 _CONV_BWD_FUSED = os.environ.get("S2T_CONV_BWD_FUSED", "1") != "0"  # s2t_conv_bwd_fused in ConvModuleFn.backward (bf16)
 
 

@@ -241,9 +241,11 @@ def rowblock_supported(x, N, act=None):
 
 
 def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual=None, ldr=0, preact=None, ldp=0, ln=None,
-                  ln_eps=1e-5, ln_lens=None, ln_T=0, x_ln=None, ln_stats=None, row_lens=None, row_T=0, drop=None, pre=None):
+                  ln_eps=1e-5, ln_lens=None, ln_T=0, x_ln=None, ln_stats=None, row_lens=None, row_T=0, drop=None, pre=None, conv=None):
     """s2t_rowblock_gemm (include/s2t_hip.h): out = epilogue(LN(x) @ w[:N]^T); ``ln`` = (gamma, beta) or None;
-    ``pre`` = (scale, shift, act): a per-column affine + activation in place of the LayerNorm (masked by ln_lens / ln_T)."""
+    ``pre`` = (scale, shift, act): a per-column affine + activation in place of the LayerNorm (masked by ln_lens / ln_T);
+    ``conv`` = (taps fp32 [256, 15], frames per utterance[, running_mean, running_var, eps]): the 15-tap depthwise
+    convolution over time in front of ``pre`` (with the statistics: ``pre`` holds gamma / beta and the kernel folds them)."""
     L.require_cuda(x, w, out, residual, preact, x_ln)
     M, d = x.shape
     a = L.RowblockArgs()
@@ -264,6 +266,11 @@ def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual
             assert ln_lens.dtype == torch.int32
             a.ln_lens, a.ln_T = ln_lens.data_ptr(), ln_T
         a.x_ln = _ptr(x_ln)
+        if conv is not None:
+            assert conv[0].dtype == torch.float32 and conv[0].is_contiguous() and tuple(conv[0].shape) == (256, 15)
+            a.conv_w, a.conv_T = conv[0].data_ptr(), int(conv[1])
+            if len(conv) > 2:  # (running_mean, running_var, eps): pre[0] / pre[1] are the BatchNorm's gamma / beta
+                a.bn_mean, a.bn_var, a.bn_eps = conv[2].data_ptr(), conv[3].data_ptr(), float(conv[4])
     assert w.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
     a.w, a.bias = w.data_ptr(), _ptr(bias)
     a.act = L.ACT_IDS[act]

@@ -454,3 +454,48 @@ def test_rowblock_gemm_affine_activation_prologue(M, mask, res, p):
     if drop is not None:  # the same elements are dropped (residual-only values survive there)
         base = resid.float() if res else torch.zeros_like(y.float())
         assert ((y.float() == base) == (y_ref.float() == base)).all()
+
+
+@pytest.mark.parametrize("B,T,mask,res", [(5, 50, True, True), (64, 250, True, True), (3, 127, False, False), (7, 18, True, False)])
+def test_rowblock_gemm_depthwise_conv_prologue(B, T, mask, res):
+    """conv = (taps, T, running statistics): the eval-mode middle of the convolution module (15-tap depthwise conv over time
+    with per-utterance zero padding, BatchNorm on the running statistics, swish, padded-frame mask) in pointwise conv 2's
+    prologue, against (a) s2t_dwconv_bn_eval_fwd followed by the plain row-block projection and (b) torch's conv1d in fp32.
+    T = 50 / 127 / 18 are not multiples of the 4-row groups, so groups straddle utterance boundaries; B*T is ragged against
+    the 64-row blocks."""
+    import torch.nn.functional as F
+    g_ = torch.Generator().manual_seed(B * 1000 + T)
+    d, Kw, M = 256, 15, B * T
+    lens_h = torch.tensor([max(T - 4 * b, 9) for b in range(B)], dtype=torch.int32)
+    G = torch.randn(B, T, d, generator=g_)
+    if mask:  # the module's input is zero on padded frames, and pointwise conv 1 + GLU keep it so
+        G = G * (torch.arange(T)[None, :, None] < lens_h[:, None, None])
+    G = G.bfloat16().reshape(M, d).to(DEV)
+    wd = (torch.randn(d, Kw, generator=g_) * 0.3).to(DEV)
+    w = (torch.randn(d, d, generator=g_) * d ** -0.5).bfloat16().to(DEV)
+    gamma = (1 + 0.2 * torch.randn(d, generator=g_)).to(DEV)
+    beta = (0.3 * torch.randn(d, generator=g_)).to(DEV)
+    rmean = (0.2 * torch.randn(d, generator=g_)).to(DEV)
+    rvar = (0.5 + torch.rand(d, generator=g_)).to(DEV)
+    lens = lens_h.to(DEV) if mask else None
+    resid = torch.randn(M, d, generator=g_).bfloat16().to(DEV) if res else None
+    a_ref = torch.empty_like(G)
+    K.dwconv_bn_eval_fwd(G, wd, a_ref, B, T, d, Kw, gamma, beta, rmean, rvar, 1e-5, "swish", lens)
+    y_ref = torch.empty_like(G)
+    K.rowblock_gemm(a_ref, w, y_ref, N=d, ldc=d, residual=resid, ldr=d, row_lens=lens, row_T=T)
+    y = torch.empty_like(G)
+    K.rowblock_gemm(G, w, y, N=d, ldc=d, residual=resid, ldr=d, row_lens=lens, row_T=T, pre=(gamma, beta, "swish"),
+                    ln_lens=lens, ln_T=T, conv=(wd, T, rmean, rvar, 1e-5))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.float(), y_ref.float(), rtol=2e-2, atol=3e-2)
+    # (b) fp32 torch: conv1d (groups = d, pad 7) -> BatchNorm eval -> swish -> mask -> bf16 -> projection (+ mask, residual)
+    x = G.float().view(B, T, d).transpose(1, 2)
+    c = F.conv1d(x, wd.view(d, 1, Kw), padding=7, groups=d).transpose(1, 2)
+    c = (c - rmean) * torch.rsqrt(rvar + 1e-5) * gamma + beta
+    c = c * torch.sigmoid(c)
+    keep = (torch.arange(T, device=DEV)[None, :] < lens[:, None]) if mask else torch.ones(B, T, dtype=torch.bool, device=DEV)
+    c = (c * keep[:, :, None]).bfloat16().float().reshape(M, d)
+    yy = (c @ w.float().t()) * keep.reshape(M, 1)
+    if res:
+        yy = yy + resid.float()
+    torch.testing.assert_close(y.float(), yy, rtol=2e-2, atol=3e-2)
