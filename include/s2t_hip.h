@@ -463,8 +463,13 @@ typedef struct s2t_ffn_args {
   float drop_h_p; uint32_t drop_h_site;
   float drop_o_p; uint32_t drop_o_site;
   const uint64_t* drop_seed;
+  /* optional exchange workspace of s2t_ffn_pair_ws_bytes(M) bytes, ZERO before its first use and owned by one stream: with
+   * it, row counts that would leave most CUs idle run two workgroups per 128-row block, each on half of the hidden units,
+   * which swap fp32 partial rows through it (csrc/ffn_pc.hip).  The kernels leave its flag words zero again. */
+  void* pair_ws; int64_t pair_ws_bytes;
 } s2t_ffn_args;
 int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
+int64_t s2t_ffn_pair_ws_bytes(int32_t M);
 
 /* s2t_ffn_fused_bwd: the input gradient of the same block's two products in one launch (what autograd derives from the
  * two F.linear, the activation and the hidden dropout of s2t_transformer_layer.py:55-66):
@@ -508,6 +513,7 @@ typedef struct s2t_ffn_bwd_args {
   float* end_ws; int32_t end_replicas;
   void* dres_out; void* dy_out;
   float drop_o_p; uint32_t drop_o_site;
+  void* pair_ws; int64_t pair_ws_bytes; /* as in s2t_ffn_args */
 } s2t_ffn_bwd_args;
 int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* args, void* stream);
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ uint4 add_bias8(uint4 qv, const float* __restrict__ b
   for (int t = 0; t < 4; ++t) {
     const float a = __uint_as_float(w[t] << 16) + bias[2 * t];
     const float b = __uint_as_float(w[t] & 0xffff0000u) + bias[2 * t + 1];
-    o[t] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+    o[t] = bf16pack(a, b);
   }
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -159,7 +159,7 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
   uint32_t o[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) o[t] = (uint32_t)f2bf(v[2 * t]) | ((uint32_t)f2bf(v[2 * t + 1]) << 16);
+  for (int t = 0; t < 4; ++t) o[t] = bf16pack(v[2 * t], v[2 * t + 1]);
   return as_frag(make_uint4(o[0], o[1], o[2], o[3]));
 }
 

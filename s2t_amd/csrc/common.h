@@ -21,6 +21,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// two fp32 -> one dword of two bf16 (a in the low half): ONE v_cvt_pk_bf16_f32.  (The scalar form
+// (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16) compiles to two conversions, a shift and an SDWA or: four VALU issues per pair
+// in epilogues that are VALU-issue bound.)
+typedef float s2t_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 s2t_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16pack(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((s2t_f32x2){a, b}, s2t_bf16x2));
+}
+
 template <typename T>
 __device__ __forceinline__ float ld_as_f32(const T* p);
 template <>
@@ -58,8 +67,8 @@ __device__ __forceinline__ void st4_from_f32<float>(float* p, const float (&v)[4
 template <>
 __device__ __forceinline__ void st4_from_f32<bf16_t>(bf16_t* p, const float (&v)[4]) {
   uint2 t;
-  t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  t.x = bf16pack(v[0], v[1]);
+  t.y = bf16pack(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = t;
 }
 

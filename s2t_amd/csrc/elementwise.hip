@@ -223,10 +223,10 @@ __global__ __launch_bounds__(256) void add_colsum2_bf16_kernel(bf16_t* __restric
       o[2 * q + 1] = a1 + b1;
     }
     uint4 t;
-    t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-    t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-    t.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
-    t.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+    t.x = bf16pack(o[0], o[1]);
+    t.y = bf16pack(o[2], o[3]);
+    t.z = bf16pack(o[4], o[5]);
+    t.w = bf16pack(o[6], o[7]);
     *reinterpret_cast<uint4*>(dst) = t;
   };
   int64_t m = r0 + rg;

@@ -518,8 +518,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args 
     if (m < p.M && n < p.N) {
       bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + coff + (int64_t)m * p.ldc + n;
       if (n + 3 < p.N && (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 7) == 0 && (coff & 3) == 0) {
-        const uint32_t lo = (uint32_t)f2bf(p.alpha * sum[0]) | ((uint32_t)f2bf(p.alpha * sum[1]) << 16);
-        const uint32_t hi = (uint32_t)f2bf(p.alpha * sum[2]) | ((uint32_t)f2bf(p.alpha * sum[3]) << 16);
+        const uint32_t lo = bf16pack(p.alpha * sum[0], p.alpha * sum[1]);
+        const uint32_t hi = bf16pack(p.alpha * sum[2], p.alpha * sum[3]);
         *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
       } else {
 #pragma unroll

@@ -273,10 +273,10 @@ __device__ __forceinline__ void st8(X* ptr, bool vec, int nv, const float (&o)[8
   if (vec && nv == 8) {
     if constexpr (sizeof(X) == 2) {
       uint4 t;
-      t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-      t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-      t.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
-      t.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+      t.x = bf16pack(o[0], o[1]);
+      t.y = bf16pack(o[2], o[3]);
+      t.z = bf16pack(o[4], o[5]);
+      t.w = bf16pack(o[6], o[7]);
       *reinterpret_cast<uint4*>(ptr) = t;
     } else {
       *reinterpret_cast<float4*>(ptr) = make_float4(o[0], o[1], o[2], o[3]);

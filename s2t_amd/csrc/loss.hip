@@ -153,7 +153,7 @@ __device__ __forceinline__ void row_map(const T* __restrict__ row, T* __restrict
         for (int q = 0; q < 4; ++q) {
           const float a = g(i * 8 + 2 * q, __uint_as_float(w[q] << 16));
           const float b = g(i * 8 + 2 * q + 1, __uint_as_float(w[q] & 0xffff0000u));
-          o[q] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+          o[q] = bf16pack(a, b);
         }
       } else {
 #pragma unroll

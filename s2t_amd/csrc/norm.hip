@@ -180,10 +180,10 @@ __device__ __forceinline__ void unpack8(const uint4 t, float (&v)[8]) {
 }
 __device__ __forceinline__ uint4 pack8f(const float (&o)[8]) {
   uint4 t;
-  t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-  t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-  t.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
-  t.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+  t.x = bf16pack(o[0], o[1]);
+  t.y = bf16pack(o[2], o[3]);
+  t.z = bf16pack(o[4], o[5]);
+  t.w = bf16pack(o[6], o[7]);
   return t;
 }
 

@@ -28,6 +28,7 @@
 //   the final row-wise epilogue runs on whole 512-byte rows (coalesced stores, LayerNorm statistics by shuffles).
 #include "common.h"
 #include "lds_dma.h"
+#include "ffn_args.h"
 
 #ifndef S2T_RB_SAVE_AUX
 #define S2T_RB_SAVE_AUX 0  // cache-policy bits of the stores of the saves (z, h, dZ): 2 = nt (streaming)
@@ -53,33 +54,6 @@ constexpr int LDS_Z = LDS_MBOX + 16384;  // backward: two 8 KiB stages of the pr
 constexpr int MAXF = 1 << 20;
 constexpr int LDS_BYTES = LDS_MBOX + 32768;   // 160 KiB in all
 
-// kernel arguments: the forward's public struct + what only the backward flavour uses (LayerNorm backward in the epilogue)
-struct FfnK : s2t_ffn_args {
-  const void* lb_x;        // [M][256] bf16 input of the leading LayerNorm (NULL: the epilogue stores dxn as it is)
-  const float* lb_gamma;
-  const float* lb_mean;
-  const float* lb_rstd;
-  const void* lb_dres;     // gradient arriving on the residual branch, added to dx (may be NULL)
-  float* lb_ws;            // [replicas][2][256] fp32 partial sums of dgamma | dbeta (atomics)
-  int lb_replicas;
-  void* lb_dx;             // [M][256] bf16
-  void* lb_dx_drop;        // optional dropout(dx) under the mask (lb_drop_p, lb_drop_site)
-  float lb_drop_p;
-  uint32_t lb_drop_site;
-  // backward of the LayerNorm BEHIND the block (final_norm) in the prologue: x is then the gradient w.r.t. that LayerNorm's
-  // output, the kernel derives dres (gradient w.r.t. the block output y) and its dropped image (the products' input)
-  const void* pl_y;        // [M][256] bf16 block output the LayerNorm normalised (NULL: x is used as it is)
-  const float* pl_gamma;
-  const float* pl_mean;
-  const float* pl_rstd;
-  const int32_t* pl_lens;  // padded-frame mask of that LayerNorm's output (rows t >= lens[b] carry no gradient)
-  int pl_T;
-  float* pl_ws;            // [replicas][2][256] partial sums of its dgamma | dbeta
-  int pl_replicas;
-  void* pl_dres;           // [M][256] bf16 out
-  void* pl_dy;             // [M][256] bf16 out: dropout(dres) under (drop_o_p, drop_o_site); NULL without output dropout
-};
-
 __device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 #if S2T_RB_DBG & 2
@@ -89,7 +63,7 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #endif
 }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return bf16pack(a, b); }
 
 // 8 fp32 -> 8 bf16, one 16-byte store
 __device__ __forceinline__ void st8row(bf16_t* ptr, const float (&v)[8]) {
@@ -1602,6 +1576,39 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
 
 }  // namespace
 
+// csrc/ffn_pc.hip: the 128-row producer / consumer form (mode 0 eval, 1 training forward, 2 backward)
+int s2t_ffn_pc_launch(const void* kargs, int mode, int split, int drop, void* stream);
+
+namespace {
+constexpr int PC_RB = 128;
+// S2T_FFN_PC=0 keeps the 64-row kernels of this file (A/B switch)
+bool pc_enabled() {
+  static const bool on = [] { const char* e = getenv("S2T_FFN_PC"); return !(e && e[0] == '0'); }();
+  return on;
+}
+int pc_num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+    return v;
+  }();
+  return n;
+}
+// two workgroups per 128-row block (each on half of the hidden units) when the whole grid is then resident at once — the
+// partners wait for each other — and the caller gave the exchange workspace
+int pc_split(int M, int F, const void* ws, int64_t ws_bytes) {
+  static const int force = [] { const char* e = getenv("S2T_FFN_PC_SPLIT"); return e ? atoi(e) : 0; }();
+  const int P = (M + PC_RB - 1) / PC_RB;
+  if (force == 1 || !ws || ws_bytes < s2t_ffn_pair_ws_bytes(M) || ((uintptr_t)ws % 16) || (F % 128)) return 1;
+  return 2 * P <= pc_num_cus() ? 2 : 1;
+}
+}  // namespace
+
+extern "C" int64_t s2t_ffn_pair_ws_bytes(int32_t M) {
+  const int64_t P = (M + PC_RB - 1) / PC_RB;
+  return P * 2 * 64 * 256 * 4 + ((P * 2 + 1) * 4 + 15) / 16 * 16;   // fp32 partial rows, then the flags + one error word
+}
+
 extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   if (!a || !a->x || !a->w1 || !a->b1 || !a->w2 || !a->b2) return S2T_ERR_ARG;
   if (a->M <= 0 || a->F <= 0) return S2T_ERR_ARG;
@@ -1625,6 +1632,14 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   const bool drop = a->drop_h_p > 0.f || a->drop_o_p > 0.f;
   FfnK k = {};
   static_cast<s2t_ffn_args&>(k) = *a;
+  if (pc_enabled()) {
+    const int split = pc_split(a->M, a->F, a->pair_ws, a->pair_ws_bytes);
+    if (split == 2) {
+      k.xws = reinterpret_cast<float*>(a->pair_ws);
+      k.xflags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a->pair_ws) + (int64_t)((a->M + PC_RB - 1) / PC_RB) * 2 * 64 * 256 * 4);
+    }
+    return s2t_ffn_pc_launch(&k, train ? 1 : 0, split, drop ? 1 : 0, stream);
+  }
 #define GO(T, A, DR) hipLaunchKernelGGL((ffn_fused_fwd_kernel<T, A, DR>), grid, block, 0, s, k)
 #define GO_A(T, DR)                                     \
   do {                                                  \
@@ -1705,6 +1720,14 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   const dim3 grid((a.M + TM - 1) / TM), block(512);
   hipStream_t s = (hipStream_t)stream;
   const bool drop = a.drop_h_p > 0.f;
+  if (pc_enabled()) {
+    const int split = pc_split(b->M, b->F, b->pair_ws, b->pair_ws_bytes);
+    if (split == 2) {
+      a.xws = reinterpret_cast<float*>(b->pair_ws);
+      a.xflags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(b->pair_ws) + (int64_t)((b->M + PC_RB - 1) / PC_RB) * 2 * 64 * 256 * 4);
+    }
+    return s2t_ffn_pc_launch(&a, 2, split, drop ? 1 : 0, stream);
+  }
 #define GO(A, DR) hipLaunchKernelGGL((ffn_fused_fwd_kernel<2, A, DR>), grid, block, 0, s, a)
   if (a.act == S2T_ACT_RELU) { if (drop) GO(S2T_ACT_RELU, true); else GO(S2T_ACT_RELU, false); }
   else if (a.act == S2T_ACT_SWISH) { if (drop) GO(S2T_ACT_SWISH, true); else GO(S2T_ACT_SWISH, false); }

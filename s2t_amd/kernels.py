@@ -94,6 +94,18 @@ def ffn_fused_supported(x, F, M=None):
     return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 256 and F % 64 == 0 and (x.shape[0] + 64) * F < 2 ** 31
 
 
+def _ffn_pair_ws(a, M, device):
+    """Exchange workspace of the two-workgroups-per-block form (s2t_ffn_pair_ws_bytes): zero at first use, one per stream."""
+    need = L.lib().s2t_ffn_pair_ws_bytes(M)
+    key = ("ffn_pair", str(device), L.stream_ptr())
+    t = _WS.get(key)
+    if t is None or t.numel() * 4 < need:
+        t = torch.zeros((need + 3) // 4, dtype=torch.float32, device=device)
+        _WS[key] = t
+    a.pair_ws, a.pair_ws_bytes = t.data_ptr(), t.numel() * 4
+    return t
+
+
 def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=None, ln_eps=1e-5, end_ln=None, y_ln=None,
                   end_stats=None, end_lens=None, end_T=0, x_ln=None, ln_stats=None, z=None, h=None, drop_h=None,
                   drop_o=None):
@@ -128,6 +140,7 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
         assert seed is None or seed.data_ptr() == drop_o[1].data_ptr()
         a.drop_o_p, a.drop_o_site, seed = float(drop_o[0]), int(drop_o[2]), drop_o[1]
     a.drop_seed = _ptr(seed)
+    _ffn_pair_ws(a, M, x.device)
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -173,6 +186,7 @@ def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=N
             dr = end["drop"]
             assert a.drop_seed is None or a.drop_seed == dr[1].data_ptr()
             a.dy_out, a.drop_o_p, a.drop_o_site, a.drop_seed = end["dy"].data_ptr(), float(dr[0]), int(dr[2]), dr[1].data_ptr()
+    _ffn_pair_ws(a, M, dy.device)
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
