@@ -546,13 +546,18 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
             for (int k = 0; k < 2; ++k) sv[k] = *reinterpret_cast<const uint4*>(mcell(c, pc >> 1, pc & 1, 8 * (2 * (nt - 6) + k) + (lane >> 3)));
           }
         }
-        piece(nt);
+        piece(nt, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) yacc[nt] = mfma32(frag(R[nt & 1][s]), hb[s], yacc[nt]);
+        for (int s = 0; s < 2; ++s) yacc[nt] = mfma32(frag(R[nt & 1][s]), hb[s], yacc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+        piece(nt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 2; s < 4; ++s) yacc[nt] = mfma32(frag(R[nt & 1][s]), hb[s], yacc[nt]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (SAVE) {
-          if (nt >= 6) {
+          if (nt >= 6) {  // behind the last DMA piece of the iteration (the pieces end with group 6's first pair)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
               const int rr = 8 * (2 * (nt - 6) + k) + (lane >> 3);
@@ -581,15 +586,18 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
     for (int c = 1; c < nchunks; ++c) {
       const bool more = c + 1 < nchunks;
       LSTAMP(0);
-      g2(c - 1, [&](int nt) __attribute__((always_inline)) {
-        // 16 pieces behind the first six groups; the last two groups carry none (the saves follow them)
-        if (nt < 4) {
-          if (more) dma_w1(c + 1, 2 * nt, 2 * nt + 2);
-          dma_w2(c, nt, nt + 1);
-        } else if (nt < 6) {
-          dma_w2(c, 4 + 2 * (nt - 4), 6 + 2 * (nt - 4));
+      g2(c - 1, [&](int nt, int half) __attribute__((always_inline)) {
+        // 16 pieces dealt over the first thirteen pairs of MFMAs, the first three pairs carrying two (a burst of pieces
+        // queues behind the other waves' at the memory pipe and parks this wave, MFMAs unissued, for over a hundred cycles a
+        // piece); the saves of groups 6 and 7 follow the last piece
+        const int k = 2 * nt + half;       // pair 0 .. 15
+        const int p0 = k < 3 ? 2 * k : k + 3, p1 = k < 3 ? 2 * k + 2 : k + 4;   // pieces p0 .. p1-1 of 16
+#pragma unroll
+        for (int q = p0; q < p1 && q < 16; ++q) {
+          if (q < 8) { if (more) dma_w1(c + 1, q, q + 1); }
+          else dma_w2(c, q - 8, q - 7);
         }
-        if (nt == 4) LSTAMP(1);
+        if (nt == 4 && half == 0) LSTAMP(1);
       });
       LSTAMP(2);
       const bool pf = pf_wg && c + 2 < nchunks;
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       LACC();
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");
-    g2(nchunks - 1, [&](int) __attribute__((always_inline)) {});
+    g2(nchunks - 1, [&](int, int) __attribute__((always_inline)) {});
   }
   PSTAMP(2);
   __syncthreads();

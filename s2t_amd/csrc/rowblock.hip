@@ -1579,12 +1579,16 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
 // csrc/ffn_pc.hip: the 128-row producer / consumer form (mode 0 eval, 1 training forward, 2 backward)
 int s2t_ffn_pc_launch(const void* kargs, int mode, int split, int drop, void* stream);
 
+#ifndef S2T_FFN_PC_DEFAULT
+#define S2T_FFN_PC_DEFAULT 5
+#endif
 namespace {
 constexpr int PC_RB = 128;
-// S2T_FFN_PC=0 keeps the 64-row kernels of this file (A/B switch)
-bool pc_enabled() {
-  static const bool on = [] { const char* e = getenv("S2T_FFN_PC"); return !(e && e[0] == '0'); }();
-  return on;
+// S2T_FFN_PC = bit mask of the flavours that run the 128-row producer / consumer kernel instead of the 64-row kernels of this
+// file: 1 eval, 2 training forward, 4 backward.  Default: what measured faster on MI355X at the headline shape.
+bool pc_enabled(int mode) {
+  static const int mask = [] { const char* e = getenv("S2T_FFN_PC"); return e ? atoi(e) : S2T_FFN_PC_DEFAULT; }();
+  return (mask >> mode) & 1;
 }
 int pc_num_cus() {
   static const int n = [] {
@@ -1632,7 +1636,7 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   const bool drop = a->drop_h_p > 0.f || a->drop_o_p > 0.f;
   FfnK k = {};
   static_cast<s2t_ffn_args&>(k) = *a;
-  if (pc_enabled()) {
+  if (pc_enabled(train ? 1 : 0)) {
     const int split = pc_split(a->M, a->F, a->pair_ws, a->pair_ws_bytes);
     if (split == 2) {
       k.xws = reinterpret_cast<float*>(a->pair_ws);
@@ -1720,7 +1724,7 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   const dim3 grid((a.M + TM - 1) / TM), block(512);
   hipStream_t s = (hipStream_t)stream;
   const bool drop = a.drop_h_p > 0.f;
-  if (pc_enabled()) {
+  if (pc_enabled(2)) {
     const int split = pc_split(b->M, b->F, b->pair_ws, b->pair_ws_bytes);
     if (split == 2) {
       a.xws = reinterpret_cast<float*>(b->pair_ws);

@@ -6,8 +6,8 @@ import torch
 from s2t_amd import kernels as K
 
 DEV = "cuda"
-M, d, F = 16000, 256, 2048
-NB = 12
+M, d, F = int(os.environ.get("PROBE_M", "16000")), 256, 2048
+NB = 12 if M <= 16000 else 3
 g = torch.Generator().manual_seed(0)
 xs = [torch.randn(M, d, generator=g).bfloat16().to(DEV) for _ in range(NB)]
 ws1 = [(torch.randn(F, d, generator=g) * d ** -0.5).bfloat16().to(DEV) for _ in range(NB)]
