@@ -1601,7 +1601,10 @@ int pc_num_cus() {
 // two workgroups per 128-row block (each on half of the hidden units) when the whole grid is then resident at once — the
 // partners wait for each other — and the caller gave the exchange workspace
 int pc_split(int M, int F, const void* ws, int64_t ws_bytes) {
-  static const int force = [] { const char* e = getenv("S2T_FFN_PC_SPLIT"); return e ? atoi(e) : 0; }();
+  // S2T_FFN_PC_SPLIT=1 pins one workgroup per block (read at every call: the two forms add the hidden units' products in
+  // different orders, so results that must match bit for bit across DIFFERENT row counts need one of them pinned)
+  const char* fe = getenv("S2T_FFN_PC_SPLIT");
+  const int force = fe ? atoi(fe) : 0;
   const int P = (M + PC_RB - 1) / PC_RB;
   if (force == 1 || !ws || ws_bytes < s2t_ffn_pair_ws_bytes(M) || ((uintptr_t)ws % 16) || (F % 128)) return 1;
   return 2 * P <= pc_num_cus() ? 2 : 1;
