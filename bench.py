@@ -24,6 +24,21 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_BF16 = 2.5e15  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_F32 = 157.3e12
+PMC_FILE = "r03_pmc_traffic.json"
+
+
+def csrc_hash():
+    """sha256 over the kernel sources (s2t_amd/csrc/*, include/*.h, sorted by name): ties a PMC traffic table to a build."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "s2t_amd", "csrc"), os.path.join(ROOT, "include")):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h")):
+                h.update(name.encode())
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(f.read())
+    return h.hexdigest()
 
 
 def _launch_ranks(n):
@@ -56,7 +71,7 @@ def synthetic_batch(B, T, V, seed, device):
     for b, l in enumerate(lens):
         src[b, l:] = 0
     ul = [int(torch.randint(20, 61, (1,), generator=g)) for _ in range(B)]
-    U = max(ul) + 1
+    U = 61  # 60 tokens + eos: every synthetic batch has the same target width, so batches can rotate through one captured step
     target = torch.full((B, U), 1, dtype=torch.long)
     prev = torch.full((B, U), 1, dtype=torch.long)
     for b, u in enumerate(ul):
@@ -132,6 +147,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="dropout / attention-dropout / activation-dropout (base.yaml: 0.1)")
     ap.add_argument("--enc-layers", type=int, default=12)
     ap.add_argument("--dec-layers", type=int, default=6)
+    ap.add_argument("--rotate", type=int, default=4, help="distinct synthetic batches cycled through the timed loop (>= 1)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -207,11 +223,18 @@ def main():
                                         reduce_dtype=torch.bfloat16 if red == "bf16" else torch.float32) \
         if (world > 1 or force_ddp) else None
     trainer = Trainer(model, crit, ddp=ddp)
-    sample, frames_local = synthetic_batch(args.batch, args.frames, V, 1 + rank, dev)
-    ft = torch.tensor([frames_local, sample["ntokens"]], dtype=torch.float64)
+    # args.rotate distinct batches (different utterance lengths, features and targets, identical tensor shapes): the timed loop
+    # hands a DIFFERENT batch to every step, so the copy into the captured step's static tensors and the per-batch
+    # bookkeeping outside the graph (lengths, masks, positions, CTC target matrices: functional.batch_memo) are inside the clock
+    # — the reference computes those inside forward()
+    nrot = max(1, args.rotate)
+    batches = [synthetic_batch(args.batch, args.frames, V, 1 + rank + 1000 * i, dev) for i in range(nrot)]
+    ft = torch.tensor([[fr, smp["ntokens"]] for smp, fr in batches], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(ft)
-    frames_global, ntok_global = int(ft[0]), int(ft[1])
+    frames_rot = [int(v) for v in ft[:, 0]]
+    ntok_rot = [int(v) for v in ft[:, 1]]
+    sample, frames_global, ntok_global = batches[0][0], frames_rot[0], ntok_rot[0]
 
     use_graph = not args.no_graph
     if use_graph:
@@ -226,20 +249,22 @@ def main():
             use_graph = False
             torch.cuda.synchronize()
 
-    def step():
+    def step(i):
+        smp = batches[i % nrot][0]
         if use_graph:
-            return trainer.replay()
-        return trainer.train_step(sample, ntok_global)
+            return trainer.replay(smp, ntok_rot[i % nrot])
+        return trainer.train_step(smp, ntok_rot[i % nrot])
 
-    for _ in range(args.warmup):
-        out = step()
+    for i in range(args.warmup):
+        out = step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
     torch.cuda.synchronize()
+    frames_timed = sum(frames_rot[(args.warmup + i) % nrot] for i in range(args.steps))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -299,20 +324,36 @@ def main():
         gemm_total = sum(v[1] for v in agg.values())
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the per-launch figure comes
         # from the committed rocprofv3 --pmc passes of this same command (tools/pmc.sh + tools/pmc_traffic.py)
-        traffic = None
+        # — and only while that file was collected from THIS kernel source: it records a hash of s2t_amd/csrc + include/, a
+        # figure from another build of the kernels is refused (traffic = null, reason in traffic_note)
+        traffic, traffic_note = None, None
+        pmc_tables = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-                for row in json.load(f)["kernels"]:
-                    if sym in row["kernel"]:
-                        traffic = row["hbm_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+                pmc = json.load(f)
+            if pmc.get("csrc_sha256") != csrc_hash():
+                traffic_note = "profiles/%s was collected from other kernel sources (csrc hash differs): refused" % PMC_FILE
+            else:
+                pmc_tables = {row["kernel"]: row["hbm_bytes_per_launch"] for row in pmc["kernels"]}
+                for kname, val in pmc_tables.items():
+                    if sym in kname:
+                        traffic = val
                         break
-        except (OSError, ValueError, KeyError):
-            pass
+                if traffic is None:
+                    traffic_note = "kernel not in profiles/%s" % PMC_FILE
+        except (OSError, ValueError, KeyError) as e:
+            traffic_note = "profiles/%s unreadable (%s)" % (PMC_FILE, type(e).__name__)
         roofline = {"bound": "mfma", "kernel": sym, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                    "frac": fl / sec / peak, "traffic": traffic, "launches_per_step": cnt,
+                    "frac": fl / sec / peak, "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": cnt,
                     "avg_launch_us": sec / cnt * 1e6, "event_pair_overhead_us": ev_over * 1e6,
                     "all_gemm_ms_per_step": gemm_total * 1e3,
                     "all_gemm_tflops": sum(v[0] for v in agg.values()) / gemm_total / 1e12}
+        # every flavour of the fused feed-forward kernel in the step (training forward and backward are within a few microseconds
+        # of each other: both are reported, not whichever totals more)
+        roofline["ffn_flavours"] = {
+            k: {"launches_per_step": v[2], "avg_launch_us": v[1] / v[2] * 1e6, "achieved": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / peak,
+                "traffic": next((t for kn, t in pmc_tables.items() if k in kn), None)}
+            for k, v in agg.items() if k.startswith("ffn_")}
         # encoder-forward-only fraction of the MFMA roofline (18.0 MFLOP per input frame for the 12-layer
         # Conformer encoder, 9.7 for the Transformer one; + 1.28 with the CTC head), eval mode, no autograd
         model.eval()
@@ -356,7 +397,7 @@ def main():
             cpu = cpu_baseline(args, V, conformer)
         result = {
             "metric": "speech-frames/sec (enc+dec fwd+bwd+update), 12L Conformer, 1000x80 fbank",
-            "value": frames_global * args.steps / dt,
+            "value": frames_timed / dt,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -370,7 +411,8 @@ def main():
             "config": {
                 "workload": "s2t_transformer_s %s %d-enc/%d-dec d256 F2048 h4 V%d, per-GPU batch %dx%dx80, CE(ls0.1)+0.3*CTC, "
                             "Adam+clip10, dropout %.2f" % (args.arch, args.enc_layers, args.dec_layers, V, args.batch, args.frames, args.dropout),
-                "global_batch": args.batch * world, "frames_per_step": frames_global, "parallelism": "dp%d" % world,
+                "global_batch": args.batch * world, "frames_per_step": frames_timed / args.steps, "parallelism": "dp%d" % world,
+                "batches_rotated": nrot,
                 "hip_graph": use_graph, "final_loss": loss_val,
                 "grad_allreduce": (("rccl (s2t_allreduce_bucket, %s buckets) inside the step graph, overlapped with backward"
                                     % ("bf16" if ddp is not None and ddp.reduce_dtype == torch.bfloat16 else "fp32"))

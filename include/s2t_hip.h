@@ -470,6 +470,8 @@ typedef struct s2t_ffn_args {
 } s2t_ffn_args;
 int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
 int64_t s2t_ffn_pair_ws_bytes(int32_t M);
+/* the kernel symbol s2t_ffn_fused_fwd launches for these arguments, as a profiler prints it (buf: >= 96 bytes) */
+int s2t_ffn_fused_describe(const s2t_ffn_args* args, char* buf, int32_t buf_bytes);
 
 /* s2t_ffn_fused_bwd: the input gradient of the same block's two products in one launch (what autograd derives from the
  * two F.linear, the activation and the hidden dropout of s2t_transformer_layer.py:55-66):
@@ -516,6 +518,7 @@ typedef struct s2t_ffn_bwd_args {
   void* pair_ws; int64_t pair_ws_bytes; /* as in s2t_ffn_args */
 } s2t_ffn_bwd_args;
 int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* args, void* stream);
+int s2t_ffn_fused_bwd_describe(const s2t_ffn_bwd_args* args, char* buf, int32_t buf_bytes);
 
 /* dst_i [cols_i][rows_i] = src_i [rows_i][cols_i]^T for n bf16 matrices in one launch; items_dev: device array;
  * tiles_dev: device array of n_tiles (matrix index, row tile, column tile) int32 triples, 64 x 64 tiles, covering every

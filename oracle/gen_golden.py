@@ -439,6 +439,10 @@ def nast_case(name, outdir, V, B, T, seed, **kw):
     had = getattr(ctc_mod, "best_alignment", None)
     ctc_mod.best_alignment = best_alignment_standin
     torch.rand, s2mod.uniform = rec_rand, rec_unif
+    # the league drop-net draws come from numpy's GLOBAL generator (modules/transformer_s2_layer.py: numpy.random.uniform):
+    # seed it, and torch's, here so that the recorded draws — and with them the whole fixture — regenerate bit for bit
+    np.random.seed(seed + 400)
+    torch.manual_seed(seed + 500)
     try:
         model.zero_grad()
         loss, sample_size, log = crit(model, sample)
@@ -661,6 +665,53 @@ def trainer_case(name, outdir, arch, V, B, T, seed, updates=5, **kw):
     print(name, "losses", losses, "gnorm", gnorms, "lr", lrs)
 
 
+def check(committed):
+    """``gen_golden.py --check <dir>``: regenerate every fixture (or the GOLDEN_ONLY group) into a temporary directory and
+    compare with the committed ``.npz`` files key by key.  fairseq's uninitialised ``_float_tensor`` buffers are skipped.
+    Exit status 1 on any difference beyond 1e-6 of a tensor's scale (threading can move the last bits of a CPU GEMM)."""
+    import glob
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="golden_check_")
+    sys.argv[1] = tmp
+    main()
+    bad = 0
+    for f in sorted(glob.glob(os.path.join(tmp, "*.npz"))):
+        name = os.path.basename(f)
+        ref = os.path.join(committed, name)
+        if not os.path.exists(ref):
+            print("MISSING in", committed, ":", name)
+            bad += 1
+            continue
+        a, b = np.load(f, allow_pickle=True), np.load(ref, allow_pickle=True)
+        keys_a = {k for k in a.files if "_float_tensor" not in k}
+        keys_b = {k for k in b.files if "_float_tensor" not in k}
+        if keys_a != keys_b:
+            print("KEYS differ in", name, sorted(keys_a ^ keys_b)[:8])
+            bad += 1
+        worst, worst_key = 0.0, None
+        for k in sorted(keys_a & keys_b):
+            x, y = a[k], b[k]
+            if x.shape != y.shape or x.dtype != y.dtype:
+                print("SHAPE/DTYPE differs:", name, k, x.shape, y.shape, x.dtype, y.dtype)
+                bad += 1
+                continue
+            if x.dtype.kind in "fc":
+                scale = max(float(np.abs(y).max()) if y.size else 0.0, 1e-30)
+                d = float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()) / scale if y.size else 0.0
+            else:
+                d = 0.0 if np.array_equal(x, y) else 1.0
+            if d > worst:
+                worst, worst_key = d, k
+        print("%-34s %d keys, worst relative difference %.2e%s" % (name, len(keys_a & keys_b), worst, (" (" + worst_key + ")") if worst_key else ""))
+        if worst > 1e-6:
+            bad += 1
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("GOLDEN_CHECK", "FAILED" if bad else "OK")
+    sys.exit(1 if bad else 0)
+
+
 def main():
     outdir = sys.argv[1]
     os.makedirs(outdir, exist_ok=True)
@@ -833,4 +884,7 @@ def main():
 
 
 if __name__ == "__main__":
+    if sys.argv[1] == "--check":
+        sys.argv.pop(1)
+        check(sys.argv[1])
     main()

@@ -1664,6 +1664,26 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   return S2T_LAUNCH_CHECK();
 }
 
+namespace {
+int ffn_describe(int mode, int act, bool drop, int M, int F, const void* ws, int64_t ws_bytes, char* buf, int n) {
+  if (!buf || n < 96) return S2T_ERR_ARG;
+  if (pc_enabled(mode)) snprintf(buf, n, "ffn_pc_kernel<%d, %d, %s, %d>", mode, act, drop ? "true" : "false", pc_split(M, F, ws, ws_bytes));
+  else snprintf(buf, n, "ffn_fused_fwd_kernel<%d, %d, %s>", mode, act, drop ? "true" : "false");
+  return S2T_OK;
+}
+}  // namespace
+
+extern "C" int s2t_ffn_fused_describe(const s2t_ffn_args* a, char* buf, int32_t n) {
+  if (!a) return S2T_ERR_ARG;
+  const bool train = a->z || a->h || a->x_ln || a->ln_mean || a->ln_rstd;
+  return ffn_describe(train ? 1 : 0, a->act, a->drop_h_p > 0.f || a->drop_o_p > 0.f, a->M, a->F, a->pair_ws, a->pair_ws_bytes, buf, n);
+}
+
+extern "C" int s2t_ffn_fused_bwd_describe(const s2t_ffn_bwd_args* b, char* buf, int32_t n) {
+  if (!b) return S2T_ERR_ARG;
+  return ffn_describe(2, b->act, b->drop_h_p > 0.f, b->M, b->F, b->pair_ws, b->pair_ws_bytes, buf, n);
+}
+
 extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   if (!b || !b->dy || !b->w2t || !b->w1t || !b->z || !b->dz) return S2T_ERR_ARG;
   if (b->end_y) {

@@ -83,6 +83,10 @@ class FlatParameters:
             else:
                 self.shadow.copy_(self.master)
 
+    def mark_transposed_stale(self):
+        """The transposed bf16 weight copies (``transposed``) no longer match the shadow: rewrite them at their next use."""
+        self._wt["fresh"] = False
+
     def zero_grad(self):
         self.grad.zero_()
 

@@ -146,9 +146,9 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
         e0.record()
         L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
         e1.record()
-        train = any(t is not None for t in (z, h, x_ln, ln_stats))
-        sym = "ffn_fused_fwd_kernel<%d, %d, %s>" % (1 if train else 0, a.act, "true" if (a.drop_h_p > 0 or a.drop_o_p > 0) else "false")
-        GEMM_PROFILE.append((sym, 4.0 * M * F * d, e0, e1, (M, F, d, 1)))  # the name rocprofv3 prints for this launch
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().s2t_ffn_fused_describe(C.byref(a), buf, 128), "s2t_ffn_fused_describe")
+        GEMM_PROFILE.append((buf.value.decode(), 4.0 * M * F * d, e0, e1, (M, F, d, 1)))  # the name rocprofv3 prints for this launch
         return
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
 
@@ -192,8 +192,9 @@ def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=N
         e0.record()
         L.check(L.lib().s2t_ffn_fused_bwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_bwd")
         e1.record()
-        sym = "ffn_fused_fwd_kernel<2, %d, %s>" % (a.act, "true" if a.drop_h_p > 0 else "false")
-        GEMM_PROFILE.append((sym, 4.0 * M * F * d, e0, e1, (M, F, d, 1)))
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().s2t_ffn_fused_bwd_describe(C.byref(a), buf, 128), "s2t_ffn_fused_bwd_describe")
+        GEMM_PROFILE.append((buf.value.decode(), 4.0 * M * F * d, e0, e1, (M, F, d, 1)))
         return
     L.check(L.lib().s2t_ffn_fused_bwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_bwd")
 

@@ -486,7 +486,7 @@ class _HipModel(model_base()):
 
     flat: Optional[FlatParameters] = None
     _compute_dtype = None
-    _master_version = -1
+    shadow_managed = False  # True: the owner of the optimizer step (s2t_amd.trainer.Trainer) refreshes the bf16 shadow itself
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -497,7 +497,6 @@ class _HipModel(model_base()):
         nn.Module.to(self, device)
         self.flat = FlatParameters(self, dtype)
         self._compute_dtype = dtype
-        self._master_version = self.flat.master._version
         for m in self.modules():
             if hasattr(m, "compute_dtype"):
                 m.compute_dtype = dtype
@@ -520,16 +519,21 @@ class _HipModel(model_base()):
             self.prepare(self._compute_dtype or torch.float32, dev)
         else:
             self.flat.reattach_grads()
-            if self.flat.master._version != self._master_version:  # an optimizer stepped the fp32 masters in place
+            # The bf16 shadow (and the transposed copies made from it) must follow the fp32 masters.  The bundled Trainer's
+            # s2t_adam_step rewrites the shadow itself (``shadow_managed``).  ANY other optimizer — torch.optim, fairseq's Adam
+            # under the reference trainer — steps ``p`` / ``p.data`` in place, which no version counter of the flat buffer
+            # records (each Parameter view has its own counter and ``.data`` aliases none), so the shadow is rewritten before
+            # every forward: one cast launch over the flat buffer.
+            if self.flat.shadow is not None and not self.shadow_managed:
                 self.flat.refresh_shadow()
-                self._master_version = self.flat.master._version
+                self.flat.mark_transposed_stale()
         return None
 
     def load_state_dict(self, state_dict, strict=True, model_cfg=None, args=None, **kw):
         r = nn.Module.load_state_dict(self, state_dict, strict=strict, **kw)
         if self.flat is not None:
             self.flat.refresh_shadow()
-            self._master_version = self.flat.master._version
+            self.flat.mark_transposed_stale()
         return r
 
 

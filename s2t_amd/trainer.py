@@ -21,6 +21,7 @@ class Trainer:
                  clip_norm=10.0, warmup_updates=10000, warmup_init_lr=1e-7):
         self.model, self.criterion, self.ddp = model, criterion, ddp
         self.flat = model.flat
+        model.shadow_managed = True  # s2t_adam_step rewrites the bf16 shadow with every update
         self.lr, self.betas, self.eps, self.wd, self.clip_norm = lr, betas, eps, weight_decay, clip_norm
         self.warmup_updates, self.warmup_init_lr = warmup_updates, warmup_init_lr
         dev = self.flat.master.device

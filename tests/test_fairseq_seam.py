@@ -139,3 +139,16 @@ def test_user_dir_registration_flags_and_checkpoint(override, tmp_path):
                 "S2T_REPO": ROOT, "S2T_REF": REF, "S2T_AMD_OVERRIDE": override})
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SEAM_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "fairseq")), reason="the reference is only present in the build container")
+@pytest.mark.parametrize("group", ["nast", "interctc"])
+def test_committed_fixtures_regenerate_from_the_reference(group, tmp_path):
+    """``oracle/gen_golden.py --check``: the committed golden vectors of a fixture group are what the reference produces
+    TODAY (regenerated into a temporary directory from the imported reference and compared key by key).  The ``nast`` group
+    holds the fixture whose training pass draws from numpy's global generator (seeded since round 3)."""
+    env = dict(os.environ)
+    env.update({"PYTHONPATH": REF + os.pathsep + os.path.join(ROOT, "oracle"), "PYTHONDONTWRITEBYTECODE": "1", "GOLDEN_ONLY": group})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden.py"), "--check", os.path.join(ROOT, "tests", "golden")],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "GOLDEN_CHECK OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])

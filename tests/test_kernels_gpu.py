@@ -375,6 +375,67 @@ def test_label_smoothed_ce(dtype):
     close(dl, lr.grad, dtype, 1 if dtype == torch.float32 else 0.5)
 
 
+def _ls_ce(logits, tgt, eps, pad=1):
+    rows, V = logits.shape
+    sums = torch.zeros(4, device=DEV)
+    K.ls_cross_entropy(logits.to(DEV).contiguous(), V, rows, V, tgt.to(DEV), pad, eps, None, 0, sums)
+    return sums.cpu()
+
+
+def _ls_fixture():
+    """The shape of the reference's own fixture (/root/reference/tests/test_label_smoothing.py:28-60): a batch of two target
+    rows of three positions over a small vocabulary, the second utterance one token shorter (its last position is padding,
+    index 1), fixed per-position distributions."""
+    g = torch.Generator().manual_seed(11)
+    V = 9
+    probs = torch.rand(2, 3, V, generator=g) + 0.05
+    probs = probs / probs.sum(-1, keepdim=True)
+    logits = probs.log() + 0.7  # any per-row shift: log_softmax removes it
+    target = torch.tensor([[4, 5, 2], [6, 2, 1]])
+    return logits, target
+
+
+def test_label_smoothing_nll_is_the_plain_cross_entropy():
+    """tests/test_label_smoothing.py:62-75 (test_nll_loss): the nll the smoothed criterion reports is CrossEntropy's loss."""
+    logits, target = _ls_fixture()
+    s = _ls_ce(logits.view(-1, logits.shape[-1]), target.view(-1), 0.1)
+    lp = torch.log_softmax(logits.view(-1, logits.shape[-1]), -1)
+    plain = torch.nn.functional.nll_loss(lp, target.view(-1), ignore_index=1, reduction="sum")
+    assert abs(float(s[1]) - float(plain)) < 1e-5
+    assert int(s[3]) == 5
+
+
+def test_label_smoothing_padding_adds_nothing():
+    """:77-95 (test_padding): the loss of the padded batch is the sum of the losses of its utterances run alone, unpadded."""
+    logits, target = _ls_fixture()
+    V = logits.shape[-1]
+    both = _ls_ce(logits.view(-1, V), target.view(-1), 0.1)
+    one = _ls_ce(logits[0], target[0], 0.1)
+    two = _ls_ce(logits[1, :2], target[1, :2], 0.1)
+    assert abs(float(both[0]) - float(one[0]) - float(two[0])) < 1e-5
+    assert abs(float(both[1]) - float(one[1]) - float(two[1])) < 1e-5
+
+
+def test_label_smoothing_reduction_is_the_sum_over_positions():
+    """:97-102 (test_reduction): the reduced loss equals the sum of the unreduced per-position losses (each position run as a
+    launch of its own here: the kernel only has the reduced form)."""
+    logits, target = _ls_fixture()
+    V = logits.shape[-1]
+    total = _ls_ce(logits.view(-1, V), target.view(-1), 0.1)
+    parts = sum(float(_ls_ce(logits.view(-1, V)[i:i + 1], target.view(-1)[i:i + 1], 0.1)[0]) for i in range(6))
+    assert abs(float(total[0]) - parts) < 1e-5
+
+
+def test_label_smoothing_zero_eps_is_nll():
+    """:104-116 (test_zero_eps): without smoothing the smoothed loss IS the nll."""
+    logits, target = _ls_fixture()
+    s = _ls_ce(logits.view(-1, logits.shape[-1]), target.view(-1), 0.0)
+    assert abs(float(s[0]) - float(s[1])) < 1e-6
+    lp = torch.log_softmax(logits.view(-1, logits.shape[-1]), -1)
+    plain = torch.nn.functional.nll_loss(lp, target.view(-1), ignore_index=1, reduction="sum")
+    assert abs(float(s[0]) - float(plain)) < 1e-5
+
+
 @pytest.mark.parametrize("longest", [15, 63, 70])
 @pytest.mark.parametrize("dtype", DT)
 def test_ctc_loss_fwd_bwd(dtype, longest):

@@ -220,3 +220,45 @@ def test_trainer_follows_the_reference_trajectory(golden_dir, mode):
                 continue
             got = sd[k[7:]].detach().float().cpu().numpy()
             assert np.abs(got - z[k]).max() <= 5e-3 * max(np.abs(z[k]).max(), 1e-3), k
+
+
+@pytest.mark.parametrize("style", ["torch_optim", "data_inplace"])
+def test_an_external_optimizer_moves_the_bf16_shadow(style):
+    """The fairseq seam in bf16: an optimizer that is NOT the bundled Trainer (torch.optim stepping ``p`` in place; fairseq's
+    Adam stepping ``p.data``, optim/adam.py:200-224) changes the fp32 masters behind the flat buffer's back — no version
+    counter of the flat buffer moves.  The next forward must nevertheless run on the NEW weights: the bf16 shadow (and the
+    transposed copies the fused backward kernels read) follow the masters, and the loss moves."""
+    model = _model(7)
+    assert model.shadow_managed is False
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    sample = _sample()
+    model.eval()  # no dropout: the two losses differ through the weights alone
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+
+    def loss_and_grad():
+        model.flat.zero_grad()
+        loss, _, _ = crit(model, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss)
+
+    l0 = loss_and_grad()
+    before = model.flat.master.clone()
+    if style == "torch_optim":
+        opt.step()
+    else:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.data.add_(p.grad.data, alpha=-0.5)
+    assert not torch.equal(before, model.flat.master), "the optimizer must have stepped the flat fp32 masters in place"
+    l1 = loss_and_grad()
+    assert torch.equal(model.flat.shadow, model.flat.master.bfloat16()), "stale bf16 shadow after an external optimizer step"
+    assert abs(l1 - l0) > 1e-3 * abs(l0), (l0, l1)
+    # and the same weights through a fresh model give the same loss: nothing else went stale
+    fresh = _model(7)
+    fresh.eval()
+    fresh.load_state_dict(model.state_dict())
+    crit2 = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    fresh.flat.zero_grad()
+    l2 = float(crit2(fresh, sample)[0])
+    assert abs(l2 - l1) <= 2e-3 * abs(l1), (l1, l2)

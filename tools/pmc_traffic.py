@@ -34,4 +34,8 @@ for r in rows[:40]:
     print("%9.2f MB rd %9.2f MB wr  x%5d  %s" % (r["read_bytes_per_launch"] / 1e6, r["write_bytes_per_launch"] / 1e6,
                                                   r["launches"], r["kernel"][:110]))
 if out_json:
-    json.dump({"unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", "kernels": rows}, open(out_json, "w"), indent=1)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_hash  # the table is only valid for the kernel sources it was collected from
+    json.dump({"unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", "csrc_sha256": csrc_hash(), "kernels": rows},
+              open(out_json, "w"), indent=1)
