@@ -492,6 +492,18 @@ class _HipModel(model_base()):
         super().__init__(*a, **k)
         self.register_forward_pre_hook(_HipModel._before_forward)
 
+    def __setattr__(self, name, value):
+        """The criteria enter through ``model.encoder(...)`` / ``model.decoder(...)``, not ``model(...)`` — the reference's do
+        too (criterions/label_smoothed_cross_entropy_with_ctc.py:80-95) — so the before-forward work hangs on those entry
+        modules as well."""
+        super().__setattr__(name, value)
+        if name in ("encoder", "decoder") and isinstance(value, nn.Module) and not getattr(value, "_s2t_entry_hook", False):
+            import weakref
+
+            value._s2t_entry_hook = True
+            owner = weakref.ref(self)
+            value.register_forward_pre_hook(lambda mod, args: _HipModel._before_forward(owner(), args) if owner() is not None else None)
+
     def prepare(self, dtype=torch.float32, device="cuda"):
         """Move to the GPU, flatten parameters (fp32 master + grads + bf16 shadow) and set the compute dtype."""
         nn.Module.to(self, device)

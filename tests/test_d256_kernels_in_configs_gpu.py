@@ -111,8 +111,8 @@ def _bf16_vs_oracle(model, args, B, T, seed):
         if k.endswith(("k_proj.bias", "linear_k.bias")):
             continue  # mathematically zero
         go = sum(W[k2].grad for k2 in W if ptr[k2] == ptr[k] and W[k2].grad is not None)
-        if "subsample" in k and go.dim() == 3:
-            go = go.permute(0, 2, 1)
+        if ("subsample" in k or ("downsampling" in k and ".conv." in k)) and go.dim() == 3:
+            go = go.permute(0, 2, 1)  # stored [Cout][k][Cin]
         gf = p.grad.detach().float().cpu()
         if go.shape != gf.shape:
             go = go.reshape(gf.shape)
@@ -131,9 +131,9 @@ def test_sate_d256_bf16_kernels_against_oracle_on_rounded_weights():
     med = float(np.median(list(errs.values())))
     print("SATE d256 bf16: loss %.5f, worst gradient %s %.4f, median %.4f, kernel calls %s" % (le, worst[0], worst[1], med, calls))
     assert calls["ffn"] >= 4 and calls["ffn_bwd"] >= 4 and calls["rb"] >= 4, calls  # the fast paths really ran
-    # measured on MI355X (round 3): loss 0.0003, worst 0.046, median 0.008; bounds at twice that
-    assert le < 1e-3
-    assert worst[1] < 1.0e-1, worst
+    # measured on MI355X (round 3): loss 0.00008, worst 0.036 (decoder.layers.1.fc1.weight), median 0.0084; bounds at twice that
+    assert le < 2e-4
+    assert worst[1] < 7.2e-2, worst
     assert med < 1.7e-2
 
 
@@ -149,10 +149,10 @@ def test_pds_conformer_d256_bf16_kernels_against_oracle_on_rounded_weights():
     med = float(np.median(list(errs.values())))
     print("PDS Conformer d256 bf16: loss %.5f, worst gradient %s %.4f, median %.4f, kernel calls %s" % (le, worst[0], worst[1], med, calls))
     assert calls["ffn"] >= 4 and calls["ffn_bwd"] >= 4 and calls["rb"] >= 4, calls
-    # measured on MI355X (round 3): see the bounds below at twice the measured error
-    assert le < 1e-3
-    assert worst[1] < 2.0e-1, worst
-    assert med < 3e-2
+    # measured on MI355X (round 3): loss 0.00002, worst 0.046 (decoder.layers.1.fc1.weight), median 0.0024; bounds at twice that
+    assert le < 2e-4
+    assert worst[1] < 9.2e-2, worst
+    assert med < 5e-3
 
 
 class _EncOnly(torch.nn.Module):

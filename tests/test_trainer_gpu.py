@@ -232,12 +232,16 @@ def test_an_external_optimizer_moves_the_bf16_shadow(style):
     assert model.shadow_managed is False
     crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
     sample = _sample()
-    model.eval()  # no dropout: the two losses differ through the weights alone
+    from s2t_amd import functional as Fn
+    model.train()  # (the convolution module's backward needs training-mode BatchNorm)
     opt = torch.optim.SGD(model.parameters(), lr=0.5)
 
-    def loss_and_grad():
-        model.flat.zero_grad()
-        loss, _, _ = crit(model, sample)
+    def loss_and_grad(m=None, cr=None):
+        m, cr = m or model, cr or crit
+        Fn.DROPOUT.begin_step(torch.device(DEV))
+        Fn.DROPOUT.set_seed(11)  # the same dropout masks every time: the losses differ through the weights alone
+        m.flat.zero_grad()
+        loss, _, _ = cr(m, sample)
         loss.backward()
         torch.cuda.synchronize()
         return float(loss)
@@ -256,9 +260,8 @@ def test_an_external_optimizer_moves_the_bf16_shadow(style):
     assert abs(l1 - l0) > 1e-3 * abs(l0), (l0, l1)
     # and the same weights through a fresh model give the same loss: nothing else went stale
     fresh = _model(7)
-    fresh.eval()
+    fresh.train()
     fresh.load_state_dict(model.state_dict())
     crit2 = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
-    fresh.flat.zero_grad()
-    l2 = float(crit2(fresh, sample)[0])
+    l2 = loss_and_grad(fresh, crit2)
     assert abs(l2 - l1) <= 2e-3 * abs(l1), (l1, l2)
