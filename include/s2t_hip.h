@@ -537,7 +537,7 @@ int s2t_transpose_bf16_batched(const s2t_transpose_item* items_dev, int n, const
  * pairs weight rows c and N/2 + c, Nout = N/2, optional pre-activation copy [M][N] value | gate); dropout on element
  * row*Nout + n; alpha; row_lens mask; residual.  x_ln / ln_mean / ln_rstd: optional saves of the LayerNorm for backward.
  * Constraints: d == 256, bf16 x / W / out / residual / preact, fp32 bias and LayerNorm parameters, 16-byte aligned pointers,
- * row strides multiples of 8 elements, N % 8 == 0 (GLU: N % 64 == 0). */
+ * row strides multiples of 8 elements, N % 8 == 0 (GLU: N % 64 == 0), N <= 4096 (S2T_ERR_UNSUPPORTED beyond). */
 typedef struct s2t_rowblock_args {
   const void* x;          /* [M][256] bf16 */
   const float* ln_gamma; const float* ln_beta; float ln_eps;

@@ -33,13 +33,17 @@ def init(rank=None, world=None, device=None):
         rank = dist.get_rank() if dist.is_initialized() else 0
     if device is not None:
         torch.cuda.set_device(device)
+    # Every rank must leave this function the same way: a failure on ONE rank (no loadable librccl on rank 0, a communicator
+    # that does not come up on rank 3) may not leave the others blocked in a collective.  Rank 0 therefore broadcasts
+    # (status, id) — not the bare id — and after s2t_comm_init the ranks agree on a common verdict over the host group.
     buf = C.create_string_buffer(128)
-    if rank == 0:
-        L.check(L.lib().s2t_comm_unique_id(buf), "s2t_comm_unique_id")
+    rc0 = L.lib().s2t_comm_unique_id(buf) if rank == 0 else 0
     if world > 1:
-        box = [bytes(buf.raw) if rank == 0 else None]
+        box = [(int(rc0), bytes(buf.raw)) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        buf = C.create_string_buffer(box[0], 128)
+        rc0, raw = box[0]
+        buf = C.create_string_buffer(raw, 128)
+    L.check(rc0, "s2t_comm_unique_id (on rank 0)")
     # RCCL prints a version banner to stdout when a communicator is created; stdout belongs to the caller (bench.py
     # prints ONE JSON line there), so fd 1 points at stderr for the duration of the call
     import os
@@ -53,7 +57,13 @@ def init(rank=None, world=None, device=None):
     finally:
         os.dup2(saved, 1)
         os.close(saved)
-    L.check(rc, "s2t_comm_init")
+    if world > 1:  # the worst status of any rank becomes everyone's: all take the library communicator or none does
+        verdict = torch.tensor([abs(int(rc))], dtype=torch.int64)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MAX)
+        if int(verdict) != 0 and rc == 0:
+            L.lib().s2t_comm_destroy()
+            rc = -4  # S2T_ERR_UNSUPPORTED: another rank has no communicator
+    L.check(rc, "s2t_comm_init (some rank)")
     _STATE["world"] = world
 
 

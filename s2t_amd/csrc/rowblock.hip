@@ -1771,6 +1771,7 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   if (a->act != S2T_ACT_NONE && !glu) return S2T_ERR_UNSUPPORTED;
   const int nout = glu ? a->N / 2 : a->N;
   if (glu ? (a->N % 64) : (a->N % 8)) return S2T_ERR_UNSUPPORTED;  // GLU: whole 32-column chunks of value and gate rows
+  if (a->N > PJ_MAXN) return S2T_ERR_UNSUPPORTED;                  // the bias row staged in LDS holds PJ_MAXN floats
   if (a->preact && !glu) return S2T_ERR_UNSUPPORTED;
   if ((a->ln_gamma != nullptr) != (a->ln_beta != nullptr)) return S2T_ERR_ARG;
   if ((a->pre_scale != nullptr) != (a->pre_shift != nullptr) || (a->pre_scale && a->ln_gamma)) return S2T_ERR_ARG;

@@ -273,10 +273,24 @@ def _dbd_buffer(H, B, Tq, ldB, dt, dev):
     if buf is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("s2t_amd: a new attention-gradient shape appeared during graph capture; run one eager step first")
-        while len(_DBD) >= 8:  # a few shapes at most (PDS stages, bucketed lengths); evict the oldest
-            _DBD.pop(next(iter(_DBD)))
+        # a few shapes at most (PDS stages, bucketed lengths); the oldest goes — unless a captured graph may hold its address
+        # (every buffer that existed when a capture was recorded stays for the life of the process: GRAPH_PINNED)
+        while len(_DBD) >= 8:
+            victim = next((k for k in _DBD if k not in GRAPH_PINNED), None)
+            if victim is None:
+                break
+            _DBD.pop(victim)
         buf = _DBD[key] = torch.zeros(H, B, Tq, ldB, dtype=dt, device=dev)
     return buf
+
+
+GRAPH_PINNED = set()
+
+
+def pin_buffers_for_graph():
+    """Called when a step is captured into a hipGraph: buffers allocated OUTSIDE the graph's pool whose addresses the graph
+    bakes in (the shared skewed-dS buffers) may never be freed or re-used for another shape afterwards."""
+    GRAPH_PINNED.update(_DBD.keys())
 
 
 _POSQ = {"entries": [], "pool": {}, "next": {}}

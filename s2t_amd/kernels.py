@@ -250,9 +250,10 @@ def transpose_batched(table, n, tiles, n_tiles):
 
 
 def rowblock_supported(x, N, act=None):
-    """s2t_rowblock_gemm covers the encoder width of the recipes: bf16, K = d = 256, N % 8 == 0 (GLU: N % 64 == 0)."""
+    """s2t_rowblock_gemm covers the encoder width of the recipes: bf16, K = d = 256, N % 8 == 0 (GLU: N % 64 == 0), N <= 4096
+    (the kernel stages the bias row in LDS)."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
-            and (N % 64 == 0 if act == "glu" else N % 8 == 0))
+            and (N % 64 == 0 if act == "glu" else N % 8 == 0) and N <= 4096)
 
 
 def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual=None, ldr=0, preact=None, ldp=0, ln=None,

@@ -126,6 +126,7 @@ class Trainer:
         # the grouped weight-gradient tables of the captured step: one pinned/device block per flush (a data-parallel step
         # flushes once per gradient stage)
         Fn.reserve_wgrad_staging(self.flat.master.device, count=8 if self.ddp is not None else 1)
+        Fn.pin_buffers_for_graph()
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         self._ssg = sample_size_global

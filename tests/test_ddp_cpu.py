@@ -97,3 +97,65 @@ def test_ddp_world2_gloo(reduce_dtype):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _worker_bound(rank, world, port, q):
+    """Random gradients of realistic spread reduced once with fp32 buckets and once with bf16 buckets."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from s2t_amd import functional as Fn
+        from s2t_amd.flat_params import FlatParameters
+        from s2t_amd.legacy_distributed_data_parallel import LegacyDistributedDataParallel
+
+        out = {}
+        for tag, rd in (("fp32", None), ("bf16", torch.bfloat16)):
+            m = Toy()
+            m.flat = FlatParameters(m, torch.float32)
+            ddp = LegacyDistributedDataParallel(m, buffer_size=2048, reduce_dtype=rd)
+            g = torch.Generator().manual_seed(100 + rank)
+            m.flat.zero_grad()
+            ddp.begin_backward()
+            for p in (m.c, m.b, m.a):
+                # log-normal magnitudes over four decades, random signs: what a gradient buffer looks like
+                mag = torch.exp(torch.randn(p.shape, generator=g) * 2.0 - 4.0)
+                p.grad.copy_(mag * torch.sign(torch.randn(p.shape, generator=g)))
+                Fn._ready(p)
+            ddp.all_reduce_grads()
+            out[tag] = m.flat.grad.clone()
+        q.put((rank, out["fp32"], out["bf16"]))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_buckets_stay_within_a_rounding_of_fp32_buckets():
+    """bench.py sends the gradient buckets in the training dtype (bf16), the reference's wire format under --fp16
+    (legacy_distributed_data_parallel.py:44-48: the buffer has the parameters' half-precision dtype).  What that costs against
+    fp32 buckets: each rank's contribution is rounded to bf16 once and the sum once more (8 mantissa bits: 2^-9 relative each
+    way), so an element of the averaged gradient is within 3 * 2^-9 of the largest contribution's magnitude, and the buffer's
+    norm moves by far less (the roundings are unbiased and independent)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bound, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, a, b in res:
+        assert b is not None, "rank %d: %s" % (rank, a)
+        # per element: bounded by the roundings of the contributions (their magnitudes sum to at most world * |mean| + slack;
+        # use the fp32 mean's own scale plus the largest single contribution seen through the bf16 result)
+        scale = torch.maximum(a.abs(), b.abs()).clamp_min(1e-30)
+        big = (b - a).abs() / scale
+        # cancellation (contributions of opposite sign) can make a tiny mean out of large parts: compare those against the parts
+        assert float(((b - a).abs() <= 3 * 2.0 ** -9 * (scale + 0.2)).float().mean()) == 1.0
+        assert float(big.median()) < 2.0 ** -8
+        assert abs(float(b.norm() / a.norm()) - 1.0) < 1e-3
+    assert torch.equal(res[0][2], res[1][2]), "both ranks must hold the same reduced gradient"
