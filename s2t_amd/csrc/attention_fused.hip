@@ -390,6 +390,203 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
 }
 
 // =====================================================================================================================
+// forward, resident form (round 3): ONE workgroup per (utterance, head) for Tq = Tk <= 256 with relative positions — the
+// encoder self-attention of the recipes (T' = 250).  K, V and ALL 2T-1 projected position rows of the head are staged in LDS
+// once (128 KiB) instead of once per 64-query block (four times at T' = 250, each behind two workgroup barriers and a
+// global round trip), the eight waves then walk their query tiles (wave w: tiles w and w + 8) over the resident images with
+// no barrier and no global load in the loop.  Arithmetic, masks and dropout bits are those of attn_fwd_kernel.
+// The rel-shift scratch is 48 band rows per wave (3.75 KiB: eight waves beside the 128 KiB of images): the 80-row band of
+// a (16 query x 64 key) block goes through it in two overlapping halves (rows 0..47 for keys 0..31, rows 32..79 for keys
+// 32..63; the shared tile of 16 rows stays in registers between the halves).
+// =====================================================================================================================
+constexpr int BH_MAXT = 256;
+constexpr int BH_BAND = 48;
+constexpr int BH_IMG = 4 * BH_MAXT * 128;              // K | V | 2 * BH_MAXT position rows
+constexpr int BH_LDS = BH_IMG + 8 * BH_BAND * SC * 4;  // 161 792 bytes
+
+// S^T tiles of (16 queries of this wave) x (64 keys from k0) from the resident images, scaled and masked (scores_block's
+// arithmetic)
+__device__ __forceinline__ void scores_block_res(const FusedArgs& a, const QFrags& qf, const char* lk, const char* lp,
+                                                 float* scratch, int q0w, int k0, int klen, int x, int y, f32x4 (&st)[4]) {
+  const char* lkb = lk + k0 * 128;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) acc = mfma16(frag_rows(lkb, kt, ks, x, y), qf.qa[ks], acc);
+    st[kt] = acc;
+  }
+  {
+    const int nbase = a.Tq - 1 - (q0w + 15) + k0;
+    const int nmax = 2 * a.Tq - 2;
+    f32x4 band[5];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      int n = nbase + 16 * nt + x;
+      n = n < 0 ? 0 : (n > nmax ? nmax : n);
+      const char* row = lp + n * 128;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc = mfma16(as_frag(*reinterpret_cast<const uint4*>(row + (((ks * 4 + y) ^ (n & 7)) << 4))), qf.qv[ks], acc);
+      band[nt] = acc;
+    }
+    // lane (x = q, y) holds band rows 16 nt + 4 y + r; element (q, key) reads band row 15 - q + key
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scratch[(16 * t + 4 * y + r) * SC + x] = band[2 * half + t][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[2 * half + kk][r] += scratch[(15 - x + 16 * kk + 4 * y + r) * SC + x];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  const int jlim = klen;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = k0 + 16 * kt + 4 * y + r;
+      const float s = st[kt][r] * a.scale;
+      st[kt][r] = j >= jlim ? -INFINITY : s;
+    }
+}
+
+// K, V (rows >= Tk zero) and the position rows (n clamped to 2Tq-2) of (b, h) into the resident images: 128-byte rows,
+// 16-byte chunk c of row r at r*128 + ((c ^ (r & 7)) << 4)
+__device__ __forceinline__ void bh_stage_images(const FusedArgs& a, char* lds, int b, int h, int tid) {
+  const bf16_t* kb = a.k + (int64_t)b * a.k_sb + h * DK;
+  const bf16_t* vb = a.v + (int64_t)b * a.v_sb + h * DK;
+  const bf16_t* pp = a.pos_p + h * DK;
+  const int nmax = 2 * a.Tq - 2;
+  uint4 t[16];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = tid + 512 * u;
+    const int r = min(c >> 3, a.Tk - 1), ch = c & 7;
+    t[u] = ldg16(kb + (int64_t)r * a.k_sr + ch * 8);
+    t[4 + u] = ldg16(vb + (int64_t)r * a.v_sr + ch * 8);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = tid + 512 * u;
+    const int n = min(c >> 3, nmax), ch = c & 7;
+    t[8 + u] = ldg16(pp + (int64_t)n * a.p_sr + ch * 8);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = tid + 512 * u;
+    const int r = c >> 3, ch = c & 7;
+    const bool ok = r < a.Tk;
+    *reinterpret_cast<uint4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = ok ? t[u] : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(lds + BH_MAXT * 128 + r * 128 + ((ch ^ (r & 7)) << 4)) = ok ? t[4 + u] : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = tid + 512 * u;
+    const int r = c >> 3, ch = c & 7;
+    *reinterpret_cast<uint4*>(lds + 2 * BH_MAXT * 128 + r * 128 + ((ch ^ (r & 7)) << 4)) = t[8 + u];
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[BH_LDS];
+  char* lk = lds;
+  char* lv = lds + BH_MAXT * 128;
+  char* lp = lds + 2 * BH_MAXT * 128;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int x = lane & 15, y = lane >> 4;
+  float* scratch = reinterpret_cast<float*>(lds + BH_IMG) + w * BH_BAND * SC;
+  const int z = blockIdx.x;
+  const int b = z / a.H, h = z % a.H;
+  const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
+  bh_stage_images(a, lds, b, h, tid);
+  const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
+  const uint32_t dth = s2t_drop_thresh(a.drop_p);
+  const float dinv = s2t_drop_scale(a.drop_p);
+  __syncthreads();
+  for (int q0w = 16 * w; q0w < a.Tq; q0w += 128) {
+    const int i = q0w + x;
+    QFrags qf;
+    load_qfrags(a, qf, b, h, i, y, true);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < a.Tk; k0 += KB) {
+      f32x4 st[4];
+      scores_block_res(a, qf, lk, lp, scratch, q0w, k0, klen, x, y, st);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float mref = (mn == -INFINITY) ? 0.f : mn;
+      const float alpha = __expf(m - mref);
+      float rs = 0.f;
+      float pr[4][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(st[kt][r] - mref);
+          rs += p;
+          pr[kt][r] = p;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      if (a.drop_p > 0.f) {
+        const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)(i < a.Tq ? i : 0)) * (uint64_t)a.Tk;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          uint32_t r16[4];
+          s2t_rand_run<4>(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), r16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pr[kt][r] = r16[r] >= dth ? pr[kt][r] * dinv : 0.f;
+        }
+      }
+      const char* lvb = lv + k0 * 128;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float pv8[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pv8[r] = pr[2 * s][r];
+          pv8[4 + r] = pr[2 * s + 1][r];
+        }
+        const bf16x8 pf = pack8(pv8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_cols_perm(lvb, dt, s, x, y), pf, o[dt]);
+      }
+    }
+    if (i < a.Tq) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)i * a.o_sr + h * DK;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        float v4[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+        st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
+      }
+      if (y == 0 && a.lse) a.lse[(int64_t)z * a.Tq + i] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+    }
+  }
+}
+
+// =====================================================================================================================
 // backward
 // =====================================================================================================================
 // ---- dQ: workgroup = 64 queries of one (b,h), wave = 16 queries; walks the key blocks ------------------------------
@@ -1002,7 +1199,11 @@ extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, con
   a.rel = pos_p != nullptr; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.pos_u = pos_u; a.pos_v = pos_v;
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site;
   dim3 grid(B * H, (Tq + 63) / 64), block(256);
-  if (a.rel) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+  // S2T_ATTN_BH=0 keeps the block-per-64-queries kernels for the short relative-position case too (A/B switch)
+  static const bool bh_on = [] { const char* e = getenv("S2T_ATTN_BH"); return !(e && e[0] == '0'); }();
+  if (a.rel && bh_on && Tq == Tk && Tk <= BH_MAXT && !causal)
+    hipLaunchKernelGGL(attn_bh_fwd_kernel, dim3(B * H), dim3(512), 0, (hipStream_t)stream, a);
+  else if (a.rel) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
   return S2T_LAUNCH_CHECK();
 }
