@@ -467,11 +467,20 @@ typedef struct s2t_ffn_args {
    * it, row counts that would leave most CUs idle run two workgroups per 128-row block, each on half of the hidden units,
    * which swap fp32 partial rows through it (csrc/ffn_pc.hip).  The kernels leave its flag words zero again. */
   void* pair_ws; int64_t pair_ws_bytes;
+  /* z_tiled_ok != 0: the caller accepts z in the TILED layout of the 128-row kernel (s2t_ffn_z_tiled tells whether this call
+   * writes it so) and has allocated s2t_ffn_z_elems(M, F) elements for it.  Tiled z: the 16-byte piece of units
+   * 64 cg + 16 s + 8 hh .. +7 of row 128 p + 32 wi + m sits at element ((((p * (F/64) + cg) * 4 + wi) * 4 + s) * 64 + 32 hh + m) * 8:
+   * a lane of the kernel owns one row and eight consecutive units, so its store (and the backward kernel's load) of a
+   * k-step is one contiguous 1 KiB per wave instead of 32-byte pieces of 32 rows.  z is private to the fused kernels
+   * (only s2t_ffn_fused_bwd reads it: pass z_tiled there); h keeps the row-major layout the weight gradient reads. */
+  int32_t z_tiled_ok;
 } s2t_ffn_args;
 int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
 int64_t s2t_ffn_pair_ws_bytes(int32_t M);
 /* the kernel symbol s2t_ffn_fused_fwd launches for these arguments, as a profiler prints it (buf: >= 96 bytes) */
 int s2t_ffn_fused_describe(const s2t_ffn_args* args, char* buf, int32_t buf_bytes);
+int s2t_ffn_z_tiled(const s2t_ffn_args* args);     /* 1: s2t_ffn_fused_fwd(args) writes z tiled */
+int64_t s2t_ffn_z_elems(int32_t M, int32_t F);     /* bf16 elements of a z buffer that either layout fits */
 
 /* s2t_ffn_fused_bwd: the input gradient of the same block's two products in one launch (what autograd derives from the
  * two F.linear, the activation and the hidden dropout of s2t_transformer_layer.py:55-66):
@@ -516,6 +525,7 @@ typedef struct s2t_ffn_bwd_args {
   void* dres_out; void* dy_out;
   float drop_o_p; uint32_t drop_o_site;
   void* pair_ws; int64_t pair_ws_bytes; /* as in s2t_ffn_args */
+  int32_t z_tiled;        /* z is in the tiled layout (s2t_ffn_args.z_tiled_ok): only the 128-row kernel reads it */
 } s2t_ffn_bwd_args;
 int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* args, void* stream);
 int s2t_ffn_fused_bwd_describe(const s2t_ffn_bwd_args* args, char* buf, int32_t buf_bytes);

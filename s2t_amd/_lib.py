@@ -63,7 +63,7 @@ class FfnArgs(C.Structure):
         ("M", C.c_int32), ("F", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
         ("drop_h_p", C.c_float), ("drop_h_site", C.c_uint32), ("drop_o_p", C.c_float), ("drop_o_site", C.c_uint32),
         ("drop_seed", C.c_void_p),
-        ("pair_ws", C.c_void_p), ("pair_ws_bytes", C.c_int64),
+        ("pair_ws", C.c_void_p), ("pair_ws_bytes", C.c_int64), ("z_tiled_ok", C.c_int32),
     ]
 
 
@@ -80,7 +80,7 @@ class FfnBwdArgs(C.Structure):
         ("end_y", C.c_void_p), ("end_gamma", C.c_void_p), ("end_mean", C.c_void_p), ("end_rstd", C.c_void_p),
         ("end_lens", C.c_void_p), ("end_T", C.c_int32), ("end_ws", C.c_void_p), ("end_replicas", C.c_int32),
         ("dres_out", C.c_void_p), ("dy_out", C.c_void_p), ("drop_o_p", C.c_float), ("drop_o_site", C.c_uint32),
-        ("pair_ws", C.c_void_p), ("pair_ws_bytes", C.c_int64),
+        ("pair_ws", C.c_void_p), ("pair_ws_bytes", C.c_int64), ("z_tiled", C.c_int32),
     ]
 
 

@@ -33,6 +33,7 @@ struct FfnK : s2t_ffn_args {
   // ffn_pc.hip with the hidden dimension split over a PAIR of workgroups: fp32 partial rows and one flag per workgroup
   float* xws;              // [pairs][2][64][256] fp32
   uint32_t* xflags;        // [pairs][2] (+ one error word behind them), zero between launches
+  int z_tiled;             // z (training forward: written, backward: read) is in the tiled layout of include/s2t_hip.h
 };
 
 }  // namespace

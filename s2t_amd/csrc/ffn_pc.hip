@@ -350,8 +350,15 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
   auto mcell = [&](int c, int s, int h, int m) __attribute__((always_inline)) -> char* {
     return mbox + (c & 1) * 16384 + wi * 4096 + s * 1024 + h * 512 + ((m ^ (2 * (2 * s + h))) & 31) * 16;
   };
+  // z: row-major [M][F], or (z_tiled) the tiled layout of include/s2t_hip.h over row blocks of 128 (rows padded)
+  const uint32_t zrows = p.z_tiled ? (uint32_t)((M + RB - 1) / RB) * RB : (uint32_t)M;
   const __amdgpu_buffer_rsrc_t zsrd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.z), 0, p.z ? (int)((uint32_t)M * (uint32_t)F * 2u) : 0, 0x00020000);
+      const_cast<void*>(p.z), 0, p.z ? (int)(zrows * (uint32_t)F * 2u) : 0, 0x00020000);
+  // byte offset of this lane's 16-byte piece of k-step s of (global) chunk cg in the tiled layout
+  const uint32_t ztl = (uint32_t)(((pair * (F / FC)) * 4 + wi) * 4) * 1024u + (uint32_t)(hh * 32 + r32) * 16u;
+  auto ztile_off = [&](int cg, int s) __attribute__((always_inline)) -> uint32_t {
+    return ztl + (uint32_t)cg * 16384u + (uint32_t)s * 1024u;
+  };
   const __amdgpu_buffer_rsrc_t hsrd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.h), 0, p.h ? (int)((uint32_t)M * (uint32_t)F * 2u) : 0, 0x00020000);
 
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       if constexpr (BWD) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const uint32_t off = (rowF + (uint32_t)(fbase + c * FC + 16 * s + 8 * hh)) * 2u;
+          const uint32_t off = p.z_tiled ? ztile_off(fbase / FC + c, s) : (rowF + (uint32_t)(fbase + c * FC + 16 * s + 8 * hh)) * 2u;
           const u32x4s t = __builtin_amdgcn_raw_buffer_load_b128(zsrd, off, 0, 0);
           sd.z[s] = make_uint4(t.x, t.y, t.z, t.w);
         }
@@ -438,8 +445,8 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
     // the finished eight values of k-step s: mailbox cell (the consumers' B fragment) and, training, 16 bytes of z
     auto e1_out = [&](int c, int s, const uint32_t (&hp)[4], const uint32_t (&zp)[4]) __attribute__((always_inline)) {
       if constexpr (TRAIN) {
-        const uint32_t f0 = (uint32_t)(fbase + c * FC + 16 * s + 8 * hh);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){zp[0], zp[1], zp[2], zp[3]}, zsrd, (rowF + f0) * 2u, 0, 0);
+        // (tiled: the wave's 64 pieces of this k-step are 1 KiB contiguous; row-major they would be 32-byte pieces of 32 rows)
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){zp[0], zp[1], zp[2], zp[3]}, zsrd, ztile_off(fbase / FC + c, s), 0, 0);
       }
       *reinterpret_cast<uint4*>(mcell(c, s, hh, r32)) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
     };

@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
 int s2t_ffn_pc_launch(const void* kargs, int mode, int split, int drop, void* stream);
 
 #ifndef S2T_FFN_PC_DEFAULT
-#define S2T_FFN_PC_DEFAULT 5
+#define S2T_FFN_PC_DEFAULT 7
 #endif
 namespace {
 constexpr int PC_RB = 128;
@@ -1590,6 +1590,8 @@ bool pc_enabled(int mode) {
   static const int mask = [] { const char* e = getenv("S2T_FFN_PC"); return e ? atoi(e) : S2T_FFN_PC_DEFAULT; }();
   return (mask >> mode) & 1;
 }
+// training forward on the 128-row kernel only when the caller takes z tiled (its lanes cannot store row-major z efficiently)
+bool pc_train(const s2t_ffn_args* a) { return pc_enabled(1) && (a->z_tiled_ok || !a->z); }
 int pc_num_cus() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -1639,8 +1641,9 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   const bool drop = a->drop_h_p > 0.f || a->drop_o_p > 0.f;
   FfnK k = {};
   static_cast<s2t_ffn_args&>(k) = *a;
-  if (pc_enabled(train ? 1 : 0)) {
+  if (train ? pc_train(a) : pc_enabled(0)) {
     const int split = pc_split(a->M, a->F, a->pair_ws, a->pair_ws_bytes);
+    k.z_tiled = 1;
     if (split == 2) {
       k.xws = reinterpret_cast<float*>(a->pair_ws);
       k.xflags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a->pair_ws) + (int64_t)((a->M + PC_RB - 1) / PC_RB) * 2 * 64 * 256 * 4);
@@ -1665,23 +1668,36 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
 }
 
 namespace {
-int ffn_describe(int mode, int act, bool drop, int M, int F, const void* ws, int64_t ws_bytes, char* buf, int n) {
+int ffn_describe(int mode, int act, bool drop, int M, int F, const void* ws, int64_t ws_bytes, char* buf, int n, bool force_pc = false) {
   if (!buf || n < 96) return S2T_ERR_ARG;
-  if (pc_enabled(mode)) snprintf(buf, n, "ffn_pc_kernel<%d, %d, %s, %d>", mode, act, drop ? "true" : "false", pc_split(M, F, ws, ws_bytes));
+  if (pc_enabled(mode) || (mode == 2 && force_pc)) snprintf(buf, n, "ffn_pc_kernel<%d, %d, %s, %d>", mode, act, drop ? "true" : "false", pc_split(M, F, ws, ws_bytes));
   else snprintf(buf, n, "ffn_fused_fwd_kernel<%d, %d, %s>", mode, act, drop ? "true" : "false");
   return S2T_OK;
 }
 }  // namespace
 
+extern "C" int s2t_ffn_z_tiled(const s2t_ffn_args* a) {
+  if (!a) return 0;
+  const bool train = a->z || a->h || a->x_ln || a->ln_mean || a->ln_rstd;
+  return train && a->z && pc_train(a) ? 1 : 0;
+}
+
+extern "C" int64_t s2t_ffn_z_elems(int32_t M, int32_t F) { return (int64_t)((M + PC_RB - 1) / PC_RB) * PC_RB * F; }
+
 extern "C" int s2t_ffn_fused_describe(const s2t_ffn_args* a, char* buf, int32_t n) {
   if (!a) return S2T_ERR_ARG;
   const bool train = a->z || a->h || a->x_ln || a->ln_mean || a->ln_rstd;
+  if (train && !pc_train(a)) {
+    if (!buf || n < 96) return S2T_ERR_ARG;
+    snprintf(buf, n, "ffn_fused_fwd_kernel<1, %d, %s>", a->act, (a->drop_h_p > 0.f || a->drop_o_p > 0.f) ? "true" : "false");
+    return S2T_OK;
+  }
   return ffn_describe(train ? 1 : 0, a->act, a->drop_h_p > 0.f || a->drop_o_p > 0.f, a->M, a->F, a->pair_ws, a->pair_ws_bytes, buf, n);
 }
 
 extern "C" int s2t_ffn_fused_bwd_describe(const s2t_ffn_bwd_args* b, char* buf, int32_t n) {
   if (!b) return S2T_ERR_ARG;
-  return ffn_describe(2, b->act, b->drop_h_p > 0.f, b->M, b->F, b->pair_ws, b->pair_ws_bytes, buf, n);
+  return ffn_describe(2, b->act, b->drop_h_p > 0.f, b->M, b->F, b->pair_ws, b->pair_ws_bytes, buf, n, b->z_tiled != 0);
 }
 
 extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
@@ -1747,7 +1763,8 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   const dim3 grid((a.M + TM - 1) / TM), block(512);
   hipStream_t s = (hipStream_t)stream;
   const bool drop = a.drop_h_p > 0.f;
-  if (pc_enabled(2)) {
+  a.z_tiled = b->z_tiled;
+  if (pc_enabled(2) || b->z_tiled) {
     const int split = pc_split(b->M, b->F, b->pair_ws, b->pair_ws_bytes);
     if (split == 2) {
       a.xws = reinterpret_cast<float*>(b->pair_ws);

@@ -861,15 +861,19 @@ class FFNBlockFn(torch.autograd.Function):
             x_ln = torch.empty(M, d, dtype=bf, device=dev)
             mean = torch.empty(M, dtype=torch.float32, device=dev)
             rstd = torch.empty(M, dtype=torch.float32, device=dev)
-            z = torch.empty(M, F_, dtype=bf, device=dev)
+            z = torch.empty(K.ffn_z_rows(M), F_, dtype=bf, device=dev)  # either layout fits (tiled: row blocks of 128)
             h = torch.empty(M, F_, dtype=bf, device=dev)
             if end_g is not None:
                 emean = torch.empty(M, dtype=torch.float32, device=dev)
                 erstd = torch.empty(M, dtype=torch.float32, device=dev)
-        K.ffn_fused_fwd(x, cw(w1), b1.data, cw(w2), b2.data, y, act=act, alpha=alpha, residual=x,
-                        ln=(gamma.data, beta.data), end_ln=(end_g.data, end_b.data) if end_g is not None else None,
-                        y_ln=y_ln, end_stats=(emean, erstd) if emean is not None else None, end_lens=end_lens, end_T=end_T,
-                        x_ln=x_ln, ln_stats=(mean, rstd) if train else None, z=z, h=h, drop_h=drop_h, drop_o=drop_o)
+        # z may come back in the 128-row kernel's TILED layout when the backward pass is the fused kernel too (its only reader)
+        fused_bwd_ok = (_FFN_FUSED_BWD and getattr(w1, "_s2t_flat", None) is not None and w1._s2t_flat.shadow is not None
+                        and getattr(w2, "_s2t_flat", None) is w1._s2t_flat and (M + 128) * F_ * 2 < 2 ** 32)
+        ctx.z_tiled = K.ffn_fused_fwd(x, cw(w1), b1.data, cw(w2), b2.data, y, act=act, alpha=alpha, residual=x,
+                                      ln=(gamma.data, beta.data), end_ln=(end_g.data, end_b.data) if end_g is not None else None,
+                                      y_ln=y_ln, end_stats=(emean, erstd) if emean is not None else None, end_lens=end_lens,
+                                      end_T=end_T, x_ln=x_ln, ln_stats=(mean, rstd) if train else None, z=z, h=h, drop_h=drop_h,
+                                      drop_o=drop_o, z_tiled_ok=train and fused_bwd_ok)
         if train:
             ctx.save_for_backward(x, x_ln, mean, rstd, z, h, y if end_g is not None else None, emean, erstd)
         ctx.p = (gamma, beta, w1, b1, w2, b2, end_g, end_b)
@@ -903,6 +907,10 @@ class FFNBlockFn(torch.autograd.Function):
 
         fused_bwd = (_FFN_FUSED_BWD and getattr(w1, "_s2t_flat", None) is not None and w1._s2t_flat.shadow is not None
                      and getattr(w2, "_s2t_flat", None) is w1._s2t_flat and M * F_ * 2 < 2 ** 32)
+        assert fused_bwd or not ctx.z_tiled, "a tiled z is read by the fused backward kernel only"
+        zt = bool(ctx.z_tiled)
+        if not zt:
+            z = z[:M]
         end_in_kernel = None
         if end_g is not None and fused_bwd and queued:
             # the trailing LayerNorm's backward rides in the fused kernel's prologue: it writes dres (gradient w.r.t. y) and
@@ -934,14 +942,14 @@ class FFNBlockFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 ws = _ln_workspace(d, x.device)
                 K.ffn_fused_bwd(dout if end_in_kernel is not None else dy, w2t, w1t, z, dz, None, act=ctx.act, alpha=ctx.alpha,
-                                drop_h=drop_h, end=end_in_kernel,
+                                drop_h=drop_h, end=end_in_kernel, z_tiled=zt,
                                 ln=dict(x=x, gamma=gamma.data, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, dx_drop=dxd,
                                         drop=ctx.up_drop))
                 _LNQ["entries"].append((ws, gamma.grad, beta.grad, d))
                 _ready(gamma, beta)
             else:
                 dxl = torch.empty_like(x)
-                K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxl, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h)
+                K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxl, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h, z_tiled=zt)
         else:
             dxl = torch.empty_like(x)
             K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,

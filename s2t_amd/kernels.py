@@ -106,11 +106,17 @@ def _ffn_pair_ws(a, M, device):
     return t
 
 
+def ffn_z_rows(M):
+    """Rows to allocate for a z buffer that fits either layout (s2t_ffn_z_elems: row blocks of 128)."""
+    return (M + 127) // 128 * 128
+
+
 def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=None, ln_eps=1e-5, end_ln=None, y_ln=None,
                   end_stats=None, end_lens=None, end_T=0, x_ln=None, ln_stats=None, z=None, h=None, drop_h=None,
-                  drop_o=None):
+                  drop_o=None, z_tiled_ok=False):
     """s2t_ffn_fused_fwd (include/s2t_hip.h): ``ln`` / ``end_ln`` = (gamma, beta) fp32 of the LayerNorm in front of /
-    behind the block; ``ln_stats`` / ``end_stats`` = (mean, rstd) outputs; drops = (p, seed tensor, site) or None."""
+    behind the block; ``ln_stats`` / ``end_stats`` = (mean, rstd) outputs; drops = (p, seed tensor, site) or None.
+    ``z_tiled_ok``: z has ``ffn_z_rows(M)`` rows and may be written in the tiled layout; returns True when it was."""
     L.require_cuda(x, w1, w2, y, y_ln, residual, x_ln, z, h)
     M, d = x.shape
     F = w1.shape[0]
@@ -141,6 +147,10 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
         a.drop_o_p, a.drop_o_site, seed = float(drop_o[0]), int(drop_o[2]), drop_o[1]
     a.drop_seed = _ptr(seed)
     _ffn_pair_ws(a, M, x.device)
+    if z_tiled_ok and z is not None:
+        assert z.numel() >= L.lib().s2t_ffn_z_elems(M, F)
+        a.z_tiled_ok = 1
+    tiled = bool(L.lib().s2t_ffn_z_tiled(C.byref(a)))
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -149,23 +159,26 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
         buf = C.create_string_buffer(128)
         L.check(L.lib().s2t_ffn_fused_describe(C.byref(a), buf, 128), "s2t_ffn_fused_describe")
         GEMM_PROFILE.append((buf.value.decode(), 4.0 * M * F * d, e0, e1, (M, F, d, 1)))  # the name rocprofv3 prints for this launch
-        return
+        return tiled
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
+    return tiled
 
 
-def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=None, end=None):
+def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=None, end=None, z_tiled=False):
     """s2t_ffn_fused_bwd (include/s2t_hip.h): dz = alpha * drop_h((dy W2) * act'(z)), dxn = dz W1, from the transposed
     weight copies ``w2t`` [F, 256] and ``w1t`` [256, F].  ``ln`` = dict(x, gamma, mean, rstd, ws, dx[, dres, dx_drop, drop])
     adds the backward of the block's leading LayerNorm (``dxn`` may then be None)."""
     L.require_cuda(dy, w2t, w1t, z, dz, dxn)
     M, d = dy.shape
     F = w2t.shape[0]
-    assert w2t.shape == (F, d) and w1t.shape == (d, F) and z.shape == (M, F) and dz.shape == (M, F)
+    assert w2t.shape == (F, d) and w1t.shape == (d, F) and dz.shape == (M, F)
+    assert (z.shape == (M, F)) if not z_tiled else (z.numel() >= L.lib().s2t_ffn_z_elems(M, F))
     assert dxn is None or dxn.shape == (M, d)
     assert all(t is None or (t.dtype == torch.bfloat16 and t.is_contiguous()) for t in (dy, w2t, w1t, z, dz, dxn))
     a = L.FfnBwdArgs()
     a.dy, a.w2t, a.w1t, a.z, a.dz, a.dxn = (_ptr(t) for t in (dy, w2t, w1t, z, dz, dxn))
     a.d, a.M, a.F, a.act, a.alpha = d, M, F, L.ACT_IDS[act], alpha
+    a.z_tiled = int(bool(z_tiled))
     if drop_h is not None and drop_h[0] > 0:
         a.drop_h_p, a.drop_h_site, a.drop_seed = float(drop_h[0]), int(drop_h[2]), drop_h[1].data_ptr()
     if ln is not None:

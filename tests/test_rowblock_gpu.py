@@ -4,6 +4,8 @@ s2t_ffn_fused_fwd is compared with (a) plain fp32 maths on the same bf16-rounded
 FeedForwardModule (fairseq/modules/s2t_transformer_layer.py:55-66) between its LayerNorm and residual — and (b) the
 unfused kernels (s2t_layernorm_fwd + two s2t_gemm) for the dropout masks, which must be the SAME masks element for
 element because the unfused backward regenerates them."""
+import os
+
 import pytest
 import torch
 
@@ -87,9 +89,18 @@ def test_ffn_fused_eval(M, F, act, use_ln, use_eln):
             assert float(yl.float().cpu()[pad].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,F,act", [(200, 256, "swish"), (4096, 2048, "relu")])
-def test_ffn_fused_train_saves_and_masks(M, F, act):
-    """Training flavour: the saves equal what the unfused kernels produce on the same inputs with the same dropout sites."""
+def _untile_z(zt, M, F):
+    """Row-major [M, F] view of a z buffer in the tiled layout of include/s2t_hip.h (s2t_ffn_args.z_tiled_ok)."""
+    P = (M + 127) // 128
+    t = zt.reshape(-1)[: P * 128 * F].view(P, F // 64, 4, 4, 2, 32, 8)   # [p][cg][wi][s][hh][m][j]
+    return t.permute(0, 2, 5, 1, 3, 4, 6).reshape(P * 128, F)[:M]        # row = 128 p + 32 wi + m, unit = 64 cg + 16 s + 8 hh + j
+
+
+@pytest.mark.parametrize("M,F,act,tiled", [(200, 256, "swish", False), (4096, 2048, "relu", False), (200, 256, "swish", True),
+                                           (4096, 2048, "swish", True), (1000, 512, "relu", True)])
+def test_ffn_fused_train_saves_and_masks(M, F, act, tiled):
+    """Training flavour: the saves equal what the unfused kernels produce on the same inputs with the same dropout sites.
+    ``tiled``: the caller accepts z in the 128-row kernel's tiled layout (that kernel then runs the training forward)."""
     x, w1, b1, w2, b2, gam, bet, eg, eb = _mk(M, F, 11)
     d = 256
     alpha = 0.5
@@ -110,11 +121,14 @@ def test_ffn_fused_train_saves_and_masks(M, F, act):
     xl_f = torch.empty_like(xd)
     mean_f, rstd_f = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
     h_f = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
-    z_f = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
+    z_f = torch.full((K.ffn_z_rows(M) if tiled else M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
     y_f = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
-    K.ffn_fused_fwd(xd, w1d, b1d, w2d, b2d, y_f, act=act, alpha=alpha, residual=xd, ln=(gd, bd), x_ln=xl_f,
-                    ln_stats=(mean_f, rstd_f), z=z_f, h=h_f, drop_h=drop_h, drop_o=drop_o)
+    was_tiled = K.ffn_fused_fwd(xd, w1d, b1d, w2d, b2d, y_f, act=act, alpha=alpha, residual=xd, ln=(gd, bd), x_ln=xl_f,
+                                ln_stats=(mean_f, rstd_f), z=z_f, h=h_f, drop_h=drop_h, drop_o=drop_o, z_tiled_ok=tiled)
     torch.cuda.synchronize()
+    assert was_tiled == (tiled and os.environ.get("S2T_FFN_PC", "7") not in ("0", "4", "5"))
+    if was_tiled:
+        z_f = _untile_z(z_f, M, F)
     assert float((mean_f - mean_u).abs().max()) < 1e-5
     assert float(((rstd_f - rstd_u) / rstd_u).abs().max()) < 1e-5
     assert float((xl_f.float() - xl_u.float()).abs().max()) <= 2 ** -6  # one bf16 ulp at |x| < 4
@@ -153,9 +167,18 @@ def test_transpose_batched():
         assert torch.equal(d_, s_.t().contiguous())
 
 
-@pytest.mark.parametrize("M,F,act,p", [(64, 64, "relu", 0.0), (200, 256, "swish", 0.1), (4096, 2048, "swish", 0.1),
-                                       (1000, 512, "relu", 0.15), (130, 128, "none", 0.0)])
-def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p):
+def _tile_z(z, M, F):
+    """The inverse of _untile_z: a row-major [M, F] z into the tiled layout (rows padded to a multiple of 128)."""
+    P = (M + 127) // 128
+    full = torch.zeros(P * 128, F, dtype=z.dtype, device=z.device)
+    full[:M] = z
+    return full.view(P, 4, 32, F // 64, 4, 2, 8).permute(0, 3, 1, 4, 5, 2, 6).contiguous().view(P * 128, F)
+
+
+@pytest.mark.parametrize("M,F,act,p,tiled", [(64, 64, "relu", 0.0, False), (200, 256, "swish", 0.1, False), (4096, 2048, "swish", 0.1, False),
+                                             (1000, 512, "relu", 0.15, False), (130, 128, "none", 0.0, False),
+                                             (200, 256, "swish", 0.1, True), (4096, 2048, "swish", 0.1, True), (1000, 512, "relu", 0.15, True)])
+def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p, tiled):
     """s2t_ffn_fused_bwd against (a) fp32 maths on the same bf16 operands and (b) the unfused s2t_gemm pair it replaces:
     dz = alpha * drop_h((dy W2) * act'(z)), dxn = dz W1 — the autograd backward of the two F.linear, the activation and the
     hidden dropout of modules/s2t_transformer_layer.py:55-66.  (b) shares the dropout mask, so dz agrees to bf16 rounding."""
@@ -174,7 +197,7 @@ def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p):
     drop = Fn.DROPOUT.next(p, torch.device(DEV))
     dz = torch.full((M, F), 3.0, dtype=torch.bfloat16, device=DEV)
     dxn = torch.full((M, d), 3.0, dtype=torch.bfloat16, device=DEV)
-    K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, act=act, alpha=alpha, drop_h=drop)
+    K.ffn_fused_bwd(dy, w2t, w1t, _tile_z(z, M, F) if tiled else z, dz, dxn, act=act, alpha=alpha, drop_h=drop, z_tiled=tiled)
     # (b) the unfused pair
     dz_u = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
     dx_u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)

@@ -30,6 +30,7 @@ def unfused(i, train):
 
 
 NODROP = os.environ.get("PROBE_NODROP", "0") == "1"
+TILED = os.environ.get("PROBE_TILED", "1") == "1"  # z in the tiled layout (what the model does when both passes are fused)
 
 
 def fused(i, train):
@@ -37,7 +38,7 @@ def fused(i, train):
     do = (0.1, seed, 2) if (train and not NODROP) else None
     K.ffn_fused_fwd(xs[i], ws1[i], b1, ws2[i], b2, y, act="swish", alpha=0.5, residual=xs[i], ln=(gam, bet),
                     x_ln=xl if train else None, ln_stats=(mean, rstd) if train else None, z=zs[i] if train else None,
-                    h=hs[i] if train else None, drop_h=dh, drop_o=do)
+                    h=hs[i] if train else None, drop_h=dh, drop_o=do, z_tiled_ok=train and TILED)
 
 
 def timeit(fn, train, rounds=4):
@@ -71,7 +72,7 @@ def bwd_unfused(i, train):
 
 
 def bwd_fused(i, train):
-    K.ffn_fused_bwd(dy, w2ts[i], w1ts[i], zs[i], hs[i], dxn, act="swish", alpha=0.5, drop_h=None if NODROP else (0.1, seed, 1))
+    K.ffn_fused_bwd(dy, w2ts[i], w1ts[i], zs[i], hs[i], dxn, act="swish", alpha=0.5, drop_h=None if NODROP else (0.1, seed, 1), z_tiled=TILED)
 
 
 print("backward, cycling %d buffer sets:  two dgrad GEMMs %.1f us   fused %.1f us" % (NB, timeit(bwd_unfused, True), timeit(bwd_fused, True)), flush=True)

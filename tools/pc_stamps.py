@@ -29,6 +29,7 @@ a.act, a.alpha = 2, 0.5
 ws = K._ffn_pair_ws(a, M, x.device)
 if train:
     a.z, a.h = z.data_ptr(), h.data_ptr()
+    a.z_tiled_ok = 1
     a.drop_h_p, a.drop_h_site, a.drop_o_p, a.drop_o_site, a.drop_seed = 0.1, 1, 0.1, 2, seed.data_ptr()
 for _ in range(3):
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "ffn")
