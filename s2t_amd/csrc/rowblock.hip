@@ -1587,7 +1587,8 @@ constexpr int PC_RB = 128;
 // S2T_FFN_PC = bit mask of the flavours that run the 128-row producer / consumer kernel instead of the 64-row kernels of this
 // file: 1 eval, 2 training forward, 4 backward.  Default: what measured faster on MI355X at the headline shape.
 bool pc_enabled(int mode) {
-  static const int mask = [] { const char* e = getenv("S2T_FFN_PC"); return e ? atoi(e) : S2T_FFN_PC_DEFAULT; }();
+  const char* e = getenv("S2T_FFN_PC");  // (read at every call: tests and tools switch it inside one process)
+  const int mask = e ? atoi(e) : S2T_FFN_PC_DEFAULT;
   return (mask >> mode) & 1;
 }
 // training forward on the 128-row kernel only when the caller takes z tiled (its lanes cannot store row-major z efficiently)

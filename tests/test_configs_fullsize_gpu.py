@@ -219,6 +219,13 @@ def test_config2p_bf16_d256_against_oracle_on_rounded_weights():
         errs[k] = float((gf - go).norm() / go.norm().clamp_min(1e-6))
     worst = max(errs.items(), key=lambda kv: kv[1])
     print("bf16 d256 gradient relative L2: worst %s %.4f, median %.4f" % (worst[0], worst[1], float(np.median(list(errs.values())))))
-    # measured on MI355X: worst 0.055 (layer-0 depthwise-conv weight), median 0.008; bounds at twice that
-    assert worst[1] < 1.1e-1, worst
-    assert float(np.median(list(errs.values()))) < 1.7e-2
+    for k_, v_ in sorted(errs.items(), key=lambda kv: -kv[1])[:12]:
+        print("    %.4f %s" % (v_, k_))
+    # measured on MI355X: worst 0.055 (layer-0 depthwise-conv weight), median 0.008 in round 2.  The figure is CHAOTIC in the
+    # summation order of any kernel on the path (round 3, tools/grad_noise.py: the same model and batch through four
+    # equally valid variants of the fused feed-forward kernels, three seeds each: medians 0.007 ... 0.019 against an fp32 run
+    # of the HIP path, in no consistent order; this test's seed: 0.006 / 0.010 / 0.034 for three of them, worst tensor 0.054 ...
+    # 0.100): one-ulp bf16 flips re-seed the rounding noise of everything downstream.  A wrong kernel shows up as an error of
+    # order one on some tensor (a transposed weight layout read 1.43), so the bounds sit above the spread, not at twice one draw.
+    assert worst[1] < 2.0e-1, worst
+    assert float(np.median(list(errs.values()))) < 6e-2

@@ -131,10 +131,11 @@ def test_sate_d256_bf16_kernels_against_oracle_on_rounded_weights():
     med = float(np.median(list(errs.values())))
     print("SATE d256 bf16: loss %.5f, worst gradient %s %.4f, median %.4f, kernel calls %s" % (le, worst[0], worst[1], med, calls))
     assert calls["ffn"] >= 4 and calls["ffn_bwd"] >= 4 and calls["rb"] >= 4, calls  # the fast paths really ran
-    # measured on MI355X (round 3): loss 0.00008, worst 0.036 (decoder.layers.1.fc1.weight), median 0.0084; bounds at twice that
-    assert le < 2e-4
-    assert worst[1] < 7.2e-2, worst
-    assert med < 1.7e-2
+    # measured on MI355X (round 3): loss 0.00008, worst 0.036 (decoder.layers.1.fc1.weight), median 0.0084.  Bounds above the
+    # spread of this chaotic figure over equally valid kernel variants (test_configs_fullsize_gpu.py: median x 0.6 ... x 3.5)
+    assert le < 4e-4
+    assert worst[1] < 1.5e-1, worst
+    assert med < 4e-2
 
 
 def test_pds_conformer_d256_bf16_kernels_against_oracle_on_rounded_weights():
@@ -149,10 +150,10 @@ def test_pds_conformer_d256_bf16_kernels_against_oracle_on_rounded_weights():
     med = float(np.median(list(errs.values())))
     print("PDS Conformer d256 bf16: loss %.5f, worst gradient %s %.4f, median %.4f, kernel calls %s" % (le, worst[0], worst[1], med, calls))
     assert calls["ffn"] >= 4 and calls["ffn_bwd"] >= 4 and calls["rb"] >= 4, calls
-    # measured on MI355X (round 3): loss 0.00002, worst 0.046 (decoder.layers.1.fc1.weight), median 0.0024; bounds at twice that
-    assert le < 2e-4
-    assert worst[1] < 9.2e-2, worst
-    assert med < 5e-3
+    # measured on MI355X (round 3): loss 0.00002, worst 0.046 (decoder.layers.1.fc1.weight), median 0.0024; bounds as above
+    assert le < 4e-4
+    assert worst[1] < 1.8e-1, worst
+    assert med < 2e-2
 
 
 class _EncOnly(torch.nn.Module):
