@@ -37,6 +37,9 @@
 #ifndef S2T_PC_SIDE_AT
 #define S2T_PC_SIDE_AT 5  // producers' MFMA group behind which the next chunk's bias / pre-activation loads are issued
 #endif
+#ifndef S2T_PC_PIECE_ORDER
+#define S2T_PC_PIECE_ORDER 0  // consumers' LDS-DMA pieces: 0 in front of each pair of MFMAs, 1 behind them with the LDS queue drained
+#endif
 #ifndef S2T_PC_DBG
 #define S2T_PC_DBG 0  // experiment switches: 1 no DMA in the loop, 2 no MFMAs, 4 no E1 arithmetic, 16 stamps
 #endif
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
             for (int k = 0; k < 2; ++k) sv[k] = *reinterpret_cast<const uint4*>(mcell(c, pc >> 1, pc & 1, 8 * (2 * (nt - 6) + k) + (lane >> 3)));
           }
         }
+#if S2T_PC_PIECE_ORDER == 0
         piece(nt, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -563,6 +567,23 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
 #pragma unroll
         for (int s = 2; s < 4; ++s) yacc[nt] = mfma32(frag(R[nt & 1][s]), hb[s], yacc[nt]);
         __builtin_amdgcn_sched_barrier(0);
+#else
+        // the pieces go out once this wave's fragment reads have landed (a piece issued beside LDS reads in flight parks the
+        // wave for 100+ cycles, one issued behind MFMAs with the LDS queue drained about half of that)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) yacc[nt] = mfma32(frag(R[nt & 1][s]), hb[s], yacc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        piece(nt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        yacc[nt] = mfma32(frag(R[nt & 1][2]), hb[2], yacc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+        piece(nt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        yacc[nt] = mfma32(frag(R[nt & 1][3]), hb[3], yacc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if constexpr (SAVE) {
           if (nt >= 6) {  // behind the last DMA piece of the iteration (the pieces end with group 6's first pair)
 #pragma unroll

@@ -10,7 +10,7 @@ for n in "${ns[@]}"; do
   d=s2t_amd/lib/pcdbg$n; mkdir -p $d; objs=""
   for f in s2t_amd/csrc/*.hip; do
     o=s2t_amd/lib/obj/$(basename ${f%.hip}).o
-    if [ "$(basename $f)" = ffn_pc.hip ]; then o=$d/ffn_pc.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DS2T_PC_DBG=$n $extra -c $f -o $o; fi
+    if [ "$(basename $f)" = ffn_pc.hip ]; then o=$d/ffn_pc.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DS2T_PC_DBG=${n%%_*} $extra -c $f -o $o; fi
     objs="$objs $o"
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libs2t_hip.so $objs
