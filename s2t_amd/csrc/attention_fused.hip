@@ -65,6 +65,17 @@ struct FusedArgs {
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
+// 16 random bits of each of the four (query, key .. key + 3) elements starting at element index `base` (= row base + a
+// multiple of 4).  `fast`: even Tk and an index space below 2^32 (wave-uniform): the row base is then even and the 32-bit
+// form needs neither 64-bit arithmetic nor an odd-start variant — the same bits either way.
+__device__ __forceinline__ void attn_rand4(uint64_t key, uint64_t base, bool fast, uint32_t (&r16)[4]) {
+  if (fast) s2t_rand_run_even32<4>(key, (uint32_t)base, r16);
+  else s2t_rand_run<4>(key, base, r16);
+}
+__device__ __forceinline__ bool attn_fast_mask(const FusedArgs& a) {
+  return (a.Tk & 1) == 0 && (uint64_t)a.B * a.H * (uint64_t)a.Tq * (uint64_t)a.Tk < (1ull << 32);
+}
+
 __device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 // add a per-column fp32 bias to 8 bf16 values (q + pos_bias_u / q + pos_bias_v), round to bf16
@@ -241,6 +252,13 @@ __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& q
   // (bitwise predicates and a select: with short-circuit conditions the compiler builds an exec-mask branch per element,
   // 16 per block and wave)
   const int i = q0w + x;
+  if (!a.causal && k0 + KB <= klen) {  // the block lies wholly inside the utterance: no per-element mask (wave-uniform branch)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[kt][r] *= a.scale;
+    return;
+  }
   const int jlim = a.causal ? min(klen, i + 1) : klen;  // keys j >= jlim are masked for this lane's query
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         uint32_t r16[4];
-        s2t_rand_run<4>(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), r16);
+        attn_rand4(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), attn_fast_mask(a), r16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) pr[kt][r] = r16[r] >= dth ? pr[kt][r] * dinv : 0.f;
       }
@@ -446,15 +464,24 @@ __device__ __forceinline__ void scores_block_res(const FusedArgs& a, const QFrag
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
-  const int jlim = klen;
+  // scores leave in the LOG2 domain (scale * log2(e) folded into one multiply: the softmax then takes v_exp_f32 as it is);
+  // a block that lies wholly inside the utterance skips the per-element mask (wave-uniform branch)
+  const float c2 = a.scale * 1.44269504088896f;
+  if (k0 + KB <= klen) {
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = k0 + 16 * kt + 4 * y + r;
-      const float s = st[kt][r] * a.scale;
-      st[kt][r] = j >= jlim ? -INFINITY : s;
-    }
+      for (int r = 0; r < 4; ++r) st[kt][r] *= c2;
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = k0 + 16 * kt + 4 * y + r;
+        const float s = st[kt][r] * c2;
+        st[kt][r] = j >= klen ? -INFINITY : s;
+      }
+  }
 }
 
 // K, V (rows >= Tk zero) and the position rows (n clamped to 2Tq-2) of (b, h) into the resident images: 128-byte rows,
@@ -530,14 +557,14 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) 
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
       const float mref = (mn == -INFINITY) ? 0.f : mn;
-      const float alpha = __expf(m - mref);
+      const float alpha = __builtin_amdgcn_exp2f(m - mref);
       float rs = 0.f;
       float pr[4][4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(st[kt][r] - mref);
+          const float p = __builtin_amdgcn_exp2f(st[kt][r] - mref);
           rs += p;
           pr[kt][r] = p;
         }
@@ -554,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) 
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
           uint32_t r16[4];
-          s2t_rand_run<4>(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), r16);
+          attn_rand4(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), attn_fast_mask(a), r16);
 #pragma unroll
           for (int r = 0; r < 4; ++r) pr[kt][r] = r16[r] >= dth ? pr[kt][r] * dinv : 0.f;
         }
@@ -581,7 +608,8 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) 
         float v4[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
         st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
       }
-      if (y == 0 && a.lse) a.lse[(int64_t)z * a.Tq + i] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+      // (m and the scores are in the log2 domain here; the backward kernels take the natural-log row statistic)
+      if (y == 0 && a.lse) a.lse[(int64_t)z * a.Tq + i] = (l > 0.f) ? (m + __log2f(l)) * 0.693147180559945f : -INFINITY;
     }
   }
 }
@@ -719,7 +747,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       uint32_t r16[4] = {65535u, 65535u, 65535u, 65535u};
-      if (a.drop_p > 0.f) s2t_rand_run<4>(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), r16);
+      if (a.drop_p > 0.f) attn_rand4(dkey, rowbase + (uint64_t)(k0 + 16 * kt + 4 * y), attn_fast_mask(a), r16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = __expf(st[kt][r] - lse_ref);  // masked keys: exp(-inf) = 0, no branch per element
