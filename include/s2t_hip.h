@@ -186,6 +186,15 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
  * floats apart (1 and 0 to accumulate in place; with the [replicas][2][cols] workspace of s2t_layernorm_fold the adds of the
  * thousand workgroups no longer serialise on 2 x 64 addresses per head).
  * bf16, dk == 64, ldb % 8 == 0, 16-byte aligned dbd / pos_pt, 8-byte aligned dq rows. */
+/* The same branch AND this call's share of the position-table gradient in one pass over dbd (csrc/relpos_glue.hip; Tq <= 256):
+ *   dq += dqv and the two column sums as s2t_relpos_dqv (pos_p: the projected positions [2Tq-1][p_sr] as the forward takes
+ *   them, not the transposed table),
+ *   dp[n][h*64+c] = sum_{b,i} dbd[h][b][i][n] * qv[b*Tq+i][h*64+c]   (fp32 [2Tq-1][H*64], OVERWRITTEN: the gradient w.r.t. the
+ *   projected positions, espnet_multihead_attention.py:313-331 backward — what the split-K GEMM over K = B*Tq produced);
+ *   dp_part: scratch of B * (2Tq-1) * H*64 bf16 (per-utterance partial sums, summed in fp32 by a second kernel). */
+int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_sr, const void* qv, void* dq, int64_t dq_sb,
+                    int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, void* dp_part, float* dp,
+                    int B, int H, int Tq, int dk, void* stream);
 int s2t_relpos_dqv(const void* dbd, int64_t ldb, const void* pos_pt, int64_t pt_ld, void* dq, int64_t dq_sb, int64_t dq_sr,
                    float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, int B, int H, int Tq, int dk,
                    void* stream);

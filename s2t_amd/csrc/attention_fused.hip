@@ -210,7 +210,9 @@ __device__ __forceinline__ void ptile_store(char* lp, const PTile& t, int tid) {
   }
 }
 
-template <bool REL, int PRE = 0>
+// LOG2: the scores leave multiplied by scale * log2(e) (the forward kernels' softmax runs on v_exp_f32 as it is; both forward
+// kernels — this block form and the resident form — do the same arithmetic, so which of them runs changes no bit)
+template <bool REL, int PRE = 0, bool LOG2 = false>
 __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& qf, const char* lk, float* scratch,
                                              int h, int q0w, int k0, int klen, int x, int y, f32x4 (&st)[4],
                                              const char* lp = nullptr, int pblk0 = 0) {
@@ -252,11 +254,12 @@ __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& q
   // (bitwise predicates and a select: with short-circuit conditions the compiler builds an exec-mask branch per element,
   // 16 per block and wave)
   const int i = q0w + x;
+  const float sc = LOG2 ? a.scale * 1.44269504088896f : a.scale;
   if (!a.causal && k0 + KB <= klen) {  // the block lies wholly inside the utterance: no per-element mask (wave-uniform branch)
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st[kt][r] *= a.scale;
+      for (int r = 0; r < 4; ++r) st[kt][r] *= sc;
     return;
   }
   const int jlim = a.causal ? min(klen, i + 1) : klen;  // keys j >= jlim are masked for this lane's query
@@ -265,7 +268,7 @@ __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& q
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = k0 + 16 * kt + 4 * y + r;
-      const float s = st[kt][r] * a.scale;
+      const float s = st[kt][r] * sc;
       st[kt][r] = j >= jlim ? -INFINITY : s;
     }
 }
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
       if constexpr (REL) ptile_load(a, tp, h, q0, k0 + KB, tid);
     }
     f32x4 st[4];
-    scores_block<REL, REL ? 2 : 0>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, lp, 3 - w);
+    scores_block<REL, REL ? 2 : 0, true>(a, qf, lk, scratch, h, q0w, k0, klen, x, y, st, lp, 3 - w);  // log2 domain
     // ---- online softmax (row = lane's query; its 16 keys in registers, the other 48 in the 3 other y-groups)
     float mx = -INFINITY;
 #pragma unroll
@@ -351,14 +354,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
     // branch-free: exp(-inf) = 0 covers masked keys and the first block (m = -inf: alpha = 0 scales l = 0 and O = 0); a row
     // that has seen no valid key yet (mn = -inf) subtracts 0 instead
     const float mref = (mn == -INFINITY) ? 0.f : mn;
-    const float alpha = __expf(m - mref);
+    const float alpha = __builtin_amdgcn_exp2f(m - mref);
     float rs = 0.f;
     float pr[4][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf(st[kt][r] - mref);
+        const float p = __builtin_amdgcn_exp2f(st[kt][r] - mref);
         rs += p;
         pr[kt][r] = p;
       }
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
       float v4[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
       st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
     }
-    if (y == 0 && a.lse) a.lse[(int64_t)z * a.Tq + i] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+    if (y == 0 && a.lse) a.lse[(int64_t)z * a.Tq + i] = (l > 0.f) ? (m + __log2f(l)) * 0.693147180559945f : -INFINITY;
   }
 }
 

@@ -1,0 +1,281 @@
+// Relative-position attention backward, everything behind the skewed score gradient dbd in ONE pass over it (round 3):
+//   dqv[b,i,h,:]  = sum_n dbd[h][b][i][n] * p[n][h*64 : h*64+64]          the (Q + pos_bias_v) branch of dQ
+//   dq[b,i,h,:]  += dqv                                                   (bf16, in place)
+//   dpos_u[h*64+c] += sum_{b,i} dq_before[b,i,h,c],  dpos_v[h*64+c] += sum_{b,i} dqv[b,i,h,c]
+//   dp_part[b][n][h*64+c] = sum_i dbd[h][b][i][n] * qv[b,i,h*64+c]        this utterance's share of the position-table gradient
+//   (espnet_multihead_attention.py:313-337 backward: matrix_bd = (q + pos_bias_v) p^T, rel_shift; linear_pos).
+// Replaces s2t_relpos_dqv (one wave per 64 queries reading 57 MB of dbd as strided fragments: 21 us per layer), the batched
+// split-K GEMM over K = B * T that read dbd a second time (64 MB, 24 us) and its reduce: dbd is read ONCE, through LDS, by
+// one workgroup per (utterance, head) that keeps the head's 2T - 1 projected position rows resident (64 KiB).
+// Per 64-query tile of the slab (dbd rows are 2T - 1 <= 512 wide: a 64 x 512 bf16 tile = 64 KiB in LDS, 16-byte chunk j of row q
+// at q*1024 + ((j ^ (q & 15)) << 4)):
+//   (1) dqv^T[c][q] = sum_n P^T[c][n] dbd^T[n][q]   A = position image read column-wise (ds_read_b64_tr_b16), B = tile rows
+//   (2) dp^T[c][n] += sum_q qv^T[c][q] dbd[q][n]    A = the qv tile read column-wise, B = the dbd tile read column-wise
+// 256 MFMAs (16x16x32) each per tile; wave w owns two (channel tile, query tile) results of (1) and position tiles 4w .. 4w+3
+// of (2) (64 accumulator registers, kept across the query tiles).  The partial dp leaves as bf16 rows of 128 bytes; a second
+// kernel sums the B partials of a head in fp32 (s2t_relpos_glue's dp output, what the linear_pos weight gradient reads).
+#include "common.h"
+
+namespace {
+
+constexpr int DK = 64;
+constexpr int NP = 512;            // position rows / dbd columns held (2T - 1 <= 511)
+constexpr int L_P = 0;             // [NP][128 B]
+constexpr int L_D = NP * 128;      // [64][1024 B]
+constexpr int L_Q = L_D + 64 * 1024;  // [64][128 B]
+constexpr int L_BYTES = L_Q + 64 * 128 + 2 * 8 * 64 * 4;  // + [2][8 waves][64] floats of column sums
+
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ uint2 tr64(const char* a) {
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(a)));
+}
+
+// column-wise fragment of an image with 128-byte rows (chunk c of row r at r*128 + ((c ^ (r & 7)) << 4)): operand rows =
+// image columns 16 cblk + x, k = image rows row0 + 32 s + 8 y + j (natural order)
+__device__ __forceinline__ bf16x8 cols128(const char* img, int row0, int cblk, int s, int x, int y) {
+  const int qq = x >> 2, p = x & 3;
+  uint32_t w[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int R = row0 + 32 * s + 8 * y + 4 * h + qq;
+    const uint2 t = tr64(img + R * 128 + (((2 * cblk + (p >> 1)) ^ (R & 7)) << 4) + (p & 1) * 8);
+    w[2 * h] = t.x;
+    w[2 * h + 1] = t.y;
+  }
+  return as_frag(make_uint4(w[0], w[1], w[2], w[3]));
+}
+// the same of the dbd tile (1024-byte rows, chunk j of row q at q*1024 + ((j ^ (q & 15)) << 4)): operand columns = tile
+// columns 16 nblk + x, k = tile rows 32 s + 8 y + j
+__device__ __forceinline__ bf16x8 cols1024(const char* img, int nblk, int s, int x, int y) {
+  const int qq = x >> 2, p = x & 3;
+  uint32_t w[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int R = 32 * s + 8 * y + 4 * h + qq;
+    const uint2 t = tr64(img + R * 1024 + (((2 * nblk + (p >> 1)) ^ (R & 15)) << 4) + (p & 1) * 8);
+    w[2 * h] = t.x;
+    w[2 * h + 1] = t.y;
+  }
+  return as_frag(make_uint4(w[0], w[1], w[2], w[3]));
+}
+
+struct GlueArgs {
+  const bf16_t* dbd;   // [H][B][Tq][ldb]
+  int64_t ldb;
+  const bf16_t* pos_p; // [2Tq-1][p_sr], head h at column h*64
+  int64_t p_sr;
+  const bf16_t* qv;    // [B*Tq][H*64]
+  bf16_t* dq;          // rows b*dq_sb + i*dq_sr, head h at column h*64
+  int64_t dq_sb, dq_sr;
+  float *du, *dv;      // column-sum targets (replicated)
+  int replicas;
+  int64_t replica_stride;
+  bf16_t* dp_part;     // [B][2Tq-1][H*64]
+  int B, H, Tq;
+};
+
+__global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[L_BYTES];
+  char* lp = lds + L_P;
+  char* ld = lds + L_D;
+  char* lq = lds + L_Q;
+  float* red = reinterpret_cast<float*>(lds + L_Q + 64 * 128);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 15, y = lane >> 4;
+  const int z = blockIdx.x;
+  const int b = z / a.H, h = z % a.H;
+  const int npos = 2 * a.Tq - 1;
+  const int d = a.H * DK;
+
+  // ---- the head's projected position rows (rows >= 2T-1 zero)
+  {
+    const bf16_t* pp = a.pos_p + h * DK;
+    uint4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = tid + 512 * u;
+      const int n = min(c >> 3, npos - 1);
+      t[u] = *reinterpret_cast<const uint4*>(pp + (int64_t)n * a.p_sr + (c & 7) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = tid + 512 * u;
+      const int n = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4)) = n < npos ? t[u] : make_uint4(0, 0, 0, 0);
+    }
+  }
+  const bf16_t* slab = a.dbd + (((int64_t)h * a.B + b) * a.Tq) * a.ldb;
+  const int nchunk = (int)(a.ldb / 8);  // 16-byte chunks per dbd row (<= 64)
+
+  f32x4 dp[4][4];  // [position tile 4w + nt][channel tile]
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ct1 = w & 3, qh = w >> 2;  // product (1): channel tile ct1, query tiles 2 qh and 2 qh + 1 of the 64-query tile
+
+  for (int q0 = 0; q0 < a.Tq; q0 += 64) {
+    __syncthreads();  // the previous tile has been read
+    {
+      uint4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = tid + 512 * u;
+        const int q = min(q0 + (c >> 6), a.Tq - 1), j = min(c & 63, nchunk - 1);
+        t[u] = *reinterpret_cast<const uint4*>(slab + (int64_t)q * a.ldb + j * 8);
+      }
+      const int qr = tid >> 3;
+      const uint4 tq = *reinterpret_cast<const uint4*>(a.qv + ((int64_t)b * a.Tq + min(q0 + qr, a.Tq - 1)) * d + h * DK + (tid & 7) * 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = tid + 512 * u;
+        const int q = c >> 6, j = c & 63;
+        const bool ok = q0 + q < a.Tq && j < nchunk;
+        *reinterpret_cast<uint4*>(ld + q * 1024 + ((j ^ (q & 15)) << 4)) = ok ? t[u] : make_uint4(0, 0, 0, 0);
+      }
+      *reinterpret_cast<uint4*>(lq + qr * 128 + (((tid & 7) ^ (qr & 7)) << 4)) = q0 + qr < a.Tq ? tq : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    // ---- (1) dqv^T[c][q] over K = the 512 position columns
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    // the dq values this lane will update travel during the products
+    uint2 old[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = min(q0 + 16 * (2 * qh + t) + x, a.Tq - 1);
+      old[t] = *reinterpret_cast<const uint2*>(a.dq + (int64_t)b * a.dq_sb + (int64_t)i * a.dq_sr + h * DK + 16 * ct1 + 4 * y);
+    }
+#pragma unroll 4
+    for (int ks = 0; ks < NP / 32; ++ks) {
+      const bf16x8 pa = cols128(lp, 0, ct1, ks, x, y);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int q = 16 * (2 * qh + t) + x;
+        const bf16x8 db = as_frag(*reinterpret_cast<const uint4*>(ld + q * 1024 + (((4 * ks + y) ^ (q & 15)) << 4)));
+        acc[t] = mfma16(pa, db, acc[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = q0 + 16 * (2 * qh + t) + x;
+      if (i < a.Tq) {
+        const uint2 o = old[t];
+        const float o4[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                             __uint_as_float(o.y & 0xffff0000u)};
+        float n4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          su[r] += o4[r];
+          sv[r] += acc[t][r];
+          n4[r] = o4[r] + acc[t][r];
+        }
+        st4_from_f32<bf16_t>(a.dq + (int64_t)b * a.dq_sb + (int64_t)i * a.dq_sr + h * DK + 16 * ct1 + 4 * y, n4);
+      }
+    }
+    // ---- (2) dp^T[c][n] += qv^T[c][q] dbd[q][n] over the tile's 64 queries
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 qa[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) qa[ct] = cols128(lq, 0, ct, s, x, y);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const bf16x8 db = cols1024(ld, 4 * w + nt, s, x, y);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = mfma16(qa[ct], db, dp[nt][ct]);
+      }
+    }
+  }
+  // ---- column sums of the two branches: 16 query lanes by shuffles, the two waves of a channel tile through LDS, one atomic
+  // per channel and branch into a replica of the workspace
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      su[r] += __shfl_xor(su[r], o, 64);
+      sv[r] += __shfl_xor(sv[r], o, 64);
+    }
+  }
+  if (x == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[(0 * 8 + w) * 64 + 4 * y + r] = su[r];   // wave w: channels 16 ct1 + 4 y + r (slot 4 y + r of its 16)
+      red[(1 * 8 + w) * 64 + 4 * y + r] = sv[r];
+    }
+  }
+  __syncthreads();  // (also: every wave is done with the dbd tile)
+  if (tid < 128) {
+    const int br = tid >> 6, c = tid & 63;
+    const int ct = c >> 4, sl = c & 15;
+    const float sum = red[(br * 8 + ct) * 64 + sl] + red[(br * 8 + ct + 4) * 64 + sl];
+    const int64_t ro = (int64_t)(z % a.replicas) * a.replica_stride;
+    atomicAdd((br ? a.dv : a.du) + ro + h * DK + c, sum);
+  }
+  // ---- dp^T -> [n][64 channels] bf16 rows in LDS (the dbd tile's place), then whole 128-byte rows to the partial table.
+  // lane (n = x, y) of tile nt holds channels 16 ct + 4 y + r of position 16 (4 w + nt) + x
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = 16 * (4 * w + nt) + x;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const uint2 v = make_uint2(bf16pack(dp[nt][ct][0], dp[nt][ct][1]), bf16pack(dp[nt][ct][2], dp[nt][ct][3]));
+      *reinterpret_cast<uint2*>(ld + n * 128 + (((2 * ct + (y >> 1)) ^ (n & 7)) << 4) + (y & 1) * 8) = v;
+    }
+  }
+  __syncthreads();
+  bf16_t* out = a.dp_part + ((int64_t)b * npos) * d + h * DK;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = tid + 512 * u;
+    const int n = c >> 3, ch = c & 7;
+    if (n < npos) *reinterpret_cast<uint4*>(out + (int64_t)n * d + ch * 8) = *reinterpret_cast<const uint4*>(ld + n * 128 + ((ch ^ (n & 7)) << 4));
+  }
+}
+
+// dp[n][col] = sum_b part[b][n][col]  (fp32 out, overwritten), 8 columns per thread
+__global__ __launch_bounds__(256) void relpos_dp_reduce_kernel(const bf16_t* __restrict__ part, float* __restrict__ dp, int B,
+                                                               int64_t per_b /* npos * d */) {
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (e >= per_b) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    const uint4 v = *reinterpret_cast<const uint4*>(part + (int64_t)b * per_b + e);
+    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[2 * t] += __uint_as_float(w4[t] << 16);
+      s[2 * t + 1] += __uint_as_float(w4[t] & 0xffff0000u);
+    }
+  }
+  *reinterpret_cast<float4*>(dp + e) = make_float4(s[0], s[1], s[2], s[3]);
+  *reinterpret_cast<float4*>(dp + e + 4) = make_float4(s[4], s[5], s[6], s[7]);
+}
+
+}  // namespace
+
+extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_sr, const void* qv, void* dq,
+                               int64_t dq_sb, int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride,
+                               void* dp_part, float* dp, int B, int H, int Tq, int dk, void* stream) {
+  if (!dbd || !pos_p || !qv || !dq || !dpos_u || !dpos_v || !dp_part || !dp || B <= 0 || H <= 0 || Tq <= 0 || replicas < 1)
+    return S2T_ERR_ARG;
+  if (dk != DK || 2 * Tq - 1 > NP - 1) return S2T_ERR_UNSUPPORTED;
+  if (ldb < 2 * Tq - 1 || ldb % 8 || ldb > NP || p_sr % 8 || dq_sr % 4 || dq_sb % 4) return S2T_ERR_ARG;
+  if (((uintptr_t)dbd % 16) || ((uintptr_t)pos_p % 16) || ((uintptr_t)qv % 16) || ((uintptr_t)dq % 8) || ((uintptr_t)dp_part % 16) ||
+      ((uintptr_t)dp % 16))
+    return S2T_ERR_ALIGN;
+  GlueArgs a = {};
+  a.dbd = (const bf16_t*)dbd; a.ldb = ldb; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.qv = (const bf16_t*)qv;
+  a.dq = (bf16_t*)dq; a.dq_sb = dq_sb; a.dq_sr = dq_sr; a.du = dpos_u; a.dv = dpos_v; a.replicas = replicas;
+  a.replica_stride = replica_stride; a.dp_part = (bf16_t*)dp_part; a.B = B; a.H = H; a.Tq = Tq;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(relpos_glue_kernel, dim3(B * H), dim3(512), 0, s, a);
+  const int64_t per_b = (int64_t)(2 * Tq - 1) * H * DK;
+  hipLaunchKernelGGL(relpos_dp_reduce_kernel, dim3((unsigned)((per_b / 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)dp_part, dp, B,
+                     per_b);
+  return S2T_LAUNCH_CHECK();
+}

@@ -1182,7 +1182,20 @@ class AttentionFn(torch.autograd.Function):
                          dbd_band_only=rel, pos_pt=pt[0] if pt is not None else None, pt_ld=pt[1] if pt is not None else 0,
                          dpos_u=prm["pos_u"].grad.view(-1) if pt is not None else None,
                          dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv)
-        if rel:
+        glue_done = False
+        if rel and _RELPOS_GLUE and pt is None and dt == torch.bfloat16 and dk == 64 and Tq <= 256 and ldq % 4 == 0 and _arm_backward_end():
+            # everything behind dbd in ONE pass over it (csrc/relpos_glue.hip): the (Q+v) branch added into dq, both bias
+            # gradients (column sums into the replicated workspace, folded with the LayerNorm gradients) and this layer's
+            # gradient w.r.t. the projected positions, queued for the batched linear_pos weight gradient
+            ws = _ln_workspace(d, dev)
+            dp = _posq_slot(n_pos, d, dev, zero=False)
+            K.relpos_glue(dBD, ldB, p, d, qv, dq, Tq * ldq, ldq, ws, ws[d:], dp, B, H, Tq, dk, replicas=K.LN_REPLICAS,
+                          replica_stride=2 * d)
+            _LNQ["entries"].append((ws, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), d))
+            _POSQ["entries"].append((dp, _pos_table_f32(pos_tab), prm["pos_w"].grad, n_pos, d))
+            _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
+            glue_done = True
+        if rel and not glue_done:
             fuse_glue = dt == torch.bfloat16 and d == 256 and ldq % 8 == 0
             # the (Q+v) branch, the add into dq and both bias gradients in one band-limited launch (s2t_relpos_dqv) when the
             # stack kept the transposed projections
@@ -2072,6 +2085,7 @@ def ctc_compress_plan(logit2d, lens32, B, T, blank, threshold):
 # SATE adapter (inter_league)
 # ------------------------------------------------------------------------------------------------
 _POS32 = {}
+_RELPOS_GLUE = os.environ.get("S2T_RELPOS_GLUE", "1") != "0"  # s2t_relpos_glue: (Q+v) branch + bias sums + position-table gradient in one pass over dbd
 _DP_SPLIT = int(os.environ.get("S2T_DP_SPLIT", "16"))  # K split of the position-table gradient GEMM (M = 2T-1, N = 64 per head, K = B*T)
 _POSW_SPLIT = int(os.environ.get("S2T_POSW_SPLIT", "0"))  # experiment: K split of the small fp32 linear_pos weight-gradient GEMM
 

@@ -649,6 +649,17 @@ def relpos_dqv(dbd, ldb, pos_pt, pt_ld, dq, dq_sb, dq_sr, dpos_u, dpos_v, B, H, 
           dpos_v.data_ptr(), replicas, replica_stride, B, H, Tq, dk)
 
 
+def relpos_glue(dbd, ldb, pos_p, p_sr, qv, dq, dq_sb, dq_sr, dpos_u, dpos_v, dp, B, H, Tq, dk, replicas=1, replica_stride=0):
+    """s2t_relpos_glue: dq += (Q+v) branch, both bias-gradient column sums, and dp (fp32 [2Tq-1, H*dk], overwritten) in one
+    pass over dbd."""
+    L.require_cuda(dbd, pos_p, qv, dq, dpos_u, dpos_v, dp)
+    assert dbd.dtype == torch.bfloat16 and pos_p.dtype == torch.bfloat16 and qv.dtype == torch.bfloat16 and dq.dtype == torch.bfloat16
+    assert dp.dtype == torch.float32 and dp.is_contiguous() and dp.shape == (2 * Tq - 1, H * dk) and qv.is_contiguous()
+    part = _scratch("relpos_dp_part", (B * (2 * Tq - 1) * H * dk + 1) // 2, dbd.device)  # fp32 scratch holding the bf16 partials
+    _call("s2t_relpos_glue", dbd.data_ptr(), ldb, pos_p.data_ptr(), p_sr, qv.data_ptr(), dq.data_ptr(), dq_sb, dq_sr,
+          dpos_u.data_ptr(), dpos_v.data_ptr(), replicas, replica_stride, part.data_ptr(), dp.data_ptr(), B, H, Tq, dk)
+
+
 def time_warp(x, y, n_frames, warp, mean_out=None):
     B, T, Cf = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype

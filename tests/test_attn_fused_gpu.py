@@ -261,3 +261,43 @@ def test_relpos_dqv(Tq, B, H):
     np.testing.assert_array_equal(got[:, d:].numpy(), dqkv.double()[:, d:].numpy())  # k | v columns untouched
     np.testing.assert_allclose(du.cpu().double().numpy(), (du0.double() + old.sum(0)).numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(dv.cpu().double().numpy(), (dv0.double() + dqv.sum(0)).numpy(), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("Tq,B,H", [(250, 3, 4), (17, 2, 2), (100, 2, 4), (251, 1, 4), (256, 2, 4)])
+def test_relpos_glue(Tq, B, H):
+    """s2t_relpos_glue against float64: everything behind the skewed score gradient in one pass over it — dqv from the band of
+    dbd added into a strided dq, both bias-gradient column sums accumulated on top of what is there (replicated workspace), and
+    the gradient w.r.t. the projected positions dp[n][h, c] = sum_{b,i} dbd[h,b,i,n] qv[b,i,h,c] (overwritten; bf16 per-utterance
+    partials summed in fp32)."""
+    g = torch.Generator().manual_seed(3 * Tq + H)
+    dk, bf = 64, torch.bfloat16
+    d = H * dk
+    n_pos = 2 * Tq - 1
+    ldb = (n_pos + 7) // 8 * 8
+    ii = torch.arange(Tq)[:, None]
+    nn = torch.arange(ldb)[None, :]
+    band = (nn >= Tq - 1 - ii) & (nn <= 2 * Tq - 2 - ii)
+    dbd = torch.where(band[None, None], torch.randn(H, B, Tq, ldb, generator=g) * 0.5, torch.zeros(H, B, Tq, ldb)).to(bf)
+    p = (torch.randn(n_pos, d, generator=g) * 0.7).to(bf)
+    qv = (torch.randn(B * Tq, d, generator=g) * 0.6).to(bf)
+    ldq = 3 * d
+    dqkv = (torch.randn(B * Tq, ldq, generator=g) * 0.5).to(bf)
+    R = 4
+    ws0 = torch.randn(R, 2, d, generator=g)
+    ws = ws0.clone().to(DEV)
+    dq_dev = dqkv.to(DEV)
+    dp = torch.full((n_pos, d), 7.0, device=DEV)
+    K.relpos_glue(dbd.to(DEV), ldb, p.to(DEV), d, qv.to(DEV), dq_dev, Tq * ldq, ldq, ws.view(-1), ws.view(-1)[d:], dp, B, H, Tq, dk,
+                  replicas=R, replica_stride=2 * d)
+    torch.cuda.synchronize()
+    dqv = torch.einsum("hbin,nhc->bihc", dbd.double()[..., :n_pos], p.double().view(n_pos, H, dk)).reshape(B * Tq, d)
+    old = dqkv.double()[:, :d]
+    got = dq_dev.cpu().double()
+    np.testing.assert_allclose(got[:, :d].numpy(), (old + dqv).numpy(), rtol=1e-2, atol=2e-2)  # one bf16 rounding of the sum
+    np.testing.assert_array_equal(got[:, d:].numpy(), dqkv.double()[:, d:].numpy())  # k | v columns untouched
+    add = (ws.cpu().double() - ws0.double()).sum(0)  # the column sums, whichever replica took them
+    np.testing.assert_allclose(add[0].numpy(), old.sum(0).numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(add[1].numpy(), dqv.sum(0).numpy(), rtol=1e-4, atol=3e-3)
+    dp_ref = torch.einsum("hbin,bihc->nhc", dbd.double()[..., :n_pos], qv.double().view(B, Tq, H, dk)).reshape(n_pos, d)
+    err = (dp.cpu().double() - dp_ref).abs().max() / dp_ref.abs().max()
+    assert err < 1e-2, float(err)  # bf16 partial per utterance
