@@ -7,11 +7,11 @@
 // Replaces s2t_relpos_dqv (one wave per 64 queries reading 57 MB of dbd as strided fragments: 21 us per layer), the batched
 // split-K GEMM over K = B * T that read dbd a second time (64 MB, 24 us) and its reduce: dbd is read ONCE, through LDS, by
 // one workgroup per (utterance, head) that keeps the head's 2T - 1 projected position rows resident (64 KiB).
-// Per 64-query tile of the slab (dbd rows are 2T - 1 <= 512 wide: a 64 x 512 bf16 tile = 64 KiB in LDS, 16-byte chunk j of row q
-// at q*1024 + ((j ^ (q & 15)) << 4)):
+// Per 32-query tile of the slab (dbd rows are 2T - 1 <= 512 wide: a 32 x 512 bf16 tile = 32 KiB in LDS, double buffered, 16-byte
+// chunk j of row q at q*1024 + ((j ^ (q & 15)) << 4)):
 //   (1) dqv^T[c][q] = sum_n P^T[c][n] dbd^T[n][q]   A = position image read column-wise (ds_read_b64_tr_b16), B = tile rows
 //   (2) dp^T[c][n] += sum_q qv^T[c][q] dbd[q][n]    A = the qv tile read column-wise, B = the dbd tile read column-wise
-// 256 MFMAs (16x16x32) each per tile; wave w owns two (channel tile, query tile) results of (1) and position tiles 4w .. 4w+3
+// 128 MFMAs (16x16x32) each per tile; wave w owns one (channel tile, query tile) result of (1) and position tiles 4w .. 4w+3
 // of (2) (64 accumulator registers, kept across the query tiles).  The partial dp leaves as bf16 rows of 128 bytes; a second
 // kernel sums the B partials of a head in fp32 (s2t_relpos_glue's dp output, what the linear_pos weight gradient reads).
 #include "common.h"
@@ -20,10 +20,11 @@ namespace {
 
 constexpr int DK = 64;
 constexpr int NP = 512;            // position rows / dbd columns held (2T - 1 <= 511)
+constexpr int TQ = 32;             // queries per tile
 constexpr int L_P = 0;             // [NP][128 B]
-constexpr int L_D = NP * 128;      // [64][1024 B]
-constexpr int L_Q = L_D + 64 * 1024;  // [64][128 B]
-constexpr int L_BYTES = L_Q + 64 * 128 + 2 * 8 * 64 * 4;  // + [2][8 waves][64] floats of column sums
+constexpr int L_D = NP * 128;      // two dbd tiles [TQ][1024 B]
+constexpr int L_Q = L_D + 2 * TQ * 1024;  // two qv tiles [TQ][128 B]
+constexpr int L_BYTES = L_Q + 2 * TQ * 128 + 2 * 8 * 64 * 4;  // + [2][8 waves][64] floats of column sums
 
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 
@@ -33,7 +34,15 @@ __device__ __forceinline__ uint2 tr64(const char* a) {
   return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(a)));
 }
 
-// column-wise fragment of an image with 128-byte rows (chunk c of row r at r*128 + ((c ^ (r & 7)) << 4)): operand rows =
+// Swizzle keys chosen for the NATURAL-order transposed reads of this kernel (a 32-lane half of ds_read_b64_tr_b16 touches rows
+// {r, r+1, r+2, r+3, r+8, .. r+11} x two adjacent 16-byte chunks: sixteen different bank groups with these keys; the usual
+// (r & 7) key puts rows r and r + 8 on the same one).  key128: images with 128-byte rows (two rows per 256-byte bank row, the
+// row's parity picks the half); key1024: the dbd tile (every row starts a bank row; also conflict-free for its ds_read_b128
+// row reads, whose 16-lane groups are rows {0-3, 12-15} at one chunk and {4-11} at the next).
+__device__ __forceinline__ int key128(int r) { return 2 * (((r >> 1) & 1) | (((r >> 3) & 1) << 1)); }
+__device__ __forceinline__ int key1024(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
+
+// column-wise fragment of an image with 128-byte rows (chunk c of row r at r*128 + ((c ^ key128(r)) << 4)): operand rows =
 // image columns 16 cblk + x, k = image rows row0 + 32 s + 8 y + j (natural order)
 __device__ __forceinline__ bf16x8 cols128(const char* img, int row0, int cblk, int s, int x, int y) {
   const int qq = x >> 2, p = x & 3;
@@ -41,13 +50,13 @@ __device__ __forceinline__ bf16x8 cols128(const char* img, int row0, int cblk, i
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int R = row0 + 32 * s + 8 * y + 4 * h + qq;
-    const uint2 t = tr64(img + R * 128 + (((2 * cblk + (p >> 1)) ^ (R & 7)) << 4) + (p & 1) * 8);
+    const uint2 t = tr64(img + R * 128 + (((2 * cblk + (p >> 1)) ^ key128(R)) << 4) + (p & 1) * 8);
     w[2 * h] = t.x;
     w[2 * h + 1] = t.y;
   }
   return as_frag(make_uint4(w[0], w[1], w[2], w[3]));
 }
-// the same of the dbd tile (1024-byte rows, chunk j of row q at q*1024 + ((j ^ (q & 15)) << 4)): operand columns = tile
+// the same of the dbd tile (1024-byte rows, chunk j of row q at q*1024 + ((j ^ key1024(q)) << 4)): operand columns = tile
 // columns 16 nblk + x, k = tile rows 32 s + 8 y + j
 __device__ __forceinline__ bf16x8 cols1024(const char* img, int nblk, int s, int x, int y) {
   const int qq = x >> 2, p = x & 3;
@@ -55,7 +64,7 @@ __device__ __forceinline__ bf16x8 cols1024(const char* img, int nblk, int s, int
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int R = 32 * s + 8 * y + 4 * h + qq;
-    const uint2 t = tr64(img + R * 1024 + (((2 * nblk + (p >> 1)) ^ (R & 15)) << 4) + (p & 1) * 8);
+    const uint2 t = tr64(img + R * 1024 + (((2 * nblk + (p >> 1)) ^ key1024(R)) << 4) + (p & 1) * 8);
     w[2 * h] = t.x;
     w[2 * h + 1] = t.y;
   }
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
     for (int u = 0; u < 8; ++u) {
       const int c = tid + 512 * u;
       const int n = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4)) = n < npos ? t[u] : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ key128(n)) << 4)) = n < npos ? t[u] : make_uint4(0, 0, 0, 0);
     }
   }
   const bf16_t* slab = a.dbd + (((int64_t)h * a.B + b) * a.Tq) * a.ldb;
@@ -117,79 +126,87 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
-  const int ct1 = w & 3, qh = w >> 2;  // product (1): channel tile ct1, query tiles 2 qh and 2 qh + 1 of the 64-query tile
+  const int ct1 = w & 3, qh = w >> 2;  // product (1): channel tile ct1, query tile qh of the 32-query tile
 
-  for (int q0 = 0; q0 < a.Tq; q0 += 64) {
-    __syncthreads();  // the previous tile has been read
-    {
-      uint4 t[8];
+  // 32-query tiles, double buffered: the next tile's rows travel global -> registers during this tile's products and are
+  // written to the other LDS buffer behind them (one barrier per tile)
+  uint4 tr[4], tqv = make_uint4(0, 0, 0, 0);
+  uint2 old_n = make_uint2(0, 0);  // the dq values this lane updates in the NEXT tile (a global round trip per tile otherwise)
+  auto tile_load = [&](int q0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = tid + 512 * u;
-        const int q = min(q0 + (c >> 6), a.Tq - 1), j = min(c & 63, nchunk - 1);
-        t[u] = *reinterpret_cast<const uint4*>(slab + (int64_t)q * a.ldb + j * 8);
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int c = tid + 512 * u;
+      const int q = min(q0 + (c >> 6), a.Tq - 1), jc = min(c & 63, nchunk - 1);
+      tr[u] = *reinterpret_cast<const uint4*>(slab + (int64_t)q * a.ldb + jc * 8);
+    }
+    if (tid < 256)
+      tqv = *reinterpret_cast<const uint4*>(a.qv + ((int64_t)b * a.Tq + min(q0 + (tid >> 3), a.Tq - 1)) * d + h * DK + (tid & 7) * 8);
+    old_n = *reinterpret_cast<const uint2*>(a.dq + (int64_t)b * a.dq_sb + (int64_t)min(q0 + 16 * qh + x, a.Tq - 1) * a.dq_sr + h * DK +
+                                            16 * ct1 + 4 * y);
+  };
+  auto tile_store = [&](int q0, int buf) __attribute__((always_inline)) {
+    char* ldb_ = ld + buf * (TQ * 1024);
+    char* lqb = lq + buf * (TQ * 128);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = tid + 512 * u;
+      const int q = c >> 6, jc = c & 63;
+      const bool ok = q0 + q < a.Tq && jc < nchunk;
+      *reinterpret_cast<uint4*>(ldb_ + q * 1024 + ((jc ^ key1024(q)) << 4)) = ok ? tr[u] : make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 256) {
       const int qr = tid >> 3;
-      const uint4 tq = *reinterpret_cast<const uint4*>(a.qv + ((int64_t)b * a.Tq + min(q0 + qr, a.Tq - 1)) * d + h * DK + (tid & 7) * 8);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = tid + 512 * u;
-        const int q = c >> 6, j = c & 63;
-        const bool ok = q0 + q < a.Tq && j < nchunk;
-        *reinterpret_cast<uint4*>(ld + q * 1024 + ((j ^ (q & 15)) << 4)) = ok ? t[u] : make_uint4(0, 0, 0, 0);
-      }
-      *reinterpret_cast<uint4*>(lq + qr * 128 + (((tid & 7) ^ (qr & 7)) << 4)) = q0 + qr < a.Tq ? tq : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(lqb + qr * 128 + (((tid & 7) ^ key128(qr)) << 4)) = q0 + qr < a.Tq ? tqv : make_uint4(0, 0, 0, 0);
     }
-    __syncthreads();
+  };
+  tile_load(0);
+  tile_store(0, 0);
+  __syncthreads();  // (also orders the position image)
+  int buf = 0;
+  for (int q0 = 0; q0 < a.Tq; q0 += TQ, buf ^= 1) {
+    const bool more = q0 + TQ < a.Tq;
+    const uint2 old = old_n;
+    if (more) tile_load(q0 + TQ);
+    const char* ldc = ld + buf * (TQ * 1024);
+    const char* lqc = lq + buf * (TQ * 128);
     // ---- (1) dqv^T[c][q] over K = the 512 position columns
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    // the dq values this lane will update travel during the products
-    uint2 old[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int i = min(q0 + 16 * (2 * qh + t) + x, a.Tq - 1);
-      old[t] = *reinterpret_cast<const uint2*>(a.dq + (int64_t)b * a.dq_sb + (int64_t)i * a.dq_sr + h * DK + 16 * ct1 + 4 * y);
-    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int i = q0 + 16 * qh + x;
+    {
+      const int q = 16 * qh + x;
 #pragma unroll 4
-    for (int ks = 0; ks < NP / 32; ++ks) {
-      const bf16x8 pa = cols128(lp, 0, ct1, ks, x, y);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int q = 16 * (2 * qh + t) + x;
-        const bf16x8 db = as_frag(*reinterpret_cast<const uint4*>(ld + q * 1024 + (((4 * ks + y) ^ (q & 15)) << 4)));
-        acc[t] = mfma16(pa, db, acc[t]);
+      for (int ks = 0; ks < NP / 32; ++ks) {
+        const bf16x8 pa = cols128(lp, 0, ct1, ks, x, y);
+        const bf16x8 db = as_frag(*reinterpret_cast<const uint4*>(ldc + q * 1024 + (((4 * ks + y) ^ key1024(q)) << 4)));
+        acc = mfma16(pa, db, acc);
       }
     }
+    if (i < a.Tq) {
+      const float o4[4] = {__uint_as_float(old.x << 16), __uint_as_float(old.x & 0xffff0000u), __uint_as_float(old.y << 16),
+                           __uint_as_float(old.y & 0xffff0000u)};
+      float n4[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int i = q0 + 16 * (2 * qh + t) + x;
-      if (i < a.Tq) {
-        const uint2 o = old[t];
-        const float o4[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
-                             __uint_as_float(o.y & 0xffff0000u)};
-        float n4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          su[r] += o4[r];
-          sv[r] += acc[t][r];
-          n4[r] = o4[r] + acc[t][r];
-        }
-        st4_from_f32<bf16_t>(a.dq + (int64_t)b * a.dq_sb + (int64_t)i * a.dq_sr + h * DK + 16 * ct1 + 4 * y, n4);
+      for (int r = 0; r < 4; ++r) {
+        su[r] += o4[r];
+        sv[r] += acc[r];
+        n4[r] = o4[r] + acc[r];
       }
+      st4_from_f32<bf16_t>(a.dq + (int64_t)b * a.dq_sb + (int64_t)i * a.dq_sr + h * DK + 16 * ct1 + 4 * y, n4);
     }
-    // ---- (2) dp^T[c][n] += qv^T[c][q] dbd[q][n] over the tile's 64 queries
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    // ---- (2) dp^T[c][n] += qv^T[c][q] dbd[q][n] over the tile's 32 queries (one k-step)
+    {
       bf16x8 qa[4];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) qa[ct] = cols128(lq, 0, ct, s, x, y);
+      for (int ct = 0; ct < 4; ++ct) qa[ct] = cols128(lqc, 0, ct, 0, x, y);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const bf16x8 db = cols1024(ld, 4 * w + nt, s, x, y);
+        const bf16x8 db = cols1024(ldc, 4 * w + nt, 0, x, y);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = mfma16(qa[ct], db, dp[nt][ct]);
       }
     }
+    if (more) tile_store(q0 + TQ, buf ^ 1);  // (the other buffer was last read a tile ago, behind the previous barrier)
+    __syncthreads();
   }
   // ---- column sums of the two branches: 16 query lanes by shuffles, the two waves of a channel tile through LDS, one atomic
   // per channel and branch into a replica of the workspace
@@ -216,7 +233,8 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
     const int64_t ro = (int64_t)(z % a.replicas) * a.replica_stride;
     atomicAdd((br ? a.dv : a.du) + ro + h * DK + c, sum);
   }
-  // ---- dp^T -> [n][64 channels] bf16 rows in LDS (the dbd tile's place), then whole 128-byte rows to the partial table.
+  // ---- dp^T -> [n][64 channels] bf16 rows in LDS (the position image's place: every product is done), then whole 128-byte
+  // rows to the partial table.
   // lane (n = x, y) of tile nt holds channels 16 ct + 4 y + r of position 16 (4 w + nt) + x
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       const uint2 v = make_uint2(bf16pack(dp[nt][ct][0], dp[nt][ct][1]), bf16pack(dp[nt][ct][2], dp[nt][ct][3]));
-      *reinterpret_cast<uint2*>(ld + n * 128 + (((2 * ct + (y >> 1)) ^ (n & 7)) << 4) + (y & 1) * 8) = v;
+      *reinterpret_cast<uint2*>(lp + n * 128 + (((2 * ct + (y >> 1)) ^ (n & 7)) << 4) + (y & 1) * 8) = v;
     }
   }
   __syncthreads();
@@ -233,27 +251,43 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
   for (int u = 0; u < 8; ++u) {
     const int c = tid + 512 * u;
     const int n = c >> 3, ch = c & 7;
-    if (n < npos) *reinterpret_cast<uint4*>(out + (int64_t)n * d + ch * 8) = *reinterpret_cast<const uint4*>(ld + n * 128 + ((ch ^ (n & 7)) << 4));
+    if (n < npos) *reinterpret_cast<uint4*>(out + (int64_t)n * d + ch * 8) = *reinterpret_cast<const uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4));
   }
 }
 
-// dp[n][col] = sum_b part[b][n][col]  (fp32 out, overwritten), 8 columns per thread
+// dp[n][col] = sum_b part[b][n][col]  (fp32 out, overwritten): 8 columns per thread, the utterances dealt to the four
+// 64-thread rows of a workgroup (independent 16-byte loads in flight), the four partial sums meet in LDS
 __global__ __launch_bounds__(256) void relpos_dp_reduce_kernel(const bf16_t* __restrict__ part, float* __restrict__ dp, int B,
                                                                int64_t per_b /* npos * d */) {
-  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-  if (e >= per_b) return;
+  __shared__ float red[3][64][8];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t e = ((int64_t)blockIdx.x * 64 + tx) * 8;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < B; ++b) {
-    const uint4 v = *reinterpret_cast<const uint4*>(part + (int64_t)b * per_b + e);
-    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+  if (e < per_b) {
+#pragma unroll 4
+    for (int b = ty; b < B; b += 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(part + (int64_t)b * per_b + e);
+      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      s[2 * t] += __uint_as_float(w4[t] << 16);
-      s[2 * t + 1] += __uint_as_float(w4[t] & 0xffff0000u);
+      for (int t = 0; t < 4; ++t) {
+        s[2 * t] += __uint_as_float(w4[t] << 16);
+        s[2 * t + 1] += __uint_as_float(w4[t] & 0xffff0000u);
+      }
     }
   }
-  *reinterpret_cast<float4*>(dp + e) = make_float4(s[0], s[1], s[2], s[3]);
-  *reinterpret_cast<float4*>(dp + e + 4) = make_float4(s[4], s[5], s[6], s[7]);
+  if (ty > 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[ty - 1][tx][t] = s[t];
+  }
+  __syncthreads();
+  if (ty == 0 && e < per_b) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) s[t] += red[g][tx][t];
+    *reinterpret_cast<float4*>(dp + e) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(dp + e + 4) = make_float4(s[4], s[5], s[6], s[7]);
+  }
 }
 
 }  // namespace
@@ -275,7 +309,7 @@ extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(relpos_glue_kernel, dim3(B * H), dim3(512), 0, s, a);
   const int64_t per_b = (int64_t)(2 * Tq - 1) * H * DK;
-  hipLaunchKernelGGL(relpos_dp_reduce_kernel, dim3((unsigned)((per_b / 8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)dp_part, dp, B,
+  hipLaunchKernelGGL(relpos_dp_reduce_kernel, dim3((unsigned)((per_b / 8 + 63) / 64)), dim3(256), 0, s, (const bf16_t*)dp_part, dp, B,
                      per_b);
   return S2T_LAUNCH_CHECK();
 }
