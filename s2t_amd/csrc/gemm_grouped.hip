@@ -305,7 +305,7 @@ constexpr int STAGE2 = 2 * PART2;     // 32 KiB
 
 __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const s2t_wgrad_problem* __restrict__ probs,
                                                           const Item* __restrict__ items, int n_items,
-                                                          float* __restrict__ ws) {
+                                                          float* __restrict__ ws, int nt_mode, int stagger) {
   typedef bf16_t T;
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE2];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -362,13 +362,27 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const s2t_wgrad_proble
     const i32x4 srdB = make_srd(reinterpret_cast<const char*>(p->B) + (int64_t)it.tn * (T2 * 2), (uint32_t)(b_bytes > 0 ? b_bytes : 0));
     const uint32_t vA0 = (uint32_t)r0 * lda2 + cp0, vA1 = (uint32_t)(r0 + 2) * lda2 + cp1;
     const uint32_t vB0 = (uint32_t)r0 * ldb2 + cp0, vB1 = (uint32_t)(r0 + 2) * ldb2 + cp1;
+    // an operand tile that no other tile of this weight reads is fetched non-temporally: its lines would only push the
+    // SHARED operand's (xn of a W1 gradient: read by all eight 256-column tiles) out of the XCD's L2
+    const bool ntA = nt_mode == 2 || (nt_mode == 1 && p->tiles_n == 1);
+    const bool ntB = nt_mode == 2 || (nt_mode == 1 && p->M <= T2);
     auto issue = [&](int kt, int st) __attribute__((always_inline)) {
       const uint32_t la = ldsw + (uint32_t)st * STAGE2;
       const uint32_t sa = (uint32_t)kt * (BK2 * lda2), sb = (uint32_t)kt * (BK2 * ldb2);
-      dma16(la, vA0, srdA, sa);
-      dma16(la + 1024, vA1, srdA, sa);
-      dma16(la + PART2, vB0, srdB, sb);
-      dma16(la + PART2 + 1024, vB1, srdB, sb);
+      if (ntA) {
+        dma16_nt(la, vA0, srdA, sa);
+        dma16_nt(la + 1024, vA1, srdA, sa);
+      } else {
+        dma16(la, vA0, srdA, sa);
+        dma16(la + 1024, vA1, srdA, sa);
+      }
+      if (ntB) {
+        dma16_nt(la + PART2, vB0, srdB, sb);
+        dma16_nt(la + PART2 + 1024, vB1, srdB, sb);
+      } else {
+        dma16(la + PART2, vB0, srdB, sb);
+        dma16(la + PART2 + 1024, vB1, srdB, sb);
+      }
     };
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -378,14 +392,17 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const s2t_wgrad_proble
     for (int e = 0; e < 8; ++e) csum[e] = 0.f;
     // every wave is done with the previous item's stages (and its LDS scratch) before new rows land in them
     __syncthreads();
+    // the tiles of one weight walk their K-range from different starting steps (wrapping around)
+    const int rot = nst > 0 ? ((it.tm + it.tn) * stagger) % nst : 0;
+    auto kstep = [&](int t) __attribute__((always_inline)) { const int r = t + rot; return kt0 + (r >= nst ? r - nst : r); };
     for (int u = 0; u < 3; ++u)
-      if (u < nst) issue(kt0 + u, (sc + u) & (NST - 1));
+      if (u < nst) issue(kstep(u), (sc + u) & (NST - 1));
     for (int t = 0; t < nst; ++t) {
       const int rem = nst - 1 - t;  // steps issued after this one
       if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
       else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (t + 3 < nst) issue(kt0 + t + 3, (sc + t + 3) & (NST - 1));
+      if (t + 3 < nst) issue(kstep(t + 3), (sc + t + 3) & (NST - 1));
       const char* pa = smem + ((sc + t) & (NST - 1)) * STAGE2;
       const char* pb = pa + PART2;
       auto tr8 = [&](const char* a) __attribute__((always_inline)) -> Frag {
@@ -493,7 +510,12 @@ extern "C" int s2t_wgrad_grouped256(const s2t_wgrad_problem* problems_dev, int n
   hipStream_t s = (hipStream_t)stream;
   const int slots = s2t_device_cu_count();  // 128 KiB of LDS per workgroup: one per CU
   dim3 grid(n_items < slots ? n_items : slots), block(512);
-  hipLaunchKernelGGL(wgrad256_kernel, grid, block, 0, s, problems_dev, reinterpret_cast<const Item*>(items_dev), n_items, ws);
+  const char* e = getenv("S2T_WG_NT");
+  const int nt_mode = e ? atoi(e) : 1;
+  const char* e2 = getenv("S2T_WG_STAG");
+  const int stagger = e2 ? atoi(e2) : 0;
+  hipLaunchKernelGGL(wgrad256_kernel, grid, block, 0, s, problems_dev, reinterpret_cast<const Item*>(items_dev), n_items, ws,
+                     nt_mode, stagger);
   hipLaunchKernelGGL(wgrad256_reduce_kernel, dim3(n_tiles, 32), dim3(512), 0, s, problems_dev,
                      reinterpret_cast<const TileRef*>(tiles_dev), ws);
   return S2T_LAUNCH_CHECK();

@@ -14,6 +14,12 @@ __device__ __forceinline__ void dma16(uint32_t lds_base, uint32_t voff, i32x4 sr
                :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
+// the same with the non-temporal policy: for bytes this launch reads ONCE (they then leave the lines of re-read operands in L2)
+__device__ __forceinline__ void dma16_nt(uint32_t lds_base, uint32_t voff, i32x4 srd, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+               :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
 // the same with an instruction offset (0..4095) that moves BOTH the global source and the LDS destination
 template <int OFF>
 __device__ __forceinline__ void dma16_off(uint32_t lds_base, uint32_t voff, i32x4 srd, uint32_t soff) {

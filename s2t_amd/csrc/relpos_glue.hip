@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int DK = 64;
+#ifndef S2T_GLUE_DBG
+#define S2T_GLUE_DBG 0  // experiment builds (tools/dbg_variant.sh): 1 no product (1), 2 no product (2), 4 one global tile load only,
+#endif                  // 8 no dq update, 16 no partial-table store
 constexpr int NP = 512;            // position rows / dbd columns held (2T - 1 <= 511)
 constexpr int TQ = 32;             // queries per tile
 constexpr int L_P = 0;             // [NP][128 B]
@@ -86,7 +89,7 @@ struct GlueArgs {
   int B, H, Tq;
 };
 
-__global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
+__global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[L_BYTES];
   char* lp = lds + L_P;
   char* ld = lds + L_D;
@@ -100,23 +103,6 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
   const int npos = 2 * a.Tq - 1;
   const int d = a.H * DK;
 
-  // ---- the head's projected position rows (rows >= 2T-1 zero)
-  {
-    const bf16_t* pp = a.pos_p + h * DK;
-    uint4 t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = tid + 512 * u;
-      const int n = min(c >> 3, npos - 1);
-      t[u] = *reinterpret_cast<const uint4*>(pp + (int64_t)n * a.p_sr + (c & 7) * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = tid + 512 * u;
-      const int n = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ key128(n)) << 4)) = n < npos ? t[u] : make_uint4(0, 0, 0, 0);
-    }
-  }
   const bf16_t* slab = a.dbd + (((int64_t)h * a.B + b) * a.Tq) * a.ldb;
   const int nchunk = (int)(a.ldb / 8);  // 16-byte chunks per dbd row (<= 64)
 
@@ -159,29 +145,75 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
       *reinterpret_cast<uint4*>(lqb + qr * 128 + (((tid & 7) ^ key128(qr)) << 4)) = q0 + qr < a.Tq ? tqv : make_uint4(0, 0, 0, 0);
     }
   };
-  tile_load(0);
+  tile_load(0);  // (in flight together with the position rows below: one global round trip for both)
+  // ---- the head's projected position rows (rows >= 2T-1 zero)
+  {
+    const bf16_t* pp = a.pos_p + h * DK;
+    uint4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = tid + 512 * u;
+      const int n = min(c >> 3, npos - 1);
+      t[u] = *reinterpret_cast<const uint4*>(pp + (int64_t)n * a.p_sr + (c & 7) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = tid + 512 * u;
+      const int n = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ key128(n)) << 4)) = n < npos ? t[u] : make_uint4(0, 0, 0, 0);
+    }
+  }
   tile_store(0, 0);
   __syncthreads();  // (also orders the position image)
   int buf = 0;
   for (int q0 = 0; q0 < a.Tq; q0 += TQ, buf ^= 1) {
     const bool more = q0 + TQ < a.Tq;
     const uint2 old = old_n;
-    if (more) tile_load(q0 + TQ);
+    if (more && !((S2T_GLUE_DBG & 4) && q0 > 0)) tile_load(q0 + TQ);
     const char* ldc = ld + buf * (TQ * 1024);
     const char* lqc = lq + buf * (TQ * 128);
     // ---- (1) dqv^T[c][q] over K = the 512 position columns
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // (hipcc sinks every fragment read to just in front of its MFMA — one exposed LDS round trip per MFMA of this dependent
+    // chain: the reads run one group of four k-steps ahead by hand, two accumulators halve the chain; the fragments of
+    // product (2) are read behind the last group's)
+    f32x4 acc, acc1 = {0.f, 0.f, 0.f, 0.f};
+    acc = acc1;
     const int i = q0 + 16 * qh + x;
+    bf16x8 qa[4], dbn[4];
     {
       const int q = 16 * qh + x;
-#pragma unroll 4
-      for (int ks = 0; ks < NP / 32; ++ks) {
-        const bf16x8 pa = cols128(lp, 0, ct1, ks, x, y);
-        const bf16x8 db = as_frag(*reinterpret_cast<const uint4*>(ldc + q * 1024 + (((4 * ks + y) ^ key1024(q)) << 4)));
-        acc = mfma16(pa, db, acc);
+      bf16x8 PA[2][4], DB[2][4];
+      auto rd1 = [&](int g, int sl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ks = 4 * g + j;
+          PA[sl][j] = cols128(lp, 0, ct1, ks, x, y);
+          DB[sl][j] = as_frag(*reinterpret_cast<const uint4*>(ldc + q * 1024 + (((4 * ks + y) ^ key1024(q)) << 4)));
+        }
+      };
+      rd1(0, 0);
+#pragma unroll
+      for (int g = 0; g < NP / 128; ++g) {
+        if (g + 1 < NP / 128) {
+          rd1(g + 1, (g + 1) & 1);
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) qa[ct] = cols128(lqc, 0, ct, 0, x, y);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) dbn[nt] = cols1024(ldc, 4 * w + nt, 0, x, y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          if (S2T_GLUE_DBG & 1) continue;
+          acc = mfma16(PA[g & 1][j], DB[g & 1][j], acc);
+          acc1 = mfma16(PA[g & 1][j + 1], DB[g & 1][j + 1], acc1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      acc += acc1;
     }
-    if (i < a.Tq) {
+    if (i < a.Tq && !(S2T_GLUE_DBG & 8)) {
       const float o4[4] = {__uint_as_float(old.x << 16), __uint_as_float(old.x & 0xffff0000u), __uint_as_float(old.y << 16),
                            __uint_as_float(old.y & 0xffff0000u)};
       float n4[4];
@@ -194,17 +226,11 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
       st4_from_f32<bf16_t>(a.dq + (int64_t)b * a.dq_sb + (int64_t)i * a.dq_sr + h * DK + 16 * ct1 + 4 * y, n4);
     }
     // ---- (2) dp^T[c][n] += qv^T[c][q] dbd[q][n] over the tile's 32 queries (one k-step)
-    {
-      bf16x8 qa[4];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) qa[ct] = cols128(lqc, 0, ct, 0, x, y);
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const bf16x8 db = cols1024(ldc, 4 * w + nt, 0, x, y);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = mfma16(qa[ct], db, dp[nt][ct]);
-      }
-    }
+      for (int ct = 0; ct < 4; ++ct)
+        if (!(S2T_GLUE_DBG & 2)) dp[nt][ct] = mfma16(qa[ct], dbn[nt], dp[nt][ct]);
     if (more) tile_store(q0 + TQ, buf ^ 1);  // (the other buffer was last read a tile ago, behind the previous barrier)
     __syncthreads();
   }
@@ -251,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void relpos_glue_kernel(const GlueArgs a) {
   for (int u = 0; u < 8; ++u) {
     const int c = tid + 512 * u;
     const int n = c >> 3, ch = c & 7;
-    if (n < npos) *reinterpret_cast<uint4*>(out + (int64_t)n * d + ch * 8) = *reinterpret_cast<const uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4));
+    if (n < npos && !(S2T_GLUE_DBG & 16)) *reinterpret_cast<uint4*>(out + (int64_t)n * d + ch * 8) = *reinterpret_cast<const uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4));
   }
 }
 
