@@ -191,7 +191,11 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
  *   them, not the transposed table),
  *   dp[n][h*64+c] = sum_{b,i} dbd[h][b][i][n] * qv[b*Tq+i][h*64+c]   (fp32 [2Tq-1][H*64], OVERWRITTEN: the gradient w.r.t. the
  *   projected positions, espnet_multihead_attention.py:313-331 backward — what the split-K GEMM over K = B*Tq produced);
- *   dp_part: scratch of B * (2Tq-1) * H*64 bf16 (per-utterance partial sums, summed in fp32 by a second kernel). */
+ *   dp_part: scratch of B * (2Tq-1) * H*64 bf16 (per-utterance partial sums, summed in fp32 by a second kernel).
+ *   dp == NULL: the partial table is left to the caller, who sums the tables of several calls (the layers of one backward
+ *   pass, each with its own dp_part) in ONE launch with s2t_relpos_dp_reduce(dp_parts[n], dps[n] — host arrays of device
+ *   pointers) — same sums, same order. */
+int s2t_relpos_dp_reduce(const void* const* dp_parts, float* const* dps, int n, int B, int H, int Tq, int dk, void* stream);
 int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_sr, const void* qv, void* dq, int64_t dq_sb,
                     int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, void* dp_part, float* dp,
                     int B, int H, int Tq, int dk, void* stream);
@@ -338,7 +342,11 @@ int s2t_dwconv_wgrad_partials(int B, int T); /* rows of C*K floats s2t_dwconv_bw
  *   only), dG = depthwise conv of dD with the flipped kernel, dZ [B*T][2C] = GLU backward of dG on the saved value | gate
  *   Z, dw[c][k] += sum_t dD[t][c] * G[t + k - pad][c] (G = the GLU output the forward convolved).  Replaces the apply pass of
  *   s2t_bn_act_bwd, s2t_dwconv_fwd(flip), s2t_glu_bwd and s2t_dwconv_bwd_weight (convolution.py:92-104 backward) without
- *   passing dD and dG through HBM.  ws: B * ceil(T/32) rows of C*K floats. */
+ *   passing dD and dG through HBM.  ws: B * ceil(T/32) rows of C*K floats.
+ *   dw == NULL: the partial rows stay in ws for the caller to fold, several modules per launch, with
+ *   s2t_rows_fold_add(partials[count], outs[count] — host arrays of device pointers; outs[i][0:n] += the fixed-order sum of the
+ *   `rows` rows of n floats of partials[i]) — the same fold. */
+int s2t_rows_fold_add(const float* const* partials, float* const* outs, int count, int rows, int64_t n, void* stream);
 int s2t_conv_bwd_fused(const void* D, const void* dA, const void* G, const void* Z, const float* w, const float* scale,
                        const float* shift, const float* mean, const float* rstd, const float* sums, float count, int act,
                        const int32_t* lens, void* dZ, float* dw, float* ws, int B, int T, int C, int K, void* stream);

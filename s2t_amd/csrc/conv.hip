@@ -363,9 +363,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(const float* __restri
   }
 }
 
-// out[0:n] += fixed-order sum of the partial rows [rows][n]
-__global__ __launch_bounds__(1024) void rows_fold_add_kernel(const float* __restrict__ partial, int rows, int64_t n,
-                                                             float* __restrict__ out) {
+// out[0:n] += fixed-order sum of the partial rows [rows][n]   (blockIdx.y: the entry of a batch)
+constexpr int ROWS_BATCH = 16;
+struct RowsBatch {
+  const float* partial[ROWS_BATCH];
+  float* out[ROWS_BATCH];
+};
+__global__ __launch_bounds__(1024) void rows_fold_add_kernel(const RowsBatch batch, int rows, int64_t n) {
+  const float* __restrict__ partial = batch.partial[blockIdx.y];
+  float* __restrict__ out = batch.out[blockIdx.y];
   __shared__ float red[16][16];
   const int64_t c = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
   const float t = fold_partial_rows(partial + c, rows, n, c < n, red);
@@ -644,7 +650,10 @@ extern "C" int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, f
     hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)G, (const bf16_t*)dD, ws, replicas, B, T, C, K, tiles_t);
   } else return S2T_ERR_DTYPE;
   const int64_t n = (int64_t)C * K;
-  hipLaunchKernelGGL(rows_fold_add_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, s, ws, nb, n, dw);
+  RowsBatch bt = {};
+  bt.partial[0] = ws;
+  bt.out[0] = dw;
+  hipLaunchKernelGGL(rows_fold_add_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, s, bt, nb, n);
   return S2T_LAUNCH_CHECK();
 }
 
@@ -652,7 +661,7 @@ extern "C" int s2t_conv_bwd_fused(const void* D, const void* dA, const void* G, 
                                   const float* scale, const float* shift, const float* mean, const float* rstd,
                                   const float* sums, float count, int act, const int32_t* lens, void* dZ, float* dw,
                                   float* ws, int B, int T, int C, int K, void* stream) {
-  if (!D || !dA || !G || !Z || !w || !scale || !shift || !mean || !rstd || !sums || !dZ || !dw || !ws) return S2T_ERR_ARG;
+  if (!D || !dA || !G || !Z || !w || !scale || !shift || !mean || !rstd || !sums || !dZ || !ws) return S2T_ERR_ARG;
   if (B <= 0 || T <= 0 || C <= 0 || K <= 0 || !(K & 1) || C % 4 || count <= 0.f) return S2T_ERR_ARG;
   if (K > 31) return S2T_ERR_UNSUPPORTED;
   const void* ptrs[] = {D, dA, G, Z, dZ};
@@ -665,8 +674,28 @@ extern "C" int s2t_conv_bwd_fused(const void* D, const void* dA, const void* G, 
   ensure_lds_optin();
   hipLaunchKernelGGL(conv_bwd_fused_kernel, grid, block, shm, s, (const bf16_t*)D, (const bf16_t*)dA, (const bf16_t*)G,
                      (const bf16_t*)Z, w, scale, shift, mean, rstd, sums, 1.0f / count, act, lens, (bf16_t*)dZ, ws, B, T, C, K);
-  const int64_t n = (int64_t)C * K;
-  hipLaunchKernelGGL(rows_fold_add_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, s, ws, B * tiles_t, n, dw);
+  if (dw) {  // (dw == NULL: the caller folds the partial rows later, several layers per launch: s2t_rows_fold_add)
+    const int64_t n = (int64_t)C * K;
+    RowsBatch bt = {};
+    bt.partial[0] = ws;
+    bt.out[0] = dw;
+    hipLaunchKernelGGL(rows_fold_add_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, s, bt, B * tiles_t, n);
+  }
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_rows_fold_add(const float* const* partials, float* const* outs, int count, int rows, int64_t n, void* stream) {
+  if (!partials || !outs || count <= 0 || rows <= 0 || n <= 0) return S2T_ERR_ARG;
+  for (int i0 = 0; i0 < count; i0 += ROWS_BATCH) {
+    const int cnt = count - i0 < ROWS_BATCH ? count - i0 : ROWS_BATCH;
+    RowsBatch bt = {};
+    for (int i = 0; i < cnt; ++i) {
+      if (!partials[i0 + i] || !outs[i0 + i]) return S2T_ERR_ARG;
+      bt.partial[i] = partials[i0 + i];
+      bt.out[i] = outs[i0 + i];
+    }
+    hipLaunchKernelGGL(rows_fold_add_kernel, dim3((unsigned)((n + 15) / 16), cnt), dim3(1024), 0, (hipStream_t)stream, bt, rows, n);
+  }
   return S2T_LAUNCH_CHECK();
 }
 

@@ -283,8 +283,15 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a) {
 
 // dp[n][col] = sum_b part[b][n][col]  (fp32 out, overwritten): 8 columns per thread, the utterances dealt to the four
 // 64-thread rows of a workgroup (independent 16-byte loads in flight), the four partial sums meet in LDS
-__global__ __launch_bounds__(256) void relpos_dp_reduce_kernel(const bf16_t* __restrict__ part, float* __restrict__ dp, int B,
-                                                               int64_t per_b /* npos * d */) {
+// (blockIdx.y: the entry of a batch — the layers of a backward pass reduced by one launch at its end)
+constexpr int DP_BATCH = 16;
+struct DpBatch {
+  const bf16_t* part[DP_BATCH];
+  float* dp[DP_BATCH];
+};
+__global__ __launch_bounds__(256) void relpos_dp_reduce_kernel(const DpBatch batch, int B, int64_t per_b /* npos * d */) {
+  const bf16_t* __restrict__ part = batch.part[blockIdx.y];
+  float* __restrict__ dp = batch.dp[blockIdx.y];
   __shared__ float red[3][64][8];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t e = ((int64_t)blockIdx.x * 64 + tx) * 8;
@@ -321,12 +328,12 @@ __global__ __launch_bounds__(256) void relpos_dp_reduce_kernel(const bf16_t* __r
 extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_sr, const void* qv, void* dq,
                                int64_t dq_sb, int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride,
                                void* dp_part, float* dp, int B, int H, int Tq, int dk, void* stream) {
-  if (!dbd || !pos_p || !qv || !dq || !dpos_u || !dpos_v || !dp_part || !dp || B <= 0 || H <= 0 || Tq <= 0 || replicas < 1)
+  if (!dbd || !pos_p || !qv || !dq || !dpos_u || !dpos_v || !dp_part || B <= 0 || H <= 0 || Tq <= 0 || replicas < 1)
     return S2T_ERR_ARG;
   if (dk != DK || 2 * Tq - 1 > NP - 1) return S2T_ERR_UNSUPPORTED;
   if (ldb < 2 * Tq - 1 || ldb % 8 || ldb > NP || p_sr % 8 || dq_sr % 4 || dq_sb % 4) return S2T_ERR_ARG;
   if (((uintptr_t)dbd % 16) || ((uintptr_t)pos_p % 16) || ((uintptr_t)qv % 16) || ((uintptr_t)dq % 8) || ((uintptr_t)dp_part % 16) ||
-      ((uintptr_t)dp % 16))
+      (dp && ((uintptr_t)dp % 16)))
     return S2T_ERR_ALIGN;
   GlueArgs a = {};
   a.dbd = (const bf16_t*)dbd; a.ldb = ldb; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.qv = (const bf16_t*)qv;
@@ -334,8 +341,32 @@ extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, 
   a.replica_stride = replica_stride; a.dp_part = (bf16_t*)dp_part; a.B = B; a.H = H; a.Tq = Tq;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(relpos_glue_kernel, dim3(B * H), dim3(512), 0, s, a);
+  if (dp) {  // (dp == NULL: the caller sums the partial tables later, several layers per launch: s2t_relpos_dp_reduce)
+    const int64_t per_b = (int64_t)(2 * Tq - 1) * H * DK;
+    DpBatch bt = {};
+    bt.part[0] = (const bf16_t*)dp_part;
+    bt.dp[0] = dp;
+    hipLaunchKernelGGL(relpos_dp_reduce_kernel, dim3((unsigned)((per_b / 8 + 63) / 64)), dim3(256), 0, s, bt, B, per_b);
+  }
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_relpos_dp_reduce(const void* const* dp_parts, float* const* dps, int n, int B, int H, int Tq, int dk,
+                                    void* stream) {
+  if (!dp_parts || !dps || n <= 0 || B <= 0 || H <= 0 || Tq <= 0) return S2T_ERR_ARG;
+  if (dk != DK) return S2T_ERR_UNSUPPORTED;
   const int64_t per_b = (int64_t)(2 * Tq - 1) * H * DK;
-  hipLaunchKernelGGL(relpos_dp_reduce_kernel, dim3((unsigned)((per_b / 8 + 63) / 64)), dim3(256), 0, s, (const bf16_t*)dp_part, dp, B,
-                     per_b);
+  for (int i0 = 0; i0 < n; i0 += DP_BATCH) {
+    const int cnt = n - i0 < DP_BATCH ? n - i0 : DP_BATCH;
+    DpBatch bt = {};
+    for (int i = 0; i < cnt; ++i) {
+      if (!dp_parts[i0 + i] || !dps[i0 + i]) return S2T_ERR_ARG;
+      if (((uintptr_t)dp_parts[i0 + i] % 16) || ((uintptr_t)dps[i0 + i] % 16)) return S2T_ERR_ALIGN;
+      bt.part[i] = (const bf16_t*)dp_parts[i0 + i];
+      bt.dp[i] = dps[i0 + i];
+    }
+    hipLaunchKernelGGL(relpos_dp_reduce_kernel, dim3((unsigned)((per_b / 8 + 63) / 64), cnt), dim3(256), 0, (hipStream_t)stream, bt, B,
+                       per_b);
+  }
   return S2T_LAUNCH_CHECK();
 }

@@ -293,8 +293,14 @@ def pin_buffers_for_graph():
     GRAPH_PINNED.update(_DBD.keys())
 
 
-_POSQ = {"entries": [], "pool": {}, "next": {}}
+_POSQ = {"entries": [], "pool": {}, "next": {}, "parts": []}
 _POSQ_CAP = 32
+# Deferred folds: the per-utterance partial tables of the position-table gradient and the partial rows of the depthwise weight
+# gradient stay in per-layer scratch and are summed at the end of backward, all layers in ONE launch each (a 5 us launch per
+# layer otherwise).  Slots beyond the cap fall back to the immediate fold.
+_FOLD_DEFER = os.environ.get("S2T_FOLD_DEFER", "1") != "0"
+_FOLD_CAP = 24
+_DWQ = {"entries": []}
 
 
 def _posq_slot(n_pos, d, dev, zero):
@@ -320,6 +326,14 @@ def _flush_posq():
     layer, as ONE batched GEMM per run of layers whose slices and gradients sit at constant strides."""
     entries, _POSQ["entries"] = _POSQ["entries"], []
     _POSQ["next"] = {}
+    parts, _POSQ["parts"] = _POSQ["parts"], []
+    groups = {}
+    for part, dp, dims in parts:  # the layers' partial tables -> their dp slices, one launch per shape
+        groups.setdefault(dims, ([], []))
+        groups[dims][0].append(part)
+        groups[dims][1].append(dp)
+    for (B, H, Tq, dk), (ps, ds) in groups.items():
+        K.relpos_dp_reduce(ps, ds, B, H, Tq, dk)
     if not entries:
         return
     entries.sort(key=lambda e: e[2].data_ptr())
@@ -353,6 +367,14 @@ def _flush_deferred():
     if entries:
         K.layernorm_fold(entries)
     _flush_posq()
+    dwq, _DWQ["entries"] = _DWQ["entries"], []
+    groups = {}
+    for ws, dw, rows, n in dwq:  # depthwise weight-gradient partial rows -> the gradients, one launch per shape
+        groups.setdefault((rows, n), ([], []))
+        groups[(rows, n)][0].append(ws)
+        groups[(rows, n)][1].append(dw)
+    for (rows, n), (wss, dws) in groups.items():
+        K.rows_fold_add(wss, dws, rows, n)
     flush_wgrads()
     ready, _BE["ready"] = _BE["ready"], []
     cb = _HOOKS["grad_ready"]
@@ -1189,8 +1211,11 @@ class AttentionFn(torch.autograd.Function):
             # gradient w.r.t. the projected positions, queued for the batched linear_pos weight gradient
             ws = _ln_workspace(d, dev)
             dp = _posq_slot(n_pos, d, dev, zero=False)
-            K.relpos_glue(dBD, ldB, p, d, qv, dq, Tq * ldq, ldq, ws, ws[d:], dp, B, H, Tq, dk, replicas=K.LN_REPLICAS,
-                          replica_stride=2 * d)
+            slot = len(_POSQ["parts"]) if (_FOLD_DEFER and len(_POSQ["parts"]) < _FOLD_CAP) else None
+            part = K.relpos_glue(dBD, ldB, p, d, qv, dq, Tq * ldq, ldq, ws, ws[d:], dp, B, H, Tq, dk, replicas=K.LN_REPLICAS,
+                                 replica_stride=2 * d, defer_slot=slot)
+            if slot is not None:
+                _POSQ["parts"].append((part, dp, (B, H, Tq, dk)))
             _LNQ["entries"].append((ws, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), d))
             _POSQ["entries"].append((dp, _pos_table_f32(pos_tab), prm["pos_w"].grad, n_pos, d))
             _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
@@ -1661,8 +1686,12 @@ class ConvModuleFn(torch.autograd.Function):
             # depthwise weight-gradient partials (dD and dG never reach HBM)
             K.bn_act_bwd(D, dA, None, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T,
                          dgamma=prm["bn_w"].grad, dbeta=prm["bn_b"].grad)
-            K.conv_bwd_fused(D, dA, g, z, wd, scale, shift, mean, rstd, sums, M, ctx.act, ctx.lens, dZ,
-                             prm["dw_w"].grad.view(d, Kw), B, T, d, Kw)
+            slot = len(_DWQ["entries"]) if (_FOLD_DEFER and len(_DWQ["entries"]) < _FOLD_CAP and _arm_backward_end()) else None
+            dwg = prm["dw_w"].grad.view(d, Kw)
+            ws_dw, rows_dw = K.conv_bwd_fused(D, dA, g, z, wd, scale, shift, mean, rstd, sums, M, ctx.act, ctx.lens, dZ, dwg,
+                                              B, T, d, Kw, defer_slot=slot)
+            if slot is not None:
+                _DWQ["entries"].append((ws_dw, dwg, rows_dw, d * Kw))
         else:
             dD = torch.empty(M, d, dtype=dt, device=dev)
             K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T,

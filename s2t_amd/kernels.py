@@ -488,15 +488,17 @@ def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
           rows, B, T, C, K)
 
 
-def conv_bwd_fused(D, dA, G, Z, w, scale, shift, mean, rstd, sums, count, act, lens, dZ, dw, B, T, C, Kw):
-    """s2t_conv_bwd_fused (include/s2t_hip.h); bf16 only."""
+def conv_bwd_fused(D, dA, G, Z, w, scale, shift, mean, rstd, sums, count, act, lens, dZ, dw, B, T, C, Kw, defer_slot=None):
+    """s2t_conv_bwd_fused (include/s2t_hip.h); bf16 only.  ``defer_slot`` = k: the depthwise weight-gradient partial rows stay in
+    the k-th scratch block, returned with their row count for a later ``rows_fold_add`` over several modules."""
     L.require_cuda(D, dA, G, Z, dZ)
     assert all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in (D, dA, G, Z, dZ))
     rows = B * ((T + 31) // 32)
-    ws = _scratch("dw_fused", rows * C * Kw, D.device)
+    ws = _scratch("dw_fused" if defer_slot is None else "dw_fused%d" % defer_slot, rows * C * Kw, D.device)
     _call("s2t_conv_bwd_fused", D.data_ptr(), dA.data_ptr(), G.data_ptr(), Z.data_ptr(), w.data_ptr(), scale.data_ptr(),
           shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), float(count), L.ACT_IDS[act], _ptr(lens),
-          dZ.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, T, C, Kw)
+          dZ.data_ptr(), dw.data_ptr() if defer_slot is None else None, ws.data_ptr(), B, T, C, Kw)
+    return ws, rows
 
 
 def dwconv_stat_partials(B, T):
@@ -649,15 +651,38 @@ def relpos_dqv(dbd, ldb, pos_pt, pt_ld, dq, dq_sb, dq_sr, dpos_u, dpos_v, B, H, 
           dpos_v.data_ptr(), replicas, replica_stride, B, H, Tq, dk)
 
 
-def relpos_glue(dbd, ldb, pos_p, p_sr, qv, dq, dq_sb, dq_sr, dpos_u, dpos_v, dp, B, H, Tq, dk, replicas=1, replica_stride=0):
+def relpos_glue(dbd, ldb, pos_p, p_sr, qv, dq, dq_sb, dq_sr, dpos_u, dpos_v, dp, B, H, Tq, dk, replicas=1, replica_stride=0,
+                defer_slot=None):
     """s2t_relpos_glue: dq += (Q+v) branch, both bias-gradient column sums, and dp (fp32 [2Tq-1, H*dk], overwritten) in one
-    pass over dbd."""
+    pass over dbd.  ``defer_slot`` = k: the per-utterance partial table goes to the k-th scratch table and is returned for a
+    later ``relpos_dp_reduce`` over several layers (dp is not written by this call)."""
     L.require_cuda(dbd, pos_p, qv, dq, dpos_u, dpos_v, dp)
     assert dbd.dtype == torch.bfloat16 and pos_p.dtype == torch.bfloat16 and qv.dtype == torch.bfloat16 and dq.dtype == torch.bfloat16
     assert dp.dtype == torch.float32 and dp.is_contiguous() and dp.shape == (2 * Tq - 1, H * dk) and qv.is_contiguous()
-    part = _scratch("relpos_dp_part", (B * (2 * Tq - 1) * H * dk + 1) // 2, dbd.device)  # fp32 scratch holding the bf16 partials
+    tag = "relpos_dp_part" if defer_slot is None else "relpos_dp_part%d" % defer_slot
+    part = _scratch(tag, (B * (2 * Tq - 1) * H * dk + 1) // 2, dbd.device)  # fp32 scratch holding the bf16 partials
     _call("s2t_relpos_glue", dbd.data_ptr(), ldb, pos_p.data_ptr(), p_sr, qv.data_ptr(), dq.data_ptr(), dq_sb, dq_sr,
-          dpos_u.data_ptr(), dpos_v.data_ptr(), replicas, replica_stride, part.data_ptr(), dp.data_ptr(), B, H, Tq, dk)
+          dpos_u.data_ptr(), dpos_v.data_ptr(), replicas, replica_stride, part.data_ptr(),
+          dp.data_ptr() if defer_slot is None else None, B, H, Tq, dk)
+    return part
+
+
+def _ptr_array(tensors):
+    import ctypes as C
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def relpos_dp_reduce(parts, dps, B, H, Tq, dk):
+    """s2t_relpos_dp_reduce: dps[i] = fp32 sum over the B per-utterance tables of parts[i], all i in one launch."""
+    L.require_cuda(*parts, *dps)
+    _call("s2t_relpos_dp_reduce", _ptr_array(parts), _ptr_array(dps), len(parts), B, H, Tq, dk)
+
+
+def rows_fold_add(partials, outs, rows, n):
+    """s2t_rows_fold_add: outs[i][0:n] += fixed-order sum of the ``rows`` partial rows of partials[i], all i in one launch."""
+    L.require_cuda(*partials, *outs)
+    assert all(t.dtype == torch.float32 for t in partials) and all(t.dtype == torch.float32 for t in outs)
+    _call("s2t_rows_fold_add", _ptr_array(partials), _ptr_array(outs), len(partials), rows, n)
 
 
 def time_warp(x, y, n_frames, warp, mean_out=None):

@@ -301,3 +301,11 @@ def test_relpos_glue(Tq, B, H):
     dp_ref = torch.einsum("hbin,bihc->nhc", dbd.double()[..., :n_pos], qv.double().view(B, Tq, H, dk)).reshape(n_pos, d)
     err = (dp.cpu().double() - dp_ref).abs().max() / dp_ref.abs().max()
     assert err < 1e-2, float(err)  # bf16 partial per utterance
+    # deferred reduce: two calls leave their partial tables, one s2t_relpos_dp_reduce launch sums both — the same bits
+    dps = [torch.full((n_pos, d), 7.0, device=DEV), torch.full((n_pos, d), -3.0, device=DEV)]
+    parts = [K.relpos_glue(dbd.to(DEV), ldb, p.to(DEV), d, qv.to(DEV), dqkv.to(DEV), Tq * ldq, ldq, ws.view(-1), ws.view(-1)[d:],
+                           dps[k], B, H, Tq, dk, replicas=R, replica_stride=2 * d, defer_slot=k) for k in range(2)]
+    assert float(dps[0].min()) == 7.0  # untouched until the reduce
+    K.relpos_dp_reduce(parts, dps, B, H, Tq, dk)
+    torch.cuda.synchronize()
+    assert torch.equal(dps[0], dp) and torch.equal(dps[1], dp)

@@ -317,6 +317,18 @@ def test_conv_bwd_fused_matches_the_four_kernel_chain(B, T, C, Kw, act):
     assert err < 1.6e-2, float(err)
     assert (dZ.float() - dZ_ref.float()).norm() / dZ_ref.float().norm() < 4e-3
     assert (dw - dw_ref).abs().max() <= 2e-3 * dw_ref.abs().max() + 1e-4
+    # deferred fold: the partial rows of two modules folded by one s2t_rows_fold_add launch give the same bits
+    dws = [torch.full((C, Kw), 0.5, device=DEV), torch.full((C, Kw), -1.25, device=DEV)]
+    parts = []
+    for k in range(2):
+        ws, rows = K.conv_bwd_fused(D.view(n, C), dA.view(n, C), G.view(n, C), Z, w, scale, shift, mean, rstd, sums2, n, act, lens,
+                                    torch.empty_like(Z), dws[k], B, T, C, Kw, defer_slot=k)
+        parts.append(ws)
+    assert torch.equal(dws[0], torch.full((C, Kw), 0.5, device=DEV))  # untouched until the fold
+    K.rows_fold_add(parts, dws, rows, C * Kw)
+    torch.cuda.synchronize()
+    assert torch.equal(dws[0], dw)
+    assert torch.equal(dws[1] + 1.75, dw) or (dws[1] + 1.75 - dw).abs().max() <= 1e-6 * dw.abs().max()
 
 
 @pytest.mark.parametrize("dtype", DT)
