@@ -299,11 +299,17 @@ __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const s2t_wgr
 // Requirements (checked by the host): bf16, lda % 8 == 0, ldb % 8 == 0, 16-byte aligned operands spanning < 2 GiB.
 constexpr int T2 = 256;
 constexpr int BK2 = 32;
-constexpr int NST = 4;
+#ifndef S2T_WG_DBG
+#define S2T_WG_DBG 0
+#endif
+#ifndef S2T_WG_NST
+#define S2T_WG_NST 4
+#endif
+constexpr int NST = S2T_WG_NST;  // LDS stages of 32 KiB (5 = all 160 KiB measured no faster than 4)
 constexpr int PART2 = BK2 * T2 * 2;   // 16 KiB: one operand's 32 k-rows of 512 B
 constexpr int STAGE2 = 2 * PART2;     // 32 KiB
 
-__global__ __launch_bounds__(512, 2) void wgrad256_kernel(const s2t_wgrad_problem* __restrict__ probs,
+__global__ __launch_bounds__(512) void wgrad256_kernel(const s2t_wgrad_problem* __restrict__ probs,
                                                           const Item* __restrict__ items, int n_items,
                                                           float* __restrict__ ws, int nt_mode, int stagger) {
   typedef bf16_t T;
@@ -367,6 +373,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const s2t_wgrad_proble
     const bool ntA = nt_mode == 2 || (nt_mode == 1 && p->tiles_n == 1);
     const bool ntB = nt_mode == 2 || (nt_mode == 1 && p->M <= T2);
     auto issue = [&](int kt, int st) __attribute__((always_inline)) {
+#if S2T_WG_DBG & 1
+      return;  // experiment: no operand traffic (the products run on whatever the stages hold)
+#endif
       const uint32_t la = ldsw + (uint32_t)st * STAGE2;
       const uint32_t sa = (uint32_t)kt * (BK2 * lda2), sb = (uint32_t)kt * (BK2 * ldb2);
       if (ntA) {
@@ -395,45 +404,104 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const s2t_wgrad_proble
     // the tiles of one weight walk their K-range from different starting steps (wrapping around)
     const int rot = nst > 0 ? ((it.tm + it.tn) * stagger) % nst : 0;
     auto kstep = [&](int t) __attribute__((always_inline)) { const int r = t + rot; return kt0 + (r >= nst ? r - nst : r); };
-    for (int u = 0; u < 3; ++u)
-      if (u < nst) issue(kstep(u), (sc + u) & (NST - 1));
-    for (int t = 0; t < nst; ++t) {
-      const int rem = nst - 1 - t;  // steps issued after this one
-      if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-      else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (t + 3 < nst) issue(kstep(t + 3), (sc + t + 3) & (NST - 1));
-      const char* pa = smem + ((sc + t) & (NST - 1)) * STAGE2;
-      const char* pb = pa + PART2;
-      auto tr8 = [&](const char* a) __attribute__((always_inline)) -> Frag {
-        typedef __attribute__((address_space(3))) s16x4* lptr;
-        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a)));
-        const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 2048)));
-        Frag f;
-        f.v = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
-        return f;
-      };
-      Frag fa[8], fb[4];
+    // Pipeline (round 3): the fragments of step t+1 are read from LDS BETWEEN the MFMAs of step t (hipcc would sink every
+    // read to just in front of its first use: 24 transposed reads of exposed latency per step, every wave in the same phase
+    // behind the step's barrier — 3 300 cycles per step against 1 024 of MFMA).  Ring of NST stages: while step t computes
+    // from registers, stage t+1 is being read and stages t+2 .. t+NST are in flight (stage t+NST reuses the slot of stage t,
+    // whose reads were retired before this step's barrier).
+    auto tr8 = [&](const char* a) __attribute__((always_inline)) -> Frag {
+      typedef __attribute__((address_space(3))) s16x4* lptr;
+      const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a)));
+      const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 2048)));
+      Frag f;
+      f.v = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+      return f;
+    };
+    auto colsum = [&](const char* pa) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = tr8(pb + offB[j]);
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const uint4 v = *reinterpret_cast<const uint4*>(pa + offC + h2 * 8192);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = tr8(pa + offA[i]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], fb[j], fa[i]);
-      if (do_cs) {
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const uint4 v = *reinterpret_cast<const uint4*>(pa + offC + h2 * 8192);
-          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            csum[2 * q4] += __uint_as_float(w4[q4] << 16);
-            csum[2 * q4 + 1] += __uint_as_float(w4[q4] & 0xffff0000u);
-          }
+        for (int q4 = 0; q4 < 4; ++q4) {
+          csum[2 * q4] += __uint_as_float(w4[q4] << 16);
+          csum[2 * q4 + 1] += __uint_as_float(w4[q4] & 0xffff0000u);
         }
       }
+    };
+    // registers: B fragments double buffered (all four feed every MFMA group of a step); A fragments ROLL — the pair a group
+    // has just used is refilled with the next step's values behind it — except the last pair, which alternates with a spare
+    // pair so that no read is issued right in front of the step's barrier
+    Frag fA[10], fb[2][4];
+    // wait until at most `stages` DMA groups (4 pieces each) of this wave are still in flight, then the workgroup barrier
+    auto wait_bar = [&](int stages, bool lgkm) __attribute__((always_inline)) {
+      // (the builtin, not inline assembly: hipcc's own wait insertion then knows that no LDS read is pending behind it —
+      // left unaware it puts a full lgkmcnt(0) in front of every MFMA group, i.e. behind the prefetch reads just issued)
+      (void)lgkm;
+      if (stages >= 3) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+      else if (stages == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      else if (stages == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int u = 0; u < NST - 1; ++u)
+      if (u < nst) issue(kstep(u), (sc + u) % NST);
+    if (nst > 0) {
+      wait_bar(min(nst - 1, NST - 2), false);
+      if (NST - 1 < nst) issue(kstep(NST - 1), (sc + NST - 1) % NST);
+      const char* pa = smem + (sc % NST) * STAGE2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[0][j] = tr8(pa + PART2 + offB[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fA[i] = tr8(pa + offA[i]);
+      if (do_cs) colsum(pa);
+    }
+    auto step = [&](int t, auto cur_c) __attribute__((always_inline)) {
+      constexpr int CUR = decltype(cur_c)::value, NXT = CUR ^ 1;
+      const bool has_next = t + 1 < nst;
+      const char* pn = smem + ((sc + t + 1) % NST) * STAGE2;
+      // Every LDS read of the previous step is retired here, on every path (the reads of stage t were issued during it: its slot
+      // is refilled behind the barrier below).  The builtin, not inline assembly: hipcc's own wait insertion then knows that
+      // nothing is pending — left unaware, or with a path that skips this wait, it puts a full lgkmcnt(0) in front of every MFMA
+      // group, i.e. behind the prefetch reads just issued.
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+      if (has_next) {
+        // steps behind t+1 issued so far: at most NST - 2 (lgkmcnt(0): the reads of stage t, issued during the previous
+        // step, are retired before the barrier behind which its slot is refilled)
+        wait_bar(min(nst - 2 - t, NST - 2), true);
+        if (t + NST < nst) issue(kstep(t + NST), (sc + t + NST) % NST);
+      }
+      // A fragment i of the CURRENT step lives in fA[i] for i < 6 and in fA[6 + 2 CUR + (i - 6)] for the last pair
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        // (unconditional: behind the last step these read a stage nobody needs — a branch here costs the precise waits)
+        fb[NXT][gq] = tr8(pn + PART2 + offB[gq]);
+        if (gq > 0) {
+          fA[2 * gq - 2] = tr8(pn + offA[2 * gq - 2]);
+          fA[2 * gq - 1] = tr8(pn + offA[2 * gq - 1]);
+        }
+        if (gq == 3) {
+          fA[6 + 2 * NXT] = tr8(pn + offA[6]);
+          fA[7 + 2 * NXT] = tr8(pn + offA[7]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 2 * gq; i < 2 * gq + 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#if S2T_WG_DBG & 2
+            asm volatile("" ::"v"(fb[CUR][j].v.x), "v"(fb[CUR][j].v.w), "v"(fA[i < 6 ? i : i + 2 * CUR].v.x),
+                         "v"(fA[i < 6 ? i : i + 2 * CUR].v.w));  // experiment: no MFMAs, the reads stay
+#else
+            mma<T>(acc[i][j], fb[CUR][j], fA[i < 6 ? i : i + 2 * CUR]);
+#endif
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (has_next && do_cs) colsum(pn);
+    };
+    for (int t = 0; t < nst; t += 2) {
+      step(t, std::integral_constant<int, 0>{});
+      if (t + 1 < nst) step(t + 1, std::integral_constant<int, 1>{});
     }
     sc += nst;
     // ---- partial tile -> workspace in register-native order; bias-gradient partial -> atomics
