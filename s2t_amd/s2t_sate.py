@@ -45,9 +45,11 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, x, B, T, lens):
         y, x = self.self_attn_layer_norm(x, fork=True)
         x = self.self_attn(y, None, x, B, T, T, lens)
-        y, x = self.final_layer_norm(x, fork=True)
-        return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                      self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
+        # (the LayerNorm, both products, activation, dropouts and the residual in one launch where the row-block kernel
+        # applies: d = 256 bf16, relu / swish, >= S2T_FFN_FUSED_MIN_ROWS rows; the LayerNorm + GEMM composition otherwise)
+        return Fn.ffn_block(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
+                            self.fc2.weight, self.fc2.bias, self.activation_fn, 1.0, self.activation_dropout_p, self.dropout_p,
+                            self.training)
 
 
 class TransformerS2EncoderLayer(TransformerEncoderLayer):
@@ -83,9 +85,11 @@ class TransformerS2EncoderLayer(TransformerEncoderLayer):
         if s2 is not None:
             y, x = self.s2_attn_norm(x, fork=True)
             x = self.s2_attn(y, s2, x, B, T, T, lens)
-        y, x = self.final_layer_norm(x, fork=True)
-        return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                      self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
+        # (the LayerNorm, both products, activation, dropouts and the residual in one launch where the row-block kernel
+        # applies: d = 256 bf16, relu / swish, >= S2T_FFN_FUSED_MIN_ROWS rows; the LayerNorm + GEMM composition otherwise)
+        return Fn.ffn_block(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
+                            self.fc2.weight, self.fc2.bias, self.activation_fn, 1.0, self.activation_dropout_p, self.dropout_p,
+                            self.training)
 
 
 def _layer_list(spec, n_layers):

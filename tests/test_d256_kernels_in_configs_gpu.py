@@ -130,7 +130,8 @@ def test_sate_d256_bf16_kernels_against_oracle_on_rounded_weights():
     worst = max(errs.items(), key=lambda kv: kv[1])
     med = float(np.median(list(errs.values())))
     print("SATE d256 bf16: loss %.5f, worst gradient %s %.4f, median %.4f, kernel calls %s" % (le, worst[0], worst[1], med, calls))
-    assert calls["ffn"] >= 4 and calls["ffn_bwd"] >= 4 and calls["rb"] >= 4, calls  # the fast paths really ran
+    # the fast paths really ran — the fused feed-forward block in the 4 acoustic AND the 2 textual layers
+    assert calls["ffn"] >= 6 and calls["ffn_bwd"] >= 6 and calls["rb"] >= 4, calls
     # measured on MI355X (round 3): loss 0.00008, worst 0.036 (decoder.layers.1.fc1.weight), median 0.0084.  Bounds above the
     # spread of this chaotic figure over equally valid kernel variants (test_configs_fullsize_gpu.py: median x 0.6 ... x 3.5)
     assert le < 4e-4
