@@ -489,8 +489,9 @@ class TransformerDecoderLayer(nn.Module):
                       0.0, 0.0, False)
 
     def forward(self, x, mem, B, U, Tm, self_lens, mem_lens, mem_kv=None):
-        y, x = self.self_attn_layer_norm(x, fork=True)
-        x = self.self_attn(y, None, x, B, U, U, self_lens, causal=True)
+        # (the LayerNorm in front of the self-attention rides in the fused q|k|v projection's prologue where the row-block
+        # kernel applies, its backward in that projection's input-gradient kernel)
+        x = self.self_attn(x, None, None, B, U, U, self_lens, causal=True, norm=self.self_attn_layer_norm)
         y, x = self.encoder_attn_layer_norm(x, fork=True)
         x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens, kv=mem_kv)
         y, x = self.final_layer_norm(x, fork=True)

@@ -43,8 +43,7 @@ class TransformerEncoderLayer(nn.Module):
         self.activation_fn = getattr(args, "activation_fn", "relu")
 
     def forward(self, x, B, T, lens):
-        y, x = self.self_attn_layer_norm(x, fork=True)
-        x = self.self_attn(y, None, x, B, T, T, lens)
+        x = self.self_attn(x, None, None, B, T, T, lens, norm=self.self_attn_layer_norm)
         # (the LayerNorm, both products, activation, dropouts and the residual in one launch where the row-block kernel
         # applies: d = 256 bf16, relu / swish, >= S2T_FFN_FUSED_MIN_ROWS rows; the LayerNorm + GEMM composition otherwise)
         return Fn.ffn_block(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
@@ -80,8 +79,7 @@ class TransformerS2EncoderLayer(TransformerEncoderLayer):
             draw = float(np.random.uniform(0, 1)) < self.league_drop_net_prob  # always drawn, like the reference
             skip = draw if skip_self_attn is None else bool(skip_self_attn)
         if not skip:
-            y, x = self.self_attn_layer_norm(x, fork=True)
-            x = self.self_attn(y, None, x, B, T, T, lens)
+            x = self.self_attn(x, None, None, B, T, T, lens, norm=self.self_attn_layer_norm)
         if s2 is not None:
             y, x = self.s2_attn_norm(x, fork=True)
             x = self.s2_attn(y, s2, x, B, T, T, lens)
