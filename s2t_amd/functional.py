@@ -1068,7 +1068,21 @@ class AttentionFn(torch.autograd.Function):
             ldq = ldk = 3 * d
         else:
             q = torch.empty(Mq, d, dtype=dt, device=dev)
-            K.gemm(xq, cw(prm["q_w"]), q, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["q_b"].data)
+            if ln_g is not None:
+                # encoder-decoder attention behind its LayerNorm (attention() only routes the row-block case here): xq is the
+                # block input, the LayerNorm rides in the query projection's prologue, the residual branch is xq itself
+                x_pre, residual = xq, xq
+                xq = torch.empty_like(x_pre) if train else None
+                ln_mean = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
+                ln_rstd = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
+                K.rowblock_gemm(x_pre, cw(prm["q_w"]), q, N=d, ldc=d, bias=prm["q_b"].data, ln=(ln_g.data, ln_b.data), x_ln=xq,
+                                ln_stats=(ln_mean, ln_rstd) if train else None)
+                ctx.ln = (ln_g, ln_b, getattr(x_pre, "_s2t_drop_o", None))
+                ctx.ln_saved = (x_pre, ln_mean, ln_rstd)
+                if xq is None:
+                    xq = x_pre
+            else:
+                K.gemm(xq, cw(prm["q_w"]), q, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["q_b"].data)
             if kv_all is not None:  # k | v of every decoder layer were projected by one launch (CrossKVFn): columns of layer l
                 l, L, _ = kv_slot
                 assert _use_fused_attention(dt, dk)
@@ -1280,8 +1294,12 @@ class AttentionFn(torch.autograd.Function):
             dxkv = None
         else:
             _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d, 1.0, prm["q_b"].grad)
-            dxq = _dgrad_rowblock(dq, prm["q_w"], d) if d == 256 else None
-            if dxq is None:
+            if ctx.ln is not None:  # query-projection dgrad + the LayerNorm's backward in one row-block launch
+                ln_g, ln_b, up_drop = ctx.ln
+                x_pre, ln_mean, ln_rstd = ctx.ln_saved
+                dx_ln = _dgrad_ln_backward(dq, prm["q_w"], d, x_pre, ln_g, ln_b, ln_mean, ln_rstd, None, 0, dres, up_drop)
+            dxq = _dgrad_rowblock(dq, prm["q_w"], d) if (d == 256 and dx_ln is None) else None
+            if dxq is None and dx_ln is None:
                 dxq = torch.empty(Mq, d, dtype=dt, device=dev)
                 K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
             if ctx.kv_slot is not None:
@@ -1294,6 +1312,12 @@ class AttentionFn(torch.autograd.Function):
                 if share["done"] == L:
                     dkv_all, share["dkv"], share["done"] = share["dkv"], None, 0
                 _ready(prm["q_w"], prm["q_b"])
+                if ctx.ln is not None:
+                    if dx_ln is None:
+                        ln_g, ln_b, up_drop = ctx.ln
+                        x_pre, ln_mean, ln_rstd = ctx.ln_saved
+                        dx_ln = _ln_backward(x_pre, ln_g, ln_b, dxq, ln_mean, ln_rstd, None, 0, dres, up_drop)
+                    return (dx_ln, None, None) + (None,) * 15 + (dkv_all, None)
                 return (dxq, None, (dres if ctx.has_res else None)) + (None,) * 15 + (dkv_all, None)
             gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
             gb = prm["k_b"].grad.as_strided((2 * d,), (1,))
@@ -1508,12 +1532,13 @@ def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False,
     that LayerNorm and doubles as the residual (``residual`` must be None).  Where the row-block projection kernel applies
     the LayerNorm rides in its prologue; otherwise it runs as its own kernel first."""
     if ln is not None:
+        # self-attention, or encoder-decoder attention on keys / values projected for the whole stack (``kv``)
         assert xkv is None and residual is None
         d = xq.shape[1]
         if not (_use_fused_attention(xq.dtype, d // H) and _rb_ok(xq, 3 * d)):
             y, xr = layer_norm(xq, ln[0], ln[1], fork=True)
             return attention(y, None, xr, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, p_attn, p_out, training,
-                             pos_p=pos_p)
+                             pos_p=pos_p, kv=kv)
     drop_a = DROPOUT.next(p_attn if training else 0.0, xq.device)
     drop_o = DROPOUT.next(p_out if training else 0.0, xq.device)
     lg, lb = ln if ln is not None else (None, None)

@@ -492,8 +492,11 @@ class TransformerDecoderLayer(nn.Module):
         # (the LayerNorm in front of the self-attention rides in the fused q|k|v projection's prologue where the row-block
         # kernel applies, its backward in that projection's input-gradient kernel)
         x = self.self_attn(x, None, None, B, U, U, self_lens, causal=True, norm=self.self_attn_layer_norm)
-        y, x = self.encoder_attn_layer_norm(x, fork=True)
-        x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens, kv=mem_kv)
+        if mem_kv is not None:  # (likewise the LayerNorm in front of the encoder-decoder attention, in its query projection)
+            x = self.encoder_attn(x, None, None, B, U, Tm, mem_lens, kv=mem_kv, norm=self.encoder_attn_layer_norm)
+        else:
+            y, x = self.encoder_attn_layer_norm(x, fork=True)
+            x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens)
         y, x = self.final_layer_norm(x, fork=True)
         return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
                       self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
