@@ -302,6 +302,9 @@ constexpr int BK2 = 32;
 #ifndef S2T_WG_DBG
 #define S2T_WG_DBG 0
 #endif
+#ifndef S2T_WG_PRIO
+#define S2T_WG_PRIO 0  // s_setprio 1 around each MFMA group
+#endif
 #ifndef S2T_WG_NST
 #define S2T_WG_NST 4
 #endif
@@ -484,6 +487,9 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const s2t_wgrad_problem* 
           fA[7 + 2 * NXT] = tr8(pn + offA[7]);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if S2T_WG_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 2 * gq; i < 2 * gq + 2; ++i)
 #pragma unroll
@@ -495,6 +501,9 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const s2t_wgrad_problem* 
             mma<T>(acc[i][j], fb[CUR][j], fA[i < 6 ? i : i + 2 * CUR]);
 #endif
           }
+#if S2T_WG_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if (has_next && do_cs) colsum(pn);

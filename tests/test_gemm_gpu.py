@@ -185,14 +185,20 @@ def test_splitk_workspace_matches_atomics_and_reference(dtype):
     np.testing.assert_allclose(dp.cpu().double().numpy(), refp.numpy(), rtol=1e-3, atol=1e-3 * refp.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", ["tiles128", "tiles256_dma"])
+@pytest.mark.parametrize("variant", ["tiles128", "tiles256_dma", "tiles256_dma_plain_loads", "tiles256_dma_all_nt_staggered"])
 def test_grouped_wgrad_matches_reference(variant, monkeypatch):
     """csrc/gemm_grouped.hip through functional.flush_wgrads: several weight gradients of different shapes (ragged tiles,
     K tails, bias gradients, alpha, accumulation into non-zero dW) in one launch vs float64 — the register-staged
     128 x 128 kernel and the LDS-DMA fed 256 x 256 one (s2t_wgrad_grouped256; there also an FFN-sized problem, a K range
     that ends inside a 32-row step and operands that are column slices of a wider buffer)."""
     from s2t_amd import functional as Fn
-    monkeypatch.setattr(Fn, "_WG_256", variant == "tiles256_dma")
+    monkeypatch.setattr(Fn, "_WG_256", variant.startswith("tiles256_dma"))
+    # the cache-policy / K-walk switches of the 256 x 256 kernel (read at every launch): same sums in another order at most
+    if variant == "tiles256_dma_plain_loads":
+        monkeypatch.setenv("S2T_WG_NT", "0")
+    if variant == "tiles256_dma_all_nt_staggered":
+        monkeypatch.setenv("S2T_WG_NT", "2")
+        monkeypatch.setenv("S2T_WG_STAG", "3")
     g = torch.Generator().manual_seed(9)
     dev = "cuda"
     specs = [(300, 200, 2100, 1.0, True), (128, 128, 64, 0.5, False), (40, 520, 4000, 1.0, True), (256, 256, 6464, 2.0, True),
