@@ -96,14 +96,16 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       pair = b;
       half = 0;
     } else {
+      // groups of 8 row blocks x SPLIT parts: the parts of a row block are blocks b, b + 8, b + 16, ...
       const int P = (M + RB - 1) / RB;
-      const int full = (P >> 3) << 4;
+      constexpr int G = 8 * SPLIT;
+      const int full = (P >> 3) * G;
       if (b < full) {
-        pair = ((b >> 4) << 3) + (b & 7);
-        half = (b >> 3) & 1;
+        pair = (b / G) * 8 + (b & 7);
+        half = (b >> 3) % SPLIT;
       } else {
-        pair = ((P >> 3) << 3) + ((b - full) >> 1);
-        half = (b - full) & 1;
+        pair = ((P >> 3) << 3) + (b - full) / SPLIT;
+        half = (b - full) % SPLIT;
       }
     }
   }
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
   const int fbase = half * FH;
   const int nchunks = FH / FC;
   constexpr int KR = RB / SPLIT;           // rows this workgroup finishes
-  const int krow0 = SPLIT == 2 ? 64 * half : 0;
+  const int krow0 = KR * half;             // (`half`: this workgroup's part, 0 .. SPLIT-1)
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 #if S2T_PC_DBG & 16
   unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
           const uint4 yr = *reinterpret_cast<const uint4*>(Yp + (int64_t)mc * D + 8 * cch);
           const float mu = p.pl_mean[mc], rs = p.pl_rstd[mc];
           const bool live = m < M;
-          const bool own = live && (SPLIT == 1 || (rl >> 6) == half);
+          const bool own = live && (SPLIT == 1 || rl / KR == half);
           const bool masked = !live || (p.pl_lens && (m % p.pl_T) >= p.pl_lens[m / p.pl_T]);
           const uint32_t dw4[4] = {raw[ps].x, raw[ps].y, raw[ps].z, raw[ps].w};
           const uint32_t yw4[4] = {yr.x, yr.y, yr.z, yr.w};
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
           ow[q] = pk2((v[2 * q] - mean) * rstd * gm[2 * q] + bt[2 * q], (v[2 * q + 1] - mean) * rstd * gm[2 * q + 1] + bt[2 * q + 1]);
         o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         if constexpr (TRAIN) {
-          if (m < M && (SPLIT == 1 || (rl >> 6) == half)) {
+          if (m < M && (SPLIT == 1 || rl / KR == half)) {
             if (p.x_ln) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.x_ln) + (int64_t)m * D + 8 * cch) = o;
             if (cch == 0) {
               if (p.ln_mean) p.ln_mean[m] = mean;
@@ -756,10 +758,67 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       for (int q = 0; q < 2; ++q) peer[ps][q] = *reinterpret_cast<const f32x4*>(pslab + rr * 256 + 128 * q + 4 * s);
     }
   }
+  // ---- SPLIT > 2 (few rows: the decoder's 3 904 on 8 x 31 workgroups): every workgroup leaves ALL the rows it does not finish
+  // in its own [128][256] fp32 slab, raises one flag per partner, waits for the SPLIT - 1 flags addressed to it (one lane of
+  // wave 0 per partner; each reader clears the flags it read) and sums its KR rows over the partners' slabs.
+  if constexpr (SPLIT > 2) {
+    {
+      float* slab = p.xws + (size_t)(pair * SPLIT + half) * (RB * 256);
+      const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, RB * 256 * 4, 0x00020000);
+      const int cc = tid & 63;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ml = 8 * q + (tid >> 6);
+        if (ml / KR == half) continue;  // (wave-uniform)
+        const u32x4s t = *reinterpret_cast<const u32x4s*>(smem + ml * 1024 + 16 * (cc ^ (ml & 7)));
+        __builtin_amdgcn_raw_buffer_store_b128(t, xs, (uint32_t)(ml * 1024 + 16 * cc), 0, 16 /* sc1 */);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    PSTAMP(5);
+    typedef __attribute__((address_space(1))) uint32_t gu32;
+    gu32* flags = (gu32*)p.xflags;   // [row block][source part][destination part]
+    if (tid < SPLIT && tid != half) __hip_atomic_store(flags + (pair * SPLIT + half) * SPLIT + tid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+      const bool mine = lane < SPLIT && lane != half;
+      gu32* pfl = flags + (pair * SPLIT + (mine ? lane : 0)) * SPLIT + half;
+      bool ok = !mine;
+      uint32_t spins = 0;
+      while (!__all(ok)) {
+        if (!ok) ok = __hip_atomic_load(pfl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > SPIN_LIMIT) {  // never seen on a resident grid: flag the launch instead of hanging the chip
+          if (lane == 0)
+            __hip_atomic_store(flags + ((M + RB - 1) / RB) * SPLIT * SPLIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (mine) __hip_atomic_store(pfl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    PSTAMP(6);
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) peer[ps][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int src = 0; src < SPLIT; ++src) {
+      if (src == half) continue;
+      const float* pslab = p.xws + (size_t)(pair * SPLIT + src) * (RB * 256);
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int ml = krow0 + (KR / 8) * wave + 2 * ps + hi;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) peer[ps][q] += *reinterpret_cast<const f32x4*>(pslab + ml * 256 + 128 * q + 4 * s);
+      }
+    }
+  }
   auto ysum = [&](int ps, int q, int ml) __attribute__((always_inline)) -> f32x4 {
     const int cc = 32 * q + s;
     f32x4 a = *reinterpret_cast<const f32x4*>(smem + ml * 1024 + 16 * (cc ^ (ml & 7)));
-    if constexpr (SPLIT == 2) a += peer[ps][q];
+    if constexpr (SPLIT >= 2) a += peer[ps][q];
     return a;
   };
 
@@ -952,7 +1011,7 @@ int launch_pc(const FfnK& k, int split, bool drop, hipStream_t s) {
   const int P = (k.M + RB - 1) / RB;
   const dim3 grid(P * split), block(512);
 #define GO(A, DR, SP) hipLaunchKernelGGL((ffn_pc_kernel<MODE, A, DR, SP>), grid, block, 0, s, k)
-#define GO_S(A, DR) do { if (split == 2) GO(A, DR, 2); else GO(A, DR, 1); } while (0)
+#define GO_S(A, DR) do { if (split == 8) GO(A, DR, 8); else if (split == 2) GO(A, DR, 2); else GO(A, DR, 1); } while (0)
 #define GO_D(A) do { if (drop) GO_S(A, true); else GO_S(A, false); } while (0)
   if (k.act == S2T_ACT_RELU) GO_D(S2T_ACT_RELU);
   else if (k.act == S2T_ACT_SWISH) GO_D(S2T_ACT_SWISH);
@@ -966,7 +1025,7 @@ int launch_pc(const FfnK& k, int split, bool drop, hipStream_t s) {
 }  // namespace
 
 // Entry points for rowblock.hip's public launchers (the C-ABI stays s2t_ffn_fused_fwd / _bwd).  mode: 0 eval, 1 training
-// forward, 2 backward; split: 1 or 2 workgroups per 128-row block.
+// forward, 2 backward; split: 1, 2 or 8 workgroups per 128-row block.
 int s2t_ffn_pc_launch(const void* kargs, int mode, int split, int drop, void* stream) {
   const FfnK& k = *static_cast<const FfnK*>(kargs);
   hipStream_t s = (hipStream_t)stream;

@@ -1601,22 +1601,39 @@ int pc_num_cus() {
   }();
   return n;
 }
-// two workgroups per 128-row block (each on half of the hidden units) when the whole grid is then resident at once — the
-// partners wait for each other — and the caller gave the exchange workspace
+// workgroups per 128-row block by the row count alone: 8 (each on an eighth of the hidden units) for few rows (the decoder's
+// 3 904: 31 blocks), 2 while the whole grid is then resident at once — the partners wait for each other — else 1
+int pc_split_rows(int M) {
+  const int P = (M + PC_RB - 1) / PC_RB;
+  const int cus = pc_num_cus();
+  return 8 * P <= cus ? 8 : (2 * P <= cus ? 2 : 1);
+}
+// bytes of the fp32 partial-row slabs of the exchange: split 2: the 64 rows the partner finishes; split 8: all 128 rows
+int64_t pc_slab_bytes(int M, int split) {
+  const int64_t P = (M + PC_RB - 1) / PC_RB;
+  return split == 2 ? P * 2 * 64 * 256 * 4 : (split == 8 ? P * 8 * PC_RB * 256 * 4 : 0);
+}
+// ... and what the caller gave: the exchange workspace, hidden units in whole chunks per part
 int pc_split(int M, int F, const void* ws, int64_t ws_bytes) {
-  // S2T_FFN_PC_SPLIT=1 pins one workgroup per block (read at every call: the two forms add the hidden units' products in
-  // different orders, so results that must match bit for bit across DIFFERENT row counts need one of them pinned)
+  // S2T_FFN_PC_SPLIT pins (1) or caps (2) the workgroups per block (read at every call: the forms add the hidden units'
+  // products in different orders, so results that must match bit for bit across DIFFERENT row counts need one of them pinned)
   const char* fe = getenv("S2T_FFN_PC_SPLIT");
   const int force = fe ? atoi(fe) : 0;
-  const int P = (M + PC_RB - 1) / PC_RB;
   if (force == 1 || !ws || ws_bytes < s2t_ffn_pair_ws_bytes(M) || ((uintptr_t)ws % 16) || (F % 128)) return 1;
-  return 2 * P <= pc_num_cus() ? 2 : 1;
+  int split = pc_split_rows(M);
+  if (split == 8 && (force == 2 || F % (8 * 128))) split = 2 * ((M + PC_RB - 1) / PC_RB) <= pc_num_cus() ? 2 : 1;
+  return split;
 }
+// the flags (split x split words per block for split 8, 2 per block for split 2, + one error word) sit behind the slabs
+uint32_t* pc_flags(void* ws, int M, int split) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + pc_slab_bytes(M, split)); }
 }  // namespace
 
 extern "C" int64_t s2t_ffn_pair_ws_bytes(int32_t M) {
   const int64_t P = (M + PC_RB - 1) / PC_RB;
-  return P * 2 * 64 * 256 * 4 + ((P * 2 + 1) * 4 + 15) / 16 * 16;   // fp32 partial rows, then the flags + one error word
+  const int split = pc_split_rows(M);  // (a launch may use fewer parts than this: it then needs less)
+  const int64_t two = pc_slab_bytes(M, 2) + ((P * 2 + 1) * 4 + 15) / 16 * 16;
+  const int64_t eight = pc_slab_bytes(M, 8) + ((P * 64 + 1) * 4 + 15) / 16 * 16;
+  return split == 8 ? (eight > two ? eight : two) : two;
 }
 
 extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
@@ -1645,9 +1662,9 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   if (train ? pc_train(a) : pc_enabled(0)) {
     const int split = pc_split(a->M, a->F, a->pair_ws, a->pair_ws_bytes);
     k.z_tiled = 1;
-    if (split == 2) {
+    if (split >= 2) {
       k.xws = reinterpret_cast<float*>(a->pair_ws);
-      k.xflags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a->pair_ws) + (int64_t)((a->M + PC_RB - 1) / PC_RB) * 2 * 64 * 256 * 4);
+      k.xflags = pc_flags(a->pair_ws, a->M, split);
     }
     return s2t_ffn_pc_launch(&k, train ? 1 : 0, split, drop ? 1 : 0, stream);
   }
@@ -1767,9 +1784,9 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   a.z_tiled = b->z_tiled;
   if (pc_enabled(2) || b->z_tiled) {
     const int split = pc_split(b->M, b->F, b->pair_ws, b->pair_ws_bytes);
-    if (split == 2) {
+    if (split >= 2) {
       a.xws = reinterpret_cast<float*>(b->pair_ws);
-      a.xflags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(b->pair_ws) + (int64_t)((b->M + PC_RB - 1) / PC_RB) * 2 * 64 * 256 * 4);
+      a.xflags = pc_flags(b->pair_ws, b->M, split);
     }
     return s2t_ffn_pc_launch(&a, 2, split, drop ? 1 : 0, stream);
   }

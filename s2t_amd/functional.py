@@ -860,7 +860,7 @@ class FFNFn(torch.autograd.Function):
 _FFN_FUSED = os.environ.get("S2T_FFN_FUSED", "1") != "0"
 _FWD_SPLITK = int(os.environ.get("S2T_FWD_SPLITK", "8"))  # most K splits of the (unfused) FFN's second forward GEMM; 0: one pass
 _FFN_FUSED_BWD = os.environ.get("S2T_FFN_FUSED_BWD", "1") != "0"  # s2t_ffn_fused_bwd for the block's input gradient
-_FFN_FUSED_MIN_ROWS = int(os.environ.get("S2T_FFN_FUSED_MIN_ROWS", "8192"))  # 64-row blocks: fewer rows leave CUs idle
+_FFN_FUSED_MIN_ROWS = int(os.environ.get("S2T_FFN_FUSED_MIN_ROWS", "1024"))  # (8192 before the eight-way split of csrc/ffn_pc.hip)
 
 
 class FFNBlockFn(torch.autograd.Function):

@@ -497,9 +497,11 @@ class TransformerDecoderLayer(nn.Module):
         else:
             y, x = self.encoder_attn_layer_norm(x, fork=True)
             x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens)
-        y, x = self.final_layer_norm(x, fork=True)
-        return Fn.ffn(y, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
-                      self.activation_fn, 1.0, x, self.activation_dropout_p, self.dropout_p, self.training)
+        # (one launch for the whole block where the row-block kernel applies: at the decoder's few thousand rows the hidden units
+        # of a 128-row block are dealt to eight workgroups, csrc/ffn_pc.hip)
+        return Fn.ffn_block(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
+                            self.fc2.weight, self.fc2.bias, self.activation_fn, 1.0, self.activation_dropout_p, self.dropout_p,
+                            self.training)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ import torch
 from s2t_amd import kernels as K
 
 DEV = "cuda"
-M, d, F = int(os.environ.get("PROBE_M", "16000")), 256, 2048
+M, d, F = int(os.environ.get("PROBE_M", "16000")), 256, int(os.environ.get("PROBE_F", "2048"))
 NB = 12 if M <= 16000 else 3
 g = torch.Generator().manual_seed(0)
 xs = [torch.randn(M, d, generator=g).bfloat16().to(DEV) for _ in range(NB)]
@@ -15,7 +15,7 @@ ws2 = [(torch.randn(d, F, generator=g) * F ** -0.5).bfloat16().to(DEV) for _ in 
 b1 = torch.zeros(F, device=DEV); b2 = torch.zeros(d, device=DEV)
 gam = torch.ones(d, device=DEV); bet = torch.zeros(d, device=DEV)
 seed = torch.tensor([1], dtype=torch.int64, device=DEV)
-zs = [torch.empty(M, F, dtype=torch.bfloat16, device=DEV) for _ in range(NB)]
+zs = [torch.empty(K.ffn_z_rows(M), F, dtype=torch.bfloat16, device=DEV) for _ in range(NB)]
 hs = [torch.empty(M, F, dtype=torch.bfloat16, device=DEV) for _ in range(NB)]
 xl = torch.empty_like(xs[0]); mean = torch.empty(M, device=DEV); rstd = torch.empty(M, device=DEV)
 y = torch.empty_like(xs[0])
