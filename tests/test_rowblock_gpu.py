@@ -522,3 +522,44 @@ def test_rowblock_gemm_depthwise_conv_prologue(B, T, mask, res):
     if res:
         yy = yy + resid.float()
     torch.testing.assert_close(y.float(), yy, rtol=2e-2, atol=3e-2)
+
+
+def test_ffn_split_follows_the_row_count(monkeypatch):
+    """Workgroups per 128-row block of the fused feed-forward kernels (csrc/ffn_pc.hip), as the launch itself reports it
+    (s2t_ffn_fused_describe prints the kernel name rocprofv3 shows): eight parts for the decoder's few thousand rows, two for
+    the encoder's 16 000, one when pinned; the result is the same function of its inputs in every form."""
+    import ctypes as C
+    from s2t_amd import _lib as L
+    d, F = 256, 2048
+    g = torch.Generator().manual_seed(11)
+    w1 = (torch.randn(F, d, generator=g) * d ** -0.5).bfloat16().to(DEV)
+    w2 = (torch.randn(d, F, generator=g) * F ** -0.5).bfloat16().to(DEV)
+    b1 = (0.1 * torch.randn(F, generator=g)).to(DEV)
+    b2 = (0.1 * torch.randn(d, generator=g)).to(DEV)
+    gam, bet = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+
+    def run(M):
+        x = torch.randn(M, d, generator=torch.Generator().manual_seed(M)).bfloat16().to(DEV)
+        y = torch.empty_like(x)
+        K.GEMM_PROFILE = []
+        try:
+            K.ffn_fused_fwd(x, w1, b1, w2, b2, y, act="relu", alpha=1.0, residual=x, ln=(gam, bet))
+            torch.cuda.synchronize()
+            name = K.GEMM_PROFILE[0][0]
+        finally:
+            K.GEMM_PROFILE = None
+        return name, y.float()
+
+    n8, y8 = run(3904)
+    assert n8.endswith(", 8>"), n8
+    n2, _ = run(16000)
+    assert n2.endswith(", 2>"), n2
+    monkeypatch.setenv("S2T_FFN_PC_SPLIT", "2")
+    m2, y2 = run(3904)
+    assert m2.endswith(", 2>"), m2
+    monkeypatch.setenv("S2T_FFN_PC_SPLIT", "1")
+    m1, y1 = run(3904)
+    assert m1.endswith(", 1>"), m1
+    # same products, added in a different order: fp32 partial sums, one bf16 rounding at the end
+    assert float((y8 - y1).abs().max()) <= 2e-2 * float(y1.abs().max())
+    assert float((y2 - y1).abs().max()) <= 2e-2 * float(y1.abs().max())
