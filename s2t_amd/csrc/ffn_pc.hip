@@ -1011,7 +1011,7 @@ int launch_pc(const FfnK& k, int split, bool drop, hipStream_t s) {
   const int P = (k.M + RB - 1) / RB;
   const dim3 grid(P * split), block(512);
 #define GO(A, DR, SP) hipLaunchKernelGGL((ffn_pc_kernel<MODE, A, DR, SP>), grid, block, 0, s, k)
-#define GO_S(A, DR) do { if (split == 8) GO(A, DR, 8); else if (split == 2) GO(A, DR, 2); else GO(A, DR, 1); } while (0)
+#define GO_S(A, DR) do { if (split == 8) GO(A, DR, 8); else if (split == 4) GO(A, DR, 4); else if (split == 2) GO(A, DR, 2); else GO(A, DR, 1); } while (0)
 #define GO_D(A) do { if (drop) GO_S(A, true); else GO_S(A, false); } while (0)
   if (k.act == S2T_ACT_RELU) GO_D(S2T_ACT_RELU);
   else if (k.act == S2T_ACT_SWISH) GO_D(S2T_ACT_SWISH);
@@ -1025,7 +1025,7 @@ int launch_pc(const FfnK& k, int split, bool drop, hipStream_t s) {
 }  // namespace
 
 // Entry points for rowblock.hip's public launchers (the C-ABI stays s2t_ffn_fused_fwd / _bwd).  mode: 0 eval, 1 training
-// forward, 2 backward; split: 1, 2 or 8 workgroups per 128-row block.
+// forward, 2 backward; split: 1, 2, 4 or 8 workgroups per 128-row block.
 int s2t_ffn_pc_launch(const void* kargs, int mode, int split, int drop, void* stream) {
   const FfnK& k = *static_cast<const FfnK*>(kargs);
   hipStream_t s = (hipStream_t)stream;

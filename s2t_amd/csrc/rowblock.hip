@@ -1602,16 +1602,16 @@ int pc_num_cus() {
   return n;
 }
 // workgroups per 128-row block by the row count alone: 8 (each on an eighth of the hidden units) for few rows (the decoder's
-// 3 904: 31 blocks), 2 while the whole grid is then resident at once — the partners wait for each other — else 1
+// 3 904: 31 blocks), 4 or 2 while the whole grid is then resident at once — the partners wait for each other — else 1
 int pc_split_rows(int M) {
   const int P = (M + PC_RB - 1) / PC_RB;
   const int cus = pc_num_cus();
-  return 8 * P <= cus ? 8 : (2 * P <= cus ? 2 : 1);
+  return 8 * P <= cus ? 8 : (4 * P <= cus ? 4 : (2 * P <= cus ? 2 : 1));
 }
 // bytes of the fp32 partial-row slabs of the exchange: split 2: the 64 rows the partner finishes; split 8: all 128 rows
 int64_t pc_slab_bytes(int M, int split) {
   const int64_t P = (M + PC_RB - 1) / PC_RB;
-  return split == 2 ? P * 2 * 64 * 256 * 4 : (split == 8 ? P * 8 * PC_RB * 256 * 4 : 0);
+  return split == 2 ? P * 2 * 64 * 256 * 4 : (split > 2 ? P * split * PC_RB * 256 * 4 : 0);
 }
 // ... and what the caller gave: the exchange workspace, hidden units in whole chunks per part
 int pc_split(int M, int F, const void* ws, int64_t ws_bytes) {
@@ -1621,10 +1621,10 @@ int pc_split(int M, int F, const void* ws, int64_t ws_bytes) {
   const int force = fe ? atoi(fe) : 0;
   if (force == 1 || !ws || ws_bytes < s2t_ffn_pair_ws_bytes(M) || ((uintptr_t)ws % 16) || (F % 128)) return 1;
   int split = pc_split_rows(M);
-  if (split == 8 && (force == 2 || F % (8 * 128))) split = 2 * ((M + PC_RB - 1) / PC_RB) <= pc_num_cus() ? 2 : 1;
+  while (split > 2 && (force == 2 || F % (split * 128))) split >>= 1;  // whole pairs of chunks per part
   return split;
 }
-// the flags (split x split words per block for split 8, 2 per block for split 2, + one error word) sit behind the slabs
+// the flags (split x split words per block for 4 or 8 parts, 2 per block for 2, + one error word) sit behind the slabs
 uint32_t* pc_flags(void* ws, int M, int split) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + pc_slab_bytes(M, split)); }
 }  // namespace
 
@@ -1632,8 +1632,8 @@ extern "C" int64_t s2t_ffn_pair_ws_bytes(int32_t M) {
   const int64_t P = (M + PC_RB - 1) / PC_RB;
   const int split = pc_split_rows(M);  // (a launch may use fewer parts than this: it then needs less)
   const int64_t two = pc_slab_bytes(M, 2) + ((P * 2 + 1) * 4 + 15) / 16 * 16;
-  const int64_t eight = pc_slab_bytes(M, 8) + ((P * 64 + 1) * 4 + 15) / 16 * 16;
-  return split == 8 ? (eight > two ? eight : two) : two;
+  const int64_t many = pc_slab_bytes(M, split) + ((P * split * split + 1) * 4 + 15) / 16 * 16;
+  return split > 2 ? (many > two ? many : two) : two;
 }
 
 extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {

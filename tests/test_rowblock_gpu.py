@@ -554,6 +554,12 @@ def test_ffn_split_follows_the_row_count(monkeypatch):
     assert n8.endswith(", 8>"), n8
     n2, _ = run(16000)
     assert n2.endswith(", 2>"), n2
+    n4, y4 = run(8000)
+    assert n4.endswith(", 4>"), n4
+    monkeypatch.setenv("S2T_FFN_PC_SPLIT", "1")
+    _, y4_1 = run(8000)
+    monkeypatch.delenv("S2T_FFN_PC_SPLIT")
+    assert float((y4 - y4_1).abs().max()) <= 2e-2 * float(y4_1.abs().max())
     monkeypatch.setenv("S2T_FFN_PC_SPLIT", "2")
     m2, y2 = run(3904)
     assert m2.endswith(", 2>"), m2
