@@ -480,9 +480,11 @@ typedef struct s2t_ffn_args {
   float drop_h_p; uint32_t drop_h_site;
   float drop_o_p; uint32_t drop_o_site;
   const uint64_t* drop_seed;
-  /* optional exchange workspace of s2t_ffn_pair_ws_bytes(M) bytes, ZERO before its first use and owned by one stream: with
-   * it, row counts that would leave most CUs idle run two workgroups per 128-row block, each on half of the hidden units,
-   * which swap fp32 partial rows through it (csrc/ffn_pc.hip).  The kernels leave its flag words zero again. */
+  /* optional exchange workspace of at least s2t_ffn_pair_ws_bytes(M) bytes, ZERO before its first use and owned by one
+   * stream: with it, row counts that would leave most CUs idle run two, four or eight workgroups per 128-row block, each on
+   * its share of the hidden units, which swap fp32 partial rows through it (csrc/ffn_pc.hip).  The flag words sit in its
+   * first 16 KiB whatever M is and the kernels leave them zero again: one workspace (sized for the largest M) serves every
+   * row count a caller runs. */
   void* pair_ws; int64_t pair_ws_bytes;
   /* z_tiled_ok != 0: the caller accepts z in the TILED layout of the 128-row kernel (s2t_ffn_z_tiled tells whether this call
    * writes it so) and has allocated s2t_ffn_z_elems(M, F) elements for it.  Tiled z: the 16-byte piece of units

@@ -1624,16 +1624,18 @@ int pc_split(int M, int F, const void* ws, int64_t ws_bytes) {
   while (split > 2 && (force == 2 || F % (split * 128))) split >>= 1;  // whole pairs of chunks per part
   return split;
 }
-// the flags (split x split words per block for 4 or 8 parts, 2 per block for 2, + one error word) sit behind the slabs
-uint32_t* pc_flags(void* ws, int M, int split) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + pc_slab_bytes(M, split)); }
+// Layout of the exchange workspace: PC_FLAG_BYTES of flags first (split x split words per block for 4 or 8 parts, 2 per block
+// for 2 — at most 8 x 256 words — and one error word behind them), the slabs behind.  The flags sit at the same place for every
+// row count and are zero between launches (their readers clear them), so ONE workspace serves every shape a caller runs.
+constexpr int64_t PC_FLAG_BYTES = 16384;
+uint32_t* pc_flags(void* ws) { return reinterpret_cast<uint32_t*>(ws); }
+float* pc_slabs(void* ws) { return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + PC_FLAG_BYTES); }
 }  // namespace
 
 extern "C" int64_t s2t_ffn_pair_ws_bytes(int32_t M) {
-  const int64_t P = (M + PC_RB - 1) / PC_RB;
   const int split = pc_split_rows(M);  // (a launch may use fewer parts than this: it then needs less)
-  const int64_t two = pc_slab_bytes(M, 2) + ((P * 2 + 1) * 4 + 15) / 16 * 16;
-  const int64_t many = pc_slab_bytes(M, split) + ((P * split * split + 1) * 4 + 15) / 16 * 16;
-  return split > 2 ? (many > two ? many : two) : two;
+  const int64_t two = pc_slab_bytes(M, 2), many = pc_slab_bytes(M, split);
+  return PC_FLAG_BYTES + (many > two ? many : two);
 }
 
 extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
@@ -1663,8 +1665,8 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
     const int split = pc_split(a->M, a->F, a->pair_ws, a->pair_ws_bytes);
     k.z_tiled = 1;
     if (split >= 2) {
-      k.xws = reinterpret_cast<float*>(a->pair_ws);
-      k.xflags = pc_flags(a->pair_ws, a->M, split);
+      k.xws = pc_slabs(a->pair_ws);
+      k.xflags = pc_flags(a->pair_ws);
     }
     return s2t_ffn_pc_launch(&k, train ? 1 : 0, split, drop ? 1 : 0, stream);
   }
@@ -1785,8 +1787,8 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   if (pc_enabled(2) || b->z_tiled) {
     const int split = pc_split(b->M, b->F, b->pair_ws, b->pair_ws_bytes);
     if (split >= 2) {
-      a.xws = reinterpret_cast<float*>(b->pair_ws);
-      a.xflags = pc_flags(b->pair_ws, b->M, split);
+      a.xws = pc_slabs(b->pair_ws);
+      a.xflags = pc_flags(b->pair_ws);
     }
     return s2t_ffn_pc_launch(&a, 2, split, drop ? 1 : 0, stream);
   }

@@ -97,11 +97,11 @@ def ffn_fused_supported(x, F, M=None):
 def _ffn_pair_ws(a, M, device):
     """Exchange workspace of the several-workgroups-per-block forms (s2t_ffn_pair_ws_bytes): zero at first use, one per stream."""
     need = L.lib().s2t_ffn_pair_ws_bytes(M)
-    # one per layout (the flags sit behind slabs whose size depends on the row count: a shared buffer would put one shape's
-    # partial rows where another shape expects zeroed flags)
-    key = ("ffn_pair", str(device), L.stream_ptr(), need)
+    # one buffer for every row count (the flags sit at its start, the same place for every shape, zero between launches); it
+    # only grows, and a new one starts zeroed
+    key = ("ffn_pair", str(device), L.stream_ptr())
     t = _WS.get(key)
-    if t is None:
+    if t is None or t.numel() * 4 < need:
         t = torch.zeros((need + 3) // 4, dtype=torch.float32, device=device)
         _WS[key] = t
     a.pair_ws, a.pair_ws_bytes = t.data_ptr(), t.numel() * 4
