@@ -14,5 +14,6 @@ def bench(M, N, Kd, rounds=30):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / rounds * 1e3
     print("M%6d N%6d K%6d : %7.1f us  %6.1f TF/s" % (M, N, Kd, us, 2.0 * M * N * Kd / us / 1e6), flush=True)
-for s in [(16000, 2048, 256), (16000, 256, 2048), (16000, 256, 256), (16000, 768, 256), (16000, 10000, 256), (16000, 2048, 1024), (8192, 8192, 8192)]:
+for s in [(16000, 2048, 256), (16000, 256, 2048), (16000, 256, 256), (16000, 768, 256), (16000, 10000, 256), (16000, 3072, 256), (3904, 10000, 256),
+          (16000, 256, 10000), (3904, 256, 10000), (16000, 2048, 1024), (8192, 8192, 8192)]:
     bench(*s)
