@@ -203,7 +203,8 @@ def main():
         try:
             Comm.init(rank, world, dev)
         except Exception as e:  # noqa: BLE001 — e.g. no loadable librccl: fall back to torch.distributed's own RCCL backend
-            # (Comm.init fails on EVERY rank or on none — it agrees on one verdict — so every rank reaches this collective)
+            # (Comm.init agrees on one verdict: it raises on every rank or on none — short of a rank dying inside RCCL's own
+            # rendezvous — so every rank reaches this collective)
             print("[bench] rank %d: library communicator unavailable (%s: %s); using torch.distributed nccl" % (rank, type(e).__name__, e),
                   file=sys.stderr)
             if world > 1:

@@ -496,6 +496,20 @@ typedef struct s2t_ffn_args {
 } s2t_ffn_args;
 int s2t_ffn_fused_fwd(const s2t_ffn_args* args, void* stream);
 int64_t s2t_ffn_pair_ws_bytes(int32_t M);
+/* Exchange health.  A workgroup whose partner's flag does not arrive within the spin limit gives up (it never happens on a
+ * grid that is resident at once; it CAN when another stream's kernels hold CUs) and COUNTS the event in one 32-bit word of
+ * the workspace, s2t_ffn_exchange_error_offset() bytes from its start (inside the first s2t_ffn_exchange_flag_bytes()
+ * bytes, the same place for every row count).  That launch's results are invalid: the caller reads the word (the bundled
+ * Trainer does after every update, kernels.ffn_exchange_poll), raises, and zero-fills the flag area before the next launch
+ * (a late partner's flag would otherwise stay raised). */
+int64_t s2t_ffn_exchange_error_offset(void);
+int64_t s2t_ffn_exchange_flag_bytes(void);
+/* Process-wide switches of the fused feed-forward kernels (first read from the environment: S2T_FFN_PC, S2T_FFN_PC_SPLIT);
+ * a negative argument leaves that switch as it is.  pc_mask: bit 0 eval, 1 training forward, 2 backward on the 128-row
+ * kernel; split_force: 0 automatic, 1 one workgroup per row block, 2 / 4 at most that many; fault (TEST HOOK): part 1 of
+ * every row block never raises its exchange flag and the spin limit is short, so that the time-out path can be exercised.
+ * Returns the settings in force (mask | split_force << 4 | fault << 12). */
+int s2t_ffn_configure(int pc_mask, int split_force, int fault);
 /* the kernel symbol s2t_ffn_fused_fwd launches for these arguments, as a profiler prints it (buf: >= 96 bytes) */
 int s2t_ffn_fused_describe(const s2t_ffn_args* args, char* buf, int32_t buf_bytes);
 int s2t_ffn_z_tiled(const s2t_ffn_args* args);     /* 1: s2t_ffn_fused_fwd(args) writes z tiled */

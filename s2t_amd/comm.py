@@ -33,16 +33,28 @@ def init(rank=None, world=None, device=None):
         rank = dist.get_rank() if dist.is_initialized() else 0
     if device is not None:
         torch.cuda.set_device(device)
-    # Every rank must leave this function the same way: a failure on ONE rank (no loadable librccl on rank 0, a communicator
-    # that does not come up on rank 3) may not leave the others blocked in a collective.  Rank 0 therefore broadcasts
-    # (status, id) — not the bare id — and after s2t_comm_init the ranks agree on a common verdict over the host group.
+    # The ranks should leave this function the same way.  What is exchanged over the host group (object collectives: they
+    # work on any backend, gloo or nccl) BEFORE anyone enters the blocking s2t_comm_init: whether each rank can load the
+    # library at all, and rank 0's (status, id).  What cannot be covered: a rank that dies or hangs INSIDE s2t_comm_init
+    # (ncclCommInitRank) leaves the others blocked there — RCCL's own rendezvous, not ours.  After the call the ranks agree
+    # on one verdict, and a rank whose communicator came up while another's did not destroys its own.
     buf = C.create_string_buffer(128)
-    rc0 = L.lib().s2t_comm_unique_id(buf) if rank == 0 else 0
+    try:
+        lib = L.lib()
+        load_err = None
+    except Exception as e:  # noqa: BLE001 — reported to every rank below
+        lib, load_err = None, "%s: %s" % (type(e).__name__, e)
+    rc0 = lib.s2t_comm_unique_id(buf) if (rank == 0 and lib is not None) else 0
     if world > 1:
-        box = [(int(rc0), bytes(buf.raw)) if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        rc0, raw = box[0]
+        states = [None] * world
+        dist.all_gather_object(states, (load_err, int(rc0), bytes(buf.raw) if rank == 0 else None))
+        bad = [(r, st[0]) for r, st in enumerate(states) if st[0] is not None]
+        if bad:
+            raise RuntimeError("s2t_amd.comm: libs2t_hip is not loadable on rank(s) %s" % bad)
+        rc0, raw = states[0][1], states[0][2]
         buf = C.create_string_buffer(raw, 128)
+    elif load_err is not None:
+        raise RuntimeError(load_err)
     L.check(rc0, "s2t_comm_unique_id (on rank 0)")
     # RCCL prints a version banner to stdout when a communicator is created; stdout belongs to the caller (bench.py
     # prints ONE JSON line there), so fd 1 points at stderr for the duration of the call
@@ -58,9 +70,14 @@ def init(rank=None, world=None, device=None):
         os.dup2(saved, 1)
         os.close(saved)
     if world > 1:  # the worst status of any rank becomes everyone's: all take the library communicator or none does
-        verdict = torch.tensor([abs(int(rc))], dtype=torch.int64)
-        dist.all_reduce(verdict, op=dist.ReduceOp.MAX)
-        if int(verdict) != 0 and rc == 0:
+        try:
+            verdicts = [None] * world
+            dist.all_gather_object(verdicts, int(rc))  # (an object collective: any backend of the default group carries it)
+        except Exception:
+            if rc == 0:
+                L.lib().s2t_comm_destroy()  # the exchange itself failed: do not leak a communicator nobody will use
+            raise
+        if any(v != 0 for v in verdicts) and rc == 0:
             L.lib().s2t_comm_destroy()
             rc = -4  # S2T_ERR_UNSUPPORTED: another rank has no communicator
     L.check(rc, "s2t_comm_init (some rank)")

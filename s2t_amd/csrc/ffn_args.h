@@ -3,6 +3,10 @@
 #pragma once
 #include "common.h"
 
+// Word of the flag area that counts exchange time-outs (the flags of every split / row count stay below word 2 560): a FIXED
+// place for every shape, read by the host (s2t_amd/kernels.py: ffn_exchange_check / ffn_exchange_poll).
+#define S2T_PC_ERR_WORD 4095
+
 namespace {
 
 // kernel arguments: the forward's public struct + what only the backward flavour uses (LayerNorm backward in the epilogue)
@@ -32,7 +36,8 @@ struct FfnK : s2t_ffn_args {
   void* pl_dy;             // [M][256] bf16 out: dropout(dres) under (drop_o_p, drop_o_site); NULL without output dropout
   // ffn_pc.hip with the hidden dimension split over a PAIR of workgroups: fp32 partial rows and one flag per workgroup
   float* xws;              // [pairs][2][64][256] fp32
-  uint32_t* xflags;        // [pairs][2] (+ one error word behind them), zero between launches
+  uint32_t* xflags;        // [pairs][2] (or [blocks][split][split]), zero between launches; word PC_ERR_WORD: exchange time-outs
+  int xfault;              // test hook (s2t_ffn_debug_fault): part 1 of every block never raises its flag, short spin limit
   int z_tiled;             // z (training forward: written, backward: read) is in the tiled layout of include/s2t_hip.h
 };
 

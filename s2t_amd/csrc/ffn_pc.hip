@@ -733,14 +733,18 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
     PSTAMP(5);
     typedef __attribute__((address_space(1))) uint32_t gu32;
     gu32* flags = (gu32*)p.xflags;
-    if (tid == 0) __hip_atomic_store(flags + pair * 2 + half, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && !(p.xfault && half == 1))
+      __hip_atomic_store(flags + pair * 2 + half, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave == 0) {
       gu32* pfl = flags + pair * 2 + (1 - half);
       uint32_t spins = 0;
+      const uint32_t spin_limit = p.xfault ? (1u << 8) : SPIN_LIMIT;
       while (__hip_atomic_load(pfl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > SPIN_LIMIT) {  // never seen on a resident grid: flag the launch instead of hanging the chip
-          if (lane == 0) __hip_atomic_store(flags + 2 * ((M + RB - 1) / RB), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > spin_limit) {
+          // never seen on a resident grid.  The launch is COUNTED in the error word (fixed place, read by the host, which raises
+          // and re-zeroes the flag area: kernels.ffn_exchange_check) instead of hanging the chip; this block's rows are invalid.
+          if (lane == 0) __hip_atomic_fetch_add(flags + S2T_PC_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
@@ -779,18 +783,19 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
     PSTAMP(5);
     typedef __attribute__((address_space(1))) uint32_t gu32;
     gu32* flags = (gu32*)p.xflags;   // [row block][source part][destination part]
-    if (tid < SPLIT && tid != half) __hip_atomic_store(flags + (pair * SPLIT + half) * SPLIT + tid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < SPLIT && tid != half && !(p.xfault && half == 1))
+      __hip_atomic_store(flags + (pair * SPLIT + half) * SPLIT + tid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave == 0) {
       const bool mine = lane < SPLIT && lane != half;
       gu32* pfl = flags + (pair * SPLIT + (mine ? lane : 0)) * SPLIT + half;
       bool ok = !mine;
       uint32_t spins = 0;
+      const uint32_t spin_limit = p.xfault ? (1u << 8) : SPIN_LIMIT;
       while (!__all(ok)) {
         if (!ok) ok = __hip_atomic_load(pfl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > SPIN_LIMIT) {  // never seen on a resident grid: flag the launch instead of hanging the chip
-          if (lane == 0)
-            __hip_atomic_store(flags + ((M + RB - 1) / RB) * SPLIT * SPLIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > spin_limit) {  // never seen on a resident grid: counted in the error word (see the two-part form above)
+          if (lane == 0) __hip_atomic_fetch_add(flags + S2T_PC_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }

@@ -1586,11 +1586,20 @@ namespace {
 constexpr int PC_RB = 128;
 // S2T_FFN_PC = bit mask of the flavours that run the 128-row producer / consumer kernel instead of the 64-row kernels of this
 // file: 1 eval, 2 training forward, 4 backward.  Default: what measured faster on MI355X at the headline shape.
-bool pc_enabled(int mode) {
-  const char* e = getenv("S2T_FFN_PC");  // (read at every call: tests and tools switch it inside one process)
-  const int mask = e ? atoi(e) : S2T_FFN_PC_DEFAULT;
-  return (mask >> mode) & 1;
+// Both switches are read from the environment ONCE (first use) and can be changed afterwards through s2t_ffn_configure
+// (tests and tools switch flavours inside one process; a getenv per launch is host time on the critical path of eager steps).
+struct PcConfig {
+  int mask, split_force, fault;
+};
+PcConfig& pc_config() {
+  static PcConfig c = [] {
+    const char* e = getenv("S2T_FFN_PC");
+    const char* fe = getenv("S2T_FFN_PC_SPLIT");
+    return PcConfig{e ? atoi(e) : S2T_FFN_PC_DEFAULT, fe ? atoi(fe) : 0, 0};
+  }();
+  return c;
 }
+bool pc_enabled(int mode) { return (pc_config().mask >> mode) & 1; }
 // training forward on the 128-row kernel only when the caller takes z tiled (its lanes cannot store row-major z efficiently)
 bool pc_train(const s2t_ffn_args* a) { return pc_enabled(1) && (a->z_tiled_ok || !a->z); }
 int pc_num_cus() {
@@ -1615,22 +1624,33 @@ int64_t pc_slab_bytes(int M, int split) {
 }
 // ... and what the caller gave: the exchange workspace, hidden units in whole chunks per part
 int pc_split(int M, int F, const void* ws, int64_t ws_bytes) {
-  // S2T_FFN_PC_SPLIT pins (1) or caps (2) the workgroups per block (read at every call: the forms add the hidden units'
-  // products in different orders, so results that must match bit for bit across DIFFERENT row counts need one of them pinned)
-  const char* fe = getenv("S2T_FFN_PC_SPLIT");
-  const int force = fe ? atoi(fe) : 0;
+  // S2T_FFN_PC_SPLIT / s2t_ffn_configure pins (1) or caps (2, 4) the workgroups per block: the forms add the hidden units'
+  // products in different orders, so results that must match bit for bit across DIFFERENT row counts need one of them pinned
+  const int force = pc_config().split_force;
   if (force == 1 || !ws || ws_bytes < s2t_ffn_pair_ws_bytes(M) || ((uintptr_t)ws % 16) || (F % 128)) return 1;
   int split = pc_split_rows(M);
-  while (split > 2 && (force == 2 || F % (split * 128))) split >>= 1;  // whole pairs of chunks per part
+  while (split > 2 && ((force >= 2 && split > force) || F % (split * 128))) split >>= 1;  // whole pairs of chunks per part
   return split;
 }
 // Layout of the exchange workspace: PC_FLAG_BYTES of flags first (split x split words per block for 4 or 8 parts, 2 per block
-// for 2 — at most 8 x 256 words — and one error word behind them), the slabs behind.  The flags sit at the same place for every
+// for 2 — at most 8 x 256 words; word S2T_PC_ERR_WORD counts exchange time-outs, the same place for every shape), the slabs behind.  The flags sit at the same place for every
 // row count and are zero between launches (their readers clear them), so ONE workspace serves every shape a caller runs.
 constexpr int64_t PC_FLAG_BYTES = 16384;
 uint32_t* pc_flags(void* ws) { return reinterpret_cast<uint32_t*>(ws); }
 float* pc_slabs(void* ws) { return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + PC_FLAG_BYTES); }
 }  // namespace
+
+static_assert((S2T_PC_ERR_WORD + 1) * 4 <= PC_FLAG_BYTES && S2T_PC_ERR_WORD >= 2560, "error word inside the flag area, above every flag");
+
+extern "C" int s2t_ffn_configure(int pc_mask, int split_force, int fault) {
+  PcConfig& c = pc_config();
+  if (pc_mask >= 0) c.mask = pc_mask;
+  if (split_force >= 0) c.split_force = split_force;
+  if (fault >= 0) c.fault = fault;
+  return (c.mask & 7) | (c.split_force << 4) | (c.fault << 12);
+}
+extern "C" int64_t s2t_ffn_exchange_error_offset(void) { return (int64_t)S2T_PC_ERR_WORD * 4; }
+extern "C" int64_t s2t_ffn_exchange_flag_bytes(void) { return PC_FLAG_BYTES; }
 
 extern "C" int64_t s2t_ffn_pair_ws_bytes(int32_t M) {
   const int split = pc_split_rows(M);  // (a launch may use fewer parts than this: it then needs less)
@@ -1667,6 +1687,7 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
     if (split >= 2) {
       k.xws = pc_slabs(a->pair_ws);
       k.xflags = pc_flags(a->pair_ws);
+      k.xfault = pc_config().fault;
     }
     return s2t_ffn_pc_launch(&k, train ? 1 : 0, split, drop ? 1 : 0, stream);
   }
@@ -1789,6 +1810,7 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
     if (split >= 2) {
       a.xws = pc_slabs(b->pair_ws);
       a.xflags = pc_flags(b->pair_ws);
+      a.xfault = pc_config().fault;
     }
     return s2t_ffn_pc_launch(&a, 2, split, drop ? 1 : 0, stream);
   }

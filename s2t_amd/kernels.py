@@ -108,6 +108,70 @@ def _ffn_pair_ws(a, M, device):
     return t
 
 
+def ffn_configure(pc_mask=None, split=None, fault=None):
+    """s2t_ffn_configure: switch the fused feed-forward flavours inside one process (None leaves a switch as it is); returns
+    the settings in force as (pc_mask, split_force, fault)."""
+    r = L.lib().s2t_ffn_configure(-1 if pc_mask is None else int(pc_mask), -1 if split is None else int(split),
+                                  -1 if fault is None else int(fault))
+    return r & 7, (r >> 4) & 0xFF, (r >> 12) & 1
+
+
+_XCHK = {"pending": []}
+
+
+def _ffn_exchange_words():
+    off = L.lib().s2t_ffn_exchange_error_offset() // 4
+    return [(k, t, off) for k, t in _WS.items() if isinstance(k, tuple) and k and k[0] == "ffn_pair"]
+
+
+def _ffn_exchange_fail(count, ws):
+    nb = L.lib().s2t_ffn_exchange_flag_bytes() // 4
+    for t in ws:
+        t[:nb].zero_()  # a late partner's flag may still be raised: the next launch must start from zero flags
+    raise RuntimeError("s2t_amd: %d fused feed-forward launch(es) timed out waiting for a partner workgroup's partial rows "
+                       "(csrc/ffn_pc.hip exchange): the results of that step are invalid.  The flags were reset; set "
+                       "S2T_FFN_PC_SPLIT=1 to run one workgroup per row block while other kernels share the GPU." % count)
+
+
+def ffn_exchange_check():
+    """Synchronous health check of the fused feed-forward exchange (every workspace of this process): raises RuntimeError
+    when a launch since the last check gave up waiting for its partner (include/s2t_hip.h, s2t_ffn_exchange_error_offset)."""
+    _XCHK["pending"].clear()
+    bad, ws = 0, []
+    for _, t, off in _ffn_exchange_words():
+        n = int(t.view(torch.int32)[off].item())
+        if n:
+            bad += n
+            ws.append(t)
+    if bad:
+        _ffn_exchange_fail(bad, ws)
+
+
+def ffn_exchange_poll():
+    """The same check without stalling the host: queues a copy of the error word(s) into pinned memory on the current stream
+    and examines the copies queued by EARLIER calls that have completed (the bundled Trainer calls this once per update, so
+    a time-out surfaces one update later at the latest; ``ffn_exchange_check`` is the synchronous form)."""
+    bad, ws, still = 0, [], []
+    for host, ev, t in _XCHK["pending"]:
+        if ev.query():
+            if int(host[0]):
+                bad += int(host[0])
+                ws.append(t)
+        else:
+            still.append((host, ev, t))
+    _XCHK["pending"] = still
+    if bad:
+        _XCHK["pending"] = []
+        _ffn_exchange_fail(bad, ws)
+    if len(_XCHK["pending"]) < 8:
+        for _, t, off in _ffn_exchange_words():
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            host.copy_(t.view(torch.int32)[off:off + 1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _XCHK["pending"].append((host, ev, t))
+
+
 def ffn_z_rows(M):
     """Rows to allocate for a z buffer that fits either layout (s2t_ffn_z_elems: row blocks of 128)."""
     return (M + 127) // 128 * 128

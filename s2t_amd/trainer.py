@@ -103,6 +103,7 @@ class Trainer:
         self._push_hyper(sample_size_global)
         loss, log = self._step_body(sample)
         self.num_updates += 1
+        K.ffn_exchange_poll()  # raises when a fused feed-forward launch of an EARLIER update timed out in its exchange
         log["gnorm"] = self.hyper[3]
         log["lr"] = self.lr_at(self.num_updates - 1)  # the rate this update ran with
         return loss, log
@@ -188,4 +189,5 @@ class Trainer:
             self.ddp.all_reduce_grads()
             self._graph2.replay()
         self.num_updates += 1
+        K.ffn_exchange_poll()  # (outside the graph: a 4-byte copy + an event; examined at a later update, never stalls)
         return self._graph_out

@@ -68,23 +68,29 @@ def test_batch_permutation_is_bit_exact(model, sample):
     assert sum(len(x) for x in ids) > 0
 
 
-def test_extra_padding_changes_no_token(model, sample, monkeypatch):
+def test_extra_padding_changes_no_token(model, sample):
     """Holds for utterances that end at least a few frames before the batch's T: like the reference's Conv1dSubsampling
     (no mask between its two convolutions, subsampling.py:145-159), the second convolution of a FULL-length utterance
     sees the zero padding of the buffer edge where a longer buffer holds GLU(bias) of the padded frames.
     The two buffers have different row counts (16 000 and 16 640): the fused feed-forward kernel would run the first with two
     workgroups per row block and the second with one, which sum the hidden units' products in different orders; bit-equal ids
     across row counts are a property of ONE summation order, so it is pinned here (S2T_FFN_PC_SPLIT, csrc/rowblock.hip)."""
-    monkeypatch.setenv("S2T_FFN_PC_SPLIT", "1")
-    model.eval()
-    ni = sample["net_input"]
-    src = ni["src_tokens"].clone()
-    lens = ni["src_lengths"].clamp(max=T - 16)
-    for b in range(B):
-        src[b, int(lens[b]):] = 0
-    padded = torch.zeros(B, T + 40, 80, device=DEV)
-    padded[:, :T] = src
-    assert _greedy(model, src, lens) == _greedy(model, padded, lens)
+    from s2t_amd import kernels as K
+
+    _, old, _ = K.ffn_configure()
+    K.ffn_configure(split=1)
+    try:
+        model.eval()
+        ni = sample["net_input"]
+        src = ni["src_tokens"].clone()
+        lens = ni["src_lengths"].clamp(max=T - 16)
+        for b in range(B):
+            src[b, int(lens[b]):] = 0
+        padded = torch.zeros(B, T + 40, 80, device=DEV)
+        padded[:, :T] = src
+        assert _greedy(model, src, lens) == _greedy(model, padded, lens)
+    finally:
+        K.ffn_configure(split=old)
 
 
 def test_loss_is_additive_over_utterances(model, sample):

@@ -16,6 +16,23 @@ from s2t_amd import kernels as K  # noqa: E402
 DEV = "cuda"
 
 
+@pytest.fixture
+def ffn_split():
+    """Pin / cap the workgroups per 128-row block of the fused feed-forward kernels for one test (s2t_ffn_configure)."""
+    _, old, _ = K.ffn_configure()
+
+    def set_(n):
+        K.ffn_configure(split=n)
+
+    yield set_
+    K.ffn_configure(split=old)
+
+
+def _ffn_name(mode_bwd=False):
+    """Kernel name of the LAST profiled fused feed-forward launch (what rocprofv3 prints)."""
+    return K.GEMM_PROFILE[-1][0]
+
+
 def _mk(M, F, seed, d=256):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(M, d, generator=g).bfloat16()
@@ -96,11 +113,19 @@ def _untile_z(zt, M, F):
     return t.permute(0, 2, 5, 1, 3, 4, 6).reshape(P * 128, F)[:M]        # row = 128 p + 32 wi + m, unit = 64 cg + 16 s + 8 hh + j
 
 
-@pytest.mark.parametrize("M,F,act,tiled", [(200, 256, "swish", False), (4096, 2048, "relu", False), (200, 256, "swish", True),
-                                           (4096, 2048, "swish", True), (1000, 512, "relu", True)])
-def test_ffn_fused_train_saves_and_masks(M, F, act, tiled):
+@pytest.mark.parametrize("M,F,act,tiled,split", [
+    (200, 256, "swish", False, None), (4096, 2048, "relu", False, None), (200, 256, "swish", True, None),
+    (4096, 2048, "swish", True, None), (1000, 512, "relu", True, None),
+    # the instantiations the headline bench runs: ffn_pc_kernel<1, 2, true, 2> (two workgroups per block: 65-128 blocks, or
+    # capped), the four-part form at 8 000 rows, and one workgroup per block
+    (16000, 2048, "swish", True, None), (4096, 2048, "swish", True, 2), (8000, 2048, "swish", True, None),
+    (4096, 2048, "swish", True, 1)])
+def test_ffn_fused_train_saves_and_masks(M, F, act, tiled, split, ffn_split):
     """Training flavour: the saves equal what the unfused kernels produce on the same inputs with the same dropout sites.
-    ``tiled``: the caller accepts z in the 128-row kernel's tiled layout (that kernel then runs the training forward)."""
+    ``tiled``: the caller accepts z in the 128-row kernel's tiled layout (that kernel then runs the training forward).
+    ``split``: workgroups per 128-row block pinned / capped (None: chosen from the row count)."""
+    if split is not None:
+        ffn_split(split)
     x, w1, b1, w2, b2, gam, bet, eg, eb = _mk(M, F, 11)
     d = 256
     alpha = 0.5
@@ -123,10 +148,19 @@ def test_ffn_fused_train_saves_and_masks(M, F, act, tiled):
     h_f = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
     z_f = torch.full((K.ffn_z_rows(M) if tiled else M, F), float("nan"), dtype=torch.bfloat16, device=DEV)
     y_f = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
-    was_tiled = K.ffn_fused_fwd(xd, w1d, b1d, w2d, b2d, y_f, act=act, alpha=alpha, residual=xd, ln=(gd, bd), x_ln=xl_f,
-                                ln_stats=(mean_f, rstd_f), z=z_f, h=h_f, drop_h=drop_h, drop_o=drop_o, z_tiled_ok=tiled)
-    torch.cuda.synchronize()
-    assert was_tiled == (tiled and os.environ.get("S2T_FFN_PC", "7") not in ("0", "4", "5"))
+    K.GEMM_PROFILE = []
+    try:
+        was_tiled = K.ffn_fused_fwd(xd, w1d, b1d, w2d, b2d, y_f, act=act, alpha=alpha, residual=xd, ln=(gd, bd), x_ln=xl_f,
+                                    ln_stats=(mean_f, rstd_f), z=z_f, h=h_f, drop_h=drop_h, drop_o=drop_o, z_tiled_ok=tiled)
+        torch.cuda.synchronize()
+        name = _ffn_name()
+    finally:
+        K.GEMM_PROFILE = None
+    K.ffn_exchange_check()
+    assert was_tiled == (tiled and bool(K.ffn_configure()[0] & 2))
+    if was_tiled and M in (16000, 8000, 4096) and F == 2048:  # the launch really was the form this case is about
+        want = {(16000, None): 2, (8000, None): 4, (4096, 2): 2, (4096, 1): 1, (4096, None): 8}[(M, split)]
+        assert name == "ffn_pc_kernel<1, %d, true, %d>" % (2 if act == "swish" else 1, want), name
     if was_tiled:
         z_f = _untile_z(z_f, M, F)
     assert float((mean_f - mean_u).abs().max()) < 1e-5
@@ -177,13 +211,20 @@ def _tile_z(z, M, F):
 
 @pytest.mark.parametrize("M,F,act,p,tiled", [(64, 64, "relu", 0.0, False), (200, 256, "swish", 0.1, False), (4096, 2048, "swish", 0.1, False),
                                              (1000, 512, "relu", 0.15, False), (130, 128, "none", 0.0, False),
-                                             (200, 256, "swish", 0.1, True), (4096, 2048, "swish", 0.1, True), (1000, 512, "relu", 0.15, True)])
-def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p, tiled):
+                                             (200, 256, "swish", 0.1, True), (4096, 2048, "swish", 0.1, True), (1000, 512, "relu", 0.15, True),
+                                             # ffn_pc_kernel<2, 2, true, 2> (the bench's backward), the four-part form, one workgroup per block
+                                             (16000, 2048, "swish", 0.1, True), (8000, 2048, "swish", 0.1, True),
+                                             (4096, 2048, "swish", 0.1, (True, 2)), (4096, 2048, "swish", 0.1, (True, 1))])
+def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p, tiled, ffn_split):
     """s2t_ffn_fused_bwd against (a) fp32 maths on the same bf16 operands and (b) the unfused s2t_gemm pair it replaces:
     dz = alpha * drop_h((dy W2) * act'(z)), dxn = dz W1 — the autograd backward of the two F.linear, the activation and the
     hidden dropout of modules/s2t_transformer_layer.py:55-66.  (b) shares the dropout mask, so dz agrees to bf16 rounding."""
     from s2t_amd import functional as Fn
 
+    split = None
+    if isinstance(tiled, tuple):
+        tiled, split = tiled
+        ffn_split(split)
     d = 256
     g = torch.Generator().manual_seed(M + F)
     dy = torch.randn(M, d, generator=g).bfloat16().to(DEV)
@@ -197,7 +238,17 @@ def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p, tiled):
     drop = Fn.DROPOUT.next(p, torch.device(DEV))
     dz = torch.full((M, F), 3.0, dtype=torch.bfloat16, device=DEV)
     dxn = torch.full((M, d), 3.0, dtype=torch.bfloat16, device=DEV)
-    K.ffn_fused_bwd(dy, w2t, w1t, _tile_z(z, M, F) if tiled else z, dz, dxn, act=act, alpha=alpha, drop_h=drop, z_tiled=tiled)
+    K.GEMM_PROFILE = []
+    try:
+        K.ffn_fused_bwd(dy, w2t, w1t, _tile_z(z, M, F) if tiled else z, dz, dxn, act=act, alpha=alpha, drop_h=drop, z_tiled=tiled)
+        torch.cuda.synchronize()
+        name = _ffn_name()
+    finally:
+        K.GEMM_PROFILE = None
+    K.ffn_exchange_check()
+    if tiled and F == 2048 and M in (16000, 8000, 4096) and (K.ffn_configure()[0] & 4):
+        want = {(16000, None): 2, (8000, None): 4, (4096, 2): 2, (4096, 1): 1, (4096, None): 8}[(M, split)]
+        assert name == "ffn_pc_kernel<2, 2, true, %d>" % want, name
     # (b) the unfused pair
     dz_u = torch.empty(M, F, dtype=torch.bfloat16, device=DEV)
     dx_u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
@@ -228,12 +279,15 @@ def test_ffn_fused_bwd_matches_the_two_dgrad_gemms(M, F, act, p, tiled):
     assert rel < 1e-2, float(rel)
 
 
-@pytest.mark.parametrize("M,F,up", [(200, 256, False), (4096, 2048, True), (1000, 512, True)])
-def test_ffn_fused_bwd_layernorm_epilogue(M, F, up):
+@pytest.mark.parametrize("M,F,up,split", [(200, 256, False, None), (4096, 2048, True, None), (1000, 512, True, None),
+                                          (16000, 2048, True, None), (8000, 2048, True, None), (4096, 2048, True, 2)])
+def test_ffn_fused_bwd_layernorm_epilogue(M, F, up, split, ffn_split):
     """s2t_ffn_fused_bwd with ln_x: dx, its dropped copy and the dgamma / dbeta partial sums against s2t_layernorm_bwd run on
     the dxn the plain form of the kernel writes (modules/layer_norm.py:30-35 backward + the residual-branch gradient)."""
     from s2t_amd import functional as Fn
 
+    if split is not None:
+        ffn_split(split)
     d = 256
     g = torch.Generator().manual_seed(M)
     dy = torch.randn(M, d, generator=g).bfloat16().to(DEV)
@@ -265,6 +319,7 @@ def test_ffn_fused_bwd_layernorm_epilogue(M, F, up):
     K.ffn_fused_bwd(dy, w2t, w1t, z, dz1, None, act="swish", alpha=0.5, drop_h=drop_h,
                     ln=dict(x=x, gamma=gam, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, dx_drop=dxd, drop=up_drop))
     torch.cuda.synchronize()
+    K.ffn_exchange_check()
     assert torch.equal(dz0, dz1)
     rel = (dx.float() - dx_u.float()).norm() / dx_u.float().norm()
     assert rel < 6e-3, float(rel)  # (the epilogue works on fp32 dxn, the separate kernel on its bf16 rounding)
@@ -524,7 +579,7 @@ def test_rowblock_gemm_depthwise_conv_prologue(B, T, mask, res):
     torch.testing.assert_close(y.float(), yy, rtol=2e-2, atol=3e-2)
 
 
-def test_ffn_split_follows_the_row_count(monkeypatch):
+def test_ffn_split_follows_the_row_count(ffn_split):
     """Workgroups per 128-row block of the fused feed-forward kernels (csrc/ffn_pc.hip), as the launch itself reports it
     (s2t_ffn_fused_describe prints the kernel name rocprofv3 shows): eight parts for the decoder's few thousand rows, two for
     the encoder's 16 000, one when pinned; the result is the same function of its inputs in every form."""
@@ -556,16 +611,51 @@ def test_ffn_split_follows_the_row_count(monkeypatch):
     assert n2.endswith(", 2>"), n2
     n4, y4 = run(8000)
     assert n4.endswith(", 4>"), n4
-    monkeypatch.setenv("S2T_FFN_PC_SPLIT", "1")
+    ffn_split(1)
     _, y4_1 = run(8000)
-    monkeypatch.delenv("S2T_FFN_PC_SPLIT")
+    ffn_split(0)
     assert float((y4 - y4_1).abs().max()) <= 2e-2 * float(y4_1.abs().max())
-    monkeypatch.setenv("S2T_FFN_PC_SPLIT", "2")
+    ffn_split(2)
     m2, y2 = run(3904)
     assert m2.endswith(", 2>"), m2
-    monkeypatch.setenv("S2T_FFN_PC_SPLIT", "1")
+    ffn_split(1)
     m1, y1 = run(3904)
     assert m1.endswith(", 1>"), m1
     # same products, added in a different order: fp32 partial sums, one bf16 rounding at the end
     assert float((y8 - y1).abs().max()) <= 2e-2 * float(y1.abs().max())
     assert float((y2 - y1).abs().max()) <= 2e-2 * float(y1.abs().max())
+
+
+@pytest.mark.parametrize("M", [16000, 3904])
+def test_ffn_exchange_timeout_is_reported(M):
+    """A partner workgroup whose flag never arrives (the s2t_ffn_configure test hook: part 1 of every row block keeps its flag
+    down, short spin limit) must not pass silently: the launch counts the event in the workspace's error word, the host
+    check raises and re-zeroes the flag area, and the next launch — hook off — runs clean and gives the pinned form's result."""
+    d, F = 256, 2048
+    x, w1, b1, w2, b2, gam, bet, eg, eb = _mk(M, F, 5)
+    xd, w1d, b1d, w2d, b2d, gd, bd = (t.to(DEV) for t in (x, w1, b1, w2, b2, gam, bet))
+
+    def run():
+        y = torch.empty_like(xd)
+        K.ffn_fused_fwd(xd, w1d, b1d, w2d, b2d, y, act="swish", alpha=0.5, residual=xd, ln=(gd, bd))
+        torch.cuda.synchronize()
+        return y.float()
+
+    y_ok = run()
+    K.ffn_exchange_check()  # clean
+    K.ffn_configure(fault=1)
+    try:
+        run()
+        with pytest.raises(RuntimeError, match="timed out"):
+            K.ffn_exchange_check()
+        # the non-blocking form the Trainer uses: queue, let the copy land, examine
+        run()
+        K.ffn_exchange_poll()
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="timed out"):
+            K.ffn_exchange_poll()
+    finally:
+        K.ffn_configure(fault=0)
+    y_again = run()
+    K.ffn_exchange_check()
+    assert torch.equal(y_again, y_ok)

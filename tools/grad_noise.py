@@ -3,10 +3,10 @@
 Per seed and variant: median / 90th percentile / worst relative L2 error over the parameter tensors.  Used to set test bounds."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, "/root/repo")
-from s2t_amd import criterions as C, functional as Fn, s2t_transformer as M
+from s2t_amd import criterions as C, functional as Fn, kernels as K, s2t_transformer as M
 DEV="cuda"; V=10000
 def grads(mask, split1, dtype, seed, layers=4):
-    os.environ["S2T_FFN_PC"]=str(mask); os.environ["S2T_FFN_PC_SPLIT"]=split1
+    K.ffn_configure(pc_mask=mask, split=int(split1))
     torch.manual_seed(seed)
     args = M.recipe_args(conformer=True, vocab_size=V, encoder_layers=layers, decoder_layers=2)
     model = M.S2TTransformerModel.build_model(args, M.FakeTask(V))
