@@ -13,6 +13,21 @@
  *   - dtype enum: S2T_F32 (parity mode, exact-f32 MFMA) or S2T_BF16 (bf16 storage, fp32 accumulate,
  *     fp32 softmax / norm statistics / losses — the reference's mixed-precision contract, trainer.py:85-90).
  *   - activations are batch-major row matrices: row m = b * T + t, columns = channels.
+ *
+ * Packed rows (padding-free batches)
+ *   The reference pads every utterance of a batch to the longest one (data/audio/speech_to_text_dataset.py:411-485) and
+ *   computes on the padded frames; here the frames of utterance b may instead sit at rows cu[b] .. cu[b] + lens[b] - 1,
+ *   followed by its HALO rows (at most (k-1)/2 frames behind the utterance's end, never beyond the padded length T: the
+ *   frames of the padded batch whose depthwise-convolution output is not zero and therefore enters the BatchNorm batch
+ *   statistics, modules/convolution.py:94-104) up to cu[b + 1].  Halo rows are treated exactly like padded frames (masked,
+ *   no gradient); the padded frames behind them — all zero in the reference after the masks — are not stored at all.
+ *   Buffers keep their padded size (B * T rows); rows >= cu[B] are never touched.
+ *   - every (row_lens / lens, row_T / T) pair of this header also takes a ROW MAP: T = S2T_ROWS_PACKED, lens[m] >= 0
+ *     ((b << 16) | t) on rows that hold a frame, < 0 on halo rows, lens[-1] = cu[B] (the live row count, read on the
+ *     device so that one captured hipGraph serves batches of any fill).  T = S2T_ROWS_BOUND applies the bound without the
+ *     mask (entry points that have no mask of their own document where they take it).
+ *   - per-utterance entry points take `cu` ([B + 1] int32, NULL = uniform layout b * T) next to lens; T stays the padded
+ *     length (position tables, BatchNorm divisor B * T).
  */
 #ifndef S2T_HIP_H
 #define S2T_HIP_H
@@ -25,6 +40,7 @@ extern "C" {
 enum { S2T_OK = 0, S2T_ERR_ARG = -1, S2T_ERR_DTYPE = -2, S2T_ERR_ALIGN = -3, S2T_ERR_UNSUPPORTED = -4 };
 enum { S2T_F32 = 0, S2T_BF16 = 1 };
 enum { S2T_ACT_NONE = 0, S2T_ACT_RELU = 1, S2T_ACT_SWISH = 2, S2T_ACT_GLU = 3 };
+enum { S2T_ROWS_PACKED = -1, S2T_ROWS_BOUND = -2 }; /* values of a row_T / T argument that make its lens pointer a row map */
 
 int s2t_version(void);
 /* number of compute units of the current device (for host-side grid heuristics) */
@@ -165,7 +181,9 @@ int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        int64_t v_sb, int64_t v_sr, void* o, int64_t o_sb, int64_t o_sr, float* lse, int B, int H, int Tq,
                        int Tk, int dk, const int32_t* key_lens, int causal, float scale, const void* pos_p, int64_t p_sr,
                        const float* pos_u, const float* pos_v, float drop_p, const uint64_t* drop_seed,
-                       uint32_t drop_site, void* stream);
+                       uint32_t drop_site,
+                       const int32_t* cu_q, const int32_t* cu_k /* packed batch: rows of utterance b on the query / key side =
+                       cu[b] .. cu[b+1] (X_sb is then unused on that side), or NULL */, void* stream);
 int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
                        int64_t v_sb, int64_t v_sr, const void* o, const void* dO, int64_t o_sb, int64_t o_sr,
                        const float* lse, float* delta, void* dq, void* dk, void* dv, void* dbd, int64_t ldb, int B, int H,
@@ -173,7 +191,8 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        int64_t p_sr, const float* pos_u, const float* pos_v, float drop_p, const uint64_t* drop_seed,
                        uint32_t drop_site, int dbd_band_only,
                        const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* qv_out,
-                       void* stream);
+                       const int32_t* cu_q, const int32_t* cu_k /* as s2t_attn_fused_fwd; lse / delta / dbd / qv_out keep their
+                       padded strides (row b*Tq + i), of which only the utterance's own rows are touched */, void* stream);
 
 /* Relative-position attention backward, the (Q + pos_bias_v) branch behind s2t_attn_fused_bwd
  * (espnet_multihead_attention.py:331-337 backward; replaces a batched GEMM over the half-empty skewed dbd rows, the
@@ -198,7 +217,9 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
 int s2t_relpos_dp_reduce(const void* const* dp_parts, float* const* dps, int n, int B, int H, int Tq, int dk, void* stream);
 int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_sr, const void* qv, void* dq, int64_t dq_sb,
                     int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, void* dp_part, float* dp,
-                    int B, int H, int Tq, int dk, void* stream);
+                    int B, int H, int Tq, int dk,
+                    const int32_t* cu /* packed batch (dq rows of utterance b from cu[b]; dbd and qv as s2t_attn_fused_bwd left
+                    them), or NULL */, void* stream);
 int s2t_relpos_dqv(const void* dbd, int64_t ldb, const void* pos_pt, int64_t pt_ld, void* dq, int64_t dq_sb, int64_t dq_sr,
                    float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, int B, int H, int Tq, int dk,
                    void* stream);
@@ -222,6 +243,8 @@ typedef struct s2t_wgrad_problem {
   float alpha;
   int32_t next;   /* index of the next problem accumulating into the same C (tied weights; same M, N), or -1:
                      only the first problem of such a chain appears in tiles_dev */
+  const int32_t* k_live; /* optional device scalar (s2t_wgrad_grouped256 only): K = min(K, *k_live), read by the kernel, and the
+                     K-steps are re-cut into nsplit balanced parts — a packed batch's live rows ("Packed rows" above) */
 } s2t_wgrad_problem;
 
 int s2t_wgrad_grouped(const s2t_wgrad_problem* problems_dev, int n_problems, const int32_t* items_dev, int n_items,
@@ -328,12 +351,14 @@ int s2t_sumsq_accum(const float* g, int64_t n, float* out, void* stream);
  *                     added to these parameter-gradient vectors
  * ------------------------------------------------------------------------------------------------ */
 int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, int flip,
-                   const float* scale, const float* shift, int act, const int32_t* lens, float* stats, void* stream);
+                   const float* scale, const float* shift, int act, const int32_t* lens,
+                   const int32_t* cu /* packed batch: rows of utterance b = cu[b] .. cu[b+1] (frames, then halo rows), or NULL */,
+                   float* stats, void* stream);
 /* eval: depthwise conv + BatchNorm (running statistics) + activation + padded-frame mask in one launch — the affine
  * gamma * rsqrt(running_var + eps), beta - running_mean * that is folded inside the kernel (convolution.py:94-104, eval) */
 int s2t_dwconv_bn_eval_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, const float* gamma,
                            const float* beta, const float* running_mean, const float* running_var, float eps, int act,
-                           const int32_t* lens, void* stream);
+                           const int32_t* lens, const int32_t* cu, void* stream);
 int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, float* dw, float* ws /* [replicas][C][K]: zero in, zero out */,
                           int replicas, int B, int T, int C, int K, void* stream);
 int s2t_dwconv_wgrad_partials(int B, int T); /* rows of C*K floats s2t_dwconv_bwd_weight needs in ws (pass as `replicas`) */
@@ -349,7 +374,8 @@ int s2t_dwconv_wgrad_partials(int B, int T); /* rows of C*K floats s2t_dwconv_bw
 int s2t_rows_fold_add(const float* const* partials, float* const* outs, int count, int rows, int64_t n, void* stream);
 int s2t_conv_bwd_fused(const void* D, const void* dA, const void* G, const void* Z, const float* w, const float* scale,
                        const float* shift, const float* mean, const float* rstd, const float* sums, float count, int act,
-                       const int32_t* lens, void* dZ, float* dw, float* ws, int B, int T, int C, int K, void* stream);
+                       const int32_t* lens, const int32_t* cu /* packed batch, as s2t_dwconv_fwd */, void* dZ, float* dw,
+                       float* ws, int B, int T, int C, int K, void* stream);
 int s2t_dwconv_stat_partials(int B, int T);
 int s2t_bn_bwd_partials(int64_t rows);
 int s2t_bn_finalize(const float* stats, int partials, float count, const float* gamma, const float* beta, float* running_mean,
@@ -371,15 +397,17 @@ int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const f
  *                          (torch.nn.CTCLoss(blank, reduction="none", zero_infinity=True)); Lmax = 2*max(S)+1 (odd)
  * ------------------------------------------------------------------------------------------------ */
 int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int V, int32_t* idx, float* top_lp,
-                   float* lse, void* stream);
+                   float* lse, const int32_t* live /* optional device scalar: only rows < *live (a packed batch's live rows) */,
+                   void* stream);
 /* SATE adapter distribution (modules/speech_to_text/adapter.py:214-217): P = softmax(x * inv_tau) per row, and its
  * backward dx = P * (dP - sum P dP) * inv_tau */
 int s2t_row_softmax_fwd(int dtype, const void* x, int64_t ldx, void* p, int64_t ldp, int64_t rows, int V, float inv_tau,
                         void* stream);
 int s2t_row_softmax_bwd(int dtype, const void* p, int64_t ldp, const void* dp, int64_t lddp, void* dx, int64_t lddx,
                         int64_t rows, int V, float inv_tau, void* stream);
-int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens, int B, int T, int blank,
-                     int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
+int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens,
+                     const int32_t* cu /* packed batch: idx / top_lp rows of utterance b from cu[b], or NULL; outputs stay [B][T] */,
+                     int B, int T, int blank, int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
 int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V, const int64_t* target,
                          int64_t pad_idx, float eps, void* dlogits, int64_t ldd, float* sums,
                          float* ws /* rows x 4 floats of scratch: per-row terms, folded into sums in a fixed order */,
@@ -391,12 +419,14 @@ int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows
 int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                      const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens, int blank,
                      float* alpha, float* beta, int Lmax, float* nll, const int64_t* force_emits, int32_t* paths,
-                     void* stream);
+                     const int32_t* cu /* packed batch: logits / lse rows of utterance b from cu[b], or NULL; alpha, beta, paths,
+                     force_emits keep the padded [B][T] strides */, void* stream);
 int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                      const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens, int blank,
                      const float* alpha, const float* beta, int Lmax, const float* nll, float gscale,
                      const float* gscale_dev /* optional device scalar multiplied into gscale (upstream gradient) */,
-                     void* grad, int64_t ldg, int wrt_logprobs, void* stream);
+                     void* grad, int64_t ldg, int wrt_logprobs,
+                     const int32_t* cu /* packed batch: logits / lse / grad rows as in s2t_ctc_loss_fwd, or NULL */, void* stream);
 /* best-alignment backtrace (torch_imputer/imputer.py:245-259,311-323) on the device: states[b][t], -1 beyond the length */
 int s2t_ctc_backtrace(const float* alpha, const int32_t* paths, const int32_t* tgt_lens, const int32_t* in_lens, int B,
                       int T, int Lmax, int32_t* states, void* stream);
@@ -429,6 +459,15 @@ int s2t_ctc_compress_plan(int dtype, const void* logits, int64_t ld, const float
                           int blank, float threshold, int32_t* src, int32_t* new_lens, void* stream);
 int s2t_compress_rows(int dtype, const void* in, void* out, const int32_t* src, const int32_t* new_lens, int B, int T,
                       int Tn, int C, int scatter, void* stream);
+
+/* ---- Packed rows <-> padded rows (see "Packed rows" at the top).  map: the row map of the batch (map[-1] = live rows);
+ * padded: [B*T][C], packed: [rows >= live][C]; rows must be multiples of 16 bytes.
+ *   to_packed = 1: packed[m] = padded[b*T + t] for map[m] = (b << 16 | t) >= 0, halo rows := 0     (m < live)
+ *   to_packed = 0: padded[b*T + t] = packed[m] on the rows that hold a frame; the caller zero-fills `out` first (padded
+ *                  frames are zero after the reference's masks, s2t_transformer.py:1765,1828-1836).
+ * Each direction is the other's backward pass. */
+int s2t_pack_rows(int dtype, const void* in, void* out, const int32_t* map, int64_t rows, int T, int C, int to_packed,
+                  void* stream);
 
 /* ---- PDS multi-scale fusion: depthwise convolution with kernel = stride = r, no padding --------
  * The depthwise stage of DownSampleConvolutionModule (fairseq/modules/downsample_convolution.py:45-54,97-100) as used by

@@ -66,7 +66,12 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(_CriterionBase):
         # before their values are used.  The reference computes them after the decoder
         # (label_smoothed_cross_entropy_with_ctc.py:95-128); the arithmetic is the same.
         ctc = inter_loss = None
-        if self.ctc_weight > 0 and len(enc["ctc_logit"]) > 0:
+        pk = enc.get("packed")
+        if self.ctc_weight > 0 and pk is not None and pk.get("ctc_logit") is not None:
+            # packed rows (s2t_amd/rows.py): the head's logits as the encoder left them, utterance b from row cu[b]
+            tmat, tl, _ = batch_bookkeeping(sample, self.padding_idx, self.eos_idx)
+            ctc = Fn.ctc_loss(pk["ctc_logit"], B, pk["T"], tmat, tl, pk["rows"], self.blank_idx, side=_CTC_SIDE, rows=pk["rows"])
+        elif self.ctc_weight > 0 and len(enc["ctc_logit"]) > 0:
             ctc_tbv = enc["ctc_logit"][0]
             Tn = ctc_tbv.shape[0]
             (in_lens,) = Fn.batch_memo(("ctc_in_lens", id(self)), (enc["encoder_padding_mask"][0],),

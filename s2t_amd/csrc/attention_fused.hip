@@ -61,7 +61,36 @@ struct FusedArgs {
   int64_t pt_ld;         // readable (zeros) for n in [-16, 2Tq-2 + 96]; with it dq receives the (Q+v) branch too and
   float *dpos_u, *dpos_v;  // the column sums of the two branches are added here ([H*DK] fp32 each)
   bf16_t* qv_out;        // (rel, optional) [B*Tq][H*DK]: Q + pos_bias_v as the kernels round it, for the position-table gradient
+  // Packed batch (include/s2t_hip.h): rows of utterance b = cu[b] .. cu[b + 1] of the query / key side.  nq / nk: the rows a
+  // kernel walks and stores (the host sets Tq / Tk; bind_utt() replaces them by the utterance's own row counts).  Tq / Tk
+  // stay the padded lengths: the centre of the position table, the strides of lse / delta / dbd / qv_out and the index space
+  // of the dropout mask do not move with the fill of a batch.
+  const int32_t *cu_q, *cu_k;
+  int nq, nk;
 };
+
+// this workgroup's utterance: row counts and base pointers of a packed batch (pointers are moved so that the uniform-layout
+// expression  base + b * X_sb + row * X_sr  lands on row cu[b] + row)
+__device__ __forceinline__ void bind_utt(FusedArgs& a, int b) {
+  if (a.cu_q) {
+    const int r0 = a.cu_q[b];
+    a.nq = a.cu_q[b + 1] - r0;
+    const int64_t oq = (int64_t)r0 * a.q_sr - (int64_t)b * a.q_sb, oo = (int64_t)r0 * a.o_sr - (int64_t)b * a.o_sb;
+    a.q += oq;
+    if (a.dq) a.dq += oq;
+    a.o += oo;
+    if (a.dO) a.dO += oo;
+  }
+  if (a.cu_k) {
+    const int r0 = a.cu_k[b];
+    a.nk = a.cu_k[b + 1] - r0;
+    const int64_t ok = (int64_t)r0 * a.k_sr - (int64_t)b * a.k_sb, ov = (int64_t)r0 * a.v_sr - (int64_t)b * a.v_sb;
+    a.k += ok;
+    a.v += ov;
+    if (a.dk) a.dk += ok;
+    if (a.dv) a.dv += ov;
+  }
+}
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
@@ -274,7 +303,7 @@ __device__ __forceinline__ void scores_block(const FusedArgs& a, const QFrags& q
 }
 
 __device__ __forceinline__ void load_qfrags(const FusedArgs& a, QFrags& qf, int b, int h, int i, int y, bool rel) {
-  const int ic = i < a.Tq ? i : a.Tq - 1;
+  const int ic = i < a.nq ? i : a.nq - 1;
   const bf16_t* qp = a.q + (int64_t)b * a.q_sb + (int64_t)ic * a.q_sr + h * DK;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -293,7 +322,10 @@ __device__ __forceinline__ void load_qfrags(const FusedArgs& a, QFrags& qf, int 
 // forward
 // =====================================================================================================================
 template <bool REL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a_in) {
+  FusedArgs a = a_in;
+  bind_utt(a, blockIdx.x / a_in.H);
+  if ((int)blockIdx.y * 64 >= a.nq) return;  // packed batch: no row of this utterance in the query block
   __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4 + (REL ? 16384 : 0)];
   char* lk = lds;
   char* lv = lds + 8192;
@@ -306,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
   const int q0 = blockIdx.y * 64;
   const int q0w = q0 + 16 * w;
   const int i = q0w + x;
-  const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
+  const int klen = a.key_lens ? min(a.key_lens[b], a.nk) : a.nk;
 
   QFrags qf;
   load_qfrags(a, qf, b, h, i, y, REL);
@@ -318,26 +350,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
 
   const bf16_t* kb = a.k + (int64_t)b * a.k_sb + h * DK;
   const bf16_t* vb = a.v + (int64_t)b * a.v_sb + h * DK;
-  int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, q0 + 64);  // keys beyond the last query of the workgroup are masked for all its rows
+  // key blocks that hold only masked keys contribute exp(-inf) = 0 to every row: not walked (the same bits)
+  int kend = min(a.nk, (klen + KB - 1) / KB * KB);
+  if (a.causal) kend = min(kend, q0 + 64);  // keys beyond the last query of the workgroup are masked for all its rows
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
 
   TileRegs tk, tv;
-  tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
-  tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
+  tile_load(tk, kb, a.k_sr, 0, a.nk, tid);
+  tile_load(tv, vb, a.v_sr, 0, a.nk, tid);
   PTile tp;  // position rows of the next block (travels like the K / V tiles)
   if constexpr (REL) ptile_load(a, tp, h, q0, 0, tid);
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
-    tile_store(lk, tk, k0, a.Tk, nullptr, tid);
-    tile_store(lv, tv, k0, a.Tk, nullptr, tid);
+    tile_store(lk, tk, k0, a.nk, nullptr, tid);
+    tile_store(lv, tv, k0, a.nk, nullptr, tid);
     if constexpr (REL) ptile_store(lp, tp, tid);
     __syncthreads();
     if (k0 + KB < kend) {  // next block's K/V (and position rows) in flight during this block's MFMAs
-      tile_load(tk, kb, a.k_sr, k0 + KB, a.Tk, tid);
-      tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
+      tile_load(tk, kb, a.k_sr, k0 + KB, a.nk, tid);
+      tile_load(tv, vb, a.v_sr, k0 + KB, a.nk, tid);
       if constexpr (REL) ptile_load(a, tp, h, q0, k0 + KB, tid);
     }
     f32x4 st[4];
@@ -374,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
     if (a.drop_p > 0.f) {
-      const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)(i < a.Tq ? i : 0)) * (uint64_t)a.Tk;
+      const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)(i < a.nq ? i : 0)) * (uint64_t)a.Tk;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         uint32_t r16[4];
@@ -398,7 +431,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a) {
     }
   }
   // ---- epilogue: O = O^T / l ; lane (x = query, y) holds d = 16dt + 4y + r
-  if (i < a.Tq) {
+  if (i < a.nq) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
     bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)i * a.o_sr + h * DK;
 #pragma unroll
@@ -498,7 +531,7 @@ __device__ __forceinline__ void bh_stage_images(const FusedArgs& a, char* lds, i
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int c = tid + 512 * u;
-    const int r = min(c >> 3, a.Tk - 1), ch = c & 7;
+    const int r = min(c >> 3, a.nk - 1), ch = c & 7;
     t[u] = ldg16(kb + (int64_t)r * a.k_sr + ch * 8);
     t[4 + u] = ldg16(vb + (int64_t)r * a.v_sr + ch * 8);
   }
@@ -512,7 +545,7 @@ __device__ __forceinline__ void bh_stage_images(const FusedArgs& a, char* lds, i
   for (int u = 0; u < 4; ++u) {
     const int c = tid + 512 * u;
     const int r = c >> 3, ch = c & 7;
-    const bool ok = r < a.Tk;
+    const bool ok = r < a.nk;
     *reinterpret_cast<uint4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = ok ? t[u] : make_uint4(0, 0, 0, 0);
     *reinterpret_cast<uint4*>(lds + BH_MAXT * 128 + r * 128 + ((ch ^ (r & 7)) << 4)) = ok ? t[4 + u] : make_uint4(0, 0, 0, 0);
   }
@@ -524,7 +557,9 @@ __device__ __forceinline__ void bh_stage_images(const FusedArgs& a, char* lds, i
   }
 }
 
-__global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a_in) {
+  FusedArgs a = a_in;
+  bind_utt(a, blockIdx.x / a_in.H);
   __shared__ __attribute__((aligned(16))) char lds[BH_LDS];
   char* lk = lds;
   char* lv = lds + BH_MAXT * 128;
@@ -534,13 +569,15 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) 
   float* scratch = reinterpret_cast<float*>(lds + BH_IMG) + w * BH_BAND * SC;
   const int z = blockIdx.x;
   const int b = z / a.H, h = z % a.H;
-  const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
+  const int klen = a.key_lens ? min(a.key_lens[b], a.nk) : a.nk;
+  // key blocks that hold only masked keys contribute exp(-inf) = 0 to every row: not walked (the same bits)
+  const int kend = min(a.nk, (klen + KB - 1) / KB * KB);
   bh_stage_images(a, lds, b, h, tid);
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
   __syncthreads();
-  for (int q0w = 16 * w; q0w < a.Tq; q0w += 128) {
+  for (int q0w = 16 * w; q0w < a.nq; q0w += 128) {
     const int i = q0w + x;
     QFrags qf;
     load_qfrags(a, qf, b, h, i, y, true);
@@ -548,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < a.Tk; k0 += KB) {
+    for (int k0 = 0; k0 < kend; k0 += KB) {
       f32x4 st[4];
       scores_block_res(a, qf, lk, lp, scratch, q0w, k0, klen, x, y, st);
       float mx = -INFINITY;
@@ -580,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
       if (a.drop_p > 0.f) {
-        const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)(i < a.Tq ? i : 0)) * (uint64_t)a.Tk;
+        const uint64_t rowbase = ((uint64_t)z * a.Tq + (uint64_t)(i < a.nq ? i : 0)) * (uint64_t)a.Tk;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
           uint32_t r16[4];
@@ -603,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) 
         for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_cols_perm(lvb, dt, s, x, y), pf, o[dt]);
       }
     }
-    if (i < a.Tq) {
+    if (i < a.nq) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
       bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)i * a.o_sr + h * DK;
 #pragma unroll
@@ -622,7 +659,10 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a) 
 // =====================================================================================================================
 // ---- dQ: workgroup = 64 queries of one (b,h), wave = 16 queries; walks the key blocks ------------------------------
 template <bool REL, bool FUSEV = false>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a_in) {
+  FusedArgs a = a_in;
+  bind_utt(a, blockIdx.x / a_in.H);
+  if ((int)blockIdx.y * 64 >= a.nq) return;  // packed batch: no row of this utterance in the query block
   __shared__ __attribute__((aligned(16))) char lds[16384 + 4 * BAND * SC * 4 + (REL ? 16384 : 0)];
   char* lp = lds + 16384 + 4 * BAND * SC * 4;  // (REL) the block's 128 position rows (ptile_*)
   char* lk = lds;
@@ -635,8 +675,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   const int q0 = blockIdx.y * 64;
   const int q0w = q0 + 16 * w;
   const int i = q0w + x;
-  const int ic = i < a.Tq ? i : a.Tq - 1;
-  const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
+  const int ic = i < a.nq ? i : a.nq - 1;
+  const int klen = a.key_lens ? min(a.key_lens[b], a.nk) : a.nk;
 
 #if S2T_ATT_DBG & 64
   unsigned long long stamp[40];
@@ -653,7 +693,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   ASTAMP();
   QFrags qf;
   load_qfrags(a, qf, b, h, i, y, REL);
-  if (REL && a.qv_out && i < a.Tq) {  // this lane's two 16-byte pieces of (q + v) of its query row
+  if (REL && a.qv_out && i < a.nq) {  // this lane's two 16-byte pieces of (q + v) of its query row
     bf16_t* qo = a.qv_out + ((int64_t)b * a.Tq + i) * (a.H * DK) + h * DK;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<uint4*>(qo + (ks * 4 + y) * 8) = __builtin_bit_cast(uint4, qf.qv[ks]);
@@ -684,7 +724,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
     del_i = part;
-    if (y == 0 && i < a.Tq) const_cast<float*>(a.delta)[(int64_t)z * a.Tq + i] = part;
+    if (y == 0 && i < a.nq) const_cast<float*>(a.delta)[(int64_t)z * a.Tq + i] = part;
   }
 
   f32x4 dq[4], dqv[4];
@@ -694,8 +734,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
 
   const bf16_t* kb = a.k + (int64_t)b * a.k_sb + h * DK;
   const bf16_t* vb = a.v + (int64_t)b * a.v_sb + h * DK;
-  int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, q0 + 64);
+  int kend = a.nk;
+  if (a.causal) kend = min(a.nk, q0 + 64);
   const uint64_t dkey = a.drop_p > 0.f ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
@@ -703,17 +743,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     // zero the part of each of this wave's rows that lies outside the band n in [Tq-1-i, Tq-1-i+Tk)
     for (int rr = 0; rr < 16; ++rr) {
       const int ii = q0w + rr;
-      if (ii >= a.Tq) break;
+      if (ii >= a.nq) break;
       bf16_t* row = a.dbd + (((int64_t)h * a.B + b) * a.Tq + ii) * a.ldb;
-      const int lo = a.Tq - 1 - ii, hi = lo + a.Tk;
+      const int lo = a.Tq - 1 - ii, hi = lo + a.nk;
       for (int n = lane; n < a.ldb; n += 64)
         if (n < lo || n >= hi) row[n] = 0;
     }
   }
 
   TileRegs tk, tv;
-  tile_load(tk, kb, a.k_sr, 0, a.Tk, tid);
-  tile_load(tv, vb, a.v_sr, 0, a.Tk, tid);
+  tile_load(tk, kb, a.k_sr, 0, a.nk, tid);
+  tile_load(tv, vb, a.v_sr, 0, a.nk, tid);
   constexpr bool BAND_ON = REL && !(S2T_ATT_DBG & 4);
   PTile tp;  // position rows of the next block (travels like the K / V tiles)
   constexpr bool PRE_ON = BAND_ON && !(S2T_ATT_DBG & 128);
@@ -722,14 +762,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
   for (int k0 = 0; k0 < kend; k0 += KB) {
     __syncthreads();
     ASTAMP();
-    tile_store(lk, tk, k0, a.Tk, nullptr, tid);
-    tile_store(lv, tv, k0, a.Tk, nullptr, tid);
+    tile_store(lk, tk, k0, a.nk, nullptr, tid);
+    tile_store(lv, tv, k0, a.nk, nullptr, tid);
     if constexpr (PRE_ON) ptile_store(lp, tp, tid);
     __syncthreads();
     ASTAMP();
     if (k0 + KB < kend) {  // next block's K/V (and position rows) in flight during this block's MFMAs
-      tile_load(tk, kb, a.k_sr, k0 + KB, a.Tk, tid);
-      tile_load(tv, vb, a.v_sr, k0 + KB, a.Tk, tid);
+      tile_load(tk, kb, a.k_sr, k0 + KB, a.nk, tid);
+      tile_load(tv, vb, a.v_sr, k0 + KB, a.nk, tid);
       if constexpr (PRE_ON) ptile_load(a, tp, h, q0, k0 + KB, tid);
     }
     f32x4 st[4];
@@ -825,11 +865,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
       // drops — no exec-mask branch per row (16 per block and wave before)
       const __amdgpu_buffer_rsrc_t dsrd = __builtin_amdgcn_make_buffer_rsrc(
           a.dbd + ((int64_t)h * a.B + b) * a.Tq * a.ldb, 0, (int)((int64_t)a.Tq * a.ldb * 2), 0x00020000);
-      const bool jok = jj < a.Tk;
+      const bool jok = jj < a.nk;
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
         const int ii = q0w + rr;
-        const uint32_t off = (jok && ii < a.Tq) ? (uint32_t)(((int64_t)ii * a.ldb + (a.Tq - 1 - ii + jj)) * 2) : 0xFFFFFFFFu;
+        const uint32_t off = (jok && ii < a.nq) ? (uint32_t)(((int64_t)ii * a.ldb + (a.Tq - 1 - ii + jj)) * 2) : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(rowv[rr]), dsrd, off, 0, 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -843,7 +883,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     for (int t = 0; t < 40; ++t) dbg[t] = t < nstamp ? stamp[t] : 0ull;
   }
 #endif
-  if (i < a.Tq) {
+  if (i < a.nq) {
     bf16_t* op = a.dq + (int64_t)b * a.q_sb + (int64_t)i * a.q_sr + h * DK;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -856,7 +896,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
     // wave by shuffles, the four waves through LDS), one atomic per column, branch and workgroup
     __syncthreads();  // the K / V tiles are no longer read
     float* red = reinterpret_cast<float*>(lds);  // [4 waves][2][64]
-    const bool live = i < a.Tq;
+    const bool live = i < a.nq;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -885,7 +925,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a) {
 constexpr int SC2 = 36;  // scratch row stride (floats) of the [16 q][32 n] band in the dK/dV kernel
 
 template <bool REL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a_in) {
+  FusedArgs a = a_in;
+  bind_utt(a, blockIdx.x / a_in.H);
+  if ((int)blockIdx.y * 64 >= a.nk) return;  // packed batch: no row of this utterance in the key block
   __shared__ __attribute__((aligned(16))) char lds[3 * 8192 + 4 * 16 * SC2 * 4 + 512 + (REL ? 16384 : 0)];
   char* lp = lds + 3 * 8192 + 4 * 16 * SC2 * 4 + 512;  // (REL) the block's 128 position rows (ptile_*)
   char* lqa = lds;            // q (abs) / q+u (rel)
@@ -901,8 +944,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   const int k0 = blockIdx.y * 64;
   const int k0w = k0 + 16 * w;
   const int j = k0w + x;                       // this lane's key
-  const int jc = j < a.Tk ? j : a.Tk - 1;
-  const int klen = a.key_lens ? min(a.key_lens[b], a.Tk) : a.Tk;
+  const int jc = j < a.nk ? j : a.nk - 1;
+  const int klen = a.key_lens ? min(a.key_lens[b], a.nk) : a.nk;
   const bool key_ok = j < klen;
 
   // K and V fragments of this lane's key (B operands: k = 32ks + 8y + jj)
@@ -933,35 +976,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
   TileRegs tq, tdo;
   float nlse = 0.f, ndel = 0.f;
   auto prefetch = [&](int q0) __attribute__((always_inline)) {
-    tile_load(tq, qb, a.q_sr, q0, a.Tq, tid);
-    tile_load(tdo, dob, a.o_sr, q0, a.Tq, tid);
+    tile_load(tq, qb, a.q_sr, q0, a.nq, tid);
+    tile_load(tdo, dob, a.o_sr, q0, a.nq, tid);
     if (tid < 64) {
-      const int qi = min(q0 + tid, a.Tq - 1);
+      const int qi = min(q0 + tid, a.nq - 1);
       nlse = a.lse[(int64_t)z * a.Tq + qi];
       ndel = a.delta[(int64_t)z * a.Tq + qi];
     }
   };
-  if (qstart < a.Tq) prefetch(qstart);
+  if (qstart < a.nq) prefetch(qstart);
   // Position rows of a whole 64-query block against this wave's 16 keys: n = nb64 + (0..79), nb64 = Tq-1-(q0+63)+k0w —
   // the band of query tile qt, position tile nt is tile 3 - qt + nt of these five.  The four waves' bands (16 rows apart)
   // are one 128-row workgroup tile starting at Tq-1-(q0+63)+k0, staged through LDS like the Q / dO tiles one block ahead
   // (ptile_*): wave w's tile t is image tile w + t.
   PTile tp;
   if constexpr (REL) {
-    if (qstart < a.Tq) ptile_load(a, tp, h, qstart, k0, tid);
+    if (qstart < a.nq) ptile_load(a, tp, h, qstart, k0, tid);
   }
-  for (int q0 = qstart; q0 < a.Tq; q0 += 64) {
+  for (int q0 = qstart; q0 < a.nq; q0 += 64) {
     __syncthreads();
-    tile_store(lqa, tq, q0, a.Tq, REL ? a.pos_u + h * DK : nullptr, tid);
-    tile_store(ldo, tdo, q0, a.Tq, nullptr, tid);
-    if (REL) tile_store(lqv, tq, q0, a.Tq, a.pos_v + h * DK, tid);
+    tile_store(lqa, tq, q0, a.nq, REL ? a.pos_u + h * DK : nullptr, tid);
+    tile_store(ldo, tdo, q0, a.nq, nullptr, tid);
+    if (REL) tile_store(lqv, tq, q0, a.nq, a.pos_v + h * DK, tid);
     if constexpr (REL) ptile_store(lp, tp, tid);
     if (tid < 64) {
       lse_s[tid] = nlse;
       del_s[tid] = ndel;
     }
     __syncthreads();
-    if (q0 + 64 < a.Tq) {  // next query block (and its position rows) in flight during this block's MFMAs
+    if (q0 + 64 < a.nq) {  // next query block (and its position rows) in flight during this block's MFMAs
       prefetch(q0 + 64);
       if constexpr (REL) ptile_load(a, tp, h, q0 + 64, k0, tid);
     }
@@ -1007,7 +1050,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
         if (fast_mask) {
 #pragma unroll
           for (int rb = 0; rb < 4; rb += 2) {
-            const int im = min(q0 + 16 * qt + 4 * y + rb + (x & 1), a.Tq - 1);
+            const int im = min(q0 + 16 * qt + 4 * y + rb + (x & 1), a.nq - 1);
             const uint32_t pair = ((uint32_t)z * (uint32_t)a.Tq + (uint32_t)im) * (uint32_t)(a.Tk >> 1) + (uint32_t)(jc >> 1);
             const uint32_t hm = s2t_mix32(pair ^ (uint32_t)dkey) ^ (uint32_t)(dkey >> 32);
             const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]: lane x ^ 1
@@ -1019,7 +1062,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = q0 + 16 * qt + 4 * y + r;
-            rbits[r] = s2t_rand_u32(dkey, ((uint64_t)z * a.Tq + (uint64_t)min(i, a.Tq - 1)) * (uint64_t)a.Tk + jc);
+            rbits[r] = s2t_rand_u32(dkey, ((uint64_t)z * a.Tq + (uint64_t)min(i, a.nq - 1)) * (uint64_t)a.Tk + jc);
           }
         }
       }
@@ -1027,7 +1070,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int ql = 16 * qt + 4 * y + r;
         const int i = q0 + ql;
-        const bool ok = key_ok & (i < a.Tq) & !((a.causal != 0) & (j > i));
+        const bool ok = key_ok & (i < a.nq) & !((a.causal != 0) & (j > i));
         const float p = __expf(ok ? s4[r] * a.scale - lse4[r] : -INFINITY);  // select on the argument, no branch
         float dp = dp4[r];
         float pdrop = p;
@@ -1059,7 +1102,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a) {
       }
     }
   }
-  if (j < a.Tk) {
+  if (j < a.nk) {
     bf16_t* kp = a.dk + (int64_t)b * a.k_sb + (int64_t)j * a.k_sr + h * DK;
     bf16_t* vp = a.dv + (int64_t)b * a.v_sb + (int64_t)j * a.v_sr + h * DK;
 #pragma unroll
@@ -1215,7 +1258,8 @@ extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, con
                                   const void* v, int64_t v_sb, int64_t v_sr, void* o, int64_t o_sb, int64_t o_sr,
                                   float* lse, int B, int H, int Tq, int Tk, int dk, const int32_t* key_lens, int causal,
                                   float scale, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
-                                  float drop_p, const uint64_t* drop_seed, uint32_t drop_site, void* stream) {
+                                  float drop_p, const uint64_t* drop_seed, uint32_t drop_site, const int32_t* cu_q,
+                                  const int32_t* cu_k, void* stream) {
   if (!q || !k || !v || !o || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
   if (dk != DK) return S2T_ERR_UNSUPPORTED;
   if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
@@ -1229,6 +1273,7 @@ extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, con
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.key_lens = key_lens; a.causal = causal; a.scale = scale;
   a.rel = pos_p != nullptr; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.pos_u = pos_u; a.pos_v = pos_v;
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site;
+  a.cu_q = cu_q; a.cu_k = cu_k; a.nq = Tq; a.nk = Tk;
   dim3 grid(B * H, (Tq + 63) / 64), block(256);
   // S2T_ATTN_BH=0 keeps the block-per-64-queries kernels for the short relative-position case too (A/B switch)
   static const bool bh_on = [] { const char* e = getenv("S2T_ATTN_BH"); return !(e && e[0] == '0'); }();
@@ -1258,7 +1303,7 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
                                   float scale, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
                                   float drop_p, const uint64_t* drop_seed, uint32_t drop_site, int dbd_band_only,
                                   const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* qv_out,
-                                  void* stream) {
+                                  const int32_t* cu_q, const int32_t* cu_k, void* stream) {
   if (!q || !k || !v || !o || !dO || !lse || !delta || !dq || !dk_ || !dv || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0)
     return S2T_ERR_ARG;
   if (dk != DK) return S2T_ERR_UNSUPPORTED;
@@ -1277,6 +1322,7 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
   a.dbd = (bf16_t*)dbd; a.ldb = ldb; a.dbd_band_only = dbd_band_only;
   a.pos_pt = (const bf16_t*)pos_pt; a.pt_ld = pt_ld; a.dpos_u = dpos_u; a.dpos_v = dpos_v;
   a.qv_out = (bf16_t*)qv_out;
+  a.cu_q = cu_q; a.cu_k = cu_k; a.nq = Tq; a.nk = Tk;
   if (qv_out && (!pos_p || ((uintptr_t)qv_out % 16))) return S2T_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   // (delta = rowsum(dO * O) is produced by the dQ kernel, which runs first, and read by the dK / dV kernel)

@@ -167,5 +167,39 @@ __device__ __forceinline__ uint64_t s2t_drop_key(const uint64_t* seed_ptr, uint3
 __device__ __forceinline__ uint32_t s2t_drop_thresh(float p) { return (uint32_t)fminf(p * 65536.0f + 0.5f, 65535.0f); }
 __device__ __forceinline__ float s2t_drop_scale(float p) { return 65536.0f / (65536.0f - (float)s2t_drop_thresh(p)); }
 
+// ---- row geometry of an activation matrix (include/s2t_hip.h, "Packed rows") ------------------------------------------
+// (lens, T) with T > 0: uniform layout, row m = b * T + t, frame valid iff t < lens[b].
+// T == S2T_ROWS_PACKED / S2T_ROWS_BOUND: `lens` is a ROW MAP of a packed batch — lens[m] >= 0 on rows that hold a frame
+// ((utterance << 16) | frame), < 0 on rows that hold none (the halo rows behind an utterance: masked like padded frames);
+// lens[-1] = live rows: rows at and beyond it are neither computed nor stored.  S2T_ROWS_BOUND applies the bound only.
+__device__ __forceinline__ bool s2t_row_masked(const int32_t* __restrict__ lens, int T, int64_t row) {
+  if (T > 0) return (int)(row % T) >= lens[row / T];
+  return T == S2T_ROWS_PACKED && lens[row] < 0;
+}
+// 32-bit form for epilogues (row < 2^31): the 64-bit division is a long software sequence
+__device__ __forceinline__ bool s2t_row_masked32(const int32_t* __restrict__ lens, int T, uint32_t row) {
+  if (T > 0) {
+    const uint32_t b = row / (uint32_t)T;
+    return (int)(row - b * (uint32_t)T) >= lens[b];
+  }
+  return T == S2T_ROWS_PACKED && lens[row] < 0;
+}
+// rows of a launch: the host's bound, or the live row count of a packed batch when that is smaller
+__device__ __forceinline__ int64_t s2t_live_rows(const int32_t* __restrict__ lens, int T, int64_t rows) {
+  if (lens && T < 0) {
+    const int64_t n = lens[-1];
+    return n < rows ? n : rows;
+  }
+  return rows;
+}
+// first row and row capacity of utterance b: cu[b] .. cu[b + 1] of a packed batch, b * T .. + T otherwise
+__device__ __forceinline__ int s2t_utt_row0(const int32_t* __restrict__ cu, int b, int T) { return cu ? cu[b] : b * T; }
+__device__ __forceinline__ int s2t_utt_rows(const int32_t* __restrict__ cu, int b, int T) { return cu ? cu[b + 1] - cu[b] : T; }
+
+// host-side check of a (lens, T) argument pair: T > 0, or one of the row-map forms
+static inline bool s2t_rows_arg_bad(const int32_t* lens, int T) {
+  return lens && T <= 0 && T != S2T_ROWS_PACKED && T != S2T_ROWS_BOUND;
+}
+
 static inline int s2t_hip_status(hipError_t e) { return e == hipSuccess ? S2T_OK : (int)e; }
 #define S2T_LAUNCH_CHECK() s2t_hip_status(hipGetLastError())

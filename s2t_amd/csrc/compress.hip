@@ -64,7 +64,40 @@ __global__ __launch_bounds__(256) void compress_rows_kernel(const uint4* __restr
   }
 }
 
+// packed rows <-> padded rows of one batch through its row map (include/s2t_hip.h, "Packed rows"); 16-byte pieces
+template <bool TO_PACKED>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                        const int32_t* __restrict__ map, int64_t rows, int T,
+                                                        int vec_per_row) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  rows = s2t_live_rows(map, S2T_ROWS_PACKED, rows);
+  if (idx >= rows * vec_per_row) return;
+  const int64_t m = idx / vec_per_row;
+  const int v = (int)(idx % vec_per_row);
+  const int e = map[m];
+  const int64_t padded = ((int64_t)(e >> 16) * T + (e & 0xffff)) * vec_per_row + v;
+  if (TO_PACKED) out[idx] = e >= 0 ? in[padded] : make_uint4(0, 0, 0, 0);
+  else if (e >= 0) out[padded] = in[idx];
+}
+
 }  // namespace
+
+extern "C" int s2t_pack_rows(int dtype, const void* in, void* out, const int32_t* map, int64_t rows, int T, int C,
+                             int to_packed, void* stream) {
+  if (!in || !out || !map || rows < 0 || T <= 0 || T > 65535 || C <= 0) return S2T_ERR_ARG;
+  const int esz = dtype == S2T_F32 ? 4 : dtype == S2T_BF16 ? 2 : 0;
+  if (!esz) return S2T_ERR_DTYPE;
+  if ((C * esz) % 16 || ((uintptr_t)in % 16) || ((uintptr_t)out % 16)) return S2T_ERR_ARG;
+  if (rows == 0) return S2T_OK;
+  const int vpr = C * esz / 16;
+  dim3 grid((unsigned)((rows * vpr + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (to_packed)
+    hipLaunchKernelGGL(pack_rows_kernel<true>, grid, dim3(256), 0, s, (const uint4*)in, (uint4*)out, map, rows, T, vpr);
+  else
+    hipLaunchKernelGGL(pack_rows_kernel<false>, grid, dim3(256), 0, s, (const uint4*)in, (uint4*)out, map, rows, T, vpr);
+  return S2T_LAUNCH_CHECK();
+}
 
 extern "C" int s2t_ctc_compress_plan(int dtype, const void* logits, int64_t ld, const float* lse, const int32_t* lens,
                                      int B, int T, int blank, float threshold, int32_t* src, int32_t* new_lens,

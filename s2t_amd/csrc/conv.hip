@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
                                                      T* __restrict__ y, int B, int T_, int C, int K, int flip,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      int act, const int32_t* __restrict__ lens,
+                                                     const int32_t* __restrict__ cu,
                                                      float* __restrict__ stats, const float* __restrict__ bn_mean,
                                                      const float* __restrict__ bn_var, float bn_eps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -63,7 +64,20 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
   const int t0 = blockIdx.x * TT;
   const int b = blockIdx.y;
   const int c0 = blockIdx.z * CCH;
-  stage_rows<T>(lx, x, (int64_t)b * T_, T_, C, c0, t0 - pad, nrows);
+  // packed batch: the utterance's rows (frames + halo rows) start at cu[b]; the grid still covers the padded length, tiles
+  // beyond the utterance's rows leave at once (their partial statistics row is zero: the frames they stand for are zero)
+  const int64_t row_b = s2t_utt_row0(cu, b, T_);
+  const int Tfull = T_;
+  T_ = s2t_utt_rows(cu, b, Tfull);
+  if (t0 >= T_) {
+    if (stats && c0 + (int)threadIdx.x < C) {
+      float* row = stats + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+      row[c0 + threadIdx.x] = 0.f;
+      row[C + c0 + threadIdx.x] = 0.f;
+    }
+    return;
+  }
+  stage_rows<T>(lx, x, row_b, T_, C, c0, t0 - pad, nrows);
   for (int idx = threadIdx.x; idx < K * CCH; idx += 256) {
     const int k = idx / CCH, c = idx % CCH;
     lw[idx] = (c0 + c < C) ? w[(int64_t)(c0 + c) * K + (flip ? K - 1 - k : k)] : 0.f;
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
         o[r] = acc[i][r];
         if (scale) o[r] = (t < len) ? act_apply(act, o[r] * sc[r] + sh[r]) : 0.f;
       }
-      st4_from_f32<T>(y + ((int64_t)b * T_ + t) * C + c, o);
+      st4_from_f32<T>(y + (row_b + t) * C + c, o);
     }
   }
   if (stats) {
@@ -275,6 +289,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ D
                                                          const int32_t* __restrict__ lens, int Tn) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int vpr = C / 4;
+  rows = s2t_live_rows(lens, Tn, rows);
   if (idx >= rows * vpr) return;
   const int64_t row = idx / vpr;
   const int c = (int)(idx % vpr) * 4;
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ D
   ld4_as_f32<T>(D + row * C + c, d);
   ld4_as_f32<float>(scale + c, sc);
   ld4_as_f32<float>(shift + c, sh);
-  const bool masked = lens && (int)(row % Tn) >= lens[row / Tn];
+  const bool masked = lens && s2t_row_masked(lens, Tn, row);
 #pragma unroll
   for (int r = 0; r < 4; ++r) o[r] = masked ? 0.f : act_apply(act, d[r] * sc[r] + sh[r]);
   st4_from_f32<T>(out + row * C + c, o);
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
   float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  rows = s2t_live_rows(lens, Tn, rows);
   if (c < C) {
     float sc[4], sh[4], mu[4], rs[4];
     ld4_as_f32<float>(scale + c, sc);
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
       for (int u = 0; u < 4; ++u) {
         const int64_t m = m0 + u * step;
         const int64_t mc = m < rows ? m : rows - 1;
-        ok[u] = m < rows && !(lens && (int)(mc % Tn) >= lens[mc / Tn]);
+        ok[u] = m < rows && !(lens && s2t_row_masked(lens, Tn, mc));
         ld4_as_f32<T>(D + mc * C + c, d[u]);
         ld4_as_f32<T>(dOut + mc * C + c, g[u]);
       }
@@ -390,6 +406,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                                                int Tn) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int vpr = C / 4;
+  rows = s2t_live_rows(lens, Tn, rows);
   if (idx >= rows * vpr) return;
   const int64_t row = idx / vpr;
   const int c = (int)(idx % vpr) * 4;
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   ld4_as_f32<float>(rstd + c, rs);
   ld4_as_f32<float>(sums + c, s1);
   ld4_as_f32<float>(sums + C + c, s2);
-  const bool masked = lens && (int)(row % Tn) >= lens[row / Tn];
+  const bool masked = lens && s2t_row_masked(lens, Tn, row);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float du = masked ? 0.f : g[r] * act_grad(act, d[r] * sc[r] + sh[r]);
@@ -427,8 +444,8 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(
     const bf16_t* __restrict__ D, const bf16_t* __restrict__ dA, const bf16_t* __restrict__ G, const bf16_t* __restrict__ Z,
     const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ sums, float inv_count,
-    int act, const int32_t* __restrict__ lens, bf16_t* __restrict__ dZ, float* __restrict__ dw_ws, int B, int T_, int C,
-    int K) {
+    int act, const int32_t* __restrict__ lens, const int32_t* __restrict__ cu, bf16_t* __restrict__ dZ,
+    float* __restrict__ dw_ws, int B, int T_, int C, int K) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int pad = (K - 1) / 2;
   const int nrows = TT + K - 1;
@@ -438,7 +455,17 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(
   const int t0 = blockIdx.x * TT;
   const int b = blockIdx.y;
   const int c0 = blockIdx.z * CCH;
-  const int len = lens ? lens[b] : T_;
+  // packed batch: rows of utterance b (frames + halo rows) from cu[b]; a tile beyond them stands for padded frames whose dD
+  // reaches no frame and whose G window is zero: nothing to store but a zero weight-gradient partial row
+  const int64_t row_b = s2t_utt_row0(cu, b, T_);
+  T_ = s2t_utt_rows(cu, b, T_);
+  if (t0 >= T_) {
+    float* dwr = dw_ws + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * C * K + (int64_t)c0 * K;
+    const int nvalid = min(CCH, C - c0) * K;
+    for (int idx = threadIdx.x; idx < nvalid; idx += 256) dwr[idx] = 0.f;
+    return;
+  }
+  const int len = lens ? min(lens[b], T_) : T_;
   for (int idx = threadIdx.x; idx < K * CCH; idx += 256) {
     const int k = idx / CCH, c = idx % CCH;
     lw[idx] = (c0 + c < C) ? w[(int64_t)(c0 + c) * K + (K - 1 - k)] : 0.f;
@@ -470,7 +497,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(
         const int t = t0 - pad + r;
         tt[q] = t;
         ok[q] = r0 + 4 * q < nrows && t >= 0 && t < T_ && c < C;
-        const int64_t row = (int64_t)b * T_ + min(max(t, 0), T_ - 1);
+        const int64_t row = row_b + min(max(t, 0), T_ - 1);
         ld4_as_f32<bf16_t>(D + row * C + cc, dv[q]);
         ld4_as_f32<bf16_t>(dA + row * C + cc, av[q]);
         ld4_as_f32<bf16_t>(G + row * C + cc, gv[q]);
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // all sixteen loads first
       const int t = min(t0 + tg * 8 + i, T_ - 1);
-      const int64_t row = (int64_t)b * T_ + t;
+      const int64_t row = row_b + t;
       const int cc = min(c, C - 4);
       ld4_as_f32<bf16_t>(Z + row * 2 * C + cc, zv[i]);
       ld4_as_f32<bf16_t>(Z + row * 2 * C + C + cc, zg[i]);
@@ -535,7 +562,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(
           da[r] = dy * sg;
           dg[r] = dy * zv[i][r] * sg * (1.f - sg);
         }
-        const int64_t row = (int64_t)b * T_ + t;
+        const int64_t row = row_b + t;
         st4_from_f32<bf16_t>(dZ + row * 2 * C + c, da);
         st4_from_f32<bf16_t>(dZ + row * 2 * C + C + c, dg);
       }
@@ -593,8 +620,8 @@ void ensure_lds_optin() {
 }  // namespace
 
 extern "C" int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K, int flip,
-                              const float* scale, const float* shift, int act, const int32_t* lens, float* stats,
-                              void* stream) {
+                              const float* scale, const float* shift, int act, const int32_t* lens, const int32_t* cu,
+                              float* stats, void* stream) {
   if (!x || !w || !y || B <= 0 || T <= 0 || C <= 0 || K <= 0 || !(K & 1) || C % 4) return S2T_ERR_ARG;
   if (K > 31) return S2T_ERR_UNSUPPORTED;
   if ((scale == nullptr) != (shift == nullptr)) return S2T_ERR_ARG;
@@ -604,17 +631,18 @@ extern "C" int s2t_dwconv_fwd(int dtype, const void* x, const float* w, void* y,
   ensure_lds_optin();
   if (dtype == S2T_F32) {
     hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, shm, s, (const float*)x, w, (float*)y, B, T, C, K, flip, scale,
-                       shift, act, lens, stats, (const float*)nullptr, (const float*)nullptr, 0.f);
+                       shift, act, lens, cu, stats, (const float*)nullptr, (const float*)nullptr, 0.f);
   } else if (dtype == S2T_BF16) {
     hipLaunchKernelGGL(dwconv_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)x, w, (bf16_t*)y, B, T, C, K, flip,
-                       scale, shift, act, lens, stats, (const float*)nullptr, (const float*)nullptr, 0.f);
+                       scale, shift, act, lens, cu, stats, (const float*)nullptr, (const float*)nullptr, 0.f);
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
 
 extern "C" int s2t_dwconv_bn_eval_fwd(int dtype, const void* x, const float* w, void* y, int B, int T, int C, int K,
                                       const float* gamma, const float* beta, const float* running_mean,
-                                      const float* running_var, float eps, int act, const int32_t* lens, void* stream) {
+                                      const float* running_var, float eps, int act, const int32_t* lens, const int32_t* cu,
+                                      void* stream) {
   if (!x || !w || !y || !gamma || !beta || !running_mean || !running_var) return S2T_ERR_ARG;
   if (B <= 0 || T <= 0 || C <= 0 || K <= 0 || !(K & 1) || C % 4) return S2T_ERR_ARG;
   if (K > 31) return S2T_ERR_UNSUPPORTED;
@@ -624,10 +652,10 @@ extern "C" int s2t_dwconv_bn_eval_fwd(int dtype, const void* x, const float* w, 
   ensure_lds_optin();
   if (dtype == S2T_F32) {
     hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, shm, s, (const float*)x, w, (float*)y, B, T, C, K, 0, gamma, beta,
-                       act, lens, (float*)nullptr, running_mean, running_var, eps);
+                       act, lens, cu, (float*)nullptr, running_mean, running_var, eps);
   } else if (dtype == S2T_BF16) {
     hipLaunchKernelGGL(dwconv_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)x, w, (bf16_t*)y, B, T, C, K, 0, gamma,
-                       beta, act, lens, (float*)nullptr, running_mean, running_var, eps);
+                       beta, act, lens, cu, (float*)nullptr, running_mean, running_var, eps);
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
@@ -659,8 +687,8 @@ extern "C" int s2t_dwconv_bwd_weight(int dtype, const void* G, const void* dD, f
 
 extern "C" int s2t_conv_bwd_fused(const void* D, const void* dA, const void* G, const void* Z, const float* w,
                                   const float* scale, const float* shift, const float* mean, const float* rstd,
-                                  const float* sums, float count, int act, const int32_t* lens, void* dZ, float* dw,
-                                  float* ws, int B, int T, int C, int K, void* stream) {
+                                  const float* sums, float count, int act, const int32_t* lens, const int32_t* cu, void* dZ,
+                                  float* dw, float* ws, int B, int T, int C, int K, void* stream) {
   if (!D || !dA || !G || !Z || !w || !scale || !shift || !mean || !rstd || !sums || !dZ || !ws) return S2T_ERR_ARG;
   if (B <= 0 || T <= 0 || C <= 0 || K <= 0 || !(K & 1) || C % 4 || count <= 0.f) return S2T_ERR_ARG;
   if (K > 31) return S2T_ERR_UNSUPPORTED;
@@ -673,7 +701,7 @@ extern "C" int s2t_conv_bwd_fused(const void* D, const void* dA, const void* G, 
   hipStream_t s = (hipStream_t)stream;
   ensure_lds_optin();
   hipLaunchKernelGGL(conv_bwd_fused_kernel, grid, block, shm, s, (const bf16_t*)D, (const bf16_t*)dA, (const bf16_t*)G,
-                     (const bf16_t*)Z, w, scale, shift, mean, rstd, sums, 1.0f / count, act, lens, (bf16_t*)dZ, ws, B, T, C, K);
+                     (const bf16_t*)Z, w, scale, shift, mean, rstd, sums, 1.0f / count, act, lens, cu, (bf16_t*)dZ, ws, B, T, C, K);
   if (dw) {  // (dw == NULL: the caller folds the partial rows later, several layers per launch: s2t_rows_fold_add)
     const int64_t n = (int64_t)C * K;
     RowsBatch bt = {};

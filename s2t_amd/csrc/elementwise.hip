@@ -13,13 +13,23 @@ __global__ __launch_bounds__(256) void add_pos_kernel(T* __restrict__ x, const f
                                                       float scale, int pos_offset) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int vec_per_row = d / 4;
+  rows = s2t_live_rows(lens, Tn, rows);
   if (idx >= rows * vec_per_row) return;
   const int64_t row = idx / vec_per_row;
   const int c = (int)(idx % vec_per_row) * 4;
-  const int b = (int)(row / Tn), t = (int)(row % Tn);
+  int t;
+  bool valid;
+  if (Tn > 0) {
+    const int b = (int)(row / Tn);
+    t = (int)(row % Tn);
+    valid = !lens || t < lens[b];
+  } else {  // packed rows: the row map holds the frame index
+    const int e = lens[row];
+    t = e & 0xffff;
+    valid = e >= 0;
+  }
   float v[4];
   ld4_as_f32<T>(x + row * d + c, v);
-  const bool valid = !lens || t < lens[b];
   float p[4] = {0.f, 0.f, 0.f, 0.f};
   if (valid && tab) ld4_as_f32<float>(tab + (int64_t)(t + pos_offset) * d + c, p);
 #pragma unroll
@@ -32,10 +42,11 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(T* __restrict__ x, const
                                                         int64_t rows, int Tn, int d) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int vec_per_row = d / 4;
+  rows = s2t_live_rows(lens, Tn, rows);
   if (idx >= rows * vec_per_row) return;
   const int64_t row = idx / vec_per_row;
   const int c = (int)(idx % vec_per_row) * 4;
-  if ((int)(row % Tn) >= lens[row / Tn]) {
+  if (s2t_row_masked(lens, Tn, row)) {
     const float z[4] = {0.f, 0.f, 0.f, 0.f};
     st4_from_f32<T>(x + row * d + c, z);
   }
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ Z, c
   ld4_as_f32<T>(Z + row * 2 * n + c, a);
   ld4_as_f32<T>(Z + row * 2 * n + n + c, g);
   ld4_as_f32<T>(dY + row * n + c, dy);
-  const bool masked = lens && (int)(row % Tn) >= lens[row / Tn];
+  const bool masked = lens && s2t_row_masked(lens, Tn, row);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float s = sigmoidf_(g[r]);
@@ -392,7 +403,7 @@ inline unsigned flat_grid(int64_t work_items) {
 
 extern "C" int s2t_add_positions(int dtype, void* x, const float* tab, const int32_t* lens, int64_t rows, int T, int d,
                                  float scale, int pos_offset, void* stream) {
-  if (!x || rows < 0 || T <= 0 || d <= 0 || d % 4) return S2T_ERR_ARG;
+  if (!x || rows < 0 || (T <= 0 && !(T == S2T_ROWS_PACKED && lens)) || d <= 0 || d % 4) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   dim3 grid((unsigned)((rows * (d / 4) + 255) / 256));
   if (dtype == S2T_F32)
@@ -404,7 +415,7 @@ extern "C" int s2t_add_positions(int dtype, void* x, const float* tab, const int
 }
 
 extern "C" int s2t_mask_rows(int dtype, void* x, const int32_t* lens, int64_t rows, int T, int d, void* stream) {
-  if (!x || !lens || rows < 0 || T <= 0 || d <= 0 || d % 4) return S2T_ERR_ARG;
+  if (!x || !lens || rows < 0 || (T <= 0 && T != S2T_ROWS_PACKED) || d <= 0 || d % 4) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   dim3 grid((unsigned)((rows * (d / 4) + 255) / 256));
   if (dtype == S2T_F32)

@@ -86,7 +86,10 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
   const bool producer = wave < 4;
   const int wi = wave & 3;                 // row group: rows 32 wi .. +32 of the block
   const int r32 = lane & 31, hh = lane >> 5;
-  const int M = p.M, F = p.F;
+  // packed batch: the live row count comes from the row map given as the mask of the trailing LayerNorm (forward: eln_lens,
+  // backward: pl_lens, S2T_ROWS_BOUND when there is no mask); the block -> (row block, part) dealing follows the HOST's M
+  const int Mh = p.M, F = p.F;
+  const int M = (int)s2t_live_rows(BWD ? p.pl_lens : p.eln_lens, BWD ? p.pl_T : p.eln_T, Mh);
   // ---- which rows, which half of the hidden units.  Pairs are dealt so that the two workgroups of a pair are blocks
   // b and b + 8 (one XCD under round-robin placement: speed only, the exchange is placement independent).
   int pair, half;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       half = 0;
     } else {
       // groups of 8 row blocks x SPLIT parts: the parts of a row block are blocks b, b + 8, b + 16, ...
-      const int P = (M + RB - 1) / RB;
+      const int P = (Mh + RB - 1) / RB;
       constexpr int G = 8 * SPLIT;
       const int full = (P >> 3) * G;
       if (b < full) {
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
     }
   }
   const int row0 = pair * RB;
+  if (row0 >= M) return;  // no live row in this block: every part of it leaves (no flag is raised, none is awaited)
   const int FH = F / SPLIT;                // hidden units of this workgroup
   const int fbase = half * FH;
   const int nchunks = FH / FC;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
           const float mu = p.pl_mean[mc], rs = p.pl_rstd[mc];
           const bool live = m < M;
           const bool own = live && (SPLIT == 1 || rl / KR == half);
-          const bool masked = !live || (p.pl_lens && (m % p.pl_T) >= p.pl_lens[m / p.pl_T]);
+          const bool masked = !live || (p.pl_lens && s2t_row_masked32(p.pl_lens, p.pl_T, (uint32_t)m));
           const uint32_t dw4[4] = {raw[ps].x, raw[ps].y, raw[ps].z, raw[ps].w};
           const uint32_t yw4[4] = {yr.x, yr.y, yr.z, yr.w};
           float dgv[8], xh[8];
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
       const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
-      const bool masked = p.eln_lens && live && (m % p.eln_T) >= p.eln_lens[m / p.eln_T];
+      const bool masked = p.eln_lens && live && s2t_row_masked32(p.eln_lens, p.eln_T, (uint32_t)m);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {

@@ -51,7 +51,11 @@ struct Cursor {
 };
 
 template <typename T, bool AKM, bool BKM, typename TC, bool GLU, int D, bool KT, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p0) {
+  // packed batch (row_T < 0: row_lens is a row map): M is the live row count, read here; the tiles beyond it are never
+  // walked.  The split-K workspace keeps the host's tile count as its stride (the second-phase kernels use the same).
+  s2t_gemm_args p = p0;
+  p.M = (int)s2t_live_rows(p0.row_lens, p0.row_T, p0.M);
   constexpr int BKE = TileTraits<T>::BKE;
   constexpr int EPB = TileTraits<T>::EPB;
   __shared__ __attribute__((aligned(16))) char smem[65536];
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
   const int bn_out = GLU ? 64 : 128;  // output columns per tile
   const int tiles_n = (nout + bn_out - 1) / bn_out;
   const int ntiles = ((p.M + BM - 1) / BM) * tiles_n;
+  const int ntiles_ws = ((p0.M + BM - 1) / BM) * tiles_n;
 
   // Persistent walk: workgroup w takes tiles w, w+G, w+2G, ... (consecutive tile ids share the A row block).  Workgroup
   // ids are dealt round-robin to the 8 XCDs, so w is permuted to give every XCD a contiguous range of tile ids: the
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
     if (p.ws) {
       // two-phase split-K: this split's partial tile goes to the workspace in register-native order (every wave
       // instruction stores 1 KiB contiguous); splitk_reduce_kernel sums the splits into C
-      float* wt = p.ws + ((((int64_t)z * p.split_k + blockIdx.y) * ntiles) + (w + c.ord * G)) * (int64_t)(BM * BN);
+      float* wt = p.ws + ((((int64_t)z * p.split_k + blockIdx.y) * ntiles_ws) + (w + c.ord * G)) * (int64_t)(BM * BN);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -490,7 +495,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const s2t_gemm_args p) {
 // Second phase of the workspace split-K: C[m][n] += alpha * sum_s partial_s[m][n].  One workgroup per (tile,
 // accumulator fragment f = i*4+j): thread t owns the same fragment element it owned in gemm_kernel (lane map of
 // the swapped 16x16 MFMA: row = x, 4 consecutive columns at 4y).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args p, int ntiles, int tiles_n) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args p0, int ntiles, int tiles_n) {
+  s2t_gemm_args p = p0;
+  p.M = (int)s2t_live_rows(p0.row_lens, p0.row_T, p0.M);  // packed batch: tiles beyond the live rows were not computed
+  if ((int)(blockIdx.x / tiles_n) * BM >= p.M) return;
   const int tile = blockIdx.x, f = blockIdx.y, z = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, x = lane & 15, y = lane >> 4;
@@ -550,7 +558,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const s2t_gemm_args 
 // pass.  One workgroup per (tile, fragment pair): lanes y and y^1 swap halves exactly as in gemm_kernel's epilogue, so
 // that a thread ends up with 8 consecutive columns of one row (and the dropout keys are those of the one-pass kernel).
 template <typename TC, bool VEC>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const s2t_gemm_args p, int ntiles, int tiles_n) {
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const s2t_gemm_args p0, int ntiles, int tiles_n) {
+  s2t_gemm_args p = p0;
+  p.M = (int)s2t_live_rows(p0.row_lens, p0.row_T, p0.M);  // packed batch: tiles beyond the live rows were not computed
+  if ((int)(blockIdx.x / tiles_n) * BM >= p.M) return;
   const int tile = blockIdx.x, it = blockIdx.y, z = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, x = lane & 15, y = lane >> 4;
@@ -607,7 +618,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const s2t_gemm_arg
 }
 
 static bool has_fused_epilogue(const s2t_gemm_args& p) {
-  return p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || p.row_lens || p.drop_p > 0.f;
+  return p.bias || p.act != S2T_ACT_NONE || p.residual || p.preact || p.dact_z || (p.row_lens && p.row_T != S2T_ROWS_BOUND) || p.drop_p > 0.f;
 }
 
 static int64_t splitk_ws_floats(const s2t_gemm_args& p) {
@@ -711,7 +722,7 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
     const int64_t b_span = (int64_t)(p.b_kmajor ? p.K : p.N) * p.ldb * esz;
     if (a_span >= (1ll << 32) || b_span >= (1ll << 32)) return S2T_ERR_UNSUPPORTED;
   }
-  if (p.row_lens && p.row_T <= 0) return S2T_ERR_ARG;
+  if (s2t_rows_arg_bad(p.row_lens, p.row_T) || (p.row_lens && p.row_T < 0 && p.batch != 1)) return S2T_ERR_ARG;
   if (p.row_lens && (int64_t)p.batch * p.M >= ((int64_t)1 << 31)) return S2T_ERR_UNSUPPORTED;  // 32-bit row arithmetic in the mask
   if (p.drop_p < 0.f || p.drop_p >= 1.f) return S2T_ERR_ARG;
   // two-phase split-K only with a large enough workspace and when every K split is non-empty (an empty split would

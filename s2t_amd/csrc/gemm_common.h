@@ -318,9 +318,7 @@ struct Epi {
   __device__ __forceinline__ bool row_masked(int64_t grow) const {
     if (!p.row_lens) return false;
     // 32-bit division (the host rejects batch * M >= 2^31 rows): the 64-bit one is a long software sequence
-    const uint32_t g32 = (uint32_t)grow, rt = (uint32_t)p.row_T;
-    const uint32_t b = g32 / rt, t = g32 - b * rt;
-    return (int)t >= p.row_lens[b];
+    return s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)grow);
   }
   // v: post-bias (post-GLU) values for output columns n0..n0+7 of row m
   __device__ __forceinline__ void finish(int m, int n0, int64_t grow, float (&v)[8]) const {

@@ -358,11 +358,13 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const s2t_wgrad_problem* 
   for (int ord = 0; ord < my_items; ++ord) {
     const Item it = items[w + ord * G];
     const s2t_wgrad_problem* p = probs + it.prob;
-    const int K = p->K;
+    // k_live (packed batch: the rows are the reduction dimension): K is read here, and the item's share of the K-steps is
+    // re-cut from it in nsplit balanced parts — every work item of the problem shrinks with the fill of the batch
+    const int K = p->k_live ? min(p->K, __builtin_amdgcn_readfirstlane(p->k_live[0])) : p->K;  // (workgroup-uniform: keep it scalar)
     const uint32_t lda2 = (uint32_t)(p->lda * 2), ldb2 = (uint32_t)(p->ldb * 2);
     const int ktiles = (K + BK2 - 1) / BK2;
-    const int kt0 = it.split * p->ksteps;
-    const int nst = min(ktiles, kt0 + p->ksteps) - kt0;
+    const int kt0 = p->k_live ? (int)((int64_t)it.split * ktiles / p->nsplit) : it.split * p->ksteps;
+    const int nst = p->k_live ? (int)((int64_t)(it.split + 1) * ktiles / p->nsplit) - kt0 : min(ktiles, kt0 + p->ksteps) - kt0;
     const bool do_cs = p->colsum != nullptr && it.tn == 0;
     // descriptors: base moved to the tile's first column, bounds at the end of the operand (K rows)
     const int64_t a_bytes = (int64_t)K * lda2 - (int64_t)it.tm * (T2 * 2);

@@ -172,7 +172,8 @@ constexpr int ARGMAX_ROWS = 8;
 template <typename T, bool ARG = true>
 __global__ __launch_bounds__(256) void argmax_lse_kernel(const T* __restrict__ logits, int64_t ld, int V, int64_t rows,
                                                          int32_t* __restrict__ idx, float* __restrict__ top_lp,
-                                                         float* __restrict__ lse_out) {
+                                                         float* __restrict__ lse_out, const int32_t* __restrict__ live) {
+  if (live) rows = min(rows, (int64_t)live[0]);  // packed batch: only the live rows
   // ARGMAX_ROWS rows per workgroup: with one row each, 16 000 workgroups of a few microseconds are bound by the dispatch
   // rate (~170 workgroups per microsecond), not by the 320 MB they read
   for (int64_t row = (int64_t)blockIdx.x * ARGMAX_ROWS; row < min(rows, ((int64_t)blockIdx.x + 1) * ARGMAX_ROWS); ++row) {
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(256) void argmax_lse_kernel(const T* __restrict__ l
 // ---- CTC greedy, stage 2: pad->blank, unique_consecutive, drop blank (s2t_ctc.py:329-347); one WG / utterance ----
 __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int32_t* __restrict__ idx,
                                                             const float* __restrict__ top_lp,
-                                                            const int32_t* __restrict__ lens, int T, int blank,
+                                                            const int32_t* __restrict__ lens,
+                                                            const int32_t* __restrict__ cu, int T, int blank,
                                                             int64_t* __restrict__ out_tokens,
                                                             int32_t* __restrict__ out_lens,
                                                             float* __restrict__ out_scores) {
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int32_t* __res
   __shared__ int carry;
   const int b = blockIdx.x;
   const int len = lens[b];
+  const int64_t r0 = s2t_utt_row0(cu, b, T);  // first row of the utterance in idx / top_lp (frames >= len are not read)
   if (threadIdx.x == 0) carry = 0;
   float score = 0.f;
   __syncthreads();
@@ -206,14 +209,17 @@ __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int32_t* __res
     const int t = base + threadIdx.x;
     int cur = blank, prev = -1;
     if (t < T) {
-      const int raw = idx[(int64_t)b * T + t];
+      // packed batch: the rows behind an utterance's frames belong to the next one — the padded frames they stand for are
+      // zero rows in the reference, whose arg-max is the blank (index 0 of a constant row) and add nothing to the score
+      const bool have = !cu || t < len;
+      const int raw = have ? idx[r0 + t] : blank;
       cur = t < len ? raw : blank;
       if (t > 0) {
-        const int rawp = idx[(int64_t)b * T + t - 1];
+        const int rawp = (!cu || t - 1 < len) ? idx[r0 + t - 1] : blank;
         prev = (t - 1) < len ? rawp : blank;
       }
       // the score uses the UNMASKED arg-max (s2t_ctc.py:327-328)
-      if (raw != blank) score += top_lp[(int64_t)b * T + t];
+      if (have && raw != blank) score += top_lp[r0 + t];
     }
     const int keep = (t < T && cur != blank && cur != prev) ? 1 : 0;
     scan[threadIdx.x] = keep;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
                                                               float* __restrict__ alpha, float* __restrict__ beta,
                                                               int Lmax, float* __restrict__ nll_out,
                                                               const int64_t* __restrict__ force_emits,
-                                                              int32_t* __restrict__ paths) {
+                                                              int32_t* __restrict__ paths, const int32_t* __restrict__ cu) {
   // force_emits (imputer loss, torch_imputer/imputer.cu:114-152): fe[b,t] >= 0 pins frame t to state fe, every other
   // state gets -inf.  paths != NULL (best alignment, torch_imputer/best_alignment.cu:57-201): max-product recursion
   // with back-pointers instead of log-sum-exp; beta is not computed.
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const T* __restric
   if (act && (s & 1) && s + 2 < L) skipn = lab != (int)targets[(int64_t)b * ldt + (s >> 1) + 1];
   float* bufA = sh;
   float* bufB = sh + (Lmax + 2);
-  const int64_t row0 = (int64_t)b * T_;
+  const int64_t row0 = s2t_utt_row0(cu, b, T_);  // logits / lse rows of the utterance (alpha, beta, paths: padded strides)
   float* al = alpha + (int64_t)b * T_ * Lmax;
   float* be = beta + (int64_t)b * T_ * Lmax;
   if (Tb <= 0) {
@@ -515,7 +521,8 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
                                                                  const int32_t* __restrict__ tgt_lens,
                                                                  const int32_t* __restrict__ in_lens, int blank,
                                                                  float* __restrict__ alpha, float* __restrict__ beta,
-                                                                 int Lmax, float* __restrict__ nll_out) {
+                                                                 int Lmax, float* __restrict__ nll_out,
+                                                                 const int32_t* __restrict__ cu) {
   constexpr int CH = 16;
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   const int b = blockIdx.x;
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
   const int lab = act1 ? (int)tg[lane] : blank;
   const bool skip = act1 && lane >= 1 && lab != (int)tg[lane - 1];
   const bool skipn = act1 && s1 + 2 < L && lab != (int)tg[lane + 1];
-  const int64_t row0 = (int64_t)b * T_;
+  const int64_t row0 = s2t_utt_row0(cu, b, T_);  // logits / lse rows of the utterance (alpha, beta: padded strides)
   if (Tb <= 0) {
     if (lane == 0 && blockIdx.y == 0) nll_out[b] = 0.f;
     return;
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
   };
   Chunk cur, nxt;
   if (blockIdx.y == 0) {
-    float* al = alpha + row0 * Lmax;
+    float* al = alpha + (int64_t)b * T_ * Lmax;
     const __amdgpu_buffer_rsrc_t asrd = __builtin_amdgcn_make_buffer_rsrc(al, 0, (int)((int64_t)T_ * Lmax * 4), 0x00020000);
     fetch(cur, 0, 1);
     float a0 = lane == 0 ? emit0(cur, 0) : -INFINITY;
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(const T* __rest
     const float l2 = L >= 2 ? lane_value(a1, max(S - 1, 0)) : -INFINITY;  // state L-2 = 2(S-1)+1
     if (lane == 0) nll_out[b] = -(l2se2(l1, l2) * LN2);
   } else {
-    float* be = beta + row0 * Lmax;
+    float* be = beta + (int64_t)b * T_ * Lmax;
     const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(be, 0, (int)((int64_t)T_ * Lmax * 4), 0x00020000);
     fetch(cur, Tb - 1, -1);
     float b0 = s0 >= L - 2 ? emit0(cur, 0) : -INFINITY;
@@ -646,15 +653,16 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        int Lmax, const float* __restrict__ nll, float gscale_host,
                                                        const float* __restrict__ gscale_dev, T* __restrict__ grad,
-                                                       int64_t ldg, int wrt_logprobs) {
+                                                       int64_t ldg, int wrt_logprobs, const int32_t* __restrict__ cu) {
   // the upstream gradient of the summed loss usually lives on the device (a 0-dim autograd tensor): multiply here
   // instead of in a separate pass over the [B*T, V] gradient
   const float gscale = gscale_dev ? gscale_host * gscale_dev[0] : gscale_host;
   // wrt_logprobs = 0: gradient w.r.t. the LOGITS (softmax - occupancy); 1: w.r.t. log-probabilities (- occupancy),
   // the quantity torch_imputer returns (imputer.cu:561-638)
   extern __shared__ float occ[];  // [Lmax] exp(alpha+beta+nll) per state, then merged per label
-  const int64_t row = blockIdx.x;
-  const int b = (int)(row / T_), t = (int)(row % T_);
+  const int b = (int)(blockIdx.x / T_), t = (int)(blockIdx.x % T_);
+  if (cu && t >= cu[b + 1] - cu[b]) return;  // packed batch: the utterance has no such row
+  const int64_t row = s2t_utt_row0(cu, b, T_) + t;
   T* g = grad + row * ldg;
   const float n = nll[b];
   const int Tb = min(in_lens[b], T_);
@@ -772,26 +780,26 @@ __global__ void ctc_backtrace_kernel(const float* __restrict__ alpha, const int3
 }  // namespace
 
 extern "C" int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int V, int32_t* idx,
-                              float* top_lp, float* lse, void* stream) {
+                              float* top_lp, float* lse, const int32_t* live, void* stream) {
   if (!logits || rows < 0 || V <= 0 || ld < V) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   dim3 grid((unsigned)((rows + ARGMAX_ROWS - 1) / ARGMAX_ROWS)), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool arg = idx != nullptr || top_lp != nullptr;
   if (dtype == S2T_F32) {
-    if (arg) hipLaunchKernelGGL((argmax_lse_kernel<float, true>), grid, block, 0, s, (const float*)logits, ld, V, rows, idx, top_lp, lse);
-    else hipLaunchKernelGGL((argmax_lse_kernel<float, false>), grid, block, 0, s, (const float*)logits, ld, V, rows, idx, top_lp, lse);
+    if (arg) hipLaunchKernelGGL((argmax_lse_kernel<float, true>), grid, block, 0, s, (const float*)logits, ld, V, rows, idx, top_lp, lse, live);
+    else hipLaunchKernelGGL((argmax_lse_kernel<float, false>), grid, block, 0, s, (const float*)logits, ld, V, rows, idx, top_lp, lse, live);
   } else if (dtype == S2T_BF16) {
-    if (arg) hipLaunchKernelGGL((argmax_lse_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)logits, ld, V, rows, idx, top_lp, lse);
-    else hipLaunchKernelGGL((argmax_lse_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)logits, ld, V, rows, idx, top_lp, lse);
+    if (arg) hipLaunchKernelGGL((argmax_lse_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)logits, ld, V, rows, idx, top_lp, lse, live);
+    else hipLaunchKernelGGL((argmax_lse_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)logits, ld, V, rows, idx, top_lp, lse, live);
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
 
-extern "C" int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens, int B, int T, int blank,
-                                int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream) {
+extern "C" int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens, const int32_t* cu, int B, int T,
+                                int blank, int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream) {
   if (!idx || !top_lp || !lens || !out_tokens || !out_lens || !out_scores || B <= 0 || T <= 0) return S2T_ERR_ARG;
-  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, idx, top_lp, lens, T, blank,
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, idx, top_lp, lens, cu, T, blank,
                      out_tokens, out_lens, out_scores);
   return S2T_LAUNCH_CHECK();
 }
@@ -815,7 +823,7 @@ extern "C" int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, i
 extern "C" int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B, int T, int V, const float* lse,
                                 const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens,
                                 int blank, float* alpha, float* beta, int Lmax, float* nll, const int64_t* force_emits,
-                                int32_t* paths, void* stream) {
+                                int32_t* paths, const int32_t* cu, void* stream) {
   if (!logits || !lse || !targets || !tgt_lens || !in_lens || !alpha || !nll) return S2T_ERR_ARG;
   if (!beta && !paths) return S2T_ERR_ARG;
   if (B <= 0 || T <= 0 || V <= 0 || Lmax <= 0 || Lmax > 1023 || !(Lmax & 1)) return S2T_ERR_ARG;
@@ -824,15 +832,15 @@ extern "C" int s2t_ctc_loss_fwd(int dtype, const void* logits, int64_t ld, int B
   hipStream_t s = (hipStream_t)stream;
   if (Lmax <= 127 && beta && !paths && !force_emits && (dtype == S2T_F32 || dtype == S2T_BF16)) {
     if (dtype == S2T_F32)
-      hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<float>, dim3(B, 2), dim3(64), 0, s, (const float*)logits, ld, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll);
+      hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<float>, dim3(B, 2), dim3(64), 0, s, (const float*)logits, ld, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, cu);
     else
-      hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<bf16_t>, dim3(B, 2), dim3(64), 0, s, (const bf16_t*)logits, ld, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll);
+      hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<bf16_t>, dim3(B, 2), dim3(64), 0, s, (const bf16_t*)logits, ld, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, cu);
     return S2T_LAUNCH_CHECK();
   }
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B, (beta && !paths) ? 2 : 1), dim3(threads), shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B, (beta && !paths) ? 2 : 1), dim3(threads), shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths, cu);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B, (beta && !paths) ? 2 : 1), dim3(threads), shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths);
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B, (beta && !paths) ? 2 : 1), dim3(threads), shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, force_emits, paths, cu);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
@@ -841,16 +849,16 @@ extern "C" int s2t_ctc_loss_bwd(int dtype, const void* logits, int64_t ld, int B
                                 const int64_t* targets, int ldt, const int32_t* tgt_lens, const int32_t* in_lens,
                                 int blank, const float* alpha, const float* beta, int Lmax, const float* nll,
                                 float gscale, const float* gscale_dev, void* grad, int64_t ldg, int wrt_logprobs,
-                                void* stream) {
+                                const int32_t* cu, void* stream) {
   if (!logits || !lse || !targets || !tgt_lens || !in_lens || !alpha || !beta || !nll || !grad) return S2T_ERR_ARG;
   if (B <= 0 || T <= 0 || V <= 0 || Lmax <= 0) return S2T_ERR_ARG;
   const size_t shm = (size_t)Lmax * sizeof(float);
   dim3 grid((unsigned)((int64_t)B * T)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ctc_grad_kernel<float>, grid, block, shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, gscale_dev, (float*)grad, ldg, wrt_logprobs);
+    hipLaunchKernelGGL(ctc_grad_kernel<float>, grid, block, shm, s, (const float*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, gscale_dev, (float*)grad, ldg, wrt_logprobs, cu);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, gscale_dev, (bf16_t*)grad, ldg, wrt_logprobs);
+    hipLaunchKernelGGL(ctc_grad_kernel<bf16_t>, grid, block, shm, s, (const bf16_t*)logits, ld, V, T, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale, gscale_dev, (bf16_t*)grad, ldg, wrt_logprobs, cu);
   else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const int32_t* __restrict__ row_lens, int row_T) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  rows = s2t_live_rows(row_lens, row_T, rows);  // packed batch: rows beyond the live ones are not touched
   if (row >= rows) return;
   const T* xr = x + row * cols;
   float v[NV][4];
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
   const float rstd = rsqrtf(wave_sum(q) / cols + eps);
   bool masked = false;
-  if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
+  if (row_lens) masked = s2t_row_masked(row_lens, row_T, row);
   T* yr = y + row * cols;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
                                                      int row_T) {
   __shared__ float red[2][4][NV * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  rows = s2t_live_rows(row_lens, row_T, rows);
   constexpr int nvec = NV;
   float ag[NV][4], ab[NV][4];
 #pragma unroll
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 
   for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
     bool masked = false;
-    if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
+    if (row_lens) masked = s2t_row_masked(row_lens, row_T, row);
     const float mu = mean[row], rs = rstd[row];
     float xh[NV][4], dg[NV][4];
     float s1 = 0.f, s2 = 0.f;
@@ -196,6 +198,8 @@ __global__ __launch_bounds__(256) void ln256_fwd_kernel(const bf16_t* __restrict
   // half-wave leaves a single load in flight per lane)
   constexpr int RPH = 2;
   const int lane = threadIdx.x & 63, l = lane & 31;
+  rows = s2t_live_rows(row_lens, row_T, rows);
+  if ((int64_t)blockIdx.x * 16 >= rows) return;  // (workgroup-uniform: a packed batch fills only part of the grid)
   const int64_t row0 = ((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5)) * RPH;
   float v[RPH][8];
   bool valid[RPH];
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void ln256_fwd_kernel(const bf16_t* __restrict
     if (!valid[u]) continue;  // (after the wave-wide shuffles)
     const int64_t row = row0 + u;
     bool masked = false;
-    if (row_lens) masked = (int)(row % row_T) >= row_lens[row / row_T];
+    if (row_lens) masked = s2t_row_masked(row_lens, row_T, row);
     float o[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = masked ? 0.f : (v[u][r] - mean) * rstd * g[r] + b[r];
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(256) void ln256_bwd_kernel(const bf16_t* __restrict
                                                         const uint64_t* __restrict__ drop_seed, uint32_t drop_site) {
   __shared__ float red[2][8][256];
   const int lane = threadIdx.x & 63, l = lane & 31, hw = (threadIdx.x >> 6) * 2 + (lane >> 5);
+  rows = s2t_live_rows(row_lens, row_T, rows);
   float g[8];
   ld4_as_f32<float>(gamma + l * 8, reinterpret_cast<float (&)[4]>(g[0]));
   ld4_as_f32<float>(gamma + l * 8 + 4, reinterpret_cast<float (&)[4]>(g[4]));
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void ln256_bwd_kernel(const bf16_t* __restrict
       mu[u] = mean[rr];
       rs[u] = rstd[rr];
       masked[u] = !valid[u];
-      if (valid[u] && row_lens) masked[u] = (int)(row % row_T) >= row_lens[row / row_T];
+      if (valid[u] && row_lens) masked[u] = s2t_row_masked(row_lens, row_T, row);
     }
 #pragma unroll
     for (int u = 0; u < RPH; ++u) {

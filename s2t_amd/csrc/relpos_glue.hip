@@ -87,10 +87,32 @@ struct GlueArgs {
   int64_t replica_stride;
   bf16_t* dp_part;     // [B][2Tq-1][H*64]
   int B, H, Tq;
+  const int32_t* cu;   // packed batch: rows of utterance b in dq = cu[b] .. cu[b+1] (dbd / qv keep their padded row strides)
 };
 
-__global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a) {
+// the first `rem` (0 < rem < 8) bf16 elements of a 16-byte piece, the rest zero
+__device__ __forceinline__ uint4 keep_first(uint4 v, int rem) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = rem - 2 * t;
+    w[t] = r >= 2 ? w[t] : (r == 1 ? (w[t] & 0xffffu) : 0u);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
   __shared__ __attribute__((aligned(16))) char lds[L_BYTES];
+  GlueArgs a = a_in;
+  // packed batch: this utterance's rows.  nq rows are walked; of a dbd row only the columns its dQ kernel wrote in THIS pass
+  // are taken — n < Tq-1-i+nq: the slab is shared by every batch, and what lies beyond may be the band of a longer utterance
+  // of an earlier one.
+  int nq = a.Tq;
+  if (a.cu) {
+    const int bb = (int)blockIdx.x / a.H, r0 = a.cu[bb];
+    nq = a.cu[bb + 1] - r0;
+    a.dq += (int64_t)r0 * a.dq_sr - (int64_t)bb * a.dq_sb;
+  }
   char* lp = lds + L_P;
   char* ld = lds + L_D;
   char* lq = lds + L_Q;
@@ -122,12 +144,12 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int c = tid + 512 * u;
-      const int q = min(q0 + (c >> 6), a.Tq - 1), jc = min(c & 63, nchunk - 1);
+      const int q = min(q0 + (c >> 6), nq - 1), jc = min(c & 63, nchunk - 1);
       tr[u] = *reinterpret_cast<const uint4*>(slab + (int64_t)q * a.ldb + jc * 8);
     }
     if (tid < 256)
-      tqv = *reinterpret_cast<const uint4*>(a.qv + ((int64_t)b * a.Tq + min(q0 + (tid >> 3), a.Tq - 1)) * d + h * DK + (tid & 7) * 8);
-    old_n = *reinterpret_cast<const uint2*>(a.dq + (int64_t)b * a.dq_sb + (int64_t)min(q0 + 16 * qh + x, a.Tq - 1) * a.dq_sr + h * DK +
+      tqv = *reinterpret_cast<const uint4*>(a.qv + ((int64_t)b * a.Tq + min(q0 + (tid >> 3), nq - 1)) * d + h * DK + (tid & 7) * 8);
+    old_n = *reinterpret_cast<const uint2*>(a.dq + (int64_t)b * a.dq_sb + (int64_t)min(q0 + 16 * qh + x, nq - 1) * a.dq_sr + h * DK +
                                             16 * ct1 + 4 * y);
   };
   auto tile_store = [&](int q0, int buf) __attribute__((always_inline)) {
@@ -137,12 +159,17 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a) {
     for (int u = 0; u < 4; ++u) {
       const int c = tid + 512 * u;
       const int q = c >> 6, jc = c & 63;
-      const bool ok = q0 + q < a.Tq && jc < nchunk;
-      *reinterpret_cast<uint4*>(ldb_ + q * 1024 + ((jc ^ key1024(q)) << 4)) = ok ? tr[u] : make_uint4(0, 0, 0, 0);
+      const bool ok = q0 + q < nq && jc < nchunk;
+      uint4 v = tr[u];
+      if (a.cu) {  // (workgroup-uniform)
+        const int rem = a.Tq - 1 - (q0 + q) + nq - 8 * jc;  // columns of this piece below the row's written band end
+        if (rem < 8) v = rem > 0 ? keep_first(v, rem) : make_uint4(0, 0, 0, 0);
+      }
+      *reinterpret_cast<uint4*>(ldb_ + q * 1024 + ((jc ^ key1024(q)) << 4)) = ok ? v : make_uint4(0, 0, 0, 0);
     }
     if (tid < 256) {
       const int qr = tid >> 3;
-      *reinterpret_cast<uint4*>(lqb + qr * 128 + (((tid & 7) ^ key128(qr)) << 4)) = q0 + qr < a.Tq ? tqv : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(lqb + qr * 128 + (((tid & 7) ^ key128(qr)) << 4)) = q0 + qr < nq ? tqv : make_uint4(0, 0, 0, 0);
     }
   };
   tile_load(0);  // (in flight together with the position rows below: one global round trip for both)
@@ -166,8 +193,8 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a) {
   tile_store(0, 0);
   __syncthreads();  // (also orders the position image)
   int buf = 0;
-  for (int q0 = 0; q0 < a.Tq; q0 += TQ, buf ^= 1) {
-    const bool more = q0 + TQ < a.Tq;
+  for (int q0 = 0; q0 < nq; q0 += TQ, buf ^= 1) {
+    const bool more = q0 + TQ < nq;
     const uint2 old = old_n;
     if (more && !((S2T_GLUE_DBG & 4) && q0 > 0)) tile_load(q0 + TQ);
     const char* ldc = ld + buf * (TQ * 1024);
@@ -213,7 +240,7 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a) {
       }
       acc += acc1;
     }
-    if (i < a.Tq && !(S2T_GLUE_DBG & 8)) {
+    if (i < nq && !(S2T_GLUE_DBG & 8)) {
       const float o4[4] = {__uint_as_float(old.x << 16), __uint_as_float(old.x & 0xffff0000u), __uint_as_float(old.y << 16),
                            __uint_as_float(old.y & 0xffff0000u)};
       float n4[4];
@@ -327,7 +354,7 @@ __global__ __launch_bounds__(256) void relpos_dp_reduce_kernel(const DpBatch bat
 
 extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_sr, const void* qv, void* dq,
                                int64_t dq_sb, int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride,
-                               void* dp_part, float* dp, int B, int H, int Tq, int dk, void* stream) {
+                               void* dp_part, float* dp, int B, int H, int Tq, int dk, const int32_t* cu, void* stream) {
   if (!dbd || !pos_p || !qv || !dq || !dpos_u || !dpos_v || !dp_part || B <= 0 || H <= 0 || Tq <= 0 || replicas < 1)
     return S2T_ERR_ARG;
   if (dk != DK || 2 * Tq - 1 > NP - 1) return S2T_ERR_UNSUPPORTED;
@@ -338,7 +365,7 @@ extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, 
   GlueArgs a = {};
   a.dbd = (const bf16_t*)dbd; a.ldb = ldb; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.qv = (const bf16_t*)qv;
   a.dq = (bf16_t*)dq; a.dq_sb = dq_sb; a.dq_sr = dq_sr; a.du = dpos_u; a.dv = dpos_v; a.replicas = replicas;
-  a.replica_stride = replica_stride; a.dp_part = (bf16_t*)dp_part; a.B = B; a.H = H; a.Tq = Tq;
+  a.replica_stride = replica_stride; a.dp_part = (bf16_t*)dp_part; a.B = B; a.H = H; a.Tq = Tq; a.cu = cu;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(relpos_glue_kernel, dim3(B * H), dim3(512), 0, s, a);
   if (dp) {  // (dp == NULL: the caller sums the partial tables later, several layers per launch: s2t_relpos_dp_reduce)

@@ -103,7 +103,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
   const int mp = wave & 1, fh = (wave >> 1) & 1, nh = wave >> 2;
   const int x = lane & 15, g = lane >> 4;
   const int row0 = blockIdx.x * TM;
-  const int M = p.M, F = p.F;
+  // packed batch: the live row count comes from the row map given as the mask of the trailing LayerNorm (forward: eln_lens,
+  // backward: pl_lens); row blocks beyond it leave at once (workgroup-uniform, before any barrier)
+  const int M = (int)s2t_live_rows(BWD ? p.pl_lens : p.eln_lens, BWD ? p.pl_T : p.eln_T, p.M), F = p.F;
+  if (row0 >= M) return;
   const int nchunks = F / FC;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 #if S2T_RB_DBG & 16
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
           const int rl = 16 * ps + (tid >> 5);
           const int m = row0 + rl;
           const bool live = m < M;
-          const bool masked = !live || (p.pl_lens && (m % p.pl_T) >= p.pl_lens[m / p.pl_T]);
+          const bool masked = !live || (p.pl_lens && s2t_row_masked32(p.pl_lens, p.pl_T, (uint32_t)m));
           const uint32_t dw4[4] = {raw[ps].x, raw[ps].y, raw[ps].z, raw[ps].w};
           const uint32_t yw4[4] = {yraw[ps].x, yraw[ps].y, yraw[ps].z, yraw[ps].w};
           float dgv[8], xh[8];
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
         const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
-        const bool masked = p.eln_lens && live && (m % p.eln_T) >= p.eln_lens[m / p.eln_T];
+        const bool masked = p.eln_lens && live && s2t_row_masked32(p.eln_lens, p.eln_T, (uint32_t)m);
         if (live) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
@@ -1012,7 +1015,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   const int mp = wave & 1, q = wave >> 1;
   const int x = lane & 15, g = lane >> 4;
   const int row0 = blockIdx.x * TM;
-  const int M = p.M, N = p.N;
+  const int M = (int)s2t_live_rows(p.row_lens, p.row_T, s2t_live_rows(p.ln_lens, p.ln_T, p.M)), N = p.N;
+  if (row0 >= M) return;  // packed batch: this row block holds no live row
   const int nout = GLU ? N / 2 : N;
   const int ncols = GLU ? 32 : 64;            // output columns per chunk
   const int nchunks = (nout + ncols - 1) / ncols;
@@ -1077,7 +1081,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     for (int pass = 0; pass < 2; ++pass) {
       const int rg = 8 * pass + wave;          // row group: rows 4 rg .. 4 rg + 3 of the block (wave-uniform)
       const int m0 = row0 + 4 * rg;
-      const int b0 = min(m0, M - 1) / T;
+      const int b0 = T > 0 ? min(m0, M - 1) / T : 0;
       const int t0 = m0 - b0 * T;              // frame of the group's first row (>= T only beyond the last row)
       uint2 raw[18];
 #pragma unroll
@@ -1085,12 +1089,20 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         const int mj = min(max(m0 - 7 + j, 0), M - 1);
         raw[j] = *reinterpret_cast<const uint2*>(X + (int64_t)mj * D + 4 * c4);
       }
-      // rows of a neighbouring utterance (and beyond either end of the batch) read as zero padding
+      // rows of a neighbouring utterance (and beyond either end of the batch) read as zero padding.  ut[j]: which utterance
+      // window row j belongs to — relative to the group's first row (uniform layout) or its index from the row map (packed
+      // batch; -1 on rows that hold no frame: halo rows are zero in G, rows beyond the live ones are not read at all)
       int ut[18];
 #pragma unroll
       for (int j = 0; j < 18; ++j) {
-        const int tj = t0 - 7 + j;
-        ut[j] = tj < 0 ? -1 : (tj >= T ? 1 : 0);
+        if (T > 0) {
+          const int tj = t0 - 7 + j;
+          ut[j] = tj < 0 ? -1 : (tj >= T ? 1 : 0);
+        } else {
+          const int mj = m0 - 7 + j;
+          const int e = (mj >= 0 && mj < M) ? p.ln_lens[mj] : -1;
+          ut[j] = e >= 0 ? (e >> 16) : -1;
+        }
       }
       float acc[4][4];
 #pragma unroll
@@ -1102,7 +1114,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         const float4 w = make_float4(wr[k], wr[15 + k], wr[30 + k], wr[45 + k]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int ui = (t0 + i >= T) ? 1 : 0;  // wave-uniform: the group straddles an utterance boundary
+          const int ui = T > 0 ? ((t0 + i >= T) ? 1 : 0) : ut[i + 7];  // wave-uniform: the group straddles an utterance boundary
           const bool ok = ut[i + k] == ui;
           const uint2 r = raw[i + k];
           const float x0 = ok ? __uint_as_float(r.x << 16) : 0.f, x1 = ok ? __uint_as_float(r.x & 0xffff0000u) : 0.f;
@@ -1116,7 +1128,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rl = 4 * rg + i, m = row0 + rl;
-        const bool masked = m >= M || (p.ln_lens && (m % p.ln_T) >= p.ln_lens[m / p.ln_T]);
+        const bool masked = m >= M || (p.ln_lens && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m));
         uint2 o;
         o.x = masked ? 0u : pack2(act_apply(p.pre_act, acc[i][0] * gm.x + bt.x), act_apply(p.pre_act, acc[i][1] * gm.y + bt.y));
         o.y = masked ? 0u : pack2(act_apply(p.pre_act, acc[i][2] * gm.z + bt.z), act_apply(p.pre_act, acc[i][3] * gm.w + bt.w));
@@ -1172,7 +1184,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
 #pragma unroll
         for (int sh = 16; sh > 0; sh >>= 1) sq += __shfl_xor(sq, sh, 64);
         const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
-        const bool masked = p.ln_lens && m < M && (m % p.ln_T) >= p.ln_lens[m / p.ln_T];
+        const bool masked = p.ln_lens && m < M && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m);
         uint32_t ow[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1188,7 +1200,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         }
       } else if (p.pre_scale) {  // per-column affine + activation (BatchNorm apply), masked rows to zero
         const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
-        const bool masked = p.ln_lens && m < M && (m % p.ln_T) >= p.ln_lens[m / p.ln_T];
+        const bool masked = p.ln_lens && m < M && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m);
         uint32_t ow[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1294,7 +1306,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-    if (p.row_lens && (m % p.row_T) >= p.row_lens[m / p.row_T]) {
+    if (p.row_lens && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)m)) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
@@ -1363,7 +1375,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
   const int mp = wave & 1, q = wave >> 1;
   const int x = lane & 15, g = lane >> 4;
   const int row0 = blockIdx.x * TM;
-  const int M = p.M, K = p.K;
+  const int M = (int)s2t_live_rows(p.ln_lens, p.ln_T, p.M), K = p.K;
+  if (row0 >= M) return;  // packed batch: this row block holds no live row
   const int KB = K / D;
   const uint32_t K2 = (uint32_t)K * 2u;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -1508,7 +1521,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
     const int ml = 8 * wave + 2 * ps + hi;
     const int m = row0 + ml;
     const bool live = m < M;
-    const bool masked = !live || (p.ln_lens && (m % p.ln_T) >= p.ln_lens[m / p.ln_T]);
+    const bool masked = !live || (p.ln_lens && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m));
     const float mu = mupre[ps], rs = rspre[ps];
     float dv[2][4], xh[2][4], dg[2][4], rr[2][4];
     float s1 = 0.f, s2 = 0.f;
@@ -1668,7 +1681,7 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   if (!a->y && !a->y_ln) return S2T_ERR_ARG;
   if ((a->eln_gamma != nullptr) != (a->y_ln != nullptr) || (a->eln_gamma && !a->eln_beta)) return S2T_ERR_ARG;
   if ((a->ln_gamma != nullptr) != (a->ln_beta != nullptr)) return S2T_ERR_ARG;
-  if (a->eln_lens && a->eln_T <= 0) return S2T_ERR_ARG;
+  if (s2t_rows_arg_bad(a->eln_lens, a->eln_T)) return S2T_ERR_ARG;
   if (a->drop_h_p < 0.f || a->drop_h_p >= 1.f || a->drop_o_p < 0.f || a->drop_o_p >= 1.f) return S2T_ERR_ARG;
   if ((a->drop_h_p > 0.f || a->drop_o_p > 0.f) && !a->drop_seed) return S2T_ERR_ARG;
   const void* ptrs[] = {a->x, a->w1, a->w2, a->residual, a->y, a->y_ln, a->x_ln, a->z, a->h, a->b1, a->b2,
@@ -1745,7 +1758,7 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   if (!b || !b->dy || !b->w2t || !b->w1t || !b->z || !b->dz) return S2T_ERR_ARG;
   if (b->end_y) {
     if (!b->end_gamma || !b->end_mean || !b->end_rstd || !b->end_ws || b->end_replicas <= 0 || !b->dres_out) return S2T_ERR_ARG;
-    if (b->end_lens && b->end_T <= 0) return S2T_ERR_ARG;
+    if (s2t_rows_arg_bad(b->end_lens, b->end_T)) return S2T_ERR_ARG;
     if (b->dy_out && (b->drop_o_p <= 0.f || b->drop_o_p >= 1.f || !b->drop_seed)) return S2T_ERR_ARG;
     if (((uintptr_t)b->end_y % 16) || ((uintptr_t)b->dres_out % 16) || ((uintptr_t)b->dy_out % 16)) return S2T_ERR_ALIGN;
   }
@@ -1837,13 +1850,14 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   if ((a->ln_mean || a->ln_rstd) && !a->ln_gamma) return S2T_ERR_ARG;
   if ((a->x_ln || a->ln_lens) && !a->ln_gamma && !a->pre_scale) return S2T_ERR_ARG;
   if (a->pre_scale && (((uintptr_t)a->pre_scale % 16) || ((uintptr_t)a->pre_shift % 16))) return S2T_ERR_ALIGN;
-  if ((a->ln_lens && a->ln_T <= 0) || (a->row_lens && a->row_T <= 0)) return S2T_ERR_ARG;
+  if (s2t_rows_arg_bad(a->ln_lens, a->ln_T) || s2t_rows_arg_bad(a->row_lens, a->row_T)) return S2T_ERR_ARG;
   if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->drop_seed)) return S2T_ERR_ARG;
   if (a->ldc < nout || a->ldc % 8 || (a->residual && (a->ldr < nout || a->ldr % 8)) || (a->preact && (a->ldp < a->N || a->ldp % 8)))
     return S2T_ERR_ALIGN;
   if (a->conv_w) {
-    if (!a->pre_scale || glu || a->drop_p > 0.f || a->x_ln || a->conv_T < 18 || (a->ln_lens && a->ln_T != a->conv_T)) return S2T_ERR_ARG;
-    if (a->M % a->conv_T) return S2T_ERR_ARG;
+    const bool conv_packed = a->conv_T == S2T_ROWS_PACKED && a->ln_lens && a->ln_T == S2T_ROWS_PACKED;  // utterances from the row map
+    if (!a->pre_scale || glu || a->drop_p > 0.f || a->x_ln || (!conv_packed && a->conv_T < 18) || (a->ln_lens && a->ln_T != a->conv_T)) return S2T_ERR_ARG;
+    if (!conv_packed && a->M % a->conv_T) return S2T_ERR_ARG;
     if ((uintptr_t)a->conv_w % 16) return S2T_ERR_ALIGN;
     if (a->bn_mean && (!a->bn_var || ((uintptr_t)a->bn_mean % 16) || ((uintptr_t)a->bn_var % 16))) return S2T_ERR_ARG;
   }
@@ -1872,7 +1886,7 @@ extern "C" int s2t_rowblock_dgrad(const s2t_rowblock_dgrad_args* a, void* stream
   if ((int64_t)(a->M + TM) * a->K * 2 >= ((int64_t)1 << 32)) return S2T_ERR_UNSUPPORTED;  // 32-bit byte offsets into dY
   if (a->ln_x) {
     if (!a->ln_gamma || !a->ln_mean || !a->ln_rstd || !a->ln_ws || a->ln_replicas <= 0 || !a->dx) return S2T_ERR_ARG;
-    if (a->ln_lens && a->ln_T <= 0) return S2T_ERR_ARG;
+    if (s2t_rows_arg_bad(a->ln_lens, a->ln_T)) return S2T_ERR_ARG;
     if (a->dx_drop && (a->up_drop_p <= 0.f || a->up_drop_p >= 1.f || !a->drop_seed)) return S2T_ERR_ARG;
   } else if (!a->dxn) return S2T_ERR_ARG;
   const void* ptrs[] = {a->dy, a->wt, a->dxn, a->ln_x, a->ln_gamma, a->dres, a->dx, a->dx_drop};

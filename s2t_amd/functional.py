@@ -468,8 +468,8 @@ def _wg_dtype():
         import numpy as np
         _WG_DTYPE = np.dtype([("A", "u8"), ("B", "u8"), ("C", "u8"), ("colsum", "u8"), ("lda", "i8"), ("ldb", "i8"),
                               ("ldc", "i8"), ("ws_base", "i8"), ("M", "i4"), ("N", "i4"), ("K", "i4"), ("tiles_n", "i4"),
-                              ("ksteps", "i4"), ("nsplit", "i4"), ("alpha", "f4"), ("next", "i4")])
-        assert _WG_DTYPE.itemsize == 96
+                              ("ksteps", "i4"), ("nsplit", "i4"), ("alpha", "f4"), ("next", "i4"), ("k_live", "u8")])
+        assert _WG_DTYPE.itemsize == 104
     return _WG_DTYPE
 
 
@@ -477,6 +477,7 @@ def flush_wgrads():
     """Run every queued weight gradient (called by the end-of-backward callback; safe to call with an empty queue)."""
     import numpy as np
     q, _WGQ["probs"] = _WGQ["probs"], []
+    q = [e if len(e) == 11 else tuple(e) + (None,) for e in q]  # (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db, packed geometry)
     if q:
         dev = q[0][0].device
         probs = np.zeros(len(q), dtype=_wg_dtype())
@@ -486,7 +487,9 @@ def flush_wgrads():
         last_of = {}
         # the LDS-DMA kernel on 256 x 256 tiles (s2t_wgrad_grouped256) when every problem meets its operand layout rules
         big = _WG_256 and all(ldy % 8 == 0 and ldx % 8 == 0 and dY.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0
-                              and M * ldy * 2 < 2 ** 31 and M * ldx * 2 < 2 ** 31 for (dY, X, _, _, _, M, ldy, ldx, _, _) in q)
+                              and M * ldy * 2 < 2 ** 31 and M * ldx * 2 < 2 ** 31 for (dY, X, _, _, _, M, ldy, ldx, _, _, _) in q)
+        if not big and any(e[10] is not None for e in q):
+            raise RuntimeError("s2t_amd: a packed batch needs the 256 x 256 grouped weight-gradient kernel (operand layout rules)")
         TL, KS, per_item = (256, 32, _WG_KSTEPS256) if big else (128, 64, _WG_KSTEPS)
         if big and _WG_AUTO:
             # K-steps per work item chosen per launch: the items of a launch run in rounds of one workgroup per CU (128 KiB of
@@ -497,7 +500,7 @@ def flush_wgrads():
             best = None
             for cand in (256, 200, 170, 128, 100, 64):
                 n_items, longest = 0, 0
-                for (_, _, _, Nout, Kin, M, _, _, _, _) in q:
+                for (_, _, _, Nout, Kin, M, _, _, _, _, _) in q:
                     kt = (M + KS - 1) // KS
                     ns = max(1, (kt + cand // 2) // cand)
                     n_items += ((Nout + TL - 1) // TL) * ((Kin + TL - 1) // TL) * ns
@@ -506,7 +509,7 @@ def flush_wgrads():
                 if best is None or cost < best[0] * 0.97:  # ties and near-ties go to the larger items (less workspace traffic)
                     best = (cost, cand)
             per_item = best[1]
-        for i, (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db) in enumerate(q):
+        for i, (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db, live) in enumerate(q):
             tm_n, tn_n = (Nout + TL - 1) // TL, (Kin + TL - 1) // TL
             ktiles = (M + KS - 1) // KS
             nsplit = (ktiles + per_item - 1) // per_item
@@ -517,7 +520,7 @@ def flush_wgrads():
                 per_item_p = per_item
             k_tail |= (M % 64) != 0
             probs[i] = (dY.data_ptr(), X.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, ldy, ldx,
-                        Kin, ws_floats, Nout, Kin, M, tn_n, per_item_p, nsplit, alpha, -1)
+                        Kin, ws_floats, Nout, Kin, M, tn_n, per_item_p, nsplit, alpha, -1, live.map_ptr - 4 if live is not None else 0)
             prev = last_of.get(dW.data_ptr())  # tied weights: chain the problems, reduce them in one workgroup
             last_of[dW.data_ptr()] = i
             if prev is not None:
@@ -593,14 +596,22 @@ def flush_wgrads():
             slot_ev[2] = ev
 
 
-def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None):
+def _wgrad(dY, X, dW, Nout, Kin, M, ldy, ldx, alpha=1.0, db=None, rows=None):
     """dW[Nout, Kin] += alpha * dY[M, Nout]^T @ X[M, Kin]   (TN GEMM, split-K over M, two-phase workspace reduction);
     db[Nout] += alpha * column sums of dY when given (taken from the staged dY tiles inside the same kernel).
     bf16 problems inside a backward pass are queued for the grouped launch (flush_wgrads)."""
     mode = _WGQ["mode"]
+    live = K.rows_geom(rows)
+    if live is not None:
+        # packed batch: M (the reduction dimension) is the padded bound, the live row count is read on the device — only the
+        # grouped launch does that (s2t_wgrad_problem.k_live), inside and outside a captured step
+        if not (dY.dtype == torch.bfloat16 and _arm_backward_end()):
+            raise RuntimeError("s2t_amd: weight gradients over packed rows run through the grouped launch (bf16, inside backward)")
+        _WGQ["probs"].append((dY, X, dW, Nout, Kin, M, ldy, ldx, float(alpha), db, live))
+        return
     if dY.dtype == torch.bfloat16 and dY.is_cuda and (mode == "1" or (mode == "graph" and torch.cuda.is_current_stream_capturing())):
         if _arm_backward_end():
-            _WGQ["probs"].append((dY, X, dW, Nout, Kin, M, ldy, ldx, float(alpha), db))
+            _WGQ["probs"].append((dY, X, dW, Nout, Kin, M, ldy, ldx, float(alpha), db, None))
             return
     tiles = ((Nout + 127) // 128) * ((Kin + 127) // 128)
     bke = 64 if dY.dtype == torch.bfloat16 else 32
@@ -622,14 +633,14 @@ class LayerNormFn(torch.autograd.Function):
     meet at x are then added inside the LayerNorm backward kernel instead of by a separate elementwise pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, lens, T, fork):
+    def forward(ctx, x, gamma, beta, lens, T, fork, bound=None):
         rows, cols = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        K.layernorm_fwd(x, gamma.data, beta.data, y, mean, rstd, rows, cols, 1e-5, lens, T)
+        K.layernorm_fwd(x, gamma.data, beta.data, y, mean, rstd, rows, cols, 1e-5, lens, T, bound=bound)
         ctx.save_for_backward(x, mean, rstd)
-        ctx.gamma, ctx.beta, ctx.lens, ctx.T = gamma, beta, lens, T
+        ctx.gamma, ctx.beta, ctx.lens, ctx.T, ctx.bound = gamma, beta, lens, T, bound
         up = getattr(x, "_s2t_drop_o", None)  # output-dropout mask of the block that produced x (see _tag_drop)
         ctx.up_drop = up if (up is not None and x.dtype == torch.bfloat16 and cols == 256) else None
         if fork:
@@ -648,35 +659,38 @@ class LayerNormFn(torch.autograd.Function):
             # partial sums into a private workspace slice; ONE fold launch for all LayerNorms at the end of backward
             ws = _ln_workspace(cols, x.device)
             K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, None, None, rows, cols, ctx.lens, ctx.T,
-                            dres, ws=ws, dx_drop=dxd, drop=ctx.up_drop)
+                            dres, ws=ws, dx_drop=dxd, drop=ctx.up_drop, bound=ctx.bound)
             _LNQ["entries"].append((ws, ctx.gamma.grad, ctx.beta.grad, cols))
         else:
             K.layernorm_bwd(x, ctx.gamma.data, dy.contiguous(), mean, rstd, dx, ctx.gamma.grad, ctx.beta.grad, rows, cols,
-                            ctx.lens, ctx.T, dres, dx_drop=dxd, drop=ctx.up_drop)
+                            ctx.lens, ctx.T, dres, dx_drop=dxd, drop=ctx.up_drop, bound=ctx.bound)
         _ready(ctx.gamma, ctx.beta)
         if dxd is not None:
             _hand_over(dx, ctx.up_drop, dxd)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, lens=None, T=0, fork=False):
-    return LayerNormFn.apply(x, gamma, beta, lens, T, fork)
+def layer_norm(x, gamma, beta, lens=None, T=0, fork=False, rows=None):
+    """``rows``: the lengths tensor of a packed batch (s2t_amd/rows.py) when there is no mask: only its live rows are
+    normalised (the same keyword on the other row-wise functions of this module)."""
+    return LayerNormFn.apply(x, gamma, beta, lens, T, fork, rows)
 
 
-def _ln_backward(x, gamma, beta, dy, mean, rstd, lens, T, dres, up_drop):
+def _ln_backward(x, gamma, beta, dy, mean, rstd, lens, T, dres, up_drop, rows=None):
     """s2t_layernorm_bwd for a LayerNorm whose forward was folded into a row-block kernel: parameter gradients through the
     queued fold (or directly outside a backward pass), the residual-branch gradient ``dres`` added in the kernel, and the
     dropped copy for the block in front handed over when ``up_drop`` names its output mask."""
-    rows, cols = x.shape
+    nrows, cols = x.shape
     dx = torch.empty_like(x)
     dxd = torch.empty_like(x) if up_drop is not None else None
     if x.is_cuda and _arm_backward_end():
         ws = _ln_workspace(cols, x.device)
-        K.layernorm_bwd(x, gamma.data, dy, mean, rstd, dx, None, None, rows, cols, lens, T, dres, ws=ws, dx_drop=dxd, drop=up_drop)
+        K.layernorm_bwd(x, gamma.data, dy, mean, rstd, dx, None, None, nrows, cols, lens, T, dres, ws=ws, dx_drop=dxd, drop=up_drop,
+                        bound=rows)
         _LNQ["entries"].append((ws, gamma.grad, beta.grad, cols))
     else:
-        K.layernorm_bwd(x, gamma.data, dy, mean, rstd, dx, gamma.grad, beta.grad, rows, cols, lens, T, dres, dx_drop=dxd,
-                        drop=up_drop)
+        K.layernorm_bwd(x, gamma.data, dy, mean, rstd, dx, gamma.grad, beta.grad, nrows, cols, lens, T, dres, dx_drop=dxd,
+                        drop=up_drop, bound=rows)
     _ready(gamma, beta)
     if dxd is not None:
         _hand_over(dx, up_drop, dxd)
@@ -698,7 +712,7 @@ _DGRAD_SPLITK_MINK = int(os.environ.get("S2T_DGRAD_SPLITK_MINK", "1024"))
 _RB_DGRAD = os.environ.get("S2T_RB_DGRAD", "1") != "0"  # s2t_rowblock_dgrad: projection dgrad + LayerNorm backward in one launch
 
 
-def _dgrad_ln_backward(dy, first_w, Kd, x_pre, gamma, beta, mean, rstd, lens, T, dres, up_drop):
+def _dgrad_ln_backward(dy, first_w, Kd, x_pre, gamma, beta, mean, rstd, lens, T, dres, up_drop, rows=None):
     """dx = LayerNorm'(dy @ W) + dres through s2t_rowblock_dgrad, or None when it does not apply (the caller then runs the
     GEMM and s2t_layernorm_bwd).  ``first_w``: first parameter of the [Kd, 256] weight (group) in the flat buffer."""
     flat = getattr(first_w, "_s2t_flat", None)
@@ -714,7 +728,7 @@ def _dgrad_ln_backward(dy, first_w, Kd, x_pre, gamma, beta, mean, rstd, lens, T,
     dxd = torch.empty_like(x_pre) if up_drop is not None else None
     ws = _ln_workspace(256, x_pre.device)
     K.rowblock_dgrad(dy, wt, ln=dict(x=x_pre, gamma=gamma.data, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, lens=lens, T=T,
-                                     dx_drop=dxd, drop=up_drop))
+                                     dx_drop=dxd, drop=up_drop), rows=rows)
     _LNQ["entries"].append((ws, gamma.grad, beta.grad, 256))
     _ready(gamma, beta)
     if dxd is not None:
@@ -726,7 +740,7 @@ _RB_DGRAD_PLAIN = os.environ.get("S2T_RB_DGRAD_PLAIN", "1") != "0"
 _BN_IN_PW2 = os.environ.get("S2T_BN_IN_PW2", "1") != "0"  # training BatchNorm apply + activation in pointwise conv 2's prologue
 
 
-def _dgrad_rowblock(dy, w_param, Kd):
+def _dgrad_rowblock(dy, w_param, Kd, rows=None):
     """dx[M, 256] = dy[M, Kd] @ W for a [Kd, 256] weight (attention output projection, pointwise conv 2: Kd = 256) through
     the row-block dgrad kernel without a LayerNorm behind it, or None when it does not apply (the caller runs s2t_gemm)."""
     flat = getattr(w_param, "_s2t_flat", None)
@@ -739,11 +753,11 @@ def _dgrad_rowblock(dy, w_param, Kd):
         _BE["flats"].append(flat)
     wt = transposed(w_param, True, Kd, 256)
     dx = torch.empty(M, 256, dtype=dy.dtype, device=dy.device)
-    K.rowblock_dgrad(dy, wt, dxn=dx)
+    K.rowblock_dgrad(dy, wt, dxn=dx, rows=rows)
     return dx
 
 
-def _dgrad(dy, w, dx, M, N, Kd, lda, ldb, ldc, alpha=1.0):
+def _dgrad(dy, w, dx, M, N, Kd, lda, ldb, ldc, alpha=1.0, rows=None):
     """dx[M, N] = alpha * dy[M, Kd] @ w[Kd, N] (input gradient of a linear layer).  A long reduction over few output tiles —
     the vocabulary projections (K = V = 10 000; M = B*U decoder rows: 32 tiles walking 157 K-steps each took 180 us) and the
     decoder's FFN — is cut into K splits whose fp32 partial tiles meet in a workspace (two-phase split-K, bf16 result)."""
@@ -753,9 +767,10 @@ def _dgrad(dy, w, dx, M, N, Kd, lda, ldb, ldc, alpha=1.0):
         if tiles < 384:
             split = max(1, min(8, 512 // tiles, Kd // 256))
     if split > 1:
-        K.gemm(dy, w, dx, M=M, N=N, K=Kd, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=True, alpha=alpha, split_k=split, c_atomic=2)
+        K.gemm(dy, w, dx, M=M, N=N, K=Kd, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=True, alpha=alpha, split_k=split, c_atomic=2,
+               rows=rows)
     else:
-        K.gemm(dy, w, dx, M=M, N=N, K=Kd, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=True, alpha=alpha)
+        K.gemm(dy, w, dx, M=M, N=N, K=Kd, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=True, alpha=alpha, rows=rows)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -767,16 +782,16 @@ class LinearFn(torch.autograd.Function):
     vocabulary size); the returned tensor is the [:, :N] view of it."""
 
     @staticmethod
-    def forward(ctx, x, w, b, alpha, residual, out_dtype):
+    def forward(ctx, x, w, b, alpha, residual, out_dtype, rows=None):
         M, Kin = x.shape
         Nout = w.shape[0]
         ldc = _pad8(Nout)
         y = torch.empty(M, ldc, dtype=out_dtype or x.dtype, device=x.device)
         ldr = residual.stride(0) if residual is not None else 0
         K.gemm(x, cw(w), y, M=M, N=Nout, K=Kin, lda=Kin, ldb=Kin, ldc=ldc, bias=b.data if b is not None else None,
-               alpha=alpha, residual=residual, ldr=ldr)
+               alpha=alpha, residual=residual, ldr=ldr, rows=rows)
         ctx.save_for_backward(x)
-        ctx.w, ctx.b, ctx.alpha, ctx.has_res = w, b, alpha, residual is not None
+        ctx.w, ctx.b, ctx.alpha, ctx.has_res, ctx.rows = w, b, alpha, residual is not None, rows
         return y[:, :Nout] if ldc != Nout else y
 
     @staticmethod
@@ -794,14 +809,14 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _dgrad(dy, cw(w), dx, M, Kin, Nout, ldy, Kin, Kin, ctx.alpha)
-        _wgrad(dy, x, w.grad, Nout, Kin, M, ldy, Kin, ctx.alpha, b.grad if b is not None else None)
+            _dgrad(dy, cw(w), dx, M, Kin, Nout, ldy, Kin, Kin, ctx.alpha, rows=ctx.rows)
+        _wgrad(dy, x, w.grad, Nout, Kin, M, ldy, Kin, ctx.alpha, b.grad if b is not None else None, rows=ctx.rows)
         _ready(w, b)
-        return dx, None, None, None, (dy if ctx.has_res else None), None
+        return dx, None, None, None, (dy if ctx.has_res else None), None, None
 
 
-def linear(x, w, b=None, alpha=1.0, residual=None, out_dtype=None):
-    return LinearFn.apply(x, w, b, alpha, residual, out_dtype)
+def linear(x, w, b=None, alpha=1.0, residual=None, out_dtype=None, rows=None):
+    return LinearFn.apply(x, w, b, alpha, residual, out_dtype, rows)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -871,7 +886,8 @@ class FFNBlockFn(torch.autograd.Function):
     Returns LN_end(y) when ``end`` = (gamma, beta) is given (the pre-norm y has no other consumer), y otherwise."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, act, alpha, train, drop_h, drop_o, end_g, end_b, end_lens, end_T):
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, act, alpha, train, drop_h, drop_o, end_g, end_b, end_lens, end_T,
+                rows=None):
         M, d = x.shape
         F_ = w1.shape[0]
         dev = x.device
@@ -895,11 +911,12 @@ class FFNBlockFn(torch.autograd.Function):
                                       ln=(gamma.data, beta.data), end_ln=(end_g.data, end_b.data) if end_g is not None else None,
                                       y_ln=y_ln, end_stats=(emean, erstd) if emean is not None else None, end_lens=end_lens,
                                       end_T=end_T, x_ln=x_ln, ln_stats=(mean, rstd) if train else None, z=z, h=h, drop_h=drop_h,
-                                      drop_o=drop_o, z_tiled_ok=train and fused_bwd_ok)
+                                      drop_o=drop_o, z_tiled_ok=train and fused_bwd_ok, rows=rows)
         if train:
             ctx.save_for_backward(x, x_ln, mean, rstd, z, h, y if end_g is not None else None, emean, erstd)
         ctx.p = (gamma, beta, w1, b1, w2, b2, end_g, end_b)
         ctx.act, ctx.alpha, ctx.drops, ctx.end_lens, ctx.end_T = act, alpha, (drop_h, drop_o), end_lens, end_T
+        ctx.rows = rows if rows is not None else (end_lens if K.rows_geom(end_lens) is not None else None)
         up = getattr(x, "_s2t_drop_o", None)  # output-dropout mask of the block that produced x (see _tag_drop)
         ctx.up_drop = up
         return y_ln if end_g is not None else y
@@ -913,17 +930,18 @@ class FFNBlockFn(torch.autograd.Function):
         drop_h, drop_o = ctx.drops
         dout = dout.contiguous()
         queued = x.is_cuda and _arm_backward_end()
+        rows = ctx.rows
 
         def ln_bwd(xx, g_, b_, dy_, mean_, rstd_, lens, T, dres, dx_drop, drop):
             dx_ = torch.empty_like(xx)
             if queued:
                 ws = _ln_workspace(d, xx.device)
                 K.layernorm_bwd(xx, g_.data, dy_, mean_, rstd_, dx_, None, None, M, d, lens, T, dres, ws=ws, dx_drop=dx_drop,
-                                drop=drop)
+                                drop=drop, bound=rows)
                 _LNQ["entries"].append((ws, g_.grad, b_.grad, d))
             else:
                 K.layernorm_bwd(xx, g_.data, dy_, mean_, rstd_, dx_, g_.grad, b_.grad, M, d, lens, T, dres, dx_drop=dx_drop,
-                                drop=drop)
+                                drop=drop, bound=rows)
             _ready(g_, b_)
             return dx_
 
@@ -964,32 +982,32 @@ class FFNBlockFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 ws = _ln_workspace(d, x.device)
                 K.ffn_fused_bwd(dout if end_in_kernel is not None else dy, w2t, w1t, z, dz, None, act=ctx.act, alpha=ctx.alpha,
-                                drop_h=drop_h, end=end_in_kernel, z_tiled=zt,
+                                drop_h=drop_h, end=end_in_kernel, z_tiled=zt, rows=rows,
                                 ln=dict(x=x, gamma=gamma.data, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, dx_drop=dxd,
                                         drop=ctx.up_drop))
                 _LNQ["entries"].append((ws, gamma.grad, beta.grad, d))
                 _ready(gamma, beta)
             else:
                 dxl = torch.empty_like(x)
-                K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxl, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h, z_tiled=zt)
+                K.ffn_fused_bwd(dy, w2t, w1t, z, dz, dxl, act=ctx.act, alpha=ctx.alpha, drop_h=drop_h, z_tiled=zt, rows=rows)
         else:
             dxl = torch.empty_like(x)
             K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
-                   dact=ctx.act, drop=drop_h)
-            _dgrad(dz, cw(w1), dxl, M, d, F_, F_, d, d)
-        _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad)
+                   dact=ctx.act, drop=drop_h, rows=rows)
+            _dgrad(dz, cw(w1), dxl, M, d, F_, F_, d, d, rows=rows)
+        _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad, rows=rows)
         _ready(w2, b2)
-        _wgrad(dz, x_ln, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)
+        _wgrad(dz, x_ln, w1.grad, F_, d, M, F_, d, 1.0, b1.grad, rows=rows)
         _ready(w1, b1)
         if dx is None:
             dx = ln_bwd(x, gamma, beta, dxl, mean, rstd, None, 0, dres, dxd, ctx.up_drop)
         if dxd is not None:
             _hand_over(dx, ctx.up_drop, dxd)
-        return (dx,) + (None,) * 15
+        return (dx,) + (None,) * 16
 
 
 def ffn_block(x, norm_g, norm_b, w1, b1, w2, b2, act, alpha, p_hidden=0.0, p_out=0.0, training=False, end_norm=None,
-              end_lens=None, end_T=0):
+              end_lens=None, end_T=0, rows=None):
     """Pre-LN feed-forward block with its residual (and the layer's trailing LayerNorm when ``end_norm`` = (gamma, beta)):
     the row-block kernel when it applies, the LayerNorm / GEMM composition otherwise."""
     M, d = x.shape
@@ -1000,8 +1018,10 @@ def ffn_block(x, norm_g, norm_b, w1, b1, w2, b2, act, alpha, p_hidden=0.0, p_out
         drop_o = DROPOUT.next(p_out if training else 0.0, x.device)
         eg, eb = end_norm if end_norm is not None else (None, None)
         out = FFNBlockFn.apply(x, norm_g, norm_b, w1, b1, w2, b2, act, alpha, torch.is_grad_enabled(), drop_h, drop_o, eg,
-                               eb, end_lens, end_T)
+                               eb, end_lens, end_T, rows)
         return out if end_norm is not None else _tag_drop(out, drop_o)
+    if K.rows_geom(rows) is not None or K.rows_geom(end_lens) is not None:
+        raise NotImplementedError("packed rows: the feed-forward block runs on the fused kernels only (d = 256, bf16)")
     y, xr = layer_norm(x, norm_g, norm_b, fork=True)
     out = ffn(y, w1, b1, w2, b2, act, alpha, xr, p_hidden, p_out, training)
     if end_norm is not None:
@@ -1036,12 +1056,19 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, train, drop_a, drop_o,
-                ln_g=None, ln_b=None, pos_p=None, kv_all=None, kv_slot=None):
+                ln_g=None, ln_b=None, pos_p=None, kv_all=None, kv_slot=None, q_rows=None):
         d = xq.shape[1]
         dk = d // H
         dt = xq.dtype
         dev = xq.device
         self_attn = xkv is None and kv_all is None
+        # packed batches (s2t_amd/rows.py): ``key_lens`` names the geometry of the key side — and of the query side in
+        # self-attention; ``q_rows`` that of the queries of an encoder-decoder attention (None: uniform rows)
+        kr = key_lens if K.rows_geom(key_lens) is not None else None
+        qr = kr if self_attn else (q_rows if K.rows_geom(q_rows) is not None else None)
+        ctx.rows = (qr, kr)
+        if (qr is not None or kr is not None) and not _use_fused_attention(dt, dk):
+            raise NotImplementedError("packed rows: attention runs on the fused kernels only (bf16, head width 64)")
         ctx.kv_slot = kv_slot if kv_all is not None else None
         Mq, Mk = B * Tq, B * Tk
         ctx.ln = None
@@ -1057,13 +1084,13 @@ class AttentionFn(torch.autograd.Function):
                 ln_mean = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
                 ln_rstd = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
                 K.rowblock_gemm(x_pre, wqkv, qkv, N=3 * d, ldc=3 * d, bias=bqkv, ln=(ln_g.data, ln_b.data), x_ln=xq,
-                                ln_stats=(ln_mean, ln_rstd) if train else None)
+                                ln_stats=(ln_mean, ln_rstd) if train else None, rows=qr)
                 ctx.ln = (ln_g, ln_b, getattr(x_pre, "_s2t_drop_o", None))
                 ctx.ln_saved = (x_pre, ln_mean, ln_rstd)
                 if xq is None:
                     xq = x_pre  # eval: only shapes / dtypes are read below
             else:
-                K.gemm(xq, wqkv, qkv, M=Mq, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, bias=bqkv)
+                K.gemm(xq, wqkv, qkv, M=Mq, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, bias=bqkv, rows=qr)
             q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
             ldq = ldk = 3 * d
         else:
@@ -1076,13 +1103,13 @@ class AttentionFn(torch.autograd.Function):
                 ln_mean = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
                 ln_rstd = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
                 K.rowblock_gemm(x_pre, cw(prm["q_w"]), q, N=d, ldc=d, bias=prm["q_b"].data, ln=(ln_g.data, ln_b.data), x_ln=xq,
-                                ln_stats=(ln_mean, ln_rstd) if train else None)
+                                ln_stats=(ln_mean, ln_rstd) if train else None, rows=qr)
                 ctx.ln = (ln_g, ln_b, getattr(x_pre, "_s2t_drop_o", None))
                 ctx.ln_saved = (x_pre, ln_mean, ln_rstd)
                 if xq is None:
                     xq = x_pre
             else:
-                K.gemm(xq, cw(prm["q_w"]), q, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["q_b"].data)
+                K.gemm(xq, cw(prm["q_w"]), q, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["q_b"].data, rows=qr)
             if kv_all is not None:  # k | v of every decoder layer were projected by one launch (CrossKVFn): columns of layer l
                 l, L, _ = kv_slot
                 assert _use_fused_attention(dt, dk)
@@ -1092,7 +1119,7 @@ class AttentionFn(torch.autograd.Function):
                 wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
                 bkv = fused_master([prm["k_b"], prm["v_b"]], 2 * d)
                 kv = torch.empty(Mk, 2 * d, dtype=dt, device=dev)
-                K.gemm(xkv, wkv, kv, M=Mk, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, bias=bkv)
+                K.gemm(xkv, wkv, kv, M=Mk, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, bias=bkv, rows=kr)
                 k, v = kv, kv[:, d:]
                 ldq, ldk = d, 2 * d
         Z = B * H
@@ -1114,14 +1141,14 @@ class AttentionFn(torch.autograd.Function):
             lse = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
             K.attn_fused_fwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, Tq * d, d, lse, B, H, Tq, Tk, dk,
                              key_lens, causal, scale, p, d, prm["pos_u"].data.view(-1) if p is not None else None,
-                             prm["pos_v"].data.view(-1) if p is not None else None, drop_a)
+                             prm["pos_v"].data.view(-1) if p is not None else None, drop_a, q_rows=qr, k_rows=kr)
             y = torch.empty(Mq, d, dtype=dt, device=dev)
             if _rb_ok(O, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1)):
                 K.rowblock_gemm(O, cw(prm["o_w"]), y, N=d, ldc=d, bias=prm["o_b"].data, residual=residual,
-                                ldr=residual.stride(0) if residual is not None else 0, drop=drop_o)
+                                ldr=residual.stride(0) if residual is not None else 0, drop=drop_o, rows=qr)
             else:
                 K.gemm(O, cw(prm["o_w"]), y, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual,
-                       ldr=d, drop=drop_o)
+                       ldr=d, drop=drop_o, rows=qr)
             ctx.drops = (drop_a, drop_o)
             ctx.fused = True
             ctx.pos_pt = getattr(pos_p, "_s2t_pt", None) if (kind == "rel" and pos_p is not None) else None
@@ -1185,11 +1212,12 @@ class AttentionFn(torch.autograd.Function):
         drop_a, drop_o = ctx.drops
         dres = dy.contiguous()
         dy = _drop_rows(dres, drop_o)
-        dO = _dgrad_rowblock(dy, prm["o_w"], d) if d == 256 else None
+        qr, kr = ctx.rows
+        dO = _dgrad_rowblock(dy, prm["o_w"], d, rows=qr) if d == 256 else None
         if dO is None:
             dO = torch.empty(Mq, d, dtype=dt, device=dev)
-            K.gemm(dy, cw(prm["o_w"]), dO, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
-        _wgrad(dy, O, prm["o_w"].grad, d, d, Mq, d, d, 1.0, prm["o_b"].grad)
+            K.gemm(dy, cw(prm["o_w"]), dO, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True, rows=qr)
+        _wgrad(dy, O, prm["o_w"].grad, d, d, Mq, d, d, 1.0, prm["o_b"].grad, rows=qr)
         _ready(prm["o_w"], prm["o_b"])
         if ctx.self_attn:
             dqkv = torch.empty(Mq, 3 * d, dtype=dt, device=dev)
@@ -1217,7 +1245,7 @@ class AttentionFn(torch.autograd.Function):
                          prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a,
                          dbd_band_only=rel, pos_pt=pt[0] if pt is not None else None, pt_ld=pt[1] if pt is not None else 0,
                          dpos_u=prm["pos_u"].grad.view(-1) if pt is not None else None,
-                         dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv)
+                         dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv, q_rows=qr, k_rows=kr)
         glue_done = False
         if rel and _RELPOS_GLUE and pt is None and dt == torch.bfloat16 and dk == 64 and Tq <= 256 and ldq % 4 == 0 and _arm_backward_end():
             # everything behind dbd in ONE pass over it (csrc/relpos_glue.hip): the (Q+v) branch added into dq, both bias
@@ -1227,13 +1255,15 @@ class AttentionFn(torch.autograd.Function):
             dp = _posq_slot(n_pos, d, dev, zero=False)
             slot = len(_POSQ["parts"]) if (_FOLD_DEFER and len(_POSQ["parts"]) < _FOLD_CAP) else None
             part = K.relpos_glue(dBD, ldB, p, d, qv, dq, Tq * ldq, ldq, ws, ws[d:], dp, B, H, Tq, dk, replicas=K.LN_REPLICAS,
-                                 replica_stride=2 * d, defer_slot=slot)
+                                 replica_stride=2 * d, defer_slot=slot, rows=qr)
             if slot is not None:
                 _POSQ["parts"].append((part, dp, (B, H, Tq, dk)))
             _LNQ["entries"].append((ws, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), d))
             _POSQ["entries"].append((dp, _pos_table_f32(pos_tab), prm["pos_w"].grad, n_pos, d))
             _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
             glue_done = True
+        if rel and not glue_done and qr is not None:
+            raise NotImplementedError("packed rows: the relative-position backward runs through s2t_relpos_glue only")
         if rel and not glue_done:
             fuse_glue = dt == torch.bfloat16 and d == 256 and ldq % 8 == 0
             # the (Q+v) branch, the add into dq and both bias gradients in one band-limited launch (s2t_relpos_dqv) when the
@@ -1283,25 +1313,26 @@ class AttentionFn(torch.autograd.Function):
             gw = fused_grad([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
             gb = prm["q_b"].grad.as_strided((3 * d,), (1,))
             wqkv = fused([prm["q_w"], prm["k_w"], prm["v_w"]], 3 * d, d)
-            _wgrad(dqkv, xq, gw, 3 * d, d, Mq, 3 * d, d, 1.0, gb)
+            _wgrad(dqkv, xq, gw, 3 * d, d, Mq, 3 * d, d, 1.0, gb, rows=qr)
             if ctx.ln is not None:  # projection dgrad + the LayerNorm's backward in one row-block launch
                 ln_g, ln_b, up_drop = ctx.ln
                 x_pre, ln_mean, ln_rstd = ctx.ln_saved
-                dx_ln = _dgrad_ln_backward(dqkv, prm["q_w"], 3 * d, x_pre, ln_g, ln_b, ln_mean, ln_rstd, None, 0, dres, up_drop)
+                dx_ln = _dgrad_ln_backward(dqkv, prm["q_w"], 3 * d, x_pre, ln_g, ln_b, ln_mean, ln_rstd, None, 0, dres, up_drop,
+                                           rows=qr)
             if dx_ln is None:
                 dxq = torch.empty(Mq, d, dtype=dt, device=dev)
-                K.gemm(dqkv, wqkv, dxq, M=Mq, N=d, K=3 * d, lda=3 * d, ldb=d, ldc=d, b_kmajor=True)
+                K.gemm(dqkv, wqkv, dxq, M=Mq, N=d, K=3 * d, lda=3 * d, ldb=d, ldc=d, b_kmajor=True, rows=qr)
             dxkv = None
         else:
-            _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d, 1.0, prm["q_b"].grad)
+            _wgrad(dq, xq, prm["q_w"].grad, d, d, Mq, d, d, 1.0, prm["q_b"].grad, rows=qr)
             if ctx.ln is not None:  # query-projection dgrad + the LayerNorm's backward in one row-block launch
                 ln_g, ln_b, up_drop = ctx.ln
                 x_pre, ln_mean, ln_rstd = ctx.ln_saved
-                dx_ln = _dgrad_ln_backward(dq, prm["q_w"], d, x_pre, ln_g, ln_b, ln_mean, ln_rstd, None, 0, dres, up_drop)
-            dxq = _dgrad_rowblock(dq, prm["q_w"], d) if (d == 256 and dx_ln is None) else None
+                dx_ln = _dgrad_ln_backward(dq, prm["q_w"], d, x_pre, ln_g, ln_b, ln_mean, ln_rstd, None, 0, dres, up_drop, rows=qr)
+            dxq = _dgrad_rowblock(dq, prm["q_w"], d, rows=qr) if (d == 256 and dx_ln is None) else None
             if dxq is None and dx_ln is None:
                 dxq = torch.empty(Mq, d, dtype=dt, device=dev)
-                K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
+                K.gemm(dq, cw(prm["q_w"]), dxq, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True, rows=qr)
             if ctx.kv_slot is not None:
                 # weight and memory gradients of the k | v projections: CrossKVFn.backward, once for the stack.  The layer
                 # that completes the shared buffer hands it on as the gradient of kv_all; the others contribute nothing
@@ -1316,24 +1347,24 @@ class AttentionFn(torch.autograd.Function):
                     if dx_ln is None:
                         ln_g, ln_b, up_drop = ctx.ln
                         x_pre, ln_mean, ln_rstd = ctx.ln_saved
-                        dx_ln = _ln_backward(x_pre, ln_g, ln_b, dxq, ln_mean, ln_rstd, None, 0, dres, up_drop)
-                    return (dx_ln, None, None) + (None,) * 15 + (dkv_all, None)
-                return (dxq, None, (dres if ctx.has_res else None)) + (None,) * 15 + (dkv_all, None)
+                        dx_ln = _ln_backward(x_pre, ln_g, ln_b, dxq, ln_mean, ln_rstd, None, 0, dres, up_drop, rows=qr)
+                    return (dx_ln, None, None) + (None,) * 15 + (dkv_all, None, None)
+                return (dxq, None, (dres if ctx.has_res else None)) + (None,) * 15 + (dkv_all, None, None)
             gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
             gb = prm["k_b"].grad.as_strided((2 * d,), (1,))
             wkv = fused([prm["k_w"], prm["v_w"]], 2 * d, d)
-            _wgrad(dkv, xkv, gw, 2 * d, d, Mk, 2 * d, d, 1.0, gb)
+            _wgrad(dkv, xkv, gw, 2 * d, d, Mk, 2 * d, d, 1.0, gb, rows=kr)
             dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
-            K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
+            K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True, rows=kr)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
         if dx_ln is not None:
-            return (dx_ln, None, None) + (None,) * 17
+            return (dx_ln, None, None) + (None,) * 18
         if ctx.ln is not None:
             ln_g, ln_b, up_drop = ctx.ln
             x_pre, ln_mean, ln_rstd = ctx.ln_saved
-            dx = _ln_backward(x_pre, ln_g, ln_b, dxq, ln_mean, ln_rstd, None, 0, dres, up_drop)
-            return (dx, None, None) + (None,) * 17
-        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 17
+            dx = _ln_backward(x_pre, ln_g, ln_b, dxq, ln_mean, ln_rstd, None, 0, dres, up_drop, rows=qr)
+            return (dx, None, None) + (None,) * 18
+        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 18
 
     @staticmethod
     def backward(ctx, dy):
@@ -1422,7 +1453,7 @@ class AttentionFn(torch.autograd.Function):
             dxkv = torch.empty(Mk, d, dtype=dt, device=dev)
             K.gemm(dkv, wkv, dxkv, M=Mk, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
         _ready(prm["q_w"], prm["k_w"], prm["v_w"], prm["q_b"], prm["k_b"], prm["v_b"])
-        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 17
+        return (dxq, dxkv, (dres if ctx.has_res else None)) + (None,) * 18
 
 
 _PT = {}
@@ -1490,16 +1521,16 @@ class CrossKVFn(torch.autograd.Function):
     gradient buffer, which the attention kernels fill column block by column block (AttentionFn, kv_slot)."""
 
     @staticmethod
-    def forward(ctx, mem, prms):
+    def forward(ctx, mem, prms, rows=None):
         Mk, d = mem.shape
         L = len(prms)
         # the layers' [2d, d] weight pairs sit apart in the flat buffer: gather them (L * 256 KiB) into one operand
         w_all = torch.cat([fused([p["k_w"], p["v_w"]], 2 * d, d) for p in prms], 0)
         b_all = torch.cat([fused_master([p["k_b"], p["v_b"]], 2 * d) for p in prms], 0)
         kv_all = torch.empty(Mk, 2 * d * L, dtype=mem.dtype, device=mem.device)
-        K.gemm(mem, w_all, kv_all, M=Mk, N=2 * d * L, K=d, lda=d, ldb=d, ldc=2 * d * L, bias=b_all)
+        K.gemm(mem, w_all, kv_all, M=Mk, N=2 * d * L, K=d, lda=d, ldb=d, ldc=2 * d * L, bias=b_all, rows=rows)
         ctx.save_for_backward(mem, w_all)
-        ctx.prms = prms
+        ctx.prms, ctx.rows = prms, rows
         return kv_all
 
     @staticmethod
@@ -1510,24 +1541,24 @@ class CrossKVFn(torch.autograd.Function):
         for l, prm in enumerate(ctx.prms):
             gw = fused_grad([prm["k_w"], prm["v_w"]], 2 * d, d)
             gb = prm["k_b"].grad.as_strided((2 * d,), (1,))
-            _wgrad(dkv_all[:, 2 * d * l:], mem, gw, 2 * d, d, Mk, 2 * d * L, d, 1.0, gb)
+            _wgrad(dkv_all[:, 2 * d * l:], mem, gw, 2 * d, d, Mk, 2 * d * L, d, 1.0, gb, rows=ctx.rows)
             _ready(prm["k_w"], prm["v_w"], prm["k_b"], prm["v_b"])
         dmem = torch.empty(Mk, d, dtype=mem.dtype, device=mem.device)
-        K.gemm(dkv_all, w_all, dmem, M=Mk, N=d, K=2 * d * L, lda=2 * d * L, ldb=d, ldc=d, b_kmajor=True)
-        return dmem, None
+        K.gemm(dkv_all, w_all, dmem, M=Mk, N=d, K=2 * d * L, lda=2 * d * L, ldb=d, ldc=d, b_kmajor=True, rows=ctx.rows)
+        return dmem, None, None
 
 
-def cross_kv(mem, prms, H):
+def cross_kv(mem, prms, H, rows=None):
     """(kv_all, share) for ``attention(..., kv=(kv_all, l, L, share))`` of the L decoder layers, or None where the fused
     attention kernels (which take the strided k / v) do not apply."""
     d = mem.shape[1]
     if not (_CROSS_KV and mem.is_cuda and len(prms) > 1 and _use_fused_attention(mem.dtype, d // H) and mem.is_contiguous()):
         return None
-    return CrossKVFn.apply(mem, prms), {}
+    return CrossKVFn.apply(mem, prms, rows if K.rows_geom(rows) is not None else None), {}
 
 
 def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False, kind="abs", pos_tab=None,
-              p_attn=0.0, p_out=0.0, training=False, ln=None, pos_p=None, kv=None):
+              p_attn=0.0, p_out=0.0, training=False, ln=None, pos_p=None, kv=None, q_rows=None):
     """``ln`` = (gamma, beta) of the LayerNorm in front of a SELF-attention block: ``xq`` is then the block input before
     that LayerNorm and doubles as the residual (``residual`` must be None).  Where the row-block projection kernel applies
     the LayerNorm rides in its prologue; otherwise it runs as its own kernel first."""
@@ -1536,9 +1567,9 @@ def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False,
         assert xkv is None and residual is None
         d = xq.shape[1]
         if not (_use_fused_attention(xq.dtype, d // H) and _rb_ok(xq, 3 * d)):
-            y, xr = layer_norm(xq, ln[0], ln[1], fork=True)
+            y, xr = layer_norm(xq, ln[0], ln[1], fork=True, rows=q_rows if kv is not None else key_lens)
             return attention(y, None, xr, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab, p_attn, p_out, training,
-                             pos_p=pos_p, kv=kv)
+                             pos_p=pos_p, kv=kv, q_rows=q_rows)
     drop_a = DROPOUT.next(p_attn if training else 0.0, xq.device)
     drop_o = DROPOUT.next(p_out if training else 0.0, xq.device)
     lg, lb = ln if ln is not None else (None, None)
@@ -1547,10 +1578,10 @@ def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False,
     if kv is not None:  # pre-projected keys / values of the whole decoder stack (cross_kv)
         kv_all, l, L, share = kv
         return _tag_drop(AttentionFn.apply(xq, None, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
-                                           torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p, kv_all, (l, L, share)),
-                         drop_o)
+                                           torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p, kv_all, (l, L, share),
+                                           q_rows), drop_o)
     return _tag_drop(AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
-                                       torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p), drop_o)
+                                       torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p, None, None, q_rows), drop_o)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1637,8 +1668,9 @@ class ConvModuleFn(torch.autograd.Function):
             ctx.ln = (ln_g, ln_b, getattr(x_pre, "_s2t_drop_o", None))
             ctx.ln_saved = (x_pre, ln_mean, ln_rstd)
         else:
-            K.gemm(x, w1, g, M=M, N=2 * d, K=d, lda=d, ldb=d, ldc=d, act="glu", preact=z, ldp=2 * d)
+            K.gemm(x, w1, g, M=M, N=2 * d, K=d, lda=d, ldb=d, ldc=d, act="glu", preact=z, ldp=2 * d, rows=lens)
         scale = shift = None
+        packed = K.rows_geom(lens) is not None  # (s2t_amd/rows.py: utterance b's frames and halo rows from cu[b])
         wd = prm["dw_w"].data.view(d, Kw)
         a = torch.empty(M, d, dtype=dt, device=dev)
         D = mean = rstd = None
@@ -1647,7 +1679,9 @@ class ConvModuleFn(torch.autograd.Function):
             shift = torch.empty(d, dtype=torch.float32, device=dev)
             D = torch.empty(M, d, dtype=dt, device=dev)
             stats = torch.empty(K.dwconv_stat_partials(B, T), 2, d, dtype=torch.float32, device=dev)
-            K.dwconv_fwd(g, wd, D, B, T, d, Kw, stats=stats)
+            # (packed batch: the statistics cover the utterances' frames and halo rows; the padded frames behind them are zero
+            # in the reference and add nothing to either sum, the divisor stays B * T)
+            K.dwconv_fwd(g, wd, D, B, T, d, Kw, stats=stats, lens=lens if packed else None)
             mean = torch.empty(d, dtype=torch.float32, device=dev)
             rstd = torch.empty(d, dtype=torch.float32, device=dev)
             K.bn_finalize(stats, M, prm["bn_w"].data, prm["bn_b"].data, bn_buf["running_mean"], bn_buf["running_var"],
@@ -1697,11 +1731,12 @@ class ConvModuleFn(torch.autograd.Function):
         dres = dy.contiguous()
         dy = _drop_rows(dres, ctx.drop_o)
         # pw2 (a's padded rows are zero, so the weight gradient needs no extra mask; dA's are zeroed in bn_act_bwd)
-        dA = _dgrad_rowblock(dy, prm["pw2_w"], d) if d == 256 else None
+        rows = ctx.lens if K.rows_geom(ctx.lens) is not None else None
+        dA = _dgrad_rowblock(dy, prm["pw2_w"], d, rows=rows) if d == 256 else None
         if dA is None:
             dA = torch.empty(M, d, dtype=dt, device=dev)
-            K.gemm(dy, cw(prm["pw2_w"]).view(d, d), dA, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True)
-        _wgrad(dy, a, prm["pw2_w"].grad.view(d, d), d, d, M, d, d)
+            K.gemm(dy, cw(prm["pw2_w"]).view(d, d), dA, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_kmajor=True, rows=rows)
+        _wgrad(dy, a, prm["pw2_w"].grad.view(d, d), d, d, M, d, d, rows=rows)
         # here dy rows of padded frames must not reach pw2's weight gradient: a is zero there -> contributes nothing
         sums = torch.empty(2 * d, dtype=torch.float32, device=dev)
         wd = prm["dw_w"].data.view(d, Kw)
@@ -1718,6 +1753,8 @@ class ConvModuleFn(torch.autograd.Function):
             if slot is not None:
                 _DWQ["entries"].append((ws_dw, dwg, rows_dw, d * Kw))
         else:
+            if rows is not None:
+                raise NotImplementedError("packed rows: the convolution module's backward runs through s2t_conv_bwd_fused only")
             dD = torch.empty(M, d, dtype=dt, device=dev)
             K.bn_act_bwd(D, dA, dD, scale, shift, mean, rstd, sums, M, ctx.act, M, d, ctx.lens, T,
                          dgamma=prm["bn_w"].grad, dbeta=prm["bn_b"].grad)
@@ -1725,7 +1762,7 @@ class ConvModuleFn(torch.autograd.Function):
             K.dwconv_fwd(dD, wd, dG, B, T, d, Kw, flip=True)
             K.dwconv_bwd_weight(g, dD, prm["dw_w"].grad.view(d, Kw), B, T, d, Kw)
             K.glu_bwd(z, dG, dZ, M, d)
-        _wgrad(dZ, x, prm["pw1_w"].grad.view(2 * d, d), 2 * d, d, M, 2 * d, d)
+        _wgrad(dZ, x, prm["pw1_w"].grad.view(2 * d, d), 2 * d, d, M, 2 * d, d, rows=rows)
         _ready(prm["pw1_w"], prm["dw_w"], prm["bn_w"], prm["bn_b"], prm["pw2_w"])
         if ctx.ln is not None:
             ln_g, ln_b, up_drop = ctx.ln
@@ -1734,7 +1771,7 @@ class ConvModuleFn(torch.autograd.Function):
             if dxp is not None:
                 return (dxp, None) + (None,) * 12
         dx = torch.empty(M, d, dtype=dt, device=dev)
-        K.gemm(dZ, cw(prm["pw1_w"]).view(2 * d, d), dx, M=M, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True)
+        K.gemm(dZ, cw(prm["pw1_w"]).view(2 * d, d), dx, M=M, N=d, K=2 * d, lda=2 * d, ldb=d, ldc=d, b_kmajor=True, rows=rows)
         if ctx.ln is not None:
             ln_g, ln_b, up_drop = ctx.ln
             x_pre, ln_mean, ln_rstd = ctx.ln_saved
@@ -1999,7 +2036,7 @@ class CTCLossFn(torch.autograd.Function):
     stay ordered on it, and the caller must ``join_side_streams()`` before it consumes the returned loss."""
 
     @staticmethod
-    def forward(ctx, logits, B, T, targets, tgt_lens, in_lens, blank, side):
+    def forward(ctx, logits, B, T, targets, tgt_lens, in_lens, blank, side, rows=None):
         V = logits.shape[1]
         dev = logits.device
         S = targets.shape[1]
@@ -2014,8 +2051,8 @@ class CTCLossFn(torch.autograd.Function):
         out = torch.empty((), dtype=torch.float32, device=dev)
 
         def run():
-            K.argmax_lse(logits, ld, B * T, V, None, None, lse)
-            K.ctc_loss_fwd(logits, ld, B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll)
+            K.argmax_lse(logits, ld, B * T, V, None, None, lse, bound=rows)
+            K.ctc_loss_fwd(logits, ld, B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, rows=rows)
             torch.nan_to_num(nll, nan=float("nan"), posinf=0.0, out=clean)  # zero_infinity
             torch.sum(clean, dim=0, out=out)
 
@@ -2031,6 +2068,7 @@ class CTCLossFn(torch.autograd.Function):
             run()
         ctx.save_for_backward(logits, lse, alpha, beta, nll, targets, tgt_lens, in_lens)
         ctx.dims = (B, T, V, S, Lmax, blank)
+        ctx.rows = rows
         return out
 
     @staticmethod
@@ -2040,12 +2078,14 @@ class CTCLossFn(torch.autograd.Function):
         grad = torch.empty(B * T, _pad8(V), dtype=logits.dtype, device=logits.device)[:, :V]
         gs = g.detach().reshape(1).float().contiguous()  # upstream gradient of the summed loss, stays on the device
         K.ctc_loss_bwd(logits, logits.stride(0), B, T, V, lse, targets, S, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll,
-                       1.0, grad, grad.stride(0), gscale_dev=gs)
-        return grad, None, None, None, None, None, None, None
+                       1.0, grad, grad.stride(0), gscale_dev=gs, rows=ctx.rows)
+        return grad, None, None, None, None, None, None, None, None
 
 
-def ctc_loss(logits, B, T, targets, tgt_lens, in_lens, blank=0, side=False):
-    return CTCLossFn.apply(logits, B, T, targets, tgt_lens, in_lens, blank, bool(side))
+def ctc_loss(logits, B, T, targets, tgt_lens, in_lens, blank=0, side=False, rows=None):
+    """``rows``: the lengths tensor of a packed batch (s2t_amd/rows.py) whose rows ``logits`` holds."""
+    return CTCLossFn.apply(logits, B, T, targets, tgt_lens, in_lens, blank, bool(side),
+                           rows if K.rows_geom(rows) is not None else None)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -11,6 +11,50 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# ---- packed rows (include/s2t_hip.h, "Packed rows"; geometry object: s2t_amd/rows.py) ----------------------------------
+# A lengths tensor of a packed batch carries its geometry as ``lens._pk`` (row map, cu, ...).  Wherever a wrapper takes a
+# (lens, T) pair it hands the kernels the row map instead; ``rows`` (a lengths tensor as well) names the batch for launches
+# that have no mask of their own and only need the live-row bound.
+ROWS_PACKED, ROWS_BOUND = -1, -2
+
+
+def rows_geom(lens):
+    return getattr(lens, "_pk", None) if lens is not None else None
+
+
+def _mask(lens, T, rows=None):
+    """(pointer, T) of a (lens, T) argument pair: the uniform layout, the row map of a packed batch, or its bound only."""
+    g = rows_geom(lens)
+    if g is not None:
+        return g.map_ptr, ROWS_PACKED
+    if lens is not None:
+        assert lens.dtype == torch.int32
+        return lens.data_ptr(), int(T)
+    g = rows_geom(rows)
+    if g is not None:
+        return g.map_ptr, ROWS_BOUND
+    return None, 0
+
+
+def _cu(lens):
+    g = rows_geom(lens)
+    return g.cu.data_ptr() if g is not None else None
+
+
+def _live(rows):
+    g = rows_geom(rows)
+    return g.map_ptr - 4 if g is not None else None
+
+
+def pack_rows(src, out, lens, to_packed=True):
+    """s2t_pack_rows: padded [B*T, C] -> packed rows (or back: ``out`` zero-filled by the caller) of the batch ``lens`` names."""
+    g = rows_geom(lens)
+    L.require_cuda(src, out)
+    assert src.dtype == out.dtype and src.is_contiguous() and out.is_contiguous() and src.shape == out.shape == (g.M, src.shape[1])
+    _call("s2t_pack_rows", L.dtype_id(src.dtype), src.data_ptr(), out.data_ptr(), g.map_ptr, g.M, g.T, src.shape[1],
+          int(bool(to_packed)))
+
+
 # Optional per-launch timing of the GEMM symbols (bench.py's roofline leg): when a list is installed here every
 # s2t_gemm launch is bracketed by HIP events on the launch stream and (symbol, flops, ev0, ev1) is appended.
 GEMM_PROFILE = None
@@ -32,7 +76,7 @@ def gemm(
     preact: Optional[torch.Tensor] = None, ldp=0, p_s=(0, 0),
     dact_z: Optional[torch.Tensor] = None, ldz=0, dact=None,
     row_lens: Optional[torch.Tensor] = None, row_T=0, split_k=1, c_atomic=False,
-    colsum_a: Optional[torch.Tensor] = None, drop=None, splitk_workspace=True,
+    colsum_a: Optional[torch.Tensor] = None, drop=None, splitk_workspace=True, rows=None,
 ):
     """Raw s2t_gemm call: C = epilogue(A_op[M,K] @ B_op[K,N]); see include/s2t_hip.h."""
     L.require_cuda(A, B, out, bias, residual, preact, dact_z, row_lens)
@@ -63,9 +107,7 @@ def gemm(
     a.dact_z, a.ldz, a.dact = _ptr(dact_z), ldz, L.ACT_IDS[dact]
     if dact_z is not None:
         assert dact_z.dtype == out.dtype
-    a.row_lens, a.row_T = _ptr(row_lens), row_T
-    if row_lens is not None:
-        assert row_lens.dtype == torch.int32
+    a.row_lens, a.row_T = _mask(row_lens, row_T, rows)
     a.split_k = split_k
     a.c_atomic = int(c_atomic)
     a.colsum_a = _ptr(colsum_a)
@@ -179,7 +221,7 @@ def ffn_z_rows(M):
 
 def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=None, ln_eps=1e-5, end_ln=None, y_ln=None,
                   end_stats=None, end_lens=None, end_T=0, x_ln=None, ln_stats=None, z=None, h=None, drop_h=None,
-                  drop_o=None, z_tiled_ok=False):
+                  drop_o=None, z_tiled_ok=False, rows=None):
     """s2t_ffn_fused_fwd (include/s2t_hip.h): ``ln`` / ``end_ln`` = (gamma, beta) fp32 of the LayerNorm in front of /
     behind the block; ``ln_stats`` / ``end_stats`` = (mean, rstd) outputs; drops = (p, seed tensor, site) or None.
     ``z_tiled_ok``: z has ``ffn_z_rows(M)`` rows and may be written in the tiled layout; returns True when it was."""
@@ -197,9 +239,8 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
         a.eln_gamma, a.eln_beta, a.y_ln = end_ln[0].data_ptr(), end_ln[1].data_ptr(), y_ln.data_ptr()
         if end_stats is not None:
             a.eln_mean, a.eln_rstd = end_stats[0].data_ptr(), end_stats[1].data_ptr()
-        if end_lens is not None:
-            assert end_lens.dtype == torch.int32
-            a.eln_lens, a.eln_T = end_lens.data_ptr(), end_T
+    # (a packed batch's row map also travels without a trailing LayerNorm: it bounds the launch to the live rows)
+    a.eln_lens, a.eln_T = _mask(end_lens if end_ln is not None else None, end_T, rows if rows is not None else end_lens)
     a.x_ln = _ptr(x_ln)
     if ln_stats is not None:
         a.ln_mean, a.ln_rstd = ln_stats[0].data_ptr(), ln_stats[1].data_ptr()
@@ -230,7 +271,7 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
     return tiled
 
 
-def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=None, end=None, z_tiled=False):
+def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=None, end=None, z_tiled=False, rows=None):
     """s2t_ffn_fused_bwd (include/s2t_hip.h): dz = alpha * drop_h((dy W2) * act'(z)), dxn = dz W1, from the transposed
     weight copies ``w2t`` [F, 256] and ``w1t`` [256, F].  ``ln`` = dict(x, gamma, mean, rstd, ws, dx[, dres, dx_drop, drop])
     adds the backward of the block's leading LayerNorm (``dxn`` may then be None)."""
@@ -259,12 +300,14 @@ def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=N
             a.dx_drop, a.up_drop_p, a.up_drop_site, a.drop_seed = ln["dx_drop"].data_ptr(), float(dr[0]), int(dr[2]), dr[1].data_ptr()
     if end is not None:  # dict(y, gamma, mean, rstd, ws, dres[, lens, T, dy, drop]): trailing LayerNorm's backward in front
         a.end_y, a.end_gamma, a.end_mean, a.end_rstd = (end[k].data_ptr() for k in ("y", "gamma", "mean", "rstd"))
-        a.end_lens, a.end_T = _ptr(end.get("lens")), int(end.get("T") or 0)
+        a.end_lens, a.end_T = _mask(end.get("lens"), int(end.get("T") or 0), rows)
         a.end_ws, a.end_replicas, a.dres_out = end["ws"].data_ptr(), LN_REPLICAS, end["dres"].data_ptr()
         if end.get("dy") is not None:
             dr = end["drop"]
             assert a.drop_seed is None or a.drop_seed == dr[1].data_ptr()
             a.dy_out, a.drop_o_p, a.drop_o_site, a.drop_seed = end["dy"].data_ptr(), float(dr[0]), int(dr[2]), dr[1].data_ptr()
+    if end is None:
+        a.end_lens, a.end_T = _mask(None, 0, rows)  # packed batch: the live-row bound
     _ffn_pair_ws(a, M, dy.device)
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -278,7 +321,7 @@ def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=N
     L.check(L.lib().s2t_ffn_fused_bwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_bwd")
 
 
-def rowblock_dgrad(dy, wt, *, dxn=None, ln=None):
+def rowblock_dgrad(dy, wt, *, dxn=None, ln=None, rows=None):
     """s2t_rowblock_dgrad (include/s2t_hip.h): dxn = dy @ W from the transposed weight ``wt`` [256, K]; ``ln`` = dict(x, gamma,
     mean, rstd, ws, dx[, dres, lens, T, dx_drop, drop]) adds the backward of the LayerNorm in front of the projection."""
     L.require_cuda(dy, wt, dxn)
@@ -292,11 +335,13 @@ def rowblock_dgrad(dy, wt, *, dxn=None, ln=None):
         assert x.shape == (M, 256) and dx.shape == (M, 256) and x.is_contiguous() and dx.is_contiguous()
         assert ln["ws"].numel() >= LN_REPLICAS * 2 * 256
         a.ln_x, a.ln_gamma, a.ln_mean, a.ln_rstd = x.data_ptr(), ln["gamma"].data_ptr(), ln["mean"].data_ptr(), ln["rstd"].data_ptr()
-        a.ln_lens, a.ln_T = _ptr(ln.get("lens")), int(ln.get("T") or 0)
+        a.ln_lens, a.ln_T = _mask(ln.get("lens"), int(ln.get("T") or 0), rows)
         a.dres, a.ln_ws, a.ln_replicas, a.dx = _ptr(ln.get("dres")), ln["ws"].data_ptr(), LN_REPLICAS, dx.data_ptr()
         if ln.get("dx_drop") is not None:
             dr = ln["drop"]
             a.dx_drop, a.up_drop_p, a.up_drop_site, a.drop_seed = ln["dx_drop"].data_ptr(), float(dr[0]), int(dr[2]), dr[1].data_ptr()
+    else:
+        a.ln_lens, a.ln_T = _mask(None, 0, rows)  # packed batch: the live-row bound
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -336,7 +381,8 @@ def rowblock_supported(x, N, act=None):
 
 
 def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual=None, ldr=0, preact=None, ldp=0, ln=None,
-                  ln_eps=1e-5, ln_lens=None, ln_T=0, x_ln=None, ln_stats=None, row_lens=None, row_T=0, drop=None, pre=None, conv=None):
+                  ln_eps=1e-5, ln_lens=None, ln_T=0, x_ln=None, ln_stats=None, row_lens=None, row_T=0, drop=None, pre=None, conv=None,
+                  rows=None):
     """s2t_rowblock_gemm (include/s2t_hip.h): out = epilogue(LN(x) @ w[:N]^T); ``ln`` = (gamma, beta) or None;
     ``pre`` = (scale, shift, act): a per-column affine + activation in place of the LayerNorm (masked by ln_lens / ln_T);
     ``conv`` = (taps fp32 [256, 15], frames per utterance[, running_mean, running_var, eps]): the 15-tap depthwise
@@ -348,22 +394,19 @@ def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual
     a.ln_eps = ln_eps
     if ln is not None:
         a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
-        if ln_lens is not None:
-            assert ln_lens.dtype == torch.int32
-            a.ln_lens, a.ln_T = ln_lens.data_ptr(), ln_T
+        a.ln_lens, a.ln_T = _mask(ln_lens, ln_T)
         a.x_ln = _ptr(x_ln)
         if ln_stats is not None:
             a.ln_mean, a.ln_rstd = ln_stats[0].data_ptr(), ln_stats[1].data_ptr()
     elif pre is not None:
         assert pre[0].dtype == torch.float32 and pre[1].dtype == torch.float32
         a.pre_scale, a.pre_shift, a.pre_act = pre[0].data_ptr(), pre[1].data_ptr(), L.ACT_IDS[pre[2]]
-        if ln_lens is not None:
-            assert ln_lens.dtype == torch.int32
-            a.ln_lens, a.ln_T = ln_lens.data_ptr(), ln_T
+        a.ln_lens, a.ln_T = _mask(ln_lens, ln_T)
         a.x_ln = _ptr(x_ln)
         if conv is not None:
             assert conv[0].dtype == torch.float32 and conv[0].is_contiguous() and tuple(conv[0].shape) == (256, 15)
-            a.conv_w, a.conv_T = conv[0].data_ptr(), int(conv[1])
+            # (packed batch: the utterance of every window row comes from the row map)
+            a.conv_w, a.conv_T = conv[0].data_ptr(), ROWS_PACKED if rows_geom(ln_lens) is not None else int(conv[1])
             if len(conv) > 2:  # (running_mean, running_var, eps): pre[0] / pre[1] are the BatchNorm's gamma / beta
                 a.bn_mean, a.bn_var, a.bn_eps = conv[2].data_ptr(), conv[3].data_ptr(), float(conv[4])
     assert w.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
@@ -372,9 +415,7 @@ def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual
     a.preact, a.ldp = _ptr(preact), ldp
     a.out, a.ldc = out.data_ptr(), ldc
     a.alpha = alpha
-    if row_lens is not None:
-        assert row_lens.dtype == torch.int32
-        a.row_lens, a.row_T = row_lens.data_ptr(), row_T
+    a.row_lens, a.row_T = _mask(row_lens, row_T, rows)
     a.residual, a.ldr = _ptr(residual), ldr
     if drop is not None and drop[0] > 0:
         a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), drop[1].data_ptr(), int(drop[2])
@@ -396,10 +437,12 @@ def _call(name, *args):
     L.check(getattr(L.lib(), name)(*args, L.stream_ptr()), name)
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, row_lens=None, row_T=0):
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps=1e-5, row_lens=None, row_T=0, bound=None):
+    """``bound``: lengths tensor of a packed batch when there is no mask (only the live rows are normalised)."""
     L.require_cuda(x, y)
+    lp, lt = _mask(row_lens, row_T, bound)
     _call("s2t_layernorm_fwd", L.dtype_id(x.dtype), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-          _ptr(mean), _ptr(rstd), rows, cols, eps, _ptr(row_lens), row_T)
+          _ptr(mean), _ptr(rstd), rows, cols, eps, lp, lt)
 
 
 LN_REPLICAS = 32
@@ -429,7 +472,7 @@ def _workspace(tag, n, device):
 
 
 def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_lens=None, row_T=0, dres=None, ws=None,
-                  dx_drop=None, drop=None):
+                  dx_drop=None, drop=None, bound=None):
     """``ws`` given and ``dgamma is None``: leave the partial sums in ``ws`` for layernorm_fold.
     ``dx_drop`` + ``drop`` = (p, seed tensor, site): also write dropout(dx) under that mask (bf16, cols == 256)."""
     if ws is None:
@@ -437,7 +480,7 @@ def layernorm_bwd(x, gamma, dy, mean, rstd, dx, dgamma, dbeta, rows, cols, row_l
     p, seed, site = (float(drop[0]), drop[1].data_ptr(), int(drop[2])) if dx_drop is not None else (0.0, None, 0)
     _call("s2t_layernorm_bwd", L.dtype_id(x.dtype), x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), mean.data_ptr(),
           rstd.data_ptr(), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), LN_REPLICAS, rows, cols,
-          _ptr(row_lens), row_T, _ptr(dres), _ptr(dx_drop), p, seed, site)
+          *_mask(row_lens, row_T, bound), _ptr(dres), _ptr(dx_drop), p, seed, site)
 
 
 class _LnFoldEntry(C.Structure):
@@ -486,11 +529,14 @@ def bias_add_rows(x, ldx, bias, out, ldo, rows, n):
 
 
 def add_positions(x, tab, lens, rows, T, d, scale=1.0, pos_offset=2):
-    _call("s2t_add_positions", L.dtype_id(x.dtype), x.data_ptr(), _ptr(tab), _ptr(lens), rows, T, d, scale, pos_offset)
+    lp, lt = _mask(lens, T)
+    _call("s2t_add_positions", L.dtype_id(x.dtype), x.data_ptr(), _ptr(tab), lp, rows, lt if lp is not None else T, d, scale,
+          pos_offset)
 
 
 def mask_rows(x, lens, rows, T, d):
-    _call("s2t_mask_rows", L.dtype_id(x.dtype), x.data_ptr(), lens.data_ptr(), rows, T, d)
+    lp, lt = _mask(lens, T)
+    _call("s2t_mask_rows", L.dtype_id(x.dtype), x.data_ptr(), lp, rows, lt, d)
 
 
 def embedding_fwd(tokens, pos, E, tab, out, n, d, scale):
@@ -539,12 +585,12 @@ def sumsq_accum(g, n, out):
 
 def dwconv_fwd(x, w, y, B, T, C, K, flip=False, scale=None, shift=None, act=None, lens=None, stats=None):
     _call("s2t_dwconv_fwd", L.dtype_id(x.dtype), x.data_ptr(), w.data_ptr(), y.data_ptr(), B, T, C, K, int(flip),
-          _ptr(scale), _ptr(shift), L.ACT_IDS[act], _ptr(lens), _ptr(stats))
+          _ptr(scale), _ptr(shift), L.ACT_IDS[act], _ptr(lens), _cu(lens), _ptr(stats))
 
 
 def dwconv_bn_eval_fwd(x, w, y, B, T, C, K, gamma, beta, running_mean, running_var, eps, act, lens=None):
     _call("s2t_dwconv_bn_eval_fwd", L.dtype_id(x.dtype), x.data_ptr(), w.data_ptr(), y.data_ptr(), B, T, C, K, gamma.data_ptr(),
-          beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), float(eps), L.ACT_IDS[act], _ptr(lens))
+          beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), float(eps), L.ACT_IDS[act], _ptr(lens), _cu(lens))
 
 
 def dwconv_bwd_weight(G, dD, dw, B, T, C, K):
@@ -563,7 +609,7 @@ def conv_bwd_fused(D, dA, G, Z, w, scale, shift, mean, rstd, sums, count, act, l
     ws = _scratch("dw_fused" if defer_slot is None else "dw_fused%d" % defer_slot, rows * C * Kw, D.device)
     _call("s2t_conv_bwd_fused", D.data_ptr(), dA.data_ptr(), G.data_ptr(), Z.data_ptr(), w.data_ptr(), scale.data_ptr(),
           shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), float(count), L.ACT_IDS[act], _ptr(lens),
-          dZ.data_ptr(), dw.data_ptr() if defer_slot is None else None, ws.data_ptr(), B, T, C, Kw)
+          _cu(lens), dZ.data_ptr(), dw.data_ptr() if defer_slot is None else None, ws.data_ptr(), B, T, C, Kw)
     return ws, rows
 
 
@@ -579,7 +625,7 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
 
 def bn_act_fwd(D, out, scale, shift, act, rows, C, lens=None, T=0):
     _call("s2t_bn_act_fwd", L.dtype_id(D.dtype), D.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-          L.ACT_IDS[act], rows, C, _ptr(lens), T)
+          L.ACT_IDS[act], rows, C, *_mask(lens, T))
 
 
 def bn_act_bwd(D, dOut, dD, scale, shift, mean, rstd, sums, count, act, rows, C, lens=None, T=0, dgamma=None, dbeta=None):
@@ -587,19 +633,21 @@ def bn_act_bwd(D, dOut, dD, scale, shift, mean, rstd, sums, count, act, rows, C,
     ws = _scratch("bn_bwd", L.lib().s2t_bn_bwd_partials(rows) * 2 * C, D.device)
     _call("s2t_bn_act_bwd", L.dtype_id(D.dtype), D.data_ptr(), dOut.data_ptr(), _ptr(dD), scale.data_ptr(),
           shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), ws.data_ptr(), _ptr(dgamma), _ptr(dbeta),
-          float(count), L.ACT_IDS[act], rows, C, _ptr(lens), T)
+          float(count), L.ACT_IDS[act], rows, C, *_mask(lens, T))
 
 
-def argmax_lse(logits, ld, rows, V, idx=None, top_lp=None, lse=None):
-    _call("s2t_argmax_lse", L.dtype_id(logits.dtype), logits.data_ptr(), ld, rows, V, _ptr(idx), _ptr(top_lp), _ptr(lse))
+def argmax_lse(logits, ld, rows, V, idx=None, top_lp=None, lse=None, bound=None):
+    _call("s2t_argmax_lse", L.dtype_id(logits.dtype), logits.data_ptr(), ld, rows, V, _ptr(idx), _ptr(top_lp), _ptr(lse),
+          _live(bound))
 
 
 def add_colsum2(a, lda, b, ldb, du, dv, rows, n):
     _call("s2t_add_colsum2", L.dtype_id(a.dtype), a.data_ptr(), lda, b.data_ptr(), ldb, du.data_ptr(), dv.data_ptr(), rows, n)
 
 
-def ctc_collapse(idx, top_lp, lens, B, T, blank, out_tokens, out_lens, out_scores):
-    _call("s2t_ctc_collapse", idx.data_ptr(), top_lp.data_ptr(), lens.data_ptr(), B, T, blank, out_tokens.data_ptr(),
+def ctc_collapse(idx, top_lp, lens, B, T, blank, out_tokens, out_lens, out_scores, rows=None):
+    _call("s2t_ctc_collapse", idx.data_ptr(), top_lp.data_ptr(), lens.data_ptr(), _cu(rows if rows is not None else lens), B, T,
+          blank, out_tokens.data_ptr(),
           out_lens.data_ptr(), out_scores.data_ptr())
 
 
@@ -610,17 +658,17 @@ def ls_cross_entropy(logits, ld, rows, V, target, pad_idx, eps, dlogits, ldd, su
 
 
 def ctc_loss_fwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll,
-                 force_emits=None, paths=None):
+                 force_emits=None, paths=None, rows=None):
     _call("s2t_ctc_loss_fwd", L.dtype_id(logits.dtype), logits.data_ptr(), ld, B, T, V, lse.data_ptr(),
           targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), _ptr(beta),
-          Lmax, nll.data_ptr(), _ptr(force_emits), _ptr(paths))
+          Lmax, nll.data_ptr(), _ptr(force_emits), _ptr(paths), _cu(rows))
 
 
 def ctc_loss_bwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll, gscale,
-                 grad, ldg, wrt_logprobs=False, gscale_dev=None):
+                 grad, ldg, wrt_logprobs=False, gscale_dev=None, rows=None):
     _call("s2t_ctc_loss_bwd", L.dtype_id(logits.dtype), logits.data_ptr(), ld, B, T, V, lse.data_ptr(),
           targets.data_ptr(), ldt, tgt_lens.data_ptr(), in_lens.data_ptr(), blank, alpha.data_ptr(), beta.data_ptr(),
-          Lmax, nll.data_ptr(), gscale, _ptr(gscale_dev), grad.data_ptr(), ldg, int(wrt_logprobs))
+          Lmax, nll.data_ptr(), gscale, _ptr(gscale_dev), grad.data_ptr(), ldg, int(wrt_logprobs), _cu(rows))
 
 
 def ctc_backtrace(alpha, paths, tgt_lens, in_lens, B, T, Lmax, states):
@@ -675,23 +723,24 @@ def row_softmax_bwd(p, ldp, dp, lddp, dx, lddx, rows, V, inv_tau=1.0):
 
 
 def attn_fused_fwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, o_sb, o_sr, lse, B, H, Tq, Tk, dk, key_lens, causal, scale,
-                   pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None):
+                   pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None, q_rows=None, k_rows=None):
+    """``q_rows`` / ``k_rows``: lengths tensor of a packed batch on the query / key side (rows of utterance b from cu[b])."""
     assert q.dtype == torch.bfloat16
     dp, ds, dsite = _drop3(drop)
     _call("s2t_attn_fused_fwd", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
           o_sb, o_sr, _ptr(lse), B, H, Tq, Tk, dk, _ptr(key_lens), int(causal), scale, _ptr(pos_p), p_sr, _ptr(pos_u),
-          _ptr(pos_v), dp, ds, dsite)
+          _ptr(pos_v), dp, ds, dsite, _cu(q_rows), _cu(k_rows))
 
 
 def attn_fused_bwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, dO, o_sb, o_sr, lse, delta, dq, dk, dv, dbd, ldb, B, H, Tq,
                    Tk, dkd, key_lens, causal, scale, pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None, dbd_band_only=False,
-                   pos_pt=None, pt_ld=0, dpos_u=None, dpos_v=None, qv_out=None):
+                   pos_pt=None, pt_ld=0, dpos_u=None, dpos_v=None, qv_out=None, q_rows=None, k_rows=None):
     """``pos_pt``: a VIEW starting at position n = 0 of the zero-padded transposed projections (see include/s2t_hip.h)."""
     dp, ds, dsite = _drop3(drop)
     _call("s2t_attn_fused_bwd", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
           dO.data_ptr(), o_sb, o_sr, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _ptr(dbd),
           ldb, B, H, Tq, Tk, dkd, _ptr(key_lens), int(causal), scale, _ptr(pos_p), p_sr, _ptr(pos_u), _ptr(pos_v), dp, ds,
-          dsite, int(dbd_band_only), _ptr(pos_pt), pt_ld, _ptr(dpos_u), _ptr(dpos_v), _ptr(qv_out))
+          dsite, int(dbd_band_only), _ptr(pos_pt), pt_ld, _ptr(dpos_u), _ptr(dpos_v), _ptr(qv_out), _cu(q_rows), _cu(k_rows))
 
 
 def fbank(wave, n_samples, feat, max_frames, win, shift, nfft, window, mel_t, preemph=0.97, remove_dc=True,
@@ -718,7 +767,7 @@ def relpos_dqv(dbd, ldb, pos_pt, pt_ld, dq, dq_sb, dq_sr, dpos_u, dpos_v, B, H, 
 
 
 def relpos_glue(dbd, ldb, pos_p, p_sr, qv, dq, dq_sb, dq_sr, dpos_u, dpos_v, dp, B, H, Tq, dk, replicas=1, replica_stride=0,
-                defer_slot=None):
+                defer_slot=None, rows=None):
     """s2t_relpos_glue: dq += (Q+v) branch, both bias-gradient column sums, and dp (fp32 [2Tq-1, H*dk], overwritten) in one
     pass over dbd.  ``defer_slot`` = k: the per-utterance partial table goes to the k-th scratch table and is returned for a
     later ``relpos_dp_reduce`` over several layers (dp is not written by this call)."""
@@ -729,7 +778,7 @@ def relpos_glue(dbd, ldb, pos_p, p_sr, qv, dq, dq_sb, dq_sr, dpos_u, dpos_v, dp,
     part = _scratch(tag, (B * (2 * Tq - 1) * H * dk + 1) // 2, dbd.device)  # fp32 scratch holding the bf16 partials
     _call("s2t_relpos_glue", dbd.data_ptr(), ldb, pos_p.data_ptr(), p_sr, qv.data_ptr(), dq.data_ptr(), dq_sb, dq_sr,
           dpos_u.data_ptr(), dpos_v.data_ptr(), replicas, replica_stride, part.data_ptr(),
-          dp.data_ptr() if defer_slot is None else None, B, H, Tq, dk)
+          dp.data_ptr() if defer_slot is None else None, B, H, Tq, dk, _cu(rows))
     return part
 
 

@@ -25,6 +25,9 @@ class Ctx:
         self.B, self.T, self.lens, self.dtype = B, T, lens_i32, dtype
         self.pos_tab = pos_tab
         self.mask_layers = mask_layers
+        # packed batch (s2t_amd/rows.py): the lengths tensor carries the geometry; launches without a mask of their own take it
+        # as ``rows`` to stop at the live rows
+        self.rows = lens_i32 if getattr(lens_i32, "_pk", None) is not None else None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -39,10 +42,10 @@ class LayerNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(dim))
         self.eps = eps
 
-    def forward(self, x2d, lens=None, T=0, fork=False):
+    def forward(self, x2d, lens=None, T=0, fork=False, rows=None):
         """``fork=True`` returns ``(LN(x), x)``: use the second value as the residual input of the block (see
         functional.LayerNormFn)."""
-        return Fn.layer_norm(x2d, self.weight, self.bias, lens, T, fork)
+        return Fn.layer_norm(x2d, self.weight, self.bias, lens, T, fork, rows=rows)
 
 
 class Linear(nn.Module):
@@ -54,8 +57,8 @@ class Linear(nn.Module):
         nn.init.xavier_uniform_(self.weight)
         self.bias = nn.Parameter(torch.zeros(out_f)) if bias else None
 
-    def forward(self, x2d, alpha=1.0, residual=None, out_dtype=None):
-        return Fn.linear(x2d, self.weight, self.bias, alpha, residual, out_dtype)
+    def forward(self, x2d, alpha=1.0, residual=None, out_dtype=None, rows=None):
+        return Fn.linear(x2d, self.weight, self.bias, alpha, residual, out_dtype, rows=rows)
 
 
 class _Conv1dK(nn.Module):
@@ -122,11 +125,12 @@ class FeedForwardModule(nn.Module):
         return Fn.ffn(x_ln, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, self.activation_fn, scale,
                       residual, self.dropout1, self.dropout2, self.training)
 
-    def block(self, x, norm, scale, end_norm=None, end_lens=None, end_T=0):
+    def block(self, x, norm, scale, end_norm=None, end_lens=None, end_T=0, rows=None):
         """x + scale * ffn(norm(x)) [-> end_norm]: the whole pre-LN block, one launch when the row-block kernel applies."""
         en = (end_norm.weight, end_norm.bias) if end_norm is not None else None
         return Fn.ffn_block(x, norm.weight, norm.bias, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
-                            self.activation_fn, scale, self.dropout1, self.dropout2, self.training, en, end_lens, end_T)
+                            self.activation_fn, scale, self.dropout1, self.dropout2, self.training, en, end_lens, end_T,
+                            rows=rows)
 
 
 class MultiheadAttention(nn.Module):
@@ -156,12 +160,13 @@ class MultiheadAttention(nn.Module):
         return {"q_w": self.q_proj.weight, "q_b": self.q_proj.bias, "k_w": self.k_proj.weight, "k_b": self.k_proj.bias,
                 "v_w": self.v_proj.weight, "v_b": self.v_proj.bias, "o_w": self.out_proj.weight, "o_b": self.out_proj.bias}
 
-    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False, norm=None, kv=None):
+    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False, norm=None, kv=None, q_rows=None):
         """``norm``: the LayerNorm in front of a self-attention block — ``xq`` is then the un-normalised block input and
-        the residual (pass ``residual=None``).  ``kv``: keys / values projected for the whole stack (Fn.cross_kv)."""
+        the residual (pass ``residual=None``).  ``kv``: keys / values projected for the whole stack (Fn.cross_kv).
+        ``q_rows``: the packed geometry of the QUERY rows of an encoder-decoder attention (key side: ``key_lens``)."""
         return Fn.attention(xq, xkv, residual, self._prm(), self.num_heads, B, Tq, Tk, key_lens, causal, "abs", None,
                             self.attn_dropout, self.out_dropout, self.training,
-                            ln=(norm.weight, norm.bias) if norm is not None else None, kv=kv)
+                            ln=(norm.weight, norm.bias) if norm is not None else None, kv=kv, q_rows=q_rows)
 
 
 class RelPositionMultiHeadedAttention(nn.Module):
@@ -334,7 +339,7 @@ class S2TTransformerEncoderLayer(nn.Module):
         """x: [B*T, d].  ``mask_output``: zero padded frames of the result (the NEXT layer's layer_padding_mask)."""
         B, T, lens = c.B, c.T, c.lens
         if self.macaron_norm is not None:
-            x = self.macaron_ffn.block(x, self.macaron_norm, self.ffn_scale)
+            x = self.macaron_ffn.block(x, self.macaron_norm, self.ffn_scale, rows=c.rows)
         if self.attn_type == "rel_pos":
             x = self.self_attn(x, None, B, T, lens, c.pos_tab, norm=self.self_attn_layer_norm,
                                pos_p=getattr(c, "cur_pos_p", None))
@@ -342,7 +347,7 @@ class S2TTransformerEncoderLayer(nn.Module):
             x = self.self_attn(x, None, None, B, T, T, lens, norm=self.self_attn_layer_norm)
         if self.conv_module is not None:
             x = self.conv_module(x, None, B, T, lens, norm=self.conv_norm)  # conv input mask fused (convolution.py:86-88)
-        x = self.ffn.block(x, self.ffn_norm, self.ffn_scale, self.final_norm, lens if mask_output else None, T)
+        x = self.ffn.block(x, self.ffn_norm, self.ffn_scale, self.final_norm, lens if mask_output else None, T, rows=c.rows)
         if self.final_norm is None and mask_output:
             x = MaskRows.apply(x, lens, T)
         return x
@@ -386,11 +391,11 @@ class CTC(nn.Module):
     def set_infer(self, is_infer, text_post_process, dictionary, path):
         self.infer_decoding, self.dictionary = is_infer, dictionary
 
-    def forward(self, x2d, out_dtype=None):
+    def forward(self, x2d, out_dtype=None, rows=None):
         if self.LayerNorm is not None:
-            x2d = self.LayerNorm(x2d)
+            x2d = self.LayerNorm(x2d, rows=rows)
         x2d = Fn.dropout(x2d, self.dropout_p, self.training)  # ctc_dropout_module (ctc.py:59)
-        return self.ctc_projection(x2d, out_dtype=out_dtype)
+        return self.ctc_projection(x2d, out_dtype=out_dtype, rows=rows)
 
 
 class Adapter(nn.Module):

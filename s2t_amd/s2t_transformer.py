@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import rows as Rows
 from .flat_params import FlatParameters
 from .modules import (CTC, TABLES, Adapter, Conv1dSubsampling, Ctx, LayerNorm, Linear, MaskRows,
                       S2TTransformerEncoderLayer, TransformerDecoderLayer, pae_oracle_mask)
@@ -62,6 +63,8 @@ class S2TTransformerEncoder(nn.Module):
             self.embed_positions = _SinPosHolder()  # keeps the reference's `embed_positions._float_tensor` key
         self.embed_ln = LayerNorm(d) if getattr(args, "encoder_embed_norm", False) else None
         self.layer_padding_mask = bool(getattr(args, "layer_padding_mask", False))
+        # rows kept behind every utterance of a packed batch: the reach of the conv module's depthwise kernel (s2t_amd/rows.py)
+        self._halo = (int(getattr(args, "cnn_module_kernel", 31)) - 1) // 2 if getattr(args, "use_cnn_module", False) else 0
         self.layers = nn.ModuleList([S2TTransformerEncoderLayer(args) for _ in range(args.encoder_layers)])
         self.layer_norm = LayerNorm(d) if args.encoder_normalize_before else None
         self.use_ctc = getattr(args, "ctc_weight", 0) > 0
@@ -154,6 +157,17 @@ class S2TTransformerEncoder(nn.Module):
     def dump(self, fstream, info=""):
         pass
 
+    def _packed_ok(self, dt, B, Tp):
+        """Packed rows where every kernel on the path takes them: the bf16 fused kernels of the recipes' width (d = 256, heads
+        of 64), enough rows for the row-block kernels, no intermediate CTC heads / prediction-aware encoding / compression
+        between the layers (their row-wise pieces still run on padded rows)."""
+        if not Rows.ENABLED or dt != torch.bfloat16 or self.embed_dim != 256:
+            return False
+        h = getattr(self.layers[0].self_attn, "num_heads", None) or getattr(self.layers[0].self_attn, "h", 0)
+        if h * 64 != self.embed_dim or self.inter_ctc_layers or self.compression_layers:
+            return False
+        return B * Tp >= 4096 and Tp <= 65535
+
     # -- forward -------------------------------------------------------------------------------------
     def forward(self, src_tokens, src_lengths=None, **kwargs):
         """src_tokens (B, T, C) float, src_lengths (B,) long -> dict of lists (s2t_transformer.py:2142-2154)."""
@@ -171,10 +185,17 @@ class S2TTransformerEncoder(nn.Module):
             return ln, ln.to(torch.int32), torch.arange(Tp, device=sl.device)[None, :] >= ln[:, None]
 
         lens, lens32, encoder_padding_mask = Fn.batch_memo(("enc_lens", id(self), Tp), (src_lengths,), length_bookkeeping)
-        x = self.subsample(src_tokens, lens32, dt)  # [B*T', d], padded frames zeroed (:1765)
+        x = self.subsample(src_tokens, Rows.detached(lens32), dt)  # [B*T', d], padded frames zeroed (:1765)
+        if self._packed_ok(dt, B, Tp):
+            # Packed rows (s2t_amd/rows.py): from here to the end of the encoder only the frames (and the conv module's halo
+            # rows) are computed; the buffers keep their B * T' rows.  ``lens32`` carries the geometry to every launch.
+            lens32 = Rows.attach(lens32, B, Tp, self._halo)
+            x = Rows.pack(x, lens32)
+        else:
+            lens32 = Rows.detached(lens32)
         c = Ctx(B, Tp, lens32, dt)
         if self.embed_ln is not None:
-            x = self.embed_ln(x)  # :1769
+            x = self.embed_ln(x, rows=c.rows)  # :1769
         if self.attn_type == "rel_pos":
             c.pos_tab = TABLES.get("rel", Tp, d, x.device, dt)  # not added to x (:1777-1778)
             if self.embed_scale != 1.0:
@@ -237,10 +258,25 @@ class S2TTransformerEncoder(nn.Module):
                 elif self.layer_padding_mask and i + 1 < n:
                     x = MaskRows.apply(x, lens32, Tp)
         if self.layer_norm is not None:
-            x = self.layer_norm(x)
+            x = self.layer_norm(x, rows=c.rows)
         if Fn.GRAD_STAGES >= 4:
             x = Fn.grad_stage(x)  # everything behind the encoder output (decoder, CTC head) forms the first gradient stage
         ctc_logit = None
+        packed = None
+        if c.rows is not None:
+            # the reference's T x B x C tensors are materialised only if somebody reads them (Rows.LazyList: zero-filled padded
+            # frames, as the reference's masked tensors hold); the consumers of this package take the packed rows under "packed"
+            rows_ = c.rows
+            logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype, rows=rows_) if self.use_ctc else None
+            packed = {"rows": rows_, "B": B, "T": Tp, "encoder_out": x, "ctc_logit": logit2d}
+            enc_list = Rows.LazyList([lambda: Rows.unpack(x, rows_).view(B, Tp, d).transpose(0, 1)])
+            ctc_list = [] if logit2d is None else Rows.LazyList(
+                [lambda: Rows.unpack(logit2d.contiguous(), rows_).view(B, Tp, -1).transpose(0, 1)])
+            return {
+                "encoder_out": enc_list, "ctc_logit": ctc_list, "inter_ctc_logits": [], "xctc_logit": [],
+                "inter_xctc_logits": [], "encoder_padding_mask": [encoder_padding_mask], "mixup": None,
+                "encoder_embedding": [], "encoder_states": [], "src_tokens": [], "src_lengths": [], "packed": packed,
+            }
         if self.use_ctc:
             logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype)
             ctc_logit = logit2d.view(B, Tp, -1).transpose(0, 1)
@@ -374,15 +410,22 @@ class TransformerDecoderScriptable(nn.Module):
         tab = TABLES.get("sin", self.max_positions() + self.padding_idx + 1, d, dev)
         x = Fn.embedding(tok, pos, self.embed_tokens.weight, tab, self.embed_scale, self.padding_idx)
         x = Fn.dropout(x, float(self.args.dropout or 0.0), self.training)  # dropout_module (transformer.py:1328)
-        mem_tbc = encoder_out["encoder_out"][0]
-        Tm = mem_tbc.shape[0]
-        mem = mem_tbc.transpose(0, 1).contiguous().view(B * Tm, d)
-        (mem_lens,) = Fn.batch_memo(("dec_mem_lens", id(self)), (encoder_out["encoder_padding_mask"][0],),
-                                    lambda m: ((~m).sum(1).to(torch.int32),))
+        pk = encoder_out.get("packed")
+        if pk is not None and pk["B"] == B and Fn._use_fused_attention(pk["encoder_out"].dtype, d // self.layers[0].encoder_attn.num_heads):
+            # the encoder's packed rows (s2t_amd/rows.py) are the memory as they are: the key side of every encoder-decoder
+            # attention reads utterance b's frames from row cu[b]
+            mem, Tm, mem_lens = pk["encoder_out"], pk["T"], pk["rows"]
+        else:
+            mem_tbc = encoder_out["encoder_out"][0]
+            Tm = mem_tbc.shape[0]
+            mem = mem_tbc.transpose(0, 1).contiguous().view(B * Tm, d)
+            (mem_lens,) = Fn.batch_memo(("dec_mem_lens", id(self)), (encoder_out["encoder_padding_mask"][0],),
+                                        lambda m: ((~m).sum(1).to(torch.int32),))
         # reference (:1340-1342): pad KEYS are masked for every query; pad queries still attend
         # k | v of the encoder memory for all layers' encoder-decoder attention in one projection (Fn.cross_kv)
         L = len(self.layers)
-        ckv = Fn.cross_kv(mem, [layer.encoder_attn._prm() for layer in self.layers], self.layers[0].encoder_attn.num_heads)
+        ckv = Fn.cross_kv(mem, [layer.encoder_attn._prm() for layer in self.layers], self.layers[0].encoder_attn.num_heads,
+                          rows=mem_lens)
         for i, layer in enumerate(self.layers):
             x = layer(x, mem, B, U, Tm, self_lens, mem_lens, mem_kv=(ckv[0], i, L, ckv[1]) if ckv is not None else None)
         if self.layer_norm is not None:
@@ -673,6 +716,9 @@ class CTCDecoder:
         net_input = sample["net_input"]
         enc = self.model(src_tokens=net_input["src_tokens"], src_lengths=net_input["src_lengths"])
         has_x = len(enc.get("xctc_logit", [])) > 0
+        pk = enc.get("packed")
+        if pk is not None and not has_x and self.ctc_inter_logit == 0 and pk.get("ctc_logit") is not None:
+            return self._collapse(pk["ctc_logit"], pk["rows"], pk["B"], pk["T"], rows=pk["rows"])  # packed rows (s2t_amd/rows.py)
         logit_tbv = enc["xctc_logit"][0] if has_x else enc["ctc_logit"][0]
         if isinstance(logit_tbv, (list, tuple)):
             logit_tbv = logit_tbv[0]
@@ -696,14 +742,22 @@ class CTCDecoder:
         if logits.stride(1) != 1:
             logits = logits.contiguous()
         lens = (~mask).sum(1).to(torch.int32)
+        return self._collapse(logits, lens, B, Tn)
+
+    def _collapse(self, logits, lens, B, Tn, rows=None):
+        """Row arg-max and CTC collapse of batch-major logit rows ``[B * Tn, V]`` (``rows``: their packed geometry, if any —
+        the frames behind an utterance's end are then not stored: they count as blank and add nothing to the score)."""
+        from . import kernels as K
+
+        V = logits.shape[1]
         dev = logits.device
         idx = torch.empty(B * Tn, dtype=torch.int32, device=dev)
         top = torch.empty(B * Tn, dtype=torch.float32, device=dev)
-        K.argmax_lse(logits, logits.stride(0), B * Tn, V, idx, top, None)
+        K.argmax_lse(logits, logits.stride(0), B * Tn, V, idx, top, None, bound=rows)
         toks = torch.zeros(B, Tn, dtype=torch.int64, device=dev)
         olen = torch.zeros(B, dtype=torch.int32, device=dev)
         osc = torch.zeros(B, dtype=torch.float32, device=dev)
-        K.ctc_collapse(idx, top, lens, B, Tn, self.blank, toks, olen, osc)
+        K.ctc_collapse(idx, top, lens, B, Tn, self.blank, toks, olen, osc, rows=rows)
         toks, olen, osc = toks.cpu(), olen.cpu(), osc.cpu()
         out = []
         for b in range(B):
