@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_BF16 = 2.5e15  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_F32 = 157.3e12
-PMC_FILE = "r03_pmc_traffic.json"
+HBM_PEAK = 8.0e12         # HBM3E, same guide (about 6.3e12 is what a streaming kernel reaches)
+PMC_FILE = "r04_pmc_traffic.json"
 
 
 def csrc_hash():
@@ -38,6 +39,10 @@ def csrc_hash():
                 h.update(name.encode())
                 with open(os.path.join(d, name), "rb") as f:
                     h.update(f.read())
+    # ... and over the compiler flags (a per-file flag changes the binary as a source line does)
+    with open(os.path.join(ROOT, "s2t_amd", "build.py"), "rb") as f:
+        h.update(b"build.py")
+        h.update(f.read())
     return h.hexdigest()
 
 
@@ -148,6 +153,10 @@ def main():
     ap.add_argument("--enc-layers", type=int, default=12)
     ap.add_argument("--dec-layers", type=int, default=6)
     ap.add_argument("--rotate", type=int, default=4, help="distinct synthetic batches cycled through the timed loop (>= 1)")
+    ap.add_argument("--blocks", type=int, default=5, help="the timed region is run this many times (each: exactly --steps steps "
+                    "between barriers); the MEDIAN block is reported, the others as its spread")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented / encoder-forward legs (PMC passes: every "
+                    "profiled launch then belongs to a full training step)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -259,22 +268,30 @@ def main():
 
     for i in range(args.warmup):
         out = step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    torch.cuda.synchronize()
-    frames_timed = sum(frames_rot[(args.warmup + i) % nrot] for i in range(args.steps))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt[0])
+    # The timed region — exactly --steps steps between a barrier + synchronize on both sides, MAX over ranks — is run
+    # --blocks times back to back; the MEDIAN block is the one reported (ms_per_step x steps = that block), the others show
+    # how far a quarter-second sample moves from run to run.
+    blocks = []
+    n_done = args.warmup
+    for _ in range(max(1, args.blocks)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(n_done + i)
+        torch.cuda.synchronize()
+        fr = sum(frames_rot[(n_done + i) % nrot] for i in range(args.steps))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        blocks.append((float(tt[0]), fr))
+        n_done += args.steps
+    order = sorted(range(len(blocks)), key=lambda j: blocks[j][0] / blocks[j][1])
+    dt, frames_timed = blocks[order[len(order) // 2]]
     loss_val = float(out[0])
 
     result = None
@@ -288,7 +305,7 @@ def main():
     passes = []
     wg_mode, Fn._WGQ["mode"] = Fn._WGQ["mode"], ("1" if use_graph else Fn._WGQ["mode"])
     try:
-        for _ in range(3):
+        for _ in range(0 if args.no_roofline else 3):
             K.GEMM_PROFILE = [] if rank == 0 else None
             trainer.train_step(sample, ntok_global)
             torch.cuda.synchronize()
@@ -296,14 +313,19 @@ def main():
     finally:
         Fn._WGQ["mode"] = wg_mode
         K.GEMM_PROFILE = None
-    if rank == 0:
+    if rank == 0 and args.no_roofline:
+        result = {"metric": "speech-frames/sec (enc+dec fwd+bwd+update), 12L Conformer, 1000x80 fbank", "value": frames_timed / dt,
+                  "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                  "note": "--no-roofline: a profiling run, not the bench line"}
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    elif rank == 0:
         same = all(len(q) == len(passes[0]) and all(a[0] == b[0] for a, b in zip(q, passes[0])) for q in passes)
         if not same:  # (never seen: the step is deterministic) fall back to the last pass alone
             passes = passes[-1:]
         prof = []
         for recs in zip(*passes):
             ms = sorted(r[2].elapsed_time(r[3]) for r in recs)[len(recs) // 2]
-            prof.append((recs[0][0], recs[0][1], ms, recs[0][4]))
+            prof.append((recs[0][0], recs[0][1], ms, recs[0][4], recs[0][5]))
         # An empty HIP event pair on this stack already reads ~4.8 us; calibrate that here (the MINIMUM over 64 empty pairs, so that the correction never flatters) and
         # take it off every launch's reading, which then agrees with the rocprofv3 kernel-trace durations.
         empty = []
@@ -315,13 +337,14 @@ def main():
         torch.cuda.synchronize()
         ev_over = min(x0.elapsed_time(x1) for x0, x1 in empty) * 1e-3
         agg = {}
-        for sym, flops, ms, shape in prof:
-            a = agg.setdefault(sym, [0.0, 0.0, 0])
+        for sym, flops, ms, shape, nbytes in prof:
+            a = agg.setdefault(sym, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += max(ms * 1e-3 - ev_over, 1e-7)
             a[2] += 1
+            a[3] += nbytes
         dom = max(agg.items(), key=lambda kv: kv[1][1])
-        sym, (fl, sec, cnt) = dom
+        sym, (fl, sec, cnt, alg_bytes) = dom
         peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
         gemm_total = sum(v[1] for v in agg.values())
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the per-launch figure comes
@@ -329,7 +352,7 @@ def main():
         # — and only while that file was collected from THIS kernel source: it records a hash of s2t_amd/csrc + include/, a
         # figure from another build of the kernels is refused (traffic = null, reason in traffic_note)
         traffic, traffic_note = None, None
-        pmc_tables = {}
+        pmc_tables, pmc = {}, {}
         try:
             with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 pmc = json.load(f)
@@ -345,17 +368,37 @@ def main():
                     traffic_note = "kernel not in profiles/%s" % PMC_FILE
         except (OSError, ValueError, KeyError) as e:
             traffic_note = "profiles/%s unreadable (%s)" % (PMC_FILE, type(e).__name__)
-        roofline = {"bound": "mfma", "kernel": sym, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                    "frac": fl / sec / peak, "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": cnt,
-                    "avg_launch_us": sec / cnt * 1e6, "event_pair_overhead_us": ev_over * 1e6,
-                    "all_gemm_ms_per_step": gemm_total * 1e3,
-                    "all_gemm_tflops": sum(v[0] for v in agg.values()) / gemm_total / 1e12}
+        def bound_of(fl_, by_, sec_):
+            """The roofline that binds a launch BY ITS ALGORITHM: the larger of bytes / HBM peak and flops / MFMA peak
+            (SURVEY.md §8d); achieved / peak / frac in that roofline's unit.  Flops and bytes count the rows a launch really
+            works on (a packed batch's live rows), the weights once."""
+            if by_ / HBM_PEAK > fl_ / peak:
+                return {"bound": "hbm", "achieved": by_ / sec_ / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": by_ / sec_ / HBM_PEAK}
+            return {"bound": "mfma", "achieved": fl_ / sec_ / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl_ / sec_ / peak}
+
+        roofline = dict(bound_of(fl, alg_bytes, sec))
+        roofline.update({"kernel": sym, "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": cnt,
+                         "avg_launch_us": sec / cnt * 1e6, "algorithmic_bytes": alg_bytes / cnt, "flops": fl / cnt,
+                         "mfma_tflops": fl / sec / 1e12, "mfma_frac": fl / sec / peak,
+                         "event_pair_overhead_us": ev_over * 1e6, "all_gemm_ms_per_step": gemm_total * 1e3,
+                         "all_gemm_tflops": sum(v[0] for v in agg.values()) / gemm_total / 1e12})
         # every flavour of the fused feed-forward kernel in the step (training forward and backward are within a few microseconds
-        # of each other: both are reported, not whichever totals more)
-        roofline["ffn_flavours"] = {
-            k: {"launches_per_step": v[2], "avg_launch_us": v[1] / v[2] * 1e6, "achieved": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / peak,
-                "traffic": next((t for kn, t in pmc_tables.items() if k in kn), None)}
-            for k, v in agg.items() if k.startswith("ffn_")}
+        # of each other: both are reported, not whichever totals more), each against the roofline that binds it, with its PMC
+        # traffic beside the algorithmic bytes
+        roofline["ffn_flavours"] = {}
+        for k, v in agg.items():
+            if not k.startswith("ffn_"):
+                continue
+            e = bound_of(v[0], v[3], v[1])
+            tr_ = next((t for kn, t in pmc_tables.items() if k in kn), None)
+            e.update({"launches_per_step": v[2], "avg_launch_us": v[1] / v[2] * 1e6, "algorithmic_bytes": v[3] / v[2],
+                      "mfma_tflops": v[0] / v[1] / 1e12, "mfma_frac": v[0] / v[1] / peak, "traffic": tr_,
+                      "traffic_over_algorithmic": (tr_ / (v[3] / v[2])) if tr_ else None})
+            roofline["ffn_flavours"][k] = e
+        # the whole step against the HBM roofline: every launch's PMC bytes (the table's per-step total) over the step time
+        if pmc_tables and pmc.get("hbm_bytes_per_step"):
+            roofline["hbm_bytes_per_step"] = pmc["hbm_bytes_per_step"]
+            roofline["hbm_frac"] = pmc["hbm_bytes_per_step"] / (dt / args.steps) / HBM_PEAK
         # encoder-forward-only fraction of the MFMA roofline (SURVEY.md §8d: 18.0 MFLOP per input frame for the 12-layer
         # Conformer encoder, 9.7 for the Transformer one; + 1.28 with the CTC head), eval mode, no autograd
         model.eval()
@@ -392,8 +435,12 @@ def main():
         enc_s = e0.elapsed_time(e1) * 1e-3 / 5
         per_frame = (18.0e6 if conformer else 9.7e6) * (args.enc_layers / 12.0) + 1.28e6
         enc_flop = per_frame * args.batch * args.frames
+        real = int(ni["src_lengths"].sum())  # (this rank's batch 0; the padded basis batch x frames is SURVEY.md §8d's)
         roofline["encoder_fwd"] = {"ms": enc_s * 1e3, "tflops": enc_flop / enc_s / 1e12, "frac": enc_flop / enc_s / peak,
-                                   "flop_per_input_frame": per_frame, "hip_graph": enc_graph is not None}
+                                   "flop_per_input_frame": per_frame, "hip_graph": enc_graph is not None,
+                                   "frames_padded": args.batch * args.frames, "frames_real": real,
+                                   "tflops_real_frames": per_frame * real / enc_s / 1e12,
+                                   "frac_real_frames": per_frame * real / enc_s / peak}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, V, conformer)
@@ -415,6 +462,9 @@ def main():
                             "Adam+clip10, dropout %.2f" % (args.arch, args.enc_layers, args.dec_layers, V, args.batch, args.frames, args.dropout),
                 "global_batch": args.batch * world, "frames_per_step": frames_timed / args.steps, "parallelism": "dp%d" % world,
                 "batches_rotated": nrot,
+                "timed_blocks_ms_per_step": [b[0] / args.steps * 1e3 for b in blocks],
+                "timed_blocks_spread": (max(b[0] for b in blocks) - min(b[0] for b in blocks)) / dt,
+                "packed_rows": bool(__import__("s2t_amd.rows", fromlist=["ENABLED"]).ENABLED),
                 "hip_graph": use_graph, "final_loss": loss_val,
                 "grad_allreduce": (("rccl (s2t_allreduce_bucket, %s buckets) inside the step graph, overlapped with backward"
                                     % ("bf16" if ddp is not None and ddp.reduce_dtype == torch.bfloat16 else "fp32"))

@@ -589,10 +589,9 @@ extern "C" int s2t_wgrad_grouped256(const s2t_wgrad_problem* problems_dev, int n
   hipStream_t s = (hipStream_t)stream;
   const int slots = s2t_device_cu_count();  // 128 KiB of LDS per workgroup: one per CU
   dim3 grid(n_items < slots ? n_items : slots), block(512);
-  const char* e = getenv("S2T_WG_NT");
-  const int nt_mode = e ? atoi(e) : 1;
-  const char* e2 = getenv("S2T_WG_STAG");
-  const int stagger = e2 ? atoi(e2) : 0;
+  // (experiment switches, read once: a getenv per launch is host time on the critical path of an eager step)
+  static const int nt_mode = [] { const char* e = getenv("S2T_WG_NT"); return e ? atoi(e) : 1; }();
+  static const int stagger = [] { const char* e = getenv("S2T_WG_STAG"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL(wgrad256_kernel, grid, block, 0, s, problems_dev, reinterpret_cast<const Item*>(items_dev), n_items, ws,
                      nt_mode, stagger);
   hipLaunchKernelGGL(wgrad256_reduce_kernel, dim3(n_tiles, 32), dim3(512), 0, s, problems_dev,

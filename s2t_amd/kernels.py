@@ -46,6 +46,16 @@ def _live(rows):
     return g.map_ptr - 4 if g is not None else None
 
 
+def _prof_rows(M, *cands):
+    """Rows a profiled launch really works on (bench.py's roofline leg only: a device-to-host copy of a packed batch's live
+    row count)."""
+    for c in cands:
+        g = rows_geom(c)
+        if g is not None:
+            return min(M, g.live_rows())
+    return M
+
+
 def pack_rows(src, out, lens, to_packed=True):
     """s2t_pack_rows: padded [B*T, C] -> packed rows (or back: ``out`` zero-filled by the caller) of the batch ``lens`` names."""
     g = rows_geom(lens)
@@ -125,7 +135,10 @@ def gemm(
         e0.record()
         L.check(L.lib().s2t_gemm(C.byref(a), L.stream_ptr()), "s2t_gemm")
         e1.record()
-        GEMM_PROFILE.append((gemm_symbol(a), 2.0 * M * N * K * max(batch, 1), e0, e1, (M, N, K, batch)))
+        Me = _prof_rows(M, row_lens, rows)
+        esz, csz = A.element_size(), out.element_size()
+        nb = max(batch, 1) * ((Me * K + N * K) * esz + Me * (N // 2 if act == "glu" else N) * csz * (2 if residual is not None else 1))
+        GEMM_PROFILE.append((gemm_symbol(a), 2.0 * Me * N * K * max(batch, 1), e0, e1, (Me, N, K, batch), float(nb)))
         return out
     L.check(L.lib().s2t_gemm(C.byref(a), L.stream_ptr()), "s2t_gemm")
     return out
@@ -265,7 +278,11 @@ def ffn_fused_fwd(x, w1, b1, w2, b2, y, *, act, alpha=1.0, residual=None, ln=Non
         e1.record()
         buf = C.create_string_buffer(128)
         L.check(L.lib().s2t_ffn_fused_describe(C.byref(a), buf, 128), "s2t_ffn_fused_describe")
-        GEMM_PROFILE.append((buf.value.decode(), 4.0 * M * F * d, e0, e1, (M, F, d, 1)))  # the name rocprofv3 prints for this launch
+        Me = _prof_rows(M, end_lens, rows)
+        # algorithmic bytes: every row tensor the call reads or writes once (x doubles as the residual), the two weights
+        n256 = 1 + sum(t is not None for t in (y, y_ln, x_ln)) + (1 if residual is not None and residual.data_ptr() != x.data_ptr() else 0)
+        nb = Me * 2 * (n256 * d + F * sum(t is not None for t in (z, h))) + 2 * F * d * 2
+        GEMM_PROFILE.append((buf.value.decode(), 4.0 * Me * F * d, e0, e1, (Me, F, d, 1), float(nb)))  # the name rocprofv3 prints for this launch
         return tiled
     L.check(L.lib().s2t_ffn_fused_fwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_fwd")
     return tiled
@@ -316,7 +333,14 @@ def ffn_fused_bwd(dy, w2t, w1t, z, dz, dxn, *, act, alpha=1.0, drop_h=None, ln=N
         e1.record()
         buf = C.create_string_buffer(128)
         L.check(L.lib().s2t_ffn_fused_bwd_describe(C.byref(a), buf, 128), "s2t_ffn_fused_bwd_describe")
-        GEMM_PROFILE.append((buf.value.decode(), 4.0 * M * F * d, e0, e1, (M, F, d, 1)))
+        Me = _prof_rows(M, end.get("lens") if end is not None else None, rows)
+        n256 = 1 + (dxn is not None)  # dy, dxn
+        if ln is not None:
+            n256 += 2 + (ln.get("dres") is not None) + (ln.get("dx_drop") is not None)  # x, dx, dres, dx_drop
+        if end is not None:
+            n256 += 2 + (end.get("dy") is not None)  # y, dres_out, dy_out
+        nb = Me * 2 * (n256 * d + 2 * F) + 2 * F * d * 2  # + z read, dz written, the two transposed weights
+        GEMM_PROFILE.append((buf.value.decode(), 4.0 * Me * F * d, e0, e1, (Me, F, d, 1), float(nb)))
         return
     L.check(L.lib().s2t_ffn_fused_bwd(C.byref(a), L.stream_ptr()), "s2t_ffn_fused_bwd")
 
@@ -347,7 +371,10 @@ def rowblock_dgrad(dy, wt, *, dxn=None, ln=None, rows=None):
         e0.record()
         L.check(L.lib().s2t_rowblock_dgrad(C.byref(a), L.stream_ptr()), "s2t_rowblock_dgrad")
         e1.record()
-        GEMM_PROFILE.append(("rowblock_dgrad_kernel", 2.0 * M * 256 * Kd, e0, e1, (M, 256, Kd, 1)))
+        Me = _prof_rows(M, ln.get("lens") if ln is not None else None, rows)
+        n256 = 1 if ln is None else 2 + (ln.get("dres") is not None) + (ln.get("dx_drop") is not None)  # dxn | x, dx, dres, dx_drop
+        nb = Me * 2 * (Kd + 256 * n256) + 256 * Kd * 2
+        GEMM_PROFILE.append(("rowblock_dgrad_kernel", 2.0 * Me * 256 * Kd, e0, e1, (Me, 256, Kd, 1), float(nb)))
         return
     L.check(L.lib().s2t_rowblock_dgrad(C.byref(a), L.stream_ptr()), "s2t_rowblock_dgrad")
 
@@ -424,7 +451,10 @@ def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual
         e0.record()
         L.check(L.lib().s2t_rowblock_gemm(C.byref(a), L.stream_ptr()), "s2t_rowblock_gemm")
         e1.record()
-        GEMM_PROFILE.append(("rowblock_gemm_kernel", 2.0 * M * N * d, e0, e1, (M, N, d, 1)))
+        Me = _prof_rows(M, ln_lens, row_lens, rows)
+        nout = N // 2 if act == "glu" else N
+        nb = Me * 2 * (d + nout * (2 if residual is not None else 1) + (N if preact is not None else 0) + (d if x_ln is not None else 0)) + N * d * 2
+        GEMM_PROFILE.append(("rowblock_gemm_kernel", 2.0 * Me * N * d, e0, e1, (Me, N, d, 1), float(nb)))
         return out
     L.check(L.lib().s2t_rowblock_gemm(C.byref(a), L.stream_ptr()), "s2t_rowblock_gemm")
     return out

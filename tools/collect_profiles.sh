@@ -3,6 +3,7 @@
 #   1. the default command under rocprofv3 --kernel-trace --stats           -> <tag>_kernel_stats_default_bench.csv + bench line
 #   2. encoder forward only, 10 eager passes                                 -> <tag>_encoder_fwd_kernel_stats.csv
 #   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE) of the hipGraph kernel mix  -> <tag>_pmc_traffic.json
+#   4. one --pmc pass of SQ counters (MFMA busy, vector active, stalls)      -> <tag>_pmc_sq.json
 # (A single-rank communicator launches no RCCL kernel — the library short-circuits a one-rank all-reduce — so the overlap of
 #  the bucketed all-reduce with backward can only be traced on a multi-GPU node: tools/ddp_overlap.py reads such a trace.)
 # Every profiler run puts the program itself after "--" and keeps counters apart from traces.
@@ -15,9 +16,13 @@ echo "step 1 done" >&2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/e -- python3 tools/enc_fwd_profile.py 10 > $out/enc.log 2>&1 || exit 1
 cp $(ls $out/e/*/*kernel_stats.csv | head -1) $out/${tag}_encoder_fwd_kernel_stats.csv
 echo "step 2 done" >&2
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pf -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pf.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pw -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pw.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pf -- python3 bench.py --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline --no-roofline > $out/pf.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pw -- python3 bench.py --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline --no-roofline > $out/pw.log 2>&1 || exit 1
 python3 tools/pmc_traffic.py $(ls $out/pf/*/*counter_collection.csv | head -1) $(ls $out/pw/*/*counter_collection.csv | head -1) --json $out/${tag}_pmc_traffic.json > $out/${tag}_pmc_traffic.txt
 echo "step 3 done" >&2
-rm -rf $out/k $out/e $out/pf $out/pw $out/d
+# 4. SQ counters of the same kernel mix (MFMA pipe busy / vector active / parked / issue-stalled) -> <tag>_pmc_sq.json
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/ps -- python3 bench.py --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline --no-roofline > $out/ps.log 2>&1 || exit 1
+python3 tools/pmc_sq.py $(ls $out/ps/*/*counter_collection.csv | head -1) --json $out/${tag}_pmc_sq.json > $out/${tag}_pmc_sq.txt
+echo "step 4 done" >&2
+rm -rf $out/k $out/e $out/pf $out/pw $out/ps $out/d
 ls -la $out

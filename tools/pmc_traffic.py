@@ -37,5 +37,9 @@ if out_json:
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import csrc_hash  # the table is only valid for the kernel sources it was collected from
-    json.dump({"unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", "csrc_sha256": csrc_hash(), "kernels": rows},
+    # per-update total: the profiled command runs full training updates only (bench.py --no-roofline), one adam_kernel each
+    updates = max([r["launches"] for r in rows if "adam_kernel" in r["kernel"]] or [0])
+    total = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
+    json.dump({"unit": "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", "csrc_sha256": csrc_hash(),
+               "updates_profiled": updates, "hbm_bytes_per_step": (total / updates) if updates else None, "kernels": rows},
               open(out_json, "w"), indent=1)
