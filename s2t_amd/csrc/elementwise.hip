@@ -354,26 +354,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   // hyper[0] = lr, hyper[1] = step_size = lr*sqrt(1-b2^t)/(1-b1^t), hyper[2] = grad_scale (device-resident so a
   // captured hipGraph replays with fresh values)
   const float lr = hyper[0], step_size = hyper[1], grad_scale = hyper[2];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    float pv[4], gv[4], mv[4], vv[4];
-    ld4_as_f32<float>(p + i * 4, pv);
-    ld4_as_f32<float>(g + i * 4, gv);
-    ld4_as_f32<float>(m + i * 4, mv);
-    ld4_as_f32<float>(v + i * 4, vv);
+  // The pass is pure streaming (30 bytes per parameter, nothing re-read): TWO 16-byte pieces per tensor and trip, all eight
+  // loads issued before the first use — one piece per trip left four loads in flight per lane and the pass at 3.6 TB/s.
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    const int64_t i1 = i0 + stride;
+    const bool two = i1 < n4;
+    const int64_t j1 = two ? i1 : i0;  // (clamped: the second piece's loads stay unconditional)
+    float pv[2][4], gv[2][4], mv[2][4], vv[2][4];
+    ld4_as_f32<float>(p + i0 * 4, pv[0]);
+    ld4_as_f32<float>(g + i0 * 4, gv[0]);
+    ld4_as_f32<float>(m + i0 * 4, mv[0]);
+    ld4_as_f32<float>(v + i0 * 4, vv[0]);
+    ld4_as_f32<float>(p + j1 * 4, pv[1]);
+    ld4_as_f32<float>(g + j1 * 4, gv[1]);
+    ld4_as_f32<float>(m + j1 * 4, mv[1]);
+    ld4_as_f32<float>(v + j1 * 4, vv[1]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float gr = gv[r] * grad_scale;
-      mv[r] = b1 * mv[r] + (1.f - b1) * gr;
-      vv[r] = b2 * vv[r] + (1.f - b2) * gr * gr;
-      float pr = pv[r];
-      if (wd != 0.f) pr -= wd * lr * pr;
-      pr -= step_size * mv[r] / (sqrtf(vv[r]) + eps);
-      pv[r] = pr;
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gr = gv[u][r] * grad_scale;
+        mv[u][r] = b1 * mv[u][r] + (1.f - b1) * gr;
+        vv[u][r] = b2 * vv[u][r] + (1.f - b2) * gr * gr;
+        float pr = pv[u][r];
+        if (wd != 0.f) pr -= wd * lr * pr;
+        pr -= step_size * mv[u][r] / (sqrtf(vv[u][r]) + eps);
+        pv[u][r] = pr;
+      }
+      if (u == 1 && !two) break;
+      const int64_t i = u ? i1 : i0;
+      st4_from_f32<float>(p + i * 4, pv[u]);
+      st4_from_f32<float>(m + i * 4, mv[u]);
+      st4_from_f32<float>(v + i * 4, vv[u]);
+      if (shadow) st4_from_f32<bf16_t>(shadow + i * 4, pv[u]);
     }
-    st4_from_f32<float>(p + i * 4, pv);
-    st4_from_f32<float>(m + i * 4, mv);
-    st4_from_f32<float>(v + i * 4, vv);
-    if (shadow) st4_from_f32<bf16_t>(shadow + i * 4, pv);
   }
 }
 
@@ -381,7 +396,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n4, float* __restrict__ out) {
   __shared__ float red[4];
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ld4_as_f32<float>(g + (i + u * stride) * 4, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+  }
+  for (; i < n4; i += stride) {
     float v[4];
     ld4_as_f32<float>(g + i * 4, v);
     acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];

@@ -229,3 +229,124 @@ def test_config2p_bf16_d256_against_oracle_on_rounded_weights():
     # order one on some tensor (a transposed weight layout read 1.43), so the bounds sit above the spread, not at twice one draw.
     assert worst[1] < 2.0e-1, worst
     assert float(np.median(list(errs.values()))) < 6e-2
+
+
+def _grads_vs_oracle(seed, variants):
+    """Relative L2 error of every parameter gradient of the 4-layer d = 256 bf16 Conformer (16 x 1000) against the fp32 oracle on
+    the same bf16-rounded weights and inputs, for each kernel variant in ``variants`` (name -> context manager factory)."""
+    from s2t_amd import functional as Fn
+
+    torch.manual_seed(seed)
+    args = M.recipe_args(conformer=True, vocab_size=V, encoder_layers=4, decoder_layers=2)
+    ref = M.S2TTransformerModel.build_model(args, M.FakeTask(V))
+    _perturb(ref, seed + 1)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(p.bfloat16().float())
+    state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    W = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in state.items()}
+    cfg = {k: getattr(args, k) for k in vars(args)}
+    B, T = 16, 1000
+    src, lens, g = _batch(B, T, seed + 2)
+    src = src.bfloat16().float()
+    ul = [int(torch.randint(20, 41, (1,), generator=g)) for _ in range(B)]
+    U = max(ul) + 1
+    target = torch.full((B, U), 1, dtype=torch.long)
+    prev = torch.full((B, U), 1, dtype=torch.long)
+    for b, u in enumerate(ul):
+        toks = torch.randint(4, V, (u,), generator=g)
+        target[b, :u] = toks
+        target[b, u] = 2
+        prev[b, 0] = 2
+        prev[b, 1:u + 1] = toks
+    sample = {"net_input": {"src_tokens": src.to(DEV), "src_lengths": lens.to(DEV), "prev_output_tokens": prev.to(DEV)},
+              "target": target.to(DEV), "ntokens": int(sum(ul) + B)}
+    loss_o, _ = O.joint_loss(W, cfg, src, lens, prev, target, eps=0.1, training=True, use_torch_ctc=True)
+    loss_o.backward()
+    out = {}
+    for name, ctx in variants.items():
+        model = M.S2TTransformerModel.build_model(args, M.FakeTask(V))
+        model.load_state_dict(state)
+        model.prepare(torch.bfloat16, DEV)
+        model.train()
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+        old = Fn._FFN_FUSED_MIN_ROWS
+        Fn._FFN_FUSED_MIN_ROWS = 1024
+        try:
+            with ctx():
+                model.flat.zero_grad()
+                loss, _, _ = crit(model, sample)
+                loss.backward()
+                torch.cuda.synchronize()
+        finally:
+            Fn._FFN_FUSED_MIN_ROWS = old
+        assert abs(float(loss.detach()) - float(loss_o.detach())) < 5e-3 * abs(float(loss_o.detach())), name
+        ptr = {k: v.data_ptr() for k, v in model.state_dict().items()}
+        errs = {}
+        for k, p in model.named_parameters():
+            if k.endswith(("k_proj.bias", "linear_k.bias")):
+                continue  # mathematically zero
+            go = sum(W[k2].grad for k2 in W if ptr[k2] == ptr[k] and W[k2].grad is not None)
+            if "subsample" in k and go.dim() == 3:
+                go = go.permute(0, 2, 1)
+            errs[k] = float((p.grad.detach().float().cpu() - go).norm() / go.norm().clamp_min(1e-6))
+        out[name] = errs
+    return out
+
+
+def test_config2p_bf16_shipped_kernels_are_as_close_to_the_oracle_as_the_composed_path():
+    """The bf16 gradient error of ONE draw is chaotic in the summation order of any kernel on the path (a one-ulp flip re-seeds
+    the rounding noise of everything behind it), so a bound on it has to sit far above a draw (the test above).  What
+    discriminates: the SAME model, weights and batch through (a) the kernels the bench runs — packed rows, the 128-row fused
+    feed-forward kernels, the fused attention — and (b) the composed path they replaced (padded rows, 64-row feed-forward
+    kernels, GEMM-composed attention: scores and probabilities through HBM), each against the fp32 oracle on the rounded weights,
+    over three seeds: per tensor the shipped kernels may not be further from the oracle than 3.5 x the composed path (a wrong
+    scale, a dropped bias gradient or a mis-indexed row shows as an error of order one on its tensor against ~0.01 - 0.05), and
+    the three-seed means of the worst tensor and of the median stay at the round-2 levels (0.11 / 0.025)."""
+    import contextlib
+    import os
+
+    from s2t_amd import kernels as K
+    from s2t_amd import rows as Rows
+
+    @contextlib.contextmanager
+    def shipped():
+        yield
+
+    @contextlib.contextmanager
+    def composed():
+        mask, split, _ = K.ffn_configure()
+        old_rows, old_env = Rows.ENABLED, os.environ.get("S2T_ATTN_COMPOSED")
+        K.ffn_configure(pc_mask=0)
+        Rows.ENABLED = False
+        os.environ["S2T_ATTN_COMPOSED"] = "1"
+        try:
+            yield
+        finally:
+            K.ffn_configure(pc_mask=mask)
+            Rows.ENABLED = old_rows
+            if old_env is None:
+                del os.environ["S2T_ATTN_COMPOSED"]
+            else:
+                os.environ["S2T_ATTN_COMPOSED"] = old_env
+
+    seeds = (51, 77, 123)
+    runs = [_grads_vs_oracle(s, {"shipped": shipped, "composed": composed}) for s in seeds]
+    names = list(runs[0]["shipped"])
+    mean = {v: {k: float(np.mean([r[v][k] for r in runs])) for k in names} for v in ("shipped", "composed")}
+    worst = {v: float(np.mean([max(r[v].values()) for r in runs])) for v in mean}
+    med = {v: float(np.mean([np.median(list(r[v].values())) for r in runs])) for v in mean}
+    print("three-seed means: worst tensor shipped %.4f composed %.4f, median shipped %.4f composed %.4f" %
+          (worst["shipped"], worst["composed"], med["shipped"], med["composed"]))
+    ratios = sorted(((mean["shipped"][k] / max(mean["composed"][k], 1e-9), k) for k in names), reverse=True)
+    for r_, k in ratios[:8]:
+        print("    x%.2f  %.4f vs %.4f  %s" % (r_, mean["shipped"][k], mean["composed"][k], k))
+    # measured on MI355X (round 4): three-seed means worst tensor 0.058 (shipped) / 0.053 (composed), median 0.0089 / 0.0052.
+    # The tensors on the SCORE path of the decoder's encoder-decoder attention (q / k projections, the LayerNorm in front) sit
+    # at 2.7 - 3.0 x the composed path's error (0.030 - 0.045 against 0.010 - 0.016): the fused backward takes
+    # delta_i = sum_c dO_ic O_ic from the bf16-rounded attention output (the flash-attention identity), the composed path sums
+    # P dP in fp32; with 250 nearly uniform keys dS = P (dP - delta) cancels to a fraction of either term.  Every other tensor
+    # is within 2 x.  A wrong scale, a dropped bias gradient or a mis-addressed row reads 1.0 on its tensor: a ratio of 50 - 100.
+    for k in names:
+        assert mean["shipped"][k] <= 3.5 * mean["composed"][k] + 0.01, (k, mean["shipped"][k], mean["composed"][k])
+    assert worst["shipped"] < 0.11 and med["shipped"] < 0.025, (worst, med)
