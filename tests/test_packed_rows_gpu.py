@@ -144,6 +144,28 @@ def test_eval_outputs_equal_the_padded_layout(conformer, split):
     assert any(len(h) > 0 for h in outs[True][3])
 
 
+def test_config5a_greedy_ids_equal_the_padded_layout():
+    """BASELINE.json configuration 5a at its literal size (12-layer Conformer + CTC head, 256 x 1000 x 80, bf16, V = 10 000):
+    the greedy token ids of the packed layout are those of the padded one, bit for bit (64 000 rows: one workgroup per row
+    block in every row-wise kernel, so no summation order depends on where a frame sits)."""
+    import bench
+
+    torch.manual_seed(3)
+    a = M.recipe_args(conformer=True, vocab_size=10000, ctc_weight=1.0)
+    model = M.S2TCTCModel.build_model(a, M.FakeTask(10000)).prepare(torch.bfloat16, DEV)
+    model.encoder.ctc_out_dtype = torch.float32
+    model.eval()
+    sample, _ = bench.synthetic_batch(256, 1000, 10000, 2, DEV)
+    ids = {}
+    with torch.no_grad():
+        for packed in (False, True):
+            with _layout(packed):
+                hyp = M.CTCDecoder([model]).generate([model], sample)
+                ids[packed] = [h[0]["tokens"].tolist() for h in hyp]
+    assert ids[False] == ids[True]
+    assert sum(len(x) for x in ids[True]) > 1000
+
+
 def _eval_both(model, sample, ni):
     outs = {}
     with torch.no_grad():
