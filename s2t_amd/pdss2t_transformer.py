@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import rows as Rows
 from .modules import (CTC, TABLES, Ctx, DownSampleConvolutionModule, LayerNorm, MaskRows, S2TTransformerEncoderLayer,
                       _Conv1dK)
 from .registry import register_model, register_model_architecture
@@ -121,6 +122,8 @@ class PDSS2TTransformerEncoder(nn.Module):
                 self.ctc.ctc_projection.weight = embed_tokens.weight
         self.compute_dtype = torch.float32
         self.ctc_out_dtype = None
+        # rows kept behind every utterance of a packed stage: the reach of the conv module's depthwise kernel (s2t_amd/rows.py)
+        self._halo = (int(getattr(args, "cnn_module_kernel", 31)) - 1) // 2 if getattr(args, "use_cnn_module", False) else 0
 
     def max_positions(self):
         return getattr(self.args, "max_source_positions", 6000)
@@ -141,9 +144,29 @@ class PDSS2TTransformerEncoder(nn.Module):
         x = x.view(B * Tn, C)
         lens32 = src_lengths.to(torch.int32)
         states = []
+        # the frame counts of every stage depend on the batch's lengths only: computed once per batch object (outside a captured
+        # step), so that the packed geometry of a stage hangs on a tensor that stays (s2t_amd/rows.py)
+        def stage_lens(sl):
+            out, l = [], sl.to(torch.int32)
+            for r in self.pds_ratios:
+                l = torch.floor((l.float() - 1) / r + 1).to(torch.int32)
+                out.append(l)
+            return tuple(out)
+
+        lens_memo = Fn.batch_memo(("pds_stage_lens", id(self)), (src_lengths,), stage_lens)
+        packed_last = None
         for i in range(self.pds_stages):
             x, Tn, lens32 = getattr(self, f"downsampling{i + 1}")(x, B, Tn, lens32)
             d = self.pds_embed_dims[i]
+            # Packed rows for the stage's layers where every kernel takes them (bf16, d = 256, heads of 64, enough rows): the
+            # down-sampling convolution in front of the next stage reads padded rows again (zero padded frames: what its own
+            # input mask makes of them, pdss2t_transformer.py:1100-1117)
+            # (relative positions: the backward behind the skewed score gradient is s2t_relpos_glue, which holds up to 256 frames)
+            pk = (Rows.ENABLED and dt == torch.bfloat16 and d == 256 and self.pds_attn_heads[i] * 64 == d and B * Tn >= 4096
+                  and Tn <= 65535 and not self.fusion_stages and (self.attn_type != "rel_pos" or Tn <= 256))
+            if pk:
+                lens32 = Rows.attach(lens_memo[i], B, Tn, self._halo)
+                x = Rows.pack(x, lens32)
             c = Ctx(B, Tn, lens32, dt)
             if self.pds_position_embed[i]:
                 if self.attn_type == "rel_pos":
@@ -154,6 +177,11 @@ class PDSS2TTransformerEncoder(nn.Module):
             x = Fn.dropout(x, self.dropout_p if i == 0 else self.pds_dropout_p, self.training)  # :1118-1121
             for layer in getattr(self, f"stage{i + 1}"):
                 x = layer(x, c, mask_output=False)
+            if pk and i + 1 < self.pds_stages:
+                x = Rows.unpack(x, lens32)
+                lens32 = Rows.detached(lens32)
+            elif pk:
+                packed_last = lens32
             states.append((x, Tn, lens32))
         if self.fusion_stages:
             fused = None
@@ -173,10 +201,22 @@ class PDSS2TTransformerEncoder(nn.Module):
                 fused = wgt * s_ if fused is None else fused + wgt * s_  # three small elementwise passes (torch)
             x = fused
         if self.layer_norm is not None:
-            x = self.layer_norm(x)
+            x = self.layer_norm(x, rows=packed_last)
         lens = lens32.long()
         mask = torch.arange(Tn, device=x.device)[None, :] >= lens[:, None]
         ctc_logit = None
+        if packed_last is not None:  # the last stage's rows stay packed for this package's consumers (s2t_transformer.py)
+            rows_, dE = packed_last, self.embed_dim
+            logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype, rows=rows_) if self.use_ctc else None
+            return {
+                "encoder_out": Rows.LazyList([lambda: Rows.unpack(x, rows_).view(B, Tn, dE).transpose(0, 1)]),
+                "ctc_logit": [] if logit2d is None else Rows.LazyList(
+                    [lambda: Rows.unpack(logit2d.contiguous(), rows_).view(B, Tn, -1).transpose(0, 1)]),
+                "inter_ctc_logits": [], "xctc_logit": [], "inter_xctc_logits": [],
+                "encoder_padding_mask": [mask], "mixup": None, "encoder_embedding": [], "encoder_states": [],
+                "src_tokens": [], "src_lengths": [],
+                "packed": {"rows": rows_, "B": B, "T": Tn, "encoder_out": x, "ctc_logit": logit2d},
+            }
         if self.use_ctc:
             ctc_logit = self.ctc(x, out_dtype=self.ctc_out_dtype).view(B, Tn, -1).transpose(0, 1)
         return {

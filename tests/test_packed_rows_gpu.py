@@ -216,6 +216,68 @@ def test_training_step_equals_the_padded_layout(conformer):
     assert float(np.median(errs)) <= 0.02, float(np.median(errs))
 
 
+@pytest.mark.parametrize("conformer", [True, False])
+def test_pds_stages_equal_the_padded_layout(conformer):
+    """Progressive down-sampling (models/speech_to_text/pdss2t_transformer.py:1042-1281; 3 stages, d = 256): a stage's layers run
+    on packed rows between its down-sampling convolution (padded rows) and the next one — every stage of the Transformer form,
+    the stages of at most 256 frames of the Conformer form (the relative-position backward's limit); one training pass against
+    the padded layout (loss, gradients, BatchNorm statistics) and the eval logits."""
+    from s2t_amd import pdss2t_transformer as PDS
+
+    def build():
+        torch.manual_seed(9)
+        a = M.recipe_args(conformer=conformer, vocab_size=V, arch="pdss2t_transformer_s_8", pds_stages=3, pds_layers="1_1_1",
+                          pds_ratios="2_2_2", pds_fusion=False, pds_embed_dims="256_256_256", pds_ds_method="conv",
+                          pds_embed_norm=True, pds_position_embed="1_1_1", pds_kernel_sizes="5_5_5", pds_ffn_ratios="8_8_8",
+                          pds_attn_heads="4_4_4", decoder_layers=1)
+        m = PDS.PDSS2TTransformerModel.build_model(a, M.FakeTask(V))
+        g = torch.Generator().manual_seed(10)
+        with torch.no_grad():
+            for n_, p in m.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+        return m.prepare(torch.bfloat16, DEV)
+
+    sample, lens = _sample(32, 1200, 21)
+    ni = sample["net_input"]
+    res = {}
+    for packed in (False, True):
+        model = build()
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+        with _layout(packed):
+            model.eval()
+            with torch.no_grad():
+                enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+                assert (enc.get("packed") is not None) == packed
+                logit = enc["ctc_logit"][0].float()
+            model.train()
+            model.flat.zero_grad()
+            loss, _, log = crit(model, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+        res[packed] = (logit, float(loss.detach()), {k: p.grad.detach().float().clone() for k, p in model.named_parameters()},
+                       {k: b.detach().float().clone() for k, b in model.named_buffers() if "running" in k})
+    Tp = res[False][0].shape[0]
+    sub = torch.tensor(lens)
+    for r in (2, 2, 2):
+        sub = torch.floor((sub.float() - 1) / r + 1).long()
+    valid = (torch.arange(Tp)[:, None] < sub[None, :]).to(DEV)
+    a, b = res[False][0][valid], res[True][0][valid]
+    assert float((a - b).norm() / a.norm()) <= 5e-3
+    assert abs(res[False][1] - res[True][1]) <= 5e-4 * abs(res[False][1]), (res[False][1], res[True][1])
+    for k in res[False][3]:
+        assert torch.allclose(res[False][3][k], res[True][3][k], rtol=2e-4, atol=2e-5), k
+    errs = []
+    for k, ga in res[False][2].items():
+        den = float(ga.norm())
+        if k.endswith(("k_proj.bias", "linear_k.bias")) or den < 1e-5:
+            continue
+        e = float((ga - res[True][2][k]).norm()) / den
+        errs.append(e)
+        assert e <= 0.08, (k, e)
+    assert float(np.median(errs)) <= 0.02
+
+
 def test_one_captured_step_serves_batches_of_any_fill():
     """The packed step captured into a hipGraph and replayed on batches of different fill gives what eager packed steps on
     the same sequence give (the live row count is read on the device: nothing in the graph depends on a batch's lengths),
