@@ -92,7 +92,7 @@ def test_ddp_world2_gloo(reduce_dtype):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, reduce_dtype)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in res:
@@ -145,7 +145,7 @@ def test_bf16_buckets_stay_within_a_rounding_of_fp32_buckets():
     procs = [ctx.Process(target=_worker_bound, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, a, b in res:
