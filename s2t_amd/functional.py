@@ -391,6 +391,12 @@ def _on_backward_end():
     for k in _LNQ["off"]:
         _LNQ["off"][k] = 0
     _BE["armed"] = False
+    _BE["count"] = _BE.get("count", 0) + 1
+
+
+def backward_count():
+    """Backward passes through this package's autograd Functions completed so far (an optimizer step follows one)."""
+    return _BE.get("count", 0)
 
 
 class GradStageFn(torch.autograd.Function):

@@ -531,6 +531,8 @@ class _HipModel(model_base()):
     _compute_dtype = None
     shadow_managed = False  # True: the owner of the optimizer step (s2t_amd.trainer.Trainer) refreshes the bf16 shadow itself
     _shadow_dirty = True
+    _step_notified = False  # attach_optimizer / notify_optimizer_step in use: refresh exactly when told
+    _refreshed_at = -1      # functional.backward_count() at the last heuristic refresh
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -583,12 +585,37 @@ class _HipModel(model_base()):
             # every forward that can be followed by an optimizer step (training mode, autograd on), and the first forward after
             # a train() / eval() switch or a checkpoint load; inference loops keep the shadow they have (one 56 us cast of
             # the 30 M parameters per forward otherwise)
-            if self.flat.shadow is not None and not self.shadow_managed and (
-                    self._shadow_dirty or (self.training and torch.is_grad_enabled())):
+            # With ``attach_optimizer`` (or explicit ``notify_optimizer_step`` calls) the refresh follows the optimizer's steps
+            # exactly — whatever mode the model is in — and the training-mode heuristic is off.  The hook sits on the model and on
+            # its encoder / decoder (a criterion may enter through either): one refresh per step, not one per entry.
+            heuristic = (self.training and torch.is_grad_enabled() and not self._step_notified
+                         and self._refreshed_at != Fn.backward_count())
+            if self.flat.shadow is not None and not self.shadow_managed and (self._shadow_dirty or heuristic):
                 self.flat.refresh_shadow()
                 self.flat.mark_transposed_stale()
                 self._shadow_dirty = False
+                self._refreshed_at = Fn.backward_count()  # (an optimizer step follows a backward pass: once per pass)
         return None
+
+    def notify_optimizer_step(self):
+        """Tell the model that an optimizer other than the bundled Trainer's has stepped the fp32 masters: the bf16 shadow (and
+        the transposed weight copies) are rewritten before the next forward, in training or eval mode, with or without autograd.
+        Once called, the per-forward heuristic (refresh before every training forward) is switched off."""
+        self._shadow_dirty = True
+        self._step_notified = True
+
+    def attach_optimizer(self, optimizer):
+        """``torch.optim.Optimizer.register_step_post_hook`` -> ``notify_optimizer_step`` (fairseq optimizers: pass
+        ``optimizer.optimizer``); returns the hook handle."""
+        import weakref
+
+        me = weakref.ref(self)
+        return optimizer.register_step_post_hook(lambda *a, **k: me() is not None and me().notify_optimizer_step())
+
+    def release_trainer(self):
+        """The bundled Trainer no longer updates this model (it set ``shadow_managed``): back to refreshing the shadow here."""
+        self.shadow_managed = False
+        self._shadow_dirty = True
 
     def train(self, mode=True):
         self._shadow_dirty = True  # whoever trained may have stepped the masters since the last forward

@@ -265,3 +265,26 @@ def test_an_external_optimizer_moves_the_bf16_shadow(style):
     crit2 = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
     l2 = loss_and_grad(fresh, crit2)
     assert abs(l2 - l1) <= 2e-3 * abs(l1), (l1, l2)
+
+
+def test_attached_optimizer_refreshes_the_shadow_in_eval_mode_too():
+    """weights stepped while the model is in eval() (dropout-off / frozen-BatchNorm fine-tuning), or followed by a
+    forward under no_grad without a mode switch, used to run on a stale bf16 shadow: the refresh heuristic only fires for
+    training-mode forwards.  ``model.attach_optimizer(opt)`` ties the refresh to the optimizer's steps instead."""
+    model = _model(9)
+    model.eval()
+    sample = _sample()
+    ni = sample["net_input"]
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    handle = model.attach_optimizer(opt)
+    with torch.no_grad():
+        a = model.encoder(ni["src_tokens"], ni["src_lengths"])["encoder_out"][0].float().clone()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.grad = torch.full_like(p, 1e-2) if p.grad is None else p.grad.fill_(1e-2)
+    opt.step()
+    with torch.no_grad():
+        b = model.encoder(ni["src_tokens"], ni["src_lengths"])["encoder_out"][0].float().clone()
+    assert torch.equal(model.flat.shadow, model.flat.master.bfloat16()), "stale bf16 shadow after a step in eval mode"
+    assert not torch.equal(a, b)
+    handle.remove()
