@@ -163,7 +163,7 @@ class PDSS2TTransformerEncoder(nn.Module):
             # input mask makes of them, pdss2t_transformer.py:1100-1117)
             # (relative positions: the backward behind the skewed score gradient is s2t_relpos_glue, which holds up to 256 frames)
             pk = (Rows.ENABLED and dt == torch.bfloat16 and d == 256 and self.pds_attn_heads[i] * 64 == d and B * Tn >= 4096
-                  and Tn <= 65535 and not self.fusion_stages and (self.attn_type != "rel_pos" or Tn <= 256))
+                  and Tn <= 65535 and not self.fusion_stages and (self.attn_type != "rel_pos" or Tn <= 256 or not torch.is_grad_enabled()))
             if pk:
                 lens32 = Rows.attach(lens_memo[i], B, Tn, self._halo)
                 x = Rows.pack(x, lens32)

@@ -166,6 +166,8 @@ class S2TTransformerEncoder(nn.Module):
         h = getattr(self.layers[0].self_attn, "num_heads", None) or getattr(self.layers[0].self_attn, "h", 0)
         if h * 64 != self.embed_dim or self.inter_ctc_layers or self.compression_layers:
             return False
+        if self.attn_type == "rel_pos" and Tp > 256 and torch.is_grad_enabled():
+            return False  # the relative-position BACKWARD behind the skewed score gradient (s2t_relpos_glue) holds 256 frames
         return B * Tp >= 4096 and Tp <= 65535
 
     # -- forward -------------------------------------------------------------------------------------

@@ -144,6 +144,94 @@ def test_eval_outputs_equal_the_padded_layout(conformer, split):
     assert any(len(h) > 0 for h in outs[True][3])
 
 
+def _sample_with_lens(lens, T, seed):
+    smp, _ = _sample(len(lens), T, seed)
+    src = smp["net_input"]["src_tokens"]
+    for b, l in enumerate(lens):
+        src[b, l:] = 0
+    smp["net_input"]["src_lengths"] = torch.tensor(lens).to(DEV)
+    return smp
+
+
+@pytest.mark.parametrize("case", ["all_full", "tiny_utterances"])
+def test_edge_fills_equal_the_padded_layout(case):
+    """No padding at all (every utterance full length: cu is the uniform layout, no halo row) and utterances of a handful of
+    frames (shorter than the depthwise kernel's reach, than an attention tile, than their CTC target allows): eval outputs bit
+    for bit with one workgroup per FFN row block, one training pass within the summation-order spread."""
+    T = 1000
+    lens = [T] * 24 if case == "all_full" else sorted([T, 997, 640, 333, 130, 41, 29, 17, 9, 5, 3, 1] * 2, reverse=True)
+    sample = _sample_with_lens(lens, T, 31)
+    ni = sample["net_input"]
+    model = _model(True)
+    model.eval()
+    _, old_split, _ = K.ffn_configure()
+    K.ffn_configure(split=1)
+    try:
+        outs = _eval_both(model, sample, ni)
+    finally:
+        K.ffn_configure(split=old_split)
+    sub = model.encoder.subsample.get_out_seq_lens_tensor(torch.tensor(lens))
+    Tp = outs[False][0].shape[0]
+    valid = (torch.arange(Tp)[:, None] < sub[None, :]).to(DEV)
+    for i in (0, 1):
+        assert torch.equal(outs[False][i][valid], outs[True][i][valid]), i
+    assert torch.equal(outs[False][2], outs[True][2]) and outs[False][3] == outs[True][3]
+    res = {}
+    for packed in (False, True):
+        m = _model(True)
+        m.train()
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+        with _layout(packed):
+            m.flat.zero_grad()
+            loss, _, log = crit(m, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+        res[packed] = (float(loss.detach()), {k: p.grad.detach().float().clone() for k, p in m.named_parameters()})
+    assert np.isfinite(res[True][0]) and abs(res[False][0] - res[True][0]) <= 5e-4 * abs(res[False][0]), (res[False][0], res[True][0])
+    errs = []
+    for k, ga in res[False][1].items():
+        den = float(ga.norm())
+        if k.endswith(("k_proj.bias", "linear_k.bias")) or den < 1e-5:
+            continue
+        gb = res[True][1][k]
+        assert bool(torch.isfinite(gb).all()), k
+        errs.append(float((ga - gb).norm()) / den)
+    assert max(errs) <= 0.1 and float(np.median(errs)) <= 0.02, (max(errs), float(np.median(errs)))
+
+
+def test_long_utterances_under_relative_positions():
+    """More than 256 frames per utterance with relative positions: the backward behind the skewed score gradient is the
+    s2t_relpos_glue kernel, which holds 256 frames — a training forward therefore stays on padded rows (no error, same result
+    as S2T_PACKED=0), inference runs packed and gives the padded layout's ids."""
+    model = _model(True, enc_layers=2, dec_layers=1)
+    sample, lens = _sample(12, 1500, 41)
+    ni = sample["net_input"]
+    model.eval()
+    ids = {}
+    _, old_split, _ = K.ffn_configure()
+    K.ffn_configure(split=1)  # (one summation order of the fused feed-forward kernels: see test_eval_outputs_…)
+    try:
+        with torch.no_grad():
+            for packed in (False, True):
+                with _layout(packed):
+                    enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+                    assert (enc.get("packed") is not None) == packed
+                    ids[packed] = [h[0]["tokens"].tolist() for h in M.CTCDecoder([model.encoder]).generate([model.encoder], sample)]
+    finally:
+        K.ffn_configure(split=old_split)
+    assert ids[False] == ids[True]
+    model.train()
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    with _layout(True):
+        enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+        assert enc.get("packed") is None
+        model.flat.zero_grad()
+        loss, _, _ = crit(model, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+
+
 def test_config5a_greedy_ids_equal_the_padded_layout():
     """BASELINE.json configuration 5a at its literal size (12-layer Conformer + CTC head, 256 x 1000 x 80, bf16, V = 10 000):
     the greedy token ids of the packed layout are those of the padded one, bit for bit (64 000 rows: one workgroup per row
