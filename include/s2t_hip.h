@@ -411,6 +411,7 @@ int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* len
 int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V, const int64_t* target,
                          int64_t pad_idx, float eps, void* dlogits, int64_t ldd, float* sums,
                          float* ws /* rows x 4 floats of scratch: per-row terms, folded into sums in a fixed order */,
+                         const int32_t* live /* optional device scalar: only rows < *live (a packed batch's live rows) */,
                          void* stream);
 /* force_emits (optional, [B][T] int64, -1 = free): imputer loss of torch_imputer/imputer.cu:57-215,339-477 (a frame
  * pinned to one extended-label state).  paths (optional, [B][T][Lmax] int32): max-product (Viterbi) recursion with

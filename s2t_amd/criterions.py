@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import kernels as K
 from .registry import criterion_base, register_criterion
 
 _CriterionBase = criterion_base()
@@ -92,10 +93,26 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(_CriterionBase):
                     inter_terms.append(Fn.ctc_loss(lg.transpose(0, 1).reshape(B * Ti, -1), B, Ti, tmat, tl, il_lens,
                                                    self.blank_idx, side=_CTC_SIDE))
                 inter_loss = inter_terms
-        logits, _ = model.decoder(prev_output_tokens=ni["prev_output_tokens"], encoder_out=enc)
-        _, U, V = logits.shape
-        sums = Fn.label_smoothed_ce(logits.reshape(B * U, V), batch_bookkeeping(sample, self.padding_idx, self.eos_idx)[2],
-                                    self.eps, self.padding_idx)
+        logits, dextra = model.decoder(prev_output_tokens=ni["prev_output_tokens"], encoder_out=enc, packed_out=True)
+        tflat = batch_bookkeeping(sample, self.padding_idx, self.eos_idx)[2]
+        dpk = dextra.get("packed") if isinstance(dextra, dict) else None
+        if dpk is not None:
+            # packed target rows (s2t_amd/rows.py): logits [B * U, V] with target b at rows cu[b] ...; the targets follow through
+            # the row map (rows that hold no token: pad, which the loss skips)
+            geom = K.rows_geom(dpk["rows"])
+            pad_idx, U_, hdr = self.padding_idx, dpk["U"], geom.HEADER
+
+            def pack_targets(t, buf):
+                m = buf[hdr:]
+                ok = m >= 0
+                idx = torch.where(ok, (m >> 16).long() * U_ + (m & 0xffff).long(), torch.zeros_like(m, dtype=torch.long))
+                return (torch.where(ok, t.reshape(-1)[idx], torch.full_like(idx, pad_idx)),)
+
+            (tpk,) = Fn.batch_memo(("targets_packed", id(self)), (tflat, geom.buf), pack_targets)
+            sums = Fn.label_smoothed_ce(logits, tpk, self.eps, self.padding_idx, rows=dpk["rows"])
+        else:
+            _, U, V = logits.shape
+            sums = Fn.label_smoothed_ce(logits.reshape(B * U, V), tflat, self.eps, self.padding_idx)
         loss = sums[0]
         sample_size = target.size(0) if self.sentence_avg else sample["ntokens"]
         log = {"trans_loss": sums[0].detach(), "nll_loss": sums[1].detach(), "ntokens": sample["ntokens"],

@@ -257,9 +257,14 @@ __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int32_t* __res
 template <typename T>
 __global__ __launch_bounds__(256) void ls_ce_kernel(const T* __restrict__ logits, int64_t ld, int V,
                                                     const int64_t* __restrict__ target, int64_t pad_idx, float eps,
-                                                    T* __restrict__ dlogits, int64_t ldd, float* __restrict__ part) {
+                                                    T* __restrict__ dlogits, int64_t ldd, float* __restrict__ part,
+                                                    const int32_t* __restrict__ live) {
   __shared__ float ssum[4];
   const int64_t row = blockIdx.x;
+  if (live && row >= live[0]) {  // packed batch: no such row (its partial terms are zero, its gradient row is never read)
+    if (threadIdx.x < 4) part[row * 4 + threadIdx.x] = 0.f;
+    return;
+  }
   const int64_t y = target[row];
   const T* x = logits + row * ld;
   T* dx = dlogits ? dlogits + row * ldd : nullptr;
@@ -806,15 +811,15 @@ extern "C" int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const i
 
 extern "C" int s2t_ls_cross_entropy(int dtype, const void* logits, int64_t ld, int64_t rows, int V,
                                     const int64_t* target, int64_t pad_idx, float eps, void* dlogits, int64_t ldd,
-                                    float* sums, float* ws /* [rows][4] scratch */, void* stream) {
+                                    float* sums, float* ws /* [rows][4] scratch */, const int32_t* live, void* stream) {
   if (!logits || !target || !sums || !ws || rows < 0 || V <= 1 || ld < V) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   dim3 grid((unsigned)rows), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(ls_ce_kernel<float>, grid, block, 0, s, (const float*)logits, ld, V, target, pad_idx, eps, (float*)dlogits, ldd, ws);
+    hipLaunchKernelGGL(ls_ce_kernel<float>, grid, block, 0, s, (const float*)logits, ld, V, target, pad_idx, eps, (float*)dlogits, ldd, ws, live);
   else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(ls_ce_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)logits, ld, V, target, pad_idx, eps, (bf16_t*)dlogits, ldd, ws);
+    hipLaunchKernelGGL(ls_ce_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)logits, ld, V, target, pad_idx, eps, (bf16_t*)dlogits, ldd, ws, live);
   else return S2T_ERR_DTYPE;
   hipLaunchKernelGGL(ls_ce_fold_kernel, dim3(1), dim3(1024), 0, s, ws, rows, sums);
   return S2T_LAUNCH_CHECK();

@@ -221,15 +221,25 @@ def refresh_batch_memos(changed):
     """``changed``: the tensors whose contents were just overwritten.  Every memo computed from one of them — or from the
     output of a memo refreshed here (the padding mask feeds the length memos) — is recomputed into its existing tensors."""
     dirty = {id(t) for t in changed}
-    for key, (srcs, _, fn, outs) in list(_MEMO.items()):  # insertion order = the order the forward pass made them
-        if not any(id(t) in dirty for t in srcs):
-            continue
-        new = fn(*srcs)
-        for o, n in zip(outs, new):
-            if torch.is_tensor(o):
-                o.copy_(n)
-                dirty.add(id(o))
-        _MEMO[key] = (srcs, tuple(t._version for t in srcs), fn, outs)
+    # Passes until nothing new becomes dirty: a memo may sit in the table BEFORE one it depends on (a key first made for an
+    # earlier batch keeps its place when a later batch replaces its entry, while that batch's own geometry memos are appended
+    # behind it), so one sweep in insertion order can recompute it from a source that is refreshed only afterwards.
+    seen = {}  # key -> the dirty sources it was last recomputed from
+    progress = True
+    while progress:
+        progress = False
+        for key, (srcs, _, fn, outs) in list(_MEMO.items()):
+            d = frozenset(id(t) for t in srcs if id(t) in dirty)
+            if not d or seen.get(key) == d:
+                continue
+            new = fn(*srcs)
+            for o, n in zip(outs, new):
+                if torch.is_tensor(o):
+                    o.copy_(n)
+                    dirty.add(id(o))
+            _MEMO[key] = (srcs, tuple(t._version for t in srcs), fn, outs)
+            seen[key] = d
+            progress = True
 
 
 _BE = {"armed": False, "ready": [], "flats": []}
@@ -1992,14 +2002,15 @@ class LabelSmoothedCEFn(torch.autograd.Function):
     the gradient w.r.t. the logits is produced in the same pass."""
 
     @staticmethod
-    def forward(ctx, logits, target, eps, pad_idx, train):
+    def forward(ctx, logits, target, eps, pad_idx, train, bound=None):
         rows, V = logits.shape
         assert logits.stride(1) == 1
         sums = torch.zeros(4, dtype=torch.float32, device=logits.device)
         dl = None
         if train:
             dl = torch.empty(rows, _pad8(V), dtype=logits.dtype, device=logits.device)[:, :V]
-        K.ls_cross_entropy(logits, logits.stride(0), rows, V, target, pad_idx, eps, dl, dl.stride(0) if train else 0, sums)
+        K.ls_cross_entropy(logits, logits.stride(0), rows, V, target, pad_idx, eps, dl, dl.stride(0) if train else 0, sums,
+                           bound=bound)
         if train:
             ctx.save_for_backward(dl)
         return sums
@@ -2008,11 +2019,13 @@ class LabelSmoothedCEFn(torch.autograd.Function):
     def backward(ctx, dsums):
         (dl,) = ctx.saved_tensors
         # only sums[0] (the loss) is differentiable
-        return dl * dsums[0].to(dl.dtype), None, None, None, None
+        return dl * dsums[0].to(dl.dtype), None, None, None, None, None
 
 
-def label_smoothed_ce(logits, target, eps, pad_idx):
-    return LabelSmoothedCEFn.apply(logits, target, eps, pad_idx, torch.is_grad_enabled() and logits.requires_grad)
+def label_smoothed_ce(logits, target, eps, pad_idx, rows=None):
+    """``rows``: the lengths tensor of a packed batch whose rows ``logits`` / ``target`` hold (only the live rows are read)."""
+    return LabelSmoothedCEFn.apply(logits, target, eps, pad_idx, torch.is_grad_enabled() and logits.requires_grad,
+                                   rows if K.rows_geom(rows) is not None else None)
 
 
 _SIDE = {"streams": {}, "pending": []}

@@ -681,10 +681,10 @@ def ctc_collapse(idx, top_lp, lens, B, T, blank, out_tokens, out_lens, out_score
           out_lens.data_ptr(), out_scores.data_ptr())
 
 
-def ls_cross_entropy(logits, ld, rows, V, target, pad_idx, eps, dlogits, ldd, sums):
+def ls_cross_entropy(logits, ld, rows, V, target, pad_idx, eps, dlogits, ldd, sums, bound=None):
     ws = _scratch("ls_ce", max(int(rows), 1) * 4, logits.device)
     _call("s2t_ls_cross_entropy", L.dtype_id(logits.dtype), logits.data_ptr(), ld, rows, V, target.data_ptr(), pad_idx,
-          eps, _ptr(dlogits), ldd, sums.data_ptr(), ws.data_ptr())
+          eps, _ptr(dlogits), ldd, sums.data_ptr(), ws.data_ptr(), _live(bound))
 
 
 def ctc_loss_fwd(logits, ld, B, T, V, lse, targets, ldt, tgt_lens, in_lens, blank, alpha, beta, Lmax, nll,

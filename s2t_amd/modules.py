@@ -496,17 +496,20 @@ class TransformerDecoderLayer(nn.Module):
     def forward(self, x, mem, B, U, Tm, self_lens, mem_lens, mem_kv=None):
         # (the LayerNorm in front of the self-attention rides in the fused q|k|v projection's prologue where the row-block
         # kernel applies, its backward in that projection's input-gradient kernel)
+        # packed target rows (s2t_amd/rows.py): ``self_lens`` then carries their geometry — the key side of the self-attention,
+        # the QUERY side of the encoder-decoder attention, the live-row bound of everything without a mask
+        rows = self_lens if getattr(self_lens, "_pk", None) is not None else None
         x = self.self_attn(x, None, None, B, U, U, self_lens, causal=True, norm=self.self_attn_layer_norm)
         if mem_kv is not None:  # (likewise the LayerNorm in front of the encoder-decoder attention, in its query projection)
-            x = self.encoder_attn(x, None, None, B, U, Tm, mem_lens, kv=mem_kv, norm=self.encoder_attn_layer_norm)
+            x = self.encoder_attn(x, None, None, B, U, Tm, mem_lens, kv=mem_kv, norm=self.encoder_attn_layer_norm, q_rows=rows)
         else:
-            y, x = self.encoder_attn_layer_norm(x, fork=True)
-            x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens)
+            y, x = self.encoder_attn_layer_norm(x, fork=True, rows=rows)
+            x = self.encoder_attn(y, mem, x, B, U, Tm, mem_lens, q_rows=rows)
         # (one launch for the whole block where the row-block kernel applies: at the decoder's few thousand rows the hidden units
         # of a 128-row block are dealt to eight workgroups, csrc/ffn_pc.hip)
         return Fn.ffn_block(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
                             self.fc2.weight, self.fc2.bias, self.activation_fn, 1.0, self.activation_dropout_p, self.dropout_p,
-                            self.training)
+                            self.training, rows=rows)
 
 
 # ------------------------------------------------------------------------------------------------

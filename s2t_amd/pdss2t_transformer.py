@@ -165,7 +165,7 @@ class PDSS2TTransformerEncoder(nn.Module):
             pk = (Rows.ENABLED and dt == torch.bfloat16 and d == 256 and self.pds_attn_heads[i] * 64 == d and B * Tn >= 4096
                   and Tn <= 65535 and not self.fusion_stages and (self.attn_type != "rel_pos" or Tn <= 256 or not torch.is_grad_enabled()))
             if pk:
-                lens32 = Rows.attach(lens_memo[i], B, Tn, self._halo)
+                lens32 = Rows.attach(lens_memo[i], B, Tn, self._halo, tag=("pds", id(self), i))
                 x = Rows.pack(x, lens32)
             c = Ctx(B, Tn, lens32, dt)
             if self.pds_position_embed[i]:

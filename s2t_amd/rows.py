@@ -29,11 +29,14 @@ class PackedRows:
 
     HEADER = 4
 
-    def __init__(self, lens32, B, T, halo):
+    def __init__(self, lens32, B, T, halo, tag=None):
         assert lens32.dtype == torch.int32 and lens32.is_cuda and T <= 65535 and B <= 32767
         self.lens, self.B, self.T, self.halo = lens32, int(B), int(T), int(halo)
         self.M = self.B * self.T
-        self.cu, self.buf = Fn.batch_memo(("packed_rows", id(lens32), self.B, self.T, self.halo), (lens32,), self._build)
+        # ``tag`` names the user of the geometry (an encoder, a decoder, a PDS stage): its memo entry is then REPLACED when the next
+        # batch object comes along (an entry per lengths tensor would grow without bound over an eager epoch)
+        self.cu, self.buf = Fn.batch_memo(("packed_rows", tag if tag is not None else id(lens32), self.B, self.T, self.halo),
+                                          (lens32,), self._build)
         self.map_ptr = self.buf.data_ptr() + 4 * self.HEADER
 
     def _build(self, lens):
@@ -83,11 +86,11 @@ class LazyList(list):
         return (self._get(i) for i in range(len(self)))
 
 
-def attach(lens32, B, T, halo):
+def attach(lens32, B, T, halo, tag=None):
     """Give ``lens32`` the packed geometry of its batch (idempotent per (B, T, halo)); returns ``lens32``."""
     g = K.rows_geom(lens32)
     if g is None or (g.B, g.T, g.halo) != (B, T, halo):
-        lens32._pk = PackedRows(lens32, B, T, halo)
+        lens32._pk = PackedRows(lens32, B, T, halo, tag)
     return lens32
 
 

@@ -191,7 +191,7 @@ class S2TTransformerEncoder(nn.Module):
         if self._packed_ok(dt, B, Tp):
             # Packed rows (s2t_amd/rows.py): from here to the end of the encoder only the frames (and the conv module's halo
             # rows) are computed; the buffers keep their B * T' rows.  ``lens32`` carries the geometry to every launch.
-            lens32 = Rows.attach(lens32, B, Tp, self._halo)
+            lens32 = Rows.attach(lens32, B, Tp, self._halo, tag=("enc", id(self)))
             x = Rows.pack(x, lens32)
         else:
             lens32 = Rows.detached(lens32)
@@ -393,7 +393,9 @@ class TransformerDecoderScriptable(nn.Module):
     def max_positions(self):
         return getattr(self.args, "max_target_positions", DEFAULT_MAX_TARGET_POSITIONS)
 
-    def extract_features(self, prev_output_tokens, encoder_out=None, incremental_state=None, **unused):
+    def extract_features(self, prev_output_tokens, encoder_out=None, incremental_state=None, packed_out=False, **unused):
+        """``packed_out`` (this package's criterion): where the target rows run packed (s2t_amd/rows.py) they are returned as they
+        are — ``[B * U, d]`` with ``extra["packed"]`` naming their geometry — instead of the reference's ``B x U x d``."""
         if incremental_state is not None:
             return self._extract_features_incremental(prev_output_tokens, encoder_out, incremental_state)
         B, U = prev_output_tokens.shape
@@ -412,6 +414,13 @@ class TransformerDecoderScriptable(nn.Module):
         tab = TABLES.get("sin", self.max_positions() + self.padding_idx + 1, d, dev)
         x = Fn.embedding(tok, pos, self.embed_tokens.weight, tab, self.embed_scale, self.padding_idx)
         x = Fn.dropout(x, float(self.args.dropout or 0.0), self.training)  # dropout_module (transformer.py:1328)
+        # Packed target rows: the collater left-aligns the targets and pads them to the longest of the batch
+        # (data/audio/speech_to_text_dataset.py:445-470); no decoder module looks across a target's end, so there is no halo.
+        dec_rows = None
+        if (Rows.ENABLED and x.dtype == torch.bfloat16 and d == 256 and self.layers[0].self_attn.num_heads * 64 == d
+                and B * U >= 2048 and U <= 65535):
+            dec_rows = self_lens = Rows.attach(self_lens, B, U, 0, tag=("dec", id(self)))
+            x = Rows.pack(x, dec_rows)
         pk = encoder_out.get("packed")
         if pk is not None and pk["B"] == B and Fn._use_fused_attention(pk["encoder_out"].dtype, d // self.layers[0].encoder_attn.num_heads):
             # the encoder's packed rows (s2t_amd/rows.py) are the memory as they are: the key side of every encoder-decoder
@@ -431,8 +440,14 @@ class TransformerDecoderScriptable(nn.Module):
         for i, layer in enumerate(self.layers):
             x = layer(x, mem, B, U, Tm, self_lens, mem_lens, mem_kv=(ckv[0], i, L, ckv[1]) if ckv is not None else None)
         if self.layer_norm is not None:
-            x = self.layer_norm(x)
-        return x.view(B, U, d), {"attn": [None], "inner_states": [], "mixup": None}
+            x = self.layer_norm(x, rows=dec_rows)
+        extra = {"attn": [None], "inner_states": [], "mixup": None}
+        if dec_rows is not None:
+            if packed_out:
+                extra["packed"] = {"rows": dec_rows, "B": B, "U": U}
+                return x, extra
+            x = Rows.unpack(x, dec_rows)  # the reference's layout (zero rows at the padded positions)
+        return x.view(B, U, d), extra
 
     def _extract_features_incremental(self, prev_output_tokens, encoder_out, incremental_state):
         """models/transformer.py:1290-1312 with ``incremental_state``: only the last position is embedded and pushed
@@ -472,15 +487,18 @@ class TransformerDecoderScriptable(nn.Module):
 
     reorder_incremental_state_scripting = reorder_incremental_state
 
-    def output_layer(self, features):
+    def output_layer(self, features, rows=None):
+        if features.dim() == 2:  # packed target rows: logits stay [B * U, V]
+            return self.output_projection(features, out_dtype=self.logits_dtype, rows=rows)
         B, U, d = features.shape
         y = self.output_projection(features.reshape(B * U, d), out_dtype=self.logits_dtype)
         return y.view(B, U, -1)
 
-    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, features_only=False, **unused):
-        x, extra = self.extract_features(prev_output_tokens, encoder_out, incremental_state)
+    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, features_only=False, packed_out=False,
+                **unused):
+        x, extra = self.extract_features(prev_output_tokens, encoder_out, incremental_state, packed_out=packed_out)
         if not features_only:
-            x = self.output_layer(x)
+            x = self.output_layer(x, rows=extra["packed"]["rows"] if "packed" in extra else None)
         return x, extra
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):

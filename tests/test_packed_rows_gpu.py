@@ -34,8 +34,8 @@ def _sample(B, T, seed, full_first=True, lo=0.55):
     src = torch.randn(B, T, 80, generator=g)
     for b, l in enumerate(lens):
         src[b, l:] = 0
-    ul = [int(torch.randint(10, 21, (1,), generator=g)) for _ in range(B)]
-    U = 21
+    ul = [int(torch.randint(30, 91, (1,), generator=g)) for _ in range(B)]  # (24 x 91 target rows: enough for the decoder's
+    U = 91                                                                   #  row-block kernels, so its rows run packed too)
     target = torch.full((B, U), 1, dtype=torch.long)
     prev = torch.full((B, U), 1, dtype=torch.long)
     for b, u in enumerate(ul):
@@ -131,13 +131,15 @@ def test_eval_outputs_equal_the_padded_layout(conformer, split):
             a, b = outs[False][i], outs[True][i]
             assert a.shape == b.shape
             assert torch.equal(a[valid], b[valid]), "frames differ between the layouts (output %d)" % i
-        assert torch.equal(outs[False][2], outs[True][2]), "decoder logits differ"
+        tokv = ni["prev_output_tokens"] != 1  # (the target rows run packed too: padded positions hold no token)
+        assert torch.equal(outs[False][2][tokv], outs[True][2][tokv]), "decoder logits differ"
         assert outs[False][3] == outs[True][3], "greedy ids differ"
     else:
         for i in (0, 1):
             a, b = outs[False][i][valid], outs[True][i][valid]
             assert float((a - b).norm() / a.norm()) <= 5e-3, i
-        a, b = outs[False][2], outs[True][2]
+        tokv = ni["prev_output_tokens"] != 1
+        a, b = outs[False][2][tokv], outs[True][2][tokv]
         assert float((a - b).norm() / a.norm()) <= 5e-3
         # (greedy ids: compared in the split = 1 run only — the random weights of this model leave many frames with near-tied
         # logits, which a last-bit difference tips either way in any layout)
@@ -175,7 +177,8 @@ def test_edge_fills_equal_the_padded_layout(case):
     valid = (torch.arange(Tp)[:, None] < sub[None, :]).to(DEV)
     for i in (0, 1):
         assert torch.equal(outs[False][i][valid], outs[True][i][valid]), i
-    assert torch.equal(outs[False][2], outs[True][2]) and outs[False][3] == outs[True][3]
+    tokv = ni["prev_output_tokens"] != 1
+    assert torch.equal(outs[False][2][tokv], outs[True][2][tokv]) and outs[False][3] == outs[True][3]
     res = {}
     for packed in (False, True):
         m = _model(True)
@@ -262,6 +265,9 @@ def _eval_both(model, sample, ni):
                 enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
                 assert (enc.get("packed") is not None) == packed
                 logits, _ = model.decoder(prev_output_tokens=ni["prev_output_tokens"], encoder_out=enc)
+                if ni["prev_output_tokens"].numel() >= 2048:  # the target rows run packed as well (what the criterion asks for)
+                    lp, ex = model.decoder(prev_output_tokens=ni["prev_output_tokens"], encoder_out=enc, packed_out=True)
+                    assert ("packed" in ex) == packed and (lp.dim() == 2) == packed
                 hyp = M.CTCDecoder([model.encoder]).generate([model.encoder], sample)
                 outs[packed] = (enc["encoder_out"][0].float(), enc["ctc_logit"][0].float(), logits.float(),
                                 [h[0]["tokens"].tolist() for h in hyp])
