@@ -469,6 +469,10 @@ int s2t_compress_rows(int dtype, const void* in, void* out, const int32_t* src, 
  * Each direction is the other's backward pass. */
 int s2t_pack_rows(int dtype, const void* in, void* out, const int32_t* map, int64_t rows, int T, int C, int to_packed,
                   void* stream);
+/* The geometry itself, from the batch's lengths (one launch per batch, outside a captured step): cu [B + 1]; map_buf: 4 header
+ * words (the last one = cu[B], the live row count) followed by the B * T row-map entries — the row map pointer the other entry
+ * points take is map_buf + 4.  halo: rows kept behind every utterance (never beyond T).  B <= 1024, T <= 65535. */
+int s2t_rows_geometry(const int32_t* lens, int B, int T, int halo, int32_t* cu, int32_t* map_buf, void* stream);
 
 /* ---- PDS multi-scale fusion: depthwise convolution with kernel = stride = r, no padding --------
  * The depthwise stage of DownSampleConvolutionModule (fairseq/modules/downsample_convolution.py:45-54,97-100) as used by

@@ -80,7 +80,60 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint4* __restrict_
   else if (e >= 0) out[padded] = in[idx];
 }
 
+// Geometry of a packed batch from its lengths, one launch: cu[b] = rows in front of utterance b (frames + halo rows each), the row
+// map behind a 4-word header whose last word is the live row count.  Every workgroup scans the (at most 1024) lengths itself and
+// fills its slice of the map: row m belongs to the utterance whose [cu[b], cu[b + 1]) holds it (binary search in LDS).
+__global__ __launch_bounds__(1024) void rows_geometry_kernel(const int32_t* __restrict__ lens, int B, int T, int halo,
+                                                             int32_t* __restrict__ cu, int32_t* __restrict__ buf, int M) {
+  __shared__ int scu[1025];
+  __shared__ int slen[1024];
+  const int tid = threadIdx.x;
+  int cap = 0, len = 0;
+  if (tid < B) {
+    len = lens[tid];
+    const int rest = T - len;
+    cap = len + (rest < 0 ? 0 : (rest < halo ? rest : halo));
+    slen[tid] = len;
+  }
+  scu[tid + 1] = cap;  // inclusive scan (Hillis-Steele) over 1024 slots
+  if (tid == 0) scu[0] = 0;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = tid + 1 > o ? scu[tid + 1 - o] : 0;
+    __syncthreads();
+    scu[tid + 1] += v;
+    __syncthreads();
+  }
+  const int live = scu[B];
+  if (blockIdx.x == 0) {
+    if (tid <= B) cu[tid] = scu[tid];
+    if (tid < 4) buf[tid] = tid == 3 ? live : 0;
+  }
+  for (int m = blockIdx.x * 1024 + tid; m < M; m += gridDim.x * 1024) {
+    int e = -1;
+    if (m < live) {
+      int lo = 0, hi = B;  // the utterance b with scu[b] <= m < scu[b + 1]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (scu[mid] <= m) lo = mid; else hi = mid;
+      }
+      const int t = m - scu[lo];
+      e = t < slen[lo] ? ((lo << 16) | t) : -1;
+    }
+    buf[4 + m] = e;
+  }
+}
+
 }  // namespace
+
+extern "C" int s2t_rows_geometry(const int32_t* lens, int B, int T, int halo, int32_t* cu, int32_t* map_buf, void* stream) {
+  if (!lens || !cu || !map_buf || B <= 0 || B > 1024 || T <= 0 || T > 65535 || halo < 0) return S2T_ERR_ARG;
+  const int M = B * T;
+  int nb = (M + 4095) / 4096;
+  if (nb > 64) nb = 64;
+  hipLaunchKernelGGL(rows_geometry_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, lens, B, T, halo, cu, map_buf, M);
+  return S2T_LAUNCH_CHECK();
+}
 
 extern "C" int s2t_pack_rows(int dtype, const void* in, void* out, const int32_t* map, int64_t rows, int T, int C,
                              int to_packed, void* stream) {

@@ -56,6 +56,10 @@ def _prof_rows(M, *cands):
     return M
 
 
+def rows_geometry(lens, B, T, halo, cu, buf):
+    _call("s2t_rows_geometry", lens.data_ptr(), B, T, halo, cu.data_ptr(), buf.data_ptr())
+
+
 def pack_rows(src, out, lens, to_packed=True):
     """s2t_pack_rows: padded [B*T, C] -> packed rows (or back: ``out`` zero-filled by the caller) of the batch ``lens`` names."""
     g = rows_geom(lens)

@@ -41,6 +41,15 @@ class PackedRows:
 
     def _build(self, lens):
         B, T, M = self.B, self.T, self.M
+        if B <= 1024:  # one launch (s2t_rows_geometry); the torch composition below is its restatement for larger batches
+            # (a refresh — new lengths copied into the same tensor, Trainer.load_batch — rewrites the tensors a captured step reads)
+            cu = getattr(self, "cu", None)
+            buf = getattr(self, "buf", None)
+            if cu is None:
+                cu = torch.empty(B + 1, dtype=torch.int32, device=lens.device)
+                buf = torch.empty(self.HEADER + M, dtype=torch.int32, device=lens.device)
+            K.rows_geometry(lens, B, T, self.halo, cu, buf)
+            return cu, buf
         cap = lens + (T - lens).clamp(min=0, max=self.halo)
         cu = torch.zeros(B + 1, dtype=torch.int32, device=lens.device)
         cu[1:] = torch.cumsum(cap, 0)
