@@ -235,6 +235,31 @@ def test_long_utterances_under_relative_positions():
     assert np.isfinite(float(loss))
 
 
+def test_beam_search_over_a_packed_encoder():
+    """fairseq's SequenceGenerator (sequence_generator.py:191-786) reads the encoder dictionary's T x B x C entries and re-orders
+    them per beam: with packed rows those entries are materialised on first access (rows.LazyList).  Plain search and the joint
+    CTC / attention search (the prefix scorer reads ``ctc_logit``) give the padded layout's hypotheses."""
+    from s2t_amd.sequence_generator import SequenceGenerator
+
+    model = _model(True, enc_layers=2, dec_layers=1)
+    model.eval()
+    sample, _ = _sample(20, 1000, 51)
+    task = M.FakeTask(V)
+    _, old_split, _ = K.ffn_configure()
+    K.ffn_configure(split=1)
+    try:
+        for ctc_w in (0.0, 0.3):
+            out = {}
+            for packed in (False, True):
+                with _layout(packed):
+                    gen = SequenceGenerator([model], task.target_dictionary, beam_size=3, max_len_a=0, max_len_b=12, ctc_weight=ctc_w)
+                    hyps = gen.generate([model], {"net_input": {k: sample["net_input"][k] for k in ("src_tokens", "src_lengths")}})
+                    out[packed] = [[(h["tokens"].tolist(), round(float(h["score"]), 3)) for h in hb] for hb in hyps]
+            assert out[False] == out[True], ctc_w
+    finally:
+        K.ffn_configure(split=old_split)
+
+
 def test_config5a_greedy_ids_equal_the_padded_layout():
     """BASELINE.json configuration 5a at its literal size (12-layer Conformer + CTC head, 256 x 1000 x 80, bf16, V = 10 000):
     the greedy token ids of the packed layout are those of the padded one, bit for bit (64 000 rows: one workgroup per row
