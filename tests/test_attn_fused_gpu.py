@@ -390,3 +390,93 @@ def test_relpos_glue_packed_rows_ignore_stale_columns():
     dp_ref = torch.einsum("hbin,bihc->nhc", clean.double()[..., :n_pos], qv.double().view(B, T, H, dk)).reshape(n_pos, d)
     err = (dp.cpu().double() - dp_ref).abs().max() / dp_ref.abs().max()
     assert err < 1e-2, float(err)
+
+
+@pytest.mark.parametrize("kind", ["self_rel", "self_causal", "cross_packed_keys", "cross_packed_both"])
+@pytest.mark.parametrize("pdrop", [0.0, 0.1])
+def test_fused_attention_on_packed_rows_equals_the_padded_layout(kind, pdrop):
+    """s2t_attn_fused_fwd / _bwd with ``cu_q`` / ``cu_k`` (include/s2t_hip.h "Packed rows"): utterance b's queries / keys start at
+    row cu[b] of a packed matrix instead of b * T.  The same values through both layouts give the same bits on every row that
+    holds a frame (and the same dropout mask: lse, delta and the mask index keep the padded strides): o, dq, dk, dv, the skewed
+    score gradient inside the written band and the rounded Q + pos_bias_v rows."""
+    from s2t_amd import rows as Rows
+
+    g = torch.Generator().manual_seed(len(kind) + int(pdrop * 100))
+    B, H, dk, bf = 5, 4, 64, torch.bfloat16
+    d = H * dk
+    rel, causal = kind == "self_rel", kind == "self_causal"
+    Tq = 61 if kind.startswith("cross") or causal else 250
+    Tk = Tq if kind.startswith("self") else 250
+    qlens = [61, 50, 33, 12, 1] if Tq == 61 else [250, 243, 180, 65, 9]
+    klens = qlens if kind.startswith("self") else [250, 243, 180, 65, 9]
+    halo = 7 if rel else 0
+    pack_q = kind != "cross_packed_keys"
+    ql = torch.tensor(qlens, dtype=torch.int32, device=DEV)
+    kl = ql if kind.startswith("self") else torch.tensor(klens, dtype=torch.int32, device=DEV)
+    if pack_q:
+        Rows.attach(ql, B, Tq, halo)
+    if kl is not ql:
+        Rows.attach(kl, B, Tk, 0)
+    q = (torch.randn(B * Tq, d, generator=g) * 0.7).to(bf).to(DEV)
+    k = (torch.randn(B * Tk, d, generator=g) * 0.7).to(bf).to(DEV)
+    v = (torch.randn(B * Tk, d, generator=g) * 0.7).to(bf).to(DEV)
+    dO = (torch.randn(B * Tq, d, generator=g) * 0.5).to(bf).to(DEV)
+    qmask = (torch.arange(Tq, device=DEV)[None, :] < ql[:, None]).reshape(-1)
+    kmask = (torch.arange(Tk, device=DEV)[None, :] < kl[:, None]).reshape(-1)
+    dO[~qmask] = 0  # padded queries carry no gradient (what the model's masks make of them)
+    pos = u = vb = None
+    if rel:
+        pos = (torch.randn(2 * Tq - 1, d, generator=g) * 0.7).to(bf).to(DEV)
+        u = (torch.randn(d, generator=g) * 0.3).to(DEV)
+        vb = (torch.randn(d, generator=g) * 0.3).to(DEV)
+    seed = torch.full((1,), 77, dtype=torch.int64, device=DEV)
+    drop = (pdrop, seed, 3) if pdrop > 0 else None
+    scale = 1.0 / math.sqrt(dk)
+    Z = B * H
+    ldb = (2 * Tq - 1 + 7) // 8 * 8
+
+    def run(packed):
+        qq = Rows.pack(q, ql) if (packed and pack_q) else q
+        kk = Rows.pack(k, kl) if packed else k
+        vv = Rows.pack(v, kl) if packed else v
+        dd = Rows.pack(dO, ql) if (packed and pack_q) else dO
+        qr = ql if (packed and pack_q) else None
+        kr = kl if packed else None
+        key_lens = kl if packed else Rows.detached(kl)
+        o = torch.zeros(B * Tq, d, dtype=bf, device=DEV)
+        lse = torch.zeros(Z, Tq, dtype=torch.float32, device=DEV)
+        K.attn_fused_fwd(qq, Tq * d, d, kk, Tk * d, d, vv, Tk * d, d, o, Tq * d, d, lse, B, H, Tq, Tk, dk, key_lens, causal, scale,
+                         pos, d if rel else 0, u, vb, drop, q_rows=qr, k_rows=kr)
+        delta = torch.zeros(Z, Tq, dtype=torch.float32, device=DEV)
+        dq = torch.zeros(B * Tq, d, dtype=bf, device=DEV)
+        dk_ = torch.zeros(B * Tk, d, dtype=bf, device=DEV)
+        dv = torch.zeros(B * Tk, d, dtype=bf, device=DEV)
+        dbd = torch.zeros(H, B, Tq, ldb, dtype=bf, device=DEV) if rel else None
+        qv = torch.zeros(B * Tq, d, dtype=bf, device=DEV) if rel else None
+        K.attn_fused_bwd(qq, Tq * d, d, kk, Tk * d, d, vv, Tk * d, d, o, dd, Tq * d, d, lse, delta, dq, dk_, dv, dbd, ldb, B, H,
+                         Tq, Tk, dk, key_lens, causal, scale, pos, d if rel else 0, u, vb, drop, dbd_band_only=rel, qv_out=qv,
+                         q_rows=qr, k_rows=kr)
+        torch.cuda.synchronize()
+        if packed:
+            if pack_q:
+                o, dq = Rows.unpack(o, ql), Rows.unpack(dq, ql)
+            dk_, dv = Rows.unpack(dk_, kl), Rows.unpack(dv, kl)
+        return o, dq, dk_, dv, dbd, qv, lse
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0][qmask], b[0][qmask]), "o"
+    assert torch.equal(a[1][qmask], b[1][qmask]), "dq"
+    assert torch.equal(a[2][kmask], b[2][kmask]), "dk"
+    assert torch.equal(a[3][kmask], b[3][kmask]), "dv"
+    lmask = qmask.view(B, Tq)[:, None, :].expand(B, H, Tq).reshape(Z, Tq)
+    assert torch.equal(a[6][lmask], b[6][lmask]), "lse"
+    assert float(b[0][qmask].float().abs().max()) > 0 and float(b[2][kmask].float().abs().max()) > 0
+    if rel:
+        assert torch.equal(a[5][qmask], b[5][qmask]), "q + pos_bias_v"
+        # the band of row i the packed pass wrote: columns T-1-i .. T-1-i+cap_b-1; inside it the two layouts agree
+        cap = torch.tensor([min(l + halo, Tq) for l in qlens], device=DEV)
+        ii = torch.arange(Tq, device=DEV)[None, :, None]
+        nn_ = torch.arange(ldb, device=DEV)[None, None, :]
+        written = (ii < cap[:, None, None]) & (nn_ >= Tq - 1 - ii) & (nn_ < Tq - 1 - ii + cap[:, None, None])
+        w4 = written[None].expand(H, B, Tq, ldb)
+        assert torch.equal(a[4][w4], b[4][w4]), "dbd"
