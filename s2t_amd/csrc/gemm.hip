@@ -25,6 +25,7 @@
 #include <utility>
 
 #include "gemm_common.h"
+#include "gemm256.h"
 
 #ifndef S2T_EPI_UNROLL
 #define S2T_EPI_UNROLL 2  // tile pairs per copy of the fused epilogue code (1, 2, 4 or 8); measured on the training
@@ -745,6 +746,8 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
     }
   }
   hipStream_t s = (hipStream_t)stream;
+  if (s2t_gemm256_eligible(p))
+    return s2t_gemm256_launch(p, p.c_dtype == S2T_F32 ? epilogue_vectorisable<float>(p, p.N) : epilogue_vectorisable<bf16_t>(p, p.N), s);
   if (p.dtype == S2T_F32) return launch<float, float>(p, s);
   if (p.c_dtype == S2T_F32 || p.ws) return launch<bf16_t, float>(p, s);  // (the partial tiles are fp32)
   return launch<bf16_t, bf16_t>(p, s);
@@ -767,6 +770,16 @@ extern "C" int s2t_gemm_describe(const s2t_gemm_args* a, char* buf, int buflen) 
   const bool kt = (a->K % (f32 ? 32 : 64)) != 0;
   const bool vec = cf32 ? epilogue_vectorisable<float>(*a, nout) : epilogue_vectorisable<bf16_t>(*a, nout);
   const bool ak = a->a_kmajor != 0, bk = a->b_kmajor != 0;
+  {
+    s2t_gemm_args q = *a;  // (the normalisation s2t_gemm applies before it asks)
+    if (q.batch <= 0) q.batch = 1;
+    if (q.split_k <= 0) q.split_k = 1;
+    if (q.split_k == 1 || q.c_atomic != 2) q.ws = nullptr;
+    if (q.split_k == 1 && s2t_gemm256_eligible(q)) {
+      const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s>", cf32 ? "float" : "unsigned short", vec ? "true" : "false");
+      return (n > 0 && n < buflen) ? S2T_OK : S2T_ERR_ARG;
+    }
+  }
   const char* t = f32 ? "float" : "unsigned short";
   const char* tc = cf32 ? "float" : "unsigned short";
   auto b = [](bool v) { return v ? "true" : "false"; };

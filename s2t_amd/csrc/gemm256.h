@@ -1,0 +1,8 @@
+// The 256 x 256 LDS-DMA path of s2t_gemm (gemm256.hip), as gemm.hip's dispatcher sees it.
+#pragma once
+#include "common.h"
+
+// true when `p` (already normalised by s2t_gemm: batch / split_k >= 1, p.ws cleared when unused) runs on the large-tile kernel
+bool s2t_gemm256_eligible(const s2t_gemm_args& p);
+// vec: every tensor of the epilogue is 16-byte aligned with N % 8 == 0 (gemm.hip, epilogue_vectorisable)
+int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s);

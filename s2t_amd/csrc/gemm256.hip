@@ -1,0 +1,367 @@
+// s2t_gemm's large-tile path for gfx950: C[M][N] = epilogue(A[M][K] . B[N][K]^T), bf16 operands, both row-major (the layout of
+// every Linear forward: modules/s2t_transformer_layer.py:55-66, modules/multihead_attention.py:161-300, modules/speech_to_text/
+// ctc.py:55-66), K a multiple of 64.
+//
+// Why a second kernel (measured on the 128 x 128, register-staged kernel of gemm.hip): a K-step there moves 32 KB through
+// ds_write_b128 (13 LDS cycles per wave-instruction) and re-fetches every operand slab once per 128-wide tile; the structure
+// tops out near 700 TFLOP/s.  Here
+//   * the tile is 256 x 256 x 64 per 512-thread workgroup (one per CU, 128 KiB of LDS): half the operand bytes per flop;
+//   * both operands go global -> LDS by LDS-DMA (buffer_load ... lds, no staging registers, no ds_write), double buffered:
+//     step s + 1 is in flight while step s is multiplied — across tile boundaries, so the next tile's first step lands during
+//     this tile's epilogue; ONE raw barrier per K-step, counted waits (the compiler does not see the DMAs);
+//   * the LDS image of an operand is [256 rows][128 B], 16-byte piece c of row r at r*128 + 16*(c ^ ((r >> 1) & 7)): the
+//     swizzle is applied to the DMA's per-lane SOURCE address (the LDS destination of a DMA is lane-linear) and again to the
+//     fragment reads, which are then conflict-free ds_read_b128;
+//   * eight waves as 2 (M) x 4 (N), 128 x 64 of C per wave = 8 x 4 v_mfma_f32_16x16x32_bf16 tiles (128 accumulator registers).
+//     The MFMA is issued with B as its first operand (D rows = n), and the B image holds its rows PERMUTED inside groups of
+//     32 (LDS row 16 t + i of a group = B row 8 (i >> 2) + 4 t + (i & 3)), so that the accumulators of an even / odd tile pair
+//     of a lane are 8 CONSECUTIVE output columns of one row: the fused epilogue (gemm_common.h, Epi) runs on the registers as
+//     they stand, 16-byte bf16 stores, no transposition through LDS;
+//   * persistent walk, XCD aware: workgroup w runs on XCD w & 7 (round-robin placement: speed only); an XCD owns whole row
+//     blocks and its 32 workgroups take the column tiles of a row block side by side, so an A slab is fetched into ONE L2.
+#include "gemm_common.h"
+#include "lds_dma.h"
+#include "gemm256.h"
+
+#ifndef S2T_G256_DBG
+#define S2T_G256_DBG 0  // experiment switches (never in a shipped build): 1 no DMA in the loop, 2 no MFMAs, 4 no epilogue
+#endif
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int OP_BYTES = 32768;          // one operand image of a K-step
+constexpr int STAGE_BYTES = 2 * OP_BYTES;
+constexpr int G256_LDS = 2 * STAGE_BYTES;
+
+// s_waitcnt immediate of gfx9: vmcnt = bits 3:0 | 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8 (15 = no wait)
+constexpr int wait_vm(int vm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (15 << 8); }
+
+struct Tile {
+  int ord, tm, tn;
+};
+
+template <typename TC, bool VEC>
+__global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
+  __shared__ __attribute__((aligned(16))) char smem[G256_LDS];
+  s2t_gemm_args p = p0;
+  p.M = (int)s2t_live_rows(p0.row_lens, p0.row_T, p0.M);  // packed batch: the row blocks beyond the live rows are never walked
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int x = lane & 15, y = lane >> 4;
+
+  const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TN - 1) / TN;
+  // ---- which tiles: XCD xc owns row blocks xc, xc + 8, ...; its workgroups (slots) take that list's tiles column-fastest
+  const int G = gridDim.x;
+  int xc = 0, slot = blockIdx.x, nslots = G, nx = 1;
+  if ((G & 7) == 0) {
+    xc = blockIdx.x & 7;
+    slot = blockIdx.x >> 3;
+    nslots = G >> 3;
+    nx = 8;
+  }
+  const int my_rows = tiles_m > xc ? (tiles_m - xc + nx - 1) / nx : 0;
+  const int local_tiles = my_rows * tiles_n;
+  if (slot >= local_tiles) return;
+  const int my_tiles = (local_tiles - slot + nslots - 1) / nslots;
+  const int nk = p.K / TK;
+  const int S = my_tiles * nk;
+  auto tile_at = [&](int ord) __attribute__((always_inline)) {
+    const int l = slot + ord * nslots;
+    const int r = l / tiles_n;
+    return Tile{ord, r * nx + xc, l - r * tiles_n};
+  };
+
+  // ---- DMA plan.  A K-step's operand image is 32 one-KiB pieces (8 rows each); wave w issues pieces 4 w .. 4 w + 3 of A and of
+  // B.  Lane l of piece q lands at row 8 q + (l >> 3), slot l & 7, and therefore FETCHES k-piece (l & 7) ^ swz(row) of the
+  // operand row that belongs there.
+  const i32x4 srdA = make_srd(p.A, (uint32_t)(((int64_t)(p0.M - 1) * p.lda + p.K) * 2));
+  const i32x4 srdB = make_srd(p.B, (uint32_t)(((int64_t)(p.N - 1) * p.ldb + p.K) * 2));
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t lda2 = (uint32_t)(p.lda * 2), ldb2 = (uint32_t)(p.ldb * 2);
+  uint32_t va[4], vb[4];
+  auto plan = [&](const Tile& t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rho = 32 * wave + 8 * q + (lane >> 3);
+      const uint32_t piece = (uint32_t)(16 * ((lane & 7) ^ ((rho >> 1) & 7)));
+      const int ga = min(t.tm * TM + rho, p.M - 1);  // rows / columns beyond the problem: a clamped duplicate, never stored
+      const int i_ = rho & 15, tau = (rho >> 4) & 1;
+      const int gb = min(t.tn * TN + (rho & ~31) + 8 * (i_ >> 2) + 4 * tau + (i_ & 3), p.N - 1);
+      va[q] = (uint32_t)ga * lda2 + piece;
+      vb[q] = (uint32_t)gb * ldb2 + piece;
+    }
+  };
+  auto piece_out = [&](int q, int kt, int stage) __attribute__((always_inline)) {
+#if !(S2T_G256_DBG & 1)
+    const uint32_t dst = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)((4 * wave + (q & 3)) * 1024);
+    if (q < 4) dma16(dst, va[q], srdA, (uint32_t)(kt * (TK * 2)));
+    else dma16(dst + OP_BYTES, vb[q - 4], srdB, (uint32_t)(kt * (TK * 2)));
+#endif
+  };
+
+  f32x4 acc[8][4];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+
+  // fragment addresses: row 16 i + x of the wave's rows, k-piece 4 ks + y -> slot (4 ks + y) ^ (x >> 1)  ((row >> 1) & 7 = x >> 1)
+  const uint32_t lo0 = (uint32_t)(x * 128 + 16 * (y ^ (x >> 1)));
+  const char* const fa0 = smem + wm * (128 * 128) + lo0;
+  const char* const fb0 = smem + OP_BYTES + wn * (64 * 128) + lo0;
+
+  auto multiply = [&](int stage, auto&& side) __attribute__((always_inline)) {
+    const char* la = fa0 + stage * STAGE_BYTES;
+    const char* lb = fb0 + stage * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // (x*128 + 16*((4+y) ^ (x>>1))) = lo0 ^ 64
+      const int kx = ks ? (int)((lo0 ^ 64u) - lo0) : 0;
+      uint4 fb[4], fa[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(lb + j * 2048 + kx);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const uint4*>(la + i * 2048 + kx);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#if S2T_G256_DBG & 2
+          asm volatile("" :: "v"(fb[j]), "v"(fa[i]));
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]),
+                                                               acc[i][j], 0, 0, 0);
+#endif
+        }
+        if (i & 1) side(ks * 4 + (i >> 1));
+      }
+    }
+  };
+
+  // ---- epilogue of tile (tm, tn): lane (x, y) holds, for row block i and tile pair jp, columns 32 jp + 8 y .. + 7 of row
+  // 16 i + x of the wave's 128 x 64.  Two row blocks (four 8-column pieces) per trip on static accumulator indices, then the
+  // rest shifts down.  Same arithmetic, in the same order, as Epi::finish (gemm_common.h) — the results of the two GEMM paths
+  // are equal bit for bit — but the operand rows of a trip (residual, act' input) are fetched side by side before any of them
+  // is used, and the switches (activation, dropout, mask) branch once per trip, not once per value.
+  auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
+#if !(S2T_G256_DBG & 4)
+    Epi<TC, VEC> e{p,
+                   reinterpret_cast<TC*>(p.C),
+                   p.residual ? reinterpret_cast<const TC*>(p.residual) : nullptr,
+                   p.preact ? reinterpret_cast<TC*>(p.preact) : nullptr,
+                   p.dact_z ? reinterpret_cast<const TC*>(p.dact_z) : nullptr,
+                   p.N,
+                   false, false, false, false};
+    if constexpr (!VEC) {
+      auto vec_ok = [](const void* ptr, int64_t ld) { return ((ld * (int64_t)sizeof(TC)) % 16 == 0) && (((uintptr_t)ptr) % 16 == 0); };
+      e.vec_c = vec_ok(e.C, p.ldc);
+      e.vec_r = e.R && vec_ok(e.R, p.ldr);
+      e.vec_p = e.P && vec_ok(e.P, p.ldp);
+      e.vec_z = e.Z && vec_ok(e.Z, p.ldz);
+    }
+    float bpre[2][8];
+    int ncol[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      ncol[jp] = t.tn * TN + wn * 64 + 32 * jp + 8 * y;
+      const int nvb = max(0, min(8, p.N - ncol[jp]));
+      e.bias8(nvb > 0 ? ncol[jp] : 0, nvb, bpre[jp]);
+    }
+    const bool has_act = p.act == S2T_ACT_RELU || p.act == S2T_ACT_SWISH;
+    const bool drop = p.drop_p > 0.f;
+    const uint64_t dkey = drop ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
+    const uint32_t dth = s2t_drop_thresh(p.drop_p);
+    const float dinv = s2t_drop_scale(p.drop_p);
+    f32x4 (&af)[32] = reinterpret_cast<f32x4 (&)[32]>(acc);
+#pragma unroll 1
+    for (int i2 = 0; i2 < 4; ++i2) {
+      if constexpr (VEC) {
+        // (two pieces — one row block — at a time: four would need 96 registers of operands beside the 128 accumulators)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = t.tm * TM + wm * 128 + (2 * i2 + h) * 16 + x;
+          bool ok[2];
+          float v[2][8], q[2][8], zz[2][8];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) ok[c] = m < p.M && ncol[c] < p.N;
+          if (e.R) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              if (ok[c]) ld8<TC>(e.R + (int64_t)m * p.ldr + ncol[c], true, 8, q[c]);
+          }
+          if (e.Z) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              if (ok[c]) ld8<TC>(e.Z + (int64_t)m * p.ldz + ncol[c], true, 8, zz[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const f32x4 t0 = af[4 * h + 2 * c], t1 = af[4 * h + 2 * c + 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[c][r] = t0[r] + bpre[c][r];
+              v[c][4 + r] = t1[r] + bpre[c][4 + r];
+            }
+          }
+          if (has_act) {
+            if (e.P) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                if (ok[c]) st8<TC>(e.P + (int64_t)m * p.ldp + ncol[c], true, 8, v[c]);
+            }
+            if (p.act == S2T_ACT_RELU) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[c][r] = v[c][r] > 0.f ? v[c][r] : 0.f;
+            } else {
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[c][r] = v[c][r] * sigmoidf_(v[c][r]);
+            }
+          }
+          if (e.Z) {
+            if (p.dact == S2T_ACT_RELU) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[c][r] *= zz[c][r] > 0.f ? 1.f : 0.f;
+            } else if (p.dact == S2T_ACT_SWISH) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[c][r] *= act_grad(S2T_ACT_SWISH, zz[c][r]);
+            }
+          }
+          if (drop) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              uint32_t r16[8];
+              s2t_rand_run<8>(dkey, (uint64_t)m * (uint64_t)p.N + (uint64_t)ncol[c], r16);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[c][r] = r16[r] >= dth ? v[c][r] * dinv : 0.f;
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[c][r] *= p.alpha;
+          if (p.row_lens && m < p.M && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)m)) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[0][r] = v[1][r] = 0.f;
+          }
+          if (e.R) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[c][r] += ok[c] ? q[c][r] : 0.f;
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            if (ok[c]) st8<TC>(e.C + (int64_t)m * p.ldc + ncol[c], true, 8, v[c]);
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = t.tm * TM + wm * 128 + (2 * i2 + h) * 16 + x;
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const f32x4 t0 = af[4 * h + 2 * jp], t1 = af[4 * h + 2 * jp + 1];
+            float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            if (m < p.M && ncol[jp] < p.N) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] += bpre[jp][r];
+              e.finish(m, ncol[jp], (int64_t)m, v);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 24; ++k) af[k] = af[k + 8];
+    }
+#endif
+  };
+
+  // ---- the walk: step s multiplies LDS stage s & 1 while step s + 1 lands in the other
+  Tile L = tile_at(0);  // tile of the step being FETCHED
+  int lkt = 0;
+  plan(L);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) piece_out(q, 0, 0);
+  auto advance_fetch = [&]() __attribute__((always_inline)) {
+    if (lkt + 1 < nk) {
+      ++lkt;
+    } else {
+      L = tile_at(L.ord + 1);
+      lkt = 0;
+      plan(L);
+    }
+  };
+  Tile C = L;           // tile of the step being multiplied
+  int ckt = 0;
+  for (int s = 0; s < S; ++s) {
+    const bool more = s + 1 < S;
+    if (more) advance_fetch();
+    // this wave's pieces of step s have landed (and its epilogue stores, if any, have left); behind the barrier everybody's
+    // have, and everybody has finished reading the other stage
+    __builtin_amdgcn_s_waitcnt(wait_vm(0));
+    asm volatile("s_barrier" ::: "memory");
+    // (the last step fetches itself once more into the idle stage: an unconditional piece keeps the MFMA stream free of branches)
+    multiply(s & 1, [&](int q) __attribute__((always_inline)) { piece_out(q, lkt, (s & 1) ^ 1); });
+    if (ckt + 1 == nk) {
+      epilogue(C);
+      if (!more) break;
+      zero_acc();
+      C = tile_at(C.ord + 1);
+      ckt = 0;
+    } else {
+      ++ckt;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(wait_vm(0));  // no DMA may still be writing this workgroup's LDS when it is handed on
+}
+
+}  // namespace
+
+// ---- host side (called by s2t_gemm) ---------------------------------------------------------------------------------
+// S2T_GEMM256 / s2t_gemm_configure: 0 never, 1 (default) where it measured faster, 2 whenever the arguments allow
+static int& g256_mode_ref() {
+  static int mode = [] { const char* e = getenv("S2T_GEMM256"); return e ? atoi(e) : 1; }();
+  return mode;
+}
+static int g256_mode() { return g256_mode_ref(); }
+
+extern "C" int s2t_gemm_configure(int large_tile_mode) {
+  if (large_tile_mode >= 0) g256_mode_ref() = large_tile_mode > 2 ? 2 : large_tile_mode;
+  return g256_mode_ref();
+}
+
+bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
+  const int mode = g256_mode();
+  if (mode <= 0) return false;
+  if (p.dtype != S2T_BF16 || p.a_kmajor || p.b_kmajor || p.act == S2T_ACT_GLU) return false;
+  if (p.batch > 1 || p.split_k > 1 || p.c_atomic || p.colsum_a || p.ws) return false;
+  if (p.K < 128 || (p.K % TK)) return false;
+  if (mode >= 2) return true;
+  const int64_t tiles = (int64_t)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
+  return tiles >= 192;
+}
+
+int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
+  const dim3 grid(s2t_device_cu_count()), block(512);
+  if (p.c_dtype == S2T_F32) {
+    if (vec) hipLaunchKernelGGL((gemm256_kernel<float, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<float, false>), grid, block, 0, s, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((gemm256_kernel<bf16_t, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<bf16_t, false>), grid, block, 0, s, p);
+  }
+  return S2T_LAUNCH_CHECK();
+}

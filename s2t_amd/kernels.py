@@ -81,6 +81,12 @@ def gemm_symbol(args):
     return buf.value.decode()
 
 
+def gemm_configure(large_tile=None):
+    """s2t_gemm_configure: 0 never / 1 automatic / 2 always (where the arguments allow) for the 256 x 256 LDS-DMA path of
+    s2t_gemm; None leaves the switch as it is.  Returns the mode in force."""
+    return int(L.lib().s2t_gemm_configure(-1 if large_tile is None else int(large_tile)))
+
+
 def gemm(
     A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int,
     lda: int, ldb: int, ldc: int, a_kmajor=False, b_kmajor=False,

@@ -326,3 +326,143 @@ def test_overwrite_splitk_without_a_workspace_runs_as_one_pass():
         torch.cuda.synchronize()
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- the 256 x 256 LDS-DMA path (gemm256.hip): bf16, row-major A and B, K % 64 == 0 ----------------------------------------
+class _large_tile:
+    """Pin s2t_gemm's large-tile switch for a block (s2t_gemm_configure): 0 never, 2 whenever the arguments allow."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = ops.gemm_configure()
+        ops.gemm_configure(self.mode)
+
+    def __exit__(self, *a):
+        ops.gemm_configure(self.prev)
+
+
+def _both_paths(call):
+    outs = []
+    for mode in (0, 2):
+        with _large_tile(mode):
+            outs.append(call())
+    torch.cuda.synchronize()
+    return outs
+
+
+@pytest.mark.parametrize("M,N,K,ldpad", [(256, 256, 128, 0), (1000, 520, 192, 0), (513, 264, 64 * 5, 8), (4100, 777 * 8, 256, 0),
+                                         (16000, 768, 256, 0), (257, 10000, 512, 0)])
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_large_tile_plain(M, N, K, ldpad, cdt):
+    """Ragged M and N (clamped duplicate rows / columns are never stored), padded leading dimensions, both output types: equal to
+    the 128 x 128 path bit for bit (same MFMA, same order over K) and to a float64 product within bf16 rounding."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dev = "cuda"
+    lda, ldb, ldc = K + ldpad, K + 2 * ldpad, N + ldpad
+    A = torch.full((M, lda), float("nan"), dtype=torch.bfloat16); A[:, :K] = _mk((M, K), torch.bfloat16, g)
+    W = torch.full((N, ldb), float("nan"), dtype=torch.bfloat16); W[:, :K] = _mk((N, K), torch.bfloat16, g, K ** -0.5)
+    Ad, Wd = A.to(dev), W.to(dev)
+
+    def call():
+        out = torch.full((M, ldc), 7.0, dtype=cdt, device=dev)
+        ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc)
+        return out
+
+    with _large_tile(2):
+        assert "gemm256_kernel" in ops.gemm_symbol(_gemm_args(Ad, Wd, call(), M, N, K, lda, ldb, ldc))
+    old, new = _both_paths(call)
+    assert torch.equal(old, new)
+    if ldpad:
+        assert (new[:, N:] == 7.0).all(), "wrote outside the N columns"
+    if M * N <= 4100 * 6216:
+        ref = A[:, :K].double() @ W[:, :K].double().t()
+        np.testing.assert_allclose(new[:, :N].cpu().double().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2 * ref.abs().max().item())
+
+
+def _gemm_args(A, B, out, M, N, K, lda, ldb, ldc):
+    from s2t_amd import _lib as L
+    a = L.GemmArgs()
+    a.dtype, a.c_dtype = L.dtype_id(A.dtype), L.dtype_id(out.dtype)
+    a.M, a.N, a.K = M, N, K
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc
+    a.batch = a.zdiv = a.split_k = 1
+    return a
+
+
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_large_tile_epilogue(cdt):
+    """Every epilogue stage on the large tile against the 128 x 128 path (bit for bit: both follow Epi::finish's order) and a
+    float64 restatement: bias, pre-activation copy, ReLU / swish, act'(z), dropout (the same counter-based mask), alpha, the
+    padded-frame mask in both row geometries, residual."""
+    g = torch.Generator().manual_seed(11)
+    dev = "cuda"
+    B_, T, K, N = 5, 150, 256, 520
+    M = B_ * T
+    A = _mk((M, K), torch.bfloat16, g).to(dev); W = _mk((N, K), torch.bfloat16, g, K ** -0.5).to(dev)
+    bias = _mk((N,), torch.float32, g).to(dev)
+    R = _mk((M, N), cdt, g).to(dev)
+    Z = _mk((M, N), cdt, g).to(dev)
+    lens = torch.tensor([150, 31, 7, 149, 1], dtype=torch.int32, device=dev)
+    seed = torch.tensor([1234], dtype=torch.int64, device=dev)
+    mask = (torch.arange(T, device=dev)[None, :] >= lens[:, None]).reshape(-1)
+    for act in ("relu", "swish", None):
+        def call():
+            out = torch.empty(M, N, dtype=cdt, device=dev)
+            pre = torch.zeros(M, N, dtype=cdt, device=dev)
+            ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, alpha=0.5, residual=R, ldr=N,
+                     preact=pre if act else None, ldp=N, row_lens=lens, row_T=T)
+            return torch.cat([out, pre])
+        old, new = _both_paths(call)
+        assert torch.equal(old, new), act
+        z = A.double() @ W.double().t() + bias.double()
+        a = {"relu": torch.relu, "swish": lambda v: v * torch.sigmoid(v), None: lambda v: v}[act](z)
+        br = 0.5 * a
+        br[mask] = 0
+        ref = R.double() + br
+        np.testing.assert_allclose(new[:M].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=4e-2)
+        if act:
+            np.testing.assert_allclose(new[M:].double().cpu().numpy(), z.cpu().numpy(), rtol=1e-2, atol=4e-2)
+    for dact in ("relu", "swish"):
+        def call():
+            out = torch.empty(M, N, dtype=cdt, device=dev)
+            ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dact_z=Z, ldz=N, dact=dact, drop=(0.25, seed, 3))
+            return out
+        old, new = _both_paths(call)
+        assert torch.equal(old, new), dact
+        zd = Z.double()
+        d = (zd > 0).double() if dact == "relu" else torch.sigmoid(zd) * (1 + zd * (1 - torch.sigmoid(zd)))
+        keep = (new[d != 0] != 0).double().mean().item()
+        assert 0.72 < keep < 0.78
+        ref = (A.double() @ W.double().t()) * d / 0.75
+        got = new.double()
+        kept = got != 0
+        np.testing.assert_allclose(got[kept].cpu().numpy(), ref[kept].cpu().numpy(), rtol=1e-2, atol=4e-2)
+
+
+def test_large_tile_packed_rows():
+    """row_T = S2T_ROWS_PACKED: the live row count is read on the device (row blocks beyond it are never walked, rows beyond it
+    never stored) and halo rows come out zero — as on the 128 x 128 path."""
+    from s2t_amd import rows as Rows
+    dev = "cuda"
+    g = torch.Generator().manual_seed(3)
+    B_, T, K, N = 40, 120, 256, 768
+    lens = torch.randint(20, T + 1, (B_,), generator=g).to(torch.int32).to(dev)
+    Rows.attach(lens, B_, T, 7, tag="test_large_tile")
+    M = B_ * T
+    live = lens._pk.live_rows()
+    assert live < M - 300
+    A = _mk((M, K), torch.bfloat16, g).to(dev); W = _mk((N, K), torch.bfloat16, g, K ** -0.5).to(dev)
+
+    def call():
+        out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, row_lens=lens, row_T=T)
+        return out
+    old, new = _both_paths(call)
+    assert torch.equal(old, new)
+    assert (new[live:] == 7.0).all()
+    m = lens._pk.row_map[:live]
+    assert (new[:live][m < 0] == 0).all()
+    ref = (A[:live].float() @ W.float().t())
+    np.testing.assert_allclose(new[:live][m >= 0].float().cpu().numpy(), ref[m >= 0].cpu().numpy(), rtol=1e-2, atol=4e-2)

@@ -95,7 +95,7 @@ if "5a" in which:
     m = M.S2TCTCModel.build_model(a, task).prepare(torch.bfloat16, dev)
     m.encoder.ctc_out_dtype = torch.float32
     greedy_cfg("5a", m, 256, 1000, torch.bfloat16)
-if "5b" in which:
+if "5b" in which or "5bg" in which:  # 5bg: the greedy pass only (profiling)
     nast = dict(encoder_type="sate", text_encoder_layers=12, acoustic_encoder="transformer", adapter="inter_league",
                 xctc_weight=1.0, ctc_weight=1.0, share_ctc_and_embed=True, share_xctc_and_embed=True, text_no_pos_emb=True,
                 textual_encoder_embed_norm=False, textual_encoder_no_scale_embedding=True, encoder_normalize_before=True,
@@ -110,6 +110,8 @@ if "5b" in which:
     print("5b   params %.1f M" % (m.flat.master.numel() / 1e6), flush=True)
     m.encoder.acoustic_encoder.ctc_out_dtype = torch.float32
     greedy_cfg("5b", m, 256, 1000, torch.bfloat16)
+    if "5b" not in which:
+        sys.exit(0)
     m.encoder.acoustic_encoder.ctc_out_dtype = None
     m.train()
     crit = C.CtcCriterion(None, task, ctc_weight=1.0, inter_ctc_weight=1.0, xctc_weight=1.0, inter_xctc_weight=1.0)
