@@ -775,10 +775,7 @@ extern "C" int s2t_gemm_describe(const s2t_gemm_args* a, char* buf, int buflen) 
     if (q.batch <= 0) q.batch = 1;
     if (q.split_k <= 0) q.split_k = 1;
     if (q.split_k == 1 || q.c_atomic != 2) q.ws = nullptr;
-    if (q.split_k == 1 && s2t_gemm256_eligible(q)) {
-      const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s>", cf32 ? "float" : "unsigned short", vec ? "true" : "false");
-      return (n > 0 && n < buflen) ? S2T_OK : S2T_ERR_ARG;
-    }
+    if (q.split_k == 1 && s2t_gemm256_eligible(q)) return s2t_gemm256_describe(q, vec, buf, buflen);
   }
   const char* t = f32 ? "float" : "unsigned short";
   const char* tc = cf32 ? "float" : "unsigned short";

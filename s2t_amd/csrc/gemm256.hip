@@ -19,12 +19,17 @@
 //     they stand, 16-byte bf16 stores, no transposition through LDS;
 //   * persistent walk, XCD aware: workgroup w runs on XCD w & 7 (round-robin placement: speed only); an XCD owns whole row
 //     blocks and its 32 workgroups take the column tiles of a row block side by side, so an A slab is fetched into ONE L2.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "gemm_common.h"
 #include "lds_dma.h"
 #include "gemm256.h"
 
+#include <type_traits>
+
 #ifndef S2T_G256_DBG
-#define S2T_G256_DBG 0  // experiment switches (never in a shipped build): 1 no DMA in the loop, 2 no MFMAs, 4 no epilogue
+#define S2T_G256_DBG 0  // experiment switches (never in a shipped build): 1 no DMA in the loop, 2 no MFMAs, 4 no epilogue, 8 every C store dropped
 #endif
 
 namespace {
@@ -41,7 +46,9 @@ struct Tile {
   int ord, tm, tn;
 };
 
-template <typename TC, bool VEC>
+// VEC: every tensor of the epilogue 16-byte aligned, N % 8 == 0.  PLAIN (needs VEC): the epilogue is bias / activation / alpha /
+// residual only (two forms in one kernel made the compiler spill the accumulators where they merge).
+template <typename TC, bool VEC, bool PLAIN>
 __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   __shared__ __attribute__((aligned(16))) char smem[G256_LDS];
   s2t_gemm_args p = p0;
@@ -97,8 +104,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   auto piece_out = [&](int q, int kt, int stage) __attribute__((always_inline)) {
 #if !(S2T_G256_DBG & 1)
     const uint32_t dst = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)((4 * wave + (q & 3)) * 1024);
-    if (q < 4) dma16(dst, va[q], srdA, (uint32_t)(kt * (TK * 2)));
-    else dma16(dst + OP_BYTES, vb[q - 4], srdB, (uint32_t)(kt * (TK * 2)));
+#ifndef S2T_G256_NT
+#define S2T_G256_NT 0  // bit 0: A pieces non-temporal, bit 1: B pieces
+#endif
+    if (q < 4) {
+      if (S2T_G256_NT & 1) dma16_nt(dst, va[q], srdA, (uint32_t)(kt * (TK * 2)));
+      else dma16(dst, va[q], srdA, (uint32_t)(kt * (TK * 2)));
+    } else {
+      if (S2T_G256_NT & 2) dma16_nt(dst + OP_BYTES, vb[q - 4], srdB, (uint32_t)(kt * (TK * 2)));
+      else dma16(dst + OP_BYTES, vb[q - 4], srdB, (uint32_t)(kt * (TK * 2)));
+    }
 #endif
   };
 
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   const char* const fa0 = smem + wm * (128 * 128) + lo0;
   const char* const fb0 = smem + OP_BYTES + wn * (64 * 128) + lo0;
 
-  auto multiply = [&](int stage, auto&& side) __attribute__((always_inline)) {
+  auto multiply = [&](int stage, int DKS, auto&& side) __attribute__((always_inline)) {
     const char* la = fa0 + stage * STAGE_BYTES;
     const char* lb = fb0 + stage * STAGE_BYTES;
 #pragma unroll
@@ -133,24 +148,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #if S2T_G256_DBG & 2
-          asm volatile("" :: "v"(fb[j]), "v"(fa[i]));
+          asm volatile("" :: "v"(fb[j].x), "v"(fb[j].w), "v"(fa[i].x), "v"(fa[i].w));
 #else
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]),
                                                                acc[i][j], 0, 0, 0);
 #endif
         }
-        if (i & 1) side(ks * 4 + (i >> 1));
+        // The eight pieces of the next step go out behind the MFMA groups of ONE half of this step.  A wave is parked for ~100+
+        // cycles per piece (the CU's vector-memory path takes 64 pieces a step at ~34 B/clk: in-kernel stamps, tools/g256_stamps.py)
+        // and issues no MFMA meanwhile, so the two waves of a SIMD (w and w + 4) take DIFFERENT halves: one multiplies while
+        // the other is parked.
+        if (ks == DKS) side(i);
       }
     }
   };
 
   // ---- epilogue of tile (tm, tn): lane (x, y) holds, for row block i and tile pair jp, columns 32 jp + 8 y .. + 7 of row
-  // 16 i + x of the wave's 128 x 64.  Two row blocks (four 8-column pieces) per trip on static accumulator indices, then the
-  // rest shifts down.  Same arithmetic, in the same order, as Epi::finish (gemm_common.h) — the results of the two GEMM paths
-  // are equal bit for bit — but the operand rows of a trip (residual, act' input) are fetched side by side before any of them
-  // is used, and the switches (activation, dropout, mask) branch once per trip, not once per value.
+  // 16 i + x of the wave's 128 x 64.  Same arithmetic, in the same order, as Epi::finish (gemm_common.h) — the results of the two
+  // GEMM paths are equal bit for bit.  The epilogue is VALU-issue bound (in-kernel stamps: 8.5 k cycles per tile for the general
+  // form, against 2 k for a K-step), so the common case — bias, activation, alpha, residual — has its own fully unrolled form on
+  // static accumulator indices; the general form (act' input, dropout, pre-activation copy, padded-frame mask) walks two row
+  // blocks per trip and shifts the remaining accumulators down (one copy of the long code).
   auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
-#if !(S2T_G256_DBG & 4)
+#if S2T_G256_DBG & 4
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+#else
     Epi<TC, VEC> e{p,
                    reinterpret_cast<TC*>(p.C),
                    p.residual ? reinterpret_cast<const TC*>(p.residual) : nullptr,
@@ -173,121 +198,204 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
       const int nvb = max(0, min(8, p.N - ncol[jp]));
       e.bias8(nvb > 0 ? ncol[jp] : 0, nvb, bpre[jp]);
     }
+    // C leaves through a raw buffer descriptor: a piece outside the problem gets an offset beyond the descriptor's range and is
+    // dropped by the hardware, so every lane ISSUES the same number of stores — the wait at the top of the next step can then
+    // leave exactly those in flight
+    const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(
+        p.C, 0, (int)(uint32_t)(((int64_t)(p.M - 1) * p.ldc + p.N) * (int64_t)sizeof(TC)), 0x00020000);
+    auto store8 = [&](bool ok, int m, int n, const float (&v)[8]) __attribute__((always_inline)) {
+#if S2T_G256_DBG & 8
+      const uint32_t off = 0xfffffff0u;
+      asm volatile("" :: "v"(ok), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+#else
+      const uint32_t off = ok ? (uint32_t)(((int64_t)m * p.ldc + n) * (int64_t)sizeof(TC)) : 0xfffffff0u;
+#endif
+      if constexpr (sizeof(TC) == 2) {
+        __builtin_amdgcn_raw_buffer_store_b128(
+            (u32x4_t){bf16pack(v[0], v[1]), bf16pack(v[2], v[3]), bf16pack(v[4], v[5]), bf16pack(v[6], v[7])}, csrd, off, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                        __float_as_uint(v[3])}, csrd, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]),
+                                                        __float_as_uint(v[7])}, csrd, ok ? off + 16u : 0xfffffff0u, 0, 0);
+      }
+    };
     const bool has_act = p.act == S2T_ACT_RELU || p.act == S2T_ACT_SWISH;
     const bool drop = p.drop_p > 0.f;
-    const uint64_t dkey = drop ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
-    const uint32_t dth = s2t_drop_thresh(p.drop_p);
-    const float dinv = s2t_drop_scale(p.drop_p);
-    f32x4 (&af)[32] = reinterpret_cast<f32x4 (&)[32]>(acc);
-#pragma unroll 1
-    for (int i2 = 0; i2 < 4; ++i2) {
-      if constexpr (VEC) {
-        // (two pieces — one row block — at a time: four would need 96 registers of operands beside the 128 accumulators)
+    if constexpr (PLAIN) {
+      const bool scale = p.alpha != 1.0f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int m = t.tm * TM + wm * 128 + (2 * i2 + h) * 16 + x;
-          bool ok[2];
-          float v[2][8], q[2][8], zz[2][8];
+      for (int i = 0; i < 8; ++i) {
+        const int m = t.tm * TM + wm * 128 + i * 16 + x;
+        bool ok[2];
+        float v[2][8], q[2][8];
 #pragma unroll
-          for (int c = 0; c < 2; ++c) ok[c] = m < p.M && ncol[c] < p.N;
-          if (e.R) {
+        for (int c = 0; c < 2; ++c) ok[c] = m < p.M && ncol[c] < p.N;
+        if (e.R) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-              if (ok[c]) ld8<TC>(e.R + (int64_t)m * p.ldr + ncol[c], true, 8, q[c]);
+          for (int c = 0; c < 2; ++c)
+            if (ok[c]) ld8<TC>(e.R + (int64_t)m * p.ldr + ncol[c], true, 8, q[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[c][r] = acc[i][2 * c][r] + bpre[c][r];
+            v[c][4 + r] = acc[i][2 * c + 1][r] + bpre[c][4 + r];
           }
-          if (e.Z) {
+        if (p.act == S2T_ACT_RELU) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-              if (ok[c]) ld8<TC>(e.Z + (int64_t)m * p.ldz + ncol[c], true, 8, zz[c]);
-          }
+          for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const f32x4 t0 = af[4 * h + 2 * c], t1 = af[4 * h + 2 * c + 1];
+            for (int r = 0; r < 8; ++r) v[c][r] = v[c][r] > 0.f ? v[c][r] : 0.f;
+        } else if (p.act == S2T_ACT_SWISH) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[c][r] = t0[r] + bpre[c][r];
-              v[c][4 + r] = t1[r] + bpre[c][4 + r];
-            }
-          }
-          if (has_act) {
-            if (e.P) {
+          for (int c = 0; c < 2; ++c)
 #pragma unroll
-              for (int c = 0; c < 2; ++c)
-                if (ok[c]) st8<TC>(e.P + (int64_t)m * p.ldp + ncol[c], true, 8, v[c]);
-            }
-            if (p.act == S2T_ACT_RELU) {
-#pragma unroll
-              for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[c][r] = v[c][r] > 0.f ? v[c][r] : 0.f;
-            } else {
-#pragma unroll
-              for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[c][r] = v[c][r] * sigmoidf_(v[c][r]);
-            }
-          }
-          if (e.Z) {
-            if (p.dact == S2T_ACT_RELU) {
-#pragma unroll
-              for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[c][r] *= zz[c][r] > 0.f ? 1.f : 0.f;
-            } else if (p.dact == S2T_ACT_SWISH) {
-#pragma unroll
-              for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[c][r] *= act_grad(S2T_ACT_SWISH, zz[c][r]);
-            }
-          }
-          if (drop) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              uint32_t r16[8];
-              s2t_rand_run<8>(dkey, (uint64_t)m * (uint64_t)p.N + (uint64_t)ncol[c], r16);
-#pragma unroll
-              for (int r = 0; r < 8; ++r) v[c][r] = r16[r] >= dth ? v[c][r] * dinv : 0.f;
-            }
-          }
+            for (int r = 0; r < 8; ++r) v[c][r] = v[c][r] * sigmoidf_(v[c][r]);
+        }
+        if (scale) {
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[c][r] *= p.alpha;
-          if (p.row_lens && m < p.M && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)m)) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[0][r] = v[1][r] = 0.f;
-          }
-          if (e.R) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-              for (int r = 0; r < 8; ++r) v[c][r] += ok[c] ? q[c][r] : 0.f;
-          }
+        }
+        if (e.R) {
 #pragma unroll
           for (int c = 0; c < 2; ++c)
-            if (ok[c]) st8<TC>(e.C + (int64_t)m * p.ldc + ncol[c], true, 8, v[c]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[c][r] += ok[c] ? q[c][r] : 0.f;
         }
-      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) store8(ok[c], m, ncol[c], v[c]);
+      }
+    } else {
+      const uint64_t dkey = drop ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
+      const uint32_t dth = s2t_drop_thresh(p.drop_p);
+      const float dinv = s2t_drop_scale(p.drop_p);
+      f32x4 (&af)[32] = reinterpret_cast<f32x4 (&)[32]>(acc);
+#pragma unroll 1
+      for (int i2 = 0; i2 < 4; ++i2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = t.tm * TM + wm * 128 + (2 * i2 + h) * 16 + x;
+          if constexpr (VEC) {
+            bool ok[2];
+            float v[2][8], q[2][8], zz[2][8];
 #pragma unroll
-          for (int jp = 0; jp < 2; ++jp) {
-            const f32x4 t0 = af[4 * h + 2 * jp], t1 = af[4 * h + 2 * jp + 1];
-            float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-            if (m < p.M && ncol[jp] < p.N) {
+            for (int c = 0; c < 2; ++c) ok[c] = m < p.M && ncol[c] < p.N;
+            if (e.R) {
 #pragma unroll
-              for (int r = 0; r < 8; ++r) v[r] += bpre[jp][r];
-              e.finish(m, ncol[jp], (int64_t)m, v);
+              for (int c = 0; c < 2; ++c)
+                if (ok[c]) ld8<TC>(e.R + (int64_t)m * p.ldr + ncol[c], true, 8, q[c]);
+            }
+            if (e.Z) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                if (ok[c]) ld8<TC>(e.Z + (int64_t)m * p.ldz + ncol[c], true, 8, zz[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const f32x4 t0 = af[4 * h + 2 * c], t1 = af[4 * h + 2 * c + 1];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[c][r] = t0[r] + bpre[c][r];
+                v[c][4 + r] = t1[r] + bpre[c][4 + r];
+              }
+            }
+            if (has_act) {
+              if (e.P) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                  if (ok[c]) st8<TC>(e.P + (int64_t)m * p.ldp + ncol[c], true, 8, v[c]);
+              }
+              if (p.act == S2T_ACT_RELU) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                  for (int r = 0; r < 8; ++r) v[c][r] = v[c][r] > 0.f ? v[c][r] : 0.f;
+              } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                  for (int r = 0; r < 8; ++r) v[c][r] = v[c][r] * sigmoidf_(v[c][r]);
+              }
+            }
+            if (e.Z) {
+              if (p.dact == S2T_ACT_RELU) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                  for (int r = 0; r < 8; ++r) v[c][r] *= zz[c][r] > 0.f ? 1.f : 0.f;
+              } else if (p.dact == S2T_ACT_SWISH) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                  for (int r = 0; r < 8; ++r) v[c][r] *= act_grad(S2T_ACT_SWISH, zz[c][r]);
+              }
+            }
+            if (drop) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {
+                uint32_t r16[8];
+                s2t_rand_run<8>(dkey, (uint64_t)m * (uint64_t)p.N + (uint64_t)ncol[c], r16);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[c][r] = r16[r] >= dth ? v[c][r] * dinv : 0.f;
+              }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[c][r] *= p.alpha;
+            if (p.row_lens && m < p.M && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)m)) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[0][r] = v[1][r] = 0.f;
+            }
+            if (e.R) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[c][r] += ok[c] ? q[c][r] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) store8(ok[c], m, ncol[c], v[c]);
+          } else {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+              const f32x4 t0 = af[4 * h + 2 * jp], t1 = af[4 * h + 2 * jp + 1];
+              float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+              if (m < p.M && ncol[jp] < p.N) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += bpre[jp][r];
+                e.finish(m, ncol[jp], (int64_t)m, v);
+              }
             }
           }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < 24; ++k) af[k] = af[k + 8];
+        for (int k = 0; k < 24; ++k) af[k] = af[k + 8];
+      }
     }
 #endif
   };
+
+  // ---- staggered start.  Every tile takes the same time, so all 256 workgroups would reach their epilogues together and
+  // write 256 tiles (33 MB of bf16) at once: the L2s hold the previous round's tiles as dirty lines, the burst drains at the
+  // HBM write rate (~6 us) and every workgroup waits for it once per tile (with the stores dropped a 64000 x 2048 x 512 launch
+  // takes 150 us instead of 200).  Spreading the starts over about one burst length keeps the epilogues apart for the whole
+  // walk: somebody is always multiplying while somebody else stores.
+#ifndef S2T_G256_STAGGER
+#define S2T_G256_STAGGER 0  // percent of one burst length (0: all workgroups start together)
+#endif
+#if S2T_G256_STAGGER
+  if (my_tiles > 1 || nk >= 8) {
+    // 100 MHz ticks: the bytes of one round of C tiles at ~5 TB/s, dealt by a bit-reversed workgroup index (neighbours far apart)
+    const uint32_t span = (uint32_t)((uint64_t)G * (uint64_t)(TM * TN * (int)sizeof(TC)) / 50000u) * S2T_G256_STAGGER / 100u;
+    const uint32_t rev = __builtin_bitreverse32((uint32_t)blockIdx.x) >> 24;  // 8 bits
+    const uint64_t until = __builtin_amdgcn_s_memrealtime() + (uint64_t)(span * rev / 256u);
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
 
   // ---- the walk: step s multiplies LDS stage s & 1 while step s + 1 lands in the other
   Tile L = tile_at(0);  // tile of the step being FETCHED
@@ -306,21 +414,60 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   };
   Tile C = L;           // tile of the step being multiplied
   int ckt = 0;
+  // stores a VEC epilogue issues per lane (none of them skipped: see csrd): 8 row blocks x 2 pieces x (1 | 2) 16-byte stores
+  constexpr int NST = 16 * (int)(sizeof(TC) / 2);
+  const bool counted = VEC && !p.preact;   // (the pre-activation copy goes out by ordinary conditional stores)
+  bool fresh_tile = false;                 // the step behind an epilogue
+#if S2T_G256_DBG & 16
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  int since_epi = 99;
+#define G256_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define G256_STAMP(v)
+#endif
   for (int s = 0; s < S; ++s) {
     const bool more = s + 1 < S;
+#if S2T_G256_DBG & 16
+    unsigned long long t0, t1, t2, t3;
+#endif
+    G256_STAMP(t0);
     if (more) advance_fetch();
-    // this wave's pieces of step s have landed (and its epilogue stores, if any, have left); behind the barrier everybody's
-    // have, and everybody has finished reading the other stage
-    __builtin_amdgcn_s_waitcnt(wait_vm(0));
+    // this wave's pieces of step s have landed; behind the barrier everybody's have, and everybody has finished reading the
+    // other stage.  Behind an epilogue the pieces are OLDER than its stores (they went out during the tile's last step), so the
+    // wait leaves exactly the stores in flight; one step later everything is waited for.
+    if (fresh_tile && counted) __builtin_amdgcn_s_waitcnt(wait_vm(NST));
+    else __builtin_amdgcn_s_waitcnt(wait_vm(0));
+    fresh_tile = false;
     asm volatile("s_barrier" ::: "memory");
+    G256_STAMP(t1);
     // (the last step fetches itself once more into the idle stage: an unconditional piece keeps the MFMA stream free of branches)
-    multiply(s & 1, [&](int q) __attribute__((always_inline)) { piece_out(q, lkt, (s & 1) ^ 1); });
+#ifndef S2T_G256_SPLIT_HALVES
+#define S2T_G256_SPLIT_HALVES 0
+#endif
+    multiply(s & 1, S2T_G256_SPLIT_HALVES ? (wave >> 2) : 0, [&](int q) __attribute__((always_inline)) { piece_out(q, lkt, (s & 1) ^ 1); });
+    G256_STAMP(t2);
+#if S2T_G256_DBG & 16
+    seg[since_epi == 0 ? 0 : since_epi == 1 ? 1 : 2] += t1 - t0;
+    seg[3] += t2 - t1;
+    seg[5] += 1;
+    ++since_epi;
+#endif
     if (ckt + 1 == nk) {
       epilogue(C);
+#if S2T_G256_DBG & 16
+      G256_STAMP(t3);
+      seg[4] += t3 - t2;
+      since_epi = 0;
+      if (!more && p.colsum_a && tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.colsum_a[blockIdx.x * 8 + k] = (float)seg[k];
+      }
+#endif
       if (!more) break;
       zero_acc();
       C = tile_at(C.ord + 1);
       ckt = 0;
+      fresh_tile = true;
     } else {
       ++ckt;
     }
@@ -347,21 +494,38 @@ bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
   const int mode = g256_mode();
   if (mode <= 0) return false;
   if (p.dtype != S2T_BF16 || p.a_kmajor || p.b_kmajor || p.act == S2T_ACT_GLU) return false;
+#if S2T_G256_DBG & 16
+  if (p.batch > 1 || p.split_k > 1 || p.c_atomic || p.ws) return false;  // (p.colsum_a receives the stamps)
+#else
   if (p.batch > 1 || p.split_k > 1 || p.c_atomic || p.colsum_a || p.ws) return false;
+#endif
   if (p.K < 128 || (p.K % TK)) return false;
   if (mode >= 2) return true;
   const int64_t tiles = (int64_t)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
   return tiles >= 192;
 }
 
+static bool g256_plain(const s2t_gemm_args& p, bool vec) {
+  return vec && !p.dact_z && !(p.drop_p > 0.f) && !p.preact && !p.row_lens;
+}
+
 int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
   const dim3 grid(s2t_device_cu_count()), block(512);
-  if (p.c_dtype == S2T_F32) {
-    if (vec) hipLaunchKernelGGL((gemm256_kernel<float, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm256_kernel<float, false>), grid, block, 0, s, p);
-  } else {
-    if (vec) hipLaunchKernelGGL((gemm256_kernel<bf16_t, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm256_kernel<bf16_t, false>), grid, block, 0, s, p);
-  }
+  const bool plain = g256_plain(p, vec);
+#define GO(TC) \
+  do { \
+    if (plain) hipLaunchKernelGGL((gemm256_kernel<TC, true, true>), grid, block, 0, s, p); \
+    else if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((gemm256_kernel<TC, false, false>), grid, block, 0, s, p); \
+  } while (0)
+  if (p.c_dtype == S2T_F32) GO(float);
+  else GO(bf16_t);
+#undef GO
   return S2T_LAUNCH_CHECK();
+}
+
+int s2t_gemm256_describe(const s2t_gemm_args& p, bool vec, char* buf, int buflen) {
+  const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
+                         vec ? "true" : "false", g256_plain(p, vec) ? "true" : "false");
+  return (n > 0 && n < buflen) ? S2T_OK : S2T_ERR_ARG;
 }

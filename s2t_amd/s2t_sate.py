@@ -206,7 +206,7 @@ class TextualEncoder(nn.Module):
             if L in self.inter_xctc_layers:
                 norm = self.layer_norm if self.share_inter_xctc_norm else getattr(self, "xctc_norm%d" % L)
                 norm_x = norm(x)
-                logit2d = self.xctc(norm_x, out_dtype=self.ctc_out_dtype)
+                logit2d = self.xctc(norm_x, out_dtype=self.ctc_out_dtype if self.xctc_pae.adapter_type == "none" else None)
                 il = logit2d.view(B, T, -1).transpose(0, 1)
                 inter_logit = il
                 orc = msk = None

@@ -236,7 +236,9 @@ class S2TTransformerEncoder(nn.Module):
                 head = self.ctc if (self.use_ctc and self.share_inter_ctc) else getattr(self, "inter_ctc%d" % L)
                 pae = self.pae if self.share_inter_ctc else getattr(self, "pae%d" % L)
                 norm_x = norm(x)
-                logit2d = head(norm_x, out_dtype=self.ctc_out_dtype)
+                # (an INTERMEDIATE head's logits feed the PAE softmax and the training losses: compute dtype, as in training;
+                # ctc_out_dtype = fp32 is for the logits that are decoded)
+                logit2d = head(norm_x, out_dtype=self.ctc_out_dtype if pae.adapter_type == "none" else None)
                 il = logit2d.view(B, Tp, -1).transpose(0, 1)
                 inter_logit = [il, encoder_padding_mask]  # the reference's [logit, padding mask] pairs
                 orc = msk = None
