@@ -48,7 +48,12 @@ struct Tile {
 
 // VEC: every tensor of the epilogue 16-byte aligned, N % 8 == 0.  PLAIN (needs VEC): the epilogue is bias / activation / alpha /
 // residual only (two forms in one kernel made the compiler spill the accumulators where they merge).
-template <typename TC, bool VEC, bool PLAIN>
+// BKM: B is k-major (B_op[k][n] at B[k*ldb + n]: the weight of a Linear seen from its input gradient, the embedding matrix of the
+// PAE product).  Its K-step image is [64 k][256 columns] (512 B per k-row, 16-byte piece c of k-row r at r*512 + 16*(c ^ 4*(r & 3))),
+// filled by the same DMA pieces (two k-rows each) and read through ds_read_b64_tr_b16, which hands lane x the operand row
+// (= B column) quad x >> 2, element x & 3 of the four 4-column quads the 16 lanes address: the quads of tile t of a pair are
+// columns 8 p + 4 t .. + 3, which is the column permutation the row-major image carries in its rows.
+template <typename TC, bool VEC, bool PLAIN, bool BKM>
 __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   __shared__ __attribute__((aligned(16))) char smem[G256_LDS];
   s2t_gemm_args p = p0;
@@ -73,7 +78,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   const int local_tiles = my_rows * tiles_n;
   if (slot >= local_tiles) return;
   const int my_tiles = (local_tiles - slot + nslots - 1) / nslots;
-  const int nk = p.K / TK;
+  const int nk = (p.K + TK - 1) / TK;
+  const int krem = p.K - (nk - 1) * TK;  // k of the last step: 64, or the tail (a multiple of 8; the pieces beyond it are fetched
+                                         // from beyond the descriptors' ranges, which reads as zero)
   const int S = my_tiles * nk;
   auto tile_at = [&](int ord) __attribute__((always_inline)) {
     const int l = slot + ord * nslots;
@@ -85,34 +92,45 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   // B.  Lane l of piece q lands at row 8 q + (l >> 3), slot l & 7, and therefore FETCHES k-piece (l & 7) ^ swz(row) of the
   // operand row that belongs there.
   const i32x4 srdA = make_srd(p.A, (uint32_t)(((int64_t)(p0.M - 1) * p.lda + p.K) * 2));
-  const i32x4 srdB = make_srd(p.B, (uint32_t)(((int64_t)(p.N - 1) * p.ldb + p.K) * 2));
+  const i32x4 srdB = make_srd(p.B, (uint32_t)(((int64_t)((BKM ? p.K : p.N) - 1) * p.ldb + (BKM ? p.N : p.K)) * 2));
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t lda2 = (uint32_t)(p.lda * 2), ldb2 = (uint32_t)(p.ldb * 2);
   uint32_t va[4], vb[4];
+  constexpr uint32_t OOB = 0xfffffff0u;
   auto plan = [&](const Tile& t) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rho = 32 * wave + 8 * q + (lane >> 3);
       const uint32_t piece = (uint32_t)(16 * ((lane & 7) ^ ((rho >> 1) & 7)));
       const int ga = min(t.tm * TM + rho, p.M - 1);  // rows / columns beyond the problem: a clamped duplicate, never stored
-      const int i_ = rho & 15, tau = (rho >> 4) & 1;
-      const int gb = min(t.tn * TN + (rho & ~31) + 8 * (i_ >> 2) + 4 * tau + (i_ & 3), p.N - 1);
       va[q] = (uint32_t)ga * lda2 + piece;
-      vb[q] = (uint32_t)gb * ldb2 + piece;
+      if constexpr (BKM) {
+        // piece 4 w + q = k-rows 2 (4 w + q) + (lane >> 5) of the step, slot lane & 31 -> columns 8 (slot ^ swz) of the tile
+        const int kr = 2 * (4 * wave + q) + (lane >> 5);
+        const int col = min(t.tn * TN + 8 * ((lane & 31) ^ (4 * (kr & 3))), p.N - 8);
+        vb[q] = (uint32_t)kr * ldb2 + (uint32_t)(col * 2);
+      } else {
+        const int i_ = rho & 15, tau = (rho >> 4) & 1;
+        const int gb = min(t.tn * TN + (rho & ~31) + 8 * (i_ >> 2) + 4 * tau + (i_ & 3), p.N - 1);
+        vb[q] = (uint32_t)gb * ldb2 + piece;
+      }
     }
   };
   auto piece_out = [&](int q, int kt, int stage) __attribute__((always_inline)) {
 #if !(S2T_G256_DBG & 1)
     const uint32_t dst = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)((4 * wave + (q & 3)) * 1024);
-#ifndef S2T_G256_NT
-#define S2T_G256_NT 0  // bit 0: A pieces non-temporal, bit 1: B pieces
-#endif
+    // row-major operand in the tail step: this lane's k-piece is (lane & 7) ^ swz(row) — dropped when it starts at or beyond K
+    const bool tail = kt == nk - 1 && krem < TK;
+    const int kpiece = (lane & 7) ^ ((4 * (q & 3) + (lane >> 4)) & 7);
     if (q < 4) {
-      if (S2T_G256_NT & 1) dma16_nt(dst, va[q], srdA, (uint32_t)(kt * (TK * 2)));
-      else dma16(dst, va[q], srdA, (uint32_t)(kt * (TK * 2)));
+      const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : va[q];
+      dma16(dst, v, srdA, (uint32_t)(kt * (TK * 2)));
+    } else if constexpr (BKM) {
+      // (k-rows at and beyond K lie beyond the descriptor's range by themselves)
+      dma16(dst + OP_BYTES, vb[q - 4], srdB, (uint32_t)kt * (uint32_t)TK * ldb2);
     } else {
-      if (S2T_G256_NT & 2) dma16_nt(dst + OP_BYTES, vb[q - 4], srdB, (uint32_t)(kt * (TK * 2)));
-      else dma16(dst + OP_BYTES, vb[q - 4], srdB, (uint32_t)(kt * (TK * 2)));
+      const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : vb[q - 4];
+      dma16(dst + OP_BYTES, v, srdB, (uint32_t)(kt * (TK * 2)));
     }
 #endif
   };
@@ -130,6 +148,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   const uint32_t lo0 = (uint32_t)(x * 128 + 16 * (y ^ (x >> 1)));
   const char* const fa0 = smem + wm * (128 * 128) + lo0;
   const char* const fb0 = smem + OP_BYTES + wn * (64 * 128) + lo0;
+  // k-major B: lane (x = 4 q + p, y) addresses k-row 8 y + 4 half + q (+ 32 ks), the quad at columns 64 wn + 32 g + 8 p + 4 t
+  // of tile j = 2 g + t: piece 8 wn + 4 g + p, its half t
+  const uint32_t tb0 = (uint32_t)((8 * y + (x >> 2)) * 512);
+  const int tq = x >> 2, tp = x & 3;
 
   auto multiply = [&](int stage, int DKS, auto&& side) __attribute__((always_inline)) {
     const char* la = fa0 + stage * STAGE_BYTES;
@@ -139,8 +161,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
       // (x*128 + 16*((4+y) ^ (x>>1))) = lo0 ^ 64
       const int kx = ks ? (int)((lo0 ^ 64u) - lo0) : 0;
       uint4 fb[4], fa[8];
+      if constexpr (BKM) {
+        const char* img = smem + stage * STAGE_BYTES + OP_BYTES + ks * (32 * 512);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(lb + j * 2048 + kx);
+        for (int j = 0; j < 4; ++j) {
+          uint32_t w[4];
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            // swizzle key of k-row 8 y + 4 half + q (+ 32 ks): 4 * (row & 3) = 4 q
+            const char* a = img + tb0 + half * (4 * 512) + 16 * ((8 * wn + 4 * (j >> 1) + tp) ^ (4 * tq)) + 8 * (j & 1);
+            const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+            const uint2 tt = __builtin_bit_cast(uint2, t);
+            w[2 * half] = tt.x;
+            w[2 * half + 1] = tt.y;
+          }
+          fb[j] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(lb + j * 2048 + kx);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const uint4*>(la + i * 2048 + kx);
 #pragma unroll
@@ -493,13 +533,14 @@ extern "C" int s2t_gemm_configure(int large_tile_mode) {
 bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
   const int mode = g256_mode();
   if (mode <= 0) return false;
-  if (p.dtype != S2T_BF16 || p.a_kmajor || p.b_kmajor || p.act == S2T_ACT_GLU) return false;
+  if (p.dtype != S2T_BF16 || p.a_kmajor || p.act == S2T_ACT_GLU) return false;
 #if S2T_G256_DBG & 16
   if (p.batch > 1 || p.split_k > 1 || p.c_atomic || p.ws) return false;  // (p.colsum_a receives the stamps)
 #else
   if (p.batch > 1 || p.split_k > 1 || p.c_atomic || p.colsum_a || p.ws) return false;
 #endif
-  if (p.K < 128 || (p.K % TK)) return false;
+  if (p.K < 128 || (p.K % 8)) return false;          // (a K tail is dropped in whole 16-byte pieces)
+  if (p.b_kmajor && (p.N % 8)) return false;         // (a k-major piece is 8 columns)
   if (mode >= 2) return true;
   const int64_t tiles = (int64_t)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
   return tiles >= 192;
@@ -512,20 +553,26 @@ static bool g256_plain(const s2t_gemm_args& p, bool vec) {
 int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
   const dim3 grid(s2t_device_cu_count()), block(512);
   const bool plain = g256_plain(p, vec);
+#define GO2(TC, BK) \
+  do { \
+    if (plain) hipLaunchKernelGGL((gemm256_kernel<TC, true, true, BK>), grid, block, 0, s, p); \
+    else if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false, BK>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((gemm256_kernel<TC, false, false, BK>), grid, block, 0, s, p); \
+  } while (0)
 #define GO(TC) \
   do { \
-    if (plain) hipLaunchKernelGGL((gemm256_kernel<TC, true, true>), grid, block, 0, s, p); \
-    else if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((gemm256_kernel<TC, false, false>), grid, block, 0, s, p); \
+    if (p.b_kmajor) GO2(TC, true); \
+    else GO2(TC, false); \
   } while (0)
   if (p.c_dtype == S2T_F32) GO(float);
   else GO(bf16_t);
+#undef GO2
 #undef GO
   return S2T_LAUNCH_CHECK();
 }
 
 int s2t_gemm256_describe(const s2t_gemm_args& p, bool vec, char* buf, int buflen) {
-  const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
-                         vec ? "true" : "false", g256_plain(p, vec) ? "true" : "false");
+  const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s, %s>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
+                         vec ? "true" : "false", g256_plain(p, vec) ? "true" : "false", p.b_kmajor ? "true" : "false");
   return (n > 0 && n < buflen) ? S2T_OK : S2T_ERR_ARG;
 }

@@ -353,31 +353,43 @@ def _both_paths(call):
 
 
 @pytest.mark.parametrize("M,N,K,ldpad", [(256, 256, 128, 0), (1000, 520, 192, 0), (513, 264, 64 * 5, 8), (4100, 777 * 8, 256, 0),
-                                         (16000, 768, 256, 0), (257, 10000, 512, 0)])
+                                         (16000, 768, 256, 0), (257, 10000, 512, 0), (300, 264, 200, 8), (700, 512, 10000, 0),
+                                         (515, 1000, 136, 0)])
 @pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
-def test_large_tile_plain(M, N, K, ldpad, cdt):
-    """Ragged M and N (clamped duplicate rows / columns are never stored), padded leading dimensions, both output types: equal to
-    the 128 x 128 path bit for bit (same MFMA, same order over K) and to a float64 product within bf16 rounding."""
+@pytest.mark.parametrize("bkm", [False, True])
+def test_large_tile_plain(M, N, K, ldpad, cdt, bkm):
+    """Ragged M, N and K (clamped duplicate rows / columns are never stored; the K tail is fetched from beyond the buffer
+    descriptors' ranges and reads as zero — the padding behind it is poisoned here), padded leading dimensions, both layouts of
+    B, both output types: equal to the 128 x 128 path bit for bit (same MFMA, same order over K) and to a float64 product
+    within bf16 rounding."""
     g = torch.Generator().manual_seed(M + N + K)
     dev = "cuda"
-    lda, ldb, ldc = K + ldpad, K + 2 * ldpad, N + ldpad
+    lda, ldc = K + ldpad, N + ldpad
     A = torch.full((M, lda), float("nan"), dtype=torch.bfloat16); A[:, :K] = _mk((M, K), torch.bfloat16, g)
-    W = torch.full((N, ldb), float("nan"), dtype=torch.bfloat16); W[:, :K] = _mk((N, K), torch.bfloat16, g, K ** -0.5)
+    Wl = _mk((N, K), torch.bfloat16, g, K ** -0.5)
+    if bkm:
+        ldb = N + 2 * ldpad
+        W = torch.full((K, ldb), float("nan"), dtype=torch.bfloat16); W[:, :N] = Wl.t()
+    else:
+        ldb = K + 2 * ldpad
+        W = torch.full((N, ldb), float("nan"), dtype=torch.bfloat16); W[:, :K] = Wl
     Ad, Wd = A.to(dev), W.to(dev)
 
     def call():
         out = torch.full((M, ldc), 7.0, dtype=cdt, device=dev)
-        ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc)
+        ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=bkm)
         return out
 
     with _large_tile(2):
-        assert "gemm256_kernel" in ops.gemm_symbol(_gemm_args(Ad, Wd, call(), M, N, K, lda, ldb, ldc))
+        a = _gemm_args(Ad, Wd, call(), M, N, K, lda, ldb, ldc)
+        a.b_kmajor = int(bkm)
+        assert "gemm256_kernel" in ops.gemm_symbol(a)
     old, new = _both_paths(call)
     assert torch.equal(old, new)
     if ldpad:
         assert (new[:, N:] == 7.0).all(), "wrote outside the N columns"
     if M * N <= 4100 * 6216:
-        ref = A[:, :K].double() @ W[:, :K].double().t()
+        ref = A[:, :K].double() @ Wl.double().t()
         np.testing.assert_allclose(new[:, :N].cpu().double().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2 * ref.abs().max().item())
 
 

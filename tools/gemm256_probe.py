@@ -10,9 +10,11 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 
 
-def run(M, N, Kd, out_dtype=torch.bfloat16, bias=False, act=None, residual=False, rounds=15, check=True):
+def run(M, N, Kd, out_dtype=torch.bfloat16, bias=False, act=None, residual=False, rounds=15, check=True, bkm=False):
     A = torch.randn(M, Kd, device=dev).to(torch.bfloat16)
     B = (torch.randn(N, Kd, device=dev) * Kd ** -0.5).to(torch.bfloat16)
+    if bkm:
+        B = B.t().contiguous()  # [K][N]
     b = torch.randn(N, device=dev) if bias else None
     R = torch.randn(M, N, device=dev).to(out_dtype) if residual else None
     outs = {}
@@ -20,14 +22,14 @@ def run(M, N, Kd, out_dtype=torch.bfloat16, bias=False, act=None, residual=False
     for mode in (0, 2):
         K.gemm_configure(mode)
         C = torch.empty(M, N, device=dev, dtype=out_dtype)
-        kw = dict(M=M, N=N, K=Kd, lda=Kd, ldb=Kd, ldc=N, bias=b, act=act, residual=R, ldr=N if residual else 0)
+        kw = dict(M=M, N=N, K=Kd, lda=Kd, ldb=N if bkm else Kd, ldc=N, bias=b, act=act, residual=R, ldr=N if residual else 0, b_kmajor=bkm)
         K.gemm(A, B, C, **kw)
         outs[mode] = C
     torch.cuda.synchronize()
     same = torch.equal(outs[0], outs[2])
     err = None
     if check and M * N <= 64000 * 2048:
-        ref = A.float() @ B.float().t()
+        ref = A.float() @ (B.float() if bkm else B.float().t())
         if bias: ref += b
         if act == "relu": ref = ref.relu()
         if residual: ref += R.float()
@@ -44,9 +46,9 @@ def run(M, N, Kd, out_dtype=torch.bfloat16, bias=False, act=None, residual=False
             ts[mode].append(e0.elapsed_time(e1) * 250)
     t0, t2 = sorted(ts[0])[rounds // 2], sorted(ts[2])[rounds // 2]
     fl = 2.0 * M * N * Kd
-    print("M%6d N%6d K%5d %s%s%s%s : old %7.1f us %6.0f TF/s | 256 %7.1f us %6.0f TF/s  x%.2f  equal=%s err=%s" % (
+    print("M%6d N%6d K%5d %s%s%s%s%s : old %7.1f us %6.0f TF/s | 256 %7.1f us %6.0f TF/s  x%.2f  equal=%s err=%s" % (
         M, N, Kd, "f32" if out_dtype == torch.float32 else "bf16", " bias" if bias else "", " " + act if act else "",
-        " res" if residual else "", t0, fl / t0 / 1e6, t2, fl / t2 / 1e6, t0 / t2, same, "%.1e" % err if err is not None else "-"), flush=True)
+        " res" if residual else "", " Bkm" if bkm else "", t0, fl / t0 / 1e6, t2, fl / t2 / 1e6, t0 / t2, same, "%.1e" % err if err is not None else "-"), flush=True)
     K.gemm_configure(1)
     return same
 
@@ -60,6 +62,9 @@ shapes = [
     (16000, 2048, 256, dict(bias=True, act="relu")), (16000, 256, 2048, dict(bias=True, residual=True)),
     (13100, 10000, 256, dict(bias=True)), (3904, 10000, 256, {}), (8192, 8192, 8192, dict(rounds=5, check=False)),
     (4096, 4096, 4096, dict(rounds=7)),
+    (1000, 520, 200, dict(bias=True)), (64000, 512, 10000, dict(bkm=True, residual=True, check=False)), (64000, 2048, 512, dict(bkm=True)),
+    (64000, 512, 2048, dict(bkm=True)), (16000, 10000, 256, dict(bkm=True)), (8192, 8192, 8192, dict(bkm=True, rounds=5, check=False)),
+    (1000, 520, 200, dict(bkm=True, bias=True)), (64000, 512, 10000, dict(residual=True, check=False)),
 ]
 ok = True
 for M, N, Kd, kw in shapes:
