@@ -543,7 +543,9 @@ bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
   if (p.b_kmajor && (p.N % 8)) return false;         // (a k-major piece is 8 columns)
   if (mode >= 2) return true;
   const int64_t tiles = (int64_t)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
-  return tiles >= 192;
+  // (tools/gemm256_probe.py border: 156 tiles 1.39x, 189 1.38x, 250 1.3x; 126-128 tiles 0.95-1.05x, 88 0.92x, 64 0.78x — below
+  // about 0.6 of a round the 128 x 128 path's 2 x 256 slots fill the chip better)
+  return tiles >= 150;
 }
 
 static bool g256_plain(const s2t_gemm_args& p, bool vec) {

@@ -30,7 +30,7 @@ def close(got, ref, dtype, mul=1.0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("cols", [32, 256, 260])
+@pytest.mark.parametrize("cols", [32, 256, 260, 512])
 def test_layernorm_fwd_bwd(dtype, cols):
     g = torch.Generator().manual_seed(cols)
     B, T = 3, 11
@@ -579,3 +579,23 @@ def test_add_colsum2_relpos_glue():
     want = (a[:, :n].float() + b.float()).to(torch.bfloat16)
     assert torch.equal(ad[:, :n].cpu(), want)
     assert torch.equal(ad[:, n:].cpu(), a[:, n:])  # the k / v slices are untouched
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,V,ld", [(37, 10000, 10000), (5, 2048, 2056), (9, 10240, 10240), (6, 1000, 1000), (4, 37, 40), (3, 2050, 2056),
+                                       (2, 12000, 12000)])
+def test_row_softmax_fwd(dtype, rows, V, ld):
+    """softmax(x / tau) over a wide vocabulary (the PAE distribution, modules/speech_to_text/adapter.py:214-217): the
+    register-resident bf16 form (V % 8 == 0, V <= 10240) and the three-pass form against torch."""
+    g = torch.Generator().manual_seed(V + rows)
+    x = torch.full((rows, ld), float("nan"), dtype=dtype)
+    x[:, :V] = rnd((rows, V), dtype, g) * 4
+    xd = x.to(DEV)
+    for tau in (1.0, 0.5):
+        p = torch.full((rows, ld), 7.0, dtype=dtype, device=DEV)
+        K.row_softmax_fwd(xd, ld, p, ld, rows, V, 1.0 / tau)
+        ref = torch.softmax(x[:, :V].double() / tau, -1)
+        np.testing.assert_allclose(p[:, :V].double().cpu().numpy(), ref.numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-5,
+                                   atol=1e-6)
+        assert (p[:, V:] == 7.0).all()
+        assert abs(p[:, :V].double().sum(-1).cpu() - 1).max() < (2e-2 if dtype == torch.bfloat16 else 1e-5)

@@ -66,6 +66,11 @@ shapes = [
     (64000, 512, 2048, dict(bkm=True)), (16000, 10000, 256, dict(bkm=True)), (8192, 8192, 8192, dict(bkm=True, rounds=5, check=False)),
     (1000, 520, 200, dict(bkm=True, bias=True)), (64000, 512, 10000, dict(residual=True, check=False)),
 ]
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == "border":  # shapes around the automatic mode's tile-count threshold
+    shapes = [(16000, 512, 512, {}), (16000, 512, 2048, {}), (8000, 1024, 256, {}), (4000, 2048, 512, {}), (16000, 768, 256, {}),
+              (16000, 1024, 256, {}), (13100, 512, 256, {}), (13100, 768, 256, {}), (2650, 10000, 256, {}), (2650, 2048, 256, {}),
+              (8192, 512, 512, {}), (32000, 256, 256, {}), (32000, 512, 256, {}), (64000, 256, 512, {}), (13100, 3072, 256, {})]
 ok = True
 for M, N, Kd, kw in shapes:
     ok &= run(M, N, Kd, **kw)
