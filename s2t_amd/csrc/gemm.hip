@@ -747,7 +747,10 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (s2t_gemm256_eligible(p))
-    return s2t_gemm256_launch(p, p.c_dtype == S2T_F32 ? epilogue_vectorisable<float>(p, p.N) : epilogue_vectorisable<bf16_t>(p, p.N), s);
+  {
+    const int nout256 = p.act == S2T_ACT_GLU ? p.N / 2 : p.N;
+    return s2t_gemm256_launch(p, p.c_dtype == S2T_F32 ? epilogue_vectorisable<float>(p, nout256) : epilogue_vectorisable<bf16_t>(p, nout256), s);
+  }
   if (p.dtype == S2T_F32) return launch<float, float>(p, s);
   if (p.c_dtype == S2T_F32 || p.ws) return launch<bf16_t, float>(p, s);  // (the partial tiles are fp32)
   return launch<bf16_t, bf16_t>(p, s);

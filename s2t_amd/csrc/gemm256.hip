@@ -53,8 +53,12 @@ struct Tile {
 // filled by the same DMA pieces (two k-rows each) and read through ds_read_b64_tr_b16, which hands lane x the operand row
 // (= B column) quad x >> 2, element x & 3 of the four 4-column quads the 16 lanes address: the quads of tile t of a pair are
 // columns 8 p + 4 t .. + 3, which is the column permutation the row-major image carries in its rows.
-template <typename TC, bool VEC, bool PLAIN, bool BKM>
+// GLU (row-major B only): N = 2 * nout weight rows, value rows then gate rows; out = (a + bias_a) * sigmoid(g + bias_g)
+// (modules/speech_to_text/subsampling.py:106-159, modules/convolution.py:94-98).  A wave's 64 image rows are the value rows and the
+// gate rows of the SAME 32 output columns (a tile is 256 x 128 outputs), so a lane's two pieces are value | gate of its columns.
+template <typename TC, bool VEC, bool PLAIN, bool BKM, bool GLU = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
+  static_assert(!(GLU && (BKM || PLAIN)), "GLU: row-major B, general epilogue");
   __shared__ __attribute__((aligned(16))) char smem[G256_LDS];
   s2t_gemm_args p = p0;
   p.M = (int)s2t_live_rows(p0.row_lens, p0.row_T, p0.M);  // packed batch: the row blocks beyond the live rows are never walked
@@ -64,7 +68,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   const int wm = wave & 1, wn = wave >> 1;
   const int x = lane & 15, y = lane >> 4;
 
-  const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TN - 1) / TN;
+  const int nout = GLU ? p.N / 2 : p.N;             // output columns
+  constexpr int TNO = GLU ? TN / 2 : TN;            // ... per tile
+  const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (nout + TNO - 1) / TNO;
   // ---- which tiles: XCD xc owns row blocks xc, xc + 8, ...; its workgroups (slots) take that list's tiles column-fastest
   const int G = gridDim.x;
   int xc = 0, slot = blockIdx.x, nslots = G, nx = 1;
@@ -111,7 +117,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
         vb[q] = (uint32_t)kr * ldb2 + (uint32_t)(col * 2);
       } else {
         const int i_ = rho & 15, tau = (rho >> 4) & 1;
-        const int gb = min(t.tn * TN + (rho & ~31) + 8 * (i_ >> 2) + 4 * tau + (i_ & 3), p.N - 1);
+        int gb;
+        if constexpr (GLU) {  // image rows 64 w' + 32 g + ..: g = 0 value, 1 gate rows of output columns 32 w' ..
+          gb = ((rho >> 5) & 1) * nout + min(t.tn * TNO + (rho >> 6) * 32 + 8 * (i_ >> 2) + 4 * tau + (i_ & 3), nout - 1);
+        } else {
+          gb = min(t.tn * TN + (rho & ~31) + 8 * (i_ >> 2) + 4 * tau + (i_ & 3), p.N - 1);
+        }
         vb[q] = (uint32_t)gb * ldb2 + piece;
       }
     }
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
                    p.residual ? reinterpret_cast<const TC*>(p.residual) : nullptr,
                    p.preact ? reinterpret_cast<TC*>(p.preact) : nullptr,
                    p.dact_z ? reinterpret_cast<const TC*>(p.dact_z) : nullptr,
-                   p.N,
+                   nout,
                    false, false, false, false};
     if constexpr (!VEC) {
       auto vec_ok = [](const void* ptr, int64_t ld) { return ((ld * (int64_t)sizeof(TC)) % 16 == 0) && (((uintptr_t)ptr) % 16 == 0); };
@@ -234,15 +245,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     int ncol[2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      ncol[jp] = t.tn * TN + wn * 64 + 32 * jp + 8 * y;
-      const int nvb = max(0, min(8, p.N - ncol[jp]));
-      e.bias8(nvb > 0 ? ncol[jp] : 0, nvb, bpre[jp]);
+      ncol[jp] = GLU ? t.tn * TNO + wn * 32 + 8 * y : t.tn * TN + wn * 64 + 32 * jp + 8 * y;
+      const int nvb = max(0, min(8, nout - ncol[jp]));
+      e.bias8(nvb > 0 ? (GLU ? jp * nout : 0) + ncol[jp] : 0, nvb, bpre[jp]);
     }
     // C leaves through a raw buffer descriptor: a piece outside the problem gets an offset beyond the descriptor's range and is
     // dropped by the hardware, so every lane ISSUES the same number of stores — the wait at the top of the next step can then
     // leave exactly those in flight
     const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(
-        p.C, 0, (int)(uint32_t)(((int64_t)(p.M - 1) * p.ldc + p.N) * (int64_t)sizeof(TC)), 0x00020000);
+        p.C, 0, (int)(uint32_t)(((int64_t)(p.M - 1) * p.ldc + nout) * (int64_t)sizeof(TC)), 0x00020000);
     auto store8 = [&](bool ok, int m, int n, const float (&v)[8]) __attribute__((always_inline)) {
 #if S2T_G256_DBG & 8
       const uint32_t off = 0xfffffff0u;
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
         bool ok[2];
         float v[2][8], q[2][8];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) ok[c] = m < p.M && ncol[c] < p.N;
+        for (int c = 0; c < 2; ++c) ok[c] = m < p.M && ncol[c] < nout;
         if (e.R) {
 #pragma unroll
           for (int c = 0; c < 2; ++c)
@@ -319,11 +330,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = t.tm * TM + wm * 128 + (2 * i2 + h) * 16 + x;
-          if constexpr (VEC) {
+          if constexpr (GLU) {
+            const f32x4 a0 = af[4 * h], a1 = af[4 * h + 1], g0 = af[4 * h + 2], g1 = af[4 * h + 3];
+            if (m < p.M && ncol[0] < nout) {
+              float a[8], gt[8], v[8];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                a[r] = a0[r] + bpre[0][r];
+                a[4 + r] = a1[r] + bpre[0][4 + r];
+                gt[r] = g0[r] + bpre[1][r];
+                gt[4 + r] = g1[r] + bpre[1][4 + r];
+              }
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] = a[r] * sigmoidf_(gt[r]);
+              if (e.P) {
+                const int nv = min(8, nout - ncol[0]);
+                st8<TC>(e.P + (int64_t)m * p.ldp + ncol[0], VEC || e.vec_p, VEC ? 8 : nv, a);
+                st8<TC>(e.P + (int64_t)m * p.ldp + nout + ncol[0], VEC || (e.vec_p && ((nout * (int)sizeof(TC)) % 16 == 0)), VEC ? 8 : nv, gt);
+              }
+              e.finish(m, ncol[0], (int64_t)m, v);
+            }
+          } else if constexpr (VEC) {
             bool ok[2];
             float v[2][8], q[2][8], zz[2][8];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) ok[c] = m < p.M && ncol[c] < p.N;
+            for (int c = 0; c < 2; ++c) ok[c] = m < p.M && ncol[c] < nout;
             if (e.R) {
 #pragma unroll
               for (int c = 0; c < 2; ++c)
@@ -378,7 +409,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #pragma unroll
               for (int c = 0; c < 2; ++c) {
                 uint32_t r16[8];
-                s2t_rand_run<8>(dkey, (uint64_t)m * (uint64_t)p.N + (uint64_t)ncol[c], r16);
+                s2t_rand_run<8>(dkey, (uint64_t)m * (uint64_t)nout + (uint64_t)ncol[c], r16);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[c][r] = r16[r] >= dth ? v[c][r] * dinv : 0.f;
               }
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
             for (int jp = 0; jp < 2; ++jp) {
               const f32x4 t0 = af[4 * h + 2 * jp], t1 = af[4 * h + 2 * jp + 1];
               float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-              if (m < p.M && ncol[jp] < p.N) {
+              if (m < p.M && ncol[jp] < nout) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] += bpre[jp][r];
                 e.finish(m, ncol[jp], (int64_t)m, v);
@@ -456,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   int ckt = 0;
   // stores a VEC epilogue issues per lane (none of them skipped: see csrd): 8 row blocks x 2 pieces x (1 | 2) 16-byte stores
   constexpr int NST = 16 * (int)(sizeof(TC) / 2);
-  const bool counted = VEC && !p.preact;   // (the pre-activation copy goes out by ordinary conditional stores)
+  const bool counted = VEC && !GLU && !p.preact;   // (the pre-activation copy and the GLU form go out by ordinary conditional stores)
   bool fresh_tile = false;                 // the step behind an epilogue
 #if S2T_G256_DBG & 16
   unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
@@ -533,7 +564,7 @@ extern "C" int s2t_gemm_configure(int large_tile_mode) {
 bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
   const int mode = g256_mode();
   if (mode <= 0) return false;
-  if (p.dtype != S2T_BF16 || p.a_kmajor || p.act == S2T_ACT_GLU) return false;
+  if (p.dtype != S2T_BF16 || p.a_kmajor || (p.act == S2T_ACT_GLU && p.b_kmajor)) return false;
 #if S2T_G256_DBG & 16
   if (p.batch > 1 || p.split_k > 1 || p.c_atomic || p.ws) return false;  // (p.colsum_a receives the stamps)
 #else
@@ -542,14 +573,14 @@ bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
   if (p.K < 128 || (p.K % 8)) return false;          // (a K tail is dropped in whole 16-byte pieces)
   if (p.b_kmajor && (p.N % 8)) return false;         // (a k-major piece is 8 columns)
   if (mode >= 2) return true;
-  const int64_t tiles = (int64_t)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
+  const int64_t tiles = (int64_t)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);  // (GLU: N / 2 outputs in 128-column tiles)
   // (tools/gemm256_probe.py border: 156 tiles 1.39x, 189 1.38x, 250 1.3x; 126-128 tiles 0.95-1.05x, 88 0.92x, 64 0.78x — below
   // about 0.6 of a round the 128 x 128 path's 2 x 256 slots fill the chip better)
   return tiles >= 150;
 }
 
 static bool g256_plain(const s2t_gemm_args& p, bool vec) {
-  return vec && !p.dact_z && !(p.drop_p > 0.f) && !p.preact && !p.row_lens;
+  return vec && p.act != S2T_ACT_GLU && !p.dact_z && !(p.drop_p > 0.f) && !p.preact && !p.row_lens;
 }
 
 int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
@@ -563,7 +594,10 @@ int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
   } while (0)
 #define GO(TC) \
   do { \
-    if (p.b_kmajor) GO2(TC, true); \
+    if (p.act == S2T_ACT_GLU) { \
+      if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false, false, true>), grid, block, 0, s, p); \
+      else hipLaunchKernelGGL((gemm256_kernel<TC, false, false, false, true>), grid, block, 0, s, p); \
+    } else if (p.b_kmajor) GO2(TC, true); \
     else GO2(TC, false); \
   } while (0)
   if (p.c_dtype == S2T_F32) GO(float);
@@ -574,7 +608,8 @@ int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
 }
 
 int s2t_gemm256_describe(const s2t_gemm_args& p, bool vec, char* buf, int buflen) {
-  const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s, %s>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
-                         vec ? "true" : "false", g256_plain(p, vec) ? "true" : "false", p.b_kmajor ? "true" : "false");
+  const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s, %s, %s>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
+                         vec ? "true" : "false", g256_plain(p, vec) ? "true" : "false", p.b_kmajor ? "true" : "false",
+                         p.act == S2T_ACT_GLU ? "true" : "false");
   return (n > 0 && n < buflen) ? S2T_OK : S2T_ERR_ARG;
 }

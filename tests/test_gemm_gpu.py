@@ -478,3 +478,32 @@ def test_large_tile_packed_rows():
     assert (new[:live][m < 0] == 0).all()
     ref = (A[:live].float() @ W.float().t())
     np.testing.assert_allclose(new[:live][m >= 0].float().cpu().numpy(), ref[m >= 0].cpu().numpy(), rtol=1e-2, atol=4e-2)
+
+
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,nout,K,stride", [(2000, 512, 400, 160), (700, 136, 192, 0), (4100, 256, 2560, 1024)])
+def test_large_tile_glu(cdt, M, nout, K, stride):
+    """The GLU form (value | gate weight rows, pre-activation halves saved) on the large tile, A rows overlapping as in the
+    subsampler's convolutions (row m starts stride elements behind row m - 1): bit for bit the 128 x 128 path's result, and
+    (a + b_a) * sigmoid(g + b_g) in float64."""
+    g = torch.Generator().manual_seed(M + nout)
+    dev = "cuda"
+    lda = stride if stride else K
+    flat = _mk(((M - 1) * lda + K,), torch.bfloat16, g).to(dev)
+    W = _mk((2 * nout, K), torch.bfloat16, g, K ** -0.5).to(dev)
+    bias = _mk((2 * nout,), torch.float32, g).to(dev)
+    R = _mk((M, nout), cdt, g).to(dev)
+
+    def call():
+        out = torch.empty(M, nout, dtype=cdt, device=dev)
+        pre = torch.zeros(M, 2 * nout, dtype=cdt, device=dev)
+        ops.gemm(flat, W, out, M=M, N=2 * nout, K=K, lda=lda, ldb=K, ldc=nout, bias=bias, act="glu", preact=pre, ldp=2 * nout,
+                 residual=R, ldr=nout, alpha=0.5)
+        return torch.cat([out, pre], 1)
+    old, new = _both_paths(call)
+    assert torch.equal(old, new)
+    A = torch.as_strided(flat, (M, K), (lda, 1)).double()
+    z = A @ W.double().t() + bias.double()
+    ref = R.double() + 0.5 * z[:, :nout] * torch.sigmoid(z[:, nout:])
+    np.testing.assert_allclose(new[:, :nout].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=4e-2)
+    np.testing.assert_allclose(new[:, nout:].double().cpu().numpy(), z.cpu().numpy(), rtol=1e-2, atol=4e-2)

@@ -21,8 +21,8 @@ def run(M, N, Kd, out_dtype=torch.bfloat16, bias=False, act=None, residual=False
     ts = {0: [], 2: []}
     for mode in (0, 2):
         K.gemm_configure(mode)
-        C = torch.empty(M, N, device=dev, dtype=out_dtype)
-        kw = dict(M=M, N=N, K=Kd, lda=Kd, ldb=N if bkm else Kd, ldc=N, bias=b, act=act, residual=R, ldr=N if residual else 0, b_kmajor=bkm)
+        C = torch.empty(M, N // 2 if act == "glu" else N, device=dev, dtype=out_dtype)
+        kw = dict(M=M, N=N, K=Kd, lda=Kd, ldb=N if bkm else Kd, ldc=N // 2 if act == "glu" else N, bias=b, act=act, residual=R, ldr=N if residual else 0, b_kmajor=bkm)
         K.gemm(A, B, C, **kw)
         outs[mode] = C
     torch.cuda.synchronize()
@@ -65,6 +65,8 @@ shapes = [
     (1000, 520, 200, dict(bias=True)), (64000, 512, 10000, dict(bkm=True, residual=True, check=False)), (64000, 2048, 512, dict(bkm=True)),
     (64000, 512, 2048, dict(bkm=True)), (16000, 10000, 256, dict(bkm=True)), (8192, 8192, 8192, dict(bkm=True, rounds=5, check=False)),
     (1000, 520, 200, dict(bkm=True, bias=True)), (64000, 512, 10000, dict(residual=True, check=False)),
+    (64000, 1024, 512, dict(act="glu", bias=True, check=False)), (32000, 1024, 400, dict(act="glu", bias=True, check=False)),
+    (128000, 4096, 400, dict(act="glu", bias=True, check=False)),
 ]
 import sys
 if len(sys.argv) > 1 and sys.argv[1] == "border":  # shapes around the automatic mode's tile-count threshold
