@@ -468,8 +468,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   }
 #endif
 
-  // ---- the walk: step s multiplies LDS stage s & 1 while step s + 1 lands in the other
-  Tile L = tile_at(0);  // tile of the step being FETCHED
+  // ---- the walk: step s multiplies LDS stage s & 1 while step s + 1 lands in the other.
+  // (S2T_G256_EARLY2, an experiment that LOST: at the end of a tile the stage just multiplied is free as well, so behind one more
+  // barrier the next tile's SECOND step can be sent into it before the epilogue starts and the next tile's first step issues
+  // nothing.  64000 x 2048 x 512: 185-193 us without, 193-196 us with; 16000 x 10000 x 256: 131 / 139.)
+  Tile L = tile_at(0);  // tile / K-step of the next step to FETCH (step fs)
   int lkt = 0;
   plan(L);
 #pragma unroll
@@ -483,12 +486,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
       plan(L);
     }
   };
-  Tile C = L;           // tile of the step being multiplied
+  int fs = 1;           // steps fetched (or in flight) so far
+  if (S > 1) advance_fetch();
+  Tile C = tile_at(0);  // tile of the step being multiplied
   int ckt = 0;
   // stores a VEC epilogue issues per lane (none of them skipped: see csrd): 8 row blocks x 2 pieces x (1 | 2) 16-byte stores
   constexpr int NST = 16 * (int)(sizeof(TC) / 2);
   const bool counted = VEC && !GLU && !p.preact;   // (the pre-activation copy and the GLU form go out by ordinary conditional stores)
-  bool fresh_tile = false;                 // the step behind an epilogue
+  int since = 99;       // steps since a tile end: 0 with the next step AND the one after in flight, 1 with one step in flight
+#ifndef S2T_G256_EARLY2
+#define S2T_G256_EARLY2 0
+#endif
 #if S2T_G256_DBG & 16
   unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
   int since_epi = 99;
@@ -497,25 +505,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #define G256_STAMP(v)
 #endif
   for (int s = 0; s < S; ++s) {
-    const bool more = s + 1 < S;
 #if S2T_G256_DBG & 16
     unsigned long long t0, t1, t2, t3;
 #endif
     G256_STAMP(t0);
-    if (more) advance_fetch();
-    // this wave's pieces of step s have landed; behind the barrier everybody's have, and everybody has finished reading the
-    // other stage.  Behind an epilogue the pieces are OLDER than its stores (they went out during the tile's last step), so the
-    // wait leaves exactly the stores in flight; one step later everything is waited for.
-    if (fresh_tile && counted) __builtin_amdgcn_s_waitcnt(wait_vm(NST));
-    else __builtin_amdgcn_s_waitcnt(wait_vm(0));
-    fresh_tile = false;
+    // This wave's pieces of step s have landed; behind the barrier everybody's have, and everybody has finished reading the
+    // other stage.  What may stay in flight is YOUNGER than those pieces: behind a tile end the (eight) pieces of step s + 1
+    // and the epilogue's stores, one step later the stores alone.
+    if (since == 0) {
+      if (counted) __builtin_amdgcn_s_waitcnt(wait_vm(8 + NST));
+      else __builtin_amdgcn_s_waitcnt(wait_vm(8));
+    } else if (since == 1 && counted) {
+      __builtin_amdgcn_s_waitcnt(wait_vm(NST));
+    } else {
+      __builtin_amdgcn_s_waitcnt(wait_vm(0));
+    }
     asm volatile("s_barrier" ::: "memory");
     G256_STAMP(t1);
-    // (the last step fetches itself once more into the idle stage: an unconditional piece keeps the MFMA stream free of branches)
-#ifndef S2T_G256_SPLIT_HALVES
-#define S2T_G256_SPLIT_HALVES 0
-#endif
-    multiply(s & 1, S2T_G256_SPLIT_HALVES ? (wave >> 2) : 0, [&](int q) __attribute__((always_inline)) { piece_out(q, lkt, (s & 1) ^ 1); });
+    const bool issue = fs == s + 1 && fs < S;
+    multiply(s & 1, 0, [&](int q) __attribute__((always_inline)) {
+      if (issue) piece_out(q, lkt, (s & 1) ^ 1);
+    });
+    if (issue) {
+      ++fs;
+      if (fs < S) advance_fetch();
+    }
+    ++since;
     G256_STAMP(t2);
 #if S2T_G256_DBG & 16
     seg[since_epi == 0 ? 0 : since_epi == 1 ? 1 : 2] += t1 - t0;
@@ -524,6 +539,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     ++since_epi;
 #endif
     if (ckt + 1 == nk) {
+      const bool more = s + 1 < S;
+      since = 1;
+      if (S2T_G256_EARLY2 && fs == s + 2 && fs < S) {
+        asm volatile("s_barrier" ::: "memory");  // every wave has finished reading stage s & 1
+#pragma unroll
+        for (int q = 0; q < 8; ++q) piece_out(q, lkt, s & 1);
+        ++fs;
+        if (fs < S) advance_fetch();
+        since = 0;
+      }
       epilogue(C);
 #if S2T_G256_DBG & 16
       G256_STAMP(t3);
@@ -538,7 +563,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
       zero_acc();
       C = tile_at(C.ord + 1);
       ckt = 0;
-      fresh_tile = true;
     } else {
       ++ckt;
     }
