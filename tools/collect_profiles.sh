@@ -4,6 +4,8 @@
 #   2. encoder forward only, 10 eager passes                                 -> <tag>_encoder_fwd_kernel_stats.csv
 #   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE) of the hipGraph kernel mix  -> <tag>_pmc_traffic.json
 #   4. one --pmc pass of SQ counters (MFMA busy, vector active, stalls)      -> <tag>_pmc_sq.json
+#   5. tools/gemm256_probe.py + SQ counters of the large-tile GEMM           -> <tag>_gemm256_probe.txt, <tag>_gemm256_pmc_sq.json
+#   6. configuration 5b greedy under --kernel-trace --stats                  -> <tag>_config5b_greedy_kernel_stats.csv
 # (A single-rank communicator launches no RCCL kernel — the library short-circuits a one-rank all-reduce — so the overlap of
 #  the bucketed all-reduce with backward can only be traced on a multi-GPU node: tools/ddp_overlap.py reads such a trace.)
 # Every profiler run puts the program itself after "--" and keeps counters apart from traces.
@@ -24,5 +26,14 @@ echo "step 3 done" >&2
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/ps -- python3 bench.py --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline --no-roofline > $out/ps.log 2>&1 || exit 1
 python3 tools/pmc_sq.py $(ls $out/ps/*/*counter_collection.csv | head -1) --json $out/${tag}_pmc_sq.json > $out/${tag}_pmc_sq.txt
 echo "step 4 done" >&2
-rm -rf $out/k $out/e $out/pf $out/pw $out/ps $out/d
+# 5. s2t_gemm's two tile paths side by side (equality + interleaved timings), and the large-tile kernel's SQ counters
+python3 tools/gemm256_probe.py > $out/${tag}_gemm256_probe.txt 2> $out/g5.err || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pg -- python3 tools/g256_time.py > $out/pg.log 2>&1 || exit 1
+python3 tools/pmc_sq.py $(ls $out/pg/*/*counter_collection.csv | head -1) --json $out/${tag}_gemm256_pmc_sq.json > $out/${tag}_gemm256_pmc_sq.txt
+echo "step 5 done" >&2
+# 6. configuration 5b (the d = 512 NAST stack), greedy pass: kernel statistics
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -- python3 tools/run_configs.py 5bg > $out/${tag}_config5b_greedy.log 2>&1 || exit 1
+cp $(ls $out/c5/*/*kernel_stats.csv | head -1) $out/${tag}_config5b_greedy_kernel_stats.csv
+echo "step 6 done" >&2
+rm -rf $out/k $out/e $out/pf $out/pw $out/ps $out/d $out/pg $out/c5
 ls -la $out
