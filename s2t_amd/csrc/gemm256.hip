@@ -43,7 +43,7 @@ constexpr int G256_LDS = 2 * STAGE_BYTES;
 constexpr int wait_vm(int vm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (15 << 8); }
 
 struct Tile {
-  int ord, tm, tn;
+  int ord, tm, tn, z;  // z: batch index (s2t_gemm's two-level batch, z0 = z / zdiv, z1 = z % zdiv)
 };
 
 // VEC: every tensor of the epilogue 16-byte aligned, N % 8 == 0.  PLAIN (needs VEC): the epilogue is bias / activation / alpha /
@@ -80,7 +80,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     nslots = G >> 3;
     nx = 8;
   }
-  const int my_rows = tiles_m > xc ? (tiles_m - xc + nx - 1) / nx : 0;
+  // (a batch is folded into the row-block index: row block rb = z * tiles_m + tm)
+  const int rbs = p.batch * tiles_m;
+  const int my_rows = rbs > xc ? (rbs - xc + nx - 1) / nx : 0;
   const int local_tiles = my_rows * tiles_n;
   if (slot >= local_tiles) return;
   const int my_tiles = (local_tiles - slot + nslots - 1) / nslots;
@@ -91,30 +93,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   auto tile_at = [&](int ord) __attribute__((always_inline)) {
     const int l = slot + ord * nslots;
     const int r = l / tiles_n;
-    return Tile{ord, r * nx + xc, l - r * tiles_n};
+    const int rb = r * nx + xc;
+    const int z = rb / tiles_m;
+    return Tile{ord, rb - z * tiles_m, l - r * tiles_n, z};
   };
 
   // ---- DMA plan.  A K-step's operand image is 32 one-KiB pieces (8 rows each); wave w issues pieces 4 w .. 4 w + 3 of A and of
   // B.  Lane l of piece q lands at row 8 q + (l >> 3), slot l & 7, and therefore FETCHES k-piece (l & 7) ^ swz(row) of the
   // operand row that belongs there.
-  const i32x4 srdA = make_srd(p.A, (uint32_t)(((int64_t)(p0.M - 1) * p.lda + p.K) * 2));
-  const i32x4 srdB = make_srd(p.B, (uint32_t)(((int64_t)((BKM ? p.K : p.N) - 1) * p.ldb + (BKM ? p.N : p.K)) * 2));
+  const int64_t z0max = (p.batch - 1) / p.zdiv, z1max = p.batch > 1 ? p.zdiv - 1 : 0;
+  const i32x4 srdA = make_srd(p.A, (uint32_t)((z0max * p.a_s0 + z1max * p.a_s1 + (int64_t)(p0.M - 1) * p.lda + p.K) * 2));
+  const i32x4 srdB = make_srd(p.B, (uint32_t)((z0max * p.b_s0 + z1max * p.b_s1 + (int64_t)((BKM ? p.K : p.N) - 1) * p.ldb + (BKM ? p.N : p.K)) * 2));
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t lda2 = (uint32_t)(p.lda * 2), ldb2 = (uint32_t)(p.ldb * 2);
   uint32_t va[4], vb[4];
   constexpr uint32_t OOB = 0xfffffff0u;
   auto plan = [&](const Tile& t) __attribute__((always_inline)) {
+    const int z0 = t.z / p.zdiv, z1 = t.z - z0 * p.zdiv;
+    const uint32_t abase = (uint32_t)((z0 * p.a_s0 + z1 * p.a_s1) * 2), bbase = (uint32_t)((z0 * p.b_s0 + z1 * p.b_s1) * 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rho = 32 * wave + 8 * q + (lane >> 3);
       const uint32_t piece = (uint32_t)(16 * ((lane & 7) ^ ((rho >> 1) & 7)));
       const int ga = min(t.tm * TM + rho, p.M - 1);  // rows / columns beyond the problem: a clamped duplicate, never stored
-      va[q] = (uint32_t)ga * lda2 + piece;
+      va[q] = abase + (uint32_t)ga * lda2 + piece;
       if constexpr (BKM) {
         // piece 4 w + q = k-rows 2 (4 w + q) + (lane >> 5) of the step, slot lane & 31 -> columns 8 (slot ^ swz) of the tile
         const int kr = 2 * (4 * wave + q) + (lane >> 5);
         const int col = min(t.tn * TN + 8 * ((lane & 31) ^ (4 * (kr & 3))), p.N - 8);
-        vb[q] = (uint32_t)kr * ldb2 + (uint32_t)(col * 2);
+        vb[q] = bbase + (uint32_t)kr * ldb2 + (uint32_t)(col * 2);
       } else {
         const int i_ = rho & 15, tau = (rho >> 4) & 1;
         int gb;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
         } else {
           gb = min(t.tn * TN + (rho & ~31) + 8 * (i_ >> 2) + 4 * tau + (i_ & 3), p.N - 1);
         }
-        vb[q] = (uint32_t)gb * ldb2 + piece;
+        vb[q] = bbase + (uint32_t)gb * ldb2 + piece;
       }
     }
   };
@@ -227,11 +234,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
 #else
+    const int ez0 = t.z / p.zdiv, ez1 = t.z - ez0 * p.zdiv;
+    const int64_t coff = ez0 * p.c_s0 + ez1 * p.c_s1;
+    const int64_t grow0 = (int64_t)t.z * p.M;  // global row of the batch's row 0 (mask, dropout index)
     Epi<TC, VEC> e{p,
-                   reinterpret_cast<TC*>(p.C),
-                   p.residual ? reinterpret_cast<const TC*>(p.residual) : nullptr,
-                   p.preact ? reinterpret_cast<TC*>(p.preact) : nullptr,
-                   p.dact_z ? reinterpret_cast<const TC*>(p.dact_z) : nullptr,
+                   reinterpret_cast<TC*>(p.C) + coff,
+                   p.residual ? reinterpret_cast<const TC*>(p.residual) + coff : nullptr,
+                   p.preact ? reinterpret_cast<TC*>(p.preact) + (ez0 * p.p_s0 + ez1 * p.p_s1) : nullptr,
+                   p.dact_z ? reinterpret_cast<const TC*>(p.dact_z) + coff : nullptr,
                    nout,
                    false, false, false, false};
     if constexpr (!VEC) {
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     // dropped by the hardware, so every lane ISSUES the same number of stores — the wait at the top of the next step can then
     // leave exactly those in flight
     const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(
-        p.C, 0, (int)(uint32_t)(((int64_t)(p.M - 1) * p.ldc + nout) * (int64_t)sizeof(TC)), 0x00020000);
+        e.C, 0, (int)(uint32_t)(((int64_t)(p.M - 1) * p.ldc + nout) * (int64_t)sizeof(TC)), 0x00020000);
     auto store8 = [&](bool ok, int m, int n, const float (&v)[8]) __attribute__((always_inline)) {
 #if S2T_G256_DBG & 8
       const uint32_t off = 0xfffffff0u;
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
                 st8<TC>(e.P + (int64_t)m * p.ldp + ncol[0], VEC || e.vec_p, VEC ? 8 : nv, a);
                 st8<TC>(e.P + (int64_t)m * p.ldp + nout + ncol[0], VEC || (e.vec_p && ((nout * (int)sizeof(TC)) % 16 == 0)), VEC ? 8 : nv, gt);
               }
-              e.finish(m, ncol[0], (int64_t)m, v);
+              e.finish(m, ncol[0], grow0 + m, v);
             }
           } else if constexpr (VEC) {
             bool ok[2];
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #pragma unroll
               for (int c = 0; c < 2; ++c) {
                 uint32_t r16[8];
-                s2t_rand_run<8>(dkey, (uint64_t)m * (uint64_t)nout + (uint64_t)ncol[c], r16);
+                s2t_rand_run<8>(dkey, (uint64_t)(grow0 + m) * (uint64_t)nout + (uint64_t)ncol[c], r16);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[c][r] = r16[r] >= dth ? v[c][r] * dinv : 0.f;
               }
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
             for (int c = 0; c < 2; ++c)
 #pragma unroll
               for (int r = 0; r < 8; ++r) v[c][r] *= p.alpha;
-            if (p.row_lens && m < p.M && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)m)) {
+            if (p.row_lens && m < p.M && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)(grow0 + m))) {
 #pragma unroll
               for (int r = 0; r < 8; ++r) v[0][r] = v[1][r] = 0.f;
             }
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
               if (m < p.M && ncol[jp] < nout) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] += bpre[jp][r];
-                e.finish(m, ncol[jp], (int64_t)m, v);
+                e.finish(m, ncol[jp], grow0 + m, v);
               }
             }
           }
@@ -590,14 +600,28 @@ bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
   if (mode <= 0) return false;
   if (p.dtype != S2T_BF16 || p.a_kmajor || (p.act == S2T_ACT_GLU && p.b_kmajor)) return false;
 #if S2T_G256_DBG & 16
-  if (p.batch > 1 || p.split_k > 1 || p.c_atomic || p.ws) return false;  // (p.colsum_a receives the stamps)
+  if (p.split_k > 1 || p.c_atomic || p.ws) return false;  // (p.colsum_a receives the stamps)
 #else
-  if (p.batch > 1 || p.split_k > 1 || p.c_atomic || p.colsum_a || p.ws) return false;
+  if (p.split_k > 1 || p.c_atomic || p.colsum_a || p.ws) return false;
+  if (p.batch > 1) {
+    // a batch is folded into the row-block walk: every operand of the whole batch inside one 32-bit byte range, and no
+    // k-major B (its K tail relies on the descriptor's end)
+    if (p.b_kmajor) return false;
+    const int64_t z0max = (p.batch - 1) / p.zdiv, z1max = p.zdiv - 1;
+    const int64_t aspan = (z0max * p.a_s0 + z1max * p.a_s1 + (int64_t)(p.M - 1) * p.lda + p.K) * 2;
+    const int64_t bspan = (z0max * p.b_s0 + z1max * p.b_s1 + (int64_t)(p.N - 1) * p.ldb + p.K) * 2;
+    if (p.a_s0 < 0 || p.a_s1 < 0 || p.b_s0 < 0 || p.b_s1 < 0 || aspan >= (1ll << 32) - 64 || bspan >= (1ll << 32) - 64) return false;
+  }
 #endif
   if (p.K < 128 || (p.K % 8)) return false;          // (a K tail is dropped in whole 16-byte pieces)
+  {
+    // C leaves through a buffer descriptor with 32-bit byte offsets (per batch)
+    const int nout = p.act == S2T_ACT_GLU ? p.N / 2 : p.N;
+    if (((int64_t)(p.M - 1) * p.ldc + nout) * (p.c_dtype == S2T_F32 ? 4 : 2) >= (1ll << 32) - 64) return false;
+  }
   if (p.b_kmajor && (p.N % 8)) return false;         // (a k-major piece is 8 columns)
   if (mode >= 2) return true;
-  const int64_t tiles = (int64_t)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);  // (GLU: N / 2 outputs in 128-column tiles)
+  const int64_t tiles = (int64_t)p.batch * ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);  // (GLU: N / 2 outputs in 128-column tiles)
   // (tools/gemm256_probe.py border: 156 tiles 1.39x, 189 1.38x, 250 1.3x; 126-128 tiles 0.95-1.05x, 88 0.92x, 64 0.78x — below
   // about 0.6 of a round the 128 x 128 path's 2 x 256 slots fill the chip better)
   return tiles >= 150;

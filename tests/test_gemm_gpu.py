@@ -507,3 +507,33 @@ def test_large_tile_glu(cdt, M, nout, K, stride):
     ref = R.double() + 0.5 * z[:, :nout] * torch.sigmoid(z[:, nout:])
     np.testing.assert_allclose(new[:, :nout].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=4e-2)
     np.testing.assert_allclose(new[:, nout:].double().cpu().numpy(), z.cpu().numpy(), rtol=1e-2, atol=4e-2)
+
+
+def test_large_tile_batched_conv_rows():
+    """A batch folded into the row-block walk (the subsampler's per-utterance convolutions: overlapping A rows, GLU, padded-frame
+    mask per utterance, dropout indices over the global row): equal to the 128 x 128 path bit for bit."""
+    g = torch.Generator().manual_seed(9)
+    dev = "cuda"
+    Bz, Tp, Cin, Kw, stride, Cout = 40, 1000, 80, 5, 2, 512
+    Tout = (Tp - Kw) // stride + 1
+    x = _mk((Bz, Tp * Cin), torch.bfloat16, g).to(dev)
+    W = _mk((Cout, Kw * Cin), torch.bfloat16, g, (Kw * Cin) ** -0.5).to(dev)
+    b = _mk((Cout,), torch.float32, g).to(dev)
+    lens = torch.randint(100, Tout + 1, (Bz,), generator=g).to(torch.int32).to(dev)
+    seed = torch.tensor([77], dtype=torch.int64, device=dev)
+    for act, nout in (("glu", Cout // 2), ("relu", Cout)):
+        def call():
+            out = torch.full((Bz, Tout, nout), 7.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm(x, W, out, M=Tout, N=Cout, K=Kw * Cin, lda=stride * Cin, ldb=Kw * Cin, ldc=nout, batch=Bz, a_s=(Tp * Cin, 0),
+                     c_s=(Tout * nout, 0), bias=b, act=act, row_lens=lens, row_T=Tout, drop=(0.1, seed, 5) if act == "relu" else None)
+            return out
+        old, new = _both_paths(call)
+        assert torch.equal(old, new), act
+        t = torch.arange(Tout, device=dev)[None] >= lens[:, None]
+        assert (new[t] == 0).all()
+        A = torch.as_strided(x, (Bz, Tout, Kw * Cin), (Tp * Cin, stride * Cin, 1)).double()
+        z = A @ W.double().t() + b.double()
+        ref = z[..., :nout] * torch.sigmoid(z[..., nout:]) if act == "glu" else torch.relu(z) / 0.9
+        got = new.double()
+        keep = (~t)[..., None] & (got != 0)
+        np.testing.assert_allclose(got[keep].cpu().numpy(), ref[keep].cpu().numpy(), rtol=1e-2, atol=4e-2)
