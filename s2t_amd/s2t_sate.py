@@ -280,7 +280,11 @@ class S2TSATEEncoder(nn.Module):
             ctc_logit = ac["ctc_logit"][0]
             logit = ctc_logit[0] if isinstance(ctc_logit, (list, tuple)) else ctc_logit  # :1008-1012
             x = self.adapter(x, logit.transpose(0, 1).reshape(B * Tn, -1))
-        self.textual_encoder.ctc_out_dtype = self.acoustic_encoder.ctc_out_dtype
+        # dtype of the XCTC logits (the decoded head of the NAST stack): `xctc_out_dtype` when set, else what the acoustic
+        # encoder's CTC head uses — a decoder that reads `xctc_logit` only can leave the acoustic CTC logits (which then feed
+        # nothing but the adapter's softmax) in the compute dtype
+        xdt = getattr(self, "xctc_out_dtype", None)
+        self.textual_encoder.ctc_out_dtype = xdt if xdt is not None else self.acoustic_encoder.ctc_out_dtype
         x, xctc_logit, inter_xctc_logits = self.textual_encoder(x, B, Tn, lens32, mask, **kwargs)
         return {
             "encoder_out": [x.view(B, Tn, d).transpose(0, 1)],

@@ -108,8 +108,9 @@ if "5b" in which or "5bg" in which:  # 5bg: the greedy pass only (profiling)
     a = M.recipe_args(conformer=True, vocab_size=V, dropout=0.15, attention_dropout=0.15, activation_dropout=0.15, **nast)
     m = M.S2TCTCModel.build_model(a, task).prepare(torch.bfloat16, dev)
     print("5b   params %.1f M" % (m.flat.master.numel() / 1e6), flush=True)
-    m.encoder.acoustic_encoder.ctc_out_dtype = torch.float32
+    m.encoder.xctc_out_dtype = torch.float32  # greedy decodes xctc_logit: fp32 there (bit-exact arg-max), compute dtype elsewhere
     greedy_cfg("5b", m, 256, 1000, torch.bfloat16)
+    m.encoder.xctc_out_dtype = None
     if "5b" not in which:
         sys.exit(0)
     m.encoder.acoustic_encoder.ctc_out_dtype = None
