@@ -179,7 +179,7 @@ class CtcCriterion(_CriterionBase):
     # ---- criterions/ctc.py:283-433 ---------------------------------------------------------------------------------
     @torch.no_grad()
     def get_ground_truth_alignment(self, model, sample, **enc_kwargs):
-        from .torch_imputer import best_alignment
+        from .torch_imputer import best_alignment_states
 
         ni = sample["net_input"]
         enc = model.encoder(ni["src_tokens"], ni["src_lengths"], **enc_kwargs)
@@ -194,9 +194,9 @@ class CtcCriterion(_CriterionBase):
         def align(logit_tbv, tokens):
             lp = torch.log_softmax(logit_tbv.float(), dim=-1)  # (T, B, V)
             keep = (tokens != self.pad_idx) & (tokens != self.eos_idx)
-            best = best_alignment(lp, tokens, in_lens, keep.sum(-1), self.blank_idx, zero_infinity=True)
-            T = lp.size(0)
-            pad = torch.tensor([a + [0] * (T - len(a)) for a in best], device=lp.device, dtype=tokens.dtype)
+            # (the reference pads the per-utterance lists with state 0 on the host, criterions/ctc.py:317-320; here the states
+            # never leave the device)
+            pad = best_alignment_states(lp, tokens, in_lens, keep.sum(-1), self.blank_idx, zero_infinity=True).to(tokens.dtype)
             pos = torch.div(pad, 2, rounding_mode="floor").clip(max=tokens.shape[1] - 1)
             oracle = tokens.gather(-1, pos)
             oracle.masked_fill_(pad % 2 == 0, self.blank_idx)

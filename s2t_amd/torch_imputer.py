@@ -68,8 +68,10 @@ def imputer_loss(log_prob, targets, force_emits, input_lengths, target_lengths, 
 
 
 @torch.no_grad()
-def best_alignment(log_prob, targets, input_lengths, target_lengths, blank=0, zero_infinity=False):
-    """torch_imputer/imputer.py:284-325 — list (per utterance) of the most probable CTC state sequence."""
+def best_alignment_states(log_prob, targets, input_lengths, target_lengths, blank=0, zero_infinity=False):
+    """The same alignment as a DEVICE tensor: int32 [B, T], the most probable CTC state per frame, 0 beyond an utterance's
+    length (what the reference's callers build from the lists: ``a + [0] * (T - len(a))``, criterions/ctc.py:317-320).  No
+    host round trip, so a training step that draws its PAE curriculum from the alignment can be captured into a hipGraph."""
     lp, tm, il, tl, lse0, B, T, V, S, L = _prep(log_prob, targets, input_lengths, target_lengths)
     dev = lp.device
     alpha = torch.empty(B, T, L, dtype=torch.float32, device=dev)
@@ -78,6 +80,12 @@ def best_alignment(log_prob, targets, input_lengths, target_lengths, blank=0, ze
     K.ctc_loss_fwd(lp, V, B, T, V, lse0, tm, tm.shape[1], tl, il, blank, alpha, None, L, nll, paths=paths)
     states = torch.empty(B, T, dtype=torch.int32, device=dev)
     K.ctc_backtrace(alpha, paths, tl, il, B, T, L, states)
-    st = states.cpu()
-    ilc = il.cpu()
-    return [st[b, : int(ilc[b])].tolist() for b in range(B)]
+    return states.masked_fill_(torch.arange(T, device=dev)[None, :] >= il.view(B, 1), 0)
+
+
+@torch.no_grad()
+def best_alignment(log_prob, targets, input_lengths, target_lengths, blank=0, zero_infinity=False):
+    """torch_imputer/imputer.py:284-325 — list (per utterance) of the most probable CTC state sequence."""
+    st = best_alignment_states(log_prob, targets, input_lengths, target_lengths, blank, zero_infinity).cpu()
+    ilc = torch.as_tensor(input_lengths).cpu()
+    return [st[b, : int(ilc[b])].tolist() for b in range(st.shape[0])]

@@ -134,6 +134,14 @@ def test_hip_imputer_and_best_alignment_match_oracle(dtype):
     np.testing.assert_allclose(lpd2.grad.cpu().numpy(), lpr.grad.numpy(), rtol=1e-3, atol=1e-4)
     got = best_alignment(lp.cuda(), tmat.cuda(), il.cuda(), tl.cuda())
     assert got == vit
+    # the device form the criterion uses (no host round trip: the PAE curriculum's step can be captured into a hipGraph):
+    # the same states, state 0 beyond an utterance's length — what criterions/ctc.py:317-320 pads the lists with
+    from s2t_amd.torch_imputer import best_alignment_states
+    st = best_alignment_states(lp.cuda(), tmat.cuda(), il.cuda(), tl.cuda()).cpu()
+    assert st.shape == (B, T)
+    for b in range(B):
+        assert st[b, : int(il[b])].tolist() == vit[b]
+        assert (st[b, int(il[b]):] == 0).all()
 
 
 @pytest.mark.gpu

@@ -104,3 +104,37 @@ def test_nast_ctc_criterion_loss_and_grads(golden_dir, name, dtype, tol, gtol):
         n += 1
     print("nast %s %s worst gradient %s %.4f" % (name, str(dtype), worst[0], worst[1]))
     assert n > 60 and worst[1] < gtol, worst
+
+
+def test_nast_training_step_captures_into_a_hipgraph():
+    """The NAST recipe's step — two encoder passes, the Viterbi alignment oracle between them (criterions/ctc.py:283-345), PAE
+    with ground-truth mixing, four CTC terms — has no host round trip: it captures, and its replays train (the alignment
+    states stay on the device, torch_imputer.best_alignment_states)."""
+    import bench
+    from s2t_amd.trainer import Trainer
+    V = 60
+    task = M.FakeTask(V)
+    nast = dict(encoder_type="sate", text_encoder_layers=3, acoustic_encoder="transformer", adapter="inter_league",
+                xctc_weight=1.0, ctc_weight=1.0, share_ctc_and_embed=True, share_xctc_and_embed=True, text_no_pos_emb=True,
+                textual_encoder_embed_norm=False, textual_encoder_no_scale_embedding=True, encoder_normalize_before=True,
+                share_inter_ctc=True, inter_ctc_weight=1.0, inter_ctc_layers="2", inter_xctc_weight=1.0, inter_xctc_layers="2",
+                ctc_pae="inter_league", xctc_pae="inter_league", xctc_cross_attn=True, cross_attn_start_layer=2,
+                cross_attn_layer=1, cross_attn_collaboration_mode="serial", cross_attn_league_drop_net=True,
+                cross_attn_league_drop_net_prob=0.1, xctc_pae_ground_truth_ratio=0.8, xctc_pae_ground_truth_only_mistake=True,
+                pae_oracle_smooth=True, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=4,
+                encoder_layers=3, subsampling_filter=256, activation_fn="relu")
+    a = M.recipe_args(conformer=True, vocab_size=V, dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, **nast)
+    torch.manual_seed(3)
+    m = M.S2TCTCModel.build_model(a, task).prepare(torch.bfloat16, DEV)
+    m.train()
+    crit = C.CtcCriterion(None, task, ctc_weight=1.0, inter_ctc_weight=1.0, xctc_weight=1.0, inter_xctc_weight=1.0)
+    crit.train()
+    tr = Trainer(m, crit, lr=1e-3, warmup_updates=1)
+    sample, _ = bench.synthetic_batch(6, 240, V, 1, DEV)
+    sample["transcript"] = {"tokens": sample["target"]}
+    first = float(tr.train_step(sample)[0])
+    tr.capture(sample)
+    losses = [float(tr.replay()[0]) for _ in range(12)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)), losses
+    assert min(losses[-3:]) < first, (first, losses)

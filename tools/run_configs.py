@@ -130,3 +130,14 @@ if "5b" in which or "5bg" in which:  # 5bg: the greedy pass only (profiling)
     dt = (time.perf_counter() - t0) / 4
     print("5b   train (eager, 2 encoder passes: alignment oracle + curriculum)  64 x 1000 : %7.2f ms/step  %7.3f M frames/s  loss %.1f  peak mem %.1f GB" % (
         dt * 1e3, frames / dt / 1e6, float(out[0]), torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
+    # the same step as ONE hipGraph (the alignment oracle stays on the device: torch_imputer.best_alignment_states)
+    tr.capture(sample)
+    for _ in range(2):
+        tr.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(6):
+        out = tr.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 6
+    print("5b   train (hipGraph replay)  64 x 1000 : %7.2f ms/step  %7.3f M frames/s  loss %.1f" % (dt * 1e3, frames / dt / 1e6, float(out[0])), flush=True)
