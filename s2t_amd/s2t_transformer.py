@@ -301,16 +301,30 @@ class S2TTransformerEncoder(nn.Module):
         }
 
     def _compress(self, x, logit2d, L, B, T, lens32, mask):
-        """s2t_transformer.py:1948-2040 for layer L.  One D2H copy of the B new lengths decides the new T' (the reference
-        synchronises on ``max(keep_flag.sum(0))`` as well), so this path is eager-only (no hipGraph capture)."""
+        """s2t_transformer.py:1948-2040 for layer L.  Eager form: one D2H copy of the B new lengths decides the new T' (the
+        reference synchronises on ``max(keep_flag.sum(0))`` as well).  ``compression_bounded`` (set by Trainer.capture, implied
+        while a stream is capturing): no host copy, T stays the bound."""
         src, new_lens = Fn.ctc_compress_plan(logit2d.detach(), lens32, B, T, 0, self.compression_thresholds[L])
-        nl = new_lens.cpu()
-        kept_all = int(nl.sum()) == B * T  # keep_flag.all(): padded frames count as dropped
-        if int(nl.min()) > 0 and not kept_all:
-            Tn = int(nl.max())
-            x = Fn.CompressRowsFn.apply(x, src, new_lens, B, T, Tn)
-            T, lens32 = Tn, new_lens
+        if getattr(self, "compression_bounded", False) or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # Capturable form: the frame axis keeps its uncompressed BOUND T and only the lengths change, on the device.  The
+            # reference's two host decisions (:1996-2001: compress only when no utterance would become empty and something is
+            # dropped) select between the plan and the identity with device-side flags.  Outputs equal the exact form's on the
+            # first max(new_lens) frames and are padding behind (masks / lengths say so to every consumer).
+            ok = (new_lens.min() > 0) & (new_lens.sum() != B * T)
+            ident = torch.arange(T, dtype=torch.int32, device=x.device)[None, :].expand(B, T)
+            src = torch.where(ok, src, ident).contiguous()
+            new_lens = torch.where(ok, new_lens, lens32)
+            x = Fn.CompressRowsFn.apply(x, src, new_lens, B, T, T)
+            lens32 = new_lens
             mask = torch.arange(T, device=x.device)[None, :] >= lens32[:, None]
+        else:
+            nl = new_lens.cpu()
+            kept_all = int(nl.sum()) == B * T  # keep_flag.all(): padded frames count as dropped
+            if int(nl.min()) > 0 and not kept_all:
+                Tn = int(nl.max())
+                x = Fn.CompressRowsFn.apply(x, src, new_lens, B, T, Tn)
+                T, lens32 = Tn, new_lens
+                mask = torch.arange(T, device=x.device)[None, :] >= lens32[:, None]
         if self.compression_norm:
             x = getattr(self, "compression_norm%d" % L)(x)
         if self.compression_pos and self.attn_type != "rel_pos":

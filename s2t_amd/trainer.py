@@ -115,6 +115,9 @@ class Trainer:
         if sample_size_global is None:
             sample_size_global = self.world * sample["ntokens"]
         self._static = sample
+        for mod in self.model.modules():  # CTC-guided compression keeps its frame axis at the bound from here on (no host copy)
+            if hasattr(mod, "compression_layers"):
+                mod.compression_bounded = True
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

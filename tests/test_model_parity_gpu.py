@@ -455,3 +455,60 @@ def test_ctc_decoder_inter_logit_option(golden_dir):
         assert [h[0]["tokens"].tolist() for h in hyps] == [t.tolist() for t in ref_h]
     with pytest.raises(NotImplementedError):
         M.CTCDecoder([model], Namespace(ctc_self_ensemble=True), None)
+
+
+@pytest.mark.parametrize("name", ["conformer_compress", "transformer_compress", "conformer_compress_margin"])
+def test_bounded_compression_equals_the_reference_on_the_kept_frames(golden_dir, name):
+    """CTC-guided compression with the frame axis kept at its uncompressed bound (the capturable form: device-side lengths, no
+    host copy): the reference's outputs on the first T' = max(new lengths) frames, padding behind them, the same decoder
+    logits."""
+    z = load(golden_dir, name)
+    model, cfg = build(z, torch.float32)
+    model.eval()
+    model.encoder.compression_bounded = True
+    src = torch.from_numpy(z["in::src_tokens"]).to(DEV)
+    lens = torch.from_numpy(z["in::src_lengths"]).to(DEV)
+    prev = torch.from_numpy(z["in::prev_output_tokens"]).to(DEV)
+    with torch.no_grad():
+        enc = model.encoder(src, lens)
+        logits, _ = model.decoder(prev, encoder_out=enc)
+    ref_mask = z["out::encoder_padding_mask"]
+    Tn = ref_mask.shape[1]
+    mask = enc["encoder_padding_mask"][0].cpu().numpy()
+    assert mask.shape[1] >= Tn and (mask[:, :Tn] == ref_mask).all() and mask[:, Tn:].all()
+    assert rel_err(enc["encoder_out"][0][:Tn], z["out::encoder_out"]) < 1e-3
+    # (frames behind T' are padding like any other: the final LayerNorm leaves its bias there, the mask marks them)
+    assert rel_err(enc["ctc_logit"][0][:Tn], z["out::ctc_logit"]) < 1e-3
+    assert rel_err(logits, z["out::decoder_logits"]) < 1e-3
+
+
+def test_training_step_with_compression_captures_into_a_hipgraph(golden_dir):
+    """Trainer.capture switches the encoder to the bounded form: the step with a compression layer is one hipGraph, and its
+    replays follow the eager (exact-form) trajectory from the same state (fixture weights, dropout 0)."""
+    from s2t_amd.trainer import Trainer
+    z = load(golden_dir, "conformer_compress_margin")
+    losses = {}
+    for mode in ("eager", "graph"):
+        model, cfg = build(z, torch.float32)
+        model.train()
+        for mod in model.modules():
+            if isinstance(getattr(mod, "p", None), float):
+                mod.p = 0.0
+            for attr in ("dropout", "attention_dropout", "activation_dropout", "dropout_p"):
+                if isinstance(getattr(mod, attr, None), float):
+                    setattr(mod, attr, 0.0)
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(model.decoder.output_projection.weight.shape[0]),
+                                                           label_smoothing=0.1, ctc_weight=cfg["ctc_weight"])
+        tr = Trainer(model, crit, lr=1e-4, warmup_updates=1)
+        sample = {"net_input": {"src_tokens": torch.from_numpy(z["in::src_tokens"]).to(DEV),
+                                "src_lengths": torch.from_numpy(z["in::src_lengths"]).to(DEV),
+                                "prev_output_tokens": torch.from_numpy(z["in::prev_output_tokens"]).to(DEV)},
+                  "target": torch.from_numpy(z["in::target"]).to(DEV), "ntokens": int(z["in::ntokens"])}
+        if mode == "graph":
+            tr.capture(sample, warmup=0)
+            assert model.encoder.compression_bounded
+            losses[mode] = [float(tr.replay()[0]) for _ in range(4)]
+        else:
+            losses[mode] = [float(tr.train_step(sample)[0]) for _ in range(4)]
+    assert all(np.isfinite(losses["graph"]))
+    np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=5e-3)
