@@ -820,6 +820,52 @@ __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const T* __restric
     st_from_f32<T>(xr + c, ld_as_f32<T>(pr + c) * (ld_as_f32<T>(dr + c) - dot) * inv_tau);
 }
 
+// The same for bf16 rows of at most 256 * 8 * NPT elements with P and dP held in registers (one read of each: the two-pass form
+// reads both twice in 2-byte scalars): V % 8 == 0, 16-byte aligned rows.
+template <int NPT>
+__global__ __launch_bounds__(256) void row_softmax_bwd_reg_kernel(const bf16_t* __restrict__ p, int64_t ldp,
+                                                                  const bf16_t* __restrict__ dp, int64_t lddp,
+                                                                  bf16_t* __restrict__ dx, int64_t lddx, int V, float inv_tau) {
+  __shared__ float sd[4];
+  const int tid = threadIdx.x;
+  const bf16_t* pr = p + (int64_t)blockIdx.x * ldp;
+  const bf16_t* dr = dp + (int64_t)blockIdx.x * lddp;
+  uint4 rp[NPT], rd[NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int c = (i * 256 + tid) * 8;
+    rp[i] = c < V ? *reinterpret_cast<const uint4*>(pr + c) : make_uint4(0, 0, 0, 0);
+    rd[i] = c < V ? *reinterpret_cast<const uint4*>(dr + c) : make_uint4(0, 0, 0, 0);
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const uint32_t a[4] = {rp[i].x, rp[i].y, rp[i].z, rp[i].w}, b[4] = {rd[i].x, rd[i].y, rd[i].z, rd[i].w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dot += __uint_as_float(a[q] << 16) * __uint_as_float(b[q] << 16) +
+             __uint_as_float(a[q] & 0xffff0000u) * __uint_as_float(b[q] & 0xffff0000u);
+  }
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) sd[tid >> 6] = dot;
+  __syncthreads();
+  dot = sd[0] + sd[1] + sd[2] + sd[3];
+  bf16_t* xr = dx + (int64_t)blockIdx.x * lddx;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int c = (i * 256 + tid) * 8;
+    if (c < V) {
+      const uint32_t a[4] = {rp[i].x, rp[i].y, rp[i].z, rp[i].w}, b[4] = {rd[i].x, rd[i].y, rd[i].z, rd[i].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        o[q] = bf16pack(__uint_as_float(a[q] << 16) * (__uint_as_float(b[q] << 16) - dot) * inv_tau,
+                        __uint_as_float(a[q] & 0xffff0000u) * (__uint_as_float(b[q] & 0xffff0000u) - dot) * inv_tau);
+      *reinterpret_cast<uint4*>(xr + c) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 // best-alignment backtrace (torch_imputer/imputer.py:245-259): start at argmax(alpha[T-1, L-2:]) + L-2 (state 0 when
 // L == 1; first maximum on ties), follow the back-pointers; one thread per utterance, states[b, t] (-1 beyond the length)
 __global__ void ctc_backtrace_kernel(const float* __restrict__ alpha, const int32_t* __restrict__ paths,
@@ -967,8 +1013,18 @@ extern "C" int s2t_row_softmax_bwd(int dtype, const void* p, int64_t ldp, const 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
     hipLaunchKernelGGL(row_softmax_bwd_kernel<float>, grid, block, 0, s, (const float*)p, ldp, (const float*)dp, lddp, (float*)dx, lddx, V, inv_tau);
-  else if (dtype == S2T_BF16)
-    hipLaunchKernelGGL(row_softmax_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)p, ldp, (const bf16_t*)dp, lddp, (bf16_t*)dx, lddx, V, inv_tau);
-  else return S2T_ERR_DTYPE;
+  else if (dtype == S2T_BF16) {
+    const bool reg = V % 8 == 0 && V <= 256 * 8 * 5 && ldp % 8 == 0 && lddp % 8 == 0 && lddx % 8 == 0 && ((uintptr_t)p % 16) == 0 &&
+                     ((uintptr_t)dp % 16) == 0 && ((uintptr_t)dx % 16) == 0;
+    const int npt = (V + 2047) / 2048;
+#define GO(N) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<N>, grid, block, 0, s, (const bf16_t*)p, ldp, (const bf16_t*)dp, lddp, (bf16_t*)dx, lddx, V, inv_tau)
+    if (reg && npt <= 1) GO(1);
+    else if (reg && npt == 2) GO(2);
+    else if (reg && npt == 3) GO(3);
+    else if (reg && npt == 4) GO(4);
+    else if (reg && npt == 5) GO(5);
+    else hipLaunchKernelGGL(row_softmax_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)p, ldp, (const bf16_t*)dp, lddp, (bf16_t*)dx, lddx, V, inv_tau);
+#undef GO
+  } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }

@@ -395,6 +395,84 @@ __global__ __launch_bounds__(256) void ln256_bwd_kernel(const bf16_t* __restrict
   atomicAdd(w + 256 + c, sb);
 }
 
+// cols = 512: a wave per row (16-byte pieces), two rows per wave and trip with every load of both requested first; the column
+// sums of dgamma / dbeta stay in registers over the trips and leave as one set of atomics per workgroup (as above)
+__global__ __launch_bounds__(256) void ln512_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        const bf16_t* __restrict__ dy, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                        const bf16_t* __restrict__ dres, float* __restrict__ ws,
+                                                        int replicas, int64_t rows, const int32_t* __restrict__ row_lens,
+                                                        int row_T) {
+  __shared__ float red[2][4][512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  rows = s2t_live_rows(row_lens, row_T, rows);
+  float g[8];
+  ld4_as_f32<float>(gamma + lane * 8, reinterpret_cast<float (&)[4]>(g[0]));
+  ld4_as_f32<float>(gamma + lane * 8 + 4, reinterpret_cast<float (&)[4]>(g[4]));
+  float ag[8], ab[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) ag[r] = ab[r] = 0.f;
+  constexpr int RPW = 2;
+  const int64_t per_trip = (int64_t)gridDim.x * 4 * RPW;
+  const int64_t trips = (rows + per_trip - 1) / per_trip;
+  for (int64_t it = 0; it < trips; ++it) {
+    const int64_t row0 = ((it * gridDim.x + blockIdx.x) * 4 + wv) * RPW;
+    uint4 tx[RPW], td[RPW], tr[RPW];
+    float mu[RPW], rs[RPW];
+    bool valid[RPW], masked[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int64_t row = row0 + u;
+      valid[u] = row < rows;
+      const int64_t rr = valid[u] ? row : rows - 1;
+      tx[u] = *reinterpret_cast<const uint4*>(x + rr * 512 + lane * 8);
+      td[u] = *reinterpret_cast<const uint4*>(dy + rr * 512 + lane * 8);
+      tr[u] = dres ? *reinterpret_cast<const uint4*>(dres + rr * 512 + lane * 8) : make_uint4(0, 0, 0, 0);
+      mu[u] = mean[rr];
+      rs[u] = rstd[rr];
+      masked[u] = !valid[u];
+      if (valid[u] && row_lens) masked[u] = s2t_row_masked(row_lens, row_T, row);
+    }
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      float xv[8], dv[8], xh[8], dg[8];
+      unpack8(tx[u], xv);
+      unpack8(td[u], dv);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float d = masked[u] ? 0.f : dv[r];
+        xh[r] = (xv[r] - mu[u]) * rs[u];
+        dg[r] = d * g[r];
+        s1 += dg[r];
+        s2 += dg[r] * xh[r];
+        ag[r] += d * xh[r];
+        ab[r] += d;
+      }
+      s1 = wave_sum(s1) * (1.f / 512.f);
+      s2 = wave_sum(s2) * (1.f / 512.f);
+      if (valid[u]) {
+        float o[8], q[8];
+        unpack8(tr[u], q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = rs[u] * (dg[r] - s1 - xh[r] * s2) + q[r];
+        *reinterpret_cast<uint4*>(dx + (row0 + u) * 512 + lane * 8) = pack8f(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    red[0][wv][lane * 8 + r] = ag[r];
+    red[1][wv][lane * 8 + r] = ab[r];
+  }
+  __syncthreads();
+  float* w = ws + (int64_t)(blockIdx.x % replicas) * 1024;
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    atomicAdd(w + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(w + 512 + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
 // dgamma += sum_r ws[r][0][:] ; dbeta += sum_r ws[r][1][:]
 __global__ void ln_bwd_finalize_kernel(float* __restrict__ ws, int replicas, int cols, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta) {
@@ -473,6 +551,12 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* x, const float* gamma, c
     hipLaunchKernelGGL(ln256_bwd_kernel, dim3((unsigned)nb8), block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean,
                        rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, row_lens, row_T, (bf16_t*)dx_drop, drop_p,
                        drop_seed, drop_site);
+  } else if (dtype == S2T_BF16 && cols == 512 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
+             ((uintptr_t)dres % 16) == 0) {
+    int64_t nb8 = (rows + 7) / 8;
+    if (nb8 > 512) nb8 = 512;
+    hipLaunchKernelGGL(ln512_bwd_kernel, dim3((unsigned)nb8), block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean, rstd,
+                       (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, row_lens, row_T);
   } else if (dtype == S2T_BF16)
     LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)x, gamma, (const bf16_t*)dy, mean, rstd, (bf16_t*)dx, (const bf16_t*)dres, ws, replicas, rows, cols, row_lens, row_T);
   else return S2T_ERR_DTYPE;

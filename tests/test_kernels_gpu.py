@@ -599,3 +599,28 @@ def test_row_softmax_fwd(dtype, rows, V, ld):
                                    atol=1e-6)
         assert (p[:, V:] == 7.0).all()
         assert abs(p[:, :V].double().sum(-1).cpu() - 1).max() < (2e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,V,ld", [(37, 10000, 10000), (5, 2048, 2056), (6, 1000, 1000), (4, 37, 40), (3, 2050, 2056), (2, 12000, 12000)])
+def test_row_softmax_bwd(dtype, rows, V, ld):
+    """dx = P * (dP - sum_j P dP) / tau (the PAE softmax's backward): both the register-resident bf16 form and the two-pass
+    form against autograd through torch.softmax."""
+    g = torch.Generator().manual_seed(V * 3 + rows)
+    x = (rnd((rows, V), torch.float32, g) * 3).requires_grad_(True)
+    tau = 0.7
+    P = torch.softmax(x / tau, -1)
+    dP = rnd((rows, V), torch.float32, g)
+    Pq, dPq = P.detach().to(dtype), dP.to(dtype)
+    (torch.softmax(x / tau, -1) * dPq.float()).sum().backward()
+    # reference on the ROUNDED operands the kernel sees
+    ref = Pq.double() * (dPq.double() - (Pq.double() * dPq.double()).sum(-1, keepdim=True)) / tau
+    pd = torch.zeros(rows, ld, dtype=dtype, device=DEV); pd[:, :V] = Pq.to(DEV)
+    dd = torch.zeros(rows, ld, dtype=dtype, device=DEV); dd[:, :V] = dPq.to(DEV)
+    dx = torch.full((rows, ld), 7.0, dtype=dtype, device=DEV)
+    K.row_softmax_bwd(pd, ld, dd, ld, dx, ld, rows, V, 1.0 / tau)
+    got = dx[:, :V].double().cpu()
+    scale = ref.abs().max().item()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-5,
+                               atol=(1e-2 if dtype == torch.bfloat16 else 1e-6) * scale)
+    assert (dx[:, V:] == 7.0).all()
