@@ -212,10 +212,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
                                                                acc[i][j], 0, 0, 0);
 #endif
         }
-        // The eight pieces of the next step go out behind the MFMA groups of ONE half of this step.  A wave is parked for ~100+
-        // cycles per piece (the CU's vector-memory path takes 64 pieces a step at ~34 B/clk: in-kernel stamps, tools/g256_stamps.py)
-        // and issues no MFMA meanwhile, so the two waves of a SIMD (w and w + 4) take DIFFERENT halves: one multiplies while
-        // the other is parked.
+        // The eight pieces of the next step go out behind the MFMA groups of the FIRST half of this step (DKS = 0; issuing them
+        // evenly over the step measured the same, letting the two waves of a SIMD issue in different halves — DKS = wave >> 2 —
+        // 5 % slower): they then have the second half to land.
         if (ks == DKS) side(i);
       }
     }
@@ -459,24 +458,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     }
 #endif
   };
-
-  // ---- staggered start.  Every tile takes the same time, so all 256 workgroups would reach their epilogues together and
-  // write 256 tiles (33 MB of bf16) at once: the L2s hold the previous round's tiles as dirty lines, the burst drains at the
-  // HBM write rate (~6 us) and every workgroup waits for it once per tile (with the stores dropped a 64000 x 2048 x 512 launch
-  // takes 150 us instead of 200).  Spreading the starts over about one burst length keeps the epilogues apart for the whole
-  // walk: somebody is always multiplying while somebody else stores.
-#ifndef S2T_G256_STAGGER
-#define S2T_G256_STAGGER 0  // percent of one burst length (0: all workgroups start together)
-#endif
-#if S2T_G256_STAGGER
-  if (my_tiles > 1 || nk >= 8) {
-    // 100 MHz ticks: the bytes of one round of C tiles at ~5 TB/s, dealt by a bit-reversed workgroup index (neighbours far apart)
-    const uint32_t span = (uint32_t)((uint64_t)G * (uint64_t)(TM * TN * (int)sizeof(TC)) / 50000u) * S2T_G256_STAGGER / 100u;
-    const uint32_t rev = __builtin_bitreverse32((uint32_t)blockIdx.x) >> 24;  // 8 bits
-    const uint64_t until = __builtin_amdgcn_s_memrealtime() + (uint64_t)(span * rev / 256u);
-    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
 
   // ---- the walk: step s multiplies LDS stage s & 1 while step s + 1 lands in the other.
   // (S2T_G256_EARLY2, an experiment that LOST: at the end of a tile the stage just multiplied is free as well, so behind one more
