@@ -106,20 +106,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   const i32x4 srdB = make_srd(p.B, (uint32_t)((z0max * p.b_s0 + z1max * p.b_s1 + (int64_t)((BKM ? p.K : p.N) - 1) * p.ldb + (BKM ? p.N : p.K)) * 2));
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t lda2 = (uint32_t)(p.lda * 2), ldb2 = (uint32_t)(p.ldb * 2);
-  uint32_t va[4], vb[4];
+  // WHO issues: a wave is parked on each piece until the CU's DMA path takes it (tools/ubench/dma_stream.hip: the 64 pieces of a
+  // step take ~1.1 k cycles — 60 B/clk/CU from L2, whoever issues them and however many CUs stream — and a wave that issues any of
+  // them sits through most of that), and a parked wave issues no MFMA: with all eight waves issuing (S2T_G256_LOADERS = 8, shipped)
+  // every SIMD idles for about that long per step, which is the gap between this kernel's ~3.8 k cycles per step and the 2 k of its
+  // MFMAs.  FOUR loader waves (0-3: one per SIMD, 16 pieces each) let the SIMD's other wave multiply meanwhile: 3.26 k -> 2.8 k
+  // cycles per step in the micro-benchmark with this kernel's reads and MFMAs, but nothing in the kernel itself (the loader's own
+  // reads + MFMAs, scheduled by the compiler for two waves sharing a SIMD, take ~2.4 k cycles behind its ~1.5 k parked: in-kernel
+  // stamps) — it needs hand-pipelined fragment reads to pay, and costs eight offset registers.  Kept as a switch.
+#ifndef S2T_G256_LOADERS
+#define S2T_G256_LOADERS 8
+#endif
+  constexpr int NLD = (VEC && !PLAIN) ? 8 : S2T_G256_LOADERS;   // 8: every wave issues its own 4 + 4 pieces
+  constexpr int PPW = 32 / NLD;           // pieces per issuing wave and operand
+  const bool loader = wave < NLD;
+  uint32_t va[PPW], vb[PPW];
   constexpr uint32_t OOB = 0xfffffff0u;
   auto plan = [&](const Tile& t) __attribute__((always_inline)) {
     const int z0 = t.z / p.zdiv, z1 = t.z - z0 * p.zdiv;
     const uint32_t abase = (uint32_t)((z0 * p.a_s0 + z1 * p.a_s1) * 2), bbase = (uint32_t)((z0 * p.b_s0 + z1 * p.b_s1) * 2);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rho = 32 * wave + 8 * q + (lane >> 3);
+    for (int q = 0; q < PPW; ++q) {
+      const int pg = PPW * wave + q;       // piece of the operand image (8 rows, or 2 k-rows of a k-major B)
+      const int rho = 8 * pg + (lane >> 3);
       const uint32_t piece = (uint32_t)(16 * ((lane & 7) ^ ((rho >> 1) & 7)));
       const int ga = min(t.tm * TM + rho, p.M - 1);  // rows / columns beyond the problem: a clamped duplicate, never stored
       va[q] = abase + (uint32_t)ga * lda2 + piece;
       if constexpr (BKM) {
         // piece 4 w + q = k-rows 2 (4 w + q) + (lane >> 5) of the step, slot lane & 31 -> columns 8 (slot ^ swz) of the tile
-        const int kr = 2 * (4 * wave + q) + (lane >> 5);
+        const int kr = 2 * pg + (lane >> 5);
         const int col = min(t.tn * TN + 8 * ((lane & 31) ^ (4 * (kr & 3))), p.N - 8);
         vb[q] = bbase + (uint32_t)kr * ldb2 + (uint32_t)(col * 2);
       } else {
@@ -136,18 +151,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   };
   auto piece_out = [&](int q, int kt, int stage) __attribute__((always_inline)) {
 #if !(S2T_G256_DBG & 1)
-    const uint32_t dst = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)((4 * wave + (q & 3)) * 1024);
+    // q: 0 .. PPW-1 the wave's A pieces, PPW .. 2 PPW - 1 its B pieces
+    const int qq = q % PPW;
+    const uint32_t dst = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)((PPW * wave + qq) * 1024);
     // row-major operand in the tail step: this lane's k-piece is (lane & 7) ^ swz(row) — dropped when it starts at or beyond K
     const bool tail = kt == nk - 1 && krem < TK;
-    const int kpiece = (lane & 7) ^ ((4 * (q & 3) + (lane >> 4)) & 7);
-    if (q < 4) {
-      const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : va[q];
+    const int kpiece = (lane & 7) ^ ((4 * (qq & 1) + (lane >> 4)) & 7);  // swz(row) = (row >> 1) & 7, row = 8 pg + (lane >> 3)
+    if (q < PPW) {
+      const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : va[qq];
       dma16(dst, v, srdA, (uint32_t)(kt * (TK * 2)));
     } else if constexpr (BKM) {
       // (k-rows at and beyond K lie beyond the descriptor's range by themselves)
-      dma16(dst + OP_BYTES, vb[q - 4], srdB, (uint32_t)kt * (uint32_t)TK * ldb2);
+      dma16(dst + OP_BYTES, vb[qq], srdB, (uint32_t)kt * (uint32_t)TK * ldb2);
     } else {
-      const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : vb[q - 4];
+      const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : vb[qq];
       dma16(dst + OP_BYTES, v, srdB, (uint32_t)(kt * (TK * 2)));
     }
 #endif
@@ -466,8 +483,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   Tile L = tile_at(0);  // tile / K-step of the next step to FETCH (step fs)
   int lkt = 0;
   plan(L);
+  if (loader) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) piece_out(q, 0, 0);
+    for (int q = 0; q < 2 * PPW; ++q) piece_out(q, 0, 0);
+  }
   auto advance_fetch = [&]() __attribute__((always_inline)) {
     if (lkt + 1 < nk) {
       ++lkt;
@@ -504,8 +523,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     // other stage.  What may stay in flight is YOUNGER than those pieces: behind a tile end the (eight) pieces of step s + 1
     // and the epilogue's stores, one step later the stores alone.
     if (since == 0) {
-      if (counted) __builtin_amdgcn_s_waitcnt(wait_vm(8 + NST));
-      else __builtin_amdgcn_s_waitcnt(wait_vm(8));
+      if (counted) __builtin_amdgcn_s_waitcnt(wait_vm(2 * PPW + NST));
+      else __builtin_amdgcn_s_waitcnt(wait_vm(2 * PPW));
     } else if (since == 1 && counted) {
       __builtin_amdgcn_s_waitcnt(wait_vm(NST));
     } else {
@@ -514,9 +533,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     asm volatile("s_barrier" ::: "memory");
     G256_STAMP(t1);
     const bool issue = fs == s + 1 && fs < S;
-    multiply(s & 1, 0, [&](int q) __attribute__((always_inline)) {
-      if (issue) piece_out(q, lkt, (s & 1) ^ 1);
-    });
+    if constexpr (NLD == 8) {
+      multiply(s & 1, 0, [&](int q) __attribute__((always_inline)) {
+        if (issue) piece_out(q, lkt, (s & 1) ^ 1);
+      });
+    } else {
+      if (issue && loader) {
+#pragma unroll
+        for (int q = 0; q < 2 * PPW; ++q) piece_out(q, lkt, (s & 1) ^ 1);
+      }
+      multiply(s & 1, 0, [&](int) __attribute__((always_inline)) {});
+    }
     if (issue) {
       ++fs;
       if (fs < S) advance_fetch();
@@ -534,8 +561,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
       since = 1;
       if (S2T_G256_EARLY2 && fs == s + 2 && fs < S) {
         asm volatile("s_barrier" ::: "memory");  // every wave has finished reading stage s & 1
+        if (loader) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) piece_out(q, lkt, s & 1);
+          for (int q = 0; q < 2 * PPW; ++q) piece_out(q, lkt, s & 1);
+        }
         ++fs;
         if (fs < S) advance_fetch();
         since = 0;
@@ -609,7 +638,8 @@ bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
 }
 
 static bool g256_plain(const s2t_gemm_args& p, bool vec) {
-  return vec && p.act != S2T_ACT_GLU && !p.dact_z && !(p.drop_p > 0.f) && !p.preact && !p.row_lens;
+  // (a row map that only BOUNDS the rows — S2T_ROWS_BOUND — is no mask: the live row count is read in every instantiation)
+  return vec && p.act != S2T_ACT_GLU && !p.dact_z && !(p.drop_p > 0.f) && !p.preact && !(p.row_lens && p.row_T != S2T_ROWS_BOUND);
 }
 
 int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
