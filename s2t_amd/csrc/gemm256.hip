@@ -108,14 +108,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   const uint32_t lda2 = (uint32_t)(p.lda * 2), ldb2 = (uint32_t)(p.ldb * 2);
   // WHO issues: a wave is parked on each piece until the CU's DMA path takes it (tools/ubench/dma_stream.hip: the 64 pieces of a
   // step take ~1.1 k cycles — 60 B/clk/CU from L2, whoever issues them and however many CUs stream — and a wave that issues any of
-  // them sits through most of that), and a parked wave issues no MFMA: with all eight waves issuing (S2T_G256_LOADERS = 8, shipped)
-  // every SIMD idles for about that long per step, which is the gap between this kernel's ~3.8 k cycles per step and the 2 k of its
-  // MFMAs.  FOUR loader waves (0-3: one per SIMD, 16 pieces each) let the SIMD's other wave multiply meanwhile: 3.26 k -> 2.8 k
-  // cycles per step in the micro-benchmark with this kernel's reads and MFMAs, but nothing in the kernel itself (the loader's own
-  // reads + MFMAs, scheduled by the compiler for two waves sharing a SIMD, take ~2.4 k cycles behind its ~1.5 k parked: in-kernel
-  // stamps) — it needs hand-pipelined fragment reads to pay, and costs eight offset registers.  Kept as a switch.
+  // them sits through most of that), and a parked wave issues no MFMA: with all eight waves issuing, every SIMD idles for about
+  // that long per step.  FOUR loader waves (0-3: one per SIMD, 16 pieces each, S2T_G256_LOADERS = 4) let the SIMD's other wave
+  // multiply meanwhile: 3.26 k -> 2.8 k cycles per step in the micro-benchmark with this kernel's reads and MFMAs; in the kernel,
+  // together with the hand-pipelined fragment reads below (a wave must run well WITHOUT a partner hiding its LDS latency), in-kernel
+  // stamps read 3.8 k -> 3.0 k cycles per step — and 3-4 % of wall time: the chip is at its power limit in this loop and gives the
+  // saved cycles back as clock (1.55 -> 1.77 GHz; MI355X_MICROARCH.md, DVFS give-back).
 #ifndef S2T_G256_LOADERS
-#define S2T_G256_LOADERS 8
+#define S2T_G256_LOADERS 4
 #endif
   constexpr int NLD = (VEC && !PLAIN) ? 8 : S2T_G256_LOADERS;   // 8: every wave issues its own 4 + 4 pieces
   constexpr int PPW = 32 / NLD;           // pieces per issuing wave and operand
@@ -188,47 +188,87 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   const uint32_t tb0 = (uint32_t)((8 * y + (x >> 2)) * 512);
   const int tq = x >> 2, tp = x & 3;
 
+  // Fragment reads of one k-sub-step (32 k): the wave's four B fragments / two of its eight A fragments
+  auto rd_b = [&](int stage, int ks, uint4 (&fb)[4]) __attribute__((always_inline)) {
+    if constexpr (BKM) {
+      const char* img = smem + stage * STAGE_BYTES + OP_BYTES + ks * (32 * 512);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t w[4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          // swizzle key of k-row 8 y + 4 half + q (+ 32 ks): 4 * (row & 3) = 4 q
+          const char* a = img + tb0 + half * (4 * 512) + 16 * ((8 * wn + 4 * (j >> 1) + tp) ^ (4 * tq)) + 8 * (j & 1);
+          const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+          const uint2 tt = __builtin_bit_cast(uint2, t);
+          w[2 * half] = tt.x;
+          w[2 * half + 1] = tt.y;
+        }
+        fb[j] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    } else {
+      // (x*128 + 16*((4+y) ^ (x>>1))) = lo0 ^ 64
+      const char* lb = fb0 + stage * STAGE_BYTES + (ks ? (int)((lo0 ^ 64u) - lo0) : 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(lb + j * 2048);
+    }
+  };
+  auto mma = [&](int i, int j, const uint4& b, const uint4& a) __attribute__((always_inline)) {
+#if S2T_G256_DBG & 2
+    asm volatile("" :: "v"(b.x), "v"(b.w), "v"(a.x), "v"(a.w));
+#else
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), acc[i][j], 0, 0, 0);
+#endif
+  };
+#ifndef S2T_G256_PIPE
+#define S2T_G256_PIPE 1
+#endif
+#if S2T_G256_PIPE
+  // The step as eight groups of eight MFMAs (k-sub-step ks = g >> 2, A rows 32 (g & 3) .. + 32): the two A fragments of group
+  // g + 1 (and, in group 1, the B fragments of the second sub-step) are requested BEFORE the MFMAs of group g are issued, the
+  // groups pinned by sched_barrier — left to itself hipcc requests a sub-step's twelve fragments together and lets its first MFMA
+  // wait for them, which two waves sharing a SIMD hide for each other but a wave whose partner is parked on DMA issue does not.
+  // The MFMA order (hence every result bit) is the one of the plain loops.
   auto multiply = [&](int stage, int DKS, auto&& side) __attribute__((always_inline)) {
     const char* la = fa0 + stage * STAGE_BYTES;
-    const char* lb = fb0 + stage * STAGE_BYTES;
+    uint4 fb[2][4], fa[2][2];
+    auto rd_a = [&](int g, uint4 (&f)[2]) __attribute__((always_inline)) {
+      const char* pa = la + ((g >> 2) ? (int)((lo0 ^ 64u) - lo0) : 0) + (g & 3) * 4096;
+      f[0] = *reinterpret_cast<const uint4*>(pa);
+      f[1] = *reinterpret_cast<const uint4*>(pa + 2048);
+    };
+    rd_b(stage, 0, fb[0]);
+    rd_a(0, fa[0]);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g + 1 < 8) rd_a(g + 1, fa[(g + 1) & 1]);
+      if (g == 1) rd_b(stage, 1, fb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma(2 * (g & 3) + ii, j, fb[g >> 2][j], fa[g & 1][ii]);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((g >> 2) == DKS) {
+        side(2 * (g & 3));
+        side(2 * (g & 3) + 1);
+      }
+    }
+  };
+#else
+  auto multiply = [&](int stage, int DKS, auto&& side) __attribute__((always_inline)) {
+    const char* la = fa0 + stage * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      // (x*128 + 16*((4+y) ^ (x>>1))) = lo0 ^ 64
       const int kx = ks ? (int)((lo0 ^ 64u) - lo0) : 0;
       uint4 fb[4], fa[8];
-      if constexpr (BKM) {
-        const char* img = smem + stage * STAGE_BYTES + OP_BYTES + ks * (32 * 512);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          uint32_t w[4];
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            // swizzle key of k-row 8 y + 4 half + q (+ 32 ks): 4 * (row & 3) = 4 q
-            const char* a = img + tb0 + half * (4 * 512) + 16 * ((8 * wn + 4 * (j >> 1) + tp) ^ (4 * tq)) + 8 * (j & 1);
-            const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
-            const uint2 tt = __builtin_bit_cast(uint2, t);
-            w[2 * half] = tt.x;
-            w[2 * half + 1] = tt.y;
-          }
-          fb[j] = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(lb + j * 2048 + kx);
-      }
+      rd_b(stage, ks, fb);
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const uint4*>(la + i * 2048 + kx);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#if S2T_G256_DBG & 2
-          asm volatile("" :: "v"(fb[j].x), "v"(fb[j].w), "v"(fa[i].x), "v"(fa[i].w));
-#else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]),
-                                                               acc[i][j], 0, 0, 0);
-#endif
-        }
+        for (int j = 0; j < 4; ++j) mma(i, j, fb[j], fa[i]);
         // The eight pieces of the next step go out behind the MFMA groups of the FIRST half of this step (DKS = 0; issuing them
         // evenly over the step measured the same, letting the two waves of a SIMD issue in different halves — DKS = wave >> 2 —
         // 5 % slower): they then have the second half to land.
@@ -236,6 +276,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
       }
     }
   };
+#endif
 
   // ---- epilogue of tile (tm, tn): lane (x, y) holds, for row block i and tile pair jp, columns 32 jp + 8 y .. + 7 of row
   // 16 i + x of the wave's 128 x 64.  Same arithmetic, in the same order, as Epi::finish (gemm_common.h) — the results of the two
