@@ -537,3 +537,52 @@ def test_large_tile_batched_conv_rows():
         got = new.double()
         keep = (~t)[..., None] & (got != 0)
         np.testing.assert_allclose(got[keep].cpu().numpy(), ref[keep].cpu().numpy(), rtol=1e-2, atol=4e-2)
+
+
+def test_large_tile_random_shapes_equal_the_small_tile_path():
+    """Forty random problems — M, N, K (multiples of 8, K >= 128), leading-dimension padding, B layout, output type, bias /
+    activation / residual / alpha / mask / dropout drawn at random — through both tile paths: equal bit for bit."""
+    rng = np.random.RandomState(7)
+    dev = "cuda"
+    seed = torch.tensor([99], dtype=torch.int64, device=dev)
+    for case in range(40):
+        M = int(rng.randint(1, 1400))
+        N = 8 * int(rng.randint(1, 140))
+        K = 8 * int(rng.randint(16, 90))
+        bkm = bool(rng.randint(2))
+        cdt = torch.float32 if rng.randint(3) == 0 else torch.bfloat16
+        pad = 8 * int(rng.randint(0, 3))
+        g = torch.Generator().manual_seed(1000 + case)
+        lda, ldc = K + pad, N + pad
+        A = torch.zeros(M, lda, dtype=torch.bfloat16); A[:, :K] = _mk((M, K), torch.bfloat16, g)
+        Wl = _mk((N, K), torch.bfloat16, g, K ** -0.5)
+        if bkm:
+            ldb = N + pad
+            W = torch.zeros(K, ldb, dtype=torch.bfloat16); W[:, :N] = Wl.t()
+        else:
+            ldb = K + pad
+            W = torch.zeros(N, ldb, dtype=torch.bfloat16); W[:, :K] = Wl
+        Ad, Wd = A.to(dev), W.to(dev)
+        kw = {}
+        if rng.randint(2):
+            kw["bias"] = _mk((N,), torch.float32, g).to(dev)
+        act = [None, "relu", "swish"][rng.randint(3)]
+        if act:
+            kw["act"] = act
+        if rng.randint(2):
+            kw["residual"] = _mk((M, ldc), cdt, g).to(dev); kw["ldr"] = ldc
+        if rng.randint(2):
+            kw["alpha"] = 0.5
+        if rng.randint(3) == 0:
+            kw["drop"] = (0.2, seed, case)
+        if rng.randint(3) == 0:
+            T = int(rng.randint(1, 60))
+            Bz = (M + T - 1) // T
+            kw["row_lens"] = torch.randint(0, T + 1, (Bz,), generator=g).to(torch.int32).to(dev); kw["row_T"] = T
+
+        def call():
+            out = torch.full((M, ldc), 7.0, dtype=cdt, device=dev)
+            ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=bkm, **kw)
+            return out
+        old, new = _both_paths(call)
+        assert torch.equal(old, new), (case, M, N, K, bkm, str(cdt), sorted(kw))
