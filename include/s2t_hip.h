@@ -112,8 +112,9 @@ int64_t s2t_gemm_ws_floats(const s2t_gemm_args* args);
 int s2t_gemm_describe(const s2t_gemm_args* args, char* buf, int buflen);
 /* Process-wide switch of s2t_gemm's large-tile path (256 x 256 x 64 tiles through LDS-DMA, gemm256.hip: bf16, both operands
  * row-major, K % 64 == 0, one batch, no split-K; results equal the 128 x 128 path's bit for bit — the same MFMA, the same order
- * over K).  mode: 0 never, 1 where it measured faster (default; first read from the environment, S2T_GEMM256), 2 whenever the
- * arguments allow; negative: leave as it is.  Returns the mode in force. */
+ * over K).  mode: 0 never, 1 where it measured faster (default; first read from the environment, S2T_GEMM256: 256-row tiles from
+ * 150 tiles, 128-row tiles when those reach 150), 2 / 3 whenever the arguments allow with 256- / 128-row tiles; negative: leave
+ * as it is.  Returns the mode in force. */
 int s2t_gemm_configure(int large_tile_mode);
 
 /* ------------------------------------------------------------------------------------------------

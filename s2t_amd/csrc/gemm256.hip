@@ -34,7 +34,7 @@
 
 namespace {
 
-constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int TN = 256, TK = 64;  // (rows per tile: the kernel's TMR, 256 or 128)
 constexpr int OP_BYTES = 32768;          // one operand image of a K-step
 constexpr int STAGE_BYTES = 2 * OP_BYTES;
 constexpr int G256_LDS = 2 * STAGE_BYTES;
@@ -56,9 +56,16 @@ struct Tile {
 // GLU (row-major B only): N = 2 * nout weight rows, value rows then gate rows; out = (a + bias_a) * sigmoid(g + bias_g)
 // (modules/speech_to_text/subsampling.py:106-159, modules/convolution.py:94-98).  A wave's 64 image rows are the value rows and the
 // gate rows of the SAME 32 output columns (a tile is 256 x 128 outputs), so a lane's two pieces are value | gate of its columns.
-template <typename TC, bool VEC, bool PLAIN, bool BKM, bool GLU = false>
+// TMR: rows per tile.  256, or 128 for problems whose 256-row tiles would fill less than 0.6 of a round (M of the order of 16 000
+// with N <= 1024: the Linears of a 64 x 1000 batch at d = 512): the same kernel with 64 x 64 of C per wave (64 accumulator
+// registers), a 16 KiB A image and twice the tiles.
+template <typename TC, bool VEC, bool PLAIN, bool BKM, bool GLU = false, int TMR = 256>
 __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   static_assert(!(GLU && (BKM || PLAIN)), "GLU: row-major B, general epilogue");
+  static_assert(TMR == 256 || TMR == 128, "tile rows");
+  constexpr int TM = TMR;
+  constexpr int TMI = TM / 32;   // 16-row blocks of a wave's TM / 2 rows
+  constexpr int APC = TM / 8;    // one-KiB pieces of the A image of a K-step
   __shared__ __attribute__((aligned(16))) char smem[G256_LDS];
   s2t_gemm_args p = p0;
   p.M = (int)s2t_live_rows(p0.row_lens, p0.row_T, p0.M);  // packed batch: the row blocks beyond the live rows are never walked
@@ -117,21 +124,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #ifndef S2T_G256_LOADERS
 #define S2T_G256_LOADERS 4
 #endif
-  constexpr int NLD = (VEC && !PLAIN) ? 8 : S2T_G256_LOADERS;   // 8: every wave issues its own 4 + 4 pieces
-  constexpr int PPW = 32 / NLD;           // pieces per issuing wave and operand
+  constexpr int NLD = (TM == 256 && VEC && !PLAIN) ? 8 : S2T_G256_LOADERS;   // 8: every wave issues its own pieces
+  constexpr int PPW = 32 / NLD;           // B pieces per issuing wave
+  constexpr int PPA = APC / NLD;          // A pieces per issuing wave
   const bool loader = wave < NLD;
-  uint32_t va[PPW], vb[PPW];
+  uint32_t va[PPA], vb[PPW];
   constexpr uint32_t OOB = 0xfffffff0u;
   auto plan = [&](const Tile& t) __attribute__((always_inline)) {
     const int z0 = t.z / p.zdiv, z1 = t.z - z0 * p.zdiv;
     const uint32_t abase = (uint32_t)((z0 * p.a_s0 + z1 * p.a_s1) * 2), bbase = (uint32_t)((z0 * p.b_s0 + z1 * p.b_s1) * 2);
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-      const int pg = PPW * wave + q;       // piece of the operand image (8 rows, or 2 k-rows of a k-major B)
-      const int rho = 8 * pg + (lane >> 3);
+    for (int q = 0; q < PPA; ++q) {
+      const int rho = 8 * (PPA * wave + q) + (lane >> 3);
       const uint32_t piece = (uint32_t)(16 * ((lane & 7) ^ ((rho >> 1) & 7)));
       const int ga = min(t.tm * TM + rho, p.M - 1);  // rows / columns beyond the problem: a clamped duplicate, never stored
       va[q] = abase + (uint32_t)ga * lda2 + piece;
+    }
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int pg = PPW * wave + q;       // piece of the B image (8 rows, or 2 k-rows of a k-major B)
+      const int rho = 8 * pg + (lane >> 3);
+      const uint32_t piece = (uint32_t)(16 * ((lane & 7) ^ ((rho >> 1) & 7)));
       if constexpr (BKM) {
         // piece 4 w + q = k-rows 2 (4 w + q) + (lane >> 5) of the step, slot lane & 31 -> columns 8 (slot ^ swz) of the tile
         const int kr = 2 * pg + (lane >> 5);
@@ -151,13 +164,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   };
   auto piece_out = [&](int q, int kt, int stage) __attribute__((always_inline)) {
 #if !(S2T_G256_DBG & 1)
-    // q: 0 .. PPW-1 the wave's A pieces, PPW .. 2 PPW - 1 its B pieces
-    const int qq = q % PPW;
-    const uint32_t dst = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)((PPW * wave + qq) * 1024);
+    // q: 0 .. PPA-1 the wave's A pieces, PPA .. PPA + PPW - 1 its B pieces
+    const bool isa = q < PPA;
+    const int qq = isa ? q : q - PPA;
+    const uint32_t dst = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)(((isa ? PPA : PPW) * wave + qq) * 1024);
     // row-major operand in the tail step: this lane's k-piece is (lane & 7) ^ swz(row) — dropped when it starts at or beyond K
     const bool tail = kt == nk - 1 && krem < TK;
     const int kpiece = (lane & 7) ^ ((4 * (qq & 1) + (lane >> 4)) & 7);  // swz(row) = (row >> 1) & 7, row = 8 pg + (lane >> 3)
-    if (q < PPW) {
+    if (isa) {
       const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : va[qq];
       dma16(dst, v, srdA, (uint32_t)(kt * (TK * 2)));
     } else if constexpr (BKM) {
@@ -170,10 +184,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #endif
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[TMI][4];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < TMI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 
   // fragment addresses: row 16 i + x of the wave's rows, k-piece 4 ks + y -> slot (4 ks + y) ^ (x >> 1)  ((row >> 1) & 7 = x >> 1)
   const uint32_t lo0 = (uint32_t)(x * 128 + 16 * (y ^ (x >> 1)));
-  const char* const fa0 = smem + wm * (128 * 128) + lo0;
+  const char* const fa0 = smem + wm * ((TM / 2) * 128) + lo0;
   const char* const fb0 = smem + OP_BYTES + wn * (64 * 128) + lo0;
   // k-major B: lane (x = 4 q + p, y) addresses k-row 8 y + 4 half + q (+ 32 ks), the quad at columns 64 wn + 32 g + 8 p + 4 t
   // of tile j = 2 g + t: piece 8 wn + 4 g + p, its half t
@@ -220,63 +234,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), acc[i][j], 0, 0, 0);
 #endif
   };
-#ifndef S2T_G256_PIPE
-#define S2T_G256_PIPE 1
-#endif
-#if S2T_G256_PIPE
-  // The step as eight groups of eight MFMAs (k-sub-step ks = g >> 2, A rows 32 (g & 3) .. + 32): the two A fragments of group
-  // g + 1 (and, in group 1, the B fragments of the second sub-step) are requested BEFORE the MFMAs of group g are issued, the
-  // groups pinned by sched_barrier — left to itself hipcc requests a sub-step's twelve fragments together and lets its first MFMA
-  // wait for them, which two waves sharing a SIMD hide for each other but a wave whose partner is parked on DMA issue does not.
-  // The MFMA order (hence every result bit) is the one of the plain loops.
-  auto multiply = [&](int stage, int DKS, auto&& side) __attribute__((always_inline)) {
+  // The step as TMI groups of eight MFMAs (k-sub-step ks = g / (TMI / 2), A rows 32 (g % (TMI / 2)) .. + 32 of the wave's): the two
+  // A fragments of group g + 1 (and, early in the first sub-step, the B fragments of the second) are requested BEFORE the MFMAs of
+  // group g are issued, the groups pinned by sched_barrier — left to itself hipcc requests a sub-step's fragments together and
+  // lets its first MFMA wait for them, which two waves sharing a SIMD hide for each other but a wave whose partner is parked on
+  // DMA issue does not.  The MFMA order (hence every result bit) is the one of plain i / j loops inside each sub-step.
+  auto multiply = [&](int stage) __attribute__((always_inline)) {
     const char* la = fa0 + stage * STAGE_BYTES;
+    constexpr int GH = TMI / 2;  // groups per sub-step
     uint4 fb[2][4], fa[2][2];
     auto rd_a = [&](int g, uint4 (&f)[2]) __attribute__((always_inline)) {
-      const char* pa = la + ((g >> 2) ? (int)((lo0 ^ 64u) - lo0) : 0) + (g & 3) * 4096;
+      const char* pa = la + ((g / GH) ? (int)((lo0 ^ 64u) - lo0) : 0) + (g % GH) * 4096;
       f[0] = *reinterpret_cast<const uint4*>(pa);
       f[1] = *reinterpret_cast<const uint4*>(pa + 2048);
     };
     rd_b(stage, 0, fb[0]);
     rd_a(0, fa[0]);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g + 1 < 8) rd_a(g + 1, fa[(g + 1) & 1]);
-      if (g == 1) rd_b(stage, 1, fb[1]);
+    for (int g = 0; g < TMI; ++g) {
+      if (g + 1 < TMI) rd_a(g + 1, fa[(g + 1) & 1]);
+      if (g == (GH > 1 ? 1 : 0)) rd_b(stage, 1, fb[1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mma(2 * (g & 3) + ii, j, fb[g >> 2][j], fa[g & 1][ii]);
+        for (int j = 0; j < 4; ++j) mma(2 * (g % GH) + ii, j, fb[g / GH][j], fa[g & 1][ii]);
       __builtin_amdgcn_sched_barrier(0);
-      if ((g >> 2) == DKS) {
-        side(2 * (g & 3));
-        side(2 * (g & 3) + 1);
-      }
     }
   };
-#else
-  auto multiply = [&](int stage, int DKS, auto&& side) __attribute__((always_inline)) {
-    const char* la = fa0 + stage * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kx = ks ? (int)((lo0 ^ 64u) - lo0) : 0;
-      uint4 fb[4], fa[8];
-      rd_b(stage, ks, fb);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const uint4*>(la + i * 2048 + kx);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mma(i, j, fb[j], fa[i]);
-        // The eight pieces of the next step go out behind the MFMA groups of the FIRST half of this step (DKS = 0; issuing them
-        // evenly over the step measured the same, letting the two waves of a SIMD issue in different halves — DKS = wave >> 2 —
-        // 5 % slower): they then have the second half to land.
-        if (ks == DKS) side(i);
-      }
-    }
-  };
-#endif
 
   // ---- epilogue of tile (tm, tn): lane (x, y) holds, for row block i and tile pair jp, columns 32 jp + 8 y .. + 7 of row
   // 16 i + x of the wave's 128 x 64.  Same arithmetic, in the same order, as Epi::finish (gemm_common.h) — the results of the two
@@ -287,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
 #if S2T_G256_DBG & 4
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < TMI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
 #else
@@ -343,8 +328,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     if constexpr (PLAIN) {
       const bool scale = p.alpha != 1.0f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = t.tm * TM + wm * 128 + i * 16 + x;
+      for (int i = 0; i < TMI; ++i) {
+        const int m = t.tm * TM + wm * (TM / 2) + i * 16 + x;
         bool ok[2];
         float v[2][8], q[2][8];
 #pragma unroll
@@ -391,12 +376,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
       const uint64_t dkey = drop ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
       const uint32_t dth = s2t_drop_thresh(p.drop_p);
       const float dinv = s2t_drop_scale(p.drop_p);
-      f32x4 (&af)[32] = reinterpret_cast<f32x4 (&)[32]>(acc);
+      f32x4 (&af)[4 * TMI] = reinterpret_cast<f32x4 (&)[4 * TMI]>(acc);
 #pragma unroll 1
-      for (int i2 = 0; i2 < 4; ++i2) {
+      for (int i2 = 0; i2 < TMI / 2; ++i2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int m = t.tm * TM + wm * 128 + (2 * i2 + h) * 16 + x;
+          const int m = t.tm * TM + wm * (TM / 2) + (2 * i2 + h) * 16 + x;
           if constexpr (GLU) {
             const f32x4 a0 = af[4 * h], a1 = af[4 * h + 1], g0 = af[4 * h + 2], g1 = af[4 * h + 3];
             if (m < p.M && ncol[0] < nout) {
@@ -511,7 +496,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
           }
         }
 #pragma unroll
-        for (int k = 0; k < 24; ++k) af[k] = af[k + 8];
+        for (int k = 0; k < 4 * TMI - 8; ++k) af[k] = af[k + 8];
       }
     }
 #endif
@@ -526,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   plan(L);
   if (loader) {
 #pragma unroll
-    for (int q = 0; q < 2 * PPW; ++q) piece_out(q, 0, 0);
+    for (int q = 0; q < PPA + PPW; ++q) piece_out(q, 0, 0);
   }
   auto advance_fetch = [&]() __attribute__((always_inline)) {
     if (lkt + 1 < nk) {
@@ -542,7 +527,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   Tile C = tile_at(0);  // tile of the step being multiplied
   int ckt = 0;
   // stores a VEC epilogue issues per lane (none of them skipped: see csrd): 8 row blocks x 2 pieces x (1 | 2) 16-byte stores
-  constexpr int NST = 16 * (int)(sizeof(TC) / 2);
+  constexpr int NST = 2 * TMI * (int)(sizeof(TC) / 2);
   const bool counted = VEC && !GLU && !p.preact;   // (the pre-activation copy and the GLU form go out by ordinary conditional stores)
   int since = 99;       // steps since a tile end: 0 with the next step AND the one after in flight, 1 with one step in flight
 #ifndef S2T_G256_EARLY2
@@ -564,8 +549,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     // other stage.  What may stay in flight is YOUNGER than those pieces: behind a tile end the (eight) pieces of step s + 1
     // and the epilogue's stores, one step later the stores alone.
     if (since == 0) {
-      if (counted) __builtin_amdgcn_s_waitcnt(wait_vm(2 * PPW + NST));
-      else __builtin_amdgcn_s_waitcnt(wait_vm(2 * PPW));
+      if (counted) __builtin_amdgcn_s_waitcnt(wait_vm(PPA + PPW + NST));
+      else __builtin_amdgcn_s_waitcnt(wait_vm(PPA + PPW));
     } else if (since == 1 && counted) {
       __builtin_amdgcn_s_waitcnt(wait_vm(NST));
     } else {
@@ -574,17 +559,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     asm volatile("s_barrier" ::: "memory");
     G256_STAMP(t1);
     const bool issue = fs == s + 1 && fs < S;
-    if constexpr (NLD == 8) {
-      multiply(s & 1, 0, [&](int q) __attribute__((always_inline)) {
-        if (issue) piece_out(q, lkt, (s & 1) ^ 1);
-      });
-    } else {
-      if (issue && loader) {
+    // (all of the step's pieces at its top — spreading them behind the MFMA groups measured the same)
+    if (issue && loader) {
 #pragma unroll
-        for (int q = 0; q < 2 * PPW; ++q) piece_out(q, lkt, (s & 1) ^ 1);
-      }
-      multiply(s & 1, 0, [&](int) __attribute__((always_inline)) {});
+      for (int q = 0; q < PPA + PPW; ++q) piece_out(q, lkt, (s & 1) ^ 1);
     }
+    multiply(s & 1);
     if (issue) {
       ++fs;
       if (fs < S) advance_fetch();
@@ -604,7 +584,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
         asm volatile("s_barrier" ::: "memory");  // every wave has finished reading stage s & 1
         if (loader) {
 #pragma unroll
-          for (int q = 0; q < 2 * PPW; ++q) piece_out(q, lkt, s & 1);
+          for (int q = 0; q < PPA + PPW; ++q) piece_out(q, lkt, s & 1);
         }
         ++fs;
         if (fs < S) advance_fetch();
@@ -634,7 +614,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 }  // namespace
 
 // ---- host side (called by s2t_gemm) ---------------------------------------------------------------------------------
-// S2T_GEMM256 / s2t_gemm_configure: 0 never, 1 (default) where it measured faster, 2 whenever the arguments allow
+// S2T_GEMM256 / s2t_gemm_configure: 0 never, 1 (default) where it measured faster, 2 whenever the arguments allow (256-row
+// tiles), 3 the same with 128-row tiles
 static int& g256_mode_ref() {
   static int mode = [] { const char* e = getenv("S2T_GEMM256"); return e ? atoi(e) : 1; }();
   return mode;
@@ -642,41 +623,47 @@ static int& g256_mode_ref() {
 static int g256_mode() { return g256_mode_ref(); }
 
 extern "C" int s2t_gemm_configure(int large_tile_mode) {
-  if (large_tile_mode >= 0) g256_mode_ref() = large_tile_mode > 2 ? 2 : large_tile_mode;
+  if (large_tile_mode >= 0) g256_mode_ref() = large_tile_mode > 3 ? 3 : large_tile_mode;
   return g256_mode_ref();
 }
 
-bool s2t_gemm256_eligible(const s2t_gemm_args& p) {
+// rows per tile of the large-tile path for these arguments: 256, 128, or 0 (the 128 x 128 kernel of gemm.hip)
+int s2t_gemm256_tile_rows(const s2t_gemm_args& p) {
   const int mode = g256_mode();
-  if (mode <= 0) return false;
-  if (p.dtype != S2T_BF16 || p.a_kmajor || (p.act == S2T_ACT_GLU && p.b_kmajor)) return false;
+  if (mode <= 0) return 0;
+  if (p.dtype != S2T_BF16 || p.a_kmajor || (p.act == S2T_ACT_GLU && p.b_kmajor)) return 0;
 #if S2T_G256_DBG & 16
-  if (p.split_k > 1 || p.c_atomic || p.ws) return false;  // (p.colsum_a receives the stamps)
+  if (p.split_k > 1 || p.c_atomic || p.ws) return 0;  // (p.colsum_a receives the stamps)
 #else
-  if (p.split_k > 1 || p.c_atomic || p.colsum_a || p.ws) return false;
+  if (p.split_k > 1 || p.c_atomic || p.colsum_a || p.ws) return 0;
   if (p.batch > 1) {
     // a batch is folded into the row-block walk: every operand of the whole batch inside one 32-bit byte range, and no
     // k-major B (its K tail relies on the descriptor's end)
-    if (p.b_kmajor) return false;
+    if (p.b_kmajor) return 0;
     const int64_t z0max = (p.batch - 1) / p.zdiv, z1max = p.zdiv - 1;
     const int64_t aspan = (z0max * p.a_s0 + z1max * p.a_s1 + (int64_t)(p.M - 1) * p.lda + p.K) * 2;
     const int64_t bspan = (z0max * p.b_s0 + z1max * p.b_s1 + (int64_t)(p.N - 1) * p.ldb + p.K) * 2;
-    if (p.a_s0 < 0 || p.a_s1 < 0 || p.b_s0 < 0 || p.b_s1 < 0 || aspan >= (1ll << 32) - 64 || bspan >= (1ll << 32) - 64) return false;
+    if (p.a_s0 < 0 || p.a_s1 < 0 || p.b_s0 < 0 || p.b_s1 < 0 || aspan >= (1ll << 32) - 64 || bspan >= (1ll << 32) - 64) return 0;
   }
 #endif
-  if (p.K < 128 || (p.K % 8)) return false;          // (a K tail is dropped in whole 16-byte pieces)
+  if (p.K < 128 || (p.K % 8)) return 0;          // (a K tail is dropped in whole 16-byte pieces)
   {
     // C leaves through a buffer descriptor with 32-bit byte offsets (per batch)
     const int nout = p.act == S2T_ACT_GLU ? p.N / 2 : p.N;
-    if (((int64_t)(p.M - 1) * p.ldc + nout) * (p.c_dtype == S2T_F32 ? 4 : 2) >= (1ll << 32) - 64) return false;
+    if (((int64_t)(p.M - 1) * p.ldc + nout) * (p.c_dtype == S2T_F32 ? 4 : 2) >= (1ll << 32) - 64) return 0;
   }
-  if (p.b_kmajor && (p.N % 8)) return false;         // (a k-major piece is 8 columns)
-  if (mode >= 2) return true;
-  const int64_t tiles = (int64_t)p.batch * ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);  // (GLU: N / 2 outputs in 128-column tiles)
-  // (tools/gemm256_probe.py border: 156 tiles 1.39x, 189 1.38x, 250 1.3x; 126-128 tiles 0.95-1.05x, 88 0.92x, 64 0.78x — below
-  // about 0.6 of a round the 128 x 128 path's 2 x 256 slots fill the chip better)
-  return tiles >= 150;
+  if (p.b_kmajor && (p.N % 8)) return 0;         // (a k-major piece is 8 columns)
+  if (mode == 2) return 256;
+  if (mode >= 3) return p.act == S2T_ACT_GLU ? 256 : 128;   // (the GLU form has 256-row tiles only)
+  // (tools/gemm256_probe.py border: 156 tiles of 256 x 256 1.39x, 189 1.38x, 250 1.3x; 126-128 tiles 0.95-1.05x, 88 0.92x, 64 0.78x
+  // — below about 0.6 of a round the 128 x 128 path's 2 x 256 slots fill the chip better; 128-row tiles when THOSE reach 0.6)
+  const int64_t cols = (p.N + TN - 1) / TN;      // (GLU: N / 2 outputs in 128-column tiles: the same count)
+  if ((int64_t)p.batch * ((p.M + 255) / 256) * cols >= 150) return 256;
+  if (p.act != S2T_ACT_GLU && (int64_t)p.batch * ((p.M + 127) / 128) * cols >= 150) return 128;
+  return 0;
 }
+
+bool s2t_gemm256_eligible(const s2t_gemm_args& p) { return s2t_gemm256_tile_rows(p) != 0; }
 
 static bool g256_plain(const s2t_gemm_args& p, bool vec) {
   // (a row map that only BOUNDS the rows — S2T_ROWS_BOUND — is no mask: the live row count is read in every instantiation)
@@ -686,11 +673,17 @@ static bool g256_plain(const s2t_gemm_args& p, bool vec) {
 int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
   const dim3 grid(s2t_device_cu_count()), block(512);
   const bool plain = g256_plain(p, vec);
+  const int rows = s2t_gemm256_tile_rows(p);
+#define GO3(TC, BK, R) \
+  do { \
+    if (plain) hipLaunchKernelGGL((gemm256_kernel<TC, true, true, BK, false, R>), grid, block, 0, s, p); \
+    else if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false, BK, false, R>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((gemm256_kernel<TC, false, false, BK, false, R>), grid, block, 0, s, p); \
+  } while (0)
 #define GO2(TC, BK) \
   do { \
-    if (plain) hipLaunchKernelGGL((gemm256_kernel<TC, true, true, BK>), grid, block, 0, s, p); \
-    else if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false, BK>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((gemm256_kernel<TC, false, false, BK>), grid, block, 0, s, p); \
+    if (rows == 128) GO3(TC, BK, 128); \
+    else GO3(TC, BK, 256); \
   } while (0)
 #define GO(TC) \
   do { \
@@ -702,14 +695,15 @@ int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
   } while (0)
   if (p.c_dtype == S2T_F32) GO(float);
   else GO(bf16_t);
+#undef GO3
 #undef GO2
 #undef GO
   return S2T_LAUNCH_CHECK();
 }
 
 int s2t_gemm256_describe(const s2t_gemm_args& p, bool vec, char* buf, int buflen) {
-  const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s, %s, %s>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
+  const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s, %s, %s, %d>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
                          vec ? "true" : "false", g256_plain(p, vec) ? "true" : "false", p.b_kmajor ? "true" : "false",
-                         p.act == S2T_ACT_GLU ? "true" : "false");
+                         p.act == S2T_ACT_GLU ? "true" : "false", s2t_gemm256_tile_rows(p) == 128 ? 128 : 256);
   return (n > 0 && n < buflen) ? S2T_OK : S2T_ERR_ARG;
 }

@@ -82,8 +82,8 @@ def gemm_symbol(args):
 
 
 def gemm_configure(large_tile=None):
-    """s2t_gemm_configure: 0 never / 1 automatic / 2 always (where the arguments allow) for the 256 x 256 LDS-DMA path of
-    s2t_gemm; None leaves the switch as it is.  Returns the mode in force."""
+    """s2t_gemm_configure: 0 never / 1 automatic / 2, 3 always (where the arguments allow; 256- / 128-row tiles) for the
+    LDS-DMA large-tile path of s2t_gemm; None leaves the switch as it is.  Returns the mode in force."""
     return int(L.lib().s2t_gemm_configure(-1 if large_tile is None else int(large_tile)))
 
 

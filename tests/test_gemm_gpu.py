@@ -330,7 +330,8 @@ def test_overwrite_splitk_without_a_workspace_runs_as_one_pass():
 
 # ---- the 256 x 256 LDS-DMA path (gemm256.hip): bf16, row-major A and B, K % 64 == 0 ----------------------------------------
 class _large_tile:
-    """Pin s2t_gemm's large-tile switch for a block (s2t_gemm_configure): 0 never, 2 whenever the arguments allow."""
+    """Pin s2t_gemm's large-tile switch for a block (s2t_gemm_configure): 0 never, 2 / 3 whenever the arguments allow with
+    256- / 128-row tiles."""
 
     def __init__(self, mode):
         self.mode = mode
@@ -344,12 +345,14 @@ class _large_tile:
 
 
 def _both_paths(call):
+    """(128 x 128 path, 256-row large tiles); the 128-row large tiles (mode 3) are checked against them on the way."""
     outs = []
-    for mode in (0, 2):
+    for mode in (0, 2, 3):
         with _large_tile(mode):
             outs.append(call())
     torch.cuda.synchronize()
-    return outs
+    assert torch.equal(outs[1], outs[2]), "128-row and 256-row large tiles differ"
+    return outs[:2]
 
 
 @pytest.mark.parametrize("M,N,K,ldpad", [(256, 256, 128, 0), (1000, 520, 192, 0), (513, 264, 64 * 5, 8), (4100, 777 * 8, 256, 0),

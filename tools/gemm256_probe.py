@@ -18,24 +18,24 @@ def run(M, N, Kd, out_dtype=torch.bfloat16, bias=False, act=None, residual=False
     b = torch.randn(N, device=dev) if bias else None
     R = torch.randn(M, N, device=dev).to(out_dtype) if residual else None
     outs = {}
-    ts = {0: [], 2: []}
-    for mode in (0, 2):
+    ts = {0: [], MODE_NEW: []}
+    for mode in (0, MODE_NEW):
         K.gemm_configure(mode)
         C = torch.empty(M, N // 2 if act == "glu" else N, device=dev, dtype=out_dtype)
         kw = dict(M=M, N=N, K=Kd, lda=Kd, ldb=N if bkm else Kd, ldc=N // 2 if act == "glu" else N, bias=b, act=act, residual=R, ldr=N if residual else 0, b_kmajor=bkm)
         K.gemm(A, B, C, **kw)
         outs[mode] = C
     torch.cuda.synchronize()
-    same = torch.equal(outs[0], outs[2])
+    same = torch.equal(outs[0], outs[MODE_NEW])
     err = None
     if check and M * N <= 64000 * 2048:
         ref = A.float() @ (B.float() if bkm else B.float().t())
         if bias: ref += b
         if act == "relu": ref = ref.relu()
         if residual: ref += R.float()
-        err = float((outs[2].float() - ref).abs().max() / ref.abs().max())
+        err = float((outs[MODE_NEW].float() - ref).abs().max() / ref.abs().max())
     for r in range(rounds):
-        for mode in (0, 2):
+        for mode in (0, MODE_NEW):
             K.gemm_configure(mode)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -44,7 +44,7 @@ def run(M, N, Kd, out_dtype=torch.bfloat16, bias=False, act=None, residual=False
             e1.record()
             torch.cuda.synchronize()
             ts[mode].append(e0.elapsed_time(e1) * 250)
-    t0, t2 = sorted(ts[0])[rounds // 2], sorted(ts[2])[rounds // 2]
+    t0, t2 = sorted(ts[0])[rounds // 2], sorted(ts[MODE_NEW])[rounds // 2]
     fl = 2.0 * M * N * Kd
     print("M%6d N%6d K%5d %s%s%s%s%s : old %7.1f us %6.0f TF/s | 256 %7.1f us %6.0f TF/s  x%.2f  equal=%s err=%s" % (
         M, N, Kd, "f32" if out_dtype == torch.float32 else "bf16", " bias" if bias else "", " " + act if act else "",
@@ -69,6 +69,12 @@ shapes = [
     (128000, 4096, 400, dict(act="glu", bias=True, check=False)),
 ]
 import sys
+MODE_NEW = 3 if (len(sys.argv) > 1 and sys.argv[1] == "rows128") else 2   # rows128: the 128-row large tiles against the 128 x 128 path
+if MODE_NEW == 3:
+    shapes = [(16000, 512, 512, dict(bias=True)), (16000, 512, 2048, dict(bias=True, residual=True)), (16000, 2048, 512, dict(bias=True, act="relu")),
+              (16000, 1536, 512, {}), (16000, 512, 256, {}), (16000, 1024, 256, {}), (13100, 512, 512, {}), (16000, 512, 512, dict(bkm=True)),
+              (16000, 512, 2048, dict(bkm=True)), (16000, 512, 10000, dict(bkm=True)), (8000, 1024, 512, {}), (32000, 256, 512, {}),
+              (2650, 2048, 256, {}), (16000, 768, 256, {}), (64000, 2048, 512, dict(bias=True))]
 if len(sys.argv) > 1 and sys.argv[1] == "border":  # shapes around the automatic mode's tile-count threshold
     shapes = [(16000, 512, 512, {}), (16000, 512, 2048, {}), (8000, 1024, 256, {}), (4000, 2048, 512, {}), (16000, 768, 256, {}),
               (16000, 1024, 256, {}), (13100, 512, 256, {}), (13100, 768, 256, {}), (2650, 10000, 256, {}), (2650, 2048, 256, {}),
