@@ -8,7 +8,6 @@ no host synchronisation, so a whole step can be captured in a hipGraph (``captur
 regime the reference's eager PyTorch loop lives in is removed rather than tuned.
 """
 import math
-import os
 
 import torch
 import torch.distributed as dist
@@ -155,37 +154,6 @@ class Trainer:
             # side stream (forked and joined inside the capture), clip and Adam — is ONE graph
             with torch.cuda.graph(self._graph):
                 self._graph_out = self._step_body(sample)
-        self._capture_bookkeeping()
-
-    @staticmethod
-    def _batch_tensors(dct):
-        for v in dct.values():
-            if isinstance(v, dict):
-                yield from Trainer._batch_tensors(v)
-            elif torch.is_tensor(v):
-                yield v
-
-    def _capture_bookkeeping(self):
-        """The per-batch bookkeeping outside the step's graph (functional.batch_memo: lengths, masks, positions, CTC target
-        matrices, packed-row geometry — some 45 launches of a few microseconds each) as a hipGraph of its own: the same
-        launches without the gaps between them.  Its sequence of device operations is a function of WHICH tensors changed
-        (always: every field of the batch), so one capture serves every batch; a memo that needs the host falls back to the
-        eager form (``S2T_MEMO_GRAPH=0`` forces that)."""
-        self._memo_graph = None
-        if os.environ.get("S2T_MEMO_GRAPH", "1") == "0" or not self.flat.master.is_cuda:
-            return
-        tens = list(self._batch_tensors(self._static))
-        try:
-            Fn.refresh_batch_memos(tens)  # (allocator warm-up outside the capture)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                Fn.refresh_batch_memos(tens)
-            self._memo_graph = g
-        except Exception:  # noqa: BLE001 — a memo with a host round trip: keep the eager refresh
-            self._memo_graph = None
-            torch.cuda.synchronize()
-            Fn.refresh_batch_memos(tens)
 
     def load_batch(self, sample):
         """Copy a batch of the captured shapes into the static one the graph reads (tensors by key, recursively), then
@@ -199,11 +167,16 @@ class Trainer:
                         raise ValueError(f"batch field {k}: shape {tuple(v.shape)} differs from the captured {tuple(dst[k].shape)}")
                     dst[k].copy_(v, non_blocking=True)
         fill(self._static, sample)
+
+        def tensors(dct):
+            for v in dct.values():
+                if isinstance(v, dict):
+                    yield from tensors(v)
+                elif torch.is_tensor(v):
+                    yield v
+
         # lengths / positions / target matrices derived from the batch, recomputed in place
-        if getattr(self, "_memo_graph", None) is not None:
-            self._memo_graph.replay()
-        else:
-            Fn.refresh_batch_memos(list(self._batch_tensors(self._static)))
+        Fn.refresh_batch_memos(list(tensors(self._static)))
 
     def replay(self, sample=None, sample_size_global=None):
         """One captured update; ``sample`` (same shapes as the captured batch) is copied into the static batch first."""
