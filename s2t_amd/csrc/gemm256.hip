@@ -124,7 +124,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #ifndef S2T_G256_LOADERS
 #define S2T_G256_LOADERS 4
 #endif
-  constexpr int NLD = (TM == 256 && VEC && !PLAIN) ? 8 : S2T_G256_LOADERS;   // 8: every wave issues its own pieces
+  // (the general vectorised epilogue at 256-row tiles — GLU included — sits at the register limit: there every wave issues its
+  // own pieces, dealt behind the MFMA groups of the step's first half; on the GLU shapes of the subsampler that form measured
+  // 12 % FASTER than four loaders — 563 against 641 us at 256 x 1000 x 80 -> 2048 — while the plain-epilogue shapes are equal
+  // or up to 4 % better with loaders)
+  constexpr int NLD = (TM == 256 && VEC && !PLAIN) ? 8 : S2T_G256_LOADERS;
   constexpr int PPW = 32 / NLD;           // B pieces per issuing wave
   constexpr int PPA = APC / NLD;          // A pieces per issuing wave
   const bool loader = wave < NLD;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   // group g are issued, the groups pinned by sched_barrier — left to itself hipcc requests a sub-step's fragments together and
   // lets its first MFMA wait for them, which two waves sharing a SIMD hide for each other but a wave whose partner is parked on
   // DMA issue does not.  The MFMA order (hence every result bit) is the one of plain i / j loops inside each sub-step.
-  auto multiply = [&](int stage) __attribute__((always_inline)) {
+  auto multiply = [&](int stage, auto&& side) __attribute__((always_inline)) {
     const char* la = fa0 + stage * STAGE_BYTES;
     constexpr int GH = TMI / 2;  // groups per sub-step
     uint4 fb[2][4], fa[2][2];
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) mma(2 * (g % GH) + ii, j, fb[g / GH][j], fa[g & 1][ii]);
       __builtin_amdgcn_sched_barrier(0);
+      if (g < GH) side(g);
     }
   };
 
@@ -559,12 +564,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     asm volatile("s_barrier" ::: "memory");
     G256_STAMP(t1);
     const bool issue = fs == s + 1 && fs < S;
-    // (all of the step's pieces at its top — spreading them behind the MFMA groups measured the same)
-    if (issue && loader) {
+    if constexpr (NLD == 8) {
+      // every wave issues: its PPA + PPW pieces dealt behind the MFMA groups of the first sub-step
+      constexpr int PER = (PPA + PPW + TMI / 2 - 1) / (TMI / 2);
+      multiply(s & 1, [&](int g) __attribute__((always_inline)) {
+        if (issue) {
 #pragma unroll
-      for (int q = 0; q < PPA + PPW; ++q) piece_out(q, lkt, (s & 1) ^ 1);
+          for (int q = PER * g; q < PER * (g + 1) && q < PPA + PPW; ++q) piece_out(q, lkt, (s & 1) ^ 1);
+        }
+      });
+    } else {
+      // loader waves: the whole step's pieces at its top
+      if (issue && loader) {
+#pragma unroll
+        for (int q = 0; q < PPA + PPW; ++q) piece_out(q, lkt, (s & 1) ^ 1);
+      }
+      multiply(s & 1, [&](int) __attribute__((always_inline)) {});
     }
-    multiply(s & 1);
     if (issue) {
       ++fs;
       if (fs < S) advance_fetch();
@@ -654,11 +670,13 @@ int s2t_gemm256_tile_rows(const s2t_gemm_args& p) {
   }
   if (p.b_kmajor && (p.N % 8)) return 0;         // (a k-major piece is 8 columns)
   if (mode == 2) return 256;
-  if (mode >= 3) return p.act == S2T_ACT_GLU ? 256 : 128;   // (the GLU form has 256-row tiles only)
+  if (mode >= 3) return 128;
   // (tools/gemm256_probe.py border: 156 tiles of 256 x 256 1.39x, 189 1.38x, 250 1.3x; 126-128 tiles 0.95-1.05x, 88 0.92x, 64 0.78x
   // — below about 0.6 of a round the 128 x 128 path's 2 x 256 slots fill the chip better; 128-row tiles when THOSE reach 0.6)
   const int64_t cols = (p.N + TN - 1) / TN;      // (GLU: N / 2 outputs in 128-column tiles: the same count)
   if ((int64_t)p.batch * ((p.M + 255) / 256) * cols >= 150) return 256;
+  // (not the GLU form: the subsampler's second convolution — 64 x 250 rows, K = 2560 — measured 85 us on 128-row tiles against
+  // 64 on the 128 x 128 kernel)
   if (p.act != S2T_ACT_GLU && (int64_t)p.batch * ((p.M + 127) / 128) * cols >= 150) return 128;
   return 0;
 }
@@ -688,8 +706,13 @@ int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
 #define GO(TC) \
   do { \
     if (p.act == S2T_ACT_GLU) { \
-      if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false, false, true>), grid, block, 0, s, p); \
-      else hipLaunchKernelGGL((gemm256_kernel<TC, false, false, false, true>), grid, block, 0, s, p); \
+      if (rows == 128) { \
+        if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false, false, true, 128>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((gemm256_kernel<TC, false, false, false, true, 128>), grid, block, 0, s, p); \
+      } else { \
+        if (vec) hipLaunchKernelGGL((gemm256_kernel<TC, true, false, false, true>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((gemm256_kernel<TC, false, false, false, true>), grid, block, 0, s, p); \
+      } \
     } else if (p.b_kmajor) GO2(TC, true); \
     else GO2(TC, false); \
   } while (0)
