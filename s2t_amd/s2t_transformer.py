@@ -206,8 +206,10 @@ class S2TTransformerEncoder(nn.Module):
             tab = TABLES.get("sin", max(self.max_positions(), Tp) + 2, d, x.device)
             x = AddPositions.apply(x, tab, lens32, Tp, self.embed_scale)  # :1773-1787
         x = Fn.dropout(x, self.dropout_p, self.training)  # dropout_module (:1794)
-        if self.layer_padding_mask:
-            x = MaskRows.apply(x, lens32, Tp)  # layer 0's masked_fill (:1828-1836); later layers: fused in final_norm
+        if self.layer_padding_mask and Rows.K.rows_geom(lens32) is None:
+            # layer 0's masked_fill (:1828-1836); later layers: fused in final_norm.  Packed rows hold no padded frames and their
+            # halo rows are zero from Rows.pack on (dropout keeps zeros), and PackFn.backward drops the halo rows' gradient
+            x = MaskRows.apply(x, lens32, Tp)
         n = len(self.layers)
         inter_ctc_logits = []
         ctc_orc = ctc_force_emit = None

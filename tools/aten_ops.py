@@ -13,13 +13,15 @@ tr = Trainer(m, crit)
 sample, frames = bench.synthetic_batch(64, 1000, V, 1, dev)
 for _ in range(3): tr.train_step(sample)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     tr.train_step(sample)
     torch.cuda.synchronize()
-rows = []
-for e in prof.key_averages(group_by_stack_n=4):
-    if e.key.startswith("aten::") and e.device_time_total > 0:
-        st = [s for s in e.stack if "s2t_amd" in s or "bench.py" in s]
-        rows.append((e.device_time_total, e.count, e.key, st[0][-70:] if st else ""))
-for t, c, k, s in sorted(rows, reverse=True)[:40]:
-    print("%8.1f us  x%3d  %-28s %s" % (t, c, k, s))
+rows = {}
+for e in prof.events():
+    if e.name.startswith("aten::") and e.device_time_total > 0 and e.name not in ("aten::zero_", "aten::zeros", "aten::clone", "aten::contiguous", "aten::zeros_like", "aten::to", "aten::ones_like"):
+        st = [s for s in (e.stack or []) if "s2t_amd" in s or "bench.py" in s]
+        key = (e.name, " <- ".join(x.split("/")[-1][:60] for x in st[:3]), str(e.input_shapes)[:60])
+        t, c = rows.get(key, (0.0, 0))
+        rows[key] = (t + e.device_time_total, c + 1)
+for (k, s, shp), (t, c) in sorted(rows.items(), key=lambda kv: -kv[1][0])[:50]:
+    print("%8.1f us  x%3d  %-22s %s %s" % (t, c, k, shp, s))
