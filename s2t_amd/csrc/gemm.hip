@@ -663,6 +663,25 @@ int launch2(const s2t_gemm_args& p, hipStream_t s) {
   return S2T_LAUNCH_CHECK();
 }
 
+// Second phase of the two-phase split-K: C = epilogue(alpha * sum of the splits' partial tiles in the workspace)
+static int splitk_second_phase(const s2t_gemm_args& p, hipStream_t s) {
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int ntiles = ((p.M + BM - 1) / BM) * tiles_n;
+  if (has_fused_epilogue(p)) {
+    const dim3 g(ntiles, 8, p.batch), b(256);
+    if (p.c_dtype == S2T_BF16) {
+      if (epilogue_vectorisable<bf16_t>(p, p.N)) hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t, true>), g, b, 0, s, p, ntiles, tiles_n);
+      else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t, false>), g, b, 0, s, p, ntiles, tiles_n);
+    } else {
+      if (epilogue_vectorisable<float>(p, p.N)) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), g, b, 0, s, p, ntiles, tiles_n);
+      else hipLaunchKernelGGL((splitk_epilogue_kernel<float, false>), g, b, 0, s, p, ntiles, tiles_n);
+    }
+  } else {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ntiles, 16, p.batch), dim3(256), 0, s, p, ntiles, tiles_n);
+  }
+  return S2T_LAUNCH_CHECK();
+}
+
 template <typename T, typename TC>
 int launch(const s2t_gemm_args& p, hipStream_t s) {
   const int nout = p.act == S2T_ACT_GLU ? p.N / 2 : p.N;
@@ -671,24 +690,28 @@ int launch(const s2t_gemm_args& p, hipStream_t s) {
   int rc;
   if (kt) rc = vec ? launch2<T, TC, true, true>(p, s) : launch2<T, TC, true, false>(p, s);
   else rc = vec ? launch2<T, TC, false, true>(p, s) : launch2<T, TC, false, false>(p, s);
-  if (rc == S2T_OK && p.ws) {
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int ntiles = ((p.M + BM - 1) / BM) * tiles_n;
-    if (has_fused_epilogue(p)) {
-      const dim3 g(ntiles, 8, p.batch), b(256);
-      if (p.c_dtype == S2T_BF16) {
-        if (epilogue_vectorisable<bf16_t>(p, p.N)) hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t, true>), g, b, 0, s, p, ntiles, tiles_n);
-        else hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t, false>), g, b, 0, s, p, ntiles, tiles_n);
-      } else {
-        if (epilogue_vectorisable<float>(p, p.N)) hipLaunchKernelGGL((splitk_epilogue_kernel<float, true>), g, b, 0, s, p, ntiles, tiles_n);
-        else hipLaunchKernelGGL((splitk_epilogue_kernel<float, false>), g, b, 0, s, p, ntiles, tiles_n);
-      }
-    } else {
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ntiles, 16, p.batch), dim3(256), 0, s, p, ntiles, tiles_n);
-    }
-    rc = S2T_LAUNCH_CHECK();
-  }
+  if (rc == S2T_OK && p.ws) rc = splitk_second_phase(p, s);
   return rc;
+}
+
+// two-phase split-K only with a large enough workspace and when every K split is non-empty (an empty split would leave its
+// workspace slice unwritten): the split count and workspace s2t_gemm runs with
+static int normalise_splitk(s2t_gemm_args& p) {
+  const int bke = p.dtype == S2T_F32 ? 32 : 64;
+  const int ktiles = (p.K + bke - 1) / bke;
+  const int per = (ktiles + p.split_k - 1) / p.split_k;
+  p.split_k = (ktiles + per - 1) / per;  // same partition without the empty trailing splits
+  const int64_t need = splitk_ws_floats(p);
+  // batches must own disjoint parts of C (the reduction is a plain read-modify-write)
+  const bool disjoint = p.batch == 1 || (p.zdiv == 1 && (p.c_s0 >= p.N || p.c_s0 >= (int64_t)p.M * p.ldc));
+  if (!(p.ws && need > 0 && p.ws_floats >= need && disjoint && ((uintptr_t)p.ws % 16) == 0)) p.ws = nullptr;
+  if (p.c_atomic == 2 && !p.ws) {
+    // overwrite needs the two-phase (workspace) reduction; without one the same result comes from a single pass
+    if (p.colsum_a) return S2T_ERR_UNSUPPORTED;
+    p.split_k = 1;
+    p.c_atomic = 0;
+  }
+  return S2T_OK;
 }
 
 }  // namespace
@@ -726,30 +749,13 @@ extern "C" int s2t_gemm(const s2t_gemm_args* a, void* stream) {
   if (s2t_rows_arg_bad(p.row_lens, p.row_T) || (p.row_lens && p.row_T < 0 && p.batch != 1)) return S2T_ERR_ARG;
   if (p.row_lens && (int64_t)p.batch * p.M >= ((int64_t)1 << 31)) return S2T_ERR_UNSUPPORTED;  // 32-bit row arithmetic in the mask
   if (p.drop_p < 0.f || p.drop_p >= 1.f) return S2T_ERR_ARG;
-  // two-phase split-K only with a large enough workspace and when every K split is non-empty (an empty split would
-  // leave its workspace slice unwritten)
-  {
-    const int bke = p.dtype == S2T_F32 ? 32 : 64;
-    const int ktiles = (p.K + bke - 1) / bke;
-    const int per = (ktiles + p.split_k - 1) / p.split_k;
-    p.split_k = (ktiles + per - 1) / per;  // same partition without the empty trailing splits
-    const bool all_splits_busy = true;
-    const int64_t need = splitk_ws_floats(p);
-    // batches must own disjoint parts of C (the reduction is a plain read-modify-write)
-    const bool disjoint = p.batch == 1 || (p.zdiv == 1 && (p.c_s0 >= p.N || p.c_s0 >= (int64_t)p.M * p.ldc));
-    if (!(p.ws && need > 0 && p.ws_floats >= need && all_splits_busy && disjoint && ((uintptr_t)p.ws % 16) == 0)) p.ws = nullptr;
-    if (p.c_atomic == 2 && !p.ws) {
-      // overwrite needs the two-phase (workspace) reduction; without one the same result comes from a single pass
-      if (p.colsum_a) return S2T_ERR_UNSUPPORTED;
-      p.split_k = 1;
-      p.c_atomic = 0;
-    }
-  }
+  if (const int rc = normalise_splitk(p); rc != S2T_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (s2t_gemm256_eligible(p))
   {
     const int nout256 = p.act == S2T_ACT_GLU ? p.N / 2 : p.N;
-    return s2t_gemm256_launch(p, p.c_dtype == S2T_F32 ? epilogue_vectorisable<float>(p, nout256) : epilogue_vectorisable<bf16_t>(p, nout256), s);
+    const int rc = s2t_gemm256_launch(p, p.c_dtype == S2T_F32 ? epilogue_vectorisable<float>(p, nout256) : epilogue_vectorisable<bf16_t>(p, nout256), s);
+    return (rc == S2T_OK && p.ws) ? splitk_second_phase(p, s) : rc;
   }
   if (p.dtype == S2T_F32) return launch<float, float>(p, s);
   if (p.c_dtype == S2T_F32 || p.ws) return launch<bf16_t, float>(p, s);  // (the partial tiles are fp32)
@@ -777,8 +783,9 @@ extern "C" int s2t_gemm_describe(const s2t_gemm_args* a, char* buf, int buflen) 
     s2t_gemm_args q = *a;  // (the normalisation s2t_gemm applies before it asks)
     if (q.batch <= 0) q.batch = 1;
     if (q.split_k <= 0) q.split_k = 1;
-    if (q.split_k == 1 || q.c_atomic != 2) q.ws = nullptr;
-    if (q.split_k == 1 && s2t_gemm256_eligible(q)) return s2t_gemm256_describe(q, vec, buf, buflen);
+    if (q.zdiv <= 0) q.zdiv = 1;
+    if (normalise_splitk(q) != S2T_OK) return S2T_ERR_UNSUPPORTED;
+    if (s2t_gemm256_eligible(q)) return s2t_gemm256_describe(q, vec, buf, buflen);
   }
   const char* t = f32 ? "float" : "unsigned short";
   const char* tc = cf32 ? "float" : "unsigned short";

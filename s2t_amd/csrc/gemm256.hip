@@ -44,6 +44,7 @@ constexpr int wait_vm(int vm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) 
 
 struct Tile {
   int ord, tm, tn, z;  // z: batch index (s2t_gemm's two-level batch, z0 = z / zdiv, z1 = z % zdiv)
+  int sp;              // K split (SPK), else 0
 };
 
 // VEC: every tensor of the epilogue 16-byte aligned, N % 8 == 0.  PLAIN (needs VEC): the epilogue is bias / activation / alpha /
@@ -59,9 +60,14 @@ struct Tile {
 // TMR: rows per tile.  256, or 128 for problems whose 256-row tiles would fill less than 0.6 of a round (M of the order of 16 000
 // with N <= 1024: the Linears of a 64 x 1000 batch at d = 512): the same kernel with 64 x 64 of C per wave (64 accumulator
 // registers), a 16 KiB A image and twice the tiles.
-template <typename TC, bool VEC, bool PLAIN, bool BKM, bool GLU = false, int TMR = 256>
+// SPK: one K split of a two-phase split-K product (s2t_gemm's c_atomic == 2 with a workspace): the (tile, split) pairs are the
+// work items — the split is the slowest index of the row-block walk — and the fp32 partial tile goes to the workspace in the
+// 128 x 128 kernel's register-native order, so that gemm.hip's second phase (splitk_reduce / splitk_epilogue) sums either
+// kernel's partials.  Long reductions over few output tiles: the input gradients of the vocabulary projections (K = 10 000).
+template <typename TC, bool VEC, bool PLAIN, bool BKM, bool GLU = false, int TMR = 256, bool SPK = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   static_assert(!(GLU && (BKM || PLAIN)), "GLU: row-major B, general epilogue");
+  static_assert(!SPK || (sizeof(TC) == 4 && VEC && PLAIN && !GLU), "split-K partials: fp32, no epilogue");
   static_assert(TMR == 256 || TMR == 128, "tile rows");
   constexpr int TM = TMR;
   constexpr int TMI = TM / 32;   // 16-row blocks of a wave's TM / 2 rows
@@ -88,21 +94,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     nx = 8;
   }
   // (a batch is folded into the row-block index: row block rb = z * tiles_m + tm)
-  const int rbs = p.batch * tiles_m;
+  const int nsp = SPK ? p.split_k : 1;
+  const int rbs = nsp * p.batch * tiles_m;
   const int my_rows = rbs > xc ? (rbs - xc + nx - 1) / nx : 0;
   const int local_tiles = my_rows * tiles_n;
   if (slot >= local_tiles) return;
   const int my_tiles = (local_tiles - slot + nslots - 1) / nslots;
-  const int nk = (p.K + TK - 1) / TK;
-  const int krem = p.K - (nk - 1) * TK;  // k of the last step: 64, or the tail (a multiple of 8; the pieces beyond it are fetched
+  const int nkT = (p.K + TK - 1) / TK;         // K-steps of the product
+  const int nk = SPK ? (nkT + nsp - 1) / nsp : nkT;  // ... of a work item (the last split's steps at and beyond nkT fetch zeros)
+  const int krem = p.K - (nkT - 1) * TK;  // k of the last step: 64, or the tail (a multiple of 8; the pieces beyond it are fetched
                                          // from beyond the descriptors' ranges, which reads as zero)
   const int S = my_tiles * nk;
   auto tile_at = [&](int ord) __attribute__((always_inline)) {
     const int l = slot + ord * nslots;
     const int r = l / tiles_n;
     const int rb = r * nx + xc;
-    const int z = rb / tiles_m;
-    return Tile{ord, rb - z * tiles_m, l - r * tiles_n, z};
+    const int zs = rb / tiles_m;
+    const int sp = SPK ? zs / p.batch : 0;
+    return Tile{ord, rb - zs * tiles_m, l - r * tiles_n, zs - sp * p.batch, sp};
   };
 
   // ---- DMA plan.  A K-step's operand image is 32 one-KiB pieces (8 rows each); wave w issues pieces 4 w .. 4 w + 3 of A and of
@@ -133,8 +142,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
   constexpr int PPA = APC / NLD;          // A pieces per issuing wave
   const bool loader = wave < NLD;
   uint32_t va[PPA], vb[PPW];
+  int lk0 = 0;  // (SPK) first K-step of the split being fetched
   constexpr uint32_t OOB = 0xfffffff0u;
   auto plan = [&](const Tile& t) __attribute__((always_inline)) {
+    if constexpr (SPK) lk0 = t.sp * nk;
     const int z0 = t.z / p.zdiv, z1 = t.z - z0 * p.zdiv;
     const uint32_t abase = (uint32_t)((z0 * p.a_s0 + z1 * p.a_s1) * 2), bbase = (uint32_t)((z0 * p.b_s0 + z1 * p.b_s1) * 2);
 #pragma unroll
@@ -173,16 +184,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
     const int qq = isa ? q : q - PPA;
     const uint32_t dst = lds0 + (uint32_t)(stage * STAGE_BYTES) + (uint32_t)(((isa ? PPA : PPW) * wave + qq) * 1024);
     // row-major operand in the tail step: this lane's k-piece is (lane & 7) ^ swz(row) — dropped when it starts at or beyond K
-    const bool tail = kt == nk - 1 && krem < TK;
+    if constexpr (SPK) kt += lk0;
+    const bool tail = kt == nkT - 1 && krem < TK;
+    const bool dead = SPK && kt >= nkT;  // (a row-major operand's bytes behind its row end are the next row's, not the range's end)
     const int kpiece = (lane & 7) ^ ((4 * (qq & 1) + (lane >> 4)) & 7);  // swz(row) = (row >> 1) & 7, row = 8 pg + (lane >> 3)
     if (isa) {
-      const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : va[qq];
+      const uint32_t v = (dead || (tail && 8 * kpiece >= krem)) ? OOB : va[qq];
       dma16(dst, v, srdA, (uint32_t)(kt * (TK * 2)));
     } else if constexpr (BKM) {
       // (k-rows at and beyond K lie beyond the descriptor's range by themselves)
       dma16(dst + OP_BYTES, vb[qq], srdB, (uint32_t)kt * (uint32_t)TK * ldb2);
     } else {
-      const uint32_t v = (tail && 8 * kpiece >= krem) ? OOB : vb[qq];
+      const uint32_t v = (dead || (tail && 8 * kpiece >= krem)) ? OOB : vb[qq];
       dma16(dst + OP_BYTES, v, srdB, (uint32_t)(kt * (TK * 2)));
     }
 #endif
@@ -281,6 +294,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const s2t_gemm_args p0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
 #else
+    if constexpr (SPK) {
+      // acc[i][2c + tau] = row 16 i + x of the wave's rows, columns 64 wn + 32 c + 8 y + 4 tau .. + 3 of the tile; in the 128 x 128
+      // kernel's order (gemm.hip, splitk_reduce_kernel) element (m, n) sits in tile (m >> 7, n >> 7) at
+      // ((i' * 4 + j') * 256 + (wm' * 2 + wn') * 64 + y' * 16 + x') * 4 + r with m & 127 = 64 wm' + 16 i' + x', n & 127 = 64 wn' + 16 j' + 4 y' + r
+      const int t128n = (p.N + 127) >> 7, t128m = (p0.M + 127) >> 7;
+      const int64_t slice = (int64_t)t128m * t128n * 16384;  // floats of one (batch, split)
+      const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+          p.ws + ((int64_t)t.z * p.split_k + t.sp) * slice, 0, (int)(uint32_t)(slice * 4), 0x00020000);
+      const int nt = 2 * t.tn + (wn >> 1);
+#pragma unroll
+      for (int i = 0; i < TMI; ++i) {
+        const int mt = TM == 256 ? 2 * t.tm + wm : t.tm;
+        const int wq = TM == 256 ? (i >> 2) : wm, iq = i & 3;
+        const bool ok = mt < t128m && nt < t128n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int jq = 2 * (j >> 1) + (y >> 1), yq = 2 * (y & 1) + (j & 1);
+          const uint32_t off = ok ? (uint32_t)(((mt * t128n + nt) * 16384 + ((iq * 4 + jq) * 256 + (wq * 2 + (wn & 1)) * 64 + yq * 16 + x) * 4) * 4)
+                                  : 0xfffffff0u;
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]),
+                                                          __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])}, wsrd, off, 0, 0);
+        }
+      }
+      return;
+    }
     const int ez0 = t.z / p.zdiv, ez1 = t.z - ez0 * p.zdiv;
     const int64_t coff = ez0 * p.c_s0 + ez1 * p.c_s1;
     const int64_t grow0 = (int64_t)t.z * p.M;  // global row of the batch's row 0 (mask, dropout index)
@@ -651,7 +689,16 @@ int s2t_gemm256_tile_rows(const s2t_gemm_args& p) {
 #if S2T_G256_DBG & 16
   if (p.split_k > 1 || p.c_atomic || p.ws) return 0;  // (p.colsum_a receives the stamps)
 #else
-  if (p.split_k > 1 || p.c_atomic || p.colsum_a || p.ws) return 0;
+  // split-K: the two-phase (workspace) form only — s2t_gemm has normalised the arguments: p.ws is set iff that form runs
+  const bool spk = p.split_k > 1 && p.c_atomic == 2 && p.ws;
+  if (!spk && (p.split_k > 1 || p.c_atomic || p.ws)) return 0;
+  if (p.colsum_a) return 0;
+  if (spk) {
+    if (p.act == S2T_ACT_GLU) return 0;
+    const int64_t slice = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * 16384 * 4;  // bytes of one (batch, split) of partials
+    if (slice >= (1ll << 32) - 64) return 0;
+    if (p.K < 64 * 8 * p.split_k) return 0;  // (at least eight K-steps per split: below that the partial tiles outweigh the product)
+  }
   if (p.batch > 1) {
     // a batch is folded into the row-block walk: every operand of the whole batch inside one 32-bit byte range, and no
     // k-major B (its K tail relies on the descriptor's end)
@@ -673,7 +720,7 @@ int s2t_gemm256_tile_rows(const s2t_gemm_args& p) {
   if (mode >= 3) return 128;
   // (tools/gemm256_probe.py border: 156 tiles of 256 x 256 1.39x, 189 1.38x, 250 1.3x; 126-128 tiles 0.95-1.05x, 88 0.92x, 64 0.78x
   // — below about 0.6 of a round the 128 x 128 path's 2 x 256 slots fill the chip better; 128-row tiles when THOSE reach 0.6)
-  const int64_t cols = (p.N + TN - 1) / TN;      // (GLU: N / 2 outputs in 128-column tiles: the same count)
+  const int64_t cols = (int64_t)(spk ? p.split_k : 1) * ((p.N + TN - 1) / TN);  // (GLU: N / 2 outputs in 128-column tiles: the same count)
   if ((int64_t)p.batch * ((p.M + 255) / 256) * cols >= 150) return 256;
   // (not the GLU form: the subsampler's second convolution — 64 x 250 rows, K = 2560 — measured 85 us on 128-row tiles against
   // 64 on the 128 x 128 kernel)
@@ -692,6 +739,16 @@ int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
   const dim3 grid(s2t_device_cu_count()), block(512);
   const bool plain = g256_plain(p, vec);
   const int rows = s2t_gemm256_tile_rows(p);
+  if (p.ws) {  // one split of a two-phase split-K product: fp32 partial tiles, the caller (s2t_gemm) runs the second phase
+    if (p.b_kmajor) {
+      if (rows == 128) hipLaunchKernelGGL((gemm256_kernel<float, true, true, true, false, 128, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm256_kernel<float, true, true, true, false, 256, true>), grid, block, 0, s, p);
+    } else {
+      if (rows == 128) hipLaunchKernelGGL((gemm256_kernel<float, true, true, false, false, 128, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm256_kernel<float, true, true, false, false, 256, true>), grid, block, 0, s, p);
+    }
+    return S2T_LAUNCH_CHECK();
+  }
 #define GO3(TC, BK, R) \
   do { \
     if (plain) hipLaunchKernelGGL((gemm256_kernel<TC, true, true, BK, false, R>), grid, block, 0, s, p); \
@@ -725,8 +782,13 @@ int s2t_gemm256_launch(const s2t_gemm_args& p, bool vec, hipStream_t s) {
 }
 
 int s2t_gemm256_describe(const s2t_gemm_args& p, bool vec, char* buf, int buflen) {
-  const int n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s, %s, %s, %d>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
-                         vec ? "true" : "false", g256_plain(p, vec) ? "true" : "false", p.b_kmajor ? "true" : "false",
-                         p.act == S2T_ACT_GLU ? "true" : "false", s2t_gemm256_tile_rows(p) == 128 ? 128 : 256);
+  int n;
+  if (p.ws)
+    n = snprintf(buf, buflen, "gemm256_kernel<float, true, true, %s, false, %d, true>", p.b_kmajor ? "true" : "false",
+                 s2t_gemm256_tile_rows(p) == 128 ? 128 : 256);
+  else
+    n = snprintf(buf, buflen, "gemm256_kernel<%s, %s, %s, %s, %s, %d, false>", p.c_dtype == S2T_F32 ? "float" : "unsigned short",
+                 vec ? "true" : "false", g256_plain(p, vec) ? "true" : "false", p.b_kmajor ? "true" : "false",
+                 p.act == S2T_ACT_GLU ? "true" : "false", s2t_gemm256_tile_rows(p) == 128 ? 128 : 256);
   return (n > 0 && n < buflen) ? S2T_OK : S2T_ERR_ARG;
 }

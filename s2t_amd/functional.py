@@ -782,6 +782,14 @@ def _dgrad(dy, w, dx, M, N, Kd, lda, ldb, ldc, alpha=1.0, rows=None):
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         if tiles < 384:
             split = max(1, min(8, 512 // tiles, Kd // 256))
+            if K.gemm_configure() != 0 and Kd % 8 == 0:
+                # the large tiles of gemm256.hip take (tile, split) pairs as work items: about one round of 256-row tiles where a
+                # split of at least eight K-steps allows it (16000 x 256 x 10000: 173 us on 128 x 128 tiles with 2 splits, 119 on
+                # 256-row tiles with 4; tools/splitk_probe.py) — else s2t_gemm falls back to 128-row tiles or the 128 x 128 kernel
+                t256 = ((M + 255) // 256) * ((N + 255) // 256)
+                s256 = min(8, -(-230 // t256))
+                if s256 > 1 and t256 * s256 >= 150 and Kd // (64 * s256) >= 24:  # (shorter splits: 128-row tiles at the split above
+                    split = s256                                                  # measured better, 16000 x 256 x 3072: 42 against 46 us)
     if split > 1:
         K.gemm(dy, w, dx, M=M, N=N, K=Kd, lda=lda, ldb=ldb, ldc=ldc, b_kmajor=True, alpha=alpha, split_k=split, c_atomic=2,
                rows=rows)
@@ -1560,7 +1568,7 @@ class CrossKVFn(torch.autograd.Function):
             _wgrad(dkv_all[:, 2 * d * l:], mem, gw, 2 * d, d, Mk, 2 * d * L, d, 1.0, gb, rows=ctx.rows)
             _ready(prm["k_w"], prm["v_w"], prm["k_b"], prm["v_b"])
         dmem = torch.empty(Mk, d, dtype=mem.dtype, device=mem.device)
-        K.gemm(dkv_all, w_all, dmem, M=Mk, N=d, K=2 * d * L, lda=2 * d * L, ldb=d, ldc=d, b_kmajor=True, rows=ctx.rows)
+        _dgrad(dkv_all, w_all, dmem, Mk, d, 2 * d * L, 2 * d * L, d, d, rows=ctx.rows)
         return dmem, None, None
 
 

@@ -456,6 +456,48 @@ def test_large_tile_epilogue(cdt):
         np.testing.assert_allclose(got[kept].cpu().numpy(), ref[kept].cpu().numpy(), rtol=1e-2, atol=4e-2)
 
 
+@pytest.mark.parametrize("M,N,K,split,bkm", [(16000, 256, 10000, 2, True), (3904, 256, 10000, 8, True), (300, 264, 4104, 4, True),
+                                             (1000, 520, 2048, 3, False), (257, 136, 10000, 7, False), (3904, 256, 2048, 4, True)])
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_large_tile_split_k(M, N, K, split, bkm, cdt):
+    """Two-phase split-K (c_atomic = 2, workspace) on the large tiles: the (tile, split) pairs are the work items, the partial
+    tiles land in the 128 x 128 kernel's workspace order and ITS second phase sums them — ragged M / N / K, a last split shorter
+    than the others (its steps beyond K fetch zeros), the fused second-phase epilogue (bias + residual, alpha), both output types:
+    equal to the 128 x 128 path bit for bit."""
+    import ctypes
+    from s2t_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K + split)
+    dev = "cuda"
+    A = _mk((M, K), torch.bfloat16, g)
+    Wl = _mk((N, K), torch.bfloat16, g, K ** -0.5)
+    Ad = A.to(dev)
+    Wd = (Wl.t().contiguous() if bkm else Wl).to(dev)
+    ldb = N if bkm else K
+    bias = _mk((N,), torch.float32, g).to(dev)
+    res = _mk((M, N), cdt, g).to(dev)
+    for epi in (False, True):
+        def call():
+            out = torch.full((M, N), 7.0, dtype=cdt, device=dev)
+            kw = dict(bias=bias, residual=res, ldr=N) if epi else {}
+            ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=K, ldb=ldb, ldc=N, b_kmajor=bkm, alpha=0.5, split_k=split, c_atomic=2, **kw)
+            return out
+
+        old, new = _both_paths(call)
+        assert torch.equal(old, new)
+        ref = 0.5 * (A.double() @ Wl.double().t() + (bias.cpu().double() if epi else 0.0)) + (res.cpu().double() if epi else 0.0)
+        np.testing.assert_allclose(new.cpu().double().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2 * ref.abs().max().item())
+    # the large-tile kernel is the one that ran (at least eight K-steps per split)
+    with _large_tile(2):
+        out = torch.empty(M, N, dtype=cdt, device=dev)
+        a = _gemm_args(Ad, Wd, out, M, N, K, K, ldb, N)
+        a.b_kmajor, a.split_k, a.c_atomic = int(bkm), split, 2
+        need = L.lib().s2t_gemm_ws_floats(ctypes.byref(a))
+        ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+        sym = ops.gemm_symbol(a)
+        assert ("gemm256_kernel" in sym and sym.endswith("true>")) == (K >= 512 * split), sym
+
+
 def test_large_tile_packed_rows():
     """row_T = S2T_ROWS_PACKED: the live row count is read on the device (row blocks beyond it are never walked, rows beyond it
     never stored) and halo rows come out zero — as on the 128 x 128 path."""

@@ -24,7 +24,7 @@ t0.record(); tr.train_step(sample); t1.record()
 torch.cuda.synchronize()
 prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
 agg = {}
-for sym, fl, e0, e1, shape in prof:
+for sym, fl, e0, e1, shape, *_ in prof:
     a = agg.setdefault((sym, shape), [0.0, 0.0, 0])
     a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = sum(a[1] for a in agg.values())
