@@ -1888,6 +1888,9 @@ def _conv_out_len(T):
     return (T - 1) // 2 + 1
 
 
+_SUB_TAPS = os.environ.get("S2T_SUB_TAPS", "0") == "1"  # subsampler input gradient tap by tap (five accumulating products)
+
+
 class SubsampleFn(torch.autograd.Function):
     """2 x [Conv1d(k=5, stride 2, pad 2) -> GLU]  (modules/speech_to_text/subsampling.py:106-159) as overlapping-row
     GEMMs over zero-padded (B, T+pad, C) buffers; the padded-frame mask of the encoder (s2t_transformer.py:1765)
@@ -1944,22 +1947,43 @@ class SubsampleFn(torch.autograd.Function):
         # rows per utterance multiply zeros.  The products then join the grouped weight-gradient launch (bias included).
         assert Tp1 == 2 * (T2 + 2) and Tp0 == 2 * (T1 + 2)
         # layer 2: GLU backward (padded frames carry no gradient)
-        dz2 = torch.empty(B, T2 + 2, C1, dtype=dt, device=dev)
+        # (two all-zero rows in FRONT of the first utterance as well: the input-gradient products below read every utterance's rows
+        # from two rows before its first)
+        dz2_buf = torch.empty(2 + B * (T2 + 2), C1, dtype=dt, device=dev)
+        dz2_buf[:2].zero_()
+        dz2 = dz2_buf[2:].view(B, T2 + 2, C1)
         dz2[:, T2:].zero_()
         K.glu_bwd(z2.view(B * T2, C1), dy, dz2, B * T2, H1, ctx.out_lens, T2, out_pad=2)
         _wgrad(dz2.view(B * (T2 + 2), C1), y1p, w1.grad.view(C1, kk * H0), C1, kk * H0, B * (T2 + 2), C1, 2 * H0, 1.0,
                b1.grad)
-        # d y1p: one GEMM per kernel tap (rows 2t+tap never collide inside one tap); accumulate tap by tap
-        dy1p = torch.zeros(B, Tp1, H0, dtype=dt, device=dev)
-        w1c = cw(w1).view(C1, kk * H0)
-        for tap in range(kk):
-            out = dy1p.view(-1)[tap * H0:]
-            K.gemm(dz2, w1c[:, tap * H0:], out, M=T2, N=H0, K=C1, lda=C1, ldb=kk * H0, ldc=2 * H0, b_kmajor=True, batch=B,
-                   a_s=((T2 + 2) * C1, 0), c_s=(Tp1 * H0, 0), residual=out, ldr=2 * H0)
+        # d y1 (the layer-1 output frames; frame f is row f + 2 of the padded buffer the forward convolved): frame f meets
+        # (t, tap) with 2 t + tap = f + 2 — the EVEN frames f = 2 u the taps 4, 2, 0 of output frames u-1, u, u+1, the ODD frames
+        # f = 2 u + 1 the taps 3, 1 of u, u+1.  The output frames of a product row are consecutive rows of dz2 (the zero rows
+        # between the utterances serve as the frames before 0 and beyond T'), so each parity is ONE product over overlapping
+        # operand rows (stride one row) against its taps' weights stacked along K, written straight into the contiguous
+        # gradient: two launches that write every row once, where five tap-by-tap products accumulated into a padded buffer
+        # (5 x read-modify-write of 33 MB at 64 x 1000 frames, a zero fill and a copy of the frames out of it): -0.07 ms per step
+        w1c = cw(w1).view(C1, kk, H0)
+        if _SUB_TAPS:  # (A/B switch: the tap-by-tap form)
+            dy1p = torch.zeros(B, Tp1, H0, dtype=dt, device=dev)
+            for tap in range(kk):
+                out = dy1p.view(-1)[tap * H0:]
+                K.gemm(dz2, w1c[:, tap], out, M=T2, N=H0, K=C1, lda=C1, ldb=kk * H0, ldc=2 * H0, b_kmajor=True, batch=B,
+                       a_s=((T2 + 2) * C1, 0), c_s=(Tp1 * H0, 0), residual=out, ldr=2 * H0)
+            dy1 = dy1p[:, 2:2 + T1].contiguous().view(B * T1, H0)
+        else:
+            dy1 = torch.empty(B * T1, H0, dtype=dt, device=dev)
+            for parity, taps in ((0, (4, 2, 0)), (1, (3, 1))):
+                nt = len(taps)
+                rows_p = (T1 + 1 - parity) // 2
+                if rows_p == 0:
+                    continue
+                wcat = torch.cat([w1c[:, tap] for tap in taps], 0)  # [nt * C1, H0], k-major
+                K.gemm(dz2_buf[4 - nt:], wcat, dy1.view(-1)[parity * H0:], M=rows_p, N=H0, K=nt * C1, lda=C1, ldb=H0, ldc=2 * H0,
+                       b_kmajor=True, batch=B, a_s=((T2 + 2) * C1, 0), c_s=(T1 * H0, 0))
         # layer 1
         dz1 = torch.empty(B, T1 + 2, C0, dtype=dt, device=dev)
         dz1[:, T1:].zero_()
-        dy1 = dy1p[:, 2:2 + T1].contiguous().view(B * T1, H0)
         K.glu_bwd(z1.view(B * T1, C0), dy1, dz1, B * T1, H0, None, T1, out_pad=2)
         _wgrad(dz1.view(B * (T1 + 2), C0), xp, w0.grad.view(C0, kk * Cin), C0, kk * Cin, B * (T1 + 2), C0, 2 * Cin, 1.0,
                b0.grad)
