@@ -89,15 +89,27 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
-  for (int k = 0; k < K; ++k) {
-    const float4 w4 = *reinterpret_cast<const float4*>(lw + k * CCH + cq * 4);
+  // (the 8 window rows of tap k are those of tap k - 1 moved by one: they stay in registers, slot (i + k) & 7 — static under the
+  // unroll by eight — and a tap fetches ONE row, K + 7 LDS reads per thread instead of 8 K; the same products in the same order)
+  float4 win[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float4 x4 = *reinterpret_cast<const float4*>(lx + (tg * 8 + i + k) * CCH + cq * 4);
-      acc[i][0] += w4.x * x4.x;
-      acc[i][1] += w4.y * x4.y;
-      acc[i][2] += w4.z * x4.z;
-      acc[i][3] += w4.w * x4.w;
+  for (int i = 0; i < 7; ++i) win[i] = *reinterpret_cast<const float4*>(lx + (tg * 8 + i) * CCH + cq * 4);
+  for (int kb = 0; kb < K; kb += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = kb + u;
+      if (k < K) {
+        const float4 w4 = *reinterpret_cast<const float4*>(lw + k * CCH + cq * 4);
+        win[(7 + u) & 7] = *reinterpret_cast<const float4*>(lx + (tg * 8 + 7 + k) * CCH + cq * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 x4 = win[(i + u) & 7];
+          acc[i][0] += w4.x * x4.x;
+          acc[i][1] += w4.y * x4.y;
+          acc[i][2] += w4.z * x4.z;
+          acc[i][3] += w4.w * x4.w;
+        }
+      }
     }
   }
   const int c = c0 + cq * 4;
@@ -529,16 +541,29 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float4 w4 = *reinterpret_cast<const float4*>(lw + k * CCH + cq * 4);
+    // The kernel is bound by vector issue (two waves per SIMD, ~4.5 k VALU instructions per thread, half of them bf16 -> fp32
+    // unpacking of LDS operands fetched again for every tap): the 8 window rows of tap k are those of tap k - 1 moved by one, so
+    // the rows stay in registers — slot (i + k) & 7, static under the unroll by eight — and each tap fetches and unpacks ONE row
+    // (K + 7 instead of 8 K).  Same products in the same order: the same bits.
+    float win[8][4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float x4[4];
-        ld4_as_f32<bf16_t>(ld_ + (tg * 8 + i + k) * CCH + cq * 4, x4);
-        acc[i][0] += w4.x * x4[0];
-        acc[i][1] += w4.y * x4[1];
-        acc[i][2] += w4.z * x4[2];
-        acc[i][3] += w4.w * x4[3];
+    for (int i = 0; i < 7; ++i) ld4_as_f32<bf16_t>(ld_ + (tg * 8 + i) * CCH + cq * 4, win[i]);
+    for (int kb = 0; kb < K; kb += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + u;
+        if (k < K) {
+          const float4 w4 = *reinterpret_cast<const float4*>(lw + k * CCH + cq * 4);
+          ld4_as_f32<bf16_t>(ld_ + (tg * 8 + 7 + k) * CCH + cq * 4, win[(7 + u) & 7]);  // row i + k of i = 7
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float (&x4)[4] = win[(i + u) & 7];
+            acc[i][0] += w4.x * x4[0];
+            acc[i][1] += w4.y * x4[1];
+            acc[i][2] += w4.z * x4[2];
+            acc[i][3] += w4.w * x4[3];
+          }
+        }
       }
     }
     float zv[8][4], zg[8][4];
@@ -569,37 +594,63 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(
     }
   }
   // ---- weight-gradient partial: dw[c][k] = sum over the tile's 32 time steps of dD[t][c] * G[t + k - pad][c]
-  float accw[8][4];  // k = tg + 4*kk
+  // Thread (cq, tg) owns EIGHT CONSECUTIVE taps k = 8 kg + j (kg = tg % NG, NG = ceil(K / 8) tap groups) over the time steps of its
+  // share th = tg / NG of the tile (NS = 4 / NG shares: two halves at K = 15, the whole tile at K = 31): the eight G rows t + k of
+  // step t are those of step t - 1 moved by one, so they too stay in registers (slot (j + t) & 7) and a step fetches and unpacks
+  // two rows — dD[t] and the new G row — where taps strided by four made it nine.  The shares of a tap meet in the transpose buffer.
+  const int NG = (K + 7) >> 3;            // 1, 2 or 4 (K <= 31; NG = 3 runs as 4 with an idle group)
+  const int NGe = NG == 3 ? 4 : NG;
+  const int NS = 4 / NGe;
+  const int kg = tg % NGe, th = tg / NGe;
+  const int k0 = 8 * kg;
+  const int tlen = TT / NS, ts = th * tlen;   // (TT = 32: 32, 16 or 8 steps, multiples of 8)
+  float accw[8][4];  // tap k0 + j
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) accw[i][r] = 0.f;
-  for (int t = 0; t < TT; ++t) {
-    float d4[4];
-    ld4_as_f32<bf16_t>(ld_ + (t + pad) * CCH + cq * 4, d4);
+  {
+    float gw[8][4];
+    auto grow = [&](int row, float (&v)[4]) __attribute__((always_inline)) {
+      ld4_as_f32<bf16_t>(lg + min(row, nrows - 1) * CCH + cq * 4, v);  // (rows beyond the window belong to taps >= K: never stored)
+    };
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int k = tg + 4 * kk;
-      if (k < K) {
-        float g4[4];
-        ld4_as_f32<bf16_t>(lg + (t + k) * CCH + cq * 4, g4);
-        accw[kk][0] += d4[0] * g4[0];
-        accw[kk][1] += d4[1] * g4[1];
-        accw[kk][2] += d4[2] * g4[2];
-        accw[kk][3] += d4[3] * g4[3];
+    for (int j = 0; j < 7; ++j) grow(ts + k0 + j, gw[j]);
+    for (int tb = 0; tb < tlen; tb += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = ts + tb + u;
+        float d4[4];
+        ld4_as_f32<bf16_t>(ld_ + (t + pad) * CCH + cq * 4, d4);
+        grow(t + k0 + 7, gw[(7 + u) & 7]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float (&g4)[4] = gw[(j + u) & 7];
+          accw[j][0] += d4[0] * g4[0];
+          accw[j][1] += d4[1] * g4[1];
+          accw[j][2] += d4[2] * g4[2];
+          accw[j][3] += d4[3] * g4[3];
+        }
       }
     }
   }
   __syncthreads();  // the flipped weights are no longer read: lw becomes the [256 channels][K] transpose buffer
+  for (int sh = 0; sh < NS; ++sh) {  // the time shares of a tap one after the other (a fixed order)
+    if (th == sh) {
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const int k = tg + 4 * kk;
-    if (k < K) {
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        if (k < K) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lw[(cq * 4 + r) * K + k] = accw[kk][r];
+          for (int r = 0; r < 4; ++r) {
+            float* q = lw + (cq * 4 + r) * K + k;
+            *q = sh == 0 ? accw[j][r] : *q + accw[j][r];
+          }
+        }
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* dwr = dw_ws + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * C * K + (int64_t)c0 * K;
   const int nvalid = min(CCH, C - c0) * K;
   for (int idx = threadIdx.x; idx < nvalid; idx += 256) dwr[idx] = lw[idx];
