@@ -133,7 +133,10 @@ __device__ __forceinline__ void tile_load(TileRegs& t, const bf16_t* __restrict_
   for (int u = 0; u < 2; ++u) {
     const int c = tid + 256 * u;
     const int r = min(row0 + (c >> 3), nrows - 1), ch = c & 7;
-    t.v[u] = ldg16(base + (int64_t)r * sr + ch * 8);
+    // (row < 2^16, row stride < 2^16 elements — the entry points check — so the offset is ONE full-rate 24-bit multiply; the
+    // 64-bit form was two quarter-rate 32-bit multiplies and a 64-bit multiply-add per load, 24 such per key block in the backward
+    // kernels, which are bound by vector issue)
+    t.v[u] = ldg16(base + (__umul24((uint32_t)r, (uint32_t)sr) + (uint32_t)(ch * 8)));
   }
 }
 __device__ __forceinline__ void tile_store(char* lds, const TileRegs& t, int row0, int nrows, const float* __restrict__ bias,
@@ -227,7 +230,7 @@ __device__ __forceinline__ void ptile_load(const FusedArgs& a, PTile& t, int h, 
     const int c = tid + 256 * u;
     int n = nb3 + (c >> 3);
     n = n < 0 ? 0 : (n > nmax ? nmax : n);
-    t.v[u] = ldg16(pp + (int64_t)n * a.p_sr + (c & 7) * 8);
+    t.v[u] = ldg16(pp + (__umul24((uint32_t)n, (uint32_t)a.p_sr) + (uint32_t)((c & 7) * 8)));
   }
 }
 __device__ __forceinline__ void ptile_store(char* lp, const PTile& t, int tid) {
@@ -1051,7 +1054,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const FusedArgs a_in)
 #pragma unroll
           for (int rb = 0; rb < 4; rb += 2) {
             const int im = min(q0 + 16 * qt + 4 * y + rb + (x & 1), a.nq - 1);
-            const uint32_t pair = ((uint32_t)z * (uint32_t)a.Tq + (uint32_t)im) * (uint32_t)(a.Tk >> 1) + (uint32_t)(jc >> 1);
+            // ((z Tq + im) (Tk / 2) in 32-bit wrap-around arithmetic, the per-lane part as a full-rate 24-bit multiply: im, Tk < 2^16)
+            const uint32_t pair = (uint32_t)z * (uint32_t)a.Tq * (uint32_t)(a.Tk >> 1) + __umul24((uint32_t)im, (uint32_t)(a.Tk >> 1)) + (uint32_t)(jc >> 1);
             const uint32_t hm = s2t_mix32(pair ^ (uint32_t)dkey) ^ (uint32_t)(dkey >> 32);
             const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]: lane x ^ 1
             const uint32_t h0 = (x & 1) ? ho : hm, h1 = (x & 1) ? hm : ho;  // hashes of queries rb, rb + 1
@@ -1262,6 +1266,9 @@ extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, con
                                   const int32_t* cu_k, void* stream) {
   if (!q || !k || !v || !o || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
   if (dk != DK) return S2T_ERR_UNSUPPORTED;
+  if (q_sr >= 65536 || k_sr >= 65536 || v_sr >= 65536 || o_sr >= 65536 || p_sr >= 65536 || Tq >= 65536 || Tk >= 65536 ||
+      q_sr < 0 || k_sr < 0 || v_sr < 0 || o_sr < 0 || p_sr < 0)
+    return S2T_ERR_UNSUPPORTED;  // (24-bit row x stride products in the tile loads)
   if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
   if (pos_p && (!pos_u || !pos_v || Tq != Tk)) return S2T_ERR_ARG;
   if ((q_sr % 8) || (k_sr % 8) || (v_sr % 8) || (o_sr % 4) || ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16))
@@ -1307,6 +1314,9 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
   if (!q || !k || !v || !o || !dO || !lse || !delta || !dq || !dk_ || !dv || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0)
     return S2T_ERR_ARG;
   if (dk != DK) return S2T_ERR_UNSUPPORTED;
+  if (q_sr >= 65536 || k_sr >= 65536 || v_sr >= 65536 || o_sr >= 65536 || p_sr >= 65536 || Tq >= 65536 || Tk >= 65536 ||
+      q_sr < 0 || k_sr < 0 || v_sr < 0 || o_sr < 0 || p_sr < 0)
+    return S2T_ERR_UNSUPPORTED;  // (24-bit row x stride products in the tile loads)
   if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
   if (pos_p && (!pos_u || !pos_v || Tq != Tk)) return S2T_ERR_ARG;
   if (dbd && ldb < 2 * Tq - 1) return S2T_ERR_ARG;
