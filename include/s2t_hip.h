@@ -182,6 +182,8 @@ int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP,
  * (column sums of the two branches, espnet_multihead_attention.py:339-345) into dpos_u / dpos_v ([H*64] fp32, atomics).
  * qv_out != NULL (relative form): the dQ kernel also writes Q + pos_v ([B*Tq][H*64] bf16, the operand of the position-table
  * gradient GEMM) instead of a separate s2t_bias_add_rows pass.
+ * Limits: dk = 64; Tq, Tk and every row stride (q_sr, k_sr, v_sr, o_sr, p_sr; elements) below 65 536 — the tile loads form
+ * row x stride with 24-bit multiplies — else S2T_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------------------------------ */
 int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
                        int64_t v_sb, int64_t v_sr, void* o, int64_t o_sb, int64_t o_sr, float* lse, int B, int H, int Tq,

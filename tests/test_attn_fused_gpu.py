@@ -480,3 +480,19 @@ def test_fused_attention_on_packed_rows_equals_the_padded_layout(kind, pdrop):
         written = (ii < cap[:, None, None]) & (nn_ >= Tq - 1 - ii) & (nn_ < Tq - 1 - ii + cap[:, None, None])
         w4 = written[None].expand(H, B, Tq, ldb)
         assert torch.equal(a[4][w4], b[4][w4]), "dbd"
+
+
+def test_strides_beyond_the_24_bit_products_are_refused():
+    """The tile loads form row x stride with 24-bit multiplies: a row stride (or a length) of 65 536 elements or more is refused
+    with S2T_ERR_UNSUPPORTED instead of reading the wrong rows."""
+    B, H, T, dk = 1, 1, 16, 64
+    q = torch.zeros(T, 65536 + 64, dtype=torch.bfloat16, device=DEV)
+    o = torch.empty(T, 64, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(T, device=DEV)
+    with pytest.raises(RuntimeError, match="s2t_attn_fused_fwd"):
+        K.attn_fused_fwd(q, T * q.shape[1], q.shape[1], q, T * q.shape[1], q.shape[1], q, T * q.shape[1], q.shape[1], o, T * 64, 64,
+                         lse, B, H, T, T, dk, None, False, 0.125)
+    qs = q[:, :64].contiguous()
+    K.attn_fused_fwd(qs, T * 64, 64, qs, T * 64, 64, qs, T * 64, 64, o, T * 64, 64, lse, B, H, T, T, dk, None, False, 0.125)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
