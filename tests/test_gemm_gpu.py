@@ -525,6 +525,32 @@ def test_large_tile_packed_rows():
     np.testing.assert_allclose(new[:live][m >= 0].float().cpu().numpy(), ref[m >= 0].cpu().numpy(), rtol=1e-2, atol=4e-2)
 
 
+def test_large_tile_split_k_packed_rows():
+    """Two-phase split-K over a packed batch (the CTC head's input gradient): the work items cover the LIVE row blocks only, the
+    second phase reads exactly those partial tiles, rows beyond the live count keep what they held — bit for bit the 128 x 128
+    path, with both tile heights."""
+    from s2t_amd import rows as Rows
+    dev = "cuda"
+    g = torch.Generator().manual_seed(5)
+    B_, T, K, N = 24, 130, 5000 + 8, 256
+    lens = torch.randint(30, T + 1, (B_,), generator=g).to(torch.int32).to(dev)
+    Rows.attach(lens, B_, T, 7, tag="test_large_tile_splitk")
+    M = B_ * T
+    live = lens._pk.live_rows()
+    assert live < M - 200
+    A = _mk((M, K), torch.bfloat16, g).to(dev); W = _mk((K, N), torch.bfloat16, g, K ** -0.5).to(dev)
+
+    def call():
+        out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_kmajor=True, split_k=4, c_atomic=2, rows=lens)
+        return out
+    old, new = _both_paths(call)
+    assert torch.equal(old, new)
+    assert (new[live:] == 7.0).all()
+    ref = A[:live].float() @ W.float()
+    np.testing.assert_allclose(new[:live].float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=4e-2)
+
+
 @pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,nout,K,stride", [(2000, 512, 400, 160), (700, 136, 192, 0), (4100, 256, 2560, 1024)])
 def test_large_tile_glu(cdt, M, nout, K, stride):
