@@ -183,7 +183,9 @@ int s2t_attn_softmax_bwd(int dtype, const void* P, int64_t ldP, const float* dP,
  * qv_out != NULL (relative form): the dQ kernel also writes Q + pos_v ([B*Tq][H*64] bf16, the operand of the position-table
  * gradient GEMM) instead of a separate s2t_bias_add_rows pass.
  * Limits: dk = 64; Tq, Tk and every row stride (q_sr, k_sr, v_sr, o_sr, p_sr; elements) below 65 536 — the tile loads form
- * row x stride with 24-bit multiplies — else S2T_ERR_UNSUPPORTED.
+ * row x stride with 24-bit multiplies — and, with relative positions, (2 Tq - 1) * p_sr below 2^32 (the position rows run to
+ * 2 Tq - 2), else S2T_ERR_UNSUPPORTED.  An utterance of a packed batch may hold no row (cu[b] == cu[b + 1]): nothing of it is
+ * read or stored.
  * ------------------------------------------------------------------------------------------------ */
 int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
                        int64_t v_sb, int64_t v_sr, void* o, int64_t o_sb, int64_t o_sr, float* lse, int B, int H, int Tq,
@@ -191,7 +193,12 @@ int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        const float* pos_u, const float* pos_v, float drop_p, const uint64_t* drop_seed,
                        uint32_t drop_site,
                        const int32_t* cu_q, const int32_t* cu_k /* packed batch: rows of utterance b on the query / key side =
-                       cu[b] .. cu[b+1] (X_sb is then unused on that side), or NULL */, void* stream);
+                       cu[b] .. cu[b+1] (X_sb is then unused on that side), or NULL */,
+                       void* o_lo /* optional, layout of o (bf16): what the rounding of the fp32 output to bf16 dropped, itself
+                       rounded to bf16.  The backward's delta = rowsum(dO * O) is taken on o + o_lo when it is given the same
+                       buffer: dS = P (dP - delta) cancels where the probabilities are nearly uniform (encoder-decoder attention
+                       over a few hundred keys, multihead_attention.py:367-420), and delta from the rounded o alone then carries
+                       an error of the size of the difference */, void* stream);
 int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
                        int64_t v_sb, int64_t v_sr, const void* o, const void* dO, int64_t o_sb, int64_t o_sr,
                        const float* lse, float* delta, void* dq, void* dk, void* dv, void* dbd, int64_t ldb, int B, int H,
@@ -200,7 +207,8 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
                        uint32_t drop_site, int dbd_band_only,
                        const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* qv_out,
                        const int32_t* cu_q, const int32_t* cu_k /* as s2t_attn_fused_fwd; lse / delta / dbd / qv_out keep their
-                       padded strides (row b*Tq + i), of which only the utterance's own rows are touched */, void* stream);
+                       padded strides (row b*Tq + i), of which only the utterance's own rows are touched */,
+                       const void* o_lo /* optional: the forward's o_lo of the same call */, void* stream);
 
 /* Relative-position attention backward, the (Q + pos_bias_v) branch behind s2t_attn_fused_bwd
  * (espnet_multihead_attention.py:331-337 backward; replaces a batched GEMM over the half-empty skewed dbd rows, the

@@ -75,7 +75,7 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(_CriterionBase):
         elif self.ctc_weight > 0 and len(enc["ctc_logit"]) > 0:
             ctc_tbv = enc["ctc_logit"][0]
             Tn = ctc_tbv.shape[0]
-            (in_lens,) = Fn.batch_memo(("ctc_in_lens", id(self)), (enc["encoder_padding_mask"][0],),
+            (in_lens,) = Fn.batch_memo(("ctc_in_lens", Fn.memo_owner(self)), (enc["encoder_padding_mask"][0],),
                                        lambda m: ((~m).sum(1).to(torch.int32),))
             tmat, tl, _ = batch_bookkeeping(sample, self.padding_idx, self.eos_idx)
             l2d = ctc_tbv.transpose(0, 1).reshape(B * Tn, -1)  # a view: the encoder's buffer is batch-major
@@ -108,7 +108,7 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(_CriterionBase):
                 idx = torch.where(ok, (m >> 16).long() * U_ + (m & 0xffff).long(), torch.zeros_like(m, dtype=torch.long))
                 return (torch.where(ok, t.reshape(-1)[idx], torch.full_like(idx, pad_idx)),)
 
-            (tpk,) = Fn.batch_memo(("targets_packed", id(self)), (tflat, geom.buf), pack_targets)
+            (tpk,) = Fn.batch_memo(("targets_packed", Fn.memo_owner(self)), (tflat, geom.buf), pack_targets)
             sums = Fn.label_smoothed_ce(logits, tpk, self.eps, self.padding_idx, rows=dpk["rows"])
         else:
             _, U, V = logits.shape

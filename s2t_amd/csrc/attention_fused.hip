@@ -38,6 +38,8 @@ struct FusedArgs {
   int64_t q_sb, q_sr, k_sb, k_sr, v_sb, v_sr;
   bf16_t* o;
   int64_t o_sb, o_sr;
+  bf16_t* o_lo;  // optional, layout of o: the bf16-rounded REMAINDER of the fp32 output (o + o_lo carries 16 mantissa bits) —
+                 // written by the forward, read by the backward's delta = rowsum(dO * O) (s2t_attn_fused_fwd in the header)
   float* lse;  // [Z][Tq]
   int B, H, Tq, Tk;
   const int32_t* key_lens;
@@ -79,6 +81,7 @@ __device__ __forceinline__ void bind_utt(FusedArgs& a, int b) {
     a.q += oq;
     if (a.dq) a.dq += oq;
     a.o += oo;
+    if (a.o_lo) a.o_lo += oo;
     if (a.dO) a.dO += oo;
   }
   if (a.cu_k) {
@@ -132,7 +135,9 @@ __device__ __forceinline__ void tile_load(TileRegs& t, const bf16_t* __restrict_
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int c = tid + 256 * u;
-    const int r = min(row0 + (c >> 3), nrows - 1), ch = c & 7;
+    // (an utterance of a packed batch may hold no row at all: the clamp then lands on row 0, never on -1 — which the 24-bit
+    // multiply below would turn into 0xFFFFFF rows)
+    const int r = max(min(row0 + (c >> 3), nrows - 1), 0), ch = c & 7;
     // (row < 2^16, row stride < 2^16 elements — the entry points check — so the offset is ONE full-rate 24-bit multiply; the
     // 64-bit form was two quarter-rate 32-bit multiplies and a 64-bit multiply-add per load, 24 such per key block in the backward
     // kernels, which are bound by vector issue)
@@ -437,10 +442,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a_in) {
   if (i < a.nq) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
     bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)i * a.o_sr + h * DK;
+    bf16_t* lo = a.o_lo ? a.o_lo + (int64_t)b * a.o_sb + (int64_t)i * a.o_sr + h * DK : nullptr;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       float v4[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
       st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
+      if (lo) {  // what the bf16 rounding of O dropped, itself rounded to bf16
+        float r4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r4[r] = v4[r] - bf2f(f2bf(v4[r]));
+        st4_from_f32<bf16_t>(lo + 16 * dt + 4 * y, r4);
+      }
     }
     if (y == 0 && a.lse) a.lse[(int64_t)z * a.Tq + i] = (l > 0.f) ? (m + __log2f(l)) * 0.693147180559945f : -INFINITY;
   }
@@ -563,6 +575,7 @@ __device__ __forceinline__ void bh_stage_images(const FusedArgs& a, char* lds, i
 __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a_in) {
   FusedArgs a = a_in;
   bind_utt(a, blockIdx.x / a_in.H);
+  if (a.nq <= 0 || a.nk <= 0) return;  // packed batch: an utterance without rows (nothing to read, nothing to store)
   __shared__ __attribute__((aligned(16))) char lds[BH_LDS];
   char* lk = lds;
   char* lv = lds + BH_MAXT * 128;
@@ -646,10 +659,17 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a_i
     if (i < a.nq) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
       bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)i * a.o_sr + h * DK;
+      bf16_t* lo = a.o_lo ? a.o_lo + (int64_t)b * a.o_sb + (int64_t)i * a.o_sr + h * DK : nullptr;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         float v4[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
         st4_from_f32<bf16_t>(op + 16 * dt + 4 * y, v4);
+        if (lo) {
+          float r4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) r4[r] = v4[r] - bf2f(f2bf(v4[r]));
+          st4_from_f32<bf16_t>(lo + 16 * dt + 4 * y, r4);
+        }
       }
       // (m and the scores are in the log2 domain here; the backward kernels take the natural-log row statistic)
       if (y == 0 && a.lse) a.lse[(int64_t)z * a.Tq + i] = (l > 0.f) ? (m + __log2f(l)) * 0.693147180559945f : -INFINITY;
@@ -709,16 +729,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a_in) 
   }
   const float lse_i = a.lse[(int64_t)z * a.Tq + ic];
   // delta_i = sum_c dO[i][c] * O[i][c]: the four lanes of a query row hold a quarter of it each (the dO fragments);
-  // written out for the dK / dV kernel that follows
+  // written out for the dK / dV kernel that follows.  dS = P (dP - delta) CANCELS where the probabilities are nearly uniform
+  // (the decoder's encoder-decoder attention over 250 keys): delta from the bf16-ROUNDED O then carries an error of the size of
+  // the difference (the composed path sums P dP in fp32).  With o_lo — what the rounding of O dropped — the sum is taken on
+  // O + o_lo, 16 mantissa bits.
   float del_i;
   {
     const bf16_t* op = a.o + (int64_t)b * a.o_sb + (int64_t)ic * a.o_sr + h * DK;
+    const bf16_t* lp_ = a.o_lo ? a.o_lo + (int64_t)b * a.o_sb + (int64_t)ic * a.o_sr + h * DK : nullptr;
     float part = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const uint4 ov = ldg16(op + (ks * 4 + y) * 8);
       const uint4 dv = __builtin_bit_cast(uint4, dof[ks]);
       const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+      if (lp_) {
+        const uint4 lv_ = ldg16(lp_ + (ks * 4 + y) * 8);
+        const uint32_t lw[4] = {lv_.x, lv_.y, lv_.z, lv_.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          part += (__uint_as_float(ow[t] << 16) + __uint_as_float(lw[t] << 16)) * __uint_as_float(dw[t] << 16) +
+                  (__uint_as_float(ow[t] & 0xffff0000u) + __uint_as_float(lw[t] & 0xffff0000u)) * __uint_as_float(dw[t] & 0xffff0000u);
+        continue;
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         part += __uint_as_float(ow[t] << 16) * __uint_as_float(dw[t] << 16) +
@@ -1263,12 +1296,15 @@ extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, con
                                   float* lse, int B, int H, int Tq, int Tk, int dk, const int32_t* key_lens, int causal,
                                   float scale, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
                                   float drop_p, const uint64_t* drop_seed, uint32_t drop_site, const int32_t* cu_q,
-                                  const int32_t* cu_k, void* stream) {
+                                  const int32_t* cu_k, void* o_lo, void* stream) {
   if (!q || !k || !v || !o || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
+  if (o_lo && ((uintptr_t)o_lo % 8)) return S2T_ERR_ALIGN;
   if (dk != DK) return S2T_ERR_UNSUPPORTED;
   if (q_sr >= 65536 || k_sr >= 65536 || v_sr >= 65536 || o_sr >= 65536 || p_sr >= 65536 || Tq >= 65536 || Tk >= 65536 ||
       q_sr < 0 || k_sr < 0 || v_sr < 0 || o_sr < 0 || p_sr < 0)
     return S2T_ERR_UNSUPPORTED;  // (24-bit row x stride products in the tile loads)
+  if (pos_p && (uint64_t)(2 * Tq - 1) * (uint64_t)p_sr >= (1ull << 32))
+    return S2T_ERR_UNSUPPORTED;  // (position rows run to 2 Tq - 2: their 24-bit product must stay inside 32 bits)
   if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
   if (pos_p && (!pos_u || !pos_v || Tq != Tk)) return S2T_ERR_ARG;
   if ((q_sr % 8) || (k_sr % 8) || (v_sr % 8) || (o_sr % 4) || ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16))
@@ -1276,7 +1312,7 @@ extern "C" int s2t_attn_fused_fwd(const void* q, int64_t q_sb, int64_t q_sr, con
   FusedArgs a = {};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr;
-  a.o = (bf16_t*)o; a.o_sb = o_sb; a.o_sr = o_sr; a.lse = lse;
+  a.o = (bf16_t*)o; a.o_sb = o_sb; a.o_sr = o_sr; a.lse = lse; a.o_lo = (bf16_t*)o_lo;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.key_lens = key_lens; a.causal = causal; a.scale = scale;
   a.rel = pos_p != nullptr; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.pos_u = pos_u; a.pos_v = pos_v;
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site;
@@ -1310,13 +1346,16 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
                                   float scale, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
                                   float drop_p, const uint64_t* drop_seed, uint32_t drop_site, int dbd_band_only,
                                   const void* pos_pt, int64_t pt_ld, float* dpos_u, float* dpos_v, void* qv_out,
-                                  const int32_t* cu_q, const int32_t* cu_k, void* stream) {
+                                  const int32_t* cu_q, const int32_t* cu_k, const void* o_lo, void* stream) {
   if (!q || !k || !v || !o || !dO || !lse || !delta || !dq || !dk_ || !dv || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0)
     return S2T_ERR_ARG;
+  if (o_lo && ((uintptr_t)o_lo % 16)) return S2T_ERR_ALIGN;
   if (dk != DK) return S2T_ERR_UNSUPPORTED;
   if (q_sr >= 65536 || k_sr >= 65536 || v_sr >= 65536 || o_sr >= 65536 || p_sr >= 65536 || Tq >= 65536 || Tk >= 65536 ||
       q_sr < 0 || k_sr < 0 || v_sr < 0 || o_sr < 0 || p_sr < 0)
     return S2T_ERR_UNSUPPORTED;  // (24-bit row x stride products in the tile loads)
+  if (pos_p && (uint64_t)(2 * Tq - 1) * (uint64_t)p_sr >= (1ull << 32))
+    return S2T_ERR_UNSUPPORTED;  // (position rows run to 2 Tq - 2: their 24-bit product must stay inside 32 bits)
   if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
   if (pos_p && (!pos_u || !pos_v || Tq != Tk)) return S2T_ERR_ARG;
   if (dbd && ldb < 2 * Tq - 1) return S2T_ERR_ARG;
@@ -1325,6 +1364,7 @@ extern "C" int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, con
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr;
   a.o = (bf16_t*)const_cast<void*>(o); a.o_sb = o_sb; a.o_sr = o_sr; a.lse = const_cast<float*>(lse);
+  a.o_lo = (bf16_t*)const_cast<void*>(o_lo);
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.key_lens = key_lens; a.causal = causal; a.scale = scale;
   a.rel = pos_p != nullptr; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.pos_u = pos_u; a.pos_v = pos_v;
   a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site;

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(1024) void rows_geometry_kernel(const int32_t* __re
   }
   const int live = scu[B];
   if (blockIdx.x == 0) {
-    if (tid <= B) cu[tid] = scu[tid];
+    if (tid < B) cu[tid] = scu[tid];
+    if (tid == 0) cu[B] = live;  // (its own store: with B = 1024 no thread has tid == B)
     if (tid < 4) buf[tid] = tid == 3 ? live : 0;
   }
   for (int m = blockIdx.x * 1024 + tid; m < M; m += gridDim.x * 1024) {

@@ -209,8 +209,11 @@ __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int32_t* __res
     const int t = base + threadIdx.x;
     int cur = blank, prev = -1;
     if (t < T) {
-      // packed batch: the rows behind an utterance's frames belong to the next one — the padded frames they stand for are
-      // zero rows in the reference, whose arg-max is the blank (index 0 of a constant row) and add nothing to the score
+      // packed batch: the rows behind an utterance's frames belong to the next one — the padded frames they stand for are not
+      // stored.  Tokens: the reference maps padded frames to the blank (s2t_ctc.py:324-326), so nothing is lost.  SCORE: the
+      // reference adds the top-1 log-probability of every frame whose UNMASKED arg-max is not the blank, padded frames included
+      // (:327-329; their logits are LayerNorm bias -> projection, not zero rows) — a packed batch cannot, so its score lacks that
+      // input-independent term (INTEGRATION.md "Hypothesis scores"; CTCDecoder.exact_scores takes the padded layout instead)
       const bool have = !cu || t < len;
       const int raw = have ? idx[r0 + t] : blank;
       cur = t < len ? raw : blank;

@@ -205,16 +205,121 @@ class _on_wgrad_stream:
 # batch object (keyed by the identity and version of the source tensors) instead of once per forward pass, so a captured step
 # replays none of them; when new data is copied INTO a captured step's static batch (Trainer.load_batch),
 # refresh_batch_memos recomputes every memo into the SAME output tensors (the graph holds their addresses).
-_MEMO = {}
+_MEMO = {}          # key -> (srcs, versions, fn, outs): the most recent batch object of each user
+_MEMO_PINNED = {}   # key -> [entries whose tensors a captured hipGraph reads]: never replaced or released while pinned
+_UID = [0]
+
+
+def memo_owner(obj):
+    """A process-unique serial for ``obj`` (an encoder, a decoder, a criterion) to key its memos by.  NOT ``id(obj)``: CPython
+    re-uses the id of a collected object, so a model built after another was dropped could land on the dead one's keys (and, with a
+    captured step, on tensors whose addresses that step's graph had baked in).  When ``obj`` is collected its entries go."""
+    uid = getattr(obj, "_s2t_uid", None)
+    if uid is None:
+        import weakref
+
+        _UID[0] += 1
+        uid = ("uid", _UID[0])
+        try:
+            object.__setattr__(obj, "_s2t_uid", uid)
+            weakref.finalize(obj, _purge_owner, uid)
+        except (AttributeError, TypeError):  # an object without attributes / weak references: the serial cannot stay with it
+            return ("id", id(obj))
+    return uid
+
+
+def _key_has(key, uid):
+    if key == uid:
+        return True
+    return isinstance(key, tuple) and any(_key_has(k, uid) for k in key)
+
+
+def _purge_owner(uid):
+    for table in (_MEMO, _MEMO_PINNED):
+        for key in [k for k in table if _key_has(k, uid)]:
+            table.pop(key, None)
+
+
+def _same_srcs(e, srcs):
+    return len(e[0]) == len(srcs) and all(a is b for a, b in zip(e[0], srcs))
+
+
+def _recompute_in_place(table_entry, key, pinned_slot=None):
+    """fn(*srcs) into the entry's EXISTING output tensors (addresses a captured graph may hold stay valid)."""
+    srcs, _, fn, outs = table_entry
+    new = fn(*srcs)
+    ok = len(new) == len(outs) and all((not torch.is_tensor(o)) or (torch.is_tensor(n) and o.shape == n.shape and o.dtype == n.dtype)
+                                       for o, n in zip(outs, new))
+    if not ok:
+        return None
+    for o, n in zip(outs, new):
+        if torch.is_tensor(o) and o is not n:
+            o.copy_(n)
+    return (srcs, tuple(t._version for t in srcs), fn, outs)
 
 
 def batch_memo(key, srcs, fn):
+    """``fn(*srcs)`` computed once per batch object.  Same source OBJECTS with new contents (their version counters moved: data
+    copied into a static batch) are recomputed INTO the existing outputs, so whoever holds those tensors — a later layer of this
+    pass, a captured graph — sees the new values at the old addresses; another batch object replaces the entry, unless a captured
+    graph reads it (pin_batch_memos): the pinned entry then stays beside the new one."""
+    pinned = _MEMO_PINNED.get(key, ())
+    for i, e in enumerate(pinned):
+        if _same_srcs(e, srcs):
+            if all(a._version == v for a, v in zip(e[0], e[1])):
+                return e[3]
+            ne = _recompute_in_place(e[:4], key)
+            if ne is None:
+                raise RuntimeError("s2t_amd: the per-batch bookkeeping %r of a captured step changed shape" % (key,))
+            pinned[i] = ne + tuple(e[4:])
+            return ne[3]
     e = _MEMO.get(key)
-    if e is not None and len(e[0]) == len(srcs) and all(a is b and a._version == v for a, b, v in zip(e[0], srcs, e[1])):
-        return e[3]
+    if e is not None and _same_srcs(e, srcs):
+        if all(a._version == v for a, v in zip(e[0], e[1])):
+            return e[3]
+        ne = _recompute_in_place(e, key)
+        if ne is not None:
+            _MEMO[key] = ne
+            return ne[3]
     outs = fn(*srcs)
     _MEMO[key] = (tuple(srcs), tuple(t._version for t in srcs), fn, outs)
     return outs
+
+
+def pin_batch_memos(tensors, owner):
+    """Called when a step over the batch ``tensors`` is captured into a hipGraph: every memo computed from them (directly or
+    through another memo's outputs) is read by the graph at its current address — from now on it is neither replaced by an eager
+    pass over another batch nor released, until ``unpin_batch_memos(owner)``."""
+    reach = {id(t) for t in tensors}
+    moved = True
+    while moved:
+        moved = False
+        for key, e in list(_MEMO.items()):
+            if any(id(t) in reach for t in e[0]):
+                _MEMO.pop(key)
+                _MEMO_PINNED.setdefault(key, []).append(e + (owner,))
+                for o in e[3]:
+                    if torch.is_tensor(o):
+                        reach.add(id(o))
+                moved = True
+    # (entries keep their 4-tuple shape for the readers above; the owner rides as a fifth element)
+
+
+def unpin_batch_memos(owner):
+    for key in list(_MEMO_PINNED):
+        keep = [e for e in _MEMO_PINNED[key] if not (len(e) > 4 and e[4] == owner)]
+        if keep:
+            _MEMO_PINNED[key] = keep
+        else:
+            _MEMO_PINNED.pop(key)
+
+
+def _all_memo_entries():
+    for key, e in list(_MEMO.items()):
+        yield _MEMO, key, None, e
+    for key, lst in list(_MEMO_PINNED.items()):
+        for i, e in enumerate(lst):
+            yield lst, key, i, e
 
 
 def refresh_batch_memos(changed):
@@ -224,21 +329,26 @@ def refresh_batch_memos(changed):
     # Passes until nothing new becomes dirty: a memo may sit in the table BEFORE one it depends on (a key first made for an
     # earlier batch keeps its place when a later batch replaces its entry, while that batch's own geometry memos are appended
     # behind it), so one sweep in insertion order can recompute it from a source that is refreshed only afterwards.
-    seen = {}  # key -> the dirty sources it was last recomputed from
+    seen = {}  # (key, slot) -> the dirty sources it was last recomputed from
     progress = True
     while progress:
         progress = False
-        for key, (srcs, _, fn, outs) in list(_MEMO.items()):
+        for table, key, slot, e in _all_memo_entries():
+            srcs, outs = e[0], e[3]
             d = frozenset(id(t) for t in srcs if id(t) in dirty)
-            if not d or seen.get(key) == d:
+            if not d or seen.get((key, slot)) == d:
                 continue
-            new = fn(*srcs)
-            for o, n in zip(outs, new):
+            ne = _recompute_in_place(e[:4], key)
+            if ne is None:
+                raise RuntimeError("s2t_amd: the per-batch bookkeeping %r changed shape under a refresh" % (key,))
+            for o in outs:
                 if torch.is_tensor(o):
-                    o.copy_(n)
                     dirty.add(id(o))
-            _MEMO[key] = (srcs, tuple(t._version for t in srcs), fn, outs)
-            seen[key] = d
+            if slot is None:
+                _MEMO[key] = ne
+            else:
+                table[slot] = ne + tuple(e[4:])
+            seen[(key, slot)] = d
             progress = True
 
 
@@ -489,11 +599,41 @@ def _wg_dtype():
     return _WG_DTYPE
 
 
+def wgrad256_eligible(M, ldy, ldx, py=0, px=0):
+    """Operand layout rules of s2t_wgrad_grouped256 (LDS-DMA of 16-byte pieces, 32-bit byte offsets inside an operand)."""
+    return (_WG_256 and ldy % 8 == 0 and ldx % 8 == 0 and py % 16 == 0 and px % 16 == 0
+            and M * ldy * 2 < 2 ** 31 and M * ldx * 2 < 2 ** 31)
+
+
 def flush_wgrads():
-    """Run every queued weight gradient (called by the end-of-backward callback; safe to call with an empty queue)."""
-    import numpy as np
+    """Run every queued weight gradient (called by the end-of-backward callback; safe to call with an empty queue).
+    The queue is split by kernel: the problems that meet the operand layout rules of the 256 x 256 LDS-DMA kernel run on it in
+    one launch, the others (an unaligned leading dimension, an operand beyond 2 GiB) on the 128 x 128 register-staged kernel in a
+    second one — one odd problem no longer moves the whole backward pass to the slow kernel, or aborts a packed batch."""
     q, _WGQ["probs"] = _WGQ["probs"], []
     q = [e if len(e) == 11 else tuple(e) + (None,) for e in q]  # (dY, X, dW, Nout, Kin, M, ldy, ldx, alpha, db, packed geometry)
+    if not q:
+        return
+    ok = [wgrad256_eligible(M, ldy, ldx, dY.data_ptr(), X.data_ptr()) for (dY, X, _, _, _, M, ldy, ldx, _, _, _) in q]
+    if any(e[10] is not None and not k for e, k in zip(q, ok)):
+        # (S2TTransformerEncoder._packed_ok and the decoder's gate keep such shapes on padded rows: wgrad256_eligible)
+        raise RuntimeError("s2t_amd: a weight gradient over packed rows does not meet the operand layout rules of the 256 x 256 "
+                           "grouped kernel, the only one that reads the live row count on the device")
+    # tied weights (one dW, several problems) are chained inside ONE launch: a chain stays together, on the 128 x 128 kernel if
+    # any of its members needs it
+    slow_dw = {e[2].data_ptr() for e, k in zip(q, ok) if not k}
+    fast = [e for e, k in zip(q, ok) if k and e[2].data_ptr() not in slow_dw]
+    slow = [e for e, k in zip(q, ok) if not (k and e[2].data_ptr() not in slow_dw)]
+    if any(e[10] is not None for e in slow):
+        raise RuntimeError("s2t_amd: a packed weight gradient is tied to one that needs the 128 x 128 grouped kernel")
+    if fast:
+        _flush_wgrad_group(fast, True)
+    if slow:
+        _flush_wgrad_group(slow, False)
+
+
+def _flush_wgrad_group(q, big):
+    import numpy as np
     if q:
         dev = q[0][0].device
         probs = np.zeros(len(q), dtype=_wg_dtype())
@@ -501,11 +641,6 @@ def flush_wgrads():
         ws_floats = 0
         k_tail = False
         last_of = {}
-        # the LDS-DMA kernel on 256 x 256 tiles (s2t_wgrad_grouped256) when every problem meets its operand layout rules
-        big = _WG_256 and all(ldy % 8 == 0 and ldx % 8 == 0 and dY.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0
-                              and M * ldy * 2 < 2 ** 31 and M * ldx * 2 < 2 ** 31 for (dY, X, _, _, _, M, ldy, ldx, _, _, _) in q)
-        if not big and any(e[10] is not None for e in q):
-            raise RuntimeError("s2t_amd: a packed batch needs the 256 x 256 grouped weight-gradient kernel (operand layout rules)")
         TL, KS, per_item = (256, 32, _WG_KSTEPS256) if big else (128, 64, _WG_KSTEPS)
         if big and _WG_AUTO:
             # K-steps per work item chosen per launch: the items of a launch run in rounds of one workgroup per CU (128 KiB of
@@ -572,9 +707,9 @@ def flush_wgrads():
         if capturing:
             # a captured graph replays the host-to-device copy from ITS pinned block on every replay: take a block the
             # eager warm-up steps allocated (no allocation while capturing) and dedicate it to the graph
-            big = [sl for sl in ring["slots"] if sl[0].numel() >= nbytes]
-            if big:
-                slot = big[0]
+            fit = [sl for sl in ring["slots"] if sl[0].numel() >= nbytes]
+            if fit:
+                slot = fit[0]
                 ring["slots"].remove(slot)  # its last eager use has completed: capture() synchronises before capturing
             else:
                 slot = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=dev), None]
@@ -1163,9 +1298,13 @@ class AttentionFn(torch.autograd.Function):
                 scale = dk ** -0.5
             O = torch.empty(Mq, d, dtype=dt, device=dev)
             lse = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
+            # encoder-decoder attention in training: the rounding remainder of O rides along for the backward's delta (its score
+            # gradient cancels over a few hundred nearly uniform keys; csrc/attention_fused.hip, attn_bwd_dq_kernel)
+            O_lo = torch.empty(Mq, d, dtype=dt, device=dev) if (train and not self_attn and _ATTN_O_LO) else None
             K.attn_fused_fwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, Tq * d, d, lse, B, H, Tq, Tk, dk,
                              key_lens, causal, scale, p, d, prm["pos_u"].data.view(-1) if p is not None else None,
-                             prm["pos_v"].data.view(-1) if p is not None else None, drop_a, q_rows=qr, k_rows=kr)
+                             prm["pos_v"].data.view(-1) if p is not None else None, drop_a, q_rows=qr, k_rows=kr, o_lo=O_lo)
+            ctx.o_lo = O_lo
             y = torch.empty(Mq, d, dtype=dt, device=dev)
             if _rb_ok(O, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1)):
                 K.rowblock_gemm(O, cw(prm["o_w"]), y, N=d, ldc=d, bias=prm["o_b"].data, residual=residual,
@@ -1269,7 +1408,9 @@ class AttentionFn(torch.autograd.Function):
                          prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a,
                          dbd_band_only=rel, pos_pt=pt[0] if pt is not None else None, pt_ld=pt[1] if pt is not None else 0,
                          dpos_u=prm["pos_u"].grad.view(-1) if pt is not None else None,
-                         dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv, q_rows=qr, k_rows=kr)
+                         dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv, q_rows=qr, k_rows=kr,
+                         o_lo=getattr(ctx, "o_lo", None))
+        ctx.o_lo = None
         glue_done = False
         if rel and _RELPOS_GLUE and pt is None and dt == torch.bfloat16 and dk == 64 and Tq <= 256 and ldq % 4 == 0 and _arm_backward_end():
             # everything behind dbd in ONE pass over it (csrc/relpos_glue.hip): the (Q+v) branch added into dq, both bias
@@ -1534,6 +1675,7 @@ def project_positions(pos_tab, weights):
     return res
 
 
+_ATTN_O_LO = os.environ.get("S2T_ATTN_O_LO", "1") != "0"  # rounding remainder of the encoder-decoder attention output for delta
 _CROSS_KV = os.environ.get("S2T_CROSS_KV", "1") != "0"  # one k | v projection of the encoder memory for the whole decoder
 
 

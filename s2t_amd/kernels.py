@@ -763,24 +763,26 @@ def row_softmax_bwd(p, ldp, dp, lddp, dx, lddx, rows, V, inv_tau=1.0):
 
 
 def attn_fused_fwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, o_sb, o_sr, lse, B, H, Tq, Tk, dk, key_lens, causal, scale,
-                   pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None, q_rows=None, k_rows=None):
-    """``q_rows`` / ``k_rows``: lengths tensor of a packed batch on the query / key side (rows of utterance b from cu[b])."""
-    assert q.dtype == torch.bfloat16
+                   pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None, q_rows=None, k_rows=None, o_lo=None):
+    """``q_rows`` / ``k_rows``: lengths tensor of a packed batch on the query / key side (rows of utterance b from cu[b]).
+    ``o_lo``: optional bf16 buffer of o's layout for the rounding remainder of the output (read back by attn_fused_bwd)."""
+    assert q.dtype == torch.bfloat16 and (o_lo is None or (o_lo.dtype == torch.bfloat16 and o_lo.shape == o.shape))
     dp, ds, dsite = _drop3(drop)
     _call("s2t_attn_fused_fwd", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
           o_sb, o_sr, _ptr(lse), B, H, Tq, Tk, dk, _ptr(key_lens), int(causal), scale, _ptr(pos_p), p_sr, _ptr(pos_u),
-          _ptr(pos_v), dp, ds, dsite, _cu(q_rows), _cu(k_rows))
+          _ptr(pos_v), dp, ds, dsite, _cu(q_rows), _cu(k_rows), _ptr(o_lo))
 
 
 def attn_fused_bwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, dO, o_sb, o_sr, lse, delta, dq, dk, dv, dbd, ldb, B, H, Tq,
                    Tk, dkd, key_lens, causal, scale, pos_p=None, p_sr=0, pos_u=None, pos_v=None, drop=None, dbd_band_only=False,
-                   pos_pt=None, pt_ld=0, dpos_u=None, dpos_v=None, qv_out=None, q_rows=None, k_rows=None):
+                   pos_pt=None, pt_ld=0, dpos_u=None, dpos_v=None, qv_out=None, q_rows=None, k_rows=None, o_lo=None):
     """``pos_pt``: a VIEW starting at position n = 0 of the zero-padded transposed projections (see include/s2t_hip.h)."""
     dp, ds, dsite = _drop3(drop)
     _call("s2t_attn_fused_bwd", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
           dO.data_ptr(), o_sb, o_sr, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _ptr(dbd),
           ldb, B, H, Tq, Tk, dkd, _ptr(key_lens), int(causal), scale, _ptr(pos_p), p_sr, _ptr(pos_u), _ptr(pos_v), dp, ds,
-          dsite, int(dbd_band_only), _ptr(pos_pt), pt_ld, _ptr(dpos_u), _ptr(dpos_v), _ptr(qv_out), _cu(q_rows), _cu(k_rows))
+          dsite, int(dbd_band_only), _ptr(pos_pt), pt_ld, _ptr(dpos_u), _ptr(dpos_v), _ptr(qv_out), _cu(q_rows), _cu(k_rows),
+          _ptr(o_lo))
 
 
 def fbank(wave, n_samples, feat, max_frames, win, shift, nfft, window, mel_t, preemph=0.97, remove_dc=True,

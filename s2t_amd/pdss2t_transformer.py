@@ -153,7 +153,7 @@ class PDSS2TTransformerEncoder(nn.Module):
                 out.append(l)
             return tuple(out)
 
-        lens_memo = Fn.batch_memo(("pds_stage_lens", id(self)), (src_lengths,), stage_lens)
+        lens_memo = Fn.batch_memo(("pds_stage_lens", Fn.memo_owner(self)), (src_lengths,), stage_lens)
         packed_last = None
         for i in range(self.pds_stages):
             x, Tn, lens32 = getattr(self, f"downsampling{i + 1}")(x, B, Tn, lens32)
@@ -162,10 +162,14 @@ class PDSS2TTransformerEncoder(nn.Module):
             # down-sampling convolution in front of the next stage reads padded rows again (zero padded frames: what its own
             # input mask makes of them, pdss2t_transformer.py:1100-1117)
             # (relative positions: the backward behind the skewed score gradient is s2t_relpos_glue, which holds up to 256 frames)
-            pk = (Rows.ENABLED and dt == torch.bfloat16 and d == 256 and self.pds_attn_heads[i] * 64 == d and B * Tn >= 4096
-                  and Tn <= 65535 and not self.fusion_stages and (self.attn_type != "rel_pos" or Tn <= 256 or not torch.is_grad_enabled()))
+            pk = (Rows.ENABLED and dt == torch.bfloat16 and d == 256 and self.pds_attn_heads[i] * 64 == d and B * Tn >= Rows.MIN_ENC_ROWS
+                  and Tn <= 65535 and not self.fusion_stages and (self.attn_type != "rel_pos" or Tn <= 256 or not torch.is_grad_enabled())
+                  # (weight gradients over packed rows: the 256 x 256 grouped kernel's operand rules, S2TTransformerEncoder._packed_ok)
+                  and (not torch.is_grad_enabled() or Fn.wgrad256_eligible(
+                      B * Tn, max(d * self.pds_ffn_ratios[i], 3 * d,
+                                  Fn._pad8(self.ctc.ctc_projection.weight.shape[0]) if (i + 1 == self.pds_stages and getattr(self, "use_ctc", False)) else 0), d)))
             if pk:
-                lens32 = Rows.attach(lens_memo[i], B, Tn, self._halo, tag=("pds", id(self), i))
+                lens32 = Rows.attach(lens_memo[i], B, Tn, self._halo, tag=("pds", Fn.memo_owner(self), i))
                 x = Rows.pack(x, lens32)
             c = Ctx(B, Tn, lens32, dt)
             if self.pds_position_embed[i]:

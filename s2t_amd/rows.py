@@ -21,6 +21,10 @@ from . import kernels as K
 
 # S2T_PACKED=0 keeps the padded layout everywhere (A/B measurements; the fp32 parity mode always does)
 ENABLED = os.environ.get("S2T_PACKED", "1") != "0"
+# Row counts from which a batch runs packed: below them the row-block kernels leave most of the chip idle either way and the
+# geometry launch is not paid back.  Module attributes so that a test can run the packed kernels on an oracle-sized batch.
+MIN_ENC_ROWS = int(os.environ.get("S2T_PACKED_MIN_ENC_ROWS", "4096"))  # B * T' of an encoder (or PDS stage)
+MIN_DEC_ROWS = int(os.environ.get("S2T_PACKED_MIN_DEC_ROWS", "2048"))  # B * U target rows of a decoder
 
 
 class PackedRows:
@@ -35,7 +39,7 @@ class PackedRows:
         self.M = self.B * self.T
         # ``tag`` names the user of the geometry (an encoder, a decoder, a PDS stage): its memo entry is then REPLACED when the next
         # batch object comes along (an entry per lengths tensor would grow without bound over an eager epoch)
-        self.cu, self.buf = Fn.batch_memo(("packed_rows", tag if tag is not None else id(lens32), self.B, self.T, self.halo),
+        self.cu, self.buf = Fn.batch_memo(("packed_rows", tag if tag is not None else Fn.memo_owner(lens32), self.B, self.T, self.halo),
                                           (lens32,), self._build)
         self.map_ptr = self.buf.data_ptr() + 4 * self.HEADER
 

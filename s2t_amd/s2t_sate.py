@@ -206,7 +206,10 @@ class TextualEncoder(nn.Module):
             if L in self.inter_xctc_layers:
                 norm = self.layer_norm if self.share_inter_xctc_norm else getattr(self, "xctc_norm%d" % L)
                 norm_x = norm(x)
-                logit2d = self.xctc(norm_x, out_dtype=self.ctc_out_dtype if self.xctc_pae.adapter_type == "none" else None)
+                # (an intermediate head that feeds PAE emits compute-dtype logits, as in training — unless a decoder reads the
+                # intermediate heads: CTCDecoder(--ctc-inter-logit) sets ``decode_inter_logits`` and they follow ctc_out_dtype)
+                logit2d = self.xctc(norm_x, out_dtype=self.ctc_out_dtype if (self.xctc_pae.adapter_type == "none" or getattr(
+                    self, "decode_inter_logits", False)) else None)
                 il = logit2d.view(B, T, -1).transpose(0, 1)
                 inter_logit = il
                 orc = msk = None

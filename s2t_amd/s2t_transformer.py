@@ -168,7 +168,15 @@ class S2TTransformerEncoder(nn.Module):
             return False
         if self.attn_type == "rel_pos" and Tp > 256 and torch.is_grad_enabled():
             return False  # the relative-position BACKWARD behind the skewed score gradient (s2t_relpos_glue) holds 256 frames
-        return B * Tp >= 4096 and Tp <= 65535
+        if torch.is_grad_enabled():
+            # weight gradients over packed rows exist on the 256 x 256 grouped kernel only (it reads the live row count on the
+            # device): its operand rules must hold for the widest operands of this stack — the feed-forward hidden activation and
+            # the CTC logits — or the batch stays padded (S2T_WG_256=0, a vocabulary beyond 2 GiB of logits)
+            widest = max(int(self.args.encoder_ffn_embed_dim), 3 * d,
+                         Fn._pad8(self.ctc.ctc_projection.weight.shape[0]) if self.use_ctc else 0)
+            if not Fn.wgrad256_eligible(B * Tp, widest, d):
+                return False
+        return B * Tp >= Rows.MIN_ENC_ROWS and Tp <= 65535
 
     # -- forward -------------------------------------------------------------------------------------
     def forward(self, src_tokens, src_lengths=None, **kwargs):
@@ -186,12 +194,12 @@ class S2TTransformerEncoder(nn.Module):
             ln = self.subsample.get_out_seq_lens_tensor(sl)
             return ln, ln.to(torch.int32), torch.arange(Tp, device=sl.device)[None, :] >= ln[:, None]
 
-        lens, lens32, encoder_padding_mask = Fn.batch_memo(("enc_lens", id(self), Tp), (src_lengths,), length_bookkeeping)
+        lens, lens32, encoder_padding_mask = Fn.batch_memo(("enc_lens", Fn.memo_owner(self), Tp), (src_lengths,), length_bookkeeping)
         x = self.subsample(src_tokens, Rows.detached(lens32), dt)  # [B*T', d], padded frames zeroed (:1765)
         if self._packed_ok(dt, B, Tp):
             # Packed rows (s2t_amd/rows.py): from here to the end of the encoder only the frames (and the conv module's halo
             # rows) are computed; the buffers keep their B * T' rows.  ``lens32`` carries the geometry to every launch.
-            lens32 = Rows.attach(lens32, B, Tp, self._halo, tag=("enc", id(self)))
+            lens32 = Rows.attach(lens32, B, Tp, self._halo, tag=("enc", Fn.memo_owner(self)))
             x = Rows.pack(x, lens32)
         else:
             lens32 = Rows.detached(lens32)
@@ -239,8 +247,10 @@ class S2TTransformerEncoder(nn.Module):
                 pae = self.pae if self.share_inter_ctc else getattr(self, "pae%d" % L)
                 norm_x = norm(x)
                 # (an INTERMEDIATE head's logits feed the PAE softmax and the training losses: compute dtype, as in training;
-                # ctc_out_dtype = fp32 is for the logits that are decoded)
-                logit2d = head(norm_x, out_dtype=self.ctc_out_dtype if pae.adapter_type == "none" else None)
+                # ctc_out_dtype = fp32 is for the logits that are decoded — CTCDecoder(--ctc-inter-logit k) decodes from an
+                # intermediate head and sets ``decode_inter_logits``: they then follow ctc_out_dtype)
+                logit2d = head(norm_x, out_dtype=self.ctc_out_dtype if (pae.adapter_type == "none" or getattr(
+                    self, "decode_inter_logits", False)) else None)
                 il = logit2d.view(B, Tp, -1).transpose(0, 1)
                 inter_logit = [il, encoder_padding_mask]  # the reference's [logit, padding mask] pairs
                 orc = msk = None
@@ -307,7 +317,10 @@ class S2TTransformerEncoder(nn.Module):
         reference synchronises on ``max(keep_flag.sum(0))`` as well).  ``compression_bounded`` (set by Trainer.capture, implied
         while a stream is capturing): no host copy, T stays the bound."""
         src, new_lens = Fn.ctc_compress_plan(logit2d.detach(), lens32, B, T, 0, self.compression_thresholds[L])
-        if getattr(self, "compression_bounded", False) or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+        # (``compression_bounded``: True = always; "train" = the captured TRAINING step's form, set by Trainer.capture and cleared
+        # by release_trainer — eval and generation on the same model keep the exact form and the reference's shapes)
+        cb = getattr(self, "compression_bounded", False)
+        if cb is True or (cb == "train" and self.training) or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
             # Capturable form: the frame axis keeps its uncompressed BOUND T and only the lengths change, on the device.  The
             # reference's two host decisions (:1996-2001: compress only when no utterance would become empty and something is
             # dropped) select between the plan and the identity with device-side flags.  Outputs equal the exact form's on the
@@ -428,19 +441,22 @@ class TransformerDecoderScriptable(nn.Module):
             # (pads in the middle) would need a mask tensor, the collater never produces them
             return tok.contiguous(), pos.contiguous(), nonpad.sum(1).to(torch.int32)
 
-        tok, pos, self_lens = Fn.batch_memo(("dec_tokens", id(self)), (prev_output_tokens,), token_bookkeeping)
+        tok, pos, self_lens = Fn.batch_memo(("dec_tokens", Fn.memo_owner(self)), (prev_output_tokens,), token_bookkeeping)
         tab = TABLES.get("sin", self.max_positions() + self.padding_idx + 1, d, dev)
         x = Fn.embedding(tok, pos, self.embed_tokens.weight, tab, self.embed_scale, self.padding_idx)
         x = Fn.dropout(x, float(self.args.dropout or 0.0), self.training)  # dropout_module (transformer.py:1328)
         # Packed target rows: the collater left-aligns the targets and pads them to the longest of the batch
         # (data/audio/speech_to_text_dataset.py:445-470); no decoder module looks across a target's end, so there is no halo.
         dec_rows = None
+        widest = max(int(self.args.decoder_ffn_embed_dim), 3 * d, Fn._pad8(self.output_projection.weight.shape[0]))
         if (Rows.ENABLED and x.dtype == torch.bfloat16 and d == 256 and self.layers[0].self_attn.num_heads * 64 == d
-                and B * U >= 2048 and U <= 65535):
-            dec_rows = self_lens = Rows.attach(self_lens, B, U, 0, tag=("dec", id(self)))
+                and B * U >= Rows.MIN_DEC_ROWS and U <= 65535
+                and (not torch.is_grad_enabled() or Fn.wgrad256_eligible(B * U, widest, d))):  # (see _packed_ok)
+            dec_rows = self_lens = Rows.attach(self_lens, B, U, 0, tag=("dec", Fn.memo_owner(self)))
             x = Rows.pack(x, dec_rows)
         pk = encoder_out.get("packed")
-        if pk is not None and pk["B"] == B and Fn._use_fused_attention(pk["encoder_out"].dtype, d // self.layers[0].encoder_attn.num_heads):
+        if (pk is not None and pk["B"] == B and Fn._use_fused_attention(pk["encoder_out"].dtype, d // self.layers[0].encoder_attn.num_heads)
+                and (not torch.is_grad_enabled() or Fn.wgrad256_eligible(B * pk["T"], 2 * d * len(self.layers), d))):
             # the encoder's packed rows (s2t_amd/rows.py) are the memory as they are: the key side of every encoder-decoder
             # attention reads utterance b's frames from row cu[b]
             mem, Tm, mem_lens = pk["encoder_out"], pk["T"], pk["rows"]
@@ -448,7 +464,7 @@ class TransformerDecoderScriptable(nn.Module):
             mem_tbc = encoder_out["encoder_out"][0]
             Tm = mem_tbc.shape[0]
             mem = mem_tbc.transpose(0, 1).contiguous().view(B * Tm, d)
-            (mem_lens,) = Fn.batch_memo(("dec_mem_lens", id(self)), (encoder_out["encoder_padding_mask"][0],),
+            (mem_lens,) = Fn.batch_memo(("dec_mem_lens", Fn.memo_owner(self)), (encoder_out["encoder_padding_mask"][0],),
                                         lambda m: ((~m).sum(1).to(torch.int32),))
         # reference (:1340-1342): pad KEYS are masked for every query; pad queries still attend
         # k | v of the encoder memory for all layers' encoder-decoder attention in one projection (Fn.cross_kv)
@@ -654,6 +670,9 @@ class _HipModel(model_base()):
         """The bundled Trainer no longer updates this model (it set ``shadow_managed``): back to refreshing the shadow here."""
         self.shadow_managed = False
         self._shadow_dirty = True
+        for mod in self.modules():  # the captured step's bounded compression form (Trainer.capture)
+            if getattr(mod, "compression_bounded", False) == "train":
+                mod.compression_bounded = False
 
     def train(self, mode=True):
         self._shadow_dirty = True  # whoever trained may have stepped the masters since the last forward
@@ -773,13 +792,29 @@ class CTCDecoder:
             raise NotImplementedError("--ctc-self-ensemble (the reference's branch refers to an undefined name, s2t_ctc.py:316)")
         if int(getattr(args, "beam", 1) or 1) > 1 and getattr(args, "ctc_infer", "greedy") == "beam":
             raise NotImplementedError("CTC beam decoding (third-party ctcdecode in the reference)")
+        # hypothesis["score"] of the reference sums the top-1 log-probability of every frame whose unmasked arg-max is not the
+        # blank, PADDED frames included (s2t_ctc.py:327-329).  Packed rows (s2t_amd/rows.py) hold no padded frames: token ids are
+        # the reference's, the score lacks the padded frames' (input-independent) term.  ``exact_scores`` = True decodes on the
+        # padded layout, whose scores are the reference's (--ctc-exact-scores / S2T_CTC_EXACT_SCORES=1).
+        import os
+        self.exact_scores = bool(getattr(args, "ctc_exact_scores", False)) or os.environ.get("S2T_CTC_EXACT_SCORES", "0") == "1"
 
     @torch.no_grad()
     def generate(self, models, sample, **kwargs):
         from . import kernels as K
 
         net_input = sample["net_input"]
-        enc = self.model(src_tokens=net_input["src_tokens"], src_lengths=net_input["src_lengths"])
+        if self.ctc_inter_logit != 0:  # the intermediate heads are decoded: they emit ctc_out_dtype (fp32 for bit-exact ids)
+            for mod in self.model.modules():
+                if hasattr(mod, "inter_ctc_layers") or hasattr(mod, "inter_xctc_layers"):
+                    mod.decode_inter_logits = True
+        was = Rows.ENABLED
+        if self.exact_scores:
+            Rows.ENABLED = False  # padded layout: the padded frames' logits exist and enter the score as in the reference
+        try:
+            enc = self.model(src_tokens=net_input["src_tokens"], src_lengths=net_input["src_lengths"])
+        finally:
+            Rows.ENABLED = was
         has_x = len(enc.get("xctc_logit", [])) > 0
         pk = enc.get("packed")
         if pk is not None and not has_x and self.ctc_inter_logit == 0 and pk.get("ctc_logit") is not None:

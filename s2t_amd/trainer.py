@@ -115,9 +115,9 @@ class Trainer:
         if sample_size_global is None:
             sample_size_global = self.world * sample["ntokens"]
         self._static = sample
-        for mod in self.model.modules():  # CTC-guided compression keeps its frame axis at the bound from here on (no host copy)
-            if hasattr(mod, "compression_layers"):
-                mod.compression_bounded = True
+        for mod in self.model.modules():  # CTC-guided compression: training passes keep the frame axis at its bound from here
+            if hasattr(mod, "compression_layers") and getattr(mod, "compression_bounded", False) is not True:  # on (no host copy)
+                mod.compression_bounded = "train"
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -127,10 +127,15 @@ class Trainer:
                 self.num_updates += 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        # the grouped weight-gradient tables of the captured step: one pinned/device block per flush (a data-parallel step
-        # flushes once per gradient stage)
-        Fn.reserve_wgrad_staging(self.flat.master.device, count=8 if self.ddp is not None else 1)
+        # the grouped weight-gradient tables of the captured step: one pinned/device block per launch (a data-parallel step
+        # flushes once per gradient stage; a flush is two launches when some problem needs the 128 x 128 kernel)
+        Fn.reserve_wgrad_staging(self.flat.master.device, count=16 if self.ddp is not None else 2)
         Fn.pin_buffers_for_graph()
+        # the per-batch bookkeeping of THIS batch object (lengths, masks, positions, packed-row geometry: functional.batch_memo)
+        # lives outside the graph, which bakes its addresses in: from here on an eager pass over another batch may not replace or
+        # release those tensors (it gets entries of its own), load_batch refreshes them in place
+        Fn.unpin_batch_memos(id(self))
+        Fn.pin_batch_memos(list(self._tensors(sample)), id(self))
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         self._ssg = sample_size_global
@@ -155,6 +160,30 @@ class Trainer:
             with torch.cuda.graph(self._graph):
                 self._graph_out = self._step_body(sample)
 
+    @staticmethod
+    def _tensors(dct):
+        for v in dct.values():
+            if isinstance(v, dict):
+                yield from Trainer._tensors(v)
+            elif torch.is_tensor(v):
+                yield v
+
+    def release(self):
+        """Drop the captured step: its graphs, the pins on the per-batch bookkeeping it read, the bounded compression form;
+        the model goes back to refreshing its bf16 shadow itself (``release_trainer``)."""
+        self._graph = self._graph2 = None
+        self._graph_out = None
+        self._static = None
+        Fn.unpin_batch_memos(id(self))
+        if hasattr(self.model, "release_trainer"):
+            self.model.release_trainer()
+
+    def __del__(self):
+        try:
+            Fn.unpin_batch_memos(id(self))
+        except Exception:  # noqa: BLE001 — interpreter shutdown
+            pass
+
     def load_batch(self, sample):
         """Copy a batch of the captured shapes into the static one the graph reads (tensors by key, recursively), then
         redo the per-batch bookkeeping that lives outside the graph (functional.batch_memo)."""
@@ -167,16 +196,8 @@ class Trainer:
                         raise ValueError(f"batch field {k}: shape {tuple(v.shape)} differs from the captured {tuple(dst[k].shape)}")
                     dst[k].copy_(v, non_blocking=True)
         fill(self._static, sample)
-
-        def tensors(dct):
-            for v in dct.values():
-                if isinstance(v, dict):
-                    yield from tensors(v)
-                elif torch.is_tensor(v):
-                    yield v
-
         # lengths / positions / target matrices derived from the batch, recomputed in place
-        Fn.refresh_batch_memos(list(tensors(self._static)))
+        Fn.refresh_batch_memos(list(self._tensors(self._static)))
 
     def replay(self, sample=None, sample_size_global=None):
         """One captured update; ``sample`` (same shapes as the captured batch) is copied into the static batch first."""

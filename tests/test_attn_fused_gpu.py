@@ -496,3 +496,53 @@ def test_strides_beyond_the_24_bit_products_are_refused():
     K.attn_fused_fwd(qs, T * 64, 64, qs, T * 64, 64, qs, T * 64, 64, o, T * 64, 64, lse, B, H, T, T, dk, None, False, 0.125)
     torch.cuda.synchronize()
     assert torch.isfinite(o.float()).all()
+
+
+def test_position_offsets_beyond_32_bits_are_refused():
+    """Relative positions: row n of the projected table runs to 2 Tq - 2 and its offset n * p_sr is a 24-bit product kept in 32
+    bits; a (length, stride) pair whose product leaves 32 bits is refused instead of wrapping."""
+    B, H, T, dk = 1, 1, 40000, 64
+    t = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)  # never read: the call must fail on its arguments
+    lse = torch.empty(64, device=DEV)
+    u = torch.zeros(64, device=DEV)
+    with pytest.raises(RuntimeError, match="s2t_attn_fused_fwd"):
+        K.attn_fused_fwd(t, T * 64, 64, t, T * 64, 64, t, T * 64, 64, t, T * 64, 64, lse, B, H, T, T, dk, None, False, 0.125,
+                         t, 65528, u, u, None)
+
+
+def test_an_utterance_without_rows_in_a_packed_batch():
+    """cu[b] == cu[b + 1]: the utterance's workgroups read and store nothing (the clamped tile rows must not go to -1), the
+    other utterances' outputs are those of the same batch without it.  Plain and relative-position self-attention forward."""
+    from s2t_amd import rows as Rows
+
+    H, dk, T = 4, 64, 96
+    d = H * dk
+    live = [96, 50]
+
+    def run(lens, rel):
+        B = len(lens)
+        lt = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        Rows.attach(lt, B, T, 0)
+        M = B * T
+        g = torch.Generator(device="cpu").manual_seed(3)
+        qkv = torch.randn(sum(live), 3 * d, generator=g).bfloat16()
+        buf = torch.zeros(M, 3 * d, dtype=torch.bfloat16)
+        buf[:sum(live)] = qkv
+        buf = buf.to(DEV)
+        O = torch.full((M, d), 7.0, dtype=torch.bfloat16, device=DEV)
+        lse = torch.zeros(B * H, T, dtype=torch.float32, device=DEV)
+        pos = u = v = None
+        if rel:
+            pos = torch.randn(2 * T - 1, d, generator=g).bfloat16().to(DEV)
+            u = torch.randn(d, generator=g).to(DEV)
+            v = torch.randn(d, generator=g).to(DEV)
+        K.attn_fused_fwd(buf, T * 3 * d, 3 * d, buf[:, d:], T * 3 * d, 3 * d, buf[:, 2 * d:], T * 3 * d, 3 * d, O, T * d, d, lse,
+                         B, H, T, T, dk, lt, False, 0.125, pos, d if rel else 0, u, v, None, q_rows=lt, k_rows=lt)
+        torch.cuda.synchronize()
+        return O[:sum(live)].clone(), O[sum(live):]
+
+    for rel in (False, True):
+        oa, rest_a = run([96, 0, 50], rel)
+        ob, _ = run([96, 50], rel)
+        assert torch.equal(oa, ob), rel
+        assert bool((rest_a.float() == 7.0).all()), rel  # nothing stored beyond the live rows

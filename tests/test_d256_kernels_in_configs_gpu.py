@@ -201,6 +201,76 @@ def test_config5a_literal_batch_256_properties():
     assert base == _greedy(model, padded, lens)
 
 
+def test_config3_literal_batch_64x2000_properties():
+    """BASELINE.json configuration 3 at its literal size: the recipe's 4-stage PDS Conformer (3 layers per stage, ratios 2-2-1-2,
+    d = 256; models/speech_to_text/pdss2t_transformer.py:1042-1281), 64 utterances of 2000 frames (stage lengths 1004 / 502 /
+    502 / 251), bf16 with fp32 CTC logits, where the CPU oracle is too slow to be the checker (the same model runs against it at
+    4 x 2000 in fp32, test_configs_fullsize_gpu.py, and at 4 x 1000 in bf16 above).  Size-independent properties of the reference:
+      * utterances are independent in eval mode: permuting the batch permutes encoder output, CTC logits and greedy ids BIT
+        FOR BIT (the stages run packed in eval: an utterance then sits at another row offset, its arithmetic does not move);
+      * extra zero padding behind every utterance changes no greedy id (one workgroup per fused-FFN row block pinned: bit
+        equality across ROW COUNTS is a property of one summation order, test_fullsize_properties_gpu.py);
+      * one training pass: finite loss and gradients, every parameter receives a gradient, and the summed eval loss is additive
+        over utterances."""
+    from s2t_amd import kernels as K
+
+    B, T = 64, 2000
+    torch.manual_seed(1)
+    a = M.recipe_args(conformer=True, vocab_size=V, arch="pdss2t_transformer_s_8", pds_stages=4, pds_layers="3_3_3_3",
+                      pds_ratios="2_2_1_2", pds_fusion=False, pds_embed_dims="256_256_256_256", pds_ds_method="conv",
+                      pds_embed_norm=True, pds_position_embed="1_1_1_1", pds_kernel_sizes="5_5_5_5", pds_ffn_ratios="8_8_8_8",
+                      pds_attn_heads="4_4_4_4")
+    model = PDS.PDSS2TTransformerModel.build_model(a, M.FakeTask(V)).prepare(torch.bfloat16, DEV)
+    model.encoder.ctc_out_dtype = torch.float32
+    model.eval()
+    sample = bench.synthetic_batch(B, T, V, 23, torch.device(DEV))[0]
+    ni = sample["net_input"]
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        e0 = model.encoder(ni["src_tokens"], ni["src_lengths"])
+        e1 = model.encoder(ni["src_tokens"][perm].contiguous(), ni["src_lengths"][perm].contiguous())
+        assert e0["encoder_out"][0].shape[0] == 251
+        assert torch.equal(e0["encoder_out"][0][:, perm], e1["encoder_out"][0])
+        assert torch.equal(e0["ctc_logit"][0][:, perm], e1["ctc_logit"][0])
+    del e0, e1
+    ids = _greedy(model, ni["src_tokens"], ni["src_lengths"])
+    assert sum(len(x) for x in ids) > 0
+    ids_p = _greedy(model, ni["src_tokens"][perm].contiguous(), ni["src_lengths"][perm].contiguous())
+    assert [ids[i] for i in perm.tolist()] == ids_p
+    _, old, _ = K.ffn_configure()
+    K.ffn_configure(split=1)
+    try:
+        src = ni["src_tokens"].clone()
+        lens = ni["src_lengths"].clamp(max=T - 64)
+        for b in range(B):
+            src[b, int(lens[b]):] = 0
+        base = _greedy(model, src, lens)
+        padded = torch.zeros(B, T + 40, 80, device=DEV)
+        padded[:, :T] = src
+        assert base == _greedy(model, padded, lens)
+        del padded, src
+    finally:
+        K.ffn_configure(split=old)
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    with torch.no_grad():
+        full = float(crit(model, sample)[0])
+        parts = 0.0
+        for i in range(0, B, 16):
+            sub = {"net_input": {k: v[i:i + 16].contiguous() for k, v in ni.items()},
+                   "target": sample["target"][i:i + 16].contiguous(), "ntokens": 1}
+            parts += float(crit(model, sub)[0])
+    assert abs(full - parts) <= 2e-3 * abs(full), (full, parts)
+    model.train()
+    model.flat.zero_grad()
+    loss = crit(model, sample)[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and bool(torch.isfinite(model.flat.grad).all())
+    dead = [k for k, p in model.named_parameters() if float(p.grad.abs().max()) == 0.0
+            and not k.endswith(("k_proj.bias", "linear_k.bias"))]  # (the key bias cancels in the softmax: mathematically zero)
+    assert not dead, dead
+
+
 def test_transformer_d256_bf16_inter_ctc_tap_layernorm_handover_on_off():
     """S2T_FUSE_LN_DROP hands dropout(dx) of a LayerNorm backward to the block in front.  With an intermediate-CTC head
     tapping a layer output (egs/mustc/asr/conf/inter.yaml; models/speech_to_text/s2t_transformer.py:1881-1946) that output

@@ -138,3 +138,116 @@ def test_nast_training_step_captures_into_a_hipgraph():
     torch.cuda.synchronize()
     assert all(np.isfinite(losses)), losses
     assert min(losses[-3:]) < first, (first, losses)
+
+
+def test_nast_recipe_width_d512_h8_bf16_against_oracle_on_rounded_weights():
+    """Configuration 5b at the recipe's WIDTH (egs/mustc/st/conf/reproduction_nast.yaml:39-44: d = 512, 8 heads, F = 2048,
+    subsampling filter 2048, V = 10 000) with 2 + 2 layers: Conformer acoustic layers, textual layers with the cross-layer
+    attention (modules/transformer_s2_layer.py:214-336), shared intermediate CTC / XCTC heads with prediction-aware encoding
+    (s2t_sate.py:692-808), in bf16 against the fp32 oracle evaluated on the SAME bf16-rounded weights and inputs.  The kernels the
+    d = 512 stack runs — the 256 x 256 LDS-DMA GEMM for every Linear (forced: the batch is oracle sized), ln512_fwd / _bwd, the
+    register-resident PAE softmax, the fused attention with eight heads of 64 — are the ones compared.  Eval: every logit family;
+    training (dropout 0, no ground-truth curriculum: deterministic): the four loss terms and every parameter gradient."""
+    from s2t_amd import kernels as K
+
+    Vn = 10000
+    task = M.FakeTask(Vn)
+    nast = dict(encoder_type="sate", text_encoder_layers=2, acoustic_encoder="transformer", adapter="inter_league",
+                xctc_weight=1.0, ctc_weight=1.0, share_ctc_and_embed=True, share_xctc_and_embed=True, text_no_pos_emb=True,
+                textual_encoder_embed_norm=False, textual_encoder_no_scale_embedding=True, encoder_normalize_before=True,
+                share_inter_ctc=True, inter_ctc_weight=1.0, inter_ctc_layers="1", inter_xctc_weight=1.0, inter_xctc_layers="1",
+                ctc_pae="inter_league", xctc_pae="inter_league", xctc_cross_attn=True, cross_attn_start_layer=2,
+                cross_attn_layer=1, cross_attn_collaboration_mode="serial", cross_attn_league_drop_net=False,
+                encoder_embed_dim=512, encoder_ffn_embed_dim=2048, encoder_attention_heads=8, encoder_layers=2,
+                subsampling_filter=2048, activation_fn="relu", arch="s2t_ctc")
+    a = M.recipe_args(conformer=True, vocab_size=Vn, **nast)
+    torch.manual_seed(5)
+    model = M.S2TCTCModel.build_model(a, task)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            p.copy_(p.bfloat16().float())
+        for n_, b in model.named_buffers():
+            if n_.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            if n_.endswith("running_var"):
+                b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g))
+    W = {k: v.detach().clone().float().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = {k: getattr(a, k) for k in vars(a)}
+    model.prepare(torch.bfloat16, DEV)
+    B, T = 8, 600
+    lens = sorted([T] + [int(torch.randint(int(0.6 * T), T + 1, (1,), generator=g)) for _ in range(B - 1)], reverse=True)
+    src = torch.randn(B, T, 80, generator=g)
+    for b, l in enumerate(lens):
+        src[b, l:] = 0
+    src = src.bfloat16().float()
+    lens = torch.tensor(lens)
+    U = 24
+    target = torch.full((B, U), 1, dtype=torch.long)
+    for b in range(B):
+        u = int(torch.randint(12, U - 1, (1,), generator=g))
+        target[b, :u] = torch.randint(4, Vn, (u,), generator=g)
+        target[b, u] = 2
+    old_mode = K.gemm_configure()
+    K.gemm_configure(2)  # the large tiles whenever the arguments allow (the dispatcher's own rule needs >= 150 tiles)
+    try:
+        model.eval()
+        with torch.no_grad():
+            enc = model.encoder(src.to(DEV), lens.to(DEV))
+            with torch.no_grad():
+                enc_o = O.sate_encoder_forward(src, lens, {k: v.detach() for k, v in W.items()}, cfg, training=False)
+        olen = [((int(l) - 1) // 2 + 1 - 1) // 2 + 1 for l in lens]
+        fm = torch.zeros(enc_o["encoder_out"][0].shape[:2], dtype=torch.bool)
+        for b, n in enumerate(olen):
+            fm[:n, b] = True
+
+        def rel_on(got, ref):
+            got = (got[0] if isinstance(got, (list, tuple)) else got).detach().float().cpu()
+            ref = ref[0] if isinstance(ref, (list, tuple)) else ref
+            return float((got - ref)[fm].abs().max() / ref[fm].abs().max().clamp_min(1e-6))
+
+        ev = {"encoder_out": rel_on(enc["encoder_out"][0], enc_o["encoder_out"][0]),
+              "ctc_logit": rel_on(enc["ctc_logit"][0], enc_o["ctc_logit"][0]),
+              "xctc_logit": rel_on(enc["xctc_logit"][0], enc_o["xctc_logit"][0]),
+              "inter_ctc": rel_on(enc["inter_ctc_logits"][0], enc_o["inter_ctc_logits"][0]),
+              "inter_xctc": rel_on(enc["inter_xctc_logits"][0], enc_o["inter_xctc_logits"][0])}
+        print("NAST d512 bf16 eval vs oracle on rounded weights:", {k: round(v, 4) for k, v in ev.items()})
+        assert max(ev.values()) < 4e-2, ev
+        model.train()
+        crit = C.CtcCriterion(None, task, ctc_weight=1.0, inter_ctc_weight=1.0, xctc_weight=1.0, inter_xctc_weight=1.0)
+        crit.train()
+        sample = {"net_input": {"src_tokens": src.to(DEV), "src_lengths": lens.to(DEV),
+                                "prev_output_tokens": torch.roll(target, 1, 1).to(DEV)},
+                  "target": target.to(DEV), "transcript": {"tokens": target.to(DEV)}, "ntokens": int((target > 2).sum() + B)}
+        model.flat.zero_grad()
+        loss, _, log = crit(model, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        K.gemm_configure(old_mode)
+    loss_o, log_o, _ = O.ctc_criterion_loss(W, cfg, src, lens, target, transcript=target, training=True)
+    loss_o.backward()
+    for k in ("ctc_loss", "inter_ctc_loss", "xctc_loss", "inter_xctc_loss"):
+        ref = float(log_o[k])
+        assert abs(float(log[k]) - ref) <= 1e-2 * abs(ref), (k, float(log[k]), ref)
+    ptr = {k: v.data_ptr() for k, v in model.state_dict().items()}
+    errs = {}
+    for k, p in model.named_parameters():
+        if k.endswith(("k_proj.bias", "linear_k.bias")):
+            continue  # mathematically zero
+        gs = [W[k2].grad for k2 in W if ptr[k2] == ptr[k] and W[k2].grad is not None]
+        if not gs:
+            assert float(p.grad.abs().max()) == 0.0, k  # a parameter the reference never reaches (the unused s2_norm)
+            continue
+        go = sum(gs)
+        if "subsample" in k and go.dim() == 3:
+            go = go.permute(0, 2, 1)
+        gf = p.grad.detach().float().cpu()
+        errs[k] = float((gf - go.reshape(gf.shape)).norm() / go.norm().clamp_min(1e-6))
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    med = float(np.median(list(errs.values())))
+    print("NAST d512 bf16 gradients vs oracle: worst %s %.4f, median %.4f over %d tensors" % (worst[0], worst[1], med, len(errs)))
+    assert len(errs) > 60
+    assert worst[1] < 2.5e-1 and med < 5e-2, (worst, med)

@@ -104,6 +104,26 @@ def test_row_map_and_round_trip():
     assert float(xp[halo_rows].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B", [1, 1023, 1024])
+def test_row_geometry_at_the_largest_batch_of_the_one_launch_form(B):
+    """s2t_rows_geometry serves up to 1024 utterances with one 1024-thread workgroup scan: cu[B] (the live row count, which
+    bounds the LAST utterance for every per-utterance kernel) has no thread of its own when B = 1024."""
+    T, halo = 9, 2
+    g_ = torch.Generator().manual_seed(B)
+    lens = torch.randint(1, T + 1, (B,), generator=g_).to(torch.int32)
+    cu = torch.full((B + 1,), -7, dtype=torch.int32, device=DEV)  # poisoned: an unwritten entry shows
+    buf = torch.full((Rows.PackedRows.HEADER + B * T,), -7, dtype=torch.int32, device=DEV)
+    K.rows_geometry(lens.to(DEV), B, T, halo, cu, buf)
+    cap = [min(l + halo, T) for l in lens.tolist()]
+    assert cu.tolist() == [0] + list(np.cumsum(cap))
+    assert int(buf[Rows.PackedRows.HEADER - 1]) == sum(cap)
+    m = buf[Rows.PackedRows.HEADER:].tolist()
+    exp = []
+    for b, (l, c) in enumerate(zip(lens.tolist(), cap)):
+        exp += [((b << 16) | t) if t < l else -1 for t in range(c)]
+    assert m[:len(exp)] == exp and all(v == -1 for v in m[len(exp):])
+
+
 @pytest.mark.parametrize("conformer", [True, False])
 @pytest.mark.parametrize("split", [1, 0])
 def test_eval_outputs_equal_the_padded_layout(conformer, split):
@@ -272,14 +292,30 @@ def test_config5a_greedy_ids_equal_the_padded_layout():
     model.encoder.ctc_out_dtype = torch.float32
     model.eval()
     sample, _ = bench.synthetic_batch(256, 1000, 10000, 2, DEV)
-    ids = {}
+    ids, sc = {}, {}
     with torch.no_grad():
         for packed in (False, True):
             with _layout(packed):
                 hyp = M.CTCDecoder([model]).generate([model], sample)
                 ids[packed] = [h[0]["tokens"].tolist() for h in hyp]
-    assert ids[False] == ids[True]
+                sc[packed] = torch.stack([h[0]["score"].reshape(()) for h in hyp])
+        with _layout(True):  # packing on, but the decoder asked for the reference's scores: it takes the padded layout
+            dec = M.CTCDecoder([model])
+            dec.exact_scores = True
+            hyp = dec.generate([model], sample)
+            ids["exact"] = [h[0]["tokens"].tolist() for h in hyp]
+            sc["exact"] = torch.stack([h[0]["score"].reshape(()) for h in hyp])
+    assert ids[False] == ids[True] == ids["exact"]
     assert sum(len(x) for x in ids[True]) > 1000
+    # hypothesis scores (INTEGRATION.md "Hypothesis scores"): the padded layout sums the padded frames' non-blank top-1
+    # log-probabilities as the reference does (s2t_ctc.py:327-329); the packed one cannot.  exact_scores restores them bit for bit;
+    # the full-length utterance (no padded frame) has the same score either way up to the summation order of its frames.
+    assert torch.equal(sc["exact"], sc[False])
+    lens = sample["net_input"]["src_lengths"].cpu()
+    full = (lens == lens.max()).nonzero().flatten().tolist()
+    for b in full:
+        assert abs(float(sc[True][b]) - float(sc[False][b])) <= 1e-4 * max(1.0, abs(float(sc[False][b])))
+    assert bool((sc[True] <= sc[False] + 1e-3).all())  # the missing term is a sum of -log p >= 0 (scores are -sum lprob)
 
 
 def _eval_both(model, sample, ni):
@@ -432,3 +468,70 @@ def test_one_captured_step_serves_batches_of_any_fill():
         assert np.isfinite(gra[i]) and abs(eag[i] - gra[i]) <= 2e-3 * abs(eag[i]), (i, eag, gra)
     for i in sorted(pad):
         assert abs(pad[i] - eag[i]) <= (1e-4 if i == 0 else 5e-3) * abs(pad[i]), (i, pad, eag)
+
+
+def test_captured_steps_survive_eager_passes_and_a_second_trainer():
+    """The per-batch bookkeeping a captured step reads (functional.batch_memo: lengths, masks, positions, packed-row geometry)
+    lives OUTSIDE its hipGraph, which bakes the addresses in.  Round 4 shelved a memory fault of a process that built, dropped
+    and rebuilt Trainers; the audit behind it ("Per-batch bookkeeping") found the table keyed by ``id(owner)`` —
+    re-used by CPython once the owner is collected — and an eager pass over ANOTHER batch object replacing (and releasing) the
+    entries of the captured batch.  Now: owners carry process-unique serials, the captured batch's entries are pinned by
+    Trainer.capture and refreshed in place.  Checked here:
+      * trainer 1: capture, replay, an eager eval pass AND an eager training-mode forward over another batch object on the same
+        model, replays on new batches — the losses equal those of a twin that never ran the eager passes;
+      * trainer 1 dropped (graphs destroyed, cache emptied), trainer 2 on a NEW model of the same architecture (the collected
+        modules' ids are up for re-use): capture and replays follow its own eager twin;
+      * nothing of trainer 1 is left pinned."""
+    import gc
+
+    batches = [_sample(24, 1000, 31 + i, full_first=(i % 2 == 0), lo=0.5 + 0.1 * i)[0] for i in range(4)]
+    other = _sample(24, 1000, 77, full_first=False, lo=0.7)[0]
+
+    def clone(bt):
+        return {"net_input": {k: v.clone() for k, v in bt["net_input"].items()}, "target": bt["target"].clone(),
+                "ntokens": bt["ntokens"]}
+
+    def run(seed, disturb):
+        model = _model(True, seed=seed, dropout=0.0)
+        model.train()
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+        tr = TR.Trainer(model, crit, lr=1e-5, warmup_updates=1, clip_norm=10.0)
+        out = []
+        tr.capture(clone(batches[0]))
+        out.append(float(tr.replay()[0]))
+        if disturb:
+            model.eval()
+            with torch.no_grad():
+                enc = model.encoder(src_tokens=other["net_input"]["src_tokens"], src_lengths=other["net_input"]["src_lengths"])
+                model.decoder(prev_output_tokens=other["net_input"]["prev_output_tokens"], encoder_out=enc)
+            model.train()
+            with torch.no_grad():
+                crit(model, other)
+        for bt in batches[1:]:
+            out.append(float(tr.replay(bt)[0]))
+        out.append(float(tr.replay(batches[0])[0]))
+        torch.cuda.synchronize()
+        return out, tr, model
+
+    with _layout(True):
+        a, tr_a, m_a = run(0, disturb=True)
+        assert any(len(e) > 4 and e[4] == id(tr_a) for lst in Fn._MEMO_PINNED.values() for e in lst)  # something IS pinned
+        owner_a = id(tr_a)
+        tr_a.release()
+        del tr_a, m_a
+        gc.collect()
+        torch.cuda.empty_cache()
+        assert not any(len(e) > 4 and e[4] == owner_a for lst in Fn._MEMO_PINNED.values() for e in lst)
+        b, tr_b, m_b = run(0, disturb=False)
+        tr_b.release()
+        del tr_b, m_b
+        gc.collect()
+        torch.cuda.empty_cache()
+        c, tr_c, m_c = run(5, disturb=True)   # a second architecture-equal model behind two dropped ones
+        d, tr_d, m_d = run(5, disturb=False)  # ... and two captured trainers alive at once
+        torch.cuda.synchronize()
+    assert all(np.isfinite(a + b + c + d))
+    for x, y in ((a, b), (c, d)):
+        for i, (u, v) in enumerate(zip(x, y)):
+            assert abs(u - v) <= 2e-4 * abs(v), (i, x, y)  # (identical kernels and data: float atomics in parameter sums only)
+    assert abs(a[0] - a[1]) > 1e-3 * abs(a[0])  # the batches really differ
