@@ -172,6 +172,7 @@ class S2TTransformerEncoder(nn.Module):
             # weight gradients over packed rows exist on the 256 x 256 grouped kernel only (it reads the live row count on the
             # device): its operand rules must hold for the widest operands of this stack — the feed-forward hidden activation and
             # the CTC logits — or the batch stays padded (S2T_WG_256=0, a vocabulary beyond 2 GiB of logits)
+            d = self.embed_dim
             widest = max(int(self.args.encoder_ffn_embed_dim), 3 * d,
                          Fn._pad8(self.ctc.ctc_projection.weight.shape[0]) if self.use_ctc else 0)
             if not Fn.wgrad256_eligible(B * Tp, widest, d):
