@@ -45,6 +45,10 @@ enum { S2T_ROWS_PACKED = -1, S2T_ROWS_BOUND = -2 }; /* values of a row_T / T arg
 int s2t_version(void);
 /* number of compute units of the current device (for host-side grid heuristics) */
 int s2t_device_cu_count(void);
+/* Test / rehearsal utility: hold n compute units (one workgroup with 96 KiB of LDS each: no large-LDS workgroup of this library
+ * fits beside it) until *stop != 0 or `ms` milliseconds (<= 2000) have passed, whichever comes first; *arrived (optional) counts
+ * the workgroups that started.  Stands in for kernels that share the GPU with this path (the RCCL all-reduce beside backward). */
+int s2t_occupy_cus(int n, int ms, const uint32_t* stop, uint32_t* arrived, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:   C = epilogue( A_op[M,K] * B_op[K,N] )
@@ -570,6 +574,11 @@ int64_t s2t_ffn_exchange_flag_bytes(void);
  * every row block never raises its exchange flag and the spin limit is short, so that the time-out path can be exercised.
  * Returns the settings in force (mask | split_force << 4 | fault << 12). */
 int s2t_ffn_configure(int pc_mask, int split_force, int fault);
+/* Compute units the fused feed-forward launches may count on being free AT ONCE (the parts of a row block wait for each other):
+ * cus > 0 sets the budget, 0 restores the device's count, < 0 only queries; returns the budget in force.  The split (parts per
+ * 128-row block) and s2t_ffn_pair_ws_bytes follow it.  The data-parallel wrapper lowers it by what its all-reduce kernels
+ * occupy beside backward (legacy_distributed_data_parallel.py:76-160); S2T_FFN_CU_BUDGET presets it. */
+int s2t_ffn_cu_budget(int cus);
 /* the kernel symbol s2t_ffn_fused_fwd launches for these arguments, as a profiler prints it (buf: >= 96 bytes) */
 int s2t_ffn_fused_describe(const s2t_ffn_args* args, char* buf, int32_t buf_bytes);
 int s2t_ffn_z_tiled(const s2t_ffn_args* args);     /* 1: s2t_ffn_fused_fwd(args) writes z tiled */

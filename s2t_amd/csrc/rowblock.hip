@@ -1602,13 +1602,14 @@ constexpr int PC_RB = 128;
 // Both switches are read from the environment ONCE (first use) and can be changed afterwards through s2t_ffn_configure
 // (tests and tools switch flavours inside one process; a getenv per launch is host time on the critical path of eager steps).
 struct PcConfig {
-  int mask, split_force, fault;
+  int mask, split_force, fault, cu_budget;
 };
 PcConfig& pc_config() {
   static PcConfig c = [] {
     const char* e = getenv("S2T_FFN_PC");
     const char* fe = getenv("S2T_FFN_PC_SPLIT");
-    return PcConfig{e ? atoi(e) : S2T_FFN_PC_DEFAULT, fe ? atoi(fe) : 0, 0};
+    const char* ce = getenv("S2T_FFN_CU_BUDGET");
+    return PcConfig{e ? atoi(e) : S2T_FFN_PC_DEFAULT, fe ? atoi(fe) : 0, 0, ce ? atoi(ce) : 0};
   }();
   return c;
 }
@@ -1624,10 +1625,13 @@ int pc_num_cus() {
   return n;
 }
 // workgroups per 128-row block by the row count alone: 8 (each on an eighth of the hidden units) for few rows (the decoder's
-// 3 904: 31 blocks), 4 or 2 while the whole grid is then resident at once — the partners wait for each other — else 1
+// 3 904: 31 blocks), 4 or 2 while the whole grid is then resident at once — the partners wait for each other — else 1.
+// "At once" is measured against the CU BUDGET: the device's compute units, or what s2t_ffn_cu_budget / S2T_FFN_CU_BUDGET leaves
+// of them when other kernels hold some (the data-parallel wrapper takes off what its all-reduce kernels occupy beside backward).
 int pc_split_rows(int M) {
   const int P = (M + PC_RB - 1) / PC_RB;
-  const int cus = pc_num_cus();
+  const int b = pc_config().cu_budget;
+  const int cus = b > 0 ? b : pc_num_cus();
   return 8 * P <= cus ? 8 : (4 * P <= cus ? 4 : (2 * P <= cus ? 2 : 1));
 }
 // bytes of the fp32 partial-row slabs of the exchange: split 2: the 64 rows the partner finishes; split 8: all 128 rows
@@ -1661,6 +1665,11 @@ extern "C" int s2t_ffn_configure(int pc_mask, int split_force, int fault) {
   if (split_force >= 0) c.split_force = split_force;
   if (fault >= 0) c.fault = fault;
   return (c.mask & 7) | (c.split_force << 4) | (c.fault << 12);
+}
+extern "C" int s2t_ffn_cu_budget(int cus) {
+  PcConfig& c = pc_config();
+  if (cus >= 0) c.cu_budget = cus;  // 0: back to the device's count
+  return c.cu_budget > 0 ? c.cu_budget : pc_num_cus();
 }
 extern "C" int64_t s2t_ffn_exchange_error_offset(void) { return (int64_t)S2T_PC_ERR_WORD * 4; }
 extern "C" int64_t s2t_ffn_exchange_flag_bytes(void) { return PC_FLAG_BYTES; }

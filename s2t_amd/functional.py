@@ -411,6 +411,7 @@ def pin_buffers_for_graph():
     """Called when a step is captured into a hipGraph: buffers allocated OUTSIDE the graph's pool whose addresses the graph
     bakes in (the shared skewed-dS buffers) may never be freed or re-used for another shape afterwards."""
     GRAPH_PINNED.update(_DBD.keys())
+    K.graphs_hold_workspaces()
 
 
 _POSQ = {"entries": [], "pool": {}, "next": {}, "parts": []}

@@ -167,6 +167,7 @@ def _ffn_pair_ws(a, M, device):
     key = ("ffn_pair", str(device), L.stream_ptr())
     t = _WS.get(key)
     if t is None or t.numel() * 4 < need:
+        _retire(t)
         t = torch.zeros((need + 3) // 4, dtype=torch.float32, device=device)
         _WS[key] = t
     a.pair_ws, a.pair_ws_bytes = t.data_ptr(), t.numel() * 4
@@ -179,6 +180,17 @@ def ffn_configure(pc_mask=None, split=None, fault=None):
     r = L.lib().s2t_ffn_configure(-1 if pc_mask is None else int(pc_mask), -1 if split is None else int(split),
                                   -1 if fault is None else int(fault))
     return r & 7, (r >> 4) & 0xFF, (r >> 12) & 1
+
+
+def ffn_cu_budget(cus=None):
+    """s2t_ffn_cu_budget: compute units the fused feed-forward split may count on (None: query; 0: the device's count)."""
+    return int(L.lib().s2t_ffn_cu_budget(-1 if cus is None else int(cus)))
+
+
+def occupy_cus(n, ms, stop=None, arrived=None, stream=None):
+    """s2t_occupy_cus on ``stream`` (a torch.cuda.Stream; default: the current one): n compute units held for at most ms milliseconds."""
+    st = stream.cuda_stream if stream is not None else L.stream_ptr()
+    L.check(L.lib().s2t_occupy_cus(int(n), int(ms), _ptr(stop), _ptr(arrived), st), "s2t_occupy_cus")
 
 
 _XCHK = {"pending": []}
@@ -496,9 +508,27 @@ def _scratch(tag, n, device):
     key = (tag, str(device), L.stream_ptr())  # per stream: concurrent streams must not share scratch
     t = _WS.get(key)
     if t is None or t.numel() < n:
+        _retire(t)
         t = torch.empty(n, dtype=torch.float32, device=device)
         _WS[key] = t
     return t
+
+
+# Workspaces that only grow are REPLACED when a larger shape comes along.  A captured hipGraph has the old buffer's address baked
+# in: once any step of this process has been captured (graphs_hold_workspaces, called by Trainer.capture) a replaced buffer is kept
+# alive instead of going back to the allocator — a later replay of that graph must not write into memory that now belongs to
+# somebody else (or to nobody: an emptied cache unmaps it).
+_WS_RETIRED = []
+_WS_GRAPHS = {"captured": False}
+
+
+def graphs_hold_workspaces():
+    _WS_GRAPHS["captured"] = True
+
+
+def _retire(t):
+    if t is not None and _WS_GRAPHS["captured"]:
+        _WS_RETIRED.append(t)
 
 
 def _workspace(tag, n, device):

@@ -77,6 +77,13 @@ class LegacyDistributedDataParallel(nn.Module):
         # one bf16 staging block per bucket (buckets may be in flight together on the side stream)
         self._stage = [torch.empty((e - s + 3) // 4 * 4, dtype=torch.bfloat16, device=flat.grad.device)
                        for s, e in self.buckets] if self.reduce_dtype == torch.bfloat16 else None
+        # RCCL's all-reduce kernels run BESIDE backward and take compute units.  The fused feed-forward kernels deal a row block
+        # to several workgroups that wait for each other (csrc/ffn_pc.hip) and size that split for a grid that is resident at
+        # once: with more than one rank the budget is lowered by what the collective may hold (S2T_COMM_CUS, default 32 — the
+        # rehearsal of tests/test_rowblock_gpu.py::test_split_ffn_forms_with_compute_units_held_by_another_kernel holds 32 and 64)
+        if flat.grad.is_cuda and self.world_size > 1 and overlap and "S2T_FFN_CU_BUDGET" not in os.environ:
+            from . import kernels as K
+            K.ffn_cu_budget(max(64, K.ffn_cu_budget(0) - int(os.environ.get("S2T_COMM_CUS", "32"))))
 
     # -- module protocol ---------------------------------------------------------------------------
     def forward(self, *args, **kwargs):

@@ -659,3 +659,65 @@ def test_ffn_exchange_timeout_is_reported(M):
     y_again = run()
     K.ffn_exchange_check()
     assert torch.equal(y_again, y_ok)
+
+
+@pytest.mark.parametrize("parked", [32, 64])
+def test_split_ffn_forms_with_compute_units_held_by_another_kernel(parked, ffn_split):
+    """The parts of a row block wait for each other's partial rows (csrc/ffn_pc.hip), and their number is sized for a grid that is
+    resident at once.  In a data-parallel step RCCL's all-reduce kernels run beside backward (legacy_distributed_data_parallel.py:
+    76-160) and take compute units.  Rehearsal on one GPU: a kernel on a side stream holds 32 / 64 CUs (s2t_occupy_cus: one
+    workgroup with 96 KiB of LDS each, so no 128 - 160 KiB workgroup of the fused kernels fits beside it) while the two-part
+    (16 000 rows, training forward and backward shapes) and eight-part (3 904 rows) forms run:
+      * no exchange time-out (the partners of a resident workgroup are dispatched within 64 blocks of it and the grid drains in
+        dispatch order: earlier groups finish and free their CUs), results equal to the one-workgroup form's;
+      * with the CU budget lowered to what is free (s2t_ffn_cu_budget, what the data-parallel wrapper does) the launch picks a
+        split whose grid fits again;
+      * the slowdown is printed."""
+    import time
+
+    d, F = 256, 2048
+    side = torch.cuda.Stream()
+    stop = torch.zeros(1, dtype=torch.int32, device=DEV)
+    arrived = torch.zeros(1, dtype=torch.int32, device=DEV)
+    cus = K.ffn_cu_budget()
+    res = {}
+    for M in (16000, 3904):
+        x, w1, b1, w2, b2, gam, bet, eg, eb = _mk(M, F, 9)
+        xd, w1d, b1d, w2d, b2d, gd, bd = (t.to(DEV) for t in (x, w1, b1, w2, b2, gam, bet))
+
+        def run(n=1):
+            y = torch.empty_like(xd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                K.ffn_fused_fwd(xd, w1d, b1d, w2d, b2d, y, act="swish", alpha=0.5, residual=xd, ln=(gd, bd))
+            torch.cuda.current_stream().synchronize()
+            return y.float(), (time.perf_counter() - t0) / n
+
+        ffn_split(1)
+        y1, _ = run()
+        ffn_split(0)
+        run(3)
+        y_free, t_free = run(20)
+        stop.zero_()
+        arrived.zero_()
+        K.occupy_cus(parked, 1500, stop, arrived, stream=side)
+        while int(arrived.cpu()) < parked:  # the occupier's workgroups are resident
+            time.sleep(0.001)
+        try:
+            y_held, t_held = run(20)
+            K.ffn_exchange_check()  # raises on an exchange time-out
+            K.ffn_cu_budget(cus - parked)
+            y_budget, t_budget = run(20)
+            K.ffn_exchange_check()
+        finally:
+            K.ffn_cu_budget(0)
+            stop.fill_(1)
+            side.synchronize()
+        tol = 2e-2 * float(y1.abs().max())  # same products, another order of the fp32 partial sums, one bf16 rounding
+        assert float((y_free - y1).abs().max()) <= tol
+        assert torch.equal(y_held, y_free)  # the same split form: where a workgroup runs does not enter its arithmetic
+        assert float((y_budget - y1).abs().max()) <= tol
+        res[M] = (t_free * 1e6, t_held * 1e6, t_budget * 1e6)
+    print("fused FFN eval forward with %d of %d CUs held: rows 16000 free %.1f us, held %.1f, held + budget %.1f; rows 3904 free %.1f, "
+          "held %.1f, held + budget %.1f" % ((parked, cus) + res[16000] + res[3904]))
