@@ -78,12 +78,15 @@ class LegacyDistributedDataParallel(nn.Module):
         self._stage = [torch.empty((e - s + 3) // 4 * 4, dtype=torch.bfloat16, device=flat.grad.device)
                        for s, e in self.buckets] if self.reduce_dtype == torch.bfloat16 else None
         # RCCL's all-reduce kernels run BESIDE backward and take compute units.  The fused feed-forward kernels deal a row block
-        # to several workgroups that wait for each other (csrc/ffn_pc.hip) and size that split for a grid that is resident at
-        # once: with more than one rank the budget is lowered by what the collective may hold (S2T_COMM_CUS, default 32 — the
-        # rehearsal of tests/test_rowblock_gpu.py::test_split_ffn_forms_with_compute_units_held_by_another_kernel holds 32 and 64)
-        if flat.grad.is_cuda and self.world_size > 1 and overlap and "S2T_FFN_CU_BUDGET" not in os.environ:
+        # to several workgroups that wait for each other (csrc/ffn_pc.hip), sized for a grid that is resident at once.  With CUs
+        # held by another kernel the late workgroups' partners are dispatched within 64 blocks of them and the grid drains in
+        # dispatch order, so the exchange completes (rehearsed with 32 and 64 CUs held: tests/test_rowblock_gpu.py::
+        # test_split_ffn_forms_with_compute_units_held_by_another_kernel) — at the price of a second round of workgroups.
+        # S2T_COMM_CUS=n lowers the budget the split is sized from (s2t_ffn_cu_budget) by n instead: fewer, longer workgroups
+        # in one round.  Which is faster beside a real all-reduce is a measurement for the 8-GPU node; default: leave the split.
+        if flat.grad.is_cuda and self.world_size > 1 and overlap and os.environ.get("S2T_COMM_CUS"):
             from . import kernels as K
-            K.ffn_cu_budget(max(64, K.ffn_cu_budget(0) - int(os.environ.get("S2T_COMM_CUS", "32"))))
+            K.ffn_cu_budget(max(64, K.ffn_cu_budget(0) - int(os.environ["S2T_COMM_CUS"])))
 
     # -- module protocol ---------------------------------------------------------------------------
     def forward(self, *args, **kwargs):
