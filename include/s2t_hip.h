@@ -422,9 +422,10 @@ int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int 
 /* SATE adapter distribution (modules/speech_to_text/adapter.py:214-217): P = softmax(x * inv_tau) per row, and its
  * backward dx = P * (dP - sum P dP) * inv_tau */
 int s2t_row_softmax_fwd(int dtype, const void* x, int64_t ldx, void* p, int64_t ldp, int64_t rows, int V, float inv_tau,
+                        const int32_t* live /* optional device scalar: only rows < *live (a packed batch's live rows) */,
                         void* stream);
 int s2t_row_softmax_bwd(int dtype, const void* p, int64_t ldp, const void* dp, int64_t lddp, void* dx, int64_t lddx,
-                        int64_t rows, int V, float inv_tau, void* stream);
+                        int64_t rows, int V, float inv_tau, const int32_t* live /* as above */, void* stream);
 int s2t_ctc_collapse(const int32_t* idx, const float* top_lp, const int32_t* lens,
                      const int32_t* cu /* packed batch: idx / top_lp rows of utterance b from cu[b], or NULL; outputs stay [B][T] */,
                      int B, int T, int blank, int64_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);

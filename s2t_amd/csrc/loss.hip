@@ -724,8 +724,9 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
 template <typename T>
 __global__ __launch_bounds__(256) void row_softmax_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ p,
                                                               int64_t ldp, int V, float inv_tau,
-                                                              const int32_t* __restrict__ lens, int Tn) {
+                                                              const int32_t* __restrict__ live, int) {
   const int64_t row = blockIdx.x;
+  if (live && row >= *live) return;  // packed batch: beyond the live rows
   const T* xr = x + row * ldx;
   T* pr = p + row * ldp;
   float mx, lse;
@@ -740,7 +741,6 @@ __global__ __launch_bounds__(256) void row_softmax_fwd_kernel(const T* __restric
   if ((threadIdx.x & 63) == 0) ss2[threadIdx.x >> 6] = s;
   __syncthreads();
   const float inv = 1.f / (ss2[0] + ss2[1] + ss2[2] + ss2[3]);
-  (void)lens; (void)Tn;
   row_map<T>(xr, pr, V, [&](int c, float v) { return __expf(v * inv_tau - m2) * inv; });
 }
 
@@ -749,9 +749,11 @@ __global__ __launch_bounds__(256) void row_softmax_fwd_kernel(const T* __restric
 // aligned rows.
 template <int NPT>
 __global__ __launch_bounds__(256) void row_softmax_fwd_reg_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ p,
-                                                                  int64_t ldp, int V, float inv_tau) {
+                                                                  int64_t ldp, int V, float inv_tau,
+                                                                  const int32_t* __restrict__ live) {
   __shared__ float red[2][4];
   const int tid = threadIdx.x;
+  if (live && (int)blockIdx.x >= *live) return;  // packed batch: beyond the live rows
   const bf16_t* xr = x + (int64_t)blockIdx.x * ldx;
   bf16_t* pr = p + (int64_t)blockIdx.x * ldp;
   uint4 raw[NPT];
@@ -807,9 +809,11 @@ __global__ __launch_bounds__(256) void row_softmax_fwd_reg_kernel(const bf16_t* 
 template <typename T>
 __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const T* __restrict__ p, int64_t ldp,
                                                               const T* __restrict__ dp, int64_t lddp,
-                                                              T* __restrict__ dx, int64_t lddx, int V, float inv_tau) {
+                                                              T* __restrict__ dx, int64_t lddx, int V, float inv_tau,
+                                                              const int32_t* __restrict__ live) {
   __shared__ float sd[4];
   const int64_t row = blockIdx.x;
+  if (live && row >= *live) return;
   const T* pr = p + row * ldp;
   const T* dr = dp + row * lddp;
   float dot = 0.f;
@@ -828,9 +832,11 @@ __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const T* __restric
 template <int NPT>
 __global__ __launch_bounds__(256) void row_softmax_bwd_reg_kernel(const bf16_t* __restrict__ p, int64_t ldp,
                                                                   const bf16_t* __restrict__ dp, int64_t lddp,
-                                                                  bf16_t* __restrict__ dx, int64_t lddx, int V, float inv_tau) {
+                                                                  bf16_t* __restrict__ dx, int64_t lddx, int V, float inv_tau,
+                                                                  const int32_t* __restrict__ live) {
   __shared__ float sd[4];
   const int tid = threadIdx.x;
+  if (live && (int)blockIdx.x >= *live) return;
   const bf16_t* pr = p + (int64_t)blockIdx.x * ldp;
   const bf16_t* dr = dp + (int64_t)blockIdx.x * lddp;
   uint4 rp[NPT], rd[NPT];
@@ -985,48 +991,48 @@ extern "C" int s2t_ctc_backtrace(const float* alpha, const int32_t* paths, const
 }
 
 extern "C" int s2t_row_softmax_fwd(int dtype, const void* x, int64_t ldx, void* p, int64_t ldp, int64_t rows, int V,
-                                   float inv_tau, void* stream) {
+                                   float inv_tau, const int32_t* live, void* stream) {
   if (!x || !p || rows < 0 || V <= 0 || ldx < V || ldp < V) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   dim3 grid((unsigned)rows), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(row_softmax_fwd_kernel<float>, grid, block, 0, s, (const float*)x, ldx, (float*)p, ldp, V, inv_tau, (const int32_t*)nullptr, 0);
+    hipLaunchKernelGGL(row_softmax_fwd_kernel<float>, grid, block, 0, s, (const float*)x, ldx, (float*)p, ldp, V, inv_tau, live, 0);
   else if (dtype == S2T_BF16) {
     const bool reg = inv_tau > 0.f && V % 8 == 0 && V <= 256 * 8 * 5 && ldx % 8 == 0 && ldp % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
                      ((uintptr_t)p % 16) == 0;
     const int npt = (V + 2047) / 2048;
-#define GO(N) hipLaunchKernelGGL(row_softmax_fwd_reg_kernel<N>, grid, block, 0, s, (const bf16_t*)x, ldx, (bf16_t*)p, ldp, V, inv_tau)
+#define GO(N) hipLaunchKernelGGL(row_softmax_fwd_reg_kernel<N>, grid, block, 0, s, (const bf16_t*)x, ldx, (bf16_t*)p, ldp, V, inv_tau, live)
     if (reg && npt <= 1) GO(1);
     else if (reg && npt == 2) GO(2);
     else if (reg && npt == 3) GO(3);
     else if (reg && npt == 4) GO(4);
     else if (reg && npt == 5) GO(5);
-    else hipLaunchKernelGGL(row_softmax_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ldx, (bf16_t*)p, ldp, V, inv_tau, (const int32_t*)nullptr, 0);
+    else hipLaunchKernelGGL(row_softmax_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ldx, (bf16_t*)p, ldp, V, inv_tau, live, 0);
 #undef GO
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();
 }
 
 extern "C" int s2t_row_softmax_bwd(int dtype, const void* p, int64_t ldp, const void* dp, int64_t lddp, void* dx,
-                                   int64_t lddx, int64_t rows, int V, float inv_tau, void* stream) {
+                                   int64_t lddx, int64_t rows, int V, float inv_tau, const int32_t* live, void* stream) {
   if (!p || !dp || !dx || rows < 0 || V <= 0) return S2T_ERR_ARG;
   if (rows == 0) return S2T_OK;
   dim3 grid((unsigned)rows), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == S2T_F32)
-    hipLaunchKernelGGL(row_softmax_bwd_kernel<float>, grid, block, 0, s, (const float*)p, ldp, (const float*)dp, lddp, (float*)dx, lddx, V, inv_tau);
+    hipLaunchKernelGGL(row_softmax_bwd_kernel<float>, grid, block, 0, s, (const float*)p, ldp, (const float*)dp, lddp, (float*)dx, lddx, V, inv_tau, live);
   else if (dtype == S2T_BF16) {
     const bool reg = V % 8 == 0 && V <= 256 * 8 * 5 && ldp % 8 == 0 && lddp % 8 == 0 && lddx % 8 == 0 && ((uintptr_t)p % 16) == 0 &&
                      ((uintptr_t)dp % 16) == 0 && ((uintptr_t)dx % 16) == 0;
     const int npt = (V + 2047) / 2048;
-#define GO(N) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<N>, grid, block, 0, s, (const bf16_t*)p, ldp, (const bf16_t*)dp, lddp, (bf16_t*)dx, lddx, V, inv_tau)
+#define GO(N) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<N>, grid, block, 0, s, (const bf16_t*)p, ldp, (const bf16_t*)dp, lddp, (bf16_t*)dx, lddx, V, inv_tau, live)
     if (reg && npt <= 1) GO(1);
     else if (reg && npt == 2) GO(2);
     else if (reg && npt == 3) GO(3);
     else if (reg && npt == 4) GO(4);
     else if (reg && npt == 5) GO(5);
-    else hipLaunchKernelGGL(row_softmax_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)p, ldp, (const bf16_t*)dp, lddp, (bf16_t*)dx, lddx, V, inv_tau);
+    else hipLaunchKernelGGL(row_softmax_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)p, ldp, (const bf16_t*)dp, lddp, (bf16_t*)dx, lddx, V, inv_tau, live);
 #undef GO
   } else return S2T_ERR_DTYPE;
   return S2T_LAUNCH_CHECK();

@@ -2394,10 +2394,12 @@ def _pos_table_f32(pos_tab):
 class AdapterFn(torch.autograd.Function):
     """out = x + dist @ W_embed, dist = softmax(ctc_logit / tau)   (modules/speech_to_text/adapter.py:214-217,264-266,
     296-297); rows flagged by ``rows`` take the (optionally smoothed) one-hot distribution of ``oracle`` instead
-    (adapter.py:245-262, the PAE ground-truth curriculum) and pass no gradient to the logits."""
+    (adapter.py:245-262, the PAE ground-truth curriculum) and pass no gradient to the logits.
+    ``packed``: the lengths tensor of a packed batch (s2t_amd/rows.py) whose rows x / logit hold: only the live rows are
+    computed and enter the weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, logit, w, tau, train, oracle, rows, smooth):
+    def forward(ctx, x, logit, w, tau, train, oracle, rows, smooth, packed=None):
         M, d = x.shape
         V = w.shape[0]
         assert logit.stride(1) == 1
@@ -2405,19 +2407,21 @@ class AdapterFn(torch.autograd.Function):
         lg = logit if logit.dtype == dt else logit.to(dt)
         ldp = _pad8(V)
         P = torch.empty(M, ldp, dtype=dt, device=dev)
-        K.row_softmax_fwd(lg, lg.stride(0), P, ldp, M, V, 1.0 / tau)
+        K.row_softmax_fwd(lg, lg.stride(0), P, ldp, M, V, 1.0 / tau, bound=packed)
         if oracle is not None:
+            assert packed is None, "the ground-truth curriculum of PAE runs on padded rows"
             on, off = (0.9 + 0.1 / V, 0.1 / V) if smooth else (1.0, 0.0)
             Pv = P[:, :V]
             Pv.masked_fill_(rows[:, None], off)
             idx = oracle.view(-1, 1)
             Pv.scatter_(1, idx, torch.where(rows[:, None], torch.full_like(Pv[:, :1], on), Pv.gather(1, idx)))
         y = torch.empty(M, d, dtype=dt, device=dev)
-        K.gemm(P, cw(w), y, M=M, N=d, K=V, lda=ldp, ldb=d, ldc=d, b_kmajor=True, residual=x, ldr=d)
+        K.gemm(P, cw(w), y, M=M, N=d, K=V, lda=ldp, ldb=d, ldc=d, b_kmajor=True, residual=x, ldr=d, rows=packed)
         if train:
             ctx.save_for_backward(P)
         ctx.w, ctx.tau, ctx.V, ctx.ldt = w, tau, V, logit.dtype
         ctx.rows = rows if oracle is not None else None
+        ctx.packed = packed
         return y
 
     @staticmethod
@@ -2429,17 +2433,18 @@ class AdapterFn(torch.autograd.Function):
         dt, dev = P.dtype, P.device
         dy = dy.contiguous()
         dP = torch.empty(M, ldp, dtype=dt, device=dev)
-        K.gemm(dy, cw(w), dP, M=M, N=V, K=d, lda=d, ldb=d, ldc=ldp)
+        K.gemm(dy, cw(w), dP, M=M, N=V, K=d, lda=d, ldb=d, ldc=ldp, rows=ctx.packed)
         dlogit = torch.empty(M, ldp, dtype=dt, device=dev)
-        K.row_softmax_bwd(P, ldp, dP, ldp, dlogit, ldp, M, V, 1.0 / ctx.tau)
+        K.row_softmax_bwd(P, ldp, dP, ldp, dlogit, ldp, M, V, 1.0 / ctx.tau, bound=ctx.packed)
         if ctx.rows is not None:
             dlogit.masked_fill_(ctx.rows[:, None], 0.0)
-        _wgrad(P, dy, w.grad, V, d, M, ldp, d)
+        _wgrad(P, dy, w.grad, V, d, M, ldp, d, rows=ctx.packed)
         _ready(w)
         dl = dlogit[:, :V]
-        return dy, (dl if ctx.ldt == dt else dl.to(ctx.ldt)), None, None, None, None, None, None
+        return dy, (dl if ctx.ldt == dt else dl.to(ctx.ldt)), None, None, None, None, None, None, None
 
 
-def adapter_inter_league(x, logit, w, tau=1.0, oracle=None, oracle_rows=None, oracle_smooth=False):
-    """x [M, d], logit [M, V]; oracle int64 [M] labels, oracle_rows bool [M] (both or neither)."""
-    return AdapterFn.apply(x, logit, w, tau, torch.is_grad_enabled(), oracle, oracle_rows, bool(oracle_smooth))
+def adapter_inter_league(x, logit, w, tau=1.0, oracle=None, oracle_rows=None, oracle_smooth=False, rows=None):
+    """x [M, d], logit [M, V]; oracle int64 [M] labels, oracle_rows bool [M] (both or neither); ``rows``: packed geometry."""
+    return AdapterFn.apply(x, logit, w, tau, torch.is_grad_enabled(), oracle, oracle_rows, bool(oracle_smooth),
+                           rows if K.rows_geom(rows) is not None else None)

@@ -783,13 +783,14 @@ def compress_rows(x, out, src, new_lens, B, T, Tn, C, scatter=False):
           Tn, C, 1 if scatter else 0)
 
 
-def row_softmax_fwd(x, ldx, p, ldp, rows, V, inv_tau=1.0):
-    _call("s2t_row_softmax_fwd", L.dtype_id(x.dtype), x.data_ptr(), ldx, p.data_ptr(), ldp, rows, V, inv_tau)
+def row_softmax_fwd(x, ldx, p, ldp, rows, V, inv_tau=1.0, bound=None):
+    """``bound``: lengths tensor of a packed batch — only its live rows are computed."""
+    _call("s2t_row_softmax_fwd", L.dtype_id(x.dtype), x.data_ptr(), ldx, p.data_ptr(), ldp, rows, V, inv_tau, _live(bound))
 
 
-def row_softmax_bwd(p, ldp, dp, lddp, dx, lddx, rows, V, inv_tau=1.0):
+def row_softmax_bwd(p, ldp, dp, lddp, dx, lddx, rows, V, inv_tau=1.0, bound=None):
     _call("s2t_row_softmax_bwd", L.dtype_id(p.dtype), p.data_ptr(), ldp, dp.data_ptr(), lddp, dx.data_ptr(), lddx, rows, V,
-          inv_tau)
+          inv_tau, _live(bound))
 
 
 def attn_fused_fwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, o_sb, o_sr, lse, B, H, Tq, Tk, dk, key_lens, causal, scale,

@@ -422,14 +422,15 @@ class Adapter(nn.Module):
         self.ground_truth_ratio = float(strategy.get("gt_ratio", 0) or 0)
         self.oracle_smooth = bool(strategy.get("oracle_smooth", False))
 
-    def forward(self, x2d, logit2d, oracle=None, oracle_mask=None):
-        """x2d [B*T, d], logit2d [B*T, V]; oracle / oracle_mask (B, T) as produced by ``pae_oracle_mask``."""
+    def forward(self, x2d, logit2d, oracle=None, oracle_mask=None, rows=None):
+        """x2d [B*T, d], logit2d [B*T, V]; oracle / oracle_mask (B, T) as produced by ``pae_oracle_mask``; ``rows``: the
+        lengths tensor of a packed batch whose rows x2d / logit2d hold (s2t_amd/rows.py)."""
         if self.adapter_type == "none":
             return x2d
         if self.ground_truth_ratio > 0 and oracle is not None:
             return Fn.adapter_inter_league(x2d, logit2d, self.embed_adapter.weight, self.temperature,
                                            oracle.reshape(-1), oracle_mask.reshape(-1), self.oracle_smooth)
-        return Fn.adapter_inter_league(x2d, logit2d, self.embed_adapter.weight, self.temperature)
+        return Fn.adapter_inter_league(x2d, logit2d, self.embed_adapter.weight, self.temperature, rows=rows)
 
 
 def pae_oracle_mask(entry, gt_ratio, adaptive=False, only_mistake=False, mask=None):

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import rows as Rows
 from .modules import TABLES, Adapter, CTC, LayerNorm, Linear, MultiheadAttention, pae_oracle_mask
 from .registry import register_model, register_model_architecture
 from .s2t_transformer import (AddPositions, Embedding, S2TTransformerEncoder, S2TTransformerModel,
@@ -43,12 +44,15 @@ class TransformerEncoderLayer(nn.Module):
         self.activation_fn = getattr(args, "activation_fn", "relu")
 
     def forward(self, x, B, T, lens):
+        # packed rows (s2t_amd/rows.py): ``lens`` then carries the geometry — key side and query side of the self-attention, the
+        # live-row bound of the feed-forward block
+        rows = lens if getattr(lens, "_pk", None) is not None else None
         x = self.self_attn(x, None, None, B, T, T, lens, norm=self.self_attn_layer_norm)
         # (the LayerNorm, both products, activation, dropouts and the residual in one launch where the row-block kernel
         # applies: d = 256 bf16, relu / swish, >= S2T_FFN_FUSED_MIN_ROWS rows; the LayerNorm + GEMM composition otherwise)
         return Fn.ffn_block(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
                             self.fc2.weight, self.fc2.bias, self.activation_fn, 1.0, self.activation_dropout_p, self.dropout_p,
-                            self.training)
+                            self.training, rows=rows)
 
 
 class TransformerS2EncoderLayer(TransformerEncoderLayer):
@@ -180,11 +184,20 @@ class TextualEncoder(nn.Module):
                 TransformerS2EncoderLayer(s2_args) for _ in range(n - self.cross_attn_start_layer + 1)]
         self.layers = nn.ModuleList(layers)
 
+    def packable(self):
+        """Packed rows (s2t_amd/rows.py) through the textual layers: the plain stack of configuration 4 (sate.yaml) — the NAST
+        extras (XCTC heads, prediction-aware encoding, cross-layer attention) read (T, B, V) views and stay on padded rows."""
+        return (self.embed_dim == 256 and not self.use_xctc and not self.inter_xctc_layers and not self.use_cross_attn
+                and len(self.layers) > 0 and self.layers[0].self_attn.num_heads * 64 == self.embed_dim)
+
     def forward(self, x, B, T, lens32, encoder_padding_mask=None, **kwargs):
         """x [B*T, d] -> (x, xctc_logit, inter_xctc_logits); logits are (T, B, V) views, inter entries follow the
-        reference: plain tensor, or [logit, None, force_emit] under the ground-truth curriculum (:774-797)."""
+        reference: plain tensor, or [logit, None, force_emit] under the ground-truth curriculum (:774-797).
+        ``lens32`` with a packed geometry (``packable()`` configurations only): x holds packed rows and stays packed."""
+        rows = lens32 if getattr(lens32, "_pk", None) is not None else None
+        assert rows is None or self.packable()
         if self.embed_ln is not None:
-            x = self.embed_ln(x)
+            x = self.embed_ln(x, rows=rows)
         if not self.text_no_pos_emb:
             tab = TABLES.get("sin", max(self.max_pos, T) + 2, self.embed_dim, x.device)
             x = AddPositions.apply(x, tab, lens32, T, self.embed_scale)
@@ -226,7 +239,7 @@ class TextualEncoder(nn.Module):
                     x = self.xctc_pae(x if self.pae_unnorm_input else norm_x, logit2d, orc, msk)
                 inter_xctc_logits.append(inter_logit)
         if self.layer_norm is not None:
-            x = self.layer_norm(x)
+            x = self.layer_norm(x, rows=rows)
         xctc_logit = None
         if self.use_xctc:
             xctc_logit = self.xctc(x, out_dtype=self.ctc_out_dtype).view(B, T, -1).transpose(0, 1)
@@ -274,6 +287,27 @@ class S2TSATEEncoder(nn.Module):
 
     def forward(self, src_tokens, src_lengths=None, **kwargs):
         ac = self.acoustic_encoder(src_tokens, src_lengths, **kwargs)
+        pk = ac.get("packed")
+        if (pk is not None and self.textual_encoder.packable() and Rows.ENABLED
+                and (self.adapter.adapter_type == "none" or pk.get("ctc_logit") is not None)):
+            # Packed rows (s2t_amd/rows.py) straight through: the acoustic encoder's rows, the adapter and the textual layers
+            # run on the frames only (s2t_sate.py:973-1075 computes them on the padded frames too; nothing downstream reads those:
+            # the decoder masks them as keys, the losses stop at the lengths)
+            rows_, B, Tn = pk["rows"], pk["B"], pk["T"]
+            x = pk["encoder_out"]
+            d = x.shape[1]
+            mask = ac["encoder_padding_mask"][0]
+            if self.adapter.adapter_type != "none":
+                x = self.adapter(x, pk["ctc_logit"], rows=rows_)
+            self.textual_encoder.ctc_out_dtype = self.acoustic_encoder.ctc_out_dtype
+            x, _, _ = self.textual_encoder(x, B, Tn, rows_, mask, **kwargs)
+            return {
+                "encoder_out": Rows.LazyList([lambda: Rows.unpack(x, rows_).view(B, Tn, d).transpose(0, 1)]),
+                "ctc_logit": ac["ctc_logit"], "inter_ctc_logits": [], "xctc_logit": [], "inter_xctc_logits": [],
+                "axctc_logit": [], "inter_axctc_logits": [], "ctc_padding_mask": [mask], "encoder_padding_mask": [mask],
+                "mixup": None, "encoder_embedding": [], "encoder_states": [], "src_tokens": [], "src_lengths": [],
+                "packed": {"rows": rows_, "B": B, "T": Tn, "encoder_out": x, "ctc_logit": pk.get("ctc_logit")},
+            }
         x_tbc = ac["encoder_out"][0]
         Tn, B, d = x_tbc.shape
         x = x_tbc.transpose(0, 1).reshape(B * Tn, d)

@@ -535,3 +535,67 @@ def test_captured_steps_survive_eager_passes_and_a_second_trainer():
         for i, (u, v) in enumerate(zip(x, y)):
             assert abs(u - v) <= 2e-4 * abs(v), (i, x, y)  # (identical kernels and data: float atomics in parameter sums only)
     assert abs(a[0] - a[1]) > 1e-3 * abs(a[0])  # the batches really differ
+
+
+def test_sate_textual_layers_run_packed_and_equal_the_padded_layout():
+    """Configuration 4's stack (s2t_sate: acoustic Transformer encoder -> inter_league adapter -> textual layers -> decoder,
+    models/speech_to_text/s2t_sate.py:973-1075) with the acoustic rows handed to the adapter and the textual layers AS THEY ARE:
+    eval outputs on the frames equal the padded layout's bit for bit (one workgroup per fused-FFN row block pinned), one training
+    pass agrees in loss and in every gradient within the spread of two summation orders."""
+    from s2t_amd import s2t_sate as SATE
+
+    def build():
+        torch.manual_seed(3)
+        a = M.recipe_args(conformer=False, vocab_size=V, arch="s2t_sate", encoder_layers=3, text_encoder_layers=2, decoder_layers=2,
+                          acoustic_encoder="transformer", adapter="inter_league", textual_encoder_embed_norm=True,
+                          textual_encoder_no_scale_embedding=True, encoder_normalize_before=True, decoder_normalize_before=True)
+        model = SATE.S2TSATEModel.build_model(a, M.FakeTask(V))
+        g = torch.Generator().manual_seed(10)
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+        return model.prepare(torch.bfloat16, DEV)
+
+    sample, lens = _sample(24, 1000, 15)
+    ni = sample["net_input"]
+    sub = torch.tensor(lens)
+    for _ in range(2):
+        sub = torch.div(sub - 1, 2, rounding_mode="floor") + 1
+    _, old, _ = K.ffn_configure()
+    res = {}
+    for packed in (False, True):
+        model = build()
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+        with _layout(packed):
+            K.ffn_configure(split=1)
+            try:
+                model.eval()
+                with torch.no_grad():
+                    enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+                    assert (enc.get("packed") is not None) == packed
+                    eo = enc["encoder_out"][0].float()
+                    logits, _ = model.decoder(prev_output_tokens=ni["prev_output_tokens"], encoder_out=enc)
+            finally:
+                K.ffn_configure(split=old)
+            model.train()
+            model.flat.zero_grad()
+            loss, _, log = crit(model, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+        res[packed] = (eo, logits.float(), float(loss.detach()), {k: p.grad.detach().float().clone() for k, p in model.named_parameters()})
+    Tp = res[False][0].shape[0]
+    valid = (torch.arange(Tp)[:, None] < sub[None, :]).to(DEV)
+    assert torch.equal(res[False][0][valid], res[True][0][valid])          # textual encoder output on the frames
+    tmask = ni["prev_output_tokens"].ne(1)
+    assert torch.equal(res[False][1][tmask], res[True][1][tmask])          # decoder logits on the target positions
+    assert abs(res[False][2] - res[True][2]) <= 5e-4 * abs(res[False][2]), (res[False][2], res[True][2])
+    errs = []
+    for k, ga in res[False][3].items():
+        den = float(ga.norm())
+        if k.endswith(("k_proj.bias", "linear_k.bias")) or den < 1e-5:
+            continue
+        e = float((ga - res[True][3][k]).norm()) / den
+        errs.append(e)
+        assert e <= 0.08, (k, e)
+    assert float(np.median(errs)) <= 0.02
