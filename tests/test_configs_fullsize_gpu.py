@@ -261,8 +261,9 @@ def test_config2p_bf16_d256_against_oracle_on_rounded_weights():
     # of the HIP path, in no consistent order; this test's seed: 0.006 / 0.010 / 0.034 for three of them, worst tensor 0.054 ...
     # 0.100): one-ulp bf16 flips re-seed the rounding noise of everything downstream.  A wrong kernel shows up as an error of
     # order one on some tensor (a transposed weight layout read 1.43), so the bounds sit above the spread, not at twice one draw.
-    assert worst[1] < 2.0e-1, worst
-    assert float(np.median(list(errs.values()))) < 6e-2
+    # Round 5, this batch (18 x 1000, packed rows on both sides): worst 0.0535 (layer-0 linear_pos.weight), median 0.0032.
+    assert worst[1] < 1.5e-1, worst
+    assert float(np.median(list(errs.values()))) < 2e-2
 
 
 def test_config2p_bf16_packed_eval_forward_against_oracle_on_rounded_weights():
@@ -311,8 +312,8 @@ def test_config2p_bf16_packed_eval_forward_against_oracle_on_rounded_weights():
     print("packed bf16 eval vs oracle on rounded weights: encoder_out %.4f ctc_logit %.4f decoder logits %.4f" % (e1, e2, e3))
     # bf16 activations through 4 Conformer layers + 2 decoder layers: the padded layout measures 0.6 - 1.2 % of the tensor's
     # largest magnitude (BF16_BOUNDS of test_model_parity_gpu.py are set the same way); per frame the packed layout computes
-    # the same arithmetic
-    assert e1 < 3e-2 and e2 < 3e-2 and e3 < 3e-2, (e1, e2, e3)
+    # the same arithmetic.  Measured on MI355X (round 5): 0.0111 / 0.0070 / 0.0032.
+    assert e1 < 2.5e-2 and e2 < 1.5e-2 and e3 < 1e-2, (e1, e2, e3)
     eo = enc["encoder_out"][0].float().cpu()
     assert float(eo[~fm].abs().max()) == 0.0  # the unpacked view's padded frames are zero rows
     # CTC-greedy ids of the packed decode (bf16 logits) against the oracle's ids: a frame may differ only where the oracle's own
@@ -457,4 +458,6 @@ def test_config2p_bf16_shipped_kernels_are_as_close_to_the_oracle_as_the_compose
     # mis-addressed row reads 1.0 on its tensor: a ratio of 50 - 100.
     for k in names:
         assert mean["shipped"][k] <= 2.0 * mean["composed"][k] + 0.01, (k, mean["shipped"][k], mean["composed"][k])
-    assert worst["shipped"] < 0.11 and med["shipped"] < 0.025, (worst, med)
+    # round 5 on this batch: three-seed means worst tensor 0.048 (shipped) / 0.049 (composed), median 0.0033 / 0.0033; the largest
+    # per-tensor ratio x1.12
+    assert worst["shipped"] < 0.11 and med["shipped"] < 0.012, (worst, med)

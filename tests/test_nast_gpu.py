@@ -214,7 +214,8 @@ def test_nast_recipe_width_d512_h8_bf16_against_oracle_on_rounded_weights():
               "inter_ctc": rel_on(enc["inter_ctc_logits"][0], enc_o["inter_ctc_logits"][0]),
               "inter_xctc": rel_on(enc["inter_xctc_logits"][0], enc_o["inter_xctc_logits"][0])}
         print("NAST d512 bf16 eval vs oracle on rounded weights:", {k: round(v, 4) for k, v in ev.items()})
-        assert max(ev.values()) < 4e-2, ev
+        # measured on MI355X (round 5): encoder_out 0.0119, ctc 0.0069, xctc 0.0065, inter-CTC 0.0057, inter-XCTC 0.0068
+        assert max(ev.values()) < 2.5e-2, ev
         model.train()
         crit = C.CtcCriterion(None, task, ctc_weight=1.0, inter_ctc_weight=1.0, xctc_weight=1.0, inter_xctc_weight=1.0)
         crit.train()
@@ -230,7 +231,7 @@ def test_nast_recipe_width_d512_h8_bf16_against_oracle_on_rounded_weights():
     loss_o, log_o, _ = O.ctc_criterion_loss(W, cfg, src, lens, target, transcript=target, training=True)
     loss_o.backward()
     for k in ("ctc_loss", "inter_ctc_loss", "xctc_loss", "inter_xctc_loss"):
-        ref = float(log_o[k])
+        ref = float(log_o[k].detach())
         assert abs(float(log[k]) - ref) <= 1e-2 * abs(ref), (k, float(log[k]), ref)
     ptr = {k: v.data_ptr() for k, v in model.state_dict().items()}
     errs = {}
@@ -250,4 +251,5 @@ def test_nast_recipe_width_d512_h8_bf16_against_oracle_on_rounded_weights():
     med = float(np.median(list(errs.values())))
     print("NAST d512 bf16 gradients vs oracle: worst %s %.4f, median %.4f over %d tensors" % (worst[0], worst[1], med, len(errs)))
     assert len(errs) > 60
-    assert worst[1] < 2.5e-1 and med < 5e-2, (worst, med)
+    # measured on MI355X (round 5): worst 0.0365 (acoustic layer 0 conv_norm.weight), median 0.0019 over 127 tensors
+    assert worst[1] < 8e-2 and med < 6e-3, (worst, med)
