@@ -225,7 +225,8 @@ int s2t_attn_fused_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k,
  * floats apart (1 and 0 to accumulate in place; with the [replicas][2][cols] workspace of s2t_layernorm_fold the adds of the
  * thousand workgroups no longer serialise on 2 x 64 addresses per head).
  * bf16, dk == 64, ldb % 8 == 0, 16-byte aligned dbd / pos_pt, 8-byte aligned dq rows. */
-/* The same branch AND this call's share of the position-table gradient in one pass over dbd (csrc/relpos_glue.hip; Tq <= 256):
+/* The same branch AND this call's share of the position-table gradient in one pass over dbd (csrc/relpos_glue.hip; any Tq:
+ * beyond 256 frames the position rows are walked in chunks of 512, every piece of a row's band still read once):
  *   dq += dqv and the two column sums as s2t_relpos_dqv (pos_p: the projected positions [2Tq-1][p_sr] as the forward takes
  *   them, not the transposed table),
  *   dp[n][h*64+c] = sum_{b,i} dbd[h][b][i][n] * qv[b*Tq+i][h*64+c]   (fp32 [2Tq-1][H*64], OVERWRITTEN: the gradient w.r.t. the
@@ -239,7 +240,12 @@ int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_s
                     int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, void* dp_part, float* dp,
                     int B, int H, int Tq, int dk,
                     const int32_t* cu /* packed batch (dq rows of utterance b from cu[b]; dbd and qv as s2t_attn_fused_bwd left
-                    them), or NULL */, void* stream);
+                    them), or NULL */,
+                    void* dq_lo /* Tq > 256 only, optional: scratch [B*Tq][H*64] bf16 (need not be initialised).  The 2Tq - 1
+                    position rows are then walked in chunks of 512 and dq takes every chunk's share in turn; with dq_lo the
+                    rounding remainder of the running bf16 sum travels from chunk to chunk, so that dq is rounded ONCE as in the
+                    one-chunk form (without it: once per chunk a row's band meets, 2 at 502 frames, 3 at 1004) */,
+                    void* stream);
 int s2t_relpos_dqv(const void* dbd, int64_t ldb, const void* pos_pt, int64_t pt_ld, void* dq, int64_t dq_sb, int64_t dq_sr,
                    float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, int B, int H, int Tq, int dk,
                    void* stream);

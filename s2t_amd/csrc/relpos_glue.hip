@@ -14,6 +14,12 @@
 // 128 MFMAs (16x16x32) each per tile; wave w owns one (channel tile, query tile) result of (1) and position tiles 4w .. 4w+3
 // of (2) (64 accumulator registers, kept across the query tiles).  The partial dp leaves as bf16 rows of 128 bytes; a second
 // kernel sums the B partials of a head in fp32 (s2t_relpos_glue's dp output, what the linear_pos weight gradient reads).
+// Round 5: sequences beyond 256 frames (the PDS stages: T' = 1004 / 502).  The 2T - 1 position rows no longer fit one image, so
+// the workgroup walks them in CHUNKS of 512: per chunk it stages that part of the position image, visits only the query tiles
+// whose band [T-1-i, T-1-i+len) meets the chunk (and only the chunk's 512 columns of their dbd rows: every (tile, chunk) piece
+// of the band is still read exactly once), adds the chunk's share of dqv into dq (the same lane updates the same dq elements in
+// every chunk: program order), and stores the chunk's rows of the partial table.  The pos_bias_u column sum takes a row's dq
+// value in the chunk that holds the low end of its band (before any update).  T' <= 256 is one chunk: the round-3 kernel.
 #include "common.h"
 
 namespace {
@@ -85,6 +91,8 @@ struct GlueArgs {
   float *du, *dv;      // column-sum targets (replicated)
   int replicas;
   int64_t replica_stride;
+  bf16_t* dq_lo;       // optional [B*Tq][H*64] scratch (Tq > 256): what the bf16 rounding of a row's RUNNING dq sum dropped,
+                       // carried from one position chunk to the next so that dq is rounded once, as in the one-chunk form
   bf16_t* dp_part;     // [B][2Tq-1][H*64]
   int B, H, Tq;
   const int32_t* cu;   // packed batch: rows of utterance b in dq = cu[b] .. cu[b+1] (dbd / qv keep their padded row strides)
@@ -128,138 +136,190 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
   const bf16_t* slab = a.dbd + (((int64_t)h * a.B + b) * a.Tq) * a.ldb;
   const int nchunk = (int)(a.ldb / 8);  // 16-byte chunks per dbd row (<= 64)
 
-  f32x4 dp[4][4];  // [position tile 4w + nt][channel tile]
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
   const int ct1 = w & 3, qh = w >> 2;  // product (1): channel tile ct1, query tile qh of the 32-query tile
+  const int nck = (npos + NP - 1) / NP;  // chunks of position rows / dbd columns
+  bf16_t* out = a.dp_part + ((int64_t)b * npos) * d + h * DK;
 
-  // 32-query tiles, double buffered: the next tile's rows travel global -> registers during this tile's products and are
-  // written to the other LDS buffer behind them (one barrier per tile)
-  uint4 tr[4], tqv = make_uint4(0, 0, 0, 0);
-  uint2 old_n = make_uint2(0, 0);  // the dq values this lane updates in the NEXT tile (a global round trip per tile otherwise)
-  auto tile_load = [&](int q0) __attribute__((always_inline)) {
+  for (int ck = 0; ck < nck; ++ck) {
+    const int n0 = ck * NP;
+    // query rows whose band [Tq-1-i, Tq-1-i+nq) meets the chunk's columns [n0, n0 + NP); whole 32-query tiles of them
+    const int i_lo = max(0, a.Tq - NP - n0), i_hi = min(nq - 1, a.Tq + nq - 2 - n0);
+    const int q_lo = i_lo & ~(TQ - 1);
+    const int jc0 = n0 / 8;
+    // the tile ranges of the neighbouring chunks: a tile's FIRST visit starts its remainder at zero, its LAST one drops it
+    const int p_lo = max(0, a.Tq - NP - (n0 - NP)) & ~(TQ - 1), p_hi = ck > 0 ? min(nq - 1, a.Tq + nq - 2 - (n0 - NP)) : -1;
+    const int x_lo = max(0, a.Tq - NP - (n0 + NP)) & ~(TQ - 1), x_hi = ck + 1 < nck ? min(nq - 1, a.Tq + nq - 2 - (n0 + NP)) : -1;
+    f32x4 dp[4][4];  // [position tile 4w + nt of the chunk][channel tile]
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = tid + 512 * u;
-      const int q = min(q0 + (c >> 6), nq - 1), jc = min(c & 63, nchunk - 1);
-      tr[u] = *reinterpret_cast<const uint4*>(slab + (int64_t)q * a.ldb + jc * 8);
-    }
-    if (tid < 256)
-      tqv = *reinterpret_cast<const uint4*>(a.qv + ((int64_t)b * a.Tq + min(q0 + (tid >> 3), nq - 1)) * d + h * DK + (tid & 7) * 8);
-    old_n = *reinterpret_cast<const uint2*>(a.dq + (int64_t)b * a.dq_sb + (int64_t)min(q0 + 16 * qh + x, nq - 1) * a.dq_sr + h * DK +
-                                            16 * ct1 + 4 * y);
-  };
-  auto tile_store = [&](int q0, int buf) __attribute__((always_inline)) {
-    char* ldb_ = ld + buf * (TQ * 1024);
-    char* lqb = lq + buf * (TQ * 128);
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = tid + 512 * u;
-      const int q = c >> 6, jc = c & 63;
-      const bool ok = q0 + q < nq && jc < nchunk;
-      uint4 v = tr[u];
-      if (a.cu) {  // (workgroup-uniform)
-        const int rem = a.Tq - 1 - (q0 + q) + nq - 8 * jc;  // columns of this piece below the row's written band end
-        if (rem < 8) v = rem > 0 ? keep_first(v, rem) : make_uint4(0, 0, 0, 0);
+      for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // 32-query tiles, double buffered: the next tile's rows travel global -> registers during this tile's products and are
+    // written to the other LDS buffer behind them (one barrier per tile)
+    uint4 tr[4], tqv = make_uint4(0, 0, 0, 0);
+    uint2 old_n = make_uint2(0, 0);  // the dq values this lane updates in the NEXT tile (a global round trip per tile otherwise)
+    auto tile_load = [&](int q0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + 512 * u;
+        const int q = min(q0 + (c >> 6), nq - 1), jc = min(jc0 + (c & 63), nchunk - 1);
+        tr[u] = *reinterpret_cast<const uint4*>(slab + (int64_t)q * a.ldb + jc * 8);
       }
-      *reinterpret_cast<uint4*>(ldb_ + q * 1024 + ((jc ^ key1024(q)) << 4)) = ok ? v : make_uint4(0, 0, 0, 0);
-    }
-    if (tid < 256) {
-      const int qr = tid >> 3;
-      *reinterpret_cast<uint4*>(lqb + qr * 128 + (((tid & 7) ^ key128(qr)) << 4)) = q0 + qr < nq ? tqv : make_uint4(0, 0, 0, 0);
-    }
-  };
-  tile_load(0);  // (in flight together with the position rows below: one global round trip for both)
-  // ---- the head's projected position rows (rows >= 2T-1 zero)
-  {
-    const bf16_t* pp = a.pos_p + h * DK;
-    uint4 t[8];
+      if (tid < 256)
+        tqv = *reinterpret_cast<const uint4*>(a.qv + ((int64_t)b * a.Tq + min(q0 + (tid >> 3), nq - 1)) * d + h * DK + (tid & 7) * 8);
+      old_n = *reinterpret_cast<const uint2*>(a.dq + (int64_t)b * a.dq_sb + (int64_t)min(q0 + 16 * qh + x, nq - 1) * a.dq_sr + h * DK +
+                                              16 * ct1 + 4 * y);
+    };
+    auto tile_store = [&](int q0, int buf) __attribute__((always_inline)) {
+      char* ldb_ = ld + buf * (TQ * 1024);
+      char* lqb = lq + buf * (TQ * 128);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = tid + 512 * u;
-      const int n = min(c >> 3, npos - 1);
-      t[u] = *reinterpret_cast<const uint4*>(pp + (int64_t)n * a.p_sr + (c & 7) * 8);
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + 512 * u;
+        const int q = c >> 6, jc = c & 63;
+        const bool ok = q0 + q < nq && jc0 + jc < nchunk;
+        uint4 v = tr[u];
+        if (a.cu) {  // (workgroup-uniform)
+          const int rem = a.Tq - 1 - (q0 + q) + nq - (n0 + 8 * jc);  // columns of this piece below the row's written band end
+          if (rem < 8) v = rem > 0 ? keep_first(v, rem) : make_uint4(0, 0, 0, 0);
+        }
+        *reinterpret_cast<uint4*>(ldb_ + q * 1024 + ((jc ^ key1024(q)) << 4)) = ok ? v : make_uint4(0, 0, 0, 0);
+      }
+      if (tid < 256) {
+        const int qr = tid >> 3;
+        *reinterpret_cast<uint4*>(lqb + qr * 128 + (((tid & 7) ^ key128(qr)) << 4)) = q0 + qr < nq ? tqv : make_uint4(0, 0, 0, 0);
+      }
+    };
+    const bool any = i_hi >= i_lo;
+    if (any) tile_load(q_lo);  // (in flight together with the position rows below: one global round trip for both)
+    // ---- the chunk's projected position rows of the head (rows >= 2T-1 zero)
+    if (any) {
+      const bf16_t* pp = a.pos_p + h * DK;
+      uint4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = tid + 512 * u;
+        const int n = min(n0 + (c >> 3), npos - 1);
+        t[u] = *reinterpret_cast<const uint4*>(pp + (int64_t)n * a.p_sr + (c & 7) * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = tid + 512 * u;
+        const int n = c >> 3, ch = c & 7;
+        *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ key128(n)) << 4)) = n0 + n < npos ? t[u] : make_uint4(0, 0, 0, 0);
+      }
+      tile_store(q_lo, 0);
     }
+    __syncthreads();  // (also orders the position image)
+    int buf = 0;
+    for (int q0 = q_lo; any && q0 <= i_hi; q0 += TQ, buf ^= 1) {
+      const bool more = q0 + TQ <= i_hi;
+      const uint2 old = old_n;
+      const bool seen = a.dq_lo && q0 >= p_lo && q0 <= p_hi;    // an earlier chunk visited this tile and left its remainder
+      const bool again = a.dq_lo && q0 >= x_lo && q0 <= x_hi;   // the next chunk visits it too
+      if (more && !((S2T_GLUE_DBG & 4) && q0 > 0)) tile_load(q0 + TQ);
+      const char* ldc = ld + buf * (TQ * 1024);
+      const char* lqc = lq + buf * (TQ * 128);
+      // ---- (1) dqv^T[c][q] over K = the chunk's 512 position columns
+      // (hipcc sinks every fragment read to just in front of its MFMA — one exposed LDS round trip per MFMA of this dependent
+      // chain: the reads run one group of four k-steps ahead by hand, two accumulators halve the chain; the fragments of
+      // product (2) are read behind the last group's)
+      f32x4 acc, acc1 = {0.f, 0.f, 0.f, 0.f};
+      acc = acc1;
+      const int i = q0 + 16 * qh + x;
+      bf16x8 qa[4], dbn[4];
+      {
+        const int q = 16 * qh + x;
+        bf16x8 PA[2][4], DB[2][4];
+        auto rd1 = [&](int g, int sl) __attribute__((always_inline)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ks = 4 * g + j;
+            PA[sl][j] = cols128(lp, 0, ct1, ks, x, y);
+            DB[sl][j] = as_frag(*reinterpret_cast<const uint4*>(ldc + q * 1024 + (((4 * ks + y) ^ key1024(q)) << 4)));
+          }
+        };
+        rd1(0, 0);
+#pragma unroll
+        for (int g = 0; g < NP / 128; ++g) {
+          if (g + 1 < NP / 128) {
+            rd1(g + 1, (g + 1) & 1);
+          } else {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) qa[ct] = cols128(lqc, 0, ct, 0, x, y);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) dbn[nt] = cols1024(ldc, 4 * w + nt, 0, x, y);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+            if (S2T_GLUE_DBG & 1) continue;
+            acc = mfma16(PA[g & 1][j], DB[g & 1][j], acc);
+            acc1 = mfma16(PA[g & 1][j + 1], DB[g & 1][j + 1], acc1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        acc += acc1;
+      }
+      if (i < nq && !(S2T_GLUE_DBG & 8)) {
+        const float o4[4] = {__uint_as_float(old.x << 16), __uint_as_float(old.x & 0xffff0000u), __uint_as_float(old.y << 16),
+                             __uint_as_float(old.y & 0xffff0000u)};
+        const bool first = (a.Tq - 1 - i) / NP == ck;  // the chunk that holds the low end of this row's band: dq is still untouched
+        bf16_t* lop = a.dq_lo ? a.dq_lo + ((int64_t)b * a.Tq + i) * d + h * DK + 16 * ct1 + 4 * y : nullptr;
+        float l4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (seen) {
+          const uint2 lv = *reinterpret_cast<const uint2*>(lop);
+          l4[0] = __uint_as_float(lv.x << 16); l4[1] = __uint_as_float(lv.x & 0xffff0000u);
+          l4[2] = __uint_as_float(lv.y << 16); l4[3] = __uint_as_float(lv.y & 0xffff0000u);
+        }
+        float n4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (first) su[r] += o4[r];
+          sv[r] += acc[r];
+          n4[r] = o4[r] + l4[r] + acc[r];
+        }
+        st4_from_f32<bf16_t>(a.dq + (int64_t)b * a.dq_sb + (int64_t)i * a.dq_sr + h * DK + 16 * ct1 + 4 * y, n4);
+        if (again) {
+          float r4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) r4[r] = n4[r] - bf2f(f2bf(n4[r]));
+          st4_from_f32<bf16_t>(lop, r4);
+        }
+      }
+      // ---- (2) dp^T[c][n] += qv^T[c][q] dbd[q][n] over the tile's 32 queries (one k-step)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          if (!(S2T_GLUE_DBG & 2)) dp[nt][ct] = mfma16(qa[ct], dbn[nt], dp[nt][ct]);
+      if (more) tile_store(q0 + TQ, buf ^ 1);  // (the other buffer was last read a tile ago, behind the previous barrier)
+      __syncthreads();
+    }
+    // ---- the chunk's dp^T -> [n][64 channels] bf16 rows in LDS (the position image's place: every product of the chunk is
+    // done), then whole 128-byte rows to the partial table (zeros where no query row met the chunk: every row of the table is
+    // written, the reduction sums all utterances).
+    // lane (n = x, y) of tile nt holds channels 16 ct + 4 y + r of position n0 + 16 (4 w + nt) + x
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = 16 * (4 * w + nt) + x;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const uint2 v = make_uint2(bf16pack(dp[nt][ct][0], dp[nt][ct][1]), bf16pack(dp[nt][ct][2], dp[nt][ct][3]));
+        *reinterpret_cast<uint2*>(lp + n * 128 + (((2 * ct + (y >> 1)) ^ (n & 7)) << 4) + (y & 1) * 8) = v;
+      }
+    }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int c = tid + 512 * u;
       const int n = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ key128(n)) << 4)) = n < npos ? t[u] : make_uint4(0, 0, 0, 0);
+      if (n0 + n < npos && !(S2T_GLUE_DBG & 16))
+        *reinterpret_cast<uint4*>(out + (int64_t)(n0 + n) * d + ch * 8) = *reinterpret_cast<const uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4));
     }
-  }
-  tile_store(0, 0);
-  __syncthreads();  // (also orders the position image)
-  int buf = 0;
-  for (int q0 = 0; q0 < nq; q0 += TQ, buf ^= 1) {
-    const bool more = q0 + TQ < nq;
-    const uint2 old = old_n;
-    if (more && !((S2T_GLUE_DBG & 4) && q0 > 0)) tile_load(q0 + TQ);
-    const char* ldc = ld + buf * (TQ * 1024);
-    const char* lqc = lq + buf * (TQ * 128);
-    // ---- (1) dqv^T[c][q] over K = the 512 position columns
-    // (hipcc sinks every fragment read to just in front of its MFMA — one exposed LDS round trip per MFMA of this dependent
-    // chain: the reads run one group of four k-steps ahead by hand, two accumulators halve the chain; the fragments of
-    // product (2) are read behind the last group's)
-    f32x4 acc, acc1 = {0.f, 0.f, 0.f, 0.f};
-    acc = acc1;
-    const int i = q0 + 16 * qh + x;
-    bf16x8 qa[4], dbn[4];
-    {
-      const int q = 16 * qh + x;
-      bf16x8 PA[2][4], DB[2][4];
-      auto rd1 = [&](int g, int sl) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ks = 4 * g + j;
-          PA[sl][j] = cols128(lp, 0, ct1, ks, x, y);
-          DB[sl][j] = as_frag(*reinterpret_cast<const uint4*>(ldc + q * 1024 + (((4 * ks + y) ^ key1024(q)) << 4)));
-        }
-      };
-      rd1(0, 0);
-#pragma unroll
-      for (int g = 0; g < NP / 128; ++g) {
-        if (g + 1 < NP / 128) {
-          rd1(g + 1, (g + 1) & 1);
-        } else {
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) qa[ct] = cols128(lqc, 0, ct, 0, x, y);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) dbn[nt] = cols1024(ldc, 4 * w + nt, 0, x, y);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-          if (S2T_GLUE_DBG & 1) continue;
-          acc = mfma16(PA[g & 1][j], DB[g & 1][j], acc);
-          acc1 = mfma16(PA[g & 1][j + 1], DB[g & 1][j + 1], acc1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      acc += acc1;
-    }
-    if (i < nq && !(S2T_GLUE_DBG & 8)) {
-      const float o4[4] = {__uint_as_float(old.x << 16), __uint_as_float(old.x & 0xffff0000u), __uint_as_float(old.y << 16),
-                           __uint_as_float(old.y & 0xffff0000u)};
-      float n4[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        su[r] += o4[r];
-        sv[r] += acc[r];
-        n4[r] = o4[r] + acc[r];
-      }
-      st4_from_f32<bf16_t>(a.dq + (int64_t)b * a.dq_sb + (int64_t)i * a.dq_sr + h * DK + 16 * ct1 + 4 * y, n4);
-    }
-    // ---- (2) dp^T[c][n] += qv^T[c][q] dbd[q][n] over the tile's 32 queries (one k-step)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-        if (!(S2T_GLUE_DBG & 2)) dp[nt][ct] = mfma16(qa[ct], dbn[nt], dp[nt][ct]);
-    if (more) tile_store(q0 + TQ, buf ^ 1);  // (the other buffer was last read a tile ago, behind the previous barrier)
-    __syncthreads();
+    __syncthreads();  // (the next chunk's position image goes where these rows were read from)
   }
   // ---- column sums of the two branches: 16 query lanes by shuffles, the two waves of a channel tile through LDS, one atomic
   // per channel and branch into a replica of the workspace
@@ -285,26 +345,6 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
     const float sum = red[(br * 8 + ct) * 64 + sl] + red[(br * 8 + ct + 4) * 64 + sl];
     const int64_t ro = (int64_t)(z % a.replicas) * a.replica_stride;
     atomicAdd((br ? a.dv : a.du) + ro + h * DK + c, sum);
-  }
-  // ---- dp^T -> [n][64 channels] bf16 rows in LDS (the position image's place: every product is done), then whole 128-byte
-  // rows to the partial table.
-  // lane (n = x, y) of tile nt holds channels 16 ct + 4 y + r of position 16 (4 w + nt) + x
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int n = 16 * (4 * w + nt) + x;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const uint2 v = make_uint2(bf16pack(dp[nt][ct][0], dp[nt][ct][1]), bf16pack(dp[nt][ct][2], dp[nt][ct][3]));
-      *reinterpret_cast<uint2*>(lp + n * 128 + (((2 * ct + (y >> 1)) ^ (n & 7)) << 4) + (y & 1) * 8) = v;
-    }
-  }
-  __syncthreads();
-  bf16_t* out = a.dp_part + ((int64_t)b * npos) * d + h * DK;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int c = tid + 512 * u;
-    const int n = c >> 3, ch = c & 7;
-    if (n < npos && !(S2T_GLUE_DBG & 16)) *reinterpret_cast<uint4*>(out + (int64_t)n * d + ch * 8) = *reinterpret_cast<const uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4));
   }
 }
 
@@ -354,11 +394,12 @@ __global__ __launch_bounds__(256) void relpos_dp_reduce_kernel(const DpBatch bat
 
 extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_sr, const void* qv, void* dq,
                                int64_t dq_sb, int64_t dq_sr, float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride,
-                               void* dp_part, float* dp, int B, int H, int Tq, int dk, const int32_t* cu, void* stream) {
+                               void* dp_part, float* dp, int B, int H, int Tq, int dk, const int32_t* cu, void* dq_lo,
+                               void* stream) {
   if (!dbd || !pos_p || !qv || !dq || !dpos_u || !dpos_v || !dp_part || B <= 0 || H <= 0 || Tq <= 0 || replicas < 1)
     return S2T_ERR_ARG;
-  if (dk != DK || 2 * Tq - 1 > NP - 1) return S2T_ERR_UNSUPPORTED;
-  if (ldb < 2 * Tq - 1 || ldb % 8 || ldb > NP || p_sr % 8 || dq_sr % 4 || dq_sb % 4) return S2T_ERR_ARG;
+  if (dk != DK || Tq > 32768) return S2T_ERR_UNSUPPORTED;
+  if (ldb < 2 * Tq - 1 || ldb % 8 || p_sr % 8 || dq_sr % 4 || dq_sb % 4) return S2T_ERR_ARG;
   if (((uintptr_t)dbd % 16) || ((uintptr_t)pos_p % 16) || ((uintptr_t)qv % 16) || ((uintptr_t)dq % 8) || ((uintptr_t)dp_part % 16) ||
       (dp && ((uintptr_t)dp % 16)))
     return S2T_ERR_ALIGN;
@@ -366,6 +407,8 @@ extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, 
   a.dbd = (const bf16_t*)dbd; a.ldb = ldb; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr; a.qv = (const bf16_t*)qv;
   a.dq = (bf16_t*)dq; a.dq_sb = dq_sb; a.dq_sr = dq_sr; a.du = dpos_u; a.dv = dpos_v; a.replicas = replicas;
   a.replica_stride = replica_stride; a.dp_part = (bf16_t*)dp_part; a.B = B; a.H = H; a.Tq = Tq; a.cu = cu;
+  if (dq_lo && ((uintptr_t)dq_lo % 8)) return S2T_ERR_ALIGN;
+  a.dq_lo = 2 * Tq - 1 > NP ? (bf16_t*)dq_lo : nullptr;  // (one chunk: one rounding anyway)
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(relpos_glue_kernel, dim3(B * H), dim3(512), 0, s, a);
   if (dp) {  // (dp == NULL: the caller sums the partial tables later, several layers per launch: s2t_relpos_dp_reduce)

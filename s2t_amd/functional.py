@@ -1413,7 +1413,7 @@ class AttentionFn(torch.autograd.Function):
                          o_lo=getattr(ctx, "o_lo", None))
         ctx.o_lo = None
         glue_done = False
-        if rel and _RELPOS_GLUE and pt is None and dt == torch.bfloat16 and dk == 64 and Tq <= 256 and ldq % 4 == 0 and _arm_backward_end():
+        if rel and _RELPOS_GLUE and pt is None and dt == torch.bfloat16 and dk == 64 and Tq <= _GLUE_MAX_T and ldq % 4 == 0 and _arm_backward_end():
             # everything behind dbd in ONE pass over it (csrc/relpos_glue.hip): the (Q+v) branch added into dq, both bias
             # gradients (column sums into the replicated workspace, folded with the LayerNorm gradients) and this layer's
             # gradient w.r.t. the projected positions, queued for the batched linear_pos weight gradient
@@ -2373,6 +2373,9 @@ def ctc_compress_plan(logit2d, lens32, B, T, blank, threshold):
 # SATE adapter (inter_league)
 # ------------------------------------------------------------------------------------------------
 _POS32 = {}
+# s2t_relpos_glue walks the position rows in chunks of 512 (round 5): any length; S2T_GLUE_MAX_T=256 restores the round-4 routing
+# (longer sequences through s2t_relpos_dqv + the split-K position-table GEMM, padded rows only) for A/B measurements
+_GLUE_MAX_T = int(os.environ.get("S2T_GLUE_MAX_T", "32768"))
 _RELPOS_GLUE = os.environ.get("S2T_RELPOS_GLUE", "1") != "0"  # s2t_relpos_glue: (Q+v) branch + bias sums + position-table gradient in one pass over dbd
 _DP_SPLIT = int(os.environ.get("S2T_DP_SPLIT", "16"))  # K split of the position-table gradient GEMM (M = 2T-1, N = 64 per head, K = B*T)
 _POSW_SPLIT = int(os.environ.get("S2T_POSW_SPLIT", "0"))  # experiment: K split of the small fp32 linear_pos weight-gradient GEMM

@@ -849,9 +849,12 @@ def relpos_glue(dbd, ldb, pos_p, p_sr, qv, dq, dq_sb, dq_sr, dpos_u, dpos_v, dp,
     assert dp.dtype == torch.float32 and dp.is_contiguous() and dp.shape == (2 * Tq - 1, H * dk) and qv.is_contiguous()
     tag = "relpos_dp_part" if defer_slot is None else "relpos_dp_part%d" % defer_slot
     part = _scratch(tag, (B * (2 * Tq - 1) * H * dk + 1) // 2, dbd.device)  # fp32 scratch holding the bf16 partials
+    # beyond 256 frames: the remainder of dq's running bf16 sum between position chunks (one buffer for every layer: a call
+    # reads only what it wrote itself)
+    lo = _scratch("relpos_dq_lo", (B * Tq * H * dk + 1) // 2, dbd.device) if Tq > 256 else None
     _call("s2t_relpos_glue", dbd.data_ptr(), ldb, pos_p.data_ptr(), p_sr, qv.data_ptr(), dq.data_ptr(), dq_sb, dq_sr,
           dpos_u.data_ptr(), dpos_v.data_ptr(), replicas, replica_stride, part.data_ptr(),
-          dp.data_ptr() if defer_slot is None else None, B, H, Tq, dk, _cu(rows))
+          dp.data_ptr() if defer_slot is None else None, B, H, Tq, dk, _cu(rows), _ptr(lo))
     return part
 
 

@@ -161,9 +161,9 @@ class PDSS2TTransformerEncoder(nn.Module):
             # Packed rows for the stage's layers where every kernel takes them (bf16, d = 256, heads of 64, enough rows): the
             # down-sampling convolution in front of the next stage reads padded rows again (zero padded frames: what its own
             # input mask makes of them, pdss2t_transformer.py:1100-1117)
-            # (relative positions: the backward behind the skewed score gradient is s2t_relpos_glue, which holds up to 256 frames)
+            # (relative positions: the backward behind the skewed score gradient is s2t_relpos_glue — any length since round 5)
             pk = (Rows.ENABLED and dt == torch.bfloat16 and d == 256 and self.pds_attn_heads[i] * 64 == d and B * Tn >= Rows.MIN_ENC_ROWS
-                  and Tn <= 65535 and not self.fusion_stages and (self.attn_type != "rel_pos" or Tn <= 256 or not torch.is_grad_enabled())
+                  and Tn <= 65535 and not self.fusion_stages and (self.attn_type != "rel_pos" or Tn <= Fn._GLUE_MAX_T or not torch.is_grad_enabled())
                   # (weight gradients over packed rows: the 256 x 256 grouped kernel's operand rules, S2TTransformerEncoder._packed_ok)
                   and (not torch.is_grad_enabled() or Fn.wgrad256_eligible(
                       B * Tn, max(d * self.pds_ffn_ratios[i], 3 * d,

@@ -166,8 +166,8 @@ class S2TTransformerEncoder(nn.Module):
         h = getattr(self.layers[0].self_attn, "num_heads", None) or getattr(self.layers[0].self_attn, "h", 0)
         if h * 64 != self.embed_dim or self.inter_ctc_layers or self.compression_layers:
             return False
-        if self.attn_type == "rel_pos" and Tp > 256 and torch.is_grad_enabled():
-            return False  # the relative-position BACKWARD behind the skewed score gradient (s2t_relpos_glue) holds 256 frames
+        if self.attn_type == "rel_pos" and Tp > Fn._GLUE_MAX_T and torch.is_grad_enabled():
+            return False  # (S2T_GLUE_MAX_T: the round-4 routing of the relative-position backward, padded rows only)
         if torch.is_grad_enabled():
             # weight gradients over packed rows exist on the 256 x 256 grouped kernel only (it reads the live row count on the
             # device): its operand rules must hold for the widest operands of this stack — the feed-forward hidden activation and
