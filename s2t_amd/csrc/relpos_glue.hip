@@ -109,6 +109,8 @@ __device__ __forceinline__ uint4 keep_first(uint4 v, int rem) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// MULTI: more than one chunk of position rows (2Tq - 1 > 512); false compiles the chunk walk away (the round-3 kernel)
+template <bool MULTI>
 __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
   __shared__ __attribute__((aligned(16))) char lds[L_BYTES];
   GlueArgs a = a_in;
@@ -138,13 +140,13 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
 
   float su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
   const int ct1 = w & 3, qh = w >> 2;  // product (1): channel tile ct1, query tile qh of the 32-query tile
-  const int nck = (npos + NP - 1) / NP;  // chunks of position rows / dbd columns
+  const int nck = MULTI ? (npos + NP - 1) / NP : 1;  // chunks of position rows / dbd columns
   bf16_t* out = a.dp_part + ((int64_t)b * npos) * d + h * DK;
 
   for (int ck = 0; ck < nck; ++ck) {
-    const int n0 = ck * NP;
+    const int n0 = MULTI ? ck * NP : 0;
     // query rows whose band [Tq-1-i, Tq-1-i+nq) meets the chunk's columns [n0, n0 + NP); whole 32-query tiles of them
-    const int i_lo = max(0, a.Tq - NP - n0), i_hi = min(nq - 1, a.Tq + nq - 2 - n0);
+    const int i_lo = MULTI ? max(0, a.Tq - NP - n0) : 0, i_hi = MULTI ? min(nq - 1, a.Tq + nq - 2 - n0) : nq - 1;
     const int q_lo = i_lo & ~(TQ - 1);
     const int jc0 = n0 / 8;
     // the tile ranges of the neighbouring chunks: a tile's FIRST visit starts its remainder at zero, its LAST one drops it
@@ -217,8 +219,8 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
     for (int q0 = q_lo; any && q0 <= i_hi; q0 += TQ, buf ^= 1) {
       const bool more = q0 + TQ <= i_hi;
       const uint2 old = old_n;
-      const bool seen = a.dq_lo && q0 >= p_lo && q0 <= p_hi;    // an earlier chunk visited this tile and left its remainder
-      const bool again = a.dq_lo && q0 >= x_lo && q0 <= x_hi;   // the next chunk visits it too
+      const bool seen = MULTI && a.dq_lo && q0 >= p_lo && q0 <= p_hi;    // an earlier chunk visited this tile and left its remainder
+      const bool again = MULTI && a.dq_lo && q0 >= x_lo && q0 <= x_hi;   // the next chunk visits it too
       if (more && !((S2T_GLUE_DBG & 4) && q0 > 0)) tile_load(q0 + TQ);
       const char* ldc = ld + buf * (TQ * 1024);
       const char* lqc = lq + buf * (TQ * 128);
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
       if (i < nq && !(S2T_GLUE_DBG & 8)) {
         const float o4[4] = {__uint_as_float(old.x << 16), __uint_as_float(old.x & 0xffff0000u), __uint_as_float(old.y << 16),
                              __uint_as_float(old.y & 0xffff0000u)};
-        const bool first = (a.Tq - 1 - i) / NP == ck;  // the chunk that holds the low end of this row's band: dq is still untouched
-        bf16_t* lop = a.dq_lo ? a.dq_lo + ((int64_t)b * a.Tq + i) * d + h * DK + 16 * ct1 + 4 * y : nullptr;
+        const bool first = !MULTI || (a.Tq - 1 - i) / NP == ck;  // the chunk that holds the low end of this row's band: dq is still untouched
+        bf16_t* lop = (MULTI && a.dq_lo) ? a.dq_lo + ((int64_t)b * a.Tq + i) * d + h * DK + 16 * ct1 + 4 * y : nullptr;
         float l4[4] = {0.f, 0.f, 0.f, 0.f};
         if (seen) {
           const uint2 lv = *reinterpret_cast<const uint2*>(lop);
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
       if (n0 + n < npos && !(S2T_GLUE_DBG & 16))
         *reinterpret_cast<uint4*>(out + (int64_t)(n0 + n) * d + ch * 8) = *reinterpret_cast<const uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4));
     }
-    __syncthreads();  // (the next chunk's position image goes where these rows were read from)
+    if (MULTI) __syncthreads();  // (the next chunk's position image goes where these rows were read from)
   }
   // ---- column sums of the two branches: 16 query lanes by shuffles, the two waves of a channel tile through LDS, one atomic
   // per channel and branch into a replica of the workspace
@@ -410,7 +412,8 @@ extern "C" int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, 
   if (dq_lo && ((uintptr_t)dq_lo % 8)) return S2T_ERR_ALIGN;
   a.dq_lo = 2 * Tq - 1 > NP ? (bf16_t*)dq_lo : nullptr;  // (one chunk: one rounding anyway)
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(relpos_glue_kernel, dim3(B * H), dim3(512), 0, s, a);
+  if (2 * Tq - 1 > NP) hipLaunchKernelGGL(relpos_glue_kernel<true>, dim3(B * H), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL(relpos_glue_kernel<false>, dim3(B * H), dim3(512), 0, s, a);
   if (dp) {  // (dp == NULL: the caller sums the partial tables later, several layers per launch: s2t_relpos_dp_reduce)
     const int64_t per_b = (int64_t)(2 * Tq - 1) * H * DK;
     DpBatch bt = {};
