@@ -72,6 +72,10 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(_CriterionBase):
             # packed rows (s2t_amd/rows.py): the head's logits as the encoder left them, utterance b from row cu[b]
             tmat, tl, _ = batch_bookkeeping(sample, self.padding_idx, self.eos_idx)
             ctc = Fn.ctc_loss(pk["ctc_logit"], B, pk["T"], tmat, tl, pk["rows"], self.blank_idx, side=_CTC_SIDE, rows=pk["rows"])
+            ipk = pk.get("inter_ctc_logit") or []
+            if self.inter_ctc_weight > 0 and len(ipk) > 0:  # criterions/ctc.py:568-633 on the packed heads (same rows, same lengths)
+                inter_loss = [Fn.ctc_loss(l2, B, pk["T"], tmat, tl, pk["rows"], self.blank_idx, side=_CTC_SIDE, rows=pk["rows"])
+                              for l2 in ipk]
         elif self.ctc_weight > 0 and len(enc["ctc_logit"]) > 0:
             ctc_tbv = enc["ctc_logit"][0]
             Tn = ctc_tbv.shape[0]

@@ -164,8 +164,11 @@ class S2TTransformerEncoder(nn.Module):
         if not Rows.ENABLED or dt != torch.bfloat16 or self.embed_dim != 256:
             return False
         h = getattr(self.layers[0].self_attn, "num_heads", None) or getattr(self.layers[0].self_attn, "h", 0)
-        if h * 64 != self.embed_dim or self.inter_ctc_layers or self.compression_layers:
-            return False
+        if h * 64 != self.embed_dim or self.compression_layers:
+            return False  # (CTC-guided compression rewrites the frame axis between the layers: padded rows)
+        if self.inter_ctc_layers and (self.ctc_pae_ground_truth_ratio > 0 or getattr(self, "decode_inter_logits", False)):
+            return False  # (intermediate heads run packed unless the ground-truth curriculum mixes (B, T) oracle labels in, or a
+                          #  decoder reads an intermediate head: --ctc-inter-logit)
         if self.attn_type == "rel_pos" and Tp > Fn._GLUE_MAX_T and torch.is_grad_enabled():
             return False  # (S2T_GLUE_MAX_T: the round-4 routing of the relative-position backward, padded rows only)
         if torch.is_grad_enabled():
@@ -220,7 +223,7 @@ class S2TTransformerEncoder(nn.Module):
             # halo rows are zero from Rows.pack on (dropout keeps zeros), and PackFn.backward drops the halo rows' gradient
             x = MaskRows.apply(x, lens32, Tp)
         n = len(self.layers)
-        inter_ctc_logits = []
+        inter_ctc_logits, inter_packed = [], []
         ctc_orc = ctc_force_emit = None
         # gradient stages (Fn.grad_stage, data-parallel steps only): where the weight gradients queued so far run and their
         # buckets start reducing beside the rest of backward (Fn.GRAD_STAGES)
@@ -246,14 +249,23 @@ class S2TTransformerEncoder(nn.Module):
                 norm = self.layer_norm if self.share_inter_ctc_norm else getattr(self, "ctc_norm%d" % L)
                 head = self.ctc if (self.use_ctc and self.share_inter_ctc) else getattr(self, "inter_ctc%d" % L)
                 pae = self.pae if self.share_inter_ctc else getattr(self, "pae%d" % L)
-                norm_x = norm(x)
+                rows_t = c.rows  # (packed rows: the tap's LayerNorm, head and PAE run on the frames only)
+                norm_x = norm(x, rows=rows_t)
                 # (an INTERMEDIATE head's logits feed the PAE softmax and the training losses: compute dtype, as in training;
                 # ctc_out_dtype = fp32 is for the logits that are decoded — CTCDecoder(--ctc-inter-logit k) decodes from an
                 # intermediate head and sets ``decode_inter_logits``: they then follow ctc_out_dtype)
                 logit2d = head(norm_x, out_dtype=self.ctc_out_dtype if (pae.adapter_type == "none" or getattr(
-                    self, "decode_inter_logits", False)) else None)
-                il = logit2d.view(B, Tp, -1).transpose(0, 1)
-                inter_logit = [il, encoder_padding_mask]  # the reference's [logit, padding mask] pairs
+                    self, "decode_inter_logits", False)) else None, rows=rows_t)
+                if rows_t is not None:
+                    # the (T, B, V) view is unpacked only if somebody reads it; this package's criterion takes the packed rows
+                    inter_packed.append(logit2d)
+                    inter_logit = Rows.LazyList([
+                        (lambda l2=logit2d, r=rows_t, T_=Tp: Rows.unpack(l2.contiguous(), r).view(B, T_, -1).transpose(0, 1)),
+                        (lambda m=encoder_padding_mask: m)])
+                    il = None
+                else:
+                    il = logit2d.view(B, Tp, -1).transpose(0, 1)
+                    inter_logit = [il, encoder_padding_mask]  # the reference's [logit, padding mask] pairs
                 orc = msk = None
                 if self.ctc_pae_ground_truth_ratio > 0:  # :1904-1935
                     oracle = (kwargs.get("ctc_alignment_oracle") or {}).get("ctc")
@@ -265,7 +277,7 @@ class S2TTransformerEncoder(nn.Module):
                         orc, msk = ctc_orc[0], ctc_orc[1]
                         inter_logit = [il, None, ctc_force_emit]
                 if pae.adapter_type != "none":
-                    x = pae(x if self.pae_unnorm_input else norm_x, logit2d, orc, msk)
+                    x = pae(x if self.pae_unnorm_input else norm_x, logit2d, orc, msk, rows=rows_t)
                 inter_ctc_logits.append(inter_logit)
                 if L in self.compression_layers:
                     x, lens32, Tp, encoder_padding_mask = self._compress(x, logit2d, L, B, Tp, lens32, encoder_padding_mask)
@@ -285,12 +297,12 @@ class S2TTransformerEncoder(nn.Module):
             # frames, as the reference's masked tensors hold); the consumers of this package take the packed rows under "packed"
             rows_ = c.rows
             logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype, rows=rows_) if self.use_ctc else None
-            packed = {"rows": rows_, "B": B, "T": Tp, "encoder_out": x, "ctc_logit": logit2d}
+            packed = {"rows": rows_, "B": B, "T": Tp, "encoder_out": x, "ctc_logit": logit2d, "inter_ctc_logit": inter_packed}
             enc_list = Rows.LazyList([lambda: Rows.unpack(x, rows_).view(B, Tp, d).transpose(0, 1)])
             ctc_list = [] if logit2d is None else Rows.LazyList(
                 [lambda: Rows.unpack(logit2d.contiguous(), rows_).view(B, Tp, -1).transpose(0, 1)])
             return {
-                "encoder_out": enc_list, "ctc_logit": ctc_list, "inter_ctc_logits": [], "xctc_logit": [],
+                "encoder_out": enc_list, "ctc_logit": ctc_list, "inter_ctc_logits": inter_ctc_logits, "xctc_logit": [],
                 "inter_xctc_logits": [], "encoder_padding_mask": [encoder_padding_mask], "mixup": None,
                 "encoder_embedding": [], "encoder_states": [], "src_tokens": [], "src_lengths": [], "packed": packed,
             }

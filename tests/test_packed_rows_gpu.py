@@ -610,3 +610,73 @@ def test_sate_textual_layers_run_packed_and_equal_the_padded_layout():
         errs.append(e)
         assert e <= 0.08, (k, e)
     assert float(np.median(errs)) <= 0.02
+
+
+@pytest.mark.parametrize("conformer", [True, False])
+def test_intermediate_ctc_taps_run_packed_and_equal_the_padded_layout(conformer):
+    """Intermediate CTC heads with prediction-aware encoding (egs/mustc/asr/conf/inter.yaml; models/speech_to_text/
+    s2t_transformer.py:1881-1946: tap LayerNorm -> shared head -> x = PAE(norm_x, logits)) on packed rows: the taps' LayerNorm,
+    projection, softmax and embedding product run on the frames only, the criterion takes the packed logits of every head.
+    Eval: encoder output and every head's logits on the frames equal the padded layout's bit for bit; one training pass: the
+    joint loss with the intermediate term and every gradient within the spread of two summation orders."""
+    def build():
+        torch.manual_seed(4)
+        a = M.recipe_args(conformer=conformer, vocab_size=V, encoder_layers=4, decoder_layers=1, inter_ctc_layers="2,3",
+                          share_inter_ctc=True, inter_ctc_weight=0.2, ctc_pae="inter_league")
+        model = M.S2TTransformerModel.build_model(a, M.FakeTask(V))
+        g = torch.Generator().manual_seed(12)
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+            for n_, b in model.named_buffers():
+                if n_.endswith("running_mean"):
+                    b.copy_(0.1 * torch.randn(b.shape, generator=g))
+                if n_.endswith("running_var"):
+                    b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g))
+        return model.prepare(torch.bfloat16, DEV)
+
+    sample, lens = _sample(24, 1000, 25)
+    ni = sample["net_input"]
+    sub = torch.tensor(lens)
+    for _ in range(2):
+        sub = torch.div(sub - 1, 2, rounding_mode="floor") + 1
+    _, old, _ = K.ffn_configure()
+    res = {}
+    for packed in (False, True):
+        model = build()
+        crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3, inter_ctc_weight=0.2)
+        with _layout(packed):
+            K.ffn_configure(split=1)
+            try:
+                model.eval()
+                with torch.no_grad():
+                    enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+                    assert (enc.get("packed") is not None) == packed
+                    assert len(enc["inter_ctc_logits"]) == 2
+                    outs = [enc["encoder_out"][0].float(), enc["ctc_logit"][0].float()] + [il[0].float() for il in enc["inter_ctc_logits"]]
+                    assert all(torch.equal(il[1], enc["encoder_padding_mask"][0]) for il in enc["inter_ctc_logits"])
+            finally:
+                K.ffn_configure(split=old)
+            model.train()
+            model.flat.zero_grad()
+            loss, _, log = crit(model, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+        res[packed] = (outs, float(loss.detach()), float(log["inter_ctc_loss"]),
+                       {k: p.grad.detach().float().clone() for k, p in model.named_parameters()})
+    Tp = res[False][0][0].shape[0]
+    valid = (torch.arange(Tp)[:, None] < sub[None, :]).to(DEV)
+    for a_, b_ in zip(res[False][0], res[True][0]):
+        assert torch.equal(a_[valid], b_[valid])
+    assert abs(res[False][1] - res[True][1]) <= 5e-4 * abs(res[False][1]), (res[False][1], res[True][1])
+    assert abs(res[False][2] - res[True][2]) <= 5e-4 * abs(res[False][2]), (res[False][2], res[True][2])
+    errs = []
+    for k, ga in res[False][3].items():
+        den = float(ga.norm())
+        if k.endswith(("k_proj.bias", "linear_k.bias")) or den < 1e-5:
+            continue
+        e = float((ga - res[True][3][k]).norm()) / den
+        errs.append(e)
+        assert e <= 0.08, (k, e)
+    assert float(np.median(errs)) <= 0.02
