@@ -6,6 +6,7 @@
 #   4. one --pmc pass of SQ counters (MFMA busy, vector active, stalls)      -> <tag>_pmc_sq.json
 #   5. tools/gemm256_probe.py + SQ counters of the large-tile GEMM           -> <tag>_gemm256_probe.txt, <tag>_gemm256_pmc_sq.json
 #   6. configuration 5b greedy under --kernel-trace --stats                  -> <tag>_config5b_greedy_kernel_stats.csv
+#   7. configuration 3 (PDS Conformer, 64 x 2000) training step, same        -> <tag>_config3_kernel_stats.csv
 # (A single-rank communicator launches no RCCL kernel — the library short-circuits a one-rank all-reduce — so the overlap of
 #  the bucketed all-reduce with backward can only be traced on a multi-GPU node: tools/ddp_overlap.py reads such a trace.)
 # Every profiler run puts the program itself after "--" and keeps counters apart from traces.
@@ -35,5 +36,8 @@ echo "step 5 done" >&2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -- python3 tools/run_configs.py 5bg > $out/${tag}_config5b_greedy.log 2>&1 || exit 1
 cp $(ls $out/c5/*/*kernel_stats.csv | head -1) $out/${tag}_config5b_greedy_kernel_stats.csv
 echo "step 6 done" >&2
-rm -rf $out/k $out/e $out/pf $out/pw $out/ps $out/d $out/pg $out/c5
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3 -- python3 tools/run_configs.py 3 > $out/${tag}_config3.log 2>&1 || exit 1
+cp $(ls $out/c3/*/*kernel_stats.csv | head -1) $out/${tag}_config3_kernel_stats.csv
+echo "step 7 done" >&2
+rm -rf $out/k $out/e $out/pf $out/pw $out/ps $out/d $out/pg $out/c5 $out/c3
 ls -la $out
