@@ -25,7 +25,17 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_BF16 = 2.5e15  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_F32 = 157.3e12
 HBM_PEAK = 8.0e12         # HBM3E, same guide (about 6.3e12 is what a streaming kernel reaches)
-PMC_FILE = "r04_pmc_traffic.json"
+def _pmc_file():
+    """The newest committed PMC traffic table (profiles/rNN_pmc_traffic.json, highest NN)."""
+    import glob
+    import re
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")),
+                   key=lambda p: int(re.search(r"r(\d+)_pmc_traffic", p).group(1)))
+    return os.path.basename(found[-1]) if found else "r05_pmc_traffic.json"
+
+
+PMC_FILE = _pmc_file()
 
 
 def csrc_hash():
