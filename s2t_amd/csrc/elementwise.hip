@@ -347,6 +347,25 @@ __global__ __launch_bounds__(256) void axpy_kernel(const T* __restrict__ a, cons
 // ---- fused Adam on flat fp32 buffers (optim/adam.py:146-226) + bf16 shadow refresh ----
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; p -= wd*lr*p ; p -= step_size * m / (sqrt(v) + eps)
 //   g is pre-multiplied by grad_scale (clip coefficient x 1/sample_size).
+#ifndef S2T_ADAM_NT
+#define S2T_ADAM_NT 0  // 1: the optimizer state (p, m, v) streams past the caches (non-temporal loads and stores)
+#endif
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void adam_ld(const float* q, float (&v)[4]) {
+#if S2T_ADAM_NT
+  const adam_f4 t = __builtin_nontemporal_load(reinterpret_cast<const adam_f4*>(q));
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+#else
+  ld4_as_f32<float>(q, v);
+#endif
+}
+__device__ __forceinline__ void adam_st(float* q, const float (&v)[4]) {
+#if S2T_ADAM_NT
+  __builtin_nontemporal_store((adam_f4){v[0], v[1], v[2], v[3]}, reinterpret_cast<adam_f4*>(q));
+#else
+  st4_from_f32<float>(q, v);
+#endif
+}
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ shadow, int64_t n4, float b1, float b2,
@@ -362,14 +381,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const bool two = i1 < n4;
     const int64_t j1 = two ? i1 : i0;  // (clamped: the second piece's loads stay unconditional)
     float pv[2][4], gv[2][4], mv[2][4], vv[2][4];
-    ld4_as_f32<float>(p + i0 * 4, pv[0]);
+    adam_ld(p + i0 * 4, pv[0]);
     ld4_as_f32<float>(g + i0 * 4, gv[0]);
-    ld4_as_f32<float>(m + i0 * 4, mv[0]);
-    ld4_as_f32<float>(v + i0 * 4, vv[0]);
-    ld4_as_f32<float>(p + j1 * 4, pv[1]);
+    adam_ld(m + i0 * 4, mv[0]);
+    adam_ld(v + i0 * 4, vv[0]);
+    adam_ld(p + j1 * 4, pv[1]);
     ld4_as_f32<float>(g + j1 * 4, gv[1]);
-    ld4_as_f32<float>(m + j1 * 4, mv[1]);
-    ld4_as_f32<float>(v + j1 * 4, vv[1]);
+    adam_ld(m + j1 * 4, mv[1]);
+    adam_ld(v + j1 * 4, vv[1]);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -384,9 +403,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       }
       if (u == 1 && !two) break;
       const int64_t i = u ? i1 : i0;
-      st4_from_f32<float>(p + i * 4, pv[u]);
-      st4_from_f32<float>(m + i * 4, mv[u]);
-      st4_from_f32<float>(v + i * 4, vv[u]);
+      adam_st(p + i * 4, pv[u]);
+      adam_st(m + i * 4, mv[u]);
+      adam_st(v + i * 4, vv[u]);
       if (shadow) st4_from_f32<bf16_t>(shadow + i * 4, pv[u]);
     }
   }

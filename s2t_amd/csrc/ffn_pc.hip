@@ -40,6 +40,14 @@
 #ifndef S2T_PC_PIECE_ORDER
 #define S2T_PC_PIECE_ORDER 0  // consumers' LDS-DMA pieces: 0 in front of each pair of MFMAs, 1 behind them with the LDS queue drained
 #endif
+#ifndef S2T_PC_SAVE_AUX
+#define S2T_PC_SAVE_AUX 2  // cache policy of the training saves (z, h / dZ): 0 default, 2 non-temporal.  They are written once and
+#endif                     // read by the backward pass a whole model later; left to the default policy they push the weights (which every
+                           // workgroup re-reads) out of L2 / the Infinity Cache: training forward 64.6 -> 58.6 us at 12 950 rows
+                           // (tools/ffn_probe_cold.py, same box), the bench step 11.60 -> 11.50 ms
+#ifndef S2T_PC_ZLOAD_AUX
+#define S2T_PC_ZLOAD_AUX 0  // cache policy of the backward's pre-activation loads (read once)
+#endif
 #ifndef S2T_PC_DBG
 #define S2T_PC_DBG 0  // experiment switches: 1 no DMA in the loop, 2 no MFMAs, 4 no E1 arithmetic, 16 stamps
 #endif
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const uint32_t off = p.z_tiled ? ztile_off(fbase / FC + c, s) : (rowF + (uint32_t)(fbase + c * FC + 16 * s + 8 * hh)) * 2u;
-          const u32x4s t = __builtin_amdgcn_raw_buffer_load_b128(zsrd, off, 0, 0);
+          const u32x4s t = __builtin_amdgcn_raw_buffer_load_b128(zsrd, off, 0, S2T_PC_ZLOAD_AUX);
           sd.z[s] = make_uint4(t.x, t.y, t.z, t.w);
         }
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
     auto e1_out = [&](int c, int s, const uint32_t (&hp)[4], const uint32_t (&zp)[4]) __attribute__((always_inline)) {
       if constexpr (TRAIN) {
         // (tiled: the wave's 64 pieces of this k-step are 1 KiB contiguous; row-major they would be 32-byte pieces of 32 rows)
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){zp[0], zp[1], zp[2], zp[3]}, zsrd, ztile_off(fbase / FC + c, s), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){zp[0], zp[1], zp[2], zp[3]}, zsrd, ztile_off(fbase / FC + c, s), 0, S2T_PC_SAVE_AUX);
       }
       *reinterpret_cast<uint4*>(mcell(c, s, hh, r32)) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
     };
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
             for (int k = 0; k < 2; ++k) {
               const int rr = 8 * (2 * (nt - 6) + k) + (lane >> 3);
               const uint32_t off = ((uint32_t)(row0 + 32 * wi + rr) * (uint32_t)F + (uint32_t)(fbase + c * FC + 8 * pc)) * 2u;
-              __builtin_amdgcn_raw_buffer_store_b128((u32x4s){sv[k].x, sv[k].y, sv[k].z, sv[k].w}, hsrd, off, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128((u32x4s){sv[k].x, sv[k].y, sv[k].z, sv[k].w}, hsrd, off, 0, S2T_PC_SAVE_AUX);
             }
           }
         }
