@@ -1350,6 +1350,9 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
 //   accumulate into the wave's 4 x 2 result tiles, which stay in registers across the K-blocks;
 //   epilogue: the fp32 rows meet in LDS ([64][256], the free weight stages) and go through s2t_layernorm_bwd's arithmetic
 //   (mask, dgamma / dbeta partial sums into the fold workspace, residual gradient, dropped copy) as in the fused FFN backward.
+#ifndef S2T_DG_A_NT
+#define S2T_DG_A_NT 0  // experiment: the dY tile of s2t_rowblock_dgrad (read once) fetched non-temporally
+#endif
 constexpr int DG_W = 0;                 // three weight stages
 constexpr int DG_A = 3 * STAGE;         // the dY tile of one K-block
 constexpr int DG_BYTES = 4 * STAGE;     // 128 KiB
@@ -1405,7 +1408,13 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
   auto issue_a = [&](int kb) __attribute__((always_inline)) {
     const uint32_t base = lds0 + DG_A + wave * 4096;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(base + 1024 * i, va[i], srda, (uint32_t)kb * 512u);
+    for (int i = 0; i < 4; ++i) {
+#if S2T_DG_A_NT
+      dma16_nt(base + 1024 * i, va[i], srda, (uint32_t)kb * 512u);
+#else
+      dma16(base + 1024 * i, va[i], srda, (uint32_t)kb * 512u);
+#endif
+    }
   };
   const int S = 4 * KB;
   issue_a(0);
