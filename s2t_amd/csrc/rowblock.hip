@@ -69,6 +69,20 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) { return bf16pack(a,
 __device__ __forceinline__ void st8row(bf16_t* ptr, const float (&v)[8]) {
   *reinterpret_cast<uint4*>(ptr) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
 }
+#ifndef S2T_RB_SAVE_NT
+#define S2T_RB_SAVE_NT 0  // experiment: the row-block projections' saves for backward (x_ln, the pre-GLU values) stored non-temporally
+#endif
+typedef uint32_t rb_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_save(void* ptr, uint4 o) {
+#if S2T_RB_SAVE_NT
+  __builtin_nontemporal_store((rb_u4){o.x, o.y, o.z, o.w}, reinterpret_cast<rb_u4*>(ptr));
+#else
+  *reinterpret_cast<uint4*>(ptr) = o;
+#endif
+}
+__device__ __forceinline__ void st8row_save(bf16_t* ptr, const float (&v)[8]) {
+  st16_save(ptr, make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])));
+}
 
 // swizzle key of row r (0..63) of a W1 chunk image: the 16 rows one fragment read touches (r = 32 fh + 8 (x>>2) + 4 ft +
 // (x&3), x = 0..15) get 16 different keys
@@ -1192,7 +1206,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
                                       (v[2 * k + 1] - mean) * rstd * gm[2 * k + 1] + bt[2 * k + 1]);
         o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         if (m < M) {
-          if (p.x_ln) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.x_ln) + (int64_t)m * D + 8 * cch) = o;
+          if (p.x_ln) st16_save(reinterpret_cast<bf16_t*>(p.x_ln) + (int64_t)m * D + 8 * cch, o);
           if (cch == 0) {
             if (p.ln_mean) p.ln_mean[m] = mean;
             if (p.ln_rstd) p.ln_rstd[m] = rstd;
@@ -1209,7 +1223,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
           ow[k] = masked ? 0u : pack2(act_apply(p.pre_act, v0), act_apply(p.pre_act, v1));
         }
         o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        if (m < M && p.x_ln) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.x_ln) + (int64_t)m * D + 8 * cch) = o;
+        if (m < M && p.x_ln) st16_save(reinterpret_cast<bf16_t*>(p.x_ln) + (int64_t)m * D + 8 * cch, o);
       }
       *reinterpret_cast<uint4*>(stage + rl * 512 + 16 * (cch ^ (rl & 15))) = o;
     }
@@ -1289,8 +1303,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
       add_bias(n0, v);
       add_bias(nout + n0, gt);
       if (Z) {
-        st8row(Z + (int64_t)m * p.ldp + n0, v);
-        st8row(Z + (int64_t)m * p.ldp + nout + n0, gt);
+        st8row_save(Z + (int64_t)m * p.ldp + n0, v);
+        st8row_save(Z + (int64_t)m * p.ldp + nout + n0, gt);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(gt[e]);
