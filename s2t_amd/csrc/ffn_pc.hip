@@ -43,8 +43,9 @@
 #ifndef S2T_PC_SAVE_AUX
 #define S2T_PC_SAVE_AUX 2  // cache policy of the training saves (z, h / dZ): 0 default, 2 non-temporal.  They are written once and
 #endif                     // read by the backward pass a whole model later; left to the default policy they push the weights (which every
-                           // workgroup re-reads) out of L2 / the Infinity Cache: training forward 64.6 -> 58.6 us at 12 950 rows
-                           // (tools/ffn_probe_cold.py, same box), the bench step 11.60 -> 11.50 ms
+                           // workgroup re-reads) out of L2 / the Infinity Cache: the isolated training forward 64.6 -> 58.6 us at
+                           // 12 950 rows (tools/ffn_probe_cold.py); inside the step the kernels AROUND the FFN gain: bench step
+                           // 11.65 -> 11.59 ms (tools/ab_bench.sh, four alternations, same box)
 #ifndef S2T_PC_ZLOAD_AUX
 #define S2T_PC_ZLOAD_AUX 0  // cache policy of the backward's pre-activation loads (read once)
 #endif
