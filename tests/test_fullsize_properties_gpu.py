@@ -159,6 +159,60 @@ def test_grouped_and_per_weight_gradients_agree(sample):
     assert float((grads["grouped"] - ref).norm() / ref.norm()) < 1e-3
 
 
+def test_grouped_weight_gradients_split_by_kernel(sample):
+    """A backward pass whose queue holds problems the 256 x 256 LDS-DMA kernel cannot take (an unaligned leading dimension, an
+    operand beyond 2 GiB: functional.wgrad256_eligible) runs them on the 128 x 128 grouped kernel in a second launch and the
+    rest on the large tiles — it no longer moves the whole pass to the slow kernel or aborts.  Rehearsed by
+    declaring every problem with a 2048-wide operand ineligible: eager and inside a captured step (two staging blocks per flush),
+    gradients equal to the all-eligible pass up to the two kernels' summation trees; tied weights (the CTC head and the decoder's
+    embedding / output projection) stay in ONE launch."""
+    from s2t_amd import rows as Rows
+    from s2t_amd.trainer import Trainer
+
+    old_rows, Rows.ENABLED = Rows.ENABLED, False  # (padded rows: a packed problem has no second kernel to go to)
+    old_mode, old_fn = Fn._WGQ["mode"], Fn.wgrad256_eligible
+    launches = []
+    orig_group = Fn._flush_wgrad_group
+
+    def spy(q, big):
+        launches.append((len(q), big))
+        return orig_group(q, big)
+
+    def picky(M_, ldy, ldx, py=0, px=0):
+        return old_fn(M_, ldy, ldx, py, px) and ldy != 2048 and ldx != 2048
+
+    try:
+        Fn._WGQ["mode"] = "1"
+        Fn._flush_wgrad_group = spy
+        grads = {}
+        for tag, fn in (("all256", old_fn), ("split", picky)):
+            torch.manual_seed(2)
+            model = M.S2TTransformerModel.build_model(M.recipe_args(conformer=False, vocab_size=V, encoder_layers=3, decoder_layers=2),
+                                                      M.FakeTask(V)).prepare(torch.bfloat16, DEV)
+            model.train()
+            crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+            Fn.wgrad256_eligible = fn
+            launches.clear()
+            model.flat.zero_grad()
+            loss, _, _ = crit(model, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads[tag] = (model.flat.grad.clone(), list(launches))
+            if tag == "split":  # the same split inside a captured step: two launches per flush, each with a staging block of its own
+                tr = Trainer(model, crit, lr=1e-6, warmup_updates=1)
+                tr.capture(sample)
+                losses = [float(tr.replay()[0]) for _ in range(3)]
+                assert all(torch.isfinite(torch.tensor(losses))), losses
+                tr.release()
+        assert [b for _, b in grads["all256"][1]] == [True]
+        assert sorted(b for _, b in grads["split"][1]) == [False, True], grads["split"][1]
+        ref, got = grads["all256"][0], grads["split"][0]
+        assert torch.isfinite(got).all()
+        assert float((got - ref).norm() / ref.norm()) < 1e-3
+    finally:
+        Fn._WGQ["mode"], Fn.wgrad256_eligible, Fn._flush_wgrad_group, Rows.ENABLED = old_mode, old_fn, orig_group, old_rows
+
+
 def test_conformer_training_pass_repeats(sample):
     """The Conformer's training-mode data path holds no order-dependent reduction either: BatchNorm batch statistics and
     the BatchNorm backward sums are per-workgroup partial rows added in a fixed order (conv.hip), so two identical passes
