@@ -987,22 +987,23 @@ class FFNFn(torch.autograd.Function):
     decoder FFN modules/transformer_layer.py:520-530)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act, alpha, residual, train, drop_h, drop_o):
+    def forward(ctx, x, w1, b1, w2, b2, act, alpha, residual, train, drop_h, drop_o, rows=None):
         M, d = x.shape
         F_ = w1.shape[0]
         h = torch.empty(M, F_, dtype=x.dtype, device=x.device)
         z = torch.empty(M, F_, dtype=x.dtype, device=x.device) if train else None
-        K.gemm(x, cw(w1), h, M=M, N=F_, K=d, lda=d, ldb=d, ldc=F_, bias=b1.data, act=act, preact=z, ldp=F_, drop=drop_h)
+        ctx.rows = rows  # packed batch (s2t_amd/rows.py): only the live rows are computed
+        K.gemm(x, cw(w1), h, M=M, N=F_, K=d, lda=d, ldb=d, ldc=F_, bias=b1.data, act=act, preact=z, ldp=F_, drop=drop_h, rows=rows)
         y = torch.empty(M, d, dtype=x.dtype, device=x.device)
         # the decoder's rows (B*U = 3904: 62 output tiles walking 32 K-steps each) leave three CUs in four idle: the long
         # reduction is cut into splits and the epilogue runs in the second phase
         split = 1
-        if _FWD_SPLITK and x.dtype == torch.bfloat16 and F_ >= 1024:
+        if _FWD_SPLITK and x.dtype == torch.bfloat16 and F_ >= 1024 and rows is None:
             tiles = ((M + 127) // 128) * ((d + 127) // 128)
             if tiles < 128:
                 split = max(1, min(_FWD_SPLITK, 512 // tiles, F_ // 256))
         K.gemm(h, cw(w2), y, M=M, N=d, K=F_, lda=F_, ldb=F_, ldc=d, bias=b2.data, alpha=alpha, residual=residual, ldr=d,
-               drop=drop_o, split_k=split, c_atomic=2 if split > 1 else False)
+               drop=drop_o, split_k=split, c_atomic=2 if split > 1 else False, rows=rows)
         ctx.drops = (drop_h, drop_o)
         if train:
             ctx.save_for_backward(x, z, h)
@@ -1021,15 +1022,16 @@ class FFNFn(torch.autograd.Function):
         dy = _drop_rows(dres, drop_o)  # gradient of the branch behind the output dropout
         # dZ = alpha * dropout_h(dY @ W2) * act'(Z)
         dz = torch.empty(M, F_, dtype=x.dtype, device=x.device)
+        rows = ctx.rows
         K.gemm(dy, cw(w2), dz, M=M, N=F_, K=d, lda=d, ldb=F_, ldc=F_, b_kmajor=True, alpha=ctx.alpha, dact_z=z, ldz=F_,
-               dact=ctx.act, drop=drop_h)
-        _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad)
+               dact=ctx.act, drop=drop_h, rows=rows)
+        _wgrad(dy, h, w2.grad, d, F_, M, d, F_, ctx.alpha, b2.grad, rows=rows)
         _ready(w2, b2)
-        _wgrad(dz, x, w1.grad, F_, d, M, F_, d, 1.0, b1.grad)
+        _wgrad(dz, x, w1.grad, F_, d, M, F_, d, 1.0, b1.grad, rows=rows)
         dx = torch.empty_like(x)
-        _dgrad(dz, cw(w1), dx, M, d, F_, F_, d, d)
+        _dgrad(dz, cw(w1), dx, M, d, F_, F_, d, d, rows=rows)
         _ready(w1, b1)
-        return dx, None, None, None, None, None, None, dres, None, None, None
+        return dx, None, None, None, None, None, None, dres, None, None, None, None
 
 
 _FFN_FUSED = os.environ.get("S2T_FFN_FUSED", "1") != "0"
@@ -1180,19 +1182,20 @@ def ffn_block(x, norm_g, norm_b, w1, b1, w2, b2, act, alpha, p_hidden=0.0, p_out
         out = FFNBlockFn.apply(x, norm_g, norm_b, w1, b1, w2, b2, act, alpha, torch.is_grad_enabled(), drop_h, drop_o, eg,
                                eb, end_lens, end_T, rows)
         return out if end_norm is not None else _tag_drop(out, drop_o)
-    if K.rows_geom(rows) is not None or K.rows_geom(end_lens) is not None:
-        raise NotImplementedError("packed rows: the feed-forward block runs on the fused kernels only (d = 256, bf16)")
-    y, xr = layer_norm(x, norm_g, norm_b, fork=True)
-    out = ffn(y, w1, b1, w2, b2, act, alpha, xr, p_hidden, p_out, training)
+    # the LayerNorm / GEMM composition (other widths, fp32); packed rows (s2t_amd/rows.py) pass through as the live-row bound
+    pk = rows if K.rows_geom(rows) is not None else (end_lens if K.rows_geom(end_lens) is not None else None)
+    y, xr = layer_norm(x, norm_g, norm_b, fork=True, rows=pk)
+    out = ffn(y, w1, b1, w2, b2, act, alpha, xr, p_hidden, p_out, training, rows=pk)
     if end_norm is not None:
-        out = layer_norm(out, end_norm[0], end_norm[1], end_lens, end_T)
+        out = layer_norm(out, end_norm[0], end_norm[1], end_lens, end_T, rows=pk if end_lens is None else None)
     return out
 
 
-def ffn(x, w1, b1, w2, b2, act, alpha, residual, p_hidden=0.0, p_out=0.0, training=False):
+def ffn(x, w1, b1, w2, b2, act, alpha, residual, p_hidden=0.0, p_out=0.0, training=False, rows=None):
     drop_h = DROPOUT.next(p_hidden if training else 0.0, x.device)
     drop_o = DROPOUT.next(p_out if training else 0.0, x.device)
-    return _tag_drop(FFNFn.apply(x, w1, b1, w2, b2, act, alpha, residual, torch.is_grad_enabled(), drop_h, drop_o), drop_o)
+    return _tag_drop(FFNFn.apply(x, w1, b1, w2, b2, act, alpha, residual, torch.is_grad_enabled(), drop_h, drop_o,
+                                 rows if K.rows_geom(rows) is not None else None), drop_o)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -82,16 +82,17 @@ class TransformerS2EncoderLayer(TransformerEncoderLayer):
         if self.training and self.league_drop_net:
             draw = float(np.random.uniform(0, 1)) < self.league_drop_net_prob  # always drawn, like the reference
             skip = draw if skip_self_attn is None else bool(skip_self_attn)
+        rows = lens if getattr(lens, "_pk", None) is not None else None  # packed rows: queries, keys and the other layer's output
         if not skip:
             x = self.self_attn(x, None, None, B, T, T, lens, norm=self.self_attn_layer_norm)
         if s2 is not None:
-            y, x = self.s2_attn_norm(x, fork=True)
-            x = self.s2_attn(y, s2, x, B, T, T, lens)
+            y, x = self.s2_attn_norm(x, fork=True, rows=rows)
+            x = self.s2_attn(y, s2, x, B, T, T, lens, q_rows=rows)
         # (the LayerNorm, both products, activation, dropouts and the residual in one launch where the row-block kernel
         # applies: d = 256 bf16, relu / swish, >= S2T_FFN_FUSED_MIN_ROWS rows; the LayerNorm + GEMM composition otherwise)
         return Fn.ffn_block(x, self.final_layer_norm.weight, self.final_layer_norm.bias, self.fc1.weight, self.fc1.bias,
                             self.fc2.weight, self.fc2.bias, self.activation_fn, 1.0, self.activation_dropout_p, self.dropout_p,
-                            self.training)
+                            self.training, rows=rows)
 
 
 def _layer_list(spec, n_layers):
@@ -185,10 +186,14 @@ class TextualEncoder(nn.Module):
         self.layers = nn.ModuleList(layers)
 
     def packable(self):
-        """Packed rows (s2t_amd/rows.py) through the textual layers: the plain stack of configuration 4 (sate.yaml) — the NAST
-        extras (XCTC heads, prediction-aware encoding, cross-layer attention) read (T, B, V) views and stay on padded rows."""
-        return (self.embed_dim == 256 and not self.use_xctc and not self.inter_xctc_layers and not self.use_cross_attn
-                and len(self.layers) > 0 and self.layers[0].self_attn.num_heads * 64 == self.embed_dim)
+        """Packed rows (s2t_amd/rows.py) through the textual layers: heads of 64; the NAST extras (XCTC heads, prediction-aware
+        encoding, cross-layer attention) run on the row map as well unless the ground-truth curriculum is on (training with
+        ``xctc_pae_ground_truth_ratio`` > 0 mixes (B, T) oracle labels in) or a decoder reads an intermediate head."""
+        if len(self.layers) == 0 or self.layers[0].self_attn.num_heads * 64 != self.embed_dim:
+            return False
+        if self.inter_xctc_layers and ((self.gt_ratio > 0 and self.training) or getattr(self, "decode_inter_logits", False)):
+            return False
+        return True
 
     def forward(self, x, B, T, lens32, encoder_padding_mask=None, **kwargs):
         """x [B*T, d] -> (x, xctc_logit, inter_xctc_logits); logits are (T, B, V) views, inter entries follow the
@@ -205,6 +210,7 @@ class TextualEncoder(nn.Module):
         elif self.embed_scale != 1.0:
             x = x * self.embed_scale
         skips = kwargs.get("drop_self_attn")  # test hook: replay of the reference's league drop-net draws
+        packed_x = {"xctc": None, "inter": []}
         attn_x = xorc = x_force_emit = None
         inter_xctc_logits, s2_i = [], 0
         for i, layer in enumerate(self.layers):
@@ -215,15 +221,19 @@ class TextualEncoder(nn.Module):
                 x = layer(x, B, T, lens32)
             L = i + 1
             if self.use_cross_attn and L == self.cross_attn_layer:
-                attn_x = self.attn_norm(x)
+                attn_x = self.attn_norm(x, rows=rows)
             if L in self.inter_xctc_layers:
                 norm = self.layer_norm if self.share_inter_xctc_norm else getattr(self, "xctc_norm%d" % L)
-                norm_x = norm(x)
+                norm_x = norm(x, rows=rows)
                 # (an intermediate head that feeds PAE emits compute-dtype logits, as in training — unless a decoder reads the
                 # intermediate heads: CTCDecoder(--ctc-inter-logit) sets ``decode_inter_logits`` and they follow ctc_out_dtype)
                 logit2d = self.xctc(norm_x, out_dtype=self.ctc_out_dtype if (self.xctc_pae.adapter_type == "none" or getattr(
-                    self, "decode_inter_logits", False)) else None)
-                il = logit2d.view(B, T, -1).transpose(0, 1)
+                    self, "decode_inter_logits", False)) else None, rows=rows)
+                if rows is not None:  # the (T, B, V) view only if somebody reads it; the packed rows ride in ``packed_x``
+                    il = Rows.LazyList([lambda l2=logit2d: Rows.unpack(l2.contiguous(), rows).view(B, T, -1).transpose(0, 1)])
+                    packed_x["inter"].append(logit2d)
+                else:
+                    il = logit2d.view(B, T, -1).transpose(0, 1)
                 inter_logit = il
                 orc = msk = None
                 if self.gt_ratio > 0:
@@ -236,15 +246,20 @@ class TextualEncoder(nn.Module):
                         orc, msk = xorc[0], xorc[1]
                         inter_logit = [il, None, x_force_emit]
                 if self.xctc_pae.adapter_type != "none":
-                    x = self.xctc_pae(x if self.pae_unnorm_input else norm_x, logit2d, orc, msk)
+                    x = self.xctc_pae(x if self.pae_unnorm_input else norm_x, logit2d, orc, msk, rows=rows)
                 inter_xctc_logits.append(inter_logit)
         if self.layer_norm is not None:
             x = self.layer_norm(x, rows=rows)
         xctc_logit = None
-        if self.use_xctc:
+        if self.use_xctc and rows is not None:
+            x2d = self.xctc(x, out_dtype=self.ctc_out_dtype, rows=rows)
+            packed_x["xctc"] = x2d
+            xctc_logit = Rows.LazyList([lambda: Rows.unpack(x2d.contiguous(), rows).view(B, T, -1).transpose(0, 1)])
+        elif self.use_xctc:
             xctc_logit = self.xctc(x, out_dtype=self.ctc_out_dtype).view(B, T, -1).transpose(0, 1)
             if x_force_emit is not None:
                 xctc_logit = [xctc_logit, None, x_force_emit]
+        self.last_packed = packed_x if rows is not None else None  # (read by S2TSATEEncoder right after this call)
         return x, xctc_logit, inter_xctc_logits
 
     ctc_out_dtype = None  # None -> compute dtype; eval decoding sets fp32
@@ -299,14 +314,19 @@ class S2TSATEEncoder(nn.Module):
             mask = ac["encoder_padding_mask"][0]
             if self.adapter.adapter_type != "none":
                 x = self.adapter(x, pk["ctc_logit"], rows=rows_)
-            self.textual_encoder.ctc_out_dtype = self.acoustic_encoder.ctc_out_dtype
-            x, _, _ = self.textual_encoder(x, B, Tn, rows_, mask, **kwargs)
+            xdt = getattr(self, "xctc_out_dtype", None)
+            self.textual_encoder.ctc_out_dtype = xdt if xdt is not None else self.acoustic_encoder.ctc_out_dtype
+            x, xctc_logit, inter_xctc_logits = self.textual_encoder(x, B, Tn, rows_, mask, **kwargs)
+            px = self.textual_encoder.last_packed or {"xctc": None, "inter": []}
             return {
                 "encoder_out": Rows.LazyList([lambda: Rows.unpack(x, rows_).view(B, Tn, d).transpose(0, 1)]),
-                "ctc_logit": ac["ctc_logit"], "inter_ctc_logits": [], "xctc_logit": [], "inter_xctc_logits": [],
+                "ctc_logit": ac["ctc_logit"], "inter_ctc_logits": ac.get("inter_ctc_logits", []),
+                "xctc_logit": [] if xctc_logit is None else xctc_logit, "inter_xctc_logits": inter_xctc_logits,
                 "axctc_logit": [], "inter_axctc_logits": [], "ctc_padding_mask": [mask], "encoder_padding_mask": [mask],
                 "mixup": None, "encoder_embedding": [], "encoder_states": [], "src_tokens": [], "src_lengths": [],
-                "packed": {"rows": rows_, "B": B, "T": Tn, "encoder_out": x, "ctc_logit": pk.get("ctc_logit")},
+                "packed": {"rows": rows_, "B": B, "T": Tn, "encoder_out": x, "ctc_logit": pk.get("ctc_logit"),
+                           "inter_ctc_logit": pk.get("inter_ctc_logit") or [], "xctc_logit": px["xctc"],
+                           "inter_xctc_logit": px["inter"]},
             }
         x_tbc = ac["encoder_out"][0]
         Tn, B, d = x_tbc.shape

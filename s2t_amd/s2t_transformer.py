@@ -158,24 +158,29 @@ class S2TTransformerEncoder(nn.Module):
         pass
 
     def _packed_ok(self, dt, B, Tp):
-        """Packed rows where every kernel on the path takes them: the bf16 fused kernels of the recipes' width (d = 256, heads
-        of 64), enough rows for the row-block kernels, no intermediate CTC heads / prediction-aware encoding / compression
-        between the layers (their row-wise pieces still run on padded rows)."""
-        if not Rows.ENABLED or dt != torch.bfloat16 or self.embed_dim != 256:
+        """Packed rows where every kernel on the path takes them: bf16, heads of 64, enough rows.  At the recipes' width
+        (d = 256) the fused row-block kernels carry training and inference; at other widths (the NAST recipe's d = 512) the
+        GEMM / LayerNorm composition takes the row map too — in INFERENCE: the convolution module's backward exists for packed
+        rows on the fused d = 256 kernel only.  CTC-guided compression rewrites the frame axis between the layers: padded."""
+        if not Rows.ENABLED or dt != torch.bfloat16:
+            return False
+        d = self.embed_dim
+        if d != 256 and torch.is_grad_enabled():
             return False
         h = getattr(self.layers[0].self_attn, "num_heads", None) or getattr(self.layers[0].self_attn, "h", 0)
-        if h * 64 != self.embed_dim or self.compression_layers:
-            return False  # (CTC-guided compression rewrites the frame axis between the layers: padded rows)
-        if self.inter_ctc_layers and (self.ctc_pae_ground_truth_ratio > 0 or getattr(self, "decode_inter_logits", False)):
-            return False  # (intermediate heads run packed unless the ground-truth curriculum mixes (B, T) oracle labels in, or a
-                          #  decoder reads an intermediate head: --ctc-inter-logit)
+        if h * 64 != d or self.compression_layers:
+            return False
+        if self.inter_ctc_layers and (self.pae_ground_truth_ratio > 0 and self.training
+                                      or getattr(self, "decode_inter_logits", False)):
+            return False  # (intermediate heads run packed unless the ground-truth curriculum is on — both of the criterion's
+                          #  passes then read (T, B, V) views and mix (B, T) oracle labels in — or a decoder reads an intermediate
+                          #  head: --ctc-inter-logit)
         if self.attn_type == "rel_pos" and Tp > Fn._GLUE_MAX_T and torch.is_grad_enabled():
             return False  # (S2T_GLUE_MAX_T: the round-4 routing of the relative-position backward, padded rows only)
         if torch.is_grad_enabled():
             # weight gradients over packed rows exist on the 256 x 256 grouped kernel only (it reads the live row count on the
             # device): its operand rules must hold for the widest operands of this stack — the feed-forward hidden activation and
             # the CTC logits — or the batch stays padded (S2T_WG_256=0, a vocabulary beyond 2 GiB of logits)
-            d = self.embed_dim
             widest = max(int(self.args.encoder_ffn_embed_dim), 3 * d,
                          Fn._pad8(self.ctc.ctc_projection.weight.shape[0]) if self.use_ctc else 0)
             if not Fn.wgrad256_eligible(B * Tp, widest, d):
@@ -830,8 +835,10 @@ class CTCDecoder:
             Rows.ENABLED = was
         has_x = len(enc.get("xctc_logit", [])) > 0
         pk = enc.get("packed")
-        if pk is not None and not has_x and self.ctc_inter_logit == 0 and pk.get("ctc_logit") is not None:
-            return self._collapse(pk["ctc_logit"], pk["rows"], pk["B"], pk["T"], rows=pk["rows"])  # packed rows (s2t_amd/rows.py)
+        if pk is not None and self.ctc_inter_logit == 0:  # packed rows (s2t_amd/rows.py): the decoded head's rows as they are
+            l2d = pk.get("xctc_logit") if has_x else pk.get("ctc_logit")
+            if l2d is not None:
+                return self._collapse(l2d, pk["rows"], pk["B"], pk["T"], rows=pk["rows"])
         logit_tbv = enc["xctc_logit"][0] if has_x else enc["ctc_logit"][0]
         if isinstance(logit_tbv, (list, tuple)):
             logit_tbv = logit_tbv[0]

@@ -680,3 +680,71 @@ def test_intermediate_ctc_taps_run_packed_and_equal_the_padded_layout(conformer)
         errs.append(e)
         assert e <= 0.08, (k, e)
     assert float(np.median(errs)) <= 0.02
+
+
+def test_nast_stack_at_d512_decodes_on_packed_rows_in_inference():
+    """Configuration 5b's stack at the recipe's width (egs/mustc/st/conf/reproduction_nast.yaml: d = 512, 8 heads of 64,
+    F = 2048): Conformer acoustic layers with shared intermediate CTC heads + prediction-aware encoding, the inter_league adapter,
+    textual layers with the cross-layer attention (modules/transformer_s2_layer.py:214-336), intermediate XCTC heads + PAE and
+    the XCTC head (s2t_sate.py:692-808) — in INFERENCE the whole stack runs on the frames only (the LayerNorm / GEMM composition
+    takes the row map at any width; training at this width stays padded).  Every logit family equals the padded layout's on the
+    frames bit for bit, and greedy CTC decoding (s2t_ctc.py:174-349) takes the packed XCTC rows as they are: same token ids."""
+    Vn = 2000
+    nast = dict(encoder_type="sate", text_encoder_layers=3, acoustic_encoder="transformer", adapter="inter_league",
+                xctc_weight=1.0, ctc_weight=1.0, share_ctc_and_embed=True, share_xctc_and_embed=True, text_no_pos_emb=True,
+                textual_encoder_embed_norm=False, textual_encoder_no_scale_embedding=True, encoder_normalize_before=True,
+                share_inter_ctc=True, inter_ctc_weight=1.0, inter_ctc_layers="1", inter_xctc_weight=1.0, inter_xctc_layers="2",
+                ctc_pae="inter_league", xctc_pae="inter_league", xctc_cross_attn=True, cross_attn_start_layer=2,
+                cross_attn_layer=1, cross_attn_collaboration_mode="serial", cross_attn_league_drop_net=True,
+                cross_attn_league_drop_net_prob=0.1, xctc_pae_ground_truth_ratio=0.8, xctc_pae_ground_truth_only_mistake=True,
+                pae_oracle_smooth=True, encoder_embed_dim=512, encoder_ffn_embed_dim=2048, encoder_attention_heads=8,
+                encoder_layers=2, subsampling_filter=2048, activation_fn="relu", arch="s2t_ctc")
+    a = M.recipe_args(conformer=True, vocab_size=Vn, **nast)
+    torch.manual_seed(8)
+    model = M.S2TCTCModel.build_model(a, M.FakeTask(Vn))
+    g = torch.Generator().manual_seed(18)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+        for n_, b in model.named_buffers():
+            if n_.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            if n_.endswith("running_var"):
+                b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=g))
+    model.prepare(torch.bfloat16, DEV)
+    model.eval()
+    model.encoder.xctc_out_dtype = torch.float32  # the decoded head in fp32 (bit-exact arg-max)
+    sample, lens = _sample(24, 1000, 31)
+    ni = sample["net_input"]
+    sub = torch.tensor(lens)
+    for _ in range(2):
+        sub = torch.div(sub - 1, 2, rounding_mode="floor") + 1
+    dec = M.CTCDecoder([model], None, None, blank_idx=0)
+    res = {}
+    for packed in (False, True):
+        with _layout(packed), torch.no_grad():
+            enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+            pk = enc.get("packed")
+            assert (pk is not None) == packed
+            if packed:  # every family rides as packed rows; nothing was unpacked to get here
+                assert pk["xctc_logit"] is not None and pk["xctc_logit"].dtype == torch.float32
+                assert len(pk["inter_ctc_logit"]) == 1 and len(pk["inter_xctc_logit"]) == 1
+            fam = {"encoder_out": enc["encoder_out"][0], "ctc": enc["ctc_logit"][0], "xctc": enc["xctc_logit"][0],
+                   "inter_ctc": enc["inter_ctc_logits"][0], "inter_xctc": enc["inter_xctc_logits"][0]}
+            fam = {k: (v[0] if isinstance(v, (list, tuple)) else v).float() for k, v in fam.items()}
+            hyps = dec.generate([model], sample)
+        res[packed] = (fam, [h[0]["tokens"].cpu() for h in hyps])
+    Tp = res[False][0]["encoder_out"].shape[0]
+    valid = (torch.arange(Tp)[:, None] < sub[None, :]).to(DEV)
+    for k in res[False][0]:
+        a_, b_ = res[False][0][k], res[True][0][k]
+        assert a_.shape == b_.shape, k
+        assert torch.equal(a_[valid], b_[valid]), (k, float((a_[valid] - b_[valid]).abs().max()))
+    assert sum(len(t) for t in res[False][1]) > 0
+    for ta, tb in zip(res[False][1], res[True][1]):
+        assert torch.equal(ta, tb)
+    # training at this width keeps the padded layout (the packed weight gradients exist on the d = 256 kernels only)
+    model.train()
+    enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
+    assert enc.get("packed") is None
