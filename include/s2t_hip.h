@@ -249,6 +249,26 @@ int s2t_relpos_glue(const void* dbd, int64_t ldb, const void* pos_p, int64_t p_s
 int s2t_relpos_dqv(const void* dbd, int64_t ldb, const void* pos_pt, int64_t pt_ld, void* dq, int64_t dq_sb, int64_t dq_sr,
                    float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, int B, int H, int Tq, int dk,
                    void* stream);
+/* The whole backward of the relative-position SELF-attention in one pass, sequences of up to 256 frames
+ * (csrc/relpos_bwd.hip; espnet_multihead_attention.py:292-356 backward): what s2t_attn_fused_bwd (relative form, dbd output)
+ * followed by s2t_relpos_glue computes, with the scores, the position band and the exponentials formed ONCE and the skewed
+ * score gradient dbd kept on the chip (one workgroup per (utterance, head); no dbd, delta or Q + pos_bias_v buffer):
+ *   dq (complete: both the (Q+u) K^T and the (Q+v) P^T branch), dk, dv in the layouts of q, k, v (bf16);
+ *   dpos_u / dpos_v += column sums of the two dq branches (replicated workspace as s2t_relpos_glue);
+ *   dp_part [B][2T-1][H*64] bf16: this call's per-utterance partial tables of the gradient w.r.t. the projected positions
+ *   (summed by s2t_relpos_dp_reduce, several calls per launch).
+ * o, dO: the forward's output and its gradient (layout o_sb / o_sr): delta = rowsum(dO * o) is taken inside.  lse: the
+ * forward's [B*H][T].  key_lens (optional) masks keys at and beyond key_lens[b]; cu: packed batch (rows of utterance b of q, k,
+ * v, o, dO and their gradients = cu[b] .. cu[b+1]; T stays the padded length: the centre of the position table, the stride of
+ * lse and the index space of the dropout mask).  Dropout as s2t_attn_fused_fwd (mask index ((b*H+h)*T + i)*T + j).
+ * Limits: bf16, dk = 64, T <= 256 (S2T_ERR_UNSUPPORTED beyond: use the three-kernel route), row strides % 8 == 0, 16-byte
+ * aligned operands. */
+int s2t_relpos_attn_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
+                        int64_t v_sb, int64_t v_sr, const void* o, const void* dO, int64_t o_sb, int64_t o_sr, const float* lse,
+                        void* dq, void* dk, void* dv, const void* pos_p, int64_t p_sr, const float* pos_u, const float* pos_v,
+                        float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, void* dp_part, int B, int H, int T,
+                        int dk_dim, const int32_t* key_lens, float scale, float drop_p, const uint64_t* drop_seed,
+                        uint32_t drop_site, const int32_t* cu, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grouped weight gradients: all dW[M=Nout][N=Kin] += alpha * dY[K=rows][M]^T @ X[K][N] (bf16 in, fp32 accumulate) of one

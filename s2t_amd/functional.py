@@ -1402,80 +1402,102 @@ class AttentionFn(torch.autograd.Function):
                 dk_, dv = dkv, dkv[:, d:]
         rel = ctx.kind == "rel"
         pt = getattr(ctx, "pos_pt", None) if (rel and _ATTN_DQV_FUSED) else None
-        delta = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
-        n_pos = 2 * Tq - 1
-        ldB = _pad8(n_pos)
-        dBD = _dbd_buffer(H, B, Tq, ldB, dt, dev) if rel else None
-        qv = torch.empty(Mq, d, dtype=dt, device=dev) if rel else None  # q + pos_bias_v, written by the dQ kernel
-        K.attn_fused_bwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, dO, Tq * d, d, lse, delta, dq, dk_, dv, dBD,
-                         ldB, B, H, Tq, Tk, dk, key_lens, ctx.causal, scale, p, d,
-                         prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a,
-                         dbd_band_only=rel, pos_pt=pt[0] if pt is not None else None, pt_ld=pt[1] if pt is not None else 0,
-                         dpos_u=prm["pos_u"].grad.view(-1) if pt is not None else None,
-                         dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv, q_rows=qr, k_rows=kr,
-                         o_lo=getattr(ctx, "o_lo", None))
-        ctx.o_lo = None
-        glue_done = False
-        if rel and _RELPOS_GLUE and pt is None and dt == torch.bfloat16 and dk == 64 and Tq <= _GLUE_MAX_T and ldq % 4 == 0 and _arm_backward_end():
-            # everything behind dbd in ONE pass over it (csrc/relpos_glue.hip): the (Q+v) branch added into dq, both bias
-            # gradients (column sums into the replicated workspace, folded with the LayerNorm gradients) and this layer's
-            # gradient w.r.t. the projected positions, queued for the batched linear_pos weight gradient
+        one_pass = False
+        if (rel and _RELPOS_ONE_PASS and _RELPOS_GLUE and pt is None and dt == torch.bfloat16 and dk == 64 and Tq == Tk
+                and Tq <= 256 and not ctx.causal and ldq % 8 == 0 and _arm_backward_end()):
+            # sequences of up to 256 frames: scores, position band and exponentials formed ONCE, the skewed score gradient kept
+            # on the chip (csrc/relpos_bwd.hip) — dq complete, dk, dv, both bias-gradient column sums and this layer's
+            # per-utterance tables of the position gradient from one launch (no dbd / delta / Q + pos_bias_v buffers)
+            n_pos = 2 * Tq - 1
             ws = _ln_workspace(d, dev)
             dp = _posq_slot(n_pos, d, dev, zero=False)
             slot = len(_POSQ["parts"]) if (_FOLD_DEFER and len(_POSQ["parts"]) < _FOLD_CAP) else None
-            part = K.relpos_glue(dBD, ldB, p, d, qv, dq, Tq * ldq, ldq, ws, ws[d:], dp, B, H, Tq, dk, replicas=K.LN_REPLICAS,
-                                 replica_stride=2 * d, defer_slot=slot, rows=qr)
+            part = K.relpos_attn_bwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, dO, Tq * d, d, lse, dq, dk_, dv, p,
+                                     d, prm["pos_u"].data.view(-1), prm["pos_v"].data.view(-1), ws, ws[d:], B, H, Tq, dk, key_lens,
+                                     scale, drop_a, replicas=K.LN_REPLICAS, replica_stride=2 * d, defer_slot=slot, rows=qr)
             if slot is not None:
                 _POSQ["parts"].append((part, dp, (B, H, Tq, dk)))
+            else:
+                K.relpos_dp_reduce([part], [dp], B, H, Tq, dk)
             _LNQ["entries"].append((ws, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), d))
             _POSQ["entries"].append((dp, _pos_table_f32(pos_tab), prm["pos_w"].grad, n_pos, d))
             _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
-            glue_done = True
-        if rel and not glue_done and qr is not None:
-            raise NotImplementedError("packed rows: the relative-position backward runs through s2t_relpos_glue only")
-        if rel and not glue_done:
-            fuse_glue = dt == torch.bfloat16 and d == 256 and ldq % 8 == 0
-            # the (Q+v) branch, the add into dq and both bias gradients in one band-limited launch (s2t_relpos_dqv) when the
-            # stack kept the transposed projections
-            pt_glue = getattr(ctx, "pos_pt", None) if (pt is None and _RELPOS_DQV and dt == torch.bfloat16 and ldq % 4 == 0) else None
-            if pt_glue is not None:
-                if _arm_backward_end():  # column sums into the replicated workspace, folded with the LayerNorm gradients
-                    ws = _ln_workspace(d, dev)
-                    K.relpos_dqv(dBD, ldB, pt_glue[0], pt_glue[1], dq, Tq * ldq, ldq, ws, ws[d:], B, H, Tq, dk,
-                                 replicas=K.LN_REPLICAS, replica_stride=2 * d)
-                    _LNQ["entries"].append((ws, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), d))
+            one_pass = True
+        if not one_pass:
+            delta = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
+            n_pos = 2 * Tq - 1
+            ldB = _pad8(n_pos)
+            dBD = _dbd_buffer(H, B, Tq, ldB, dt, dev) if rel else None
+            qv = torch.empty(Mq, d, dtype=dt, device=dev) if rel else None  # q + pos_bias_v, written by the dQ kernel
+            K.attn_fused_bwd(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, dO, Tq * d, d, lse, delta, dq, dk_, dv, dBD,
+                             ldB, B, H, Tq, Tk, dk, key_lens, ctx.causal, scale, p, d,
+                             prm["pos_u"].data.view(-1) if rel else None, prm["pos_v"].data.view(-1) if rel else None, drop_a,
+                             dbd_band_only=rel, pos_pt=pt[0] if pt is not None else None, pt_ld=pt[1] if pt is not None else 0,
+                             dpos_u=prm["pos_u"].grad.view(-1) if pt is not None else None,
+                             dpos_v=prm["pos_v"].grad.view(-1) if pt is not None else None, qv_out=qv, q_rows=qr, k_rows=kr,
+                             o_lo=getattr(ctx, "o_lo", None))
+            ctx.o_lo = None
+            glue_done = False
+            if rel and _RELPOS_GLUE and pt is None and dt == torch.bfloat16 and dk == 64 and Tq <= _GLUE_MAX_T and ldq % 4 == 0 and _arm_backward_end():
+                # everything behind dbd in ONE pass over it (csrc/relpos_glue.hip): the (Q+v) branch added into dq, both bias
+                # gradients (column sums into the replicated workspace, folded with the LayerNorm gradients) and this layer's
+                # gradient w.r.t. the projected positions, queued for the batched linear_pos weight gradient
+                ws = _ln_workspace(d, dev)
+                dp = _posq_slot(n_pos, d, dev, zero=False)
+                slot = len(_POSQ["parts"]) if (_FOLD_DEFER and len(_POSQ["parts"]) < _FOLD_CAP) else None
+                part = K.relpos_glue(dBD, ldB, p, d, qv, dq, Tq * ldq, ldq, ws, ws[d:], dp, B, H, Tq, dk, replicas=K.LN_REPLICAS,
+                                     replica_stride=2 * d, defer_slot=slot, rows=qr)
+                if slot is not None:
+                    _POSQ["parts"].append((part, dp, (B, H, Tq, dk)))
+                _LNQ["entries"].append((ws, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), d))
+                _POSQ["entries"].append((dp, _pos_table_f32(pos_tab), prm["pos_w"].grad, n_pos, d))
+                _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
+                glue_done = True
+            if rel and not glue_done and qr is not None:
+                raise NotImplementedError("packed rows: the relative-position backward runs through s2t_relpos_glue only")
+            if rel and not glue_done:
+                fuse_glue = dt == torch.bfloat16 and d == 256 and ldq % 8 == 0
+                # the (Q+v) branch, the add into dq and both bias gradients in one band-limited launch (s2t_relpos_dqv) when the
+                # stack kept the transposed projections
+                pt_glue = getattr(ctx, "pos_pt", None) if (pt is None and _RELPOS_DQV and dt == torch.bfloat16 and ldq % 4 == 0) else None
+                if pt_glue is not None:
+                    if _arm_backward_end():  # column sums into the replicated workspace, folded with the LayerNorm gradients
+                        ws = _ln_workspace(d, dev)
+                        K.relpos_dqv(dBD, ldB, pt_glue[0], pt_glue[1], dq, Tq * ldq, ldq, ws, ws[d:], B, H, Tq, dk,
+                                     replicas=K.LN_REPLICAS, replica_stride=2 * d)
+                        _LNQ["entries"].append((ws, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), d))
+                    else:
+                        K.relpos_dqv(dBD, ldB, pt_glue[0], pt_glue[1], dq, Tq * ldq, ldq, prm["pos_u"].grad.view(-1),
+                                     prm["pos_v"].grad.view(-1), B, H, Tq, dk)
+                elif pt is None:
+                    if not fuse_glue:
+                        K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
+                    dqv = torch.empty(Mq, d, dtype=dt, device=dev)
+                    K.gemm(dBD, p, dqv, M=Tq, N=dk, K=n_pos, lda=ldB, ldb=d, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
+                           a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
+                    if not fuse_glue:
+                        K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
+                ktiles = (Mq + 63) // 64
+                sk = max(1, min(ktiles, _DP_SPLIT))
+                # two-phase split-K in overwrite mode (c_atomic = 2) needs no zero fill of dp
+                pos32 = _pos_table_f32(pos_tab)
+                queued = _arm_backward_end()
+                dp = _posq_slot(n_pos, d, dev, zero=sk <= 1) if queued else \
+                    (torch.empty if sk > 1 else torch.zeros)(n_pos, d, dtype=torch.float32, device=dev)
+                K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
+                       a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=sk, c_atomic=2 if sk > 1 else True)
+                if queued:  # linear_pos weight gradients of all layers: one batched launch at the end of the pass
+                    _POSQ["entries"].append((dp, pos32, prm["pos_w"].grad, n_pos, d))
                 else:
-                    K.relpos_dqv(dBD, ldB, pt_glue[0], pt_glue[1], dq, Tq * ldq, ldq, prm["pos_u"].grad.view(-1),
-                                 prm["pos_v"].grad.view(-1), B, H, Tq, dk)
-            elif pt is None:
-                if not fuse_glue:
-                    K.colsum_accum(dq, ldq, prm["pos_u"].grad.view(-1), Mq, d)
-                dqv = torch.empty(Mq, d, dtype=dt, device=dev)
-                K.gemm(dBD, p, dqv, M=Tq, N=dk, K=n_pos, lda=ldB, ldb=d, ldc=d, b_kmajor=True, batch=Z, zdiv=H,
-                       a_s=(Tq * ldB, B * Tq * ldB), b_s=(0, dk), c_s=(Tq * d, dk))
-                if not fuse_glue:
-                    K.colsum_accum(dqv, d, prm["pos_v"].grad.view(-1), Mq, d)
-            ktiles = (Mq + 63) // 64
-            sk = max(1, min(ktiles, _DP_SPLIT))
-            # two-phase split-K in overwrite mode (c_atomic = 2) needs no zero fill of dp
-            pos32 = _pos_table_f32(pos_tab)
-            queued = _arm_backward_end()
-            dp = _posq_slot(n_pos, d, dev, zero=sk <= 1) if queued else \
-                (torch.empty if sk > 1 else torch.zeros)(n_pos, d, dtype=torch.float32, device=dev)
-            K.gemm(dBD, qv, dp, M=n_pos, N=dk, K=Mq, lda=ldB, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True, batch=H, zdiv=1,
-                   a_s=(B * Tq * ldB, 0), b_s=(dk, 0), c_s=(dk, 0), split_k=sk, c_atomic=2 if sk > 1 else True)
-            if queued:  # linear_pos weight gradients of all layers: one batched launch at the end of the pass
-                _POSQ["entries"].append((dp, pos32, prm["pos_w"].grad, n_pos, d))
-            else:
-                K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
-                       split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
-            if pt is not None or pt_glue is not None:
-                pass  # the kernel wrote the complete dq and added both bias gradients
-            elif fuse_glue:  # dq += dqv, pos_u.grad += colsum(dq), pos_v.grad += colsum(dqv) in one pass
-                K.add_colsum2(dq, ldq, dqv, d, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), Mq, d)
-            else:
-                dq[:, :d].add_(dqv)
-            _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
+                    K.gemm(dp, pos32, prm["pos_w"].grad, M=d, N=d, K=n_pos, lda=d, ldb=d, ldc=d, a_kmajor=True, b_kmajor=True,
+                           split_k=_POSW_SPLIT if _POSW_SPLIT else max(1, min(8, (n_pos + 63) // 64)), c_atomic=True)
+                if pt is not None or pt_glue is not None:
+                    pass  # the kernel wrote the complete dq and added both bias gradients
+                elif fuse_glue:  # dq += dqv, pos_u.grad += colsum(dq), pos_v.grad += colsum(dqv) in one pass
+                    K.add_colsum2(dq, ldq, dqv, d, prm["pos_u"].grad.view(-1), prm["pos_v"].grad.view(-1), Mq, d)
+                else:
+                    dq[:, :d].add_(dqv)
+                _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
         dxq = None
         dx_ln = None
         if ctx.self_attn:
@@ -2379,6 +2401,7 @@ _POS32 = {}
 # s2t_relpos_glue walks the position rows in chunks of 512 (round 5): any length; S2T_GLUE_MAX_T=256 restores the round-4 routing
 # (longer sequences through s2t_relpos_dqv + the split-K position-table GEMM, padded rows only) for A/B measurements
 _GLUE_MAX_T = int(os.environ.get("S2T_GLUE_MAX_T", "32768"))
+_RELPOS_ONE_PASS = os.environ.get("S2T_RELPOS_ONE_PASS", "1") != "0"  # s2t_relpos_attn_bwd: T' <= 256, the whole rel-pos backward in one launch
 _RELPOS_GLUE = os.environ.get("S2T_RELPOS_GLUE", "1") != "0"  # s2t_relpos_glue: (Q+v) branch + bias sums + position-table gradient in one pass over dbd
 _DP_SPLIT = int(os.environ.get("S2T_DP_SPLIT", "16"))  # K split of the position-table gradient GEMM (M = 2T-1, N = 64 per head, K = B*T)
 _POSW_SPLIT = int(os.environ.get("S2T_POSW_SPLIT", "0"))  # experiment: K split of the small fp32 linear_pos weight-gradient GEMM

@@ -858,6 +858,25 @@ def relpos_glue(dbd, ldb, pos_p, p_sr, qv, dq, dq_sb, dq_sr, dpos_u, dpos_v, dp,
     return part
 
 
+def relpos_attn_bwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, dO, o_sb, o_sr, lse, dq, dk, dv, pos_p, p_sr, pos_u, pos_v,
+                    dpos_u, dpos_v, B, H, T, dkd, key_lens, scale, drop=None, replicas=1, replica_stride=0, defer_slot=None,
+                    rows=None):
+    """s2t_relpos_attn_bwd: the relative-position self-attention backward in one launch (T <= 256).  Returns the scratch that
+    holds the per-utterance partial tables of the position gradient (``relpos_dp_reduce`` sums them); ``defer_slot`` as
+    ``relpos_glue``."""
+    L.require_cuda(q, k, v, o, dO, lse, dq, dk, dv, pos_p, pos_u, pos_v, dpos_u, dpos_v)
+    assert all(t.dtype == torch.bfloat16 for t in (q, k, v, o, dO, dq, dk, dv, pos_p))
+    assert lse.dtype == torch.float32 and dpos_u.dtype == torch.float32 and dpos_v.dtype == torch.float32
+    tag = "relpos_dp_part" if defer_slot is None else "relpos_dp_part%d" % defer_slot
+    part = _scratch(tag, (B * (2 * T - 1) * H * dkd + 1) // 2, q.device)  # fp32 scratch holding the bf16 partials
+    dp, ds, dsite = _drop3(drop)
+    _call("s2t_relpos_attn_bwd", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
+          dO.data_ptr(), o_sb, o_sr, lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), pos_p.data_ptr(), p_sr,
+          pos_u.data_ptr(), pos_v.data_ptr(), dpos_u.data_ptr(), dpos_v.data_ptr(), replicas, replica_stride, part.data_ptr(),
+          B, H, T, dkd, _ptr(key_lens), scale, dp, ds, dsite, _cu(rows))
+    return part
+
+
 def _ptr_array(tensors):
     import ctypes as C
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

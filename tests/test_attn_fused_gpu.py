@@ -549,3 +549,126 @@ def test_an_utterance_without_rows_in_a_packed_batch():
         ob, _ = run([96, 50], rel)
         assert torch.equal(oa, ob), rel
         assert bool((rest_a.float() == 7.0).all()), rel  # nothing stored beyond the live rows
+
+
+@pytest.mark.parametrize("T,B,H,pdrop,lens", [(250, 3, 4, 0.0, None), (250, 3, 4, 0.1, None), (256, 2, 4, 0.1, None),
+                                              (100, 2, 2, 0.0, None), (17, 2, 2, 0.1, None), (33, 1, 4, 0.0, None),
+                                              (250, 4, 4, 0.1, [250, 201, 131, 30]), (256, 3, 2, 0.0, [256, 97, 1])])
+def test_relpos_backward_in_one_pass(T, B, H, pdrop, lens):
+    """s2t_relpos_attn_bwd (csrc/relpos_bwd.hip; espnet_multihead_attention.py:292-356 backward): dq (both branches), dk, dv,
+    the two position-bias gradients and the gradient w.r.t. the projected positions from ONE launch, against float64 autograd on
+    the bf16-rounded operands — uniform rows with padded keys (lens = None: key_lens masks) and a packed batch (lens: rows of
+    utterance b from cu[b]; stale values outside the utterances must not be read or written)."""
+    g = torch.Generator().manual_seed(T * 7 + B + int(pdrop * 100))
+    dk = 64
+    d = H * dk
+    Z = B * H
+    bf = torch.bfloat16
+    packed = lens is not None
+    klen = torch.tensor(lens if packed else [T, max(1, T - 7), max(1, T // 2), 5][:B], dtype=torch.int32)
+    q = (torch.randn(B, T, d, generator=g) * 0.7).to(bf)
+    k = (torch.randn(B, T, d, generator=g) * 0.7).to(bf)
+    v = (torch.randn(B, T, d, generator=g) * 0.7).to(bf)
+    dO = (torch.randn(B, T, d, generator=g) * 0.5).to(bf)
+    pos = (torch.randn(2 * T - 1, d, generator=g) * 0.7).to(bf)
+    u = torch.randn(H, dk, generator=g) * 0.3
+    vb = torch.randn(H, dk, generator=g) * 0.3
+    scale = 1.0 / math.sqrt(dk)
+    seed = torch.full((1,), 4321, dtype=torch.int64, device=DEV)
+    drop = (pdrop, seed, 3) if pdrop > 0 else None
+    if packed:
+        for b in range(B):  # rows beyond an utterance carry no gradient and are not part of the problem
+            dO[b, int(klen[b]):] = 0
+    pp, ud, vbd, kl = pos.to(DEV), u.reshape(-1).to(DEV), vb.reshape(-1).to(DEV), klen.to(DEV)
+    o = torch.empty(B, T, d, dtype=bf, device=DEV)
+    lse = torch.empty(Z, T, dtype=torch.float32, device=DEV)
+    qd, kd, vd, dOd = q.to(DEV), k.to(DEV), v.to(DEV), dO.to(DEV)
+    K.attn_fused_fwd(qd, T * d, d, kd, T * d, d, vd, T * d, d, o, T * d, d, lse, B, H, T, T, dk, kl, False, scale, pp, d, ud, vbd,
+                     drop)
+    R = 4
+    du = torch.full((R, 2, d), 0.5, dtype=torch.float32, device=DEV)
+
+    class _Rows:  # what kernels._cu() reads
+        pass
+
+    if packed:
+        cu = torch.zeros(B + 1, dtype=torch.int32)
+        cu[1:] = torch.cumsum(klen, 0)
+        n = int(cu[-1])
+
+        def pack(t, fill=None):
+            out = torch.full((n + 3, d), 7.0 if fill is None else fill, dtype=bf, device=DEV)
+            for b in range(B):
+                out[int(cu[b]):int(cu[b + 1])] = t[b, :int(klen[b])]
+            return out
+
+        qp, kp, vp, op, dop = pack(qd), pack(kd), pack(vd), pack(o), pack(dOd)
+        dqp, dkp, dvp = pack(qd, 7.0), pack(qd, 7.0), pack(qd, 7.0)
+        dqp.fill_(7.0); dkp.fill_(7.0); dvp.fill_(7.0)
+        from s2t_amd import rows as Rows
+        rows = Rows.attach(kl.clone(), B, T, 0)
+        # (the geometry's cu must be this test's: no halo rows)
+        assert torch.equal(K.rows_geom(rows).cu.cpu()[:B + 1], cu)
+        part = K.relpos_attn_bwd(qp, 0, d, kp, 0, d, vp, 0, d, op, dop, 0, d, lse, dqp, dkp, dvp, pp, d, ud, vbd, du.view(-1),
+                                 du.view(-1)[d:], B, H, T, dk, rows, scale, drop, replicas=R, replica_stride=2 * d, rows=rows)
+        torch.cuda.synchronize()
+        assert float(dqp[n:].float().min()) == 7.0 and float(dkp[n:].float().min()) == 7.0 and float(dvp[n:].float().min()) == 7.0
+
+        def unpack(t):
+            out = torch.zeros(B, T, d, dtype=bf, device=DEV)
+            for b in range(B):
+                out[b, :int(klen[b])] = t[int(cu[b]):int(cu[b + 1])]
+            return out
+
+        dq, dkk, dv = unpack(dqp), unpack(dkp), unpack(dvp)
+    else:
+        dq = torch.full((B, T, d), 7.0, dtype=bf, device=DEV)
+        dkk = torch.full((B, T, d), 7.0, dtype=bf, device=DEV)
+        dv = torch.full((B, T, d), 7.0, dtype=bf, device=DEV)
+        part = K.relpos_attn_bwd(qd, T * d, d, kd, T * d, d, vd, T * d, d, o, dOd, T * d, d, lse, dq, dkk, dv, pp, d, ud, vbd,
+                                 du.view(-1), du.view(-1)[d:], B, H, T, dk, kl, scale, drop, replicas=R, replica_stride=2 * d)
+    dp = torch.full((2 * T - 1, d), 3.0, dtype=torch.float32, device=DEV)
+    K.relpos_dp_reduce([part], [dp], B, H, T, dk)
+    torch.cuda.synchronize()
+
+    # ---- float64 autograd reference on the same bf16-rounded operands
+    qh = q.double().view(B, T, H, dk).permute(0, 2, 1, 3)
+    kh = k.double().view(B, T, H, dk).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    vh = v.double().view(B, T, H, dk).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    qu = (qh + u.double()[None, :, None, :]).to(bf).double().requires_grad_(True)
+    qv = (qh + vb.double()[None, :, None, :]).to(bf).double().requires_grad_(True)
+    ph = pos.double().view(-1, H, dk).permute(1, 2, 0).clone().requires_grad_(True)  # (H, dk, 2T-1)
+    bd_full = qv @ ph[None]
+    idx = (T - 1) - torch.arange(T)[:, None] + torch.arange(T)[None, :]
+    s = (qu @ kh.transpose(-1, -2) + torch.gather(bd_full, 3, idx[None, None].expand(B, H, T, T))) * scale
+    mask = torch.arange(T)[None, :] >= klen.long()[:, None]
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    pr = torch.softmax(s, -1)
+    if pdrop > 0:
+        keep = _dropout_mask(Z, T, T, drop).view(B, H, T, T)
+        pr = pr * keep / (1.0 - pdrop)
+    oref = pr @ vh
+    (oref * dO.double().view(B, T, H, dk).permute(0, 2, 1, 3)).sum().backward()
+
+    def rel_err(got, ref):
+        return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+    valid = (torch.arange(T)[None, :] < klen.long()[:, None]) if packed else torch.ones(B, T, dtype=torch.bool)
+    vm = valid[:, None, :, None].double()
+    got_dq = dq.cpu().double().view(B, T, H, dk).permute(0, 2, 1, 3)
+    got_dk = dkk.cpu().double().view(B, T, H, dk).permute(0, 2, 1, 3)
+    got_dv = dv.cpu().double().view(B, T, H, dk).permute(0, 2, 1, 3)
+    ref_dq = (qu.grad + qv.grad) * vm
+    assert rel_err(got_dq * vm, ref_dq) < 1.5e-2
+    assert rel_err(got_dk, kh.grad) < 1.5e-2
+    assert rel_err(got_dv, vh.grad) < 1.5e-2
+    for b in range(B):  # padded keys get exactly zero gradient
+        if int(klen[b]) < T:
+            assert float(got_dk[b, :, int(klen[b]):].abs().max()) == 0.0 and float(got_dv[b, :, int(klen[b]):].abs().max()) == 0.0
+    got_u = du[:, 0].sum(0).cpu().double().view(H, dk) - 0.5 * R
+    got_v = du[:, 1].sum(0).cpu().double().view(H, dk) - 0.5 * R
+    ref_u, ref_v = (qu.grad * vm).sum((0, 2)), (qv.grad * vm).sum((0, 2))
+    assert (got_u - ref_u).abs().max() <= 2e-2 * ref_u.abs().max() + 1e-4
+    assert (got_v - ref_v).abs().max() <= 2e-2 * ref_v.abs().max() + 1e-4
+    ref_dp = ph.grad.permute(2, 0, 1).reshape(2 * T - 1, d)  # (2T-1, H*dk)
+    assert rel_err(dp.cpu().double(), ref_dp) < 1.5e-2
