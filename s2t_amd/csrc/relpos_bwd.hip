@@ -6,16 +6,25 @@
 // (csrc/relpos_glue.hip: dbd read back): the scores are formed once and dbd never leaves the chip.
 //
 // One workgroup of 8 waves per (utterance, head); resident in LDS for the whole kernel: the head's 2T-1 projected position rows
-// (64 KiB) and its K rows (32 KiB).  Wave w keeps the K / V fragments of keys 32w .. 32w+31 and their dK / dV accumulators, and
-// the accumulators of position tiles {w, w+8, w+16, w+24} of the position-table gradient.  Per tile of 32 queries:
+// (64 KiB) and its K rows (32 KiB).  Wave w keeps the V fragments of keys 32w .. 32w+31 and their dK / dV accumulators, and
+// the accumulators of position tiles {w, w+8, w+16, w+24} of the position-table gradient (144 of its 256 registers).  Per
+// tile of 32 queries:
 //   phase A  (Q+u), (Q+v), dO rows -> LDS; delta = rowsum(dO * O); the tile's columns of the dbd image zeroed
-//   phase B  every wave, its 32 keys x the 32 queries: S = (Q+u) K^T, the position band (Q+v) P^T re-indexed through a
-//            wave-private scratch (the reference's rel_shift), dP = dO V^T, P = exp(S - lse), dropout, dS = P (dP - delta);
-//            dV += Pd^T dO, dK += dS^T (Q+u) straight from the registers; dS (bf16) written SKEWED into the dbd image
-//            [32 q][512 n], n = T-1-i+j — the one exchange of the tile between the three owners of its products
-//   phase C  wave (channel tile, query half):  dQ^T = K^T dS^T (keys gathered along the skew) + P^T dbd^T (aligned rows);
-//            wave (position tiles):            dp^T += (Q+v)^T dbd
-// Three barriers per tile.  All products are 16x16x32 bf16 MFMAs; fragment layouts as in attention_fused.hip / relpos_glue.hip.
+//   phase B  every wave, its 32 keys x the 32 queries: S = (Q+u) K^T, the position band (Q+v) P^T re-indexed inside the
+//            registers (the reference's rel_shift = a rotation of each 16-lane row: DPP), dP = dO V^T, P = exp(S - lse), dropout,
+//            dS = P (dP - delta); dV += Pd^T dO, dK += dS^T (Q+u) straight from the registers; dS (bf16) written to LDS twice:
+//            SKEWED into the dbd image [32 q][512 n], n = T-1-i+j, and by key [32 q][256 j] — the one exchange of the tile
+//            between the three owners of its products
+//   phase C  wave (channel tile, query half):  dQ^T = K^T dS^T (rows of the copy by key) + P^T dbd^T (rows of the image);
+//            wave (position tiles):            dp^T += (Q+v)^T dbd (columns of the image)
+// Three barriers per tile.  Products are 16x16x32 bf16 MFMAs (16x16x16 for dV / dK: one query tile at a time, so that a tile's
+// Pd / dS die early); fragment layouts as in attention_fused.hip / relpos_glue.hip.
+// Measured (tools/rpb_probe.py, 64 utterances x 4 heads, T' = 250, fill 0.8): 70 us; both waves of a SIMD are bound by vector
+// issue in phase B (~870 vector instructions per wave and tile: exponentials, dropout hash, rel_shift, the addresses of 32
+// two-byte LDS writes), the matrix work is ~7 us of it.  What it took to run without scratch spills (each cost 10 - 40 us):
+// lane coordinates re-derived per phase (asm barrier) so that swizzled LDS addresses are not hoisted out of the tile loop; no
+// branch around accumulating MFMAs (a join rotates the ~130 loop-carried registers); one kernel per dropout form; the next
+// tile's rows fetched unconditionally (clamped) at the head of phase C.
 #include "common.h"
 
 #ifndef S2T_RPB_DBG
@@ -42,8 +51,8 @@ constexpr int L_DO = L_QV + TQ * 128;           //                  dO
 constexpr int L_DA = L_DO + TQ * 128;           // [TQ][512 B]      dS of the tile by KEY (unskewed), chunk c of row q at (c ^ (q & 15))
 constexpr int L_ST = L_DA + TQ * 512;           // lse[32], delta[32]
 constexpr int L_BI = L_ST + 2 * TQ * 4;         // pos_bias_u[64], pos_bias_v[64] of the head (floats)
-constexpr int L_CS = L_BI + 2 * DK * 4;          // column sums of the two dQ branches: [8 waves][2][16 channels] floats
-constexpr int L_BYTES = L_CS + 8 * 2 * 16 * 4;
+constexpr int L_BYTES = L_BI + 2 * DK * 4;
+static_assert(TQ * 512 >= 2 * 8 * 64 * 4, "the column sums of the epilogue fit the copy by key");
 static_assert(L_BYTES <= 160 * 1024, "LDS budget");
 
 typedef short s16x4v __attribute__((ext_vector_type(4)));
@@ -281,8 +290,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float* csum = reinterpret_cast<float*>(lds + L_CS) + w * 32;  // this wave's [2][16]: branch, channel 16 ct1 + (0..15)
-  if (lane < 32) csum[lane] = 0.f;
+  float su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
   const int ct1 = w & 3, qh = w >> 2;  // phase C: channel tile and query half of this wave's dQ block
 
   const uint64_t dkey = DROP ? s2t_drop_key(a.drop_seed, a.drop_site) : 0ull;
@@ -573,26 +581,14 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
     }
     RSTAMP();
     {
-      // column sums over the tile's queries for the two position-bias gradients: the 16 query lanes of a channel by DPP row
-      // shifts, the running sums in LDS (eight registers per lane across the tile loop were eight too many)
+      // running column sums of the two dQ branches for the position-bias gradients (per lane; folded after the last tile)
       const bool live = i < nq;
       float n4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         n4[r] = acc3[r] + acc1[r];
-        float u_ = live ? acc3[r] : 0.f, v_ = live ? acc1[r] : 0.f;
-        u_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u_), 0x118, 0xf, 0xf, true));  // row_shr:8
-        v_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_), 0x118, 0xf, 0xf, true));
-        u_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u_), 0x114, 0xf, 0xf, true));  // row_shr:4
-        v_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_), 0x114, 0xf, 0xf, true));
-        u_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u_), 0x112, 0xf, 0xf, true));  // row_shr:2
-        v_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_), 0x112, 0xf, 0xf, true));
-        u_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u_), 0x111, 0xf, 0xf, true));  // row_shr:1
-        v_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_), 0x111, 0xf, 0xf, true));
-        if (xc == 15) {  // lane 15 of the row holds the sum of its 16 lanes
-          csum[4 * yc + r] += u_;
-          csum[16 + 4 * yc + r] += v_;
-        }
+        su[r] += live ? acc3[r] : 0.f;
+        sv[r] += live ? acc1[r] : 0.f;
       }
       if (live) st4_from_f32<bf16_t>(a.dq + (int64_t)b * a.q_sb + (int64_t)i * a.q_sr + h * DK + 16 * ct1 + 4 * yc, n4);
     }
@@ -649,6 +645,24 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
       *reinterpret_cast<uint2*>(lp + n * 128 + (((2 * ct + (y >> 1)) ^ (n & 7)) << 4) + (y & 1) * 8) = v;
     }
   }
+  // column sums of the two dQ branches: 16 query lanes by shuffles, the two waves of a channel tile through LDS (the copy by key
+  // is no longer read: the barrier above), one atomic per channel and branch into a replica of the workspace
+  float* red = reinterpret_cast<float*>(lds + L_DA);  // [2][8 waves][64]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      su[r] += __shfl_xor(su[r], o, 64);
+      sv[r] += __shfl_xor(sv[r], o, 64);
+    }
+  }
+  if (x == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[(0 * 8 + w) * 64 + 4 * y + r] = su[r];
+      red[(1 * 8 + w) * 64 + 4 * y + r] = sv[r];
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -656,11 +670,10 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
     const int n = c >> 3, ch = c & 7;
     if (n < npos) *reinterpret_cast<uint4*>(out + (int64_t)n * d + ch * 8) = *reinterpret_cast<const uint4*>(lp + n * 128 + ((ch ^ (n & 7)) << 4));
   }
-  if (tid < 128) {  // (the running column sums: wave ct and wave ct + 4 hold the two query halves of channel tile ct)
+  if (tid < 128) {
     const int br = tid >> 6, c = tid & 63;
     const int ct = c >> 4, sl = c & 15;
-    const float* cs = reinterpret_cast<const float*>(lds + L_CS);
-    const float sum = cs[ct * 32 + br * 16 + sl] + cs[(ct + 4) * 32 + br * 16 + sl];
+    const float sum = red[(br * 8 + ct) * 64 + sl] + red[(br * 8 + ct + 4) * 64 + sl];
     const int64_t ro = (int64_t)(z % a.replicas) * a.replica_stride;
     atomicAdd((br ? a.dv_ : a.du) + ro + h * DK + c, sum);
   }
