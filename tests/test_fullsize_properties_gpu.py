@@ -8,6 +8,7 @@ V = 10 000), where the CPU oracle is too slow to serve as the checker (SURVEY.md
   * the grouped weight-gradient launch, the per-weight split-K GEMMs and (through the trainer test) graph replay give
     the same gradients.
 """
+import numpy as np
 import pytest
 import torch
 
@@ -233,3 +234,42 @@ def test_conformer_training_pass_repeats(sample):
     print("loss", out[0][0], out[1][0], "grad noise", noise)
     assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[0][0])  # the loss scalar itself is an atomic sum over rows
     assert noise < 1e-4, noise
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_one_pass_relpos_backward_equals_the_three_kernel_route_in_the_model(sample, packed):
+    """The bench's Conformer at its literal batch: a training pass whose relative-position attention backward runs in ONE launch per
+    layer (s2t_relpos_attn_bwd, T' = 250 <= 256) against the same pass on the three-kernel route (s2t_attn_fused_bwd writing the
+    skewed score gradient + s2t_relpos_glue; S2T_RELPOS_ONE_PASS=0) — same loss (the forward is the same code), every parameter
+    gradient equal up to the two routes' roundings (the one-pass kernel rounds dq once, where the glue added into a bf16 dq)."""
+    from s2t_amd import rows as Rows
+
+    old_rows, old_one = Rows.ENABLED, Fn._RELPOS_ONE_PASS
+    res = {}
+    try:
+        Rows.ENABLED = packed
+        for one in (False, True):
+            Fn._RELPOS_ONE_PASS = one
+            torch.manual_seed(2)
+            model = M.S2TTransformerModel.build_model(M.recipe_args(conformer=True, vocab_size=V, encoder_layers=4, decoder_layers=2),
+                                                      M.FakeTask(V)).prepare(torch.bfloat16, DEV)
+            model.train()
+            crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+            model.flat.zero_grad()
+            loss, _, _ = crit(model, sample)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[one] = (float(loss.detach()), {k: p.grad.detach().float().clone() for k, p in model.named_parameters()})
+    finally:
+        Rows.ENABLED, Fn._RELPOS_ONE_PASS = old_rows, old_one
+    assert abs(res[False][0] - res[True][0]) <= 2e-6 * abs(res[False][0]), (res[False][0], res[True][0])
+    errs = {}
+    for k, ga in res[False][1].items():
+        den = float(ga.norm())
+        if den < 1e-6 or k.endswith(("linear_k.bias", "k_proj.bias")):  # (mathematically zero: softmax is shift invariant)
+            continue
+        errs[k] = float((ga - res[True][1][k]).norm()) / den
+    worst = max(errs, key=errs.get)
+    print("one-pass vs three-kernel route (packed=%s): median %.2e, worst %.2e (%s)" % (packed, float(np.median(list(errs.values()))), errs[worst], worst))
+    assert errs[worst] <= 3e-2, (worst, errs[worst])
+    assert float(np.median(list(errs.values()))) <= 5e-3
