@@ -44,15 +44,21 @@ constexpr int KMAX = 256; // keys (= frames) of an utterance
 
 constexpr int L_P = 0;                          // [NP][128 B]      projected position rows of the head, key128 swizzle
 constexpr int L_K = L_P + NP * 128;             // [KMAX][128 B]    K rows of the (utterance, head), key128 swizzle
-constexpr int L_D = L_K + KMAX * 128;           // [TQ][1024 B]     skewed dS of the tile, key1024 swizzle
-constexpr int L_QU = L_D + TQ * 1024;           // [TQ][128 B]      Q + pos_bias_u, (r & 7) swizzle
+// The two dS images have PADDED rows instead of an XOR swizzle (+16 bytes: consecutive rows start four banks apart, so the
+// sixteen rows of a row-wise ds_read_b128 cover the 64 banks once): an element's address is then LINEAR in (query, key), and the
+// 32 two-byte writes of a wave per tile are one base register + an immediate offset each (with the swizzle: six vector
+// instructions of address arithmetic per write, a quarter of the vector work of the phase that bounds the kernel).
+constexpr int DROW = 1024 + 16;                 // row stride of the skewed image (512 columns + pad)
+constexpr int AROW = 512 + 16;                  // row stride of the copy by key (256 keys + pad)
+constexpr int L_D = L_K + KMAX * 128;           // [TQ][DROW]       skewed dS of the tile: row q, column n = T-1-i+j
+constexpr int L_QU = L_D + TQ * DROW;           // [TQ][128 B]      Q + pos_bias_u, (r & 7) swizzle
 constexpr int L_QV = L_QU + TQ * 128;           //                  Q + pos_bias_v
 constexpr int L_DO = L_QV + TQ * 128;           //                  dO
-constexpr int L_DA = L_DO + TQ * 128;           // [TQ][512 B]      dS of the tile by KEY (unskewed), chunk c of row q at (c ^ (q & 15))
-constexpr int L_ST = L_DA + TQ * 512;           // lse[32], delta[32]
+constexpr int L_DA = L_DO + TQ * 128;           // [TQ][AROW]       dS of the tile by KEY (unskewed)
+constexpr int L_ST = L_DA + TQ * AROW;          // lse[32], delta[32]
 constexpr int L_BI = L_ST + 2 * TQ * 4;         // pos_bias_u[64], pos_bias_v[64] of the head (floats)
 constexpr int L_BYTES = L_BI + 2 * DK * 4;
-static_assert(TQ * 512 >= 2 * 8 * 64 * 4, "the column sums of the epilogue fit the copy by key");
+static_assert(TQ * AROW >= 2 * 8 * 64 * 4, "the column sums of the epilogue fit the copy by key");
 static_assert(L_BYTES <= 160 * 1024, "LDS budget");
 
 typedef short s16x4v __attribute__((ext_vector_type(4)));
@@ -88,7 +94,6 @@ __device__ __forceinline__ uint2 tr64(const char* a) {
 }
 // swizzle keys of relpos_glue.hip (natural-order transposed reads without bank conflicts)
 __device__ __forceinline__ int key128(int r) { return 2 * (((r >> 1) & 1) | (((r >> 3) & 1) << 1)); }
-__device__ __forceinline__ int key1024(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
 
 // 8 bf16 + per-column fp32 bias, rounded to bf16 (q + pos_bias_u / q + pos_bias_v as the forward rounds them)
 __device__ __forceinline__ uint4 add_bias8(uint4 qv, const float* __restrict__ bias) {
@@ -167,21 +172,20 @@ __device__ __forceinline__ bf16x8 cols128(const char* img, int row0, int cblk, i
   }
   return as_frag(make_uint4(w[0], w[1], w[2], w[3]));
 }
-// ---- the dbd image (1024-byte rows, key1024) -----------------------------------------------------------------------------
+// ---- the skewed dS image (rows of DROW bytes, no swizzle) ------------------------------------------------------------------
 // column-wise: operand columns = image columns 16 nblk + x, k = image rows 8 y + j
-__device__ __forceinline__ bf16x8 cols1024(const char* img, int nblk, int x, int y) {
+__device__ __forceinline__ bf16x8 colsD(const char* img, int nblk, int x, int y) {
   const int qq = x >> 2, p = x & 3;
   uint32_t w[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int R = 8 * y + 4 * h + qq;
-    const uint2 t = tr64(img + R * 1024 + (((2 * nblk + (p >> 1)) ^ key1024(R)) << 4) + (p & 1) * 8);
+    const uint2 t = tr64(img + R * DROW + nblk * 32 + p * 8);
     w[2 * h] = t.x;
     w[2 * h + 1] = t.y;
   }
   return as_frag(make_uint4(w[0], w[1], w[2], w[3]));
 }
-__device__ __forceinline__ int dbd_addr(int q, int n) { return q * 1024 + ((((n >> 3) ^ key1024(q))) << 4) + (n & 7) * 2; }
 
 // DROP: 0 no dropout, 1 the 32-bit pair hash (even T, index space below 2^32), 2 the general 64-bit-indexed hash — one
 // instantiation each: with both hashes compiled in, the one that never runs still costs registers in a kernel that has none to spare
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
       for (int u = 0; u < 4; ++u) {
         const int c = tl + 512 * u;
         const int r = c >> 6, ch = c & 63;
-        if (ch >= c_lo && ch <= c_hi) *reinterpret_cast<uint4*>(ld + r * 1024 + ((ch ^ key1024(r)) << 4)) = make_uint4(0, 0, 0, 0);
+        if (ch >= c_lo && ch <= c_hi) *reinterpret_cast<uint4*>(ld + r * DROW + ch * 16) = make_uint4(0, 0, 0, 0);
       }
     }
     __syncthreads();
@@ -515,22 +519,22 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
             dk[kt][ct] = mfma16k16(aqu, __builtin_bit_cast(s16x4v, make_uint2(dw[kt][0], dw[kt][1])), dk[kt][ct]);
           }
         }
-        // dS -> the dbd image, skewed: row q, column n = T-1-(q0+q) + key, and the copy by key.  No branch per row: a row beyond
-        // the utterance holds zeros (its probabilities are exp(-inf)), written at the columns of query T-1 when it lies beyond
-        // the padded length too
+        // dS -> the skewed image (row q, column n = T-1-(q0+q) + key) and the copy by key: addresses linear in (q, key), one base
+        // each per lane (query 4y, key 32w + x) and immediate offsets.  No branch per row: a row beyond the utterance holds zeros
+        // (its probabilities are exp(-inf)); beyond the PADDED length its columns run below zero, into the pad and the highest
+        // columns of the row in front of it, which no product of the tile reads (they lie beyond the band of its last row).
+        {
+          char* wi = ld + (4 * yl) * (DROW - 2) + (T - 1 - q0 + 32 * w + xl) * 2;
+          char* wa = lda + (4 * yl) * AROW + (32 * w + xl) * 2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ql = 16 * qt + 4 * yl + r;
-          const int nb = T - 1 - min(q0 + ql, T - 1) + 32 * w + xl;
-          const int rowa = ql * 1024, kq = key1024(ql);
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
-            const int n = nb + 16 * kt, key = 32 * w + 16 * kt + xl;
-            const uint32_t wd = dw[kt][r >> 1];
-            const bf16_t val = (bf16_t)((r & 1) ? (wd >> 16) : (wd & 0xffffu));
-            *reinterpret_cast<bf16_t*>(ld + rowa + (((n >> 3) ^ kq) << 4) + (n & 7) * 2) = val;
-            *reinterpret_cast<bf16_t*>(lda + ql * 512 + (((key >> 3) ^ (ql & 15)) << 4) + (key & 7) * 2) = val;  // the copy by key
-          }
+            for (int kt = 0; kt < 2; ++kt) {
+              const uint32_t wd = dw[kt][r >> 1];
+              const bf16_t val = (bf16_t)((r & 1) ? (wd >> 16) : (wd & 0xffffu));
+              *reinterpret_cast<bf16_t*>(wi + (16 * qt + r) * (DROW - 2) + kt * 32) = val;
+              *reinterpret_cast<bf16_t*>(wa + (16 * qt + r) * AROW + kt * 32) = val;
+            }
         }
       }
     }
@@ -552,8 +556,8 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 #pragma unroll 1
       for (int s = 0; s < nkw; s += 2) {  // (pairs: K rows beyond the utterance are zero and so are the dS of their waves)
         const bf16x8 k0 = cols128(lk, 32 * s, ct1, xc, yc), k1 = cols128(lk, 32 * s + 32, ct1, xc, yc);
-        const bf16x8 b0 = as_frag(*reinterpret_cast<const uint4*>(lda + q * 512 + (((4 * s + yc) ^ (q & 15)) << 4)));
-        const bf16x8 b1 = as_frag(*reinterpret_cast<const uint4*>(lda + q * 512 + (((4 * s + 4 + yc) ^ (q & 15)) << 4)));
+        const bf16x8 b0 = as_frag(*reinterpret_cast<const uint4*>(lda + q * AROW + (4 * s + yc) * 16));
+        const bf16x8 b1 = as_frag(*reinterpret_cast<const uint4*>(lda + q * AROW + (4 * s + 4 + yc) * 16));
         acc3 = mfma16(k0, b0, acc3);
         acc3b = mfma16(k1, b1, acc3b);
       }
@@ -567,14 +571,14 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
       int ks = ks_lo;
       for (; ks + 1 <= ks_hi; ks += 2) {
         const bf16x8 pa0 = cols128(lp, 32 * ks, ct1, xc, yc), pa1 = cols128(lp, 32 * ks + 32, ct1, xc, yc);
-        const bf16x8 db0 = as_frag(*reinterpret_cast<const uint4*>(ld + q * 1024 + (((4 * ks + yc) ^ key1024(q)) << 4)));
-        const bf16x8 db1 = as_frag(*reinterpret_cast<const uint4*>(ld + q * 1024 + (((4 * ks + 4 + yc) ^ key1024(q)) << 4)));
+        const bf16x8 db0 = as_frag(*reinterpret_cast<const uint4*>(ld + q * DROW + (4 * ks + yc) * 16));
+        const bf16x8 db1 = as_frag(*reinterpret_cast<const uint4*>(ld + q * DROW + (4 * ks + 4 + yc) * 16));
         acc1 = mfma16(pa0, db0, acc1);
         accb = mfma16(pa1, db1, accb);
       }
       if (ks <= ks_hi) {
         const bf16x8 pa0 = cols128(lp, 32 * ks, ct1, xc, yc);
-        const bf16x8 db0 = as_frag(*reinterpret_cast<const uint4*>(ld + q * 1024 + (((4 * ks + yc) ^ key1024(q)) << 4)));
+        const bf16x8 db0 = as_frag(*reinterpret_cast<const uint4*>(ld + q * DROW + (4 * ks + yc) * 16));
         acc1 = mfma16(pa0, db0, acc1);
       }
       acc1 += accb;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
       for (int nt = 0; nt < 4; ++nt) {
         const int tg = w + 8 * nt;
         if (tg >= t_lo && tg <= t_hi) {  // (wave-uniform)
-          const bf16x8 dbn = cols1024(ld, tg, xc, yc);
+          const bf16x8 dbn = colsD(ld, tg, xc, yc);
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) dp[nt][ct] = mfma16(qa[ct], dbn, dp[nt][ct]);
         }

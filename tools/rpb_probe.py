@@ -45,7 +45,7 @@ for r in range(7):
     ts.append(e0.elapsed_time(e1) * 100)
 print("relpos_attn_bwd %d rows (fill %.2f): %.1f us" % (n, n / (B * T), sorted(ts)[3]), flush=True)
 st = part.view(torch.int64)[(B * (2 * T - 1) * d * 2) // 8:][:8 * 16].cpu().view(8, 16)
-if int(st[0, 0]) != 0 and int(st[0, 1]) > int(st[0, 0]):
+if int(st[0, 0]) > 0 and 0 < int(st[0, 1]) - int(st[0, 0]) < 10 ** 9:
     # stamps: 0 loop start | second tile: 1 after the top barrier, 2 after phase A + barrier, 3 end of phase B, 4 after the barrier,
     # 5 after product (3), 6 after product (1), 7 after the dq store + product (2) | 8 after the loop
     names = ["tile0", "A+bar", "B", "wait", "(3)", "(1)", "st+(2)", "tiles2.."]
