@@ -476,8 +476,9 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
                 const uint32_t hm = s2t_mix32(pair ^ (uint32_t)dkey) ^ (uint32_t)(dkey >> 32);
                 const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xf, 0xf, true);  // lane xl ^ 1
                 const uint32_t h0 = (xl & 1) ? ho : hm, h1 = (xl & 1) ? hm : ho;
-                rbits[rb] = (jck & 1) ? (h0 >> 16) : (h0 & 0xffffu);
-                rbits[rb + 1] = (jck & 1) ? (h1 >> 16) : (h1 & 0xffffu);
+                const uint32_t hsh = (uint32_t)(jck & 1) << 4;  // the odd key of a pair takes the high half: one bit-field extract
+                rbits[rb] = __builtin_amdgcn_ubfe(h0, hsh, 16);
+                rbits[rb + 1] = __builtin_amdgcn_ubfe(h1, hsh, 16);
               }
             } else {
 #pragma unroll
@@ -495,12 +496,12 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
             const float p = __expf(ok ? s4[kt][r] * a.scale - lse4[r] : -INFINITY);
             float dpv = dp4[kt][r], pdrop = p;
             if constexpr (DROP != 0 && !(S2T_RPB_DBG & 8)) {
-              const bool keep = rbits[r] >= dth;
-              dpv = keep ? dpv * dinv : 0.f;
-              pdrop = keep ? p * dinv : 0.f;
+              const float m = rbits[r] >= dth ? dinv : 0.f;  // (one select on the multiplier instead of one per product)
+              dpv *= m;
+              pdrop = p * m;
             }
             pd4[r] = pdrop;
-            ds4[r] = p * (dpv - del4[r]) * a.scale;
+            ds4[r] = (p * a.scale) * (dpv - del4[r]);
           }
           pw[kt][0] = bf16pack(pd4[0], pd4[1]);
           pw[kt][1] = bf16pack(pd4[2], pd4[3]);
