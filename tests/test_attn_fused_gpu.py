@@ -553,7 +553,9 @@ def test_an_utterance_without_rows_in_a_packed_batch():
 
 @pytest.mark.parametrize("T,B,H,pdrop,lens", [(250, 3, 4, 0.0, None), (250, 3, 4, 0.1, None), (256, 2, 4, 0.1, None),
                                               (100, 2, 2, 0.0, None), (17, 2, 2, 0.1, None), (33, 1, 4, 0.0, None),
-                                              (250, 4, 4, 0.1, [250, 201, 131, 30]), (256, 3, 2, 0.0, [256, 97, 1])])
+                                              (251, 2, 4, 0.1, None), (3, 2, 2, 0.0, None), (64, 2, 8, 0.1, None),
+                                              (250, 4, 4, 0.1, [250, 201, 131, 30]), (256, 3, 2, 0.0, [256, 97, 1]),
+                                              (251, 3, 2, 0.1, [251, 64, 33])])
 def test_relpos_backward_in_one_pass(T, B, H, pdrop, lens):
     """s2t_relpos_attn_bwd (csrc/relpos_bwd.hip; espnet_multihead_attention.py:292-356 backward): dq (both branches), dk, dv,
     the two position-bias gradients and the gradient w.r.t. the projected positions from ONE launch, against float64 autograd on
@@ -672,3 +674,60 @@ def test_relpos_backward_in_one_pass(T, B, H, pdrop, lens):
     assert (got_v - ref_v).abs().max() <= 2e-2 * ref_v.abs().max() + 1e-4
     ref_dp = ph.grad.permute(2, 0, 1).reshape(2 * T - 1, d)  # (2T-1, H*dk)
     assert rel_err(dp.cpu().double(), ref_dp) < 1.5e-2
+
+
+def test_relpos_backward_in_one_pass_with_an_empty_utterance_and_refused_shapes():
+    """A packed batch may hold an utterance without rows (cu[b] == cu[b + 1]): nothing of it is read, its gradient rows do not
+    exist, and its table of the position gradient is ZERO (the reduction sums every utterance's table) — the other utterances'
+    results equal those of the batch without it.  Sequences beyond 256 frames are refused (S2T_ERR_UNSUPPORTED: the three-kernel
+    route takes them)."""
+    from s2t_amd import rows as Rows
+
+    T, H, dk = 100, 2, 64
+    d = H * dk
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    scale = 1.0 / math.sqrt(dk)
+    pos = (torch.randn(2 * T - 1, d, generator=g) * 0.7).to(bf).to(DEV)
+    u = (torch.randn(d, generator=g) * 0.3).to(DEV)
+    vb = (torch.randn(d, generator=g) * 0.3).to(DEV)
+
+    def run(lens):
+        B = len(lens)
+        n = sum(lens)
+        gg = torch.Generator().manual_seed(5)
+        rowsd = {k_: (torch.randn(sum(l for l in lens if l), d, generator=gg) * 0.6).to(bf).to(DEV) for k_ in "qkvoD"}
+        lse = torch.zeros(B * H, T, dtype=torch.float32, device=DEV)
+        lse_live = torch.randn(sum(1 for l in lens if l) * H, T, generator=gg).to(DEV) + 6.0
+        j = 0
+        for b, l in enumerate(lens):
+            if l:
+                lse[b * H:(b + 1) * H] = lse_live[j * H:(j + 1) * H]
+                j += 1
+        kl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        rows = Rows.attach(kl, B, T, 0)
+        dq = torch.full((n + 2, d), 7.0, dtype=bf, device=DEV)
+        dkk, dv = dq.clone(), dq.clone()
+        du = torch.zeros(2, d, dtype=torch.float32, device=DEV)
+        part = K.relpos_attn_bwd(rowsd["q"], 0, d, rowsd["k"], 0, d, rowsd["v"], 0, d, rowsd["o"], rowsd["D"], 0, d, lse, dq, dkk, dv,
+                                 pos, d, u, vb, du.view(-1), du.view(-1)[d:], B, H, T, dk, rows, scale, None, rows=rows)
+        dp = torch.empty(2 * T - 1, d, dtype=torch.float32, device=DEV)
+        K.relpos_dp_reduce([part], [dp], B, H, T, dk)
+        torch.cuda.synchronize()
+        tables = part.view(torch.bfloat16)[:B * (2 * T - 1) * d].view(B, 2 * T - 1, d).float().clone()
+        return dq[:n].float(), dkk[:n].float(), dv[:n].float(), du.clone(), dp.clone(), tables, (dq[n:], dkk[n:], dv[n:])
+
+    a = run([100, 0, 37])
+    b = run([100, 37])
+    for x_, y_ in zip(a[:3], b[:3]):
+        assert torch.equal(x_, y_)
+    assert torch.equal(a[3], b[3]) and torch.allclose(a[4], b[4], rtol=0, atol=0)
+    assert float(a[5][1].abs().max()) == 0.0 and torch.equal(a[5][0], b[5][0]) and torch.equal(a[5][2], b[5][1])
+    assert all(float(t.float().min()) == 7.0 and float(t.float().max()) == 7.0 for t in a[6])
+    # beyond 256 frames: refused
+    Tl = 257
+    z = torch.zeros(Tl, d, dtype=bf, device=DEV)
+    with pytest.raises(RuntimeError):
+        K.relpos_attn_bwd(z, Tl * d, d, z, Tl * d, d, z, Tl * d, d, z, z, Tl * d, d, torch.zeros(H, Tl, device=DEV), z.clone(), z.clone(),
+                          z.clone(), torch.zeros(2 * Tl - 1, d, dtype=bf, device=DEV), d, u, vb, torch.zeros(d, device=DEV),
+                          torch.zeros(d, device=DEV), 1, H, Tl, dk, None, scale, None)
