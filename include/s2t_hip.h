@@ -269,6 +269,18 @@ int s2t_relpos_attn_bwd(const void* q, int64_t q_sb, int64_t q_sr, const void* k
                         float* dpos_u, float* dpos_v, int replicas, int64_t replica_stride, void* dp_part, int B, int H, int T,
                         int dk_dim, const int32_t* key_lens, float scale, float drop_p, const uint64_t* drop_seed,
                         uint32_t drop_site, const int32_t* cu, void* stream);
+/* The same schedule for PLAIN scaled-dot-product attention (multihead_attention.py:161-431 backward; csrc/relpos_bwd.hip, the
+ * kernel without its position terms): what the two kernels of s2t_attn_fused_bwd compute — dq, dk, dv in the layouts of q, k, v —
+ * from ONE launch, scores and probabilities formed once, delta = rowsum(dO * (o + o_lo)) taken inside (no delta buffer).
+ * Queries and keys may differ in number (Tq, Tk) and packing (cu_q, cu_k); causal != 0 masks key j > query i; key_lens masks
+ * keys at and beyond key_lens[b]; dropout as s2t_attn_fused_fwd (mask index ((b*H+h)*Tq + i)*Tk + j).  An utterance without
+ * queries gives zero dk / dv rows, one without keys zero dq rows.
+ * Limits: bf16, dk = 64, Tk <= 256 (S2T_ERR_UNSUPPORTED beyond: s2t_attn_fused_bwd), row strides % 8 == 0, 16-byte aligned. */
+int s2t_attn_bwd_one_pass(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
+                          int64_t v_sb, int64_t v_sr, const void* o, const void* dO, int64_t o_sb, int64_t o_sr, const float* lse,
+                          void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int dk_dim, const int32_t* key_lens,
+                          int causal, float scale, float drop_p, const uint64_t* drop_seed, uint32_t drop_site,
+                          const int32_t* cu_q, const int32_t* cu_k, const void* o_lo, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grouped weight gradients: all dW[M=Nout][N=Kin] += alpha * dY[K=rows][M]^T @ X[K][N] (bf16 in, fp32 accumulate) of one

@@ -77,7 +77,11 @@ struct RpbArgs {
   int replicas;
   int64_t replica_stride;
   bf16_t* dp_part;  // [B][2T-1][H*64]
-  int B, H, T;
+  int B, H, T;      // T: the (padded) number of queries — with positions also that of the keys
+  int Tk;           // (plain form) the padded number of keys
+  int causal;       // (plain form) key j > query i masked
+  const bf16_t* o_lo;  // (plain form, optional) the forward's rounding remainder of o: delta is taken on o + o_lo
+  const int32_t* cu_k; // (plain form) packed key side: rows of utterance b of k, v, dk, dv = cu_k[b] .. cu_k[b+1]
   const int32_t* key_lens;
   float scale;
   float drop_p;
@@ -189,7 +193,11 @@ __device__ __forceinline__ bf16x8 colsD(const char* img, int nblk, int x, int y)
 
 // DROP: 0 no dropout, 1 the 32-bit pair hash (even T, index space below 2^32), 2 the general 64-bit-indexed hash — one
 // instantiation each: with both hashes compiled in, the one that never runs still costs registers in a kernel that has none to spare
-template <int DROP>
+// REL: the relative-position form.  false: plain scaled-dot-product attention (multihead_attention.py:161-431 backward; the decoder's
+// self- and encoder-decoder attention, the encoder of the plain Transformer recipes) on the same schedule — no position image, no
+// skewed image, products (1) and (2) and the bias sums compiled away; queries and keys may differ in number and packing, the
+// causal mask and the o_lo form of delta exist only here.
+template <int DROP, bool REL>
 __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in) {
   __shared__ __attribute__((aligned(16))) char lds[L_BYTES];
   RpbArgs a = a_in;
@@ -201,15 +209,24 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
   const int T = a.T;
   const int npos = 2 * T - 1;
   const int d = a.H * DK;
-  int nq = T;
+  const int Tk = REL ? T : a.Tk;
+  int nq = T, nk = Tk;
   if (a.cu) {
     const int r0 = a.cu[b];
     nq = a.cu[b + 1] - r0;
-    const int64_t oq = (int64_t)r0 * a.q_sr - (int64_t)b * a.q_sb, ok = (int64_t)r0 * a.k_sr - (int64_t)b * a.k_sb;
-    const int64_t ov = (int64_t)r0 * a.v_sr - (int64_t)b * a.v_sb, oo = (int64_t)r0 * a.o_sr - (int64_t)b * a.o_sb;
-    a.q += oq; a.dq += oq; a.k += ok; a.dk += ok; a.v += ov; a.dv += ov; a.o += oo; a.dO += oo;
+    const int64_t oq = (int64_t)r0 * a.q_sr - (int64_t)b * a.q_sb, oo = (int64_t)r0 * a.o_sr - (int64_t)b * a.o_sb;
+    a.q += oq; a.dq += oq; a.o += oo; a.dO += oo;
+    if (!REL && a.o_lo) a.o_lo += oo;
   }
-  const int klen = a.key_lens ? min(a.key_lens[b], nq) : nq;
+  const int32_t* cuk = REL ? a.cu : a.cu_k;
+  if (REL) nk = nq;
+  if (cuk) {
+    const int r0 = cuk[b];
+    nk = cuk[b + 1] - r0;
+    const int64_t ok = (int64_t)r0 * a.k_sr - (int64_t)b * a.k_sb, ov = (int64_t)r0 * a.v_sr - (int64_t)b * a.v_sb;
+    a.k += ok; a.dk += ok; a.v += ov; a.dv += ov;
+  }
+  const int klen = a.key_lens ? min(a.key_lens[b], nk) : nk;
   char* lp = lds + L_P;
   char* lk = lds + L_K;
   char* ld = lds + L_D;
@@ -219,11 +236,20 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
   char* lda = lds + L_DA;
   float* lse_s = reinterpret_cast<float*>(lds + L_ST);
   float* del_s = lse_s + TQ;
-  bf16_t* out = a.dp_part + ((int64_t)b * npos) * d + h * DK;
+  bf16_t* out = REL ? a.dp_part + ((int64_t)b * npos) * d + h * DK : nullptr;
 
-  if (nq <= 0) {  // an utterance without rows: its table of partial sums is zero (the reduction adds every utterance's)
+  if (REL && nq <= 0) {  // an utterance without rows: its table of partial sums is zero (the reduction adds every utterance's)
     for (int c = tid; c < npos * 8; c += 512)
       *reinterpret_cast<uint4*>(out + (int64_t)(c >> 3) * d + (c & 7) * 8) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  if (!REL && (nq <= 0 || nk <= 0)) {  // no query of the utterance: its keys get zero gradients; no key: its queries do
+    for (int c = tid; c < max(nk, 0) * 8; c += 512) {
+      *reinterpret_cast<uint4*>(a.dk + (int64_t)b * a.k_sb + (int64_t)(c >> 3) * a.k_sr + h * DK + (c & 7) * 8) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(a.dv + (int64_t)b * a.v_sb + (int64_t)(c >> 3) * a.v_sr + h * DK + (c & 7) * 8) = make_uint4(0, 0, 0, 0);
+    }
+    for (int c = tid; c < max(nq, 0) * 8; c += 512)
+      *reinterpret_cast<uint4*>(a.dq + (int64_t)b * a.q_sb + (int64_t)(c >> 3) * a.q_sr + h * DK + (c & 7) * 8) = make_uint4(0, 0, 0, 0);
     return;
   }
   const bf16_t* qb = a.q + (int64_t)b * a.q_sb + h * DK;
@@ -231,9 +257,10 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
   const bf16_t* vb = a.v + (int64_t)b * a.v_sb + h * DK;
   const bf16_t* ob = a.o + (int64_t)b * a.o_sb + h * DK;
   const bf16_t* dob = a.dO + (int64_t)b * a.o_sb + h * DK;
+  const bf16_t* olb = (!REL && a.o_lo) ? a.o_lo + (int64_t)b * a.o_sb + h * DK : nullptr;
 
   // ---- tile operands global -> registers (one tile ahead): threads 0..255 the Q pieces, 256..511 the dO and O pieces
-  uint4 t0 = make_uint4(0, 0, 0, 0), t1 = make_uint4(0, 0, 0, 0);
+  uint4 t0 = make_uint4(0, 0, 0, 0), t1 = make_uint4(0, 0, 0, 0), t2 = make_uint4(0, 0, 0, 0);
   float nlse = 0.f;
   const int prow = (tid & 255) >> 3, pch = tid & 7;
   auto tile_load = [&](int q0) __attribute__((always_inline)) {
@@ -243,6 +270,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
     } else {
       t0 = ldg16(dob + (int64_t)r * a.o_sr + pch * 8);
       t1 = ldg16(ob + (int64_t)r * a.o_sr + pch * 8);
+      if (!REL && olb) t2 = ldg16(olb + (int64_t)r * a.o_sr + pch * 8);
     }
     if (tid < TQ) nlse = a.lse[(int64_t)z * T + min(q0 + tid, nq - 1)];
   };
@@ -250,38 +278,42 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 
   // ---- resident images: the head's position rows (rows >= 2T-1 zero) and the K rows (rows >= nq zero)
   {
-    const bf16_t* pp = a.pos_p + h * DK;
     uint4 t[8];
+    if constexpr (REL) {
+      const bf16_t* pp = a.pos_p + h * DK;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = tid + 512 * u;
-      t[u] = ldg16(pp + (int64_t)min(c >> 3, npos - 1) * a.p_sr + (c & 7) * 8);
+      for (int u = 0; u < 8; ++u) {
+        const int c = tid + 512 * u;
+        t[u] = ldg16(pp + (int64_t)min(c >> 3, npos - 1) * a.p_sr + (c & 7) * 8);
+      }
     }
     uint4 tk[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int c = tid + 512 * u;
-      tk[u] = ldg16(kb + (int64_t)min(c >> 3, nq - 1) * a.k_sr + (c & 7) * 8);
+      tk[u] = ldg16(kb + (int64_t)min(c >> 3, nk - 1) * a.k_sr + (c & 7) * 8);
     }
+    if constexpr (REL) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int c = tid + 512 * u;
-      const int n = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ key128(n)) << 4)) = n < npos ? t[u] : make_uint4(0, 0, 0, 0);
+      for (int u = 0; u < 8; ++u) {
+        const int c = tid + 512 * u;
+        const int n = c >> 3, ch = c & 7;
+        *reinterpret_cast<uint4*>(lp + n * 128 + ((ch ^ key128(n)) << 4)) = n < npos ? t[u] : make_uint4(0, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int c = tid + 512 * u;
       const int n = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(lk + n * 128 + ((ch ^ key128(n)) << 4)) = n < nq ? tk[u] : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(lk + n * 128 + ((ch ^ key128(n)) << 4)) = n < nk ? tk[u] : make_uint4(0, 0, 0, 0);
     }
   }
   // ---- this wave's keys: fragments (B operands: lane x = key, k = 32 ks + 8 y + j) and accumulators
-  const int nkw = (nq + 31) >> 5;            // waves that hold keys
+  const int nkw = (nk + 31) >> 5;            // waves that hold keys
   bf16x8 vf[2][2];  // (the K fragments are row reads of the resident image: 16 registers fewer across the tile loop)
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
-    const bf16_t* vp = vb + (int64_t)min(32 * w + 16 * kt + x, nq - 1) * a.v_sr;
+    const bf16_t* vp = vb + (int64_t)min(32 * w + 16 * kt + x, nk - 1) * a.v_sr;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) vf[kt][ks] = as_frag(ldg16(vp + (ks * 4 + y) * 8));
   }
@@ -301,7 +333,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
   const uint32_t dth = s2t_drop_thresh(a.drop_p);
   const float dinv = s2t_drop_scale(a.drop_p);
   float* bias_s = reinterpret_cast<float*>(lds + L_BI);
-  if (tid < 2 * DK) bias_s[tid] = tid < DK ? a.pos_u[h * DK + tid] : a.pos_v[h * DK + tid - DK];
+  if (REL && tid < 2 * DK) bias_s[tid] = tid < DK ? a.pos_u[h * DK + tid] : a.pos_v[h * DK + tid - DK];
 
 #if S2T_RPB_DBG & 64
   unsigned long long stamp[16];  // kernel start .. loop, the nine stamps of the second tile, loop end
@@ -336,8 +368,12 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
       if (tl < 256) {
         const int r = prow_;
         const uint4 z4 = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(lqu + r * 128 + ((pch_ ^ (r & 7)) << 4)) = live ? add_bias8(t0, bias_s + pch_ * 8) : z4;
-        *reinterpret_cast<uint4*>(lqv + r * 128 + ((pch_ ^ (r & 7)) << 4)) = live ? add_bias8(t0, bias_s + DK + pch_ * 8) : z4;
+        if constexpr (REL) {
+          *reinterpret_cast<uint4*>(lqu + r * 128 + ((pch_ ^ (r & 7)) << 4)) = live ? add_bias8(t0, bias_s + pch_ * 8) : z4;
+          *reinterpret_cast<uint4*>(lqv + r * 128 + ((pch_ ^ (r & 7)) << 4)) = live ? add_bias8(t0, bias_s + DK + pch_ * 8) : z4;
+        } else {
+          *reinterpret_cast<uint4*>(lqu + r * 128 + ((pch_ ^ (r & 7)) << 4)) = live ? t0 : z4;
+        }
       } else {
         const int r = prow_;
         *reinterpret_cast<uint4*>(ldo + r * 128 + ((pch_ ^ (r & 7)) << 4)) = live ? t0 : make_uint4(0, 0, 0, 0);
@@ -347,18 +383,27 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
         for (int t = 0; t < 4; ++t)
           part += __uint_as_float(ow[t] << 16) * __uint_as_float(dw[t] << 16) +
                   __uint_as_float(ow[t] & 0xffff0000u) * __uint_as_float(dw[t] & 0xffff0000u);
+        if (!REL && olb) {  // (workgroup-uniform) delta on o + o_lo: 16 mantissa bits of the forward's fp32 output
+          const uint32_t lw[4] = {t2.x, t2.y, t2.z, t2.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            part += __uint_as_float(lw[t] << 16) * __uint_as_float(dw[t] << 16) +
+                    __uint_as_float(lw[t] & 0xffff0000u) * __uint_as_float(dw[t] & 0xffff0000u);
+        }
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);
         part += __shfl_xor(part, 4, 64);
         if (pch_ == 0) del_s[r] = part;
       }
       if (tl < TQ) lse_s[tl] = nlse;
-      // zero the touched columns of the image (32 rows xl 64 chunks, 4 pieces per thread)
+      // zero the touched columns of the image (32 rows x 64 chunks, 4 pieces per thread)
+      if constexpr (REL) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = tl + 512 * u;
-        const int r = c >> 6, ch = c & 63;
-        if (ch >= c_lo && ch <= c_hi) *reinterpret_cast<uint4*>(ld + r * DROW + ch * 16) = make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+          const int c = tl + 512 * u;
+          const int r = c >> 6, ch = c & 63;
+          if (ch >= c_lo && ch <= c_hi) *reinterpret_cast<uint4*>(ld + r * DROW + ch * 16) = make_uint4(0, 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -375,7 +420,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
         f32x4 s4[2], dp4[2], bd[3];
         uint32_t pw[2][2], dw[2][2];  // Pd and dS of this query tile as bf16 pairs: [key tile][queries 4y + (0, 1) | (2, 3)]
         // position band of (16 q x 32 keys): rows n = nb0 + (0..46), nb0 = T-1-(q0+16qt+15) + 32w; lane x = n index of a tile
-        {
+        if constexpr (REL) {
           bf16x8 qv[2];
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) qv[ks] = rows7(lqv, qt, ks, xl, yl);
@@ -407,6 +452,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
         // the LDS crossbar, twelve per query tile, one wait — and a select between the two tiles.  (Before: twelve LDS writes,
         // eight reads and four waits per query tile through a wave-private scratch of 18 KiB in all; as DPP row rotates, whose
         // amount cannot depend on the row: three per register, 72 vector instructions per tile in a phase bound by vector issue.)
+        if constexpr (REL)
         {
           float rt[3][4];
 #if S2T_RPB_SHIFT == 1
@@ -461,7 +507,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           const int jkey = 32 * w + 16 * kt + xl;
-          const int jck = min(jkey, nq - 1);
+          const int jck = min(jkey, nk - 1);
           const bool key_okk = jkey < klen;
           // dropout bits as attn_bwd_dkv_kernel draws them: one 32-bit hash serves an even / odd key pair of a query row; lanes
           // xl and xl ^ 1 hash one query each of a pair of queries and swap
@@ -471,7 +517,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 #pragma unroll
               for (int rb = 0; rb < 4; rb += 2) {
                 const int im = min(q0 + 16 * qt + 4 * yl + rb + (xl & 1), nq - 1);
-                const uint32_t pair = (uint32_t)z * (uint32_t)T * (uint32_t)(T >> 1) + __umul24((uint32_t)im, (uint32_t)(T >> 1)) +
+                const uint32_t pair = (uint32_t)z * (uint32_t)T * (uint32_t)(Tk >> 1) + __umul24((uint32_t)im, (uint32_t)(Tk >> 1)) +
                                       (uint32_t)(jck >> 1);
                 const uint32_t hm = s2t_mix32(pair ^ (uint32_t)dkey) ^ (uint32_t)(dkey >> 32);
                 const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xf, 0xf, true);  // lane xl ^ 1
@@ -484,7 +530,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int i = min(q0 + 16 * qt + 4 * yl + r, nq - 1);
-                rbits[r] = s2t_rand_u32(dkey, ((uint64_t)z * T + (uint64_t)i) * (uint64_t)T + jck);
+                rbits[r] = s2t_rand_u32(dkey, ((uint64_t)z * T + (uint64_t)i) * (uint64_t)Tk + jck);
               }
             }
           }
@@ -492,7 +538,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = q0 + 16 * qt + 4 * yl + r;
-            const bool ok = key_okk & (i < nq);
+            const bool ok = key_okk & (i < nq) & !(!REL && a.causal != 0 && jkey > i);
             const float p = __expf(ok ? s4[kt][r] * a.scale - lse4[r] : -INFINITY);
             float dpv = dp4[kt][r], pdrop = p;
             if constexpr (DROP != 0 && !(S2T_RPB_DBG & 8)) {
@@ -525,7 +571,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
         // (its probabilities are exp(-inf)); beyond the PADDED length its columns run below zero, into the pad and the highest
         // columns of the row in front of it, which no product of the tile reads (they lie beyond the band of its last row).
         {
-          char* wi = ld + (4 * yl) * (DROW - 2) + (T - 1 - q0 + 32 * w + xl) * 2;
+          char* wi = REL ? ld + (4 * yl) * (DROW - 2) + (T - 1 - q0 + 32 * w + xl) * 2 : nullptr;
           char* wa = lda + (4 * yl) * AROW + (32 * w + xl) * 2;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -533,7 +579,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
             for (int kt = 0; kt < 2; ++kt) {
               const uint32_t wd = dw[kt][r >> 1];
               const bf16_t val = (bf16_t)((r & 1) ? (wd >> 16) : (wd & 0xffffu));
-              *reinterpret_cast<bf16_t*>(wi + (16 * qt + r) * (DROW - 2) + kt * 32) = val;
+              if constexpr (REL) *reinterpret_cast<bf16_t*>(wi + (16 * qt + r) * (DROW - 2) + kt * 32) = val;
               *reinterpret_cast<bf16_t*>(wa + (16 * qt + r) * AROW + kt * 32) = val;
             }
         }
@@ -566,7 +612,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
     }
     RSTAMP();
     // (1) dQ(bd)^T[c][q] = sum_n P^T[c][n] dbd^T[n][q] over the touched columns (k-steps of 32)
-    if (!(S2T_RPB_DBG & 1)) {
+    if constexpr (REL && !(S2T_RPB_DBG & 1)) {
       f32x4 accb = {0.f, 0.f, 0.f, 0.f};
       const int ks_lo = nlo >> 5, ks_hi = nhi >> 5;
       int ks = ks_lo;
@@ -592,13 +638,15 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         n4[r] = acc3[r] + acc1[r];
-        su[r] += live ? acc3[r] : 0.f;
-        sv[r] += live ? acc1[r] : 0.f;
+        if constexpr (REL) {
+          su[r] += live ? acc3[r] : 0.f;
+          sv[r] += live ? acc1[r] : 0.f;
+        }
       }
       if (live) st4_from_f32<bf16_t>(a.dq + (int64_t)b * a.q_sb + (int64_t)i * a.q_sr + h * DK + 16 * ct1 + 4 * yc, n4);
     }
     // (2) dp^T[c][n] += sum_q (Q+v)^T[c][q] dbd[q][n]: this wave's position tiles w + 8 nt that meet the touched columns
-    if (!(S2T_RPB_DBG & 2)) {
+    if constexpr (REL && !(S2T_RPB_DBG & 2)) {
       const int t_lo = nlo >> 4, t_hi = nhi >> 4;
       bf16x8 qa[4];
 #pragma unroll
@@ -618,7 +666,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 #if S2T_RPB_DBG & 64
   stamp_on = 1;
   RSTAMP();
-  if (lane == 0 && blockIdx.x == 0) {
+  if (REL && lane == 0 && blockIdx.x == 0) {
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.dp_part + (int64_t)a.B * npos * d) + w * 16;
     for (int t = 0; t < 16; ++t) dbg[t] = t < nstamp ? stamp[t] : 0ull;
   }
@@ -627,7 +675,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
     const int j = 32 * w + 16 * kt + x;
-    if (j < nq) {
+    if (j < nk) {
       bf16_t* kp = a.dk + (int64_t)b * a.k_sb + (int64_t)j * a.k_sr + h * DK;
       bf16_t* vp = a.dv + (int64_t)b * a.v_sb + (int64_t)j * a.v_sr + h * DK;
 #pragma unroll
@@ -639,6 +687,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
       }
     }
   }
+  if constexpr (REL) {
   // ---- dp^T -> [n][64 channels] bf16 rows in LDS (the position image's place), then whole 128-byte rows to the partial table
   __syncthreads();  // every product is done with the position image
 #pragma unroll
@@ -682,6 +731,7 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
     const int64_t ro = (int64_t)(z % a.replicas) * a.replica_stride;
     atomicAdd((br ? a.dv_ : a.du) + ro + h * DK + c, sum);
   }
+  }
 }
 
 }  // namespace
@@ -708,12 +758,39 @@ extern "C" int s2t_relpos_attn_bwd(const void* q, int64_t q_sb, int64_t q_sr, co
   a.o = (const bf16_t*)o; a.dO = (const bf16_t*)dO; a.o_sb = o_sb; a.o_sr = o_sr; a.lse = lse;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.pos_p = (const bf16_t*)pos_p; a.p_sr = p_sr;
   a.pos_u = pos_u; a.pos_v = pos_v; a.du = dpos_u; a.dv_ = dpos_v; a.replicas = replicas; a.replica_stride = replica_stride;
-  a.dp_part = (bf16_t*)dp_part; a.B = B; a.H = H; a.T = T; a.key_lens = key_lens; a.scale = scale; a.drop_p = drop_p;
+  a.dp_part = (bf16_t*)dp_part; a.B = B; a.H = H; a.T = T; a.Tk = T; a.key_lens = key_lens; a.scale = scale; a.drop_p = drop_p;
   a.drop_seed = drop_seed; a.drop_site = drop_site; a.cu = cu;
   const bool fast = (T & 1) == 0 && (uint64_t)B * H * (uint64_t)T * (uint64_t)(T >> 1) < (1ull << 32);
   hipStream_t st = (hipStream_t)stream;
-  if (drop_p <= 0.f) hipLaunchKernelGGL(relpos_attn_bwd_kernel<0>, dim3(B * H), dim3(512), 0, st, a);
-  else if (fast) hipLaunchKernelGGL(relpos_attn_bwd_kernel<1>, dim3(B * H), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(relpos_attn_bwd_kernel<2>, dim3(B * H), dim3(512), 0, st, a);
+  if (drop_p <= 0.f) hipLaunchKernelGGL((relpos_attn_bwd_kernel<0, true>), dim3(B * H), dim3(512), 0, st, a);
+  else if (fast) hipLaunchKernelGGL((relpos_attn_bwd_kernel<1, true>), dim3(B * H), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((relpos_attn_bwd_kernel<2, true>), dim3(B * H), dim3(512), 0, st, a);
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_attn_bwd_one_pass(const void* q, int64_t q_sb, int64_t q_sr, const void* k, int64_t k_sb, int64_t k_sr, const void* v,
+                                     int64_t v_sb, int64_t v_sr, const void* o, const void* dO, int64_t o_sb, int64_t o_sr,
+                                     const float* lse, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int dk_dim,
+                                     const int32_t* key_lens, int causal, float scale, float drop_p, const uint64_t* drop_seed,
+                                     uint32_t drop_site, const int32_t* cu_q, const int32_t* cu_k, const void* o_lo, void* stream) {
+  if (!q || !k || !v || !o || !dO || !lse || !dq || !dk || !dv || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return S2T_ERR_ARG;
+  if (dk_dim != DK || Tk > KMAX) return S2T_ERR_UNSUPPORTED;
+  if (q_sr % 8 || k_sr % 8 || v_sr % 8 || o_sr % 8 || q_sb % 8 || k_sb % 8 || v_sb % 8 || o_sb % 8) return S2T_ERR_ARG;
+  if (((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16) || ((uintptr_t)o % 16) || ((uintptr_t)dO % 16) ||
+      ((uintptr_t)dq % 16) || ((uintptr_t)dk % 16) || ((uintptr_t)dv % 16) || (o_lo && ((uintptr_t)o_lo % 16)))
+    return S2T_ERR_ALIGN;
+  if (drop_p < 0.f || drop_p >= 1.f) return S2T_ERR_ARG;
+  RpbArgs a = {};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.q_sb = q_sb; a.q_sr = q_sr; a.k_sb = k_sb; a.k_sr = k_sr; a.v_sb = v_sb; a.v_sr = v_sr;
+  a.o = (const bf16_t*)o; a.dO = (const bf16_t*)dO; a.o_sb = o_sb; a.o_sr = o_sr; a.lse = lse;
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.replicas = 1;
+  a.B = B; a.H = H; a.T = Tq; a.Tk = Tk; a.causal = causal; a.o_lo = (const bf16_t*)o_lo; a.key_lens = key_lens; a.scale = scale;
+  a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_site = drop_site; a.cu = cu_q; a.cu_k = cu_k;
+  const bool fast = (Tk & 1) == 0 && (uint64_t)B * H * (uint64_t)Tq * (uint64_t)(Tk >> 1) < (1ull << 32);
+  hipStream_t st = (hipStream_t)stream;
+  if (drop_p <= 0.f) hipLaunchKernelGGL((relpos_attn_bwd_kernel<0, false>), dim3(B * H), dim3(512), 0, st, a);
+  else if (fast) hipLaunchKernelGGL((relpos_attn_bwd_kernel<1, false>), dim3(B * H), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((relpos_attn_bwd_kernel<2, false>), dim3(B * H), dim3(512), 0, st, a);
   return S2T_LAUNCH_CHECK();
 }

@@ -1423,6 +1423,16 @@ class AttentionFn(torch.autograd.Function):
             _POSQ["entries"].append((dp, _pos_table_f32(pos_tab), prm["pos_w"].grad, n_pos, d))
             _ready(prm["pos_w"], prm["pos_u"], prm["pos_v"])
             one_pass = True
+        if (not rel and _ATTN_ONE_PASS and dt == torch.bfloat16 and dk == 64 and _ATTN_ONE_PASS_MIN_TK <= Tk <= 256 and ldq % 8 == 0
+                and ldk % 8 == 0):
+            # plain attention over 160 - 256 keys (encoder-decoder attention, the plain Transformer encoder): dq, dk, dv from one
+            # launch on the schedule of the relative-position kernel (csrc/relpos_bwd.hip without its position terms).  Fewer keys
+            # leave most of its eight key-owning waves idle: the decoder's self-attention (61 x 61: 13.8 us on the two kernels,
+            # 14.6 in one pass; 250 x 250: 52.6 / 42.7; 61 x 250: 23.4 / 17.5 — tools/attn_bwd_routes.py) stays on two kernels
+            K.attn_bwd_one_pass(q, Tq * ldq, ldq, k, Tk * ldk, ldk, v, Tk * ldk, ldk, O, dO, Tq * d, d, lse, dq, dk_, dv, B, H, Tq, Tk,
+                                dk, key_lens, ctx.causal, scale, drop_a, q_rows=qr, k_rows=kr, o_lo=getattr(ctx, "o_lo", None))
+            ctx.o_lo = None
+            one_pass = True
         if not one_pass:
             delta = torch.empty(Z, Tq, dtype=torch.float32, device=dev)
             n_pos = 2 * Tq - 1
@@ -2401,6 +2411,8 @@ _POS32 = {}
 # s2t_relpos_glue walks the position rows in chunks of 512 (round 5): any length; S2T_GLUE_MAX_T=256 restores the round-4 routing
 # (longer sequences through s2t_relpos_dqv + the split-K position-table GEMM, padded rows only) for A/B measurements
 _GLUE_MAX_T = int(os.environ.get("S2T_GLUE_MAX_T", "32768"))
+_ATTN_ONE_PASS = os.environ.get("S2T_ATTN_ONE_PASS", "1") != "0"  # s2t_attn_bwd_one_pass: plain attention, dq / dk / dv in one launch
+_ATTN_ONE_PASS_MIN_TK = int(os.environ.get("S2T_ATTN_ONE_PASS_MIN_TK", "160"))  # (keys per utterance from which it beats the two kernels)
 _RELPOS_ONE_PASS = os.environ.get("S2T_RELPOS_ONE_PASS", "1") != "0"  # s2t_relpos_attn_bwd: T' <= 256, the whole rel-pos backward in one launch
 _RELPOS_GLUE = os.environ.get("S2T_RELPOS_GLUE", "1") != "0"  # s2t_relpos_glue: (Q+v) branch + bias sums + position-table gradient in one pass over dbd
 _DP_SPLIT = int(os.environ.get("S2T_DP_SPLIT", "16"))  # K split of the position-table gradient GEMM (M = 2T-1, N = 64 per head, K = B*T)

@@ -877,6 +877,17 @@ def relpos_attn_bwd(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, dO, o_sb, o_
     return part
 
 
+def attn_bwd_one_pass(q, q_sb, q_sr, k, k_sb, k_sr, v, v_sb, v_sr, o, dO, o_sb, o_sr, lse, dq, dk, dv, B, H, Tq, Tk, dkd, key_lens,
+                      causal, scale, drop=None, q_rows=None, k_rows=None, o_lo=None):
+    """s2t_attn_bwd_one_pass: plain attention backward in one launch (Tk <= 256): dq, dk, dv; no delta buffer."""
+    L.require_cuda(q, k, v, o, dO, lse, dq, dk, dv)
+    assert all(t.dtype == torch.bfloat16 for t in (q, k, v, o, dO, dq, dk, dv)) and lse.dtype == torch.float32
+    dp, ds, dsite = _drop3(drop)
+    _call("s2t_attn_bwd_one_pass", q.data_ptr(), q_sb, q_sr, k.data_ptr(), k_sb, k_sr, v.data_ptr(), v_sb, v_sr, o.data_ptr(),
+          dO.data_ptr(), o_sb, o_sr, lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Tq, Tk, dkd, _ptr(key_lens),
+          int(causal), scale, dp, ds, dsite, _cu(q_rows), _cu(k_rows), _ptr(o_lo))
+
+
 def _ptr_array(tensors):
     import ctypes as C
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

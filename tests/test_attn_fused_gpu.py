@@ -731,3 +731,69 @@ def test_relpos_backward_in_one_pass_with_an_empty_utterance_and_refused_shapes(
         K.relpos_attn_bwd(z, Tl * d, d, z, Tl * d, d, z, Tl * d, d, z, z, Tl * d, d, torch.zeros(H, Tl, device=DEV), z.clone(), z.clone(),
                           z.clone(), torch.zeros(2 * Tl - 1, d, dtype=bf, device=DEV), d, u, vb, torch.zeros(d, device=DEV),
                           torch.zeros(d, device=DEV), 1, H, Tl, dk, None, scale, None)
+
+
+@pytest.mark.parametrize("Tq,Tk,causal,pdrop,use_lo", [(250, 250, False, 0.0, False), (61, 61, True, 0.0, False),
+                                                       (61, 250, False, 0.0, True), (130, 130, False, 0.1, False),
+                                                       (91, 249, False, 0.1, True), (33, 33, True, 0.1, False),
+                                                       (300, 256, False, 0.0, False)])
+def test_plain_backward_in_one_pass(Tq, Tk, causal, pdrop, use_lo):
+    """s2t_attn_bwd_one_pass (csrc/relpos_bwd.hip without its position terms; multihead_attention.py:161-431 backward): dq, dk, dv
+    of plain attention from ONE launch against float64 autograd on the bf16-rounded operands — self-attention, the decoder's causal
+    form, encoder-decoder shapes (Tq != Tk, odd Tk: the general dropout hash), with the forward's rounding remainder o_lo — and
+    against the two kernels of s2t_attn_fused_bwd (same inputs: within the two routes' roundings)."""
+    g = torch.Generator().manual_seed(Tq * 13 + Tk + int(pdrop * 10))
+    B, H, dk = 3, 4, 64
+    d = H * dk
+    Z = B * H
+    bf = torch.bfloat16
+    q = (torch.randn(B, Tq, d, generator=g) * 0.7).to(bf)
+    k = (torch.randn(B, Tk, d, generator=g) * 0.7).to(bf)
+    v = (torch.randn(B, Tk, d, generator=g) * 0.7).to(bf)
+    dO = (torch.randn(B, Tq, d, generator=g) * 0.5).to(bf)
+    klen = torch.tensor([Tk, max(1, Tk - 7), max(1, Tk // 2)], dtype=torch.int32)
+    scale = dk ** -0.5
+    seed = torch.full((1,), 99, dtype=torch.int64, device=DEV)
+    drop = (pdrop, seed, 4) if pdrop > 0 else None
+    qd, kd, vd, dOd, kl = q.to(DEV), k.to(DEV), v.to(DEV), dO.to(DEV), klen.to(DEV)
+    o = torch.empty(B, Tq, d, dtype=bf, device=DEV)
+    o_lo = torch.empty_like(o) if use_lo else None
+    lse = torch.empty(Z, Tq, dtype=torch.float32, device=DEV)
+    K.attn_fused_fwd(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, Tq * d, d, lse, B, H, Tq, Tk, dk, kl, causal, scale, None, 0,
+                     None, None, drop, o_lo=o_lo)
+    dq = torch.full((B, Tq, d), 7.0, dtype=bf, device=DEV)
+    dkk = torch.full((B, Tk, d), 7.0, dtype=bf, device=DEV)
+    dv = torch.full((B, Tk, d), 7.0, dtype=bf, device=DEV)
+    K.attn_bwd_one_pass(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, dOd, Tq * d, d, lse, dq, dkk, dv, B, H, Tq, Tk, dk, kl, causal,
+                        scale, drop, o_lo=o_lo)
+    # the two-kernel route on the same inputs
+    delta = torch.empty(Z, Tq, dtype=torch.float32, device=DEV)
+    dq2, dk2, dv2 = torch.empty_like(dq), torch.empty_like(dkk), torch.empty_like(dv)
+    K.attn_fused_bwd(qd, Tq * d, d, kd, Tk * d, d, vd, Tk * d, d, o, dOd, Tq * d, d, lse, delta, dq2, dk2, dv2, None, 0, B, H, Tq, Tk,
+                     dk, kl, causal, scale, None, 0, None, None, drop, o_lo=o_lo)
+    torch.cuda.synchronize()
+
+    qh = q.double().view(B, Tq, H, dk).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    kh = k.double().view(B, Tk, H, dk).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    vh = v.double().view(B, Tk, H, dk).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    s = s.masked_fill((torch.arange(Tk)[None, :] >= klen.long()[:, None])[:, None, None, :], float("-inf"))
+    if causal:
+        s = s + torch.triu(torch.full((Tq, Tk), float("-inf"), dtype=torch.float64), 1)
+    pr = torch.softmax(s, -1)
+    if pdrop > 0:
+        pr = pr * _dropout_mask(Z, Tq, Tk, drop).view(B, H, Tq, Tk) / (1.0 - pdrop)
+    ((pr @ vh) * dO.double().view(B, Tq, H, dk).permute(0, 2, 1, 3)).sum().backward()
+
+    def rel_err(got, ref):
+        return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+    hq = lambda t, T_: t.cpu().double().view(B, T_, H, dk).permute(0, 2, 1, 3)
+    e1 = (rel_err(hq(dq, Tq), qh.grad), rel_err(hq(dkk, Tk), kh.grad), rel_err(hq(dv, Tk), vh.grad))
+    e2 = (rel_err(hq(dq2, Tq), qh.grad), rel_err(hq(dk2, Tk), kh.grad), rel_err(hq(dv2, Tk), vh.grad))
+    print("one pass", ["%.2e" % e for e in e1], "two kernels", ["%.2e" % e for e in e2])
+    assert max(e1) < 1.5e-2
+    assert all(a_ <= 1.5 * b_ + 1e-3 for a_, b_ in zip(e1, e2))
+    for b in range(B):  # padded keys get exactly zero gradient
+        if int(klen[b]) < Tk:
+            assert float(hq(dkk, Tk)[b, :, int(klen[b]):].abs().max()) == 0.0 and float(hq(dv, Tk)[b, :, int(klen[b]):].abs().max()) == 0.0
