@@ -31,6 +31,9 @@
 #define S2T_RPB_DBG 0  // experiment builds: 1 no product (1), 2 no product (2), 4 no product (3), 8 no dropout arithmetic
 #endif
 
+#ifndef S2T_RPB_PRIO
+#define S2T_RPB_PRIO 0  // experiment: s_setprio of waves 4 - 7 in the score phase
+#endif
 #ifndef S2T_RPB_SHIFT
 #define S2T_RPB_SHIFT 1  // the rel_shift of the position band: 0 ds_bpermute_b32 (12 per query tile, measured 86 us), 1 DPP row rotates (79 us: fewer live registers)
 #endif
@@ -411,6 +414,11 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
     // ---- phase B: scores of this wave's 32 keys against the tile's 32 queries
     int xl = x, yl = y;
     asm volatile("" : "+v"(xl), "+v"(yl));
+#if S2T_RPB_PRIO
+    // the two waves of a SIMD (w, w + 4) enter the phase together and are bound by vector issue; the arbiter serves the older
+    // one first, which then waits at the barrier while the younger runs alone with its dependency stalls exposed
+    if (w >= 4) __builtin_amdgcn_s_setprio(S2T_RPB_PRIO);
+#endif
     {  // (waves whose keys all lie beyond the utterance run along: they would wait at the barrier anyway, and a branch around the
        //  accumulating MFMAs costs a rotation of the ~130 loop-carried accumulator registers at its join; their dS are zeros)
 #pragma unroll
@@ -585,6 +593,9 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
         }
       }
     }
+#if S2T_RPB_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     RSTAMP();
     __syncthreads();
     RSTAMP();
