@@ -389,8 +389,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a_in) {
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = s2t_xmax<16>(mx);
+    mx = s2t_xmax<32>(mx);
     const float mn = fmaxf(m, mx);
     // branch-free: exp(-inf) = 0 covers masked keys and the first block (m = -inf: alpha = 0 scales l = 0 and O = 0); a row
     // that has seen no valid key yet (mn = -inf) subtracts 0 instead
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FusedArgs a_in) {
         rs += p;
         pr[kt][r] = p;
       }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
+    rs = s2t_xadd<16>(rs);
+    rs = s2t_xadd<32>(rs);
     l = l * alpha + rs;
     m = mn;
 #pragma unroll
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a_i
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = s2t_xmax<16>(mx);
+      mx = s2t_xmax<32>(mx);
       const float mn = fmaxf(m, mx);
       const float mref = (mn == -INFINITY) ? 0.f : mn;
       const float alpha = __builtin_amdgcn_exp2f(m - mref);
@@ -624,8 +624,8 @@ __global__ __launch_bounds__(512, 2) void attn_bh_fwd_kernel(const FusedArgs a_i
           rs += p;
           pr[kt][r] = p;
         }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
+      rs = s2t_xadd<16>(rs);
+      rs = s2t_xadd<32>(rs);
       l = l * alpha + rs;
       m = mn;
 #pragma unroll
@@ -757,8 +757,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a_in) 
         part += __uint_as_float(ow[t] << 16) * __uint_as_float(dw[t] << 16) +
                 __uint_as_float(ow[t] & 0xffff0000u) * __uint_as_float(dw[t] & 0xffff0000u);
     }
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
+    part = s2t_xadd<16>(part);
+    part = s2t_xadd<32>(part);
     del_i = part;
     if (y == 0 && i < a.nq) const_cast<float*>(a.delta)[(int64_t)z * a.Tq + i] = part;
   }
@@ -938,11 +938,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const FusedArgs a_in) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float su = live ? dq[dt][r] : 0.f, sv = live ? dqv[dt][r] : 0.f;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          su += __shfl_xor(su, o, 64);
-          sv += __shfl_xor(sv, o, 64);
-        }
+        su = s2t_sum16_up(su);
+        sv = s2t_sum16_up(sv);
         if (x == 0) {
           red[(w * 2 + 0) * 64 + 16 * dt + 4 * y + r] = su;
           red[(w * 2 + 1) * 64 + 16 * dt + 4 * y + r] = sv;
@@ -1263,11 +1260,8 @@ __global__ __launch_bounds__(64) void relpos_dqv_kernel(const bf16_t* __restrict
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        su[nt][r] += __shfl_xor(su[nt][r], o, 64);
-        sv[nt][r] += __shfl_xor(sv[nt][r], o, 64);
-      }
+      su[nt][r] = s2t_sum16_up(su[nt][r]);
+      sv[nt][r] = s2t_sum16_up(sv[nt][r]);
     }
   // (a thousand workgroups adding to the same 2 x 64 floats of a head serialise in the L2 atomic units — measured: half of
   // the kernel's time — so the sums are spread over `replicas` copies that a later fold adds up: the LayerNorm

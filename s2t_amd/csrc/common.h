@@ -90,16 +90,63 @@ __device__ __forceinline__ float act_grad(int act, float z) {
   return 1.f;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// ---- cross-lane steps without the LDS crossbar -----------------------------------------------------------------------------
+// `__shfl_xor` compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): an LDS round trip (100+ cycles, behind whatever the LDS
+// queue holds) per butterfly step, ten of them one after the other in a LayerNorm prologue.  The same exchanges as vector
+// instructions: DPP inside a 16-lane row (quad_perm for xor 1 / 2, two bank-masked row shifts for xor 4, a row rotation for
+// xor 8), v_permlane16_swap / v_permlane32_swap (gfx950) across rows.  s2t_xadd<O>(v) == v + __shfl_xor(v, O) bit for bit
+// (the add is commutative), likewise s2t_xmax.  tools/ubench/red_dpp.hip checks every step against __shfl_xor on the GPU.
+template <int O>
+__device__ __forceinline__ float s2t_lane_xor_dpp(float v) {   // value of lane ^ O, O in {1, 2, 4, 8}
+  const int iv = __builtin_bit_cast(int, v);
+  if constexpr (O == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+  else if constexpr (O == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+  else if constexpr (O == 4) {
+    int t = __builtin_amdgcn_update_dpp(iv, iv, 0x104, 0xf, 0x5, false);   // row_shl:4 into banks 0, 2: lane i <- lane i + 4
+    t = __builtin_amdgcn_update_dpp(t, iv, 0x114, 0xf, 0xA, false);        // row_shr:4 into banks 1, 3: lane i <- lane i - 4
+    return __builtin_bit_cast(float, t);
+  } else {
+    static_assert(O == 8, "DPP covers xor 1, 2, 4, 8");
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x128, 0xf, 0xf, false));  // row_ror:8
+  }
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+// v_permlane16_swap a, b: rows 1 and 3 of a change places with rows 0 and 2 of b.  With a = b = v: a' = [r0 r0 r2 r2],
+// b' = [r1 r1 r3 r3] — every lane holds its own value and its xor-16 partner's (in one order or the other).
+// (written as inline assembly: hipcc 7.2 hands back the FIRST result for both elements of __builtin_amdgcn_permlane16_swap's
+// pair — `v_add_f32 v1, v1, v1` behind the swap.  The s_nop covers the two wait states a VALU write needs before a permlane
+// reads the register; the compiler cannot see into the asm.)
+__device__ __forceinline__ void s2t_pair16(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+__device__ __forceinline__ void s2t_pair32(float v, float& a, float& b) {   // the same across the wave's halves (xor 32)
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+template <int O>
+__device__ __forceinline__ float s2t_xadd(float v) {
+  if constexpr (O == 16) { float a, b; s2t_pair16(v, a, b); return a + b; }
+  else if constexpr (O == 32) { float a, b; s2t_pair32(v, a, b); return a + b; }
+  else return v + s2t_lane_xor_dpp<O>(v);
+}
+template <int O>
+__device__ __forceinline__ float s2t_xmax(float v) {
+  if constexpr (O == 16) { float a, b; s2t_pair16(v, a, b); return fmaxf(a, b); }
+  else if constexpr (O == 32) { float a, b; s2t_pair32(v, a, b); return fmaxf(a, b); }
+  else return fmaxf(v, s2t_lane_xor_dpp<O>(v));
+}
+// butterflies in the order of the loops they replace (widest step first): results bit-equal to those loops
+__device__ __forceinline__ float s2t_sum16(float v) { return s2t_xadd<1>(s2t_xadd<2>(s2t_xadd<4>(s2t_xadd<8>(v)))); }
+__device__ __forceinline__ float s2t_sum16_up(float v) { return s2t_xadd<8>(s2t_xadd<4>(s2t_xadd<2>(s2t_xadd<1>(v)))); }  // narrowest step first
+__device__ __forceinline__ float s2t_sum32(float v) { return s2t_sum16(s2t_xadd<16>(v)); }
+__device__ __forceinline__ float s2t_sum64(float v) { return s2t_sum32(s2t_xadd<32>(v)); }
+__device__ __forceinline__ float s2t_max16(float v) { return s2t_xmax<1>(s2t_xmax<2>(s2t_xmax<4>(s2t_xmax<8>(v)))); }
+__device__ __forceinline__ float s2t_max32(float v) { return s2t_max16(s2t_xmax<16>(v)); }
+__device__ __forceinline__ float s2t_max64(float v) { return s2t_max32(s2t_xmax<32>(v)); }
+__device__ __forceinline__ float wave_sum(float v) { return s2t_sum64(v); }
+__device__ __forceinline__ float wave_max(float v) { return s2t_max64(v); }
 
 // Counter-based dropout RNG: keep(seed, site, element index) is a pure function, so the backward pass regenerates
 // the mask instead of storing it.  One 32-bit hash serves TWO consecutive elements (16 random bits each; the keep
@@ -177,12 +224,13 @@ __device__ __forceinline__ bool s2t_row_masked(const int32_t* __restrict__ lens,
   return T == S2T_ROWS_PACKED && lens[row] < 0;
 }
 // 32-bit form for epilogues (row < 2^31): the 64-bit division is a long software sequence
+// (ONE load whose result no branch waits for: with a load per layout behind a branch each, the compiler waits for the entry
+// where it is requested, and a prologue that masks four rows pays four memory round trips one after the other)
 __device__ __forceinline__ bool s2t_row_masked32(const int32_t* __restrict__ lens, int T, uint32_t row) {
-  if (T > 0) {
-    const uint32_t b = row / (uint32_t)T;
-    return (int)(row - b * (uint32_t)T) >= lens[b];
-  }
-  return T == S2T_ROWS_PACKED && lens[row] < 0;
+  if (T <= 0 && T != S2T_ROWS_PACKED) return false;
+  const uint32_t b = T > 0 ? row / (uint32_t)T : row;
+  const int v = lens[b];
+  return T > 0 ? (int)(row - b * (uint32_t)T) >= v : v < 0;
 }
 // rows of a launch: the host's bound, or the live row count of a packed batch when that is smaller
 __device__ __forceinline__ int64_t s2t_live_rows(const int32_t* __restrict__ lens, int T, int64_t rows) {

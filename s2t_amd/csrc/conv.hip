@@ -244,8 +244,8 @@ __device__ __forceinline__ float fold_partial_rows(const float* __restrict__ col
     }
     for (; r < rows; r += 64) acc += col[(int64_t)r * ld];
   }
-  acc += __shfl_xor(acc, 16);
-  acc += __shfl_xor(acc, 32);
+  acc = s2t_xadd<16>(acc);
+  acc = s2t_xadd<32>(acc);
   __syncthreads();  // `red` may still be read from a previous call
   if ((threadIdx.x & 63) < 16) red[wv][cl] = acc;
   __syncthreads();

@@ -55,6 +55,23 @@
 
 namespace {
 
+// The LayerNorm-backward reductions of MODE 2 keep the LDS-crossbar form (__shfl_xor): with the DPP form (csrc/common.h) hipcc
+// spills five registers INSIDE the consumers' chunk loop (scratch loads there make the compiler wait for the DMA stream:
+// 72 -> 106 us per launch); S2T_PC_BWD_DPP=1 selects the DPP form for a newer compiler to try
+#ifndef S2T_PC_BWD_DPP
+#define S2T_PC_BWD_DPP 0
+#endif
+__device__ __forceinline__ float pc_shfl_sum32(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#if S2T_PC_BWD_DPP
+#define PC_BWD_SUM32(v) s2t_sum32(v)
+#else
+#define PC_BWD_SUM32(v) pc_shfl_sum32(v)
+#endif
+
 constexpr int D = 256;
 constexpr int RB = 128;             // rows per workgroup
 constexpr int FC = 64;              // hidden units per chunk
@@ -256,11 +273,8 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
               }
             }
           }
-#pragma unroll
-          for (int sh = 16; sh > 0; sh >>= 1) {
-            s1 += __shfl_xor(s1, sh, 64);
-            s2 += __shfl_xor(s2, sh, 64);
-          }
+          s1 = PC_BWD_SUM32(s1);
+          s2 = PC_BWD_SUM32(s2);
           s1 *= 1.0f / D;
           s2 *= 1.0f / D;
           uint32_t rw[4], yw[4];
@@ -305,8 +319,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += v[j];
-#pragma unroll
-        for (int sh = 16; sh > 0; sh >>= 1) sum += __shfl_xor(sum, sh, 64);
+        sum = s2t_sum32(sum);
         const float mean = sum * (1.0f / D);
         float sq = 0.f;
 #pragma unroll
@@ -314,8 +327,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
           const float dd = v[j] - mean;
           sq += dd * dd;
         }
-#pragma unroll
-        for (int sh = 16; sh > 0; sh >>= 1) sq += __shfl_xor(sq, sh, 64);
+        sq = s2t_sum32(sq);
         const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
         uint32_t ow[4];
 #pragma unroll
@@ -542,7 +554,6 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
       yacc[nt] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const uint32_t g2off = (uint32_t)(r32 * 128);
     const int g2key = (r32 >> 1) & 7;
     // G2 of chunk c with the DMA pieces of the running iteration spread over its MFMA groups, and (training / backward) the
     // saved tensor of the same chunk row-major out of the mailbox: lane (row 8 q + (l >> 3), piece l & 7) -> a wave
@@ -553,7 +564,11 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       bf16x8 hb[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) hb[s] = frag(*reinterpret_cast<const uint4*>(mcell(c, s, hh, r32)));
-      const char* l2 = smem + L_W2 + (c & 1) * STAGE + g2off;
+      // (this lane's row offset is formed HERE from the lane id, behind an asm the compiler cannot hoist: kept across the loop
+      // it was the one register hipcc spilled — a scratch reload and its vmcnt(0) at the head of every chunk)
+      uint32_t ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const char* l2 = smem + L_W2 + (c & 1) * STAGE + (ln & 31u) * 128u;
       auto rd_w = [&](int nt, uint4 (&a)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const uint4*>(l2 + nt * 4096 + 16 * ((2 * s + hh) ^ g2key));
@@ -903,11 +918,8 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
             ab[q][r] += dv[q][r];
           }
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          s1 += __shfl_xor(s1, o, 64);
-          s2 += __shfl_xor(s2, o, 64);
-        }
+        s1 = PC_BWD_SUM32(s1);
+        s2 = PC_BWD_SUM32(s2);
         s1 *= 1.0f / D;
         s2 *= 1.0f / D;
         if (live) {
@@ -981,8 +993,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum += v[q][r];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      sum = s2t_sum32(sum);
       const float mean = sum * (1.0f / D);
       float sq = 0.f;
 #pragma unroll
@@ -992,8 +1003,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
           const float d = v[q][r] - mean;
           sq += d * d;
         }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+      sq = s2t_sum32(sq);
       const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
       const bool masked = p.eln_lens && live && s2t_row_masked32(p.eln_lens, p.eln_T, (uint32_t)m);
       if (live) {

@@ -168,8 +168,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 // wave: half the instructions per row and twice the bytes per memory instruction of the generic kernels, which are
 // issue/latency bound on 512-byte rows (the model width of every recipe is 256).
 __device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = s2t_sum32(v);
   return v;
 }
 __device__ __forceinline__ void unpack8(const uint4 t, float (&v)[8]) {

@@ -393,9 +393,9 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
             part += __uint_as_float(lw[t] << 16) * __uint_as_float(dw[t] << 16) +
                     __uint_as_float(lw[t] & 0xffff0000u) * __uint_as_float(dw[t] & 0xffff0000u);
         }
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
+        part = s2t_xadd<1>(part);
+        part = s2t_xadd<2>(part);
+        part = s2t_xadd<4>(part);
         if (pch_ == 0) del_s[r] = part;
       }
       if (tl < TQ) lse_s[tl] = nlse;
@@ -715,11 +715,8 @@ __global__ __launch_bounds__(512) void relpos_attn_bwd_kernel(const RpbArgs a_in
   float* red = reinterpret_cast<float*>(lds + L_DA);  // [2][8 waves][64]
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      su[r] += __shfl_xor(su[r], o, 64);
-      sv[r] += __shfl_xor(sv[r], o, 64);
-    }
+    su[r] = s2t_sum16_up(su[r]);
+    sv[r] = s2t_sum16_up(sv[r]);
   }
   if (x == 0) {
 #pragma unroll

@@ -327,11 +327,8 @@ __global__ __launch_bounds__(512) void relpos_glue_kernel(const GlueArgs a_in) {
   // per channel and branch into a replica of the workspace
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      su[r] += __shfl_xor(su[r], o, 64);
-      sv[r] += __shfl_xor(sv[r], o, 64);
-    }
+    su[r] = s2t_sum16_up(su[r]);
+    sv[r] = s2t_sum16_up(sv[r]);
   }
   if (x == 0) {
 #pragma unroll

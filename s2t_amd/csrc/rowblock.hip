@@ -36,6 +36,12 @@
 #ifndef S2T_RB_SPREAD
 #define S2T_RB_SPREAD 1  // LDS-DMA pieces spread over the iteration's MFMA groups (0: all at the head of the iteration)
 #endif
+#ifndef S2T_RBG_ORDER
+#define S2T_RBG_ORDER 1  // row-block projections: 1 the DMA of chunk c+2 in front of read-out c-1's stores with a counted wait that
+#endif                   // leaves those stores in flight; 0 the order of rounds 2 - 4 (stores, DMA, vmcnt(4): every store acknowledged)
+#ifndef S2T_RBG_STAGGER
+#define S2T_RBG_STAGGER 1  // row-block projections: the workgroups of an XCD start their walk over W's chunks at different chunks
+#endif
 #ifndef S2T_RB_DBG
 #define S2T_RB_DBG 0  // kernel-experiment switches (tools/rb_dbg_build.sh): 1 no DMA inside the loop, 2 no MFMAs, 4 no E1,
                       // 8 no z / h saves, 16 s_memtime stamps, 32 no L2 warm-up loads
@@ -293,11 +299,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
               ab[j] += dv;
             }
           }
-#pragma unroll
-          for (int sh = 16; sh > 0; sh >>= 1) {
-            s1 += __shfl_xor(s1, sh, 64);
-            s2 += __shfl_xor(s2, sh, 64);
-          }
+          s1 = s2t_sum32(s1);
+          s2 = s2t_sum32(s2);
           s1 *= 1.0f / D;
           s2 *= 1.0f / D;
           uint32_t rw[4], yw[4];
@@ -345,8 +348,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += v[j];
-#pragma unroll
-        for (int sh = 16; sh > 0; sh >>= 1) sum += __shfl_xor(sum, sh, 64);
+        sum = s2t_sum32(sum);
         const float mean = sum * (1.0f / D);
         float sq = 0.f;
 #pragma unroll
@@ -354,8 +356,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
           const float dd = v[j] - mean;
           sq += dd * dd;
         }
-#pragma unroll
-        for (int sh = 16; sh > 0; sh >>= 1) sq += __shfl_xor(sq, sh, 64);
+        sq = s2t_sum32(sq);
         const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
         uint32_t ow[4];
 #pragma unroll
@@ -868,11 +869,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
               ab[q][r] += dv[q][r];
             }
           }
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-          }
+          s1 = s2t_sum32(s1);
+          s2 = s2t_sum32(s2);
           s1 *= 1.0f / D;
           s2 *= 1.0f / D;
           if (live) {
@@ -957,8 +955,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
         for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int r = 0; r < 4; ++r) sum += v[q][r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        sum = s2t_sum32(sum);
         const float mean = sum * (1.0f / D);
         float sq = 0.f;
 #pragma unroll
@@ -968,8 +965,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
             const float d = v[q][r] - mean;
             sq += d * d;
           }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        sq = s2t_sum32(sq);
         const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
         const bool masked = p.eln_lens && live && s2t_row_masked32(p.eln_lens, p.eln_T, (uint32_t)m);
         if (live) {
@@ -1013,6 +1009,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_fwd_kernel(const FfnK p) {
 //   and read back one chunk later by all 512 threads as (row, 8 consecutive columns): 16-byte residual loads and stores.
 //   GLU: the chunk holds 32 value rows (weight rows 32c .. +32) and the 32 gate rows of the SAME output columns (weight
 //   rows N/2 + 32c ..), so value and gate meet in one result tile.
+#if S2T_RB_DBG & 64
+__device__ unsigned long long s2t_rbg_dbg_buf[2 * 32];
+#define RBG_STAMP(i) do { if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) { __builtin_amdgcn_sched_barrier(0); \
+    s2t_rbg_dbg_buf[(blockIdx.x ? 32 : 0) + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define RBG_STAMP(i)
+#endif
 constexpr int PJ_STAGES = 3;
 constexpr int PJ_W = 0;                          // three weight stages
 constexpr int PJ_TILE = PJ_STAGES * STAGE;       // two fp32 result tiles of 16 KiB
@@ -1029,13 +1032,19 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   const int mp = wave & 1, q = wave >> 1;
   const int x = lane & 15, g = lane >> 4;
   const int row0 = blockIdx.x * TM;
+  RBG_STAMP(0);
   const int M = (int)s2t_live_rows(p.row_lens, p.row_T, s2t_live_rows(p.ln_lens, p.ln_T, p.M)), N = p.N;
   if (row0 >= M) return;  // packed batch: this row block holds no live row
+  RBG_STAMP(1);
   const int nout = GLU ? N / 2 : N;
   const int ncols = GLU ? 32 : 64;            // output columns per chunk
   const int nchunks = (nout + ncols - 1) / ncols;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const i32x4 srd = make_srd(p.w, (uint32_t)N * D * 2u);  // rows beyond N read as zero (descriptor bounds)
+  // (the seed is read HERE: requested in front of the loop its round trip stood between the prologue and the first chunk)
+  const uint64_t key = DROP ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
+  const uint32_t th = s2t_drop_thresh(p.drop_p);
+  const float inv = s2t_drop_scale(p.drop_p);
 
   // DMA plan: chunk row u = 8 wave + 2 i + hi (512 B each) at LDS slot s = l & 31 holding k-chunk s ^ (u & 15);
   // weight row of chunk row u: plain 64 c + u; GLU u < 32: 32 c + u (value), u >= 32: N/2 + 32 c + u - 32 (gate)
@@ -1048,9 +1057,18 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     const int wrow = GLU ? (u < 32 ? u : N / 2 + u - 32) : u;
     ve = (uint32_t)(wrow * 512 + 16 * (s_ ^ (u & 15)));
   }
+  // The workgroups of an XCD (blocks b, b + 8, ...) walk the chunks of W from different starting points: they all stream the
+  // same 128 - 384 KiB from that XCD's L2 at the same time, and in lockstep they would all ask the same channels
+  // (chunk = output columns: the order changes no result)
+#if S2T_RBG_STAGGER
+  const int crot = (int)((blockIdx.x >> 3) % (unsigned)nchunks);
+#else
+  const int crot = 0;
+#endif
+  auto cmap = [&](int c) __attribute__((always_inline)) -> int { const int t = c + crot; return t >= nchunks ? t - nchunks : t; };
   auto issue = [&](int c) __attribute__((always_inline)) {
     const uint32_t base = lds0 + PJ_W + (c % PJ_STAGES) * STAGE + wave * 4096;
-    const uint32_t soff = (uint32_t)c * (uint32_t)(ncols * 512);
+    const uint32_t soff = (uint32_t)cmap(c) * (uint32_t)(ncols * 512);
     dma16_off<0>(base, ve, srd, soff);
     dma16_off<1024>(base, ve ^ 32u, srd, soff);
     dma16_off<2048>(base, ve ^ 64u, srd, soff);
@@ -1062,6 +1080,26 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     float* lb = reinterpret_cast<float*>(smem + PJ_BIAS);
     for (int i = tid; i < N; i += 512) lb[i] = p.bias ? p.bias[i] : 0.f;
   }
+  // read-out of a chunk's result tile: thread (row er = tid >> 3, ej = tid & 7) owns 8 consecutive units 8 ej .. 8 ej + 7
+  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.residual);
+  const int er = tid >> 3, ej = tid & 7;
+  const int em = row0 + er;
+  const bool elive = em < M && (!GLU || ej < 4);
+  // (the row's mask entry is read ONCE: a global load inside the loop would make the compiler wait for the DMAs in flight)
+  const bool emasked = elive && p.row_lens && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)em);
+  auto res_load = [&](int c) __attribute__((always_inline)) -> uint4 {
+    const int n0 = ncols * cmap(c) + 8 * ej;
+    if (R && elive && n0 < nout) return *reinterpret_cast<const uint4*>(R + (int64_t)em * p.ldr + n0);
+    return make_uint4(0, 0, 0, 0);
+  };
+  // Four chunks (the residual projections of the layers: N = 256): every residual piece of the thread is requested HERE, beside
+  // the first weight chunks and the rows (the wait that closes the prologue covers them: no wait inside the loop), and the
+  // chunk loop is unrolled (static registers).  Other widths with a residual request the piece of a read-out inside the loop
+  // (slow form).
+  const bool res4 = R && nchunks == 4;
+  uint4 rp[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rp[c] = res4 ? res_load(c) : make_uint4(0, 0, 0, 0);
 
   // ---- prologue: (LayerNorm of) the 64 rows staged in the third weight stage, then this wave's B fragments --------
   if constexpr (CONV) {
@@ -1165,10 +1203,14 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
       bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1v.x; bt[5] = b1v.y; bt[6] = b1v.z; bt[7] = b1v.w;
     }
     uint4 raw[4];
+    bool pmask[4];   // the rows' mask entries, requested together with the rows (one by one behind each pass's stores they cost a
+                     // memory round trip per pass)
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-      const int mc = min(row0 + 16 * ps + (tid >> 5), M - 1);
+      const int m = row0 + 16 * ps + (tid >> 5);
+      const int mc = min(m, M - 1);
       raw[ps] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * D + 8 * cch);
+      pmask[ps] = p.ln_lens && m < M && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m);
     }
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -1186,8 +1228,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += v[j];
-#pragma unroll
-        for (int sh = 16; sh > 0; sh >>= 1) sum += __shfl_xor(sum, sh, 64);
+        sum = s2t_sum32(sum);
         const float mean = sum * (1.0f / D);
         float sq = 0.f;
 #pragma unroll
@@ -1195,10 +1236,9 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
           const float dd = v[j] - mean;
           sq += dd * dd;
         }
-#pragma unroll
-        for (int sh = 16; sh > 0; sh >>= 1) sq += __shfl_xor(sq, sh, 64);
+        sq = s2t_sum32(sq);
         const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
-        const bool masked = p.ln_lens && m < M && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m);
+        const bool masked = pmask[ps];
         uint32_t ow[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1214,7 +1254,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         }
       } else if (p.pre_scale) {  // per-column affine + activation (BatchNorm apply), masked rows to zero
         const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
-        const bool masked = p.ln_lens && m < M && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m);
+        const bool masked = pmask[ps];
         uint32_t ow[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1228,8 +1268,11 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
       *reinterpret_cast<uint4*>(stage + rl * 512 + 16 * (cch ^ (rl & 15))) = o;
     }
   }
+  RBG_STAMP(2);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): chunks 0 and 1, the staged rows and the compiler's own loads / stores
+  RBG_STAMP(3);
   __syncthreads();
+  RBG_STAMP(4);
   bf16x8 xn[2][8];
   {
     const char* stage = smem + PJ_W + 2 * STAGE;
@@ -1242,19 +1285,31 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // fragments held before chunk 2 lands in that stage
+  RBG_STAMP(5);
 
-  const uint64_t key = DROP ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
-  const uint32_t th = s2t_drop_thresh(p.drop_p);
-  const float inv = s2t_drop_scale(p.drop_p);
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.residual);
-  bf16_t* OUT = reinterpret_cast<bf16_t*>(p.out);
-  bf16_t* Z = reinterpret_cast<bf16_t*>(p.preact);
+  const bool Z = p.preact != nullptr;
+  const float* lbias = reinterpret_cast<const float*>(smem + PJ_BIAS);
+  // Stores go through buffer descriptors: a lane without an output (row beyond the live ones, GLU's idle half, a column tail)
+  // offers an offset beyond the descriptor and the hardware drops it, so EVERY wave issues the same number of store
+  // instructions per read-out — the counted waits below depend on it.  (Extents below 2 GiB: checked at the entry point.)
+  constexpr uint32_t DROPPED = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((uint32_t)p.M * (uint32_t)p.ldc * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t zsrd = __builtin_amdgcn_make_buffer_rsrc(p.preact, 0, p.preact ? (int)((uint32_t)p.M * (uint32_t)p.ldp * 2u) : 0, 0x00020000);
+  auto bst8 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t off, const float (&v)[8], int aux) __attribute__((always_inline)) {
+    const rb_u4 t = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    if (aux) __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
+  };
 
   // result tile: fp32 [64 rows][64 units], 16-byte piece pc (4 units) of row r at r*256 + 16*(pc ^ (r & 15))
   auto read_a = [&](int c, uint4 (&af)[8]) __attribute__((always_inline)) {
     const char* lw = smem + PJ_W + (c % PJ_STAGES) * STAGE + (16 * q + x) * 512;
 #pragma unroll
+#if S2T_RB_DBG & 128
+    for (int ks = 0; ks < 8; ++ks) af[ks] = make_uint4(ks, lane, c, 1);
+#else
     for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const uint4*>(lw + 16 * ((4 * ks + g) ^ x));
+#endif
   };
   auto mma_store = [&](int c, const uint4 (&af)[8]) __attribute__((always_inline)) {
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -1270,16 +1325,6 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
       *reinterpret_cast<f32x4*>(tile + r * 256 + 16 * ((4 * q + g) ^ x)) = acc[mt];  // r & 15 == x
     }
   };
-  // read-out of chunk c's tile: thread (row r = tid >> 3, j = tid & 7) owns 8 consecutive units 8j .. 8j+7
-  const int er = tid >> 3, ej = tid & 7;
-  const int em = row0 + er;
-  const bool elive = em < M && (!GLU || ej < 4);
-  const float* lbias = reinterpret_cast<const float*>(smem + PJ_BIAS);
-  auto res_prefetch = [&](int c) __attribute__((always_inline)) -> uint4 {
-    const int n0 = ncols * c + 8 * ej;
-    if (R && elive && n0 < nout) return *reinterpret_cast<const uint4*>(R + (int64_t)em * p.ldr + n0);
-    return make_uint4(0, 0, 0, 0);
-  };
   auto emit = [&](int c, const uint4 rres) __attribute__((always_inline)) {
     const char* tile = smem + PJ_TILE + (c & 1) * 16384;
     const int r = er, j = ej, m = em;
@@ -1293,24 +1338,26 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
       const f32x4 b1v = *reinterpret_cast<const f32x4*>(lbias + n0 + 4);
       v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1v[0]; v[5] += b1v[1]; v[6] += b1v[2]; v[7] += b1v[3];
     };
-    const int n0 = ncols * c + 8 * j;
-    if (!elive || n0 >= nout) return;
+    const int n0 = ncols * cmap(c) + 8 * j;
+    const bool live = elive && n0 < nout;
+    const int n0c = live ? n0 : 0;   // (idle lanes compute on column 0's bias and drop the store)
     float v[8];
     if constexpr (GLU) {
       float gt[8];
-      ld8t(j, v);
-      ld8t(4 + j, gt);
-      add_bias(n0, v);
-      add_bias(nout + n0, gt);
+      ld8t(j & 3, v);
+      ld8t(4 + (j & 3), gt);
+      add_bias(n0c, v);
+      add_bias(nout + n0c, gt);
       if (Z) {
-        st8row_save(Z + (int64_t)m * p.ldp + n0, v);
-        st8row_save(Z + (int64_t)m * p.ldp + nout + n0, gt);
+        const uint32_t zo = live ? ((uint32_t)m * (uint32_t)p.ldp + (uint32_t)n0) * 2u : DROPPED;
+        bst8(zsrd, zo, v, S2T_RB_SAVE_NT);
+        bst8(zsrd, live ? zo + (uint32_t)nout * 2u : DROPPED, gt, S2T_RB_SAVE_NT);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(gt[e]);
     } else {
       ld8t(j, v);
-      add_bias(n0, v);
+      add_bias(n0c, v);
     }
     if constexpr (DROP) {
       uint32_t r16[8];
@@ -1320,7 +1367,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-    if (p.row_lens && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)m)) {
+    if (emasked) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = 0.f;
     }
@@ -1332,26 +1379,75 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         v[2 * k + 1] += __uint_as_float(w4[k] & 0xffff0000u);
       }
     }
-    st8row(OUT + (int64_t)m * p.ldc + n0, v);
+    bst8(osrd, live ? ((uint32_t)m * (uint32_t)p.ldc + (uint32_t)n0) * 2u : DROPPED, v, 0);
+  };
+  const int nst = 1 + ((GLU && Z) ? 2 : 0);   // store instructions of one read-out (every wave, see above)
+  auto wait_vm = [&](int n) __attribute__((always_inline)) {   // s_waitcnt vmcnt(n) lgkmcnt(0) + barrier, n uniform
+    switch (n) {
+#define S2T_RB_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      S2T_RB_W(1) S2T_RB_W(2) S2T_RB_W(3) S2T_RB_W(4) S2T_RB_W(5) S2T_RB_W(6) S2T_RB_W(7) S2T_RB_W(8) S2T_RB_W(9) S2T_RB_W(10)
+#undef S2T_RB_W
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
   };
 
-  // iteration c: the residual load of the pending read-out and the fragment reads of chunk c go out first; the read-out of
-  // tile (c-1) & 1 fills the time they take; DMA of chunk c+2 (its stage held chunk c-1, read before the last barrier);
-  // product of chunk c into tile c & 1.  The closing wait leaves the youngest DMA group (chunk c+2) in flight.
-  for (int c = 0; c < nchunks; ++c) {
+  // iteration c: the fragment reads of chunk c go out first; the DMA of chunk c+2 (its stage held chunk c-1, read before the
+  // last barrier); the read-out of tile (c-1) & 1 fills the time the reads take; product of chunk c into tile c & 1.
+  // The closing wait needs chunk c+1 in LDS and nothing else.  In issue order the wave's outstanding operations are then
+  //   DMA(c+1) | stores of read-out c-2 | DMA(c+2) | stores of read-out c-1
+  // so everything behind DMA(c+1) may stay in flight: a store's acknowledgement (about a microsecond) is never waited for
+  // (the order stores -> DMA -> vmcnt(4) of rounds 2 - 4 paid it once per chunk: 1.3 us per chunk for 0.3 us of work).
+  auto step = [&](int c, const uint4 rres) __attribute__((always_inline)) {
     const bool more = c + 2 < nchunks;
-    // (a wait for this load also waits for the OLDER DMAs of chunk c+1, which have had an iteration; the DMAs of chunk c+2
-    // are issued behind the read-out, so no compiler-inserted wait ever covers them)
-    const uint4 rres = c > 0 ? res_prefetch(c - 1) : make_uint4(0, 0, 0, 0);
     uint4 af[8];
     read_a(c, af);
+#if S2T_RBG_ORDER
+#if !(S2T_RB_DBG & 1)
+    if (more) issue(c + 2);
+#endif
+#if !(S2T_RB_DBG & 4)
+    if (c > 0) emit(c - 1, rres);
+#endif
+    mma_store(c, af);
+    if (c + 1 < nchunks) wait_vm((c >= 2 ? nst : 0) + (more ? 4 : 0) + (c >= 1 ? nst : 0));
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
     if (c > 0) emit(c - 1, rres);
     if (more) issue(c + 2);
     mma_store(c, af);
     if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    RBG_STAMP(6 + (c < 20 ? c : 20));
+  };
+  if (res4) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) step(c, rp[c > 0 ? c - 1 : 0]);
+    emit(3, rp[3]);
+  } else if (!R) {
+    for (int c = 0; c < nchunks; ++c) step(c, make_uint4(0, 0, 0, 0));
+    emit(nchunks - 1, make_uint4(0, 0, 0, 0));
+  } else {
+    // (a wait for the residual load also waits for the OLDER DMAs of chunk c+1, which have had an iteration; the DMAs of chunk
+    // c+2 are issued behind the read-out, so no compiler-inserted wait ever covers them)
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = c + 2 < nchunks;
+      const uint4 rres = c > 0 ? res_load(c - 1) : make_uint4(0, 0, 0, 0);
+      uint4 af[8];
+      read_a(c, af);
+      if (c > 0) emit(c - 1, rres);
+      if (more) issue(c + 2);
+      mma_store(c, af);
+      if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    emit(nchunks - 1, res_load(nchunks - 1));
   }
-  emit(nchunks - 1, res_prefetch(nchunks - 1));
+#if S2T_RB_DBG & 64
+  RBG_STAMP(28);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RBG_STAMP(29);
+#endif
 }
 
 // ===============================================================================================================
@@ -1569,11 +1665,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
         ab[qq][r] += dv[qq][r];
       }
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      s1 += __shfl_xor(s1, o, 64);
-      s2 += __shfl_xor(s2, o, 64);
-    }
+    s1 = s2t_sum32(s1);
+    s2 = s2t_sum32(s2);
     s1 *= 1.0f / D;
     s2 *= 1.0f / D;
     if (live) {
@@ -1867,6 +1960,11 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   return S2T_LAUNCH_CHECK();
 }
 
+#if S2T_RB_DBG & 64
+extern "C" int s2t_rbg_dbg_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(s2t_rbg_dbg_buf), sizeof(unsigned long long) * 64);
+}
+#endif
 extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   if (!a || !a->x || !a->w || !a->out) return S2T_ERR_ARG;
   if (a->M <= 0 || a->N <= 0) return S2T_ERR_ARG;
@@ -1886,6 +1984,8 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->drop_seed)) return S2T_ERR_ARG;
   if (a->ldc < nout || a->ldc % 8 || (a->residual && (a->ldr < nout || a->ldr % 8)) || (a->preact && (a->ldp < a->N || a->ldp % 8)))
     return S2T_ERR_ALIGN;
+  // (the kernel's stores address out / preact through 32-bit byte offsets of buffer descriptors)
+  if ((int64_t)a->M * a->ldc * 2 >= ((int64_t)1 << 31) || (a->preact && (int64_t)a->M * a->ldp * 2 >= ((int64_t)1 << 31))) return S2T_ERR_UNSUPPORTED;
   if (a->conv_w) {
     const bool conv_packed = a->conv_T == S2T_ROWS_PACKED && a->ln_lens && a->ln_T == S2T_ROWS_PACKED;  // utterances from the row map
     if (!a->pre_scale || glu || a->drop_p > 0.f || a->x_ln || (!conv_packed && a->conv_T < 18) || (a->ln_lens && a->ln_T != a->conv_T)) return S2T_ERR_ARG;
