@@ -554,21 +554,24 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
       yacc[nt] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int g2key = (r32 >> 1) & 7;
     // G2 of chunk c with the DMA pieces of the running iteration spread over its MFMA groups, and (training / backward) the
     // saved tensor of the same chunk row-major out of the mailbox: lane (row 8 q + (l >> 3), piece l & 7) -> a wave
     // instruction covers 8 whole 128-byte lines.  ALWAYS four store instructions behind the last DMA piece (the closing wait
     // counts on it); the descriptor drops rows >= M and everything when the tensor was not asked for.
     // The fragment reads of output tile nt + 1 go out BEFORE the MFMAs of tile nt (see the producers' loop).
     auto g2 = [&](int c, auto&& piece) __attribute__((always_inline)) {
+      // Every per-lane address of the chunk is formed HERE from the lane id, behind an asm the compiler cannot hoist: carried
+      // across the loop (four mailbox cells, four fragment offsets, the row offset, the save cells) they cost the registers
+      // hipcc then spilled INSIDE the loop — a scratch reload and its vmcnt(0), which also waits for the DMA stream and the
+      // saves in flight, at the head of every chunk.  ~30 vector instructions per chunk instead.
+      uint32_t ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const int r32 = (int)(ln & 31u), hh = (int)(ln >> 5), lane = (int)ln;
+      const int g2key = (r32 >> 1) & 7;
       bf16x8 hb[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) hb[s] = frag(*reinterpret_cast<const uint4*>(mcell(c, s, hh, r32)));
-      // (this lane's row offset is formed HERE from the lane id, behind an asm the compiler cannot hoist: kept across the loop
-      // it was the one register hipcc spilled — a scratch reload and its vmcnt(0) at the head of every chunk)
-      uint32_t ln;
-      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-      const char* l2 = smem + L_W2 + (c & 1) * STAGE + (ln & 31u) * 128u;
+      const char* l2 = smem + L_W2 + (c & 1) * STAGE + r32 * 128;
       auto rd_w = [&](int nt, uint4 (&a)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const uint4*>(l2 + nt * 4096 + 16 * ((2 * s + hh) ^ g2key));

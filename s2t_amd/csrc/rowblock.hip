@@ -1530,6 +1530,39 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
   issue_a(0);
   issue_w(0);
   issue_w(1);
+  // the LayerNorm-backward operands of this thread's epilogue rows are requested HERE, beside the first weight chunks and
+  // the dY tile, and arrive under the product loop (inside the pass loop of the epilogue they were one global round trip
+  // per pass; requested behind the loop they stood between the loop and the LDS exchange)
+  // (so do the rows' mask entries, the LayerNorm's gamma and the dropout seed: requested behind the exchange they were a
+  // round trip each, the mask entries one per pass)
+  uint2 xpre[4][2], rpre[4][2];
+  float mupre[4], rspre[4];
+  bool mpre[4] = {false, false, false, false};
+  float gmm[2][4];
+  uint64_t key_u = 0ull;
+  if (p.ln_x) {
+    const bf16_t* Xp = reinterpret_cast<const bf16_t*>(p.ln_x);
+    const bf16_t* Dp = reinterpret_cast<const bf16_t*>(p.dres);
+    key_u = p.dx_drop ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const float4 t = *reinterpret_cast<const float4*>(p.ln_gamma + 128 * qq + 4 * (lane & 31));
+      gmm[qq][0] = t.x; gmm[qq][1] = t.y; gmm[qq][2] = t.z; gmm[qq][3] = t.w;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int mr = row0 + 8 * wave + 2 * ps + (lane >> 5);
+      const int mc = min(mr, M - 1);
+      mpre[ps] = mr >= M || (p.ln_lens && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)mr));
+      mupre[ps] = p.ln_mean[mc];
+      rspre[ps] = p.ln_rstd[mc];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        xpre[ps][qq] = *reinterpret_cast<const uint2*>(Xp + (int64_t)mc * D + 128 * qq + 4 * (lane & 31));
+        rpre[ps][qq] = Dp ? *reinterpret_cast<const uint2*>(Dp + (int64_t)mc * D + 128 * qq + 4 * (lane & 31)) : make_uint2(0, 0);
+      }
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
   f32x4 acc[4][2];
@@ -1574,25 +1607,6 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
-  // the LayerNorm-backward operands of this thread's epilogue rows travel during the LDS exchange below (inside the pass
-  // loop they were one global round trip per pass)
-  uint2 xpre[4][2], rpre[4][2];
-  float mupre[4], rspre[4];
-  if (p.ln_x) {
-    const bf16_t* Xp = reinterpret_cast<const bf16_t*>(p.ln_x);
-    const bf16_t* Dp = reinterpret_cast<const bf16_t*>(p.dres);
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int mc = min(row0 + 8 * wave + 2 * ps + (lane >> 5), M - 1);
-      mupre[ps] = p.ln_mean[mc];
-      rspre[ps] = p.ln_rstd[mc];
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        xpre[ps][qq] = *reinterpret_cast<const uint2*>(Xp + (int64_t)mc * D + 128 * qq + 4 * (lane & 31));
-        rpre[ps][qq] = Dp ? *reinterpret_cast<const uint2*>(Dp + (int64_t)mc * D + 128 * qq + 4 * (lane & 31)) : make_uint2(0, 0);
-      }
-    }
-  }
   // ---- fp32 rows into LDS: row m at m*1024 + 16*(cc ^ (m & 7)), cc = 4-column piece 16c + 4q + g
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -1624,23 +1638,19 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
   const bf16_t* DR = reinterpret_cast<const bf16_t*>(p.dres);
   bf16_t* DX = reinterpret_cast<bf16_t*>(p.dx);
   bf16_t* DXD = reinterpret_cast<bf16_t*>(p.dx_drop);
-  const uint64_t key_u = DXD ? s2t_drop_key(p.drop_seed, p.drop_site) : 0ull;
   const uint32_t th_u = s2t_drop_thresh(p.drop_p);
   const float inv_u = s2t_drop_scale(p.drop_p);
-  float gmm[2][4], ag[2][4], ab[2][4];
+  float ag[2][4], ab[2][4];
 #pragma unroll
-  for (int qq = 0; qq < 2; ++qq) {
-    const float4 t = *reinterpret_cast<const float4*>(p.ln_gamma + 128 * qq + 4 * sl);
-    gmm[qq][0] = t.x; gmm[qq][1] = t.y; gmm[qq][2] = t.z; gmm[qq][3] = t.w;
+  for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ag[qq][r] = ab[qq][r] = 0.f;
-  }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int ml = 8 * wave + 2 * ps + hi;
     const int m = row0 + ml;
     const bool live = m < M;
-    const bool masked = !live || (p.ln_lens && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m));
+    const bool masked = mpre[ps];
     const float mu = mupre[ps], rs = rspre[ps];
     float dv[2][4], xh[2][4], dg[2][4], rr[2][4];
     float s1 = 0.f, s2 = 0.f;

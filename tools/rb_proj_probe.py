@@ -83,3 +83,24 @@ for name, N, act, ln, res, drop in cases:
                 line.append("%s +%d" % (names.get(i, "c%d" % (i - 6)), st[i] - prev))
                 prev = st[i]
             print("   wg%-3d total %d clk: %s" % (100 * wg, prev - t0, ", ".join(line)), flush=True)
+
+# ---- input-gradient kernels (s2t_rowblock_dgrad): QKV (K = 768) and pointwise conv 1 (K = 512) with the LayerNorm backward,
+# a plain K = 256 projection
+ws = torch.zeros(K.LN_REPLICAS * 2 * 256, device=DEV)
+for name, Kd, ln in (("dgrad qkv", 768, True), ("dgrad pw1", 512, True), ("dgrad 256", 256, False)):
+    dy = torch.randn(M, Kd, generator=g).bfloat16().to(DEV)
+    wt = (torch.randn(256, Kd, generator=g) * 256 ** -0.5).bfloat16().to(DEV)
+    dx = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV)
+    dres = torch.randn(M, 256, generator=g).bfloat16().to(DEV)
+    dxd = torch.empty_like(dx)
+
+    def dg():
+        if ln:
+            K.rowblock_dgrad(dy, wt, ln=dict(x=x, gamma=gam, mean=mean, rstd=rstd, ws=ws, dx=dx, dres=dres, lens=lens, T=250,
+                                             dx_drop=dxd, drop=(0.1, seed, 9)))
+        else:
+            K.rowblock_dgrad(dy, wt, dxn=dx)
+
+    mean.zero_(); rstd.fill_(1.0)
+    t = timeit(dg)
+    print("%-9s K=%4d  rowblock %.1f us (%.0f TF/s)" % (name, Kd, t, 2.0 * M * 256 * Kd / t / 1e6), flush=True)
