@@ -206,9 +206,11 @@ __device__ __forceinline__ void s2t_rand_run_even32(uint64_t key, uint32_t base,
     r16[2 * q + 1] = h >> 16;
   }
 }
-__device__ __forceinline__ uint64_t s2t_drop_key(const uint64_t* seed_ptr, uint32_t site) {
-  const uint64_t seed = seed_ptr ? *seed_ptr : 0ull;
+__device__ __forceinline__ uint64_t s2t_drop_key_of(uint64_t seed, uint32_t site) {
   return (seed * 0xD1342543DE82EF95ull) ^ ((uint64_t)site * 0xA24BAED4963EE407ull);
+}
+__device__ __forceinline__ uint64_t s2t_drop_key(const uint64_t* seed_ptr, uint32_t site) {
+  return s2t_drop_key_of(seed_ptr ? *seed_ptr : 0ull, site);
 }
 // element kept iff its 16 random bits >= thresh; survivors scaled by s2t_drop_scale
 __device__ __forceinline__ uint32_t s2t_drop_thresh(float p) { return (uint32_t)fminf(p * 65536.0f + 0.5f, 65535.0f); }
@@ -224,13 +226,19 @@ __device__ __forceinline__ bool s2t_row_masked(const int32_t* __restrict__ lens,
   return T == S2T_ROWS_PACKED && lens[row] < 0;
 }
 // 32-bit form for epilogues (row < 2^31): the 64-bit division is a long software sequence
-// (ONE load whose result no branch waits for: with a load per layout behind a branch each, the compiler waits for the entry
-// where it is requested, and a prologue that masks four rows pays four memory round trips one after the other)
+// The test in two halves: s2t_row_mask_entry REQUESTS what the test of a row needs (one load, or a constant that never masks
+// when there is no mask), s2t_row_mask_test evaluates it.  A prologue that masks several rows requests all entries first and
+// tests them where it uses them: with request and test in one expression (a bool per row) the compiler waits for each entry
+// where it is requested — one memory round trip per row, one after the other.
+__device__ __forceinline__ int s2t_row_mask_entry(const int32_t* __restrict__ lens, int T, uint32_t row) {
+  if (!lens || (T <= 0 && T != S2T_ROWS_PACKED)) return T > 0 ? 0x7fffffff : 0;
+  return lens[T > 0 ? row / (uint32_t)T : row];
+}
+__device__ __forceinline__ bool s2t_row_mask_test(int T, uint32_t row, int entry) {
+  return T > 0 ? (int)(row % (uint32_t)T) >= entry : entry < 0;
+}
 __device__ __forceinline__ bool s2t_row_masked32(const int32_t* __restrict__ lens, int T, uint32_t row) {
-  if (T <= 0 && T != S2T_ROWS_PACKED) return false;
-  const uint32_t b = T > 0 ? row / (uint32_t)T : row;
-  const int v = lens[b];
-  return T > 0 ? (int)(row - b * (uint32_t)T) >= v : v < 0;
+  return s2t_row_mask_test(T, row, s2t_row_mask_entry(lens, T, row));
 }
 // rows of a launch: the host's bound, or the live row count of a packed batch when that is smaller
 __device__ __forceinline__ int64_t s2t_live_rows(const int32_t* __restrict__ lens, int T, int64_t rows) {

@@ -242,16 +242,40 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) ag[j] = ab[j] = 0.f;
+        // The operands of FOUR passes are requested together before the first of them computes: requested pass by pass (behind
+        // the previous pass's stores, which the compiler will not move a load across) each pass paid a memory round trip AND
+        // the acknowledgement of those stores, eight times one after the other at the head of every backward launch.  (All
+        // eight at once cost registers that hipcc took from the producers' chunk loop: spills inside it.)
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
+        for (int ph = 0; ph < 2; ++ph) {
+        uint4 yrs[4];
+        float mus[4], rss[4];
+        int mke[4];
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+          const int m = row0 + 16 * (4 * ph + pq) + (tid >> 5);
+          const int mc = min(m, M - 1);
+          yrs[pq] = *reinterpret_cast<const uint4*>(Yp + (int64_t)mc * D + 8 * cch);
+          mus[pq] = p.pl_mean[mc];
+          rss[pq] = p.pl_rstd[mc];
+          mke[pq] = s2t_row_mask_entry(p.pl_lens, p.pl_T, (uint32_t)m);
+        }
+        bool mks[4];   // (lane masks in scalar registers)
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+          const int m = row0 + 16 * (4 * ph + pq) + (tid >> 5);
+          mks[pq] = m >= M || s2t_row_mask_test(p.pl_T, (uint32_t)m, mke[pq]);
+        }
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+          const int ps = 4 * ph + pq;
           const int rl = 16 * ps + (tid >> 5);
           const int m = row0 + rl;
-          const int mc = min(m, M - 1);
-          const uint4 yr = *reinterpret_cast<const uint4*>(Yp + (int64_t)mc * D + 8 * cch);
-          const float mu = p.pl_mean[mc], rs = p.pl_rstd[mc];
+          const uint4 yr = yrs[pq];
+          const float mu = mus[pq], rs = rss[pq];
           const bool live = m < M;
           const bool own = live && (SPLIT == 1 || rl / KR == half);
-          const bool masked = !live || (p.pl_lens && s2t_row_masked32(p.pl_lens, p.pl_T, (uint32_t)m));
+          const bool masked = mks[pq];
           const uint32_t dw4[4] = {raw[ps].x, raw[ps].y, raw[ps].z, raw[ps].w};
           const uint32_t yw4[4] = {yr.x, yr.y, yr.z, yr.w};
           float dgv[8], xh[8];
@@ -293,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
             if (own) *reinterpret_cast<uint4*>(DY + (int64_t)m * D + 8 * cch) = o;
           }
           raw[ps] = o;
+        }
         }
         // [2][16][256] fp32 = 32 KiB in the mailbox region (idle until the first chunk)
         float* red = reinterpret_cast<float*>(smem + L_MB);

@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   const int em = row0 + er;
   const bool elive = em < M && (!GLU || ej < 4);
   // (the row's mask entry is read ONCE: a global load inside the loop would make the compiler wait for the DMAs in flight)
-  const bool emasked = elive && p.row_lens && s2t_row_masked32(p.row_lens, p.row_T, (uint32_t)em);
+  const int emask_e = s2t_row_mask_entry(p.row_lens, p.row_T, (uint32_t)em);   // (tested behind the prologue)
   auto res_load = [&](int c) __attribute__((always_inline)) -> uint4 {
     const int n0 = ncols * cmap(c) + 8 * ej;
     if (R && elive && n0 < nout) return *reinterpret_cast<const uint4*>(R + (int64_t)em * p.ldr + n0);
@@ -1203,14 +1203,14 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
       bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1v.x; bt[5] = b1v.y; bt[6] = b1v.z; bt[7] = b1v.w;
     }
     uint4 raw[4];
-    bool pmask[4];   // the rows' mask entries, requested together with the rows (one by one behind each pass's stores they cost a
+    int pmask[4];   // the rows' mask entries, requested together with the rows (one by one behind each pass's stores they cost a
                      // memory round trip per pass)
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int m = row0 + 16 * ps + (tid >> 5);
       const int mc = min(m, M - 1);
       raw[ps] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * D + 8 * cch);
-      pmask[ps] = p.ln_lens && m < M && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)m);
+      pmask[ps] = s2t_row_mask_entry(p.ln_lens, p.ln_T, (uint32_t)m);
     }
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         }
         sq = s2t_sum32(sq);
         const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
-        const bool masked = pmask[ps];
+        const bool masked = m < M && s2t_row_mask_test(p.ln_T, (uint32_t)m, pmask[ps]);
         uint32_t ow[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         }
       } else if (p.pre_scale) {  // per-column affine + activation (BatchNorm apply), masked rows to zero
         const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
-        const bool masked = pmask[ps];
+        const bool masked = m < M && s2t_row_mask_test(p.ln_T, (uint32_t)m, pmask[ps]);
         uint32_t ow[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1288,6 +1288,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   RBG_STAMP(5);
 
   const bool Z = p.preact != nullptr;
+  const bool emasked = elive && s2t_row_mask_test(p.row_T, (uint32_t)em, emask_e);
   const float* lbias = reinterpret_cast<const float*>(smem + PJ_BIAS);
   // Stores go through buffer descriptors: a lane without an output (row beyond the live ones, GLU's idle half, a column tail)
   // offers an offset beyond the descriptor and the hardware drops it, so EVERY wave issues the same number of store
@@ -1537,7 +1538,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
   // round trip each, the mask entries one per pass)
   uint2 xpre[4][2], rpre[4][2];
   float mupre[4], rspre[4];
-  bool mpre[4] = {false, false, false, false};
+  int mpre[4] = {0, 0, 0, 0};
   float gmm[2][4];
   uint64_t key_u = 0ull;
   if (p.ln_x) {
@@ -1553,7 +1554,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
     for (int ps = 0; ps < 4; ++ps) {
       const int mr = row0 + 8 * wave + 2 * ps + (lane >> 5);
       const int mc = min(mr, M - 1);
-      mpre[ps] = mr >= M || (p.ln_lens && s2t_row_masked32(p.ln_lens, p.ln_T, (uint32_t)mr));
+      mpre[ps] = s2t_row_mask_entry(p.ln_lens, p.ln_T, (uint32_t)mr);
       mupre[ps] = p.ln_mean[mc];
       rspre[ps] = p.ln_rstd[mc];
 #pragma unroll
@@ -1650,7 +1651,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
     const int ml = 8 * wave + 2 * ps + hi;
     const int m = row0 + ml;
     const bool live = m < M;
-    const bool masked = mpre[ps];
+    const bool masked = !live || s2t_row_mask_test(p.ln_T, (uint32_t)m, mpre[ps]);
     const float mu = mupre[ps], rs = rspre[ps];
     float dv[2][4], xh[2][4], dg[2][4], rr[2][4];
     float s1 = 0.f, s2 = 0.f;
