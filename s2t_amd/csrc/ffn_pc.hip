@@ -159,6 +159,12 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
 #define LACC()
 #endif
   PSTAMP(0);
+  // forward flavours: the dropout seed is read ONCE, here (a scalar load in front of every store; requested where a key is first
+  // used it was a vector load whose round trip stood in front of the producers' chunk loop and in front of the row epilogue).
+  // (Not in the backward flavour: there the two scalar registers it holds across the kernel tip hipcc into spilling inside the
+  // producers' loop — tools/spill_sites.sh.)
+  uint64_t seed_top = 0ull;
+  if constexpr (!BWD) seed_top = (DROP && p.drop_seed) ? *p.drop_seed : 0ull;
 
   const i32x4 srd1 = make_srd(p.w1, (uint32_t)F * D * 2u);
   const i32x4 srd2 = make_srd(p.w2, (uint32_t)F * D * 2u);
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
   PSTAMP(1);
   if (producer) {
     // =========================================== producers: G1 + E1 ===================================================
-    const uint64_t key_h = DROP ? s2t_drop_key(p.drop_seed, p.drop_h_site) : 0ull;
+    const uint64_t key_h = DROP ? (BWD ? s2t_drop_key(p.drop_seed, p.drop_h_site) : s2t_drop_key_of(seed_top, p.drop_h_site)) : 0ull;
     const uint32_t th_h = s2t_drop_thresh(p.drop_h_p);
     const float inv_h = s2t_drop_scale(p.drop_h_p);
     // MFMA row rho = r32 of a 32-unit tile is fed with unit pi(rho) (bits 2 and 3 swapped)
@@ -762,6 +768,33 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       }
     }
   }
+  // So do the column parameters of the row epilogue, the mask entries of its rows and (backward) the dropout seed: requested
+  // behind the exchange each was a memory round trip on the tail of the launch — the mask entries one per pass, each behind that
+  // pass's stores and their acknowledgement.
+  float b2v[2][4], eg[2][4], eb[2][4], gmm[2][4];
+  int emk[NPS];
+  uint64_t seed_tail = 0ull;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4 t = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + 128 * q + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b2v[q][0] = t.x; b2v[q][1] = t.y; b2v[q][2] = t.z; b2v[q][3] = t.w;
+    if (p.eln_gamma) {
+      const float4 a = *reinterpret_cast<const float4*>(p.eln_gamma + 128 * q + 4 * s);
+      const float4 b = *reinterpret_cast<const float4*>(p.eln_beta + 128 * q + 4 * s);
+      eg[q][0] = a.x; eg[q][1] = a.y; eg[q][2] = a.z; eg[q][3] = a.w;
+      eb[q][0] = b.x; eb[q][1] = b.y; eb[q][2] = b.z; eb[q][3] = b.w;
+    }
+    if constexpr (BWD) {
+      if (p.lb_x) {
+        const float4 g4 = *reinterpret_cast<const float4*>(p.lb_gamma + 128 * q + 4 * s);
+        gmm[q][0] = g4.x; gmm[q][1] = g4.y; gmm[q][2] = g4.z; gmm[q][3] = g4.w;
+      }
+    }
+  }
+  if constexpr (BWD) seed_tail = p.drop_seed ? *p.drop_seed : 0ull;
+#pragma unroll
+  for (int ps = 0; ps < NPS; ++ps)
+    emk[ps] = p.eln_gamma ? s2t_row_mask_entry(p.eln_lens, p.eln_T, (uint32_t)(row0 + krow0 + (KR / 8) * wave + 2 * ps + hi)) : 0;
   __syncthreads();
   PSTAMP(4);
 
@@ -884,24 +917,12 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
   };
 
   // ---- row epilogue ----------------------------------------------------------------------------------------------
-  const uint64_t key_o = DROP ? s2t_drop_key(p.drop_seed, p.drop_o_site) : 0ull;
+  const uint64_t key_o = DROP ? s2t_drop_key_of(BWD ? seed_tail : seed_top, p.drop_o_site) : 0ull;
   const uint32_t th_o = s2t_drop_thresh(p.drop_o_p);
   const float inv_o = s2t_drop_scale(p.drop_o_p);
   const bf16_t* R = reinterpret_cast<const bf16_t*>(p.residual);
   bf16_t* Y = reinterpret_cast<bf16_t*>(p.y);
   bf16_t* YL = reinterpret_cast<bf16_t*>(p.y_ln);
-  float b2v[2][4], eg[2][4], eb[2][4];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float4 t = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + 128 * q + 4 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-    b2v[q][0] = t.x; b2v[q][1] = t.y; b2v[q][2] = t.z; b2v[q][3] = t.w;
-    if (p.eln_gamma) {
-      const float4 a = *reinterpret_cast<const float4*>(p.eln_gamma + 128 * q + 4 * s);
-      const float4 b = *reinterpret_cast<const float4*>(p.eln_beta + 128 * q + 4 * s);
-      eg[q][0] = a.x; eg[q][1] = a.y; eg[q][2] = a.z; eg[q][3] = a.w;
-      eb[q][0] = b.x; eb[q][1] = b.y; eb[q][2] = b.z; eb[q][3] = b.w;
-    }
-  }
   if constexpr (BWD) {
     if (p.lb_x) {
       // ---- backward of the block's leading LayerNorm on the fp32 dXn rows (s2t_layernorm_bwd's arithmetic):
@@ -910,17 +931,14 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
       //   (the mailbox region, idle by now), 512 atomics per workgroup into one replica of the workspace
       bf16_t* DX = reinterpret_cast<bf16_t*>(p.lb_dx);
       bf16_t* DXD = reinterpret_cast<bf16_t*>(p.lb_dx_drop);
-      const uint64_t key_u = DXD ? s2t_drop_key(p.drop_seed, p.lb_drop_site) : 0ull;
+      const uint64_t key_u = DXD ? s2t_drop_key_of(seed_tail, p.lb_drop_site) : 0ull;
       const uint32_t th_u = s2t_drop_thresh(p.lb_drop_p);
       const float inv_u = s2t_drop_scale(p.lb_drop_p);
-      float gmm[2][4], ag[2][4], ab[2][4];
+      float ag[2][4], ab[2][4];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(p.lb_gamma + 128 * q + 4 * s);
-        gmm[q][0] = t.x; gmm[q][1] = t.y; gmm[q][2] = t.z; gmm[q][3] = t.w;
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ag[q][r] = ab[q][r] = 0.f;
-      }
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
         const int ml = krow0 + (KR / 8) * wave + 2 * ps + hi;
@@ -1033,7 +1051,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
         }
       sq = s2t_sum32(sq);
       const float rstd = rsqrtf(sq * (1.0f / D) + p.ln_eps);
-      const bool masked = p.eln_lens && live && s2t_row_masked32(p.eln_lens, p.eln_T, (uint32_t)m);
+      const bool masked = live && s2t_row_mask_test(p.eln_T, (uint32_t)m, emk[ps]);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
