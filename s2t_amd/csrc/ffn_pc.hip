@@ -49,6 +49,9 @@
 #ifndef S2T_PC_ZLOAD_AUX
 #define S2T_PC_ZLOAD_AUX 0  // cache policy of the backward's pre-activation loads (read once)
 #endif
+#ifndef S2T_PC_PRIO
+#define S2T_PC_PRIO 0  // experiment: s_setprio of the producers (bits 0-1) and the consumers (bits 2-3) for the chunk loop
+#endif
 #ifndef S2T_PC_DBG
 #define S2T_PC_DBG 0  // experiment switches: 1 no DMA in the loop, 2 no MFMAs, 4 no E1 arithmetic, 16 stamps
 #endif
@@ -425,6 +428,11 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
 
   f32x16 yacc[8];
   PSTAMP(1);
+#if S2T_PC_PRIO
+  // wave priority: the producers' chain (G1 -> E1 -> mailbox) is the critical path of a chunk, the consumers have slack
+  if (producer) __builtin_amdgcn_s_setprio(S2T_PC_PRIO & 3);
+  else __builtin_amdgcn_s_setprio((S2T_PC_PRIO >> 2) & 3);
+#endif
   if (producer) {
     // =========================================== producers: G1 + E1 ===================================================
     const uint64_t key_h = DROP ? (BWD ? s2t_drop_key(p.drop_seed, p.drop_h_site) : s2t_drop_key_of(seed_top, p.drop_h_site)) : 0ull;
