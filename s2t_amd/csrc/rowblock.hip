@@ -39,6 +39,9 @@
 #ifndef S2T_RBG_ORDER
 #define S2T_RBG_ORDER 1  // row-block projections: 1 the DMA of chunk c+2 in front of read-out c-1's stores with a counted wait that
 #endif                   // leaves those stores in flight; 0 the order of rounds 2 - 4 (stores, DMA, vmcnt(4): every store acknowledged)
+#ifndef S2T_RBG_SKEW
+#define S2T_RBG_SKEW 0  // experiment (measured: no gain, 19.2 against 18.4 us): waves 4 - 7 run product then read-out, waves 0 - 3 read-out then product
+#endif
 #ifndef S2T_RBG_STAGGER
 #define S2T_RBG_STAGGER 1  // row-block projections: the workgroups of an XCD start their walk over W's chunks at different chunks
 #endif
@@ -1406,10 +1409,22 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
 #if !(S2T_RB_DBG & 1)
     if (more) issue(c + 2);
 #endif
+#if S2T_RBG_SKEW
+    // the two waves of a SIMD (w and w + 4) take the read-out and the product in opposite orders: in the same order both sit
+    // in vector arithmetic at the same time and then both queue at the matrix pipe
+    if (wave < 4) {
+      if (c > 0) emit(c - 1, rres);
+      mma_store(c, af);
+    } else {
+      mma_store(c, af);
+      if (c > 0) emit(c - 1, rres);
+    }
+#else
 #if !(S2T_RB_DBG & 4)
     if (c > 0) emit(c - 1, rres);
 #endif
     mma_store(c, af);
+#endif
     if (c + 1 < nchunks) wait_vm((c >= 2 ? nst : 0) + (more ? 4 : 0) + (c >= 1 ? nst : 0));
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
