@@ -533,6 +533,23 @@ int s2t_pack_rows(int dtype, const void* in, void* out, const int32_t* map, int6
  * points take is map_buf + 4.  halo: rows kept behind every utterance (never beyond T).  B <= 1024, T <= 65535. */
 int s2t_rows_geometry(const int32_t* lens, int B, int T, int halo, int32_t* cu, int32_t* map_buf, void* stream);
 
+/* ---- Per-batch bookkeeping of a training step, one launch per item, written INTO tensors a captured step reads (round 5).
+ * The reference derives these inside forward() from the collater's fields (data/audio/speech_to_text_dataset.py:411-485):
+ * s2t_subsampled_lengths: modules/speech_to_text/subsampling.py:150-154 (get_out_seq_lens_tensor: n_layers stride-2
+ *   convolutions, l -> floor((l - 1) / 2) + 1) and data/data_utils.py:518-522 (lengths_to_padding_mask): len64 / len32 [B],
+ *   mask_u8 [B][Tp] = (t >= l_b) as bytes (a torch.bool tensor); any output may be NULL.
+ * s2t_token_positions: utils.py:240-250 (make_positions): positions[b][u] = (# non-pad tokens up to and including u) * nonpad
+ *   + pad_idx, counts[b] = non-pad tokens of row b (the target-side key lengths, models/transformer.py:1340-1342).
+ * s2t_ctc_targets: criterions/ctc.py:516-540: tmat [B][U] = the labels of row b (neither pad nor eos) in order, followed by the
+ *   dropped tokens in order; counts[b] = labels.  tmat must not alias target.
+ * s2t_gather_rows_i64: out[m] = map[m] >= 0 ? src[(map[m] >> 16) * U + (map[m] & 0xffff)] : fill for every row m < rows of a
+ *   packed batch's row map (the flattened targets of the cross-entropy on packed target rows). */
+int s2t_subsampled_lengths(const int64_t* src_lengths, int B, int Tp, int n_layers, int64_t* len64, int32_t* len32, void* mask_u8,
+                           void* stream);
+int s2t_token_positions(const int64_t* tokens, int B, int U, int64_t pad_idx, int32_t* positions, int32_t* counts, void* stream);
+int s2t_ctc_targets(const int64_t* target, int B, int U, int64_t pad_idx, int64_t eos_idx, int64_t* tmat, int32_t* counts, void* stream);
+int s2t_gather_rows_i64(const int64_t* src, const int32_t* map, int64_t rows, int U, int64_t fill, int64_t* out, void* stream);
+
 /* ---- PDS multi-scale fusion: depthwise convolution with kernel = stride = r, no padding --------
  * The depthwise stage of DownSampleConvolutionModule (fairseq/modules/downsample_convolution.py:45-54,97-100) as used by
  * PDSS2TTransformerEncoder.forward, pdss2t_transformer.py:1187-1233.  x [B][Tin][C] channels-last, w [C][r] fp32,

@@ -38,6 +38,13 @@ def batch_bookkeeping(sample, pad_idx, eos_idx):
         tmat, tl = ctc_targets(target, pad_idx, eos_idx)
         return tmat, tl, target.reshape(-1).contiguous()
 
+    def into(target, outs):  # the same into the memo's tensors, one launch (functional._recompute_in_place)
+        K.ctc_targets(target, pad_idx, eos_idx, outs[0], outs[1])
+        if outs[2].data_ptr() != target.data_ptr():
+            outs[2].copy_(target.reshape(-1))
+
+    if sample["target"].dtype == torch.int64 and sample["target"].is_contiguous():
+        fn.into = into
     return Fn.batch_memo(("targets", pad_idx, eos_idx), (sample["target"],), fn)
 
 
@@ -112,6 +119,11 @@ class LabelSmoothedCrossEntropyCriterionWithCTC(_CriterionBase):
                 idx = torch.where(ok, (m >> 16).long() * U_ + (m & 0xffff).long(), torch.zeros_like(m, dtype=torch.long))
                 return (torch.where(ok, t.reshape(-1)[idx], torch.full_like(idx, pad_idx)),)
 
+            def pack_targets_into(t, buf, outs):
+                K.gather_rows_i64(t, buf[hdr:], U_, pad_idx, outs[0])
+
+            if tflat.dtype == torch.int64 and tflat.is_contiguous():
+                pack_targets.into = pack_targets_into
             (tpk,) = Fn.batch_memo(("targets_packed", Fn.memo_owner(self)), (tflat, geom.buf), pack_targets)
             sums = Fn.label_smoothed_ce(logits, tpk, self.eps, self.padding_idx, rows=dpk["rows"])
         else:

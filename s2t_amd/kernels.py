@@ -56,6 +56,41 @@ def _prof_rows(M, *cands):
     return M
 
 
+def subsampled_lengths(src_lengths, Tp, len64, len32, mask, n_layers=2):
+    """s2t_subsampled_lengths: the subsampler's output lengths (int64 and int32) and the padding mask [B, Tp] (torch.bool), in place."""
+    L.require_cuda(src_lengths, len64, len32, mask)
+    assert src_lengths.dtype == torch.int64 and src_lengths.is_contiguous() and mask.dtype == torch.bool and mask.is_contiguous()
+    assert len64.dtype == torch.int64 and len32.dtype == torch.int32 and tuple(mask.shape) == (src_lengths.numel(), Tp)
+    _call("s2t_subsampled_lengths", src_lengths.data_ptr(), src_lengths.numel(), Tp, n_layers, len64.data_ptr(), len32.data_ptr(),
+          mask.data_ptr())
+
+
+def token_positions(tokens, pad_idx, positions, counts):
+    """s2t_token_positions: fairseq's make_positions (int32) and the non-pad count per row, in place."""
+    L.require_cuda(tokens, positions, counts)
+    B, U = tokens.shape
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and positions.dtype == torch.int32 and positions.is_contiguous()
+    assert counts.dtype == torch.int32 and tuple(positions.shape) == (B, U) and counts.numel() == B
+    _call("s2t_token_positions", tokens.data_ptr(), B, U, int(pad_idx), positions.data_ptr(), counts.data_ptr())
+
+
+def ctc_targets(target, pad_idx, eos_idx, tmat, counts):
+    """s2t_ctc_targets: the left-packed label matrix and the label counts of criterions/ctc.py:516-540, in place."""
+    L.require_cuda(target, tmat, counts)
+    B, U = target.shape
+    assert target.dtype == torch.int64 and target.is_contiguous() and tmat.dtype == torch.int64 and tmat.is_contiguous()
+    assert counts.dtype == torch.int32 and tuple(tmat.shape) == (B, U) and counts.numel() == B and tmat.data_ptr() != target.data_ptr()
+    _call("s2t_ctc_targets", target.data_ptr(), B, U, int(pad_idx), int(eos_idx), tmat.data_ptr(), counts.data_ptr())
+
+
+def gather_rows_i64(src, row_map, U, fill, out):
+    """s2t_gather_rows_i64: ``src`` [B * U] int64 through a packed batch's row map (``fill`` on rows that hold no token), in place."""
+    L.require_cuda(src, row_map, out)
+    assert src.dtype == torch.int64 and src.is_contiguous() and out.dtype == torch.int64 and out.is_contiguous()
+    assert row_map.dtype == torch.int32 and row_map.is_contiguous() and out.numel() == row_map.numel()
+    _call("s2t_gather_rows_i64", src.data_ptr(), row_map.data_ptr(), row_map.numel(), U, int(fill), out.data_ptr())
+
+
 def rows_geometry(lens, B, T, halo, cu, buf):
     _call("s2t_rows_geometry", lens.data_ptr(), B, T, halo, cu.data_ptr(), buf.data_ptr())
 

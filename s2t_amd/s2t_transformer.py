@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import kernels as K
 from . import rows as Rows
 from .flat_params import FlatParameters
 from .modules import (CTC, TABLES, Adapter, Conv1dSubsampling, Ctx, LayerNorm, Linear, MaskRows,
@@ -203,6 +204,11 @@ class S2TTransformerEncoder(nn.Module):
             ln = self.subsample.get_out_seq_lens_tensor(sl)
             return ln, ln.to(torch.int32), torch.arange(Tp, device=sl.device)[None, :] >= ln[:, None]
 
+        def length_bookkeeping_into(sl, outs):  # the same into the memo's tensors, one launch (functional._recompute_in_place)
+            K.subsampled_lengths(sl, Tp, outs[0], outs[1], outs[2])
+
+        if src_lengths.dtype == torch.int64 and src_lengths.is_contiguous():
+            length_bookkeeping.into = length_bookkeeping_into
         lens, lens32, encoder_padding_mask = Fn.batch_memo(("enc_lens", Fn.memo_owner(self), Tp), (src_lengths,), length_bookkeeping)
         x = self.subsample(src_tokens, Rows.detached(lens32), dt)  # [B*T', d], padded frames zeroed (:1765)
         if self._packed_ok(dt, B, Tp):
@@ -459,6 +465,13 @@ class TransformerDecoderScriptable(nn.Module):
             # (pads in the middle) would need a mask tensor, the collater never produces them
             return tok.contiguous(), pos.contiguous(), nonpad.sum(1).to(torch.int32)
 
+        def token_bookkeeping_into(tok, outs):  # the same into the memo's tensors, one launch
+            if outs[0] is not tok:
+                outs[0].copy_(tok)
+            K.token_positions(outs[0], pad_idx, outs[1], outs[2])
+
+        if prev_output_tokens.dtype == torch.int64:
+            token_bookkeeping.into = token_bookkeeping_into
         tok, pos, self_lens = Fn.batch_memo(("dec_tokens", Fn.memo_owner(self)), (prev_output_tokens,), token_bookkeeping)
         tab = TABLES.get("sin", self.max_positions() + self.padding_idx + 1, d, dev)
         x = Fn.embedding(tok, pos, self.embed_tokens.weight, tab, self.embed_scale, self.padding_idx)
