@@ -737,6 +737,14 @@ typedef struct s2t_rowblock_args {
   const float* bn_mean; const float* bn_var; float bn_eps;
 } s2t_rowblock_args;
 int s2t_rowblock_gemm(const s2t_rowblock_args* args, void* stream);
+/* s2t_rowblock_chain: two projections of the same rows in ONE launch (round 5) — `first`: a plain N = 256 projection (no
+ * LayerNorm / affine in front, no GLU; bias, dropout, row mask, residual as in s2t_rowblock_gemm): the attention output
+ * projection of a layer (multihead_attention.py:420, espnet_multihead_attention.py:155 + the layer's residual,
+ * s2t_transformer_layer.py:283-288); `second`: a projection of LayerNorm(first's output) without dropout and residual:
+ * conv_norm + pointwise conv 1 + GLU (convolution.py:86-92).  second->x is ignored (the rows stay on the chip); every output
+ * of both — first->out included — is written exactly as by two s2t_rowblock_gemm launches.  S2T_ERR_UNSUPPORTED outside
+ * that shape (callers then launch the two separately). */
+int s2t_rowblock_chain(const s2t_rowblock_args* first, const s2t_rowblock_args* second, void* stream);
 
 /* s2t_rowblock_dgrad: the input gradient of a 256 -> K projection that sits BEHIND a LayerNorm, and that
  * LayerNorm's backward, in one launch on the same 64-row blocks (the autograd backward of F.layer_norm + F.linear /

@@ -1026,18 +1026,18 @@ constexpr int PJ_BIAS = PJ_TILE + 2 * 16384;     // fp32 bias[N] (N <= PJ_MAXN)
 constexpr int PJ_MAXN = 4096;
 constexpr int PJ_BYTES = PJ_BIAS + PJ_MAXN * 4;  // 144 KiB
 
-template <bool GLU, bool DROP, bool CONV = false>
-__global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowblock_args p) {
-  __shared__ __attribute__((aligned(16))) char smem[PJ_BYTES];
+// The body of one projection on the workgroup's 64 rows.  SRC_LDS: the rows come from the bf16 image [64][512 B] a previous
+// body of the same workgroup left in the result-tile region (rowblock_chain_kernel) instead of from p.x; KEEP: the packed
+// output pieces of the thread (N = 256: four chunks) are also handed back in `keep` for that image.
+template <bool GLU, bool DROP, bool CONV, bool SRC_LDS, bool KEEP>
+__device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, const int M, uint4 (&keep)[4]) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mp = wave & 1, q = wave >> 1;
   const int x = lane & 15, g = lane >> 4;
   const int row0 = blockIdx.x * TM;
-  RBG_STAMP(0);
-  const int M = (int)s2t_live_rows(p.row_lens, p.row_T, s2t_live_rows(p.ln_lens, p.ln_T, p.M)), N = p.N;
-  if (row0 >= M) return;  // packed batch: this row block holds no live row
+  const int N = p.N;
   RBG_STAMP(1);
   const int nout = GLU ? N / 2 : N;
   const int ncols = GLU ? 32 : 64;            // output columns per chunk
@@ -1212,7 +1212,12 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     for (int ps = 0; ps < 4; ++ps) {
       const int m = row0 + 16 * ps + (tid >> 5);
       const int mc = min(m, M - 1);
-      raw[ps] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * D + 8 * cch);
+      if constexpr (SRC_LDS) {
+        const int rl = 16 * ps + (tid >> 5);
+        raw[ps] = *reinterpret_cast<const uint4*>(smem + PJ_TILE + rl * 512 + 16 * (cch ^ (rl & 15)));
+      } else {
+        raw[ps] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * D + 8 * cch);
+      }
       pmask[ps] = s2t_row_mask_entry(p.ln_lens, p.ln_T, (uint32_t)m);
     }
 #pragma unroll
@@ -1299,10 +1304,11 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   constexpr uint32_t DROPPED = 0x80000000u;
   const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((uint32_t)p.M * (uint32_t)p.ldc * 2u), 0x00020000);
   const __amdgpu_buffer_rsrc_t zsrd = __builtin_amdgcn_make_buffer_rsrc(p.preact, 0, p.preact ? (int)((uint32_t)p.M * (uint32_t)p.ldp * 2u) : 0, 0x00020000);
-  auto bst8 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t off, const float (&v)[8], int aux) __attribute__((always_inline)) {
+  auto bst8 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t off, const float (&v)[8], int aux) __attribute__((always_inline)) -> uint4 {
     const rb_u4 t = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
     if (aux) __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 2);
     else __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
+    return make_uint4(t.x, t.y, t.z, t.w);
   };
 
   // result tile: fp32 [64 rows][64 units], 16-byte piece pc (4 units) of row r at r*256 + 16*(pc ^ (r & 15))
@@ -1329,7 +1335,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
       *reinterpret_cast<f32x4*>(tile + r * 256 + 16 * ((4 * q + g) ^ x)) = acc[mt];  // r & 15 == x
     }
   };
-  auto emit = [&](int c, const uint4 rres) __attribute__((always_inline)) {
+  auto emit = [&](int c, const uint4 rres) __attribute__((always_inline)) -> uint4 {
     const char* tile = smem + PJ_TILE + (c & 1) * 16384;
     const int r = er, j = ej, m = em;
     auto ld8t = [&](int j8, float (&v)[8]) __attribute__((always_inline)) {
@@ -1383,7 +1389,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
         v[2 * k + 1] += __uint_as_float(w4[k] & 0xffff0000u);
       }
     }
-    bst8(osrd, live ? ((uint32_t)m * (uint32_t)p.ldc + (uint32_t)n0) * 2u : DROPPED, v, 0);
+    return bst8(osrd, live ? ((uint32_t)m * (uint32_t)p.ldc + (uint32_t)n0) * 2u : DROPPED, v, 0);
   };
   const int nst = 1 + ((GLU && Z) ? 2 : 0);   // store instructions of one read-out (every wave, see above)
   auto wait_vm = [&](int n) __attribute__((always_inline)) {   // s_waitcnt vmcnt(n) lgkmcnt(0) + barrier, n uniform
@@ -1421,7 +1427,10 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
     }
 #else
 #if !(S2T_RB_DBG & 4)
-    if (c > 0) emit(c - 1, rres);
+    if (c > 0) {
+      const uint4 kp = emit(c - 1, rres);
+      if constexpr (KEEP) keep[(c - 1) & 3] = kp;
+    }
 #endif
     mma_store(c, af);
 #endif
@@ -1436,10 +1445,11 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
 #endif
     RBG_STAMP(6 + (c < 20 ? c : 20));
   };
-  if (res4) {
+  if (res4 || KEEP) {   // (KEEP: N = 256, checked at the entry point; without a residual the pieces are zero)
 #pragma unroll
     for (int c = 0; c < 4; ++c) step(c, rp[c > 0 ? c - 1 : 0]);
-    emit(3, rp[3]);
+    const uint4 kp = emit(3, rp[3]);
+    if constexpr (KEEP) keep[3] = kp;
   } else if (!R) {
     for (int c = 0; c < nchunks; ++c) step(c, make_uint4(0, 0, 0, 0));
     emit(nchunks - 1, make_uint4(0, 0, 0, 0));
@@ -1464,6 +1474,53 @@ __global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowbloc
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   RBG_STAMP(29);
 #endif
+}
+
+template <bool GLU, bool DROP, bool CONV = false>
+__global__ __launch_bounds__(512, 2) void rowblock_gemm_kernel(const s2t_rowblock_args p) {
+  __shared__ __attribute__((aligned(16))) char smem[PJ_BYTES];
+  const int tid = threadIdx.x;
+  RBG_STAMP(0);
+  const int M = (int)s2t_live_rows(p.row_lens, p.row_T, s2t_live_rows(p.ln_lens, p.ln_T, p.M));
+  if ((int)blockIdx.x * TM >= M) return;  // packed batch: this row block holds no live row
+  uint4 keep[4];
+  rb_body<GLU, DROP, CONV, false, false>(p, smem, M, keep);
+}
+
+// s2t_rowblock_chain: two projections of the same 64 rows in one launch — first: a plain N = 256 projection (the attention
+// output projection: bias, dropout, residual); second: a projection of LayerNorm(first's output) (pointwise conv 1 + GLU,
+// convolution.py:86-92).  The first body's bf16 output rows stay in the workgroup (registers -> the result-tile region as a row
+// image) and the second body's prologue normalises them from there: one launch, one row load and one kernel head fewer per
+// layer; every output — including the first projection's, which the layer needs as residual and for backward — is written as
+// by the two separate launches, bit for bit.
+struct RbChain {
+  s2t_rowblock_args a, b;
+};
+template <bool DROP1, bool GLU2>
+__global__ __launch_bounds__(512, 2) void rowblock_chain_kernel(const RbChain p) {
+  __shared__ __attribute__((aligned(16))) char smem[PJ_BYTES];
+  const int tid = threadIdx.x;
+  RBG_STAMP(0);
+  const int M = (int)s2t_live_rows(p.a.row_lens, p.a.row_T, s2t_live_rows(p.b.ln_lens, p.b.ln_T, s2t_live_rows(p.b.row_lens, p.b.row_T, p.a.M)));
+  if ((int)blockIdx.x * TM >= M) return;
+  uint4 keep[4];
+  rb_body<false, DROP1, false, false, true>(p.a, smem, M, keep);
+  __syncthreads();   // every wave is through its read-outs (the tile region) and its products
+  {
+    // the read-out's ownership: row er, the c-th chunk of this workgroup's walk = column block (c + crot) & 3 (the staggered
+    // walk of rb_body), columns 8 ej .. + 7 of it -> 16-byte piece 8 * block + ej of the row
+    const int er = tid >> 3, ej = tid & 7;
+#if S2T_RBG_STAGGER
+    const int crot = (int)((blockIdx.x >> 3) & 3u);
+#else
+    const int crot = 0;
+#endif
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<uint4*>(smem + PJ_TILE + er * 512 + 16 * ((8 * ((c + crot) & 3) + ej) ^ (er & 15))) = keep[c];
+  }
+  __syncthreads();
+  rb_body<GLU2, false, false, true, false>(p.b, smem, M, keep);
 }
 
 // ===============================================================================================================
@@ -1991,7 +2048,7 @@ extern "C" int s2t_rbg_dbg_read(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(s2t_rbg_dbg_buf), sizeof(unsigned long long) * 64);
 }
 #endif
-extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
+static int rowblock_args_check(const s2t_rowblock_args* a) {
   if (!a || !a->x || !a->w || !a->out) return S2T_ERR_ARG;
   if (a->M <= 0 || a->N <= 0) return S2T_ERR_ARG;
   if (a->d != D) return S2T_ERR_UNSUPPORTED;
@@ -2022,6 +2079,13 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   const void* ptrs[] = {a->x, a->w, a->out, a->residual, a->preact, a->x_ln, a->bias, a->ln_gamma, a->ln_beta};
   for (const void* q : ptrs)
     if (q && ((uintptr_t)q % 16)) return S2T_ERR_ALIGN;
+  return S2T_OK;
+}
+
+extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
+  const int chk = rowblock_args_check(a);
+  if (chk != S2T_OK) return chk;
+  const bool glu = a->act == S2T_ACT_GLU;
   const dim3 grid((a->M + TM - 1) / TM), block(512);
   hipStream_t s = (hipStream_t)stream;
   const bool drop = a->drop_p > 0.f;
@@ -2033,6 +2097,36 @@ extern "C" int s2t_rowblock_gemm(const s2t_rowblock_args* a, void* stream) {
   } else {
     if (drop) hipLaunchKernelGGL((rowblock_gemm_kernel<false, true>), grid, block, 0, s, *a);
     else hipLaunchKernelGGL((rowblock_gemm_kernel<false, false>), grid, block, 0, s, *a);
+  }
+  return S2T_LAUNCH_CHECK();
+}
+
+extern "C" int s2t_rowblock_chain(const s2t_rowblock_args* first, const s2t_rowblock_args* second, void* stream) {
+  if (!first || !second) return S2T_ERR_ARG;
+  int e = rowblock_args_check(first);
+  if (e != S2T_OK) return e;
+  s2t_rowblock_args b = *second;
+  if (!b.x) b.x = first->out;   // (the second projection reads the first one's rows from the chip; x is not dereferenced)
+  e = rowblock_args_check(&b);
+  if (e != S2T_OK) return e;
+  // first: plain 256-column projection of rows given as they are; second: behind a LayerNorm of the first one's output
+  if (first->act != S2T_ACT_NONE || first->N != D || first->ln_gamma || first->pre_scale || first->conv_w || first->preact ||
+      first->ldc != D)
+    return S2T_ERR_UNSUPPORTED;
+  if (!b.ln_gamma || b.pre_scale || b.conv_w || b.x != first->out || b.M != first->M || b.drop_p > 0.f || b.residual)
+    return S2T_ERR_UNSUPPORTED;
+  RbChain k;
+  k.a = *first;
+  k.b = b;
+  const dim3 grid((first->M + TM - 1) / TM), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  const bool drop = first->drop_p > 0.f, glu = b.act == S2T_ACT_GLU;
+  if (drop) {
+    if (glu) hipLaunchKernelGGL((rowblock_chain_kernel<true, true>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((rowblock_chain_kernel<true, false>), grid, block, 0, s, k);
+  } else {
+    if (glu) hipLaunchKernelGGL((rowblock_chain_kernel<false, true>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((rowblock_chain_kernel<false, false>), grid, block, 0, s, k);
   }
   return S2T_LAUNCH_CHECK();
 }

@@ -1317,8 +1317,22 @@ class AttentionFn(torch.autograd.Function):
             ctx.o_lo = O_lo
             y = torch.empty(Mq, d, dtype=dt, device=dev)
             if _rb_ok(O, d) and (residual is None or (residual.stride(0) % 8 == 0 and residual.stride(1) == 1)):
-                K.rowblock_gemm(O, cw(prm["o_w"]), y, N=d, ldc=d, bias=prm["o_b"].data, residual=residual,
-                                ldr=residual.stride(0) if residual is not None else 0, drop=drop_o, rows=qr)
+                first = dict(x=O, w=cw(prm["o_w"]), out=y, N=d, ldc=d, bias=prm["o_b"].data, residual=residual,
+                             ldr=residual.stride(0) if residual is not None else 0, drop=drop_o, rows=qr)
+                req = _CHAIN["req"]
+                if req is not None and self_attn and _rb_ok(y, 2 * d, "glu"):
+                    cz = torch.empty(Mq, 2 * d, dtype=dt, device=dev) if train else None
+                    cg = torch.empty(Mq, d, dtype=dt, device=dev)
+                    cx = torch.empty(Mq, d, dtype=dt, device=dev) if train else None
+                    cm = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
+                    cr = torch.empty(Mq, dtype=torch.float32, device=dev) if train else None
+                    K.rowblock_chain(first, dict(x=y, w=req["w1"], out=cg, N=2 * d, ldc=d, act="glu", preact=cz, ldp=2 * d,
+                                                 ln=(req["ln_g"].data, req["ln_b"].data), ln_lens=req["lens"], ln_T=req["T"],
+                                                 x_ln=cx, ln_stats=(cm, cr) if train else None))
+                    _CHAIN["out"] = {"key": (req["w1"].data_ptr(), req["ln_g"].data_ptr(), bool(train), id(req["lens"]), req["T"]),
+                                     "g": cg, "z": cz, "x": cx, "mean": cm, "rstd": cr}
+                else:
+                    K.rowblock_gemm(first.pop("x"), first.pop("w"), first.pop("out"), **first)
             else:
                 K.gemm(O, cw(prm["o_w"]), y, M=Mq, N=d, K=d, lda=d, ldb=d, ldc=d, bias=prm["o_b"].data, residual=residual,
                        ldr=d, drop=drop_o, rows=qr)
@@ -1765,8 +1779,11 @@ def cross_kv(mem, prms, H, rows=None):
     return CrossKVFn.apply(mem, prms, rows if K.rows_geom(rows) is not None else None), {}
 
 
+_CHAIN = {"req": None, "out": None}
+
+
 def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False, kind="abs", pos_tab=None,
-              p_attn=0.0, p_out=0.0, training=False, ln=None, pos_p=None, kv=None, q_rows=None):
+              p_attn=0.0, p_out=0.0, training=False, ln=None, pos_p=None, kv=None, q_rows=None, chain=None):
     """``ln`` = (gamma, beta) of the LayerNorm in front of a SELF-attention block: ``xq`` is then the block input before
     that LayerNorm and doubles as the residual (``residual`` must be None).  Where the row-block projection kernel applies
     the LayerNorm rides in its prologue; otherwise it runs as its own kernel first."""
@@ -1788,8 +1805,18 @@ def attention(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens=None, causal=False,
         return _tag_drop(AttentionFn.apply(xq, None, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
                                            torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p, kv_all, (l, L, share),
                                            q_rows), drop_o)
-    return _tag_drop(AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
-                                       torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p, None, None, q_rows), drop_o)
+    # ``chain`` (a Conformer layer: dict(w1, ln_g, ln_b, lens, T) of the convolution module that follows): the output projection
+    # and conv_norm + pointwise conv 1 + GLU run as ONE launch (s2t_rowblock_chain); what the module's first stage would have
+    # produced rides on the output tensor, ConvModuleFn picks it up instead of launching
+    _CHAIN["req"], _CHAIN["out"] = (chain if K.RB_CHAIN else None), None
+    try:
+        y = _tag_drop(AttentionFn.apply(xq, xkv, residual, prm, H, B, Tq, Tk, key_lens, causal, kind, pos_tab,
+                                        torch.is_grad_enabled(), drop_a, drop_o, lg, lb, pos_p, None, None, q_rows), drop_o)
+    finally:
+        _CHAIN["req"] = None
+    if _CHAIN["out"] is not None:
+        y._s2t_chain, _CHAIN["out"] = _CHAIN["out"], None
+    return y
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1871,8 +1898,15 @@ class ConvModuleFn(torch.autograd.Function):
             x = torch.empty_like(x_pre) if train else x_pre
             ln_mean = torch.empty(M, dtype=torch.float32, device=dev) if train else None
             ln_rstd = torch.empty(M, dtype=torch.float32, device=dev) if train else None
-            K.rowblock_gemm(x_pre, w1, g, N=2 * d, ldc=d, act="glu", preact=z, ldp=2 * d, ln=(ln_g.data, ln_b.data),
-                            ln_lens=lens, ln_T=T, x_ln=x if train else None, ln_stats=(ln_mean, ln_rstd) if train else None)
+            pre = getattr(x_pre, "_s2t_chain", None)
+            if pre is not None and pre["key"] == (w1.data_ptr(), ln_g.data_ptr(), bool(train), id(lens), T):
+                # produced by the launch that made x_pre (attention(): s2t_rowblock_chain)
+                g, z, ln_mean, ln_rstd = pre["g"], pre["z"], pre["mean"], pre["rstd"]
+                x = pre["x"] if train else x_pre
+                x_pre._s2t_chain = None
+            else:
+                K.rowblock_gemm(x_pre, w1, g, N=2 * d, ldc=d, act="glu", preact=z, ldp=2 * d, ln=(ln_g.data, ln_b.data),
+                                ln_lens=lens, ln_T=T, x_ln=x if train else None, ln_stats=(ln_mean, ln_rstd) if train else None)
             ctx.ln = (ln_g, ln_b, getattr(x_pre, "_s2t_drop_o", None))
             ctx.ln_saved = (x_pre, ln_mean, ln_rstd)
         else:

@@ -2,6 +2,8 @@
 import ctypes as C
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -457,6 +459,24 @@ def transpose_batched(table, n, tiles, n_tiles):
     _call("s2t_transpose_bf16_batched", table.data_ptr(), n, tiles.data_ptr(), n_tiles)
 
 
+RB_CHAIN = os.environ.get("S2T_RB_CHAIN", "1") != "0"  # attention output projection + conv_norm + pointwise conv 1 in one launch
+
+
+def rowblock_chain(first, second):
+    """s2t_rowblock_chain: ``first`` / ``second`` are the keyword dictionaries of two rowblock_gemm calls (``x``, ``w``, ``out``
+    as keys too) on the same rows, the second reading the first's output through a LayerNorm; one launch, same results."""
+    fa = dict(first)
+    a = rowblock_gemm(fa.pop("x"), fa.pop("w"), fa.pop("out"), _args_only=True, **fa)
+    sb = dict(second)
+    b = rowblock_gemm(sb.pop("x"), sb.pop("w"), sb.pop("out"), _args_only=True, **sb)
+    if GEMM_PROFILE is not None:  # (the instrumented step of bench.py times kernels one by one: two launches there)
+        fa, sb = dict(first), dict(second)
+        rowblock_gemm(fa.pop("x"), fa.pop("w"), fa.pop("out"), **fa)
+        rowblock_gemm(sb.pop("x"), sb.pop("w"), sb.pop("out"), **sb)
+        return
+    L.check(L.lib().s2t_rowblock_chain(C.byref(a), C.byref(b), L.stream_ptr()), "s2t_rowblock_chain")
+
+
 def rowblock_supported(x, N, act=None):
     """s2t_rowblock_gemm covers the encoder width of the recipes: bf16, K = d = 256, N % 8 == 0 (GLU: N % 64 == 0), N <= 4096
     (the kernel stages the bias row in LDS)."""
@@ -466,7 +486,7 @@ def rowblock_supported(x, N, act=None):
 
 def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual=None, ldr=0, preact=None, ldp=0, ln=None,
                   ln_eps=1e-5, ln_lens=None, ln_T=0, x_ln=None, ln_stats=None, row_lens=None, row_T=0, drop=None, pre=None, conv=None,
-                  rows=None):
+                  rows=None, _args_only=False):
     """s2t_rowblock_gemm (include/s2t_hip.h): out = epilogue(LN(x) @ w[:N]^T); ``ln`` = (gamma, beta) or None;
     ``pre`` = (scale, shift, act): a per-column affine + activation in place of the LayerNorm (masked by ln_lens / ln_T);
     ``conv`` = (taps fp32 [256, 15], frames per utterance[, running_mean, running_var, eps]): the 15-tap depthwise
@@ -503,6 +523,8 @@ def rowblock_gemm(x, w, out, *, N, ldc, bias=None, act=None, alpha=1.0, residual
     a.residual, a.ldr = _ptr(residual), ldr
     if drop is not None and drop[0] > 0:
         a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), drop[1].data_ptr(), int(drop[2])
+    if _args_only:
+        return a
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -160,13 +160,13 @@ class MultiheadAttention(nn.Module):
         return {"q_w": self.q_proj.weight, "q_b": self.q_proj.bias, "k_w": self.k_proj.weight, "k_b": self.k_proj.bias,
                 "v_w": self.v_proj.weight, "v_b": self.v_proj.bias, "o_w": self.out_proj.weight, "o_b": self.out_proj.bias}
 
-    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False, norm=None, kv=None, q_rows=None):
+    def forward(self, xq, xkv, residual, B, Tq, Tk, key_lens=None, causal=False, norm=None, kv=None, q_rows=None, chain=None):
         """``norm``: the LayerNorm in front of a self-attention block — ``xq`` is then the un-normalised block input and
         the residual (pass ``residual=None``).  ``kv``: keys / values projected for the whole stack (Fn.cross_kv).
         ``q_rows``: the packed geometry of the QUERY rows of an encoder-decoder attention (key side: ``key_lens``)."""
         return Fn.attention(xq, xkv, residual, self._prm(), self.num_heads, B, Tq, Tk, key_lens, causal, "abs", None,
                             self.attn_dropout, self.out_dropout, self.training,
-                            ln=(norm.weight, norm.bias) if norm is not None else None, kv=kv, q_rows=q_rows)
+                            ln=(norm.weight, norm.bias) if norm is not None else None, kv=kv, q_rows=q_rows, chain=chain)
 
 
 class RelPositionMultiHeadedAttention(nn.Module):
@@ -199,10 +199,10 @@ class RelPositionMultiHeadedAttention(nn.Module):
                 "o_w": self.linear_out.weight, "o_b": self.linear_out.bias, "pos_w": self.linear_pos.weight,
                 "pos_u": self.pos_bias_u, "pos_v": self.pos_bias_v}
 
-    def forward(self, x, residual, B, T, key_lens, pos_tab, norm=None, pos_p=None):
+    def forward(self, x, residual, B, T, key_lens, pos_tab, norm=None, pos_p=None, chain=None):
         return Fn.attention(x, None, residual, self._prm(), self.h, B, T, T, key_lens, False, "rel", pos_tab,
                             self.attn_dropout, self.out_dropout, self.training,
-                            ln=(norm.weight, norm.bias) if norm is not None else None, pos_p=pos_p)
+                            ln=(norm.weight, norm.bias) if norm is not None else None, pos_p=pos_p, chain=chain)
 
 
 class _BatchNorm1d(nn.Module):
@@ -340,11 +340,18 @@ class S2TTransformerEncoderLayer(nn.Module):
         B, T, lens = c.B, c.T, c.lens
         if self.macaron_norm is not None:
             x = self.macaron_ffn.block(x, self.macaron_norm, self.ffn_scale, rows=c.rows)
+        # the attention output projection and the convolution module's conv_norm + pointwise conv 1 + GLU are row-local
+        # neighbours: one launch where the row-block kernels apply (functional.attention, s2t_rowblock_chain)
+        chain = None
+        if self.conv_module is not None:
+            d = x.shape[1]
+            chain = {"w1": Fn.cw(self.conv_module.pointwise_conv1.weight).view(2 * d, d), "ln_g": self.conv_norm.weight,
+                     "ln_b": self.conv_norm.bias, "lens": lens, "T": T}
         if self.attn_type == "rel_pos":
             x = self.self_attn(x, None, B, T, lens, c.pos_tab, norm=self.self_attn_layer_norm,
-                               pos_p=getattr(c, "cur_pos_p", None))
+                               pos_p=getattr(c, "cur_pos_p", None), chain=chain)
         else:
-            x = self.self_attn(x, None, None, B, T, T, lens, norm=self.self_attn_layer_norm)
+            x = self.self_attn(x, None, None, B, T, T, lens, norm=self.self_attn_layer_norm, chain=chain)
         if self.conv_module is not None:
             x = self.conv_module(x, None, B, T, lens, norm=self.conv_norm)  # conv input mask fused (convolution.py:86-88)
         x = self.ffn.block(x, self.ffn_norm, self.ffn_scale, self.final_norm, lens if mask_output else None, T, rows=c.rows)

@@ -721,3 +721,62 @@ def test_split_ffn_forms_with_compute_units_held_by_another_kernel(parked, ffn_s
         res[M] = (t_free * 1e6, t_held * 1e6, t_budget * 1e6)
     print("fused FFN eval forward with %d of %d CUs held: rows 16000 free %.1f us, held %.1f, held + budget %.1f; rows 3904 free %.1f, "
           "held %.1f, held + budget %.1f" % ((parked, cus) + res[16000] + res[3904]))
+
+
+@pytest.mark.parametrize("M,packed,train,p,glu", [(16000, True, True, 0.1, True), (16000, False, True, 0.1, True),
+                                                   (4033, True, False, 0.0, True), (250, False, True, 0.0, True),
+                                                   (6000, True, True, 0.1, False)])
+def test_rowblock_chain_equals_two_launches(M, packed, train, p, glu):
+    """s2t_rowblock_chain (the attention output projection, then conv_norm + pointwise conv 1 + GLU on the rows it left in the
+    workgroup — s2t_transformer_layer.py:283-288, convolution.py:86-92) against the two s2t_rowblock_gemm launches it
+    replaces: every output of both stages bit for bit — uniform and packed rows, with and without dropout / training saves."""
+    from s2t_amd import rows as Rows
+
+    d, T = 256, 250
+    B = (M + T - 1) // T
+    Mr = B * T
+    g = torch.Generator().manual_seed(M + 7 * packed + 3 * train)
+    O = torch.randn(Mr, d, generator=g).bfloat16().to(DEV)
+    res = torch.randn(Mr, d, generator=g).bfloat16().to(DEV)
+    wo = (torch.randn(d, d, generator=g) * d ** -0.5).bfloat16().to(DEV)
+    bo = torch.randn(d, generator=g).to(DEV) * 0.1
+    N2 = 2 * d if glu else 3 * d
+    w1 = (torch.randn(N2, d, generator=g) * d ** -0.5).bfloat16().to(DEV)
+    b1 = torch.randn(N2, generator=g).to(DEV) * 0.1
+    gam = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    bet = (0.1 * torch.randn(d, generator=g)).to(DEV)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = T
+    lens = lens.to(DEV)
+    if packed:
+        lens = Rows.attach(lens, B, T, 7)
+    else:
+        lens = Rows.detached(lens)
+    seed = torch.tensor([99], dtype=torch.int64, device=DEV)
+    nout = d if glu else N2
+
+    def outs():
+        return dict(y=torch.zeros(Mr, d, dtype=torch.bfloat16, device=DEV), o2=torch.zeros(Mr, nout, dtype=torch.bfloat16, device=DEV),
+                    z=torch.zeros(Mr, N2, dtype=torch.bfloat16, device=DEV) if (train and glu) else None,
+                    xl=torch.zeros(Mr, d, dtype=torch.bfloat16, device=DEV) if train else None,
+                    mean=torch.zeros(Mr, device=DEV) if train else None, rstd=torch.zeros(Mr, device=DEV) if train else None)
+
+    def stages(o):
+        first = dict(x=O, w=wo, out=o["y"], N=d, ldc=d, bias=bo, residual=res, ldr=d, drop=(p, seed, 5) if p > 0 else None,
+                     rows=lens if packed else None)
+        second = dict(x=o["y"], w=w1, out=o["o2"], N=N2, ldc=nout, bias=b1, act="glu" if glu else None, preact=o["z"],
+                      ldp=N2 if o["z"] is not None else 0, ln=(gam, bet), ln_lens=lens, ln_T=T, x_ln=o["xl"],
+                      ln_stats=(o["mean"], o["rstd"]) if train else None)
+        return first, second
+
+    a, b = outs(), outs()
+    f, s = stages(a)
+    K.rowblock_gemm(f.pop("x"), f.pop("w"), f.pop("out"), **f)
+    K.rowblock_gemm(s.pop("x"), s.pop("w"), s.pop("out"), **s)
+    f, s = stages(b)
+    K.rowblock_chain(f, s)
+    torch.cuda.synchronize()
+    for k in a:
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), k
+    assert float(a["o2"].float().abs().sum()) > 0
