@@ -353,7 +353,12 @@ def main():
             a[1] += max(ms * 1e-3 - ev_over, 1e-7)
             a[2] += 1
             a[3] += nbytes
-        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        # The two training flavours of the fused feed-forward kernel total within 1 % of each other and swapped places from run to
+        # run (round 5: 69.6 against 70.0 us per launch); kernels within 1.5 % of the largest total are a tie, broken by the larger
+        # algorithmic traffic per launch (a stable choice; every FFN flavour is reported in `ffn_flavours` either way)
+        top = max(v[1] for v in agg.values())
+        tied = [kv for kv in agg.items() if kv[1][1] >= 0.985 * top]
+        dom = max(tied, key=lambda kv: (kv[1][3] / max(kv[1][2], 1), kv[1][1]))
         sym, (fl, sec, cnt, alg_bytes) = dom
         peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
         gemm_total = sum(v[1] for v in agg.values())
@@ -390,7 +395,7 @@ def main():
         roofline.update({"kernel": sym, "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": cnt,
                          "avg_launch_us": sec / cnt * 1e6, "algorithmic_bytes": alg_bytes / cnt, "flops": fl / cnt,
                          "mfma_tflops": fl / sec / 1e12, "mfma_frac": fl / sec / peak,
-                         "event_pair_overhead_us": ev_over * 1e6, "all_gemm_ms_per_step": gemm_total * 1e3,
+                         "event_pair_overhead_us": ev_over * 1e6, "tied_for_dominant": sorted(k for k, _ in tied), "all_gemm_ms_per_step": gemm_total * 1e3,
                          "all_gemm_tflops": sum(v[0] for v in agg.values()) / gemm_total / 1e12})
         # every flavour of the fused feed-forward kernel in the step (training forward and backward are within a few microseconds
         # of each other: both are reported, not whichever totals more), each against the roofline that binds it, with its PMC
