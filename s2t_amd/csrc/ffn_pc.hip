@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
           yrs[pq] = *reinterpret_cast<const uint4*>(Yp + (int64_t)mc * D + 8 * cch);
           mus[pq] = p.pl_mean[mc];
           rss[pq] = p.pl_rstd[mc];
-          mke[pq] = s2t_row_mask_entry(p.pl_lens, p.pl_T, (uint32_t)m);
+          mke[pq] = s2t_row_mask_entry(p.pl_lens, p.pl_T, (uint32_t)mc);   // (the CLAMPED row: a tail block reads no entry beyond the map)
         }
         bool mks[4];   // (lane masks in scalar registers)
 #pragma unroll
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
   if constexpr (BWD) seed_tail = p.drop_seed ? *p.drop_seed : 0ull;
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps)
-    emk[ps] = p.eln_gamma ? s2t_row_mask_entry(p.eln_lens, p.eln_T, (uint32_t)(row0 + krow0 + (KR / 8) * wave + 2 * ps + hi)) : 0;
+    emk[ps] = p.eln_gamma ? s2t_row_mask_entry(p.eln_lens, p.eln_T, (uint32_t)min(row0 + krow0 + (KR / 8) * wave + 2 * ps + hi, M - 1)) : 0;
   __syncthreads();
   PSTAMP(4);
 

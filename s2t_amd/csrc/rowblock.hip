@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
   const int em = row0 + er;
   const bool elive = em < M && (!GLU || ej < 4);
   // (the row's mask entry is read ONCE: a global load inside the loop would make the compiler wait for the DMAs in flight)
-  const int emask_e = s2t_row_mask_entry(p.row_lens, p.row_T, (uint32_t)em);   // (tested behind the prologue)
+  const int emask_e = s2t_row_mask_entry(p.row_lens, p.row_T, (uint32_t)min(em, M - 1));   // (tested behind the prologue)
   auto res_load = [&](int c) __attribute__((always_inline)) -> uint4 {
     const int n0 = ncols * cmap(c) + 8 * ej;
     if (R && elive && n0 < nout) return *reinterpret_cast<const uint4*>(R + (int64_t)em * p.ldr + n0);
@@ -1218,7 +1218,7 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
       } else {
         raw[ps] = *reinterpret_cast<const uint4*>(X + (int64_t)mc * D + 8 * cch);
       }
-      pmask[ps] = s2t_row_mask_entry(p.ln_lens, p.ln_T, (uint32_t)m);
+      pmask[ps] = s2t_row_mask_entry(p.ln_lens, p.ln_T, (uint32_t)mc);
     }
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_dgrad_kernel(const DgradK p) 
     for (int ps = 0; ps < 4; ++ps) {
       const int mr = row0 + 8 * wave + 2 * ps + (lane >> 5);
       const int mc = min(mr, M - 1);
-      mpre[ps] = s2t_row_mask_entry(p.ln_lens, p.ln_T, (uint32_t)mr);
+      mpre[ps] = s2t_row_mask_entry(p.ln_lens, p.ln_T, (uint32_t)mc);
       mupre[ps] = p.ln_mean[mc];
       rspre[ps] = p.ln_rstd[mc];
 #pragma unroll

@@ -268,25 +268,29 @@ def batch_memo(key, srcs, fn):
     """``fn(*srcs)`` computed once per batch object.  Same source OBJECTS with new contents (their version counters moved: data
     copied into a static batch) are recomputed INTO the existing outputs, so whoever holds those tensors — a later layer of this
     pass, a captured graph — sees the new values at the old addresses; another batch object replaces the entry, unless a captured
-    graph reads it (pin_batch_memos): the pinned entry then stays beside the new one."""
-    pinned = _MEMO_PINNED.get(key, ())
-    for i, e in enumerate(pinned):
-        if _same_srcs(e, srcs):
-            if all(a._version == v for a, v in zip(e[0], e[1])):
-                return e[3]
-            ne = _recompute_in_place(e[:4], key)
-            if ne is None:
-                raise RuntimeError("s2t_amd: the per-batch bookkeeping %r of a captured step changed shape" % (key,))
-            pinned[i] = ne + tuple(e[4:])
-            return ne[3]
-    e = _MEMO.get(key)
-    if e is not None and _same_srcs(e, srcs):
+    graph reads it (pin_batch_memos): the pinned entry then stays beside the new one.
+
+    A moved version refreshes through ``refresh_batch_memos``: every memo computed from the moved sources AND every memo computed
+    from the outputs of one refreshed here (the padding mask feeds the length memos, the lengths the packed-row geometry) is
+    recomputed in the same sweep.  The one-launch ``into`` forms write through raw addresses, so an output's own version counter
+    never moves: without the cascade a dependent memo would pass its version check and hand back the previous batch's values
+    (ADVICE round 5)."""
+    for table in (_MEMO_PINNED.get(key, ()), None):
+        if table is None:
+            e = _MEMO.get(key)
+        else:
+            e = next((x for x in table if _same_srcs(x, srcs)), None)
+        if e is None or not _same_srcs(e, srcs):
+            continue
         if all(a._version == v for a, v in zip(e[0], e[1])):
             return e[3]
-        ne = _recompute_in_place(e, key)
-        if ne is not None:
-            _MEMO[key] = ne
-            return ne[3]
+        refresh_batch_memos([a for a, v in zip(e[0], e[1]) if a._version != v])
+        if table is None:
+            e = _MEMO.get(key)  # (dropped by the refresh when its outputs changed shape: computed afresh below)
+            if e is not None and _same_srcs(e, srcs):
+                return e[3]
+        else:
+            return next(x for x in table if _same_srcs(x, srcs))[3]
     outs = fn(*srcs)
     _MEMO[key] = (tuple(srcs), tuple(t._version for t in srcs), fn, outs)
     return outs
@@ -346,7 +350,13 @@ def refresh_batch_memos(changed):
                 continue
             ne = _recompute_in_place(e[:4], key)
             if ne is None:
-                raise RuntimeError("s2t_amd: the per-batch bookkeeping %r changed shape under a refresh" % (key,))
+                if slot is None:
+                    # an unpinned entry whose outputs changed shape (e.g. a longer longest target): nobody holds its addresses
+                    # but this pass — drop it; batch_memo computes it afresh, and memos made from its old outputs no longer match
+                    _MEMO.pop(key, None)
+                    progress = True
+                    continue
+                raise RuntimeError("s2t_amd: the per-batch bookkeeping %r of a captured step changed shape under a refresh" % (key,))
             for o in outs:
                 if torch.is_tensor(o):
                     dirty.add(id(o))

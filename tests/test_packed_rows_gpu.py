@@ -748,3 +748,48 @@ def test_nast_stack_at_d512_decodes_on_packed_rows_in_inference():
     model.train()
     enc = model.encoder(src_tokens=ni["src_tokens"], src_lengths=ni["src_lengths"])
     assert enc.get("packed") is None
+
+
+@pytest.mark.parametrize("conformer", [True, False])
+def test_an_eager_pass_over_a_batch_overwritten_in_place_sees_the_new_batch(conformer):
+    """a static batch whose tensors are overwritten IN PLACE (``copy_`` of a new batch into the same tensors,
+    without Trainer.load_batch) and then run eagerly.  The memos made from the raw tensors notice the moved version counters; the
+    memos made from THEIR outputs (CTC input lengths and key masks from the padding mask, the packed row map from the int32
+    lengths, the packed targets) are written through raw addresses by the one-launch forms, so their own counters never move —
+    the refresh must cascade.  Loss, CTC-greedy ids and every gradient of the overwritten batch equal those of the same data in
+    fresh tensors."""
+    model = _model(conformer)
+    crit = C.LabelSmoothedCrossEntropyCriterionWithCTC(M.FakeTask(V), label_smoothing=0.1, ctc_weight=0.3)
+    first, _ = _sample(24, 1000, 41)
+    second, lens2 = _sample(24, 1000, 42, lo=0.3)  # other lengths (shorter utterances), other targets, the same shapes
+    assert not torch.equal(first["net_input"]["src_lengths"], second["net_input"]["src_lengths"])
+
+    def run(sample):
+        model.train()
+        model.flat.zero_grad()
+        loss, _, _ = crit(model, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+        grad = model.flat.grad.clone()
+        model.eval()
+        with torch.no_grad():
+            enc = model.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+            ids = enc["ctc_logit"][0].float().argmax(-1).clone()
+            mask = enc["encoder_padding_mask"][0].clone()
+        return float(loss.detach()), grad, ids, mask
+
+    static = {"net_input": {k: v.clone() for k, v in first["net_input"].items()}, "target": first["target"].clone(),
+              "ntokens": first["ntokens"]}
+    l_first = run(static)[0]
+    # the new batch INTO the same tensor objects
+    for k, v in second["net_input"].items():
+        static["net_input"][k].copy_(v)
+    static["target"].copy_(second["target"])
+    static["ntokens"] = second["ntokens"]
+    got = run(static)
+    want = run(second)
+    assert abs(l_first - want[0]) > 1e-3 * abs(want[0])  # the two batches really differ
+    assert torch.equal(got[3], want[3])                  # padding mask of the new lengths
+    assert abs(got[0] - want[0]) <= 1e-5 * abs(want[0]), (got[0], want[0])
+    assert torch.equal(got[2], want[2])
+    assert float((got[1] - want[1]).norm() / want[1].norm()) <= 1e-4
