@@ -12,7 +12,8 @@ fairseq/distributed/legacy_distributed_data_parallel.py:76-160, fairseq/trainer.
      parameters' last contribution would miss that contribution);
   3. the number of _ready reports per parameter is the same on every pass, on both ranks;
   4. three Trainer updates: eager data-parallel steps against the captured form (graph 1 = forward + backward, eager bucket
-     all-reduce, graph 2 = clip + Adam) end at the same fp32 masters, and both ranks hold the same masters bit for bit.
+     all-reduce, graph 2 = clip + Adam) end at the same fp32 masters, and the two ranks' masters agree (the reduced gradients are equal bit for bit; each rank's
+     gradient norm is an fp32 atomic sum of its own, so the clip coefficients may differ in the last bit).
 
 Usage: ddp_two_ranks_worker.py RANK WORLD PORT OUTDIR
 """
@@ -166,9 +167,9 @@ def _variant(name, rank, world, torch, dist):
     res["losses_graph"] = finals["graph"][0]
     both = [None] * world
     dist.all_gather_object(both, pg)
-    res["masters_equal_on_ranks_graph"] = bool(torch.equal(both[0], both[1]))
+    res["masters_rank_diff_graph"] = float((both[0] - both[1]).abs().max() / both[0].abs().max())
     dist.all_gather_object(both, pe)
-    res["masters_equal_on_ranks_eager"] = bool(torch.equal(both[0], both[1]))
+    res["masters_rank_diff_eager"] = float((both[0] - both[1]).abs().max() / both[0].abs().max())
     return res
 
 

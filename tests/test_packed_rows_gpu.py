@@ -764,32 +764,48 @@ def test_an_eager_pass_over_a_batch_overwritten_in_place_sees_the_new_batch(conf
     second, lens2 = _sample(24, 1000, 42, lo=0.3)  # other lengths (shorter utterances), other targets, the same shapes
     assert not torch.equal(first["net_input"]["src_lengths"], second["net_input"]["src_lengths"])
 
-    def run(sample):
+    def evaluate(sample):
+        model.eval()
+        with torch.no_grad():
+            enc = model.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+            logits, _ = model.decoder(sample["net_input"]["prev_output_tokens"], encoder_out=enc)
+            return enc["ctc_logit"][0].float().argmax(-1).clone(), enc["encoder_padding_mask"][0].clone(), logits.float().clone()
+
+    def train(sample):
         model.train()
         model.flat.zero_grad()
         loss, _, _ = crit(model, sample)
         loss.backward()
         torch.cuda.synchronize()
-        grad = model.flat.grad.clone()
-        model.eval()
-        with torch.no_grad():
-            enc = model.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
-            ids = enc["ctc_logit"][0].float().argmax(-1).clone()
-            mask = enc["encoder_padding_mask"][0].clone()
-        return float(loss.detach()), grad, ids, mask
+        return float(loss.detach()), model.flat.grad.clone()
 
     static = {"net_input": {k: v.clone() for k, v in first["net_input"].items()}, "target": first["target"].clone(),
               "ntokens": first["ntokens"]}
-    l_first = run(static)[0]
-    # the new batch INTO the same tensor objects
+    # eval passes first (a training pass moves the BatchNorm running statistics the eval passes read)
+    ev_first = evaluate(static)
+    for k, v in second["net_input"].items():   # the new batch INTO the same tensor objects
+        static["net_input"][k].copy_(v)
+    static["target"].copy_(second["target"])
+    static["ntokens"] = second["ntokens"]
+    ev_got = evaluate(static)
+    ev_want = evaluate(second)
+    assert not torch.equal(ev_first[1], ev_want[1])          # the two batches really differ (other lengths)
+    assert torch.equal(ev_got[1], ev_want[1])                # padding mask of the NEW lengths
+    assert torch.equal(ev_got[0], ev_want[0])                # CTC-greedy frames
+    tm = second["net_input"]["prev_output_tokens"].ne(1)
+    assert torch.equal(ev_got[2][tm], ev_want[2][tm])        # decoder logits (packed target rows, key masks of the new lengths)
+    # training passes (batch statistics: independent of the running ones): back to the first batch, then the second in place
+    for k, v in first["net_input"].items():
+        static["net_input"][k].copy_(v)
+    static["target"].copy_(first["target"])
+    static["ntokens"] = first["ntokens"]
+    l_first = train(static)[0]
     for k, v in second["net_input"].items():
         static["net_input"][k].copy_(v)
     static["target"].copy_(second["target"])
     static["ntokens"] = second["ntokens"]
-    got = run(static)
-    want = run(second)
-    assert abs(l_first - want[0]) > 1e-3 * abs(want[0])  # the two batches really differ
-    assert torch.equal(got[3], want[3])                  # padding mask of the new lengths
+    got = train(static)
+    want = train(second)
+    assert abs(l_first - want[0]) > 1e-3 * abs(want[0])
     assert abs(got[0] - want[0]) <= 1e-5 * abs(want[0]), (got[0], want[0])
-    assert torch.equal(got[2], want[2])
     assert float((got[1] - want[1]).norm() / want[1].norm()) <= 1e-4

@@ -1,0 +1,123 @@
+"""Perf guard ("weak" 15): the fused feed-forward kernels sit at 256 VGPRs and their register allocation is
+fragile — a DPP reduction in the backward flavour's prologue once moved five spills into the consumers' chunk loop (72 -> 106 µs
+per launch, csrc/ffn_pc.hip), and a toolchain bump can do the same silently: correctness tests stay green, the step loses 10 %.
+This file times the three flavours the bench runs (eval, training forward, backward; 16 000 rows, d = 256, F = 2048, swish,
+dropout 0.1, buffers cycled through 12 sets so that the saves go to HBM as inside the model) and the three row-block kernels
+with the most launches per step, and fails when one is slower than 1.15 x its recorded time.
+
+RECORDED: device time per launch (HIP events on the launch stream around 4 x 12 launches, best of three such measurements) on
+MI355X, round 6, from the sources of this commit.  The runs that set them and the spread over boxes are in DESIGN.md §6.
+A kernel that got FASTER by more than 15 % only prints a note: re-record."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from s2t_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+M, D, F = 16000, 256, 2048
+NB = 12
+TOL = 1.15
+
+# µs per launch, MI355X (see the module docstring)
+RECORDED = {
+    "ffn_eval": 48.0,
+    "ffn_train_fwd": 66.0,
+    "ffn_bwd": 68.0,
+    "qkv_projection": 17.0,
+    "rowblock_dgrad_k768": 19.0,
+}
+
+
+@pytest.fixture(scope="module")
+def bufs():
+    g = torch.Generator().manual_seed(0)
+    b = {}
+    b["xs"] = [torch.randn(M, D, generator=g).bfloat16().to(DEV) for _ in range(NB)]
+    b["w1"] = [(torch.randn(F, D, generator=g) * D ** -0.5).bfloat16().to(DEV) for _ in range(NB)]
+    b["w2"] = [(torch.randn(D, F, generator=g) * F ** -0.5).bfloat16().to(DEV) for _ in range(NB)]
+    b["w1t"] = [w.t().contiguous() for w in b["w1"]]
+    b["w2t"] = [w.t().contiguous() for w in b["w2"]]
+    b["b1"] = torch.zeros(F, device=DEV)
+    b["b2"] = torch.zeros(D, device=DEV)
+    b["gam"] = torch.ones(D, device=DEV)
+    b["bet"] = torch.zeros(D, device=DEV)
+    b["seed"] = torch.tensor([1], dtype=torch.int64, device=DEV)
+    b["zs"] = [torch.empty(K.ffn_z_rows(M), F, dtype=torch.bfloat16, device=DEV) for _ in range(NB)]
+    b["hs"] = [torch.empty(M, F, dtype=torch.bfloat16, device=DEV) for _ in range(NB)]
+    b["xl"] = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    b["mean"] = torch.empty(M, device=DEV)
+    b["rstd"] = torch.empty(M, device=DEV)
+    b["y"] = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    b["dy"] = torch.randn(M, D, generator=g).bfloat16().to(DEV)
+    b["dxn"] = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    b["wqkv"] = [(torch.randn(3 * D, D, generator=g) * D ** -0.5).bfloat16().to(DEV) for _ in range(NB)]
+    b["wqkvt"] = [w.t().contiguous() for w in b["wqkv"]]
+    b["bqkv"] = torch.zeros(3 * D, device=DEV)
+    b["qkv"] = [torch.empty(M, 3 * D, dtype=torch.bfloat16, device=DEV) for _ in range(NB)]
+    b["dqkv"] = [torch.randn(M, 3 * D, generator=g).bfloat16().to(DEV) for _ in range(2)]
+    return b
+
+
+def _time(fn, rounds=4, repeats=3):
+    for i in range(NB):
+        fn(i)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rounds):
+            for i in range(NB):
+                fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / (rounds * NB) * 1e3
+        best = t if best is None else min(best, t)
+    return best
+
+
+def _check(name, t):
+    rec = RECORDED[name]
+    print("perf guard %-22s %7.2f us per launch (recorded %.1f, bound %.1f)" % (name, t, rec, TOL * rec))
+    if t < rec / TOL:
+        print("    (more than 15 %% faster than recorded: re-record %s)" % name)
+    assert t <= TOL * rec, "%s: %.2f us per launch against %.1f recorded (x%.2f): a spill or a lost overlap?" % (name, t, rec, t / rec)
+
+
+def test_fused_ffn_flavours_hold_their_recorded_times(bufs):
+    b = bufs
+
+    def fwd(i, train):
+        dh = (0.1, b["seed"], 1) if train else None
+        do = (0.1, b["seed"], 2) if train else None
+        K.ffn_fused_fwd(b["xs"][i], b["w1"][i], b["b1"], b["w2"][i], b["b2"], b["y"], act="swish", alpha=0.5, residual=b["xs"][i],
+                        ln=(b["gam"], b["bet"]), x_ln=b["xl"] if train else None, ln_stats=(b["mean"], b["rstd"]) if train else None,
+                        z=b["zs"][i] if train else None, h=b["hs"][i] if train else None, drop_h=dh, drop_o=do, z_tiled_ok=train)
+
+    def bwd(i):
+        K.ffn_fused_bwd(b["dy"], b["w2t"][i], b["w1t"][i], b["zs"][i], b["hs"][i], b["dxn"], act="swish", alpha=0.5,
+                        drop_h=(0.1, b["seed"], 1), z_tiled=True)
+
+    t_eval = _time(lambda i: fwd(i, False))
+    t_train = _time(lambda i: fwd(i, True))
+    t_bwd = _time(bwd)
+    K.ffn_exchange_poll()
+    _check("ffn_eval", t_eval)
+    _check("ffn_train_fwd", t_train)
+    _check("ffn_bwd", t_bwd)
+
+
+def test_row_block_projections_hold_their_recorded_times(bufs):
+    b = bufs
+
+    def qkv(i):
+        K.rowblock_gemm(b["xs"][i], b["wqkv"][i], b["qkv"][i], N=3 * D, ldc=3 * D, bias=b["bqkv"], ln=(b["gam"], b["bet"]),
+                        x_ln=b["xl"], ln_stats=(b["mean"], b["rstd"]))
+
+    def dgrad(i):
+        K.rowblock_dgrad(b["dqkv"][i & 1], b["wqkvt"][i], dxn=b["dxn"])
+
+    _check("qkv_projection", _time(qkv))
+    _check("rowblock_dgrad_k768", _time(dgrad))
