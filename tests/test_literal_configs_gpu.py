@@ -27,7 +27,7 @@ from test_configs_fullsize_gpu import PK_B, PK_T, PK_UHI, PK_ULO, _batch, _Packi
 
 DEV = "cuda"
 V = 10000
-S2T_R6_DECODER_PERM_EXACT = False  # (set once measured: see test_config4_literal_sate_12_6_6_batch_64x1000_properties)
+S2T_R6_DECODER_PERM_EXACT = True  # measured on MI355X (round 6): with one workgroup per FFN row block the permuted decoder logits are bit-exact
 
 
 def test_config2p_full_depth_12_6_bf16_against_oracle_on_rounded_weights():
@@ -168,7 +168,8 @@ def test_config4_literal_sate_12_6_6_batch_64x1000_properties():
     rel = float((pa - pb).norm() / pa.norm())
     agree = float((pa.argmax(-1) == pb.argmax(-1)).float().mean())
     print("config 4, permuted batch, decoder logits in the shipped configuration: relative L2 %.2e, arg-max agreement %.4f" % (rel, agree))
-    assert rel <= 1e-2 and agree >= 0.98, (rel, agree)
+    # measured on MI355X (round 6): relative L2 6.9e-4, arg-max agreement 1.0000
+    assert rel <= 2e-3 and agree >= 0.999, (rel, agree)
     _, old_split, _ = K.ffn_configure()
     K.ffn_configure(split=1)
     try:
@@ -213,9 +214,11 @@ def test_config4_literal_sate_12_6_6_batch_64x1000_properties():
               "decoder logits %s" % tuple("(%.2e, %.4f)" % st for st in stats))
         # the two buffers have different row counts (16 000 / 16 640 rows): GEMM tile boundaries and with them fp32 summation orders may
         # move, so what holds is agreement to bf16 rounding noise through 24 layers (test_extra_padding_in_the_default_configuration)
+        # measured on MI355X (round 6): all three families BIT-EXACT on the frames / target positions (relative L2 0, agreement 1) with one
+        # workgroup per FFN row block; what is asserted leaves room for a GEMM tile boundary that moves with the row count
         for rel, agree in stats:
-            assert rel <= 2e-2, stats
-        assert stats[0][1] >= 0.97 and stats[2][1] >= 0.97, stats
+            assert rel <= 2e-3, stats
+        assert stats[0][1] >= 0.999 and stats[2][1] >= 0.999, stats
         del padded, src, ea, eb, la, lb
     finally:
         K.ffn_configure(split=old)
@@ -324,5 +327,6 @@ def test_config5b_literal_nast_12_12_d512_batch_256x1000_properties():
     rel = float((va - vb).norm() / va.norm())
     agree = float((va.argmax(-1) == vb.argmax(-1)).float().mean())
     print("config 5b 256 x 1000, 40 extra padded frames: xctc logits relative L2 %.5f, frame arg-max agreement %.4f" % (rel, agree))
-    assert rel <= 3e-2, rel
-    assert agree >= 0.95, agree
+    # measured on MI355X (round 6): relative L2 0.00000, agreement 1.0000
+    assert rel <= 2e-3, rel
+    assert agree >= 0.999, agree
