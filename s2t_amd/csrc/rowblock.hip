@@ -1839,13 +1839,26 @@ int64_t pc_slab_bytes(int M, int split) {
   return split == 2 ? P * 2 * 64 * 256 * 4 : (split > 2 ? P * split * PC_RB * 256 * 4 : 0);
 }
 // ... and what the caller gave: the exchange workspace, hidden units in whole chunks per part
-int pc_split(int M, int F, const void* ws, int64_t ws_bytes) {
+// mode 0 eval, 1 training forward, 2 backward.  The training flavours take at most FOUR parts per block unless a split is forced:
+// at the decoder's 3 904 rows (31 blocks) eight parts exchange 8 x 128 KiB of fp32 partial rows per block — 3.2 x the launch's
+// algorithmic bytes — and measure no faster than four (tools/ffn_split_probe.py, MI355X: training forward 30.5 / 29.8 us, backward
+// 29.4 / 27.8 us for 8 / 4 parts; eval 24.6 / 25.3: eval keeps eight).  S2T_FFN_PC_TRAIN_MAX_SPLIT=8 restores round 5's choice.
+int pc_train_max_split() {
+  static const int v = [] {
+    const char* e = getenv("S2T_FFN_PC_TRAIN_MAX_SPLIT");
+    const int n = e ? atoi(e) : 4;
+    return (n == 1 || n == 2 || n == 4 || n == 8) ? n : 4;
+  }();
+  return v;
+}
+int pc_split(int M, int F, const void* ws, int64_t ws_bytes, int mode) {
   // S2T_FFN_PC_SPLIT / s2t_ffn_configure pins (1) or caps (2, 4) the workgroups per block: the forms add the hidden units'
   // products in different orders, so results that must match bit for bit across DIFFERENT row counts need one of them pinned
   const int force = pc_config().split_force;
   if (force == 1 || !ws || ws_bytes < s2t_ffn_pair_ws_bytes(M) || ((uintptr_t)ws % 16) || (F % 128)) return 1;
   int split = pc_split_rows(M);
   while (split > 2 && ((force >= 2 && split > force) || F % (split * 128))) split >>= 1;  // whole pairs of chunks per part
+  if (mode != 0 && force == 0) while (split > 2 && split > pc_train_max_split()) split >>= 1;
   return split;
 }
 // Layout of the exchange workspace: PC_FLAG_BYTES of flags first (split x split words per block for 4 or 8 parts, 2 per block
@@ -1903,7 +1916,7 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
   FfnK k = {};
   static_cast<s2t_ffn_args&>(k) = *a;
   if (train ? pc_train(a) : pc_enabled(0)) {
-    const int split = pc_split(a->M, a->F, a->pair_ws, a->pair_ws_bytes);
+    const int split = pc_split(a->M, a->F, a->pair_ws, a->pair_ws_bytes, train ? 1 : 0);
     k.z_tiled = 1;
     if (split >= 2) {
       k.xws = pc_slabs(a->pair_ws);
@@ -1932,7 +1945,7 @@ extern "C" int s2t_ffn_fused_fwd(const s2t_ffn_args* a, void* stream) {
 namespace {
 int ffn_describe(int mode, int act, bool drop, int M, int F, const void* ws, int64_t ws_bytes, char* buf, int n, bool force_pc = false) {
   if (!buf || n < 96) return S2T_ERR_ARG;
-  if (pc_enabled(mode) || (mode == 2 && force_pc)) snprintf(buf, n, "ffn_pc_kernel<%d, %d, %s, %d>", mode, act, drop ? "true" : "false", pc_split(M, F, ws, ws_bytes));
+  if (pc_enabled(mode) || (mode == 2 && force_pc)) snprintf(buf, n, "ffn_pc_kernel<%d, %d, %s, %d>", mode, act, drop ? "true" : "false", pc_split(M, F, ws, ws_bytes, mode));
   else snprintf(buf, n, "ffn_fused_fwd_kernel<%d, %d, %s>", mode, act, drop ? "true" : "false");
   return S2T_OK;
 }
@@ -2027,7 +2040,7 @@ extern "C" int s2t_ffn_fused_bwd(const s2t_ffn_bwd_args* b, void* stream) {
   const bool drop = a.drop_h_p > 0.f;
   a.z_tiled = b->z_tiled;
   if (pc_enabled(2) || b->z_tiled) {
-    const int split = pc_split(b->M, b->F, b->pair_ws, b->pair_ws_bytes);
+    const int split = pc_split(b->M, b->F, b->pair_ws, b->pair_ws_bytes, 2);
     if (split >= 2) {
       a.xws = pc_slabs(b->pair_ws);
       a.xflags = pc_flags(b->pair_ws);

@@ -210,21 +210,33 @@ _MEMO_PINNED = {}   # key -> [entries whose tensors a captured hipGraph reads]: 
 _UID = [0]
 
 
-def memo_owner(obj):
-    """A process-unique serial for ``obj`` (an encoder, a decoder, a criterion) to key its memos by.  NOT ``id(obj)``: CPython
-    re-uses the id of a collected object, so a model built after another was dropped could land on the dead one's keys (and, with a
-    captured step, on tensors whose addresses that step's graph had baked in).  When ``obj`` is collected its entries go."""
-    uid = getattr(obj, "_s2t_uid", None)
-    if uid is None:
-        import weakref
+_UID_SELF = {}  # uid -> weak reference to the object the serial was made for
 
-        _UID[0] += 1
-        uid = ("uid", _UID[0])
-        try:
-            object.__setattr__(obj, "_s2t_uid", uid)
-            weakref.finalize(obj, _purge_owner, uid)
-        except (AttributeError, TypeError):  # an object without attributes / weak references: the serial cannot stay with it
-            return ("id", id(obj))
+
+def memo_owner(obj):
+    """A process-unique serial for ``obj`` (an encoder, a decoder, a criterion, a trainer) to key its memos by.  NOT ``id(obj)``:
+    CPython re-uses the id of a collected object, so a model built after another was dropped could land on the dead one's keys (and,
+    with a captured step, on tensors whose addresses that step's graph had baked in).  When ``obj`` is collected its entries go.
+    The serial rides in the object's ``__dict__``, which ``copy.deepcopy`` / pickling carry over to the copy (an EMA model): a
+    serial found on an object it was not made for is replaced by a fresh one, so two live owners never share keys (and the
+    original's finalizer never purges the copy's entries)."""
+    import weakref
+
+    uid = getattr(obj, "_s2t_uid", None)
+    if uid is not None:
+        ref = _UID_SELF.get(uid)
+        if ref is not None and ref() is obj:
+            return uid
+        uid = None  # inherited through a copy (or its first owner is gone): this object gets its own
+    _UID[0] += 1
+    uid = ("uid", _UID[0])
+    try:
+        object.__setattr__(obj, "_s2t_uid", uid)
+        _UID_SELF[uid] = weakref.ref(obj)
+        weakref.finalize(obj, _purge_owner, uid)
+    except (AttributeError, TypeError):  # an object without attributes / weak references: the serial cannot stay with it
+        _UID_SELF.pop(uid, None)
+        return ("id", id(obj))
     return uid
 
 
@@ -235,6 +247,7 @@ def _key_has(key, uid):
 
 
 def _purge_owner(uid):
+    _UID_SELF.pop(uid, None)
     for table in (_MEMO, _MEMO_PINNED):
         for key in [k for k in table if _key_has(k, uid)]:
             table.pop(key, None)
@@ -316,8 +329,18 @@ def pin_batch_memos(tensors, owner):
 
 
 def unpin_batch_memos(owner):
+    """Release ``owner``'s pins.  An entry whose key has no newer entry in the table goes BACK there (as the most recent batch of
+    its user) instead of being dropped: a re-capture over the same static batch then finds — and pins — the very tensors its warm-up
+    steps read, where dropping them left the bookkeeping to be recomputed inside the stream capture, in the graph's private
+    pool, unpinned."""
     for key in list(_MEMO_PINNED):
-        keep = [e for e in _MEMO_PINNED[key] if not (len(e) > 4 and e[4] == owner)]
+        keep = []
+        for e in _MEMO_PINNED[key]:
+            if len(e) > 4 and e[4] == owner:
+                if key not in _MEMO:
+                    _MEMO[key] = tuple(e[:4])
+            else:
+                keep.append(e)
         if keep:
             _MEMO_PINNED[key] = keep
         else:

@@ -835,9 +835,11 @@ class CTCDecoder:
         from . import kernels as K
 
         net_input = sample["net_input"]
+        flagged = []
         if self.ctc_inter_logit != 0:  # the intermediate heads are decoded: they emit ctc_out_dtype (fp32 for bit-exact ids)
             for mod in self.model.modules():
                 if hasattr(mod, "inter_ctc_layers") or hasattr(mod, "inter_xctc_layers"):
+                    flagged.append((mod, getattr(mod, "decode_inter_logits", False)))
                     mod.decode_inter_logits = True
         was = Rows.ENABLED
         if self.exact_scores:
@@ -846,6 +848,10 @@ class CTCDecoder:
             enc = self.model(src_tokens=net_input["src_tokens"], src_lengths=net_input["src_lengths"])
         finally:
             Rows.ENABLED = was
+            # the flag is this decode's, not the model's: left set, later training / eval passes of the same model would refuse packed
+            # rows and emit ctc_out_dtype logits from the intermediate heads
+            for mod, old in flagged:
+                mod.decode_inter_logits = old
         has_x = len(enc.get("xctc_logit", [])) > 0
         pk = enc.get("packed")
         if pk is not None and self.ctc_inter_logit == 0:  # packed rows (s2t_amd/rows.py): the decoded head's rows as they are

@@ -134,8 +134,8 @@ class Trainer:
         # the per-batch bookkeeping of THIS batch object (lengths, masks, positions, packed-row geometry: functional.batch_memo)
         # lives outside the graph, which bakes its addresses in: from here on an eager pass over another batch may not replace or
         # release those tensors (it gets entries of its own), load_batch refreshes them in place
-        Fn.unpin_batch_memos(id(self))
-        Fn.pin_batch_memos(list(self._tensors(sample)), id(self))
+        Fn.unpin_batch_memos(Fn.memo_owner(self))
+        Fn.pin_batch_memos(list(self._tensors(sample)), Fn.memo_owner(self))
         self._graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         self._ssg = sample_size_global
@@ -174,13 +174,15 @@ class Trainer:
         self._graph = self._graph2 = None
         self._graph_out = None
         self._static = None
-        Fn.unpin_batch_memos(id(self))
+        Fn.unpin_batch_memos(Fn.memo_owner(self))
         if hasattr(self.model, "release_trainer"):
             self.model.release_trainer()
 
     def __del__(self):
         try:
-            Fn.unpin_batch_memos(id(self))
+            uid = self.__dict__.get("_s2t_uid")
+            if uid is not None:
+                Fn.unpin_batch_memos(uid)
         except Exception:  # noqa: BLE001 — interpreter shutdown
             pass
 
