@@ -61,6 +61,12 @@ namespace {
 // The LayerNorm-backward reductions of MODE 2 keep the LDS-crossbar form (__shfl_xor): with the DPP form (csrc/common.h) hipcc
 // spills five registers INSIDE the consumers' chunk loop (scratch loads there make the compiler wait for the DMA stream:
 // 72 -> 106 us per launch); S2T_PC_BWD_DPP=1 selects the DPP form for a newer compiler to try
+#ifndef S2T_PC_XCHG_SC1
+#define S2T_PC_XCHG_SC1 1  // the partial-row exchange reads the partners' slabs with sc1 loads (L2-served, past this CU's L1) instead of
+#endif                     // an agent-scope acquire (buffer_inv sc1 + the wait for it: ~1.7 us per launch) followed by plain loads: MI355X_MICROARCH.md,
+                           // "Valid forms", first row of the sc1 table — every byte stored sc1 and drained, ONE lane's sc1 flag store behind the
+                           // workgroup barrier, an sc1 poll, the other waves behind a barrier the polling wave joins, 16-byte sc1 loads, one
+                           // workgroup per CU (160 KiB of LDS), torch's (hipMalloc) memory.  0: round 5's acquire + plain loads.
 #ifndef S2T_PC_BWD_DPP
 #define S2T_PC_BWD_DPP 0
 #endif
@@ -811,6 +817,9 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
   // acquire drops this CU's stale lines, then plain loads (cdna_hip_programming.md, Guideline 16, R1).  Flags are zero
   // between launches: the reader of a flag clears it.
   f32x4 peer[NPS][2];
+  // (the four-part backward flavour keeps the acquire form: with the descriptor loads hipcc moves three fragment registers of its
+  // chunk loop to scratch — tools/spill_sites.sh)
+  constexpr bool XSC1 = S2T_PC_XCHG_SC1 != 0 && !(BWD && SPLIT == 4);
   if constexpr (SPLIT == 2) {
     {
       float* slab = p.xws + (size_t)(pair * 2 + half) * (64 * 256);
@@ -845,18 +854,28 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!XSC1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       if (lane == 0) __hip_atomic_store(pfl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     PSTAMP(6);
     const float* pslab = p.xws + (size_t)(pair * 2 + (1 - half)) * (64 * 256);
+    const __amdgpu_buffer_rsrc_t ps_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pslab), 0, 64 * 256 * 4, 0x00020000);
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       const int rr = (KR / 8) * wave + 2 * ps + hi;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) peer[ps][q] = *reinterpret_cast<const f32x4*>(pslab + rr * 256 + 128 * q + 4 * s);
+      for (int q = 0; q < 2; ++q) {
+        if constexpr (XSC1) {
+          const u32x4s t = __builtin_amdgcn_raw_buffer_load_b128(ps_rs, (uint32_t)((rr * 256 + 128 * q + 4 * s) * 4), 0, 16 /* sc1 */);
+          peer[ps][q] = __builtin_bit_cast(f32x4, t);
+        } else {
+          peer[ps][q] = *reinterpret_cast<const f32x4*>(pslab + rr * 256 + 128 * q + 4 * s);
+        }
+      }
     }
   }
   // ---- SPLIT > 2 (few rows: the decoder's 3 904 on 8 x 31 workgroups): every workgroup leaves ALL the rows it does not finish
@@ -896,8 +915,10 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!XSC1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       if (mine) __hip_atomic_store(pfl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -909,11 +930,19 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
     for (int src = 0; src < SPLIT; ++src) {
       if (src == half) continue;
       const float* pslab = p.xws + (size_t)(pair * SPLIT + src) * (RB * 256);
+      const __amdgpu_buffer_rsrc_t ps_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pslab), 0, RB * 256 * 4, 0x00020000);
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
         const int ml = krow0 + (KR / 8) * wave + 2 * ps + hi;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) peer[ps][q] += *reinterpret_cast<const f32x4*>(pslab + ml * 256 + 128 * q + 4 * s);
+        for (int q = 0; q < 2; ++q) {
+          if constexpr (XSC1) {
+            const u32x4s t = __builtin_amdgcn_raw_buffer_load_b128(ps_rs, (uint32_t)((ml * 256 + 128 * q + 4 * s) * 4), 0, 16 /* sc1 */);
+            peer[ps][q] += __builtin_bit_cast(f32x4, t);
+          } else {
+            peer[ps][q] += *reinterpret_cast<const f32x4*>(pslab + ml * 256 + 128 * q + 4 * s);
+          }
+        }
       }
     }
   }

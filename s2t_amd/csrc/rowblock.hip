@@ -1839,15 +1839,17 @@ int64_t pc_slab_bytes(int M, int split) {
   return split == 2 ? P * 2 * 64 * 256 * 4 : (split > 2 ? P * split * PC_RB * 256 * 4 : 0);
 }
 // ... and what the caller gave: the exchange workspace, hidden units in whole chunks per part
-// mode 0 eval, 1 training forward, 2 backward.  The training flavours take at most FOUR parts per block unless a split is forced:
-// at the decoder's 3 904 rows (31 blocks) eight parts exchange 8 x 128 KiB of fp32 partial rows per block — 3.2 x the launch's
-// algorithmic bytes — and measure no faster than four (tools/ffn_split_probe.py, MI355X: training forward 30.5 / 29.8 us, backward
-// 29.4 / 27.8 us for 8 / 4 parts; eval 24.6 / 25.3: eval keeps eight).  S2T_FFN_PC_TRAIN_MAX_SPLIT=8 restores round 5's choice.
+// mode 0 eval, 1 training forward, 2 backward.  S2T_FFN_PC_TRAIN_MAX_SPLIT caps the parts per block of the training flavours
+// (default 8: no cap).  Round 6 measured the cap at four: at the decoder's 3 904 rows (31 blocks) eight parts exchange 8 x 128 KiB of
+// fp32 partial rows per block — 3.2 x the launch's algorithmic bytes — and the ISOLATED kernels are as fast or faster with four
+// (tools/ffn_split_probe.py, MI355X: training forward 30.5 / 29.8 us, backward 29.4 / 27.8 us for 8 / 4 parts; eval 24.6 / 25.3),
+// but the STEP is slower with four: 10.52 / 10.53 / 10.50 ms against 10.46 / 10.44 / 10.43 with eight (tools/ab_env.sh, three
+// alternations on one box) — so eight stays.
 int pc_train_max_split() {
   static const int v = [] {
     const char* e = getenv("S2T_FFN_PC_TRAIN_MAX_SPLIT");
-    const int n = e ? atoi(e) : 4;
-    return (n == 1 || n == 2 || n == 4 || n == 8) ? n : 4;
+    const int n = e ? atoi(e) : 8;
+    return (n == 1 || n == 2 || n == 4 || n == 8) ? n : 8;
   }();
   return v;
 }

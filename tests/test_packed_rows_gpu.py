@@ -526,8 +526,8 @@ def test_captured_steps_survive_eager_passes_and_a_second_trainer():
 
     with _layout(True):
         a, tr_a, m_a = run(0, disturb=True)
-        assert any(len(e) > 4 and e[4] == id(tr_a) for lst in Fn._MEMO_PINNED.values() for e in lst)  # something IS pinned
-        owner_a = id(tr_a)
+        assert any(len(e) > 4 and e[4] == Fn.memo_owner(tr_a) for lst in Fn._MEMO_PINNED.values() for e in lst)  # something IS pinned
+        owner_a = Fn.memo_owner(tr_a)
         tr_a.release()
         del tr_a, m_a
         gc.collect()

@@ -48,7 +48,7 @@ constexpr int D = 256, TM = 64, CW = 128;
 constexpr int STAGE = CW * 512;            // 64 KiB: one chunk of W
 constexpr int L_W = 0;                     // two stages
 constexpr int L_OUT = 2 * STAGE;           // bf16 tile [64 rows][256 B] (16 KiB); the prologue's X image (32 KiB) starts here too
-constexpr int L_BIAS = L_OUT + 16384;      // fp32 bias[N], N <= 1024 (written after the X image is dead)
+constexpr int L_BIAS = L_OUT + 16384;      // fp32 bias[N], N <= 4096 (written after the X image is dead)
 constexpr int L_BYTES = L_OUT + 32768;     // 160 KiB
 
 struct Args {
@@ -65,7 +65,7 @@ __device__ __forceinline__ void wait_vm_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory");
 }
 
-template <int ROLES>
+template <int ROLES, int STORE = 1>
 __global__ __launch_bounds__(512, 2) void rowpanel_kernel(const Args p) {
   __shared__ __attribute__((aligned(16))) char smem[L_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,9 +152,9 @@ __global__ __launch_bounds__(512, 2) void rowpanel_kernel(const Args p) {
     // chunk c has landed (issued two iterations ago; what may stay in flight: the stores of the last two read-outs and DMA(c + 1))
     if (c >= 2) {
       if (!ROLES) {
-        if (c + 1 < NC) wait_vm_barrier<12>(); else wait_vm_barrier<4>();
+        if (c + 1 < NC) wait_vm_barrier<STORE ? 12 : 8>(); else wait_vm_barrier<STORE ? 4 : 0>();
       } else {
-        if (loader) { if (c + 1 < NC) wait_vm_barrier<24>(); else wait_vm_barrier<8>(); }   // 16 pieces of DMA(c + 1) + 2 read-outs x 4 stores
+        if (loader) { if (c + 1 < NC) wait_vm_barrier<STORE ? 24 : 16>(); else wait_vm_barrier<STORE ? 8 : 0>(); }   // 16 pieces of DMA(c + 1) + 2 read-outs x 4 stores
         else asm volatile("s_barrier" ::: "memory");
       }
     } else {
@@ -210,8 +210,12 @@ __global__ __launch_bounds__(512, 2) void rowpanel_kernel(const Args p) {
           const int n0 = c * CW + 8 * ej;
           const uint32_t o0 = (m < M && n0 < N) ? ((uint32_t)m * (uint32_t)N + (uint32_t)n0) * 2u : 0x80000000u;
           const uint32_t o1 = (m < M && n0 + 64 < N) ? o0 + 128u : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128((u32x4){v0.x, v0.y, v0.z, v0.w}, osrd, o0, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128((u32x4){v1.x, v1.y, v1.z, v1.w}, osrd, o1, 0, 0);
+          if constexpr (STORE) {
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){v0.x, v0.y, v0.z, v0.w}, osrd, o0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){v1.x, v1.y, v1.z, v1.w}, osrd, o1, 0, 0);
+          } else {
+            asm volatile("" ::"v"(v0.x), "v"(v1.x), "v"(o0), "v"(o1));   // (the intermediate stays on the chip: what a fused layer kernel would do)
+          }
         }
       }
     }
@@ -232,13 +236,13 @@ static uint16_t f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
-template <int ROLES>
+template <int ROLES, int STORE = 1>
 static void run(int M, int N, int nsets, const std::vector<uint16_t*>& xs, const std::vector<uint16_t*>& ws, float* bias, const std::vector<uint16_t*>& ys,
                 unsigned long long* dcyc, const std::vector<uint16_t>& hx, const std::vector<uint16_t>& hw, const std::vector<float>& hb) {
   const int blocks = (M + TM - 1) / TM;
   Args a{xs[0], ws[0], bias, ys[0], M, N, dcyc};
   hipMemset(ys[0], 0, (size_t)M * N * 2);
-  hipLaunchKernelGGL((rowpanel_kernel<ROLES>), dim3(blocks), dim3(512), 0, 0, a);
+  hipLaunchKernelGGL((rowpanel_kernel<ROLES, STORE>), dim3(blocks), dim3(512), 0, 0, a);
   hipDeviceSynchronize();
   // check sampled rows against fp64 (set 0 holds the host copies)
   std::vector<uint16_t> hy((size_t)M * N);
@@ -262,7 +266,7 @@ static void run(int M, int N, int nsets, const std::vector<uint16_t*>& xs, const
     for (int r = 0; r < rounds; ++r)
       for (int i = 0; i < nsets; ++i) {
         Args b{xs[i], ws[i], bias, ys[i], M, N, nullptr};
-        hipLaunchKernelGGL((rowpanel_kernel<ROLES>), dim3(blocks), dim3(512), 0, 0, b);
+        hipLaunchKernelGGL((rowpanel_kernel<ROLES, STORE>), dim3(blocks), dim3(512), 0, 0, b);
       }
     hipEventRecord(e1);
     hipDeviceSynchronize();
@@ -274,15 +278,16 @@ static void run(int M, int N, int nsets, const std::vector<uint16_t*>& xs, const
   hipMemcpy(h.data(), dcyc, blocks * 8, hipMemcpyDeviceToHost);
   std::sort(h.begin(), h.end());
   const double flop = 2.0 * M * N * D, bytes = 2.0 * ((double)M * D + (double)M * N + (double)N * D);
-  printf("rowpanel roles=%d  M %5d N %4d: %6.2f us per launch  (%5.1f TFLOP/s, %4.2f TB/s algorithmic)  in-kernel clocks median %llu max %llu   worst rel err %.2e %s\n",
-         ROLES, M, N, best, flop / best * 1e-6, bytes / best * 1e-6, h[blocks / 2], h[blocks - 1], worst, worst < 2e-2 ? "ok" : "MISMATCH");
+  if (!STORE) worst = 0;
+  printf("rowpanel roles=%d store=%d  M %5d N %4d: %6.2f us per launch  (%5.1f TFLOP/s, %4.2f TB/s algorithmic)  in-kernel clocks median %llu max %llu   worst rel err %.2e %s\n",
+         ROLES, STORE, M, N, best, flop / best * 1e-6, bytes / best * 1e-6, h[blocks / 2], h[blocks - 1], worst, worst < 2e-2 ? "ok" : "MISMATCH");
   fflush(stdout);
 }
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 16000;
   const int nsets = 6;
-  const int NMAX = 1024;
+  const int NMAX = 4096;
   std::vector<uint16_t> hx((size_t)M * D), hw((size_t)NMAX * D);
   std::vector<float> hb(NMAX);
   srand(1);
@@ -305,6 +310,13 @@ int main(int argc, char** argv) {
   for (int N : {256, 512, 768, 1024}) {
     run<0>(M, N, nsets, xs, ws, bias, ys, dcyc, hx, hw, hb);
     run<1>(M, N, nsets, xs, ws, bias, ys, dcyc, hx, hw, hb);
+  }
+  // the same loops with the output tile left in LDS (no HBM write): the rate at which a 64-row block can pull K = 256 weight
+  // panels through LDS-DMA and multiply them — what a layer-resident kernel's projections would run at.  N = 4096 = 32 chunks
+  // (2 MiB of W per workgroup: one FFN's worth) isolates the steady state from the prologue.
+  for (int N : {1024, 4096}) {
+    run<0, 0>(M, N, nsets, xs, ws, bias, ys, dcyc, hx, hw, hb);
+    run<1, 0>(M, N, nsets, xs, ws, bias, ys, dcyc, hx, hw, hb);
   }
   return 0;
 }
