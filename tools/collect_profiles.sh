@@ -39,5 +39,19 @@ echo "step 6 done" >&2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3 -- python3 tools/run_configs.py 3 > $out/${tag}_config3.log 2>&1 || exit 1
 cp $(ls $out/c3/*/*kernel_stats.csv | head -1) $out/${tag}_config3_kernel_stats.csv
 echo "step 7 done" >&2
-rm -rf $out/k $out/e $out/pf $out/pw $out/ps $out/d $out/pg $out/c5 $out/c3
+# 8. encoder forward at 4 x the batch (256 x 1000): the same kernels with 3.2 rounds of workgroups (speed-of-light table, tools/sol_table.py)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/e4 -- python3 tools/enc_fwd_profile.py 5 256 > $out/enc256.log 2>&1 || exit 1
+cp $(ls $out/e4/*/*kernel_stats.csv | head -1) $out/${tag}_encoder_fwd_b256_kernel_stats.csv
+python3 tools/sol_table.py $out/${tag}_encoder_fwd_kernel_stats.csv $(grep -o "([0-9]* frames)" $out/enc.log | tr -dc 0-9) \
+    $out/${tag}_encoder_fwd_b256_kernel_stats.csv $(grep -o "([0-9]* frames)" $out/enc256.log | tr -dc 0-9) > $out/${tag}_sol_table.md 2> $out/sol.err
+echo "step 8 done" >&2
+# 9. launches per captured replay that are not this library's kernels (copyBuffer / fillBuffer / ATen), by differencing two traces
+tools/copybuffer_per_replay.sh $out/copybuf > $out/${tag}_aten_per_replay.txt 2>&1 || exit 1
+echo "step 9 done" >&2
+# 10. the row-panel projection prototype (tools/ubench/rowpanel_proj.hip) beside the shipped kernel, every configuration's timing
+timeout -k 10 200 tools/ubench/rowpanel_proj > $out/${tag}_rowpanel_proto.txt 2>&1
+python3 tools/rb_proj_times.py >> $out/${tag}_rowpanel_proto.txt 2>&1
+python3 tools/run_configs.py 1 2 2p 3 4 5a 5b > $out/${tag}_configs.log 2>&1
+echo "step 10 done" >&2
+rm -rf $out/k $out/e $out/pf $out/pw $out/ps $out/d $out/pg $out/c5 $out/c3 $out/e4 $out/copybuf
 ls -la $out
