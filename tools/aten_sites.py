@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where the ATen kernels of a training step come from: every aten op on >= 1000 elements with the s2t_amd frames that issued it
-(TorchDispatchMode; the profiler on this image returns no Python stacks)."""
+"""Where the ATen kernels of a training step come from: every aten op on >= MIN elements (argv[1], default 1000; 1 lists every op that
+launches a kernel, the 4-byte fills included) with the s2t_amd frames that issued it (TorchDispatchMode; the profiler on this image
+returns no Python stacks)."""
 import os, sys, traceback, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -15,6 +16,7 @@ sample, frames = bench.synthetic_batch(64, 1000, V, 1, dev)
 for _ in range(3): tr.train_step(sample)
 torch.cuda.synchronize()
 seen = collections.Counter()
+MIN = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 SKIP = ("aten.view", "aten._unsafe_view", "aten.detach", "aten.alias", "aten.as_strided", "aten.t.", "aten.transpose", "aten.select.", "aten.slice.", "aten.unsqueeze",
         "aten.squeeze", "aten.expand", "aten.permute", "aten.reshape", "aten.empty", "aten.new_empty", "aten.unbind", "aten.split", "aten._local_scalar")
 class Spy(TorchDispatchMode):
@@ -24,7 +26,7 @@ class Spy(TorchDispatchMode):
         if not name.startswith(SKIP):
             ts = [a for a in list(args) + [out] if torch.is_tensor(a) and a.is_cuda]
             n = max([t.numel() for t in ts], default=0)
-            if n >= 1000:
+            if n >= MIN:
                 st = [f"{os.path.basename(f.filename)}:{f.lineno}:{f.name}" for f in traceback.extract_stack() if "s2t_amd" in f.filename][-3:]
                 seen[(name, tuple(ts[0].shape) if ts else (), " <- ".join(reversed(st)))] += 1
         return out
