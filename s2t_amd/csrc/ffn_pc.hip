@@ -40,6 +40,9 @@
 #ifndef S2T_PC_PIECE_ORDER
 #define S2T_PC_PIECE_ORDER 0  // consumers' LDS-DMA pieces: 0 in front of each pair of MFMAs, 1 behind them with the LDS queue drained
 #endif
+#ifndef S2T_PC_BURST_AT
+#define S2T_PC_BURST_AT -1  // experiment (round 6, tools/ubench/stream_mfma.hip): the consumers' 16 LDS-DMA pieces of a chunk as ONE burst in
+#endif                      // front of MFMA pair BURST_AT (0 .. 12) instead of dealt over the first thirteen pairs (-1)
 #ifndef S2T_PC_SAVE_AUX
 #define S2T_PC_SAVE_AUX 2  // cache policy of the training saves (z, h / dZ): 0 default, 2 non-temporal.  They are written once and
 #endif                     // read by the backward pass a whole model later; left to the default policy they push the weights (which every
@@ -697,7 +700,11 @@ __global__ __launch_bounds__(512, 2) void ffn_pc_kernel(const FfnK p) {
         // queues behind the other waves' at the memory pipe and parks this wave, MFMAs unissued, for over a hundred cycles a
         // piece); the saves of groups 6 and 7 follow the last piece
         const int k = 2 * nt + half;       // pair 0 .. 15
+#if S2T_PC_BURST_AT >= 0
+        const int p0 = k == S2T_PC_BURST_AT ? 0 : 16, p1 = 16;
+#else
         const int p0 = k < 3 ? 2 * k : k + 3, p1 = k < 3 ? 2 * k + 2 : k + 4;   // pieces p0 .. p1-1 of 16
+#endif
 #pragma unroll
         for (int q = p0; q < p1 && q < 16; ++q) {
           if (q < 8) { if (more) dma_w1(c + 1, q, q + 1); }

@@ -1335,7 +1335,7 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
       *reinterpret_cast<f32x4*>(tile + r * 256 + 16 * ((4 * q + g) ^ x)) = acc[mt];  // r & 15 == x
     }
   };
-  auto emit = [&](int c, const uint4 rres) __attribute__((always_inline)) -> uint4 {
+  auto emit = [&](int c, const uint4 rres, auto&& pre_store) __attribute__((always_inline)) -> uint4 {
     const char* tile = smem + PJ_TILE + (c & 1) * 16384;
     const int r = er, j = ej, m = em;
     auto ld8t = [&](int j8, float (&v)[8]) __attribute__((always_inline)) {
@@ -1359,6 +1359,7 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
       add_bias(n0c, v);
       add_bias(nout + n0c, gt);
       if (Z) {
+        pre_store();
         const uint32_t zo = live ? ((uint32_t)m * (uint32_t)p.ldp + (uint32_t)n0) * 2u : DROPPED;
         bst8(zsrd, zo, v, S2T_RB_SAVE_NT);
         bst8(zsrd, live ? zo + (uint32_t)nout * 2u : DROPPED, gt, S2T_RB_SAVE_NT);
@@ -1389,8 +1390,10 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
         v[2 * k + 1] += __uint_as_float(w4[k] & 0xffff0000u);
       }
     }
+    if (!(GLU && Z)) pre_store();
     return bst8(osrd, live ? ((uint32_t)m * (uint32_t)p.ldc + (uint32_t)n0) * 2u : DROPPED, v, 0);
   };
+  auto nothing = []() __attribute__((always_inline)) {};
   const int nst = 1 + ((GLU && Z) ? 2 : 0);   // store instructions of one read-out (every wave, see above)
   auto wait_vm = [&](int n) __attribute__((always_inline)) {   // s_waitcnt vmcnt(n) lgkmcnt(0) + barrier, n uniform
     switch (n) {
@@ -1411,24 +1414,37 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
     const bool more = c + 2 < nchunks;
     uint4 af[8];
     read_a(c, af);
-#if S2T_RBG_ORDER
+#if S2T_RBG_ORDER == 1
 #if !(S2T_RB_DBG & 1)
     if (more) issue(c + 2);
 #endif
+#endif
+#if S2T_RBG_ORDER == 2
+    // the DMA of chunk c + 2 goes out INSIDE the read-out, in front of its first store (still DMA before stores: the counted
+    // wait below is unchanged) — behind the read-out's LDS reads and arithmetic instead of beside the fragment reads just
+    // requested: a piece issued with LDS reads in flight parks the wave 100 - 185 clocks, one in a vector-only stretch 25 - 60
+    // (MI355X_MICROARCH.md; tools/ubench/stream_mfma.hip: "burst mid-step" against "burst")
+    if (c == 0 && more) issue(c + 2);
+#endif
+#if S2T_RBG_ORDER
 #if S2T_RBG_SKEW
     // the two waves of a SIMD (w and w + 4) take the read-out and the product in opposite orders: in the same order both sit
     // in vector arithmetic at the same time and then both queue at the matrix pipe
     if (wave < 4) {
-      if (c > 0) emit(c - 1, rres);
+      if (c > 0) emit(c - 1, rres, nothing);
       mma_store(c, af);
     } else {
       mma_store(c, af);
-      if (c > 0) emit(c - 1, rres);
+      if (c > 0) emit(c - 1, rres, nothing);
     }
 #else
 #if !(S2T_RB_DBG & 4)
     if (c > 0) {
-      const uint4 kp = emit(c - 1, rres);
+#if S2T_RBG_ORDER == 2
+      const uint4 kp = emit(c - 1, rres, [&]() __attribute__((always_inline)) { if (more) issue(c + 2); });
+#else
+      const uint4 kp = emit(c - 1, rres, nothing);
+#endif
       if constexpr (KEEP) keep[(c - 1) & 3] = kp;
     }
 #endif
@@ -1437,7 +1453,7 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
     if (c + 1 < nchunks) wait_vm((c >= 2 ? nst : 0) + (more ? 4 : 0) + (c >= 1 ? nst : 0));
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-    if (c > 0) emit(c - 1, rres);
+    if (c > 0) emit(c - 1, rres, nothing);
     if (more) issue(c + 2);
     mma_store(c, af);
     if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1448,11 +1464,11 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
   if (res4 || KEEP) {   // (KEEP: N = 256, checked at the entry point; without a residual the pieces are zero)
 #pragma unroll
     for (int c = 0; c < 4; ++c) step(c, rp[c > 0 ? c - 1 : 0]);
-    const uint4 kp = emit(3, rp[3]);
+    const uint4 kp = emit(3, rp[3], nothing);
     if constexpr (KEEP) keep[3] = kp;
   } else if (!R) {
     for (int c = 0; c < nchunks; ++c) step(c, make_uint4(0, 0, 0, 0));
-    emit(nchunks - 1, make_uint4(0, 0, 0, 0));
+    emit(nchunks - 1, make_uint4(0, 0, 0, 0), nothing);
   } else {
     // (a wait for the residual load also waits for the OLDER DMAs of chunk c+1, which have had an iteration; the DMAs of chunk
     // c+2 are issued behind the read-out, so no compiler-inserted wait ever covers them)
@@ -1461,13 +1477,13 @@ __device__ __forceinline__ void rb_body(const s2t_rowblock_args& p, char* smem, 
       const uint4 rres = c > 0 ? res_load(c - 1) : make_uint4(0, 0, 0, 0);
       uint4 af[8];
       read_a(c, af);
-      if (c > 0) emit(c - 1, rres);
+      if (c > 0) emit(c - 1, rres, nothing);
       if (more) issue(c + 2);
       mma_store(c, af);
       if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    emit(nchunks - 1, res_load(nchunks - 1));
+    emit(nchunks - 1, res_load(nchunks - 1), nothing);
   }
 #if S2T_RB_DBG & 64
   RBG_STAMP(28);
