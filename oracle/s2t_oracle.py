@@ -8,7 +8,11 @@ package ``s2t_amd`` never imports it and has no CPU fallback.
 Pinning: every function here is checked against golden vectors dumped from the reference itself
 (``oracle/gen_golden.py`` -> ``tests/golden/*.npz``) by ``tests/test_oracle_golden.py`` — EXCEPT ``kaldi_fbank``
 (row a1): the reference delegates it to torchaudio.compliance.kaldi.fbank, a third-party dependency that is neither in
-/root/reference nor in this image, so that function restates torchaudio's published algorithm and its PARITY IS UNPINNED.
+/root/reference nor in this image, so that function restates torchaudio's published algorithm and its PARITY IS UNPINNED
+against the reference.  Since round 6 it is cross-checked against an INDEPENDENT restatement of the same call — Hugging Face
+transformers' Speech2TextFeatureExtractor (the port of this fairseq front-end; its numpy path for machines without torchaudio),
+run here by oracle/gen_golden_fbank.py into tests/golden/fbank_hf_speech2text.npz: agreement to 1e-6 absolute on log-mel values
+(tests/test_frontend.py).  Two third-party-independent restatements agreeing is evidence, not a pin to the reference.
 
 All tensors are batch-major ``(B, T, C)`` inside the oracle; the reference is time-major between
 modules (``(T, B, C)``), so boundary outputs are transposed back where the reference returns them.

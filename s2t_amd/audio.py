@@ -3,7 +3,8 @@
 Reference seam (paths relative to /root/reference/fairseq):
   * ``data/audio/audio_utils.py:59-79`` ``_get_torchaudio_fbank(waveform, sample_rate, n_bins=80)`` — waveform in int16
     range (``:31-32``), delegated to ``torchaudio.compliance.kaldi.fbank`` with its defaults.  torchaudio is third-party
-    and absent from the reference tree and from this image: the kernel follows its published algorithm, parity unpinned.
+    and absent from the reference tree and from this image: the kernel follows its published algorithm; parity is unpinned against
+    the reference and cross-checked against Hugging Face's independent port of the same call (tests/golden/fbank_hf_speech2text.npz).
   * ``data/audio/feature_transforms/utterance_cmvn.py`` ``UtteranceCMVN`` (``from_config_dict`` / ``__call__``), registered as
     ``utterance_cmvn`` (``feature_transforms/__init__.py:18-36``).
 

@@ -1,8 +1,11 @@
 """Feature front-end.
 
-CPU: properties of the oracle's Kaldi-fbank restatement (a1 is third-party in the reference: parity unpinned, so the
-oracle is anchored on the algorithm's own invariants) and the CMVN oracle against the reference's formula.
-GPU: ``s2t_fbank`` / ``s2t_utterance_cmvn`` through the C-ABI against the oracle."""
+CPU: properties of the oracle's Kaldi-fbank restatement (a1 is third-party in the reference: torchaudio, absent here and
+unpinned there, so the oracle cannot be pinned to the reference itself: it is anchored on the algorithm's own invariants and,
+since round 6, cross-checked against an INDEPENDENT restatement of the same call — Hugging Face's Speech2TextFeatureExtractor,
+the port of this very fairseq front-end, through tests/golden/fbank_hf_speech2text.npz, made by oracle/gen_golden_fbank.py) and
+the CMVN oracle against the reference's formula.
+GPU: ``s2t_fbank`` / ``s2t_utterance_cmvn`` through the C-ABI against the oracle and against that fixture."""
 import numpy as np
 import pytest
 import torch
@@ -38,6 +41,26 @@ def test_oracle_fbank_tone_lands_in_its_mel_bin_and_dc_is_removed():
     np.testing.assert_allclose(O.kaldi_fbank(w + 5000.0), O.kaldi_fbank(w), atol=1e-6)  # remove_dc_offset
     # energies scale quadratically with the amplitude: +2 log 2 per doubling
     np.testing.assert_allclose(O.kaldi_fbank(2 * w)[:, 20:40], O.kaldi_fbank(w)[:, 20:40] + 2 * np.log(2.0), atol=1e-6)
+
+
+def test_oracle_fbank_agrees_with_the_hf_speech2text_port(golden_dir):
+    """Two independent restatements of torchaudio.compliance.kaldi.fbank(wave * 2**15, num_mel_bins=80, sample_frequency=16000)
+    (fairseq/data/audio/audio_utils.py:59-79): the oracle's float64 numpy and transformers' float32 numpy (the fixture).  Log-mel
+    values of magnitude up to 25: they agree to float32 rounding."""
+    import os
+
+    z = np.load(os.path.join(golden_dir, "fbank_hf_speech2text.npz"))
+    n = 0
+    for k in z.files:
+        if not k.startswith("in::wave"):
+            continue
+        w = z[k].astype(np.float64) * 2.0 ** 15
+        ref = z["out::fbank" + k[len("in::wave"):]]
+        got = O.kaldi_fbank(w)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=5e-6)
+        n += 1
+    assert n == 5
 
 
 def test_oracle_mel_banks_partition():
@@ -82,6 +105,25 @@ def test_fbank_kernel_matches_oracle():
         assert np.abs(got[T:]).max(initial=0.0) == 0.0  # collater padding
     single = A.get_torchaudio_fbank(waves[1].cpu().numpy(), 16000, n_bins=80)
     np.testing.assert_allclose(single, feat[1, :75].cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_fbank_kernel_matches_the_hf_speech2text_fixture(golden_dir):
+    """s2t_fbank against the independent restatement's vectors (see the module docstring): fp32 FFT and mel accumulation on the
+    GPU against transformers' float32 numpy: 2e-3 absolute on log-mel values (the bound of the oracle comparison above)."""
+    import os
+
+    from s2t_amd import audio as A
+
+    z = np.load(os.path.join(golden_dir, "fbank_hf_speech2text.npz"))
+    names = sorted(k for k in z.files if k.startswith("in::wave"))
+    waves = [torch.from_numpy(z[k] * np.float32(2.0 ** 15)).cuda() for k in names]
+    feat, n_frames = A.fbank_batch(waves, sample_rate=16000, n_bins=80)
+    torch.cuda.synchronize()
+    for i, k in enumerate(names):
+        ref = z["out::fbank" + k[len("in::wave"):]]
+        assert int(n_frames[i]) == ref.shape[0]
+        np.testing.assert_allclose(feat[i, :ref.shape[0]].cpu().numpy(), ref, rtol=0, atol=2e-3)
 
 
 @pytest.mark.gpu
