@@ -138,3 +138,58 @@ def test_position_tables_match_oracle():
     from s2t_amd.modules import rel_pos_table, sinusoidal_table
     assert torch.equal(sinusoidal_table(50, 32), O.sinusoidal_table(50, 32))
     assert torch.equal(rel_pos_table(13, 32), O.rel_pos_table(13, 32))
+
+
+def test_batch_memo_refresh_cascades_and_owners_of_copies_are_distinct():
+    """functional.batch_memo on CPU tensors (no launch involved): (1) a memo computed from ANOTHER memo's outputs is refreshed in the
+    same sweep when the root's contents change in place (the cascade of ADVICE round 5; the case that needs it — outputs written
+    through raw addresses by the one-launch forms, whose version counters never move — exists on the GPU only:
+    tests/test_packed_rows_gpu.py::test_an_eager_pass_over_a_batch_overwritten_in_place_sees_the_new_batch); (2) an unpinned entry
+    whose outputs change shape is recomputed afresh; (3) a deep copy of an owner gets a serial of its own; (4) unpinning hands an
+    entry back when no newer one exists."""
+    import copy
+
+    from s2t_amd import functional as Fn
+
+    class Owner:
+        pass
+
+    own = Owner()
+    root = torch.tensor([3, 5, 7])
+
+    def lens(r):
+        return (r * 2,)
+
+    def total(l):
+        return (l.sum().reshape(1),)
+
+    k1, k2 = ("t_lens", Fn.memo_owner(own)), ("t_total", Fn.memo_owner(own))
+    (l,) = Fn.batch_memo(k1, (root,), lens)
+    (t,) = Fn.batch_memo(k2, (l,), total)
+    assert int(t) == 30
+    root.copy_(torch.tensor([1, 1, 1]))       # the batch overwritten in place
+    (l2,) = Fn.batch_memo(k1, (root,), lens)  # first memo of the pass notices the moved version ...
+    assert l2 is l and l.tolist() == [2, 2, 2]
+    (t2,) = Fn.batch_memo(k2, (l,), total)    # ... and the dependent one was refreshed in the same sweep
+    assert t2 is t and int(t) == 6, int(t)
+    # (2) a shape change of an unpinned entry
+    def ragged(r):
+        return (torch.arange(int(r.sum())),)
+    k3 = ("t_ragged", Fn.memo_owner(own))
+    (a,) = Fn.batch_memo(k3, (root,), ragged)
+    assert a.numel() == 3
+    root.copy_(torch.tensor([2, 2, 2]))
+    (b,) = Fn.batch_memo(k3, (root,), ragged)
+    assert b.numel() == 6
+    # (3) a copied owner does not share the original's keys
+    twin = copy.deepcopy(own)
+    assert Fn.memo_owner(twin) != Fn.memo_owner(own) and Fn.memo_owner(own) == k1[1]
+    # (4) pin, then unpin: the entry is back in the table (a re-capture over the same batch finds it)
+    Fn.pin_batch_memos([root], ("test-owner",))
+    assert k1 in Fn._MEMO_PINNED and k1 not in Fn._MEMO
+    Fn.unpin_batch_memos(("test-owner",))
+    assert k1 in Fn._MEMO and k1 not in Fn._MEMO_PINNED
+    (l3,) = Fn.batch_memo(k1, (root,), lens)
+    assert l3 is l
+    for k in (k1, k2, k3):
+        Fn._MEMO.pop(k, None)
