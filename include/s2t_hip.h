@@ -457,6 +457,16 @@ int s2t_bn_act_bwd(int dtype, const void* D, const void* dOut, void* dD, const f
 int s2t_argmax_lse(int dtype, const void* logits, int64_t ld, int64_t rows, int V, int32_t* idx, float* top_lp,
                    float* lse, const int32_t* live /* optional device scalar: only rows < *live (a packed batch's live rows) */,
                    void* stream);
+/* CTC head + greedy arg-max in one launch for d = 256 (csrc/ctc_head.hip): idx[r] = first arg-max of x[r] . w^T + bias over the V
+ * vocabulary entries, top_lp[r] = its log-probability (max - logsumexp), lse[r] = the logsumexp; fp32 accumulation of the bf16
+ * products, fp32 bias — the arithmetic of s2t_gemm with an fp32 output followed by s2t_argmax_lse, without the [M][V] fp32 logits
+ * ever reaching HBM.  Replaces, for greedy decoding, modules/speech_to_text/ctc.py:60-63 (ctc_projection) +
+ * models/speech_to_text/s2t_ctc.py:312-328 (log-softmax, arg-max and its log-probability per frame).
+ * x: bf16 rows [M][ldx] (ldx >= 256, % 8 == 0), w: bf16 [V][256], bias: fp32 [V] or NULL, any of idx / top_lp / lse may be NULL
+ * (not all).  live: optional device scalar, only rows < *live are computed (a packed batch's live rows).  Limits: V >= 128,
+ * V * 512 < 2^32 (S2T_ERR_UNSUPPORTED beyond), 16-byte aligned x and w. */
+int s2t_ctc_head_greedy(const void* x, int64_t ldx, const void* w, const float* bias, int64_t M, int V, int32_t* idx,
+                        float* top_lp, float* lse, const int32_t* live, void* stream);
 /* SATE adapter distribution (modules/speech_to_text/adapter.py:214-217): P = softmax(x * inv_tau) per row, and its
  * backward dx = P * (dP - sum P dP) * inv_tau */
 int s2t_row_softmax_fwd(int dtype, const void* x, int64_t ldx, void* p, int64_t ldp, int64_t rows, int V, float inv_tau,

@@ -768,6 +768,22 @@ def argmax_lse(logits, ld, rows, V, idx=None, top_lp=None, lse=None, bound=None)
           _live(bound))
 
 
+def ctc_head_greedy(x, w, bias, idx=None, top_lp=None, lse=None, bound=None):
+    """s2t_ctc_head_greedy (include/s2t_hip.h): arg-max / its log-probability / logsumexp of x @ w^T + bias per row, fp32 arithmetic, the
+    logits never stored.  x: bf16 [M, 256] rows (row stride % 8 == 0), w: bf16 [V, 256], bias: fp32 [V] or None."""
+    L.require_cuda(x, w, bias, idx, top_lp, lse)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.shape[1] == 256 and w.shape[1] == 256 and x.stride(1) == 1
+    assert w.is_contiguous() and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))
+    _call("s2t_ctc_head_greedy", x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), x.shape[0], w.shape[0], _ptr(idx), _ptr(top_lp),
+          _ptr(lse), _live(bound))
+
+
+def ctc_head_greedy_supported(x, w):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 256 and x.stride(1) == 1 and x.stride(0) % 8 == 0
+            and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] == 256 and w.is_contiguous() and w.shape[0] >= 128
+            and w.shape[0] * 512 < 2 ** 32)
+
+
 def add_colsum2(a, lda, b, ldb, du, dv, rows, n):
     _call("s2t_add_colsum2", L.dtype_id(a.dtype), a.data_ptr(), lda, b.data_ptr(), ldb, du.data_ptr(), dv.data_ptr(), rows, n)
 

@@ -404,6 +404,28 @@ class CTC(nn.Module):
         x2d = Fn.dropout(x2d, self.dropout_p, self.training)  # ctc_dropout_module (ctc.py:59)
         return self.ctc_projection(x2d, out_dtype=out_dtype, rows=rows)
 
+    def greedy_supported(self, x2d):
+        """The head + arg-max in one launch (csrc/ctc_head.hip) applies: inference, bf16 rows of width 256."""
+        from . import kernels as K
+
+        return (not self.training and not torch.is_grad_enabled() and x2d.dtype == torch.bfloat16
+                and K.ctc_head_greedy_supported(x2d, Fn.cw(self.ctc_projection.weight)))
+
+    def greedy(self, x2d, rows=None):
+        """-> (idx int32 [M], top_lp fp32 [M]): per row the first arg-max of the head's fp32 logits and its log-probability
+        (s2t_ctc.py:312-328), the [M, V] logits never stored: what ``forward(out_dtype=float32)`` followed by ``s2t_argmax_lse`` gives,
+        up to the summation order of the fp32 products inside a logit."""
+        from . import kernels as K
+
+        if self.LayerNorm is not None:
+            x2d = self.LayerNorm(x2d, rows=rows)
+        M = x2d.shape[0]
+        idx = torch.zeros(M, dtype=torch.int32, device=x2d.device)   # (rows beyond a packed batch's live ones stay blank / 0)
+        top = torch.zeros(M, dtype=torch.float32, device=x2d.device)
+        b = self.ctc_projection.bias
+        K.ctc_head_greedy(x2d, Fn.cw(self.ctc_projection.weight), b.data if b is not None else None, idx, top, None, bound=rows)
+        return idx, top
+
 
 class Adapter(nn.Module):
     """modules/speech_to_text/adapter.py:89-349 — `inter_league`: x + dist @ embed_adapter.weight with

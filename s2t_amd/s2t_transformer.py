@@ -307,11 +307,23 @@ class S2TTransformerEncoder(nn.Module):
             # the reference's T x B x C tensors are materialised only if somebody reads them (Rows.LazyList: zero-filled padded
             # frames, as the reference's masked tensors hold); the consumers of this package take the packed rows under "packed"
             rows_ = c.rows
-            logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype, rows=rows_) if self.use_ctc else None
-            packed = {"rows": rows_, "B": B, "T": Tp, "encoder_out": x, "ctc_logit": logit2d, "inter_ctc_logit": inter_packed}
+            greedy = None
+            if (self.use_ctc and getattr(self, "ctc_greedy_only", False) and self.ctc_out_dtype == torch.float32
+                    and self.ctc.greedy_supported(x)):
+                # CTCDecoder.generate is the only reader and wants arg-max + its log-probability per frame: the head and the
+                # arg-max in one launch, the [rows, V] fp32 logits never stored (csrc/ctc_head.hip); whoever still asks for
+                # "ctc_logit" gets it computed on demand
+                greedy = self.ctc.greedy(x, rows=rows_)
+                logit2d = None
+                ctc_list = Rows.LazyList([lambda: Rows.unpack(self.ctc(x, out_dtype=self.ctc_out_dtype, rows=rows_).contiguous(), rows_)
+                                          .view(B, Tp, -1).transpose(0, 1)])
+            else:
+                logit2d = self.ctc(x, out_dtype=self.ctc_out_dtype, rows=rows_) if self.use_ctc else None
+                ctc_list = [] if logit2d is None else Rows.LazyList(
+                    [lambda: Rows.unpack(logit2d.contiguous(), rows_).view(B, Tp, -1).transpose(0, 1)])
+            packed = {"rows": rows_, "B": B, "T": Tp, "encoder_out": x, "ctc_logit": logit2d, "inter_ctc_logit": inter_packed,
+                      "ctc_greedy": greedy}
             enc_list = Rows.LazyList([lambda: Rows.unpack(x, rows_).view(B, Tp, d).transpose(0, 1)])
-            ctc_list = [] if logit2d is None else Rows.LazyList(
-                [lambda: Rows.unpack(logit2d.contiguous(), rows_).view(B, Tp, -1).transpose(0, 1)])
             return {
                 "encoder_out": enc_list, "ctc_logit": ctc_list, "inter_ctc_logits": inter_ctc_logits, "xctc_logit": [],
                 "inter_xctc_logits": [], "encoder_padding_mask": [encoder_padding_mask], "mixup": None,
@@ -829,6 +841,7 @@ class CTCDecoder:
         # padded layout, whose scores are the reference's (--ctc-exact-scores / S2T_CTC_EXACT_SCORES=1).
         import os
         self.exact_scores = bool(getattr(args, "ctc_exact_scores", False)) or os.environ.get("S2T_CTC_EXACT_SCORES", "0") == "1"
+        self.fused_head = os.environ.get("S2T_CTC_HEAD_FUSED", "1") != "0"
 
     @torch.no_grad()
     def generate(self, models, sample, **kwargs):
@@ -844,16 +857,28 @@ class CTCDecoder:
         was = Rows.ENABLED
         if self.exact_scores:
             Rows.ENABLED = False  # padded layout: the padded frames' logits exist and enter the score as in the reference
+        # a plain Transformer / Conformer encoder whose final head is what gets decoded: head + arg-max in one launch, no logits
+        # (S2T_CTC_HEAD_FUSED=0 keeps the two-kernel route)
+        enc_mod = getattr(self.model, "encoder", None) or getattr(self.model, "e", None)
+        fused = (self.fused_head and self.ctc_inter_logit == 0 and type(enc_mod) is S2TTransformerEncoder
+                 and not getattr(enc_mod, "ctc_greedy_only", False))
+        if fused:
+            enc_mod.ctc_greedy_only = True
         try:
             enc = self.model(src_tokens=net_input["src_tokens"], src_lengths=net_input["src_lengths"])
         finally:
             Rows.ENABLED = was
+            if fused:
+                enc_mod.ctc_greedy_only = False
             # the flag is this decode's, not the model's: left set, later training / eval passes of the same model would refuse packed
             # rows and emit ctc_out_dtype logits from the intermediate heads
             for mod, old in flagged:
                 mod.decode_inter_logits = old
         has_x = len(enc.get("xctc_logit", [])) > 0
         pk = enc.get("packed")
+        if pk is not None and self.ctc_inter_logit == 0 and not has_x and pk.get("ctc_greedy") is not None:
+            idx, top = pk["ctc_greedy"]
+            return self._collapse_ids(idx, top, pk["rows"], pk["B"], pk["T"], rows=pk["rows"])
         if pk is not None and self.ctc_inter_logit == 0:  # packed rows (s2t_amd/rows.py): the decoded head's rows as they are
             l2d = pk.get("xctc_logit") if has_x else pk.get("ctc_logit")
             if l2d is not None:
@@ -893,6 +918,13 @@ class CTCDecoder:
         idx = torch.empty(B * Tn, dtype=torch.int32, device=dev)
         top = torch.empty(B * Tn, dtype=torch.float32, device=dev)
         K.argmax_lse(logits, logits.stride(0), B * Tn, V, idx, top, None, bound=rows)
+        return self._collapse_ids(idx, top, lens, B, Tn, rows=rows)
+
+    def _collapse_ids(self, idx, top, lens, B, Tn, rows=None):
+        """CTC collapse of per-frame arg-max ids / log-probabilities (s2t_ctc.py:324-347)."""
+        from . import kernels as K
+
+        dev = idx.device
         toks = torch.zeros(B, Tn, dtype=torch.int64, device=dev)
         olen = torch.zeros(B, dtype=torch.int32, device=dev)
         osc = torch.zeros(B, dtype=torch.float32, device=dev)
