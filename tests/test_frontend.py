@@ -166,6 +166,23 @@ def test_oracle_specaugment_matches_reference(golden_dir):
         assert (y != x).any()
 
 
+def test_oracle_row_resize_agrees_with_aten_bilinear():
+    """The time warp of SpecAugment resizes two row blocks with cv2.resize(..., INTER_LINEAR) (specaugment.py:96-112); OpenCV is
+    absent here and unpinned in the reference, so ``resize_rows_linear`` restates its convention (half-pixel centres, source rows
+    clamped at the edges, no anti-aliasing when shrinking).  An independent implementation of the same convention is at hand:
+    ATen's bilinear interpolation with align_corners=False.  They agree to the rounding of the fp32 source coordinate (OpenCV and
+    the restatement form it in float, ATen in another order): evidence for the convention, not a pin to OpenCV."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(0)
+    for rows, new in ((37, 50), (50, 37), (100, 101), (64, 3), (5, 40), (120, 119), (1, 7)):
+        x = rng.standard_normal((rows, 80)).astype(np.float32)
+        a = O.resize_rows_linear(x, new)
+        b = F.interpolate(torch.from_numpy(x)[None, None], size=(new, 80), mode="bilinear", align_corners=False)[0, 0].numpy()
+        assert a.shape == b.shape == (new, 80)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+
+
 def test_oracle_time_warp_properties():
     """The restated INTER_LINEAR row mapping (cv2 is absent: parity unpinned): same size = identity; a ramp stays the same
     ramp away from the clamped ends (half-pixel centres); the warp keeps the frame count and leaves the feature axis alone."""
